@@ -1,0 +1,226 @@
+/*
+ * ref_driver.c - golden-vector generator.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Our own source, linked against the reference library built by build_ref.sh
+ * (oracle/_ref/libsafecrypto_ref.so, compiled from /root/reference where it lies).
+ * It calls the reference through its public function-pointer tables exactly as the
+ * reference's schemes do (utils_arith_ntt() src/utils/arith/arith.c:360,
+ * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
+ * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
+ *
+ * Usage: ref_driver <ntt|cdt|all> <outdir>
+ *
+ * Fixture format (one file per topic): repeated records
+ *     @ <name> <count>\n  followed by <count> whitespace separated decimal integers.
+ */
+/* table gates the scheme *_params.h headers set for the library build (e.g. ring_tesla_params.h:20-21) */
+#define NTT_NEEDS_7681
+#define NTT_NEEDS_8380417
+#define NTT_NEEDS_12289
+#define NTT_NEEDS_8399873
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#include "safecrypto.h"
+#include "safecrypto_private.h"
+#include "utils/arith/arith.h"
+#include "utils/arith/ntt.h"
+#include "utils/arith/ntt_tables.h"
+#include "utils/sampling/sampling.h"
+#include "utils/crypto/prng.h"
+
+static uint64_t sm_state;
+static uint64_t splitmix64(void)
+{
+    uint64_t z = (sm_state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+static void rec_i32(FILE *f, const char *name, const int32_t *v, size_t n)
+{
+    fprintf(f, "@ %s %zu\n", name, n);
+    for (size_t i = 0; i < n; i++) fprintf(f, "%d%c", v[i], ((i & 15) == 15 || i + 1 == n) ? '\n' : ' ');
+}
+static void rec_i16(FILE *f, const char *name, const int16_t *v, size_t n)
+{
+    fprintf(f, "@ %s %zu\n", name, n);
+    for (size_t i = 0; i < n; i++) fprintf(f, "%d%c", v[i], ((i & 15) == 15 || i + 1 == n) ? '\n' : ' ');
+}
+static void rec_u64(FILE *f, const char *name, const uint64_t *v, size_t n)
+{
+    fprintf(f, "@ %s %zu\n", name, n);
+    for (size_t i = 0; i < n; i++) fprintf(f, "%llu%c", (unsigned long long)v[i], ((i & 7) == 7 || i + 1 == n) ? '\n' : ' ');
+}
+
+/* ------------------------------------------------------------------ NTT ---- */
+
+typedef struct {
+    int32_t q; int n; int is16;
+    const void *w, *r;
+} ntt_cfg_t;
+
+static void ntt_case(FILE *f, const ntt_cfg_t *c, safecrypto_ntt_e backend, const char *bname, int emit_inputs)
+{
+    const utils_arith_ntt_t *ntt = utils_arith_ntt(backend);
+    ntt_params_t p;
+    char name[128];
+    int n = c->n, q = c->q;
+    const int NP = 4;             /* polynomials per case */
+    int32_t *a = malloc(sizeof(int32_t) * n * NP), *b = malloc(sizeof(int32_t) * n * NP);
+    int32_t *fa = malloc(sizeof(int32_t) * n), *fb = malloc(sizeof(int32_t) * n);
+    int32_t *out = malloc(sizeof(int32_t) * n * NP);
+
+    init_reduce(&p, n, q);
+
+    /* inputs: poly 0 = ramp a[i]=i (SURVEY sanity vector), 1 = small signed {-12..12}
+     * (mirrors small_rand_dist_32, src/unit/unit_ntt.c:501-524), 2,3 = uniform [0,q) */
+    sm_state = 0x5afec0de00000000ULL + (uint64_t)q * 4096 + n;
+    for (int i = 0; i < n; i++) { a[i] = i; b[i] = (n - 1 - i); }
+    for (int i = 0; i < n; i++) { a[n + i] = (int)(splitmix64() % 25) - 12; b[n + i] = (int)(splitmix64() % 25) - 12; }
+    for (int k = 2; k < NP; k++)
+        for (int i = 0; i < n; i++) { a[k * n + i] = (int)(splitmix64() % (uint64_t)q); b[k * n + i] = (int)(splitmix64() % (uint64_t)q); }
+    if (emit_inputs) {
+        snprintf(name, sizeof name, "q%d_n%d_a", q, n); rec_i32(f, name, a, (size_t)n * NP);
+        snprintf(name, sizeof name, "q%d_n%d_b", q, n); rec_i32(f, name, b, (size_t)n * NP);
+    }
+
+    /* forward NTT then normalize_32 -> canonical representative (SURVEY 8(a) contract) */
+    for (int k = 0; k < NP; k++) {
+        if (c->is16) ntt->fwd_ntt_32_16(out + k * n, &p, a + k * n, (const SINT16 *)c->w);
+        else         ntt->fwd_ntt_32_32(out + k * n, &p, a + k * n, (const SINT32 *)c->w);
+        ntt->normalize_32(out + k * n, n, &p);
+    }
+    snprintf(name, sizeof name, "q%d_n%d_%s_fwd", q, n, bname); rec_i32(f, name, out, (size_t)n * NP);
+
+    /* inverse of the canonical forward output: must return a mod q (canonical) */
+    for (int k = 0; k < NP; k++) {
+        int32_t *t = out + k * n;
+        if (c->is16) ntt->inv_ntt_32_16(t, &p, t, (const SINT16 *)c->w, (const SINT16 *)c->r);
+        else         ntt->inv_ntt_32_32(t, &p, t, (const SINT32 *)c->w, (const SINT32 *)c->r);
+    }
+    snprintf(name, sizeof name, "q%d_n%d_%s_inv", q, n, bname); rec_i32(f, name, out, (size_t)n * NP);
+
+    /* negacyclic product a*b through fwd, fwd, pointwise, inv exactly as the schemes do */
+    for (int k = 0; k < NP; k++) {
+        if (c->is16) { ntt->fwd_ntt_32_16(fa, &p, a + k * n, (const SINT16 *)c->w); ntt->fwd_ntt_32_16(fb, &p, b + k * n, (const SINT16 *)c->w); }
+        else         { ntt->fwd_ntt_32_32(fa, &p, a + k * n, (const SINT32 *)c->w); ntt->fwd_ntt_32_32(fb, &p, b + k * n, (const SINT32 *)c->w); }
+        ntt->mul_32_pointwise(fa, &p, fa, fb);
+        if (c->is16) ntt->inv_ntt_32_16(out + k * n, &p, fa, (const SINT16 *)c->w, (const SINT16 *)c->r);
+        else         ntt->inv_ntt_32_32(out + k * n, &p, fa, (const SINT32 *)c->w, (const SINT32 *)c->r);
+    }
+    snprintf(name, sizeof name, "q%d_n%d_%s_mul", q, n, bname); rec_i32(f, name, out, (size_t)n * NP);
+
+    /* center_32 of the uniform inputs */
+    memcpy(out, a, sizeof(int32_t) * n * NP);
+    ntt->center_32(out, (size_t)n * NP, &p);
+    snprintf(name, sizeof name, "q%d_n%d_%s_center", q, n, bname); rec_i32(f, name, out, (size_t)n * NP);
+
+    free(a); free(b); free(fa); free(fb); free(out);
+}
+
+static int gen_ntt(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/ntt_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    const ntt_cfg_t cfgs[] = {
+        { 7681,    256,  1, w7681_n256,     r7681_n256 },
+        { 8380417, 256,  0, w8380417_n256,  r8380417_n256 },
+        { 12289,   512,  1, w12289_n512,    r12289_n512 },
+        { 12289,   1024, 1, w12289_n1024,   r12289_n1024 },
+        { 8399873, 512,  0, w8399873_n512,  r8399873_n512 },
+    };
+    for (size_t i = 0; i < sizeof cfgs / sizeof cfgs[0]; i++) {
+        const ntt_cfg_t *c = &cfgs[i];
+        char name[64];
+        /* the reference's generated twiddle tables (build_tools/ntt_table_gen/main.c:205-297) */
+        snprintf(name, sizeof name, "q%d_n%d_w", c->q, c->n);
+        if (c->is16) rec_i16(f, name, (const int16_t *)c->w, c->n); else rec_i32(f, name, (const int32_t *)c->w, c->n);
+        snprintf(name, sizeof name, "q%d_n%d_r", c->q, c->n);
+        if (c->is16) rec_i16(f, name, (const int16_t *)c->r, c->n); else rec_i32(f, name, (const int32_t *)c->r, c->n);
+        ntt_case(f, c, SC_NTT_FLOATING_POINT, "fp", 1);
+        ntt_case(f, c, SC_NTT_REFERENCE, "ref", 0);
+        if (c->q == 7681)    ntt_case(f, c, SC_NTT_SOLINAS_7681, "sol", 0);
+        if (c->q == 8380417) ntt_case(f, c, SC_NTT_SOLINAS_8380417, "sol", 0);
+    }
+    /* scalar known answers, src/unit/unit_ntt.c:166-320 */
+    {
+        const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+        ntt_params_t p; init_reduce(&p, 1024, 12289);
+        int32_t v[4];
+        v[0] = ntt->muln_32(1234, 5678, &p);
+        v[1] = ntt->muln_32(-1234, 5678, &p);
+        v[2] = ntt->muln_32(12288, 12288, &p);
+        v[3] = ntt->modn_32(12289 * 12289 - 1, &p);
+        rec_i32(f, "scalar_q12289_fp", v, 4);
+    }
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ CDT ---- */
+
+typedef struct __attribute__((packed)) { UINT64 *cdf; SINT32 cdf_size; } cdf64_view_t; /* src/utils/sampling/gaussian_cdf.c:74-81 */
+
+static prng_ctx_t *seeded_prng(const uint8_t *seed, size_t len)
+{
+    /* the seeding pattern of src/unit/unit_module_lwe.c:44-47 */
+    prng_ctx_t *ctx = prng_create(SC_ENTROPY_USER_PROVIDED, SC_PRNG_AES_CTR_DRBG, SC_PRNG_THREADING_NONE, 0x00100000);
+    prng_set_entropy(ctx, seed, len);
+    prng_init(ctx, NULL, 0);
+    return ctx;
+}
+
+static int cdt_case(FILE *f, float tail, float sigma, int nsamp, const char *tag)
+{
+    static const uint8_t seed[32] = { 3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3, 2, 3, 8, 4, 6, 2, 6, 4, 3, 3, 8, 3, 2, 7, 9, 5 };
+    char name[96];
+    prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32);
+    utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, NORMAL_SAMPLES, 512,
+                                         SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
+    if (!s) return 1;
+    const cdf64_view_t *g = (const cdf64_view_t *)s->gauss;
+    snprintf(name, sizeof name, "%s_cdf", tag);
+    rec_u64(f, name, (const uint64_t *)g->cdf, (size_t)g->cdf_size);
+
+    /* the twin PRNG (same seed) yields the uniform words the sampler is about to consume:
+     * gaussian_cdf_sample_64 takes exactly one prng_64 per sample (gaussian_cdf.c:639-659) */
+    uint64_t *x = malloc(sizeof(uint64_t) * nsamp);
+    int32_t *v = malloc(sizeof(int32_t) * nsamp);
+    for (int i = 0; i < nsamp; i++) x[i] = prng_64(p2);
+    get_vector_32(s, v, nsamp, 0);
+    snprintf(name, sizeof name, "%s_uniform", tag); rec_u64(f, name, x, nsamp);
+    snprintf(name, sizeof name, "%s_samples", tag); rec_i32(f, name, v, nsamp);
+    free(x); free(v);
+    destroy_sampler(&s);
+    prng_destroy(p1); prng_destroy(p2);
+    return 0;
+}
+
+static int gen_cdt(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/cdt_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = 0;
+    rc |= cdt_case(f, 13.42f, 215.0f, 2048, "bliss1_s215_t13.42");     /* bliss_b.c:342-344, bliss_params.c:35-43 */
+    rc |= cdt_case(f, 12.0f, 100.0f, 1024, "unit_s100_t12");           /* src/unit/unit_sampling.c:194-222 */
+    rc |= cdt_case(f, 10.0f, 1.7f, 512, "leaf_s1.7_t10");              /* falcon-like leaf sampler, gpv.c:2674-2676 */
+    fclose(f);
+    return rc;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|all> <outdir>\n", argv[0]); return 2; }
+    int all = !strcmp(argv[1], "all"), rc = 0;
+    if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
+    if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
+    return rc;
+}

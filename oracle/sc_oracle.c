@@ -1,0 +1,277 @@
+/*
+ * sc_oracle.c - CPU restatement of libsafecrypto's polynomial hot path.
+ * TEST INFRASTRUCTURE ONLY - see sc_oracle.h for the rules and the pinning status.
+ *
+ * All paths below are relative to the reference tree (libsafecrypto 0.2.0-79).
+ */
+#include "sc_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ tables ---- */
+
+static int64_t mulmod64(int64_t a, int64_t b, int64_t q) { return (int64_t)(((__int128)a * b) % q); }
+
+/* src/utils/arith/roots_of_unity.c:67-88: first m in 2..q-2 with m^n == q-1 (so m is a
+ * primitive 2n-th root of unity); the loop multiplies n times rather than using a ladder. */
+int32_t orc_find_root(int32_t q, int n)
+{
+    for (int64_t m = 2; m < (int64_t)q - 1; m++) {
+        int64_t p = 1;
+        for (int l = 1; l <= n; l++) p = mulmod64(p, m, q);
+        if (p == (int64_t)q - 1) return (int32_t)m;
+    }
+    return 0;
+}
+
+/* roots_of_unity.c:90-104 (xgcd(n,q) -> |x|) and :141-173 (fwd[i]=g^i, inv[i]=inv_p*g^i).
+ * With q == 1 (mod n) the Bezout coefficient of smallest magnitude is x = -(q-1)/n, so
+ * inv_p = (q-1)/n == -n^{-1} (mod q); the sign is undone by ntt32_flip_generic. */
+int orc_make_tables(int32_t q, int n, int32_t *w, int32_t *r)
+{
+    int32_t g = orc_find_root(q, n);
+    if (g == 0) return 1;
+    /* extended Euclid on (n, q), tracking only the coefficient of n */
+    int64_t r0 = n, r1 = q, s0 = 1, s1 = 0;
+    while (r1 != 0) {
+        int64_t t = r0 / r1, tmp;
+        tmp = r0 - t * r1; r0 = r1; r1 = tmp;
+        tmp = s0 - t * s1; s0 = s1; s1 = tmp;
+    }
+    if (r0 != 1) return 1;
+    int64_t inv_p = s0 < 0 ? -s0 : s0;
+    w[0] = 1;
+    for (int i = 1; i < n; i++) w[i] = (int32_t)mulmod64(w[i - 1], g, q);
+    r[0] = (int32_t)inv_p;
+    for (int i = 1; i < n; i++) r[i] = (int32_t)mulmod64(r[i - 1], g, q);
+    return 0;
+}
+
+/* ------------------------------------------------------------- reduction ---- */
+
+/* ntt_template.c.in:700-701, 786-787 (the _ENABLE_REFERENCE branch): C remainder, sign
+ * follows the dividend, |result| < q.  The other backends return different
+ * representatives of the same residue; parity is on canonical values. */
+int32_t orc_modn(int32_t x, int32_t q) { return x % q; }
+int32_t orc_muln(int32_t x, int32_t y, int32_t q) { return (int32_t)(((int64_t)x * (int64_t)y) % q); }
+
+/* ------------------------------------------------------------ transforms ---- */
+
+/* ntt_template.c.in:956-1007 generic tail: v[i] = muln(t[i], u[i]) for i = n-1..0 */
+void orc_mul_pointwise(int32_t *v, int n, int32_t q, const int32_t *t, const int32_t *u)
+{
+    for (int i = n; i--;) v[i] = orc_muln(t[i], u[i], q);
+}
+
+/* ntt.c:470-569: in-place bit-reversal permutation (the LUTs enumerate the swap pairs
+ * (i, rev(i)) with i < rev(i); the generic loops compute the same pairs). */
+void orc_inverse_shuffle(int32_t *v, int n)
+{
+    int bits = 0;
+    while ((1 << bits) < n) bits++;
+    for (int i = 0; i < n; i++) {
+        int j = 0;
+        for (int b = 0; b < bits; b++) j |= ((i >> b) & 1) << (bits - 1 - b);
+        if (i < j) { int32_t t = v[i]; v[i] = v[j]; v[j] = t; }
+    }
+}
+
+/* ntt_template.c.in:1144-1222 (_NTT_MK1): radix-2 decimation in time on bit-reversed
+ * input; the stage of half-size i uses twiddle w[j * (n/i)] (l starts at n and halves as
+ * i doubles, :1160); j = 0 butterflies skip the multiply and only reduce (:1208-1213);
+ * sums and differences are stored unreduced. */
+void orc_fft(int32_t *v, int n, int32_t q, const int32_t *w)
+{
+    for (int i = 1, l = n; i < n; i <<= 1, l >>= 1) {
+        int i_next = i + i;
+        for (int k = 0; k < n; k += i_next) {
+            int32_t x = orc_modn(v[k + i], q);
+            v[k + i] = v[k] - x;
+            v[k] = v[k] + x;
+        }
+        for (int j = 1; j < i; j++) {
+            int32_t y = w[j * l];
+            for (int k = j; k < n; k += i_next) {
+                int32_t x = orc_muln(v[k + i], y, q);
+                v[k + i] = v[k] - x;
+                v[k] = v[k] + x;
+            }
+        }
+    }
+}
+
+/* ntt_template.c.in:1541-1552: twist by w, bit-reverse, fft.
+ * Result: V[k] == sum_i t[i] g^{i(2k+1)} (mod q), natural order, NOT canonical. */
+void orc_fwd_ntt(int32_t *v, int n, int32_t q, const int32_t *t, const int32_t *w)
+{
+    orc_mul_pointwise(v, n, q, t, w);
+    orc_inverse_shuffle(v, n);
+    orc_fft(v, n, q, w);
+}
+
+/* ntt.c:572-604: a[0] = -a[0]; swap a[i] <-> a[n-i] for i = 1..(n-1)/2; then one
+ * conditional +q and one conditional -q per coefficient -> canonical [0,q). */
+static void orc_flip(int32_t *v, int n, int32_t q)
+{
+    int limit = (n - 1) >> 1;
+    for (int i = 1, j = n - 1; i <= limit; i++, j--) { int32_t x = v[i]; v[i] = v[j]; v[j] = x; }
+    v[0] = -v[0];
+    for (int i = n; i--;) {
+        int32_t x = v[i];
+        if (x < 0) x += q;
+        if (x >= q) x -= q;
+        v[i] = x;
+    }
+}
+
+/* ntt_template.c.in:1567-1589: copy, bit-reverse, the SAME forward fft, pointwise by r, flip */
+void orc_inv_ntt(int32_t *v, int n, int32_t q, const int32_t *t, const int32_t *w, const int32_t *r)
+{
+    if (v != t) memmove(v, t, sizeof(int32_t) * (size_t)n);
+    orc_inverse_shuffle(v, n);
+    orc_fft(v, n, q, w);
+    orc_mul_pointwise(v, n, q, v, r);
+    orc_flip(v, n, q);
+}
+
+/* ntt_template.c.in:1841-1901: modn then +q if negative, -q if >= q */
+void orc_normalize(int32_t *v, size_t len, int32_t q)
+{
+    for (size_t i = len; i--;) {
+        int32_t x = orc_modn(v[i], q);
+        if (x < 0) x += q;
+        if (x >= q) x -= q;
+        v[i] = x;
+    }
+}
+
+/* ntt_template.c.in:1777-1839: modn then fold into [-(q-1)/2, (q-1)/2] */
+void orc_center(int32_t *v, size_t len, int32_t q)
+{
+    int32_t q2 = (q - 1) >> 1;
+    for (size_t i = len; i--;) {
+        int32_t x = orc_modn(v[i], q);
+        while (x < -q2) x += q;
+        while (x > q2) x -= q;
+        v[i] = x;
+    }
+}
+
+void orc_polymul(int32_t *c, int n, int32_t q, const int32_t *a, const int32_t *b, const int32_t *w, const int32_t *r)
+{
+    int32_t *fa = malloc(sizeof(int32_t) * (size_t)n * 2), *fb = fa + n;
+    orc_fwd_ntt(fa, n, q, a, w);
+    orc_fwd_ntt(fb, n, q, b, w);
+    orc_mul_pointwise(fa, n, q, fa, fb);
+    orc_inv_ntt(c, n, q, fa, w, r);
+    free(fa);
+}
+
+void orc_polymul_ntt(int32_t *c, int n, int32_t q, const int32_t *a, const int32_t *bhat, const int32_t *w, const int32_t *r)
+{
+    int32_t *fa = malloc(sizeof(int32_t) * (size_t)n);
+    orc_fwd_ntt(fa, n, q, a, w);
+    orc_mul_pointwise(fa, n, q, fa, bhat);
+    orc_inv_ntt(c, n, q, fa, w, r);
+    free(fa);
+}
+
+/* ntt.c:381-400: v = t * sum_k x^{pos[k]} in Z[x]/(x^n+1), exact integers (no reduction) */
+void orc_mult_sparse(int32_t *v, int n, int omega, const int32_t *t, const int32_t *pos)
+{
+    for (int i = n; i--;) v[i] = 0;
+    for (int i = 0; i < omega; i++) {
+        int p = pos[i];
+        for (int j = 0; j < p; j++) v[j] += t[j + n - p];
+        for (int j = p; j < n; j++) v[j] -= t[j - p];
+    }
+}
+
+/* poly_32.c:48-62 */
+void orc_poly_add(int32_t *out, int n, const int32_t *a, const int32_t *b) { for (int i = n; i--;) out[i] = a[i] + b[i]; }
+void orc_poly_sub(int32_t *out, int n, const int32_t *a, const int32_t *b) { for (int i = n; i--;) out[i] = a[i] - b[i]; }
+
+/* --------------------------------------------------------------- sampler ---- */
+
+/* sc_math.c sc_ceil_log2 applied to (UINT32)(tail*sigma) (gaussian_cdf.c:562): the number
+ * of bits needed so that 2^bits >= the value */
+int orc_cdt_bits(float tail, float sigma)
+{
+    float prod = tail * sigma;             /* FLOAT product as in the reference */
+    uint32_t v = (uint32_t)prod;
+    int bits = 0;
+    while (((uint64_t)1 << bits) < v) bits++;
+    return bits;
+}
+
+/* gaussian_cdf.c:555-610: d = 2/sqrt(2 pi) * 2^64 / sigma ; cdf[0]=0 ; cdf[i] = (UINT64)s
+ * with s_1 = d/2, s_{i+1} = s_i + d*expl(-i^2/(2 sigma^2)) in long double; stop early if
+ * the cast yields 0; the rest (always including the last entry) is all-ones. */
+int orc_cdt_create(float tail, float sigma_f, uint64_t *cdf, int size)
+{
+    (void)tail;
+    /* SC_M_2_SQRTPIl * SC_M_SQRT1_2l, include/safecrypto_types.h long-double constants */
+    const long double two_sqrtpi = 1.128379167095512573896158903121545172L;
+    const long double sqrt1_2    = 0.707106781186547524400844362104849039L;
+    long double sigma = sigma_f;
+    long double d = two_sqrtpi * sqrt1_2 * 18446744073709551616.0L / sigma;
+    /* sigma is a FLOAT in the reference, so sigma*sigma is a float product (:595) */
+    float sigma_sq = sigma_f * sigma_f;
+    long double e = -0.5L / sigma_sq;
+    long double s = 0.5L * d;
+    int i;
+    cdf[0] = 0;
+    for (i = 1; i < size - 1; i++) {
+        cdf[i] = (uint64_t)s;
+        if (cdf[i] == 0) break;
+        s += d * expl(e * ((long double)(i * i)));
+    }
+    for (; i < size; i++) cdf[i] = 0xFFFFFFFFFFFFFFFFULL;
+    return 0;
+}
+
+/* gaussian_cdf.c:536-553 + :639-659 (k == 0): a = largest index reached by the halving
+ * search with "cdf[b] < x"; the sign is the LSB of the same uniform word. */
+int32_t orc_cdt_sample(uint64_t x, const uint64_t *cdf, int size)
+{
+    uint32_t a = 0;
+    for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) {
+        uint32_t b = a + st;
+        if (b < (uint32_t)size && cdf[b] < x) a = b;
+    }
+    return (x & 1) ? (int32_t)a : -(int32_t)a;
+}
+
+/* sampling.c:211-228 with discard == 0: sequential fill, v[i] = sample + centre */
+void orc_cdt_sample_vector(int32_t *v, size_t n, const uint64_t *x, const uint64_t *cdf, int size, int32_t centre)
+{
+    for (size_t i = 0; i < n; i++) v[i] = orc_cdt_sample(x[i], cdf, size) + centre;
+}
+
+/* ---------------------------------------------------------------- batches ---- */
+
+void orc_batch_fwd_ntt(int32_t *out, const int32_t *in, size_t batch, int n, int32_t q, const int32_t *w)
+{
+    for (size_t b = 0; b < batch; b++) {
+        orc_fwd_ntt(out + b * n, n, q, in + b * n, w);
+        orc_normalize(out + b * n, (size_t)n, q);
+    }
+}
+
+void orc_batch_inv_ntt(int32_t *out, const int32_t *in, size_t batch, int n, int32_t q, const int32_t *w, const int32_t *r)
+{
+    for (size_t b = 0; b < batch; b++) orc_inv_ntt(out + b * n, n, q, in + b * n, w, r);
+}
+
+void orc_batch_polymul_ntt(int32_t *out, const int32_t *a, const int32_t *bhat, size_t batch, int n, int32_t q,
+                           const int32_t *w, const int32_t *r)
+{
+    int32_t *fa = malloc(sizeof(int32_t) * (size_t)n);
+    for (size_t b = 0; b < batch; b++) {
+        orc_fwd_ntt(fa, n, q, a + b * n, w);
+        orc_mul_pointwise(fa, n, q, fa, bhat + b * n);
+        orc_inv_ntt(out + b * n, n, q, fa, w, r);
+    }
+    free(fa);
+}
