@@ -1,0 +1,145 @@
+/*
+ * sc_hip.h - C ABI of the MI355X (gfx950) batched lattice-arithmetic engine that stands
+ * behind libsafecrypto's polynomial hot path.
+ *
+ * Every entry point is plain C (pointers + sizes, no C++/torch types).  Each one names the
+ * reference interface it replaces (paths relative to the libsafecrypto tree, 0.2.0-79).
+ * The reference works on ONE polynomial per call; the engine's native unit is a BATCH of
+ * polynomials stored row-major as int32 [batch][n] (SINT32, src/utils/arith/ntt.h), so
+ * every call takes a batch count.  batch = 1 reproduces the reference call exactly.
+ *
+ * Conventions
+ *   - return 0 (SC_FUNC_SUCCESS, include/safecrypto_types.h:71) or 1 (SC_FUNC_FAILURE, :72)
+ *   - "d_" pointers are device (HBM) addresses, "h_" pointers host addresses
+ *   - stream is a hipStream_t passed as void* (NULL = the null stream); device-pointer
+ *     calls are asynchronous on that stream, host-pointer calls return after the copy back
+ *   - outputs are canonical where the reference's are (SURVEY.md 8(a) bit-exact contract):
+ *     forward NTT results are returned already normalised to [0,q), i.e. equal to the
+ *     reference's fwd_ntt_32_* followed by normalize_32
+ *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
+ *     sc_hip_last_error) when no gfx950 device / kernel image is available
+ */
+#ifndef SC_HIP_H
+#define SC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_HIP_SUCCESS 0
+#define SC_HIP_FAILURE 1
+
+typedef struct sc_hip_ctx  sc_hip_ctx_t;   /* one per (process, device)                    */
+typedef struct sc_hip_plan sc_hip_plan_t;  /* one per (q, n): twiddles resident in HBM     */
+typedef struct sc_hip_cdt  sc_hip_cdt_t;   /* one per (tail, sigma): CDT resident in HBM   */
+
+/* ---- lifetime ------------------------------------------------------------------ */
+
+/* replaces nothing in the reference (it has no device notion); the analogue of
+ * safecrypto_create's per-context vtable wiring, src/schemes/sig/dilithium/dilithium.c:207-209 */
+int  sc_hip_ctx_create(int device, sc_hip_ctx_t **ctx);
+void sc_hip_ctx_destroy(sc_hip_ctx_t *ctx);
+const char *sc_hip_last_error(void);
+int  sc_hip_device_count(void);
+int  sc_hip_synchronize(sc_hip_ctx_t *ctx, void *stream);
+
+/* replaces: init_reduce (src/utils/arith/ntt.c:132-140) + the generated tables w<q>_n<n>,
+ * r<q>_n<n> (build_tools/ntt_table_gen/main.c:205-297, roots_of_unity.c:67-173).
+ * g = smallest m >= 2 with m^n == -1 (mod q), exactly the reference's choice, so the
+ * transform is the same function.  n in {256,512,1024}; q prime, q == 1 (mod 2n), q < 2^30. */
+int  sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_plan_t **plan);
+void sc_hip_plan_destroy(sc_hip_plan_t *plan);
+int32_t sc_hip_plan_q(const sc_hip_plan_t *plan);
+int     sc_hip_plan_n(const sc_hip_plan_t *plan);
+int32_t sc_hip_plan_root(const sc_hip_plan_t *plan);           /* g                         */
+/* host copies of the reference-format tables (w[i]=g^i, r[i]=((q-1)/n) g^i), n entries each */
+int  sc_hip_plan_tables(const sc_hip_plan_t *plan, int32_t *h_w, int32_t *h_r);
+/* selects the modular-multiply code path: 0 = auto, 1 = 24-bit Shoup (q < 2^23),
+ * 2 = 32-bit Shoup (q < 2^30).  For measurement; results are identical. */
+int  sc_hip_plan_set_arith(sc_hip_plan_t *plan, int mode);
+
+/* ---- batched transforms, device pointers ------------------------------------------- */
+
+/* replaces: fwd_ntt_32_32 / fwd_ntt_32_16 (ntt_template.c.in:1541-1552,1615-1626) followed by
+ * normalize_32 (:1841-1901).  in: any int32 representatives; out: V[k] = sum_i t[i] g^{i(2k+1)}
+ * in [0,q), natural order.  d_out may alias d_in. */
+int sc_hip_ntt_fwd(sc_hip_plan_t *plan, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream);
+
+/* replaces: inv_ntt_32_32 / inv_ntt_32_16 (ntt_template.c.in:1567-1589,1641-1663) including
+ * ntt32_flip_generic (ntt.c:584-604): exact inverse of the above, canonical [0,q). */
+int sc_hip_ntt_inv(sc_hip_plan_t *plan, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream);
+
+/* replaces: mul_32_pointwise / mul_32_pointwise_16 (ntt_template.c.in:956-1141) followed by
+ * normalize_32: out[i] = a[i]*b[i] mod q in [0,q).  len = total coefficients. */
+int sc_hip_pointwise(sc_hip_plan_t *plan, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+
+/* fused fwd_ntt -> mul_32_pointwise -> inv_ntt (the sequence at e.g. bliss_b.c:1378-1384,
+ * module_lwe.c:1357-1370): out = INTT(NTT(a) o bhat), bhat given in the NTT domain in the
+ * reference's natural order (e.g. a stored public key).  BASELINE.json config 2. */
+int sc_hip_polymul_ntt(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream);
+
+/* fused product of two coefficient-domain polynomials: out = a*b mod (x^n+1, q), canonical
+ * (fwd, fwd, mul_32_pointwise, inv: ring_tesla.c:752-910 pattern). */
+int sc_hip_polymul(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+
+/* replaces: normalize_32 / center_32 (ntt_template.c.in:1777-1901), in place allowed */
+int sc_hip_normalize(sc_hip_plan_t *plan, size_t len, const int32_t *d_in, int32_t *d_out, void *stream);
+int sc_hip_center(sc_hip_plan_t *plan, size_t len, const int32_t *d_in, int32_t *d_out, void *stream);
+
+/* replaces: utils_arith_poly_t add_32 / sub_32 (src/utils/arith/poly_32.c:48-62); no reduction */
+int sc_hip_poly_add(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+int sc_hip_poly_sub(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+
+/* replaces: create_rand_product_32_csprng / _16_ with the matrix already expanded
+ * (src/utils/arith/module_lwe.c:588-748): t[b][i] = INTT( sum_j Ahat[i][j] o NTT(y[b][j]) ),
+ * canonical.  d_Ahat: [k][l][n] NTT-domain rows in the reference's natural order (one key,
+ * shared by the batch); d_y: [batch][l][n]; d_t: [batch][k][n].  transposed != 0 uses
+ * Ahat[j][i] (module_lwe.c:617-633, Kyber encryption). */
+int sc_hip_matvec(sc_hip_plan_t *plan, size_t batch, int k, int l, int transposed,
+                  const int32_t *d_Ahat, const int32_t *d_y, int32_t *d_t, void *stream);
+
+/* ---- CDT Gaussian sampler -------------------------------------------------------------- */
+
+/* replaces: create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, ...) ->
+ * gaussian_cdf_create_64 (src/utils/sampling/sampling.c:425-469, gaussian_cdf.c:555-610).
+ * The table is built on the host in long double exactly as the reference does and uploaded. */
+int  sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t **cdt);
+/* host-only half of the above (no device needed): number of entries 2^ceil(log2(tail*sigma))
+ * and the table itself.  NOTE the reference's table is a function of the host's x87 expl()
+ * (f2xm1 differs in the last bit between CPU vendors), so tables are reproducible per host,
+ * not across hosts; samples are a pure function of (table, uniform word). */
+int  sc_hip_cdt_table_size(float tail, float sigma);
+int  sc_hip_cdt_build_table(float tail, float sigma, uint64_t *h_cdf, int size);
+/* sampler over a caller-supplied monotone table (size a power of two, 2..4096), e.g. the
+ * per-leaf tables Falcon's tree sampler creates on the fly (src/utils/arith/gpv.c:2671-2686)
+ * precomputed at key load */
+int  sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h_cdf, int size, sc_hip_cdt_t **cdt);
+void sc_hip_cdt_destroy(sc_hip_cdt_t *cdt);
+int  sc_hip_cdt_size(const sc_hip_cdt_t *cdt);
+int  sc_hip_cdt_table(const sc_hip_cdt_t *cdt, uint64_t *h_cdf);
+
+/* replaces: get_vector_32 -> sample_vector_32 -> gaussian_cdf_sample_64 + binary_search_64
+ * (sampling.c:211-228,556-580; gaussian_cdf.c:536-553,639-659) with the uniform 64-bit words
+ * (the reference's prng_64 outputs) supplied by the caller: out[i] = sample(x[i]) + centre. */
+int sc_hip_cdt_sample(sc_hip_cdt_t *cdt, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
+
+/* ---- host-buffer convenience (H2D, kernel, D2H; synchronous) ---------------------------- */
+int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
+int sc_hip_ntt_inv_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
+int sc_hip_polymul_ntt_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out);
+int sc_hip_cdt_sample_host(sc_hip_cdt_t *cdt, size_t count, const uint64_t *h_uniform, int32_t centre, int32_t *h_out);
+
+/* ---- timing helper ---------------------------------------------------------------------- */
+/* Runs `iters` back-to-back launches of one op (0 fwd, 1 inv, 2 polymul_ntt, 3 polymul) on
+ * `stream`, bracketed by hipEvents recorded on that same stream; returns the average
+ * per-launch milliseconds in *ms.  Used by bench.py for the roofline figure. */
+int sc_hip_time_op(sc_hip_plan_t *plan, int op, size_t batch, const int32_t *d_a, const int32_t *d_b,
+                   int32_t *d_out, void *stream, int iters, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_HIP_H */

@@ -1,0 +1,83 @@
+// modarith.h - in-register modular arithmetic for gfx950 (device side).
+//
+// Two constant-multiplier code paths (Shoup: the multiplier w comes with a precomputed
+// companion wp = floor(w * BETA / q)):
+//   MODE_U24: BETA = 2^24, built from the full-rate 24-bit multiplies v_mul_u32_u24 /
+//             v_mul_hi_u32_u24 (valid while every multiplied value is < 2^24, q < 2^23)
+//   MODE_U32: BETA = 2^32, built from v_mul_hi_u32 / v_mul_lo_u32 (q < 2^30)
+// Both return a*w mod q as a lazily reduced value in [0, 2q).  Data-by-data products use a
+// signed 32-bit Montgomery step.  The reference reduces with a double-precision quotient
+// (ntt_template.c.in:756-760,848-851); only the residue classes have to agree, and every
+// kernel ends by mapping to the canonical representative the reference produces.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+enum { MODE_U24 = 1, MODE_U32 = 2 };
+
+// Per-modulus scalars, passed by value as kernel arguments (they end up in SGPRs).
+struct ModK {
+    uint32_t q;        // modulus
+    uint32_t q2;       // 2q
+    uint32_t qinv;     // q^{-1} mod 2^32           (Montgomery)
+    uint32_t m32;      // floor(2^32 / q)           (reduction of arbitrary int32 inputs)
+    uint32_t one_p;    // floor(BETA / q)           (Shoup companion of w = 1: a generic reduce)
+    uint32_t half;     // (q-1)/2                   (center)
+};
+
+// v_mul_u32_u24 / v_mul_hi_u32_u24 (full-rate 24x24-bit multiplies) through the LLVM intrinsics;
+// hipcc 7.2 has no __builtin_amdgcn_mul*_u24, and the (a & 0xffffff) * (b & 0xffffff) idiom is
+// only sometimes selected as the 24-bit form.
+extern "C" __device__ uint32_t sc_llvm_mul_u24(uint32_t, uint32_t) __asm("llvm.amdgcn.mul.u24.i32");
+extern "C" __device__ uint32_t sc_llvm_mulhi_u24(uint32_t, uint32_t) __asm("llvm.amdgcn.mulhi.u24");
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { return sc_llvm_mul_u24(a, b); }
+__device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) { return sc_llvm_mulhi_u24(a, b); }
+
+__device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) { return min(x, x - m); }  // x in [0,2m) -> [0,m)
+
+template <int MODE> struct Mod;
+
+template <> struct Mod<MODE_U24> {
+    static constexpr uint64_t BETA = 1ull << 24;
+    // a < 2^24, w < q < 2^23, wp = floor(w 2^24 / q)  ->  a*w mod q in [0,2q)
+    static __device__ __forceinline__ uint32_t mulc(uint32_t a, uint32_t w, uint32_t wp, const ModK &k)
+    {
+        const uint32_t lo = mul_u24(a, wp);                               // bits 31:0  of a*wp
+        const uint32_t hi = mulhi_u24(a, wp);                             // bits 47:32 of a*wp
+        const uint32_t qh = __builtin_amdgcn_alignbit(hi, lo, 24);        // floor(a*wp / 2^24) < 2^24
+        return mul_u24(a, w) - mul_u24(qh, k.q);
+    }
+};
+
+template <> struct Mod<MODE_U32> {
+    static constexpr uint64_t BETA = 1ull << 32;
+    // a < 2^32, w < q < 2^30, wp = floor(w 2^32 / q)  ->  a*w mod q in [0,2q)
+    static __device__ __forceinline__ uint32_t mulc(uint32_t a, uint32_t w, uint32_t wp, const ModK &k)
+    {
+        uint32_t qh = __umulhi(a, wp);
+        return a * w - qh * k.q;
+    }
+};
+
+// arbitrary int32 -> [0, 2q)
+__device__ __forceinline__ uint32_t reduce_i32(int32_t x, const ModK &k)
+{
+    int32_t qh = __mulhi(x, (int32_t)k.m32);
+    int32_t r = x - qh * (int32_t)k.q;            // in [-q, 2q)
+    r += (r >> 31) & (int32_t)k.q;
+    return (uint32_t)r;
+}
+
+// a*b*2^-32 mod q in [0,q); needs a*b < q*2^32
+__device__ __forceinline__ uint32_t montmul(uint32_t a, uint32_t b, const ModK &k)
+{
+    uint64_t p = (uint64_t)a * b;
+    uint32_t m = (uint32_t)p * k.qinv;
+    int32_t t = (int32_t)(uint32_t)(p >> 32) - (int32_t)__umulhi(m, k.q);
+    t += (t >> 31) & (int32_t)k.q;
+    return (uint32_t)t;
+}
+
+}  // namespace sc

@@ -1,0 +1,612 @@
+// sc_hip.hip - kernels and C ABI (include/sc_hip.h) of the MI355X lattice-arithmetic engine.
+// gfx950 only; there is no host fallback: without a device every compute entry fails.
+#include "../../include/sc_hip.h"
+#include "ntt_core.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+using namespace sc;
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+enum { OP_FWD = 0, OP_INV = 1, OP_MULNTT = 2, OP_MUL = 3 };
+
+struct NttArgs {
+    const int32_t *in0;
+    const int32_t *in1;
+    int32_t *out;
+    const uint32_t *zf, *zfp;     // forward twiddles zeta[k] = g^bitrev(k) and Shoup companions
+    const uint32_t *zi, *zip;     // inverse twiddles zeta[k]^-1 and companions
+    unsigned long long batch;
+    ModK k;
+    uint32_t c0, c0p, c1, c1p;    // inverse output scale (n^-1 [* 2^32]) and zeta[1]^-1 * scale
+};
+
+__host__ __device__ constexpr int brv4(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// One wavefront handles PW polynomials at a time and loops over the batch (persistent waves:
+// the per-lane twiddles are loaded once).  256 threads = 4 independent waves per workgroup;
+// LDS: 4 KB per wave (one polynomial image per polynomial in flight).
+template <int L, int MODE, bool LAZY, int OP>
+__global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
+{
+    using Y = Lay<L>;
+    constexpr int N = Y::N, LP = Y::LP, PW = Y::PW;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pw = lane / LP, lp = lane % LP;
+    uint32_t *lds_poly = lds + wid * 1024 + pw * N;
+    const int blp = (int)(__builtin_bitreverse32((uint32_t)lp) >> (32 - (L - 4)));   // bitrev_{L-4}(lp)
+    const ModK k = a.k;
+
+    TwSet<L> twf, twi;
+    if (OP != OP_INV) twf.load(a.zf, a.zfp, lp);
+    if (OP != OP_FWD) twi.load(a.zi, a.zip, lp);
+
+    const unsigned long long groups = (a.batch + PW - 1) / PW;
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += (unsigned long long)gridDim.x * 4) {
+        const unsigned long long poly = g * PW + pw;
+        const bool valid = poly < a.batch;
+        const size_t base = (size_t)poly * N;
+        uint32_t x[16];
+
+        if (OP == OP_INV) {
+            // NTT-domain input, natural order: position j = lp*16+r wants V[bitrev(j)]
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(a.in0[base + brv4(r) * LP + blp], k) : 0u;
+        } else {
+            // coefficient-domain input: layout b0(0): position j = r*LP + lp
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(a.in0[base + r * LP + lp], k) : 0u;
+            fwd_core<L, MODE, LAZY>(x, twf, lds_poly, lp, k);
+        }
+
+        if (OP == OP_FWD) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t v = x[r];
+                if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
+                v = csub(v, k.q);
+                if (valid) a.out[base + brv4(r) * LP + blp] = (int32_t)v;
+            }
+            continue;
+        }
+
+        if (OP == OP_MULNTT) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t b = valid ? reduce_i32(a.in1[base + brv4(r) * LP + blp], k) : 0u;
+                x[r] = montmul(x[r], b, k);
+            }
+        }
+        if (OP == OP_MUL) {
+            uint32_t y[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) y[r] = valid ? reduce_i32(a.in1[base + r * LP + lp], k) : 0u;
+            fwd_core<L, MODE, false>(y, twf, lds_poly, lp, k);      // [0,2q)
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = montmul(x[r], y[r], k);
+        }
+
+        inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if (valid) a.out[base + r * LP + lp] = (int32_t)x[r];
+    }
+}
+
+enum { EW_POINTWISE = 0, EW_NORMALIZE = 1, EW_CENTER = 2, EW_ADD = 3, EW_SUB = 4 };
+
+// Elementwise ops on int32 arrays, 16 B per lane, grid-stride.  r2 = 2^32 mod q (Shoup pair
+// r2/r2p) turns the Montgomery product a*b*2^-32 back into a*b.
+template <int OPE>
+__global__ __launch_bounds__(256) void ew_kernel(const int32_t *__restrict__ a, const int32_t *__restrict__ b, int32_t *__restrict__ out,
+                                                 size_t len, ModK k, uint32_t r2, uint32_t r2p)
+{
+    const size_t nv = len / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const int4 va = reinterpret_cast<const int4 *>(a)[i];
+        int4 vb = make_int4(0, 0, 0, 0);
+        if (OPE == EW_POINTWISE || OPE == EW_ADD || OPE == EW_SUB) vb = reinterpret_cast<const int4 *>(b)[i];
+        int xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w}, o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (OPE == EW_ADD) o[e] = xa[e] + xb[e];
+            else if (OPE == EW_SUB) o[e] = xa[e] - xb[e];
+            else {
+                uint32_t v = reduce_i32(xa[e], k);
+                if (OPE == EW_POINTWISE) {
+                    v = montmul(v, reduce_i32(xb[e], k), k);                 // a b 2^-32, [0,q)
+                    v = Mod<MODE_U32>::mulc(v, r2, r2p, k);                   // * 2^32
+                }
+                v = csub(v, k.q);
+                if (OPE == EW_CENTER) o[e] = (v > k.half) ? (int32_t)v - (int32_t)k.q : (int32_t)v;
+                else o[e] = (int32_t)v;
+            }
+        }
+        reinterpret_cast<int4 *>(out)[i] = make_int4(o[0], o[1], o[2], o[3]);
+    }
+    // tail (len not a multiple of 4)
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) {
+        const size_t i = nv * 4 + threadIdx.x;
+        int32_t o;
+        if (OPE == EW_ADD) o = a[i] + b[i];
+        else if (OPE == EW_SUB) o = a[i] - b[i];
+        else {
+            uint32_t v = reduce_i32(a[i], k);
+            if (OPE == EW_POINTWISE) {
+                v = montmul(v, reduce_i32(b[i], k), k);
+                v = Mod<MODE_U32>::mulc(v, r2, r2p, k);
+            }
+            v = csub(v, k.q);
+            o = (OPE == EW_CENTER && v > k.half) ? (int32_t)v - (int32_t)k.q : (int32_t)v;
+        }
+        out[i] = o;
+    }
+}
+
+// CDT sampler: the table (<= 4096 x u64 = 32 KB) is staged in LDS once per workgroup; each lane
+// then resolves samples with the reference's halving search (gaussian_cdf.c:536-553): the
+// largest index b reached with cdf[b] < x, sign from the LSB of x (:658).
+__global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, int size, const uint64_t *__restrict__ x,
+                                                  int32_t *__restrict__ out, size_t count, int32_t centre)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t u = x[i];
+        uint32_t a = 0;
+        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) {
+            const uint32_t b = a + st;            // b < size always holds for a power-of-two table
+            if (tab[b] < u) a = b;
+        }
+        out[i] = ((u & 1) ? (int32_t)a : -(int32_t)a) + centre;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+
+static thread_local std::string g_err;
+static int fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct sc_hip_ctx {
+    int device;
+    int cus;
+};
+
+struct sc_hip_plan {
+    sc_hip_ctx *ctx;
+    int32_t q;
+    int n, L;
+    int32_t g;
+    int mode;                     // MODE_U24 / MODE_U32 in use
+    bool lazy24, lazy32;
+    std::vector<int32_t> w, r;    // reference-format tables (host)
+    uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
+    ModK k[2];
+    uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
+    uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
+    uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
+};
+
+struct sc_hip_cdt {
+    sc_hip_ctx *ctx;
+    float tail, sigma;
+    int size;
+    std::vector<uint64_t> cdf;
+    uint64_t *d_cdf;
+};
+
+static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((unsigned __int128)a * b) % q); }
+static uint64_t powmod(uint64_t a, uint64_t e, uint64_t q)
+{
+    uint64_t r = 1; a %= q;
+    while (e) { if (e & 1) r = mulmod(r, a, q); a = mulmod(a, a, q); e >>= 1; }
+    return r;
+}
+static uint32_t brv(uint32_t x, int bits) { uint32_t r = 0; for (int b = 0; b < bits; b++) r |= ((x >> b) & 1u) << (bits - 1 - b); return r; }
+static bool is_prime(uint64_t q) { if (q < 2) return false; for (uint64_t d = 2; d * d <= q; d++) if (q % d == 0) return false; return true; }
+
+extern "C" const char *sc_hip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sc_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sc_hip_ctx_create(int device, sc_hip_ctx_t **out)
+{
+    if (!out) return fail("ctx_create: null output");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail("ctx_create: no such HIP device (the engine has no CPU fallback)");
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    sc_hip_ctx *c = new sc_hip_ctx;
+    c->device = device;
+    c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    *out = c;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_ctx_destroy(sc_hip_ctx_t *ctx) { delete ctx; }
+
+extern "C" int sc_hip_synchronize(sc_hip_ctx_t *ctx, void *stream)
+{
+    if (!ctx) return fail("synchronize: null ctx");
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return SC_HIP_SUCCESS;
+}
+
+// Shoup companion floor(w * 2^bits / q)
+static uint32_t shoup(uint64_t w, uint64_t q, int bits) { return (uint32_t)((((unsigned __int128)w) << bits) / q); }
+
+extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_plan_t **out)
+{
+    if (!ctx || !out) return fail("plan_create: null argument");
+    if (n != 256 && n != 512 && n != 1024) return fail("plan_create: n must be 256, 512 or 1024");
+    if (q < 3 || (uint32_t)q >= (1u << 30) || !is_prime((uint64_t)q) || ((uint64_t)q - 1) % (2 * (uint64_t)n) != 0)
+        return fail("plan_create: q must be a prime < 2^30 with q == 1 (mod 2n)");
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint64_t Q = (uint64_t)q;
+    // the reference's root: smallest m >= 2 with m^n == -1 (roots_of_unity.c:67-88)
+    uint64_t g = 0;
+    for (uint64_t m = 2; m < Q - 1; m++) if (powmod(m, (uint64_t)n, Q) == Q - 1) { g = m; break; }
+    if (!g) return fail("plan_create: no primitive 2n-th root of unity");
+
+    sc_hip_plan *p = new sc_hip_plan;
+    p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
+    p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
+    p->w.resize(n); p->r.resize(n);
+    p->w[0] = 1;
+    for (int i = 1; i < n; i++) p->w[i] = (int32_t)mulmod((uint64_t)p->w[i - 1], g, Q);
+    p->r[0] = (int32_t)((Q - 1) / (uint64_t)n);              // -n^-1 mod q (roots_of_unity.c:90-104)
+    for (int i = 1; i < n; i++) p->r[i] = (int32_t)mulmod((uint64_t)p->r[i - 1], g, Q);
+
+    const int L = p->L;
+    std::vector<uint64_t> zf(n), zi(n);
+    for (int kx = 0; kx < n; kx++) { zf[kx] = powmod(g, brv((uint32_t)kx, L), Q); zi[kx] = powmod(zf[kx], Q - 2, Q); }
+    const uint64_t ninv = powmod((uint64_t)n, Q - 2, Q);
+    const uint64_t R = (1ull << 32) % Q;
+    uint32_t qinv = 1;                                         // q^-1 mod 2^32 by Newton
+    for (int i = 0; i < 5; i++) qinv *= 2u - (uint32_t)q * qinv;
+
+    for (int mi = 0; mi < 2; mi++) {
+        const int bits = mi == 0 ? 24 : 32;
+        ModK &k = p->k[mi];
+        k.q = (uint32_t)q; k.q2 = 2u * (uint32_t)q; k.qinv = qinv;
+        k.m32 = (uint32_t)((1ull << 32) / Q);
+        k.one_p = shoup(1, Q, bits);
+        k.half = (uint32_t)((q - 1) >> 1);
+        std::vector<uint32_t> h(4 * (size_t)n);
+        for (int kx = 0; kx < n; kx++) {
+            h[kx] = (uint32_t)zf[kx];             h[n + kx] = shoup(zf[kx], Q, bits);
+            h[2 * n + kx] = (uint32_t)zi[kx];     h[3 * n + kx] = shoup(zi[kx], Q, bits);
+        }
+        p->d_tab[mi] = nullptr;
+        if (hipMalloc(&p->d_tab[mi], h.size() * 4) != hipSuccess ||
+            hipMemcpy(p->d_tab[mi], h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            delete p;
+            return fail("plan_create: cannot upload twiddle tables");
+        }
+        const uint64_t s0 = ninv, s1 = mulmod(ninv, zi[1], Q);
+        const uint64_t m0 = mulmod(ninv, R, Q), m1 = mulmod(m0, zi[1], Q);
+        p->c_inv[mi][0] = (uint32_t)s0;  p->c_inv[mi][1] = shoup(s0, Q, bits);
+        p->c_inv[mi][2] = (uint32_t)s1;  p->c_inv[mi][3] = shoup(s1, Q, bits);
+        p->c_mont[mi][0] = (uint32_t)m0; p->c_mont[mi][1] = shoup(m0, Q, bits);
+        p->c_mont[mi][2] = (uint32_t)m1; p->c_mont[mi][3] = shoup(m1, Q, bits);
+    }
+    p->r2 = (uint32_t)R; p->r2p = shoup(R, Q, 32);
+    // lazy forward butterflies: values reach 2q(L+1); they must stay below BETA and the
+    // Montgomery product bound 4q(L+2) < 2^32 must hold
+    p->lazy24 = (2ull * Q * (uint64_t)(L + 2) < (1ull << 24));
+    p->lazy32 = (Q < (1ull << 25));
+    p->mode = (Q < (1ull << 23)) ? MODE_U24 : MODE_U32;
+    *out = p;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
+{
+    if (!p) return;
+    for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)hipFree(p->d_tab[i]);
+    delete p;
+}
+extern "C" int32_t sc_hip_plan_q(const sc_hip_plan_t *p) { return p ? p->q : 0; }
+extern "C" int sc_hip_plan_n(const sc_hip_plan_t *p) { return p ? p->n : 0; }
+extern "C" int32_t sc_hip_plan_root(const sc_hip_plan_t *p) { return p ? p->g : 0; }
+extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t *h_r)
+{
+    if (!p || !h_w || !h_r) return fail("plan_tables: null argument");
+    memcpy(h_w, p->w.data(), sizeof(int32_t) * (size_t)p->n);
+    memcpy(h_r, p->r.data(), sizeof(int32_t) * (size_t)p->n);
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
+{
+    if (!p) return fail("plan_set_arith: null plan");
+    if (mode == 0) mode = ((uint64_t)p->q < (1ull << 23)) ? MODE_U24 : MODE_U32;
+    if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
+    if (mode != MODE_U24 && mode != MODE_U32) return fail("plan_set_arith: mode must be 0, 1 or 2");
+    p->mode = mode;
+    return SC_HIP_SUCCESS;
+}
+
+template <int L, int MODE, bool LAZY, int OP>
+static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP>), dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+template <int L, int OP>
+static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
+{
+    if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
+        return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
+    } else {
+        if (mode == MODE_U24) return lazy ? launch_ntt_t<L, MODE_U24, true, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s);
+        return lazy ? launch_ntt_t<L, MODE_U32, true, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
+    }
+}
+template <int OP>
+static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
+{
+    switch (L) {
+    case 8: return launch_ntt_l<8, OP>(a, mode, lazy, blocks, s);
+    case 9: return launch_ntt_l<9, OP>(a, mode, lazy, blocks, s);
+    default: return launch_ntt_l<10, OP>(a, mode, lazy, blocks, s);
+    }
+}
+
+static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream)
+{
+    if (!p) return fail("ntt: null plan");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d0 || !dout || ((op == OP_MULNTT || op == OP_MUL) && !d1)) return fail("ntt: null device pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const int mi = p->mode == MODE_U24 ? 0 : 1;
+    const int n = p->n;
+    NttArgs a;
+    a.in0 = d0; a.in1 = d1; a.out = dout;
+    a.zf = p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.batch = batch; a.k = p->k[mi];
+    const uint32_t *c = (op == OP_INV) ? p->c_inv[mi] : p->c_mont[mi];
+    a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
+    const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
+    const int pw = 1024 / n;                                  // polynomials per wave
+    const size_t groups = (batch + pw - 1) / pw;
+    size_t blocks = (groups + 3) / 4;
+    const size_t cap = (size_t)p->ctx->cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipError_t e;
+    switch (op) {
+    case OP_FWD: e = launch_ntt_op<OP_FWD>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
+    case OP_INV: e = launch_ntt_op<OP_INV>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
+    case OP_MULNTT: e = launch_ntt_op<OP_MULNTT>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
+    default: e = launch_ntt_op<OP_MUL>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
+    }
+    if (e != hipSuccess) return fail(std::string("ntt kernel launch: ") + hipGetErrorString(e));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_ntt_fwd(sc_hip_plan_t *p, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream)
+{ return run_ntt(p, OP_FWD, batch, d_in, nullptr, d_out, stream); }
+extern "C" int sc_hip_ntt_inv(sc_hip_plan_t *p, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream)
+{ return run_ntt(p, OP_INV, batch, d_in, nullptr, d_out, stream); }
+extern "C" int sc_hip_polymul_ntt(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
+{ return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream); }
+extern "C" int sc_hip_polymul(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
+{ return run_ntt(p, OP_MUL, batch, d_a, d_b, d_out, stream); }
+
+template <int OPE>
+static int run_ew(sc_hip_ctx *ctx, const ModK &k, uint32_t r2, uint32_t r2p, size_t len, const int32_t *a, const int32_t *b, int32_t *out, void *stream)
+{
+    if (len == 0) return SC_HIP_SUCCESS;
+    if (!a || !out || ((OPE == EW_POINTWISE || OPE == EW_ADD || OPE == EW_SUB) && !b)) return fail("elementwise: null device pointer");
+    if ((((uintptr_t)a | (uintptr_t)out | (uintptr_t)b) & 15) != 0) return fail("elementwise: device pointers must be 16-byte aligned");
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t blocks = (len / 4 + 255) / 256;
+    if (blocks == 0) blocks = 1;
+    const size_t cap = (size_t)ctx->cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((ew_kernel<OPE>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, len, k, r2, r2p);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_pointwise(sc_hip_plan_t *p, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
+{ if (!p) return fail("pointwise: null plan"); return run_ew<EW_POINTWISE>(p->ctx, p->k[1], p->r2, p->r2p, len, d_a, d_b, d_out, stream); }
+extern "C" int sc_hip_normalize(sc_hip_plan_t *p, size_t len, const int32_t *d_in, int32_t *d_out, void *stream)
+{ if (!p) return fail("normalize: null plan"); return run_ew<EW_NORMALIZE>(p->ctx, p->k[1], 0, 0, len, d_in, nullptr, d_out, stream); }
+extern "C" int sc_hip_center(sc_hip_plan_t *p, size_t len, const int32_t *d_in, int32_t *d_out, void *stream)
+{ if (!p) return fail("center: null plan"); return run_ew<EW_CENTER>(p->ctx, p->k[1], 0, 0, len, d_in, nullptr, d_out, stream); }
+extern "C" int sc_hip_poly_add(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
+{ if (!ctx) return fail("poly_add: null ctx"); ModK k = {}; return run_ew<EW_ADD>(ctx, k, 0, 0, len, d_a, d_b, d_out, stream); }
+extern "C" int sc_hip_poly_sub(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
+{ if (!ctx) return fail("poly_sub: null ctx"); ModK k = {}; return run_ew<EW_SUB>(ctx, k, 0, 0, len, d_a, d_b, d_out, stream); }
+
+extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int transposed,
+                             const int32_t *d_Ahat, const int32_t *d_y, int32_t *d_t, void *stream)
+{
+    (void)p; (void)batch; (void)kk; (void)l; (void)transposed; (void)d_Ahat; (void)d_y; (void)d_t; (void)stream;
+    return fail("matvec: not built yet in this round");
+}
+
+// ---- CDT -----------------------------------------------------------------------------------
+
+extern "C" int sc_hip_cdt_table_size(float tail, float sigma)
+{
+    if (!(tail > 0.f) || !(sigma > 0.f)) return 0;
+    // size = 2^ceil(log2((size_t)(tail*sigma)))  (gaussian_cdf.c:562, sc_math.c sc_ceil_log2)
+    const float prod = tail * sigma;
+    const uint32_t v = (uint32_t)prod;
+    int bits = 0;
+    while ((1ull << bits) < v) bits++;
+    return 1 << bits;
+}
+
+extern "C" int sc_hip_cdt_build_table(float tail, float sigma, uint64_t *cdf, int size)
+{
+    if (!cdf || size != sc_hip_cdt_table_size(tail, sigma) || size < 2) return fail("cdt_build_table: bad size");
+    // long-double recurrence of gaussian_cdf.c:588-607 (sigma*sigma is a FLOAT product there)
+    const long double two_sqrtpi = 1.128379167095512573896158903121545172L;
+    const long double sqrt1_2 = 0.707106781186547524400844362104849039L;
+    const long double d = two_sqrtpi * sqrt1_2 * 18446744073709551616.0L / (long double)sigma;
+    const float sigma_sq = sigma * sigma;
+    const long double e = -0.5L / (long double)sigma_sq;
+    long double s = 0.5L * d;
+    int i;
+    cdf[0] = 0;
+    for (i = 1; i < size - 1; i++) {
+        cdf[i] = (uint64_t)s;
+        if (cdf[i] == 0) break;
+        s += d * expl(e * ((long double)(i * i)));
+    }
+    for (; i < size; i++) cdf[i] = 0xFFFFFFFFFFFFFFFFull;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h_cdf, int size, sc_hip_cdt_t **out)
+{
+    if (!ctx || !out || !h_cdf) return fail("cdt_create_from_table: null argument");
+    if (size < 2 || size > 4096 || (size & (size - 1))) return fail("cdt_create: table must have 2..4096 entries, a power of two (LDS residency)");
+    for (int i = 1; i < size; i++) if (h_cdf[i] < h_cdf[i - 1]) return fail("cdt_create_from_table: table is not monotone");
+    sc_hip_cdt *c = new sc_hip_cdt;
+    c->ctx = ctx; c->tail = 0.f; c->sigma = 0.f; c->size = size;
+    c->cdf.assign(h_cdf, h_cdf + size);
+    c->d_cdf = nullptr;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * size) != hipSuccess ||
+        hipMemcpy(c->d_cdf, c->cdf.data(), sizeof(uint64_t) * size, hipMemcpyHostToDevice) != hipSuccess) {
+        delete c;
+        return fail("cdt_create: cannot upload the table");
+    }
+    *out = c;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t **out)
+{
+    if (!ctx || !out) return fail("cdt_create: null argument");
+    const int size = sc_hip_cdt_table_size(tail, sigma);
+    if (size < 2 || size > 4096) return fail("cdt_create: tail*sigma must give a table of 2..4096 entries (LDS residency)");
+    std::vector<uint64_t> t((size_t)size);
+    if (sc_hip_cdt_build_table(tail, sigma, t.data(), size) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    if (sc_hip_cdt_create_from_table(ctx, t.data(), size, out) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    (*out)->tail = tail; (*out)->sigma = sigma;
+    return SC_HIP_SUCCESS;
+}
+extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)hipFree(c->d_cdf); delete c; }
+extern "C" int sc_hip_cdt_size(const sc_hip_cdt_t *c) { return c ? c->size : 0; }
+extern "C" int sc_hip_cdt_table(const sc_hip_cdt_t *c, uint64_t *h)
+{
+    if (!c || !h) return fail("cdt_table: null argument");
+    memcpy(h, c->cdf.data(), sizeof(uint64_t) * (size_t)c->size);
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream)
+{
+    if (!c) return fail("cdt_sample: null sampler");
+    if (count == 0) return SC_HIP_SUCCESS;
+    if (!d_uniform || !d_out) return fail("cdt_sample: null device pointer");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    size_t blocks = (count + 256 * 16 - 1) / (256 * 16);       // >= 16 samples per lane amortise the table load
+    if (blocks == 0) blocks = 1;
+    const size_t cap = (size_t)c->ctx->cus * 4;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(cdt_kernel, dim3((unsigned)blocks), dim3(256), sizeof(uint64_t) * (size_t)c->size, (hipStream_t)stream,
+                       c->d_cdf, c->size, d_uniform, d_out, count, centre);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// ---- host-buffer convenience ---------------------------------------------------------------
+
+static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t *h0, const int32_t *h1, int32_t *hout)
+{
+    if (!p) return fail("host op: null plan");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h0 || !hout) return fail("host op: null host pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const size_t bytes = batch * (size_t)p->n * sizeof(int32_t);
+    int32_t *d0 = nullptr, *d1 = nullptr;
+    HIPCHK(hipMalloc(&d0, bytes));
+    int rc = SC_HIP_SUCCESS;
+    if (hipMemcpy(d0, h0, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+    if (rc == SC_HIP_SUCCESS && h1) {
+        if (hipMalloc(&d1, bytes) != hipSuccess || hipMemcpy(d1, h1, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+    }
+    if (rc == SC_HIP_SUCCESS) rc = run_ntt(p, op, batch, d0, d1, d0, nullptr);
+    if (rc == SC_HIP_SUCCESS && hipMemcpy(hout, d0, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("host op: D2H copy failed");
+    (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    return rc;
+}
+extern "C" int sc_hip_ntt_fwd_host(sc_hip_plan_t *p, size_t batch, const int32_t *h_in, int32_t *h_out)
+{ return host_roundtrip(p, OP_FWD, batch, h_in, nullptr, h_out); }
+extern "C" int sc_hip_ntt_inv_host(sc_hip_plan_t *p, size_t batch, const int32_t *h_in, int32_t *h_out)
+{ return host_roundtrip(p, OP_INV, batch, h_in, nullptr, h_out); }
+extern "C" int sc_hip_polymul_ntt_host(sc_hip_plan_t *p, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out)
+{ if (!h_bhat) return fail("polymul_ntt_host: null host pointer"); return host_roundtrip(p, OP_MULNTT, batch, h_a, h_bhat, h_out); }
+extern "C" int sc_hip_cdt_sample_host(sc_hip_cdt_t *c, size_t count, const uint64_t *h_uniform, int32_t centre, int32_t *h_out)
+{
+    if (!c) return fail("cdt_sample_host: null sampler");
+    if (count == 0) return SC_HIP_SUCCESS;
+    if (!h_uniform || !h_out) return fail("cdt_sample_host: null host pointer");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    uint64_t *dx = nullptr; int32_t *dv = nullptr;
+    HIPCHK(hipMalloc(&dx, count * 8));
+    int rc = SC_HIP_SUCCESS;
+    if (hipMalloc(&dv, count * 4) != hipSuccess || hipMemcpy(dx, h_uniform, count * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail("cdt_sample_host: H2D failed");
+    if (rc == SC_HIP_SUCCESS) rc = sc_hip_cdt_sample(c, count, dx, centre, dv, nullptr);
+    if (rc == SC_HIP_SUCCESS && hipMemcpy(h_out, dv, count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("cdt_sample_host: D2H failed");
+    (void)hipFree(dx);
+    if (dv) (void)hipFree(dv);
+    return rc;
+}
+
+// ---- timing --------------------------------------------------------------------------------
+
+extern "C" int sc_hip_time_op(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d_a, const int32_t *d_b,
+                              int32_t *d_out, void *stream, int iters, float *ms)
+{
+    if (!p || !ms || iters <= 0) return fail("time_op: bad argument");
+    if (op < 0 || op > 3) return fail("time_op: op must be 0..3");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    int rc = SC_HIP_SUCCESS;
+    (void)hipEventRecord(e0, (hipStream_t)stream);
+    for (int i = 0; i < iters && rc == SC_HIP_SUCCESS; i++) rc = run_ntt(p, op, batch, d_a, d_b, d_out, stream);
+    (void)hipEventRecord(e1, (hipStream_t)stream);
+    if (rc == SC_HIP_SUCCESS && hipEventSynchronize(e1) != hipSuccess) rc = fail("time_op: event synchronize failed");
+    float t = 0.f;
+    if (rc == SC_HIP_SUCCESS && hipEventElapsedTime(&t, e0, e1) != hipSuccess) rc = fail("time_op: elapsed time failed");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)iters;
+    return rc;
+}

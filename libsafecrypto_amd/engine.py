@@ -1,0 +1,291 @@
+"""ctypes binding of include/sc_hip.h.  No CPU fallback: if the library or a gfx950 device
+is missing every compute call raises EngineError."""
+import ctypes as C
+import os
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(ROOT, 'lib', 'libsc_hip.so')
+
+# every symbol include/sc_hip.h declares (the CPU test-suite checks the library exports them)
+SYMBOLS = [
+    'sc_hip_ctx_create', 'sc_hip_ctx_destroy', 'sc_hip_last_error', 'sc_hip_device_count', 'sc_hip_synchronize',
+    'sc_hip_plan_create', 'sc_hip_plan_destroy', 'sc_hip_plan_q', 'sc_hip_plan_n', 'sc_hip_plan_root',
+    'sc_hip_plan_tables', 'sc_hip_plan_set_arith',
+    'sc_hip_ntt_fwd', 'sc_hip_ntt_inv', 'sc_hip_pointwise', 'sc_hip_polymul_ntt', 'sc_hip_polymul',
+    'sc_hip_normalize', 'sc_hip_center', 'sc_hip_poly_add', 'sc_hip_poly_sub', 'sc_hip_matvec',
+    'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_create_from_table',
+    'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
+    'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
+    'sc_hip_time_op',
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build_cdt_table(tail, sigma):
+    """host-only: the table gaussian_cdf_create_64 would build on THIS host"""
+    import numpy as np
+    L = load_library()
+    size = L.sc_hip_cdt_table_size(tail, sigma)
+    t = np.empty(size, dtype=np.uint64)
+    _chk(L, L.sc_hip_cdt_build_table(tail, sigma, C.c_void_p(t.ctypes.data), size), 'cdt_build_table')
+    return t
+
+
+_LIB = None
+
+
+def load_library(path=LIB_PATH):
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(path):
+        raise EngineError(f'{path} is missing: run __graft_entry__.build() (make -C libsafecrypto_amd/csrc); '
+                          'there is no CPU fallback')
+    # torch's wheel bundles its own libamdhip64.so.7: import it first so that this process holds
+    # ONE HIP runtime (ours resolves the same SONAME to the already-loaded copy); two runtimes in
+    # one process leave the second without a visible GPU.  A pure C host links /opt/rocm's.
+    import torch  # noqa: F401
+    L = C.CDLL(path)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    L.sc_hip_last_error.restype = C.c_char_p
+    L.sc_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.sc_hip_ctx_destroy.argtypes = [vp]
+    L.sc_hip_ctx_destroy.restype = None
+    L.sc_hip_synchronize.argtypes = [vp, vp]
+    L.sc_hip_plan_create.argtypes = [vp, i32, C.c_int, C.POINTER(vp)]
+    L.sc_hip_plan_destroy.argtypes = [vp]
+    L.sc_hip_plan_destroy.restype = None
+    L.sc_hip_plan_q.argtypes = [vp]
+    L.sc_hip_plan_q.restype = i32
+    L.sc_hip_plan_n.argtypes = [vp]
+    L.sc_hip_plan_root.argtypes = [vp]
+    L.sc_hip_plan_root.restype = i32
+    L.sc_hip_plan_tables.argtypes = [vp, vp, vp]
+    L.sc_hip_plan_set_arith.argtypes = [vp, C.c_int]
+    for name in ('sc_hip_ntt_fwd', 'sc_hip_ntt_inv'):
+        getattr(L, name).argtypes = [vp, sz, vp, vp, vp]
+    for name in ('sc_hip_polymul_ntt', 'sc_hip_polymul', 'sc_hip_pointwise'):
+        getattr(L, name).argtypes = [vp, sz, vp, vp, vp, vp]
+    for name in ('sc_hip_normalize', 'sc_hip_center'):
+        getattr(L, name).argtypes = [vp, sz, vp, vp, vp]
+    for name in ('sc_hip_poly_add', 'sc_hip_poly_sub'):
+        getattr(L, name).argtypes = [vp, sz, vp, vp, vp, vp]
+    L.sc_hip_matvec.argtypes = [vp, sz, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.sc_hip_cdt_create.argtypes = [vp, C.c_float, C.c_float, C.POINTER(vp)]
+    L.sc_hip_cdt_table_size.argtypes = [C.c_float, C.c_float]
+    L.sc_hip_cdt_build_table.argtypes = [C.c_float, C.c_float, vp, C.c_int]
+    L.sc_hip_cdt_create_from_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.sc_hip_cdt_destroy.argtypes = [vp]
+    L.sc_hip_cdt_destroy.restype = None
+    L.sc_hip_cdt_size.argtypes = [vp]
+    L.sc_hip_cdt_table.argtypes = [vp, vp]
+    L.sc_hip_cdt_sample.argtypes = [vp, sz, vp, i32, vp, vp]
+    L.sc_hip_ntt_fwd_host.argtypes = [vp, sz, vp, vp]
+    L.sc_hip_ntt_inv_host.argtypes = [vp, sz, vp, vp]
+    L.sc_hip_polymul_ntt_host.argtypes = [vp, sz, vp, vp, vp]
+    L.sc_hip_cdt_sample_host.argtypes = [vp, sz, vp, i32, vp]
+    L.sc_hip_time_op.argtypes = [vp, C.c_int, sz, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
+    _LIB = L
+    return L
+
+
+def _chk(L, rc, what):
+    if rc != 0:
+        raise EngineError(f'{what}: {L.sc_hip_last_error().decode()}')
+
+
+def _ptr(t):
+    """device (torch tensor) or host (numpy array) pointer"""
+    if hasattr(t, 'data_ptr'):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def _stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One per (process, device): mirrors the per-context wiring safecrypto_create does
+    (sc->sc_ntt / sc->sc_gauss, src/schemes/sig/dilithium/dilithium.c:207-209)."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ctx_create(device, C.byref(h)), 'sc_hip_ctx_create')
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def plan(self, q, n):
+        return NttPlan(self, q, n)
+
+    def sampler(self, tail=None, sigma=None, table=None):
+        return CdtSampler(self, tail, sigma, table)
+
+    def synchronize(self):
+        _chk(self.L, self.L.sc_hip_synchronize(self.h, _stream()), 'sc_hip_synchronize')
+
+    def poly_add(self, a, b, out=None):
+        import torch
+        out = torch.empty_like(a) if out is None else out
+        _chk(self.L, self.L.sc_hip_poly_add(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'poly_add')
+        return out
+
+    def poly_sub(self, a, b, out=None):
+        import torch
+        out = torch.empty_like(a) if out is None else out
+        _chk(self.L, self.L.sc_hip_poly_sub(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'poly_sub')
+        return out
+
+
+class NttPlan:
+    """(q, n) context: the GPU counterpart of ntt_params_t + w/r tables."""
+
+    def __init__(self, eng, q, n):
+        self.eng, self.L = eng, eng.L
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_plan_create(eng.h, q, n, C.byref(h)), 'sc_hip_plan_create')
+        self.h, self.q, self.n = h, q, n
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_plan_destroy(self.h)
+            self.h = None
+
+    @property
+    def root(self):
+        return self.L.sc_hip_plan_root(self.h)
+
+    def tables(self):
+        import numpy as np
+        w = np.empty(self.n, dtype=np.int32)
+        r = np.empty(self.n, dtype=np.int32)
+        _chk(self.L, self.L.sc_hip_plan_tables(self.h, _ptr(w), _ptr(r)), 'plan_tables')
+        return w, r
+
+    def set_arith(self, mode):
+        _chk(self.L, self.L.sc_hip_plan_set_arith(self.h, mode), 'plan_set_arith')
+
+    def _batch(self, t):
+        assert t.dtype.is_floating_point is False and t.element_size() == 4 and t.is_contiguous()
+        assert t.numel() % self.n == 0
+        return t.numel() // self.n
+
+    def _out(self, a, out):
+        import torch
+        return torch.empty_like(a) if out is None else out
+
+    def fwd(self, a, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_ntt_fwd(self.h, self._batch(a), _ptr(a), _ptr(out), _stream()), 'ntt_fwd')
+        return out
+
+    def inv(self, a, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_ntt_inv(self.h, self._batch(a), _ptr(a), _ptr(out), _stream()), 'ntt_inv')
+        return out
+
+    def polymul_ntt(self, a, bhat, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_polymul_ntt(self.h, self._batch(a), _ptr(a), _ptr(bhat), _ptr(out), _stream()), 'polymul_ntt')
+        return out
+
+    def polymul(self, a, b, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_polymul(self.h, self._batch(a), _ptr(a), _ptr(b), _ptr(out), _stream()), 'polymul')
+        return out
+
+    def pointwise(self, a, b, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_pointwise(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'pointwise')
+        return out
+
+    def normalize(self, a, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_normalize(self.h, a.numel(), _ptr(a), _ptr(out), _stream()), 'normalize')
+        return out
+
+    def center(self, a, out=None):
+        out = self._out(a, out)
+        _chk(self.L, self.L.sc_hip_center(self.h, a.numel(), _ptr(a), _ptr(out), _stream()), 'center')
+        return out
+
+    # host-buffer entry points (numpy in / numpy out), the shape the reference's vtable has
+    def fwd_host(self, a):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        out = np.empty_like(a)
+        _chk(self.L, self.L.sc_hip_ntt_fwd_host(self.h, a.size // self.n, _ptr(a), _ptr(out)), 'ntt_fwd_host')
+        return out
+
+    def inv_host(self, a):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        out = np.empty_like(a)
+        _chk(self.L, self.L.sc_hip_ntt_inv_host(self.h, a.size // self.n, _ptr(a), _ptr(out)), 'ntt_inv_host')
+        return out
+
+    def polymul_ntt_host(self, a, bhat):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        bhat = np.ascontiguousarray(bhat, dtype=np.int32)
+        out = np.empty_like(a)
+        _chk(self.L, self.L.sc_hip_polymul_ntt_host(self.h, a.size // self.n, _ptr(a), _ptr(bhat), _ptr(out)), 'polymul_ntt_host')
+        return out
+
+    def time_op(self, op, a, b, out, iters):
+        ms = C.c_float()
+        bp = _ptr(b) if b is not None else C.c_void_p()
+        _chk(self.L, self.L.sc_hip_time_op(self.h, op, self._batch(a), _ptr(a), bp, _ptr(out), _stream(), iters, C.byref(ms)), 'time_op')
+        return ms.value
+
+
+class CdtSampler:
+    """create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, ...) counterpart."""
+
+    def __init__(self, eng, tail=None, sigma=None, table=None):
+        self.eng, self.L = eng, eng.L
+        h = C.c_void_p()
+        if table is not None:
+            import numpy as np
+            t = np.ascontiguousarray(table, dtype=np.uint64)
+            _chk(self.L, self.L.sc_hip_cdt_create_from_table(eng.h, _ptr(t), t.size, C.byref(h)), 'sc_hip_cdt_create_from_table')
+        else:
+            _chk(self.L, self.L.sc_hip_cdt_create(eng.h, tail, sigma, C.byref(h)), 'sc_hip_cdt_create')
+        self.h = h
+        self.size = self.L.sc_hip_cdt_size(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_cdt_destroy(self.h)
+            self.h = None
+
+    def table(self):
+        import numpy as np
+        t = np.empty(self.size, dtype=np.uint64)
+        _chk(self.L, self.L.sc_hip_cdt_table(self.h, _ptr(t)), 'cdt_table')
+        return t
+
+    def sample(self, uniform, centre=0, out=None):
+        """uniform: int64 device tensor holding the u64 words bit-for-bit"""
+        import torch
+        assert uniform.element_size() == 8 and uniform.is_contiguous()
+        out = torch.empty(uniform.numel(), dtype=torch.int32, device=uniform.device) if out is None else out
+        _chk(self.L, self.L.sc_hip_cdt_sample(self.h, uniform.numel(), _ptr(uniform), centre, _ptr(out), _stream()), 'cdt_sample')
+        return out
+
+    def sample_host(self, uniform, centre=0):
+        import numpy as np
+        u = np.ascontiguousarray(uniform, dtype=np.uint64)
+        out = np.empty(u.size, dtype=np.int32)
+        _chk(self.L, self.L.sc_hip_cdt_sample_host(self.h, u.size, _ptr(u), centre, _ptr(out)), 'cdt_sample_host')
+        return out

@@ -9,7 +9,7 @@ def load_golden(name):
     out = {}
     cur = None
     vals = []
-    with open(os.path.join(GOLDEN_DIR, name)) as f:
+    with open(name if os.path.isabs(name) else os.path.join(GOLDEN_DIR, name)) as f:
         for line in f:
             if line.startswith('@'):
                 if cur is not None:
