@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py - headline measurement of the MI355X lattice-arithmetic engine.
+
+Workload (BASELINE.json configs[1], with the reference's real Kyber modulus - SURVEY.md section 0):
+n = 256, q = 7681, batch = 65536 polynomials per GPU; one "step" = one pass of the fused hot
+path  c = INTT( NTT(a) o bhat )  over the batch (sc_hip_polymul_ntt: forward NTT, pointwise
+multiply by an NTT-domain operand, inverse NTT, canonical output), inputs resident in HBM.
+Metric: NTT/s, counting the two transforms of each triple (BASELINE.md counts the same way).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Independent polynomials shard across ranks with no data-path collective (weak scaling: every
+rank runs its own 65536-polynomial batch); the only collectives are the timing barrier and the
+MAX over ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+Q, N, BATCH = 7681, 256, 65536
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_TRIPLE = 12 * N        # read a (4n) + read bhat (4n) + write c (4n)  
+
+
+def cpu_baseline(seconds=10.0):
+    """Single-thread CPU baseline on this host: the reference itself (oracle/_ref, built from the
+    reference sources in the dev container) when its binary travelled here, else our C port."""
+    drv = os.path.join(ROOT, 'oracle', '_ref', 'ref_driver')
+    sample = f'{seconds:.0f} s of fwd_ntt->mul_32_pointwise->inv_ntt on n={N}, q={Q} polynomials (pool of 1024, uniform [0,q)), 1 thread'
+    if os.path.exists(drv):
+        try:
+            out = subprocess.check_output([drv, 'bench', str(Q), str(N), str(seconds)], timeout=seconds * 3 + 30)
+            r = json.loads(out.decode().strip().splitlines()[-1])
+            return {'value': 2.0 * r['triples_per_sec'], 'unit': 'NTT/s', 'cores': 1, 'kind': 'reference',
+                    'sample': sample + ' (reference SC_NTT_FLOATING_POINT backend, gcc -O2)'}
+        except Exception as e:  # fall through to the port
+            sys.stderr.write(f'cpu_baseline: reference binary failed ({e}); using the port\n')
+    import numpy as np
+    from tests import oracle_lib as O
+    w, r = O.tables(Q, N)
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, Q, size=(1024, N)).astype(np.int32)
+    b = rng.integers(0, Q, size=(1024, N)).astype(np.int32)
+    done, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        O.polymul_ntt(a, b, Q, w, r)
+        done += 1024
+    dt = time.perf_counter() - t0
+    return {'value': 2.0 * done / dt, 'unit': 'NTT/s', 'cores': 1, 'kind': 'port', 'sample': sample + ' (oracle/sc_oracle.c, gcc -O2)'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device: the engine has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from libsafecrypto_amd import Engine
+    eng = Engine(local_rank)
+    plan = eng.plan(Q, N)
+
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1 + rank)
+    a = torch.randint(0, Q, (BATCH, N), dtype=torch.int32, device='cuda', generator=gen)
+    bhat = torch.randint(0, Q, (BATCH, N), dtype=torch.int32, device='cuda', generator=gen)
+    out = torch.empty_like(a)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.polymul_ntt(a, bhat, out)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.polymul_ntt(a, bhat, out)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # size-independent self check of the timed output (never timed): NTT(c) == NTT(a) o bhat
+    assert torch.equal(plan.fwd(out), plan.pointwise(plan.fwd(a), bhat)), 'bench output failed the convolution check'
+
+    if rank == 0:
+        # dominant kernel's duration, HIP events on the stream it is launched on
+        kern_ms = plan.time_op(2, a, bhat, out, 50)
+        achieved = BATCH * BYTES_PER_TRIPLE / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # per-launch HBM bytes from rocprofv3 --pmc
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get('polymul_ntt_n256_b65536_bytes')
+            except Exception:
+                traffic = None
+        fwd_ms = {}
+        for (q2, n2, b2) in [(7681, 256, 65536), (8380417, 256, 65536), (12289, 512, 32768), (12289, 1024, 16384)]:
+            p2 = plan if (q2, n2) == (Q, N) else eng.plan(q2, n2)
+            x = torch.randint(0, q2, (b2, n2), dtype=torch.int32, device='cuda', generator=gen)
+            y = torch.empty_like(x)
+            p2.fwd(x, y)
+            ms = p2.time_op(0, x, None, y, 50)
+            fwd_ms[f'q{q2}_n{n2}'] = {'NTT/s': b2 / (ms * 1e-3), 'GB/s': b2 * 8 * n2 / (ms * 1e-3) / 1e9}
+        value = 2.0 * BATCH * world * args.steps / elapsed
+        res = {
+            'metric': 'NTT/s (n=256, q=7681; fused fwd NTT + pointwise + inv NTT over batch 65536 per GPU, 2 NTTs per polynomial)',
+            'value': value, 'unit': 'NTT/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u32', 'data': 'synthetic',
+            'config': {'workload': 'BASELINE configs[1]: Kyber set 1 (n=256, q=7681 - the reference has no q=3329) '
+                                   'batched NTT + pointwise-mul + INTT, batch=65536 per GPU', 'n': N, 'q': Q,
+                       'batch_per_gpu': BATCH, 'parallelism': f'shard{world} (independent polynomials, no collective)'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'ntt_kernel<8,*,*,OP_MULNTT>', 'kernel_ms': kern_ms,
+                         'algorithmic_bytes_per_launch': BATCH * BYTES_PER_TRIPLE},
+            'extra': {'fwd_ntt': fwd_ms},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -9,6 +9,7 @@
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
  * Usage: ref_driver <ntt|cdt|all> <outdir>
+ *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *
  * Fixture format (one file per topic): repeated records
  *     @ <name> <count>\n  followed by <count> whitespace separated decimal integers.
@@ -27,6 +28,7 @@
 #include "safecrypto_private.h"
 #include "utils/arith/arith.h"
 #include "utils/arith/ntt.h"
+#include "utils/arith/roots_of_unity.h"
 #include "utils/arith/ntt_tables.h"
 #include "utils/sampling/sampling.h"
 #include "utils/crypto/prng.h"
@@ -216,8 +218,48 @@ static int gen_cdt(const char *dir)
     return rc;
 }
 
+/* -------------------------------------------------------------- CPU baseline ---- */
+
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+
+/* The reference's own code path for BASELINE config 2, single thread, default (floating
+ * point) reduction backend as the schemes select it (dilithium.c:184-191, kyber_kem.c:102-110):
+ * fwd_ntt -> mul_32_pointwise -> inv_ntt per polynomial, over a resident pool of polynomials. */
+static int bench_ntt(int32_t q, int n, double seconds)
+{
+    const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+    ntt_params_t p;
+    const int POOL = 1024;
+    int32_t *w = malloc(sizeof(int32_t) * n), *r = malloc(sizeof(int32_t) * n);
+    int16_t *w16 = malloc(sizeof(int16_t) * n), *r16 = malloc(sizeof(int16_t) * n);
+    int32_t *a = malloc(sizeof(int32_t) * n * POOL), *b = malloc(sizeof(int32_t) * n * POOL), *o = malloc(sizeof(int32_t) * n * POOL);
+    init_reduce(&p, n, q);
+    if (roots_of_unity_s32(w, r, n, q, 0, 0) != SC_FUNC_SUCCESS) return 1;
+    const int is16 = q < 32768;
+    for (int i = 0; i < n; i++) { w16[i] = (int16_t)w[i]; r16[i] = (int16_t)r[i]; }
+    sm_state = 1;
+    for (int i = 0; i < n * POOL; i++) { a[i] = (int)(splitmix64() % (uint64_t)q); b[i] = (int)(splitmix64() % (uint64_t)q); }
+    uint64_t done = 0, chk = 0;
+    double t0 = now_s(), t1;
+    do {
+        for (int k = 0; k < POOL; k++) {
+            int32_t *v = o + k * n;
+            if (is16) { ntt->fwd_ntt_32_16(v, &p, a + k * n, w16); ntt->mul_32_pointwise(v, &p, v, b + k * n); ntt->inv_ntt_32_16(v, &p, v, w16, r16); }
+            else      { ntt->fwd_ntt_32_32(v, &p, a + k * n, w);   ntt->mul_32_pointwise(v, &p, v, b + k * n); ntt->inv_ntt_32_32(v, &p, v, w, r); }
+            chk += (uint32_t)v[0];
+        }
+        done += POOL;
+        t1 = now_s();
+    } while (t1 - t0 < seconds);
+    printf("{\"q\": %d, \"n\": %d, \"triples\": %llu, \"seconds\": %.6f, \"triples_per_sec\": %.1f, \"checksum\": %llu}\n",
+           q, n, (unsigned long long)done, t1 - t0, done / (t1 - t0), (unsigned long long)chk);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
