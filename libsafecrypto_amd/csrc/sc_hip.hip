@@ -35,6 +35,22 @@ __host__ __device__ constexpr int brv4(int r) { return ((r & 1) << 3) | ((r & 2)
 // One wavefront handles PW polynomials at a time and loops over the batch (persistent waves:
 // the per-lane twiddles are loaded once).  256 threads = 4 independent waves per workgroup;
 // LDS: 4 KB per wave (one polynomial image per polynomial in flight).
+//
+// The loop is software-pipelined: the 16 input words of the NEXT group are requested before the
+// current group's butterflies start, so every resident wave always has 4 KB of HBM reads in
+// flight (the kernel is otherwise a load -> compute -> store chain per wave and runs at the
+// memory latency, not the memory bandwidth).  Groups are disjoint in memory, so running ahead
+// is safe when out aliases in.
+template <int L, int OP>
+struct Io {
+    using Y = Lay<L>;
+    // element offset of register r for this lane: coefficient-domain arrays are read/written in
+    // round-0 layout (j = r*LP + lp); NTT-domain arrays (natural order in memory) in the last
+    // round's layout with the bit reversal applied (position j = lp*16+r  <->  index bitrev_L(j))
+    static __device__ __forceinline__ int off_coef(int r, int lp) { return r * Y::LP + lp; }
+    static __device__ __forceinline__ int off_ntt(int r, int blp) { return brv4(r) * Y::LP + blp; }
+};
+
 template <int L, int MODE, bool LAZY, int OP>
 __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 {
@@ -53,54 +69,79 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
     if (OP != OP_FWD) twi.load(a.zi, a.zip, lp);
 
     const unsigned long long groups = (a.batch + PW - 1) / PW;
-    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long gstride = (unsigned long long)gridDim.x * 4;
+    unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
+    if (g >= groups) return;
+
+    // in0 is read in the layout the first transform wants
+    const int off0 = (OP == OP_INV) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp);
+    int32_t nx[16];                                      // raw words of the group about to be processed
+    {
+        const unsigned long long poly = g * PW + pw;
+        const int32_t *src = a.in0 + (size_t)poly * N + off0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) nx[r] = (poly < a.batch) ? src[(OP == OP_INV ? brv4(r) : r) * LP] : 0;
+    }
+
+    for (; g < groups; g += gstride) {
         const unsigned long long poly = g * PW + pw;
         const bool valid = poly < a.batch;
         const size_t base = (size_t)poly * N;
         uint32_t x[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = reduce_i32(nx[r], k);
 
-        if (OP == OP_INV) {
-            // NTT-domain input, natural order: position j = lp*16+r wants V[bitrev(j)]
+        // second operand of this group: requested now, consumed after the forward transform
+        int32_t nb[16];
+        if (OP == OP_MULNTT || OP == OP_MUL) {
+            const int32_t *srcb = a.in1 + base + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(a.in0[base + brv4(r) * LP + blp], k) : 0u;
-        } else {
-            // coefficient-domain input: layout b0(0): position j = r*LP + lp
-#pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(a.in0[base + r * LP + lp], k) : 0u;
-            fwd_core<L, MODE, LAZY>(x, twf, lds_poly, lp, k);
+            for (int r = 0; r < 16; r++) nb[r] = valid ? srcb[(OP == OP_MULNTT ? brv4(r) : r) * LP] : 0;
         }
+        // first operand of the next group (run-ahead)
+        auto prefetch = [&]() {
+            const unsigned long long npoly = (g + gstride) * PW + pw;
+            const bool nvalid = (g + gstride < groups) && (npoly < a.batch);
+            const int32_t *src = a.in0 + (size_t)npoly * N + off0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) nx[r] = nvalid ? src[(OP == OP_INV ? brv4(r) : r) * LP] : 0;
+        };
+        if (OP == OP_FWD || OP == OP_INV) prefetch();
+
+        if (OP != OP_INV) fwd_core<L, MODE, LAZY>(x, twf, lds_poly, lp, k);
 
         if (OP == OP_FWD) {
+            int32_t *dst = a.out + base + Io<L, OP>::off_ntt(0, blp);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t v = x[r];
                 if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
                 v = csub(v, k.q);
-                if (valid) a.out[base + brv4(r) * LP + blp] = (int32_t)v;
+                if (valid) dst[brv4(r) * LP] = (int32_t)v;
             }
             continue;
         }
 
         if (OP == OP_MULNTT) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t b = valid ? reduce_i32(a.in1[base + brv4(r) * LP + blp], k) : 0u;
-                x[r] = montmul(x[r], b, k);
-            }
+            for (int r = 0; r < 16; r++) x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
+            prefetch();
         }
         if (OP == OP_MUL) {
             uint32_t y[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) y[r] = valid ? reduce_i32(a.in1[base + r * LP + lp], k) : 0u;
+            for (int r = 0; r < 16; r++) y[r] = reduce_i32(nb[r], k);
+            prefetch();
             fwd_core<L, MODE, false>(y, twf, lds_poly, lp, k);      // [0,2q)
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = montmul(x[r], y[r], k);
         }
 
         inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+        int32_t *dst = a.out + base + Io<L, OP>::off_coef(0, lp);
 #pragma unroll
         for (int r = 0; r < 16; r++)
-            if (valid) a.out[base + r * LP + lp] = (int32_t)x[r];
+            if (valid) dst[r * LP] = (int32_t)x[r];
     }
 }
 
@@ -181,6 +222,7 @@ __global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ c
 // ------------------------------------------------------------------------------------------
 
 static thread_local std::string g_err;
+static int g_cus = 256;
 static int fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
 #define HIPCHK(expr)                                                                          \
     do {                                                                                      \
@@ -247,6 +289,7 @@ extern "C" int sc_hip_ctx_create(int device, sc_hip_ctx_t **out)
     sc_hip_ctx *c = new sc_hip_ctx;
     c->device = device;
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_cus = c->cus;
     *out = c;
     return SC_HIP_SUCCESS;
 }
@@ -324,7 +367,9 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     // Montgomery product bound 4q(L+2) < 2^32 must hold
     p->lazy24 = (2ull * Q * (uint64_t)(L + 2) < (1ull << 24));
     p->lazy32 = (Q < (1ull << 25));
-    p->mode = (Q < (1ull << 23)) ? MODE_U24 : MODE_U32;
+    // measured on MI355X (profiles/microbench_r01b.txt): v_mul_lo/hi_u32 issue at full rate on gfx950,
+    // so the 4-instruction 32-bit Shoup product beats the 6-instruction 24-bit one for every q
+    p->mode = MODE_U32;
     *out = p;
     return SC_HIP_SUCCESS;
 }
@@ -348,16 +393,26 @@ extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t 
 extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
-    if (mode == 0) mode = ((uint64_t)p->q < (1ull << 23)) ? MODE_U24 : MODE_U32;
+    if (mode == 0) mode = MODE_U32;
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
     if (mode != MODE_U24 && mode != MODE_U32) return fail("plan_set_arith: mode must be 0, 1 or 2");
     p->mode = mode;
     return SC_HIP_SUCCESS;
 }
 
+// grid = what is resident at once (occupancy x CUs), so that every wave loops over many groups
+// and the run-ahead pipeline stays primed; never more blocks than there are groups of 4 waves
 template <int L, int MODE, bool LAZY, int OP>
 static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
 {
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_kernel<L, MODE, LAZY, OP>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        per_cu = nb;
+    }
+    const long long cap = (long long)per_cu * g_cus;
+    if (blocks > cap) blocks = (int)cap;
     hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP>), dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -399,8 +454,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int pw = 1024 / n;                                  // polynomials per wave
     const size_t groups = (batch + pw - 1) / pw;
     size_t blocks = (groups + 3) / 4;
-    const size_t cap = (size_t)p->ctx->cus * 8;
-    if (blocks > cap) blocks = cap;
+    if (blocks > (size_t)1 << 30) blocks = (size_t)1 << 30;
     hipError_t e;
     switch (op) {
     case OP_FWD: e = launch_ntt_op<OP_FWD>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
