@@ -131,6 +131,9 @@ int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, 
 int sc_hip_ntt_inv_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
 int sc_hip_polymul_ntt_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out);
 int sc_hip_cdt_sample_host(sc_hip_cdt_t *cdt, size_t count, const uint64_t *h_uniform, int32_t centre, int32_t *h_out);
+int sc_hip_pointwise_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_a, const int32_t *h_b, int32_t *h_out);
+int sc_hip_normalize_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_in, int32_t *h_out);
+int sc_hip_center_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_in, int32_t *h_out);
 
 /* ---- timing helper ---------------------------------------------------------------------- */
 /* Runs `iters` back-to-back launches of one op (0 fwd, 1 inv, 2 polymul_ntt, 3 polymul) on

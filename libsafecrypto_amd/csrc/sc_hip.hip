@@ -641,6 +641,37 @@ extern "C" int sc_hip_cdt_sample_host(sc_hip_cdt_t *c, size_t count, const uint6
     return rc;
 }
 
+static int host_ew(sc_hip_plan_t *p, int which, size_t len, const int32_t *h0, const int32_t *h1, int32_t *hout)
+{
+    if (!p) return fail("host op: null plan");
+    if (len == 0) return SC_HIP_SUCCESS;
+    if (!h0 || !hout || (which == EW_POINTWISE && !h1)) return fail("host op: null host pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const size_t bytes = len * sizeof(int32_t);
+    int32_t *d0 = nullptr, *d1 = nullptr;
+    HIPCHK(hipMalloc(&d0, bytes));
+    int rc = SC_HIP_SUCCESS;
+    if (hipMemcpy(d0, h0, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+    if (rc == SC_HIP_SUCCESS && which == EW_POINTWISE) {
+        if (hipMalloc(&d1, bytes) != hipSuccess || hipMemcpy(d1, h1, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+    }
+    if (rc == SC_HIP_SUCCESS) {
+        if (which == EW_POINTWISE) rc = sc_hip_pointwise(p, len, d0, d1, d0, nullptr);
+        else if (which == EW_NORMALIZE) rc = sc_hip_normalize(p, len, d0, d0, nullptr);
+        else rc = sc_hip_center(p, len, d0, d0, nullptr);
+    }
+    if (rc == SC_HIP_SUCCESS && hipMemcpy(hout, d0, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("host op: D2H copy failed");
+    (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    return rc;
+}
+extern "C" int sc_hip_pointwise_host(sc_hip_plan_t *p, size_t len, const int32_t *h_a, const int32_t *h_b, int32_t *h_out)
+{ return host_ew(p, EW_POINTWISE, len, h_a, h_b, h_out); }
+extern "C" int sc_hip_normalize_host(sc_hip_plan_t *p, size_t len, const int32_t *h_in, int32_t *h_out)
+{ return host_ew(p, EW_NORMALIZE, len, h_in, nullptr, h_out); }
+extern "C" int sc_hip_center_host(sc_hip_plan_t *p, size_t len, const int32_t *h_in, int32_t *h_out)
+{ return host_ew(p, EW_CENTER, len, h_in, nullptr, h_out); }
+
 // ---- timing --------------------------------------------------------------------------------
 
 extern "C" int sc_hip_time_op(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d_a, const int32_t *d_b,

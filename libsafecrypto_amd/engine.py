@@ -16,8 +16,11 @@ SYMBOLS = [
     'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_create_from_table',
     'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
     'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
+    'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
     'sc_hip_time_op',
 ]
+# include/sc_hip_vtable.h
+VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors']
 
 
 class EngineError(RuntimeError):

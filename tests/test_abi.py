@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_symbols():
-    text = open(os.path.join(ROOT, 'include', 'sc_hip.h')).read()
+def _header_symbols(name='sc_hip.h'):
+    text = open(os.path.join(ROOT, 'include', name)).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(sc_hip_[a-z0-9_]+)\s*\(', text)))
 
@@ -26,6 +26,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/sc_hip.h but not exported'
     assert sorted(engine.SYMBOLS) == syms          # the Python binding covers the whole header
+    vsyms = [s for s in _header_symbols('sc_hip_vtable.h') if s not in ('sc_hip_ntt_params', 'sc_hip_ntt32_vtable')]
+    assert sorted(engine.VTABLE_SYMBOLS) == vsyms
+    for s in vsyms:
+        assert hasattr(lib, s), f'{s} declared in include/sc_hip_vtable.h but not exported'
 
 
 def test_no_cpu_fallback_without_gpu():
