@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *
  * Fixture format (one file per topic): repeated records
@@ -218,6 +218,94 @@ static int gen_cdt(const char *dir)
     return rc;
 }
 
+/* ------------------------------------------------------------ Dilithium ---- */
+
+#include "schemes/sig/dilithium/dilithium.h"
+#include "schemes/sig/dilithium/dilithium_params.h"
+#include "utils/arith/module_lwe.h"
+
+static void rec_u8(FILE *f, const char *name, const uint8_t *v, size_t n)
+{
+    fprintf(f, "@ %s %zu\n", name, n);
+    for (size_t i = 0; i < n; i++) fprintf(f, "%u%c", v[i], ((i & 31) == 31 || i + 1 == n) ? '\n' : ' ');
+    if (n == 0) fprintf(f, "\n");
+}
+
+/* One key pair of parameter set `set` (3 = "Dilithium-III": k=6,l=5, dilithium_params.c:56-64) made by the
+ * reference's keygen; the expanded matrix A (NTT domain, row-major i then j) exactly as
+ * create_rand_product_32_csprng regenerates it from rho (module_lwe.c:519-547,641-660, create_csprng :914-940);
+ * signatures of counter-derived messages by safecrypto_sign (deterministic: USE_DETERMINISTIC_DILITHIUM) and the
+ * verdict of safecrypto_verify on the genuine and on a tampered signature. */
+static int dilithium_case(FILE *f, int set, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "dil%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const dilithium_set_t *P = sc->dilithium->params;
+    const int n = P->n, k = P->k, l = P->l;
+    int32_t par[16] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->k, (int32_t)P->l, (int32_t)P->d,
+                        (int32_t)P->weight_of_c, (int32_t)P->gamma_1, (int32_t)P->gamma_1_bits, (int32_t)P->gamma_2,
+                        (int32_t)P->eta, (int32_t)P->z_bits, (int32_t)P->beta, (int32_t)P->omega, (int32_t)P->omega_bits, set };
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 16);
+    const SINT32 *priv = (const SINT32 *)sc->privkey->key;
+    const SINT32 *pub = (const SINT32 *)sc->pubkey->key;
+    snprintf(name, sizeof name, "%s_s1", tag); rec_i32(f, name, priv, (size_t)l * n);
+    snprintf(name, sizeof name, "%s_s2", tag); rec_i32(f, name, priv + l * n, (size_t)k * n);
+    snprintf(name, sizeof name, "%s_t", tag);  rec_i32(f, name, priv + (l + k) * n, (size_t)k * n);
+    const uint8_t *tail = (const uint8_t *)(priv + (NUM_DILITHIUM_PRIVKEY_K * k + l) * n);
+    snprintf(name, sizeof name, "%s_rho", tag); rec_u8(f, name, tail, 32);
+    snprintf(name, sizeof name, "%s_K", tag);   rec_u8(f, name, tail + 32, 32);
+    snprintf(name, sizeof name, "%s_tr", tag);  rec_u8(f, name, tail + 64, 48);
+    snprintf(name, sizeof name, "%s_t1", tag);  rec_i32(f, name, pub, (size_t)k * n);
+    snprintf(name, sizeof name, "%s_pub_rho", tag); rec_u8(f, name, (const uint8_t *)(pub + k * n), 32);
+
+    /* the matrix, in the order the reference draws it */
+    int32_t *A = malloc(sizeof(int32_t) * (size_t)k * l * n);
+    prng_ctx_t *csprng = create_csprng(sc, tail, 32);
+    for (int i = 0; i < k * l; i++) uniform_random_ring_q_csprng(csprng, A + (size_t)i * n, n, P->q, P->q_bits);
+    prng_destroy(csprng);
+    snprintf(name, sizeof name, "%s_Ahat", tag); rec_i32(f, name, A, (size_t)k * l * n);
+    free(A);
+
+    sm_state = 0xd111000000000000ULL + set;
+    int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t msg[96];
+        size_t mlen = (m == 0) ? 0 : (m == 1) ? 1 : (m == 2) ? 96 : 64;     /* empty / tiny / long / the bench's 64 B */
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        uint8_t *sig = NULL; size_t siglen = 0;
+        size_t before = sc->stats.sig_num_trials;
+        if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        trials[m] = (int32_t)(sc->stats.sig_num_trials - before);
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+        snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+        verdicts[2 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        sig[siglen / 2] ^= 0x10;                                             /* func_alg_dilithium.c:200-222 style bit flip */
+        verdicts[2 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        free(sig);
+    }
+    snprintf(name, sizeof name, "%s_trials", tag); rec_i32(f, name, trials, nmsg);
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
+    free(trials); free(verdicts);
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_dilithium(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/dilithium_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = dilithium_case(f, 3, 12);
+    rc |= dilithium_case(f, 1, 4);
+    fclose(f);
+    return rc;
+}
+
 /* -------------------------------------------------------------- CPU baseline ---- */
 
 #include <time.h>
@@ -264,5 +352,6 @@ int main(int argc, char **argv)
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
+    if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     return rc;
 }

@@ -1,0 +1,354 @@
+/*
+ * sc_oracle_dilithium.c - CPU restatement of the reference's Dilithium sign / verify path.
+ * TEST INFRASTRUCTURE ONLY (see sc_oracle.h).  Pinned: tests/test_oracle_dilithium.py reproduces the
+ * reference's signatures byte for byte (tests/golden/dilithium_ref.txt, made by oracle/ref_driver.c
+ * from the reference build).  Paths are relative to the reference tree.
+ *
+ * The matrix A is an INPUT (NTT domain, row-major [k][l][n]) - the reference re-derives it from rho
+ * with its AES-CTR-DRBG on every call (module_lwe.c:519-547,914-940); the fixture carries the
+ * matrix the reference drew, so no DRBG is restated here.
+ */
+#include "sc_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ SHAKE ---- */
+/* The reference's xof layer (src/utils/crypto/xof.c over sha3/tinysha3.c) is SHAKE128/256 sponge
+ * framing (rate 168/136, pad 0x1F .. 0x80, incremental absorb/squeeze) around a permutation that is
+ * NOT Keccak-f[1600]: the library is always compiled with -DSHA3_UNROLLED
+ * (src/utils/crypto/Makefile.am:94) and the unrolled chi step (sha3/tinysha3.c:186-235) walks the
+ * five "rows" at offsets 0,1,2,3,4 instead of 0,5,10,15,20 - five overlapping, sequentially applied
+ * updates of st[0..8]; st[9..24] never see chi.  theta, rho-pi and iota are the standard ones.  Every
+ * hash the schemes take goes through it, so signatures are only reproducible with the same quirk.
+ * orc_keccak_standard = 1 switches to the FIPS 202 chi (used only to validate this file's sponge
+ * against hashlib). */
+typedef struct { uint64_t s[25]; unsigned rate, pos; } shake_t;
+int orc_keccak_standard = 0;
+
+static const uint64_t RC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL };
+static const int ROTC[24] = { 1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44 };
+static const int PILN[24] = { 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1 };
+#define ROL64(x, n) (((x) << (n)) | ((x) >> (64 - (n))))
+
+static void keccakf(uint64_t st[25])
+{
+    uint64_t bc[5], t;
+    for (int r = 0; r < 24; r++) {
+        for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
+        for (int i = 0; i < 5; i++) { t = bc[(i + 4) % 5] ^ ROL64(bc[(i + 1) % 5], 1); for (int j = 0; j < 25; j += 5) st[j + i] ^= t; }
+        t = st[1];
+        for (int i = 0; i < 24; i++) { int j = PILN[i]; bc[0] = st[j]; st[j] = ROL64(t, ROTC[i]); t = bc[0]; }
+        for (int jj = 0; jj < 5; jj++) {
+            const int j = orc_keccak_standard ? 5 * jj : jj;          /* tinysha3.c:186-235: j = 0,1,2,3,4 */
+            for (int i = 0; i < 5; i++) bc[i] = st[j + i];
+            for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
+        }
+        st[0] ^= RC[r];
+    }
+}
+static void shake_init(shake_t *c, int bits) { memset(c, 0, sizeof *c); c->rate = 200 - 2 * (unsigned)bits / 8; }
+static void shake_absorb(shake_t *c, const uint8_t *in, size_t len)
+{
+    for (size_t i = 0; i < len; i++) {
+        c->s[c->pos >> 3] ^= (uint64_t)in[i] << (8 * (c->pos & 7));
+        if (++c->pos == c->rate) { keccakf(c->s); c->pos = 0; }
+    }
+}
+static void shake_final(shake_t *c)
+{
+    c->s[c->pos >> 3] ^= (uint64_t)0x1F << (8 * (c->pos & 7));
+    c->s[(c->rate - 1) >> 3] ^= (uint64_t)0x80 << (8 * ((c->rate - 1) & 7));
+    keccakf(c->s);
+    c->pos = 0;
+}
+static void shake_squeeze(shake_t *c, uint8_t *out, size_t len)
+{
+    for (size_t i = 0; i < len; i++) {
+        if (c->pos == c->rate) { keccakf(c->s); c->pos = 0; }
+        out[i] = (uint8_t)(c->s[c->pos >> 3] >> (8 * (c->pos & 7)));
+        c->pos++;
+    }
+}
+
+void orc_shake(int bits, const uint8_t *in, size_t inlen, uint8_t *out, size_t outlen)
+{
+    shake_t c; shake_init(&c, bits); shake_absorb(&c, in, inlen); shake_final(&c); shake_squeeze(&c, out, outlen);
+}
+
+/* ------------------------------------------------------------- bit packer ---- */
+/* src/utils/entropy/packer.c:299-351: an MSB-first bit stream (the 64-bit scratch word is stored big
+ * endian), values masked to `bits`; flush pads the last byte with zero bits. */
+typedef struct { uint8_t *buf; size_t bitpos; } bitw_t;
+static void bw_put(bitw_t *w, uint32_t v, int bits)
+{
+    for (int b = bits - 1; b >= 0; b--) {
+        if ((w->bitpos & 7) == 0) w->buf[w->bitpos >> 3] = 0;
+        w->buf[w->bitpos >> 3] |= (uint8_t)(((v >> b) & 1u) << (7 - (w->bitpos & 7)));
+        w->bitpos++;
+    }
+}
+typedef struct { const uint8_t *buf; size_t bitpos, bitlen; int err; } bitr_t;
+static uint32_t br_get(bitr_t *r, int bits)
+{
+    uint32_t v = 0;
+    for (int b = 0; b < bits; b++) {
+        if (r->bitpos >= r->bitlen) { r->err = 1; return 0; }
+        v = (v << 1) | ((r->buf[r->bitpos >> 3] >> (7 - (r->bitpos & 7))) & 1u);
+        r->bitpos++;
+    }
+    return v;
+}
+
+/* --------------------------------------------------------------- helpers ---- */
+
+/* module_lwe.c:89-104 decompose(t1,t0,t,d): t0 = t mod+- 2^d mapped to [0,q), t1 = (t - t0)/2^d */
+void orc_dil_decompose(int32_t *t1, int32_t *t0, const int32_t *t, size_t len, int d, int32_t q)
+{
+    const int32_t mask = (1 << d) - 1, sign = 1 << d, thresh = 1 << (d - 1);
+    for (size_t i = 0; i < len; i++) {
+        int32_t x = t[i] & mask;
+        x -= (x > thresh) * sign;
+        t1[i] = (t[i] - x) >> d;
+        t0[i] = (x >= 0) ? x : x + q;
+    }
+}
+
+/* module_lwe.h:52-66,110-136 round_alpha with alpha = 2*gamma_2, Barrett k = 30, m = floor(2^30/alpha)
+ * (dilithium.c:196-204, ntt.c:142-146) */
+static uint32_t round_alpha(uint32_t a, int32_t *a0, int32_t alpha, int32_t q)
+{
+    const int64_t m = (1 << 30) / alpha;
+    int64_t t = ((int64_t)a * m) >> 30, c = (int64_t)a - t * alpha;
+    if (alpha <= c) c -= alpha;
+    *a0 = (int32_t)c;
+    if (*a0 > (alpha >> 1)) *a0 -= alpha;
+    uint32_t a1 = a - (uint32_t)*a0;
+    if (a1 == (uint32_t)(q - 1)) { a1 = 0; *a0 -= 1; }
+    else {
+        int64_t t2 = ((int64_t)a1 * m) >> 30, c2 = (int64_t)a1 - t2 * alpha;
+        if (alpha <= c2) t2++;
+        a1 = (uint32_t)t2;
+    }
+    return a1;
+}
+
+/* dilithium.c:1185-1200 */
+static int check_norm_inf(const int32_t *v, size_t len, int32_t q, int32_t b)
+{
+    const int32_t lower_half = (q - 1) >> 1, upper_b = q - b;
+    int bad = 0;
+    for (size_t i = 0; i < len; i++) {
+        const int smaller = v[i] <= lower_half;
+        bad |= (smaller && (v[i] >= b)) || (!smaller && (v[i] <= upper_b));
+    }
+    return bad;
+}
+
+/* module_lwe.c:201-244 expand_mask */
+static void expand_mask(const uint8_t *K, const uint8_t *mu, uint16_t kappa, int32_t gamma1, int32_t q, size_t limit, int32_t *y)
+{
+    const uint8_t kb[2] = { (uint8_t)(kappa >> 8), (uint8_t)(kappa & 0xFF) };
+    const int32_t thresh = 2 * gamma1 - 2, add = q + gamma1 - 1;
+    shake_t x; shake_init(&x, 256);
+    shake_absorb(&x, mu, 48); shake_absorb(&x, K, 32); shake_absorb(&x, kb, 2); shake_final(&x);
+    size_t j = 0;
+    while (j < limit) {
+        uint8_t s[5];
+        shake_squeeze(&x, s, 5);
+        const uint32_t s0 = (((uint32_t)s[2] & 0xF) << 16) | ((uint32_t)s[1] << 8) | s[0];
+        const uint32_t s1 = ((uint32_t)s[4] << 12) | ((uint32_t)s[3] << 4) | ((uint32_t)s[2] >> 4);
+        y[j] = add - (int32_t)s0; j += ((s0 - (uint32_t)thresh) >> 31);
+        if (j == limit) break;
+        y[j] = add - (int32_t)s1; j += ((s1 - (uint32_t)thresh) >> 31);
+    }
+}
+
+/* dilithium.c:1011-1036 h_function_deterministic (SHAKE128 variant) + module_lwe.c:1115-1141 kyber_oracle_core */
+static void h_function(int32_t *c, const uint8_t *mu, const uint8_t *w1, size_t w1len, int n, int weight)
+{
+    const int nwb = (weight + 7) >> 3;
+    uint8_t signs[8 + 64 + 8];
+    shake_t x; shake_init(&x, 128);
+    shake_absorb(&x, mu, 48); shake_absorb(&x, w1, w1len); shake_final(&x);
+    shake_squeeze(&x, signs, (size_t)(nwb + weight));
+    for (int i = 0; i < n - weight; i++) c[i] = 0;
+    uint8_t mask = 1;
+    for (int i = n - weight, j = 0, kk = nwb; i < n; i++, kk++) {
+        size_t b = signs[kk];
+        while (b > (size_t)i) b >>= 1;
+        c[i] = c[b];
+        c[b] = (signs[j] & mask) ? -1 : 1;
+        mask = (uint8_t)(mask << 1);
+        if (mask == 0) { mask = 1; j++; }
+    }
+}
+
+/* module_lwe.c:588-667, NOT_TRANSPOSED, matrix given: w[i] = INTT(sum_j A[i][j] o NTT(y[j])), canonical */
+static void matvec(int32_t *w_out, const int32_t *A, const int32_t *y, int n, int k, int l, int32_t q, const int32_t *w, const int32_t *r)
+{
+    int32_t *yh = malloc(sizeof(int32_t) * (size_t)n * (l + 1)), *acc = yh + (size_t)l * n;
+    for (int j = 0; j < l; j++) { orc_fwd_ntt(yh + j * n, n, q, y + j * n, w); orc_normalize(yh + j * n, (size_t)n, q); }
+    for (int i = 0; i < k; i++) {
+        for (int e = 0; e < n; e++) {
+            int64_t s = 0;
+            for (int j = 0; j < l; j++) s += (int64_t)yh[j * n + e] * A[((size_t)i * l + j) * n + e] % q;
+            acc[e] = (int32_t)(s % q);
+        }
+        orc_inv_ntt(w_out + i * n, n, q, acc, w, r);
+    }
+    free(yh);
+}
+
+/* c * a mod (x^n+1, q) for c in {-1,0,1}^n: the value of sparse_mul_mod_ring / sparse_mul_mod_q_ring
+ * (dilithium.c:1314-1383) as an element of Z_q, canonical */
+static void sparse_mul(int32_t *out, const int32_t *a, const int32_t *c, int n, int32_t q)
+{
+    int64_t *t = calloc((size_t)2 * n, sizeof(int64_t));
+    for (int j = 0; j < n; j++) {
+        if (c[j] == 0) continue;
+        for (int e = 0; e < n; e++) t[j + e] += (c[j] < 0) ? -(int64_t)a[e] : (int64_t)a[e];
+    }
+    for (int j = 0; j < n; j++) { int64_t v = (t[j] - t[j + n]) % q; if (v < 0) v += q; out[j] = (int32_t)v; }
+    free(t);
+}
+
+/* dilithium.c:1258-1284 make_hint */
+static int make_hint(int32_t *h, const int32_t *r, const int32_t *z, size_t len, int32_t alpha, int32_t q)
+{
+    int sum = 0;
+    for (size_t i = 0; i < len; i++) {
+        int32_t add = r[i] + z[i], t;
+        add -= (add >= q) * q;
+        add += (add < 0) * q;
+        const uint32_t r1 = round_alpha((uint32_t)r[i], &t, alpha, q), r0 = round_alpha((uint32_t)add, &t, alpha, q);
+        h[i] = r1 != r0;
+        sum += h[i];
+    }
+    return sum;
+}
+
+typedef struct { int n, q, q_bits, k, l, d, weight, gamma1, gamma1_bits, gamma2, eta, z_bits, beta, omega, omega_bits, set; } dilp_t;
+
+/* ------------------------------------------------------------------ sign ---- */
+/* dilithium.c:1397-1958 (SC_SCHEME_SIG_DILITHIUM, USE_DETERMINISTIC_DILITHIUM, sparse multiplier build).
+ * par: the 16 ints of the fixture's *_params record.  Returns 0 and the packed signature. */
+int orc_dilithium_sign(const int32_t *par, const int32_t *s1, const int32_t *s2, const int32_t *t,
+                       const uint8_t *K, const uint8_t *tr, const int32_t *Ahat,
+                       const uint8_t *msg, size_t mlen, uint8_t *sig, size_t *siglen, int32_t *trials)
+{
+    dilp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, k = P.k, l = P.l, q = P.q, alpha = 2 * P.gamma2;
+    int32_t *w_t = malloc(sizeof(int32_t) * (size_t)n * 2), *r_t = w_t + n;
+    if (orc_make_tables(q, n, w_t, r_t)) { free(w_t); return 1; }
+    int32_t *buf = malloc(sizeof(int32_t) * (size_t)n * (7 * k + 3 * l + 2));
+    int32_t *t1 = buf, *t0 = t1 + k * n, *w = t0 + k * n, *h = w + k * n, *ct0 = h + k * n, *wcs2 = ct0 + k * n, *tmpk = wcs2 + k * n;
+    int32_t *y = tmpk + k * n, *z = y + l * n, *c = z + l * n;   /* + n spare */
+    uint8_t *w1b = malloc((size_t)k * n);
+    uint8_t mu[48];
+    orc_dil_decompose(t1, t0, t, (size_t)k * n, P.d, q);
+    { shake_t x; shake_init(&x, 256); shake_absorb(&x, tr, 48); shake_absorb(&x, msg, mlen); shake_final(&x); shake_squeeze(&x, mu, 48); }
+    uint16_t kappa = 0;
+    int ntr = 0, num_ones = 0;
+    for (;;) {
+        ntr++;
+        expand_mask(K, mu, kappa, P.gamma1, q, (size_t)l * n, y);
+        matvec(w, Ahat, y, n, k, l, q, w_t, r_t);
+        for (int i = 0; i < k * n; i++) { int32_t r1; w1b[i] = (uint8_t)round_alpha((uint32_t)w[i], &r1, alpha, q); }
+        h_function(c, mu, w1b, (size_t)k * n, n, P.weight);
+        /* z = y + c*s1, canonical; check 1 */
+        for (int i = 0; i < l; i++) sparse_mul(z + i * n, s1 + i * n, c, n, q);
+        for (int i = 0; i < l * n; i++) z[i] = (int32_t)(((int64_t)z[i] + y[i]) % q);
+        if (check_norm_inf(z, (size_t)l * n, q, P.gamma1 - P.beta)) { kappa++; continue; }
+        /* check 2: low bits of w - c*s2 */
+        for (int i = 0; i < k; i++) sparse_mul(tmpk + i * n, s2 + i * n, c, n, q);
+        for (int i = 0; i < k * n; i++) { int32_t v = w[i] - tmpk[i]; wcs2[i] = v < 0 ? v + q : v; }
+        for (int i = 0; i < k * n; i++) { int32_t r1; round_alpha((uint32_t)wcs2[i], &r1, alpha, q); ct0[i] = r1 < 0 ? q + r1 : r1; }
+        if (check_norm_inf(ct0, (size_t)k * n, q, P.gamma2 - P.beta)) { kappa++; continue; }
+        /* check 3: c*t0 */
+        for (int i = 0; i < k; i++) sparse_mul(ct0 + i * n, t0 + i * n, c, n, q);
+        if (check_norm_inf(ct0, (size_t)k * n, q, P.gamma2 - P.beta)) { kappa++; continue; }
+        /* hint (dilithium.c:1712-1725): r = w - cs2 + ct0, z = -ct0 (poly_32_mod_negate maps 0 -> q) */
+        for (int i = 0; i < k * n; i++) { wcs2[i] = (int32_t)(((int64_t)wcs2[i] + ct0[i]) % q); ct0[i] = q - ct0[i]; }
+        num_ones = make_hint(h, wcs2, ct0, (size_t)k * n, alpha, q);
+        if (num_ones > P.omega) { kappa++; continue; }
+        break;
+    }
+    orc_center(z, (size_t)l * n, q);
+    /* packing, dilithium.c:1903-1951 */
+    const int h_bits = 8 + ((k + 1) >> 1);
+    bitw_t bw = { sig, 0 };
+    for (int i = 0; i < l * n; i++) bw_put(&bw, (uint32_t)z[i], P.z_bits);
+    bw_put(&bw, (uint32_t)num_ones, P.omega_bits);
+    for (int i = 0, left = num_ones; left; i++) if (h[i]) { bw_put(&bw, (uint32_t)i, h_bits); left--; }
+    for (int i = 0; i < n; i++) bw_put(&bw, (uint32_t)c[i], 2);
+    *siglen = (bw.bitpos + 7) >> 3;
+    if (trials) *trials = ntr;
+    free(w1b); free(buf); free(w_t);
+    return 0;
+}
+
+/* module_lwe.c:140-180 collision_resistant_hash_t1: SHAKE256( pack(rho as 32x8 bits, t1 as k*n x bits) ) -> 48 B */
+void orc_dilithium_crh_t1(const uint8_t *rho, const int32_t *t1, size_t len, int bits, uint8_t *out48)
+{
+    uint8_t *m = calloc(32 + (len * (size_t)bits + 7) / 8 + 8, 1);
+    bitw_t bw = { m, 0 };
+    for (int i = 0; i < 32; i++) bw_put(&bw, rho[i], 8);
+    for (size_t i = 0; i < len; i++) bw_put(&bw, (uint32_t)t1[i], bits);
+    orc_shake(256, m, (bw.bitpos + 7) >> 3, out48, 48);
+    free(m);
+}
+
+/* ---------------------------------------------------------------- verify ---- */
+/* dilithium.c:2002-2240.  Returns 0 (SC_FUNC_SUCCESS) for a valid signature, 1 otherwise. */
+int orc_dilithium_verify(const int32_t *par, const int32_t *t1, const uint8_t *rho, const int32_t *Ahat,
+                         const uint8_t *msg, size_t mlen, const uint8_t *sig, size_t siglen)
+{
+    dilp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, k = P.k, l = P.l, q = P.q, alpha = 2 * P.gamma2;
+    int rc = 1;
+    int32_t *w_t = malloc(sizeof(int32_t) * (size_t)n * 2), *r_t = w_t + n;
+    if (orc_make_tables(q, n, w_t, r_t)) { free(w_t); return 1; }
+    int32_t *buf = calloc((size_t)n * (3 * k + l + 2), sizeof(int32_t));
+    int32_t *z = buf, *h = z + l * n, *w = h + k * n, *t0 = w + k * n, *c = t0 + k * n, *c2 = c + n;
+    uint8_t *w1b = malloc((size_t)k * n);
+    bitr_t br = { sig, 0, siglen * 8, 0 };
+    for (int i = 0; i < l * n; i++) {
+        uint32_t v = br_get(&br, P.z_bits);
+        int32_t sv = (int32_t)(v << (32 - P.z_bits)) >> (32 - P.z_bits);       /* signed raw coefficient */
+        z[i] = sv < 0 ? sv + q : sv;
+    }
+    const int h_bits = 8 + ((k + 1) >> 1);
+    uint32_t num_ones = br_get(&br, P.omega_bits);
+    for (uint32_t i = 0; i < num_ones && !br.err; i++) { uint32_t pos = br_get(&br, h_bits); if (pos < (uint32_t)(k * n)) h[pos] = 1; else br.err = 1; }
+    for (int i = 0; i < n; i++) { uint32_t v = br_get(&br, 2); c[i] = (v == 3) ? -1 : (int32_t)v; }
+    if (br.err) goto done;
+    uint8_t mu[48];
+    orc_dilithium_crh_t1(rho, t1, (size_t)k * n, P.q_bits - P.d, mu);
+    { shake_t x; shake_init(&x, 256); shake_absorb(&x, mu, 48); shake_absorb(&x, msg, mlen); shake_final(&x); shake_squeeze(&x, mu, 48); }
+    if (check_norm_inf(z, (size_t)l * n, q, P.gamma1 - P.beta)) goto done;
+    { int ones = 0; for (int i = 0; i < k * n; i++) ones += h[i]; if (ones > P.omega) goto done; }
+    matvec(w, Ahat, z, n, k, l, q, w_t, r_t);
+    for (int i = 0; i < k * n; i++) t0[i] = t1[i] << P.d;
+    for (int i = 0; i < k; i++) sparse_mul(t0 + i * n, t0 + i * n, c, n, q);
+    for (int i = 0; i < k * n; i++) { int32_t v = w[i] - t0[i]; t0[i] = v < 0 ? v + q : v; }
+    /* use_hint, dilithium.c:1286-1312 */
+    {
+        const int32_t m = (q - 1) / alpha, m_mask = m - 1;
+        for (int i = 0; i < k * n; i++) {
+            int32_t a0; int32_t a1 = (int32_t)round_alpha((uint32_t)t0[i], &a0, alpha, q);
+            if (h[i] == 1) { if (a0 > 0) a1++; else a1--; }
+            if (a1 < 0) a1 += m;
+            w1b[i] = (uint8_t)(a1 & m_mask);
+        }
+    }
+    h_function(c2, mu, w1b, (size_t)k * n, n, P.weight);
+    rc = memcmp(c, c2, sizeof(int32_t) * (size_t)n) ? 1 : 0;
+done:
+    free(w1b); free(buf); free(w_t);
+    return rc;
+}

@@ -15,7 +15,8 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        if not os.path.exists(path):
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_dilithium.c', 'sc_oracle.h')]
+        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
         L.orc_find_root.restype = C.c_int32
@@ -42,8 +43,66 @@ def lib():
         L.orc_batch_fwd_ntt.argtypes = [i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p]
         L.orc_batch_inv_ntt.argtypes = [i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p, i32p]
         L.orc_batch_polymul_ntt.argtypes = [i32p, i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p, i32p]
+        u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags='C_CONTIGUOUS')
+        L.orc_shake.argtypes = [C.c_int, u8p, C.c_size_t, u8p, C.c_size_t]
+        L.orc_dil_decompose.argtypes = [i32p, i32p, i32p, C.c_size_t, C.c_int, C.c_int32]
+        L.orc_dilithium_crh_t1.argtypes = [u8p, i32p, C.c_size_t, C.c_int, u8p]
+        L.orc_dilithium_sign.argtypes = [i32p, i32p, i32p, i32p, u8p, u8p, i32p, u8p, C.c_size_t, u8p,
+                                         C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+        L.orc_dilithium_verify.argtypes = [i32p, i32p, u8p, i32p, u8p, C.c_size_t, u8p, C.c_size_t]
         _LIB = L
     return _LIB
+
+
+class DilKey:
+    """one Dilithium key pair + expanded matrix, as the fixture (or a test) provides it"""
+
+    def __init__(self, par, s1, s2, t, rho, K, tr, t1, Ahat):
+        f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+        self.par = f(par, np.int32)
+        self.s1, self.s2, self.t, self.t1, self.Ahat = (f(x, np.int32) for x in (s1, s2, t, t1, Ahat))
+        self.rho, self.K, self.tr = (f(x, np.uint8) for x in (rho, K, tr))
+        self.n, self.q, self.k, self.l = int(par[0]), int(par[1]), int(par[3]), int(par[4])
+
+    @classmethod
+    def from_golden(cls, G, tag):
+        return cls(*(G[f'{tag}_{x}'] for x in ('params', 's1', 's2', 't', 'rho', 'K', 'tr', 't1', 'Ahat')))
+
+
+def _msgbuf(msg):
+    m = np.frombuffer(bytes(msg), dtype=np.uint8) if len(msg) else np.zeros(0, dtype=np.uint8)
+    return np.ascontiguousarray(np.concatenate([m, np.zeros(1, dtype=np.uint8)])), len(msg)
+
+
+def dilithium_sign(key, msg):
+    sig = np.zeros(8192, dtype=np.uint8)
+    sl, tr = C.c_size_t(0), C.c_int32(0)
+    m, ml = _msgbuf(msg)
+    rc = lib().orc_dilithium_sign(key.par, key.s1, key.s2, key.t, key.K, key.tr, key.Ahat, m, ml, sig, C.byref(sl), C.byref(tr))
+    assert rc == 0
+    return bytes(sig[:sl.value]), tr.value
+
+
+def dilithium_verify(key, msg, sig):
+    m, ml = _msgbuf(msg)
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    return lib().orc_dilithium_verify(key.par, key.t1, key.rho, key.Ahat, m, ml, s, s.size)
+
+
+def shake(bits, data, outlen, standard=False):
+    """standard=True: FIPS 202; False: the reference's permutation (see sc_oracle_dilithium.c)"""
+    C.c_int.in_dll(lib(), 'orc_keccak_standard').value = 1 if standard else 0
+    try:
+        return _shake(bits, data, outlen)
+    finally:
+        C.c_int.in_dll(lib(), 'orc_keccak_standard').value = 0
+
+
+def _shake(bits, data, outlen):
+    m, ml = _msgbuf(data)
+    out = np.zeros(outlen, dtype=np.uint8)
+    lib().orc_shake(bits, m, ml, out, outlen)
+    return bytes(out)
 
 
 def tables(q, n):
