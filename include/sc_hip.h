@@ -126,6 +126,50 @@ int  sc_hip_cdt_table(const sc_hip_cdt_t *cdt, uint64_t *h_cdf);
  * (the reference's prng_64 outputs) supplied by the caller: out[i] = sample(x[i]) + centre. */
 int sc_hip_cdt_sample(sc_hip_cdt_t *cdt, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
 
+/* ---- Dilithium: batched sign / verify under one key --------------------------------------- */
+
+/* the fields of dilithium_set_t the engine needs (src/schemes/sig/dilithium/dilithium_params.h:60-93,
+ * values dilithium_params.c:22-113; "Dilithium-III" = set 3: k=6, l=5) */
+typedef struct sc_hip_dilithium_params {
+    int32_t n, q, q_bits, k, l, d, weight_of_c, gamma_1, gamma_1_bits, gamma_2, eta, z_bits, beta, omega, omega_bits, set;
+} sc_hip_dilithium_params_t;
+typedef struct sc_hip_dilithium sc_hip_dilithium_t;
+
+/* replaces: dilithium_create (dilithium.c:79) for the arithmetic side */
+int  sc_hip_dilithium_create(sc_hip_ctx_t *ctx, const sc_hip_dilithium_params_t *params, sc_hip_dilithium_t **h);
+void sc_hip_dilithium_destroy(sc_hip_dilithium_t *h);
+/* key material exactly as the reference holds it in sc->privkey->key / sc->pubkey->key (dilithium.c:810-824):
+ * s1 [l][n], s2 [k][n], t [k][n] (SINT32), K[32], tr[48]; t1 [k][n], rho[32].  Ahat = the matrix
+ * create_rand_product_32_csprng draws from rho ([k][l][n], NTT domain, row-major; module_lwe.c:519-547,641-660):
+ * the host's reference-compatible DRBG expands it once per key and hands it over. */
+int  sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *h, const int32_t *s1, const int32_t *s2, const int32_t *t,
+                                  const uint8_t *K, const uint8_t *tr, const int32_t *Ahat);
+int  sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *h, const int32_t *t1, const uint8_t *rho, const int32_t *Ahat);
+size_t sc_hip_dilithium_sig_max(const sc_hip_dilithium_t *h);      /* bytes a signature can take */
+
+/* replaces: safecrypto_sign -> dilithium_sign (src/safecrypto.c:1108, dilithium.c:1397-1958) for `batch`
+ * messages.  d_msgs [batch][msg_stride] bytes; d_mlens uint32[batch] or NULL (then every message is fixed_len
+ * bytes); d_sigs [batch][sig_stride], sig_stride >= sc_hip_dilithium_sig_max(); d_siglens uint32[batch];
+ * d_trials (optional) uint32[batch] = attempts taken.  Signatures are byte-identical to the reference's
+ * (deterministic signing).  Synchronous with respect to `stream` on return (the rejection loop reads back
+ * one counter per round). */
+int sc_hip_dilithium_sign(sc_hip_dilithium_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                          uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
+/* replaces: safecrypto_verify -> dilithium_verify (dilithium.c:2002-2240).  d_verdicts[i] = 0 (SC_FUNC_SUCCESS)
+ * for a valid signature, 1 otherwise.  Asynchronous on `stream`. */
+int sc_hip_dilithium_verify(sc_hip_dilithium_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                            uint32_t fixed_len, const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens,
+                            uint32_t *d_verdicts, void *stream);
+int sc_hip_dilithium_sign_host(sc_hip_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+                               uint32_t fixed_len, uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials);
+int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+                                 uint32_t fixed_len, const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+
+/* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
+ * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
+ * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */
+int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *h_in, size_t len, uint8_t *h_out, size_t outlen);
+
 /* ---- host-buffer convenience (H2D, kernel, D2H; synchronous) ---------------------------- */
 int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
 int sc_hip_ntt_inv_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);

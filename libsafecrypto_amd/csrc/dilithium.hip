@@ -1,0 +1,842 @@
+// dilithium.hip - batched Dilithium sign / verify on MI355X behind the C ABI of include/sc_hip.h.
+//
+// Replaces, for a batch of messages under one key, dilithium_sign / dilithium_verify
+// (src/schemes/sig/dilithium/dilithium.c:1397-1958, 2002-2240; build switches of dilithium_params.h:35-56:
+// DILITHIUM_USE_CSPRNG_SAM, DILITHIUM_USE_H_FUNC_XOF (SHAKE128), DILITHIUM_USE_SPARSE_MULTIPLIER,
+// USE_DETERMINISTIC_DILITHIUM) and the helpers they call in src/utils/arith/module_lwe.c
+// (expand_mask :201-244, create_rand_product_32_csprng :588-667 with the matrix already expanded,
+// high/low_order_bits :1075-1113, kyber_oracle_core :1115-1141, round_alpha module_lwe.h:110-136,
+// make_hint / use_hint / check_norm_inf dilithium.c:1185-1312).
+//
+// Everything of an attempt runs on the device: SHAKE (the reference's permutation, keccak_dev.h), mask
+// expansion, A*y through the NTT machinery of ntt_core.h, rounding, challenge, the three c*key products
+// (as NTT-domain products - equal mod q to the reference's sparse schoolbook multiplier), norm checks,
+// hints and the MSB-first bit packing of the signature (src/utils/entropy/packer.c:299-351).  The
+// rejection loop is batched: each round works on the list of still-active messages, accepted ones are
+// packed and drop out, rejected ones get kappa+1 (deterministic signing makes every attempt a pure
+// function of (key, message, kappa), so results equal the reference's byte for byte).
+#include "engine_internal.h"
+#include "keccak_dev.h"
+#include "ntt_core.h"
+
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+constexpr int L8 = 8, N = 256, LP = 16, PW = 4;
+constexpr int HT = 64;                    // threads per workgroup of the one-thread-per-message kernels
+
+struct DilP {                             // dilithium_set_t (dilithium_params.h:60-93), the fields used here
+    int32_t n, q, q_bits, k, l, d, weight, gamma1, gamma1_bits, gamma2, eta, z_bits, beta, omega, omega_bits, set;
+};
+
+__host__ __device__ constexpr int brv4c(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// round_alpha, module_lwe.h:52-66,110-136, alpha = 2*gamma_2, Barrett m = floor(2^30/alpha), k = 30
+__device__ __forceinline__ uint32_t round_alpha(uint32_t a, int32_t &a0, int32_t alpha, int32_t am, int32_t q)
+{
+    int64_t t = ((int64_t)a * am) >> 30, c = (int64_t)a - t * alpha;
+    if (alpha <= c) c -= alpha;
+    a0 = (int32_t)c;
+    if (a0 > (alpha >> 1)) a0 -= alpha;
+    uint32_t a1 = a - (uint32_t)a0;
+    if (a1 == (uint32_t)(q - 1)) { a1 = 0; a0 -= 1; }
+    else {
+        int64_t t2 = ((int64_t)a1 * am) >> 30, c2 = (int64_t)a1 - t2 * alpha;
+        if (alpha <= c2) t2++;
+        a1 = (uint32_t)t2;
+    }
+    return a1;
+}
+
+// check_norm_inf on one canonical value, dilithium.c:1185-1200
+__device__ __forceinline__ bool norm_bad(uint32_t v, uint32_t q, uint32_t b)
+{
+    const uint32_t lower_half = (q - 1) >> 1;
+    return (v <= lower_half) ? (v >= b) : (v <= q - b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT-shaped kernels (n = 256: 16 lanes per polynomial, 4 polynomials per wave, 32-bit Shoup path)
+// ------------------------------------------------------------------------------------------------
+
+enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CZ = 2, DOP_CS2 = 3, DOP_CT0 = 4, DOP_CT1 = 5, DOP_KEYPREP = 6 };
+
+struct DilNtt {
+    const uint32_t *zf, *zfp, *zi, *zip;
+    ModK k;
+    uint32_t c0, c0p, c1, c1p;            // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs): Montgomery-form keys need no 2^32 fix
+    uint32_t r2, r2p;                     // 2^32 mod q (Shoup pair)
+    const uint32_t *active;               // item ids of this round (NULL: identity)
+    uint32_t njobs;                       // active items * per
+    int per;                              // polynomials per item handled by this launch
+    int l, kk;
+    int32_t alpha, am, gamma1_beta, gamma2_beta, d;
+    const int32_t *in;                    // DOP_FWD_INT / KEYPREP: natural-order input [item][per][n]
+    uint32_t *out_int;                    // DOP_FWD_INT / KEYPREP: internal-order canonical (KEYPREP: Montgomery form)
+    const uint32_t *yh;                   // [item][l][n] internal
+    const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
+    const uint32_t *ch;                   // [item][n] internal (NTT of c)
+    const int32_t *y;                     // [item][l][n] natural (mask)
+    int32_t *w;                           // [item][k][n] natural canonical
+    uint8_t *w1;                          // [item][k*n]
+    int32_t *z;                           // [item][l][n]
+    int32_t *r;                           // [item][k][n]  (w - c s2)
+    uint8_t *h;                           // [item][k*n]
+    uint32_t *flags, *ones;               // per item
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pw = lane / LP, lp = lane % LP;
+    uint32_t *lds_poly = lds + wid * 1024 + pw * N;
+    const int blp = brv4c(lp);
+    const ModK k = a.k;
+    TwSet<L8> tw;
+    if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) tw.load(a.zf, a.zfp, lp); else tw.load(a.zi, a.zip, lp);
+
+    const uint32_t groups = (a.njobs + PW - 1) / PW;
+    for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
+        const uint32_t job = g * PW + pw;
+        const bool valid = job < a.njobs;
+        const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
+        const uint32_t item = a.active ? a.active[aidx] : aidx;
+        uint32_t x[16];
+
+        if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) {
+            const int32_t *src = a.in + ((size_t)item * a.per + sub) * N + lp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(src[r * LP], k) : 0u;
+            fwd_core<L8, MODE_U32, true>(x, tw, lds_poly, lp, k);
+            uint32_t *dst = a.out_int + ((size_t)item * a.per + sub) * N + lp * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t v = csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+                if (OP == DOP_KEYPREP) v = csub(Mod<MODE_U32>::mulc(v, a.r2, a.r2p, k), k.q);
+                x[r] = v;
+            }
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) reinterpret_cast<uint4 *>(dst)[c] = make_uint4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+            }
+            continue;
+        }
+
+        // NTT-domain product(s) in internal order (16 contiguous words per lane)
+        if (OP == DOP_MATVEC) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = 0;
+            for (int j = 0; j < a.l; j++) {
+                const uint4 *py = reinterpret_cast<const uint4 *>(a.yh + ((size_t)item * a.l + j) * N + lp * 16);
+                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + ((size_t)sub * a.l + j) * N + lp * 16);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint4 vy = valid ? py[c] : make_uint4(0, 0, 0, 0), va = pa[c];
+                    x[4 * c + 0] = csub(x[4 * c + 0] + montmul(vy.x, va.x, k), k.q2);
+                    x[4 * c + 1] = csub(x[4 * c + 1] + montmul(vy.y, va.y, k), k.q2);
+                    x[4 * c + 2] = csub(x[4 * c + 2] + montmul(vy.z, va.z, k), k.q2);
+                    x[4 * c + 3] = csub(x[4 * c + 3] + montmul(vy.w, va.w, k), k.q2);
+                }
+            }
+        } else {
+            const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)item * N + lp * 16);
+            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)sub * N + lp * 16);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint4 vc = valid ? pc[c] : make_uint4(0, 0, 0, 0), vk = pk[c];
+                x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
+                x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
+            }
+        }
+        inv_core<L8, MODE_U32>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
+        if (!valid) continue;
+
+        const size_t pk_off = ((size_t)item * a.kk + sub) * N + lp;     // [item][k][n] arrays
+        const size_t pl_off = ((size_t)item * a.l + sub) * N + lp;      // [item][l][n] arrays
+        if (OP == DOP_MATVEC) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int32_t a0;
+                a.w[pk_off + r * LP] = (int32_t)x[r];
+                a.w1[pk_off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
+            }
+        } else if (OP == DOP_CZ) {            // z = y + c s1, normalize, ||z||inf < gamma1 - beta
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t yy = reduce_i32(a.y[pl_off + r * LP], k);
+                const uint32_t zz = csub(csub(x[r] + yy, k.q2), k.q);
+                a.z[pl_off + r * LP] = (int32_t)zz;
+                bad |= norm_bad(zz, k.q, (uint32_t)a.gamma1_beta);
+            }
+            if (bad) atomicOr(&a.flags[item], 1u);
+        } else if (OP == DOP_CS2) {           // r = w - c s2 ; ||LowBits(r)||inf < gamma2 - beta
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t rr = csub(ww + k.q - x[r], k.q);
+                a.r[pk_off + r * LP] = (int32_t)rr;
+                int32_t a0;
+                round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + (int32_t)k.q) : (uint32_t)a0;       // low_order_bits
+                bad |= norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
+            }
+            if (bad) atomicOr(&a.flags[item], 2u);
+        } else if (OP == DOP_CT0) {           // ct0 ; ||ct0||inf < gamma2 - beta ; hint = [HighBits(r + ct0) != HighBits(r)]
+            bool bad = false;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                bad |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta);
+                const uint32_t rr = (uint32_t)a.r[pk_off + r * LP];
+                const uint32_t s = csub(rr + x[r], k.q);        // wcs2 + ct0 (dilithium.c:1714-1715)
+                int32_t a0;
+                // make_hint (dilithium.c:1258-1284): r = s, z = q - ct0, (r + z) mod q == rr
+                const uint32_t hi_s = round_alpha(s, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t hi_r = round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t hb = hi_s != hi_r;
+                a.h[pk_off + r * LP] = (uint8_t)hb;
+                cnt += hb;
+            }
+            if (bad) atomicOr(&a.flags[item], 4u);
+            if (cnt) atomicAdd(&a.ones[item], cnt);
+        } else if (OP == DOP_CT1) {           // verify: w' = A z - c t1 2^d ; w1 = UseHint(h, w')   (dilithium.c:1286-1312)
+            const int32_t m = ((int32_t)k.q - 1) / a.alpha, m_mask = m - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t t = csub(ww + k.q - x[r], k.q);
+                int32_t a0;
+                int32_t a1 = (int32_t)round_alpha(t, a0, a.alpha, a.am, (int32_t)k.q);
+                if (a.h[pk_off + r * LP] == 1) { if (a0 > 0) a1++; else a1--; }
+                if (a1 < 0) a1 += m;
+                a.w1[pk_off + r * LP] = (uint8_t)(a1 & m_mask);
+            }
+        }
+    }
+}
+
+// natural-order NTT-domain array -> internal order, Montgomery form (for the expanded matrix A)
+__global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoly * N) return;
+    const size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
+    const uint32_t nat = __builtin_bitreverse32(j) >> 24;
+    uint32_t v = reduce_i32(in[p * N + nat], k);
+    out[i] = csub(Mod<MODE_U32>::mulc(v, r2, r2p, k), k.q);
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-thread-per-message kernels (hashing, challenge, decisions, packing)
+// ------------------------------------------------------------------------------------------------
+
+// mu = SHAKE256(tr || M)  (collision_resistant_hash_message, module_lwe.c:182-198)
+__global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uint8_t *msgs, size_t stride, const uint32_t *lens,
+                                                    uint32_t fixed_len, uint8_t *mu, uint32_t count)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t item = blockIdx.x * HT + threadIdx.x;
+    const bool valid = item < count;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
+    if (!valid) return;
+    sp.absorb(tr, 48);
+    const uint32_t len = lens ? lens[item] : fixed_len;
+    sp.absorb(msgs + (size_t)item * stride, len);
+    sp.finalize();
+    for (int i = 0; i < 48; i++) mu[(size_t)item * 48 + i] = sp.squeeze_byte();
+}
+
+// tr = SHAKE256( pack(rho: 32 x 8 bits, t1: k*n x bits) )  (collision_resistant_hash_t1, module_lwe.c:140-180)
+__global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, const int32_t *t1, uint32_t len, int bits, uint8_t *out48)
+{
+    __shared__ uint64_t st[25 * HT];
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < 32; i++) sp.absorb_byte(rho[i]);
+    uint32_t acc = 0; int nb = 0;
+    for (uint32_t i = 0; i < len; i++) {
+        acc = (acc << bits) | ((uint32_t)t1[i] & ((1u << bits) - 1)); nb += bits;
+        while (nb >= 8) { sp.absorb_byte((uint8_t)(acc >> (nb - 8))); nb -= 8; }
+        acc &= (1u << nb) - 1;
+    }
+    if (nb) sp.absorb_byte((uint8_t)(acc << (8 - nb)));
+    sp.finalize();
+    for (int i = 0; i < 48; i++) out48[i] = sp.squeeze_byte();
+}
+
+// y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244)
+__global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *active, uint32_t nact, const uint8_t *K, const uint8_t *mu,
+                                                        const uint32_t *kappa, int32_t *y, int limit, int32_t gamma1, int32_t q)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    sp.absorb(mu + (size_t)item * 48, 48);
+    sp.absorb(K, 32);
+    const uint32_t kp = kappa[item];
+    sp.absorb_byte((uint8_t)(kp >> 8)); sp.absorb_byte((uint8_t)(kp & 0xFF));
+    sp.finalize();
+    const uint32_t thresh = (uint32_t)(2 * gamma1 - 2);
+    const int32_t add = q + gamma1 - 1;
+    int32_t *yy = y + (size_t)item * limit;
+    int j = 0;
+    while (j < limit) {
+        uint32_t s0 = sp.squeeze_byte(); s0 |= (uint32_t)sp.squeeze_byte() << 8;
+        const uint32_t b2 = sp.squeeze_byte();
+        s0 |= (b2 & 0xF) << 16;
+        uint32_t s1 = b2 >> 4; s1 |= (uint32_t)sp.squeeze_byte() << 4; s1 |= (uint32_t)sp.squeeze_byte() << 12;
+        if (s0 < thresh) yy[j++] = add - (int32_t)s0;
+        if (j == limit) break;
+        if (s1 < thresh) yy[j++] = add - (int32_t)s1;
+    }
+}
+
+// c = H(mu, w1): SHAKE128 -> 8 sign bytes + 60 position bytes -> kyber_oracle_core
+// (dilithium.c:1011-1036, module_lwe.c:1115-1141).  mode 0: write c; mode 1 (verify): compare with the signature's c.
+__global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *active, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
+                                                           int w1len, int weight, int32_t *c, int mode, uint32_t *verdict)
+{
+    __shared__ uint64_t st[25 * HT];
+    __shared__ int8_t cc[HT * N];
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    const bool valid = aidx < nact;
+    const uint32_t item = valid ? (active ? active[aidx] : aidx) : 0;
+    int8_t *mine = cc + threadIdx.x;          // per-lane private column: coefficient i at mine[i*HT] (no systematic bank conflict)
+    if (valid) {
+        sp.absorb(mu + (size_t)item * 48, 48);
+        sp.absorb(w1 + (size_t)item * w1len, (size_t)w1len);
+        sp.finalize();
+        const int nwb = (weight + 7) >> 3;
+        uint8_t signs[16];
+        for (int i = 0; i < nwb; i++) signs[i] = sp.squeeze_byte();
+        for (int i = 0; i < N; i++) mine[i * HT] = 0;
+        uint32_t sj = 0, mask = 1;
+        for (int i = N - weight; i < N; i++) {
+            uint32_t b = sp.squeeze_byte();
+            while (b > (uint32_t)i) b >>= 1;
+            mine[i * HT] = mine[b * HT];
+            uint8_t sgn = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) if ((uint32_t)t == sj) sgn = signs[t];
+            mine[b * HT] = (sgn & mask) ? -1 : 1;
+            mask <<= 1;
+            if (mask == 256) { mask = 1; sj++; }
+        }
+        if (mode == 0) {
+            for (int i = 0; i < N; i++) c[(size_t)item * N + i] = mine[i * HT];
+        } else {
+            uint32_t neq = 0;
+            for (int i = 0; i < N; i++) neq |= (uint32_t)(c[(size_t)item * N + i] != mine[i * HT]);
+            if (neq) verdict[item] = 1;
+        }
+    }
+}
+
+// MSB-first bit writer into a byte buffer whose bytes are zero or already hold earlier bits
+struct BitW {
+    uint8_t *p; uint32_t bitpos;
+    __device__ __forceinline__ void put(uint32_t v, int bits)
+    {
+        for (int b = bits - 1; b >= 0; b--) {
+            const uint32_t byte = bitpos >> 3, sh = 7 - (bitpos & 7);
+            if (sh == 7) p[byte] = 0;
+            p[byte] |= (uint8_t)(((v >> b) & 1u) << sh);
+            bitpos++;
+        }
+    }
+};
+
+// accept / reject (dilithium.c:1655-1725) + the signature tail: num_ones, hint positions, c (2 bits each)
+// (dilithium.c:1926-1945).  Rejected messages get kappa+1 and go to the next round's list.
+__global__ __launch_bounds__(HT) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
+                                                        uint32_t *status, uint32_t round, const uint8_t *h, const int32_t *c,
+                                                        uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
+                                                        uint32_t *next_active, uint32_t *next_count, DilP P)
+{
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t fl = flags[item], no = ones[item];
+    flags[item] = 0; ones[item] = 0;
+    if (fl != 0 || no > (uint32_t)P.omega) {
+        kappa[item] += 1;
+        next_active[atomicAdd(next_count, 1u)] = item;
+        return;
+    }
+    status[item] = round + 1;                                       // accepted in this round
+    trials[item] = kappa[item] + 1;
+    const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
+    BitW bw{ sigs + (size_t)item * sig_stride, (uint32_t)(P.l * P.n * P.z_bits) };
+    bw.put(no, P.omega_bits);
+    const uint8_t *hh = h + (size_t)item * kn;
+    for (int i = 0; i < kn; i++) if (hh[i]) bw.put((uint32_t)i, h_bits);
+    const int32_t *ci = c + (size_t)item * P.n;
+    for (int i = 0; i < P.n; i++) bw.put((uint32_t)ci[i], 2);
+    siglens[item] = (bw.bitpos + 7) >> 3;
+}
+
+// z part of the signature of the messages accepted this round: centre (ntt32_center) and raw z_bits per coefficient,
+// two coefficients per thread (2*z_bits = 40 bits = 5 bytes)  (dilithium.c:1803,1914-1917)
+__global__ void dil_packz_kernel(const uint32_t *active, uint32_t nact, const uint32_t *status, uint32_t round, const int32_t *z,
+                                 uint8_t *sigs, size_t sig_stride, int ln, int z_bits, int32_t q)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pairs = ln / 2;
+    const size_t aidx = t / pairs; const int pr = (int)(t % pairs);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : (uint32_t)aidx;
+    if (status[item] != round + 1) return;
+    const int32_t half = (q - 1) >> 1;
+    int32_t v0 = z[(size_t)item * ln + 2 * pr], v1 = z[(size_t)item * ln + 2 * pr + 1];
+    if (v0 > half) v0 -= q;
+    if (v1 > half) v1 -= q;
+    const uint64_t m = (1ull << z_bits) - 1;
+    const uint64_t bits = (((uint64_t)(uint32_t)v0 & m) << z_bits) | ((uint64_t)(uint32_t)v1 & m);     // 2*z_bits bits, MSB first
+    const int nbytes = 2 * z_bits / 8;
+    uint8_t *dst = sigs + (size_t)item * sig_stride + (size_t)pr * nbytes;
+    for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * (nbytes - 1 - b)));
+}
+
+// verify: unpack z (-> canonical), hints, c; structural checks (dilithium.c:2065-2123)
+__global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits, int32_t q,
+                                   uint32_t gamma1_beta, uint32_t *verdict)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int pairs = ln / 2;
+    const size_t item = t / pairs; const int pr = (int)(t % pairs);
+    if (item >= count) return;
+    const int nbytes = 2 * z_bits / 8;
+    const uint8_t *src = sigs + item * sig_stride + (size_t)pr * nbytes;
+    uint64_t bits = 0;
+    for (int b = 0; b < nbytes; b++) bits = (bits << 8) | src[b];
+    const uint64_t m = (1ull << z_bits) - 1;
+    int32_t v[2] = { (int32_t)((bits >> z_bits) & m), (int32_t)(bits & m) };
+    bool bad = false;
+    for (int e = 0; e < 2; e++) {
+        int32_t sv = (int32_t)((uint32_t)v[e] << (32 - z_bits)) >> (32 - z_bits);     // signed raw coefficient
+        const uint32_t zz = (uint32_t)(sv < 0 ? sv + q : sv);                          // normalize_32
+        z[item * ln + 2 * pr + e] = (int32_t)zz;
+        bad |= norm_bad(zz, (uint32_t)q, gamma1_beta);
+    }
+    if (bad) verdict[item] = 1;
+}
+
+__global__ __launch_bounds__(HT) void dil_unpack_tail_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
+                                                             uint8_t *h, int32_t *c, uint32_t *verdict, DilP P)
+{
+    const uint32_t item = blockIdx.x * HT + threadIdx.x;
+    if (item >= count) return;
+    const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
+    const uint8_t *s = sigs + (size_t)item * sig_stride;
+    const uint32_t total = siglens[item] * 8;
+    uint32_t pos = (uint32_t)(P.l * P.n * P.z_bits);
+    bool err = total < pos;
+    auto get = [&](int bits) -> uint32_t {
+        uint32_t v = 0;
+        for (int b = 0; b < bits; b++) {
+            if (pos >= total) { err = true; return 0; }
+            v = (v << 1) | ((s[pos >> 3] >> (7 - (pos & 7))) & 1u);
+            pos++;
+        }
+        return v;
+    };
+    uint8_t *hh = h + (size_t)item * kn;
+    for (int i = 0; i < kn; i++) hh[i] = 0;
+    uint32_t no = err ? 0 : get(P.omega_bits), cnt = 0;
+    for (uint32_t i = 0; i < no && !err; i++) {
+        const uint32_t p = get(h_bits);
+        if (p >= (uint32_t)kn) { err = true; break; }          // the reference writes h[p] unchecked; out-of-range = invalid
+        cnt += (hh[p] == 0);
+        hh[p] = 1;
+    }
+    int32_t *ci = c + (size_t)item * P.n;
+    for (int i = 0; i < P.n; i++) { const uint32_t v = err ? 0 : get(2); ci[i] = (v == 3) ? -1 : (int32_t)v; }
+    if (err || cnt > (uint32_t)P.omega) verdict[item] = 1;     // check_hint_ones (dilithium.c:2119-2123)
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+struct sc_hip_dilithium {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    DilP P;
+    bool have_priv, have_pub;
+    uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
+    uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
+    // workspace
+    size_t cap;
+    uint8_t *mu, *w1, *h;
+    uint32_t *kappa, *flags, *ones, *status, *trials, *act[2], *cnt, *verdict, *siglen_dev;
+    int32_t *y, *w, *c, *z, *r;
+    uint32_t *yh, *ch;
+    uint8_t *msg_dev, *sig_dev;
+    size_t msg_cap, sig_cap;
+};
+
+static void free_ws(sc_hip_dilithium *d)
+{
+    void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->flags, d->ones, d->status, d->trials, d->act[0], d->act[1], d->cnt, d->verdict,
+                     d->siglen_dev, d->y, d->w, d->c, d->z, d->r, d->yh, d->ch };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    d->mu = d->w1 = d->h = nullptr; d->kappa = d->flags = d->ones = d->status = d->trials = d->act[0] = d->act[1] = d->cnt = d->verdict = d->siglen_dev = nullptr;
+    d->y = d->w = d->c = d->z = d->r = nullptr; d->yh = d->ch = nullptr;
+    d->cap = 0;
+}
+
+static int ensure_ws(sc_hip_dilithium *d, size_t batch)
+{
+    if (batch <= d->cap) return SC_HIP_SUCCESS;
+    free_ws(d);
+    const size_t n = d->P.n, k = d->P.k, l = d->P.l;
+#define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
+    WS(d->mu, batch * 48); WS(d->w1, batch * k * n); WS(d->h, batch * k * n);
+    WS(d->kappa, batch * 4); WS(d->flags, batch * 4); WS(d->ones, batch * 4); WS(d->status, batch * 4); WS(d->trials, batch * 4);
+    WS(d->act[0], batch * 4); WS(d->act[1], batch * 4); WS(d->cnt, 64); WS(d->verdict, batch * 4); WS(d->siglen_dev, batch * 4);
+    WS(d->y, batch * l * n * 4); WS(d->w, batch * k * n * 4); WS(d->c, batch * n * 4); WS(d->z, batch * l * n * 4); WS(d->r, batch * k * n * 4);
+    WS(d->yh, batch * l * n * 4); WS(d->ch, batch * n * 4);
+#undef WS
+    d->cap = batch;
+    return SC_HIP_SUCCESS;
+}
+
+static DilNtt base_args(sc_hip_dilithium *d)
+{
+    sc_hip_plan *p = d->plan;
+    DilNtt a;
+    memset(&a, 0, sizeof a);
+    const int n = p->n;
+    a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.k = p->k[1];
+    a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
+    a.r2 = p->r2; a.r2p = p->r2p;
+    a.l = d->P.l; a.kk = d->P.k;
+    a.alpha = 2 * d->P.gamma2; a.am = (1 << 30) / a.alpha;
+    a.gamma1_beta = d->P.gamma1 - d->P.beta; a.gamma2_beta = d->P.gamma2 - d->P.beta; a.d = d->P.d;
+    a.yh = d->yh; a.ch = d->ch; a.y = d->y; a.w = d->w; a.w1 = d->w1; a.z = d->z; a.r = d->r; a.h = d->h; a.flags = d->flags; a.ones = d->ones;
+    return a;
+}
+
+template <int OP>
+static int launch_dil(sc_hip_dilithium *d, DilNtt a, uint32_t nitems, int per, hipStream_t s)
+{
+    a.per = per; a.njobs = nitems * (uint32_t)per;
+    if (a.njobs == 0) return SC_HIP_SUCCESS;
+    size_t blocks = ((size_t)a.njobs + 15) / 16;
+    const size_t cap = (size_t)d->ctx->cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((dil_ntt_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_dilithium_create(sc_hip_ctx_t *ctx, const sc_hip_dilithium_params_t *params, sc_hip_dilithium_t **out)
+{
+    if (!ctx || !params || !out) return fail("dilithium_create: null argument");
+    DilP P;
+    static_assert(sizeof(DilP) == sizeof(sc_hip_dilithium_params_t), "parameter struct layout");
+    memcpy(&P, params, sizeof P);
+    if (P.n != 256) return fail("dilithium_create: n must be 256");
+    if (P.k < 1 || P.k > 8 || P.l < 1 || P.l > 8) return fail("dilithium_create: k, l out of range");
+    if (P.weight < 1 || P.weight > 64 || (P.l * P.n * P.z_bits) % 8 || (2 * P.z_bits) % 8 || P.z_bits > 24) return fail("dilithium_create: unsupported packing parameters");
+    if (((P.q - 1) / (2 * P.gamma2)) & (((P.q - 1) / (2 * P.gamma2)) - 1)) return fail("dilithium_create: (q-1)/(2 gamma_2) must be a power of two");
+    sc_hip_plan *plan = nullptr;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    sc_hip_dilithium *d = new sc_hip_dilithium;
+    memset(d, 0, sizeof *d);
+    d->ctx = ctx; d->plan = plan; d->P = P;
+    *out = d;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
+{
+    if (!d) return;
+    free_ws(d);
+    void *ptrs[] = { d->d_A, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    sc_hip_plan_destroy(d->plan);
+    delete d;
+}
+
+// upload natural-order coefficient-domain polynomials and leave their NTT (internal order, Montgomery form) in *dst
+static int key_ntt(sc_hip_dilithium *d, const int32_t *h_polys, size_t npoly, uint32_t **dst)
+{
+    const size_t bytes = npoly * N * 4;
+    int32_t *tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, bytes));
+    if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
+    HIPCHK(hipMemcpy(tmp, h_polys, bytes, hipMemcpyHostToDevice));
+    DilNtt a = base_args(d);
+    a.in = tmp; a.out_int = *dst; a.active = nullptr;
+    int rc = launch_dil<DOP_KEYPREP>(d, a, (uint32_t)npoly, 1, nullptr);
+    if (rc == SC_HIP_SUCCESS && hipDeviceSynchronize() != hipSuccess) rc = fail("dilithium key load: kernel failed");
+    (void)hipFree(tmp);
+    return rc;
+}
+
+static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
+{
+    const size_t np = (size_t)d->P.k * d->P.l, bytes = np * N * 4;
+    int32_t *tmp = nullptr;
+    HIPCHK(hipMalloc((void **)&tmp, bytes));
+    if (!d->d_A) HIPCHK(hipMalloc((void **)&d->d_A, bytes));
+    HIPCHK(hipMemcpy(tmp, h_Ahat, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, nullptr, tmp, d->d_A, np, d->plan->k[1], d->plan->r2, d->plan->r2p);
+    int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t *s1, const int32_t *s2, const int32_t *t,
+                                            const uint8_t *K, const uint8_t *tr, const int32_t *Ahat)
+{
+    if (!d || !s1 || !s2 || !t || !K || !tr || !Ahat) return fail("dilithium_set_privkey: null argument");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    const int k = d->P.k, l = d->P.l, q = d->P.q, dd = d->P.d;
+    // decompose(t) -> t0 in [0,q) (module_lwe.c:89-104); only t0 is needed by the signer
+    std::vector<int32_t> t0((size_t)k * N);
+    const int32_t mask = (1 << dd) - 1, sign = 1 << dd, thresh = 1 << (dd - 1);
+    for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = (x >= 0) ? x : x + q; }
+    if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
+    if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
+    if (!d->d_K) HIPCHK(hipMalloc((void **)&d->d_K, 32));
+    if (!d->d_tr_priv) HIPCHK(hipMalloc((void **)&d->d_tr_priv, 48));
+    HIPCHK(hipMemcpy(d->d_K, K, 32, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->d_tr_priv, tr, 48, hipMemcpyHostToDevice));
+    d->have_priv = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *d, const int32_t *t1, const uint8_t *rho, const int32_t *Ahat)
+{
+    if (!d || !t1 || !rho || !Ahat) return fail("dilithium_set_pubkey: null argument");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    const int k = d->P.k;
+    std::vector<int32_t> t1s((size_t)k * N);
+    for (size_t i = 0; i < t1s.size(); i++) t1s[i] = t1[i] << d->P.d;              // t1 . 2^d (dilithium.c:2163-2166)
+    if (key_ntt(d, t1s.data(), (size_t)k, &d->d_t1s)) return SC_HIP_FAILURE;
+    if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
+    if (!d->d_rho) HIPCHK(hipMalloc((void **)&d->d_rho, 32));
+    if (!d->d_tr_pub) HIPCHK(hipMalloc((void **)&d->d_tr_pub, 48));
+    HIPCHK(hipMemcpy(d->d_rho, rho, 32, hipMemcpyHostToDevice));
+    int32_t *dt1 = nullptr;
+    HIPCHK(hipMalloc((void **)&dt1, t1s.size() * 4));
+    HIPCHK(hipMemcpy(dt1, t1, t1s.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3(1), dim3(HT), 0, nullptr, d->d_rho, dt1, (uint32_t)t1s.size(), d->P.q_bits - d->P.d, d->d_tr_pub);
+    int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium_set_pubkey: CRH kernel failed");
+    (void)hipFree(dt1);
+    d->have_pub = (rc == SC_HIP_SUCCESS);
+    return rc;
+}
+
+extern "C" size_t sc_hip_dilithium_sig_max(const sc_hip_dilithium_t *d)
+{
+    if (!d) return 0;
+    const DilP &P = d->P;
+    const size_t bits = (size_t)P.l * P.n * P.z_bits + P.omega_bits + (size_t)P.omega * (8 + ((P.k + 1) >> 1)) + 2 * (size_t)P.n;
+    return (bits + 7) / 8;
+}
+
+// d_msgs: [batch][msg_stride] bytes, d_mlens: per-message lengths (NULL: every message is fixed_len bytes);
+// d_sigs: [batch][sig_stride] bytes (sig_stride >= sc_hip_dilithium_sig_max), d_siglens / d_trials: uint32 [batch]
+extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                                     uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream)
+{
+    if (!d) return fail("dilithium_sign: null handle");
+    if (!d->have_priv) return fail("dilithium_sign: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 16) return fail("dilithium_sign: batch too large");
+    if (!d_msgs && (d_mlens || fixed_len)) return fail("dilithium_sign: null message buffer");
+    if (!d_sigs || !d_siglens) return fail("dilithium_sign: null output buffer");
+    if (sig_stride < sc_hip_dilithium_sig_max(d)) return fail("dilithium_sign: sig_stride smaller than sc_hip_dilithium_sig_max()");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    if (ensure_ws(d, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const DilP &P = d->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k, l = P.l;
+    HIPCHK(hipMemsetAsync(d->kappa, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(d->flags, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(d->ones, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(d->status, 0, batch * 4, s));
+    uint32_t *trials = d_trials ? d_trials : d->trials;
+    hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d->d_tr_priv, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
+    HIPCHK(hipGetLastError());
+
+    uint32_t nact = B;
+    const uint32_t *active = nullptr;                 // round 0: identity
+    for (uint32_t round = 0; nact > 0; round++) {
+        if (round > 1000) return fail("dilithium_sign: rejection loop did not terminate");
+        uint32_t *next = d->act[round & 1];
+        HIPCHK(hipMemsetAsync(d->cnt, 0, 4, s));
+        const unsigned hb = (nact + HT - 1) / HT;
+        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->d_K, d->mu, d->kappa, d->y, l * P.n, P.gamma1, P.q);
+        HIPCHK(hipGetLastError());
+        DilNtt a = base_args(d);
+        a.active = active;
+        a.in = d->y; a.out_int = d->yh;
+        if (launch_dil<DOP_FWD_INT>(d, a, nact, l, s)) return SC_HIP_FAILURE;
+        a.key = d->d_A;
+        if (launch_dil<DOP_MATVEC>(d, a, nact, k, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
+        HIPCHK(hipGetLastError());
+        a.in = d->c; a.out_int = d->ch;
+        if (launch_dil<DOP_FWD_INT>(d, a, nact, 1, s)) return SC_HIP_FAILURE;
+        a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nact, l, s)) return SC_HIP_FAILURE;
+        a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nact, k, s)) return SC_HIP_FAILURE;
+        a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nact, k, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(dil_finish_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->flags, d->ones, d->kappa, d->status, round, d->h, d->c,
+                           d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
+        HIPCHK(hipGetLastError());
+        const size_t zthreads = (size_t)nact * (size_t)(l * P.n / 2);
+        hipLaunchKernelGGL(dil_packz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, active, nact, d->status, round, d->z,
+                           d_sigs, sig_stride, l * P.n, P.z_bits, P.q);
+        HIPCHK(hipGetLastError());
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, d->cnt, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nact = cnt;
+        active = next;
+    }
+    return SC_HIP_SUCCESS;
+}
+
+// d_verdicts[i] = 0 (SC_FUNC_SUCCESS) when signature i verifies, 1 otherwise (test/functional/func_alg_dilithium.c:225)
+extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                                       uint32_t fixed_len, const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens,
+                                       uint32_t *d_verdicts, void *stream)
+{
+    if (!d) return fail("dilithium_verify: null handle");
+    if (!d->have_pub) return fail("dilithium_verify: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 16) return fail("dilithium_verify: batch too large");
+    if (!d_sigs || !d_siglens || !d_verdicts) return fail("dilithium_verify: null buffer");
+    if (!d_msgs && (d_mlens || fixed_len)) return fail("dilithium_verify: null message buffer");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    if (ensure_ws(d, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const DilP &P = d->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k, l = P.l;
+    if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return fail("dilithium_verify: sig_stride too small");
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    const unsigned hb = (B + HT - 1) / HT;
+    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
+    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
+                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3(hb), dim3(HT), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
+    hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
+    HIPCHK(hipGetLastError());
+    DilNtt a = base_args(d);
+    a.active = nullptr;
+    a.in = d->z; a.out_int = d->yh;
+    if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
+    a.key = d->d_A;
+    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    a.in = d->c; a.out_int = d->ch;
+    if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
+    a.key = d->d_t1s;
+    if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, d->c, 1, d_verdicts);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// ---- host-buffer convenience (the shape safecrypto_sign / safecrypto_verify have, for a batch) ----
+
+static int stage(void **dev, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return SC_HIP_SUCCESS;
+    if (*dev) (void)hipFree(*dev);
+    *dev = nullptr; *cap = 0;
+    HIPCHK(hipMalloc(dev, bytes));
+    *cap = bytes;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_dilithium_sign_host(sc_hip_dilithium_t *d, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+                                          uint32_t fixed_len, uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials)
+{
+    if (!d) return fail("dilithium_sign_host: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_sigs || !h_siglens) return fail("dilithium_sign_host: null output");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    const size_t moff = (batch * msg_stride + 7) & ~(size_t)7, sbytes = batch * sig_stride, soff = (sbytes + 7) & ~(size_t)7;
+    if (stage((void **)&d->msg_dev, &d->msg_cap, moff + batch * 4 + 8) || stage((void **)&d->sig_dev, &d->sig_cap, soff + batch * 8 + 8)) return SC_HIP_FAILURE;
+    uint32_t *dl = (uint32_t *)(d->msg_dev + moff), *dsl = (uint32_t *)(d->sig_dev + soff), *dtr = dsl + batch;
+    if (h_msgs && batch * msg_stride) HIPCHK(hipMemcpy(d->msg_dev, h_msgs, batch * msg_stride, hipMemcpyHostToDevice));
+    if (h_mlens) HIPCHK(hipMemcpy(dl, h_mlens, batch * 4, hipMemcpyHostToDevice));
+    int rc = sc_hip_dilithium_sign(d, batch, d->msg_dev, msg_stride, h_mlens ? dl : nullptr, fixed_len, d->sig_dev, sig_stride, dsl, dtr, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(h_sigs, d->sig_dev, sbytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_siglens, dsl, batch * 4, hipMemcpyDeviceToHost));
+    if (h_trials) HIPCHK(hipMemcpy(h_trials, dtr, batch * 4, hipMemcpyDeviceToHost));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *d, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+                                            uint32_t fixed_len, const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts)
+{
+    if (!d) return fail("dilithium_verify_host: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_sigs || !h_siglens || !h_verdicts) return fail("dilithium_verify_host: null buffer");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    const size_t moff = (batch * msg_stride + 7) & ~(size_t)7, sbytes = batch * sig_stride, soff = (sbytes + 7) & ~(size_t)7;
+    if (stage((void **)&d->msg_dev, &d->msg_cap, moff + batch * 4 + 8) || stage((void **)&d->sig_dev, &d->sig_cap, soff + batch * 8 + 8)) return SC_HIP_FAILURE;
+    uint32_t *dl = (uint32_t *)(d->msg_dev + moff), *dsl = (uint32_t *)(d->sig_dev + soff), *dv = dsl + batch;
+    if (h_msgs && batch * msg_stride) HIPCHK(hipMemcpy(d->msg_dev, h_msgs, batch * msg_stride, hipMemcpyHostToDevice));
+    if (h_mlens) HIPCHK(hipMemcpy(dl, h_mlens, batch * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->sig_dev, h_sigs, sbytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dsl, h_siglens, batch * 4, hipMemcpyHostToDevice));
+    int rc = sc_hip_dilithium_verify(d, batch, d->msg_dev, msg_stride, h_mlens ? dl : nullptr, fixed_len, d->sig_dev, sig_stride, dsl, dv, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(hipMemcpy(h_verdicts, dv, batch * 4, hipMemcpyDeviceToHost));
+    return SC_HIP_SUCCESS;
+}
+
+// the reference's hash as a test hook: SHAKE128/256 framing around its permutation (standard != 0: FIPS 202 chi)
+namespace {
+template <bool STD>
+__global__ __launch_bounds__(HT) void shake_test_kernel(int rate, const uint8_t *in, uint32_t len, uint8_t *out, uint32_t outlen)
+{
+    __shared__ uint64_t st[25 * HT];
+    Sponge<HT, STD> sp; sp.init(st, threadIdx.x, rate);
+    if (threadIdx.x != 0) return;
+    sp.absorb(in, len);
+    sp.finalize();
+    for (uint32_t i = 0; i < outlen; i++) out[i] = sp.squeeze_byte();
+}
+}  // namespace
+
+extern "C" int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *h_in, size_t len, uint8_t *h_out, size_t outlen)
+{
+    if (!ctx || !h_out || (len && !h_in)) return fail("shake_host: null argument");
+    if (bits != 128 && bits != 256) return fail("shake_host: bits must be 128 or 256");
+    HIPCHK(hipSetDevice(ctx->device));
+    uint8_t *din = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc((void **)&din, len + 8));
+    HIPCHK(hipMalloc((void **)&dout, outlen + 8));
+    if (len) HIPCHK(hipMemcpy(din, h_in, len, hipMemcpyHostToDevice));
+    const int rate = 200 - 2 * bits / 8;
+    if (standard) hipLaunchKernelGGL(shake_test_kernel<true>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
+    else hipLaunchKernelGGL(shake_test_kernel<false>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
+    int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("shake_host: kernel failed");
+    if (rc == SC_HIP_SUCCESS) HIPCHK(hipMemcpy(h_out, dout, outlen, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    return rc;
+}

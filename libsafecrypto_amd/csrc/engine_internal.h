@@ -1,0 +1,46 @@
+// engine_internal.h - host-side structures shared by the translation units of libsc_hip.so.
+#pragma once
+#include "../../include/sc_hip.h"
+#include "modarith.h"
+
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace sc {
+int fail(const std::string &m);      // records the message for sc_hip_last_error, returns SC_HIP_FAILURE
+}
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return sc::fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct sc_hip_ctx {
+    int device;
+    int cus;
+};
+
+struct sc_hip_plan {
+    sc_hip_ctx *ctx;
+    int32_t q;
+    int n, L;
+    int32_t g;
+    int mode;                     // MODE_U24 / MODE_U32 in use
+    bool lazy24, lazy32;
+    std::vector<int32_t> w, r;    // reference-format tables (host)
+    uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
+    sc::ModK k[2];
+    uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
+    uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
+    uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
+};
+
+struct sc_hip_cdt {
+    sc_hip_ctx *ctx;
+    float tail, sigma;
+    int size;
+    std::vector<uint64_t> cdf;
+    uint64_t *d_cdf;
+};

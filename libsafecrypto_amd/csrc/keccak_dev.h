@@ -1,0 +1,119 @@
+// keccak_dev.h - device sponge compatible with the reference's xof layer
+// (src/utils/crypto/xof.c over src/utils/crypto/sha3/tinysha3.c).
+//
+// Framing is SHAKE128/256 (rate 168/136, pad 0x1F ... 0x80, incremental absorb / squeeze,
+// tinysha3.c:308-330,382-404).  The permutation is the one the reference actually runs: the library
+// is always built with -DSHA3_UNROLLED (src/utils/crypto/Makefile.am:94) and that variant's chi step
+// (tinysha3.c:186-235) updates the overlapping windows st[j..j+4], j = 0,1,2,3,4, one after the other,
+// instead of the five rows at 0,5,10,15,20 - so it is NOT Keccak-f[1600].  Signatures, challenge
+// polynomials and masks of the reference are only reproducible with the same permutation, hence it is
+// reproduced here bit for bit (template flag STD selects the FIPS 202 chi for self-tests).
+//
+// One hash instance per lane.  The 25-word state lives in LDS, word w of lane t at st[w*NT + t]
+// (conflict-free 8-byte accesses); absorb/squeeze address it dynamically, the permutation pulls it into
+// registers with static indices.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sc {
+
+__device__ __forceinline__ uint64_t rol64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+template <bool STD>
+__device__ __forceinline__ void keccak_permute_regs(uint64_t (&s)[25])
+{
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL };
+    constexpr int ROTC[24] = { 1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44 };
+    constexpr int PILN[24] = { 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1 };
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        uint64_t bc[5], t;
+#pragma unroll
+        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            t = bc[(i + 4) % 5] ^ rol64(bc[(i + 1) % 5], 1);
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+        }
+        t = s[1];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            const uint64_t nx = s[PILN[i]];
+            s[PILN[i]] = rol64(t, ROTC[i]);
+            t = nx;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++) {
+            const int j = STD ? 5 * jj : jj;                    // tinysha3.c:186-235 uses 0,1,2,3,4
+            uint64_t c0 = s[j], c1 = s[j + 1], c2 = s[j + 2], c3 = s[j + 3], c4 = s[j + 4];
+            s[j] ^= (~c1) & c2; s[j + 1] ^= (~c2) & c3; s[j + 2] ^= (~c3) & c4; s[j + 3] ^= (~c4) & c0; s[j + 4] ^= (~c0) & c1;
+        }
+        s[0] ^= RC[r];
+    }
+}
+
+// NT = threads per workgroup (LDS stride of the state words)
+template <int NT, bool STD = false>
+struct Sponge {
+    uint64_t *st;          // LDS: &state[threadIdx.x]
+    int rate, pos;
+
+    __device__ __forceinline__ void init(uint64_t *lds_state, int tid, int rate_bytes)
+    {
+        st = lds_state + tid; rate = rate_bytes; pos = 0;
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT] = 0;
+    }
+    __device__ __forceinline__ void permute()
+    {
+        uint64_t s[25];
+#pragma unroll
+        for (int w = 0; w < 25; w++) s[w] = st[w * NT];
+        keccak_permute_regs<STD>(s);
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT] = s[w];
+    }
+    __device__ __forceinline__ void absorb_byte(uint8_t b)
+    {
+        st[(pos >> 3) * NT] ^= (uint64_t)b << (8 * (pos & 7));
+        if (++pos == rate) { permute(); pos = 0; }
+    }
+    // pos must be a multiple of 8 (rates are multiples of 8)
+    __device__ __forceinline__ void absorb_u64(uint64_t v)
+    {
+        st[(pos >> 3) * NT] ^= v;
+        pos += 8;
+        if (pos == rate) { permute(); pos = 0; }
+    }
+    __device__ __forceinline__ void absorb(const uint8_t *p, size_t len)
+    {
+        size_t i = 0;
+        while (i < len && (pos & 7)) absorb_byte(p[i++]);
+        if ((((uintptr_t)(p + i)) & 7) == 0)
+            for (; i + 8 <= len; i += 8) absorb_u64(*reinterpret_cast<const uint64_t *>(p + i));
+        for (; i < len; i++) absorb_byte(p[i]);
+    }
+    __device__ __forceinline__ void finalize()
+    {
+        st[(pos >> 3) * NT] ^= (uint64_t)0x1F << (8 * (pos & 7));
+        st[((rate - 1) >> 3) * NT] ^= (uint64_t)0x80 << (8 * ((rate - 1) & 7));
+        permute();
+        pos = 0;
+    }
+    __device__ __forceinline__ uint8_t squeeze_byte()
+    {
+        if (pos == rate) { permute(); pos = 0; }
+        const uint8_t b = (uint8_t)(st[(pos >> 3) * NT] >> (8 * (pos & 7)));
+        pos++;
+        return b;
+    }
+};
+
+}  // namespace sc

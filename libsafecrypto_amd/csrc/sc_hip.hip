@@ -221,42 +221,12 @@ __global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ c
 // host side
 // ------------------------------------------------------------------------------------------
 
+#include "engine_internal.h"
+
 static thread_local std::string g_err;
 static int g_cus = 256;
-static int fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
-        if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-struct sc_hip_ctx {
-    int device;
-    int cus;
-};
-
-struct sc_hip_plan {
-    sc_hip_ctx *ctx;
-    int32_t q;
-    int n, L;
-    int32_t g;
-    int mode;                     // MODE_U24 / MODE_U32 in use
-    bool lazy24, lazy32;
-    std::vector<int32_t> w, r;    // reference-format tables (host)
-    uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
-    ModK k[2];
-    uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
-    uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
-    uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
-};
-
-struct sc_hip_cdt {
-    sc_hip_ctx *ctx;
-    float tail, sigma;
-    int size;
-    std::vector<uint64_t> cdf;
-    uint64_t *d_cdf;
-};
+int sc::fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
+using sc::fail;
 
 static uint64_t mulmod(uint64_t a, uint64_t b, uint64_t q) { return (uint64_t)(((unsigned __int128)a * b) % q); }
 static uint64_t powmod(uint64_t a, uint64_t e, uint64_t q)

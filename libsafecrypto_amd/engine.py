@@ -17,6 +17,9 @@ SYMBOLS = [
     'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
     'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
     'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
+    'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
+    'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
+    'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -90,6 +93,18 @@ def load_library(path=LIB_PATH):
     L.sc_hip_ntt_inv_host.argtypes = [vp, sz, vp, vp]
     L.sc_hip_polymul_ntt_host.argtypes = [vp, sz, vp, vp, vp]
     L.sc_hip_cdt_sample_host.argtypes = [vp, sz, vp, i32, vp]
+    L.sc_hip_dilithium_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_dilithium_destroy.argtypes = [vp]
+    L.sc_hip_dilithium_destroy.restype = None
+    L.sc_hip_dilithium_set_privkey.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.sc_hip_dilithium_set_pubkey.argtypes = [vp, vp, vp, vp]
+    L.sc_hip_dilithium_sig_max.argtypes = [vp]
+    L.sc_hip_dilithium_sig_max.restype = sz
+    L.sc_hip_dilithium_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_dilithium_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
+    L.sc_hip_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
+    L.sc_hip_shake_host.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, sz]
     L.sc_hip_time_op.argtypes = [vp, C.c_int, sz, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
     _LIB = L
     return L
@@ -130,6 +145,17 @@ class Engine:
 
     def plan(self, q, n):
         return NttPlan(self, q, n)
+
+    def dilithium(self, params):
+        return Dilithium(self, params)
+
+    def shake(self, bits, data, outlen, standard=False):
+        """the reference's XOF (or FIPS 202 with standard=True) evaluated on the device"""
+        import numpy as np
+        d = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(outlen, dtype=np.uint8)
+        _chk(self.L, self.L.sc_hip_shake_host(self.h, bits, 1 if standard else 0, _ptr(d), len(data), _ptr(out), outlen), 'shake_host')
+        return bytes(out)
 
     def sampler(self, tail=None, sigma=None, table=None):
         return CdtSampler(self, tail, sigma, table)
@@ -292,3 +318,91 @@ class CdtSampler:
         out = np.empty(u.size, dtype=np.int32)
         _chk(self.L, self.L.sc_hip_cdt_sample_host(self.h, u.size, _ptr(u), centre, _ptr(out)), 'cdt_sample_host')
         return out
+
+
+class Dilithium:
+    """Batched Dilithium sign / verify under one key (dilithium_sign / dilithium_verify counterpart).
+    params: the 16 ints {n,q,q_bits,k,l,d,weight_of_c,gamma_1,gamma_1_bits,gamma_2,eta,z_bits,beta,omega,omega_bits,set}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 16
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_dilithium_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_dilithium_create')
+        self.h = h
+        self.sig_max = self.L.sc_hip_dilithium_sig_max(h)
+        self.sig_stride = (self.sig_max + 15) & ~15
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_dilithium_destroy(self.h)
+            self.h = None
+
+    @staticmethod
+    def _a(x, dt):
+        import numpy as np
+        return np.ascontiguousarray(np.asarray(x), dtype=dt)
+
+    def set_privkey(self, s1, s2, t, K, tr, Ahat):
+        import numpy as np
+        a = [self._a(s1, np.int32), self._a(s2, np.int32), self._a(t, np.int32), self._a(K, np.uint8), self._a(tr, np.uint8), self._a(Ahat, np.int32)]
+        _chk(self.L, self.L.sc_hip_dilithium_set_privkey(self.h, *[_ptr(x) for x in a]), 'dilithium_set_privkey')
+
+    def set_pubkey(self, t1, rho, Ahat):
+        import numpy as np
+        a = [self._a(t1, np.int32), self._a(rho, np.uint8), self._a(Ahat, np.int32)]
+        _chk(self.L, self.L.sc_hip_dilithium_set_pubkey(self.h, *[_ptr(x) for x in a]), 'dilithium_set_pubkey')
+
+    # device-buffer entry points: torch uint8 [batch][stride] messages / signatures, int32 lengths
+    def sign(self, msgs, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=msgs.device)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
+        trials = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_dilithium_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(),
+                                                  fixed_len, _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _stream()), 'dilithium_sign')
+        return sigs, siglens, trials
+
+    def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_dilithium_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(),
+                                                    fixed_len, _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'dilithium_verify')
+        return verdicts
+
+    # host-buffer entry points: python bytes in / out (the shape safecrypto_sign / safecrypto_verify have)
+    def _pack_msgs(self, msgs):
+        import numpy as np
+        stride = max(8, (max((len(m) for m in msgs), default=0) + 7) & ~7)
+        buf = np.zeros((len(msgs), stride), dtype=np.uint8)
+        for i, m in enumerate(msgs):
+            buf[i, :len(m)] = np.frombuffer(bytes(m), dtype=np.uint8)
+        lens = np.array([len(m) for m in msgs], dtype=np.uint32)
+        return buf, stride, lens
+
+    def sign_host(self, msgs):
+        import numpy as np
+        buf, stride, lens = self._pack_msgs(msgs)
+        n = len(msgs)
+        sigs = np.zeros((n, self.sig_stride), dtype=np.uint8)
+        sl = np.zeros(n, dtype=np.uint32)
+        tr = np.zeros(n, dtype=np.uint32)
+        _chk(self.L, self.L.sc_hip_dilithium_sign_host(self.h, n, _ptr(buf), stride, _ptr(lens), 0, _ptr(sigs), self.sig_stride, _ptr(sl), _ptr(tr)), 'dilithium_sign_host')
+        return [bytes(sigs[i, :sl[i]]) for i in range(n)], [int(x) for x in tr]
+
+    def verify_host(self, msgs, sigs):
+        import numpy as np
+        buf, stride, lens = self._pack_msgs(msgs)
+        n = len(msgs)
+        sstride = max(self.sig_stride, (max(len(s) for s in sigs) + 15) & ~15)
+        sb = np.zeros((n, sstride), dtype=np.uint8)
+        for i, s_ in enumerate(sigs):
+            sb[i, :len(s_)] = np.frombuffer(bytes(s_), dtype=np.uint8)
+        sl = np.array([len(s_) for s_ in sigs], dtype=np.uint32)
+        v = np.ones(n, dtype=np.uint32)
+        _chk(self.L, self.L.sc_hip_dilithium_verify_host(self.h, n, _ptr(buf), stride, _ptr(lens), 0, _ptr(sb), sstride, _ptr(sl), _ptr(v)), 'dilithium_verify_host')
+        return [int(x) for x in v]

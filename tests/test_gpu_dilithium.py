@@ -1,0 +1,125 @@
+"""GPU parity for batched Dilithium sign / verify (C ABI: sc_hip_dilithium_*), against signatures the
+reference produced (tests/golden/dilithium_ref.txt) and against the pinned oracle on seeded messages.
+Byte-exact: deterministic signing makes a signature a pure function of (key, message)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from libsafecrypto_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('dilithium_ref.txt')
+
+
+def golden_msgs(G, tag):
+    out, i = [], 0
+    while f'{tag}_msg{i}' in G:
+        out.append((bytes(G[f'{tag}_msg{i}'].astype(np.uint8)), bytes(G[f'{tag}_sig{i}'].astype(np.uint8)), int(G[f'{tag}_trials'][i])))
+        i += 1
+    return out
+
+
+def make(eng, key):
+    d = eng.dilithium(key.par)
+    d.set_privkey(key.s1, key.s2, key.t, key.K, key.tr, key.Ahat)
+    d.set_pubkey(key.t1, key.rho, key.Ahat)
+    return d
+
+
+def test_device_xof_is_the_references_permutation(eng):
+    for n in (0, 1, 47, 48, 135, 136, 137, 168, 169, 1000, 1584):
+        data = bytes((i * 13 + 5) & 0xFF for i in range(n))
+        assert eng.shake(128, data, 200, standard=True) == hashlib.shake_128(data).digest(200)
+        assert eng.shake(256, data, 200, standard=True) == hashlib.shake_256(data).digest(200)
+        assert eng.shake(128, data, 200) == O.shake(128, data, 200)
+        assert eng.shake(256, data, 200) == O.shake(256, data, 200)
+    msg = bytes.fromhex('01080f161d242b323940474e555c636a71787f868d949ba2a9b0b7bec5ccd3da02890866240a817ede7ec72775abce636fd6')
+    assert eng.shake(256, msg, 48).hex() == ('ba1789c93f9d0640b0f5e41a6f59c1310f643847fc10afeb65ee638e67610bf9'
+                                             'dba6b1551cd5eac169615555dbf22a67')     # captured from the reference build
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_sign_reproduces_reference_signatures(eng, G, tag):
+    key = O.DilKey.from_golden(G, tag)
+    d = make(eng, key)
+    gm = golden_msgs(G, tag)
+    sigs, trials = d.sign_host([m for m, _, _ in gm])
+    for i, (m, sig, tr) in enumerate(gm):
+        assert sigs[i] == sig, (tag, i)
+        assert trials[i] == tr
+    d.close()
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_verify_matches_reference_verdicts(eng, G, tag):
+    key = O.DilKey.from_golden(G, tag)
+    d = make(eng, key)
+    gm = golden_msgs(G, tag)
+    msgs, sigs, exp = [], [], []
+    for i, (m, sig, _) in enumerate(gm):
+        bad = bytearray(sig); bad[len(bad) // 2] ^= 0x10
+        msgs += [m, m, m + b'x', m]
+        sigs += [sig, bytes(bad), sig, sig[:len(sig) - 40]]
+        exp += [int(G[f'{tag}_verify'][2 * i]), int(G[f'{tag}_verify'][2 * i + 1]), 1, 1]
+    assert exp[0] == 0 and exp[1] == 1
+    assert d.verify_host(msgs, sigs) == exp
+    d.close()
+
+
+def test_batch_vs_oracle_seeded(eng, G):
+    """257 seeded messages of ragged lengths (0..200 bytes) under the Dilithium-III fixture key: every
+    signature equals the oracle's, attempts included; then everything verifies on the device and the oracle"""
+    key = O.DilKey.from_golden(G, 'dil3')
+    d = make(eng, key)
+    rng = np.random.default_rng(2024)
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 201)), dtype=np.uint8)) for _ in range(257)]
+    sigs, trials = d.sign_host(msgs)
+    for i in range(0, 257, 8):                       # the oracle is slow: check a strided sample exactly
+        es, et = O.dilithium_sign(key, msgs[i])
+        assert sigs[i] == es and trials[i] == et, i
+    assert max(trials) > 3                            # the rejection loop really ran several rounds
+    assert d.verify_host(msgs, sigs) == [0] * 257
+    for i in range(0, 257, 32):
+        assert O.dilithium_verify(key, msgs[i], sigs[i]) == 0
+    d.close()
+
+
+def test_device_buffers_full_config3_properties(eng, G):
+    """BASELINE config 3 shape: 16384 messages of 64 bytes, one key, device-resident buffers.
+    Size-independent properties: sign -> verify accepts all; flipping one bit of a message or a
+    signature rejects exactly those; a sample equals the oracle byte for byte."""
+    import torch
+    key = O.DilKey.from_golden(G, 'dil3')
+    d = make(eng, key)
+    B = 16384
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    sigs, siglens, trials = d.sign(msgs, fixed_len=64)
+    torch.cuda.synchronize()
+    assert int(siglens.min()) > 3200 and int(siglens.max()) <= d.sig_max
+    assert 2.5 < float(trials.float().mean()) < 4.5          # ~3.4 trials per signature
+    v = d.verify(msgs, sigs, siglens, fixed_len=64)
+    assert int(v.sum()) == 0
+    bad_m = msgs.clone(); bad_m[::7, 5] ^= 1
+    assert torch.equal(d.verify(bad_m, sigs, siglens, fixed_len=64).bool().cpu(), (torch.arange(B) % 7 == 0))
+    bad_s = sigs.clone(); bad_s[::5, 1000] ^= 0x40
+    assert torch.equal(d.verify(msgs, bad_s, siglens, fixed_len=64).bool().cpu(), (torch.arange(B) % 5 == 0))
+    mh, sh, lh = msgs.cpu().numpy(), sigs.cpu().numpy(), siglens.cpu().numpy()
+    for i in (0, 4097, 16383):
+        es, _ = O.dilithium_sign(key, bytes(mh[i]))
+        assert bytes(sh[i, :lh[i]]) == es
+    d.close()
