@@ -12,9 +12,11 @@
 // expansion, A*y through the NTT machinery of ntt_core.h, rounding, challenge, the three c*key products
 // (as NTT-domain products - equal mod q to the reference's sparse schoolbook multiplier), norm checks,
 // hints and the MSB-first bit packing of the signature (src/utils/entropy/packer.c:299-351).  The
-// rejection loop is batched: each round works on the list of still-active messages, accepted ones are
-// packed and drop out, rejected ones get kappa+1 (deterministic signing makes every attempt a pure
-// function of (key, message, kappa), so results equal the reference's byte for byte).
+// rejection loop is batched and speculative: deterministic signing makes an attempt a pure function of
+// (key, message, kappa), so each round evaluates S consecutive kappa values of every still-active message
+// side by side ("slots") and accepts the LOWEST successful kappa - exactly the attempt the reference's
+// sequential loop stops at, hence byte-identical signatures - while the round count (the latency of the
+// one-lane-per-hash SHAKE kernels) drops from ~30 to a handful; S grows as messages finish.
 #include "engine_internal.h"
 #include "keccak_dev.h"
 #include "ntt_core.h"
@@ -69,8 +71,7 @@ struct DilNtt {
     ModK k;
     uint32_t c0, c0p, c1, c1p;            // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs): Montgomery-form keys need no 2^32 fix
     uint32_t r2, r2p;                     // 2^32 mod q (Shoup pair)
-    const uint32_t *active;               // item ids of this round (NULL: identity)
-    uint32_t njobs;                       // active items * per
+    uint32_t njobs;                       // slots * per (every per-attempt array is indexed by slot)
     int per;                              // polynomials per item handled by this launch
     int l, kk;
     int32_t alpha, am, gamma1_beta, gamma2_beta, d;
@@ -95,7 +96,6 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pw = lane / LP, lp = lane % LP;
     uint32_t *lds_poly = lds + wid * 1024 + pw * N;
-    const int blp = brv4c(lp);
     const ModK k = a.k;
     TwSet<L8> tw;
     if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) tw.load(a.zf, a.zfp, lp); else tw.load(a.zi, a.zip, lp);
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
         const uint32_t job = g * PW + pw;
         const bool valid = job < a.njobs;
         const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
-        const uint32_t item = a.active ? a.active[aidx] : aidx;
+        const uint32_t item = aidx;           // slot index
         uint32_t x[16];
 
         if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) {
@@ -272,22 +272,21 @@ __global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, cons
 }
 
 // y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244)
-__global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *active, uint32_t nact, const uint8_t *K, const uint8_t *mu,
-                                                        const uint32_t *kappa, int32_t *y, int limit, int32_t gamma1, int32_t q)
+__global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *slot_item, const uint32_t *slot_kappa, uint32_t nslots, const uint8_t *K,
+                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q)
 {
     __shared__ uint64_t st[25 * HT];
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
-    if (aidx >= nact) return;
-    const uint32_t item = active ? active[aidx] : aidx;
-    sp.absorb(mu + (size_t)item * 48, 48);
+    if (aidx >= nslots) return;
+    sp.absorb(mu + (size_t)slot_item[aidx] * 48, 48);
     sp.absorb(K, 32);
-    const uint32_t kp = kappa[item];
+    const uint32_t kp = slot_kappa[aidx] & 0xFFFFu;            // UINT16 kappa (dilithium.c:1421)
     sp.absorb_byte((uint8_t)(kp >> 8)); sp.absorb_byte((uint8_t)(kp & 0xFF));
     sp.finalize();
     const uint32_t thresh = (uint32_t)(2 * gamma1 - 2);
     const int32_t add = q + gamma1 - 1;
-    int32_t *yy = y + (size_t)item * limit;
+    int32_t *yy = y + (size_t)aidx * limit;
     int j = 0;
     while (j < limit) {
         uint32_t s0 = sp.squeeze_byte(); s0 |= (uint32_t)sp.squeeze_byte() << 8;
@@ -302,7 +301,7 @@ __global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *active, 
 
 // c = H(mu, w1): SHAKE128 -> 8 sign bytes + 60 position bytes -> kyber_oracle_core
 // (dilithium.c:1011-1036, module_lwe.c:1115-1141).  mode 0: write c; mode 1 (verify): compare with the signature's c.
-__global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *active, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
+__global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *slot_item, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
                                                            int w1len, int weight, int32_t *c, int mode, uint32_t *verdict)
 {
     __shared__ uint64_t st[25 * HT];
@@ -310,10 +309,11 @@ __global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *activ
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
     const bool valid = aidx < nact;
-    const uint32_t item = valid ? (active ? active[aidx] : aidx) : 0;
+    const uint32_t item = valid ? aidx : 0;                                    // slot: index of w1 / c
+    const uint32_t mitem = valid ? (slot_item ? slot_item[aidx] : aidx) : 0;   // message: index of mu
     int8_t *mine = cc + threadIdx.x;          // per-lane private column: coefficient i at mine[i*HT] (no systematic bank conflict)
     if (valid) {
-        sp.absorb(mu + (size_t)item * 48, 48);
+        sp.absorb(mu + (size_t)mitem * 48, 48);
         sp.absorb(w1 + (size_t)item * w1len, (size_t)w1len);
         sp.finalize();
         const int nwb = (weight + 7) >> 3;
@@ -342,62 +342,88 @@ __global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *activ
     }
 }
 
-// MSB-first bit writer into a byte buffer whose bytes are zero or already hold earlier bits
+// MSB-first bit writer: bits are collected in a register and leave as whole bytes (packer.c:299-351 semantics:
+// values masked to `bits`, the last byte zero padded)
 struct BitW {
-    uint8_t *p; uint32_t bitpos;
+    uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
     __device__ __forceinline__ void put(uint32_t v, int bits)
     {
-        for (int b = bits - 1; b >= 0; b--) {
-            const uint32_t byte = bitpos >> 3, sh = 7 - (bitpos & 7);
-            if (sh == 7) p[byte] = 0;
-            p[byte] |= (uint8_t)(((v >> b) & 1u) << sh);
-            bitpos++;
-        }
+        acc = (acc << bits) | (uint64_t)(v & ((1u << bits) - 1u)); nb += bits;
+        while (nb >= 8) { p[nbytes++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
     }
+    __device__ __forceinline__ void flush() { if (nb) { p[nbytes++] = (uint8_t)(acc << (8 - nb)); nb = 0; } }
 };
 
-// accept / reject (dilithium.c:1655-1725) + the signature tail: num_ones, hint positions, c (2 bits each)
-// (dilithium.c:1926-1945).  Rejected messages get kappa+1 and go to the next round's list.
-__global__ __launch_bounds__(HT) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
-                                                        uint32_t *status, uint32_t round, const uint8_t *h, const int32_t *c,
+// one slot table per round: slot aidx*S + a  ->  (message active[aidx], kappa base + a)
+__global__ void dil_slots_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *kappa, uint32_t *slot_item, uint32_t *slot_kappa)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nact * S) return;
+    const uint32_t item = active ? active[s / S] : s / S;
+    slot_item[s] = item;
+    slot_kappa[s] = kappa[item] + s % S;
+}
+
+// accept / reject (dilithium.c:1655-1725) over the S speculative attempts of a message, lowest kappa first, + the
+// signature tail of the accepted attempt: num_ones, hint positions, c (2 bits each) (dilithium.c:1926-1945).
+// Messages with no accepted attempt advance kappa by S and go to the next round's list.
+__global__ __launch_bounds__(HT) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
+                                                        int32_t *acc_slot, const uint8_t *h, const int32_t *c,
                                                         uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
                                                         uint32_t *next_active, uint32_t *next_count, DilP P)
 {
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
-    const uint32_t fl = flags[item], no = ones[item];
-    flags[item] = 0; ones[item] = 0;
-    if (fl != 0 || no > (uint32_t)P.omega) {
-        kappa[item] += 1;
+    int found = -1;
+    for (uint32_t a = 0; a < S; a++) {
+        const uint32_t slot = aidx * S + a;
+        if (found < 0 && flags[slot] == 0 && ones[slot] <= (uint32_t)P.omega) found = (int)a;
+        if (found != (int)a) { flags[slot] = 0; ones[slot] = 0; }
+    }
+    if (found < 0) {
+        acc_slot[aidx] = -1;
+        kappa[item] += S;
         next_active[atomicAdd(next_count, 1u)] = item;
         return;
     }
-    status[item] = round + 1;                                       // accepted in this round
-    trials[item] = kappa[item] + 1;
+    const uint32_t slot = aidx * S + (uint32_t)found;
+    const uint32_t no = ones[slot];
+    flags[slot] = 0; ones[slot] = 0;
+    acc_slot[aidx] = (int32_t)slot;
+    trials[item] = kappa[item] + (uint32_t)found + 1;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
-    BitW bw{ sigs + (size_t)item * sig_stride, (uint32_t)(P.l * P.n * P.z_bits) };
+    BitW bw{ sigs + (size_t)item * sig_stride, (uint32_t)(P.l * P.n * P.z_bits / 8), 0, 0 };
     bw.put(no, P.omega_bits);
-    const uint8_t *hh = h + (size_t)item * kn;
-    for (int i = 0; i < kn; i++) if (hh[i]) bw.put((uint32_t)i, h_bits);
-    const int32_t *ci = c + (size_t)item * P.n;
+    const uint64_t *hh = reinterpret_cast<const uint64_t *>(h + (size_t)slot * kn);      // kn is a multiple of 8
+    for (int w = 0; w < kn / 8; w++) {
+        uint64_t v = hh[w];
+        while (v) {
+            const int b = __ffsll((long long)v) - 1;                   // bytes are 0 or 1: bit 8*i of the word = h[8w+i]
+            bw.put((uint32_t)(8 * w + (b >> 3)), h_bits);
+            v &= v - 1;
+        }
+    }
+    const int32_t *ci = c + (size_t)slot * P.n;
     for (int i = 0; i < P.n; i++) bw.put((uint32_t)ci[i], 2);
-    siglens[item] = (bw.bitpos + 7) >> 3;
+    bw.flush();
+    siglens[item] = bw.nbytes;
 }
 
 // z part of the signature of the messages accepted this round: centre (ntt32_center) and raw z_bits per coefficient,
 // two coefficients per thread (2*z_bits = 40 bits = 5 bytes)  (dilithium.c:1803,1914-1917)
-__global__ void dil_packz_kernel(const uint32_t *active, uint32_t nact, const uint32_t *status, uint32_t round, const int32_t *z,
+__global__ void dil_packz_kernel(const uint32_t *active, uint32_t nact, const int32_t *acc_slot, const int32_t *z,
                                  uint8_t *sigs, size_t sig_stride, int ln, int z_bits, int32_t q)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int pairs = ln / 2;
     const size_t aidx = t / pairs; const int pr = (int)(t % pairs);
     if (aidx >= nact) return;
+    const int32_t slot = acc_slot[aidx];
+    if (slot < 0) return;
     const uint32_t item = active ? active[aidx] : (uint32_t)aidx;
-    if (status[item] != round + 1) return;
     const int32_t half = (q - 1) >> 1;
-    int32_t v0 = z[(size_t)item * ln + 2 * pr], v1 = z[(size_t)item * ln + 2 * pr + 1];
+    int32_t v0 = z[(size_t)slot * ln + 2 * pr], v1 = z[(size_t)slot * ln + 2 * pr + 1];
     if (v0 > half) v0 -= q;
     if (v1 > half) v1 -= q;
     const uint64_t m = (1ull << z_bits) - 1;
@@ -480,7 +506,9 @@ struct sc_hip_dilithium {
     // workspace
     size_t cap;
     uint8_t *mu, *w1, *h;
-    uint32_t *kappa, *flags, *ones, *status, *trials, *act[2], *cnt, *verdict, *siglen_dev;
+    size_t slot_cap;
+    uint32_t *kappa, *flags, *ones, *trials, *act[2], *cnt, *slot_item, *slot_kappa;
+    int32_t *acc_slot;
     int32_t *y, *w, *c, *z, *r;
     uint32_t *yh, *ch;
     uint8_t *msg_dev, *sig_dev;
@@ -489,27 +517,33 @@ struct sc_hip_dilithium {
 
 static void free_ws(sc_hip_dilithium *d)
 {
-    void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->flags, d->ones, d->status, d->trials, d->act[0], d->act[1], d->cnt, d->verdict,
-                     d->siglen_dev, d->y, d->w, d->c, d->z, d->r, d->yh, d->ch };
+    void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->flags, d->ones, d->trials, d->act[0], d->act[1], d->cnt, d->slot_item, d->slot_kappa,
+                     d->acc_slot, d->y, d->w, d->c, d->z, d->r, d->yh, d->ch };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    d->mu = d->w1 = d->h = nullptr; d->kappa = d->flags = d->ones = d->status = d->trials = d->act[0] = d->act[1] = d->cnt = d->verdict = d->siglen_dev = nullptr;
-    d->y = d->w = d->c = d->z = d->r = nullptr; d->yh = d->ch = nullptr;
-    d->cap = 0;
+    d->mu = d->w1 = d->h = nullptr; d->kappa = d->flags = d->ones = d->trials = d->act[0] = d->act[1] = d->cnt = d->slot_item = d->slot_kappa = nullptr;
+    d->acc_slot = nullptr; d->y = d->w = d->c = d->z = d->r = nullptr; d->yh = d->ch = nullptr;
+    d->cap = 0; d->slot_cap = 0;
 }
 
-static int ensure_ws(sc_hip_dilithium *d, size_t batch)
+// per-message state for `batch` messages, per-attempt arrays for `slots` attempts (slots >= batch)
+static int ensure_ws(sc_hip_dilithium *d, size_t batch, size_t slots)
 {
-    if (batch <= d->cap) return SC_HIP_SUCCESS;
+    if (batch <= d->cap && slots <= d->slot_cap) return SC_HIP_SUCCESS;
+    if (batch < d->cap) batch = d->cap;
+    if (slots < d->slot_cap) slots = d->slot_cap;
     free_ws(d);
     const size_t n = d->P.n, k = d->P.k, l = d->P.l;
 #define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
-    WS(d->mu, batch * 48); WS(d->w1, batch * k * n); WS(d->h, batch * k * n);
-    WS(d->kappa, batch * 4); WS(d->flags, batch * 4); WS(d->ones, batch * 4); WS(d->status, batch * 4); WS(d->trials, batch * 4);
-    WS(d->act[0], batch * 4); WS(d->act[1], batch * 4); WS(d->cnt, 64); WS(d->verdict, batch * 4); WS(d->siglen_dev, batch * 4);
-    WS(d->y, batch * l * n * 4); WS(d->w, batch * k * n * 4); WS(d->c, batch * n * 4); WS(d->z, batch * l * n * 4); WS(d->r, batch * k * n * 4);
-    WS(d->yh, batch * l * n * 4); WS(d->ch, batch * n * 4);
+    WS(d->mu, batch * 48); WS(d->kappa, batch * 4); WS(d->trials, batch * 4); WS(d->act[0], batch * 4); WS(d->act[1], batch * 4); WS(d->cnt, 64);
+    WS(d->acc_slot, batch * 4);
+    WS(d->slot_item, slots * 4); WS(d->slot_kappa, slots * 4); WS(d->flags, slots * 4); WS(d->ones, slots * 4);
+    WS(d->w1, slots * k * n); WS(d->h, slots * k * n);
+    WS(d->y, slots * l * n * 4); WS(d->w, slots * k * n * 4); WS(d->c, slots * n * 4); WS(d->z, slots * l * n * 4); WS(d->r, slots * k * n * 4);
+    WS(d->yh, slots * l * n * 4); WS(d->ch, slots * n * 4);
 #undef WS
-    d->cap = batch;
+    HIPCHK(hipMemset(d->flags, 0, slots * 4));
+    HIPCHK(hipMemset(d->ones, 0, slots * 4));
+    d->cap = batch; d->slot_cap = slots;
     return SC_HIP_SUCCESS;
 }
 
@@ -581,7 +615,7 @@ static int key_ntt(sc_hip_dilithium *d, const int32_t *h_polys, size_t npoly, ui
     if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
     HIPCHK(hipMemcpy(tmp, h_polys, bytes, hipMemcpyHostToDevice));
     DilNtt a = base_args(d);
-    a.in = tmp; a.out_int = *dst; a.active = nullptr;
+    a.in = tmp; a.out_int = *dst;
     int rc = launch_dil<DOP_KEYPREP>(d, a, (uint32_t)npoly, 1, nullptr);
     if (rc == SC_HIP_SUCCESS && hipDeviceSynchronize() != hipSuccess) rc = fail("dilithium key load: kernel failed");
     (void)hipFree(tmp);
@@ -664,15 +698,14 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
     if (!d_sigs || !d_siglens) return fail("dilithium_sign: null output buffer");
     if (sig_stride < sc_hip_dilithium_sig_max(d)) return fail("dilithium_sign: sig_stride smaller than sc_hip_dilithium_sig_max()");
     HIPCHK(hipSetDevice(d->ctx->device));
-    if (ensure_ws(d, batch)) return SC_HIP_FAILURE;
+    // attempts evaluated side by side per round: 4 per message while the whole batch is active, more as it thins out
+    const size_t slot_target = batch * 4 > 4096 ? batch * 4 : 4096;
+    if (ensure_ws(d, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const DilP &P = d->P;
     const uint32_t B = (uint32_t)batch;
     const int k = P.k, l = P.l;
     HIPCHK(hipMemsetAsync(d->kappa, 0, batch * 4, s));
-    HIPCHK(hipMemsetAsync(d->flags, 0, batch * 4, s));
-    HIPCHK(hipMemsetAsync(d->ones, 0, batch * 4, s));
-    HIPCHK(hipMemsetAsync(d->status, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : d->trials;
     hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d->d_tr_priv, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
     HIPCHK(hipGetLastError());
@@ -680,30 +713,34 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
     uint32_t nact = B;
     const uint32_t *active = nullptr;                 // round 0: identity
     for (uint32_t round = 0; nact > 0; round++) {
-        if (round > 1000) return fail("dilithium_sign: rejection loop did not terminate");
+        if (round > 4000) return fail("dilithium_sign: rejection loop did not terminate");
+        uint32_t S = (uint32_t)(d->slot_cap / nact);
+        if (S > 32) S = 32;
+        if (S < 1) S = 1;
+        const uint32_t nslots = nact * S;
         uint32_t *next = d->act[round & 1];
         HIPCHK(hipMemsetAsync(d->cnt, 0, 4, s));
-        const unsigned hb = (nact + HT - 1) / HT;
-        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->d_K, d->mu, d->kappa, d->y, l * P.n, P.gamma1, P.q);
+        hipLaunchKernelGGL(dil_slots_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nact, S, d->kappa, d->slot_item, d->slot_kappa);
+        const unsigned hb = (nslots + HT - 1) / HT;
+        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, d->slot_kappa, nslots, d->d_K, d->mu, d->y, l * P.n, P.gamma1, P.q);
         HIPCHK(hipGetLastError());
         DilNtt a = base_args(d);
-        a.active = active;
         a.in = d->y; a.out_int = d->yh;
-        if (launch_dil<DOP_FWD_INT>(d, a, nact, l, s)) return SC_HIP_FAILURE;
+        if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
         a.key = d->d_A;
-        if (launch_dil<DOP_MATVEC>(d, a, nact, k, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
+        if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, nslots, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
         a.in = d->c; a.out_int = d->ch;
-        if (launch_dil<DOP_FWD_INT>(d, a, nact, 1, s)) return SC_HIP_FAILURE;
-        a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nact, l, s)) return SC_HIP_FAILURE;
-        a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nact, k, s)) return SC_HIP_FAILURE;
-        a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nact, k, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(dil_finish_kernel, dim3(hb), dim3(HT), 0, s, active, nact, d->flags, d->ones, d->kappa, d->status, round, d->h, d->c,
+        if (launch_dil<DOP_FWD_INT>(d, a, nslots, 1, s)) return SC_HIP_FAILURE;
+        a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
+        a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
                            d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
         HIPCHK(hipGetLastError());
         const size_t zthreads = (size_t)nact * (size_t)(l * P.n / 2);
-        hipLaunchKernelGGL(dil_packz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, active, nact, d->status, round, d->z,
+        hipLaunchKernelGGL(dil_packz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, active, nact, d->acc_slot, d->z,
                            d_sigs, sig_stride, l * P.n, P.z_bits, P.q);
         HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
@@ -727,7 +764,7 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     if (!d_sigs || !d_siglens || !d_verdicts) return fail("dilithium_verify: null buffer");
     if (!d_msgs && (d_mlens || fixed_len)) return fail("dilithium_verify: null message buffer");
     HIPCHK(hipSetDevice(d->ctx->device));
-    if (ensure_ws(d, batch)) return SC_HIP_FAILURE;
+    if (ensure_ws(d, batch, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const DilP &P = d->P;
     const uint32_t B = (uint32_t)batch;
@@ -742,7 +779,6 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
-    a.active = nullptr;
     a.in = d->z; a.out_int = d->yh;
     if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
     a.key = d->d_A;
