@@ -56,6 +56,41 @@ def cpu_baseline(seconds=10.0):
     return {'value': 2.0 * done / dt, 'unit': 'NTT/s', 'cores': 1, 'kind': 'port', 'sample': sample + ' (oracle/sc_oracle.c, gcc -O2)'}
 
 
+def dilithium_extra(eng, torch, cpu_seconds):
+    """North-star companion figure: Dilithium-III (reference set 3: k=6, l=5) full sign / verify of 16384 64-byte
+    messages under one key, messages and signatures resident in HBM (BASELINE configs[2])."""
+    from tests.golden_io import load_golden
+    G = load_golden('dilithium_ref.txt')       # key material produced by the reference's keygen (data, not code)
+    tag, batch = 'dil3', 16384
+    d = eng.dilithium(G[f'{tag}_params'])
+    d.set_privkey(*(G[f'{tag}_{x}'] for x in ('s1', 's2', 't', 'K', 'tr', 'Ahat')))
+    d.set_pubkey(G[f'{tag}_t1'], G[f'{tag}_rho'], G[f'{tag}_Ahat'])
+    g = torch.Generator(device='cuda')
+    g.manual_seed(3)
+    msgs = torch.randint(0, 256, (batch, 64), dtype=torch.uint8, device='cuda', generator=g)
+    sigs, siglens, trials = d.sign(msgs, fixed_len=64)
+    torch.cuda.synchronize()
+    ts, tv = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); sigs, siglens, trials = d.sign(msgs, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); v = d.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+    assert int(v.sum()) == 0, 'bench signatures failed verification'
+    out = {'workload': 'BASELINE configs[2]: Dilithium-III (n=256, q=8380417, k=6, l=5) sign + verify, batch 16384, 64-byte messages, one key',
+           'sign_ops_per_s': batch / min(ts), 'verify_ops_per_s': batch / min(tv), 'sign_ms_per_batch': min(ts) * 1e3,
+           'verify_ms_per_batch': min(tv) * 1e3, 'mean_attempts_per_signature': float(trials.float().mean())}
+    drv = os.path.join(ROOT, 'oracle', '_ref', 'ref_driver')
+    if cpu_seconds > 0 and os.path.exists(drv):
+        try:
+            r = json.loads(subprocess.check_output([drv, 'bench_dil', '3', str(cpu_seconds)], timeout=cpu_seconds * 3 + 30).decode().strip().splitlines()[-1])
+            out['cpu_reference'] = {'sign_ops_per_s': r['sign_per_sec'], 'verify_ops_per_s': r['verify_per_sec'], 'cores': 1, 'kind': 'reference',
+                                    'sample': f'{cpu_seconds:.0f} s of safecrypto_sign + {cpu_seconds / 4:.0f} s of safecrypto_verify, set 3, 64-byte messages, one key, 1 thread'}
+            out['sign_speedup_vs_cpu_thread'] = out['sign_ops_per_s'] / r['sign_per_sec']
+        except Exception as e:
+            sys.stderr.write(f'dilithium cpu baseline failed: {e}\n')
+    d.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -146,6 +181,11 @@ def main():
                          'algorithmic_bytes_per_launch': BATCH * BYTES_PER_TRIPLE},
             'extra': {'fwd_ntt': fwd_ms},
         }
+        if world == 1:
+            try:
+                res['extra']['dilithium3'] = dilithium_extra(eng, torch, 0.0 if args.no_cpu_baseline else args.cpu_seconds)
+            except Exception as e:        # an extra must never break the contract line
+                res['extra']['dilithium3'] = {'error': str(e)}
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res), flush=True)

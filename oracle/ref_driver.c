@@ -10,6 +10,7 @@
  *
  * Usage: ref_driver <ntt|cdt|dilithium|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
+ *        ref_driver bench_dil <set> <seconds>    (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
  * Fixture format (one file per topic): repeated records
  *     @ <name> <count>\n  followed by <count> whitespace separated decimal integers.
@@ -345,8 +346,40 @@ static int bench_ntt(int32_t q, int n, double seconds)
     return 0;
 }
 
+/* safecrypto_sign / safecrypto_verify of the reference, one key, 64-byte counter-derived messages
+ * (the loop of test/functional/func_alg_dilithium.c:191-230 without the key regeneration) */
+static int bench_dil(int set, double seconds)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+    if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    enum { POOL = 64 };
+    uint8_t msg[POOL][64], *sig[POOL]; size_t siglen[POOL];
+    sm_state = 7;
+    for (int i = 0; i < POOL; i++) { for (int j = 0; j < 64; j++) msg[i][j] = (uint8_t)splitmix64(); sig[i] = NULL; siglen[i] = 0; }
+    uint64_t nsign = 0, nver = 0; size_t tr0 = sc->stats.sig_num_trials;
+    double t0 = now_s(), t1;
+    do {
+        for (int i = 0; i < POOL; i++) {
+            if (sig[i]) { free(sig[i]); sig[i] = NULL; siglen[i] = 0; }
+            if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg[i], 64, &sig[i], &siglen[i])) return 1;
+        }
+        nsign += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds);
+    const double ts = t1 - t0; const double trials = (double)(sc->stats.sig_num_trials - tr0) / (double)nsign;
+    t0 = now_s();
+    do {
+        for (int i = 0; i < POOL; i++) if (SC_FUNC_SUCCESS != safecrypto_verify(sc, msg[i], 64, sig[i], siglen[i])) return 1;
+        nver += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds / 4);
+    printf("{\"set\": %d, \"sign_per_sec\": %.1f, \"verify_per_sec\": %.1f, \"signs\": %llu, \"trials_per_sig\": %.3f}\n",
+           set, nsign / ts, nver / (t1 - t0), (unsigned long long)nsign, trials);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_dil(atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
