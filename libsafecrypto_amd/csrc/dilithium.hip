@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             for (int r = 0; r < 16; r++) {
                 int32_t a0;
                 a.w[pk_off + r * LP] = (int32_t)x[r];
-                a.w1[pk_off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
+                if (a.w1) a.w1[pk_off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
             }
         } else if (OP == DOP_CZ) {            // z = y + c s1, normalize, ||z||inf < gamma1 - beta
             bool bad = false;
@@ -223,11 +223,13 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 }
 
 // natural-order NTT-domain array -> internal order, Montgomery form (for the expanded matrix A)
-__global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p)
+// rows/cols != 0: the input is [cols][rows][n] and is transposed on the way (out is always [rows][cols][n])
+__global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p, int rows = 0, int cols = 0)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npoly * N) return;
-    const size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
+    size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
+    if (rows) p = (p % (size_t)cols) * (size_t)rows + p / (size_t)cols;
     const uint32_t nat = __builtin_bitreverse32(j) >> 24;
     uint32_t v = reduce_i32(in[p * N + nat], k);
     out[i] = csub(Mod<MODE_U32>::mulc(v, r2, r2p, k), k.q);
@@ -675,6 +677,41 @@ extern "C" int sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *d, const int32_t 
     (void)hipFree(dt1);
     d->have_pub = (rc == SC_HIP_SUCCESS);
     return rc;
+}
+
+// generic module-LWE product (create_rand_product_32/16_csprng with the matrix expanded, module_lwe.c:588-748):
+// t[b][i] = INTT( sum_j A[i][j] o NTT(y[b][j]) ), canonical.  n = 256 (every user of the reference is).
+extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int transposed,
+                             const int32_t *d_Ahat, const int32_t *d_y, int32_t *d_t, void *stream)
+{
+    if (!p) return fail("matvec: null plan");
+    if (p->n != 256) return fail("matvec: n must be 256");
+    if (kk < 1 || kk > 16 || l < 1 || l > 16) return fail("matvec: k, l must be in 1..16");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 32) return fail("matvec: batch too large");
+    if (!d_Ahat || !d_y || !d_t) return fail("matvec: null device pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const size_t need = ((size_t)kk * l + batch * (size_t)l) * N * 4;
+    if (need > p->mv_cap) {
+        if (p->mv_ws) (void)hipFree(p->mv_ws);
+        p->mv_ws = nullptr; p->mv_cap = 0;
+        HIPCHK(hipMalloc((void **)&p->mv_ws, need));
+        p->mv_cap = need;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *A_int = p->mv_ws, *yh = p->mv_ws + (size_t)kk * l * N;
+    const size_t np = (size_t)kk * l;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, s, d_Ahat, A_int, np, p->k[1], p->r2, p->r2p,
+                       transposed ? kk : 0, transposed ? l : 0);
+    HIPCHK(hipGetLastError());
+    sc_hip_dilithium tmp;
+    memset(&tmp, 0, sizeof tmp);
+    tmp.ctx = p->ctx; tmp.plan = p; tmp.P.n = 256; tmp.P.q = p->q; tmp.P.k = kk; tmp.P.l = l; tmp.P.gamma2 = 1 << 20;
+    DilNtt a = base_args(&tmp);
+    a.in = d_y; a.out_int = yh; a.yh = yh; a.key = A_int; a.w = d_t; a.w1 = nullptr;
+    if (launch_dil<DOP_FWD_INT>(&tmp, a, (uint32_t)batch, l, s)) return SC_HIP_FAILURE;
+    if (launch_dil<DOP_MATVEC>(&tmp, a, (uint32_t)batch, kk, s)) return SC_HIP_FAILURE;
+    return SC_HIP_SUCCESS;
 }
 
 extern "C" size_t sc_hip_dilithium_sig_max(const sc_hip_dilithium_t *d)

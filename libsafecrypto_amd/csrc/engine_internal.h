@@ -35,6 +35,8 @@ struct sc_hip_plan {
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
     uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
     uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
+    uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order
+    size_t mv_cap;
 };
 
 struct sc_hip_cdt {

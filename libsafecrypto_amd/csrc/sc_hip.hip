@@ -292,6 +292,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
 
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
+    p->mv_ws = nullptr; p->mv_cap = 0;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
     p->w[0] = 1;
@@ -348,6 +349,7 @@ extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
 {
     if (!p) return;
     for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)hipFree(p->d_tab[i]);
+    if (p->mv_ws) (void)hipFree(p->mv_ws);
     delete p;
 }
 extern "C" int32_t sc_hip_plan_q(const sc_hip_plan_t *p) { return p ? p->q : 0; }
@@ -472,12 +474,7 @@ extern "C" int sc_hip_poly_add(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a
 extern "C" int sc_hip_poly_sub(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
 { if (!ctx) return fail("poly_sub: null ctx"); ModK k = {}; return run_ew<EW_SUB>(ctx, k, 0, 0, len, d_a, d_b, d_out, stream); }
 
-extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int transposed,
-                             const int32_t *d_Ahat, const int32_t *d_y, int32_t *d_t, void *stream)
-{
-    (void)p; (void)batch; (void)kk; (void)l; (void)transposed; (void)d_Ahat; (void)d_y; (void)d_t; (void)stream;
-    return fail("matvec: not built yet in this round");
-}
+// sc_hip_matvec lives in dilithium.hip (it shares the module-LWE kernels)
 
 // ---- CDT -----------------------------------------------------------------------------------
 

@@ -233,6 +233,14 @@ class NttPlan:
         _chk(self.L, self.L.sc_hip_polymul(self.h, self._batch(a), _ptr(a), _ptr(b), _ptr(out), _stream()), 'polymul')
         return out
 
+    def matvec(self, Ahat, y, k, l, transposed=False):
+        """t[b][i] = INTT(sum_j A[i][j] o NTT(y[b][j])) - create_rand_product_* with the matrix expanded"""
+        import torch
+        batch = y.numel() // (l * self.n)
+        t = torch.empty((batch, k, self.n), dtype=torch.int32, device=y.device)
+        _chk(self.L, self.L.sc_hip_matvec(self.h, batch, k, l, 1 if transposed else 0, _ptr(Ahat), _ptr(y), _ptr(t), _stream()), 'matvec')
+        return t
+
     def pointwise(self, a, b, out=None):
         out = self._out(a, out)
         _chk(self.L, self.L.sc_hip_pointwise(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'pointwise')
