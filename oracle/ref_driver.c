@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_dil <set> <seconds>    (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
@@ -307,6 +307,92 @@ static int gen_dilithium(const char *dir)
     return rc;
 }
 
+/* --------------------------------------------------------------- BLISS-B ---- */
+
+#include "schemes/sig/bliss_b/bliss_b.h"
+#include "schemes/sig/bliss_b/bliss_params.h"
+
+typedef struct __attribute__((packed)) { UINT64 *cdf; SINT32 cdf_size; SINT32 k; SINT32 use_kl; prng_ctx_t *prng_ctx; } cdf64_full_view_t; /* gaussian_cdf.c:74-81 */
+
+/* BLISS-B signing draws ALL its randomness from sc->prng_ctx[0] as a stream of 32-bit pool words
+ * (prng_64 = two words, prng_var = a bit reservoir refilled by prng_32; src/utils/crypto/prng.c:963-1048).
+ * For each message the context's CSPRNG is replaced by a freshly seeded one and a twin with the same seed
+ * is read with prng_32 only: that is the "random tape" the signature is a pure function of. */
+static int bliss_case(FILE *f, int set, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "bliss%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const bliss_set_t *P = sc->bliss->params;
+    const int n = P->n;
+    int32_t par[16] = { P->n, P->q, P->q_bits, P->n_bits, P->d, P->p, P->kappa, P->b_inf, (int32_t)P->b_l2, P->z1_bits, P->z2_bits, set, 0, 0, 0, 0 };
+    float fl[3] = { P->sig, P->m, 13.42f };
+    memcpy(&par[12], fl, 12);                                   /* sigma, M, tail as raw float bits */
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 16);
+    snprintf(name, sizeof name, "%s_f", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+    snprintf(name, sizeof name, "%s_g", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key + n, n);
+    snprintf(name, sizeof name, "%s_a", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xb1155000ULL + set;
+    /* candidates are drawn until nmsg are kept: the first nmsg-3 whatever they need, then three that took >= 3 attempts
+     * (a second fresh pair of Gaussian vectors) */
+    int kept = 0, long_ones = 0;
+    for (int cand = 0; cand < 4000 && kept < nmsg; cand++) {
+        uint8_t msg[96], seed[32];
+        size_t mlen = (cand == 0) ? 1 : (cand == 1) ? 96 : 64;  /* oracle() rejects an empty message (bliss_b.c:571-574) */
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        sc->sc_gauss->prng_ctx = mine;
+        ((cdf64_full_view_t *)sc->sc_gauss->gauss)->prng_ctx = mine;
+        uint8_t *sig = NULL; size_t siglen = 0;
+        size_t before = sc->stats.sig_num_trials;
+        if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        const int tr = (int)(sc->stats.sig_num_trials - before);
+        const int keep = (kept < nmsg - 3) || (tr >= 3 && long_ones < 3);
+        if (keep) {
+            const int m = kept++;
+            if (tr >= 3 && m >= nmsg - 3) long_ones++;
+            trials[m] = tr;
+            const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+            int32_t *tape = malloc(sizeof(int32_t) * words);
+            for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+            snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+            snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+            snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+            verdicts[2 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+            sig[siglen / 3] ^= 0x04;
+            verdicts[2 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+            free(tape);
+        }
+        free(sig);
+        sc->prng_ctx[0] = orig; sc->sc_gauss->prng_ctx = orig; ((cdf64_full_view_t *)sc->sc_gauss->gauss)->prng_ctx = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    if (kept != nmsg) return 1;
+    snprintf(name, sizeof name, "%s_trials", tag); rec_i32(f, name, trials, nmsg);
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
+    free(trials); free(verdicts);
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_bliss(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/bliss_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = bliss_case(f, 1, 9);
+    fclose(f);
+    return rc;
+}
+
 /* -------------------------------------------------------------- CPU baseline ---- */
 
 #include <time.h>
@@ -386,5 +472,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
+    if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
     return rc;
 }

@@ -1,0 +1,229 @@
+/*
+ * sc_oracle_bliss.c - CPU restatement of the reference's BLISS-B sign / verify path.
+ * TEST INFRASTRUCTURE ONLY (see sc_oracle.h).  Pinned: tests/test_oracle_bliss.py reproduces the reference's
+ * signatures byte for byte from (key, message, random tape) fixtures (tests/golden/bliss_ref.txt, made by
+ * oracle/ref_driver.c from the reference build).  Paths are relative to the reference tree.
+ *
+ * Randomness: bliss_b_sign draws everything from one CSPRNG context as a stream of 32-bit pool words
+ * (src/utils/crypto/prng.c:963-1048): prng_64 = two words (high first), prng_var(n) = a 32-bit reservoir
+ * refilled by prng_32, prng_bit = prng_var(1), prng_double = prng_var(27), prng_var(26).  The stream ("tape")
+ * is an input here; the consumption rules are restated below.
+ */
+#include "sc_oracle.h"
+#include "sc_oracle_keccak.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { const uint32_t *w; size_t len, pos; uint32_t var_buf; int var_bits; int underrun; } tape_t;
+
+static uint32_t t32(tape_t *t) { if (t->pos >= t->len) { t->underrun = 1; return 0; } return t->w[t->pos++]; }
+static uint64_t t64(tape_t *t) { uint64_t hi = t32(t); return (hi << 32) | t32(t); }                     /* prng.c:963-976 */
+static uint32_t tvar(tape_t *t, int n)                                                                       /* prng.c:1017-1048 */
+{
+    uint32_t mask = (n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1u), ret = t->var_buf;
+    if (t->var_bits < n) {
+        const int bits = n - t->var_bits;
+        ret <<= bits;
+        t->var_buf = t32(t);
+        ret |= t->var_buf & ((1u << bits) - 1u);
+        t->var_buf >>= bits;
+        t->var_bits = 32 - bits;
+    } else {
+        t->var_buf >>= n;
+        t->var_bits -= n;
+    }
+    return ret & mask;
+}
+static double tdouble(tape_t *t) { uint32_t a = tvar(t, 27), b = tvar(t, 26); return (a * 67108864.0 + b) * 1.11022302462516e-16; }   /* prng.c:1010-1015 */
+
+typedef struct { int n, q, q_bits, n_bits, d, p, kappa, b_inf, b_l2, z1_bits, z2_bits, set; float sigma, m, tail; int pad; } blissp_t;
+
+/* bliss_b.c:58-64 */
+static int32_t barrett(int64_t x, int k, int64_t m, int64_t q) { int64_t t = (x * m) >> k, c = x - t * q; if (q <= c) c -= q; return (int32_t)c; }
+
+/* bliss_b.c:552-620: SHA3-512(m || z as little-endian int16 || r_be16), r = 0,1,.., 9-bit indices from big-endian
+ * byte pairs, first kappa distinct ones */
+static int bliss_oracle(int32_t *c_idx, int kappa, const uint8_t *m, size_t mlen, const int16_t *z, int n, int mask)
+{
+    uint8_t *fl = calloc((size_t)n, 1), md[64];
+    int cnt = 0;
+    if (mlen == 0) { free(fl); return 1; }
+    for (int r = 0; r < 65536; r++) {
+        shake_t h; sha3_init(&h, 64);
+        shake_absorb(&h, m, mlen);
+        shake_absorb(&h, (const uint8_t *)z, 2 * (size_t)n);
+        const uint8_t t[2] = { (uint8_t)(r >> 8), (uint8_t)(r & 0xFF) };
+        shake_absorb(&h, t, 2);
+        sha3_final(&h, md, 64);
+        for (int i = 0; i < 64; i += 2) {
+            const int idx = ((((int)md[i]) << 8) + md[i + 1]) & mask;
+            if (!fl[idx]) {
+                c_idx[cnt++] = idx;
+                if (cnt == kappa) { free(fl); return 0; }
+                fl[idx] = 1;
+            }
+        }
+    }
+    free(fl);
+    return 1;
+}
+
+/* bliss_b.c:622-679 */
+static void greedy_sc(const int16_t *f, const int16_t *g, int n, const int32_t *c_idx, int kappa, int32_t *x, int32_t *y)
+{
+    memset(x, 0, sizeof(int32_t) * (size_t)n); memset(y, 0, sizeof(int32_t) * (size_t)n);
+    for (int k = 0; k < kappa; k++) {
+        const int i = c_idx[k];
+        int32_t sgn = 0;
+        for (int j = 0; j < n - i; j++) sgn += f[j] * x[i + j] + g[j] * y[i + j];
+        for (int j = n - i; j < n; j++) sgn -= f[j] * x[i + j - n] + g[j] * y[i + j - n];
+        if (sgn > 0) {
+            for (int j = 0; j < n - i; j++) { x[i + j] -= f[j]; y[i + j] -= g[j]; }
+            for (int j = n - i; j < n; j++) { x[i + j - n] += f[j]; y[i + j - n] += g[j]; }
+        } else {
+            for (int j = 0; j < n - i; j++) { x[i + j] += f[j]; y[i + j] += g[j]; }
+            for (int j = n - i; j < n; j++) { x[i + j - n] -= f[j]; y[i + j - n] -= g[j]; }
+        }
+    }
+}
+
+/* bliss_b.c:1010-1043 */
+static int check_norms(const blissp_t *P, const int32_t *t, const int16_t *z)
+{
+    int32_t max = 0, mz = 0, nt = 0, nz = 0;
+    for (int i = 0; i < P->n; i++) { if (t[i] > max) max = t[i]; if (-t[i] > max) max = -t[i]; }
+    if (max > P->b_inf) return 1;
+    for (int i = 0; i < P->n; i++) { if (z[i] > mz) mz = z[i]; if (-z[i] > mz) mz = -z[i]; }
+    if ((mz << P->d) > P->b_inf) return 1;
+    for (int i = 0; i < P->n; i++) { nt += t[i] * t[i]; nz += z[i] * z[i]; }
+    if (nt + (nz << (2 * P->d)) > P->b_l2) return 1;
+    return 0;
+}
+
+typedef struct { uint8_t *buf; size_t bitpos; } bw_t;
+static void bw_put(bw_t *w, uint32_t v, int bits)
+{
+    for (int b = bits - 1; b >= 0; b--) {
+        if ((w->bitpos & 7) == 0) w->buf[w->bitpos >> 3] = 0;
+        w->buf[w->bitpos >> 3] |= (uint8_t)(((v >> b) & 1u) << (7 - (w->bitpos & 7)));
+        w->bitpos++;
+    }
+}
+
+/* bliss_b.c:1266-1535 (raw signature coding, 64-bit CDT sampler, no blinding / discard).  par = the 16 ints of the
+ * fixture's *_params record; f, g, a = the key as the reference stores it (SINT16; a in the NTT domain);
+ * tape = the CSPRNG's 32-bit word stream.  Returns 0, the packed signature, the attempts taken and the words consumed;
+ * 2 = the tape ran out before a signature was accepted. */
+int orc_bliss_sign(const int32_t *par, const int16_t *f, const int16_t *g, const int16_t *a, const uint8_t *msg, size_t mlen,
+                   const uint32_t *tape, size_t tape_len, uint8_t *sig, size_t *siglen, int32_t *trials, size_t *consumed)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, q = P.q;
+    int32_t *wt = malloc(sizeof(int32_t) * (size_t)n * 9), *rt = wt + n, *a32 = rt + n, *t = a32 + n, *u = t + n, *v = u + n, *x = v + n, *y = x + n, *uz = y + n;
+    int16_t *z = malloc(sizeof(int16_t) * (size_t)n);
+    int32_t c_idx[64];
+    if (orc_make_tables(q, n, wt, rt)) return 1;
+    for (int i = 0; i < n; i++) a32[i] = a[i];
+    const int bits = orc_cdt_bits(P.tail, P.sigma), size = 1 << bits;
+    uint64_t *cdf = malloc(sizeof(uint64_t) * (size_t)size);
+    orc_cdt_create(P.tail, P.sigma, cdf, size);
+    tape_t T = { tape, tape_len, 0, 0, 0, 0 };
+    const double inv_sig2 = 1.0 / ((double)P.sigma * P.sigma);
+    const int k2q = 30, kp = 30;
+    const int64_t m2q = (1 << 30) / (2 * q), mp = (1 << 30) / P.p;     /* barrett_init on ntt_2q / ntt_p (bliss_b.c:278-280) */
+    int rc = 2, iter;
+    (void)uz;
+    for (iter = 0; iter < 99999 && !T.underrun; iter++) {
+        if (iter & 1) { int32_t *tmp = t; t = u; u = tmp; }
+        else {
+            for (int i = 0; i < n; i++) t[i] = orc_cdt_sample(t64(&T), cdf, size);
+            for (int i = 0; i < n; i++) u[i] = orc_cdt_sample(t64(&T), cdf, size);
+        }
+        if (T.underrun) break;
+        orc_polymul_ntt(v, n, q, t, a32, wt, rt);                       /* fwd_ntt, mul_32_pointwise_16, inv_ntt: canonical */
+        /* round_and_drop, bliss_b.c:681-703 */
+        for (int i = n; i--;) {
+            int32_t tmp = v[i];
+            tmp += (tmp & 1) * q;
+            tmp = barrett((int64_t)tmp + u[i], k2q, m2q, 2 * q);
+            tmp += (tmp < 0) * 2 * q;
+            v[i] = tmp;
+            z[i] = (int16_t)barrett((tmp + (1 << (P.d - 1))) >> P.d, kp, mp, P.p);
+        }
+        if (bliss_oracle(c_idx, P.kappa, msg, mlen, z, n, (1 << P.n_bits) - 1)) continue;
+        greedy_sc(f, g, n, c_idx, P.kappa, x, y);
+        if (tvar(&T, 1)) { for (int i = 0; i < n; i++) { t[i] -= x[i]; u[i] -= y[i]; } }
+        else             { for (int i = 0; i < n; i++) { t[i] += x[i]; u[i] += y[i]; } }
+        int32_t num = 0, den = 0;
+        for (int i = 0; i < n; i++) { num += x[i] * x[i] + y[i] * y[i]; den += t[i] * x[i] + u[i] * y[i]; }
+        const double thresh = 1.0 / (P.m * exp(-0.5 * inv_sig2 * num) * cosh(inv_sig2 * den));
+        const double rr = tdouble(&T);
+        if (T.underrun) break;
+        if (rr > thresh) continue;
+        /* signature_gen, bliss_b.c:1045-1075 (the Barrett multiplier is built from q, not p - kept as is) */
+        {
+            const int32_t kk = 30, mm = (1 << kk) / q, q2 = 2 * q, p2 = P.p >> 1;
+            for (int i = n; i--;) {
+                int32_t tmp = v[i] - u[i];
+                tmp += (tmp < 0) * q2;
+                tmp -= (tmp >= q2) * q2;
+                tmp = ((tmp + (1 << (P.d - 1))) >> P.d);
+                tmp = tmp - ((tmp * mm) >> kk) * P.p;
+                tmp -= (P.p <= tmp) * P.p;
+                tmp = z[i] - tmp;
+                tmp += (tmp <= -p2) * P.p;
+                tmp -= (tmp > p2) * P.p;
+                z[i] = (int16_t)tmp;
+            }
+        }
+        if (check_norms(&P, t, z)) continue;
+        bw_t bw = { sig, 0 };
+        for (int i = 0; i < n; i++) bw_put(&bw, (uint32_t)t[i], P.z1_bits);
+        for (int i = 0; i < n; i++) bw_put(&bw, (uint32_t)(int32_t)z[i], P.z2_bits);
+        for (int i = 0; i < P.kappa; i++) bw_put(&bw, (uint32_t)c_idx[i], P.n_bits);
+        *siglen = (bw.bitpos + 7) >> 3;
+        rc = 0;
+        iter++;
+        break;
+    }
+    if (trials) *trials = iter;
+    if (consumed) *consumed = T.pos;
+    free(cdf); free(z); free(wt);
+    return rc;
+}
+
+/* bliss_b.c:1583-1740.  Returns 0 (SC_FUNC_SUCCESS) for a valid signature, 1 otherwise. */
+int orc_bliss_verify(const int32_t *par, const int16_t *a, const uint8_t *msg, size_t mlen, const uint8_t *sig, size_t siglen)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, q = P.q;
+    if (siglen * 8 < (size_t)(n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits)) return 1;
+    int32_t *wt = malloc(sizeof(int32_t) * (size_t)n * 5), *rt = wt + n, *a32 = rt + n, *t = a32 + n, *v = t + n;
+    int16_t *z = malloc(sizeof(int16_t) * (size_t)n);
+    int32_t c_idx[64], my_idx[64];
+    int rc = 1;
+    if (orc_make_tables(q, n, wt, rt)) return 1;
+    for (int i = 0; i < n; i++) a32[i] = a[i];
+    size_t bp = 0;
+#define GET(dst, bits) do { uint32_t v_ = 0; for (int b_ = 0; b_ < (bits); b_++, bp++) v_ = (v_ << 1) | ((sig[bp >> 3] >> (7 - (bp & 7))) & 1u); (dst) = v_; } while (0)
+    for (int i = 0; i < n; i++) { uint32_t r; GET(r, P.z1_bits); t[i] = (int32_t)(r << (32 - P.z1_bits)) >> (32 - P.z1_bits); }
+    for (int i = 0; i < n; i++) { uint32_t r; GET(r, P.z2_bits); z[i] = (int16_t)((int32_t)(r << (32 - P.z2_bits)) >> (32 - P.z2_bits)); }
+    for (int i = 0; i < P.kappa; i++) { uint32_t r; GET(r, P.n_bits); c_idx[i] = (int32_t)r; }
+#undef GET
+    if (check_norms(&P, t, z)) goto done;
+    orc_polymul_ntt(v, n, q, t, a32, wt, rt);
+    for (int i = n; i--;) v[i] += (v[i] & 1) * q;
+    for (int i = 0; i < P.kappa; i++) v[c_idx[i]] = barrett((int64_t)v[c_idx[i]] + q, 30, (1 << 30) / (2 * q), 2 * q);
+    for (int i = n; i--;) {
+        int32_t tmp = ((v[i] + (1 << (P.d - 1))) >> P.d) + z[i];
+        tmp -= (tmp >= P.p) * P.p;
+        tmp += (tmp < 0) * P.p;
+        z[i] = (int16_t)tmp;
+    }
+    if (bliss_oracle(my_idx, P.kappa, msg, mlen, z, n, (1 << P.n_bits) - 1)) goto done;
+    rc = memcmp(my_idx, c_idx, sizeof(int32_t) * (size_t)P.kappa) ? 1 : 0;
+done:
+    free(z); free(wt);
+    return rc;
+}

@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_dilithium.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -50,8 +50,40 @@ def lib():
         L.orc_dilithium_sign.argtypes = [i32p, i32p, i32p, i32p, u8p, u8p, i32p, u8p, C.c_size_t, u8p,
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
         L.orc_dilithium_verify.argtypes = [i32p, i32p, u8p, i32p, u8p, C.c_size_t, u8p, C.c_size_t]
+        i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS')
+        u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS')
+        L.orc_sha3.argtypes = [C.c_int, u8p, C.c_size_t, u8p]
+        L.orc_bliss_sign.argtypes = [i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+        L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
         _LIB = L
     return _LIB
+
+
+class BlissKey:
+    def __init__(self, par, f, g, a):
+        self.par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+        self.f, self.g, self.a = (np.ascontiguousarray(np.asarray(x), dtype=np.int16) for x in (f, g, a))
+        self.n, self.q = int(par[0]), int(par[1])
+
+    @classmethod
+    def from_golden(cls, G, tag):
+        return cls(*(G[f'{tag}_{x}'] for x in ('params', 'f', 'g', 'a')))
+
+
+def bliss_sign(key, msg, tape):
+    sig = np.zeros(4096, dtype=np.uint8)
+    sl, tr, used = C.c_size_t(0), C.c_int32(0), C.c_size_t(0)
+    m, ml = _msgbuf(msg)
+    tp = np.ascontiguousarray(np.asarray(tape).astype(np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+    rc = lib().orc_bliss_sign(key.par, key.f, key.g, key.a, m, ml, tp, tp.size, sig, C.byref(sl), C.byref(tr), C.byref(used))
+    return rc, bytes(sig[:sl.value]), tr.value, used.value
+
+
+def bliss_verify(key, msg, sig):
+    m, ml = _msgbuf(msg)
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    return lib().orc_bliss_verify(key.par, key.a, m, ml, s, s.size)
 
 
 class DilKey:
