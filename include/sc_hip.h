@@ -165,6 +165,36 @@ int sc_hip_dilithium_sign_host(sc_hip_dilithium_t *h, size_t batch, const uint8_
 int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
                                  uint32_t fixed_len, const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
 
+/* ---- BLISS-B: batched sign / verify under one key ------------------------------------------ */
+
+/* the fields of bliss_set_t the engine needs (src/schemes/sig/bliss_b/bliss_params.h:43-75, values
+ * bliss_params.c:25-73; BLISS-B-I = set 1) + the sampler tail (13.42, bliss_b.c:342-344) */
+typedef struct sc_hip_bliss_params {
+    int32_t n, q, q_bits, n_bits, d, p, kappa, b_inf, b_l2, z1_bits, z2_bits, set;
+    float sigma, m, tail;
+    int32_t pad;
+} sc_hip_bliss_params_t;
+typedef struct sc_hip_bliss sc_hip_bliss_t;
+
+int  sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_t *params, sc_hip_bliss_t **h);
+void sc_hip_bliss_destroy(sc_hip_bliss_t *h);
+/* keys as the reference stores them (bliss_b.c:1220-1245,1328-1330): f, g SINT16[n] (NULL, NULL for verify only),
+ * a SINT16[n] in the NTT domain */
+int  sc_hip_bliss_set_key(sc_hip_bliss_t *h, const int16_t *f, const int16_t *g, const int16_t *a);
+size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *h);
+
+/* replaces: safecrypto_sign -> bliss_b_sign (bliss_b.c:1266-1535) for `batch` messages.  The reference draws all of a
+ * signature's randomness from its CSPRNG as 32-bit pool words (prng.c:963-1048); the engine owns no CSPRNG, so each
+ * message comes with that word stream: d_tapes uint32 [batch][tape_stride], d_tape_lens (or NULL: tape_stride words
+ * each).  A fresh attempt consumes 4n words, every attempt 1-2 more.  d_status[i]: 1 signed, 2 tape exhausted,
+ * 3 empty message (refused by the reference's oracle).  Signatures equal the reference's for the same words. */
+int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                      const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                      uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_verify -> bliss_b_verify (bliss_b.c:1583-1740); d_verdicts[i] = 0 valid / 1 invalid */
+int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                        const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

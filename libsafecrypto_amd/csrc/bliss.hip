@@ -1,0 +1,542 @@
+// bliss.hip - batched BLISS-B sign / verify on MI355X behind the C ABI of include/sc_hip.h.
+//
+// Replaces, for a batch of messages under one key, bliss_b_sign / bliss_b_verify
+// (src/schemes/sig/bliss_b/bliss_b.c:1266-1535, 1583-1740; raw signature coding, 64-bit CDT sampler, no blinding):
+// get_vector_32 x2 (sampling.c:556-580 -> gaussian_cdf.c:536-659), fwd_ntt/mul_32_pointwise_16/inv_ntt
+// (bliss_b.c:1378-1384), round_and_drop (:681-703), oracle (:552-620, SHA3-512 - the reference's permutation,
+// keccak_dev.h), greedy_sc (:622-679), the +-(x,y) choice, the exp/cosh rejection (:1407-1428), signature_gen
+// (:1045-1075), check_norms (:1010-1043) and the MSB-first bit packing (:1447-1463).
+//
+// Randomness: the reference draws everything from ONE CSPRNG context as a stream of 32-bit pool words
+// (src/utils/crypto/prng.c:963-1048: prng_64 = two words, high first; prng_var(n) = a 32-bit reservoir refilled
+// by prng_32; prng_bit = prng_var(1); prng_double = prng_var(27), prng_var(26)).  The engine owns no CSPRNG: each
+// message comes with its "tape" of such words (the host's reference-compatible generator fills it) and the
+// consumption rules are reproduced here, so a signature is the same pure function of (key, message, tape) as in
+// the reference - byte for byte (tests/golden/bliss_ref.txt).  A tape that runs out is reported per message.
+#include "engine_internal.h"
+#include "keccak_dev.h"
+
+#include <math.h>
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+constexpr int HT = 64;
+
+struct BlissP {              // bliss_set_t (bliss_params.h:43-75), the fields used here
+    int32_t n, q, q_bits, n_bits, d, p, kappa, b_inf, b_l2, z1_bits, z2_bits, set;
+    float sigma, m, tail;
+    int32_t pad;
+};
+
+// bliss_b.c:58-64
+__device__ __forceinline__ int32_t barrett(int64_t x, int64_t m, int64_t q) { int64_t t = (x * m) >> 30, c = x - t * q; if (q <= c) c -= q; return (int32_t)c; }
+
+struct Tape {                // one message's CSPRNG word stream + the prng_var reservoir (prng.c:1017-1048)
+    const uint32_t *w; uint32_t len, pos, var_buf; int var_bits; bool underrun;
+    __device__ __forceinline__ uint32_t w32() { if (pos >= len) { underrun = true; return 0; } return w[pos++]; }
+    __device__ __forceinline__ uint32_t var(int n)
+    {
+        uint32_t ret = var_buf;
+        if (var_bits < n) {
+            const int bits = n - var_bits;
+            ret <<= bits;
+            var_buf = w32();
+            ret |= var_buf & ((1u << bits) - 1u);
+            var_buf >>= bits;
+            var_bits = 32 - bits;
+        } else {
+            var_buf >>= n;
+            var_bits -= n;
+        }
+        return ret & ((1u << n) - 1u);
+    }
+    __device__ __forceinline__ double dbl() { const uint32_t a = var(27), b = var(26); return (a * 67108864.0 + b) * 1.11022302462516e-16; }
+};
+
+struct St {                  // per-message state arrays (device)
+    uint32_t *pos, *var_buf, *iter, *cur, *status;
+    int32_t *var_bits;
+};
+
+// start of an attempt (bliss_b.c:1366-1373): odd attempts swap t and u, even ones draw 2n fresh samples
+__global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, const uint32_t *tape_lens, uint32_t tape_stride, int n,
+                                uint32_t *need, uint32_t *sbase, uint32_t *siglens, const uint32_t *mlens)
+{
+    const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    if (mlens && mlens[item] == 0) { s.status[item] = 3; siglens[item] = 0; need[aidx] = 2; return; }       // oracle() refuses an empty message
+    if (s.iter[item] & 1) { s.cur[item] ^= 1; need[aidx] = 0; return; }
+    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item];
+    if (pos + 4u * (uint32_t)n > len) { s.status[item] = 2; siglens[item] = 0; need[aidx] = 2; return; }     // tape exhausted
+    need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + 4u * (uint32_t)n;
+}
+
+// get_vector_32(t), get_vector_32(u): sample s of the attempt uses tape words 2s (high) and 2s+1 (low)
+__global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *cur,
+                                                        const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, int size, int32_t *tu, int n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
+    __syncthreads();
+    const size_t total = (size_t)nact * 2 * n, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        const uint32_t aidx = (uint32_t)(t / (2 * (size_t)n)); const int sidx = (int)(t % (2 * (size_t)n));
+        if (need[aidx] != 1) continue;
+        const uint32_t item = active ? active[aidx] : aidx;
+        const uint32_t *tp = tapes + (size_t)item * tape_stride + sbase[aidx] + 2 * sidx;
+        const uint64_t u = ((uint64_t)tp[0] << 32) | tp[1];
+        uint32_t a = 0;
+        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
+        const int32_t v = (u & 1) ? (int32_t)a : -(int32_t)a;
+        const uint32_t c = cur[item];
+        const int which = sidx < n ? (int)c : (int)(c ^ 1);
+        tu[((size_t)item * 2 + which) * n + (sidx % n)] = v;
+    }
+}
+
+// dense copy of the current t for the NTT product
+__global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    tin[t] = (need[aidx] == 2) ? 0 : tu[((size_t)item * 2 + cur[item]) * n + i];
+}
+
+// round_and_drop, bliss_b.c:681-703
+__global__ void bl_round_kernel(const uint32_t *active, uint32_t nact, const uint32_t *cur, const int32_t *tu, int32_t *v, int16_t *z, BlissP P)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = P.n;
+    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const int32_t u = tu[((size_t)item * 2 + (cur[item] ^ 1)) * n + i];
+    const int32_t two_q = 2 * P.q;
+    int32_t tmp = v[t];
+    tmp += (tmp & 1) * P.q;
+    tmp = barrett((int64_t)tmp + u, (1 << 30) / two_q, two_q);
+    tmp += (tmp < 0) * two_q;
+    v[t] = tmp;
+    z[t] = (int16_t)barrett((tmp + (1 << (P.d - 1))) >> P.d, (1 << 30) / P.p, P.p);
+}
+
+// oracle, bliss_b.c:552-620: SHA3-512(m || z (int16, little endian) || r_be16), r = 0,1,...; 9-bit indices from big-endian
+// byte pairs; the first kappa distinct ones.  mode 0: write them; mode 1 (verify): compare with the signature's.
+__global__ __launch_bounds__(HT) void bl_oracle_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride,
+                                                       const uint32_t *mlens, uint32_t fixed_len, const int16_t *z, int32_t *cidx, uint32_t *ok,
+                                                       int mode, uint32_t *verdict, BlissP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    __shared__ uint32_t fl[32 * HT];
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
+    if (aidx >= nact) return;
+    if (need && need[aidx] == 2) { if (ok) ok[aidx] = 0; return; }
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t mlen = mlens ? mlens[item] : fixed_len;
+    if (mlen == 0) { if (mode == 0) ok[aidx] = 0; else verdict[item] = 1; return; }
+    const uint8_t *m = msgs + (size_t)item * msg_stride;
+    const uint8_t *zb = reinterpret_cast<const uint8_t *>(z + (size_t)aidx * P.n);
+    uint32_t *myfl = fl + threadIdx.x;
+    for (int w = 0; w < (P.n + 31) / 32; w++) myfl[w * HT] = 0;
+    const int mask = (1 << P.n_bits) - 1;
+    int cnt = 0;
+    uint32_t neq = 0;
+    bool done = false;
+    for (int r = 0; r < 65536 && !done; r++) {
+        sp.init(st, threadIdx.x, 72);
+        sp.absorb(m, mlen);
+        sp.absorb(zb, 2 * (size_t)P.n);
+        sp.absorb_byte((uint8_t)(r >> 8)); sp.absorb_byte((uint8_t)(r & 0xFF));
+        sp.finalize(0x06);
+        for (int i = 0; i < 64 && !done; i += 2) {
+            const uint32_t hi = sp.squeeze_byte(), lo = sp.squeeze_byte();
+            const int idx = (int)((hi << 8) + lo) & mask;
+            const uint32_t bit = 1u << (idx & 31), wv = myfl[(idx >> 5) * HT];
+            if (!(wv & bit)) {
+                if (mode == 0) cidx[(size_t)aidx * P.kappa + cnt] = idx; else neq |= (uint32_t)(cidx[(size_t)aidx * P.kappa + cnt] != idx);
+                cnt++;
+                if (cnt == P.kappa) done = true;
+                myfl[(idx >> 5) * HT] = wv | bit;
+            }
+        }
+    }
+    if (mode == 0) ok[aidx] = done ? 1u : 0u;
+    else if (!done || neq) verdict[item] = 1;
+}
+
+__device__ __forceinline__ int32_t wave_sum(int32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ int32_t wave_max(int32_t v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+
+struct BitW {
+    uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
+    __device__ __forceinline__ void put(uint32_t v, int bits)
+    {
+        acc = (acc << bits) | (uint64_t)(v & ((1u << bits) - 1u)); nb += bits;
+        while (nb >= 8) { p[nbytes++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+    }
+    __device__ __forceinline__ void flush() { if (nb) { p[nbytes++] = (uint8_t)(acc << (8 - nb)); nb = 0; } }
+};
+
+// one wavefront per message: greedy_sc, the +-(x,y) choice, the rejection test, signature_gen, check_norms, packing
+// (bliss_b.c:1399-1463).  Coefficient j = lane + 64 c.
+__global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *ok, St s,
+                                                        const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
+                                                        const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
+                                                        const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
+                                                        uint32_t *next_active, uint32_t *next_count, BlissP P)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
+    const uint32_t aidx = blockIdx.x * 4 + wid;
+    if (aidx >= nact) return;
+    if (need[aidx] == 2) return;                                          // tape exhausted: already reported
+    const uint32_t item = active ? active[aidx] : aidx;
+    int32_t *x = xy + (size_t)wid * 2 * n, *y = x + n;
+    const uint32_t it = s.iter[item];
+    auto reject = [&]() {
+        if (lane == 0) { s.iter[item] = it + 1; next_active[atomicAdd(next_count, 1u)] = item; }
+    };
+    if (!ok[aidx]) { reject(); return; }                                  // oracle failed: continue (bliss_b.c:1395-1397)
+
+    // greedy_sc
+    for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < P.kappa; k++) {
+        const int i = cidx[(size_t)aidx * P.kappa + k];
+        int32_t sgn = 0;
+        for (int c = 0; c < C; c++) {
+            const int j = lane + 64 * c;
+            int idx = i + j; int32_t sg = 1;
+            if (idx >= n) { idx -= n; sg = -1; }
+            sgn += sg * ((int32_t)f[j] * x[idx] + (int32_t)g[j] * y[idx]);
+        }
+        sgn = wave_sum(sgn);
+        for (int c = 0; c < C; c++) {
+            const int j = lane + 64 * c;
+            int idx = i + j; int32_t sg = 1;
+            if (idx >= n) { idx -= n; sg = -1; }
+            if (sgn > 0) sg = -sg;
+            x[idx] += sg * (int32_t)f[j];
+            y[idx] += sg * (int32_t)g[j];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+
+    // the CSPRNG reservoir of this message (every lane computes the same scalar sequence; lane 0 writes it back)
+    Tape T{ tapes + (size_t)item * tape_stride, tape_lens ? tape_lens[item] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
+    const uint32_t cur = s.cur[item];
+    int32_t *t = tu + ((size_t)item * 2 + cur) * n, *u = tu + ((size_t)item * 2 + (cur ^ 1)) * n;
+    const bool sub = T.var(1) != 0;
+    int32_t num = 0, den = 0;
+    for (int c = 0; c < C; c++) {
+        const int j = lane + 64 * c;
+        const int32_t xx = x[j], yy = y[j];
+        const int32_t tt = sub ? t[j] - xx : t[j] + xx, uu = sub ? u[j] - yy : u[j] + yy;
+        t[j] = tt; u[j] = uu;
+        num += xx * xx + yy * yy;
+        den += tt * xx + uu * yy;
+    }
+    num = wave_sum(num); den = wave_sum(den);
+    const double inv_sig2 = 1.0 / ((double)P.sigma * P.sigma);
+    const double thresh = 1.0 / (P.m * exp(-0.5 * inv_sig2 * num) * cosh(inv_sig2 * den));
+    const double rr = T.dbl();
+    if (lane == 0) { s.pos[item] = T.pos; s.var_buf[item] = T.var_buf; s.var_bits[item] = T.var_bits; }
+    if (T.underrun) { if (lane == 0) { s.status[item] = 2; siglens[item] = 0; } return; }
+    if (rr > thresh) { reject(); return; }
+
+    // signature_gen (bliss_b.c:1045-1075; its Barrett multiplier is built from q, not p - kept) + check_norms (:1010-1043)
+    const int32_t mm = (1 << 30) / P.q, q2 = 2 * P.q, p2 = P.p >> 1;
+    int32_t maxt = 0, maxz = 0, nt = 0, nz = 0;
+    for (int c = 0; c < C; c++) {
+        const int j = lane + 64 * c;
+        int32_t tmp = v[(size_t)aidx * n + j] - u[j];
+        tmp += (tmp < 0) * q2;
+        tmp -= (tmp >= q2) * q2;
+        tmp = ((tmp + (1 << (P.d - 1))) >> P.d);
+        tmp = tmp - ((tmp * mm) >> 30) * P.p;
+        tmp -= (P.p <= tmp) * P.p;
+        tmp = (int32_t)z[(size_t)aidx * n + j] - tmp;
+        tmp += (tmp <= -p2) * P.p;
+        tmp -= (tmp > p2) * P.p;
+        const int32_t zz = (int32_t)(int16_t)tmp, tt = t[j];
+        x[j] = tt; y[j] = zz;                                            // staged for the packer
+        maxt = max(maxt, max(tt, -tt)); maxz = max(maxz, max(zz, -zz));
+        nt += tt * tt; nz += zz * zz;
+    }
+    maxt = wave_max(maxt); maxz = wave_max(maxz); nt = wave_sum(nt); nz = wave_sum(nz);
+    if (maxt > P.b_inf || (maxz << P.d) > P.b_inf || nt + (nz << (2 * P.d)) > P.b_l2) { reject(); return; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        BitW bw{ sigs + (size_t)item * sig_stride, 0, 0, 0 };
+        for (int j = 0; j < n; j++) bw.put((uint32_t)x[j], P.z1_bits);
+        for (int j = 0; j < n; j++) bw.put((uint32_t)y[j], P.z2_bits);
+        for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);
+        bw.flush();
+        siglens[item] = bw.nbytes;
+        trials[item] = it + 1;
+        s.status[item] = 1;
+        s.iter[item] = it + 1;
+    }
+}
+
+// ---- verify -----------------------------------------------------------------------------------------------------------
+
+// unpack t (z1_bits, signed), z (z2_bits, signed), c_idx (n_bits): bliss_b.c:1641-1657
+__global__ void bl_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, int32_t *t, int16_t *z, int32_t *cidx,
+                                 uint32_t *verdict, BlissP P)
+{
+    const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * P.n + P.kappa;
+    const uint32_t item = (uint32_t)(tt / per); const int e = (int)(tt % per);
+    if (item >= count) return;
+    const uint32_t need_bits = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits);
+    if (siglens[item] * 8 < need_bits) { if (e == 0) verdict[item] = 1; if (e < P.n) t[(size_t)item * P.n + e] = 0; return; }
+    int bits; uint32_t off;
+    if (e < P.n) { bits = P.z1_bits; off = (uint32_t)e * P.z1_bits; }
+    else if (e < 2 * P.n) { bits = P.z2_bits; off = (uint32_t)(P.n * P.z1_bits + (e - P.n) * P.z2_bits); }
+    else { bits = P.n_bits; off = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + (e - 2 * P.n) * P.n_bits); }
+    const uint8_t *s = sigs + (size_t)item * sig_stride;
+    uint32_t val = 0;
+    for (int b = 0; b < bits; b++) { const uint32_t bp = off + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+    if (e < P.n) t[(size_t)item * P.n + e] = (int32_t)(val << (32 - bits)) >> (32 - bits);
+    else if (e < 2 * P.n) z[(size_t)item * P.n + (e - P.n)] = (int16_t)((int32_t)(val << (32 - bits)) >> (32 - bits));
+    else cidx[(size_t)item * P.kappa + (e - 2 * P.n)] = (int32_t)val;
+}
+
+// check_norms on the received (t, z): one wavefront per signature
+__global__ __launch_bounds__(256) void bl_vnorm_kernel(const int32_t *t, const int16_t *z, uint32_t count, uint32_t *verdict, BlissP P)
+{
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n;
+    const uint32_t item = blockIdx.x * 4 + wid;
+    if (item >= count) return;
+    int32_t maxt = 0, maxz = 0, nt = 0, nz = 0;
+    for (int j = lane; j < n; j += 64) {
+        const int32_t tt = t[(size_t)item * n + j], zz = z[(size_t)item * n + j];
+        maxt = max(maxt, max(tt, -tt)); maxz = max(maxz, max(zz, -zz));
+        nt += tt * tt; nz += zz * zz;
+    }
+    maxt = wave_max(maxt); maxz = wave_max(maxz); nt = wave_sum(nt); nz = wave_sum(nz);
+    if (lane == 0 && (maxt > P.b_inf || (maxz << P.d) > P.b_inf || nt + (nz << (2 * P.d)) > P.b_l2)) verdict[item] = 1;
+}
+
+// v += (v & 1) q ; then the kappa single-coefficient corrections, in order (bliss_b.c:1690-1698)
+__global__ void bl_vparity_kernel(int32_t *v, size_t len, int32_t q)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) { const int32_t x = v[i]; v[i] = x + (x & 1) * q; }
+}
+__global__ void bl_vcidx_kernel(int32_t *v, const int32_t *cidx, uint32_t count, BlissP P)
+{
+    const uint32_t item = blockIdx.x * blockDim.x + threadIdx.x;
+    if (item >= count) return;
+    const int32_t two_q = 2 * P.q;
+    for (int k = 0; k < P.kappa; k++) {
+        int32_t *p = v + (size_t)item * P.n + cidx[(size_t)item * P.kappa + k];
+        *p = barrett((int64_t)*p + P.q, (1 << 30) / two_q, two_q);
+    }
+}
+// z <- ((v + 2^(d-1)) >> d) + z mod p  (bliss_b.c:1700-1706)
+__global__ void bl_vz_kernel(const int32_t *v, int16_t *z, size_t len, BlissP P)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    int32_t tmp = ((v[i] + (1 << (P.d - 1))) >> P.d) + z[i];
+    tmp -= (tmp >= P.p) * P.p;
+    tmp += (tmp < 0) * P.p;
+    z[i] = (int16_t)tmp;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+
+struct sc_hip_bliss {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    sc_hip_cdt *cdt;
+    BlissP P;
+    bool have_key;
+    int16_t *d_f, *d_g;
+    int32_t *d_a;
+    size_t cap;
+    St st;
+    uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
+    int32_t *tu, *tin, *v, *cidx;
+    int16_t *z;
+};
+
+static void bl_free_ws(sc_hip_bliss *b)
+{
+    void *ptrs[] = { b->st.pos, b->st.var_buf, b->st.iter, b->st.cur, b->st.status, b->st.var_bits, b->act[0], b->act[1], b->cnt, b->need, b->sbase, b->ok,
+                     b->trials, b->tu, b->tin, b->v, b->cidx, b->z };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    memset(&b->st, 0, sizeof b->st);
+    b->act[0] = b->act[1] = b->cnt = b->need = b->sbase = b->ok = b->trials = nullptr;
+    b->tu = b->tin = b->v = b->cidx = nullptr; b->z = nullptr; b->cap = 0;
+}
+
+static int bl_ensure_ws(sc_hip_bliss *b, size_t batch)
+{
+    if (batch <= b->cap) return SC_HIP_SUCCESS;
+    bl_free_ws(b);
+    const size_t n = b->P.n;
+#define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
+    WS(b->st.pos, batch * 4); WS(b->st.var_buf, batch * 4); WS(b->st.iter, batch * 4); WS(b->st.cur, batch * 4); WS(b->st.status, batch * 4); WS(b->st.var_bits, batch * 4);
+    WS(b->act[0], batch * 4); WS(b->act[1], batch * 4); WS(b->cnt, 64); WS(b->need, batch * 4); WS(b->sbase, batch * 4); WS(b->ok, batch * 4); WS(b->trials, batch * 4);
+    WS(b->tu, batch * 2 * n * 4); WS(b->tin, batch * n * 4); WS(b->v, batch * n * 4); WS(b->cidx, batch * (size_t)b->P.kappa * 4); WS(b->z, batch * n * 2);
+#undef WS
+    b->cap = batch;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_t *params, sc_hip_bliss_t **out)
+{
+    if (!ctx || !params || !out) return fail("bliss_create: null argument");
+    static_assert(sizeof(BlissP) == sizeof(sc_hip_bliss_params_t), "parameter struct layout");
+    BlissP P; memcpy(&P, params, sizeof P);
+    if (P.n != 256 && P.n != 512) return fail("bliss_create: n must be 256 or 512");
+    if (P.kappa < 1 || P.kappa > 64 || P.n_bits < 1 || (1 << P.n_bits) != P.n) return fail("bliss_create: bad kappa / n_bits");
+    if (P.z1_bits < 2 || P.z1_bits > 24 || P.z2_bits < 2 || P.z2_bits > 16 || P.d < 1 || P.d > 20 || P.p < 2) return fail("bliss_create: bad packing / rounding parameters");
+    sc_hip_plan *plan = nullptr; sc_hip_cdt *cdt = nullptr;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    if (sc_hip_cdt_create(ctx, P.tail, P.sigma, &cdt) != SC_HIP_SUCCESS) { sc_hip_plan_destroy(plan); return SC_HIP_FAILURE; }
+    sc_hip_bliss *b = new sc_hip_bliss;
+    memset(b, 0, sizeof *b);
+    b->ctx = ctx; b->plan = plan; b->cdt = cdt; b->P = P;
+    *out = b;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
+{
+    if (!b) return;
+    bl_free_ws(b);
+    if (b->d_f) (void)hipFree(b->d_f);
+    if (b->d_g) (void)hipFree(b->d_g);
+    if (b->d_a) (void)hipFree(b->d_a);
+    sc_hip_cdt_destroy(b->cdt);
+    sc_hip_plan_destroy(b->plan);
+    delete b;
+}
+
+// f, g: private key (SINT16[n] each, bliss_b.c:1328-1330; may be NULL for a verify-only handle); a: public key in the NTT domain
+extern "C" int sc_hip_bliss_set_key(sc_hip_bliss_t *b, const int16_t *f, const int16_t *g, const int16_t *a)
+{
+    if (!b || !a) return fail("bliss_set_key: null argument");
+    if ((f == nullptr) != (g == nullptr)) return fail("bliss_set_key: f and g go together");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    const size_t n = b->P.n;
+    std::vector<int32_t> a32(n);
+    for (size_t i = 0; i < n; i++) a32[i] = a[i];
+    if (!b->d_a) HIPCHK(hipMalloc((void **)&b->d_a, n * 4));
+    HIPCHK(hipMemcpy(b->d_a, a32.data(), n * 4, hipMemcpyHostToDevice));
+    if (f) {
+        if (!b->d_f) HIPCHK(hipMalloc((void **)&b->d_f, n * 2));
+        if (!b->d_g) HIPCHK(hipMalloc((void **)&b->d_g, n * 2));
+        HIPCHK(hipMemcpy(b->d_f, f, n * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b->d_g, g, n * 2, hipMemcpyHostToDevice));
+    }
+    b->have_key = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *b)
+{
+    if (!b) return 0;
+    return ((size_t)b->P.n * (b->P.z1_bits + b->P.z2_bits) + (size_t)b->P.kappa * b->P.n_bits + 7) / 8;
+}
+
+extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                 const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                 uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!b) return fail("bliss_sign: null handle");
+    if (!b->have_key || !b->d_f) return fail("bliss_sign: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("bliss_sign: batch too large");
+    if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("bliss_sign: null buffer");
+    if (!d_mlens && fixed_len == 0) return fail("bliss_sign: empty messages are rejected by the reference's oracle (bliss_b.c:571-574)");
+    if (sig_stride < sc_hip_bliss_sig_bytes(b)) return fail("bliss_sign: sig_stride smaller than sc_hip_bliss_sig_bytes()");
+    if (tape_stride > 0xffffffffu) return fail("bliss_sign: tape too long");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (bl_ensure_ws(b, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const BlissP &P = b->P;
+    const uint32_t B = (uint32_t)batch;
+    const int n = P.n;
+    St st = b->st;
+    HIPCHK(hipMemsetAsync(st.pos, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_buf, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_bits, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(st.iter, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.cur, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.status, 0, batch * 4, s));
+    uint32_t *trials = d_trials ? d_trials : b->trials;
+    HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
+    uint32_t nact = B;
+    const uint32_t *active = nullptr;
+    for (uint32_t round = 0; nact > 0; round++) {
+        if (round > 100000) return fail("bliss_sign: rejection loop did not terminate");
+        uint32_t *next = b->act[round & 1];
+        HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
+        hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, d_tape_lens, (uint32_t)tape_stride, n, b->need, b->sbase, d_siglens, d_mlens);
+        const size_t nsamp = (size_t)nact * 2 * n;
+        size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
+        if (sblocks > (size_t)b->ctx->cus * 4) sblocks = (size_t)b->ctx->cus * 4;
+        hipLaunchKernelGGL(bl_sample_kernel, dim3((unsigned)sblocks), dim3(256), sizeof(uint64_t) * (size_t)b->cdt->size, s, active, nact, b->need, b->sbase, st.cur,
+                           d_tapes, tape_stride, b->cdt->d_cdf, b->cdt->size, b->tu, n);
+        const size_t ne = (size_t)nact * n;
+        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, b->tu, b->tin, n);
+        HIPCHK(hipGetLastError());
+        if (sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, b->tu, b->v, b->z, P);
+        hipLaunchKernelGGL(bl_oracle_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, d_msgs, msg_stride, d_mlens, fixed_len, b->z, b->cidx, b->ok,
+                           0, (uint32_t *)nullptr, P);
+        hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, d_tapes, tape_stride, d_tape_lens,
+                           b->d_f, b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P);
+        HIPCHK(hipGetLastError());
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nact = cnt;
+        active = next;
+    }
+    if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_bliss_verify(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                   const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (!b) return fail("bliss_verify: null handle");
+    if (!b->have_key) return fail("bliss_verify: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("bliss_verify: batch too large");
+    if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("bliss_verify: null buffer");
+    if (!d_mlens && fixed_len == 0) return fail("bliss_verify: empty messages are rejected by the reference's oracle");
+    if (sig_stride < sc_hip_bliss_sig_bytes(b)) return fail("bliss_verify: sig_stride smaller than sc_hip_bliss_sig_bytes()");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (bl_ensure_ws(b, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const BlissP &P = b->P;
+    const uint32_t B = (uint32_t)batch;
+    const int n = P.n;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    const size_t nu = batch * (size_t)(2 * n + P.kappa), ne = batch * (size_t)n;
+    hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
+    hipLaunchKernelGGL(bl_vnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, b->tin, b->z, B, d_verdicts, P);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(b->plan, batch, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(bl_vparity_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, b->v, ne, P.q);
+    hipLaunchKernelGGL(bl_vcidx_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b->v, b->cidx, B, P);
+    hipLaunchKernelGGL(bl_vz_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, b->v, b->z, ne, P);
+    hipLaunchKernelGGL(bl_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len,
+                       b->z, b->cidx, (uint32_t *)nullptr, 1, d_verdicts, P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}

@@ -39,6 +39,10 @@ struct sc_hip_plan {
     size_t mv_cap;
 };
 
+namespace sc {
+int polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream);
+}
+
 struct sc_hip_cdt {
     sc_hip_ctx *ctx;
     float tail, sigma;

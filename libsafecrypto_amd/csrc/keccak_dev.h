@@ -100,9 +100,10 @@ struct Sponge {
             for (; i + 8 <= len; i += 8) absorb_u64(*reinterpret_cast<const uint64_t *>(p + i));
         for (; i < len; i++) absorb_byte(p[i]);
     }
-    __device__ __forceinline__ void finalize()
+    // pad = 0x1F: SHAKE (tinysha3.c:382-388); pad = 0x06: fixed-output SHA-3 (tinysha3.c:334-340)
+    __device__ __forceinline__ void finalize(uint32_t pad = 0x1F)
     {
-        st[(pos >> 3) * NT] ^= (uint64_t)0x1F << (8 * (pos & 7));
+        st[(pos >> 3) * NT] ^= (uint64_t)pad << (8 * (pos & 7));
         st[((rate - 1) >> 3) * NT] ^= (uint64_t)0x80 << (8 * ((rate - 1) & 7));
         permute();
         pos = 0;

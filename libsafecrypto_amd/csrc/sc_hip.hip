@@ -26,6 +26,7 @@ struct NttArgs {
     const uint32_t *zf, *zfp;     // forward twiddles zeta[k] = g^bitrev(k) and Shoup companions
     const uint32_t *zi, *zip;     // inverse twiddles zeta[k]^-1 and companions
     unsigned long long batch;
+    unsigned in1_bcast;           // != 0: every polynomial is multiplied by the SAME second operand (a public key)
     ModK k;
     uint32_t c0, c0p, c1, c1p;    // inverse output scale (n^-1 [* 2^32]) and zeta[1]^-1 * scale
 };
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
         if (OP == OP_MULNTT || OP == OP_MUL) {
-            const int32_t *srcb = a.in1 + base + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
+            const int32_t *srcb = a.in1 + (a.in1_bcast ? 0 : base) + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
             for (int r = 0; r < 16; r++) nb[r] = valid ? srcb[(OP == OP_MULNTT ? brv4(r) : r) * LP] : 0;
         }
@@ -408,7 +409,7 @@ static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, in
     }
 }
 
-static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream)
+static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream, bool bcast = false)
 {
     if (!p) return fail("ntt: null plan");
     if (batch == 0) return SC_HIP_SUCCESS;
@@ -417,7 +418,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int mi = p->mode == MODE_U24 ? 0 : 1;
     const int n = p->n;
     NttArgs a;
-    a.in0 = d0; a.in1 = d1; a.out = dout;
+    a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
     a.zf = p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
     const uint32_t *c = (op == OP_INV) ? p->c_inv[mi] : p->c_mont[mi];
@@ -444,6 +445,9 @@ extern "C" int sc_hip_ntt_inv(sc_hip_plan_t *p, size_t batch, const int32_t *d_i
 { return run_ntt(p, OP_INV, batch, d_in, nullptr, d_out, stream); }
 extern "C" int sc_hip_polymul_ntt(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
 { return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream); }
+// internal: out[b] = INTT(NTT(a[b]) o bhat) with ONE NTT-domain operand for the whole batch (bliss_b.c:1378-1384: bhat = public key a)
+int sc::polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
+{ return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream, true); }
 extern "C" int sc_hip_polymul(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
 { return run_ntt(p, OP_MUL, batch, d_a, d_b, d_out, stream); }
 

@@ -20,6 +20,7 @@ SYMBOLS = [
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -105,6 +106,14 @@ def load_library(path=LIB_PATH):
     L.sc_hip_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_shake_host.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, sz]
+    L.sc_hip_bliss_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_bliss_destroy.argtypes = [vp]
+    L.sc_hip_bliss_destroy.restype = None
+    L.sc_hip_bliss_set_key.argtypes = [vp, vp, vp, vp]
+    L.sc_hip_bliss_sig_bytes.argtypes = [vp]
+    L.sc_hip_bliss_sig_bytes.restype = sz
+    L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_time_op.argtypes = [vp, C.c_int, sz, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
     _LIB = L
     return L
@@ -145,6 +154,9 @@ class Engine:
 
     def plan(self, q, n):
         return NttPlan(self, q, n)
+
+    def bliss(self, params):
+        return Bliss(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -414,3 +426,55 @@ class Dilithium:
         v = np.ones(n, dtype=np.uint32)
         _chk(self.L, self.L.sc_hip_dilithium_verify_host(self.h, n, _ptr(buf), stride, _ptr(lens), 0, _ptr(sb), sstride, _ptr(sl), _ptr(v)), 'dilithium_verify_host')
         return [int(x) for x in v]
+
+
+class Bliss:
+    """Batched BLISS-B sign / verify under one key (bliss_b_sign / bliss_b_verify counterpart).
+    params: the 16 words of the fixture record {n,q,q_bits,n_bits,d,p,kappa,b_inf,b_l2,z1_bits,z2_bits,set, f32 sigma, f32 M, f32 tail, 0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 16
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_bliss_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_bliss_create')
+        self.h = h
+        self.n = int(self.par[0])
+        self.sig_bytes = self.L.sc_hip_bliss_sig_bytes(h)
+        self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_bliss_destroy(self.h)
+            self.h = None
+
+    def set_key(self, f, g, a):
+        import numpy as np
+        fa = np.ascontiguousarray(np.asarray(f), dtype=np.int16) if f is not None else None
+        ga = np.ascontiguousarray(np.asarray(g), dtype=np.int16) if g is not None else None
+        aa = np.ascontiguousarray(np.asarray(a), dtype=np.int16)
+        _chk(self.L, self.L.sc_hip_bliss_set_key(self.h, _ptr(fa) if fa is not None else C.c_void_p(), _ptr(ga) if ga is not None else C.c_void_p(), _ptr(aa)), 'bliss_set_key')
+
+    def sign(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        """msgs uint8 [batch][stride], tapes int32/uint32 [batch][tape_stride] (device tensors)"""
+        import torch
+        batch = msgs.shape[0]
+        dev = msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        trials = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_bliss_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                              _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+                                              _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'bliss_sign')
+        return sigs, siglens, trials, status
+
+    def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
+        return verdicts

@@ -1,0 +1,130 @@
+"""GPU parity for batched BLISS-B sign / verify (C ABI: sc_hip_bliss_*): byte-identical to signatures the
+reference produced from the same (key, message, CSPRNG word tape), and to the pinned oracle on seeded tapes."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from libsafecrypto_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('bliss_ref.txt')
+
+
+def cases(G, tag='bliss1'):
+    out, i = [], 0
+    while f'{tag}_msg{i}' in G:
+        out.append((bytes(G[f'{tag}_msg{i}'].astype(np.uint8)), (G[f'{tag}_tape{i}'].astype(np.int64) & 0xFFFFFFFF).astype(np.uint32),
+                    bytes(G[f'{tag}_sig{i}'].astype(np.uint8)), int(G[f'{tag}_trials'][i])))
+        i += 1
+    return out
+
+
+def pack(msgs, tapes, tape_words):
+    import torch
+    n = len(msgs)
+    stride = max(8, (max(len(m) for m in msgs) + 7) & ~7)
+    mb = np.zeros((n, stride), dtype=np.uint8)
+    for i, m in enumerate(msgs):
+        mb[i, :len(m)] = np.frombuffer(m, dtype=np.uint8)
+    tb = np.zeros((n, tape_words), dtype=np.uint32)
+    tl = np.zeros(n, dtype=np.int32)
+    for i, t in enumerate(tapes):
+        k = min(len(t), tape_words)
+        tb[i, :k] = t[:k]; tl[i] = k
+    return (torch.from_numpy(mb).cuda(), torch.from_numpy(np.array([len(m) for m in msgs], dtype=np.int32)).cuda(),
+            torch.from_numpy(tb.view(np.int32)).cuda(), torch.from_numpy(tl).cuda())
+
+
+def test_sign_reproduces_reference_signatures(eng, G):
+    import torch
+    key = O.BlissKey.from_golden(G, 'bliss1')
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    cs = cases(G)
+    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], 4200)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    torch.cuda.synchronize()
+    sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
+    assert status.cpu().tolist() == [1] * len(cs)
+    for i, (_, _, sig, tr) in enumerate(cs):
+        assert bytes(sh[i, :lh[i]]) == sig, i
+        assert int(trials[i]) == tr
+    v = b.verify(msgs, sigs, siglens, mlens=mlens)
+    assert v.cpu().tolist() == [0] * len(cs)
+    bad = sigs.clone(); bad[:, 986 // 3] ^= 0x04                    # the fixture's tampering
+    assert b.verify(msgs, bad, siglens, mlens=mlens).cpu().tolist() == [int(G['bliss1_verify'][2 * i + 1]) for i in range(len(cs))] == [1] * len(cs)
+    b.close()
+
+
+def test_batch_vs_oracle_seeded_tapes(eng, G):
+    """1000 messages with seeded random tapes of 3 fresh attempts' worth: attempts, consumed-word bookkeeping and
+    signatures equal the oracle's; short tapes are reported (status 2), empty messages refused (status 3)"""
+    import torch
+    key = O.BlissKey.from_golden(G, 'bliss1')
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    rng = np.random.default_rng(77)
+    B, W = 1000, 3 * 2048 + 64
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8)) for _ in range(B)]
+    tapes = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+    tapes[5] = tapes[5][:1500]            # cannot even sample once
+    tapes[6] = tapes[6][:2049]            # runs dry inside prng_double
+    msgs[7] = b''
+    m_d, ml_d, t_d, tl_d = pack(msgs, tapes, W)
+    sigs, siglens, trials, status = b.sign(m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+    torch.cuda.synchronize()
+    sh, lh, st, tr = sigs.cpu().numpy(), siglens.cpu().numpy(), status.cpu().numpy(), trials.cpu().numpy()
+    assert st[5] == 2 and st[6] == 2 and st[7] == 3 and lh[5] == 0
+    checked = multi = 0
+    for i in list(range(0, B, 9)) + [i for i in range(B) if tr[i] >= 3][:10]:
+        if i in (5, 6, 7):
+            continue
+        rc, es, et, _ = O.bliss_sign(key, msgs[i], tapes[i])
+        assert (rc == 0) == (st[i] == 1), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == es and tr[i] == et, i
+            checked += 1; multi += et >= 2
+    assert checked > 100 and multi > 5
+    ok = st == 1
+    v = b.verify(m_d, sigs, siglens, mlens=ml_d).cpu().numpy()
+    assert np.all(v[ok] == 0) and np.all(v[~ok] == 1)
+    for i in range(0, B, 97):
+        if ok[i]:
+            assert O.bliss_verify(key, msgs[i], bytes(sh[i, :lh[i]])) == 0
+    b.close()
+
+
+def test_full_config4_shape_properties(eng, G):
+    """BASELINE config 3 shape: BLISS-B-I, batch 16384, 64-byte messages, device-resident buffers: everything signs
+    (2 fresh attempts of tape suffice for all but a handful), verifies, and tampering is caught"""
+    import torch
+    key = O.BlissKey.from_golden(G, 'bliss1')
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    B, W = 16384, 4 * 2048 + 64
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, W), dtype=torch.int32, device='cuda', generator=g)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, fixed_len=64)
+    torch.cuda.synchronize()
+    ok = status == 1
+    assert int(ok.sum()) > B - 20
+    assert 1.1 < float(trials[ok].float().mean()) < 1.6            # 1.27 trials per signature
+    assert int(b.verify(msgs, sigs, siglens, fixed_len=64)[ok].sum()) == 0
+    bad = msgs.clone(); bad[::3, 0] ^= 1
+    v = b.verify(bad, sigs, siglens, fixed_len=64)
+    assert torch.equal((v != 0).cpu() | ~ok.cpu(), (torch.arange(B) % 3 == 0) | ~ok.cpu())
+    mh, th, sh, lh = msgs.cpu().numpy(), tapes.cpu().numpy().view(np.uint32), sigs.cpu().numpy(), siglens.cpu().numpy()
+    for i in (0, 8191, 16383):
+        rc, es, _, _ = O.bliss_sign(key, bytes(mh[i]), th[i])
+        assert rc == 0 and bytes(sh[i, :lh[i]]) == es
+    b.close()
