@@ -1,0 +1,245 @@
+// mlwe_kernels.h - the NTT-shaped kernels of the module-LWE schemes (Dilithium, Kyber): n = 256, 16 lanes per
+// polynomial, 4 polynomials per wavefront, 32-bit Shoup arithmetic, NTT-domain data kept in the engine's internal order
+// (position j = lane*16 + r holds natural index bitrev8(j): 16 contiguous words per lane).  Included by dilithium.hip
+// and kyber.hip; everything has internal linkage.
+#pragma once
+#include "engine_internal.h"
+#include "ntt_core.h"
+#include <string.h>
+
+namespace sc_mlwe {
+using namespace sc;
+
+constexpr int L8 = 8, N = 256, LP = 16, PW = 4;
+
+__host__ __device__ constexpr int brv4c(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+// round_alpha, module_lwe.h:52-66,110-136, alpha = 2*gamma_2, Barrett m = floor(2^30/alpha), k = 30
+__device__ __forceinline__ uint32_t round_alpha(uint32_t a, int32_t &a0, int32_t alpha, int32_t am, int32_t q)
+{
+    int64_t t = ((int64_t)a * am) >> 30, c = (int64_t)a - t * alpha;
+    if (alpha <= c) c -= alpha;
+    a0 = (int32_t)c;
+    if (a0 > (alpha >> 1)) a0 -= alpha;
+    uint32_t a1 = a - (uint32_t)a0;
+    if (a1 == (uint32_t)(q - 1)) { a1 = 0; a0 -= 1; }
+    else {
+        int64_t t2 = ((int64_t)a1 * am) >> 30, c2 = (int64_t)a1 - t2 * alpha;
+        if (alpha <= c2) t2++;
+        a1 = (uint32_t)t2;
+    }
+    return a1;
+}
+
+// check_norm_inf on one canonical value, dilithium.c:1185-1200
+__device__ __forceinline__ bool norm_bad(uint32_t v, uint32_t q, uint32_t b)
+{
+    const uint32_t lower_half = (q - 1) >> 1;
+    return (v <= lower_half) ? (v >= b) : (v <= q - b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT-shaped kernels (n = 256: 16 lanes per polynomial, 4 polynomials per wave, 32-bit Shoup path)
+// ------------------------------------------------------------------------------------------------
+
+enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CZ = 2, DOP_CS2 = 3, DOP_CT0 = 4, DOP_CT1 = 5, DOP_KEYPREP = 6 };
+
+struct DilNtt {
+    const uint32_t *zf, *zfp, *zi, *zip;
+    ModK k;
+    uint32_t c0, c0p, c1, c1p;            // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs): Montgomery-form keys need no 2^32 fix
+    uint32_t r2, r2p;                     // 2^32 mod q (Shoup pair)
+    uint32_t njobs;                       // slots * per (every per-attempt array is indexed by slot)
+    int per;                              // polynomials per item handled by this launch
+    int l, kk;
+    int32_t alpha, am, gamma1_beta, gamma2_beta, d;
+    const int32_t *in;                    // DOP_FWD_INT / KEYPREP: natural-order input [item][per][n]
+    uint32_t *out_int;                    // DOP_FWD_INT / KEYPREP: internal-order canonical (KEYPREP: Montgomery form)
+    const uint32_t *yh;                   // [item][l][n] internal
+    const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
+    const uint32_t *ch;                   // [item][n] internal (NTT of c)
+    const int32_t *y;                     // [item][l][n] natural (mask)
+    int32_t *w;                           // [item][k][n] natural canonical
+    uint8_t *w1;                          // [item][k*n]
+    int32_t *z;                           // [item][l][n]
+    int32_t *r;                           // [item][k][n]  (w - c s2)
+    uint8_t *h;                           // [item][k*n]
+    uint32_t *flags, *ones;               // per item
+};
+
+template <int OP>
+__global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pw = lane / LP, lp = lane % LP;
+    uint32_t *lds_poly = lds + wid * 1024 + pw * N;
+    const ModK k = a.k;
+    TwSet<L8> tw;
+    if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) tw.load(a.zf, a.zfp, lp); else tw.load(a.zi, a.zip, lp);
+
+    const uint32_t groups = (a.njobs + PW - 1) / PW;
+    for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
+        const uint32_t job = g * PW + pw;
+        const bool valid = job < a.njobs;
+        const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
+        const uint32_t item = aidx;           // slot index
+        uint32_t x[16];
+
+        if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) {
+            const int32_t *src = a.in + ((size_t)item * a.per + sub) * N + lp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(src[r * LP], k) : 0u;
+            fwd_core<L8, MODE_U32, true>(x, tw, lds_poly, lp, k);
+            uint32_t *dst = a.out_int + ((size_t)item * a.per + sub) * N + lp * 16;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                uint32_t v = csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+                if (OP == DOP_KEYPREP) v = csub(Mod<MODE_U32>::mulc(v, a.r2, a.r2p, k), k.q);
+                x[r] = v;
+            }
+            if (valid) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) reinterpret_cast<uint4 *>(dst)[c] = make_uint4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+            }
+            continue;
+        }
+
+        // NTT-domain product(s) in internal order (16 contiguous words per lane)
+        if (OP == DOP_MATVEC) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = 0;
+            for (int j = 0; j < a.l; j++) {
+                const uint4 *py = reinterpret_cast<const uint4 *>(a.yh + ((size_t)item * a.l + j) * N + lp * 16);
+                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + ((size_t)sub * a.l + j) * N + lp * 16);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint4 vy = valid ? py[c] : make_uint4(0, 0, 0, 0), va = pa[c];
+                    x[4 * c + 0] = csub(x[4 * c + 0] + montmul(vy.x, va.x, k), k.q2);
+                    x[4 * c + 1] = csub(x[4 * c + 1] + montmul(vy.y, va.y, k), k.q2);
+                    x[4 * c + 2] = csub(x[4 * c + 2] + montmul(vy.z, va.z, k), k.q2);
+                    x[4 * c + 3] = csub(x[4 * c + 3] + montmul(vy.w, va.w, k), k.q2);
+                }
+            }
+        } else {
+            const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)item * N + lp * 16);
+            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)sub * N + lp * 16);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint4 vc = valid ? pc[c] : make_uint4(0, 0, 0, 0), vk = pk[c];
+                x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
+                x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
+            }
+        }
+        inv_core<L8, MODE_U32>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
+        if (!valid) continue;
+
+        const size_t pk_off = ((size_t)item * a.kk + sub) * N + lp;     // [item][k][n] arrays
+        const size_t pl_off = ((size_t)item * a.l + sub) * N + lp;      // [item][l][n] arrays
+        if (OP == DOP_MATVEC) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int32_t a0;
+                a.w[pk_off + r * LP] = (int32_t)x[r];
+                if (a.w1) a.w1[pk_off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
+            }
+        } else if (OP == DOP_CZ) {            // z = y + c s1, normalize, ||z||inf < gamma1 - beta
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t yy = reduce_i32(a.y[pl_off + r * LP], k);
+                const uint32_t zz = csub(csub(x[r] + yy, k.q2), k.q);
+                a.z[pl_off + r * LP] = (int32_t)zz;
+                bad |= norm_bad(zz, k.q, (uint32_t)a.gamma1_beta);
+            }
+            if (bad) atomicOr(&a.flags[item], 1u);
+        } else if (OP == DOP_CS2) {           // r = w - c s2 ; ||LowBits(r)||inf < gamma2 - beta
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t rr = csub(ww + k.q - x[r], k.q);
+                a.r[pk_off + r * LP] = (int32_t)rr;
+                int32_t a0;
+                round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + (int32_t)k.q) : (uint32_t)a0;       // low_order_bits
+                bad |= norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
+            }
+            if (bad) atomicOr(&a.flags[item], 2u);
+        } else if (OP == DOP_CT0) {           // ct0 ; ||ct0||inf < gamma2 - beta ; hint = [HighBits(r + ct0) != HighBits(r)]
+            bool bad = false;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                bad |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta);
+                const uint32_t rr = (uint32_t)a.r[pk_off + r * LP];
+                const uint32_t s = csub(rr + x[r], k.q);        // wcs2 + ct0 (dilithium.c:1714-1715)
+                int32_t a0;
+                // make_hint (dilithium.c:1258-1284): r = s, z = q - ct0, (r + z) mod q == rr
+                const uint32_t hi_s = round_alpha(s, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t hi_r = round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
+                const uint32_t hb = hi_s != hi_r;
+                a.h[pk_off + r * LP] = (uint8_t)hb;
+                cnt += hb;
+            }
+            if (bad) atomicOr(&a.flags[item], 4u);
+            if (cnt) atomicAdd(&a.ones[item], cnt);
+        } else if (OP == DOP_CT1) {           // verify: w' = A z - c t1 2^d ; w1 = UseHint(h, w')   (dilithium.c:1286-1312)
+            const int32_t m = ((int32_t)k.q - 1) / a.alpha, m_mask = m - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t t = csub(ww + k.q - x[r], k.q);
+                int32_t a0;
+                int32_t a1 = (int32_t)round_alpha(t, a0, a.alpha, a.am, (int32_t)k.q);
+                if (a.h[pk_off + r * LP] == 1) { if (a0 > 0) a1++; else a1--; }
+                if (a1 < 0) a1 += m;
+                a.w1[pk_off + r * LP] = (uint8_t)(a1 & m_mask);
+            }
+        }
+    }
+}
+
+// natural-order NTT-domain array -> internal order, Montgomery form (for the expanded matrix A)
+// rows/cols != 0: the input is [cols][rows][n] and is transposed on the way (out is always [rows][cols][n])
+static __global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p, int rows = 0, int cols = 0)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoly * N) return;
+    size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
+    if (rows) p = (p % (size_t)cols) * (size_t)rows + p / (size_t)cols;
+    const uint32_t nat = __builtin_bitreverse32(j) >> 24;
+    uint32_t v = reduce_i32(in[p * N + nat], k);
+    out[i] = csub(Mod<MODE_U32>::mulc(v, r2, r2p, k), k.q);
+}
+
+
+// kernel arguments common to every launch for plan p (k x l module, rounding modulus alpha = 2*gamma_2)
+static inline DilNtt mlwe_base_args(sc_hip_plan *p, int kk, int l, int32_t gamma2)
+{
+    DilNtt a;
+    memset(&a, 0, sizeof a);
+    const int n = p->n;
+    a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.k = p->k[1];
+    a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
+    a.r2 = p->r2; a.r2p = p->r2p;
+    a.l = l; a.kk = kk;
+    a.alpha = 2 * gamma2; a.am = (1 << 30) / a.alpha;
+    return a;
+}
+
+template <int OP>
+static int mlwe_launch(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, int per, hipStream_t s)
+{
+    a.per = per; a.njobs = nitems * (uint32_t)per;
+    if (a.njobs == 0) return SC_HIP_SUCCESS;
+    size_t blocks = ((size_t)a.njobs + 15) / 16;
+    const size_t cap = (size_t)ctx->cus * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((dil_ntt_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+}  // namespace sc_mlwe

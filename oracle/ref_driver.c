@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_dil <set> <seconds>    (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
@@ -393,6 +393,79 @@ static int gen_bliss(const char *dir)
     return rc;
 }
 
+/* ----------------------------------------------------------------- Kyber ---- */
+
+#include "schemes/kem/kyber/kyber_kem.h"
+#include "schemes/kem/kyber/kyber_kem_params.h"
+
+/* Kyber (round 1, q = 7681) CPA encryption / decryption as kyber_kem_encapsulation / _decapsulation call them
+ * (kyber_kem.c:866,992): kyber_cpa_enc / kyber_cpa_dec of module_lwe.c:1268-1481 on a key made by the reference's keygen.
+ * The matrix is dumped in the order the CSPRNG generates it (k*k polynomials, module_lwe.c:519-547); the noise is the
+ * byte stream the (2k+1)*n/256 prng_mem(eta*64) calls of binomial_rand_sample_csprng return for seed r
+ * (module_lwe.c:380-412,1306-1316), read from a twin generator. */
+static int kyber_case(FILE *f, int set, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "kyber%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const kyber_set_t *P = sc->kyber->params;
+    const int n = P->n, k = P->k, eta = P->eta;
+    int32_t par[16] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->q_inv, (int32_t)P->q_norm, (int32_t)P->k, (int32_t)P->eta,
+                        (int32_t)P->d_u, (int32_t)P->d_v, (int32_t)P->d_t, set, 0, 0, 0, 0, 0 };
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 16);
+    const SINT32 *priv = (const SINT32 *)sc->privkey->key, *pub = (const SINT32 *)sc->pubkey->key;
+    const SINT32 *t_ntt = pub + k * n;
+    const UINT8 *rho = (const UINT8 *)(t_ntt + k * n);
+    snprintf(name, sizeof name, "%s_s_ntt", tag); rec_i32(f, name, priv, (size_t)k * n);
+    snprintf(name, sizeof name, "%s_t_ntt", tag); rec_i32(f, name, t_ntt, (size_t)k * n);
+    snprintf(name, sizeof name, "%s_rho", tag); rec_u8(f, name, rho, 32);
+    int32_t *G = malloc(sizeof(int32_t) * (size_t)k * k * n);
+    prng_ctx_t *cs = create_csprng(sc, rho, 32);
+    for (int i = 0; i < k * k; i++) uniform_random_ring_q_csprng(cs, G + (size_t)i * n, n, P->q, P->q_bits);
+    prng_destroy(cs);
+    snprintf(name, sizeof name, "%s_Agen", tag); rec_i32(f, name, G, (size_t)k * k * n);
+    free(G);
+    const int nbytes = (2 * k + 1) * n * eta / 4;
+    int32_t *u = malloc(sizeof(int32_t) * (size_t)(k + 1) * n * 2), *v = u + k * n, *u2 = v + n, *v2 = u2 + k * n;
+    int32_t *heap = calloc((size_t)(8 * k + 8) * n, sizeof(int32_t));
+    sm_state = 0x4b79626572ULL + set;
+    for (int mi = 0; mi < nmsg; mi++) {
+        uint8_t m[32], r[32], noise[8192], m2[32];
+        for (int i = 0; i < 32; i++) { m[i] = (uint8_t)splitmix64(); r[i] = (uint8_t)splitmix64(); }
+        if (mi == 0) memset(m, 0, 32);
+        if (mi == 1) memset(m, 0xFF, 32);
+        prng_ctx_t *tw = create_csprng(sc, r, 32);
+        for (int off = 0; off < nbytes; off += eta * 64) prng_mem(tw, noise + off, eta * 64);
+        prng_destroy(tw);
+        if (SC_FUNC_SUCCESS != kyber_cpa_enc(sc, 1, u, v, t_ntt, 1, rho, n, k, m, r, heap)) return 1;
+        snprintf(name, sizeof name, "%s_m%d", tag, mi); rec_u8(f, name, m, 32);
+        snprintf(name, sizeof name, "%s_noise%d", tag, mi); rec_u8(f, name, noise, nbytes);
+        snprintf(name, sizeof name, "%s_u%d", tag, mi); rec_i32(f, name, u, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_v%d", tag, mi); rec_i32(f, name, v, n);
+        memcpy(u2, u, sizeof(int32_t) * (size_t)k * n); memcpy(v2, v, sizeof(int32_t) * n);
+        if (SC_FUNC_SUCCESS != kyber_cpa_dec(sc, u2, v2, 1, priv, n, k, m2)) return 1;
+        snprintf(name, sizeof name, "%s_dec%d", tag, mi); rec_u8(f, name, m2, 32);
+    }
+    free(u); free(heap);
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_kyber(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/kyber_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = kyber_case(f, 1, 6);
+    rc |= kyber_case(f, 2, 2);
+    fclose(f);
+    return rc;
+}
+
 /* -------------------------------------------------------------- CPU baseline ---- */
 
 #include <time.h>
@@ -473,5 +546,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
+    if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
     return rc;
 }

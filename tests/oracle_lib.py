@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -56,8 +56,26 @@ def lib():
         L.orc_bliss_sign.argtypes = [i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
+        L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
+        L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
         _LIB = L
     return _LIB
+
+
+def kyber_enc(par, t_ntt, Agen, m, noise):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    par = f(par, np.int32)
+    n, k = int(par[0]), int(par[5])
+    u, v = np.zeros(k * n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    assert lib().orc_kyber_cpa_enc(par, f(t_ntt, np.int32), f(Agen, np.int32), f(m, np.uint8), f(noise, np.uint8), u, v) == 0
+    return u, v
+
+
+def kyber_dec(par, s_ntt, u, v):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    m = np.zeros(32, dtype=np.uint8)
+    assert lib().orc_kyber_cpa_dec(f(par, np.int32), f(s_ntt, np.int32), f(u, np.int32), f(v, np.int32), m) == 0
+    return m
 
 
 class BlissKey:
