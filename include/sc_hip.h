@@ -195,6 +195,30 @@ int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, si
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* ---- Kyber (round 1, q = 7681): batched CPA encryption / decryption under one key ------------ */
+
+/* kyber_set_t fields (src/utils/arith/module_lwe.h:70-93, values kyber_kem_params.c:24-49; set 1: k = 3) */
+typedef struct sc_hip_kyber_params {
+    int32_t n, q, q_bits; uint32_t q_inv; int32_t q_norm, k, eta, d_u, d_v, d_t, set, pad[5];
+} sc_hip_kyber_params_t;
+typedef struct sc_hip_kyber sc_hip_kyber_t;
+
+int  sc_hip_kyber_create(sc_hip_ctx_t *ctx, const sc_hip_kyber_params_t *params, sc_hip_kyber_t **h);
+void sc_hip_kyber_destroy(sc_hip_kyber_t *h);
+/* t_ntt [k][n]: NTT(t) as the public key stores it (kyber_kem.c:636-650); Agen [k*k][n]: the matrix polynomials in the order
+ * the CSPRNG seeded with rho generates them (module_lwe.c:519-547) - the host expands them once per key */
+int  sc_hip_kyber_set_pubkey(sc_hip_kyber_t *h, const int32_t *t_ntt, const int32_t *Agen);
+int  sc_hip_kyber_set_privkey(sc_hip_kyber_t *h, const int32_t *s_ntt);      /* NTT(s) [k][n], kyber_kem.c:624-639 */
+size_t sc_hip_kyber_noise_bytes(const sc_hip_kyber_t *h);                   /* (2k+1)*n*eta/4 */
+
+/* replaces: kyber_cpa_enc (module_lwe.c:1268-1401) for `batch` 32-byte messages d_m [batch][32]; d_noise [batch][noise_stride]
+ * holds, per message, the bytes binomial_rand_sample_csprng draws from the CSPRNG seeded with r (r, e1, e2 in that order);
+ * outputs the compressed ciphertext polynomials u int32 [batch][k][n] (d_u bits) and v int32 [batch][n] (d_v bits) */
+int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, const uint8_t *d_noise, size_t noise_stride,
+                         int32_t *d_u, int32_t *d_v, void *stream);
+/* replaces: kyber_cpa_dec (module_lwe.c:1415-1481); u, v are not modified; d_m [batch][32] */
+int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32_t *d_u, const int32_t *d_v, uint8_t *d_m, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

@@ -20,6 +20,8 @@ SYMBOLS = [
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
+    'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
+    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
     'sc_hip_time_op',
 ]
@@ -106,6 +108,15 @@ def load_library(path=LIB_PATH):
     L.sc_hip_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_shake_host.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, sz]
+    L.sc_hip_kyber_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_kyber_destroy.argtypes = [vp]
+    L.sc_hip_kyber_destroy.restype = None
+    L.sc_hip_kyber_set_pubkey.argtypes = [vp, vp, vp]
+    L.sc_hip_kyber_set_privkey.argtypes = [vp, vp]
+    L.sc_hip_kyber_noise_bytes.argtypes = [vp]
+    L.sc_hip_kyber_noise_bytes.restype = sz
+    L.sc_hip_kyber_cpa_enc.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp]
+    L.sc_hip_kyber_cpa_dec.argtypes = [vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_bliss_destroy.argtypes = [vp]
     L.sc_hip_bliss_destroy.restype = None
@@ -154,6 +165,9 @@ class Engine:
 
     def plan(self, q, n):
         return NttPlan(self, q, n)
+
+    def kyber(self, params):
+        return Kyber(self, params)
 
     def bliss(self, params):
         return Bliss(self, params)
@@ -478,3 +492,50 @@ class Bliss:
         _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
         return verdicts
+
+
+class Kyber:
+    """Batched Kyber (round 1) CPA encryption / decryption under one key (kyber_cpa_enc / kyber_cpa_dec counterpart).
+    params: {n,q,q_bits,q_inv,q_norm,k,eta,d_u,d_v,d_t,set,0,0,0,0,0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 16
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_kyber_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_kyber_create')
+        self.h = h
+        self.n, self.k = int(self.par[0]), int(self.par[5])
+        self.noise_bytes = self.L.sc_hip_kyber_noise_bytes(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_kyber_destroy(self.h)
+            self.h = None
+
+    def set_pubkey(self, t_ntt, Agen):
+        import numpy as np
+        a = [np.ascontiguousarray(np.asarray(x), dtype=np.int32) for x in (t_ntt, Agen)]
+        _chk(self.L, self.L.sc_hip_kyber_set_pubkey(self.h, _ptr(a[0]), _ptr(a[1])), 'kyber_set_pubkey')
+
+    def set_privkey(self, s_ntt):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(s_ntt), dtype=np.int32)
+        _chk(self.L, self.L.sc_hip_kyber_set_privkey(self.h, _ptr(a)), 'kyber_set_privkey')
+
+    def enc(self, m, noise):
+        """m uint8 [batch][32], noise uint8 [batch][stride >= noise_bytes] (device) -> u int32 [batch][k][n], v int32 [batch][n]"""
+        import torch
+        batch = m.shape[0]
+        u = torch.empty((batch, self.k, self.n), dtype=torch.int32, device=m.device)
+        v = torch.empty((batch, self.n), dtype=torch.int32, device=m.device)
+        _chk(self.L, self.L.sc_hip_kyber_cpa_enc(self.h, batch, _ptr(m), _ptr(noise), noise.stride(0), _ptr(u), _ptr(v), _stream()), 'kyber_cpa_enc')
+        return u, v
+
+    def dec(self, u, v):
+        import torch
+        batch = v.shape[0]
+        m = torch.empty((batch, 32), dtype=torch.uint8, device=v.device)
+        _chk(self.L, self.L.sc_hip_kyber_cpa_dec(self.h, batch, _ptr(u), _ptr(v), _ptr(m), _stream()), 'kyber_cpa_dec')
+        return m
