@@ -49,4 +49,5 @@ struct sc_hip_cdt {
     int size;
     std::vector<uint64_t> cdf;
     uint64_t *d_cdf;
+    uint16_t *d_guide;            // 257(+1) entries: max{b : cdf[b] < t*2^56}
 };

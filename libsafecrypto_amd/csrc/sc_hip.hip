@@ -197,24 +197,40 @@ __global__ __launch_bounds__(256) void ew_kernel(const int32_t *__restrict__ a, 
     }
 }
 
-// CDT sampler: the table (<= 4096 x u64 = 32 KB) is staged in LDS once per workgroup; each lane
-// then resolves samples with the reference's halving search (gaussian_cdf.c:536-553): the
-// largest index b reached with cdf[b] < x, sign from the LSB of x (:658).
-__global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, int size, const uint64_t *__restrict__ x,
+// CDT sampler.  The reference's halving search (gaussian_cdf.c:536-553) returns, for a monotone table, the largest index b
+// with cdf[b] < x (0 if there is none); the sign is the LSB of the same word (:658).  The same value is found faster through
+// a 257-entry guide table on the top byte of x: guide[t] = max{b : cdf[b] < t*2^56}, so the answer lies in
+// [guide[t], guide[t+1]] - one or two probes for a Gaussian table instead of log2(size).  Table (<= 32 KB) and guide in LDS,
+// two samples per lane per iteration (16-byte loads, 8-byte stores).
+__device__ __forceinline__ int32_t cdt_one(uint64_t u, const uint64_t *tab, const uint16_t *guide, int32_t centre)
+{
+    const uint32_t t = (uint32_t)(u >> 56);
+    uint32_t lo = guide[t], hi = guide[t + 1];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (tab[mid] < u) lo = mid; else hi = mid - 1;
+    }
+    return ((u & 1) ? (int32_t)lo : -(int32_t)lo) + centre;
+}
+
+__global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, const uint64_t *__restrict__ x,
                                                   int32_t *__restrict__ out, size_t count, int32_t centre)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size);
     for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
+    for (int i = threadIdx.x; i < 258; i += blockDim.x) guide[i] = gd[i];
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
-        const uint64_t u = x[i];
-        uint32_t a = 0;
-        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) {
-            const uint32_t b = a + st;            // b < size always holds for a power-of-two table
-            if (tab[b] < u) a = b;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, pairs = count / 2;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+    if (vec) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
+            const ulonglong2 u = reinterpret_cast<const ulonglong2 *>(x)[i];
+            reinterpret_cast<int2 *>(out)[i] = make_int2(cdt_one(u.x, tab, guide, centre), cdt_one(u.y, tab, guide, centre));
         }
-        out[i] = ((u & 1) ? (int32_t)a : -(int32_t)a) + centre;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && (count & 1)) out[count - 1] = cdt_one(x[count - 1], tab, guide, centre);
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = cdt_one(x[i], tab, guide, centre);
     }
 }
 
@@ -522,9 +538,23 @@ extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h
     sc_hip_cdt *c = new sc_hip_cdt;
     c->ctx = ctx; c->tail = 0.f; c->sigma = 0.f; c->size = size;
     c->cdf.assign(h_cdf, h_cdf + size);
-    c->d_cdf = nullptr;
+    c->d_cdf = nullptr; c->d_guide = nullptr;
+    // guide[t] = max{b : cdf[b] < t * 2^56} (0 if none), t = 0..256 (t = 256 stands for 2^64: every entry qualifies that is < 2^64)
+    uint16_t guide[258];
+    {
+        int b = 0;
+        for (int t = 0; t <= 256; t++) {
+            if (t == 256) { guide[t] = (uint16_t)(size - 1); break; }
+            const uint64_t lim = (uint64_t)t << 56;
+            while (b + 1 < size && h_cdf[b + 1] < lim) b++;
+            guide[t] = (uint16_t)((t == 0) ? 0 : ((h_cdf[b] < lim) ? b : 0));
+        }
+        guide[257] = guide[256];
+    }
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * size) != hipSuccess ||
-        hipMemcpy(c->d_cdf, c->cdf.data(), sizeof(uint64_t) * size, hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(c->d_cdf, c->cdf.data(), sizeof(uint64_t) * size, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&c->d_guide, sizeof guide) != hipSuccess || hipMemcpy(c->d_guide, guide, sizeof guide, hipMemcpyHostToDevice) != hipSuccess) {
+        if (c->d_cdf) (void)hipFree(c->d_cdf);
         delete c;
         return fail("cdt_create: cannot upload the table");
     }
@@ -543,7 +573,7 @@ extern "C" int sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_
     (*out)->tail = tail; (*out)->sigma = sigma;
     return SC_HIP_SUCCESS;
 }
-extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)hipFree(c->d_cdf); delete c; }
+extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)hipFree(c->d_cdf); if (c->d_guide) (void)hipFree(c->d_guide); delete c; }
 extern "C" int sc_hip_cdt_size(const sc_hip_cdt_t *c) { return c ? c->size : 0; }
 extern "C" int sc_hip_cdt_table(const sc_hip_cdt_t *c, uint64_t *h)
 {
@@ -557,12 +587,12 @@ extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *
     if (count == 0) return SC_HIP_SUCCESS;
     if (!d_uniform || !d_out) return fail("cdt_sample: null device pointer");
     HIPCHK(hipSetDevice(c->ctx->device));
-    size_t blocks = (count + 256 * 16 - 1) / (256 * 16);       // >= 16 samples per lane amortise the table load
+    size_t blocks = (count + 256 * 32 - 1) / (256 * 32);       // >= 32 samples per lane amortise the table load
     if (blocks == 0) blocks = 1;
     const size_t cap = (size_t)c->ctx->cus * 4;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(cdt_kernel, dim3((unsigned)blocks), dim3(256), sizeof(uint64_t) * (size_t)c->size, (hipStream_t)stream,
-                       c->d_cdf, c->size, d_uniform, d_out, count, centre);
+    hipLaunchKernelGGL(cdt_kernel, dim3((unsigned)blocks), dim3(256), sizeof(uint64_t) * (size_t)c->size + 520, (hipStream_t)stream,
+                       c->d_cdf, c->d_guide, c->size, d_uniform, d_out, count, centre);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
