@@ -91,6 +91,45 @@ def dilithium_extra(eng, torch, cpu_seconds):
     return out
 
 
+def bliss_kyber_extra(eng, torch):
+    """BASELINE configs[3] (BLISS-B-I sign with the CDT sampler on the GPU, batch 16384) and the scheme-level form of
+    configs[1] (Kyber set 1 CPA encryption / decryption, batch 65536); keys produced by the reference's keygen (fixtures)."""
+    from tests.golden_io import load_golden
+    out = {}
+    G = load_golden('bliss_ref.txt')
+    b = eng.bliss(G['bliss1_params']); b.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
+    g = torch.Generator(device='cuda'); g.manual_seed(11)
+    B, W = 16384, 4 * 2048 + 64
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, W), dtype=torch.int32, device='cuda', generator=g)
+    b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+    ts, tv = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); sigs, siglens, trials, status = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); v = b.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+    ok = status == 1
+    assert int(v[ok].sum()) == 0 and int(ok.sum()) > B - 20
+    out['bliss_b_1'] = {'workload': 'BASELINE configs[3]: BLISS-B-I (n=512, q=12289) sign with the CDT sampler on the GPU, batch 16384, 64-byte messages, '
+                                    'per-message CSPRNG word tapes resident in HBM', 'sign_ops_per_s': B / min(ts), 'verify_ops_per_s': B / min(tv),
+                        'mean_attempts_per_signature': float(trials[ok].float().mean())}
+    b.close()
+    G = load_golden('kyber_ref.txt')
+    ky = eng.kyber(G['kyber1_params']); ky.set_pubkey(G['kyber1_t_ntt'], G['kyber1_Agen']); ky.set_privkey(G['kyber1_s_ntt'])
+    B = 65536
+    m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+    noise = torch.randint(0, 256, (B, ky.noise_bytes), dtype=torch.uint8, device='cuda', generator=g)
+    u, v = ky.enc(m, noise); torch.cuda.synchronize()
+    te, td = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); u, v = ky.enc(m, noise); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); mm = ky.dec(u, v); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+    assert torch.equal(mm, m)
+    out['kyber_1_cpa'] = {'workload': 'Kyber set 1 (k=3, q=7681) CPA encryption / decryption, batch 65536, one key', 'enc_ops_per_s': B / min(te),
+                          'dec_ops_per_s': B / min(td)}
+    ky.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,6 +225,10 @@ def main():
                 res['extra']['dilithium3'] = dilithium_extra(eng, torch, 0.0 if args.no_cpu_baseline else args.cpu_seconds)
             except Exception as e:        # an extra must never break the contract line
                 res['extra']['dilithium3'] = {'error': str(e)}
+            try:
+                res['extra'].update(bliss_kyber_extra(eng, torch))
+            except Exception as e:
+                res['extra']['bliss_kyber'] = {'error': str(e)}
         if not args.no_cpu_baseline and world == 1:
             res['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(res), flush=True)
