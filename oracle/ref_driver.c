@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_dil <set> <seconds>    (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
@@ -466,6 +466,104 @@ static int gen_kyber(const char *dir)
     return rc;
 }
 
+/* ---------------------------------------------------------------- Falcon ---- */
+#include "schemes/sig/falcon/falcon.h"
+#include "schemes/sig/falcon/falcon_params.h"
+#include "utils/arith/gpv.h"
+
+static void rec_f64(FILE *f, const char *name, const double *v, size_t n)
+{
+    /* doubles travel as their IEEE-754 bit patterns */
+    fprintf(f, "@ %s %zu\n", name, n);
+    for (size_t i = 0; i < n; i++) { int64_t b; memcpy(&b, &v[i], 8); fprintf(f, "%lld%c", (long long)b, (i % 8 == 7 || i + 1 == n) ? '\n' : ' '); }
+}
+
+/* Falcon signing (src/schemes/sig/falcon/falcon.c:808-935) draws its randomness inside
+ * gaussian_lattice_sample_fft (src/utils/arith/gpv.c:2663-2714): one throw-away CDF sampler per tree leaf
+ * on sc->prng_ctx[0], two prng_64 per leaf.  Same tape technique as BLISS: a freshly seeded CSPRNG per
+ * message and a twin read with prng_32 only.  Two kinds of record: the sampler alone on a synthetic target
+ * c (s1, s2 as returned), and whole signatures (message -> packed bytes, verify verdicts). */
+static int falcon_case(FILE *f, int set, int nsamp, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "falcon%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_FALCON, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const falcon_set_t *P = sc->falcon->params;
+    const int n = P->n, logn = P->n_bits;
+    int32_t par[8] = { P->n, P->q, P->q_bits, P->n_bits, set, 0, 0, 0 };
+    float bd = P->bd; memcpy(&par[5], &bd, 4);
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
+    snprintf(name, sizeof name, "%s_privkey", tag); rec_i32(f, name, (const int32_t *)sc->privkey->key, 4 * (size_t)n);  /* f g F G */
+    snprintf(name, sizeof name, "%s_h", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    snprintf(name, sizeof name, "%s_sk", tag); rec_f64(f, name, sc->falcon->sk, (size_t)(logn + 5) * n);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xfa1c0000ULL + set;
+    int32_t *c = malloc(sizeof(int32_t) * n), *s1 = malloc(sizeof(int32_t) * n), *s2 = malloc(sizeof(int32_t) * n);
+    for (int m = 0; m < nsamp; m++) {
+        uint8_t seed[32];
+        for (int i = 0; i < n; i++) c[i] = (int32_t)(splitmix64() % (uint64_t)P->q);
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        if (SC_FUNC_SUCCESS != gaussian_sample_with_tree(sc, sc->falcon->sk, 0, n, P->q, logn, c, 0, s1, s2)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_c%d", tag, m); rec_i32(f, name, c, n);
+        snprintf(name, sizeof name, "%s_ctape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_s1_%d", tag, m); rec_i32(f, name, s1, n);
+        snprintf(name, sizeof name, "%s_s2_%d", tag, m); rec_i32(f, name, s2, n);
+        free(tape);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    int32_t *verdicts = malloc(sizeof(int32_t) * nmsg * 2), *status = malloc(sizeof(int32_t) * nmsg);
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t msg[200], seed[32];
+        size_t mlen = (m == 0) ? 1 : (m == 1) ? 200 : 48;
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *sig = NULL; size_t siglen = 0;
+        status[m] = safecrypto_sign(sc, msg, mlen, &sig, &siglen);
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+        verdicts[2 * m] = verdicts[2 * m + 1] = -1;
+        if (SC_FUNC_SUCCESS == status[m]) {
+            verdicts[2 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+            sig[siglen / 3] ^= 0x10;
+            verdicts[2 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        }
+        free(tape); free(sig);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    snprintf(name, sizeof name, "%s_status", tag); rec_i32(f, name, status, nmsg);
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
+    free(c); free(s1); free(s2); free(verdicts); free(status);
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_falcon(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/falcon_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = falcon_case(f, 0, 2, 4) | falcon_case(f, 2, 1, 2);
+    fclose(f);
+    return rc;
+}
+
 /* -------------------------------------------------------------- CPU baseline ---- */
 
 #include <time.h>
@@ -540,12 +638,13 @@ int main(int argc, char **argv)
 {
     if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_dil(atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
     if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
+    if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
     return rc;
 }

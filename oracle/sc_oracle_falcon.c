@@ -1,0 +1,329 @@
+/*
+ * sc_oracle_falcon.c - CPU restatement of the reference's Falcon signing path.  TEST INFRASTRUCTURE ONLY
+ * (checker for tests/, smoke() and bench.py's cpu_baseline leg; the product never links or calls it).
+ *
+ * Follows, for the binary rings (sets 0 and 2, x^n + 1):
+ *   src/utils/arith/gpv.c:2961-3090   gaussian_sample_with_tree  (ter == 0 branch)
+ *   src/utils/arith/gpv.c:2663-2714   gaussian_lattice_sample_fft (fast Fourier sampling over the LDL tree)
+ *   src/utils/arith/falcon_fft.c:203-378, 380-424, 466-483, 543-553, 694-785
+ *                                      FFT / iFFT / add / sub / mul_fft / mulconst / split_fft / merge_fft
+ *   src/schemes/sig/falcon/falcon.c:511-521, 534-591, 808-935, 955-1040
+ *                                      check_norm_bd, oracle_xof + h_function_xof, sign, verify
+ * IEEE-754 double arithmetic, one rounding per operation, in the reference's operation order (the reference
+ * is built without FMA contraction; this file must be compiled with -ffp-contract=off).
+ *
+ * The reference's root table fpr_gm_tab (falcon_fft.h, 1024 complex constants) is not copied: gm_init()
+ * regenerates it - exp(i*pi*j/2048) in binary128 from a Taylor series and repeated multiplication, rounded to
+ * double - and tests/test_oracle_falcon.py pins the result indirectly (the fixtures' s1/s2 only come out
+ * bit-exact when every constant is).
+ *
+ * Randomness: every tree leaf builds a throw-away 64-bit CDF sampler (tail 10, sigma = (float)leaf) on
+ * sc->prng_ctx[0] and draws two samples, i.e. two prng_64 = four 32-bit pool words, high word first
+ * (src/utils/crypto/prng.c:963-976).  The tape is that word stream.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "sc_oracle.h"
+#include "sc_oracle_keccak.h"
+
+typedef __float128 q_t;
+
+static double gm[2048];
+static int gm_ready;
+
+static unsigned brev(unsigned x, int bits)
+{
+    unsigned r = 0;
+    for (int b = 0; b < bits; b++) r |= ((x >> b) & 1u) << (bits - 1 - b);
+    return r;
+}
+
+/* GM[k], k in [m, 2m) with m = 2^logm, is w^rev(k) for w = exp(i*pi/N): the angle is pi*(2*rev_logm(k-m)+1)/(2m).
+ * Entry 0 is (0,0) and entry 1 is written as (-0.0, 1.0) in the reference's table. */
+static void gm_init(void)
+{
+    if (gm_ready) return;
+    const q_t pi = (q_t)3.141592653589793116 + (q_t)1.2246467991473532e-16 + (q_t)(-2.9947698097183397e-33);
+    const q_t x = pi / 2048, x2 = x * x;
+    q_t ts = x, tc = 1, s1 = x, c1 = 1;
+    for (int k = 1; k < 16; k++) {
+        tc = -tc * x2 / ((2 * k - 1) * (2 * k)); c1 += tc;
+        ts = -ts * x2 / ((2 * k) * (2 * k + 1)); s1 += ts;
+    }
+    static q_t cr[2049], ci[2049];
+    cr[0] = 1; ci[0] = 0;
+    for (int j = 1; j <= 2048; j++) { cr[j] = cr[j - 1] * c1 - ci[j - 1] * s1; ci[j] = cr[j - 1] * s1 + ci[j - 1] * c1; }
+    gm[0] = 0.0; gm[1] = 0.0;
+    for (int logm = 0; logm < 10; logm++) {
+        const unsigned m = 1u << logm;
+        for (unsigned i1 = 0; i1 < m; i1++) {
+            const unsigned k = m + i1, j = (2 * brev(i1, logm) + 1) * (2048 / (2 * m));
+            gm[2 * k] = (double)cr[j]; gm[2 * k + 1] = (double)ci[j];
+        }
+    }
+    gm[2] = -0.0; gm[3] = 1.0;
+    gm_ready = 1;
+}
+
+const double *orc_falcon_gm(void) { gm_init(); return gm; }
+
+#define CMUL(dr, di, ar, ai, br, bi) do { double ar_ = (ar), ai_ = (ai), br_ = (br), bi_ = (bi); \
+    double r_ = (ar_ * br_) - (ai_ * bi_), i_ = (ar_ * bi_) + (ai_ * br_); (dr) = r_; (di) = i_; } while (0)
+
+/* falcon_fft.c:203-282 */
+void orc_falcon_fft(double *f, unsigned logn)
+{
+    gm_init();
+    const size_t n = (size_t)1 << logn, hn = n >> 1;
+    size_t t = hn, m = 2;
+    for (unsigned u = 1; u < logn; u++, m <<= 1) {
+        const size_t ht = t >> 1, hm = m >> 1;
+        for (size_t i1 = 0, j1 = 0; i1 < hm; i1++, j1 += t) {
+            const double sr = gm[(m + i1) << 1], si = gm[((m + i1) << 1) + 1];
+            for (size_t j = j1; j < j1 + ht; j++) {
+                double xr = f[j], xi = f[j + hn], yr = f[j + ht], yi = f[j + ht + hn];
+                CMUL(yr, yi, yr, yi, sr, si);
+                f[j] = xr + yr; f[j + hn] = xi + yi;
+                f[j + ht] = xr - yr; f[j + ht + hn] = xi - yi;
+            }
+        }
+        t = ht;
+    }
+}
+
+/* falcon_fft.c:284-378 */
+void orc_falcon_ifft(double *f, unsigned logn)
+{
+    gm_init();
+    const size_t n = (size_t)1 << logn, hn = n >> 1;
+    size_t t = 1, m = n;
+    for (unsigned u = logn; u > 1; u--) {
+        const size_t hm = m >> 1, dt = t << 1;
+        for (size_t i1 = 0, j1 = 0; j1 < hn; i1++, j1 += dt) {
+            const double sr = gm[(hm + i1) << 1], si = -gm[((hm + i1) << 1) + 1];
+            for (size_t j = j1; j < j1 + t; j++) {
+                double xr = f[j], xi = f[j + hn], yr = f[j + t], yi = f[j + t + hn];
+                f[j] = xr + yr; f[j + hn] = xi + yi;
+                xr = xr - yr; xi = xi - yi;
+                CMUL(f[j + t], f[j + t + hn], xr, xi, sr, si);
+            }
+        }
+        t = dt; m = hm;
+    }
+    if (logn > 0) {
+        const double ni = ldexp(2, -(int)logn);
+        for (size_t u = 0; u < n; u++) f[u] = f[u] * ni;
+    }
+}
+
+static void poly_mul_fft(double *a, const double *b, unsigned logn)           /* falcon_fft.c:466-483 */
+{
+    const size_t hn = ((size_t)1 << logn) >> 1;
+    for (size_t u = 0; u < hn; u++) CMUL(a[u], a[u + hn], a[u], a[u + hn], b[u], b[u + hn]);
+}
+
+static void split_fft(double *f0, double *f1, const double *f, unsigned logn)   /* falcon_fft.c:694-739 */
+{
+    const size_t n = (size_t)1 << logn, hn = n >> 1, qn = hn >> 1;
+    f0[0] = f[0]; f1[0] = f[hn];
+    for (size_t u = 0; u < qn; u++) {
+        const double ar = f[2 * u], ai = f[2 * u + hn], br = f[2 * u + 1], bi = f[2 * u + 1 + hn];
+        double tr = ar + br, ti = ai + bi;
+        f0[u] = tr * 0.5; f0[u + qn] = ti * 0.5;
+        tr = ar - br; ti = ai - bi;
+        CMUL(tr, ti, tr, ti, gm[(u + hn) << 1], -gm[((u + hn) << 1) + 1]);
+        f1[u] = tr * 0.5; f1[u + qn] = ti * 0.5;
+    }
+}
+
+static void merge_fft(double *f, const double *f0, const double *f1, unsigned logn)  /* falcon_fft.c:742-785 */
+{
+    const size_t n = (size_t)1 << logn, hn = n >> 1, qn = hn >> 1;
+    f[0] = f0[0]; f[hn] = f1[0];
+    for (size_t u = 0; u < qn; u++) {
+        const double ar = f0[u], ai = f0[u + qn];
+        double br, bi;
+        CMUL(br, bi, f1[u], f1[u + qn], gm[(u + hn) << 1], gm[((u + hn) << 1) + 1]);
+        f[2 * u] = ar + br; f[2 * u + hn] = ai + bi;
+        f[2 * u + 1] = ar - br; f[2 * u + 1 + hn] = ai - bi;
+    }
+}
+
+typedef struct { const uint32_t *w; size_t len, pos; int underrun; } ftape_t;
+static uint64_t f64w(ftape_t *t)
+{
+    if (t->pos + 2 > t->len) { t->underrun = 1; return 0; }
+    const uint64_t hi = t->w[t->pos], lo = t->w[t->pos + 1];
+    t->pos += 2;
+    return (hi << 32) | lo;
+}
+
+static unsigned treesize(unsigned logn) { return (logn + 1) << logn; }             /* falcon_ldl.h:56-71 */
+
+/* gpv.c:2663-2714 */
+static void ffsample(double *z0, double *z1, const double *tree, const double *t0, const double *t1, unsigned logn,
+                     double *tmp, ftape_t *tape)
+{
+    const size_t n = (size_t)1 << logn;
+    if (n == 1) {
+        const float sigma = (float)tree[0];
+        const int size = 1 << orc_cdt_bits(10.0f, sigma);
+        uint64_t *cdf = malloc(sizeof(uint64_t) * (size_t)(size < 2 ? 2 : size));
+        orc_cdt_create(10.0f, sigma, cdf, size);
+        z0[0] = floor(t0[0]) + orc_cdt_sample(f64w(tape), cdf, size);
+        z1[0] = floor(t1[0]) + orc_cdt_sample(f64w(tape), cdf, size);
+        free(cdf);
+        return;
+    }
+    const size_t hn = n >> 1;
+    const double *tree0 = tree + n, *tree1 = tree + n + treesize(logn - 1);
+    split_fft(z1, z1 + hn, t1, logn);
+    ffsample(tmp, tmp + hn, tree1, z1, z1 + hn, logn - 1, tmp + n, tape);
+    merge_fft(z1, tmp, tmp + hn, logn);
+    memcpy(tmp, t1, n * sizeof *t1);
+    for (size_t u = 0; u < n; u++) tmp[u] = tmp[u] - z1[u];
+    poly_mul_fft(tmp, tree, logn);
+    for (size_t u = 0; u < n; u++) tmp[u] = tmp[u] + t0[u];
+    split_fft(z0, z0 + hn, tmp, logn);
+    ffsample(tmp, tmp + hn, tree0, z0, z0 + hn, logn - 1, tmp + n, tape);
+    merge_fft(z0, tmp, tmp + hn, logn);
+}
+
+/* gpv.c:2961-3090, ter == 0.  sk = b00 | b01 | b10 | b11 | tree as load_skey leaves it (falcon_keygen.h:107-136).
+ * Returns 0, or 2 when the tape is too short (4n words are needed). */
+int orc_falcon_sample(const double *sk, int n, int q, int logn, const int32_t *c, const uint32_t *tape, size_t tape_len,
+                      int32_t *s1, int32_t *s2)
+{
+    gm_init();
+    const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * (size_t)n, *b11 = sk + 3 * (size_t)n, *tree = sk + 4 * (size_t)n;
+    double *c0 = malloc(sizeof(double) * 11 * (size_t)n), *c1 = c0 + n, *tmp = c1 + n, *z0 = tmp + 7 * (size_t)n, *z1 = z0 + n;
+    ftape_t tp = { tape, tape_len, 0, 0 };
+    for (int i = 0; i < n; i++) c0[i] = c[i];
+    const double ni = 1.0 / (double)(long)q;
+    orc_falcon_fft(c0, (unsigned)logn);
+    memcpy(c1, c0, sizeof(double) * (size_t)n);
+    poly_mul_fft(c1, b01, (unsigned)logn);
+    for (int i = 0; i < n; i++) c1[i] = c1[i] * -ni;
+    poly_mul_fft(c0, b11, (unsigned)logn);
+    for (int i = 0; i < n; i++) c0[i] = c0[i] * ni;
+    ffsample(z0, z1, tree, c0, c1, (unsigned)logn, tmp, &tp);
+    memcpy(c0, z0, sizeof(double) * (size_t)n);
+    memcpy(c1, z1, sizeof(double) * (size_t)n);
+    poly_mul_fft(z0, b00, (unsigned)logn);
+    poly_mul_fft(z1, b10, (unsigned)logn);
+    for (int i = 0; i < n; i++) z0[i] = z0[i] + z1[i];
+    memcpy(z1, c0, sizeof(double) * (size_t)n);
+    poly_mul_fft(z1, b01, (unsigned)logn);
+    memcpy(c0, z0, sizeof(double) * (size_t)n);
+    poly_mul_fft(c1, b11, (unsigned)logn);
+    for (int i = 0; i < n; i++) c1[i] = c1[i] + z1[i];
+    orc_falcon_ifft(c0, (unsigned)logn);
+    orc_falcon_ifft(c1, (unsigned)logn);
+    if (s1) for (int i = 0; i < n; i++) s1[i] = (int32_t)(c[i] - llrint(c0[i]));
+    for (int i = 0; i < n; i++) s2[i] = (int32_t)-llrint(c1[i]);
+    free(c0);
+    return tp.underrun ? 2 : 0;
+}
+
+/* falcon.c:534-591: SHAKE128 (the reference's permutation) over the message, then n 32-bit little-endian words;
+ * y = word & (2^q_bits - 1); y -= ((SINT32)(q - y) >> 31) * q - which ADDS q when y > q (the product is taken
+ * in UINT32), so c ranges over [0, 2^q_bits + q).  Restated as it behaves. */
+void orc_falcon_hash_to_ring(int32_t *c, int n, int q, int q_bits, const uint8_t *msg, size_t mlen)
+{
+    shake_t sh;
+    shake_init(&sh, 128);
+    shake_absorb(&sh, msg, mlen);
+    shake_final(&sh);
+    const uint32_t mask = (1u << q_bits) - 1;
+    for (int i = 0; i < n; i++) {
+        uint8_t b[4];
+        shake_squeeze(&sh, b, 4);
+        uint32_t y = ((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) & mask;
+        y -= (uint32_t)((int32_t)((uint32_t)q - y) >> 31) * (uint32_t)q;
+        c[i] = (int32_t)y;
+    }
+}
+
+/* falcon.c:511-521: integer squares, FLOAT accumulation from the top index down, sqrtf, ">= bd" fails */
+static int norm_fails(float bd, const int32_t *s1, const int32_t *s2, int n)
+{
+    float norm = 0;
+    for (int i = n; i--;) norm += s1[i] * s1[i] + s2[i] * s2[i];
+    norm = sqrtf(norm);
+    return norm >= bd;
+}
+
+/* falcon.c:808-935.  par = the fixture's *_params record (n, q, q_bits, n_bits, set, bd as float bits).
+ * Returns 0 = SC_FUNC_SUCCESS with the packed s2 ((q_bits-2)-bit two's complement, MSB first), 1 = norm bound
+ * exceeded (the reference gives up, it does not retry), 2 = tape too short. */
+int orc_falcon_sign(const int32_t *par, const double *sk, const uint8_t *msg, size_t mlen, const uint32_t *tape, size_t tape_len,
+                    uint8_t *sig, size_t *siglen)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], logn = par[3];
+    float bd; memcpy(&bd, &par[5], 4);
+    int32_t *c = malloc(sizeof(int32_t) * 3 * (size_t)n), *s1 = c + n, *s2 = s1 + n;
+    int rc;
+    orc_falcon_hash_to_ring(c, n, q, q_bits, msg, mlen);
+    if ((rc = orc_falcon_sample(sk, n, q, logn, c, tape, tape_len, s1, s2)) != 0) goto done;
+    orc_center(s2, (size_t)n, q);
+    if (norm_fails(bd, s1, s2, n)) { rc = 1; goto done; }
+    {
+        const int bits = q_bits - 2;
+        size_t bp = 0;
+        memset(sig, 0, ((size_t)n * (size_t)bits + 7) / 8);
+        for (int i = 0; i < n; i++)
+            for (int b = bits - 1; b >= 0; b--, bp++)
+                sig[bp >> 3] |= (uint8_t)((((uint32_t)s2[i] >> b) & 1u) << (7 - (bp & 7)));
+        *siglen = (bp + 7) / 8;
+    }
+    rc = 0;
+done:
+    free(c);
+    return rc;
+}
+
+/* falcon.c:955-1040.  h = the public key in the coefficient domain.  Returns 0 for a valid signature. */
+int orc_falcon_verify(const int32_t *par, const int16_t *h, const uint8_t *msg, size_t mlen, const uint8_t *sig, size_t siglen)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], bits = q_bits - 2;
+    float bd; memcpy(&bd, &par[5], 4);
+    if (siglen * 8 < (size_t)n * (size_t)bits) return 1;
+    int32_t *w = malloc(sizeof(int32_t) * 6 * (size_t)n), *r = w + n, *c = r + n, *s1 = c + n, *s2 = s1 + n, *h32 = s2 + n;
+    int rc = 1;
+    if (orc_make_tables(q, n, w, r)) goto done;
+    size_t bp = 0;
+    for (int i = 0; i < n; i++) {
+        uint32_t v = 0;
+        for (int b = 0; b < bits; b++, bp++) v = (v << 1) | ((sig[bp >> 3] >> (7 - (bp & 7))) & 1u);
+        s2[i] = (int32_t)(v << (32 - bits)) >> (32 - bits);
+    }
+    orc_center(s2, (size_t)n, q);
+    orc_falcon_hash_to_ring(c, n, q, q_bits, msg, mlen);
+    for (int i = 0; i < n; i++) h32[i] = h[i];
+    orc_normalize(h32, (size_t)n, q);
+    for (int i = 0; i < n; i++) s1[i] = s2[i];
+    orc_normalize(s1, (size_t)n, q);
+    orc_polymul(s1, n, q, s1, h32, w, r);
+    for (int i = 0; i < n; i++) s1[i] = c[i] - s1[i];
+    orc_center(s1, (size_t)n, q);
+    rc = norm_fails(bd, s1, s2, n) ? 1 : 0;
+done:
+    free(w);
+    return rc;
+}
+
+/* per-leaf sigma in visiting order (tree1 subtree first, then tree0): what a batched engine tabulates at key load */
+static void leaves_rec(const double *tree, unsigned logn, float *out, size_t *k)
+{
+    if (logn == 0) { out[(*k)++] = (float)tree[0]; return; }
+    const size_t n = (size_t)1 << logn;
+    leaves_rec(tree + n + treesize(logn - 1), logn - 1, out, k);
+    leaves_rec(tree + n, logn - 1, out, k);
+}
+void orc_falcon_leaf_sigmas(const double *sk, int n, int logn, float *out)
+{
+    size_t k = 0;
+    leaves_rec(sk + 4 * (size_t)n, (unsigned)logn, out, &k);
+}

@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -58,8 +58,73 @@ def lib():
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
+        f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
+        f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
+        L.orc_falcon_gm.restype = C.POINTER(C.c_double)
+        L.orc_falcon_fft.argtypes = [f64p, C.c_uint]
+        L.orc_falcon_ifft.argtypes = [f64p, C.c_uint]
+        L.orc_falcon_sample.argtypes = [f64p, C.c_int, C.c_int, C.c_int, i32p, u32p, C.c_size_t, i32p, i32p]
+        L.orc_falcon_hash_to_ring.argtypes = [i32p, C.c_int, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.orc_falcon_sign.argtypes = [i32p, f64p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t)]
+        L.orc_falcon_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
+        L.orc_falcon_leaf_sigmas.argtypes = [f64p, C.c_int, C.c_int, f32p]
         _LIB = L
     return _LIB
+
+
+class FalconKey:
+    """one Falcon key as the fixture provides it: params, expanded private key (doubles), public key h"""
+
+    def __init__(self, par, sk_bits, h):
+        self.par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+        self.sk = np.ascontiguousarray(np.asarray(sk_bits, dtype=np.int64)).view(np.float64)
+        self.h = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
+        self.n, self.q, self.q_bits, self.logn = (int(x) for x in self.par[:4])
+        self.bd = float(self.par[5:6].view(np.float32)[0])
+        self.sig_bytes = (self.n * (self.q_bits - 2) + 7) // 8
+
+    @classmethod
+    def from_golden(cls, G, tag):
+        return cls(G[f'{tag}_params'], G[f'{tag}_sk'], G[f'{tag}_h'])
+
+
+def _tape(tape):
+    return np.ascontiguousarray(np.asarray(tape).astype(np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+
+
+def falcon_sample(key, c, tape):
+    s1, s2 = np.zeros(key.n, dtype=np.int32), np.zeros(key.n, dtype=np.int32)
+    tp = _tape(tape)
+    rc = lib().orc_falcon_sample(key.sk, key.n, key.q, key.logn, np.ascontiguousarray(np.asarray(c), dtype=np.int32), tp, tp.size, s1, s2)
+    return rc, s1, s2
+
+
+def falcon_hash_to_ring(key, msg):
+    c = np.zeros(key.n, dtype=np.int32)
+    m, ml = _msgbuf(msg)
+    lib().orc_falcon_hash_to_ring(c, key.n, key.q, key.q_bits, m, ml)
+    return c
+
+
+def falcon_sign(key, msg, tape):
+    sig = np.zeros(key.sig_bytes + 8, dtype=np.uint8)
+    sl = C.c_size_t(0)
+    m, ml = _msgbuf(msg)
+    tp = _tape(tape)
+    rc = lib().orc_falcon_sign(key.par, key.sk, m, ml, tp, tp.size, sig, C.byref(sl))
+    return rc, bytes(sig[:sl.value])
+
+
+def falcon_verify(key, msg, sig):
+    m, ml = _msgbuf(msg)
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    return lib().orc_falcon_verify(key.par, key.h, m, ml, s, s.size)
+
+
+def falcon_leaf_sigmas(key):
+    out = np.zeros(key.n, dtype=np.float32)
+    lib().orc_falcon_leaf_sigmas(key.sk, key.n, key.logn, out)
+    return out
 
 
 def kyber_enc(par, t_ntt, Agen, m, noise):
