@@ -219,6 +219,43 @@ int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, co
 /* replaces: kyber_cpa_dec (module_lwe.c:1415-1481); u, v are not modified; d_m [batch][32] */
 int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32_t *d_u, const int32_t *d_v, uint8_t *d_m, void *stream);
 
+/* ---- Falcon (binary rings, sets 0 and 2): batched tree sampler, sign / verify under one key -- */
+
+/* falcon_set_t fields (src/schemes/sig/falcon/falcon_params.h:38-55, values falcon_params.c:24-55) */
+typedef struct sc_hip_falcon_params {
+    int32_t n, q, q_bits, n_bits, set;
+    float bd;
+    int32_t pad[2];
+} sc_hip_falcon_params_t;
+typedef struct sc_hip_falcon sc_hip_falcon_t;
+
+int  sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_falcon_t **h);
+void sc_hip_falcon_destroy(sc_hip_falcon_t *h);
+/* sk: the expanded private key sc->falcon->sk that load_skey builds (src/schemes/sig/falcon/falcon.c:786-790,
+ * src/utils/arith/falcon_keygen.c:6107-6170; offsets falcon_keygen.h:107-136): b00 | b01 | b10 | b11 in FFT form and the
+ * normalised LDL tree, (n_bits + 5) * n doubles.  The n per-leaf CDF tables the reference builds on the fly
+ * (src/utils/arith/gpv.c:2671-2686) are tabulated here, once, on the host. */
+int  sc_hip_falcon_set_privkey(sc_hip_falcon_t *h, const double *sk);
+/* pk: h in the coefficient domain, SINT16[n] (first half of sc->pubkey->key, falcon.c:772-780) */
+int  sc_hip_falcon_set_pubkey(sc_hip_falcon_t *h, const int16_t *pk);
+size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *h);      /* n * (q_bits - 2) / 8 */
+
+/* replaces: gaussian_sample_with_tree (src/utils/arith/gpv.c:2961-3090, ter == 0) for `batch` targets d_c int32 [batch][n].
+ * Randomness as for BLISS: d_tapes uint32 [batch][tape_stride] holds each target's CSPRNG pool words (4n are consumed:
+ * two prng_64 per tree leaf, high word first); d_tape_lens NULL = tape_stride words each.  Outputs d_s1 (may be NULL) and
+ * d_s2 int32 [batch][n], bit for bit the reference's; d_status[i] (may be NULL) = 2 when tape i is too short, else 0. */
+int sc_hip_falcon_sample(sc_hip_falcon_t *h, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                         int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_sign -> falcon_sig_sign (src/schemes/sig/falcon/falcon.c:808-935): SHAKE128 hash to the ring, the
+ * tree sampler, centring, the norm bound, raw (q_bits-2)-bit packing of s2.  d_status[i]: 1 signed, 2 tape too short,
+ * 4 norm bound exceeded (the reference returns SC_FUNC_FAILURE there, it does not retry); d_siglens[i] = 0 unless signed. */
+int sc_hip_falcon_sign(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_verify -> falcon_sig_verify (falcon.c:955-1040); d_verdicts[i] = 0 valid / 1 invalid */
+int sc_hip_falcon_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

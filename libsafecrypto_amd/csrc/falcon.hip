@@ -1,0 +1,670 @@
+// falcon.hip - batched Falcon signing (fast Fourier sampling over the LDL tree) and verification on MI355X
+// behind the C ABI of include/sc_hip.h.  Binary rings only (parameter sets 0 and 2, x^n + 1, n = 512 / 1024).
+//
+// Replaces, for a batch of messages under one key:
+//   gaussian_sample_with_tree      src/utils/arith/gpv.c:2961-3090 (ter == 0 branch)
+//   gaussian_lattice_sample_fft    src/utils/arith/gpv.c:2663-2714
+//   falcon_FFT / iFFT / poly_*     src/utils/arith/falcon_fft.c:203-378, 380-424, 466-483, 543-553, 694-785
+//   falcon_sig_sign / _verify      src/schemes/sig/falcon/falcon.c:808-935, 955-1040 (hash to ring :534-591, norm :511-521)
+//
+// Arithmetic is IEEE-754 binary64 with one rounding per operation in the reference's operation order (the reference
+// is built without FMA contraction, hence -ffp-contract=off / the pragma below): s1 and s2 come out bit for bit.
+//
+// Mapping: ONE LANE PER SIGNATURE.  The sampler is a depth-first walk over a binary tree whose two halves depend on
+// each other through the Gaussian samples - there is no parallelism inside a signature below the top few levels, but a
+// batch is embarrassingly parallel and every lane of a wavefront takes the same path (the tree shape is fixed, the
+// sampler is branch-free), so 64 signatures run in lockstep without divergence.  Working polynomials (6n doubles per
+// signature) live in HBM interleaved across the batch - element e of signature b at ws[e*B + b] - so every access of a
+// wavefront is one contiguous 512-byte row; key material (basis, tree, roots) is read at wave-uniform addresses.
+// The recursion is unrolled by hand into a loop over levels; the passes the reference makes between the two recursive
+// calls (merge, (t1 - z1)*L + t0, split) are fused into one sweep, and the bottom 2^FK-coefficient sub-trees run
+// entirely in registers.  HBM traffic per signature is about 9n doubles per tree level above the register block.
+//
+// Randomness: each tree leaf builds a throw-away 64-bit CDF sampler with sigma = (float)leaf and draws two samples
+// (two prng_64 = four 32-bit CSPRNG pool words, high word first, prng.c:963-976).  The engine owns no CSPRNG: each
+// message travels with that word stream (4n words), and the n per-leaf CDF tables are tabulated on the host when the
+// key is loaded (same long-double code path as sc_hip_cdt_build_table), in visiting order.
+#pragma clang fp contract(off)
+#include "engine_internal.h"
+#include "keccak_dev.h"
+
+#include <math.h>
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+constexpr int HT = 64;       // hash kernel: lanes per workgroup (LDS sponge states)
+constexpr int FK = 3;        // sub-trees of 2^FK coefficients are sampled in registers
+constexpr int ST = 256;      // sampler kernel: lanes per workgroup
+
+struct FalP { int32_t n, q, q_bits, n_bits, set; float bd; int32_t pad[2]; };   // falcon_set_t fields (falcon_params.h:38-55)
+
+__host__ __device__ constexpr uint32_t treesize(uint32_t logn) { return (logn + 1) << logn; }    // falcon_ldl.h:56-71
+
+// FPC_MUL (falcon_fft.c:101-117): two products then one add/sub per component, each rounded
+__device__ __forceinline__ void cmul(double &dr, double &di, double ar, double ai, double br, double bi)
+{
+    const double r = (ar * br) - (ai * bi), i = (ar * bi) + (ai * br);
+    dr = r; di = i;
+}
+
+// gaussian_cdf.c:536-553 + :639-659: halving search for the largest b with cdf[b] < x, sign = LSB of x
+__device__ __forceinline__ double cdt_pick(const uint64_t *__restrict__ cdf, int ts_log, uint64_t x)
+{
+    uint32_t a = 0;
+    for (int s = ts_log - 1; s >= 0; s--) { const uint32_t b = a + (1u << s); if (cdf[b] < x) a = b; }
+    const int32_t v = (x & 1) ? (int32_t)a : -(int32_t)a;
+    return (double)v;
+}
+
+struct Leaf {                 // leaf tables in visiting order + this signature's word stream
+    const uint64_t *__restrict__ tabs;
+    const uint32_t *__restrict__ tape;
+    int ts_log;
+    uint32_t idx;
+};
+
+// ---- register-resident bottom of the tree (gpv.c:2663-2714 on 2^L coefficients) ------------------------------------
+
+template <int L> struct FFS {
+    static constexpr int N = 1 << L, HN = N / 2, QN = HN / 2;
+    static __device__ __forceinline__ void split(double (&f0)[HN], double (&f1)[HN], const double (&f)[N], const double *__restrict__ gm)
+    {
+        if (QN == 0) { f0[0] = f[0]; f1[0] = f[HN]; }
+#pragma unroll
+        for (int u = 0; u < QN; u++) {
+            const double ar = f[2 * u], ai = f[2 * u + HN], br = f[2 * u + 1], bi = f[2 * u + 1 + HN];
+            double tr = ar + br, ti = ai + bi;
+            f0[u] = tr * 0.5; f0[u + QN] = ti * 0.5;
+            tr = ar - br; ti = ai - bi;
+            cmul(tr, ti, tr, ti, gm[(u + HN) << 1], -gm[((u + HN) << 1) + 1]);
+            f1[u] = tr * 0.5; f1[u + QN] = ti * 0.5;
+        }
+    }
+    static __device__ __forceinline__ void merge(double (&f)[N], const double (&f0)[HN], const double (&f1)[HN], const double *__restrict__ gm)
+    {
+        if (QN == 0) { f[0] = f0[0]; f[HN] = f1[0]; }
+#pragma unroll
+        for (int u = 0; u < QN; u++) {
+            const double ar = f0[u], ai = f0[u + QN];
+            double br, bi;
+            cmul(br, bi, f1[u], f1[u + QN], gm[(u + HN) << 1], gm[((u + HN) << 1) + 1]);
+            f[2 * u] = ar + br; f[2 * u + HN] = ai + bi;
+            f[2 * u + 1] = ar - br; f[2 * u + 1 + HN] = ai - bi;
+        }
+    }
+    static __device__ __forceinline__ void run(double (&z0)[N], double (&z1)[N], const double *__restrict__ tree, const double (&t0)[N], const double (&t1)[N],
+                                               const double *__restrict__ gm, Leaf &lf)
+    {
+        double a0[HN], a1[HN], w0[HN], w1[HN], tmp[N];
+        split(a0, a1, t1, gm);
+        FFS<L - 1>::run(w0, w1, tree + N + treesize(L - 1), a0, a1, gm, lf);
+        merge(z1, w0, w1, gm);
+#pragma unroll
+        for (int u = 0; u < HN; u++) {
+            double tr = t1[u] - z1[u], ti = t1[u + HN] - z1[u + HN];
+            cmul(tr, ti, tr, ti, tree[u], tree[u + HN]);
+            tmp[u] = tr + t0[u]; tmp[u + HN] = ti + t0[u + HN];
+        }
+        split(a0, a1, tmp, gm);
+        FFS<L - 1>::run(w0, w1, tree + N, a0, a1, gm, lf);
+        merge(z0, w0, w1, gm);
+    }
+};
+
+template <> struct FFS<0> {
+    static __device__ __forceinline__ void run(double (&z0)[1], double (&z1)[1], const double *__restrict__, const double (&t0)[1], const double (&t1)[1],
+                                               const double *__restrict__, Leaf &lf)
+    {
+        const uint64_t *cdf = lf.tabs + ((size_t)lf.idx << lf.ts_log);
+        const uint32_t *w = lf.tape + 4 * (size_t)lf.idx;
+        const uint64_t x0 = ((uint64_t)w[0] << 32) | w[1], x1 = ((uint64_t)w[2] << 32) | w[3];
+        z0[0] = floor(t0[0]) + cdt_pick(cdf, lf.ts_log, x0);
+        z1[0] = floor(t1[0]) + cdt_pick(cdf, lf.ts_log, x1);
+        lf.idx++;
+    }
+};
+
+// ---- one signature's column of the interleaved workspace ---------------------------------------------------------------
+
+struct Col {
+    double *p; size_t B;
+    __device__ __forceinline__ double ld(uint32_t e) const { return p[(size_t)e * B]; }
+    __device__ __forceinline__ void st(uint32_t e, double v) const { p[(size_t)e * B] = v; }
+};
+
+// falcon_fft.c:203-282
+__device__ void fft_col(const Col &c, uint32_t f, int logn, const double *__restrict__ gm)
+{
+    const uint32_t n = 1u << logn, hn = n >> 1;
+    uint32_t t = hn, m = 2;
+    for (int u = 1; u < logn; u++, m <<= 1) {
+        const uint32_t ht = t >> 1, hm = m >> 1;
+        for (uint32_t i1 = 0, j1 = 0; i1 < hm; i1++, j1 += t) {
+            const double sr = gm[(m + i1) << 1], si = gm[((m + i1) << 1) + 1];
+            for (uint32_t j = j1; j < j1 + ht; j++) {
+                const double xr = c.ld(f + j), xi = c.ld(f + j + hn);
+                double yr = c.ld(f + j + ht), yi = c.ld(f + j + ht + hn);
+                cmul(yr, yi, yr, yi, sr, si);
+                c.st(f + j, xr + yr); c.st(f + j + hn, xi + yi);
+                c.st(f + j + ht, xr - yr); c.st(f + j + ht + hn, xi - yi);
+            }
+        }
+        t = ht;
+    }
+}
+
+// falcon_fft.c:284-378 without the final scaling (the caller applies f*ni while it rounds to integers)
+__device__ void ifft_col(const Col &c, uint32_t f, int logn, const double *__restrict__ gm)
+{
+    const uint32_t n = 1u << logn, hn = n >> 1;
+    uint32_t t = 1, m = n;
+    for (int u = logn; u > 1; u--) {
+        const uint32_t hm = m >> 1, dt = t << 1;
+        for (uint32_t i1 = 0, j1 = 0; j1 < hn; i1++, j1 += dt) {
+            const double sr = gm[(hm + i1) << 1], si = -gm[((hm + i1) << 1) + 1];
+            for (uint32_t j = j1; j < j1 + t; j++) {
+                double xr = c.ld(f + j), xi = c.ld(f + j + hn);
+                const double yr = c.ld(f + j + t), yi = c.ld(f + j + t + hn);
+                c.st(f + j, xr + yr); c.st(f + j + hn, xi + yi);
+                xr = xr - yr; xi = xi - yi;
+                double pr, pi;
+                cmul(pr, pi, xr, xi, sr, si);
+                c.st(f + j + t, pr); c.st(f + j + t + hn, pi);
+            }
+        }
+        t = dt; m = hm;
+    }
+}
+
+// falcon_fft.c:694-739, level l >= 2
+__device__ __forceinline__ void split_col(const Col &c, uint32_t f0, uint32_t f1, uint32_t f, int l, const double *__restrict__ gm)
+{
+    const uint32_t hn = (1u << l) >> 1, qn = hn >> 1;
+    for (uint32_t u = 0; u < qn; u++) {
+        const double ar = c.ld(f + 2 * u), ai = c.ld(f + 2 * u + hn), br = c.ld(f + 2 * u + 1), bi = c.ld(f + 2 * u + 1 + hn);
+        double tr = ar + br, ti = ai + bi;
+        c.st(f0 + u, tr * 0.5); c.st(f0 + u + qn, ti * 0.5);
+        tr = ar - br; ti = ai - bi;
+        cmul(tr, ti, tr, ti, gm[(u + hn) << 1], -gm[((u + hn) << 1) + 1]);
+        c.st(f1 + u, tr * 0.5); c.st(f1 + u + qn, ti * 0.5);
+    }
+}
+
+// falcon_fft.c:742-785, level l >= 2
+__device__ __forceinline__ void merge_col(const Col &c, uint32_t f, uint32_t f0, uint32_t f1, int l, const double *__restrict__ gm)
+{
+    const uint32_t hn = (1u << l) >> 1, qn = hn >> 1;
+    for (uint32_t u = 0; u < qn; u++) {
+        const double ar = c.ld(f0 + u), ai = c.ld(f0 + u + qn);
+        double br, bi;
+        cmul(br, bi, c.ld(f1 + u), c.ld(f1 + u + qn), gm[(u + hn) << 1], gm[((u + hn) << 1) + 1]);
+        c.st(f + 2 * u, ar + br); c.st(f + 2 * u + hn, ai + bi);
+        c.st(f + 2 * u + 1, ar - br); c.st(f + 2 * u + 1 + hn, ai - bi);
+    }
+}
+
+// Workspace layout per signature, in doubles: C0 | C1 | Z0 | Z1 | T (2n).  A node at level l (2^l coefficients) below
+// the top writes its results z0, z1 into its parent's scratch and scratches in T beyond it, exactly as the reference's
+// pointer arithmetic does (gpv.c:2693-2711): tmp(l) = T + 2n - 2^(l+1), z0(l) = tmp(l+1), z1(l) = tmp(l+1) + 2^l, and
+// its targets t0, t1 are the two halves of the parent's z1 (first call) or z0 (second call).
+struct Walk {
+    uint32_t n; int logn; uint32_t ph;      // ph bit l: the node on the current path at level l is in its second half
+    __device__ __forceinline__ uint32_t tmp(int l) const { return 4 * n + 2 * n - (2u << l); }
+    __device__ __forceinline__ uint32_t z0(int l) const { return l == logn ? 2 * n : tmp(l + 1); }
+    __device__ __forceinline__ uint32_t z1(int l) const { return l == logn ? 3 * n : tmp(l + 1) + (1u << l); }
+    __device__ __forceinline__ uint32_t t0(int l) const { return l == logn ? 0 : (((ph >> (l + 1)) & 1) ? z0(l + 1) : z1(l + 1)); }
+    __device__ __forceinline__ uint32_t t1(int l) const { return l == logn ? n : t0(l) + (1u << l); }
+};
+
+// gaussian_sample_with_tree for one signature per lane.  c: int32 [batch][n]; tapes: uint32 [batch][tape_stride];
+// s1 (may be null), s2: int32 [batch][n]; status[b] |= 2 when the tape is shorter than 4n words (nothing is sampled then).
+__global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B, double *__restrict__ ws, const int32_t *__restrict__ c,
+                                                        const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
+                                                        const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs, int ts_log,
+                                                        int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni)
+{
+    const uint32_t b = blockIdx.x * ST + threadIdx.x;
+    if (b >= batch) return;
+    const uint32_t n = (uint32_t)P.n; const int logn = P.n_bits;
+    const uint32_t have = tape_lens ? tape_lens[b] : (uint32_t)tape_stride;
+    if (have < 4 * n) { status[b] = 2; return; }
+    const Col col = { ws + b, B };
+    const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
+    const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n, hn = n >> 1;
+    const int32_t *cb = c + (size_t)b * n;
+    for (uint32_t i = 0; i < n; i++) col.st(C0 + i, (double)cb[i]);
+    fft_col(col, C0, logn, gm);
+    // c1 = c0 * b01 * (-1/q) ; c0 = c0 * b11 * (1/q)   (gpv.c:3049-3054)
+    for (uint32_t u = 0; u < hn; u++) {
+        const double ar = col.ld(C0 + u), ai = col.ld(C0 + u + hn);
+        double r, i;
+        cmul(r, i, ar, ai, b01[u], b01[u + hn]);
+        col.st(C1 + u, r * -ni); col.st(C1 + u + hn, i * -ni);
+        cmul(r, i, ar, ai, b11[u], b11[u + hn]);
+        col.st(C0 + u, r * ni); col.st(C0 + u + hn, i * ni);
+    }
+
+    // ---- fast Fourier sampling, depth first, the second-half tree (tree1) before the first (gpv.c:2693-2711)
+    Leaf lf = { tabs, tapes + (size_t)b * tape_stride, ts_log, 0 };
+    Walk w = { n, logn, 0 };
+    uint32_t toff = 0;                           // offset of the current node's tree block
+    int l = logn;
+    bool entering = true;
+    for (;;) {
+        const uint32_t m = 1u << l, hm = m >> 1, qn = hm >> 1;
+        if (entering) {
+            if (l == FK) {
+                double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
+                const uint32_t pt0 = w.t0(l), pt1 = w.t1(l), pz0 = w.z0(l), pz1 = w.z1(l);
+#pragma unroll
+                for (int i = 0; i < (1 << FK); i++) { t0r[i] = col.ld(pt0 + i); t1r[i] = col.ld(pt1 + i); }
+                FFS<FK>::run(z0r, z1r, tree + toff, t0r, t1r, gm, lf);
+#pragma unroll
+                for (int i = 0; i < (1 << FK); i++) { col.st(pz0 + i, z0r[i]); col.st(pz1 + i, z1r[i]); }
+                entering = false; l++;
+                continue;
+            }
+            split_col(col, w.z1(l), w.z1(l) + hm, w.t1(l), l, gm);
+            w.ph &= ~(1u << l);
+            toff += m + treesize(l - 1); l--;
+            continue;
+        }
+        if (!((w.ph >> l) & 1)) {
+            // back from tree1: z1 = merge(child); x = (t1 - z1)*L + t0; (z0 halves) = split(x) - one sweep over pairs
+            toff -= m + treesize(l - 1);
+            const uint32_t ch = w.tmp(l), pz1 = w.z1(l), pz0 = w.z0(l), pt0 = w.t0(l), pt1 = w.t1(l);
+            const double *L = tree + toff;
+            for (uint32_t u = 0; u < qn; u++) {
+                const double gr = gm[(u + hm) << 1], gi = gm[((u + hm) << 1) + 1];
+                const double ar = col.ld(ch + u), ai = col.ld(ch + u + qn);
+                double br, bi;
+                cmul(br, bi, col.ld(ch + hm + u), col.ld(ch + hm + u + qn), gr, gi);
+                const double e_r = ar + br, e_i = ai + bi, o_r = ar - br, o_i = ai - bi;     // z1 at complex slots 2u, 2u+1
+                col.st(pz1 + 2 * u, e_r); col.st(pz1 + 2 * u + hm, e_i);
+                col.st(pz1 + 2 * u + 1, o_r); col.st(pz1 + 2 * u + 1 + hm, o_i);
+                double xr = col.ld(pt1 + 2 * u) - e_r, xi = col.ld(pt1 + 2 * u + hm) - e_i;
+                cmul(xr, xi, xr, xi, L[2 * u], L[2 * u + hm]);
+                xr = xr + col.ld(pt0 + 2 * u); xi = xi + col.ld(pt0 + 2 * u + hm);
+                double yr = col.ld(pt1 + 2 * u + 1) - o_r, yi = col.ld(pt1 + 2 * u + 1 + hm) - o_i;
+                cmul(yr, yi, yr, yi, L[2 * u + 1], L[2 * u + 1 + hm]);
+                yr = yr + col.ld(pt0 + 2 * u + 1); yi = yi + col.ld(pt0 + 2 * u + 1 + hm);
+                double tr = xr + yr, ti = xi + yi;
+                col.st(pz0 + u, tr * 0.5); col.st(pz0 + u + qn, ti * 0.5);
+                tr = xr - yr; ti = xi - yi;
+                cmul(tr, ti, tr, ti, gr, -gi);
+                col.st(pz0 + hm + u, tr * 0.5); col.st(pz0 + hm + u + qn, ti * 0.5);
+            }
+            w.ph |= 1u << l;
+            toff += m; l--;
+            entering = true;
+            continue;
+        }
+        // back from tree0: z0 = merge(child); this node is done
+        toff -= m;
+        merge_col(col, w.z0(l), w.tmp(l), w.tmp(l) + hm, l, gm);
+        w.ph &= ~(1u << l);
+        if (l == logn) break;
+        l++;
+    }
+
+    // ---- lattice point (gpv.c:3064-3076): c0 <- z0*b00 + z1*b10 ; c1 <- z1*b11 + z0*b01
+    for (uint32_t u = 0; u < hn; u++) {
+        const double z0r = col.ld(Z0 + u), z0i = col.ld(Z0 + u + hn), z1r = col.ld(Z1 + u), z1i = col.ld(Z1 + u + hn);
+        double pr, pi, qr, qi;
+        cmul(pr, pi, z0r, z0i, b00[u], b00[u + hn]);
+        cmul(qr, qi, z1r, z1i, b10[u], b10[u + hn]);
+        col.st(C0 + u, pr + qr); col.st(C0 + u + hn, pi + qi);
+        cmul(pr, pi, z0r, z0i, b01[u], b01[u + hn]);
+        cmul(qr, qi, z1r, z1i, b11[u], b11[u + hn]);
+        col.st(C1 + u, qr + pr); col.st(C1 + u + hn, qi + pi);
+    }
+    ifft_col(col, C0, logn, gm);
+    ifft_col(col, C1, logn, gm);
+    const double sc2 = ldexp(2.0, -logn);                           // falcon_fft.c:370-377
+    int32_t *o1 = s1 ? s1 + (size_t)b * n : nullptr, *o2 = s2 + (size_t)b * n;
+    for (uint32_t i = 0; i < n; i++) {
+        const long long r0 = (long long)rint(col.ld(C0 + i) * sc2), r1 = (long long)rint(col.ld(C1 + i) * sc2);
+        if (o1) o1[i] = (int32_t)((long long)cb[i] - r0);
+        o2[i] = (int32_t)-r1;
+    }
+}
+
+// ---- hash to ring (falcon.c:534-591): SHAKE128 with the reference's permutation, n little-endian 32-bit words --------
+__global__ __launch_bounds__(HT) void fal_hash_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
+                                                      int32_t *__restrict__ c, FalP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t b = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    if (b >= batch) return;
+    const uint32_t mlen = mlens ? mlens[b] : fixed_len;
+    sp.absorb(msgs + (size_t)b * msg_stride, mlen);
+    sp.finalize(0x1F);
+    const uint32_t mask = (1u << P.q_bits) - 1u, q = (uint32_t)P.q;
+    int32_t *cb = c + (size_t)b * P.n;
+    for (int i = 0; i < P.n; i++) {
+        uint32_t y = sp.squeeze_byte();
+        y |= (uint32_t)sp.squeeze_byte() << 8; y |= (uint32_t)sp.squeeze_byte() << 16; y |= (uint32_t)sp.squeeze_byte() << 24;
+        y &= mask;
+        y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
+        cb[i] = (int32_t)y;
+    }
+}
+
+__device__ __forceinline__ int32_t centre_mod(int32_t x, int32_t q)      // ntt center_32: the representative in [-(q-1)/2, (q-1)/2]
+{
+    int32_t r = x % q;
+    const int32_t q2 = (q - 1) >> 1;
+    if (r < -q2) r += q;
+    if (r > q2) r -= q;
+    return r;
+}
+
+// falcon.c:511-521: integer squares, FLOAT accumulation from the top index down, sqrtf, ">= bd" fails
+__device__ __forceinline__ bool norm_fails(const int32_t *s1, const int32_t *s2, int n, float bd)
+{
+    float norm = 0;
+    for (int i = n; i--;) norm += (float)(s1[i] * s1[i] + s2[i] * s2[i]);
+    norm = sqrtf(norm);
+    return norm >= bd;
+}
+
+struct BitW {
+    uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
+    __device__ __forceinline__ void put(uint32_t v, int bits)
+    {
+        acc = (acc << bits) | (uint64_t)(v & ((1u << bits) - 1u)); nb += bits;
+        while (nb >= 8) { p[nbytes++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+    }
+    __device__ __forceinline__ void flush() { if (nb) { p[nbytes++] = (uint8_t)(acc << (8 - nb)); nb = 0; } }
+};
+
+// falcon.c:879-905: centre s2, norm test (no retry in the reference), raw (q_bits-2)-bit packing of s2
+__global__ void fal_finish_kernel(uint32_t batch, const int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint8_t *__restrict__ sigs, size_t sig_stride,
+                                  uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    siglens[b] = 0;
+    if (status[b] == 2) return;
+    const int n = P.n;
+    const int32_t *a1 = s1 + (size_t)b * n; int32_t *a2 = s2 + (size_t)b * n;
+    for (int i = 0; i < n; i++) a2[i] = centre_mod(a2[i], P.q);
+    if (norm_fails(a1, a2, n, P.bd)) { status[b] = 4; return; }
+    BitW bw = { sigs + (size_t)b * sig_stride, 0, 0, 0 };
+    for (int i = 0; i < n; i++) bw.put((uint32_t)a2[i], P.q_bits - 2);
+    bw.flush();
+    siglens[b] = bw.nbytes;
+    status[b] = 1;
+}
+
+// ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------
+__global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
+                                  uint32_t *__restrict__ verdict, FalP P)
+{
+    const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = (uint32_t)(tt / P.n); const int e = (int)(tt % P.n);
+    if (b >= batch) return;
+    const int bits = P.q_bits - 2;
+    if ((size_t)siglens[b] * 8 < (size_t)P.n * bits) { if (e == 0) verdict[b] = 1; s2[tt] = 0; return; }
+    const uint8_t *s = sigs + (size_t)b * sig_stride;
+    uint32_t val = 0;
+    for (int k = 0; k < bits; k++) { const uint32_t bp = (uint32_t)e * bits + k; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+    s2[tt] = centre_mod((int32_t)(val << (32 - bits)) >> (32 - bits), P.q);
+}
+
+// s1 = centre(c - s2*h) ; norm test
+__global__ void fal_vfinish_kernel(uint32_t batch, const int32_t *__restrict__ c, int32_t *__restrict__ prod, const int32_t *__restrict__ s2, uint32_t *__restrict__ verdict, FalP P)
+{
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const int n = P.n;
+    int32_t *a1 = prod + (size_t)b * n;
+    const int32_t *cb = c + (size_t)b * n, *a2 = s2 + (size_t)b * n;
+    for (int i = 0; i < n; i++) a1[i] = centre_mod(cb[i] - a1[i], P.q);
+    if (norm_fails(a1, a2, n, P.bd)) verdict[b] = 1;
+}
+
+// exp(i*pi*j/2048), j = 0..2048, in binary128 (Taylor series for the first step, then repeated multiplication); GM[k] for
+// k in [m, 2m), m = 2^logm, is the root with angle pi*(2*rev_logm(k-m)+1)/(2m), rounded to double - this regenerates the
+// reference's fpr_gm_tab (falcon_fft.h) bit for bit, including its (-0.0, 1.0) spelling of entry 1.
+void make_gm(std::vector<double> &gm)
+{
+    typedef __float128 q_t;
+    const q_t pi = (q_t)3.141592653589793116 + (q_t)1.2246467991473532e-16 + (q_t)(-2.9947698097183397e-33);
+    const q_t x = pi / 2048, x2 = x * x;
+    q_t ts = x, tc = 1, s1 = x, c1 = 1;
+    for (int k = 1; k < 16; k++) {
+        tc = -tc * x2 / (q_t)((2 * k - 1) * (2 * k)); c1 += tc;
+        ts = -ts * x2 / (q_t)((2 * k) * (2 * k + 1)); s1 += ts;
+    }
+    std::vector<q_t> cr(2049), ci(2049);
+    cr[0] = 1; ci[0] = 0;
+    for (int j = 1; j <= 2048; j++) { cr[j] = cr[j - 1] * c1 - ci[j - 1] * s1; ci[j] = cr[j - 1] * s1 + ci[j - 1] * c1; }
+    gm.assign(2048, 0.0);
+    for (int logm = 0; logm < 10; logm++) {
+        const unsigned m = 1u << logm;
+        for (unsigned i1 = 0; i1 < m; i1++) {
+            unsigned rev = 0;
+            for (int bb = 0; bb < logm; bb++) rev |= ((i1 >> bb) & 1u) << (logm - 1 - bb);
+            const unsigned k = m + i1, j = (2 * rev + 1) * (2048 / (2 * m));
+            gm[2 * k] = (double)cr[j]; gm[2 * k + 1] = (double)ci[j];
+        }
+    }
+    gm[2] = -0.0; gm[3] = 1.0;
+}
+
+}  // namespace
+
+struct sc_hip_falcon {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    FalP P;
+    bool have_sk, have_pk;
+    double *d_sk, *d_gm;
+    uint64_t *d_tabs; int ts_log;
+    int32_t *d_hhat;
+    size_t cap;
+    double *ws;
+    int32_t *c, *s1, *s2;
+    uint32_t *status, *siglens;
+};
+
+static void fal_free_ws(sc_hip_falcon *f)
+{
+    void *ptrs[] = { f->ws, f->c, f->s1, f->s2, f->status, f->siglens };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    f->ws = nullptr; f->c = f->s1 = f->s2 = nullptr; f->status = f->siglens = nullptr; f->cap = 0;
+}
+
+static int fal_ensure_ws(sc_hip_falcon *f, size_t batch)
+{
+    if (batch <= f->cap) return SC_HIP_SUCCESS;
+    fal_free_ws(f);
+    const size_t n = f->P.n;
+    HIPCHK(hipMalloc((void **)&f->ws, batch * 6 * n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&f->c, batch * n * 4));
+    HIPCHK(hipMalloc((void **)&f->s1, batch * n * 4));
+    HIPCHK(hipMalloc((void **)&f->s2, batch * n * 4));
+    HIPCHK(hipMalloc((void **)&f->status, batch * 4));
+    HIPCHK(hipMalloc((void **)&f->siglens, batch * 4));
+    f->cap = batch;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_falcon_t **out)
+{
+    if (!ctx || !params || !out) return fail("falcon_create: null argument");
+    static_assert(sizeof(FalP) == sizeof(sc_hip_falcon_params_t), "parameter struct layout");
+    FalP P; memcpy(&P, params, sizeof P);
+    if (P.set == 1) return fail("falcon_create: the ternary ring (set 1, x^n - x^(n/2) + 1) is not served");
+    if ((P.n != 512 && P.n != 1024) || (1 << P.n_bits) != P.n) return fail("falcon_create: n must be 512 or 1024 with n_bits = log2 n");
+    if (P.q_bits < 4 || P.q_bits > 30 || P.q < 3 || P.q >= (1 << P.q_bits)) return fail("falcon_create: bad q / q_bits");
+    sc_hip_plan *plan = nullptr;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    HIPCHK(hipSetDevice(ctx->device));
+    sc_hip_falcon *f = new sc_hip_falcon;
+    memset(f, 0, sizeof *f);
+    f->ctx = ctx; f->plan = plan; f->P = P;
+    std::vector<double> gm;
+    make_gm(gm);
+    if (hipMalloc((void **)&f->d_gm, gm.size() * sizeof(double)) != hipSuccess ||
+        hipMemcpy(f->d_gm, gm.data(), gm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        sc_hip_falcon_destroy(f);
+        return fail("falcon_create: device allocation failed");
+    }
+    *out = f;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
+{
+    if (!f) return;
+    fal_free_ws(f);
+    void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    sc_hip_plan_destroy(f->plan);
+    delete f;
+}
+
+static void leaf_sigmas(const double *tree, unsigned logn, std::vector<float> &out)
+{
+    if (logn == 0) { out.push_back((float)tree[0]); return; }
+    const size_t n = (size_t)1 << logn;
+    leaf_sigmas(tree + n + treesize(logn - 1), logn - 1, out);         // tree1 is visited first (gpv.c:2693-2700)
+    leaf_sigmas(tree + n, logn - 1, out);
+}
+
+// sk: the expanded private key load_skey leaves in sc->falcon->sk (falcon.c:786-790, falcon_keygen.c:6107-6170):
+// b00 | b01 | b10 | b11 in FFT form, then the normalised LDL tree; (n_bits + 5) * n doubles
+extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk)
+{
+    if (!f || !sk) return fail("falcon_set_privkey: null argument");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    const size_t n = f->P.n, total = (size_t)(f->P.n_bits + 5) * n;
+    std::vector<float> sig;
+    leaf_sigmas(sk + 4 * n, (unsigned)f->P.n_bits, sig);
+    int ts = 2;
+    for (float s : sig) {
+        if (!(s > 0.0f) || !(s < 400.0f)) return fail("falcon_set_privkey: a tree leaf is not a usable standard deviation");
+        const int sz = sc_hip_cdt_table_size(10.0f, s);
+        if (sz > ts) ts = sz;
+    }
+    int ts_log = 0;
+    while ((1 << ts_log) < ts) ts_log++;
+    std::vector<uint64_t> tabs(n << ts_log, ~0ULL);
+    for (size_t i = 0; i < n; i++) {
+        const int sz = sc_hip_cdt_table_size(10.0f, sig[i]);
+        if (sz >= 2) { if (sc_hip_cdt_build_table(10.0f, sig[i], &tabs[i << ts_log], sz) != SC_HIP_SUCCESS) return SC_HIP_FAILURE; }
+        else tabs[i << ts_log] = 0;                                     // a one-entry table always yields 0
+    }
+    if (f->d_tabs) { (void)hipFree(f->d_tabs); f->d_tabs = nullptr; }
+    HIPCHK(hipMalloc((void **)&f->d_tabs, tabs.size() * 8));
+    HIPCHK(hipMemcpy(f->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
+    if (!f->d_sk) HIPCHK(hipMalloc((void **)&f->d_sk, total * sizeof(double)));
+    HIPCHK(hipMemcpy(f->d_sk, sk, total * sizeof(double), hipMemcpyHostToDevice));
+    f->ts_log = ts_log;
+    f->have_sk = true;
+    return SC_HIP_SUCCESS;
+}
+
+// h: the public key in the coefficient domain, SINT16[n] (the first half of sc->pubkey->key, falcon.c:772-780)
+extern "C" int sc_hip_falcon_set_pubkey(sc_hip_falcon_t *f, const int16_t *h)
+{
+    if (!f || !h) return fail("falcon_set_pubkey: null argument");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    const size_t n = f->P.n;
+    std::vector<int32_t> h32(n);
+    for (size_t i = 0; i < n; i++) { int32_t v = h[i] % f->P.q; if (v < 0) v += f->P.q; h32[i] = v; }
+    if (!f->d_hhat) HIPCHK(hipMalloc((void **)&f->d_hhat, n * 4));
+    HIPCHK(hipMemcpy(f->d_hhat, h32.data(), n * 4, hipMemcpyHostToDevice));
+    if (sc_hip_ntt_fwd(f->plan, 1, f->d_hhat, f->d_hhat, nullptr) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    f->have_pk = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *f)
+{
+    if (!f) return 0;
+    return ((size_t)f->P.n * (size_t)(f->P.q_bits - 2) + 7) / 8;
+}
+
+static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s)
+{
+    HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
+    hipLaunchKernelGGL(fal_sample_kernel, dim3((unsigned)((batch + ST - 1) / ST)), dim3(ST), 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens,
+                       f->d_sk, f->d_gm, f->d_tabs, f->ts_log, d_s1, d_s2, d_status, f->P,
+                       1.0 / (double)(long)f->P.q /* fpr_inverse_of, falcon_fft.h:57-60 */);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+static int fal_check_common(const sc_hip_falcon *f, size_t batch, const char *who)
+{
+    if (!f) return fail(std::string(who) + ": null handle");
+    if (batch > 0x7fffffffu / 4096) return fail(std::string(who) + ": batch too large");
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_falcon_sample(sc_hip_falcon_t *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                    int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, void *stream)
+{
+    if (fal_check_common(f, batch, "falcon_sample")) return SC_HIP_FAILURE;
+    if (!f->have_sk) return fail("falcon_sample: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_c || !d_tapes || !d_s2) return fail("falcon_sample: null buffer");
+    if (tape_stride > 0xffffffffu) return fail("falcon_sample: tape too long");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    return fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, d_tape_lens, d_s1, d_s2, d_status ? d_status : f->status, (hipStream_t)stream);
+}
+
+extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                  const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                  uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
+{
+    if (fal_check_common(f, batch, "falcon_sign")) return SC_HIP_FAILURE;
+    if (!f->have_sk) return fail("falcon_sign: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("falcon_sign: null buffer");
+    if (sig_stride < sc_hip_falcon_sig_bytes(f)) return fail("falcon_sign: sig_stride smaller than sc_hip_falcon_sig_bytes()");
+    if (tape_stride > 0xffffffffu) return fail("falcon_sign: tape too long");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    uint32_t *status = d_status ? d_status : f->status;
+    hipLaunchKernelGGL(fal_hash_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
+    HIPCHK(hipGetLastError());
+    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(fal_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                    const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (fal_check_common(f, batch, "falcon_verify")) return SC_HIP_FAILURE;
+    if (!f->have_pk) return fail("falcon_verify: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("falcon_verify: null buffer");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    const size_t ne = batch * (size_t)f->P.n;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P);
+    hipLaunchKernelGGL(fal_hash_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}

@@ -23,6 +23,8 @@ SYMBOLS = [
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
+    'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
+    'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -125,6 +127,16 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sig_bytes.restype = sz
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_falcon_destroy.argtypes = [vp]
+    L.sc_hip_falcon_destroy.restype = None
+    L.sc_hip_falcon_set_privkey.argtypes = [vp, vp]
+    L.sc_hip_falcon_set_pubkey.argtypes = [vp, vp]
+    L.sc_hip_falcon_sig_bytes.argtypes = [vp]
+    L.sc_hip_falcon_sig_bytes.restype = sz
+    L.sc_hip_falcon_sample.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
+    L.sc_hip_falcon_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.sc_hip_falcon_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_time_op.argtypes = [vp, C.c_int, sz, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
     _LIB = L
     return L
@@ -171,6 +183,9 @@ class Engine:
 
     def bliss(self, params):
         return Bliss(self, params)
+
+    def falcon(self, params):
+        return Falcon(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -491,6 +506,73 @@ class Bliss:
         verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
         _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
+        return verdicts
+
+
+class Falcon:
+    """Batched Falcon (sets 0 and 2) tree sampler / sign / verify under one key (gaussian_sample_with_tree, falcon_sig_sign,
+    falcon_sig_verify counterpart).  params: the 8 words {n, q, q_bits, n_bits, set, f32 bd, 0, 0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 8
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_falcon_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_falcon_create')
+        self.h = h
+        self.n = int(self.par[0])
+        self.sig_bytes = self.L.sc_hip_falcon_sig_bytes(h)
+        self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_falcon_destroy(self.h)
+            self.h = None
+
+    def set_privkey(self, sk):
+        """sk: float64 [(n_bits+5)*n], the expanded key (b00|b01|b10|b11|tree)"""
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(sk), dtype=np.float64)
+        assert a.size == (int(self.par[3]) + 5) * self.n
+        _chk(self.L, self.L.sc_hip_falcon_set_privkey(self.h, _ptr(a)), 'falcon_set_privkey')
+
+    def set_pubkey(self, h):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
+        assert a.size == self.n
+        _chk(self.L, self.L.sc_hip_falcon_set_pubkey(self.h, _ptr(a)), 'falcon_set_pubkey')
+
+    def sample(self, c, tapes, tape_lens=None, want_s1=True):
+        """c int32 [batch][n], tapes int32/uint32 [batch][>= 4n] (device) -> s1, s2 int32 [batch][n], status"""
+        import torch
+        batch, dev = c.shape[0], c.device
+        s1 = torch.empty((batch, self.n), dtype=torch.int32, device=dev) if want_s1 else None
+        s2 = torch.empty((batch, self.n), dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_falcon_sample(self.h, batch, _ptr(c), _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+                                                 _ptr(s1) if want_s1 else nul, _ptr(s2), _ptr(status), _stream()), 'falcon_sample')
+        return s1, s2, status
+
+    def sign(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_falcon_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                               _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+                                               _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(status), _stream()), 'falcon_sign')
+        return sigs, siglens, status
+
+    def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_falcon_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                 _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'falcon_verify')
         return verdicts
 
 
