@@ -10,7 +10,8 @@
  *
  * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
- *        ref_driver bench_dil <set> <seconds>    (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
+ *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
+ *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
  * Fixture format (one file per topic): repeated records
  *     @ <name> <count>\n  followed by <count> whitespace separated decimal integers.
@@ -605,10 +606,10 @@ static int bench_ntt(int32_t q, int n, double seconds)
 
 /* safecrypto_sign / safecrypto_verify of the reference, one key, 64-byte counter-derived messages
  * (the loop of test/functional/func_alg_dilithium.c:191-230 without the key regeneration) */
-static int bench_dil(int set, double seconds)
+static int bench_sig(sc_scheme_e scheme, int set, double seconds)
 {
     UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
     if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     enum { POOL = 64 };
     uint8_t msg[POOL][64], *sig[POOL]; size_t siglen[POOL];
@@ -636,7 +637,9 @@ static int bench_dil(int set, double seconds)
 
 int main(int argc, char **argv)
 {
-    if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_dil(atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_sig(SC_SCHEME_SIG_DILITHIUM, atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
