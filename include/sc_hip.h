@@ -165,6 +165,34 @@ int sc_hip_dilithium_sign_host(sc_hip_dilithium_t *h, size_t batch, const uint8_
 int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
                                  uint32_t fixed_len, const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
 
+/* ---- remaining sc_ntt / sc_poly / sc_vec entries, batched (csrc/ops.hip) -------------------- */
+
+/* replaces: pwr_32 (src/utils/arith/ntt_template.c.in:1689-1720) elementwise: d_out[i] = d_x[i]^e mod q, canonical; e >= 0 */
+int sc_hip_ntt_pwr(sc_hip_plan_t *plan, size_t len, const int32_t *d_x, int32_t e, int32_t *d_out, void *stream);
+/* replaces: invert_32 (ntt_template.c.in:1722-1747) for `batch` polynomials of plan-n coefficients, in place: v <- v^(q-2).
+ * d_rc[i] = 0 (SC_FUNC_SUCCESS) or 1 (SC_FUNC_FAILURE: polynomial i has a coefficient = 0 mod q; as in the reference the
+ * coefficients before the first such one are inverted and the rest left untouched).  Outputs canonical. */
+int sc_hip_ntt_invert(sc_hip_plan_t *plan, size_t batch, int32_t *d_v, int32_t *d_rc, void *stream);
+/* replaces: div_32 (ntt_template.c.in:1749-1775): num <- num * den^(q-2), same failure rule */
+int sc_hip_ntt_div(sc_hip_plan_t *plan, size_t batch, int32_t *d_num, const int32_t *d_den, int32_t *d_rc, void *stream);
+/* replaces: mul_32_sparse / mul_32_sparse_16 (src/utils/arith/ntt.c:381-422; ring_tesla.c:856-871,1015-1023):
+ * out[j] = sum_k (j < pos_k ? t[j + n - pos_k] : -t[j - pos_k]) in exact (wrapping) integers, i.e. -t * sum_k x^pos_k in
+ * Z[x]/(x^n+1) as the reference computes it; d_pos int32 [batch][omega], d_t [batch][n]; d_out must not alias d_t */
+int sc_hip_mult_sparse(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const int32_t *d_t, const int32_t *d_pos, int32_t *d_out, void *stream);
+int sc_hip_mult_sparse_16(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const int16_t *d_t, const int32_t *d_pos, int32_t *d_out, void *stream);
+/* replaces: utils_arith_poly mul_32_scalar, mod_negate_32 (src/utils/arith/poly_32.c:46-52,149-155) on flat arrays (16-byte
+ * aligned), add_32_scalar (:38-43; coefficient 0 of each of `batch` polynomials of n coefficients, per-polynomial scalars;
+ * sub_32_scalar = negated scalars), cmp_not_equal_32 (:157-165; d_out[i] = OR of the XORs, 0 iff equal).
+ * add_single_32 / sub_single_32 (:64-82) are sc_hip_poly_add / sc_hip_poly_sub with d_out == d_a. */
+int sc_hip_poly_mul_scalar(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_in, int32_t scalar, int32_t *d_out, void *stream);
+int sc_hip_poly_mod_negate(sc_hip_ctx_t *ctx, size_t len, int32_t q, const int32_t *d_in, int32_t *d_out, void *stream);
+int sc_hip_poly_add_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, int32_t *d_polys, const int32_t *d_scalars, void *stream);
+int sc_hip_poly_cmp_not_equal(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+/* replaces: utils_arith_vectors absmax_32 / scalar_32 (src/utils/arith/vectors.c:25-60) per polynomial: max |v_j| ; sum t_j u_j
+ * (SINT32, wrapping) */
+int sc_hip_vec_absmax(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_v, int32_t *d_out, void *stream);
+int sc_hip_vec_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_t, const int32_t *d_u, int32_t *d_out, void *stream);
+
 /* ---- BLISS-B: batched sign / verify under one key ------------------------------------------ */
 
 /* the fields of bliss_set_t the engine needs (src/schemes/sig/bliss_b/bliss_params.h:43-75, values

@@ -25,6 +25,9 @@ SYMBOLS = [
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
+    'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
+    'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
+    'sc_hip_vec_absmax', 'sc_hip_vec_scalar',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -127,6 +130,17 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sig_bytes.restype = sz
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
+    L.sc_hip_ntt_invert.argtypes = [vp, sz, vp, vp, vp]
+    L.sc_hip_ntt_div.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.sc_hip_mult_sparse.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.sc_hip_mult_sparse_16.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
+    L.sc_hip_poly_mul_scalar.argtypes = [vp, sz, vp, i32, vp, vp]
+    L.sc_hip_poly_mod_negate.argtypes = [vp, sz, i32, vp, vp, vp]
+    L.sc_hip_poly_add_scalar.argtypes = [vp, sz, sz, vp, vp, vp]
+    L.sc_hip_poly_cmp_not_equal.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.sc_hip_vec_absmax.argtypes = [vp, sz, sz, vp, vp, vp]
+    L.sc_hip_vec_scalar.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_falcon_destroy.argtypes = [vp]
     L.sc_hip_falcon_destroy.restype = None
@@ -216,6 +230,48 @@ class Engine:
         _chk(self.L, self.L.sc_hip_poly_sub(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'poly_sub')
         return out
 
+    # utils_arith_poly / utils_arith_vectors entries (device tensors, int32; per-polynomial ops take [batch][n])
+    def poly_mul_scalar(self, a, scalar, out=None):
+        import torch
+        out = torch.empty_like(a) if out is None else out
+        _chk(self.L, self.L.sc_hip_poly_mul_scalar(self.h, a.numel(), _ptr(a), int(scalar), _ptr(out), _stream()), 'poly_mul_scalar')
+        return out
+
+    def poly_mod_negate(self, a, q, out=None):
+        import torch
+        out = torch.empty_like(a) if out is None else out
+        _chk(self.L, self.L.sc_hip_poly_mod_negate(self.h, a.numel(), int(q), _ptr(a), _ptr(out), _stream()), 'poly_mod_negate')
+        return out
+
+    def poly_add_scalar(self, polys, scalars):
+        """in place: coefficient 0 of polynomial i += scalars[i]"""
+        _chk(self.L, self.L.sc_hip_poly_add_scalar(self.h, polys.shape[0], polys.shape[1], _ptr(polys), _ptr(scalars), _stream()), 'poly_add_scalar')
+        return polys
+
+    def _per_poly(self, fn, what, a, b=None):
+        import torch
+        out = torch.empty(a.shape[0], dtype=torch.int32, device=a.device)
+        args = [self.h, a.shape[0], a.shape[1], _ptr(a)] + ([_ptr(b)] if b is not None else []) + [_ptr(out), _stream()]
+        _chk(self.L, fn(*args), what)
+        return out
+
+    def poly_cmp_not_equal(self, a, b):
+        return self._per_poly(self.L.sc_hip_poly_cmp_not_equal, 'poly_cmp_not_equal', a, b)
+
+    def vec_absmax(self, v):
+        return self._per_poly(self.L.sc_hip_vec_absmax, 'vec_absmax', v)
+
+    def vec_scalar(self, t, u):
+        return self._per_poly(self.L.sc_hip_vec_scalar, 'vec_scalar', t, u)
+
+    def mult_sparse(self, t, pos):
+        """t int32 or int16 [batch][n], pos int32 [batch][omega] -> int32 [batch][n] (mul_32_sparse / mul_32_sparse_16)"""
+        import torch
+        out = torch.empty(t.shape, dtype=torch.int32, device=t.device)
+        fn = self.L.sc_hip_mult_sparse_16 if t.dtype == torch.int16 else self.L.sc_hip_mult_sparse
+        _chk(self.L, fn(self.h, t.shape[0], t.shape[1], pos.shape[1], _ptr(t), _ptr(pos), _ptr(out), _stream()), 'mult_sparse')
+        return out
+
 
 class NttPlan:
     """(q, n) context: the GPU counterpart of ntt_params_t + w/r tables."""
@@ -296,6 +352,24 @@ class NttPlan:
         out = self._out(a, out)
         _chk(self.L, self.L.sc_hip_center(self.h, a.numel(), _ptr(a), _ptr(out), _stream()), 'center')
         return out
+
+    def pwr(self, x, e, out=None):
+        out = self._out(x, out)
+        _chk(self.L, self.L.sc_hip_ntt_pwr(self.h, x.numel(), _ptr(x), int(e), _ptr(out), _stream()), 'ntt_pwr')
+        return out
+
+    def invert(self, v):
+        """in place on v [batch][n]; returns the per-polynomial return codes (0 ok / 1 a coefficient was 0 mod q)"""
+        import torch
+        rc = torch.empty(v.shape[0], dtype=torch.int32, device=v.device)
+        _chk(self.L, self.L.sc_hip_ntt_invert(self.h, v.shape[0], _ptr(v), _ptr(rc), _stream()), 'ntt_invert')
+        return rc
+
+    def div(self, num, den):
+        import torch
+        rc = torch.empty(num.shape[0], dtype=torch.int32, device=num.device)
+        _chk(self.L, self.L.sc_hip_ntt_div(self.h, num.shape[0], _ptr(num), _ptr(den), _ptr(rc), _stream()), 'ntt_div')
+        return rc
 
     # host-buffer entry points (numpy in / numpy out), the shape the reference's vtable has
     def fwd_host(self, a):

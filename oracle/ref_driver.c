@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
@@ -467,6 +467,90 @@ static int gen_kyber(const char *dir)
     return rc;
 }
 
+/* ------------------------------------------------- small arithmetic entries ---- */
+/* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
+ * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
+ * inputs through the reference's own function-pointer tables. */
+static int gen_ops(const char *dir)
+{
+    char path[512], name[96];
+    snprintf(path, sizeof path, "%s/ops_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+    const utils_arith_poly_t *poly = utils_arith_poly();
+    const utils_arith_vec_t *vec = utils_arith_vectors();
+    const int qs[2] = { 12289, 8380417 }, ns[2] = { 512, 256 };
+    for (int c = 0; c < 2; c++) {
+        const int q = qs[c], n = ns[c], NP = 4;
+        ntt_params_t p; init_reduce(&p, n, q);
+        int32_t *a = malloc(sizeof(int32_t) * n * NP), *b = malloc(sizeof(int32_t) * n * NP), *o = malloc(sizeof(int32_t) * n * NP);
+        int32_t rc[4], sc4[8];
+        sm_state = 0x0b5000ULL + (uint64_t)q;
+        /* poly 0,1: uniform non-zero residues; 2: signed small values (non-canonical inputs); 3: contains zeros (failure case) */
+        for (int i = 0; i < n; i++) { a[i] = 1 + (int)(splitmix64() % (uint64_t)(q - 1)); b[i] = 1 + (int)(splitmix64() % (uint64_t)(q - 1)); }
+        for (int i = 0; i < n; i++) { a[n + i] = 1 + (int)(splitmix64() % (uint64_t)(q - 1)); b[n + i] = (int)(splitmix64() % (uint64_t)q); }
+        for (int i = 0; i < n; i++) { int v = (int)(splitmix64() % 4001) - 2000; a[2 * n + i] = v ? v : 7; b[2 * n + i] = (int)(splitmix64() % 4001) - 2000; }
+        for (int i = 0; i < n; i++) { a[3 * n + i] = 1 + (int)(splitmix64() % (uint64_t)(q - 1)); b[3 * n + i] = (int)(splitmix64() % (uint64_t)q); }
+        a[3 * n + n / 3] = 0; a[3 * n + n / 2] = q;        /* both are zero mod q; the first one stops the reference */
+        snprintf(name, sizeof name, "q%d_n%d_a", q, n); rec_i32(f, name, a, (size_t)n * NP);
+        snprintf(name, sizeof name, "q%d_n%d_b", q, n); rec_i32(f, name, b, (size_t)n * NP);
+        /* invert_32: in place, stops at the first zero (earlier entries already inverted); normalised for the fixture */
+        memcpy(o, a, sizeof(int32_t) * n * NP);
+        for (int k = 0; k < NP; k++) { rc[k] = ntt->invert_32(o + k * n, &p, n); ntt->normalize_32(o + k * n, n, &p); }
+        snprintf(name, sizeof name, "q%d_n%d_invert", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        snprintf(name, sizeof name, "q%d_n%d_invert_rc", q, n); rec_i32(f, name, rc, NP);
+        /* div_32: num = b, den = a */
+        memcpy(o, b, sizeof(int32_t) * n * NP);
+        for (int k = 0; k < NP; k++) { rc[k] = ntt->div_32(o + k * n, a + k * n, &p, n); ntt->normalize_32(o + k * n, n, &p); }
+        snprintf(name, sizeof name, "q%d_n%d_div", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        snprintf(name, sizeof name, "q%d_n%d_div_rc", q, n); rec_i32(f, name, rc, NP);
+        /* pwr_32 with exponents 0, 1, 2, 65537, q-2 on poly 0 (canonical inputs) */
+        const int32_t es[5] = { 0, 1, 2, 65537, q - 2 };
+        for (int e = 0; e < 5; e++) {
+            for (int i = 0; i < n; i++) o[i] = ntt->pwr_32(a[i], es[e], &p);
+            ntt->normalize_32(o, n, &p);
+            snprintf(name, sizeof name, "q%d_n%d_pwr%d", q, n, e); rec_i32(f, name, o, n);
+        }
+        rec_i32(f, c == 0 ? "q12289_pwr_exponents" : "q8380417_pwr_exponents", es, 5);
+        /* mul_32_sparse: omega distinct positions per polynomial, t = b (signed values for poly 2) */
+        const int omega = 11;
+        int32_t *pos = malloc(sizeof(int32_t) * omega * NP);
+        for (int k = 0; k < NP; k++)
+            for (int i = 0; i < omega; i++) {
+                int v, dup;
+                do { v = (int)(splitmix64() % (uint64_t)n); dup = 0; for (int j = 0; j < i; j++) dup |= pos[k * omega + j] == v; } while (dup);
+                pos[k * omega + i] = v;
+            }
+        pos[0] = 0;                                                   /* exercise position 0 */
+        for (int k = 0; k < NP; k++) ntt->mul_32_sparse(o + k * n, n, omega, b + k * n, pos + k * omega);
+        snprintf(name, sizeof name, "q%d_n%d_sparse_pos", q, n); rec_i32(f, name, pos, (size_t)omega * NP);
+        snprintf(name, sizeof name, "q%d_n%d_sparse", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        free(pos);
+        /* poly entries */
+        memcpy(o, a, sizeof(int32_t) * n * NP); poly->mul_32_scalar(o, (size_t)n * NP, -3);
+        snprintf(name, sizeof name, "q%d_n%d_mul_scalar_m3", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        memcpy(o, a, sizeof(int32_t) * n * NP); for (int k = 0; k < NP; k++) poly->add_32_scalar(o + k * n, n, 1000 + k);
+        snprintf(name, sizeof name, "q%d_n%d_add_scalar", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        poly->mod_negate_32(o, (size_t)n * NP, q, b);
+        snprintf(name, sizeof name, "q%d_n%d_mod_negate", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        memcpy(o, a, sizeof(int32_t) * n * NP); poly->add_single_32(o, (size_t)n * NP, b);
+        snprintf(name, sizeof name, "q%d_n%d_add_single", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        memcpy(o, a, sizeof(int32_t) * n * NP); poly->sub_single_32(o, (size_t)n * NP, b);
+        snprintf(name, sizeof name, "q%d_n%d_sub_single", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        /* cmp_not_equal: a vs a (0), a vs a with one coefficient changed, a vs b */
+        memcpy(o, a, sizeof(int32_t) * n * NP); o[n + 17] ^= 0x40;
+        rc[0] = poly->cmp_not_equal_32(a, a, n); rc[1] = poly->cmp_not_equal_32(a + n, o + n, n);
+        rc[2] = poly->cmp_not_equal_32(a + 2 * n, b + 2 * n, n); rc[3] = poly->cmp_not_equal_32(a + 3 * n, o + 3 * n, n);
+        snprintf(name, sizeof name, "q%d_n%d_cmp", q, n); rec_i32(f, name, rc, 4);
+        for (int k = 0; k < NP; k++) { sc4[k] = vec->absmax_32(b + k * n, n); sc4[4 + k] = vec->scalar_32(a + k * n, b + k * n, n); }
+        snprintf(name, sizeof name, "q%d_n%d_absmax_scalar", q, n); rec_i32(f, name, sc4, 8);
+        free(a); free(b); free(o);
+    }
+    fclose(f);
+    return 0;
+}
+
 /* ---------------------------------------------------------------- Falcon ---- */
 #include "schemes/sig/falcon/falcon.h"
 #include "schemes/sig/falcon/falcon_params.h"
@@ -641,7 +725,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
@@ -649,5 +733,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
     if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
     if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
+    if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);
     return rc;
 }

@@ -192,6 +192,62 @@ void orc_mult_sparse(int32_t *v, int n, int omega, const int32_t *t, const int32
 void orc_poly_add(int32_t *out, int n, const int32_t *a, const int32_t *b) { for (int i = n; i--;) out[i] = a[i] + b[i]; }
 void orc_poly_sub(int32_t *out, int n, const int32_t *a, const int32_t *b) { for (int i = n; i--;) out[i] = a[i] - b[i]; }
 
+/* ntt_template.c.in:1689-1720: square-and-multiply, LSB first, through muln (sqrn = muln(x,x)) */
+int32_t orc_pwr(int32_t x, int32_t e, int32_t q)
+{
+    int32_t y = (e & 1) ? x : 1;
+    e >>= 1;
+    while (e > 0) {
+        x = orc_muln(x, x, q);
+        if (e & 1) y = orc_muln(x, y, q);
+        e >>= 1;
+    }
+    return y;
+}
+
+/* ntt_template.c.in:1722-1747: in place x -> x^(q-2); stops with SC_FUNC_FAILURE (1) at the first x = 0 mod q,
+ * leaving the earlier entries inverted and the rest untouched */
+int orc_invert(int32_t *v, size_t n, int32_t q)
+{
+    for (size_t i = 0; i < n; i++) {
+        int32_t x = orc_modn(v[i], q);
+        if (x == 0) return 1;
+        v[i] = orc_pwr(x, q - 2, q);
+    }
+    return 0;
+}
+
+/* ntt_template.c.in:1749-1775: num[i] = muln(num[i], den[i]^(q-2)); same early exit */
+int orc_div(int32_t *num, const int32_t *den, size_t n, int32_t q)
+{
+    for (size_t i = 0; i < n; i++) {
+        int32_t x = orc_modn(den[i], q);
+        if (x == 0) return 1;
+        num[i] = orc_muln(num[i], orc_pwr(x, q - 2, q), q);
+    }
+    return 0;
+}
+
+/* poly_32.c:38-82,149-165 and vectors.c:25-60 (SINT32 arithmetic wraps) */
+void orc_poly_mul_scalar(int32_t *p, size_t n, int32_t s) { for (size_t i = n; i--;) p[i] = (int32_t)((uint32_t)p[i] * (uint32_t)s); }
+void orc_poly_add_scalar(int32_t *p, size_t n, int32_t s) { if (n > 0) p[0] = (int32_t)((uint32_t)p[0] + (uint32_t)s); }
+void orc_poly_mod_negate(int32_t *out, size_t n, int32_t q, const int32_t *in) { for (size_t i = n; i--;) out[i] = q - in[i]; }
+void orc_poly_add_single(int32_t *out, size_t n, const int32_t *in) { for (size_t i = n; i--;) out[i] = (int32_t)((uint32_t)out[i] + (uint32_t)in[i]); }
+void orc_poly_sub_single(int32_t *out, size_t n, const int32_t *in) { for (size_t i = n; i--;) out[i] = (int32_t)((uint32_t)out[i] - (uint32_t)in[i]); }
+int32_t orc_poly_cmp_not_equal(const int32_t *a, const int32_t *b, size_t n) { int32_t ne = 0; for (size_t i = n; i--;) ne |= a[i] ^ b[i]; return ne; }
+int32_t orc_vec_absmax(const int32_t *v, size_t n)
+{
+    int32_t max = 0;
+    for (size_t i = 0; i < n; i++) { if (v[i] > max) max = v[i]; if (-v[i] > max) max = -v[i]; }
+    return max;
+}
+int32_t orc_vec_scalar(const int32_t *t, const int32_t *u, size_t n)
+{
+    uint32_t sum = 0;
+    for (size_t i = 0; i < n; i++) sum += (uint32_t)t[i] * (uint32_t)u[i];
+    return (int32_t)sum;
+}
+
 /* --------------------------------------------------------------- sampler ---- */
 
 /* sc_math.c sc_ceil_log2 applied to (UINT32)(tail*sigma) (gaussian_cdf.c:562): the number

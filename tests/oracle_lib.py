@@ -34,6 +34,21 @@ def lib():
         L.orc_polymul.argtypes = [i32p, C.c_int, C.c_int32, i32p, i32p, i32p, i32p]
         L.orc_polymul_ntt.argtypes = [i32p, C.c_int, C.c_int32, i32p, i32p, i32p, i32p]
         L.orc_mult_sparse.argtypes = [i32p, C.c_int, C.c_int, i32p, i32p]
+        L.orc_pwr.restype = C.c_int32
+        L.orc_pwr.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+        L.orc_invert.argtypes = [i32p, C.c_size_t, C.c_int32]
+        L.orc_div.argtypes = [i32p, i32p, C.c_size_t, C.c_int32]
+        L.orc_poly_mul_scalar.argtypes = [i32p, C.c_size_t, C.c_int32]
+        L.orc_poly_add_scalar.argtypes = [i32p, C.c_size_t, C.c_int32]
+        L.orc_poly_mod_negate.argtypes = [i32p, C.c_size_t, C.c_int32, i32p]
+        L.orc_poly_add_single.argtypes = [i32p, C.c_size_t, i32p]
+        L.orc_poly_sub_single.argtypes = [i32p, C.c_size_t, i32p]
+        L.orc_poly_cmp_not_equal.restype = C.c_int32
+        L.orc_poly_cmp_not_equal.argtypes = [i32p, i32p, C.c_size_t]
+        L.orc_vec_absmax.restype = C.c_int32
+        L.orc_vec_absmax.argtypes = [i32p, C.c_size_t]
+        L.orc_vec_scalar.restype = C.c_int32
+        L.orc_vec_scalar.argtypes = [i32p, i32p, C.c_size_t]
         L.orc_cdt_bits.restype = C.c_int
         L.orc_cdt_bits.argtypes = [C.c_float, C.c_float]
         L.orc_cdt_create.argtypes = [C.c_float, C.c_float, u64p, C.c_int]
