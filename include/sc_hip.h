@@ -169,12 +169,12 @@ int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *h, size_t batch, const uint
 
 /* replaces: pwr_32 (src/utils/arith/ntt_template.c.in:1689-1720) elementwise: d_out[i] = d_x[i]^e mod q, canonical; e >= 0 */
 int sc_hip_ntt_pwr(sc_hip_plan_t *plan, size_t len, const int32_t *d_x, int32_t e, int32_t *d_out, void *stream);
-/* replaces: invert_32 (ntt_template.c.in:1722-1747) for `batch` polynomials of plan-n coefficients, in place: v <- v^(q-2).
+/* replaces: invert_32 (ntt_template.c.in:1722-1747) for `batch` arrays of n coefficients (any n >= 1; the plan supplies q), in place: v <- v^(q-2).
  * d_rc[i] = 0 (SC_FUNC_SUCCESS) or 1 (SC_FUNC_FAILURE: polynomial i has a coefficient = 0 mod q; as in the reference the
  * coefficients before the first such one are inverted and the rest left untouched).  Outputs canonical. */
-int sc_hip_ntt_invert(sc_hip_plan_t *plan, size_t batch, int32_t *d_v, int32_t *d_rc, void *stream);
+int sc_hip_ntt_invert(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *d_v, int32_t *d_rc, void *stream);
 /* replaces: div_32 (ntt_template.c.in:1749-1775): num <- num * den^(q-2), same failure rule */
-int sc_hip_ntt_div(sc_hip_plan_t *plan, size_t batch, int32_t *d_num, const int32_t *d_den, int32_t *d_rc, void *stream);
+int sc_hip_ntt_div(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *d_num, const int32_t *d_den, int32_t *d_rc, void *stream);
 /* replaces: mul_32_sparse / mul_32_sparse_16 (src/utils/arith/ntt.c:381-422; ring_tesla.c:856-871,1015-1023):
  * out[j] = sum_k (j < pos_k ? t[j + n - pos_k] : -t[j - pos_k]) in exact (wrapping) integers, i.e. -t * sum_k x^pos_k in
  * Z[x]/(x^n+1) as the reference computes it; d_pos int32 [batch][omega], d_t [batch][n]; d_out must not alias d_t */
@@ -297,6 +297,9 @@ int sc_hip_cdt_sample_host(sc_hip_cdt_t *cdt, size_t count, const uint64_t *h_un
 int sc_hip_pointwise_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_a, const int32_t *h_b, int32_t *h_out);
 int sc_hip_normalize_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_in, int32_t *h_out);
 int sc_hip_center_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_in, int32_t *h_out);
+int sc_hip_ntt_invert_host(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *h_v, int32_t *h_rc);
+int sc_hip_ntt_div_host(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *h_num, const int32_t *h_den, int32_t *h_rc);
+int sc_hip_mult_sparse_host(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const void *h_t, int t_is_16, const int32_t *h_pos, int32_t *h_out);
 
 /* ---- timing helper ---------------------------------------------------------------------- */
 /* Runs `iters` back-to-back launches of one op (0 fwd, 1 inv, 2 polymul_ntt, 3 polymul) on

@@ -43,6 +43,12 @@ typedef struct sc_hip_ntt32_vtable {
     void (*inv_ntt_32_16)(int32_t *v, const sc_hip_ntt_params_t *p, const int32_t *t, const int16_t *w, const int16_t *r);
     void (*fwd_ntt_32_16_large)(int32_t *v, const sc_hip_ntt_params_t *p, const int32_t *t, const int16_t *w);
     void (*inv_ntt_32_16_large)(int32_t *v, const sc_hip_ntt_params_t *p, const int32_t *t, const int16_t *w, const int16_t *r);
+    /* ntt.h:150-153,164-165,240-241,250-251: sparse products (ring-TESLA) and the fallible pointwise inverse / division
+     * (0 = SC_FUNC_SUCCESS, 1 = SC_FUNC_FAILURE; an engine error also returns 1 and is counted) */
+    void (*mul_32_sparse)(int32_t *v, size_t n, uint16_t omega, const int32_t *t, const int32_t *c);
+    void (*mul_32_sparse_16)(int32_t *v, size_t n, uint16_t omega, const int16_t *t, const int32_t *c);
+    int32_t (*invert_32)(int32_t *v, const sc_hip_ntt_params_t *p, size_t n);
+    int32_t (*div_32)(int32_t *num, const int32_t *den, const sc_hip_ntt_params_t *p, size_t n);
 } sc_hip_ntt32_vtable_t;
 
 /* replaces: utils_arith_ntt(safecrypto_ntt_e) (src/utils/arith/arith.c:360-396) for a new

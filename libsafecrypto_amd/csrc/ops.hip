@@ -158,14 +158,15 @@ int run_reduce(sc_hip_ctx *ctx, size_t batch, size_t n, const int32_t *a, const 
     return SC_HIP_SUCCESS;
 }
 
-int run_invert(sc_hip_plan *p, size_t batch, int32_t *v, const int32_t *den, int32_t *rc, void *stream, const char *who)
+int run_invert(sc_hip_plan *p, size_t batch, size_t n, int32_t *v, const int32_t *den, int32_t *rc, void *stream, const char *who)
 {
     if (!p) return fail(std::string(who) + ": null plan");
     if (batch == 0) return SC_HIP_SUCCESS;
+    if (n == 0 || n > 0x7fffffffu) return fail(std::string(who) + ": bad length");
     if (!v || !rc) return fail(std::string(who) + ": null buffer");
     if (batch > 0x7fffffffu) return fail(std::string(who) + ": batch too large");
     HIPCHK(hipSetDevice(p->ctx->device));
-    hipLaunchKernelGGL(invert_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, den, rc, batch, (size_t)p->n, p->k[1], p->r2, p->r2p);
+    hipLaunchKernelGGL(invert_kernel, dim3((unsigned)((batch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, v, den, rc, batch, n, p->k[1], p->r2, p->r2p);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -193,12 +194,12 @@ extern "C" int sc_hip_ntt_pwr(sc_hip_plan_t *p, size_t len, const int32_t *d_x, 
     if (e < 0) return fail("ntt_pwr: negative exponent");
     return run_flat<FL_PWR>(p->ctx, p->k[1], p->r2, p->r2p, len, d_x, e, d_out, stream, "ntt_pwr");
 }
-extern "C" int sc_hip_ntt_invert(sc_hip_plan_t *p, size_t batch, int32_t *d_v, int32_t *d_rc, void *stream)
-{ return run_invert(p, batch, d_v, nullptr, d_rc, stream, "ntt_invert"); }
-extern "C" int sc_hip_ntt_div(sc_hip_plan_t *p, size_t batch, int32_t *d_num, const int32_t *d_den, int32_t *d_rc, void *stream)
+extern "C" int sc_hip_ntt_invert(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *d_v, int32_t *d_rc, void *stream)
+{ return run_invert(p, batch, n, d_v, nullptr, d_rc, stream, "ntt_invert"); }
+extern "C" int sc_hip_ntt_div(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *d_num, const int32_t *d_den, int32_t *d_rc, void *stream)
 {
     if (!d_den) return fail("ntt_div: null buffer");
-    return run_invert(p, batch, d_num, d_den, d_rc, stream, "ntt_div");
+    return run_invert(p, batch, n, d_num, d_den, d_rc, stream, "ntt_div");
 }
 extern "C" int sc_hip_mult_sparse(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const int32_t *d_t, const int32_t *d_pos, int32_t *d_out, void *stream)
 { return run_sparse<int32_t>(ctx, batch, n, omega, d_t, d_pos, d_out, stream, "mult_sparse"); }
@@ -224,3 +225,52 @@ extern "C" int sc_hip_vec_absmax(sc_hip_ctx_t *ctx, size_t batch, size_t n, cons
 { return run_reduce<RD_ABSMAX>(ctx, batch, n, d_v, nullptr, d_out, stream, "vec_absmax"); }
 extern "C" int sc_hip_vec_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_t, const int32_t *d_u, int32_t *d_out, void *stream)
 { return run_reduce<RD_SCALAR>(ctx, batch, n, d_t, d_u, d_out, stream, "vec_scalar"); }
+
+// ---- host-buffer variants (H2D, kernel, D2H; synchronous) used by the reference-shaped vtable --------------------------------
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? SC_HIP_SUCCESS : fail("host op: device allocation failed"); }
+};
+}
+
+static int invert_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_v, const int32_t *h_den, int32_t *h_rc, const char *who)
+{
+    if (!p) return fail(std::string(who) + ": null plan");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (n == 0) return fail(std::string(who) + ": bad length");
+    if (!h_v || !h_rc) return fail(std::string(who) + ": null host pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const size_t bytes = batch * n * 4;
+    DevBuf v, d, rc;
+    if (v.get(bytes) || rc.get(batch * 4) || (h_den && d.get(bytes))) return SC_HIP_FAILURE;
+    HIPCHK(hipMemcpy(v.p, h_v, bytes, hipMemcpyHostToDevice));
+    if (h_den) HIPCHK(hipMemcpy(d.p, h_den, bytes, hipMemcpyHostToDevice));
+    if (run_invert(p, batch, n, (int32_t *)v.p, h_den ? (const int32_t *)d.p : nullptr, (int32_t *)rc.p, nullptr, who)) return SC_HIP_FAILURE;
+    HIPCHK(hipMemcpy(h_v, v.p, bytes, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(h_rc, rc.p, batch * 4, hipMemcpyDeviceToHost));
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_ntt_invert_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_v, int32_t *h_rc)
+{ return invert_host(p, batch, n, h_v, nullptr, h_rc, "ntt_invert_host"); }
+extern "C" int sc_hip_ntt_div_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_num, const int32_t *h_den, int32_t *h_rc)
+{ if (!h_den) return fail("ntt_div_host: null host pointer"); return invert_host(p, batch, n, h_num, h_den, h_rc, "ntt_div_host"); }
+
+extern "C" int sc_hip_mult_sparse_host(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const void *h_t, int t_is_16, const int32_t *h_pos, int32_t *h_out)
+{
+    if (!ctx) return fail("mult_sparse_host: null context");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_t || !h_pos || !h_out || n < 1 || omega < 0) return fail("mult_sparse_host: bad argument");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t tb = batch * (size_t)n * (t_is_16 ? 2 : 4), pb = batch * (size_t)omega * 4, ob = batch * (size_t)n * 4;
+    DevBuf t, pos, out;
+    if (t.get(tb) || pos.get(pb) || out.get(ob)) return SC_HIP_FAILURE;
+    HIPCHK(hipMemcpy(t.p, h_t, tb, hipMemcpyHostToDevice));
+    if (pb) HIPCHK(hipMemcpy(pos.p, h_pos, pb, hipMemcpyHostToDevice));
+    const int rc = t_is_16 ? sc_hip_mult_sparse_16(ctx, batch, n, omega, (const int16_t *)t.p, (const int32_t *)pos.p, (int32_t *)out.p, nullptr)
+                           : sc_hip_mult_sparse(ctx, batch, n, omega, (const int32_t *)t.p, (const int32_t *)pos.p, (int32_t *)out.p, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(h_out, out.p, ob, hipMemcpyDeviceToHost));
+    return SC_HIP_SUCCESS;
+}

@@ -27,7 +27,7 @@ SYMBOLS = [
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
-    'sc_hip_vec_absmax', 'sc_hip_vec_scalar',
+    'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -131,8 +131,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
-    L.sc_hip_ntt_invert.argtypes = [vp, sz, vp, vp, vp]
-    L.sc_hip_ntt_div.argtypes = [vp, sz, vp, vp, vp, vp]
+    L.sc_hip_ntt_invert.argtypes = [vp, sz, sz, vp, vp, vp]
+    L.sc_hip_ntt_div.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.sc_hip_mult_sparse.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
     L.sc_hip_mult_sparse_16.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
     L.sc_hip_poly_mul_scalar.argtypes = [vp, sz, vp, i32, vp, vp]
@@ -362,13 +362,13 @@ class NttPlan:
         """in place on v [batch][n]; returns the per-polynomial return codes (0 ok / 1 a coefficient was 0 mod q)"""
         import torch
         rc = torch.empty(v.shape[0], dtype=torch.int32, device=v.device)
-        _chk(self.L, self.L.sc_hip_ntt_invert(self.h, v.shape[0], _ptr(v), _ptr(rc), _stream()), 'ntt_invert')
+        _chk(self.L, self.L.sc_hip_ntt_invert(self.h, v.shape[0], v.shape[1], _ptr(v), _ptr(rc), _stream()), 'ntt_invert')
         return rc
 
     def div(self, num, den):
         import torch
         rc = torch.empty(num.shape[0], dtype=torch.int32, device=num.device)
-        _chk(self.L, self.L.sc_hip_ntt_div(self.h, num.shape[0], _ptr(num), _ptr(den), _ptr(rc), _stream()), 'ntt_div')
+        _chk(self.L, self.L.sc_hip_ntt_div(self.h, num.shape[0], num.shape[1], _ptr(num), _ptr(den), _ptr(rc), _stream()), 'ntt_div')
         return rc
 
     # host-buffer entry points (numpy in / numpy out), the shape the reference's vtable has

@@ -42,6 +42,8 @@ class VT(C.Structure):
         ('fwd_ntt_32_32_large', F(None, i32p, pp, i32p, i32p)), ('inv_ntt_32_32_large', F(None, i32p, pp, i32p, i32p, i32p)),
         ('fwd_ntt_32_16', F(None, i32p, pp, i32p, i16p)), ('inv_ntt_32_16', F(None, i32p, pp, i32p, i16p, i16p)),
         ('fwd_ntt_32_16_large', F(None, i32p, pp, i32p, i16p)), ('inv_ntt_32_16_large', F(None, i32p, pp, i32p, i16p, i16p)),
+        ('mul_32_sparse', F(None, i32p, C.c_size_t, C.c_uint16, i32p, i32p)), ('mul_32_sparse_16', F(None, i32p, C.c_size_t, C.c_uint16, i16p, i32p)),
+        ('invert_32', F(C.c_int32, i32p, pp, C.c_size_t)), ('div_32', F(C.c_int32, i32p, i32p, pp, C.c_size_t)),
     ]
 
 
@@ -100,4 +102,24 @@ def test_vtable_calls(q, n, is16):
     O.lib().orc_normalize(e1, e1.size, q)
     O.lib().orc_center(e2, e2.size, q)
     assert np.array_equal(nrm, e1) and np.array_equal(cen, e2)
+    # ring-TESLA style sparse products (ring_tesla.c:856-871,1015) and BLISS-keygen style inversion (bliss_b.c:1193)
+    pos = rng.permutation(n)[:11].astype(np.int32)
+    sp, exp_sp = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    vt.mul_32_sparse(P(sp), n, 11, P(t), P(pos))
+    O.lib().orc_mult_sparse(exp_sp, n, 11, t.copy(), pos.copy())
+    assert np.array_equal(sp, exp_sp)
+    t16 = t.astype(np.int16)
+    vt.mul_32_sparse_16(P(sp), n, 11, t16.ctypes.data_as(i16p), P(pos))
+    assert np.array_equal(sp, exp_sp)
+    nz = rng.integers(1, q, size=n).astype(np.int32)
+    iv = nz.copy()
+    assert vt.invert_32(P(iv), C.byref(p), n) == 0
+    assert ((iv.astype(np.int64) * nz) % q == 1).all()
+    num = a.copy()
+    assert vt.div_32(P(num), P(nz), C.byref(p), n) == 0
+    assert np.array_equal(num, (a.astype(np.int64) * iv % q).astype(np.int32))
+    nz[n // 2] = 0
+    half = nz.copy()
+    assert vt.invert_32(P(half), C.byref(p), n) == 1                     # SC_FUNC_FAILURE, stopped at the zero
+    assert np.array_equal(half[n // 2:], nz[n // 2:]) and np.array_equal(half[:n // 2], iv[:n // 2])
     assert L.sc_hip_vtable_errors() == e0
