@@ -29,6 +29,7 @@
 #include "keccak_dev.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace sc;
@@ -50,11 +51,16 @@ __device__ __forceinline__ void cmul(double &dr, double &di, double ar, double a
     dr = r; di = i;
 }
 
-// gaussian_cdf.c:536-553 + :639-659: halving search for the largest b with cdf[b] < x, sign = LSB of x
-__device__ __forceinline__ double cdt_pick(const uint64_t *__restrict__ cdf, int ts_log, uint64_t x)
+// gaussian_cdf.c:536-553 + :639-659: the halving search returns the largest b with cdf[b] < x (0 if none); the table is
+// monotone (all-ones from some index on), so that is the NUMBER of entries b >= 1 with cdf[b] < x.  The row address is
+// wave-uniform, so the entries arrive through scalar loads and the count is 2 VALU instructions per entry with no dependent
+// memory access (the search would be log2(size) dependent loads per sample).  Sign = LSB of x.
+template <int TSL>
+__device__ __forceinline__ double cdt_pick(const uint64_t *__restrict__ cdf, uint64_t x)
 {
     uint32_t a = 0;
-    for (int s = ts_log - 1; s >= 0; s--) { const uint32_t b = a + (1u << s); if (cdf[b] < x) a = b; }
+#pragma unroll
+    for (int b = 1; b < (1 << TSL); b++) a += (cdf[b] < x) ? 1u : 0u;
     const int32_t v = (x & 1) ? (int32_t)a : -(int32_t)a;
     return (double)v;
 }
@@ -62,13 +68,12 @@ __device__ __forceinline__ double cdt_pick(const uint64_t *__restrict__ cdf, int
 struct Leaf {                 // leaf tables in visiting order + this signature's word stream
     const uint64_t *__restrict__ tabs;
     const uint32_t *__restrict__ tape;
-    int ts_log;
     uint32_t idx;
 };
 
 // ---- register-resident bottom of the tree (gpv.c:2663-2714 on 2^L coefficients) ------------------------------------
 
-template <int L> struct FFS {
+template <int L, int TSL> struct FFS {
     static constexpr int N = 1 << L, HN = N / 2, QN = HN / 2;
     static __device__ __forceinline__ void split(double (&f0)[HN], double (&f1)[HN], const double (&f)[N], const double *__restrict__ gm)
     {
@@ -100,7 +105,7 @@ template <int L> struct FFS {
     {
         double a0[HN], a1[HN], w0[HN], w1[HN], tmp[N];
         split(a0, a1, t1, gm);
-        FFS<L - 1>::run(w0, w1, tree + N + treesize(L - 1), a0, a1, gm, lf);
+        FFS<L - 1, TSL>::run(w0, w1, tree + N + treesize(L - 1), a0, a1, gm, lf);
         merge(z1, w0, w1, gm);
 #pragma unroll
         for (int u = 0; u < HN; u++) {
@@ -109,101 +114,166 @@ template <int L> struct FFS {
             tmp[u] = tr + t0[u]; tmp[u + HN] = ti + t0[u + HN];
         }
         split(a0, a1, tmp, gm);
-        FFS<L - 1>::run(w0, w1, tree + N, a0, a1, gm, lf);
+        FFS<L - 1, TSL>::run(w0, w1, tree + N, a0, a1, gm, lf);
         merge(z0, w0, w1, gm);
     }
 };
 
-template <> struct FFS<0> {
+template <int TSL> struct FFS<0, TSL> {
     static __device__ __forceinline__ void run(double (&z0)[1], double (&z1)[1], const double *__restrict__, const double (&t0)[1], const double (&t1)[1],
                                                const double *__restrict__, Leaf &lf)
     {
-        const uint64_t *cdf = lf.tabs + ((size_t)lf.idx << lf.ts_log);
-        const uint32_t *w = lf.tape + 4 * (size_t)lf.idx;
-        const uint64_t x0 = ((uint64_t)w[0] << 32) | w[1], x1 = ((uint64_t)w[2] << 32) | w[3];
-        z0[0] = floor(t0[0]) + cdt_pick(cdf, lf.ts_log, x0);
-        z1[0] = floor(t1[0]) + cdt_pick(cdf, lf.ts_log, x1);
+        const uint64_t *cdf = lf.tabs + ((size_t)lf.idx << TSL);
+        const uint4 w = *reinterpret_cast<const uint4 *>(lf.tape + 4 * (size_t)lf.idx);      // tape rows are 16-byte aligned
+        const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
+        z0[0] = floor(t0[0]) + cdt_pick<TSL>(cdf, x0);
+        z1[0] = floor(t1[0]) + cdt_pick<TSL>(cdf, x1);
         lf.idx++;
     }
 };
 
-// ---- one signature's column of the interleaved workspace ---------------------------------------------------------------
-
+// ---- one signature's share of the interleaved workspace ------------------------------------------------------------------
+//
+// G lanes work on one signature (G = 1: a lane per signature, best for large batches; G = 8: eight lanes per signature and
+// eight signatures per wavefront, which cuts the length of every sweep a lone wavefront has to walk by 8 and puts 8x as many
+// wavefronts on the chip - the small-batch variant).  Element e of signature b lives at ((e / G) * B + b) * G + e % G, so the
+// G lanes of a group read G consecutive doubles and a wavefront reads one contiguous 512-byte row either way.
+template <int G>
 struct Col {
-    double *p; size_t B;
-    __device__ __forceinline__ double ld(uint32_t e) const { return p[(size_t)e * B]; }
-    __device__ __forceinline__ void st(uint32_t e, double v) const { p[(size_t)e * B] = v; }
+    double *p; size_t B;        // p = ws + b * G
+    __device__ __forceinline__ size_t at(uint32_t e) const { return G == 1 ? (size_t)e * B : ((size_t)(e / G) * B) * G + (e % G); }
+    __device__ __forceinline__ double ld(uint32_t e) const { return p[at(e)]; }
+    __device__ __forceinline__ void st(uint32_t e, double v) const { p[at(e)] = v; }
 };
 
-// falcon_fft.c:203-282
-__device__ void fft_col(const Col &c, uint32_t f, int logn, const double *__restrict__ gm)
+// Lanes of a group exchange data through the workspace between sweeps: make the sweep's stores visible to the other lanes of
+// the wavefront (workgroup-scope release/acquire = wait for the stores; one CU, one L1) and keep the compiler from moving
+// accesses across.  Nothing to do for G = 1.
+template <int G> __device__ __forceinline__ void sweep_sync()
 {
-    const uint32_t n = 1u << logn, hn = n >> 1;
-    uint32_t t = hn, m = 2;
+    if (G > 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+}
+
+// Every sweep below is a chain "load a few doubles - a handful of flops - store" per iteration, all through one pointer, so the
+// compiler keeps the iterations in order and a lone wavefront would pay one full memory latency per iteration.  The iterations
+// of one sweep touch disjoint elements, so the loads of PU iterations are issued together before any of them is consumed.
+constexpr int PU = 8;
+constexpr int SU = 4;     // the tree sweeps: qn >= 4 pairs at the smallest level kept in memory (l = FK + 1 = 4)
+
+// falcon_fft.c:203-282; n/4 butterflies per stage, flat index bf -> (i1 = bf / ht, j = i1*t + bf % ht)
+template <int G>
+__device__ void fft_col(const Col<G> &c, uint32_t g, uint32_t f, int logn, const double *__restrict__ gm)
+{
+    const uint32_t n = 1u << logn, hn = n >> 1, nb = n >> 2;           // nb >= 128 is a multiple of PU * G
+    uint32_t m = 2;
     for (int u = 1; u < logn; u++, m <<= 1) {
-        const uint32_t ht = t >> 1, hm = m >> 1;
-        for (uint32_t i1 = 0, j1 = 0; i1 < hm; i1++, j1 += t) {
-            const double sr = gm[(m + i1) << 1], si = gm[((m + i1) << 1) + 1];
-            for (uint32_t j = j1; j < j1 + ht; j++) {
-                const double xr = c.ld(f + j), xi = c.ld(f + j + hn);
-                double yr = c.ld(f + j + ht), yi = c.ld(f + j + ht + hn);
-                cmul(yr, yi, yr, yi, sr, si);
-                c.st(f + j, xr + yr); c.st(f + j + hn, xi + yi);
-                c.st(f + j + ht, xr - yr); c.st(f + j + ht + hn, xi - yi);
+        const int lt = logn - u, lht = lt - 1;                       // t = 2^lt, ht = 2^lht
+        const uint32_t ht = 1u << lht;
+        for (uint32_t b0 = 0; b0 < nb; b0 += PU * G) {
+            double xr[PU], xi[PU], yr[PU], yi[PU]; uint32_t j[PU], tw[PU];
+#pragma unroll
+            for (int k = 0; k < PU; k++) {
+                const uint32_t bf = b0 + k * G + g, i1 = bf >> lht;
+                j[k] = (i1 << lt) + (bf & (ht - 1)); tw[k] = (m + i1) << 1;
+                xr[k] = c.ld(f + j[k]); xi[k] = c.ld(f + j[k] + hn); yr[k] = c.ld(f + j[k] + ht); yi[k] = c.ld(f + j[k] + ht + hn);
+            }
+#pragma unroll
+            for (int k = 0; k < PU; k++) {
+                cmul(yr[k], yi[k], yr[k], yi[k], gm[tw[k]], gm[tw[k] + 1]);
+                c.st(f + j[k], xr[k] + yr[k]); c.st(f + j[k] + hn, xi[k] + yi[k]);
+                c.st(f + j[k] + ht, xr[k] - yr[k]); c.st(f + j[k] + ht + hn, xi[k] - yi[k]);
             }
         }
-        t = ht;
+        sweep_sync<G>();
     }
 }
 
 // falcon_fft.c:284-378 without the final scaling (the caller applies f*ni while it rounds to integers)
-__device__ void ifft_col(const Col &c, uint32_t f, int logn, const double *__restrict__ gm)
+template <int G>
+__device__ void ifft_col(const Col<G> &c, uint32_t g, uint32_t f, int logn, const double *__restrict__ gm)
 {
-    const uint32_t n = 1u << logn, hn = n >> 1;
-    uint32_t t = 1, m = n;
-    for (int u = logn; u > 1; u--) {
-        const uint32_t hm = m >> 1, dt = t << 1;
-        for (uint32_t i1 = 0, j1 = 0; j1 < hn; i1++, j1 += dt) {
-            const double sr = gm[(hm + i1) << 1], si = -gm[((hm + i1) << 1) + 1];
-            for (uint32_t j = j1; j < j1 + t; j++) {
-                double xr = c.ld(f + j), xi = c.ld(f + j + hn);
-                const double yr = c.ld(f + j + t), yi = c.ld(f + j + t + hn);
-                c.st(f + j, xr + yr); c.st(f + j + hn, xi + yi);
-                xr = xr - yr; xi = xi - yi;
+    const uint32_t n = 1u << logn, hn = n >> 1, nb = n >> 2;
+    uint32_t m = n;
+    int lt = 0;                                                       // t = 2^lt
+    for (int u = logn; u > 1; u--, lt++) {
+        const uint32_t hm = m >> 1, t = 1u << lt;
+        for (uint32_t b0 = 0; b0 < nb; b0 += PU * G) {
+            double xr[PU], xi[PU], yr[PU], yi[PU]; uint32_t j[PU], tw[PU];
+#pragma unroll
+            for (int k = 0; k < PU; k++) {
+                const uint32_t bf = b0 + k * G + g, i1 = bf >> lt;
+                j[k] = (i1 << (lt + 1)) + (bf & (t - 1)); tw[k] = (hm + i1) << 1;
+                xr[k] = c.ld(f + j[k]); xi[k] = c.ld(f + j[k] + hn); yr[k] = c.ld(f + j[k] + t); yi[k] = c.ld(f + j[k] + t + hn);
+            }
+#pragma unroll
+            for (int k = 0; k < PU; k++) {
+                c.st(f + j[k], xr[k] + yr[k]); c.st(f + j[k] + hn, xi[k] + yi[k]);
+                const double dr = xr[k] - yr[k], di = xi[k] - yi[k];
                 double pr, pi;
-                cmul(pr, pi, xr, xi, sr, si);
-                c.st(f + j + t, pr); c.st(f + j + t + hn, pi);
+                cmul(pr, pi, dr, di, gm[tw[k]], -gm[tw[k] + 1]);
+                c.st(f + j[k] + t, pr); c.st(f + j[k] + t + hn, pi);
             }
         }
-        t = dt; m = hm;
+        sweep_sync<G>();
+        m = hm;
     }
 }
 
-// falcon_fft.c:694-739, level l >= 2
-__device__ __forceinline__ void split_col(const Col &c, uint32_t f0, uint32_t f1, uint32_t f, int l, const double *__restrict__ gm)
+// falcon_fft.c:694-739, level l >= 4 (qn >= 4 is a multiple of SU; with G > 1 lanes beyond qn idle)
+template <int G>
+__device__ __forceinline__ void split_col(const Col<G> &c, uint32_t g, uint32_t f0, uint32_t f1, uint32_t f, int l, const double *__restrict__ gm)
 {
     const uint32_t hn = (1u << l) >> 1, qn = hn >> 1;
-    for (uint32_t u = 0; u < qn; u++) {
-        const double ar = c.ld(f + 2 * u), ai = c.ld(f + 2 * u + hn), br = c.ld(f + 2 * u + 1), bi = c.ld(f + 2 * u + 1 + hn);
-        double tr = ar + br, ti = ai + bi;
-        c.st(f0 + u, tr * 0.5); c.st(f0 + u + qn, ti * 0.5);
-        tr = ar - br; ti = ai - bi;
-        cmul(tr, ti, tr, ti, gm[(u + hn) << 1], -gm[((u + hn) << 1) + 1]);
-        c.st(f1 + u, tr * 0.5); c.st(f1 + u + qn, ti * 0.5);
+    for (uint32_t u0 = 0; u0 < qn; u0 += SU * G) {
+        double ar[SU], ai[SU], br[SU], bi[SU];
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            if (G == 1 || u < qn) { ar[k] = c.ld(f + 2 * u); ai[k] = c.ld(f + 2 * u + hn); br[k] = c.ld(f + 2 * u + 1); bi[k] = c.ld(f + 2 * u + 1 + hn); }
+        }
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            if (G == 1 || u < qn) {
+                double tr = ar[k] + br[k], ti = ai[k] + bi[k];
+                c.st(f0 + u, tr * 0.5); c.st(f0 + u + qn, ti * 0.5);
+                tr = ar[k] - br[k]; ti = ai[k] - bi[k];
+                cmul(tr, ti, tr, ti, gm[(u + hn) << 1], -gm[((u + hn) << 1) + 1]);
+                c.st(f1 + u, tr * 0.5); c.st(f1 + u + qn, ti * 0.5);
+            }
+        }
     }
+    sweep_sync<G>();
 }
 
-// falcon_fft.c:742-785, level l >= 2
-__device__ __forceinline__ void merge_col(const Col &c, uint32_t f, uint32_t f0, uint32_t f1, int l, const double *__restrict__ gm)
+// falcon_fft.c:742-785, level l >= 4
+template <int G>
+__device__ __forceinline__ void merge_col(const Col<G> &c, uint32_t g, uint32_t f, uint32_t f0, uint32_t f1, int l, const double *__restrict__ gm)
 {
     const uint32_t hn = (1u << l) >> 1, qn = hn >> 1;
-    for (uint32_t u = 0; u < qn; u++) {
-        const double ar = c.ld(f0 + u), ai = c.ld(f0 + u + qn);
-        double br, bi;
-        cmul(br, bi, c.ld(f1 + u), c.ld(f1 + u + qn), gm[(u + hn) << 1], gm[((u + hn) << 1) + 1]);
-        c.st(f + 2 * u, ar + br); c.st(f + 2 * u + hn, ai + bi);
-        c.st(f + 2 * u + 1, ar - br); c.st(f + 2 * u + 1 + hn, ai - bi);
+    for (uint32_t u0 = 0; u0 < qn; u0 += SU * G) {
+        double ar[SU], ai[SU], cr[SU], ci[SU];
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            if (G == 1 || u < qn) { ar[k] = c.ld(f0 + u); ai[k] = c.ld(f0 + u + qn); cr[k] = c.ld(f1 + u); ci[k] = c.ld(f1 + u + qn); }
+        }
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            if (G == 1 || u < qn) {
+                double br, bi;
+                cmul(br, bi, cr[k], ci[k], gm[(u + hn) << 1], gm[((u + hn) << 1) + 1]);
+                c.st(f + 2 * u, ar[k] + br); c.st(f + 2 * u + hn, ai[k] + bi);
+                c.st(f + 2 * u + 1, ar[k] - br); c.st(f + 2 * u + 1 + hn, ai[k] - bi);
+            }
+        }
     }
+    sweep_sync<G>();
 }
 
 // Workspace layout per signature, in doubles: C0 | C1 | Z0 | Z1 | T (2n).  A node at level l (2^l coefficients) below
@@ -219,36 +289,48 @@ struct Walk {
     __device__ __forceinline__ uint32_t t1(int l) const { return l == logn ? n : t0(l) + (1u << l); }
 };
 
-// gaussian_sample_with_tree for one signature per lane.  c: int32 [batch][n]; tapes: uint32 [batch][tape_stride];
-// s1 (may be null), s2: int32 [batch][n]; status[b] |= 2 when the tape is shorter than 4n words (nothing is sampled then).
+// gaussian_sample_with_tree, G lanes per signature.  c: int32 [batch][n]; tapes: uint32 [batch][tape_stride];
+// s1 (may be null), s2: int32 [batch][n]; status[b] = 2 when the tape is shorter than 4n words (nothing is sampled then).
+template <int TSL, int G>
 __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B, double *__restrict__ ws, const int32_t *__restrict__ c,
                                                         const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
-                                                        const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs, int ts_log,
+                                                        const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                         int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni)
 {
-    const uint32_t b = blockIdx.x * ST + threadIdx.x;
+    const uint32_t tid = blockIdx.x * ST + threadIdx.x, b = tid / G, g = tid % G;
     if (b >= batch) return;
     const uint32_t n = (uint32_t)P.n; const int logn = P.n_bits;
     const uint32_t have = tape_lens ? tape_lens[b] : (uint32_t)tape_stride;
-    if (have < 4 * n) { status[b] = 2; return; }
-    const Col col = { ws + b, B };
+    if (have < 4 * n) { if (g == 0) status[b] = 2; return; }
+    const Col<G> col = { ws + (size_t)b * G, B };
     const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
     const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n, hn = n >> 1;
     const int32_t *cb = c + (size_t)b * n;
-    for (uint32_t i = 0; i < n; i++) col.st(C0 + i, (double)cb[i]);
-    fft_col(col, C0, logn, gm);
-    // c1 = c0 * b01 * (-1/q) ; c0 = c0 * b11 * (1/q)   (gpv.c:3049-3054)
-    for (uint32_t u = 0; u < hn; u++) {
-        const double ar = col.ld(C0 + u), ai = col.ld(C0 + u + hn);
-        double r, i;
-        cmul(r, i, ar, ai, b01[u], b01[u + hn]);
-        col.st(C1 + u, r * -ni); col.st(C1 + u + hn, i * -ni);
-        cmul(r, i, ar, ai, b11[u], b11[u + hn]);
-        col.st(C0 + u, r * ni); col.st(C0 + u + hn, i * ni);
+    for (uint32_t i0 = 4 * g; i0 < n; i0 += 4 * G) {                  // rows of c are 16-byte aligned (n*4 bytes each)
+        const int4 cv = *reinterpret_cast<const int4 *>(cb + i0);
+        col.st(C0 + i0, (double)cv.x); col.st(C0 + i0 + 1, (double)cv.y); col.st(C0 + i0 + 2, (double)cv.z); col.st(C0 + i0 + 3, (double)cv.w);
     }
+    sweep_sync<G>();
+    fft_col<G>(col, g, C0, logn, gm);
+    // c1 = c0 * b01 * (-1/q) ; c0 = c0 * b11 * (1/q)   (gpv.c:3049-3054)
+    for (uint32_t u0 = 0; u0 < hn; u0 += PU * G) {
+        double ar[PU], ai[PU];
+#pragma unroll
+        for (int k = 0; k < PU; k++) { const uint32_t u = u0 + k * G + g; ar[k] = col.ld(C0 + u); ai[k] = col.ld(C0 + u + hn); }
+#pragma unroll
+        for (int k = 0; k < PU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            double r, i;
+            cmul(r, i, ar[k], ai[k], b01[u], b01[u + hn]);
+            col.st(C1 + u, r * -ni); col.st(C1 + u + hn, i * -ni);
+            cmul(r, i, ar[k], ai[k], b11[u], b11[u + hn]);
+            col.st(C0 + u, r * ni); col.st(C0 + u + hn, i * ni);
+        }
+    }
+    sweep_sync<G>();
 
     // ---- fast Fourier sampling, depth first, the second-half tree (tree1) before the first (gpv.c:2693-2711)
-    Leaf lf = { tabs, tapes + (size_t)b * tape_stride, ts_log, 0 };
+    Leaf lf = { tabs, tapes + (size_t)b * tape_stride, 0 };
     Walk w = { n, logn, 0 };
     uint32_t toff = 0;                           // offset of the current node's tree block
     int l = logn;
@@ -257,17 +339,23 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
         const uint32_t m = 1u << l, hm = m >> 1, qn = hm >> 1;
         if (entering) {
             if (l == FK) {
-                double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
-                const uint32_t pt0 = w.t0(l), pt1 = w.t1(l), pz0 = w.z0(l), pz1 = w.z1(l);
+                // the whole sub-tree in the registers of the group's first lane (its 2 x 8 inputs are one 64-byte line each)
+                if (g == 0) {
+                    double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
+                    const uint32_t pt0 = w.t0(l), pt1 = w.t1(l), pz0 = w.z0(l), pz1 = w.z1(l);
 #pragma unroll
-                for (int i = 0; i < (1 << FK); i++) { t0r[i] = col.ld(pt0 + i); t1r[i] = col.ld(pt1 + i); }
-                FFS<FK>::run(z0r, z1r, tree + toff, t0r, t1r, gm, lf);
+                    for (int i = 0; i < (1 << FK); i++) { t0r[i] = col.ld(pt0 + i); t1r[i] = col.ld(pt1 + i); }
+                    Leaf mine = lf;                                    // a copy: lf.idx stays wave-uniform (scalar table loads)
+                    FFS<FK, TSL>::run(z0r, z1r, tree + toff, t0r, t1r, gm, mine);
 #pragma unroll
-                for (int i = 0; i < (1 << FK); i++) { col.st(pz0 + i, z0r[i]); col.st(pz1 + i, z1r[i]); }
+                    for (int i = 0; i < (1 << FK); i++) { col.st(pz0 + i, z0r[i]); col.st(pz1 + i, z1r[i]); }
+                }
+                lf.idx += 1u << FK;
+                sweep_sync<G>();
                 entering = false; l++;
                 continue;
             }
-            split_col(col, w.z1(l), w.z1(l) + hm, w.t1(l), l, gm);
+            split_col<G>(col, g, w.z1(l), w.z1(l) + hm, w.t1(l), l, gm);
             w.ph &= ~(1u << l);
             toff += m + treesize(l - 1); l--;
             continue;
@@ -277,26 +365,43 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
             toff -= m + treesize(l - 1);
             const uint32_t ch = w.tmp(l), pz1 = w.z1(l), pz0 = w.z0(l), pt0 = w.t0(l), pt1 = w.t1(l);
             const double *L = tree + toff;
-            for (uint32_t u = 0; u < qn; u++) {
-                const double gr = gm[(u + hm) << 1], gi = gm[((u + hm) << 1) + 1];
-                const double ar = col.ld(ch + u), ai = col.ld(ch + u + qn);
-                double br, bi;
-                cmul(br, bi, col.ld(ch + hm + u), col.ld(ch + hm + u + qn), gr, gi);
-                const double e_r = ar + br, e_i = ai + bi, o_r = ar - br, o_i = ai - bi;     // z1 at complex slots 2u, 2u+1
-                col.st(pz1 + 2 * u, e_r); col.st(pz1 + 2 * u + hm, e_i);
-                col.st(pz1 + 2 * u + 1, o_r); col.st(pz1 + 2 * u + 1 + hm, o_i);
-                double xr = col.ld(pt1 + 2 * u) - e_r, xi = col.ld(pt1 + 2 * u + hm) - e_i;
-                cmul(xr, xi, xr, xi, L[2 * u], L[2 * u + hm]);
-                xr = xr + col.ld(pt0 + 2 * u); xi = xi + col.ld(pt0 + 2 * u + hm);
-                double yr = col.ld(pt1 + 2 * u + 1) - o_r, yi = col.ld(pt1 + 2 * u + 1 + hm) - o_i;
-                cmul(yr, yi, yr, yi, L[2 * u + 1], L[2 * u + 1 + hm]);
-                yr = yr + col.ld(pt0 + 2 * u + 1); yi = yi + col.ld(pt0 + 2 * u + 1 + hm);
-                double tr = xr + yr, ti = xi + yi;
-                col.st(pz0 + u, tr * 0.5); col.st(pz0 + u + qn, ti * 0.5);
-                tr = xr - yr; ti = xi - yi;
-                cmul(tr, ti, tr, ti, gr, -gi);
-                col.st(pz0 + hm + u, tr * 0.5); col.st(pz0 + hm + u + qn, ti * 0.5);
+            constexpr int FU = 4;                                  // 12 loads per pair of complex slots
+            for (uint32_t u0 = 0; u0 < qn; u0 += FU * G) {
+                double ar[FU], ai[FU], cr[FU], ci[FU], p1[FU][4], p0[FU][4];
+#pragma unroll
+                for (int k = 0; k < FU; k++) {
+                    const uint32_t u = u0 + k * G + g;
+                    if (G == 1 || u < qn) {
+                        ar[k] = col.ld(ch + u); ai[k] = col.ld(ch + u + qn); cr[k] = col.ld(ch + hm + u); ci[k] = col.ld(ch + hm + u + qn);
+                        p1[k][0] = col.ld(pt1 + 2 * u); p1[k][1] = col.ld(pt1 + 2 * u + hm); p1[k][2] = col.ld(pt1 + 2 * u + 1); p1[k][3] = col.ld(pt1 + 2 * u + 1 + hm);
+                        p0[k][0] = col.ld(pt0 + 2 * u); p0[k][1] = col.ld(pt0 + 2 * u + hm); p0[k][2] = col.ld(pt0 + 2 * u + 1); p0[k][3] = col.ld(pt0 + 2 * u + 1 + hm);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < FU; k++) {
+                    const uint32_t u = u0 + k * G + g;
+                    if (G == 1 || u < qn) {
+                        const double gr = gm[(u + hm) << 1], gi = gm[((u + hm) << 1) + 1];
+                        double br, bi;
+                        cmul(br, bi, cr[k], ci[k], gr, gi);
+                        const double e_r = ar[k] + br, e_i = ai[k] + bi, o_r = ar[k] - br, o_i = ai[k] - bi;     // z1 at complex slots 2u, 2u+1
+                        col.st(pz1 + 2 * u, e_r); col.st(pz1 + 2 * u + hm, e_i);
+                        col.st(pz1 + 2 * u + 1, o_r); col.st(pz1 + 2 * u + 1 + hm, o_i);
+                        double xr = p1[k][0] - e_r, xi = p1[k][1] - e_i;
+                        cmul(xr, xi, xr, xi, L[2 * u], L[2 * u + hm]);
+                        xr = xr + p0[k][0]; xi = xi + p0[k][1];
+                        double yr = p1[k][2] - o_r, yi = p1[k][3] - o_i;
+                        cmul(yr, yi, yr, yi, L[2 * u + 1], L[2 * u + 1 + hm]);
+                        yr = yr + p0[k][2]; yi = yi + p0[k][3];
+                        double tr = xr + yr, ti = xi + yi;
+                        col.st(pz0 + u, tr * 0.5); col.st(pz0 + u + qn, ti * 0.5);
+                        tr = xr - yr; ti = xi - yi;
+                        cmul(tr, ti, tr, ti, gr, -gi);
+                        col.st(pz0 + hm + u, tr * 0.5); col.st(pz0 + hm + u + qn, ti * 0.5);
+                    }
+                }
             }
+            sweep_sync<G>();
             w.ph |= 1u << l;
             toff += m; l--;
             entering = true;
@@ -304,31 +409,45 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
         }
         // back from tree0: z0 = merge(child); this node is done
         toff -= m;
-        merge_col(col, w.z0(l), w.tmp(l), w.tmp(l) + hm, l, gm);
+        merge_col<G>(col, g, w.z0(l), w.tmp(l), w.tmp(l) + hm, l, gm);
         w.ph &= ~(1u << l);
         if (l == logn) break;
         l++;
     }
 
     // ---- lattice point (gpv.c:3064-3076): c0 <- z0*b00 + z1*b10 ; c1 <- z1*b11 + z0*b01
-    for (uint32_t u = 0; u < hn; u++) {
-        const double z0r = col.ld(Z0 + u), z0i = col.ld(Z0 + u + hn), z1r = col.ld(Z1 + u), z1i = col.ld(Z1 + u + hn);
-        double pr, pi, qr, qi;
-        cmul(pr, pi, z0r, z0i, b00[u], b00[u + hn]);
-        cmul(qr, qi, z1r, z1i, b10[u], b10[u + hn]);
-        col.st(C0 + u, pr + qr); col.st(C0 + u + hn, pi + qi);
-        cmul(pr, pi, z0r, z0i, b01[u], b01[u + hn]);
-        cmul(qr, qi, z1r, z1i, b11[u], b11[u + hn]);
-        col.st(C1 + u, qr + pr); col.st(C1 + u + hn, qi + pi);
+    for (uint32_t u0 = 0; u0 < hn; u0 += PU * G) {
+        double z0r[PU], z0i[PU], z1r[PU], z1i[PU];
+#pragma unroll
+        for (int k = 0; k < PU; k++) { const uint32_t u = u0 + k * G + g; z0r[k] = col.ld(Z0 + u); z0i[k] = col.ld(Z0 + u + hn); z1r[k] = col.ld(Z1 + u); z1i[k] = col.ld(Z1 + u + hn); }
+#pragma unroll
+        for (int k = 0; k < PU; k++) {
+            const uint32_t u = u0 + k * G + g;
+            double pr, pi, qr, qi;
+            cmul(pr, pi, z0r[k], z0i[k], b00[u], b00[u + hn]);
+            cmul(qr, qi, z1r[k], z1i[k], b10[u], b10[u + hn]);
+            col.st(C0 + u, pr + qr); col.st(C0 + u + hn, pi + qi);
+            cmul(pr, pi, z0r[k], z0i[k], b01[u], b01[u + hn]);
+            cmul(qr, qi, z1r[k], z1i[k], b11[u], b11[u + hn]);
+            col.st(C1 + u, qr + pr); col.st(C1 + u + hn, qi + pi);
+        }
     }
-    ifft_col(col, C0, logn, gm);
-    ifft_col(col, C1, logn, gm);
+    sweep_sync<G>();
+    ifft_col<G>(col, g, C0, logn, gm);
+    ifft_col<G>(col, g, C1, logn, gm);
     const double sc2 = ldexp(2.0, -logn);                           // falcon_fft.c:370-377
     int32_t *o1 = s1 ? s1 + (size_t)b * n : nullptr, *o2 = s2 + (size_t)b * n;
-    for (uint32_t i = 0; i < n; i++) {
-        const long long r0 = (long long)rint(col.ld(C0 + i) * sc2), r1 = (long long)rint(col.ld(C1 + i) * sc2);
-        if (o1) o1[i] = (int32_t)((long long)cb[i] - r0);
-        o2[i] = (int32_t)-r1;
+    for (uint32_t i0 = 0; i0 < n; i0 += PU * G) {
+        double v0[PU], v1[PU]; int32_t cv[PU];
+#pragma unroll
+        for (int k = 0; k < PU; k++) { const uint32_t i = i0 + k * G + g; v0[k] = col.ld(C0 + i); v1[k] = col.ld(C1 + i); cv[k] = cb[i]; }
+#pragma unroll
+        for (int k = 0; k < PU; k++) {
+            const uint32_t i = i0 + k * G + g;
+            const long long r0 = (long long)rint(v0[k] * sc2), r1 = (long long)rint(v1[k] * sc2);
+            if (o1) o1[i] = (int32_t)((long long)cv[k] - r0);
+            o2[i] = (int32_t)-r1;
+        }
     }
 }
 
@@ -466,6 +585,7 @@ struct sc_hip_falcon {
     bool have_sk, have_pk;
     double *d_sk, *d_gm;
     uint64_t *d_tabs; int ts_log;
+    int force_g;                 // 0 = choose by batch size; 1 / 8 = lanes per signature (test hook, SC_HIP_FALCON_LANES)
     int32_t *d_hhat;
     size_t cap;
     double *ws;
@@ -509,6 +629,7 @@ extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_param
     sc_hip_falcon *f = new sc_hip_falcon;
     memset(f, 0, sizeof *f);
     f->ctx = ctx; f->plan = plan; f->P = P;
+    if (const char *e = getenv("SC_HIP_FALCON_LANES")) { const int v = atoi(e); f->force_g = (v == 1 || v == 8) ? v : 0; }
     std::vector<double> gm;
     make_gm(gm);
     if (hipMalloc((void **)&f->d_gm, gm.size() * sizeof(double)) != hipSuccess ||
@@ -553,8 +674,9 @@ extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk)
         const int sz = sc_hip_cdt_table_size(10.0f, s);
         if (sz > ts) ts = sz;
     }
-    int ts_log = 0;
+    int ts_log = 4;                                                    // kernels are instantiated for 16, 32 and 64 entries per leaf
     while ((1 << ts_log) < ts) ts_log++;
+    if (ts_log > 6) return fail("falcon_set_privkey: a tree leaf needs a CDF table of more than 64 entries (sigma > 6.4)");
     std::vector<uint64_t> tabs(n << ts_log, ~0ULL);
     for (size_t i = 0; i < n; i++) {
         const int sz = sc_hip_cdt_table_size(10.0f, sig[i]);
@@ -597,9 +719,23 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
                              int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s)
 {
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
-    hipLaunchKernelGGL(fal_sample_kernel, dim3((unsigned)((batch + ST - 1) / ST)), dim3(ST), 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens,
-                       f->d_sk, f->d_gm, f->d_tabs, f->ts_log, d_s1, d_s2, d_status, f->P,
-                       1.0 / (double)(long)f->P.q /* fpr_inverse_of, falcon_fft.h:57-60 */);
+    const double ni = 1.0 / (double)(long)f->P.q;                    /* fpr_inverse_of, falcon_fft.h:57-60 */
+    // up to one lane-per-signature wavefront per CU the walk is latency-bound (measured crossover on MI355X between 16 K and
+    // 32 K signatures): spread each signature over 8 lanes
+    const bool wide = f->force_g ? f->force_g == 8 : batch <= (size_t)f->ctx->cus * 64;
+    const size_t threads = wide ? batch * 8 : batch;
+    const dim3 grid((unsigned)((threads + ST - 1) / ST)), block(ST);
+#define FAL_LAUNCH(TSL, G) hipLaunchKernelGGL((fal_sample_kernel<TSL, G>), grid, block, 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
+                                              f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni)
+#define FAL_PICK(TSL) do { if (wide) FAL_LAUNCH(TSL, 8); else FAL_LAUNCH(TSL, 1); } while (0)
+    switch (f->ts_log) {
+    case 4: FAL_PICK(4); break;
+    case 5: FAL_PICK(5); break;
+    case 6: FAL_PICK(6); break;
+    default: return fail("falcon: unsupported leaf table size");
+    }
+#undef FAL_PICK
+#undef FAL_LAUNCH
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -618,7 +754,9 @@ extern "C" int sc_hip_falcon_sample(sc_hip_falcon_t *f, size_t batch, const int3
     if (!f->have_sk) return fail("falcon_sample: no private key loaded");
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_c || !d_tapes || !d_s2) return fail("falcon_sample: null buffer");
+    if (((uintptr_t)d_c & 15) != 0) return fail("falcon_sample: d_c must be 16-byte aligned");
     if (tape_stride > 0xffffffffu) return fail("falcon_sample: tape too long");
+    if (((uintptr_t)d_tapes & 15) != 0 || (tape_stride & 3) != 0) return fail("falcon_sample: tapes must be 16-byte aligned rows (tape_stride a multiple of 4 words)");
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
     return fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, d_tape_lens, d_s1, d_s2, d_status ? d_status : f->status, (hipStream_t)stream);
@@ -634,6 +772,7 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
     if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("falcon_sign: null buffer");
     if (sig_stride < sc_hip_falcon_sig_bytes(f)) return fail("falcon_sign: sig_stride smaller than sc_hip_falcon_sig_bytes()");
     if (tape_stride > 0xffffffffu) return fail("falcon_sign: tape too long");
+    if (((uintptr_t)d_tapes & 15) != 0 || (tape_stride & 3) != 0) return fail("falcon_sign: tapes must be 16-byte aligned rows (tape_stride a multiple of 4 words)");
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
