@@ -109,3 +109,27 @@ def test_batch_vs_oracle_seeded(eng, G):
     mb2 = mb.clone(); mb2[:, 0] ^= 1
     assert f.verify(mb2, sigs, siglens, mlens=ml).cpu().numpy().min() == 1
     f.close()
+
+
+@pytest.mark.parametrize('lanes', ['1', '8'])
+def test_both_lane_mappings_reproduce_reference(eng, G, lanes, monkeypatch):
+    """the engine picks 1 or 8 lanes per signature by batch size; both mappings are forced here (SC_HIP_FALCON_LANES is read
+    when the handle is created) and must give the reference's s1, s2 and, on a seeded batch, the oracle's"""
+    import torch
+    monkeypatch.setenv('SC_HIP_FALCON_LANES', lanes)
+    key, f = open_key(eng, G, 'falcon2')
+    c = np.asarray(G['falcon2_c0'], dtype=np.int32)[None, :]
+    tp = u32(G['falcon2_ctape0'])[None, :]
+    s1, s2, status = f.sample(torch.from_numpy(c).cuda(), torch.from_numpy(tp.view(np.int32)).cuda())
+    assert np.array_equal(s1[0].cpu().numpy(), np.asarray(G['falcon2_s1_0'], dtype=np.int32))
+    assert np.array_equal(s2[0].cpu().numpy(), np.asarray(G['falcon2_s2_0'], dtype=np.int32))
+    rng = np.random.default_rng(int(lanes))
+    B = 77                                                   # ragged: the last wavefront is partly empty in either mapping
+    cs = rng.integers(0, key.q, size=(B, key.n), dtype=np.int32)
+    tps = rng.integers(0, 2**32, size=(B, 4 * key.n), dtype=np.uint64).astype(np.uint32)
+    s1, s2, status = f.sample(torch.from_numpy(cs).cuda(), torch.from_numpy(tps.view(np.int32)).cuda())
+    s1, s2 = s1.cpu().numpy(), s2.cpu().numpy()
+    for i in (0, 1, 38, 76):
+        rc, o1, o2 = O.falcon_sample(key, cs[i], tps[i])
+        assert rc == 0 and np.array_equal(s1[i], o1) and np.array_equal(s2[i], o2), i
+    f.close()
