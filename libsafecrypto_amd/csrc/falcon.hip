@@ -482,16 +482,23 @@ __device__ __forceinline__ int32_t centre_mod(int32_t x, int32_t q)      // ntt 
     return r;
 }
 
-// falcon.c:511-521: integer squares, FLOAT accumulation from the top index down, sqrtf, ">= bd" fails
-__device__ __forceinline__ bool norm_fails(const int32_t *s1, const int32_t *s2, int n, float bd)
+// falcon.c:511-521: norm += s1[i]*s1[i] + s2[i]*s2[i] (integer expression, converted to FLOAT) from the top index down, sqrtf,
+// ">= bd" fails.  Float addition is not associative and the sum passes 2^24, so the order is kept: the squares are formed in
+// parallel into LDS and ONE lane adds them up in the reference's order.
+__device__ __forceinline__ bool norm_fails_lds(const int32_t *sq, int n, float bd)
 {
     float norm = 0;
-    for (int i = n; i--;) norm += (float)(s1[i] * s1[i] + s2[i] * s2[i]);
+    for (int i = n - 4; i >= 0; i -= 4) {
+        const int4 v = *reinterpret_cast<const int4 *>(sq + i);
+        norm += (float)v.w; norm += (float)v.z; norm += (float)v.y; norm += (float)v.x;
+    }
     norm = sqrtf(norm);
     return norm >= bd;
 }
 
-struct BitW {
+constexpr int FW = 4;        // finish kernels: wavefronts (= signatures) per workgroup
+
+struct BitW {                // generic MSB-first packer (any coefficient width)
     uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
     __device__ __forceinline__ void put(uint32_t v, int bits)
     {
@@ -501,23 +508,44 @@ struct BitW {
     __device__ __forceinline__ void flush() { if (nb) { p[nbytes++] = (uint8_t)(acc << (8 - nb)); nb = 0; } }
 };
 
-// falcon.c:879-905: centre s2, norm test (no retry in the reference), raw (q_bits-2)-bit packing of s2
-__global__ void fal_finish_kernel(uint32_t batch, const int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint8_t *__restrict__ sigs, size_t sig_stride,
-                                  uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P)
+// falcon.c:879-905: centre s2, norm test (no retry in the reference), raw (q_bits-2)-bit MSB-first packing of s2.
+// One wavefront per signature; coefficient i = lane + 64 k.
+__global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, const int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint8_t *__restrict__ sigs, size_t sig_stride,
+                                                             uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) int32_t fin_lds[];       // per wave: n squares
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = P.n;
+    const uint32_t b = blockIdx.x * FW + wv;
     if (b >= batch) return;
-    siglens[b] = 0;
-    if (status[b] == 2) return;
-    const int n = P.n;
+    if (status[b] == 2) { if (lane == 0) siglens[b] = 0; return; }
+    int32_t *sq = fin_lds + (size_t)wv * n;
     const int32_t *a1 = s1 + (size_t)b * n; int32_t *a2 = s2 + (size_t)b * n;
-    for (int i = 0; i < n; i++) a2[i] = centre_mod(a2[i], P.q);
-    if (norm_fails(a1, a2, n, P.bd)) { status[b] = 4; return; }
-    BitW bw = { sigs + (size_t)b * sig_stride, 0, 0, 0 };
-    for (int i = 0; i < n; i++) bw.put((uint32_t)a2[i], P.q_bits - 2);
-    bw.flush();
-    siglens[b] = bw.nbytes;
-    status[b] = 1;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t x = a1[i], y = centre_mod(a2[i], P.q);
+        a2[i] = y;
+        sq[i] = x * x + y * y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int bad = 0;
+    if (lane == 0) bad = norm_fails_lds(sq, n, P.bd) ? 1 : 0;
+    bad = __shfl(bad, 0);
+    if (bad) { if (lane == 0) { status[b] = 4; siglens[b] = 0; } return; }
+    uint8_t *out = sigs + (size_t)b * sig_stride;
+    const int bits = P.q_bits - 2;
+    if (bits == 12) {
+        // two coefficients -> three bytes
+        for (int p = lane; p < n / 2; p += 64) {
+            const uint32_t u = (uint32_t)a2[2 * p] & 0xFFFu, v = (uint32_t)a2[2 * p + 1] & 0xFFFu;
+            out[3 * p] = (uint8_t)(u >> 4); out[3 * p + 1] = (uint8_t)(((u & 0xFu) << 4) | (v >> 8)); out[3 * p + 2] = (uint8_t)(v & 0xFFu);
+        }
+        if (lane == 0) { siglens[b] = (uint32_t)(n / 2) * 3; status[b] = 1; }
+    } else if (lane == 0) {
+        BitW bw = { out, 0, 0, 0 };
+        for (int i = 0; i < n; i++) bw.put((uint32_t)a2[i], bits);
+        bw.flush();
+        siglens[b] = bw.nbytes;
+        status[b] = 1;
+    }
 }
 
 // ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------
@@ -535,16 +563,22 @@ __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ si
     s2[tt] = centre_mod((int32_t)(val << (32 - bits)) >> (32 - bits), P.q);
 }
 
-// s1 = centre(c - s2*h) ; norm test
-__global__ void fal_vfinish_kernel(uint32_t batch, const int32_t *__restrict__ c, int32_t *__restrict__ prod, const int32_t *__restrict__ s2, uint32_t *__restrict__ verdict, FalP P)
+// s1 = centre(c - s2*h) ; norm test.  One wavefront per signature.
+__global__ __launch_bounds__(64 * FW) void fal_vfinish_kernel(uint32_t batch, const int32_t *__restrict__ c, const int32_t *__restrict__ prod, const int32_t *__restrict__ s2,
+                                                              uint32_t *__restrict__ verdict, FalP P)
 {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) int32_t fin_lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = P.n;
+    const uint32_t b = blockIdx.x * FW + wv;
     if (b >= batch) return;
-    const int n = P.n;
-    int32_t *a1 = prod + (size_t)b * n;
-    const int32_t *cb = c + (size_t)b * n, *a2 = s2 + (size_t)b * n;
-    for (int i = 0; i < n; i++) a1[i] = centre_mod(cb[i] - a1[i], P.q);
-    if (norm_fails(a1, a2, n, P.bd)) verdict[b] = 1;
+    int32_t *sq = fin_lds + (size_t)wv * n;
+    const int32_t *cb = c + (size_t)b * n, *pb = prod + (size_t)b * n, *a2 = s2 + (size_t)b * n;
+    for (int i = lane; i < n; i += 64) {
+        const int32_t x = centre_mod(cb[i] - pb[i], P.q), y = a2[i];
+        sq[i] = x * x + y * y;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (lane == 0 && norm_fails_lds(sq, n, P.bd)) verdict[b] = 1;
 }
 
 // exp(i*pi*j/2048), j = 0..2048, in binary128 (Taylor series for the first step, then repeated multiplication); GM[k] for
@@ -781,7 +815,7 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
     hipLaunchKernelGGL(fal_hash_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
     HIPCHK(hipGetLastError());
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(fal_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
+    hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -803,7 +837,7 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     hipLaunchKernelGGL(fal_hash_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
+    hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

@@ -173,6 +173,12 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _rows(t):
+    """row stride (in elements) of a [batch][row] tensor; a size-1 leading dimension may carry any stride"""
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
 class Engine:
     """One per (process, device): mirrors the per-context wiring safecrypto_create does
     (sc->sc_ntt / sc->sc_gauss, src/schemes/sig/dilithium/dilithium.c:207-209)."""
@@ -485,7 +491,7 @@ class Dilithium:
         sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=msgs.device)
         siglens = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
         trials = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
-        _chk(self.L, self.L.sc_hip_dilithium_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(),
+        _chk(self.L, self.L.sc_hip_dilithium_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(),
                                                   fixed_len, _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _stream()), 'dilithium_sign')
         return sigs, siglens, trials
 
@@ -493,8 +499,8 @@ class Dilithium:
         import torch
         batch = msgs.shape[0]
         verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
-        _chk(self.L, self.L.sc_hip_dilithium_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(),
-                                                    fixed_len, _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'dilithium_verify')
+        _chk(self.L, self.L.sc_hip_dilithium_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(),
+                                                    fixed_len, _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'dilithium_verify')
         return verdicts
 
     # host-buffer entry points: python bytes in / out (the shape safecrypto_sign / safecrypto_verify have)
@@ -569,8 +575,8 @@ class Bliss:
         trials = torch.zeros(batch, dtype=torch.int32, device=dev)
         status = torch.zeros(batch, dtype=torch.int32, device=dev)
         nul = C.c_void_p()
-        _chk(self.L, self.L.sc_hip_bliss_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else nul, fixed_len,
-                                              _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+        _chk(self.L, self.L.sc_hip_bliss_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                              _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
                                               _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'bliss_sign')
         return sigs, siglens, trials, status
 
@@ -578,8 +584,8 @@ class Bliss:
         import torch
         batch = msgs.shape[0]
         verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
-        _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
-                                                _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
+        _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
         return verdicts
 
 
@@ -625,7 +631,7 @@ class Falcon:
         s2 = torch.empty((batch, self.n), dtype=torch.int32, device=dev)
         status = torch.zeros(batch, dtype=torch.int32, device=dev)
         nul = C.c_void_p()
-        _chk(self.L, self.L.sc_hip_falcon_sample(self.h, batch, _ptr(c), _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+        _chk(self.L, self.L.sc_hip_falcon_sample(self.h, batch, _ptr(c), _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
                                                  _ptr(s1) if want_s1 else nul, _ptr(s2), _ptr(status), _stream()), 'falcon_sample')
         return s1, s2, status
 
@@ -636,8 +642,8 @@ class Falcon:
         siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
         status = torch.zeros(batch, dtype=torch.int32, device=dev)
         nul = C.c_void_p()
-        _chk(self.L, self.L.sc_hip_falcon_sign(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else nul, fixed_len,
-                                               _ptr(tapes), tapes.stride(0), _ptr(tape_lens) if tape_lens is not None else nul,
+        _chk(self.L, self.L.sc_hip_falcon_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                               _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
                                                _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(status), _stream()), 'falcon_sign')
         return sigs, siglens, status
 
@@ -645,8 +651,8 @@ class Falcon:
         import torch
         batch = msgs.shape[0]
         verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
-        _chk(self.L, self.L.sc_hip_falcon_verify(self.h, batch, _ptr(msgs), msgs.stride(0), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
-                                                 _ptr(sigs), sigs.stride(0), _ptr(siglens), _ptr(verdicts), _stream()), 'falcon_verify')
+        _chk(self.L, self.L.sc_hip_falcon_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'falcon_verify')
         return verdicts
 
 
@@ -686,7 +692,7 @@ class Kyber:
         batch = m.shape[0]
         u = torch.empty((batch, self.k, self.n), dtype=torch.int32, device=m.device)
         v = torch.empty((batch, self.n), dtype=torch.int32, device=m.device)
-        _chk(self.L, self.L.sc_hip_kyber_cpa_enc(self.h, batch, _ptr(m), _ptr(noise), noise.stride(0), _ptr(u), _ptr(v), _stream()), 'kyber_cpa_enc')
+        _chk(self.L, self.L.sc_hip_kyber_cpa_enc(self.h, batch, _ptr(m), _ptr(noise), _rows(noise), _ptr(u), _ptr(v), _stream()), 'kyber_cpa_enc')
         return u, v
 
     def dec(self, u, v):

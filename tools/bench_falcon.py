@@ -34,5 +34,8 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'one':
         print(json.dumps(run(0, 131072, reps=1)), flush=True)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cfg4':
+        print(json.dumps(run(2, 8192, reps=5)), flush=True)
+        sys.exit(0)
     for s, bsz in ((0, 4096), (0, 32768), (0, 131072), (2, 32768), (2, 131072)):
         print(json.dumps(run(s, bsz)), flush=True)
