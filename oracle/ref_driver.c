@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
@@ -450,8 +450,73 @@ static int kyber_case(FILE *f, int set, int nmsg)
         if (SC_FUNC_SUCCESS != kyber_cpa_dec(sc, u2, v2, 1, priv, n, k, m2)) return 1;
         snprintf(name, sizeof name, "%s_dec%d", tag, mi); rec_u8(f, name, m2, 32);
     }
+    /* KEM level (kyber_kem.c:855-1040): the context's CSPRNG is replaced by a seeded one so that m = its first prng_mem(32)
+     * is known (read from a twin); ciphertext and shared key as the reference packs them, and what decapsulation returns */
+    snprintf(name, sizeof name, "%s_t", tag); rec_i32(f, name, pub, (size_t)k * n);
+    snprintf(name, sizeof name, "%s_z", tag); rec_u8(f, name, (const UINT8 *)(priv + 3 * (size_t)k * n), 32);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    for (int mi = 0; mi < nmsg; mi++) {
+        uint8_t seed[32], m[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        prng_mem(twin, m, 32);
+        UINT8 *ct = NULL, *key = NULL, *key2 = NULL; size_t ctlen = 0, keylen = 0, key2len = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_encapsulation(sc, &ct, &ctlen, &key, &keylen)) return 1;
+        if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, ct, ctlen, &key2, &key2len)) return 1;
+        snprintf(name, sizeof name, "%s_kem_m%d", tag, mi); rec_u8(f, name, m, 32);
+        snprintf(name, sizeof name, "%s_kem_ct%d", tag, mi); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_kem_key%d", tag, mi); rec_u8(f, name, key, keylen);
+        snprintf(name, sizeof name, "%s_kem_dec%d", tag, mi); rec_u8(f, name, key2, key2len);
+        ct[ctlen / 2] ^= 0x20;                                   /* a damaged ciphertext still decapsulates - to another key */
+        free(key2); key2 = NULL; key2len = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, ct, ctlen, &key2, &key2len)) return 1;
+        snprintf(name, sizeof name, "%s_kem_decbad%d", tag, mi); rec_u8(f, name, key2, key2len);
+        free(ct); free(key); free(key2);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
     free(u); free(heap);
     safecrypto_destroy(sc);
+    return 0;
+}
+
+/* the CTR-DRBG behind create_csprng (module_lwe.c:914-940; ctr_drbg.c, prng.c:95-143,981-993,1050-1107): byte streams of
+ * prng_mem calls of assorted lengths and the word stream of prng_32 / prng_64, for seeds of several lengths */
+static int gen_drbg(const char *dir)
+{
+    char path[512], name[96];
+    snprintf(path, sizeof path, "%s/drbg_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    static const UINT8 nonce[16] = "dilithiumcrystal";
+    const int lens[5] = { 32, 32, 48, 64, 7 };
+    const int32_t calls[6] = { 256, 100, 64, 1, 512, 1024 + 37 };
+    rec_i32(f, "drbg_mem_calls", calls, 6);
+    sm_state = 0xd4b6ULL;
+    for (int c = 0; c < 5; c++) {
+        uint8_t seed[64];
+        for (int i = 0; i < lens[c]; i++) seed[i] = (uint8_t)splitmix64();
+        if (c == 0) memset(seed, 0, 32);
+        snprintf(name, sizeof name, "drbg%d_seed", c); rec_u8(f, name, seed, lens[c]);
+        for (int variant = 0; variant < 2; variant++) {
+            prng_ctx_t *p = prng_create(SC_ENTROPY_USER_PROVIDED, SC_PRNG_AES_CTR_DRBG, SC_PRNG_THREADING_NONE, 0x01000000);
+            prng_set_entropy(p, seed, lens[c]);
+            prng_init(p, nonce, 16);
+            if (variant == 0) {
+                uint8_t buf[4096]; size_t off = 0;
+                for (int k = 0; k < 6; k++) { prng_mem(p, buf + off, calls[k]); off += calls[k]; }
+                snprintf(name, sizeof name, "drbg%d_mem", c); rec_u8(f, name, buf, off);
+            } else if (c == 1 || c == 4) {
+                int32_t w[4200 + 16];
+                for (int k = 0; k < 4200; k++) w[k] = (int32_t)prng_32(p);         /* crosses the 4096-word pool refill */
+                for (int k = 0; k < 8; k++) { uint64_t x = prng_64(p); w[4200 + 2 * k] = (int32_t)(x >> 32); w[4201 + 2 * k] = (int32_t)x; }
+                snprintf(name, sizeof name, "drbg%d_words", c); rec_i32(f, name, w, 4216);
+            }
+            prng_destroy(p);
+        }
+    }
+    fclose(f);
     return 0;
 }
 
@@ -725,7 +790,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
@@ -734,5 +799,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
     if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
     if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);
+    if (all || !strcmp(argv[1], "drbg")) rc |= gen_drbg(argv[2]);
     return rc;
 }

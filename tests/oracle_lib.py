@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -73,6 +73,15 @@ def lib():
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
+        L.orc_drbg_create.restype = C.c_void_p
+        L.orc_drbg_create.argtypes = [u8p, C.c_size_t]
+        L.orc_drbg_destroy.argtypes = [C.c_void_p]
+        L.orc_drbg_mem.argtypes = [C.c_void_p, u8p, C.c_int32]
+        L.orc_drbg_32.restype = C.c_uint32
+        L.orc_drbg_32.argtypes = [C.c_void_p]
+        L.orc_drbg_64.restype = C.c_uint64
+        L.orc_drbg_64.argtypes = [C.c_void_p]
+        L.orc_aes256_ecb.argtypes = [u8p, u8p, u8p]
         f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
         f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
         L.orc_falcon_gm.restype = C.POINTER(C.c_double)
@@ -280,3 +289,27 @@ def cdt_sample(x, cdf, centre=0):
     v = np.empty(x.size, dtype=np.int32)
     lib().orc_cdt_sample_vector(v, x.size, x, cdf, cdf.size, centre)
     return v
+
+
+class Drbg:
+    """the reference's AES-256 CTR-DRBG seeded as create_csprng does"""
+
+    def __init__(self, seed):
+        s = np.ascontiguousarray(np.frombuffer(bytes(seed), dtype=np.uint8))
+        self.h = lib().orc_drbg_create(s, s.size)
+
+    def mem(self, n):
+        out = np.zeros(max(n, 1), dtype=np.uint8)
+        lib().orc_drbg_mem(self.h, out, n)
+        return bytes(out[:n])
+
+    def u32(self):
+        return lib().orc_drbg_32(self.h)
+
+    def u64(self):
+        return lib().orc_drbg_64(self.h)
+
+    def close(self):
+        if self.h:
+            lib().orc_drbg_destroy(self.h)
+            self.h = None
