@@ -112,3 +112,94 @@ int orc_kyber_cpa_dec(const int32_t *par, const int32_t *s_ntt, const int32_t *u
     free(w);
     return 0;
 }
+
+
+/* ---- KEM level: kyber_kem_encapsulation / kyber_kem_decapsulation (src/schemes/kem/kyber/kyber_kem.c:690-800, 855-1040) ----
+ * Build options of the reference: hash = SHA3-512 (its permutation), oracle bytes and noise through the AES CTR-DRBG
+ * (KYBER_KEM_USE_CSPRNG_SAM, no KYBER_KEM_USE_H_FUNC_XOF), NTT(t) and NTT(s) stored in the keys. */
+
+/* kem_g_function (:757-800) + kyber_oracle_bytes (:745-755): SHA3-512(rho | t as 16-bit LE | m) -> md; a CSPRNG seeded with
+ * md[0..32) yields 96 bytes = K_bar | r | d */
+static void kem_g(const int32_t *par, const uint8_t *rho, const int32_t *t, const uint8_t *m, uint8_t *krd)
+{
+    const int n = par[0], k = par[5];
+    const size_t len = 32 + (size_t)k * n * 2 + 32;
+    uint8_t *b = malloc(len), *p = b, md[64];
+    memcpy(p, rho, 32); p += 32;
+    for (int i = 0; i < k * n; i++) { *p++ = (uint8_t)(t[i] & 0xFF); *p++ = (uint8_t)(t[i] >> 8); }
+    memcpy(p, m, 32);
+    orc_sha3(64, b, len, md);
+    orc_drbg_t *d = orc_drbg_create(md, 32);
+    orc_drbg_mem(d, krd, 96);
+    orc_drbg_destroy(d);
+    free(b);
+}
+
+/* kem_h_function (:690-743): SHA3-512(K_bar | u, v as 16-bit LE | d) */
+static void kem_h(const int32_t *par, const uint8_t *kbar, const int32_t *u, const int32_t *v, const uint8_t *dd, uint8_t *md)
+{
+    const int n = par[0], k = par[5];
+    const size_t len = 32 + (size_t)(k + 1) * n * 2 + 32;
+    uint8_t *b = malloc(len), *p = b;
+    memcpy(p, kbar, 32); p += 32;
+    for (int i = 0; i < k * n; i++) { *p++ = (uint8_t)(u[i] & 0xFF); *p++ = (uint8_t)(u[i] >> 8); }
+    for (int i = 0; i < n; i++) { *p++ = (uint8_t)(v[i] & 0xFF); *p++ = (uint8_t)(v[i] >> 8); }
+    memcpy(p, dd, 32);
+    orc_sha3(64, b, len, md);
+    free(b);
+}
+
+/* the bytes kyber_cpa_enc draws from create_csprng(sc, r, 32): one prng_mem(eta*64) per polynomial of r, e1, e2 */
+static void noise_from_seed(const int32_t *par, const uint8_t *r, uint8_t *noise)
+{
+    const int n = par[0], k = par[5], eta = par[6];
+    orc_drbg_t *d = orc_drbg_create(r, 32);
+    for (int i = 0; i < 2 * k + 1; i++) orc_drbg_mem(d, noise + (size_t)i * eta * (n / 4), eta * (n / 4));
+    orc_drbg_destroy(d);
+}
+
+size_t orc_kyber_ct_bytes(const int32_t *par) { return ((size_t)par[5] * par[0] * par[7] + (size_t)par[0] * par[8]) / 8 + 32; }
+
+/* t = the public key's coefficient-domain polynomial vector as stored (first k*n words of sc->pubkey->key); m = the 32 bytes
+ * the reference draws with prng_mem(sc->prng_ctx[0]).  ct: u (d_u bits each) | v (d_v bits) | d, MSB-first; key: 32 bytes. */
+int orc_kyber_kem_enc(const int32_t *par, const int32_t *t, const int32_t *t_ntt, const uint8_t *rho, const int32_t *Agen, const uint8_t *m,
+                      uint8_t *ct, uint8_t *key)
+{
+    const int n = par[0], k = par[5], du = par[7], dv = par[8];
+    uint8_t krd[96], md[64], noise[8192];
+    int32_t *u = malloc(sizeof(int32_t) * (size_t)(k + 1) * n), *v = u + (size_t)k * n;
+    kem_g(par, rho, t, m, krd);
+    noise_from_seed(par, krd + 32, noise);
+    if (orc_kyber_cpa_enc(par, t_ntt, Agen, m, noise, u, v)) { free(u); return 1; }
+    kem_h(par, krd, u, v, krd + 64, md);
+    size_t bp = 0;
+    memset(ct, 0, orc_kyber_ct_bytes(par));
+    for (int i = 0; i < k * n; i++) for (int b = du - 1; b >= 0; b--, bp++) ct[bp >> 3] |= (uint8_t)((((uint32_t)u[i] >> b) & 1u) << (7 - (bp & 7)));
+    for (int i = 0; i < n; i++) for (int b = dv - 1; b >= 0; b--, bp++) ct[bp >> 3] |= (uint8_t)((((uint32_t)v[i] >> b) & 1u) << (7 - (bp & 7)));
+    memcpy(ct + (bp >> 3), krd + 64, 32);
+    memcpy(key, md, 32);
+    free(u);
+    return 0;
+}
+
+/* kyber_kem_decapsulation (:930-1040): m' = dec(u, v); (K', r', d') = G(rho, t, m'); (u', v') = enc(m', r'); key = H(K', u', v', d)
+ * with d taken from the ciphertext (this version neither compares the re-encryption nor substitutes z) */
+int orc_kyber_kem_dec(const int32_t *par, const int32_t *s_ntt, const int32_t *t, const int32_t *t_ntt, const uint8_t *rho, const int32_t *Agen,
+                      const uint8_t *ct, uint8_t *key)
+{
+    const int n = par[0], k = par[5], du = par[7], dv = par[8];
+    uint8_t krd[96], md[64], noise[8192], m[32];
+    int32_t *u = malloc(sizeof(int32_t) * (size_t)(k + 1) * n), *v = u + (size_t)k * n;
+    size_t bp = 0;
+    for (int i = 0; i < k * n; i++) { uint32_t x = 0; for (int b = 0; b < du; b++, bp++) x = (x << 1) | ((ct[bp >> 3] >> (7 - (bp & 7))) & 1u); u[i] = (int32_t)x; }
+    for (int i = 0; i < n; i++) { uint32_t x = 0; for (int b = 0; b < dv; b++, bp++) x = (x << 1) | ((ct[bp >> 3] >> (7 - (bp & 7))) & 1u); v[i] = (int32_t)x; }
+    const uint8_t *dd = ct + (bp >> 3);
+    if (orc_kyber_cpa_dec(par, s_ntt, u, v, m)) { free(u); return 1; }
+    kem_g(par, rho, t, m, krd);
+    noise_from_seed(par, krd + 32, noise);
+    if (orc_kyber_cpa_enc(par, t_ntt, Agen, m, noise, u, v)) { free(u); return 1; }
+    kem_h(par, krd, u, v, dd, md);
+    memcpy(key, md, 32);
+    free(u);
+    return 0;
+}

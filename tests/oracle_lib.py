@@ -73,6 +73,10 @@ def lib():
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
+        L.orc_kyber_ct_bytes.restype = C.c_size_t
+        L.orc_kyber_ct_bytes.argtypes = [i32p]
+        L.orc_kyber_kem_enc.argtypes = [i32p, i32p, i32p, u8p, i32p, u8p, u8p, u8p]
+        L.orc_kyber_kem_dec.argtypes = [i32p, i32p, i32p, i32p, u8p, i32p, u8p, u8p]
         L.orc_drbg_create.restype = C.c_void_p
         L.orc_drbg_create.argtypes = [u8p, C.c_size_t]
         L.orc_drbg_destroy.argtypes = [C.c_void_p]
@@ -313,3 +317,19 @@ class Drbg:
         if self.h:
             lib().orc_drbg_destroy(self.h)
             self.h = None
+
+
+def kyber_kem_enc(par, t, t_ntt, rho, Agen, m):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    par = f(par, np.int32)
+    ct, key = np.zeros(lib().orc_kyber_ct_bytes(par), dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+    assert lib().orc_kyber_kem_enc(par, f(t, np.int32), f(t_ntt, np.int32), f(rho, np.uint8), f(Agen, np.int32), f(m, np.uint8), ct, key) == 0
+    return bytes(ct), bytes(key)
+
+
+def kyber_kem_dec(par, s_ntt, t, t_ntt, rho, Agen, ct):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    key = np.zeros(32, dtype=np.uint8)
+    c = np.ascontiguousarray(np.frombuffer(bytes(ct), dtype=np.uint8))
+    assert lib().orc_kyber_kem_dec(f(par, np.int32), f(s_ntt, np.int32), f(t, np.int32), f(t_ntt, np.int32), f(rho, np.uint8), f(Agen, np.int32), c, key) == 0
+    return bytes(key)

@@ -16,3 +16,18 @@ def test_enc_dec_vs_reference(tag, nmsg):
         assert np.array_equal(u, G[f'{tag}_u{i}']) and np.array_equal(v, G[f'{tag}_v{i}']), (tag, i)
         m = O.kyber_dec(par, G[f'{tag}_s_ntt'], u, v)
         assert np.array_equal(m, G[f'{tag}_dec{i}']) and np.array_equal(m, G[f'{tag}_m{i}'])
+
+
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+def test_kem_vs_reference(tag, nmsg):
+    """safecrypto_encapsulation / safecrypto_decapsulation: ciphertext bytes and shared keys for the same key pair and m"""
+    G = load_golden('kyber_ref.txt')
+    par = G[f'{tag}_params']
+    u8 = lambda a: bytes(np.asarray(a, dtype=np.uint8))
+    for i in range(nmsg):
+        ct, key = O.kyber_kem_enc(par, G[f'{tag}_t'], G[f'{tag}_t_ntt'], G[f'{tag}_rho'], G[f'{tag}_Agen'], G[f'{tag}_kem_m{i}'])
+        assert ct == u8(G[f'{tag}_kem_ct{i}']) and key == u8(G[f'{tag}_kem_key{i}']), (tag, i)
+        args = (par, G[f'{tag}_s_ntt'], G[f'{tag}_t'], G[f'{tag}_t_ntt'], G[f'{tag}_rho'], G[f'{tag}_Agen'])
+        assert O.kyber_kem_dec(*args, ct) == u8(G[f'{tag}_kem_dec{i}']) == key
+        bad = bytearray(ct); bad[len(bad) // 2] ^= 0x20
+        assert O.kyber_kem_dec(*args, bytes(bad)) == u8(G[f'{tag}_kem_decbad{i}'])
