@@ -193,6 +193,20 @@ int sc_hip_poly_cmp_not_equal(sc_hip_ctx_t *ctx, size_t batch, size_t n, const i
 int sc_hip_vec_absmax(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_v, int32_t *d_out, void *stream);
 int sc_hip_vec_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_t, const int32_t *d_u, int32_t *d_out, void *stream);
 
+/* ---- the reference's default CSPRNG on the device (csrc/drbg.hip, drbg_dev.h) ------------------ */
+
+/* replaces: create_csprng(sc, seed, seed_len) (src/utils/arith/module_lwe.c:914-940; AES-256 CTR-DRBG of
+ * src/utils/crypto/ctr_drbg.c with the seed as circular user entropy) followed by prng_mem (src/utils/crypto/prng.c:1050-1107),
+ * for `batch` independent seeds d_seeds [batch][seed_stride]: d_out row i = the first nbytes of generator i's byte stream
+ * (nbytes and out_stride multiples of 16; a prng_mem(len) call consumes ceil(len/64)*64 bytes of this stream). */
+int sc_hip_drbg_mem(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                    uint8_t *d_out, size_t out_stride, size_t nbytes, void *stream);
+/* same generators read through prng_32 / prng_64 (prng.c:95-143,963-993: 64-bit little-endian draws, high word first):
+ * d_out row i = the first nwords pool words - the "tape" format sc_hip_bliss_sign / sc_hip_falcon_sign consume
+ * (nwords and out_stride_words multiples of 4) */
+int sc_hip_drbg_words(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                      uint32_t *d_out, size_t out_stride_words, size_t nwords, void *stream);
+
 /* ---- BLISS-B: batched sign / verify under one key ------------------------------------------ */
 
 /* the fields of bliss_set_t the engine needs (src/schemes/sig/bliss_b/bliss_params.h:43-75, values

@@ -1,0 +1,121 @@
+// drbg.hip - batched expansion of seeds with the reference's default CSPRNG (AES-256 CTR-DRBG, see drbg_dev.h) behind the C ABI
+// of include/sc_hip.h: one generator per seed, one lane per generator.  This is what create_csprng(sc, seed, len) followed by
+// prng_mem / prng_32 calls yields on the host (src/utils/arith/module_lwe.c:914-940, src/utils/crypto/prng.c:963-1107), so
+// per-message randomness (Kyber's noise from r, signing tapes) and per-key expansions (the matrix from rho) can be produced
+// where they are consumed instead of being uploaded.
+#include "engine_internal.h"
+#include "drbg_dev.h"
+
+#include <string.h>
+
+using namespace sc;
+
+namespace sc {
+
+// FIPS-197 on the host, only to build the constants of DrbgConst (S-box; the three instantiation blocks under the zero key)
+namespace {
+uint8_t h_xtime(uint8_t x) { return (uint8_t)((x << 1) ^ ((x >> 7) * 0x1b)); }
+uint8_t h_gmul(uint8_t a, uint8_t b) { uint8_t r = 0; while (b) { if (b & 1) r ^= a; a = h_xtime(a); b >>= 1; } return r; }
+
+void h_aes256_zero_key_encrypt(const uint8_t sbox[256], const uint8_t in[16], uint8_t out[16])
+{
+    uint8_t w[60][4];
+    memset(w, 0, 32);
+    uint8_t rc = 1;
+    for (int i = 8; i < 60; i++) {
+        uint8_t t[4]; memcpy(t, w[i - 1], 4);
+        if (i % 8 == 0) { const uint8_t t0 = t[0]; t[0] = sbox[t[1]] ^ rc; t[1] = sbox[t[2]]; t[2] = sbox[t[3]]; t[3] = sbox[t0]; rc = h_xtime(rc); }
+        else if (i % 8 == 4) for (int j = 0; j < 4; j++) t[j] = sbox[t[j]];
+        for (int j = 0; j < 4; j++) w[i][j] = w[i - 8][j] ^ t[j];
+    }
+    const uint8_t *rk = &w[0][0];
+    uint8_t s[16], t[16];
+    for (int i = 0; i < 16; i++) s[i] = in[i] ^ rk[i];
+    for (int r = 1; r <= 14; r++) {
+        for (int c = 0; c < 4; c++) for (int row = 0; row < 4; row++) t[4 * c + row] = sbox[s[4 * ((c + row) & 3) + row]];
+        if (r < 14) {
+            for (int c = 0; c < 4; c++) {
+                const uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+                s[4 * c] = (uint8_t)(h_xtime(a0) ^ h_xtime(a1) ^ a1 ^ a2 ^ a3);
+                s[4 * c + 1] = (uint8_t)(a0 ^ h_xtime(a1) ^ h_xtime(a2) ^ a2 ^ a3);
+                s[4 * c + 2] = (uint8_t)(a0 ^ a1 ^ h_xtime(a2) ^ h_xtime(a3) ^ a3);
+                s[4 * c + 3] = (uint8_t)(h_xtime(a0) ^ a0 ^ a1 ^ a2 ^ h_xtime(a3));
+            }
+        } else memcpy(s, t, 16);
+        for (int i = 0; i < 16; i++) s[i] ^= rk[16 * r + i];
+    }
+    memcpy(out, s, 16);
+}
+}  // namespace
+
+const DrbgConst &drbg_const()
+{
+    static DrbgConst c;
+    static bool ready = false;
+    if (!ready) {
+        for (int x = 0; x < 256; x++) {
+            uint8_t inv = 0;
+            if (x) for (int y = 1; y < 256; y++) if (h_gmul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+            uint8_t s = inv, r = inv;
+            for (int i = 0; i < 4; i++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
+            c.sbox[x] = s ^ 0x63;
+        }
+        for (uint32_t ctr = 1; ctr <= 3; ctr++) {                      // ctr_drbg.c:104-128: block index 2, 1, 0
+            uint8_t blk[16];
+            for (int w = 0; w < 4; w++) { blk[4 * w] = (uint8_t)ctr; blk[4 * w + 1] = blk[4 * w + 2] = blk[4 * w + 3] = 0; }
+            h_aes256_zero_key_encrypt(c.sbox, blk, c.init_bytes + 16 * (3 - ctr));
+        }
+        ready = true;
+    }
+    return c;
+}
+
+}  // namespace sc
+
+namespace {
+
+// out row i = the first nblk 16-byte blocks of generator i's stream; words != 0: in prng_32 order (w1, w0, w3, w2 per block)
+__global__ __launch_bounds__(256) void drbg_expand_kernel(uint32_t batch, const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len,
+                                                          uint8_t *__restrict__ out, size_t out_stride, uint32_t nblk, int words, DrbgConst C)
+{
+    __shared__ AesLds L;
+    L.fill(C);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch) return;
+    Drbg d;
+    d.init(seeds + (size_t)i * seed_stride, seed_len, C, L);
+    uint4 *o = reinterpret_cast<uint4 *>(out + (size_t)i * out_stride);
+    for (uint32_t b = 0; b < nblk; b++) {
+        uint32_t w[4];
+        d.block(w, L);
+        o[b] = words ? make_uint4(w[1], w[0], w[3], w[2]) : make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+int run_expand(sc_hip_ctx *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, void *d_out, size_t out_stride, size_t nbytes, int words,
+               void *stream, const char *who)
+{
+    if (!ctx) return fail(std::string(who) + ": null context");
+    if (batch == 0 || nbytes == 0) return SC_HIP_SUCCESS;
+    if (!d_seeds || !d_out) return fail(std::string(who) + ": null buffer");
+    if (seed_len == 0 || seed_len > seed_stride || seed_len > 0xffffffffu) return fail(std::string(who) + ": bad seed length / stride");
+    if ((nbytes & 15) != 0 || out_stride < nbytes || (out_stride & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
+        return fail(std::string(who) + ": output rows must be 16-byte aligned multiples of 16 bytes");
+    if (batch > 0x7fffffffu || nbytes / 16 > 0xffffffffu) return fail(std::string(who) + ": too large");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(drbg_expand_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)batch, d_seeds, seed_stride, (uint32_t)seed_len,
+                       (uint8_t *)d_out, out_stride, (uint32_t)(nbytes / 16), words, sc::drbg_const());
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" int sc_hip_drbg_mem(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                               uint8_t *d_out, size_t out_stride, size_t nbytes, void *stream)
+{ return run_expand(ctx, batch, d_seeds, seed_stride, seed_len, d_out, out_stride, nbytes, 0, stream, "drbg_mem"); }
+
+extern "C" int sc_hip_drbg_words(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                 uint32_t *d_out, size_t out_stride_words, size_t nwords, void *stream)
+{ return run_expand(ctx, batch, d_seeds, seed_stride, seed_len, d_out, out_stride_words * 4, nwords * 4, 1, stream, "drbg_words"); }

@@ -28,6 +28,7 @@ SYMBOLS = [
     'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
+    'sc_hip_drbg_mem', 'sc_hip_drbg_words',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -141,6 +142,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_poly_cmp_not_equal.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.sc_hip_vec_absmax.argtypes = [vp, sz, sz, vp, vp, vp]
     L.sc_hip_vec_scalar.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
+    L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_falcon_destroy.argtypes = [vp]
     L.sc_hip_falcon_destroy.restype = None
@@ -234,6 +237,19 @@ class Engine:
         import torch
         out = torch.empty_like(a) if out is None else out
         _chk(self.L, self.L.sc_hip_poly_sub(self.h, a.numel(), _ptr(a), _ptr(b), _ptr(out), _stream()), 'poly_sub')
+        return out
+
+    # the reference's AES-256 CTR-DRBG, one generator per seed row (uint8 [batch][seed_len] device tensor)
+    def drbg_mem(self, seeds, nbytes):
+        import torch
+        out = torch.empty((seeds.shape[0], nbytes), dtype=torch.uint8, device=seeds.device)
+        _chk(self.L, self.L.sc_hip_drbg_mem(self.h, seeds.shape[0], _ptr(seeds), _rows(seeds), seeds.shape[1], _ptr(out), nbytes, nbytes, _stream()), 'drbg_mem')
+        return out
+
+    def drbg_words(self, seeds, nwords):
+        import torch
+        out = torch.empty((seeds.shape[0], nwords), dtype=torch.int32, device=seeds.device)
+        _chk(self.L, self.L.sc_hip_drbg_words(self.h, seeds.shape[0], _ptr(seeds), _rows(seeds), seeds.shape[1], _ptr(out), nwords, nwords, _stream()), 'drbg_words')
         return out
 
     # utils_arith_poly / utils_arith_vectors entries (device tensors, int32; per-polynomial ops take [batch][n])
