@@ -298,6 +298,18 @@ int sc_hip_falcon_sign(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, 
 int sc_hip_falcon_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* KEM level, with the reference's build options (SHA3-512 with its own permutation, AES CTR-DRBG for oracle bytes and noise):
+ * extra public-key material that only enters the G hash - t: the coefficient-domain vector as stored (first k*n words of
+ * sc->pubkey->key, kyber_kem.c:636-650), rho: the 32-byte matrix seed */
+int  sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, const uint8_t *rho);
+size_t sc_hip_kyber_ct_bytes(const sc_hip_kyber_t *h);                       /* (k*n*d_u + n*d_v)/8 + 32 */
+/* replaces: safecrypto_encapsulation -> kyber_kem_encapsulation (src/schemes/kem/kyber/kyber_kem.c:855-928) for `batch` values
+ * d_m [batch][32] (what prng_mem(sc->prng_ctx[0], m, 32) returned): ciphertexts d_ct [batch][ct_stride] in the reference's wire
+ * format (u | v | d) and 32-byte shared keys d_keys [batch][32] */
+int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
+/* replaces: safecrypto_decapsulation -> kyber_kem_decapsulation (kyber_kem.c:930-1040); needs set_privkey too */
+int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

@@ -71,6 +71,18 @@ struct Sponge {
 #pragma unroll
         for (int w = 0; w < 25; w++) st[w * NT] = 0;
     }
+    // resume from a stored state (25 words) taken at a block boundary
+    __device__ __forceinline__ void load(uint64_t *lds_state, int tid, int rate_bytes, const uint64_t *__restrict__ src)
+    {
+        st = lds_state + tid; rate = rate_bytes; pos = 0;
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT] = src[w];
+    }
+    __device__ __forceinline__ void save(uint64_t *dst) const
+    {
+#pragma unroll
+        for (int w = 0; w < 25; w++) dst[w] = st[w * NT];
+    }
     __device__ __forceinline__ void permute()
     {
         uint64_t s[25];

@@ -4,10 +4,19 @@
 // kyber_kem_encapsulation / _decapsulation call them (src/schemes/kem/kyber/kyber_kem.c:866,992-1001; keys hold NTT(t)
 // and NTT(s): kyber_kem_params.h:43,46), with binomial_rand_sample_csprng (:380-412), create_rand_product_16_csprng in
 // its TRANSPOSED form (:588-748) and mlwe_compress / mlwe_decompress (:43-69, reproduced literally, wrap-around included).
-// What the reference derives with its AES-CTR-DRBG is an input: the k*k matrix polynomials in generation order (once per
-// key) and, per message, the (2k+1)*n*eta/4 noise bytes its prng_mem calls return for the seed r.
+// At the CPA level what the reference derives with its AES-CTR-DRBG is an input: the k*k matrix polynomials in generation
+// order (once per key) and, per message, the (2k+1)*n*eta/4 noise bytes its prng_mem calls return for the seed r.
+//
+// KEM level (kyber_kem_encapsulation / kyber_kem_decapsulation, kyber_kem.c:855-1040, with the reference's build options:
+// SHA3-512 with its own permutation as the hash, the AES CTR-DRBG for the oracle bytes and the noise): G = SHA3-512(rho | t as
+// 16-bit LE | m) -> a DRBG seeded with md[0..32) yields K_bar | r | d (kem_g_function :757-800, kyber_oracle_bytes :745-755);
+// a DRBG seeded with r yields the noise (module_lwe.c:1290-1340); K = SHA3-512(K_bar | u | v as 16-bit LE | d)[0..32)
+// (kem_h_function :690-743); ciphertext = u (d_u bits) | v (d_v bits) | d, MSB-first.  The part of G's input that is the same
+// for every message (rho | t, 21 whole SHA3-512 blocks of it) is absorbed once per key.
 #include "engine_internal.h"
 #include "mlwe_kernels.h"
+#include "keccak_dev.h"
+#include "drbg_dev.h"
 
 using namespace sc;
 using namespace sc_mlwe;
@@ -82,7 +91,114 @@ __global__ void ky_dec_finish_kernel(const int32_t *v, const int32_t *x, uint8_t
     m[(size_t)item * 32 + byte] = (uint8_t)b;
 }
 
+
+constexpr int KHT = 64;      // KEM hash kernels: lanes per workgroup (LDS sponge states)
+
+// once per key: the sponge state after the whole 72-byte blocks of rho | t16
+__global__ void ky_gprefix_kernel(const uint8_t *__restrict__ prefix, uint32_t full_bytes, uint64_t *__restrict__ state)
+{
+    __shared__ uint64_t st[25 * KHT];
+    Sponge<KHT> sp; sp.init(st, threadIdx.x, 72);
+    if (threadIdx.x != 0) return;
+    sp.absorb(prefix, full_bytes);
+    sp.save(state);
+}
+
+// G and the two DRBG expansions, one lane per message: krd [batch][96] = K_bar | r | d ; noise [batch][noise_stride]
+__global__ __launch_bounds__(KHT) void ky_g_kernel(uint32_t batch, const uint8_t *__restrict__ m, const uint64_t *__restrict__ gstate, const uint8_t *__restrict__ tail, uint32_t tail_len,
+                                                   uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C)
+{
+    __shared__ uint64_t st[25 * KHT];
+    __shared__ AesLds L;
+    L.fill(C);
+    __syncthreads();
+    const uint32_t i = blockIdx.x * KHT + threadIdx.x;
+    Sponge<KHT> sp; sp.load(st, threadIdx.x, 72, gstate);
+    if (i >= batch) return;
+    sp.absorb(tail, tail_len);
+    sp.absorb(m + (size_t)i * 32, 32);
+    sp.finalize(0x06);
+    uint8_t md[32];
+    for (int b = 0; b < 32; b++) md[b] = sp.squeeze_byte();
+    Drbg d;
+    d.init(md, 32, C, L);
+    uint4 *o = reinterpret_cast<uint4 *>(krd + (size_t)i * 96);
+    uint32_t w[4], r32[8];
+    for (int b = 0; b < 6; b++) {
+        d.block(w, L);
+        o[b] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (b == 2) { r32[0] = w[0]; r32[1] = w[1]; r32[2] = w[2]; r32[3] = w[3]; }
+        if (b == 3) { r32[4] = w[0]; r32[5] = w[1]; r32[6] = w[2]; r32[7] = w[3]; }
+    }
+    uint8_t r[32];
+    for (int b = 0; b < 32; b++) r[b] = (uint8_t)(r32[b >> 2] >> (8 * (b & 3)));
+    d.init(r, 32, C, L);
+    uint4 *no = reinterpret_cast<uint4 *>(noise + (size_t)i * noise_stride);
+    for (uint32_t b = 0; b < noise_blocks; b++) { d.block(w, L); no[b] = make_uint4(w[0], w[1], w[2], w[3]); }
+}
+
+// H: key = SHA3-512(K_bar | u16 | v16 | d)[0..32); d from krd (encapsulation) or from the ciphertext (decapsulation)
+__global__ __launch_bounds__(KHT) void ky_h_kernel(uint32_t batch, const uint8_t *__restrict__ krd, const int32_t *__restrict__ u, const int32_t *__restrict__ v,
+                                                   const uint8_t *__restrict__ dsrc, size_t d_stride, uint8_t *__restrict__ keys, KyP P)
+{
+    __shared__ uint64_t st[25 * KHT];
+    const uint32_t i = blockIdx.x * KHT + threadIdx.x;
+    Sponge<KHT> sp; sp.init(st, threadIdx.x, 72);
+    if (i >= batch) return;
+    const uint64_t *kb = reinterpret_cast<const uint64_t *>(krd + (size_t)i * 96);
+    for (int w = 0; w < 4; w++) sp.absorb_u64(kb[w]);
+    const int kn = P.k * P.n;
+    const int4 *pu = reinterpret_cast<const int4 *>(u + (size_t)i * kn), *pv = reinterpret_cast<const int4 *>(v + (size_t)i * P.n);
+    for (int g = 0; g < kn / 4; g++) { const int4 c = pu[g]; sp.absorb_u64((uint64_t)(c.x & 0xFFFF) | ((uint64_t)(c.y & 0xFFFF) << 16) | ((uint64_t)(c.z & 0xFFFF) << 32) | ((uint64_t)(c.w & 0xFFFF) << 48)); }
+    for (int g = 0; g < P.n / 4; g++) { const int4 c = pv[g]; sp.absorb_u64((uint64_t)(c.x & 0xFFFF) | ((uint64_t)(c.y & 0xFFFF) << 16) | ((uint64_t)(c.z & 0xFFFF) << 32) | ((uint64_t)(c.w & 0xFFFF) << 48)); }
+    sp.absorb(dsrc + (size_t)i * d_stride, 32);
+    sp.finalize(0x06);
+    uint8_t *o = keys + (size_t)i * 32;
+    for (int b = 0; b < 32; b++) o[b] = sp.squeeze_byte();
+}
+
+// ciphertext byte j of message i: u (d_u bits each) | v (d_v bits each), MSB first, then d (kyber_kem.c:888-896)
+__global__ void ky_pack_kernel(uint32_t batch, const int32_t *__restrict__ u, const int32_t *__restrict__ v, const uint8_t *__restrict__ krd, uint8_t *__restrict__ ct, size_t ct_stride, KyP P)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t ubits = (uint32_t)(P.k * P.n * P.d_u), vbits = (uint32_t)(P.n * P.d_v), body = (ubits + vbits) / 8, per = body + 32;
+    const uint32_t i = (uint32_t)(t / per), j = (uint32_t)(t % per);
+    if (i >= batch) return;
+    uint8_t out;
+    if (j >= body) out = krd[(size_t)i * 96 + 64 + (j - body)];
+    else {
+        uint32_t acc = 0;
+        for (int b = 0; b < 8; b++) {
+            const uint32_t bp = 8 * j + b;
+            uint32_t bit;
+            if (bp < ubits) { const uint32_t c = bp / P.d_u, k = bp % P.d_u; bit = ((uint32_t)u[(size_t)i * P.k * P.n + c] >> (P.d_u - 1 - k)) & 1u; }
+            else { const uint32_t q = bp - ubits, c = q / P.d_v, k = q % P.d_v; bit = ((uint32_t)v[(size_t)i * P.n + c] >> (P.d_v - 1 - k)) & 1u; }
+            acc = (acc << 1) | bit;
+        }
+        out = (uint8_t)acc;
+    }
+    ct[(size_t)i * ct_stride + j] = out;
+}
+
+// kyber_kem.c:976-983: coefficient e of message i from the packed ciphertext
+__global__ void ky_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ ct, size_t ct_stride, int32_t *__restrict__ u, int32_t *__restrict__ v, KyP P)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = (P.k + 1) * P.n;
+    const uint32_t i = (uint32_t)(t / per); const int e = (int)(t % per);
+    if (i >= batch) return;
+    const uint8_t *s = ct + (size_t)i * ct_stride;
+    const int kn = P.k * P.n;
+    const int bits = e < kn ? P.d_u : P.d_v;
+    const uint32_t off = e < kn ? (uint32_t)e * P.d_u : (uint32_t)kn * P.d_u + (uint32_t)(e - kn) * P.d_v;
+    uint32_t val = 0;
+    for (int b = 0; b < bits; b++) { const uint32_t bp = off + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+    if (e < kn) u[(size_t)i * kn + e] = (int32_t)val; else v[(size_t)i * P.n + (e - kn)] = (int32_t)val;
+}
+
 }  // namespace
+
+namespace sc { const DrbgConst &drbg_const(); }
 
 struct sc_hip_kyber {
     sc_hip_ctx *ctx;
@@ -93,6 +209,11 @@ struct sc_hip_kyber {
     size_t cap;
     int32_t *r, *e1, *e2, *u0, *v0;
     uint32_t *yh;
+    // KEM level
+    bool have_kem;
+    uint64_t *d_gstate; uint8_t *d_gtail; uint32_t gtail_len;      // G's per-key prefix: sponge state after its whole blocks + the rest
+    size_t kem_cap;
+    uint8_t *krd, *noise, *mbuf; int32_t *ku, *kv;
 };
 
 static int ky_ensure(sc_hip_kyber *h, size_t batch)
@@ -128,7 +249,7 @@ extern "C" int sc_hip_kyber_create(sc_hip_ctx_t *ctx, const sc_hip_kyber_params_
 extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
 {
     if (!h) return;
-    void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh };
+    void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     sc_hip_plan_destroy(h->plan);
     delete h;
@@ -224,6 +345,115 @@ extern "C" int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32
     a.key = h->d_s; a.w = h->v0; a.w1 = nullptr;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ky_dec_finish_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, s, d_v, h->v0, d_m, B, P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+
+// ---- KEM level --------------------------------------------------------------------------------------------------------------
+
+static size_t ky_noise_stride(const sc_hip_kyber *h) { return (sc_hip_kyber_noise_bytes(h) + 15) & ~(size_t)15; }
+
+static int ky_kem_ensure(sc_hip_kyber *h, size_t batch)
+{
+    if (batch <= h->kem_cap) return SC_HIP_SUCCESS;
+    void *old[] = { h->krd, h->noise, h->mbuf, h->ku, h->kv };
+    for (void *p : old) if (p) (void)hipFree(p);
+    h->krd = h->noise = h->mbuf = nullptr; h->ku = h->kv = nullptr; h->kem_cap = 0;
+    const size_t kn = (size_t)h->P.k * N;
+    HIPCHK(hipMalloc((void **)&h->krd, batch * 96)); HIPCHK(hipMalloc((void **)&h->noise, batch * ky_noise_stride(h))); HIPCHK(hipMalloc((void **)&h->mbuf, batch * 32));
+    HIPCHK(hipMalloc((void **)&h->ku, batch * kn * 4)); HIPCHK(hipMalloc((void **)&h->kv, batch * N * 4));
+    h->kem_cap = batch;
+    return SC_HIP_SUCCESS;
+}
+
+// t: the public key's coefficient-domain vector as the reference stores it (first k*n words of sc->pubkey->key, kyber_kem.c:636-650),
+// rho: its 32-byte seed; both only enter the G hash
+extern "C" int sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, const uint8_t *rho)
+{
+    if (!h || !t || !rho) return fail("kyber_set_kem_pubkey: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t kn = (size_t)h->P.k * N, len = 32 + 2 * kn, full = len / 72 * 72;
+    std::vector<uint8_t> pre(len);
+    memcpy(pre.data(), rho, 32);
+    for (size_t i = 0; i < kn; i++) { pre[32 + 2 * i] = (uint8_t)(t[i] & 0xFF); pre[33 + 2 * i] = (uint8_t)(t[i] >> 8); }
+    uint8_t *d_pre = nullptr;
+    HIPCHK(hipMalloc((void **)&d_pre, len));
+    if (!h->d_gstate) HIPCHK(hipMalloc((void **)&h->d_gstate, 25 * 8));
+    if (h->d_gtail) { (void)hipFree(h->d_gtail); h->d_gtail = nullptr; }
+    HIPCHK(hipMalloc((void **)&h->d_gtail, len - full + 8));
+    HIPCHK(hipMemcpy(d_pre, pre.data(), len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_gtail, pre.data() + full, len - full, hipMemcpyHostToDevice));
+    h->gtail_len = (uint32_t)(len - full);
+    hipLaunchKernelGGL(ky_gprefix_kernel, dim3(1), dim3(KHT), 0, nullptr, d_pre, (uint32_t)full, h->d_gstate);
+    const int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber_set_kem_pubkey: kernel failed");
+    (void)hipFree(d_pre);
+    h->have_kem = rc == SC_HIP_SUCCESS;
+    return rc;
+}
+
+extern "C" size_t sc_hip_kyber_ct_bytes(const sc_hip_kyber_t *h)
+{ return h ? ((size_t)h->P.k * N * h->P.d_u + (size_t)N * h->P.d_v) / 8 + 32 : 0; }
+
+static int ky_kem_check(sc_hip_kyber *h, size_t batch, const char *who)
+{
+    if (!h) return fail(std::string(who) + ": null handle");
+    if (!h->have_pub || !h->have_kem) return fail(std::string(who) + ": public key (set_pubkey + set_kem_pubkey) not loaded");
+    if (((h->P.k * N * h->P.d_u + N * h->P.d_v) & 7) != 0) return fail(std::string(who) + ": ciphertext body is not a whole number of bytes");
+    if (batch > 0x7fffffffu / 4096) return fail(std::string(who) + ": batch too large");
+    return SC_HIP_SUCCESS;
+}
+
+// G -> (K_bar, r, d), noise; CPA encryption of m under r; into h->ku, h->kv
+static int ky_kem_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, hipStream_t s)
+{
+    const uint32_t B = (uint32_t)batch;
+    const size_t ns = ky_noise_stride(h);
+    hipLaunchKernelGGL(ky_g_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
+                       (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
+    HIPCHK(hipGetLastError());
+    return sc_hip_kyber_cpa_enc(h, batch, d_m, h->noise, ns, h->ku, h->kv, s);
+}
+
+// replaces: kyber_kem_encapsulation (kyber_kem.c:855-928); d_m [batch][32] = the bytes prng_mem(sc->prng_ctx[0], m, 32) returns
+extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream)
+{
+    if (ky_kem_check(h, batch, "kyber_kem_encaps")) return SC_HIP_FAILURE;
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_m || !d_ct || !d_keys) return fail("kyber_kem_encaps: null buffer");
+    if (ct_stride < sc_hip_kyber_ct_bytes(h)) return fail("kyber_kem_encaps: ct_stride smaller than sc_hip_kyber_ct_bytes()");
+    if ((sc_hip_kyber_noise_bytes(h) & 15) != 0) return fail("kyber_kem_encaps: noise length is not a multiple of 16");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (ky_kem_ensure(h, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    if (ky_kem_core(h, batch, d_m, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
+    const size_t nb = batch * sc_hip_kyber_ct_bytes(h);
+    hipLaunchKernelGGL(ky_pack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: kyber_kem_decapsulation (kyber_kem.c:930-1040)
+extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream)
+{
+    if (ky_kem_check(h, batch, "kyber_kem_decaps")) return SC_HIP_FAILURE;
+    if (!h->have_priv) return fail("kyber_kem_decaps: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_ct || !d_keys) return fail("kyber_kem_decaps: null buffer");
+    if (ct_stride < sc_hip_kyber_ct_bytes(h)) return fail("kyber_kem_decaps: ct_stride smaller than sc_hip_kyber_ct_bytes()");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (ky_kem_ensure(h, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    const size_t ne = batch * (size_t)(h->P.k + 1) * N;
+    hipLaunchKernelGGL(ky_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, h->ku, h->kv, h->P);
+    HIPCHK(hipGetLastError());
+    if (sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
+    if (ky_kem_core(h, batch, h->mbuf, s)) return SC_HIP_FAILURE;
+    const size_t body = sc_hip_kyber_ct_bytes(h) - 32;
+    hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

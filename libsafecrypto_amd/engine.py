@@ -21,7 +21,7 @@ SYMBOLS = [
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
-    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec',
+    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
@@ -142,6 +142,11 @@ def load_library(path=LIB_PATH):
     L.sc_hip_poly_cmp_not_equal.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.sc_hip_vec_absmax.argtypes = [vp, sz, sz, vp, vp, vp]
     L.sc_hip_vec_scalar.argtypes = [vp, sz, sz, vp, vp, vp, vp]
+    L.sc_hip_kyber_set_kem_pubkey.argtypes = [vp, vp, vp]
+    L.sc_hip_kyber_ct_bytes.argtypes = [vp]
+    L.sc_hip_kyber_ct_bytes.restype = sz
+    L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
+    L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -701,6 +706,30 @@ class Kyber:
         import numpy as np
         a = np.ascontiguousarray(np.asarray(s_ntt), dtype=np.int32)
         _chk(self.L, self.L.sc_hip_kyber_set_privkey(self.h, _ptr(a)), 'kyber_set_privkey')
+
+    def set_kem_pubkey(self, t, rho):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(t), dtype=np.int32)
+        r = np.ascontiguousarray(np.asarray(rho), dtype=np.uint8)
+        assert a.size == self.k * self.n and r.size == 32
+        _chk(self.L, self.L.sc_hip_kyber_set_kem_pubkey(self.h, _ptr(a), _ptr(r)), 'kyber_set_kem_pubkey')
+        self.ct_bytes = self.L.sc_hip_kyber_ct_bytes(self.h)
+
+    def encaps(self, m):
+        """m uint8 [batch][32] (device) -> ciphertexts uint8 [batch][ct_bytes], keys uint8 [batch][32]"""
+        import torch
+        batch = m.shape[0]
+        ct = torch.empty((batch, self.ct_bytes), dtype=torch.uint8, device=m.device)
+        keys = torch.empty((batch, 32), dtype=torch.uint8, device=m.device)
+        _chk(self.L, self.L.sc_hip_kyber_kem_encaps(self.h, batch, _ptr(m), _ptr(ct), self.ct_bytes, _ptr(keys), _stream()), 'kyber_kem_encaps')
+        return ct, keys
+
+    def decaps(self, ct):
+        import torch
+        batch = ct.shape[0]
+        keys = torch.empty((batch, 32), dtype=torch.uint8, device=ct.device)
+        _chk(self.L, self.L.sc_hip_kyber_kem_decaps(self.h, batch, _ptr(ct), _rows(ct), _ptr(keys), _stream()), 'kyber_kem_decaps')
+        return keys
 
     def enc(self, m, noise):
         """m uint8 [batch][32], noise uint8 [batch][stride >= noise_bytes] (device) -> u int32 [batch][k][n], v int32 [batch][n]"""

@@ -60,3 +60,46 @@ def test_batch_vs_oracle_and_roundtrip(eng):
         assert np.array_equal(u[i].cpu().numpy().reshape(-1), eu) and np.array_equal(v[i].cpu().numpy(), ev)
         assert np.array_equal(O.kyber_dec(G['kyber1_params'], G['kyber1_s_ntt'], eu, ev), mh[i])
     ky.close()
+
+
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+def test_kem_vs_reference(eng, tag, nmsg):
+    """safecrypto_encapsulation / safecrypto_decapsulation on the device: G hash, DRBG oracle bytes and noise, CPA encryption,
+    H hash, packing - the reference's ciphertext bytes and shared keys for the same key pair and m"""
+    import torch
+    G = load_golden('kyber_ref.txt')
+    ky = make(eng, G, tag)
+    ky.set_kem_pubkey(G[f'{tag}_t'], G[f'{tag}_rho'])
+    u8 = lambda a: np.asarray(a, dtype=np.uint8)
+    m = np.stack([u8(G[f'{tag}_kem_m{i}']) for i in range(nmsg)])
+    ct, keys = ky.encaps(torch.from_numpy(m).cuda())
+    cth, kh = ct.cpu().numpy(), keys.cpu().numpy()
+    for i in range(nmsg):
+        assert cth[i].tobytes() == u8(G[f'{tag}_kem_ct{i}']).tobytes(), (tag, i)
+        assert kh[i].tobytes() == u8(G[f'{tag}_kem_key{i}']).tobytes(), (tag, i)
+    dk = ky.decaps(ct).cpu().numpy()
+    assert np.array_equal(dk, kh)
+    bad = ct.clone(); bad[:, ky.ct_bytes // 2] ^= 0x20
+    dkb = ky.decaps(bad).cpu().numpy()
+    for i in range(nmsg):
+        assert dkb[i].tobytes() == u8(G[f'{tag}_kem_decbad{i}']).tobytes(), (tag, i)
+    ky.close()
+
+
+def test_kem_batch_vs_oracle(eng):
+    import torch
+    G = load_golden('kyber_ref.txt')
+    tag = 'kyber1'
+    ky = make(eng, G, tag)
+    ky.set_kem_pubkey(G[f'{tag}_t'], G[f'{tag}_rho'])
+    rng = np.random.default_rng(8)
+    B = 333
+    m = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    ct, keys = ky.encaps(torch.from_numpy(m).cuda())
+    dk = ky.decaps(ct)
+    assert torch.equal(dk, keys)
+    cth, kh = ct.cpu().numpy(), keys.cpu().numpy()
+    for i in (0, 63, 64, 200, 332):
+        oc, ok = O.kyber_kem_enc(G[f'{tag}_params'], G[f'{tag}_t'], G[f'{tag}_t_ntt'], G[f'{tag}_rho'], G[f'{tag}_Agen'], m[i])
+        assert cth[i].tobytes() == oc and kh[i].tobytes() == ok, i
+    ky.close()
