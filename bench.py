@@ -169,6 +169,25 @@ def bliss_kyber_extra(eng, torch):
     assert torch.equal(mm, m)
     out['kyber_1_cpa'] = {'workload': 'Kyber set 1 (k=3, q=7681) CPA encryption / decryption, batch 65536, one key', 'enc_ops_per_s': B / min(te),
                           'dec_ops_per_s': B / min(td)}
+    # KEM level: safecrypto_encapsulation / safecrypto_decapsulation entirely on the device (hashes, DRBG, CPA, packing)
+    ky.set_kem_pubkey(G['kyber1_t'], G['kyber1_rho'])
+    ct, keys = ky.encaps(m); torch.cuda.synchronize()
+    te, td = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); ct, keys = ky.encaps(m); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); k2 = ky.decaps(ct); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+    assert torch.equal(k2, keys)
+    kem = {'workload': 'Kyber set 1 KEM encapsulation / decapsulation (reference wire format), batch 65536, one key, 32-byte m per operation resident in HBM',
+           'encaps_ops_per_s': B / min(te), 'decaps_ops_per_s': B / min(td)}
+    drv = os.path.join(ROOT, 'oracle', '_ref', 'ref_driver')
+    if os.path.exists(drv):
+        try:
+            r = json.loads(subprocess.check_output([drv, 'bench_kyber', '1', '3'], timeout=60, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            kem['cpu_reference'] = {'encaps_ops_per_s': r['encaps_per_sec'], 'decaps_ops_per_s': r['decaps_per_sec'], 'cores': 1, 'kind': 'reference',
+                                    'sample': '3 s of safecrypto_encapsulation + 1.5 s of safecrypto_decapsulation, set 1, one key, 1 thread'}
+        except Exception as e:
+            sys.stderr.write(f'kyber cpu baseline failed: {e}\n')
+    out['kyber_1_kem'] = kem
     ky.close()
     return out
 

@@ -10,6 +10,7 @@
  *
  * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
+ *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
@@ -784,8 +785,36 @@ static int bench_sig(sc_scheme_e scheme, int set, double seconds)
     return 0;
 }
 
+static int bench_kem(int set, double seconds)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+    if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    enum { POOL = 64 };
+    UINT8 *ct[POOL], *key[POOL]; size_t ctlen[POOL], keylen[POOL];
+    memset(ct, 0, sizeof ct); memset(key, 0, sizeof key);
+    uint64_t nenc = 0, ndec = 0;
+    double t0 = now_s(), t1;
+    do {
+        for (int i = 0; i < POOL; i++) {
+            free(ct[i]); free(key[i]); ct[i] = key[i] = NULL; ctlen[i] = keylen[i] = 0;
+            if (SC_FUNC_SUCCESS != safecrypto_encapsulation(sc, &ct[i], &ctlen[i], &key[i], &keylen[i])) return 1;
+        }
+        nenc += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds);
+    const double te = t1 - t0;
+    t0 = now_s();
+    do {
+        for (int i = 0; i < POOL; i++) { UINT8 *k2 = NULL; size_t k2len = 0; if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, ct[i], ctlen[i], &k2, &k2len)) return 1; free(k2); }
+        ndec += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds / 2);
+    printf("{\"set\": %d, \"encaps_per_sec\": %.1f, \"decaps_per_sec\": %.1f, \"encaps\": %llu}\n", set, nenc / te, ndec / (t1 - t0), (unsigned long long)nenc);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "bench_kyber")) return bench_kem(atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_sig(SC_SCHEME_SIG_DILITHIUM, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
