@@ -207,6 +207,13 @@ int sc_hip_drbg_mem(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, siz
 int sc_hip_drbg_words(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
                       uint32_t *d_out, size_t out_stride_words, size_t nwords, void *stream);
 
+/* replaces: the npoly calls of uniform_random_ring_q_csprng on create_csprng(sc, rho, rho_len) (src/utils/arith/module_lwe.c:519-547,
+ * n = 256) with which Kyber and Dilithium expand their public matrices: d_out int32 [nkeys][npoly][256] in generation order -
+ * the `Agen` / `Ahat` argument of sc_hip_kyber_set_pubkey / sc_hip_dilithium_set_*key, one 32-byte seed per key instead of
+ * npoly KB.  (As in the reference the entries are 16-bit draws masked to q_bits, minus q when >= q.) */
+int sc_hip_mlwe_expand_matrix(sc_hip_ctx_t *ctx, size_t nkeys, const uint8_t *d_rho, size_t rho_stride, size_t rho_len, int npoly, int32_t q, int q_bits,
+                              int32_t *d_out, void *stream);
+
 /* ---- BLISS-B: batched sign / verify under one key ------------------------------------------ */
 
 /* the fields of bliss_set_t the engine needs (src/schemes/sig/bliss_b/bliss_params.h:43-75, values

@@ -93,6 +93,31 @@ __global__ __launch_bounds__(256) void drbg_expand_kernel(uint32_t batch, const 
     }
 }
 
+// uniform_random_ring_q_csprng (src/utils/arith/module_lwe.c:519-547, n = 256) for polynomial p of key i: the p-th prng_mem(512)
+// of the generator seeded with rho_i -> 256 little-endian 16-bit words, masked to q_bits, minus q when >= q.  One lane per
+// (key, polynomial): CTR mode lets every lane start at its own block after its own key schedule.
+__global__ __launch_bounds__(256) void drbg_matrix_kernel(uint32_t nkeys, uint32_t npoly, const uint8_t *__restrict__ rho, size_t rho_stride, uint32_t rho_len,
+                                                          int32_t *__restrict__ out, int32_t q, uint32_t mask, DrbgConst C)
+{
+    __shared__ AesLds L;
+    L.fill(C);
+    __syncthreads();
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nkeys * npoly) return;
+    const uint32_t key = t / npoly, p = t % npoly;
+    Drbg d;
+    d.init(rho + (size_t)key * rho_stride, rho_len, C, L);
+    d.counter += p * 32;                                               // 512 bytes = 32 blocks per polynomial
+    int4 *o = reinterpret_cast<int4 *>(out + (size_t)t * 256);
+    for (int b = 0; b < 32; b++) {
+        uint32_t w[4]; int32_t a[8];
+        d.block(w, L);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { int32_t v = (int32_t)(((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu) & mask); v -= (v >= q) ? q : 0; a[j] = v; }
+        o[2 * b] = make_int4(a[0], a[1], a[2], a[3]); o[2 * b + 1] = make_int4(a[4], a[5], a[6], a[7]);
+    }
+}
+
 int run_expand(sc_hip_ctx *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, void *d_out, size_t out_stride, size_t nbytes, int words,
                void *stream, const char *who)
 {
@@ -119,3 +144,21 @@ extern "C" int sc_hip_drbg_mem(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d
 extern "C" int sc_hip_drbg_words(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
                                  uint32_t *d_out, size_t out_stride_words, size_t nwords, void *stream)
 { return run_expand(ctx, batch, d_seeds, seed_stride, seed_len, d_out, out_stride_words * 4, nwords * 4, 1, stream, "drbg_words"); }
+
+// replaces: the npoly calls of uniform_random_ring_q_csprng(create_csprng(sc, rho, rho_len), ...) with which the schemes expand
+// their public matrices (module_lwe.c:519-547; kyber_kem.c / dilithium.c key generation and create_rand_product_*_csprng), n = 256
+extern "C" int sc_hip_mlwe_expand_matrix(sc_hip_ctx_t *ctx, size_t nkeys, const uint8_t *d_rho, size_t rho_stride, size_t rho_len, int npoly, int32_t q, int q_bits,
+                                         int32_t *d_out, void *stream)
+{
+    if (!ctx) return fail("mlwe_expand_matrix: null context");
+    if (nkeys == 0 || npoly == 0) return SC_HIP_SUCCESS;
+    if (!d_rho || !d_out) return fail("mlwe_expand_matrix: null buffer");
+    if (rho_len == 0 || rho_len > rho_stride || npoly < 0 || q < 2 || q_bits < 1 || q_bits > 30) return fail("mlwe_expand_matrix: bad argument");
+    if (nkeys * (size_t)npoly > 0x7fffffffu || ((uintptr_t)d_out & 15) != 0) return fail("mlwe_expand_matrix: too large / misaligned output");
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t threads = nkeys * (size_t)npoly;
+    hipLaunchKernelGGL(drbg_matrix_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)nkeys, (uint32_t)npoly, d_rho, rho_stride,
+                       (uint32_t)rho_len, d_out, q, (1u << q_bits) - 1u, sc::drbg_const());
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}

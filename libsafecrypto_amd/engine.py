@@ -28,7 +28,7 @@ SYMBOLS = [
     'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
-    'sc_hip_drbg_mem', 'sc_hip_drbg_words',
+    'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -147,6 +147,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_kyber_ct_bytes.restype = sz
     L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.sc_hip_mlwe_expand_matrix.argtypes = [vp, sz, vp, sz, sz, C.c_int, i32, C.c_int, vp, vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -249,6 +250,13 @@ class Engine:
         import torch
         out = torch.empty((seeds.shape[0], nbytes), dtype=torch.uint8, device=seeds.device)
         _chk(self.L, self.L.sc_hip_drbg_mem(self.h, seeds.shape[0], _ptr(seeds), _rows(seeds), seeds.shape[1], _ptr(out), nbytes, nbytes, _stream()), 'drbg_mem')
+        return out
+
+    def expand_matrix(self, rho, npoly, q, q_bits):
+        """rho uint8 [nkeys][len] (device) -> int32 [nkeys][npoly][256]: the matrix polynomials in generation order"""
+        import torch
+        out = torch.empty((rho.shape[0], npoly, 256), dtype=torch.int32, device=rho.device)
+        _chk(self.L, self.L.sc_hip_mlwe_expand_matrix(self.h, rho.shape[0], _ptr(rho), _rows(rho), rho.shape[1], npoly, int(q), int(q_bits), _ptr(out), _stream()), 'mlwe_expand_matrix')
         return out
 
     def drbg_words(self, seeds, nwords):

@@ -55,3 +55,24 @@ def test_batch_vs_oracle(eng):
     for i in (0, 1, 63, 64, 255, 256, 699):
         d = O.Drbg(seeds[i].tobytes()); assert d.mem(1792) == out[i].tobytes(); d.close()
         d = O.Drbg(seeds[i].tobytes()); assert [d.u32() for _ in range(64)] == words[i].tolist(); d.close()
+
+
+def test_matrix_expansion_matches_reference(eng):
+    """the public matrices of the Kyber and Dilithium fixtures, regenerated on the device from the 32-byte rho"""
+    import torch
+    K = load_golden('kyber_ref.txt')
+    D = load_golden('dilithium_ref.txt')
+    for tag in ('kyber1', 'kyber2'):
+        par = K[f'{tag}_params']
+        k = int(par[5])
+        rho = torch.from_numpy(np.asarray(K[f'{tag}_rho'], dtype=np.uint8)[None, :].copy()).cuda()
+        A = eng.expand_matrix(rho, k * k, int(par[1]), int(par[2])).cpu().numpy().reshape(-1)
+        assert np.array_equal(A, np.asarray(K[f'{tag}_Agen'], dtype=np.int32)), tag
+    tags = sorted({n.split('_')[0] for n in D if n.endswith('_Ahat')})
+    assert tags
+    rhos = np.stack([np.asarray(D[f'{t}_rho'], dtype=np.uint8) for t in tags])
+    for i, t in enumerate(tags):
+        par = D[f'{t}_params']
+        npoly = int(par[3]) * int(par[4])
+        A = eng.expand_matrix(torch.from_numpy(rhos).cuda(), npoly, int(par[1]), int(par[2])).cpu().numpy()
+        assert np.array_equal(A[i].reshape(-1), np.asarray(D[f'{t}_Ahat'], dtype=np.int32)), t
