@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
@@ -533,6 +533,78 @@ static int gen_kyber(const char *dir)
     return rc;
 }
 
+/* ------------------------------------------------------------- ring-TESLA ---- */
+#include "schemes/sig/ring_tesla/ring_tesla.h"
+#include "schemes/sig/ring_tesla/ring_tesla_params.h"
+
+/* ring_tesla_sign (src/schemes/sig/ring_tesla/ring_tesla.c:752-910) draws n prng_32 words per attempt from sc->prng_ctx[0];
+ * same tape technique as BLISS.  The public polynomials a1, a2 are constants of the reference (ring_tesla_params.h:85-88) and
+ * travel as data. */
+static int tesla_case(FILE *f, int set, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "tesla%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_RING_TESLA, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const ring_tesla_set_t *P = sc->ring_tesla->params;
+    const int n = P->n;
+    int32_t par[12] = { (int32_t)P->n, (int32_t)P->n_bits, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->b, (int32_t)P->b_bits, (int32_t)P->omega, (int32_t)P->d,
+                        (int32_t)P->bound, (int32_t)P->u, set, 0 };
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 12);
+    snprintf(name, sizeof name, "%s_a1", tag); rec_i32(f, name, set == 0 ? a1_0 : a1_1, n);
+    snprintf(name, sizeof name, "%s_a2", tag); rec_i32(f, name, set == 0 ? a2_0 : a2_1, n);
+    snprintf(name, sizeof name, "%s_s", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+    snprintf(name, sizeof name, "%s_e1", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key + n, n);
+    snprintf(name, sizeof name, "%s_e2", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key + 2 * n, n);
+    snprintf(name, sizeof name, "%s_t1", tag); rec_i32(f, name, (const int32_t *)sc->pubkey->key, n);
+    snprintf(name, sizeof name, "%s_t2", tag); rec_i32(f, name, (const int32_t *)sc->pubkey->key + n, n);
+    int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0x7e51a000ULL + set;
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t msg[150], seed[32];
+        size_t mlen = (m == 0) ? 1 : (m == 1) ? 150 : 40;
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *sig = NULL; size_t siglen = 0;
+        size_t before = sc->stats.sig_num_trials;
+        if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        trials[m] = (int)(sc->stats.sig_num_trials - before);
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+        verdicts[2 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        sig[siglen / 3] ^= 0x08;
+        verdicts[2 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        free(tape); free(sig);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    snprintf(name, sizeof name, "%s_trials", tag); rec_i32(f, name, trials, nmsg);
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
+    free(trials); free(verdicts);
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_tesla(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/tesla_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = tesla_case(f, 0, 8);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -818,8 +890,9 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_sig(SC_SCHEME_SIG_DILITHIUM, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
@@ -829,5 +902,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
     if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);
     if (all || !strcmp(argv[1], "drbg")) rc |= gen_drbg(argv[2]);
+    if (all || !strcmp(argv[1], "tesla")) rc |= gen_tesla(argv[2]);
     return rc;
 }

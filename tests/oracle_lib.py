@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -86,6 +86,11 @@ def lib():
         L.orc_drbg_64.restype = C.c_uint64
         L.orc_drbg_64.argtypes = [C.c_void_p]
         L.orc_aes256_ecb.argtypes = [u8p, u8p, u8p]
+        L.orc_tesla_sig_bytes.restype = C.c_size_t
+        L.orc_tesla_sig_bytes.argtypes = [i32p]
+        L.orc_tesla_sign.argtypes = [i32p, i32p, i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
+                                     C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
+        L.orc_tesla_verify.argtypes = [i32p, i32p, i32p, i32p, i32p, u8p, C.c_size_t, u8p, C.c_size_t]
         f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
         f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
         L.orc_falcon_gm.restype = C.POINTER(C.c_double)
@@ -333,3 +338,34 @@ def kyber_kem_dec(par, s_ntt, t, t_ntt, rho, Agen, ct):
     c = np.ascontiguousarray(np.frombuffer(bytes(ct), dtype=np.uint8))
     assert lib().orc_kyber_kem_dec(f(par, np.int32), f(s_ntt, np.int32), f(t, np.int32), f(t_ntt, np.int32), f(rho, np.uint8), f(Agen, np.int32), c, key) == 0
     return bytes(key)
+
+
+class TeslaKey:
+    """ring-TESLA key pair + the reference's public constants, as the fixture provides them"""
+
+    def __init__(self, par, a1, a2, s, e1, e2, t1, t2):
+        f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+        self.par = f(par, np.int32)
+        self.a1, self.a2, self.t1, self.t2 = (f(x, np.int32) for x in (a1, a2, t1, t2))
+        self.s, self.e1, self.e2 = (f(x, np.int16) for x in (s, e1, e2))
+        self.n, self.q = int(par[0]), int(par[2])
+        self.sig_bytes = lib().orc_tesla_sig_bytes(self.par)
+
+    @classmethod
+    def from_golden(cls, G, tag):
+        return cls(*(G[f'{tag}_{x}'] for x in ('params', 'a1', 'a2', 's', 'e1', 'e2', 't1', 't2')))
+
+
+def tesla_sign(key, msg, tape):
+    sig = np.zeros(key.sig_bytes + 8, dtype=np.uint8)
+    sl, tr, used = C.c_size_t(0), C.c_int32(0), C.c_size_t(0)
+    m, ml = _msgbuf(msg)
+    tp = _tape(tape)
+    rc = lib().orc_tesla_sign(key.par, key.a1, key.a2, key.s, key.e1, key.e2, m, ml, tp, tp.size, sig, C.byref(sl), C.byref(tr), C.byref(used))
+    return rc, bytes(sig[:sl.value]), tr.value, used.value
+
+
+def tesla_verify(key, msg, sig):
+    m, ml = _msgbuf(msg)
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    return lib().orc_tesla_verify(key.par, key.a1, key.a2, key.t1, key.t2, m, ml, s, s.size)
