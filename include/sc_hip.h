@@ -244,6 +244,32 @@ int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, si
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* ---- ring-TESLA: batched sign / verify under one key ---------------------------------------- */
+
+/* ring_tesla_set_t fields (src/schemes/sig/ring_tesla/ring_tesla_params.h:43-67, values ring_tesla_params.c:22-40; set 0) */
+typedef struct sc_hip_tesla_params {
+    int32_t n, n_bits, q, q_bits, b, b_bits, omega, d, bound, u, set, pad;
+} sc_hip_tesla_params_t;
+typedef struct sc_hip_tesla sc_hip_tesla_t;
+
+int  sc_hip_tesla_create(sc_hip_ctx_t *ctx, const sc_hip_tesla_params_t *params, sc_hip_tesla_t **h);
+void sc_hip_tesla_destroy(sc_hip_tesla_t *h);
+/* a1, a2: the reference's public polynomials in the NTT domain (a1_0 / a2_0, ring_tesla_params.h:85-88); s, e1, e2: the private key
+ * as stored (SINT16[n] each, ring_tesla.c:703-730; NULLs for a verify-only handle); t1, t2: the public key (SINT32[n] each; NULLs
+ * for a sign-only handle) */
+int  sc_hip_tesla_set_key(sc_hip_tesla_t *h, const int32_t *a1, const int32_t *a2, const int16_t *s, const int16_t *e1, const int16_t *e2,
+                          const int32_t *t1, const int32_t *t2);
+size_t sc_hip_tesla_sig_bytes(const sc_hip_tesla_t *h);        /* n*q_bits/8 + 64 */
+/* replaces: safecrypto_sign -> ring_tesla_sign (src/schemes/sig/ring_tesla/ring_tesla.c:752-910) for `batch` messages; tapes as for
+ * BLISS (n CSPRNG pool words per attempt).  d_status[i]: 1 signed, 2 tape exhausted.  Signatures equal the reference's for the
+ * same words - including the behaviours of its oracle documented in csrc/tesla.hip. */
+int sc_hip_tesla_sign(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                      const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                      uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_verify -> ring_tesla_verify (ring_tesla.c:922-1040); d_verdicts[i] = 0 valid / 1 invalid */
+int sc_hip_tesla_verify(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                        const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 /* ---- Kyber (round 1, q = 7681): batched CPA encryption / decryption under one key ------------ */
 
 /* kyber_set_t fields (src/utils/arith/module_lwe.h:70-93, values kyber_kem_params.c:24-49; set 1: k = 3) */

@@ -1,0 +1,477 @@
+// tesla.hip - batched ring-TESLA sign / verify on MI355X behind the C ABI of include/sc_hip.h.
+//
+// Replaces, for a batch of messages under one key, ring_tesla_sign / ring_tesla_verify
+// (src/schemes/sig/ring_tesla/ring_tesla.c:752-910, 922-1040; raw signature coding) with test_w / test_rejection (:542-595) and
+// the random oracle of src/schemes/sig/ring_tesla/random_oracle.c: poly_rounding + SHA3-512 (the reference's permutation,
+// keccak_dev.h) over the big-endian words, the Salsa20-keyed stream (random_stream) and populate_c.
+//
+// Two behaviours of the reference are reproduced, not repaired: salsa20_core stores its result with SC_BIG_ENDIAN_32_COPY
+// (src/utils/crypto/salsa/salsa20.c:93), so every 32-bit word of the stream is byte-swapped relative to Salsa20; and
+// poly_rounding computes (p - modn(p)) >> d with modn over the ring modulus q, which is 0 for every centred or normalised
+// coefficient.  The rounding is still evaluated here as written; when it is 0 for a whole message - always, with the reference's
+// arithmetic - the hash resumes from the sponge state after the 56 whole all-zero blocks, kept per handle.
+//
+// Randomness: n prng_32 words of sc->prng_ctx[0] per attempt (ring_tesla.c:818-822); each message travels with its word tape
+// as for BLISS (or the tape is expanded on the device with sc_hip_drbg_words).  Mapping: y / products on the batched NTT kernels
+// (the public a1, a2 are NTT-domain constants of the reference, passed in as data), one lane per message for the hash and the
+// Salsa20 stream, one wavefront per message for the sparse products, the three tests and the packing.
+#include "engine_internal.h"
+#include "keccak_dev.h"
+
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+constexpr int HT = 64;
+
+struct TsP { int32_t n, n_bits, q, q_bits, b, b_bits, omega, d, bound, u, set, pad; };    // ring_tesla_set_t fields (ring_tesla_params.h:43-67)
+
+struct St { uint32_t *pos, *status; };
+
+// start of an attempt: n fresh words -> y = (word & (2^(b_bits+1) - 1)) - b   (ring_tesla.c:818-822)
+__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nact, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase,
+                                uint32_t *siglens, uint32_t *trials, int n)
+{
+    const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item];
+    if (pos + (uint32_t)n > len) { s.status[item] = 2; siglens[item] = 0; need[aidx] = 2; return; }     // tape exhausted
+    need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + (uint32_t)n; trials[item]++;
+}
+
+__global__ void ts_y_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aidx = (uint32_t)(t / P.n); const int i = (int)(t % P.n);
+    if (aidx >= nact) return;
+    if (need[aidx] != 1) { y[t] = 0; return; }
+    const uint32_t item = active ? active[aidx] : aidx;
+    y[t] = (int32_t)(tapes[(size_t)item * tape_stride + sbase[aidx] + i] & ((1u << (P.b_bits + 1)) - 1u)) - P.b;
+}
+
+__device__ __forceinline__ int32_t centre_q(int32_t x, int32_t q)   // ntt center_32 on a canonical value
+{ return x > ((q - 1) >> 1) ? x - q : x; }
+
+// poly_rounding (random_oracle.c:28-40) on both polynomials; cen != 0: the inputs are canonical and are centred first (signing
+// hashes centre(v), ring_tesla.c:843-849; verification hashes normalised w).  nz[aidx] = 1 if any rounded value is non-zero.
+__global__ __launch_bounds__(256) void ts_round_kernel(uint32_t nact, const int32_t *v1, const int32_t *v2, int32_t *r1, int32_t *r2, uint32_t *nz, int cen, TsP P)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (aidx >= nact) return;
+    uint32_t any = 0;
+    for (int i = lane; i < P.n; i += 64) {
+        const size_t k = (size_t)aidx * P.n + i;
+        const int32_t a = cen ? centre_q(v1[k], P.q) : v1[k], b = cen ? centre_q(v2[k], P.q) : v2[k];
+        const int32_t ra = (a - a % P.q) >> P.d, rb = (b - b % P.q) >> P.d;
+        r1[k] = ra; r2[k] = rb;
+        any |= (uint32_t)(ra | rb);
+    }
+    for (int o = 32; o > 0; o >>= 1) any |= (uint32_t)__shfl_xor((int)any, o);
+    if (lane == 0) nz[aidx] = any != 0;
+}
+
+// once per handle: the SHA3-512 sponge after `blocks` all-zero 72-byte blocks
+__global__ void ts_zero_prefix_kernel(uint32_t blocks, uint64_t *state)
+{
+    __shared__ uint64_t st[25 * HT];
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
+    if (threadIdx.x != 0) return;
+    for (uint32_t b = 0; b < blocks; b++) sp.permute();               // absorbing zeros leaves the state unchanged before each permutation
+    sp.save(state);
+}
+
+__device__ __forceinline__ uint32_t rotl(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+
+// oracle (random_oracle.c:42-66) then f_function (:162-176): md = SHA3-512(BE32(r1) | BE32(r2) | m); Salsa20 stream keyed with
+// md[0..32), nonce 1..8, 64-bit block counter, 800 bytes, each word stored byte-swapped (salsa20.c:93); omega distinct positions
+// from big-endian byte pairs.  mode 0 (sign): writes md and c.  mode 1 (verify): c comes from the signature's digest (sigmd) and
+// the recomputed md is compared with it.
+__global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+                                                       uint32_t fixed_len, const int32_t *r1, const int32_t *r2, const uint32_t *nz, const uint64_t *zstate, uint32_t zblocks,
+                                                       uint8_t *md_out, int mode, uint32_t *verdict, const uint8_t *sigs, size_t sig_stride, uint32_t md_off, TsP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
+    if (aidx >= nact) return;
+    if (need && need[aidx] == 2) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t mlen = mlens ? mlens[item] : fixed_len;
+    const int n = P.n;
+    if (nz[aidx] == 0) {
+        sp.load(st, threadIdx.x, 72, zstate);
+        for (uint32_t k = zblocks * 9; k < (uint32_t)n; k++) sp.absorb_u64(0);        // 8n zero bytes in all, zblocks*72 already in the state
+    } else {
+        for (int k = 0; k < 2; k++) {
+            const int32_t *r = (k ? r2 : r1) + (size_t)aidx * n;
+            for (int i = 0; i < n; i += 2) {
+                const uint32_t a = (uint32_t)r[i], b = (uint32_t)r[i + 1];
+                sp.absorb_u64((uint64_t)__builtin_bswap32(a) | ((uint64_t)__builtin_bswap32(b) << 32));
+            }
+        }
+    }
+    sp.absorb(msgs + (size_t)item * msg_stride, mlen);
+    sp.finalize(0x06);
+    uint8_t md[64];
+    for (int b = 0; b < 64; b++) md[b] = sp.squeeze_byte();
+    if (mode == 0) {
+        uint4 *o = reinterpret_cast<uint4 *>(md_out + (size_t)aidx * 64);
+        const uint4 *mi = reinterpret_cast<const uint4 *>(md);
+        for (int k = 0; k < 4; k++) o[k] = mi[k];
+    } else {
+        const uint8_t *sm = sigs + (size_t)item * sig_stride + md_off;
+        uint32_t neq = 0;
+        for (int b = 0; b < 64; b++) neq |= (uint32_t)(md[b] ^ sm[b]);
+        if (neq) verdict[item] = 1;
+    }
+}
+
+// f_function alone: c from a 64-byte digest (md rows for signing, the signature's digest for verification)
+__global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *md_rows, size_t md_stride, uint32_t md_off, int by_item,
+                                                  int32_t *cidx, TsP P)
+{
+    __shared__ uint32_t used[16 * HT];                                 // n <= 512 flags per lane, bit-packed
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    if (aidx >= nact) return;
+    if (need && need[aidx] == 2) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint8_t *md = md_rows + (size_t)(by_item ? item : aidx) * md_stride + md_off;
+    uint32_t key[8];
+    for (int w = 0; w < 8; w++) key[w] = (uint32_t)md[4 * w] | ((uint32_t)md[4 * w + 1] << 8) | ((uint32_t)md[4 * w + 2] << 16) | ((uint32_t)md[4 * w + 3] << 24);
+    uint32_t *fl = used + threadIdx.x;
+    for (int w = 0; w < 16; w++) fl[w * HT] = 0;
+    int cnt = 0;
+    for (uint32_t blk = 0; blk < 13 && cnt < P.omega; blk++) {           // 800 bytes = 12.5 blocks
+        const uint32_t in[16] = { 0x61707865u, key[0], key[1], key[2], key[3], 0x3320646eu, 0x04030201u, 0x08070605u, blk, 0u, 0x79622d32u, key[4], key[5], key[6], key[7], 0x6b206574u };
+        uint32_t x[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) x[i] = in[i];
+#pragma unroll 1
+        for (int rnd = 0; rnd < 10; rnd++) {
+            x[ 4] ^= rotl(x[ 0] + x[12],  7); x[ 8] ^= rotl(x[ 4] + x[ 0],  9); x[12] ^= rotl(x[ 8] + x[ 4], 13); x[ 0] ^= rotl(x[12] + x[ 8], 18);
+            x[ 9] ^= rotl(x[ 5] + x[ 1],  7); x[13] ^= rotl(x[ 9] + x[ 5],  9); x[ 1] ^= rotl(x[13] + x[ 9], 13); x[ 5] ^= rotl(x[ 1] + x[13], 18);
+            x[14] ^= rotl(x[10] + x[ 6],  7); x[ 2] ^= rotl(x[14] + x[10],  9); x[ 6] ^= rotl(x[ 2] + x[14], 13); x[10] ^= rotl(x[ 6] + x[ 2], 18);
+            x[ 3] ^= rotl(x[15] + x[11],  7); x[ 7] ^= rotl(x[ 3] + x[15],  9); x[11] ^= rotl(x[ 7] + x[ 3], 13); x[15] ^= rotl(x[11] + x[ 7], 18);
+            x[ 1] ^= rotl(x[ 0] + x[ 3],  7); x[ 2] ^= rotl(x[ 1] + x[ 0],  9); x[ 3] ^= rotl(x[ 2] + x[ 1], 13); x[ 0] ^= rotl(x[ 3] + x[ 2], 18);
+            x[ 6] ^= rotl(x[ 5] + x[ 4],  7); x[ 7] ^= rotl(x[ 6] + x[ 5],  9); x[ 4] ^= rotl(x[ 7] + x[ 6], 13); x[ 5] ^= rotl(x[ 4] + x[ 7], 18);
+            x[11] ^= rotl(x[10] + x[ 9],  7); x[ 8] ^= rotl(x[11] + x[10],  9); x[ 9] ^= rotl(x[ 8] + x[11], 13); x[10] ^= rotl(x[ 9] + x[ 8], 18);
+            x[12] ^= rotl(x[15] + x[14],  7); x[13] ^= rotl(x[12] + x[15],  9); x[14] ^= rotl(x[13] + x[12], 13); x[15] ^= rotl(x[14] + x[13], 18);
+        }
+        const int words = (blk == 12) ? 8 : 16;                           // the last block contributes 32 bytes
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (i < words && cnt < P.omega) {
+                const uint32_t v = x[i] + in[i];                          // stream bytes of this word, in order: v>>24, v>>16, v>>8, v
+                for (int h = 0; h < 2 && cnt < P.omega; h++) {
+                    const int pos = (int)((h ? v : (v >> 16)) & 0xFFFFu) & (P.n - 1);
+                    const uint32_t bit = 1u << (pos & 31), wv = fl[(pos >> 5) * HT];
+                    if (!(wv & bit)) { fl[(pos >> 5) * HT] = wv | bit; cidx[(size_t)aidx * P.omega + cnt] = pos; cnt++; }
+                }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int32_t wave_or(int32_t v) { for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o); return v; }
+
+// mul_32_sparse[_16] on coefficient j (ntt.c:381-422): sum_k (j < pos_k ? t[j + n - pos_k] : -t[j - pos_k])
+template <typename T>
+__device__ __forceinline__ int32_t sparse_at(const T *t, const int32_t *c, int omega, int n, int j)
+{
+    int32_t acc = 0;
+    for (int k = 0; k < omega; k++) { const int p = c[k]; acc += (j < p) ? (int32_t)t[j + n - p] : -(int32_t)t[j - p]; }
+    return acc;
+}
+
+__device__ __forceinline__ int32_t norm_q(int32_t x, int32_t q) { int32_t r = x % q; return r < 0 ? r + q : r; }     // normalize_32
+
+// test_w (ring_tesla.c:542-578) on a normalised value
+__device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
+{
+    const int32_t d_sub = 1 << (P.d - 1);
+    int32_t left = (val & ((1 << P.d) - 1)) - d_sub + 1;
+    if (left < 0) left = -left;
+    return left > d_sub - P.bound;
+}
+
+// one wavefront per message (ring_tesla.c:852-900): w1 = v1 - e1*c, w2 = v2 - e2*c normalised and tested, z = y + s*c centred and
+// tested, packing.  v1, v2 are canonical products; the key polynomials sit in LDS.
+__global__ __launch_bounds__(256) void ts_decide_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, St s, const int16_t *key, const int32_t *v1, const int32_t *v2,
+                                                        const int32_t *y, const int32_t *cidx, const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens,
+                                                        uint32_t *next_active, uint32_t *next_count, TsP P)
+{
+    extern __shared__ int16_t ks[];                                    // s | e1 | e2
+    const int n = P.n;
+    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) ks[i] = key[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (aidx >= nact) return;
+    if (need[aidx] == 2) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const int32_t *c = cidx + (size_t)aidx * P.omega;
+    int32_t bad = 0;
+    for (int j = lane; j < n; j += 64) {
+        const size_t k = (size_t)aidx * n + j;
+        const int32_t a = norm_q(centre_q(v1[k], P.q) - sparse_at(ks + n, c, P.omega, n, j), P.q);
+        const int32_t b = norm_q(centre_q(v2[k], P.q) - sparse_at(ks + 2 * n, c, P.omega, n, j), P.q);
+        bad |= (w_bad(a, P) || w_bad(b, P)) ? 1 : 0;
+    }
+    bad = wave_or(bad);
+    const int32_t th = P.b - P.u;
+    uint8_t *out = sigs + (size_t)item * sig_stride;
+    if (!bad) {
+        for (int j = lane; j < n; j += 64) {
+            const int32_t z = centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
+            bad |= (z < -th || z > th) ? 1 : 0;
+        }
+        bad = wave_or(bad);
+    }
+    if (bad) {
+        if (lane == 0) next_active[atomicAdd(next_count, 1u)] = item;
+        return;
+    }
+    // z: q_bits-bit two's complement, MSB first (q_bits = 24 for set 0: three bytes per coefficient), then the digest
+    if (P.q_bits == 24) {
+        for (int j = lane; j < n; j += 64) {
+            const uint32_t z = (uint32_t)centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
+            out[3 * j] = (uint8_t)(z >> 16); out[3 * j + 1] = (uint8_t)(z >> 8); out[3 * j + 2] = (uint8_t)z;
+        }
+    } else if (lane == 0) {
+        uint64_t acc = 0; int nb = 0; uint32_t w = 0;
+        for (int j = 0; j < n; j++) {
+            const uint32_t z = (uint32_t)centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
+            acc = (acc << P.q_bits) | (z & ((1u << P.q_bits) - 1u)); nb += P.q_bits;
+            while (nb >= 8) { out[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+        }
+        if (nb) out[w++] = (uint8_t)(acc << (8 - nb));
+    }
+    const uint32_t zb = ((uint32_t)n * P.q_bits + 7) / 8;
+    out[zb + lane] = md[(size_t)aidx * 64 + lane];
+    if (lane == 0) { siglens[item] = zb + 64; s.status[item] = 1; }
+}
+
+// ---- verify ---------------------------------------------------------------------------------------------------------------
+
+// z from the signature (ring_tesla.c:984-996) + test_rejection; one wavefront per signature
+__global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int32_t *z, uint32_t *verdict, TsP P)
+{
+    const int lane = threadIdx.x & 63, n = P.n;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= batch) return;
+    const uint32_t zb = ((uint32_t)n * P.q_bits + 7) / 8;
+    if (siglens[item] < zb + 64) { for (int j = lane; j < n; j += 64) z[(size_t)item * n + j] = 0; if (lane == 0) verdict[item] = 1; return; }
+    const uint8_t *s = sigs + (size_t)item * sig_stride;
+    const int32_t th = P.b - P.u;
+    int32_t bad = 0;
+    for (int j = lane; j < n; j += 64) {
+        uint32_t val = 0;
+        for (int b = 0; b < P.q_bits; b++) { const uint32_t bp = (uint32_t)j * P.q_bits + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+        const int32_t zz = (int32_t)(val << (32 - P.q_bits)) >> (32 - P.q_bits);
+        z[(size_t)item * n + j] = zz;
+        bad |= (zz < -th || zz > th) ? 1 : 0;
+    }
+    bad = wave_or(bad);
+    if (bad && lane == 0) verdict[item] = 1;
+}
+
+// w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products
+__global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *t1, const int32_t *t2, const int32_t *cidx, TsP P)
+{
+    const int lane = threadIdx.x & 63, n = P.n;
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= batch) return;
+    const int32_t *c = cidx + (size_t)item * P.omega;
+    for (int j = lane; j < n; j += 64) {
+        const size_t k = (size_t)item * n + j;
+        w1[k] = norm_q(w1[k] - sparse_at(t1, c, P.omega, n, j), P.q);
+        w2[k] = norm_q(w2[k] - sparse_at(t2, c, P.omega, n, j), P.q);
+    }
+}
+
+}  // namespace
+
+struct sc_hip_tesla {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    TsP P;
+    bool have_priv, have_pub;
+    int32_t *d_a1, *d_a2, *d_t1, *d_t2;
+    int16_t *d_key;                      // s | e1 | e2
+    uint64_t *d_zstate; uint32_t zblocks;
+    size_t cap;
+    St st;
+    uint32_t *act[2], *cnt, *need, *sbase, *nz, *trials;
+    int32_t *y, *v1, *v2, *r1, *r2, *cidx;
+    uint8_t *md;
+};
+
+static void ts_free_ws(sc_hip_tesla *t)
+{
+    void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->need, t->sbase, t->nz, t->trials, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->md };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->need = t->sbase = t->nz = t->trials = nullptr;
+    t->y = t->v1 = t->v2 = t->r1 = t->r2 = t->cidx = nullptr; t->md = nullptr; t->cap = 0;
+}
+
+static int ts_ensure_ws(sc_hip_tesla *t, size_t batch)
+{
+    if (batch <= t->cap) return SC_HIP_SUCCESS;
+    ts_free_ws(t);
+    const size_t n = t->P.n;
+#define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
+    WS(t->st.pos, batch * 4); WS(t->st.status, batch * 4); WS(t->act[0], batch * 4); WS(t->act[1], batch * 4); WS(t->cnt, 64); WS(t->need, batch * 4); WS(t->sbase, batch * 4);
+    WS(t->nz, batch * 4); WS(t->trials, batch * 4);
+    WS(t->y, batch * n * 4); WS(t->v1, batch * n * 4); WS(t->v2, batch * n * 4); WS(t->r1, batch * n * 4); WS(t->r2, batch * n * 4);
+    WS(t->cidx, batch * (size_t)t->P.omega * 4); WS(t->md, batch * 64);
+#undef WS
+    t->cap = batch;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_tesla_create(sc_hip_ctx_t *ctx, const sc_hip_tesla_params_t *params, sc_hip_tesla_t **out)
+{
+    if (!ctx || !params || !out) return fail("tesla_create: null argument");
+    static_assert(sizeof(TsP) == sizeof(sc_hip_tesla_params_t), "parameter struct layout");
+    TsP P; memcpy(&P, params, sizeof P);
+    if (P.n != 512 || (1 << P.n_bits) != P.n) return fail("tesla_create: n must be 512");
+    if (P.omega < 1 || P.omega > 64 || P.d < 2 || P.d > 30 || P.q_bits < 8 || P.q_bits > 30 || P.b_bits < 1 || P.b_bits > 30 || P.q < 3) return fail("tesla_create: parameters out of range");
+    sc_hip_plan *plan = nullptr;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    HIPCHK(hipSetDevice(ctx->device));
+    sc_hip_tesla *t = new sc_hip_tesla;
+    memset(t, 0, sizeof *t);
+    t->ctx = ctx; t->plan = plan; t->P = P;
+    t->zblocks = (uint32_t)(8 * P.n / 72);
+    if (hipMalloc((void **)&t->d_zstate, 25 * 8) != hipSuccess) { sc_hip_tesla_destroy(t); return fail("tesla_create: device allocation failed"); }
+    hipLaunchKernelGGL(ts_zero_prefix_kernel, dim3(1), dim3(HT), 0, nullptr, t->zblocks, t->d_zstate);
+    if (hipDeviceSynchronize() != hipSuccess) { sc_hip_tesla_destroy(t); return fail("tesla_create: kernel failed"); }
+    *out = t;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_tesla_destroy(sc_hip_tesla_t *t)
+{
+    if (!t) return;
+    ts_free_ws(t);
+    void *ptrs[] = { t->d_a1, t->d_a2, t->d_t1, t->d_t2, t->d_key, t->d_zstate };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    sc_hip_plan_destroy(t->plan);
+    delete t;
+}
+
+static int ts_upload32(int32_t **dst, const int32_t *src, size_t n)
+{
+    if (!*dst) HIPCHK(hipMalloc((void **)dst, n * 4));
+    HIPCHK(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+    return SC_HIP_SUCCESS;
+}
+
+// a1, a2: the reference's public polynomials, NTT domain (a1_0 / a2_0, ring_tesla_params.h:85-88); s, e1, e2: the private key as
+// stored (SINT16 [3][n], ring_tesla.c:703-730; NULL for a verify-only handle); t1, t2: the public key (SINT32 [2][n]; NULL for sign-only)
+extern "C" int sc_hip_tesla_set_key(sc_hip_tesla_t *t, const int32_t *a1, const int32_t *a2, const int16_t *s, const int16_t *e1, const int16_t *e2,
+                                    const int32_t *t1, const int32_t *t2)
+{
+    if (!t || !a1 || !a2) return fail("tesla_set_key: null argument");
+    if ((s == nullptr) != (e1 == nullptr) || (s == nullptr) != (e2 == nullptr) || (t1 == nullptr) != (t2 == nullptr)) return fail("tesla_set_key: s, e1, e2 go together; t1, t2 go together");
+    HIPCHK(hipSetDevice(t->ctx->device));
+    const size_t n = t->P.n;
+    if (ts_upload32(&t->d_a1, a1, n) || ts_upload32(&t->d_a2, a2, n)) return SC_HIP_FAILURE;
+    if (s) {
+        if (!t->d_key) HIPCHK(hipMalloc((void **)&t->d_key, 3 * n * 2));
+        HIPCHK(hipMemcpy(t->d_key, s, n * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t->d_key + n, e1, n * 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t->d_key + 2 * n, e2, n * 2, hipMemcpyHostToDevice));
+        t->have_priv = true;
+    }
+    if (t1) {
+        if (ts_upload32(&t->d_t1, t1, n) || ts_upload32(&t->d_t2, t2, n)) return SC_HIP_FAILURE;
+        t->have_pub = true;
+    }
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_tesla_sig_bytes(const sc_hip_tesla_t *t)
+{ return t ? ((size_t)t->P.n * t->P.q_bits + 7) / 8 + 64 : 0; }
+
+extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                 const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                 uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!t) return fail("tesla_sign: null handle");
+    if (!t->have_priv) return fail("tesla_sign: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("tesla_sign: batch too large");
+    if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("tesla_sign: null buffer");
+    if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_sign: sig_stride smaller than sc_hip_tesla_sig_bytes()");
+    if (tape_stride > 0xffffffffu) return fail("tesla_sign: tape too long");
+    HIPCHK(hipSetDevice(t->ctx->device));
+    if (ts_ensure_ws(t, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const TsP &P = t->P;
+    const int n = P.n;
+    St st = t->st;
+    HIPCHK(hipMemsetAsync(st.pos, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.status, 0, batch * 4, s));
+    uint32_t *trials = d_trials ? d_trials : t->trials;
+    HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
+    uint32_t nact = (uint32_t)batch;
+    const uint32_t *active = nullptr;
+    for (uint32_t round = 0; nact > 0; round++) {
+        if (round >= 9999) break;                                       // the reference's own cap (ring_tesla.c:814); leftovers keep status 0
+        uint32_t *next = t->act[round & 1];
+        HIPCHK(hipMemsetAsync(t->cnt, 0, 4, s));
+        hipLaunchKernelGGL(ts_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, d_siglens, trials, n);
+        const size_t ne = (size_t)nact * n;
+        hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, t->need, t->sbase, d_tapes, tape_stride, t->y, P);
+        HIPCHK(hipGetLastError());
+        if (sc::polymul_ntt_bcast(t->plan, nact, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
+        if (sc::polymul_ntt_bcast(t->plan, nact, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(ts_round_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, nact, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P);
+        hipLaunchKernelGGL(ts_oracle_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
+                           t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P);
+        hipLaunchKernelGGL(ts_f_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P);
+        hipLaunchKernelGGL(ts_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, active, nact, t->need, st, t->d_key, t->v1, t->v2, t->y, t->cidx, t->md,
+                           d_sigs, sig_stride, d_siglens, next, t->cnt, P);
+        HIPCHK(hipGetLastError());
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, t->cnt, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nact = cnt;
+        active = next;
+    }
+    if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                   const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (!t) return fail("tesla_verify: null handle");
+    if (!t->have_pub) return fail("tesla_verify: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("tesla_verify: batch too large");
+    if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("tesla_verify: null buffer");
+    if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_verify: sig_stride smaller than sc_hip_tesla_sig_bytes()");
+    HIPCHK(hipSetDevice(t->ctx->device));
+    if (ts_ensure_ws(t, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const TsP &P = t->P;
+    const uint32_t B = (uint32_t)batch;
+    const uint32_t md_off = ((uint32_t)P.n * P.q_bits + 7) / 8;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    hipLaunchKernelGGL(ts_unpack_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, t->y, d_verdicts, P);
+    hipLaunchKernelGGL(ts_f_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_sigs, sig_stride, md_off, 1, t->cidx, P);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
+    if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P);
+    hipLaunchKernelGGL(ts_round_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->r1, t->r2, t->nz, 0, P);
+    hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
+                       t->d_zstate, t->zblocks, (uint8_t *)nullptr, 1, d_verdicts, d_sigs, sig_stride, md_off, P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}

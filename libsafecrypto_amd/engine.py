@@ -29,6 +29,7 @@ SYMBOLS = [
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
+    'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -147,6 +148,14 @@ def load_library(path=LIB_PATH):
     L.sc_hip_kyber_ct_bytes.restype = sz
     L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.sc_hip_tesla_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_tesla_destroy.argtypes = [vp]
+    L.sc_hip_tesla_destroy.restype = None
+    L.sc_hip_tesla_set_key.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sc_hip_tesla_sig_bytes.argtypes = [vp]
+    L.sc_hip_tesla_sig_bytes.restype = sz
+    L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_mlwe_expand_matrix.argtypes = [vp, sz, vp, sz, sz, C.c_int, i32, C.c_int, vp, vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
@@ -215,6 +224,9 @@ class Engine:
 
     def falcon(self, params):
         return Falcon(self, params)
+
+    def tesla(self, params):
+        return Tesla(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -615,6 +627,55 @@ class Bliss:
         verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
         _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
+        return verdicts
+
+
+class Tesla:
+    """Batched ring-TESLA sign / verify under one key (ring_tesla_sign / ring_tesla_verify counterpart).
+    params: the 12 words {n, n_bits, q, q_bits, b, b_bits, omega, d, bound, u, set, 0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 12
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_tesla_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_tesla_create')
+        self.h = h
+        self.n = int(self.par[0])
+        self.sig_bytes = self.L.sc_hip_tesla_sig_bytes(h)
+        self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_tesla_destroy(self.h)
+            self.h = None
+
+    def set_key(self, a1, a2, s=None, e1=None, e2=None, t1=None, t2=None):
+        import numpy as np
+        f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt) if a is not None else None
+        arrs = [f(a1, np.int32), f(a2, np.int32), f(s, np.int16), f(e1, np.int16), f(e2, np.int16), f(t1, np.int32), f(t2, np.int32)]
+        _chk(self.L, self.L.sc_hip_tesla_set_key(self.h, *[_ptr(a) if a is not None else C.c_void_p() for a in arrs]), 'tesla_set_key')
+
+    def sign(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        trials = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_tesla_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                              _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
+                                              _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'tesla_sign')
+        return sigs, siglens, trials, status
+
+    def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_tesla_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'tesla_verify')
         return verdicts
 
 

@@ -1,0 +1,99 @@
+"""GPU parity for batched ring-TESLA sign / verify (C ABI: sc_hip_tesla_*): byte-identical to signatures the reference produced
+from the same (key, message, CSPRNG word tape), and to the pinned oracle on seeded tapes."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from libsafecrypto_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('tesla_ref.txt')
+
+
+def u32(a):
+    return (np.asarray(a).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def pack(msgs, tapes, tape_words):
+    import torch
+    n = len(msgs)
+    stride = max(8, (max(len(m) for m in msgs) + 7) & ~7)
+    mb = np.zeros((n, stride), dtype=np.uint8)
+    for i, m in enumerate(msgs):
+        mb[i, :len(m)] = np.frombuffer(m, dtype=np.uint8)
+    tb = np.zeros((n, tape_words), dtype=np.uint32)
+    tl = np.zeros(n, dtype=np.int32)
+    for i, t in enumerate(tapes):
+        k = min(len(t), tape_words)
+        tb[i, :k] = t[:k]; tl[i] = k
+    return (torch.from_numpy(mb).cuda(), torch.from_numpy(np.array([len(m) for m in msgs], dtype=np.int32)).cuda(),
+            torch.from_numpy(tb.view(np.int32)).cuda(), torch.from_numpy(tl).cuda())
+
+
+def open_key(eng, G):
+    key = O.TeslaKey.from_golden(G, 'tesla0')
+    t = eng.tesla(key.par)
+    t.set_key(key.a1, key.a2, key.s, key.e1, key.e2, key.t1, key.t2)
+    return key, t
+
+
+def test_sign_verify_reproduce_reference(eng, G):
+    import torch
+    key, t = open_key(eng, G)
+    msgs = [bytes(np.asarray(G[f'tesla0_msg{m}'], dtype=np.uint8)) for m in range(8)]
+    tapes = [u32(G[f'tesla0_tape{m}']) for m in range(8)]
+    mb, ml, tb, tl = pack(msgs, tapes, 4096)
+    sigs, siglens, trials, status = t.sign(mb, tb, mlens=ml, tape_lens=tl)
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [1] * 8
+    assert trials.cpu().tolist() == [int(x) for x in G['tesla0_trials']]
+    sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
+    for m in range(8):
+        assert bytes(sh[m, :lh[m]]) == bytes(np.asarray(G[f'tesla0_sig{m}'], dtype=np.uint8)), m
+    assert t.verify(mb, sigs, siglens, mlens=ml).cpu().tolist() == [0] * 8
+    bad = sigs.clone(); bad[:, key.sig_bytes // 3] ^= 0x08                       # the fixture's tampering: still accepted by the reference
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [int(G['tesla0_verify'][2 * m + 1]) for m in range(8)] == [0] * 8
+    bad = sigs.clone(); bad[:, key.sig_bytes - 1] ^= 1                           # the digest
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    bad = sigs.clone(); bad[:, 0] ^= 0x40                                        # z[0] outside the rejection bound
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    mb2 = mb.clone(); mb2[:, 0] ^= 1
+    assert t.verify(mb2, sigs, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    t.close()
+
+
+def test_batch_vs_oracle_seeded_tapes(eng, G):
+    import torch
+    key, t = open_key(eng, G)
+    rng = np.random.default_rng(5)
+    B, W = 300, 12 * 512
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 90)), dtype=np.uint8)) for _ in range(B)]
+    tapes = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+    tapes[3] = tapes[3][:300]                                                   # not even one attempt
+    mb, ml, tb, tl = pack(msgs, tapes, W)
+    sigs, siglens, trials, status = t.sign(mb, tb, mlens=ml, tape_lens=tl)
+    torch.cuda.synchronize()
+    sh, lh, tr, st = sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy(), status.cpu().numpy()
+    assert st[3] == 2 and lh[3] == 0
+    for i in list(range(0, 30)) + [B - 1]:
+        rc, sig, otr, used = O.tesla_sign(key, msgs[i], tapes[i])
+        assert (rc, int(st[i])) in ((0, 1), (2, 2)), i
+        assert tr[i] == otr, i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == sig, i
+    ok = st == 1
+    v = t.verify(mb, sigs, siglens, mlens=ml).cpu().numpy()
+    assert np.array_equal(v[ok], np.zeros(ok.sum(), dtype=v.dtype)) and v[3] == 1
+    t.close()
