@@ -189,6 +189,31 @@ def bliss_kyber_extra(eng, torch):
             sys.stderr.write(f'kyber cpu baseline failed: {e}\n')
     out['kyber_1_kem'] = kem
     ky.close()
+    # ring-TESLA set 0 (n=512, q=8399873): the fourth scheme the north star names
+    G = load_golden('tesla_ref.txt')
+    ts = eng.tesla(G['tesla0_params'])
+    ts.set_key(*(G[f'tesla0_{x}'] for x in ('a1', 'a2', 's', 'e1', 'e2', 't1', 't2')))
+    B, W = 16384, 24 * 512
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, W), dtype=torch.int32, device='cuda', generator=g)
+    ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+    tsn, tvf = [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); sigs, siglens, trials, status = ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); tsn.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); v = ts.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tvf.append(time.perf_counter() - t0)
+    ok = status == 1
+    assert int(v[ok].sum()) == 0 and int(ok.sum()) > B - 20
+    rt = {'workload': 'ring-TESLA set 0 (n=512, q=8399873) sign / verify, batch 16384, 64-byte messages, per-message CSPRNG word tapes resident in HBM',
+          'sign_ops_per_s': B / min(tsn), 'verify_ops_per_s': B / min(tvf), 'mean_attempts_per_signature': float(trials[ok].float().mean())}
+    if os.path.exists(drv):
+        try:
+            r = json.loads(subprocess.check_output([drv, 'bench_tesla', '0', '3'], timeout=60, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            rt['cpu_reference'] = {'sign_ops_per_s': r['sign_per_sec'], 'verify_ops_per_s': r['verify_per_sec'], 'cores': 1, 'kind': 'reference',
+                                   'sample': '3 s of safecrypto_sign + 0.75 s of safecrypto_verify, set 0, 64-byte messages, one key, 1 thread'}
+        except Exception as e:
+            sys.stderr.write(f'ring-tesla cpu baseline failed: {e}\n')
+    out['ring_tesla_0'] = rt
+    ts.close()
     return out
 
 
