@@ -21,6 +21,7 @@
 #include "keccak_dev.h"
 #include "mlwe_kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 using namespace sc;
@@ -515,8 +516,14 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
     if (!d_sigs || !d_siglens) return fail("dilithium_sign: null output buffer");
     if (sig_stride < sc_hip_dilithium_sig_max(d)) return fail("dilithium_sign: sig_stride smaller than sc_hip_dilithium_sig_max()");
     HIPCHK(hipSetDevice(d->ctx->device));
-    // attempts evaluated side by side per round: 4 per message while the whole batch is active, more as it thins out
-    const size_t slot_target = batch * 4 > 4096 ? batch * 4 : 4096;
+    // Attempts evaluated side by side per round ("slots").  More slots per message mean fewer rounds (each round costs the latency
+    // of the lane-per-attempt hash kernels plus a host synchronisation) but more attempts thrown away after the first success.
+    // Measured on MI355X (tools/bench_dilithium.py, SC_HIP_DIL_SLOTS=1..8): about 48 K slots per round is the sweet spot - 8 per
+    // message for small batches, 3 at 16 K messages, 1 from 48 K messages up; as the batch thins out the same slots go deeper.
+    size_t slot_target = batch * 8 < 49152 ? batch * 8 : 49152;
+    if (slot_target < batch) slot_target = batch;
+    if (const char *e = getenv("SC_HIP_DIL_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 32) slot_target = batch * (size_t)v; }
+    if (slot_target < 4096) slot_target = 4096;
     if (ensure_ws(d, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const DilP &P = d->P;
