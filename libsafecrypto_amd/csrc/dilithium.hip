@@ -393,29 +393,28 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
 static int key_ntt(sc_hip_dilithium *d, const int32_t *h_polys, size_t npoly, uint32_t **dst)
 {
     const size_t bytes = npoly * N * 4;
-    int32_t *tmp = nullptr;
-    HIPCHK(hipMalloc((void **)&tmp, bytes));
+    DevBuf tb;
+    if (tb.get(bytes)) return SC_HIP_FAILURE;
+    int32_t *tmp = tb.as<int32_t>();
     if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
     HIPCHK(hipMemcpy(tmp, h_polys, bytes, hipMemcpyHostToDevice));
     DilNtt a = base_args(d);
     a.in = tmp; a.out_int = *dst;
     int rc = launch_dil<DOP_KEYPREP>(d, a, (uint32_t)npoly, 1, nullptr);
     if (rc == SC_HIP_SUCCESS && hipDeviceSynchronize() != hipSuccess) rc = fail("dilithium key load: kernel failed");
-    (void)hipFree(tmp);
     return rc;
 }
 
 static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
 {
     const size_t np = (size_t)d->P.k * d->P.l, bytes = np * N * 4;
-    int32_t *tmp = nullptr;
-    HIPCHK(hipMalloc((void **)&tmp, bytes));
+    DevBuf tb;
+    if (tb.get(bytes)) return SC_HIP_FAILURE;
+    int32_t *tmp = tb.as<int32_t>();
     if (!d->d_A) HIPCHK(hipMalloc((void **)&d->d_A, bytes));
     HIPCHK(hipMemcpy(tmp, h_Ahat, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, nullptr, tmp, d->d_A, np, d->plan->k[1], d->plan->r2, d->plan->r2p);
-    int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
-    (void)hipFree(tmp);
-    return rc;
+    return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
 }
 
 extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t *s1, const int32_t *s2, const int32_t *t,
@@ -450,12 +449,12 @@ extern "C" int sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *d, const int32_t 
     if (!d->d_rho) HIPCHK(hipMalloc((void **)&d->d_rho, 32));
     if (!d->d_tr_pub) HIPCHK(hipMalloc((void **)&d->d_tr_pub, 48));
     HIPCHK(hipMemcpy(d->d_rho, rho, 32, hipMemcpyHostToDevice));
-    int32_t *dt1 = nullptr;
-    HIPCHK(hipMalloc((void **)&dt1, t1s.size() * 4));
+    DevBuf t1b;
+    if (t1b.get(t1s.size() * 4)) return SC_HIP_FAILURE;
+    int32_t *dt1 = t1b.as<int32_t>();
     HIPCHK(hipMemcpy(dt1, t1, t1s.size() * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dil_crh_t1_kernel, dim3(1), dim3(HT), 0, nullptr, d->d_rho, dt1, (uint32_t)t1s.size(), d->P.q_bits - d->P.d, d->d_tr_pub);
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium_set_pubkey: CRH kernel failed");
-    (void)hipFree(dt1);
     d->have_pub = (rc == SC_HIP_SUCCESS);
     return rc;
 }
@@ -688,15 +687,14 @@ extern "C" int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, cons
     if (!ctx || !h_out || (len && !h_in)) return fail("shake_host: null argument");
     if (bits != 128 && bits != 256) return fail("shake_host: bits must be 128 or 256");
     HIPCHK(hipSetDevice(ctx->device));
-    uint8_t *din = nullptr, *dout = nullptr;
-    HIPCHK(hipMalloc((void **)&din, len + 8));
-    HIPCHK(hipMalloc((void **)&dout, outlen + 8));
+    DevBuf ib, ob;
+    if (ib.get(len + 8) || ob.get(outlen + 8)) return SC_HIP_FAILURE;
+    uint8_t *din = ib.as<uint8_t>(), *dout = ob.as<uint8_t>();
     if (len) HIPCHK(hipMemcpy(din, h_in, len, hipMemcpyHostToDevice));
     const int rate = 200 - 2 * bits / 8;
     if (standard) hipLaunchKernelGGL(shake_test_kernel<true>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
     else hipLaunchKernelGGL(shake_test_kernel<false>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("shake_host: kernel failed");
     if (rc == SC_HIP_SUCCESS) HIPCHK(hipMemcpy(h_out, dout, outlen, hipMemcpyDeviceToHost));
-    (void)hipFree(din); (void)hipFree(dout);
     return rc;
 }

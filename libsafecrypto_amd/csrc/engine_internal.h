@@ -11,6 +11,19 @@ namespace sc {
 int fail(const std::string &m);      // records the message for sc_hip_last_error, returns SC_HIP_FAILURE
 }
 
+namespace sc {
+// scoped device temporary (key loads, host-buffer variants): freed on every exit path
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? 0 : fail("device allocation failed"); }
+    template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+}
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \

@@ -259,15 +259,14 @@ extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
 static int ky_load(sc_hip_kyber *h, const int32_t *host, size_t npoly, uint32_t **dst, int rows, int cols)
 {
     const size_t bytes = npoly * N * 4;
-    int32_t *tmp = nullptr;
     HIPCHK(hipSetDevice(h->ctx->device));
-    HIPCHK(hipMalloc((void **)&tmp, bytes));
+    DevBuf tb;
+    if (tb.get(bytes)) return SC_HIP_FAILURE;
+    int32_t *tmp = tb.as<int32_t>();
     if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
     HIPCHK(hipMemcpy(tmp, host, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, nullptr, tmp, *dst, npoly, h->plan->k[1], h->plan->r2, h->plan->r2p, rows, cols);
-    int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber key load: kernel failed");
-    (void)hipFree(tmp);
-    return rc;
+    return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber key load: kernel failed");
 }
 
 // t_ntt: NTT(t) as the public key stores it (kyber_kem.c:636-650); Agen: the k*k matrix polynomials in the order the
@@ -377,8 +376,9 @@ extern "C" int sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, 
     std::vector<uint8_t> pre(len);
     memcpy(pre.data(), rho, 32);
     for (size_t i = 0; i < kn; i++) { pre[32 + 2 * i] = (uint8_t)(t[i] & 0xFF); pre[33 + 2 * i] = (uint8_t)(t[i] >> 8); }
-    uint8_t *d_pre = nullptr;
-    HIPCHK(hipMalloc((void **)&d_pre, len));
+    DevBuf pb;
+    if (pb.get(len)) return SC_HIP_FAILURE;
+    uint8_t *d_pre = pb.as<uint8_t>();
     if (!h->d_gstate) HIPCHK(hipMalloc((void **)&h->d_gstate, 25 * 8));
     if (h->d_gtail) { (void)hipFree(h->d_gtail); h->d_gtail = nullptr; }
     HIPCHK(hipMalloc((void **)&h->d_gtail, len - full + 8));
@@ -387,7 +387,6 @@ extern "C" int sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, 
     h->gtail_len = (uint32_t)(len - full);
     hipLaunchKernelGGL(ky_gprefix_kernel, dim3(1), dim3(KHT), 0, nullptr, d_pre, (uint32_t)full, h->d_gstate);
     const int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber_set_kem_pubkey: kernel failed");
-    (void)hipFree(d_pre);
     h->have_kem = rc == SC_HIP_SUCCESS;
     return rc;
 }

@@ -227,13 +227,6 @@ extern "C" int sc_hip_vec_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, cons
 { return run_reduce<RD_SCALAR>(ctx, batch, n, d_t, d_u, d_out, stream, "vec_scalar"); }
 
 // ---- host-buffer variants (H2D, kernel, D2H; synchronous) used by the reference-shaped vtable --------------------------------
-namespace {
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? SC_HIP_SUCCESS : fail("host op: device allocation failed"); }
-};
-}
 
 static int invert_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_v, const int32_t *h_den, int32_t *h_rc, const char *who)
 {
