@@ -15,7 +15,7 @@
 
 namespace sc {
 
-enum { MODE_U24 = 1, MODE_U32 = 2 };
+enum { MODE_U24 = 1, MODE_U32 = 2, MODE_MAD = 3 };
 
 // Per-modulus scalars, passed by value as kernel arguments (they end up in SGPRs).
 struct ModK {
@@ -32,7 +32,9 @@ struct ModK {
 // only sometimes selected as the 24-bit form.
 extern "C" __device__ uint32_t sc_llvm_mul_u24(uint32_t, uint32_t) __asm("llvm.amdgcn.mul.u24.i32");
 extern "C" __device__ uint32_t sc_llvm_mulhi_u24(uint32_t, uint32_t) __asm("llvm.amdgcn.mulhi.u24");
+extern "C" __device__ int32_t sc_llvm_mul_i24(int32_t, int32_t) __asm("llvm.amdgcn.mul.i24.i32");
 __device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) { return sc_llvm_mul_u24(a, b); }
+__device__ __forceinline__ int32_t mul_i24(int32_t a, int32_t b) { return sc_llvm_mul_i24(a, b); }
 __device__ __forceinline__ uint32_t mulhi_u24(uint32_t a, uint32_t b) { return sc_llvm_mulhi_u24(a, b); }
 
 __device__ __forceinline__ uint32_t csub(uint32_t x, uint32_t m) { return min(x, x - m); }  // x in [0,2m) -> [0,m)
@@ -58,6 +60,19 @@ template <> struct Mod<MODE_U32> {
     {
         uint32_t qh = __umulhi(a, wp);
         return a * w - qh * k.q;
+    }
+};
+
+// Small moduli (q < 2^14: 7681, 12289): every value a kernel multiplies stays below 2^23, so the quotient estimate
+// qh = floor(a wp / 2^32) <= a fits a signed 24-bit operand and the correction a*w - qh*q is ONE multiply-add
+// (v_mad_i32_i24 with the constant -q): 3 instructions per constant product instead of 4.  Same Shoup companion (BETA = 2^32)
+// as MODE_U32, same result range [0, 2q).
+template <> struct Mod<MODE_MAD> {
+    static constexpr uint64_t BETA = 1ull << 32;
+    static __device__ __forceinline__ uint32_t mulc(uint32_t a, uint32_t w, uint32_t wp, const ModK &k)
+    {
+        const uint32_t qh = __umulhi(a, wp);
+        return mul_u24(a, w) + (uint32_t)mul_i24((int32_t)qh, -(int32_t)k.q);
     }
 };
 

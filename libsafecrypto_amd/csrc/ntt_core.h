@@ -110,31 +110,41 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
     }
 }
 
-// One inverse (Gentleman-Sande) stage on register bit T:  (a, b) -> (a + b, (a - b) zeta^-1)
-template <int MODE, int T>
+// One inverse (Gentleman-Sande) stage on register bit T:  (a, b) -> (a + b, (a - b) zeta^-1).
+// G < 0: inputs and outputs in [0, 2q).  G >= 0 (MODE_MAD only): inputs below 2q 2^G; the sums are left to grow (below
+// 2q 2^(G+1)) and the difference is biased by 2q 2^G instead of reduced - 3 instructions saved per butterfly.  With q < 2^14 and
+// at most 8 growing stages every multiplied value stays below 2^23, which is what MODE_MAD needs.
+template <int MODE, int T, int G>
 __device__ __forceinline__ void gs_stage(uint32_t (&x)[16], const uint32_t (&tw)[15], const uint32_t (&twp)[15], const ModK &k)
 {
+    static_assert(G < 0 || MODE == MODE_MAD, "growing sums need the small-modulus mode");
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & (1 << T)) continue;
         const int idx = (1 << (3 - T)) - 1 + (r >> (T + 1));
         const uint32_t a = x[r], b = x[r | (1 << T)];
-        uint32_t d = a + k.q2 - b;                       // (0, 4q)
-        if (MODE == MODE_U24) d = csub(d, k.q2);         // the 24-bit multiplier needs d < 2^24
-        x[r] = csub(a + b, k.q2);
-        x[r | (1 << T)] = Mod<MODE>::mulc(d, tw[idx], twp[idx], k);
+        if constexpr (G >= 0) {
+            const uint32_t d = a + (k.q2 << G) - b;
+            x[r] = a + b;
+            x[r | (1 << T)] = Mod<MODE>::mulc(d, tw[idx], twp[idx], k);
+        } else {
+            uint32_t d = a + k.q2 - b;                       // (0, 4q)
+            if (MODE == MODE_U24) d = csub(d, k.q2);         // the 24-bit multiplier needs d < 2^24
+            x[r] = csub(a + b, k.q2);
+            x[r | (1 << T)] = Mod<MODE>::mulc(d, tw[idx], twp[idx], k);
+        }
     }
 }
 
 // Last inverse stage (s = 0, register bit 3 of round 0) with the output scale folded in:
 // (a, b) -> ((a + b) c0, (a - b) c1), c0 = scale, c1 = zeta^-1 scale; result canonical [0,q).
-template <int MODE>
+template <int MODE, int G>
 __device__ __forceinline__ void gs_last_stage(uint32_t (&x)[16], uint32_t c0, uint32_t c0p, uint32_t c1, uint32_t c1p, const ModK &k)
 {
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = x[r], b = x[r | 8];
-        uint32_t s = a + b, d = a + k.q2 - b;
+        uint32_t s = a + b, d = a + (G >= 0 ? (k.q2 << G) : k.q2) - b;
         if (MODE == MODE_U24) { s = csub(s, k.q2); d = csub(d, k.q2); }
         x[r] = csub(Mod<MODE>::mulc(s, c0, c0p, k), k.q);
         x[r | 8] = csub(Mod<MODE>::mulc(d, c1, c1p, k), k.q);
@@ -152,13 +162,14 @@ __device__ __forceinline__ void ct_round(uint32_t (&x)[16], const uint32_t (&tw)
     ct_stage<MODE, LAZY, 0>(x, tw, twp, k);
 }
 
-template <int MODE, int NS, bool SKIP_TOP>
+// G0: growth exponent of the round's first stage (see gs_stage), < 0 for a round kept in [0, 2q)
+template <int MODE, int NS, bool SKIP_TOP, int G0>
 __device__ __forceinline__ void gs_round(uint32_t (&x)[16], const uint32_t (&tw)[15], const uint32_t (&twp)[15], const ModK &k)
 {
-    gs_stage<MODE, 0>(x, tw, twp, k);
-    if constexpr (NS >= 2) gs_stage<MODE, 1>(x, tw, twp, k);
-    if constexpr (NS >= 3) gs_stage<MODE, 2>(x, tw, twp, k);
-    if constexpr (NS >= 4 && !SKIP_TOP) gs_stage<MODE, 3>(x, tw, twp, k);
+    gs_stage<MODE, 0, G0>(x, tw, twp, k);
+    if constexpr (NS >= 2) gs_stage<MODE, 1, (G0 < 0 ? -1 : G0 + 1)>(x, tw, twp, k);
+    if constexpr (NS >= 3) gs_stage<MODE, 2, (G0 < 0 ? -1 : G0 + 2)>(x, tw, twp, k);
+    if constexpr (NS >= 4 && !SKIP_TOP) gs_stage<MODE, 3, (G0 < 0 ? -1 : G0 + 3)>(x, tw, twp, k);
 }
 
 // Twiddle sets held by a wave for one direction.
@@ -198,14 +209,17 @@ __device__ __forceinline__ void inv_core(uint32_t (&x)[16], const TwSet<L> &tw, 
                                          uint32_t c0, uint32_t c0p, uint32_t c1, uint32_t c1p)
 {
     using Y = Lay<L>;
+    // small-modulus mode: the last 8 stages (rounds 1 and 0) let the sums grow; the L-8 stages of round 2 stay reduced
+    constexpr bool GROW = MODE == MODE_MAD;
+    static_assert(!GROW || Y::ns(1) == 4, "growth bookkeeping assumes 4 + 4 stages in rounds 1 and 0");
     if constexpr (Y::NR == 3) {
-        gs_round<MODE, Y::ns(2), false>(x, tw.t2, tw.t2p, k);
+        gs_round<MODE, Y::ns(2), false, -1>(x, tw.t2, tw.t2p, k);
         exchange<Y::b0(2), Y::b0(1)>(x, lds_poly, lp);
     }
-    gs_round<MODE, Y::ns(1), false>(x, tw.t1, tw.t1p, k);
+    gs_round<MODE, Y::ns(1), false, (GROW ? 0 : -1)>(x, tw.t1, tw.t1p, k);
     exchange<Y::b0(1), Y::b0(0)>(x, lds_poly, lp);
-    gs_round<MODE, 4, true>(x, tw.t0, tw.t0p, k);
-    gs_last_stage<MODE>(x, c0, c0p, c1, c1p, k);
+    gs_round<MODE, 4, true, (GROW ? 4 : -1)>(x, tw.t0, tw.t0p, k);
+    gs_last_stage<MODE, (GROW ? 7 : -1)>(x, c0, c0p, c1, c1p, k);
 }
 
 }  // namespace sc

@@ -358,6 +358,8 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     // measured on MI355X (profiles/microbench_r01b.txt): v_mul_lo/hi_u32 issue at full rate on gfx950,
     // so the 4-instruction 32-bit Shoup product beats the 6-instruction 24-bit one for every q
     p->mode = MODE_U32;
+    // q < 2^14 (7681, 12289): the 3-instruction multiply-add form with growing inverse sums (modarith.h MODE_MAD, ntt_core.h)
+    if (Q < (1ull << 14)) p->mode = MODE_MAD;
     *out = p;
     return SC_HIP_SUCCESS;
 }
@@ -382,9 +384,10 @@ extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t 
 extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
-    if (mode == 0) mode = MODE_U32;
+    if (mode == 0) mode = (uint64_t)p->q < (1ull << 14) ? MODE_MAD : MODE_U32;
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
-    if (mode != MODE_U24 && mode != MODE_U32) return fail("plan_set_arith: mode must be 0, 1 or 2");
+    if (mode == MODE_MAD && (uint64_t)p->q >= (1ull << 14)) return fail("plan_set_arith: the multiply-add path needs q < 2^14");
+    if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD) return fail("plan_set_arith: mode must be 0, 1, 2 or 3");
     p->mode = mode;
     return SC_HIP_SUCCESS;
 }
@@ -409,8 +412,10 @@ template <int L, int OP>
 static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
 {
     if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
+        if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
     } else {
+        if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, true, OP>(a, blocks, s);          // q < 2^14: always lazy
         if (mode == MODE_U24) return lazy ? launch_ntt_t<L, MODE_U24, true, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s);
         return lazy ? launch_ntt_t<L, MODE_U32, true, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
     }
