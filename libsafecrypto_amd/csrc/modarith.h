@@ -76,13 +76,30 @@ template <> struct Mod<MODE_MAD> {
     }
 };
 
-// arbitrary int32 -> [0, 2q)
+// arbitrary int32 -> [0, 2q).  qh = floor(x m32 / 2^32) is floor(x/q) or one more, so r = x - qh q lies in [-q, 2q);
+// read as unsigned, the smaller of r and r + q is the representative in [0, 2q).
 __device__ __forceinline__ uint32_t reduce_i32(int32_t x, const ModK &k)
 {
-    int32_t qh = __mulhi(x, (int32_t)k.m32);
-    int32_t r = x - qh * (int32_t)k.q;            // in [-q, 2q)
-    r += (r >> 31) & (int32_t)k.q;
-    return (uint32_t)r;
+    const int32_t qh = __mulhi(x, (int32_t)k.m32);
+    const uint32_t r = (uint32_t)x - (uint32_t)qh * k.q;
+    return min(r, r + k.q);
+}
+
+// the same for q < 2^14 (|qh| < 2^19 fits a signed 24-bit operand): the correction is one multiply-add
+__device__ __forceinline__ uint32_t reduce_i32_small(int32_t x, const ModK &k)
+{
+    const int32_t qh = __mulhi(x, (int32_t)k.m32);
+    const uint32_t r = (uint32_t)x + (uint32_t)mul_i24(qh, -(int32_t)k.q);
+    return min(r, r + k.q);
+}
+
+// q < 2^14: x*y for x*y < 2^32 (x a lazily grown NTT output, y canonical) -> [0, 2q): plain product, Barrett quotient, one
+// multiply-add; replaces the 8-instruction Montgomery step and leaves no 2^-32 factor behind
+__device__ __forceinline__ uint32_t mulmod_small(uint32_t x, uint32_t y, const ModK &k)
+{
+    const uint32_t t = x * y;
+    const uint32_t qh = __umulhi(t, k.m32);
+    return t + (uint32_t)mul_i24((int32_t)qh, -(int32_t)k.q);
 }
 
 // a*b*2^-32 mod q in [0,q); needs a*b < q*2^32

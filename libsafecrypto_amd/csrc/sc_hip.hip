@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         const size_t base = (size_t)poly * N;
         uint32_t x[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = reduce_i32(nx[r], k);
+        for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
 
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
@@ -125,17 +125,23 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 
         if (OP == OP_MULNTT) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
+            for (int r = 0; r < 16; r++) {
+                if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
+                else x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
+            }
             prefetch();
         }
         if (OP == OP_MUL) {
             uint32_t y[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) y[r] = reduce_i32(nb[r], k);
+            for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
             prefetch();
             fwd_core<L, MODE, false>(y, twf, lds_poly, lp, k);      // [0,2q)
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = montmul(x[r], y[r], k);
+            for (int r = 0; r < 16; r++) {
+                if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(y[r], k.q), k);
+                else x[r] = montmul(x[r], y[r], k);
+            }
         }
 
         inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
@@ -442,7 +448,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
     a.zf = p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
-    const uint32_t *c = (op == OP_INV) ? p->c_inv[mi] : p->c_mont[mi];
+    const uint32_t *c = (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus product leaves no 2^-32
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
     const int pw = 1024 / n;                                  // polynomials per wave
