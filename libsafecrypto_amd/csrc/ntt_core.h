@@ -98,7 +98,9 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
     for (int r = 0; r < 16; r++) {
         if (r & (1 << T)) continue;
         const int idx = (1 << (3 - T)) - 1 + (r >> (T + 1));
-        const uint32_t t = Mod<MODE>::mulc(x[r | (1 << T)], tw[idx], twp[idx], k);
+        // small-modulus mode: forward values stay below 2q(L+1) < 2^18.1, so value * twiddle fits 32 bits and a Barrett step on the
+        // product needs no per-twiddle companion (15-30 fewer live registers per wave: one more wave per SIMD)
+        const uint32_t t = (MODE == MODE_MAD) ? mulmod_small(x[r | (1 << T)], tw[idx], k) : Mod<MODE>::mulc(x[r | (1 << T)], tw[idx], twp[idx], k);
         const uint32_t a = x[r];
         if (LAZY) {                      // values grow by < 2q per stage, never reduced
             x[r] = a + t;
