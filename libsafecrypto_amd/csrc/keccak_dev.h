@@ -18,7 +18,17 @@
 
 namespace sc {
 
-__device__ __forceinline__ uint64_t rol64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// 64-bit rotate by a compile-time amount as two v_alignbit_b32 on the halves (full rate); the generic (x << n) | (x >> (64 - n))
+// becomes v_lshlrev_b64 + v_lshrrev_b64 + 2 v_or, and 64-bit shifts issue at a fraction of the 32-bit rate on gfx950 - the
+// permutation spends a quarter of its instructions on rotates.
+__device__ __forceinline__ uint64_t rol64(uint64_t x, int n)
+{
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (n >= 32) { const uint32_t t = lo; lo = hi; hi = t; n -= 32; }
+    if (n == 0) return ((uint64_t)hi << 32) | lo;
+    const uint32_t nlo = __builtin_amdgcn_alignbit(lo, hi, 32 - n), nhi = __builtin_amdgcn_alignbit(hi, lo, 32 - n);
+    return ((uint64_t)nhi << 32) | nlo;
+}
 
 template <bool STD>
 __device__ __forceinline__ void keccak_permute_regs(uint64_t (&s)[25])
