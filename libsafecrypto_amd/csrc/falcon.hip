@@ -164,63 +164,121 @@ template <int G> __device__ __forceinline__ void sweep_sync()
 constexpr int PU = 8;
 constexpr int SU = 4;     // the tree sweeps: qn >= 4 pairs at the smallest level kept in memory (l = FK + 1 = 4)
 
-// falcon_fft.c:203-282; n/4 butterflies per stage, flat index bf -> (i1 = bf / ht, j = i1*t + bf % ht)
+// The transforms run R = 3 (then 2 or 1) butterfly stages per sweep: the 2^R points j0 + a*Q that those stages connect are
+// loaded once, all R stages run in registers, and the points are written back - the same operations on the same operands in the
+// same order per element as the reference's stage-by-stage loops (each element's value after stage s depends only on its stage
+// s-1 inputs), at a third of the HBM traffic.  PG groups are in flight per lane so that a lone wavefront has 2^R * 2 * PG loads
+// outstanding.
+
+// falcon_fft.c:203-282, stages u .. u+R-1 (m = 2^u, half-span ht = hn >> u at stage u): group g -> block i1 = g / Q, j0 = i1*P*Q + g % Q
+// with Q the half-span of the pass's last stage; point a sits in twiddle block (i1 << s) + (a >> (R - s)) of stage u + s.
+template <int G, int R>
+__device__ __forceinline__ void fft_pass(const Col<G> &c, uint32_t g, uint32_t f, uint32_t hn, int u, const double *__restrict__ gm)
+{
+    constexpr int P = 1 << R, PG = (R == 3) ? 2 : 4;
+    const int lq = __builtin_ctz(hn) - u - (R - 1);                    // Q = hn >> (u + R - 1)
+    const uint32_t Q = 1u << lq, groups = hn >> R, m = 1u << u;
+    for (uint32_t g0 = 0; g0 < groups; g0 += PG * G) {
+        double xr[PG][P], xi[PG][P]; uint32_t j0[PG], i1[PG];
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t grp = g0 + k * G + g;
+            i1[k] = grp >> lq; j0[k] = ((i1[k] << R) << lq) + (grp & (Q - 1));
+            if (G == 1 || grp < groups) {
+#pragma unroll
+                for (int a = 0; a < P; a++) { xr[k][a] = c.ld(f + j0[k] + (a << lq)); xi[k][a] = c.ld(f + j0[k] + (a << lq) + hn); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t grp = g0 + k * G + g;
+            if (G == 1 || grp < groups) {
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int sp = P >> (s + 1);
+#pragma unroll
+                    for (int a = 0; a < P; a++) {
+                        if (a & sp) continue;
+                        const uint32_t tw = (((m << s) + (i1[k] << s) + (uint32_t)(a >> (R - s)))) << 1;
+                        double yr, yi;
+                        cmul(yr, yi, xr[k][a + sp], xi[k][a + sp], gm[tw], gm[tw + 1]);
+                        const double ar = xr[k][a], ai = xi[k][a];
+                        xr[k][a] = ar + yr; xi[k][a] = ai + yi;
+                        xr[k][a + sp] = ar - yr; xi[k][a + sp] = ai - yi;
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < P; a++) { c.st(f + j0[k] + (a << lq), xr[k][a]); c.st(f + j0[k] + (a << lq) + hn, xi[k][a]); }
+            }
+        }
+    }
+    sweep_sync<G>();
+}
+
 template <int G>
 __device__ void fft_col(const Col<G> &c, uint32_t g, uint32_t f, int logn, const double *__restrict__ gm)
 {
-    const uint32_t n = 1u << logn, hn = n >> 1, nb = n >> 2;           // nb >= 128 is a multiple of PU * G
-    uint32_t m = 2;
-    for (int u = 1; u < logn; u++, m <<= 1) {
-        const int lt = logn - u, lht = lt - 1;                       // t = 2^lt, ht = 2^lht
-        const uint32_t ht = 1u << lht;
-        for (uint32_t b0 = 0; b0 < nb; b0 += PU * G) {
-            double xr[PU], xi[PU], yr[PU], yi[PU]; uint32_t j[PU], tw[PU];
-#pragma unroll
-            for (int k = 0; k < PU; k++) {
-                const uint32_t bf = b0 + k * G + g, i1 = bf >> lht;
-                j[k] = (i1 << lt) + (bf & (ht - 1)); tw[k] = (m + i1) << 1;
-                xr[k] = c.ld(f + j[k]); xi[k] = c.ld(f + j[k] + hn); yr[k] = c.ld(f + j[k] + ht); yi[k] = c.ld(f + j[k] + ht + hn);
-            }
-#pragma unroll
-            for (int k = 0; k < PU; k++) {
-                cmul(yr[k], yi[k], yr[k], yi[k], gm[tw[k]], gm[tw[k] + 1]);
-                c.st(f + j[k], xr[k] + yr[k]); c.st(f + j[k] + hn, xi[k] + yi[k]);
-                c.st(f + j[k] + ht, xr[k] - yr[k]); c.st(f + j[k] + ht + hn, xi[k] - yi[k]);
-            }
-        }
-        sweep_sync<G>();
-    }
+    const uint32_t hn = (1u << logn) >> 1;
+    int u = 1;
+    for (; u + 2 < logn; u += 3) fft_pass<G, 3>(c, g, f, hn, u, gm);
+    if (u + 1 < logn) fft_pass<G, 2>(c, g, f, hn, u, gm);
+    else if (u < logn) fft_pass<G, 1>(c, g, f, hn, u, gm);
 }
 
-// falcon_fft.c:284-378 without the final scaling (the caller applies f*ni while it rounds to integers)
+// falcon_fft.c:284-378 without the final scaling (the caller applies f*ni while it rounds to integers).  R stages starting at
+// half-span t0 = 2^lt and table offset hm0: group g -> block iB = g >> lt, j0 = iB*P*t0 + g % t0; at stage s the pair (a, a + 2^s)
+// uses the conjugate of gm[(hm0 >> s) + iB*(P >> (s+1)) + (a >> (s+1))].
+template <int G, int R>
+__device__ __forceinline__ void ifft_pass(const Col<G> &c, uint32_t g, uint32_t f, uint32_t hn, int lt, uint32_t hm0, const double *__restrict__ gm)
+{
+    constexpr int P = 1 << R, PG = (R == 3) ? 2 : 4;
+    const uint32_t t0 = 1u << lt, groups = hn >> R;
+    for (uint32_t g0 = 0; g0 < groups; g0 += PG * G) {
+        double xr[PG][P], xi[PG][P]; uint32_t j0[PG], iB[PG];
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t grp = g0 + k * G + g;
+            iB[k] = grp >> lt; j0[k] = ((iB[k] << R) << lt) + (grp & (t0 - 1));
+            if (G == 1 || grp < groups) {
+#pragma unroll
+                for (int a = 0; a < P; a++) { xr[k][a] = c.ld(f + j0[k] + (a << lt)); xi[k][a] = c.ld(f + j0[k] + (a << lt) + hn); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t grp = g0 + k * G + g;
+            if (G == 1 || grp < groups) {
+#pragma unroll
+                for (int s = 0; s < R; s++) {
+                    const int sp = 1 << s;
+#pragma unroll
+                    for (int a = 0; a < P; a++) {
+                        if (a & sp) continue;
+                        const uint32_t tw = ((hm0 >> s) + iB[k] * (uint32_t)(P >> (s + 1)) + (uint32_t)(a >> (s + 1))) << 1;
+                        const double ar = xr[k][a], ai = xi[k][a], br = xr[k][a + sp], bi = xi[k][a + sp];
+                        xr[k][a] = ar + br; xi[k][a] = ai + bi;
+                        const double dr = ar - br, di = ai - bi;
+                        cmul(xr[k][a + sp], xi[k][a + sp], dr, di, gm[tw], -gm[tw + 1]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < P; a++) { c.st(f + j0[k] + (a << lt), xr[k][a]); c.st(f + j0[k] + (a << lt) + hn, xi[k][a]); }
+            }
+        }
+    }
+    sweep_sync<G>();
+}
+
 template <int G>
 __device__ void ifft_col(const Col<G> &c, uint32_t g, uint32_t f, int logn, const double *__restrict__ gm)
 {
-    const uint32_t n = 1u << logn, hn = n >> 1, nb = n >> 2;
-    uint32_t m = n;
-    int lt = 0;                                                       // t = 2^lt
-    for (int u = logn; u > 1; u--, lt++) {
-        const uint32_t hm = m >> 1, t = 1u << lt;
-        for (uint32_t b0 = 0; b0 < nb; b0 += PU * G) {
-            double xr[PU], xi[PU], yr[PU], yi[PU]; uint32_t j[PU], tw[PU];
-#pragma unroll
-            for (int k = 0; k < PU; k++) {
-                const uint32_t bf = b0 + k * G + g, i1 = bf >> lt;
-                j[k] = (i1 << (lt + 1)) + (bf & (t - 1)); tw[k] = (hm + i1) << 1;
-                xr[k] = c.ld(f + j[k]); xi[k] = c.ld(f + j[k] + hn); yr[k] = c.ld(f + j[k] + t); yi[k] = c.ld(f + j[k] + t + hn);
-            }
-#pragma unroll
-            for (int k = 0; k < PU; k++) {
-                c.st(f + j[k], xr[k] + yr[k]); c.st(f + j[k] + hn, xi[k] + yi[k]);
-                const double dr = xr[k] - yr[k], di = xi[k] - yi[k];
-                double pr, pi;
-                cmul(pr, pi, dr, di, gm[tw[k]], -gm[tw[k] + 1]);
-                c.st(f + j[k] + t, pr); c.st(f + j[k] + t + hn, pi);
-            }
-        }
-        sweep_sync<G>();
-        m = hm;
-    }
+    const uint32_t n = 1u << logn, hn = n >> 1;
+    int left = logn - 1, lt = 0;                                      // stages to go; half-span 2^lt; first stage uses hm = n/2
+    uint32_t hm = n >> 1;
+    for (; left >= 3; left -= 3, lt += 3, hm >>= 3) ifft_pass<G, 3>(c, g, f, hn, lt, hm, gm);
+    if (left == 2) ifft_pass<G, 2>(c, g, f, hn, lt, hm, gm);
+    else if (left == 1) ifft_pass<G, 1>(c, g, f, hn, lt, hm, gm);
 }
 
 // falcon_fft.c:694-739, level l >= 4 (qn >= 4 is a multiple of SU; with G > 1 lanes beyond qn idle)
