@@ -17,7 +17,7 @@
 // signature) live in HBM interleaved across the batch - element e of signature b at ws[e*B + b] - so every access of a
 // wavefront is one contiguous 512-byte row; key material (basis, tree, roots) is read at wave-uniform addresses.
 // The recursion is unrolled by hand into a loop over levels; the passes the reference makes between the two recursive
-// calls (merge, (t1 - z1)*L + t0, split) are fused into one sweep, and the bottom 2^FK-coefficient sub-trees run
+// calls (merge, (t1 - z1)*L + t0, split) are fused into one sweep, and the bottom 8- or 16-coefficient sub-trees run
 // entirely in registers.  HBM traffic per signature is about 9n doubles per tree level above the register block.
 //
 // Randomness: each tree leaf builds a throw-away 64-bit CDF sampler with sigma = (float)leaf and draws two samples
@@ -37,7 +37,8 @@ using namespace sc;
 namespace {
 
 constexpr int HT = 64;       // hash kernel: lanes per workgroup (LDS sponge states)
-constexpr int FK = 3;        // sub-trees of 2^FK coefficients are sampled in registers
+constexpr int FK1 = 4;       // sub-trees of 2^FK coefficients are sampled in registers: 16 with a lane per signature,
+constexpr int FK8 = 3;       // 8 when eight lanes share one (the sub-tree runs on one lane of the group)
 constexpr int ST = 256;      // sampler kernel: lanes per workgroup
 
 struct FalP { int32_t n, q, q_bits, n_bits, set; float bd; int32_t pad[2]; };   // falcon_set_t fields (falcon_params.h:38-55)
@@ -162,7 +163,7 @@ template <int G> __device__ __forceinline__ void sweep_sync()
 // compiler keeps the iterations in order and a lone wavefront would pay one full memory latency per iteration.  The iterations
 // of one sweep touch disjoint elements, so the loads of PU iterations are issued together before any of them is consumed.
 constexpr int PU = 8;
-constexpr int SU = 4;     // the tree sweeps: qn >= 4 pairs at the smallest level kept in memory (l = FK + 1 = 4)
+constexpr int SU = 4;     // the tree sweeps: qn >= 4 pairs at the smallest level kept in memory (l = FK + 1 >= 4)
 
 // The transforms run R = 3 (then 2 or 1) butterfly stages per sweep: the 2^R points j0 + a*Q that those stages connect are
 // loaded once, all R stages run in registers, and the points are written back - the same operations on the same operands in the
@@ -355,6 +356,7 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
                                                         const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                         int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni)
 {
+    constexpr int FK = (G == 1) ? FK1 : FK8;
     const uint32_t tid = blockIdx.x * ST + threadIdx.x, b = tid / G, g = tid % G;
     if (b >= batch) return;
     const uint32_t n = (uint32_t)P.n; const int logn = P.n_bits;
