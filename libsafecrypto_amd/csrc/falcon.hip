@@ -612,15 +612,27 @@ __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, con
 __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
                                   uint32_t *__restrict__ verdict, FalP P)
 {
+    // one lane per PAIR of coefficients; with the 12-bit coding of both parameter sets a pair is exactly three bytes
     const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t b = (uint32_t)(tt / P.n); const int e = (int)(tt % P.n);
+    const int hn = P.n / 2;
+    const uint32_t b = (uint32_t)(tt / hn); const int e = (int)(tt % hn) * 2;
     if (b >= batch) return;
     const int bits = P.q_bits - 2;
-    if ((size_t)siglens[b] * 8 < (size_t)P.n * bits) { if (e == 0) verdict[b] = 1; s2[tt] = 0; return; }
+    int32_t *o = s2 + (size_t)b * P.n + e;
+    if ((size_t)siglens[b] * 8 < (size_t)P.n * bits) { if (e == 0) verdict[b] = 1; o[0] = o[1] = 0; return; }
     const uint8_t *s = sigs + (size_t)b * sig_stride;
-    uint32_t val = 0;
-    for (int k = 0; k < bits; k++) { const uint32_t bp = (uint32_t)e * bits + k; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
-    s2[tt] = centre_mod((int32_t)(val << (32 - bits)) >> (32 - bits), P.q);
+    if (bits == 12) {
+        const uint8_t *p = s + (e / 2) * 3;
+        const uint32_t w = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
+        o[0] = centre_mod((int32_t)((w >> 12) << 20) >> 20, P.q);
+        o[1] = centre_mod((int32_t)((w & 0xFFFu) << 20) >> 20, P.q);
+        return;
+    }
+    for (int h = 0; h < 2; h++) {
+        uint32_t val = 0;
+        for (int k = 0; k < bits; k++) { const uint32_t bp = (uint32_t)(e + h) * bits + k; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+        o[h] = centre_mod((int32_t)(val << (32 - bits)) >> (32 - bits), P.q);
+    }
 }
 
 // s1 = centre(c - s2*h) ; norm test.  One wavefront per signature.
@@ -893,7 +905,7 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P);
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P);
     hipLaunchKernelGGL(fal_hash_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
