@@ -22,6 +22,7 @@
 #define NTT_NEEDS_8380417
 #define NTT_NEEDS_12289
 #define NTT_NEEDS_8399873
+#define NTT_NEEDS_51750913
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -163,6 +164,43 @@ static int gen_ntt(const char *dir)
         v[2] = ntt->muln_32(12288, 12288, &p);
         v[3] = ntt->modn_32(12289 * 12289 - 1, &p);
         rec_i32(f, "scalar_q12289_fp", v, 4);
+    }
+    fclose(f);
+    return 0;
+}
+
+/* the `_large` transform variants (modn after every addition, ntt_template.c.in:1246-1339,1484-1613) that ENS / DLP / ring-TESLA-1
+ * use with the 26-bit modulus 51750913 (the only large-modulus tables the library build contains): forward (normalised), inverse and product vectors for two polynomials per (q, n) */
+static int gen_ntt_large(const char *dir)
+{
+    char path[512], name[96];
+    snprintf(path, sizeof path, "%s/ntt_large_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    const struct { int32_t q; int n; const SINT32 *w, *r; } cf[2] = {
+        { 51750913, 512, w51750913_n512, r51750913_n512 }, { 51750913, 1024, w51750913_n1024, r51750913_n1024 } };
+    const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+    for (int c = 0; c < 2; c++) {
+        const int q = cf[c].q, n = cf[c].n, NP = 2;
+        ntt_params_t p; init_reduce(&p, n, q);
+        int32_t *a = malloc(sizeof(int32_t) * n * NP), *b = malloc(sizeof(int32_t) * n * NP), *o = malloc(sizeof(int32_t) * n * NP), *fa = malloc(sizeof(int32_t) * n), *fb = malloc(sizeof(int32_t) * n);
+        sm_state = 0x1a46e000ULL + (uint64_t)q + n;
+        for (int i = 0; i < n; i++) { a[i] = (int)(splitmix64() % (uint64_t)q); b[i] = (int)(splitmix64() % (uint64_t)q); }
+        for (int i = 0; i < n; i++) { a[n + i] = (int)(splitmix64() % 2001) - 1000; b[n + i] = (int)(splitmix64() % 25) - 12; }
+        snprintf(name, sizeof name, "q%d_n%d_w1", q, n); rec_i32(f, name, cf[c].w + 1, 1);             /* the root the tables were built from */
+        snprintf(name, sizeof name, "q%d_n%d_a", q, n); rec_i32(f, name, a, (size_t)n * NP);
+        snprintf(name, sizeof name, "q%d_n%d_b", q, n); rec_i32(f, name, b, (size_t)n * NP);
+        for (int k = 0; k < NP; k++) { ntt->fwd_ntt_32_32_large(o + k * n, &p, a + k * n, cf[c].w); ntt->normalize_32(o + k * n, n, &p); }
+        snprintf(name, sizeof name, "q%d_n%d_fwd", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        for (int k = 0; k < NP; k++) { ntt->inv_ntt_32_32_large(o + k * n, &p, o + k * n, cf[c].w, cf[c].r); ntt->normalize_32(o + k * n, n, &p); }
+        snprintf(name, sizeof name, "q%d_n%d_inv", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        for (int k = 0; k < NP; k++) {
+            ntt->fwd_ntt_32_32_large(fa, &p, a + k * n, cf[c].w); ntt->fwd_ntt_32_32_large(fb, &p, b + k * n, cf[c].w);
+            ntt->mul_32_pointwise(fa, &p, fa, fb);
+            ntt->inv_ntt_32_32_large(o + k * n, &p, fa, cf[c].w, cf[c].r); ntt->normalize_32(o + k * n, n, &p);
+        }
+        snprintf(name, sizeof name, "q%d_n%d_mul", q, n); rec_i32(f, name, o, (size_t)n * NP);
+        free(a); free(b); free(o); free(fa); free(fb);
     }
     fclose(f);
     return 0;
@@ -895,6 +933,7 @@ int main(int argc, char **argv)
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
+    if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);

@@ -133,3 +133,18 @@ def test_cdt_table_and_samples_vs_reference(tag, tail, sigma):
     v = O.cdt_sample(G[f'{tag}_uniform'], cdf)
     assert np.array_equal(v, G[f'{tag}_samples'])
     assert np.abs(v).max() < cdf.size          # unit_sampling.c:194-222 bound
+
+
+@pytest.mark.parametrize('q,n', [(51750913, 512), (51750913, 1024)])
+def test_large_modulus_variants_vs_reference(q, n):
+    """fwd_ntt_32_32_large / inv_ntt_32_32_large of the reference (26-bit modulus, ENS / DLP / ring-TESLA-1) - the oracle's
+    transforms are the same functions mod q, compared after normalize_32 (tests/golden/ntt_large_ref.txt)"""
+    G = load_golden('ntt_large_ref.txt')
+    w, r = O.tables(q, n)
+    assert int(w[1]) == int(G[f'q{q}_n{n}_w1'][0])
+    a = G[f'q{q}_n{n}_a'].astype(np.int32).reshape(2, n)
+    b = G[f'q{q}_n{n}_b'].astype(np.int32).reshape(2, n)
+    f = O.fwd_ntt(a, q, w)
+    assert np.array_equal(f.reshape(-1), G[f'q{q}_n{n}_fwd'])
+    assert np.array_equal(O.inv_ntt(f, q, w, r).reshape(-1), G[f'q{q}_n{n}_inv'])
+    assert np.array_equal(O.polymul_ntt(a, O.fwd_ntt(b, q, w), q, w, r).reshape(-1), G[f'q{q}_n{n}_mul'])

@@ -28,5 +28,8 @@ def run(batch=16384, reps=3):
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 1:
+        print(json.dumps(run(int(sys.argv[1]))))
+        sys.exit(0)
     for bsz in (1024, 16384, 65536):
         print(json.dumps(run(bsz)))
