@@ -18,6 +18,10 @@
  *     reference's fwd_ntt_32_* followed by normalize_32
  *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
  *     sc_hip_last_error) when no gfx950 device / kernel image is available
+ *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs are immutable after
+ *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t) owns the
+ *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
+ *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
  */
 #ifndef SC_HIP_H
 #define SC_HIP_H
@@ -57,8 +61,9 @@ int     sc_hip_plan_n(const sc_hip_plan_t *plan);
 int32_t sc_hip_plan_root(const sc_hip_plan_t *plan);           /* g                         */
 /* host copies of the reference-format tables (w[i]=g^i, r[i]=((q-1)/n) g^i), n entries each */
 int  sc_hip_plan_tables(const sc_hip_plan_t *plan, int32_t *h_w, int32_t *h_r);
-/* selects the modular-multiply code path: 0 = auto (= 2, the faster one on gfx950),
- * 1 = 24-bit Shoup (q < 2^23), 2 = 32-bit Shoup (q < 2^30).  For measurement; results are identical. */
+/* selects the modular-multiply code path: 0 = auto (3 for q < 2^14, else 2),
+ * 1 = 24-bit Shoup (q < 2^23), 2 = 32-bit Shoup (q < 2^30), 3 = small-modulus multiply-add form (q < 2^14).
+ * For measurement; results are identical. */
 int  sc_hip_plan_set_arith(sc_hip_plan_t *plan, int mode);
 
 /* ---- batched transforms, device pointers ------------------------------------------- */
