@@ -30,26 +30,31 @@ struct TsP { int32_t n, n_bits, q, q_bits, b, b_bits, omega, d, bound, u, set, p
 
 struct St { uint32_t *pos, *status; };
 
-// start of an attempt: n fresh words -> y = (word & (2^(b_bits+1) - 1)) - b   (ring_tesla.c:818-822)
-__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nact, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase,
-                                uint32_t *siglens, uint32_t *trials, int n)
+// Attempts are evaluated S at a time per message ("slots": slot = aidx * S + k tries the k-th next attempt of active message
+// aidx, tape words [pos + k n, pos + (k+1) n)) and the LOWEST accepted k wins - exactly the attempt the reference's loop would have
+// stopped at.  While most of the batch is active S is 1-2; as the batch thins out the same slot budget goes deeper, so the long
+// tail of the rejection loop (P(accept) ~ 0.32) costs a few rounds instead of twenty.
+__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase, int n)
 {
-    const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (aidx >= nact) return;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= nslots) return;
+    const uint32_t aidx = slot / S, k = slot % S;
     const uint32_t item = active ? active[aidx] : aidx;
-    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item];
-    if (pos + (uint32_t)n > len) { s.status[item] = 2; siglens[item] = 0; need[aidx] = 2; return; }     // tape exhausted
-    need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + (uint32_t)n; trials[item]++;
+    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item] + k * (uint32_t)n;
+    if (pos + (uint32_t)n > len) { need[slot] = 2; return; }             // the tape ends before this attempt
+    need[slot] = 1; sbase[slot] = pos;
 }
 
-__global__ void ts_y_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P)
+// y = (word & (2^(b_bits+1) - 1)) - b   (ring_tesla.c:818-822)
+__global__ void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t aidx = (uint32_t)(t / P.n); const int i = (int)(t % P.n);
-    if (aidx >= nact) return;
-    if (need[aidx] != 1) { y[t] = 0; return; }
+    const uint32_t slot = (uint32_t)(t / P.n); const int i = (int)(t % P.n);
+    if (slot >= nslots) return;
+    if (need[slot] != 1) { y[t] = 0; return; }
+    const uint32_t aidx = slot / S;
     const uint32_t item = active ? active[aidx] : aidx;
-    y[t] = (int32_t)(tapes[(size_t)item * tape_stride + sbase[aidx] + i] & ((1u << (P.b_bits + 1)) - 1u)) - P.b;
+    y[t] = (int32_t)(tapes[(size_t)item * tape_stride + sbase[slot] + i] & ((1u << (P.b_bits + 1)) - 1u)) - P.b;
 }
 
 __device__ __forceinline__ int32_t centre_q(int32_t x, int32_t q)   // ntt center_32 on a canonical value
@@ -90,7 +95,7 @@ __device__ __forceinline__ uint32_t rotl(uint32_t x, int k) { return (x << k) | 
 // md[0..32), nonce 1..8, 64-bit block counter, 800 bytes, each word stored byte-swapped (salsa20.c:93); omega distinct positions
 // from big-endian byte pairs.  mode 0 (sign): writes md and c.  mode 1 (verify): c comes from the signature's digest (sigmd) and
 // the recomputed md is compared with it.
-__global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+__global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
                                                        uint32_t fixed_len, const int32_t *r1, const int32_t *r2, const uint32_t *nz, const uint64_t *zstate, uint32_t zblocks,
                                                        uint8_t *md_out, int mode, uint32_t *verdict, const uint8_t *sigs, size_t sig_stride, uint32_t md_off, TsP P)
 {
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, u
     Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
     if (aidx >= nact) return;
     if (need && need[aidx] == 2) return;
-    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t item = active ? active[aidx / S] : aidx / S;        // aidx counts slots here
     const uint32_t mlen = mlens ? mlens[item] : fixed_len;
     const int n = P.n;
     if (nz[aidx] == 0) {
@@ -198,61 +203,84 @@ __device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
     return left > d_sub - P.bound;
 }
 
-// one wavefront per message (ring_tesla.c:852-900): w1 = v1 - e1*c, w2 = v2 - e2*c normalised and tested, z = y + s*c centred and
-// tested, packing.  v1, v2 are canonical products; the key polynomials sit in LDS.
-__global__ __launch_bounds__(256) void ts_decide_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, St s, const int16_t *key, const int32_t *v1, const int32_t *v2,
-                                                        const int32_t *y, const int32_t *cidx, const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens,
-                                                        uint32_t *next_active, uint32_t *next_count, TsP P)
+// one wavefront per slot (ring_tesla.c:852-880): w1 = v1 - e1*c, w2 = v2 - e2*c normalised and tested, z = y + s*c centred and
+// tested.  v1, v2 are canonical products; the key polynomials sit in LDS.  acc[slot] = 1 and z[slot] are left for the selection.
+__global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const uint32_t *need, const int16_t *key, const int32_t *v1, const int32_t *v2,
+                                                        const int32_t *y, const int32_t *cidx, int32_t *zout, uint32_t *acc, TsP P)
 {
     extern __shared__ int16_t ks[];                                    // s | e1 | e2
     const int n = P.n;
     for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) ks[i] = key[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (aidx >= nact) return;
-    if (need[aidx] == 2) return;
-    const uint32_t item = active ? active[aidx] : aidx;
-    const int32_t *c = cidx + (size_t)aidx * P.omega;
+    const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= nslots) return;
+    if (need[slot] == 2) { if (lane == 0) acc[slot] = 0; return; }
+    const int32_t *c = cidx + (size_t)slot * P.omega;
     int32_t bad = 0;
     for (int j = lane; j < n; j += 64) {
-        const size_t k = (size_t)aidx * n + j;
+        const size_t k = (size_t)slot * n + j;
         const int32_t a = norm_q(centre_q(v1[k], P.q) - sparse_at(ks + n, c, P.omega, n, j), P.q);
         const int32_t b = norm_q(centre_q(v2[k], P.q) - sparse_at(ks + 2 * n, c, P.omega, n, j), P.q);
         bad |= (w_bad(a, P) || w_bad(b, P)) ? 1 : 0;
     }
     bad = wave_or(bad);
     const int32_t th = P.b - P.u;
-    uint8_t *out = sigs + (size_t)item * sig_stride;
     if (!bad) {
         for (int j = lane; j < n; j += 64) {
-            const int32_t z = centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
+            const size_t k = (size_t)slot * n + j;
+            const int32_t z = centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[k], P.q), P.q);
+            zout[k] = z;
             bad |= (z < -th || z > th) ? 1 : 0;
         }
         bad = wave_or(bad);
     }
-    if (bad) {
-        if (lane == 0) next_active[atomicAdd(next_count, 1u)] = item;
+    if (lane == 0) acc[slot] = bad ? 0u : 1u;
+}
+
+// one wavefront per active message: the lowest accepted slot becomes the signature (z: q_bits-bit two's complement MSB first -
+// three bytes per coefficient for q_bits = 24 - then the digest, ring_tesla.c:882-900); a slot beyond the end of the tape before
+// any acceptance ends the message with status 2; otherwise the message goes to the next round S attempts further on.
+__global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint32_t *acc, St s, const int32_t *zs,
+                                                        const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
+                                                        uint32_t *next_active, uint32_t *next_count, TsP P)
+{
+    const int lane = threadIdx.x & 63, n = P.n;
+    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    uint32_t win = S, dead = S;                                      // first accepted slot / first slot past the tape
+    for (uint32_t k = 0; k < S; k++) {
+        const uint32_t slot = aidx * S + k;
+        if (need[slot] == 2) { dead = k; break; }
+        if (acc[slot]) { win = k; break; }
+    }
+    if (win == S) {
+        if (lane == 0) {
+            if (dead < S) { trials[item] += dead; s.pos[item] += dead * (uint32_t)n; s.status[item] = 2; siglens[item] = 0; }
+            else { trials[item] += S; s.pos[item] += S * (uint32_t)n; next_active[atomicAdd(next_count, 1u)] = item; }
+        }
         return;
     }
-    // z: q_bits-bit two's complement, MSB first (q_bits = 24 for set 0: three bytes per coefficient), then the digest
+    const uint32_t slot = aidx * S + win;
+    const int32_t *z = zs + (size_t)slot * n;
+    uint8_t *out = sigs + (size_t)item * sig_stride;
     if (P.q_bits == 24) {
         for (int j = lane; j < n; j += 64) {
-            const uint32_t z = (uint32_t)centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
-            out[3 * j] = (uint8_t)(z >> 16); out[3 * j + 1] = (uint8_t)(z >> 8); out[3 * j + 2] = (uint8_t)z;
+            const uint32_t v = (uint32_t)z[j];
+            out[3 * j] = (uint8_t)(v >> 16); out[3 * j + 1] = (uint8_t)(v >> 8); out[3 * j + 2] = (uint8_t)v;
         }
     } else if (lane == 0) {
-        uint64_t acc = 0; int nb = 0; uint32_t w = 0;
+        uint64_t a = 0; int nb = 0; uint32_t w = 0;
         for (int j = 0; j < n; j++) {
-            const uint32_t z = (uint32_t)centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[(size_t)aidx * n + j], P.q), P.q);
-            acc = (acc << P.q_bits) | (z & ((1u << P.q_bits) - 1u)); nb += P.q_bits;
-            while (nb >= 8) { out[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+            a = (a << P.q_bits) | ((uint32_t)z[j] & ((1u << P.q_bits) - 1u)); nb += P.q_bits;
+            while (nb >= 8) { out[w++] = (uint8_t)(a >> (nb - 8)); nb -= 8; }
         }
-        if (nb) out[w++] = (uint8_t)(acc << (8 - nb));
+        if (nb) out[w++] = (uint8_t)(a << (8 - nb));
     }
     const uint32_t zb = ((uint32_t)n * P.q_bits + 7) / 8;
-    out[zb + lane] = md[(size_t)aidx * 64 + lane];
-    if (lane == 0) { siglens[item] = zb + 64; s.status[item] = 1; }
+    out[zb + lane] = md[(size_t)slot * 64 + lane];
+    if (lane == 0) { siglens[item] = zb + 64; s.status[item] = 1; trials[item] += win + 1; s.pos[item] += (win + 1) * (uint32_t)n; }
 }
 
 // ---- verify ---------------------------------------------------------------------------------------------------------------
@@ -303,33 +331,36 @@ struct sc_hip_tesla {
     int32_t *d_a1, *d_a2, *d_t1, *d_t2;
     int16_t *d_key;                      // s | e1 | e2
     uint64_t *d_zstate; uint32_t zblocks;
-    size_t cap;
+    size_t cap, slot_cap;                // messages / slots (attempts evaluated side by side) the workspace holds
     St st;
-    uint32_t *act[2], *cnt, *need, *sbase, *nz, *trials;
-    int32_t *y, *v1, *v2, *r1, *r2, *cidx;
+    uint32_t *act[2], *cnt, *need, *sbase, *nz, *trials, *acc;
+    int32_t *y, *v1, *v2, *r1, *r2, *cidx, *zs;
     uint8_t *md;
 };
 
 static void ts_free_ws(sc_hip_tesla *t)
 {
-    void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->need, t->sbase, t->nz, t->trials, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->md };
+    void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->need, t->sbase, t->nz, t->trials, t->acc, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->zs, t->md };
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->need = t->sbase = t->nz = t->trials = nullptr;
-    t->y = t->v1 = t->v2 = t->r1 = t->r2 = t->cidx = nullptr; t->md = nullptr; t->cap = 0;
+    t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->need = t->sbase = t->nz = t->trials = t->acc = nullptr;
+    t->y = t->v1 = t->v2 = t->r1 = t->r2 = t->cidx = t->zs = nullptr; t->md = nullptr; t->cap = t->slot_cap = 0;
 }
 
-static int ts_ensure_ws(sc_hip_tesla *t, size_t batch)
+// per-message state for `batch` messages, per-attempt arrays for `slots` attempts (slots >= batch)
+static int ts_ensure_ws(sc_hip_tesla *t, size_t batch, size_t slots)
 {
-    if (batch <= t->cap) return SC_HIP_SUCCESS;
+    if (batch <= t->cap && slots <= t->slot_cap) return SC_HIP_SUCCESS;
+    if (batch < t->cap) batch = t->cap;
+    if (slots < t->slot_cap) slots = t->slot_cap;
     ts_free_ws(t);
     const size_t n = t->P.n;
 #define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
-    WS(t->st.pos, batch * 4); WS(t->st.status, batch * 4); WS(t->act[0], batch * 4); WS(t->act[1], batch * 4); WS(t->cnt, 64); WS(t->need, batch * 4); WS(t->sbase, batch * 4);
-    WS(t->nz, batch * 4); WS(t->trials, batch * 4);
-    WS(t->y, batch * n * 4); WS(t->v1, batch * n * 4); WS(t->v2, batch * n * 4); WS(t->r1, batch * n * 4); WS(t->r2, batch * n * 4);
-    WS(t->cidx, batch * (size_t)t->P.omega * 4); WS(t->md, batch * 64);
+    WS(t->st.pos, batch * 4); WS(t->st.status, batch * 4); WS(t->act[0], batch * 4); WS(t->act[1], batch * 4); WS(t->cnt, 64); WS(t->trials, batch * 4);
+    WS(t->need, slots * 4); WS(t->sbase, slots * 4); WS(t->nz, slots * 4); WS(t->acc, slots * 4);
+    WS(t->y, slots * n * 4); WS(t->v1, slots * n * 4); WS(t->v2, slots * n * 4); WS(t->r1, slots * n * 4); WS(t->r2, slots * n * 4); WS(t->zs, slots * n * 4);
+    WS(t->cidx, slots * (size_t)t->P.omega * 4); WS(t->md, slots * 64);
 #undef WS
-    t->cap = batch;
+    t->cap = batch; t->slot_cap = slots;
     return SC_HIP_SUCCESS;
 }
 
@@ -410,7 +441,9 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
     if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_sign: sig_stride smaller than sc_hip_tesla_sig_bytes()");
     if (tape_stride > 0xffffffffu) return fail("tesla_sign: tape too long");
     HIPCHK(hipSetDevice(t->ctx->device));
-    if (ts_ensure_ws(t, batch)) return SC_HIP_FAILURE;
+    size_t slot_target = batch * 2;                                    // two attempts per message while the whole batch is active
+    if (slot_target < 4096) slot_target = 4096;
+    if (ts_ensure_ws(t, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const TsP &P = t->P;
     const int n = P.n;
@@ -422,20 +455,24 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
     const uint32_t *active = nullptr;
     for (uint32_t round = 0; nact > 0; round++) {
         if (round >= 9999) break;                                       // the reference's own cap (ring_tesla.c:814); leftovers keep status 0
+        uint32_t S = (uint32_t)(t->slot_cap / nact);
+        if (S > 32) S = 32;
+        if (S < 1) S = 1;
+        const uint32_t nslots = nact * S;
         uint32_t *next = t->act[round & 1];
         HIPCHK(hipMemsetAsync(t->cnt, 0, 4, s));
-        hipLaunchKernelGGL(ts_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, d_siglens, trials, n);
-        const size_t ne = (size_t)nact * n;
-        hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, t->need, t->sbase, d_tapes, tape_stride, t->y, P);
+        hipLaunchKernelGGL(ts_begin_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nslots, S, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, n);
+        const size_t ne = (size_t)nslots * n;
+        hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P);
         HIPCHK(hipGetLastError());
-        if (sc::polymul_ntt_bcast(t->plan, nact, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
-        if (sc::polymul_ntt_bcast(t->plan, nact, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(ts_round_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, nact, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P);
-        hipLaunchKernelGGL(ts_oracle_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
+        if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
+        if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(ts_round_kernel, dim3((nslots + 3) / 4), dim3(256), 0, s, nslots, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P);
+        hipLaunchKernelGGL(ts_oracle_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, active, nslots, S, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                            t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P);
-        hipLaunchKernelGGL(ts_f_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P);
-        hipLaunchKernelGGL(ts_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, active, nact, t->need, st, t->d_key, t->v1, t->v2, t->y, t->cidx, t->md,
-                           d_sigs, sig_stride, d_siglens, next, t->cnt, P);
+        hipLaunchKernelGGL(ts_f_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, nslots, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P);
+        hipLaunchKernelGGL(ts_decide_kernel, dim3((nslots + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, nslots, t->need, t->d_key, t->v1, t->v2, t->y, t->cidx, t->zs, t->acc, P);
+        hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P);
         HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, t->cnt, 4, hipMemcpyDeviceToHost, s));
@@ -457,7 +494,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("tesla_verify: null buffer");
     if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_verify: sig_stride smaller than sc_hip_tesla_sig_bytes()");
     HIPCHK(hipSetDevice(t->ctx->device));
-    if (ts_ensure_ws(t, batch)) return SC_HIP_FAILURE;
+    if (ts_ensure_ws(t, batch, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const TsP &P = t->P;
     const uint32_t B = (uint32_t)batch;
@@ -470,7 +507,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P);
     hipLaunchKernelGGL(ts_round_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->r1, t->r2, t->nz, 0, P);
-    hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
+    hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, 1u, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                        t->d_zstate, t->zblocks, (uint8_t *)nullptr, 1, d_verdicts, d_sigs, sig_stride, md_off, P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
