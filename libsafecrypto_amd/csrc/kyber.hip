@@ -157,43 +157,51 @@ __global__ __launch_bounds__(KHT) void ky_h_kernel(uint32_t batch, const uint8_t
     for (int b = 0; b < 32; b++) o[b] = sp.squeeze_byte();
 }
 
-// ciphertext byte j of message i: u (d_u bits each) | v (d_v bits each), MSB first, then d (kyber_kem.c:888-896)
+// ciphertext = u (d_u bits per coefficient) | v (d_v bits) MSB first, then d (kyber_kem.c:888-896).  Eight coefficients of
+// width d are exactly d bytes: one lane packs one such group (u groups first, then v groups, then the 32 bytes of d by the
+// last 32 lanes of the message's range).
 __global__ void ky_pack_kernel(uint32_t batch, const int32_t *__restrict__ u, const int32_t *__restrict__ v, const uint8_t *__restrict__ krd, uint8_t *__restrict__ ct, size_t ct_stride, KyP P)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ubits = (uint32_t)(P.k * P.n * P.d_u), vbits = (uint32_t)(P.n * P.d_v), body = (ubits + vbits) / 8, per = body + 32;
+    const uint32_t ug = (uint32_t)(P.k * P.n / 8), vg = (uint32_t)(P.n / 8), per = ug + vg + 32;
     const uint32_t i = (uint32_t)(t / per), j = (uint32_t)(t % per);
     if (i >= batch) return;
-    uint8_t out;
-    if (j >= body) out = krd[(size_t)i * 96 + 64 + (j - body)];
-    else {
-        uint32_t acc = 0;
-        for (int b = 0; b < 8; b++) {
-            const uint32_t bp = 8 * j + b;
-            uint32_t bit;
-            if (bp < ubits) { const uint32_t c = bp / P.d_u, k = bp % P.d_u; bit = ((uint32_t)u[(size_t)i * P.k * P.n + c] >> (P.d_u - 1 - k)) & 1u; }
-            else { const uint32_t q = bp - ubits, c = q / P.d_v, k = q % P.d_v; bit = ((uint32_t)v[(size_t)i * P.n + c] >> (P.d_v - 1 - k)) & 1u; }
-            acc = (acc << 1) | bit;
-        }
-        out = (uint8_t)acc;
+    uint8_t *out = ct + (size_t)i * ct_stride;
+    const uint32_t ubytes = ug * (uint32_t)P.d_u, vbytes = vg * (uint32_t)P.d_v;
+    if (j >= ug + vg) { const uint32_t b = j - ug - vg; out[ubytes + vbytes + b] = krd[(size_t)i * 96 + 64 + b]; return; }
+    const bool isu = j < ug;
+    const int d = isu ? P.d_u : P.d_v;
+    const int32_t *src = isu ? u + (size_t)i * P.k * P.n + (size_t)j * 8 : v + (size_t)i * P.n + (size_t)(j - ug) * 8;
+    uint8_t *o = out + (isu ? (size_t)j * d : (size_t)ubytes + (size_t)(j - ug) * d);
+    const int4 lo = *reinterpret_cast<const int4 *>(src), hi = *reinterpret_cast<const int4 *>(src + 4);
+    const uint32_t c[8] = { (uint32_t)lo.x, (uint32_t)lo.y, (uint32_t)lo.z, (uint32_t)lo.w, (uint32_t)hi.x, (uint32_t)hi.y, (uint32_t)hi.z, (uint32_t)hi.w };
+    uint32_t acc = 0; int nb = 0, w = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        acc = (acc << d) | (c[e] & ((1u << d) - 1u)); nb += d;
+        while (nb >= 8) { o[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
     }
-    ct[(size_t)i * ct_stride + j] = out;
 }
 
-// kyber_kem.c:976-983: coefficient e of message i from the packed ciphertext
+// kyber_kem.c:976-983: one lane unpacks the d bytes of a group of eight coefficients
 __global__ void ky_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ ct, size_t ct_stride, int32_t *__restrict__ u, int32_t *__restrict__ v, KyP P)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = (P.k + 1) * P.n;
-    const uint32_t i = (uint32_t)(t / per); const int e = (int)(t % per);
+    const uint32_t ug = (uint32_t)(P.k * P.n / 8), vg = (uint32_t)(P.n / 8), per = ug + vg;
+    const uint32_t i = (uint32_t)(t / per), j = (uint32_t)(t % per);
     if (i >= batch) return;
-    const uint8_t *s = ct + (size_t)i * ct_stride;
-    const int kn = P.k * P.n;
-    const int bits = e < kn ? P.d_u : P.d_v;
-    const uint32_t off = e < kn ? (uint32_t)e * P.d_u : (uint32_t)kn * P.d_u + (uint32_t)(e - kn) * P.d_v;
-    uint32_t val = 0;
-    for (int b = 0; b < bits; b++) { const uint32_t bp = off + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
-    if (e < kn) u[(size_t)i * kn + e] = (int32_t)val; else v[(size_t)i * P.n + (e - kn)] = (int32_t)val;
+    const bool isu = j < ug;
+    const int d = isu ? P.d_u : P.d_v;
+    const uint8_t *src = ct + (size_t)i * ct_stride + (isu ? (size_t)j * d : (size_t)ug * P.d_u + (size_t)(j - ug) * d);
+    int32_t *dst = isu ? u + (size_t)i * P.k * P.n + (size_t)j * 8 : v + (size_t)i * P.n + (size_t)(j - ug) * 8;
+    uint32_t acc = 0, c[8]; int nb = 0, r = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        while (nb < d) { acc = (acc << 8) | src[r++]; nb += 8; }
+        c[e] = (acc >> (nb - d)) & ((1u << d) - 1u); nb -= d;
+    }
+    *reinterpret_cast<int4 *>(dst) = make_int4((int32_t)c[0], (int32_t)c[1], (int32_t)c[2], (int32_t)c[3]);
+    *reinterpret_cast<int4 *>(dst + 4) = make_int4((int32_t)c[4], (int32_t)c[5], (int32_t)c[6], (int32_t)c[7]);
 }
 
 }  // namespace
@@ -428,7 +436,7 @@ extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const ui
     const uint32_t B = (uint32_t)batch;
     if (ky_kem_core(h, batch, d_m, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
-    const size_t nb = batch * sc_hip_kyber_ct_bytes(h);
+    const size_t nb = batch * (size_t)((h->P.k + 1) * N / 8 + 32);
     hipLaunchKernelGGL(ky_pack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
@@ -446,7 +454,7 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
     if (ky_kem_ensure(h, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t B = (uint32_t)batch;
-    const size_t ne = batch * (size_t)(h->P.k + 1) * N;
+    const size_t ne = batch * (size_t)((h->P.k + 1) * N / 8);
     hipLaunchKernelGGL(ky_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, h->ku, h->kv, h->P);
     HIPCHK(hipGetLastError());
     if (sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
