@@ -217,14 +217,20 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
     if (slot >= nslots) return;
     if (need[slot] == 2) { if (lane == 0) acc[slot] = 0; return; }
     const int32_t *c = cidx + (size_t)slot * P.omega;
+    // the reference tests w1, then w2, then z and leaves at the first failure (ring_tesla.c:852-880): so does the wavefront
     int32_t bad = 0;
     for (int j = lane; j < n; j += 64) {
-        const size_t k = (size_t)slot * n + j;
-        const int32_t a = norm_q(centre_q(v1[k], P.q) - sparse_at(ks + n, c, P.omega, n, j), P.q);
-        const int32_t b = norm_q(centre_q(v2[k], P.q) - sparse_at(ks + 2 * n, c, P.omega, n, j), P.q);
-        bad |= (w_bad(a, P) || w_bad(b, P)) ? 1 : 0;
+        const int32_t a = norm_q(centre_q(v1[(size_t)slot * n + j], P.q) - sparse_at(ks + n, c, P.omega, n, j), P.q);
+        bad |= w_bad(a, P) ? 1 : 0;
     }
     bad = wave_or(bad);
+    if (!bad) {
+        for (int j = lane; j < n; j += 64) {
+            const int32_t b = norm_q(centre_q(v2[(size_t)slot * n + j], P.q) - sparse_at(ks + 2 * n, c, P.omega, n, j), P.q);
+            bad |= w_bad(b, P) ? 1 : 0;
+        }
+        bad = wave_or(bad);
+    }
     const int32_t th = P.b - P.u;
     if (!bad) {
         for (int j = lane; j < n; j += 64) {
@@ -298,7 +304,8 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const ui
     int32_t bad = 0;
     for (int j = lane; j < n; j += 64) {
         uint32_t val = 0;
-        for (int b = 0; b < P.q_bits; b++) { const uint32_t bp = (uint32_t)j * P.q_bits + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+        if (P.q_bits == 24) val = ((uint32_t)s[3 * j] << 16) | ((uint32_t)s[3 * j + 1] << 8) | s[3 * j + 2];
+        else for (int b = 0; b < P.q_bits; b++) { const uint32_t bp = (uint32_t)j * P.q_bits + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
         const int32_t zz = (int32_t)(val << (32 - P.q_bits)) >> (32 - P.q_bits);
         z[(size_t)item * n + j] = zz;
         bad |= (zz < -th || zz > th) ? 1 : 0;
