@@ -259,37 +259,53 @@ __global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint3
     if (bad) verdict[item] = 1;
 }
 
-__global__ __launch_bounds__(HT) void dil_unpack_tail_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
-                                                             uint8_t *h, int32_t *c, uint32_t *verdict, DilP P)
+// the tail of a signature (dilithium.c:2085-2123): omega_bits count, `count` hint positions of h_bits each, then c as n 2-bit
+// codes (3 = -1).  One wavefront per signature: every field has a fixed width, so lane i reads hint i and four codes of c; the
+// number of DISTINCT hint positions (what the reference's "cnt += h[p] == 0; h[p] = 1" loop counts) comes from an LDS bitmap.
+__global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
+                                                              uint8_t *h, int32_t *c, uint32_t *verdict, DilP P)
 {
-    const uint32_t item = blockIdx.x * HT + threadIdx.x;
+    __shared__ uint32_t seen[4][64];                                   // k*n <= 2048 hint positions per signature
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t item = blockIdx.x * 4 + wv;
     if (item >= count) return;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
     const uint8_t *s = sigs + (size_t)item * sig_stride;
     const uint32_t total = siglens[item] * 8;
-    uint32_t pos = (uint32_t)(P.l * P.n * P.z_bits);
-    bool err = total < pos;
-    auto get = [&](int bits) -> uint32_t {
-        uint32_t v = 0;
-        for (int b = 0; b < bits; b++) {
-            if (pos >= total) { err = true; return 0; }
-            v = (v << 1) | ((s[pos >> 3] >> (7 - (pos & 7))) & 1u);
-            pos++;
-        }
-        return v;
+    const uint32_t zbits = (uint32_t)(P.l * P.n * P.z_bits);
+    auto get = [&](uint32_t pos, int bits) -> uint32_t {                // bits <= 16, the caller has checked pos + bits <= total
+        const uint32_t b0 = pos >> 3;
+        const uint32_t w = ((uint32_t)s[b0] << 16) | ((uint32_t)(b0 + 1 < sig_stride ? s[b0 + 1] : 0) << 8) | (b0 + 2 < sig_stride ? s[b0 + 2] : 0);
+        return (w >> (24 - (pos & 7) - bits)) & ((1u << bits) - 1u);
     };
     uint8_t *hh = h + (size_t)item * kn;
-    for (int i = 0; i < kn; i++) hh[i] = 0;
-    uint32_t no = err ? 0 : get(P.omega_bits), cnt = 0;
-    for (uint32_t i = 0; i < no && !err; i++) {
-        const uint32_t p = get(h_bits);
-        if (p >= (uint32_t)kn) { err = true; break; }          // the reference writes h[p] unchecked; out-of-range = invalid
-        cnt += (hh[p] == 0);
-        hh[p] = 1;
+    for (int i = lane * 16; i < kn; i += 64 * 16) *reinterpret_cast<uint4 *>(hh + i) = make_uint4(0, 0, 0, 0);
+    seen[wv][lane] = 0;
+    bool err = total < zbits + (uint32_t)P.omega_bits;
+    const uint32_t no = err ? 0 : get(zbits, P.omega_bits);
+    const uint32_t hbase = zbits + (uint32_t)P.omega_bits, cbase = hbase + no * (uint32_t)h_bits;
+    if (!err && total < cbase + 2u * (uint32_t)P.n) err = true;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t fresh = 0, oob = 0;
+    if (!err) {
+        for (uint32_t i = lane; i < no; i += 64) {
+            const uint32_t p = get(hbase + i * (uint32_t)h_bits, h_bits);
+            if (p >= (uint32_t)kn) { oob = 1; continue; }                // the reference writes h[p] unchecked; out-of-range = invalid
+            const uint32_t bit = 1u << (p & 31), old = atomicOr(&seen[wv][p >> 5], bit);
+            fresh += (old & bit) ? 0u : 1u;
+            hh[p] = 1;
+        }
     }
+    for (int o = 32; o > 0; o >>= 1) { fresh += (uint32_t)__shfl_xor((int)fresh, o); oob |= (uint32_t)__shfl_xor((int)oob, o); }
     int32_t *ci = c + (size_t)item * P.n;
-    for (int i = 0; i < P.n; i++) { const uint32_t v = err ? 0 : get(2); ci[i] = (v == 3) ? -1 : (int32_t)v; }
-    if (err || cnt > (uint32_t)P.omega) verdict[item] = 1;     // check_hint_ones (dilithium.c:2119-2123)
+    for (int i = lane * 4; i < P.n; i += 256) {
+        const uint32_t v = err ? 0u : get(cbase + 2u * (uint32_t)i, 8);
+        int32_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) { const uint32_t t = (v >> (6 - 2 * e)) & 3u; o4[e] = (t == 3) ? -1 : (int32_t)t; }
+        *reinterpret_cast<int4 *>(ci + i) = make_int4(o4[0], o4[1], o4[2], o4[3]);
+    }
+    if (lane == 0 && (err || oob || fresh > (uint32_t)P.omega)) verdict[item] = 1;     // check_hint_ones (dilithium.c:2119-2123)
 }
 
 }  // namespace
@@ -598,7 +614,7 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
     hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
                        (uint32_t)(P.gamma1 - P.beta), d_verdicts);
-    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3(hb), dim3(HT), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
+    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
     hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
