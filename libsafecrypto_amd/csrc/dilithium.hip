@@ -169,47 +169,65 @@ __global__ void dil_slots_kernel(const uint32_t *active, uint32_t nact, uint32_t
 // accept / reject (dilithium.c:1655-1725) over the S speculative attempts of a message, lowest kappa first, + the
 // signature tail of the accepted attempt: num_ones, hint positions, c (2 bits each) (dilithium.c:1926-1945).
 // Messages with no accepted attempt advance kappa by S and go to the next round's list.
-__global__ __launch_bounds__(HT) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
-                                                        int32_t *acc_slot, const uint8_t *h, const int32_t *c,
-                                                        uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, DilP P)
+// One wavefront per active message.  The tail (count, hint positions in ascending order, c) is assembled MSB-first in LDS as
+// big-endian 32-bit words - every field's bit offset follows from a prefix sum of the per-lane hint counts - and leaves as bytes.
+__global__ __launch_bounds__(256) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
+                                                         int32_t *acc_slot, const uint8_t *h, const int32_t *c,
+                                                         uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
+                                                         uint32_t *next_active, uint32_t *next_count, DilP P)
 {
-    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    __shared__ uint32_t tail[4][128];                                  // <= omega_bits + omega*h_bits + 2n bits = 4096 bits
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t aidx = blockIdx.x * 4 + wv;
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     int found = -1;
-    for (uint32_t a = 0; a < S; a++) {
+    for (uint32_t a = 0; a < S; a++) {                                 // every lane walks the (few) slots: same answer, no broadcast
         const uint32_t slot = aidx * S + a;
         if (found < 0 && flags[slot] == 0 && ones[slot] <= (uint32_t)P.omega) found = (int)a;
-        if (found != (int)a) { flags[slot] = 0; ones[slot] = 0; }
     }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t no = 0;
+    if (found >= 0) no = ones[aidx * S + (uint32_t)found];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (uint32_t a = lane; a < S; a += 64) { flags[aidx * S + a] = 0; ones[aidx * S + a] = 0; }     // leave the per-slot accumulators clean
     if (found < 0) {
-        acc_slot[aidx] = -1;
-        kappa[item] += S;
-        next_active[atomicAdd(next_count, 1u)] = item;
+        if (lane == 0) { acc_slot[aidx] = -1; kappa[item] += S; next_active[atomicAdd(next_count, 1u)] = item; }
         return;
     }
     const uint32_t slot = aidx * S + (uint32_t)found;
-    const uint32_t no = ones[slot];
-    flags[slot] = 0; ones[slot] = 0;
-    acc_slot[aidx] = (int32_t)slot;
-    trials[item] = kappa[item] + (uint32_t)found + 1;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
-    BitW bw{ sigs + (size_t)item * sig_stride, (uint32_t)(P.l * P.n * P.z_bits / 8), 0, 0 };
-    bw.put(no, P.omega_bits);
-    const uint64_t *hh = reinterpret_cast<const uint64_t *>(h + (size_t)slot * kn);      // kn is a multiple of 8
-    for (int w = 0; w < kn / 8; w++) {
-        uint64_t v = hh[w];
-        while (v) {
-            const int b = __ffsll((long long)v) - 1;                   // bytes are 0 or 1: bit 8*i of the word = h[8w+i]
-            bw.put((uint32_t)(8 * w + (b >> 3)), h_bits);
-            v &= v - 1;
-        }
-    }
+    uint32_t *tw = tail[wv];
+    tw[lane] = 0; tw[lane + 64] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    auto put = [&](uint32_t off, uint32_t v, int bits) {                // bits <= 16: at most two words
+        const uint32_t w = off >> 5; const int sh = 32 - (int)(off & 31) - bits;
+        if (sh >= 0) atomicOr(&tw[w], v << sh);
+        else { atomicOr(&tw[w], v >> (-sh)); atomicOr(&tw[w + 1], v << (32 + sh)); }
+    };
+    if (lane == 0) put(0, no, P.omega_bits);
+    // hints: lane owns bytes [lane*chunk, (lane+1)*chunk) of h; positions go out in ascending order
+    const int chunk = kn / 64;                                          // kn = k*256
+    const uint8_t *hh = h + (size_t)slot * kn + (size_t)lane * chunk;
+    uint32_t mine = 0;
+    for (int i = 0; i < chunk; i++) mine += hh[i];
+    uint32_t incl = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+    uint32_t rank = incl - mine;
+    for (int i = 0; i < chunk; i++)
+        if (hh[i]) { put((uint32_t)P.omega_bits + rank * (uint32_t)h_bits, (uint32_t)(lane * chunk + i), h_bits); rank++; }
+    const uint32_t cbase = (uint32_t)P.omega_bits + no * (uint32_t)h_bits;
     const int32_t *ci = c + (size_t)slot * P.n;
-    for (int i = 0; i < P.n; i++) bw.put((uint32_t)ci[i], 2);
-    bw.flush();
-    siglens[item] = bw.nbytes;
+    for (int i = lane * 4; i < P.n; i += 256) {
+        const int4 v = *reinterpret_cast<const int4 *>(ci + i);
+        const uint32_t b = (((uint32_t)v.x & 3u) << 6) | (((uint32_t)v.y & 3u) << 4) | (((uint32_t)v.z & 3u) << 2) | ((uint32_t)v.w & 3u);
+        put(cbase + 2u * (uint32_t)i, b, 8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t tbits = cbase + 2u * (uint32_t)P.n, tbytes = (tbits + 7) / 8, zbytes = (uint32_t)(P.l * P.n * P.z_bits / 8);
+    uint8_t *out = sigs + (size_t)item * sig_stride + zbytes;
+    for (uint32_t i = lane; i < tbytes; i += 64) out[i] = (uint8_t)(tw[i >> 2] >> (24 - 8 * (i & 3)));
+    if (lane == 0) { acc_slot[aidx] = (int32_t)slot; trials[item] = kappa[item] + (uint32_t)found + 1; siglens[item] = zbytes + tbytes; }
 }
 
 // z part of the signature of the messages accepted this round: centre (ntt32_center) and raw z_bits per coefficient,
@@ -575,7 +593,7 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
         a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
         a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
         a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
+        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
                            d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
         HIPCHK(hipGetLastError());
         const size_t zthreads = (size_t)nact * (size_t)(l * P.n / 2);
