@@ -89,15 +89,28 @@ __global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *slot_ite
     const uint32_t thresh = (uint32_t)(2 * gamma1 - 2);
     const int32_t add = q + gamma1 - 1;
     int32_t *yy = y + (size_t)aidx * limit;
+    // The 5-byte groups of the reference (two 20-bit samples: b0 | b1<<8 | (b2&15)<<16 and b2>>4 | b3<<4 | b4<<12, module_lwe.c:218-236)
+    // are consecutive 20-bit fields of the squeezed stream read as a little-endian bit string.  The 17 words of a block are
+    // taken from the state in one go and fed through a bit buffer 32 bits at a time - no per-byte LDS round trip.
     int j = 0;
+    uint64_t buf = 0; int nb = 0;
     while (j < limit) {
-        uint32_t s0 = sp.squeeze_byte(); s0 |= (uint32_t)sp.squeeze_byte() << 8;
-        const uint32_t b2 = sp.squeeze_byte();
-        s0 |= (b2 & 0xF) << 16;
-        uint32_t s1 = b2 >> 4; s1 |= (uint32_t)sp.squeeze_byte() << 4; s1 |= (uint32_t)sp.squeeze_byte() << 12;
-        if (s0 < thresh) yy[j++] = add - (int32_t)s0;
-        if (j == limit) break;
-        if (s1 < thresh) yy[j++] = add - (int32_t)s1;
+        uint64_t blk[17];
+#pragma unroll
+        for (int w = 0; w < 17; w++) blk[w] = sp.st[w * HT];
+#pragma unroll
+        for (int w = 0; w < 17; w++) {
+#pragma unroll
+            for (int hlf = 0; hlf < 2; hlf++) {
+                buf |= (uint64_t)(uint32_t)(blk[w] >> (32 * hlf)) << nb; nb += 32;
+                while (nb >= 20) {
+                    const uint32_t smp = (uint32_t)buf & 0xFFFFFu;
+                    buf >>= 20; nb -= 20;
+                    if (smp < thresh && j < limit) yy[j++] = add - (int32_t)smp;
+                }
+            }
+        }
+        if (j < limit) sp.permute();
     }
 }
 
