@@ -524,12 +524,19 @@ __global__ __launch_bounds__(HT) void fal_hash_kernel(uint32_t batch, const uint
     sp.finalize(0x1F);
     const uint32_t mask = (1u << P.q_bits) - 1u, q = (uint32_t)P.q;
     int32_t *cb = c + (size_t)b * P.n;
-    for (int i = 0; i < P.n; i++) {
-        uint32_t y = sp.squeeze_byte();
-        y |= (uint32_t)sp.squeeze_byte() << 8; y |= (uint32_t)sp.squeeze_byte() << 16; y |= (uint32_t)sp.squeeze_byte() << 24;
+    auto map = [&](uint32_t y) -> int32_t {
         y &= mask;
         y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
-        cb[i] = (int32_t)y;
+        return (int32_t)y;
+    };
+    // the 168-byte rate is 21 state words = 42 little-endian 32-bit draws per permutation, read straight from the state
+    for (int i = 0; i < P.n;) {
+#pragma unroll 1
+        for (int w = 0; w < 21 && i < P.n; w++, i += 2) {
+            const uint64_t v = sp.st[w * HT];
+            *reinterpret_cast<int2 *>(cb + i) = make_int2(map((uint32_t)v), map((uint32_t)(v >> 32)));
+        }
+        if (i < P.n) sp.permute();
     }
 }
 
