@@ -273,17 +273,36 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     maxt = wave_max(maxt); maxz = wave_max(maxz); nt = wave_sum(nt); nz = wave_sum(nz);
     if (maxt > P.b_inf || (maxz << P.d) > P.b_inf || nt + (nz << (2 * P.d)) > P.b_l2) { reject(); return; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-        BitW bw{ sigs + (size_t)item * sig_stride, 0, 0, 0 };
+    uint8_t *out = sigs + (size_t)item * sig_stride;
+    if (P.z1_bits == 12 && P.z2_bits == 3) {
+        // BLISS-B-I..IV coding: two 12-bit t coefficients are three bytes, eight 3-bit z coefficients are three bytes - every
+        // lane packs its share; the kappa 9-bit indices (byte aligned start) are left to one lane
+        for (int p = lane; p < n / 2; p += 64) {
+            const uint32_t a = (uint32_t)x[2 * p] & 0xFFFu, b = (uint32_t)x[2 * p + 1] & 0xFFFu;
+            out[3 * p] = (uint8_t)(a >> 4); out[3 * p + 1] = (uint8_t)(((a & 0xFu) << 4) | (b >> 8)); out[3 * p + 2] = (uint8_t)b;
+        }
+        uint8_t *oz = out + n * 12 / 8;
+        for (int gq = lane; gq < n / 8; gq += 64) {
+            uint32_t acc = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc = (acc << 3) | ((uint32_t)y[8 * gq + e] & 7u);
+            oz[3 * gq] = (uint8_t)(acc >> 16); oz[3 * gq + 1] = (uint8_t)(acc >> 8); oz[3 * gq + 2] = (uint8_t)acc;
+        }
+        if (lane == 0) {
+            BitW bw{ out, (uint32_t)(n * 15 / 8), 0, 0 };
+            for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);
+            bw.flush();
+            siglens[item] = bw.nbytes;
+        }
+    } else if (lane == 0) {
+        BitW bw{ out, 0, 0, 0 };
         for (int j = 0; j < n; j++) bw.put((uint32_t)x[j], P.z1_bits);
         for (int j = 0; j < n; j++) bw.put((uint32_t)y[j], P.z2_bits);
         for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);
         bw.flush();
         siglens[item] = bw.nbytes;
-        trials[item] = it + 1;
-        s.status[item] = 1;
-        s.iter[item] = it + 1;
     }
+    if (lane == 0) { trials[item] = it + 1; s.status[item] = 1; s.iter[item] = it + 1; }
 }
 
 // ---- verify -----------------------------------------------------------------------------------------------------------
