@@ -517,6 +517,28 @@ static int kyber_case(FILE *f, int set, int nmsg)
     }
     free(u); free(heap);
     safecrypto_destroy(sc);
+    /* key generation (kyber_kem.c:575-670, module_lwe.c:1189-1266) from a seeded context CSPRNG: everything the key pair holds */
+    for (int kg = 0; kg < 2; kg++) {
+        uint8_t seed[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        safecrypto_t *s2 = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+        if (!s2) return 1;
+        prng_ctx_t *o2 = s2->prng_ctx[0], *mine = seeded_prng(seed, 32);
+        s2->prng_ctx[0] = mine;
+        if (SC_FUNC_SUCCESS != safecrypto_keygen(s2)) return 1;
+        const SINT32 *pv = (const SINT32 *)s2->privkey->key, *pb = (const SINT32 *)s2->pubkey->key;
+        snprintf(name, sizeof name, "%s_kg_seed%d", tag, kg); rec_u8(f, name, seed, 32);
+        snprintf(name, sizeof name, "%s_kg_s_ntt%d", tag, kg); rec_i32(f, name, pv, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_kg_t%d", tag, kg); rec_i32(f, name, pb, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_kg_t_ntt%d", tag, kg); rec_i32(f, name, pb + (size_t)k * n, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_kg_rho%d", tag, kg); rec_u8(f, name, (const UINT8 *)(pb + 2 * (size_t)k * n), 32);
+        snprintf(name, sizeof name, "%s_kg_z%d", tag, kg); rec_u8(f, name, (const UINT8 *)(pv + 3 * (size_t)k * n), 32);
+        int same = !memcmp(pv + (size_t)k * n, pb, sizeof(SINT32) * 2 * (size_t)k * n) && !memcmp((const UINT8 *)(pv + 3 * (size_t)k * n) + 32, pb + 2 * (size_t)k * n, 32);
+        if (!same) return 1;                                      /* the private key repeats t | NTT(t) | rho */
+        s2->prng_ctx[0] = o2;
+        prng_destroy(mine);
+        safecrypto_destroy(s2);
+    }
     return 0;
 }
 

@@ -158,3 +158,17 @@ uint32_t orc_drbg_32(orc_drbg_t *d)
 
 /* prng.c:963-976 */
 uint64_t orc_drbg_64(orc_drbg_t *d) { const uint64_t hi = orc_drbg_32(d); return (hi << 32) | orc_drbg_32(d); }
+
+/* uniform_random_ring_q_csprng (src/utils/arith/module_lwe.c:519-547, n = 256) on create_csprng(rho): polynomial p is the p-th
+ * prng_mem(512): 256 little-endian 16-bit words masked to q_bits, minus q when >= q */
+void orc_expand_matrix(const uint8_t *rho, size_t rho_len, int npoly, int32_t q, int q_bits, int32_t *out)
+{
+    orc_drbg_t *d = orc_drbg_create(rho, rho_len);
+    const int32_t mask = (1 << q_bits) - 1;
+    for (int p = 0; p < npoly; p++) {
+        uint8_t b[512];
+        orc_drbg_mem(d, b, 512);
+        for (int i = 0; i < 256; i++) { int32_t v = (int32_t)((uint32_t)b[2 * i] | ((uint32_t)b[2 * i + 1] << 8)) & mask; v -= (v >= q) * q; out[p * 256 + i] = v; }
+    }
+    orc_drbg_destroy(d);
+}

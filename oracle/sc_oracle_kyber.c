@@ -203,3 +203,36 @@ int orc_kyber_kem_dec(const int32_t *par, const int32_t *s_ntt, const int32_t *t
     free(u);
     return 0;
 }
+
+
+/* kyber_kem_keygen (kyber_kem.c:575-670) over kyber_cpa_keygen (module_lwe.c:1189-1266), with the context CSPRNG seeded by `seed`:
+ * stream = rho block (64 bytes, 32 used) | k noise blocks for s | k noise blocks for e | z block (64 bytes, 32 used).
+ * Outputs as the key pair stores them: s_ntt = centre(NTT(s)); t = normalise(decompress(compress(centre(A s + e), d_t)));
+ * t_ntt = centre(NTT(t)); rho; z. */
+int orc_kyber_keygen(const int32_t *par, const uint8_t *seed, size_t seed_len, int32_t *s_ntt, int32_t *t, int32_t *t_ntt, uint8_t *rho, uint8_t *z)
+{
+    kyp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, k = P.k, q = P.q;
+    int32_t *w = malloc(sizeof(int32_t) * (size_t)n * (2 + 2 * k + k * k)), *r = w + n, *sh = r + n, *e = sh + k * n, *G = e + k * n;
+    uint8_t blk[64], noise[1024];
+    if (orc_make_tables(q, n, w, r)) { free(w); return 1; }
+    orc_drbg_t *d = orc_drbg_create(seed, seed_len);
+    orc_drbg_mem(d, blk, 32); memcpy(rho, blk, 32);
+    for (int j = 0; j < k; j++) { orc_drbg_mem(d, noise, P.eta * 64); binomial(noise, P.eta, sh + j * n, (size_t)n); }
+    for (int j = 0; j < k; j++) { orc_drbg_mem(d, noise, P.eta * 64); binomial(noise, P.eta, e + j * n, (size_t)n); }
+    orc_expand_matrix(rho, 32, k * k, q, P.q_bits, G);
+    for (int j = 0; j < k; j++) { orc_fwd_ntt(sh + j * n, n, q, sh + j * n, w); orc_normalize(sh + j * n, (size_t)n, q); }
+    matvec(t, G, k, k, 0, sh, n, q, w, r);
+    for (int i = 0; i < k * n; i++) { s_ntt[i] = sh[i]; t[i] += e[i]; }
+    orc_center(s_ntt, (size_t)k * n, q);
+    orc_center(t, (size_t)k * n, q);
+    compress(t, (size_t)k * n, P.d_t, (uint32_t)q, P.q_inv, P.q_norm);
+    decompress(t, (size_t)k * n, P.d_t, (uint32_t)q);
+    orc_normalize(t, (size_t)k * n, q);
+    for (int j = 0; j < k; j++) orc_fwd_ntt(t_ntt + j * n, n, q, t + j * n, w);
+    orc_center(t_ntt, (size_t)k * n, q);
+    orc_drbg_mem(d, blk, 32); memcpy(z, blk, 32);
+    orc_drbg_destroy(d);
+    free(w);
+    return 0;
+}

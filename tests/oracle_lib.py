@@ -73,6 +73,8 @@ def lib():
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
+        L.orc_kyber_keygen.argtypes = [i32p, u8p, C.c_size_t, i32p, i32p, i32p, u8p, u8p]
+        L.orc_expand_matrix.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int32, C.c_int, i32p]
         L.orc_kyber_ct_bytes.restype = C.c_size_t
         L.orc_kyber_ct_bytes.argtypes = [i32p]
         L.orc_kyber_kem_enc.argtypes = [i32p, i32p, i32p, u8p, i32p, u8p, u8p, u8p]
@@ -369,3 +371,21 @@ def tesla_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_tesla_verify(key.par, key.a1, key.a2, key.t1, key.t2, m, ml, s, s.size)
+
+
+def kyber_keygen(par, seed):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    par = f(par, np.int32)
+    kn = int(par[5]) * int(par[0])
+    s_ntt, t, t_ntt = (np.zeros(kn, dtype=np.int32) for _ in range(3))
+    rho, z = np.zeros(32, dtype=np.uint8), np.zeros(32, dtype=np.uint8)
+    sd = f(seed, np.uint8)
+    assert lib().orc_kyber_keygen(par, sd, sd.size, s_ntt, t, t_ntt, rho, z) == 0
+    return s_ntt, t, t_ntt, rho, z
+
+
+def expand_matrix(rho, npoly, q, q_bits):
+    r = np.ascontiguousarray(np.asarray(rho), dtype=np.uint8)
+    out = np.zeros(npoly * 256, dtype=np.int32)
+    lib().orc_expand_matrix(r, r.size, npoly, q, q_bits, out)
+    return out

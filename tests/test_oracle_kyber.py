@@ -31,3 +31,17 @@ def test_kem_vs_reference(tag, nmsg):
         assert O.kyber_kem_dec(*args, ct) == u8(G[f'{tag}_kem_dec{i}']) == key
         bad = bytearray(ct); bad[len(bad) // 2] ^= 0x20
         assert O.kyber_kem_dec(*args, bytes(bad)) == u8(G[f'{tag}_kem_decbad{i}'])
+
+
+@pytest.mark.parametrize('tag', ['kyber1', 'kyber2'])
+def test_keygen_vs_reference(tag):
+    """safecrypto_keygen with the context CSPRNG seeded: every component of the key pair; and the matrix expansion from rho"""
+    G = load_golden('kyber_ref.txt')
+    par = G[f'{tag}_params']
+    for i in range(2):
+        s_ntt, t, t_ntt, rho, z = O.kyber_keygen(par, G[f'{tag}_kg_seed{i}'])
+        assert np.array_equal(rho, G[f'{tag}_kg_rho{i}']) and np.array_equal(z, G[f'{tag}_kg_z{i}'])
+        assert np.array_equal(s_ntt, G[f'{tag}_kg_s_ntt{i}'])
+        assert np.array_equal(t, G[f'{tag}_kg_t{i}']) and np.array_equal(t_ntt, G[f'{tag}_kg_t_ntt{i}'])
+    k = int(par[5])
+    assert np.array_equal(O.expand_matrix(G[f'{tag}_rho'], k * k, int(par[1]), int(par[2])), G[f'{tag}_Agen'])
