@@ -348,6 +348,13 @@ int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m,
 /* replaces: safecrypto_decapsulation -> kyber_kem_decapsulation (kyber_kem.c:930-1040); needs set_privkey too */
 int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
 
+/* replaces: safecrypto_keygen -> kyber_kem_keygen (kyber_kem.c:575-670; kyber_cpa_keygen, module_lwe.c:1189-1266) for `batch` key pairs.
+ * Key i draws what the reference draws from sc->prng_ctx[0] - rho, the noise of s and e, z, in that order - from a CTR-DRBG seeded
+ * with d_seeds[i]; its matrix comes from a second generator seeded with rho.  Outputs in the key pair's layouts: d_s_ntt (centred
+ * NTT(s)), d_t, d_t_ntt (centred NTT(t)) int32 [batch][k][n]; d_rho, d_z uint8 [batch][32].  The handle needs no key loaded. */
+int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                        int32_t *d_s_ntt, int32_t *d_t, int32_t *d_t_ntt, uint8_t *d_rho, uint8_t *d_z, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

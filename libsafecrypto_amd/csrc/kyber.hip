@@ -92,6 +92,48 @@ __global__ void ky_dec_finish_kernel(const int32_t *v, const int32_t *x, uint8_t
 }
 
 
+// key generation: s and e (k polynomials each) from the 2k noise blocks of a key's stream (module_lwe.c:1215-1216)
+__global__ void ky_kg_binomial_kernel(const uint8_t *stream, size_t stride, size_t noise_off, uint32_t count, int32_t *s, int32_t *e, KyP P)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kn4 = P.k * P.n / 4, per = 2 * kn4;
+    const uint32_t item = (uint32_t)(t / per); const int g = (int)(t % per);
+    if (item >= count) return;
+    const uint8_t *b = stream + (size_t)item * stride + noise_off + (size_t)g * P.eta;
+    uint32_t a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int x = 0; x < P.eta; x++) { const uint32_t v = b[x]; for (int i = 0; i < 8; i++) a[i] += v & (1u << i); }
+    int32_t *dst = (g < kn4) ? s + ((size_t)item * kn4 + g) * 4 : e + ((size_t)item * kn4 + (g - kn4)) * 4;
+    dst[0] = (int32_t)a[0] - (int32_t)(a[1] >> 1);
+    dst[1] = (int32_t)(a[2] >> 2) - (int32_t)(a[3] >> 3);
+    dst[2] = (int32_t)(a[4] >> 4) - (int32_t)(a[5] >> 5);
+    dst[3] = (int32_t)(a[6] >> 6) - (int32_t)(a[7] >> 7);
+}
+
+// t = normalise(decompress(compress(centre(A s + e), d_t)))   (module_lwe.c:1251-1255); as canonical, e small signed
+__global__ void ky_kg_t_kernel(const int32_t *as, const int32_t *e, int32_t *t, size_t len, KyP P)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    int32_t v = (as[i] + e[i]) % P.q;                                  // centre_32: the representative in [-(q-1)/2, (q-1)/2]
+    const int32_t q2 = (P.q - 1) >> 1;
+    if (v < -q2) v += P.q;
+    if (v > q2) v -= P.q;
+    v = ky_compress(v, P.d_t, (uint32_t)P.q, P.q_inv, P.q_norm);
+    v = (int32_t)(v * P.q) >> P.d_t;                                   // mlwe_decompress (module_lwe.c:58-69)
+    v %= P.q; if (v < 0) v += P.q;
+    t[i] = v;
+}
+
+// rho and z of every key out of its stream: bytes [0, 32) and [z_off, z_off + 32)
+__global__ void ky_kg_slices_kernel(const uint8_t *stream, size_t stride, size_t z_off, uint32_t count, uint8_t *rho, uint8_t *z)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t item = (uint32_t)(t / 64); const int b = (int)(t % 64);
+    if (item >= count) return;
+    const uint8_t *s = stream + (size_t)item * stride;
+    if (b < 32) rho[(size_t)item * 32 + b] = s[b]; else z[(size_t)item * 32 + (b - 32)] = s[z_off + (b - 32)];
+}
+
 constexpr int KHT = 64;      // KEM hash kernels: lanes per workgroup (LDS sponge states)
 
 // once per key: the sponge state after the whole 72-byte blocks of rho | t16
@@ -462,5 +504,52 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
     const size_t body = sc_hip_kyber_ct_bytes(h) - 32;
     hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+
+// ---- key generation ---------------------------------------------------------------------------------------------------------
+
+// replaces: safecrypto_keygen -> kyber_kem_keygen (kyber_kem.c:575-670) over kyber_cpa_keygen (module_lwe.c:1189-1266) for `batch`
+// key pairs, key i drawing what the reference draws from sc->prng_ctx[0] out of a CTR-DRBG seeded with d_seeds[i] (rho, the noise
+// of s and e, z - in that order; the matrix comes from a second generator seeded with rho, as in the reference).  Outputs in the
+// layouts the key pair uses: s_ntt, t, t_ntt int32 [batch][k][n]; rho, z [batch][32].
+extern "C" int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                   int32_t *d_s_ntt, int32_t *d_t, int32_t *d_t_ntt, uint8_t *d_rho, uint8_t *d_z, void *stream)
+{
+    if (!h) return fail("kyber_keygen: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_seeds || !d_s_ntt || !d_t || !d_t_ntt || !d_rho || !d_z) return fail("kyber_keygen: null buffer");
+    if (batch > 0x7fffffffu / 4096) return fail("kyber_keygen: batch too large");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (ky_ensure(h, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const KyP &P = h->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k;
+    const size_t kn = (size_t)k * N, noise = (size_t)2 * k * P.eta * 64, slen = 64 + noise + 64, npoly = batch * (size_t)k * k;
+    DevBuf sb, ab, am;
+    if (sb.get(batch * slen) || ab.get(npoly * N * 4) || am.get(npoly * N * 4)) return SC_HIP_FAILURE;
+    uint8_t *strm = sb.as<uint8_t>();
+    if (sc_hip_drbg_mem(h->ctx, batch, d_seeds, seed_stride, seed_len, strm, slen, slen, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ky_kg_slices_kernel, dim3((unsigned)((batch * 64 + 255) / 256)), dim3(256), 0, s, strm, slen, 64 + noise, B, d_rho, d_z);
+    const size_t ng = batch * (size_t)(2 * k * N / 4);
+    hipLaunchKernelGGL(ky_kg_binomial_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, strm, slen, (size_t)64, B, h->r, h->e1, P);
+    HIPCHK(hipGetLastError());
+    // every key its own matrix: expand from rho, bring into the kernels' internal Montgomery form (no transposition: t = A s)
+    if (sc_hip_mlwe_expand_matrix(h->ctx, batch, d_rho, 32, 32, k * k, P.q, P.q_bits, ab.as<int32_t>(), s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab.as<int32_t>(), am.as<uint32_t>(), npoly, h->plan->k[1], h->plan->r2, h->plan->r2p, 0, 0);
+    HIPCHK(hipGetLastError());
+    DilNtt a = mlwe_base_args(h->plan, k, k, 1 << 20);
+    a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
+    if (mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
+    a.key = am.as<uint32_t>(); a.key_item_stride = (size_t)k * k * N; a.w = h->u0; a.w1 = nullptr;
+    if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ky_kg_t_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, h->u0, h->e1, d_t, batch * kn, P);
+    HIPCHK(hipGetLastError());
+    // the stored NTT forms are in the reference's natural order, centred (kyber_kem.c:648-651, module_lwe.c:1256)
+    if (sc_hip_ntt_fwd(h->plan, batch * (size_t)k, h->r, d_s_ntt, s) || sc_hip_center(h->plan, batch * kn, d_s_ntt, d_s_ntt, s)) return SC_HIP_FAILURE;
+    if (sc_hip_ntt_fwd(h->plan, batch * (size_t)k, d_t, d_t_ntt, s) || sc_hip_center(h->plan, batch * kn, d_t_ntt, d_t_ntt, s)) return SC_HIP_FAILURE;
+    HIPCHK(hipStreamSynchronize(s));                                   // the scoped temporaries are released on return
     return SC_HIP_SUCCESS;
 }

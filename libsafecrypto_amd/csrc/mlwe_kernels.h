@@ -62,6 +62,7 @@ struct DilNtt {
     uint32_t *out_int;                    // DOP_FWD_INT / KEYPREP: internal-order canonical (KEYPREP: Montgomery form)
     const uint32_t *yh;                   // [item][l][n] internal
     const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
+    size_t key_item_stride;               // words between the matrices of consecutive items (0: one matrix for the whole batch)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
     const int32_t *y;                     // [item][l][n] natural (mask)
     int32_t *w;                           // [item][k][n] natural canonical
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             for (int r = 0; r < 16; r++) x[r] = 0;
             for (int j = 0; j < a.l; j++) {
                 const uint4 *py = reinterpret_cast<const uint4 *>(a.yh + ((size_t)item * a.l + j) * N + lp * 16);
-                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + ((size_t)sub * a.l + j) * N + lp * 16);
+                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + (size_t)item * a.key_item_stride + ((size_t)sub * a.l + j) * N + lp * 16);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint4 vy = valid ? py[c] : make_uint4(0, 0, 0, 0), va = pa[c];

@@ -21,7 +21,7 @@ SYMBOLS = [
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
-    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps',
+    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
@@ -148,6 +148,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_kyber_ct_bytes.restype = sz
     L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.sc_hip_kyber_keygen.argtypes = [vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.sc_hip_tesla_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_tesla_destroy.argtypes = [vp]
     L.sc_hip_tesla_destroy.restype = None
@@ -783,6 +784,15 @@ class Kyber:
         assert a.size == self.k * self.n and r.size == 32
         _chk(self.L, self.L.sc_hip_kyber_set_kem_pubkey(self.h, _ptr(a), _ptr(r)), 'kyber_set_kem_pubkey')
         self.ct_bytes = self.L.sc_hip_kyber_ct_bytes(self.h)
+
+    def keygen(self, seeds):
+        """seeds uint8 [batch][len] (device) -> s_ntt, t, t_ntt int32 [batch][k][n]; rho, z uint8 [batch][32]"""
+        import torch
+        batch, dev = seeds.shape[0], seeds.device
+        s_ntt, t, t_ntt = (torch.empty((batch, self.k, self.n), dtype=torch.int32, device=dev) for _ in range(3))
+        rho, z = (torch.empty((batch, 32), dtype=torch.uint8, device=dev) for _ in range(2))
+        _chk(self.L, self.L.sc_hip_kyber_keygen(self.h, batch, _ptr(seeds), _rows(seeds), seeds.shape[1], _ptr(s_ntt), _ptr(t), _ptr(t_ntt), _ptr(rho), _ptr(z), _stream()), 'kyber_keygen')
+        return s_ntt, t, t_ntt, rho, z
 
     def encaps(self, m):
         """m uint8 [batch][32] (device) -> ciphertexts uint8 [batch][ct_bytes], keys uint8 [batch][32]"""

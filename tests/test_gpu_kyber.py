@@ -103,3 +103,35 @@ def test_kem_batch_vs_oracle(eng):
         oc, ok = O.kyber_kem_enc(G[f'{tag}_params'], G[f'{tag}_t'], G[f'{tag}_t_ntt'], G[f'{tag}_rho'], G[f'{tag}_Agen'], m[i])
         assert cth[i].tobytes() == oc and kh[i].tobytes() == ok, i
     ky.close()
+
+
+@pytest.mark.parametrize('tag', ['kyber1', 'kyber2'])
+def test_keygen_vs_reference(eng, tag):
+    """batched key generation from per-key seeds: every component of the reference's key pair for the fixture's seeds, the oracle's
+    on a seeded batch, and a generated key pair encapsulates / decapsulates"""
+    import torch
+    G = load_golden('kyber_ref.txt')
+    par = G[f'{tag}_params']
+    ky = eng.kyber(par)
+    rng = np.random.default_rng(3)
+    B = 70
+    seeds = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    seeds[0] = np.asarray(G[f'{tag}_kg_seed0'], dtype=np.uint8); seeds[B - 1] = np.asarray(G[f'{tag}_kg_seed1'], dtype=np.uint8)
+    s_ntt, t, t_ntt, rho, z = (x.cpu().numpy() for x in ky.keygen(torch.from_numpy(seeds).cuda()))
+    for row, i in ((0, 0), (B - 1, 1)):
+        assert np.array_equal(rho[row], G[f'{tag}_kg_rho{i}']) and np.array_equal(z[row], G[f'{tag}_kg_z{i}'])
+        assert np.array_equal(s_ntt[row].reshape(-1), G[f'{tag}_kg_s_ntt{i}'])
+        assert np.array_equal(t[row].reshape(-1), G[f'{tag}_kg_t{i}'])
+        assert np.array_equal(t_ntt[row].reshape(-1), G[f'{tag}_kg_t_ntt{i}'])
+    for row in (1, 33, 64):
+        o = O.kyber_keygen(par, seeds[row])
+        for got, want in zip((s_ntt[row], t[row], t_ntt[row], rho[row], z[row]), o):
+            assert np.array_equal(got.reshape(-1), want)
+    # use key 33: expand its matrix, load it, run the KEM round trip
+    k = int(par[5])
+    A = eng.expand_matrix(torch.from_numpy(rho[33:34].copy()).cuda(), k * k, int(par[1]), int(par[2])).cpu().numpy().reshape(-1)
+    ky.set_pubkey(t_ntt[33].reshape(-1), A); ky.set_privkey(s_ntt[33].reshape(-1)); ky.set_kem_pubkey(t[33].reshape(-1), rho[33])
+    m = torch.from_numpy(rng.integers(0, 256, size=(5, 32), dtype=np.uint8)).cuda()
+    ct, keys = ky.encaps(m)
+    assert torch.equal(ky.decaps(ct), keys)
+    ky.close()
