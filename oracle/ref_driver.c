@@ -331,7 +331,31 @@ static int dilithium_case(FILE *f, int set, int nmsg)
     snprintf(name, sizeof name, "%s_trials", tag); rec_i32(f, name, trials, nmsg);
     snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
     free(trials); free(verdicts);
+    { int32_t eb = (int32_t)P->eta_bits; snprintf(name, sizeof name, "%s_eta_bits", tag); rec_i32(f, name, &eb, 1); }
     safecrypto_destroy(sc);
+    /* key generation (dilithium.c:752-935) from a seeded context CSPRNG: every component of the key pair */
+    for (int kg = 0; kg < 2; kg++) {
+        uint8_t seed[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        safecrypto_t *s2 = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+        if (!s2) return 1;
+        prng_ctx_t *o2 = s2->prng_ctx[0], *mine = seeded_prng(seed, 32);
+        s2->prng_ctx[0] = mine;
+        if (SC_FUNC_SUCCESS != safecrypto_keygen(s2)) return 1;
+        const SINT32 *pv = (const SINT32 *)s2->privkey->key, *pb = (const SINT32 *)s2->pubkey->key;
+        const uint8_t *tl = (const uint8_t *)(pv + (NUM_DILITHIUM_PRIVKEY_K * k + l) * n);
+        snprintf(name, sizeof name, "%s_kg_seed%d", tag, kg); rec_u8(f, name, seed, 32);
+        snprintf(name, sizeof name, "%s_kg_s1_%d", tag, kg); rec_i32(f, name, pv, (size_t)l * n);
+        snprintf(name, sizeof name, "%s_kg_s2_%d", tag, kg); rec_i32(f, name, pv + l * n, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_kg_t%d", tag, kg); rec_i32(f, name, pv + (l + k) * n, (size_t)k * n);
+        snprintf(name, sizeof name, "%s_kg_rho%d", tag, kg); rec_u8(f, name, tl, 32);
+        snprintf(name, sizeof name, "%s_kg_K%d", tag, kg); rec_u8(f, name, tl + 32, 32);
+        snprintf(name, sizeof name, "%s_kg_tr%d", tag, kg); rec_u8(f, name, tl + 64, 48);
+        snprintf(name, sizeof name, "%s_kg_t1_%d", tag, kg); rec_i32(f, name, pb, (size_t)k * n);
+        s2->prng_ctx[0] = o2;
+        prng_destroy(mine);
+        safecrypto_destroy(s2);
+    }
     return 0;
 }
 

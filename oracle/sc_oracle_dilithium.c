@@ -287,3 +287,56 @@ done:
     free(w1b); free(buf); free(w_t);
     return rc;
 }
+
+
+/* ------------------------------------------------------------------- keygen ---- */
+/* uniform_rand_sample_small_csprng, src/utils/arith/module_lwe.c:280-310: the loop draws 512-byte blocks for i = 0, 1024, ... <
+ * m*n and writes 1024 samples per block - past the end of s for m*n = 1280 or 1536, as the reference does into its own key
+ * buffer (the overflow lands in memory that is rewritten afterwards); what survives is the first m*n samples of the blocks.
+ * Two samples per byte: (b & mask) and ((b >> 4) & mask), halved when > 2 eta, stored as eta - value. */
+static void sample_small(orc_drbg_t *d, int eta, int eta_bits, int32_t *s, size_t count)
+{
+    const uint32_t mask = (1u << (eta_bits + 1)) - 1;
+    size_t o = 0;
+    for (size_t i = 0; i < count; i += 1024) {
+        uint8_t r[512];
+        orc_drbg_mem(d, r, 512);
+        for (int j = 0; j < 512; j++) {
+            uint32_t b = r[j];
+            for (int h = 0; h < 2; h++) {
+                uint32_t t = b & mask;
+                if (t > 2u * (uint32_t)eta) t >>= 1;
+                if (o < count) s[o] = eta - (int32_t)t;
+                o++;
+                b >>= 4;
+            }
+        }
+    }
+}
+
+/* dilithium_keygen (src/schemes/sig/dilithium/dilithium.c:752-935) with the context CSPRNG seeded by `seed`: stream = rho block |
+ * K block | blocks of s1 | blocks of s2; A from a second generator seeded with rho; t = normalise(A s1 + s2); t1 = high part
+ * (decompose, d bits); tr = CRH(rho, t1).  eta_bits is dilithium_set_t::eta_bits. */
+int orc_dilithium_keygen(const int32_t *par, int eta_bits, const uint8_t *seed, size_t seed_len,
+                         int32_t *s1, int32_t *s2, int32_t *t, uint8_t *rho, uint8_t *K, uint8_t *tr, int32_t *t1)
+{
+    dilp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, k = P.k, l = P.l, q = P.q;
+    int32_t *w_t = malloc(sizeof(int32_t) * (size_t)n * (2 + k * l + k)), *r_t = w_t + n, *A = r_t + n, *t0 = A + (size_t)k * l * n;
+    uint8_t blk[64];
+    if (orc_make_tables(q, n, w_t, r_t)) { free(w_t); return 1; }
+    orc_drbg_t *d = orc_drbg_create(seed, seed_len);
+    orc_drbg_mem(d, blk, 32); memcpy(rho, blk, 32);
+    orc_drbg_mem(d, blk, 32); memcpy(K, blk, 32);
+    sample_small(d, P.eta, eta_bits, s1, (size_t)l * n);
+    sample_small(d, P.eta, eta_bits, s2, (size_t)k * n);
+    orc_drbg_destroy(d);
+    orc_expand_matrix(rho, 32, k * l, q, P.q_bits, A);
+    matvec(t, A, s1, n, k, l, q, w_t, r_t);
+    for (int i = 0; i < k * n; i++) t[i] += s2[i];
+    orc_normalize(t, (size_t)k * n, q);
+    orc_dil_decompose(t1, t0, t, (size_t)k * n, P.d, q);
+    orc_dilithium_crh_t1(rho, t1, (size_t)k * n, P.q_bits - P.d, tr);
+    free(w_t);
+    return 0;
+}

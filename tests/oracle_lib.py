@@ -64,6 +64,7 @@ def lib():
         L.orc_dilithium_crh_t1.argtypes = [u8p, i32p, C.c_size_t, C.c_int, u8p]
         L.orc_dilithium_sign.argtypes = [i32p, i32p, i32p, i32p, u8p, u8p, i32p, u8p, C.c_size_t, u8p,
                                          C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+        L.orc_dilithium_keygen.argtypes = [i32p, C.c_int, u8p, C.c_size_t, i32p, i32p, i32p, u8p, u8p, u8p, i32p]
         L.orc_dilithium_verify.argtypes = [i32p, i32p, u8p, i32p, u8p, C.c_size_t, u8p, C.c_size_t]
         i16p = np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS')
         u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS')
@@ -389,3 +390,14 @@ def expand_matrix(rho, npoly, q, q_bits):
     out = np.zeros(npoly * 256, dtype=np.int32)
     lib().orc_expand_matrix(r, r.size, npoly, q, q_bits, out)
     return out
+
+
+def dilithium_keygen(par, eta_bits, seed):
+    f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
+    par = f(par, np.int32)
+    n, k, l = int(par[0]), int(par[3]), int(par[4])
+    s1, s2, t, t1 = np.zeros(l * n, np.int32), np.zeros(k * n, np.int32), np.zeros(k * n, np.int32), np.zeros(k * n, np.int32)
+    rho, K, tr = np.zeros(32, np.uint8), np.zeros(32, np.uint8), np.zeros(48, np.uint8)
+    sd = f(seed, np.uint8)
+    assert lib().orc_dilithium_keygen(par, int(eta_bits), sd, sd.size, s1, s2, t, rho, K, tr, t1) == 0
+    return s1, s2, t, rho, K, tr, t1

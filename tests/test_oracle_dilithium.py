@@ -72,3 +72,13 @@ def test_verify_matches_reference_verdicts(G, tag):
         bad[len(bad) // 2] ^= 0x10
         assert O.dilithium_verify(key, m, bytes(bad)) == int(G[f'{tag}_verify'][2 * i + 1]) == 1
         assert O.dilithium_verify(key, m + b'x', sig) == 1
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_keygen_vs_reference(tag):
+    """safecrypto_keygen with the context CSPRNG seeded: s1, s2, t, rho, K, tr, t1 of the reference's key pair"""
+    G = load_golden('dilithium_ref.txt')
+    for i in range(2):
+        out = O.dilithium_keygen(G[f'{tag}_params'], int(G[f'{tag}_eta_bits'][0]), G[f'{tag}_kg_seed{i}'])
+        for got, name in zip(out, ('s1_', 's2_', 't', 'rho', 'K', 'tr', 't1_')):
+            assert np.array_equal(got, G[f'{tag}_kg_{name}{i}']), (tag, i, name)
