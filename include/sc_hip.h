@@ -355,6 +355,14 @@ int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_ct
 int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
                         int32_t *d_s_ntt, int32_t *d_t, int32_t *d_t_ntt, uint8_t *d_rho, uint8_t *d_z, void *stream);
 
+/* replaces: safecrypto_keygen -> dilithium_keygen (src/schemes/sig/dilithium/dilithium.c:752-935) for `batch` key pairs.  Key i draws
+ * what the reference draws from sc->prng_ctx[0] - rho, K, the sample blocks of s1 and of s2 (uniform_rand_sample_small_csprng,
+ * module_lwe.c:280-310) - from a CTR-DRBG seeded with d_seeds[i]; its matrix comes from a second generator seeded with rho.
+ * eta_bits = dilithium_set_t::eta_bits.  Outputs in the key pair's layouts: d_s1 int32 [batch][l][n]; d_s2, d_t, d_t1 [batch][k][n];
+ * d_rho, d_K uint8 [batch][32]; d_tr [batch][48].  The handle needs no key loaded. */
+int sc_hip_dilithium_keygen(sc_hip_dilithium_t *h, size_t batch, int eta_bits, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                            int32_t *d_s1, int32_t *d_s2, int32_t *d_t, uint8_t *d_rho, uint8_t *d_K, uint8_t *d_tr, int32_t *d_t1, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

@@ -56,11 +56,15 @@ __global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uin
 }
 
 // tr = SHAKE256( pack(rho: 32 x 8 bits, t1: k*n x bits) )  (collision_resistant_hash_t1, module_lwe.c:140-180)
-__global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, const int32_t *t1, uint32_t len, int bits, uint8_t *out48)
+// tr = CRH(rho, t1) (collision_resistant_hash_t1, dilithium.c:1038-1075): SHAKE256 over rho and the bit-packed t1 -> 48 bytes;
+// one lane per key (count keys: rho [count][32], t1 [count][len], out [count][48])
+__global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, const int32_t *t1, uint32_t len, int bits, uint8_t *out48, uint32_t count)
 {
     __shared__ uint64_t st[25 * HT];
     Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const uint32_t key = blockIdx.x * HT + threadIdx.x;
+    if (key >= count) return;
+    rho += (size_t)key * 32; t1 += (size_t)key * len; out48 += (size_t)key * 48;
     for (int i = 0; i < 32; i++) sp.absorb_byte(rho[i]);
     uint32_t acc = 0; int nb = 0;
     for (uint32_t i = 0; i < len; i++) {
@@ -71,6 +75,43 @@ __global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, cons
     if (nb) sp.absorb_byte((uint8_t)(acc << (8 - nb)));
     sp.finalize();
     for (int i = 0; i < 48; i++) out48[i] = sp.squeeze_byte();
+}
+
+// ---- key generation (dilithium.c:752-935) -----------------------------------------------------------------------------------
+
+// rho and K of every key out of its CSPRNG stream: the first 32 bytes of the first two 64-byte prng_mem blocks
+__global__ void dil_kg_slices_kernel(const uint8_t *stream, size_t stride, uint32_t count, uint8_t *rho, uint8_t *K)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t item = (uint32_t)(t / 64); const int b = (int)(t % 64);
+    if (item >= count) return;
+    const uint8_t *s = stream + (size_t)item * stride;
+    if (b < 32) rho[(size_t)item * 32 + b] = s[b]; else K[(size_t)item * 32 + (b - 32)] = s[64 + (b - 32)];
+}
+
+// uniform_rand_sample_small_csprng (module_lwe.c:280-310): sample o of a vector is half (o & 1) of byte o >> 1 of its blocks:
+// (b >> 4*half) & mask, halved when > 2 eta, stored as eta - value
+__global__ void dil_kg_small_kernel(const uint8_t *stream, size_t stride, size_t off, uint32_t count, int per, int eta, uint32_t mask, int32_t *out)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t item = (uint32_t)(t / per); const int o = (int)(t % per);
+    if (item >= count) return;
+    uint32_t v = ((uint32_t)stream[(size_t)item * stride + off + (o >> 1)] >> (4 * (o & 1))) & mask;
+    if (v > 2u * (uint32_t)eta) v >>= 1;
+    out[t] = eta - (int32_t)v;
+}
+
+// t = normalise(A s1 + s2) ; t1 = its high part (decompose, module_lwe.c:73-104)
+__global__ void dil_kg_t_kernel(const int32_t *as1, const int32_t *s2, int32_t *t, int32_t *t1, size_t len, int32_t q, int d)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    int32_t v = (as1[i] + s2[i]) % q;
+    if (v < 0) v += q;
+    t[i] = v;
+    int32_t x = v & ((1 << d) - 1);
+    x -= (x > (1 << (d - 1))) * (1 << d);
+    t1[i] = (v - x) >> d;
 }
 
 // y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244)
@@ -500,7 +541,7 @@ extern "C" int sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *d, const int32_t 
     if (t1b.get(t1s.size() * 4)) return SC_HIP_FAILURE;
     int32_t *dt1 = t1b.as<int32_t>();
     HIPCHK(hipMemcpy(dt1, t1, t1s.size() * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3(1), dim3(HT), 0, nullptr, d->d_rho, dt1, (uint32_t)t1s.size(), d->P.q_bits - d->P.d, d->d_tr_pub);
+    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3(1), dim3(HT), 0, nullptr, d->d_rho, dt1, (uint32_t)t1s.size(), d->P.q_bits - d->P.d, d->d_tr_pub, 1u);
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium_set_pubkey: CRH kernel failed");
     d->have_pub = (rc == SC_HIP_SUCCESS);
     return rc;
@@ -744,4 +785,48 @@ extern "C" int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, cons
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("shake_host: kernel failed");
     if (rc == SC_HIP_SUCCESS) HIPCHK(hipMemcpy(h_out, dout, outlen, hipMemcpyDeviceToHost));
     return rc;
+}
+
+
+// replaces: safecrypto_keygen -> dilithium_keygen (dilithium.c:752-935) for `batch` key pairs.  Key i draws what the reference
+// draws from sc->prng_ctx[0] - rho, K, the blocks of s1, the blocks of s2 - from a CTR-DRBG seeded with d_seeds[i]; its matrix
+// comes from a second generator seeded with rho.  eta_bits = dilithium_set_t::eta_bits.  Outputs in the key pair's layouts:
+// s1 [batch][l][n], s2, t, t1 [batch][k][n] int32; rho, K [batch][32]; tr [batch][48].
+extern "C" int sc_hip_dilithium_keygen(sc_hip_dilithium_t *d, size_t batch, int eta_bits, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                       int32_t *d_s1, int32_t *d_s2, int32_t *d_t, uint8_t *d_rho, uint8_t *d_K, uint8_t *d_tr, int32_t *d_t1, void *stream)
+{
+    if (!d) return fail("dilithium_keygen: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_seeds || !d_s1 || !d_s2 || !d_t || !d_rho || !d_K || !d_tr || !d_t1) return fail("dilithium_keygen: null buffer");
+    if (eta_bits < 1 || eta_bits > 3) return fail("dilithium_keygen: eta_bits out of range");
+    if (batch > 0x7fffffffu / 4096) return fail("dilithium_keygen: batch too large");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const DilP &P = d->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k, l = P.l;
+    const size_t ln = (size_t)l * N, kn = (size_t)k * N;
+    const size_t b1 = (ln + 1023) / 1024 * 512, b2 = (kn + 1023) / 1024 * 512, slen = 128 + b1 + b2, npoly = batch * (size_t)k * l;
+    DevBuf sb, ab, am, yh, w;
+    if (sb.get(batch * slen) || ab.get(npoly * N * 4) || am.get(npoly * N * 4) || yh.get(batch * ln * 4) || w.get(batch * kn * 4)) return SC_HIP_FAILURE;
+    uint8_t *strm = sb.as<uint8_t>();
+    if (sc_hip_drbg_mem(d->ctx, batch, d_seeds, seed_stride, seed_len, strm, slen, slen, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_kg_slices_kernel, dim3((unsigned)((batch * 64 + 255) / 256)), dim3(256), 0, s, strm, slen, B, d_rho, d_K);
+    const uint32_t mask = (1u << (eta_bits + 1)) - 1u;
+    hipLaunchKernelGGL(dil_kg_small_kernel, dim3((unsigned)((batch * ln + 255) / 256)), dim3(256), 0, s, strm, slen, (size_t)128, B, (int)ln, P.eta, mask, d_s1);
+    hipLaunchKernelGGL(dil_kg_small_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, strm, slen, (size_t)128 + b1, B, (int)kn, P.eta, mask, d_s2);
+    HIPCHK(hipGetLastError());
+    if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab.as<int32_t>(), s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab.as<int32_t>(), am.as<uint32_t>(), npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
+    HIPCHK(hipGetLastError());
+    DilNtt a = base_args(d);
+    a.in = d_s1; a.out_int = yh.as<uint32_t>(); a.yh = yh.as<uint32_t>();
+    if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
+    a.key = am.as<uint32_t>(); a.key_item_stride = (size_t)k * l * N; a.w = w.as<int32_t>(); a.w1 = nullptr;
+    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_kg_t_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, w.as<int32_t>(), d_s2, d_t, d_t1, batch * kn, P.q, P.d);
+    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d_rho, d_t1, (uint32_t)kn, P.q_bits - P.d, d_tr, B);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                                   // the scoped temporaries are released on return
+    return SC_HIP_SUCCESS;
 }

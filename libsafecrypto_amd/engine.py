@@ -19,7 +19,7 @@ SYMBOLS = [
     'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_sign_host',
-    'sc_hip_dilithium_verify_host', 'sc_hip_shake_host',
+    'sc_hip_dilithium_verify_host', 'sc_hip_shake_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
@@ -148,6 +148,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_kyber_ct_bytes.restype = sz
     L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.sc_hip_dilithium_keygen.argtypes = [vp, sz, C.c_int, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_kyber_keygen.argtypes = [vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.sc_hip_tesla_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_tesla_destroy.argtypes = [vp]
@@ -525,6 +526,19 @@ class Dilithium:
         import numpy as np
         a = [self._a(t1, np.int32), self._a(rho, np.uint8), self._a(Ahat, np.int32)]
         _chk(self.L, self.L.sc_hip_dilithium_set_pubkey(self.h, *[_ptr(x) for x in a]), 'dilithium_set_pubkey')
+
+    def keygen(self, seeds, eta_bits):
+        """seeds uint8 [batch][len] (device) -> s1 [batch][l][n], s2, t, t1 [batch][k][n] int32; rho, K [batch][32]; tr [batch][48]"""
+        import torch
+        n, k, l = int(self.par[0]), int(self.par[3]), int(self.par[4])
+        batch, dev = seeds.shape[0], seeds.device
+        s1 = torch.empty((batch, l, n), dtype=torch.int32, device=dev)
+        s2, t, t1 = (torch.empty((batch, k, n), dtype=torch.int32, device=dev) for _ in range(3))
+        rho, K = (torch.empty((batch, 32), dtype=torch.uint8, device=dev) for _ in range(2))
+        tr = torch.empty((batch, 48), dtype=torch.uint8, device=dev)
+        _chk(self.L, self.L.sc_hip_dilithium_keygen(self.h, batch, int(eta_bits), _ptr(seeds), _rows(seeds), seeds.shape[1], _ptr(s1), _ptr(s2), _ptr(t),
+                                                    _ptr(rho), _ptr(K), _ptr(tr), _ptr(t1), _stream()), 'dilithium_keygen')
+        return s1, s2, t, rho, K, tr, t1
 
     # device-buffer entry points: torch uint8 [batch][stride] messages / signatures, int32 lengths
     def sign(self, msgs, mlens=None, fixed_len=0):

@@ -123,3 +123,35 @@ def test_device_buffers_full_config3_properties(eng, G):
         es, _ = O.dilithium_sign(key, bytes(mh[i]))
         assert bytes(sh[i, :lh[i]]) == es
     d.close()
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_keygen_vs_reference(eng, tag):
+    """batched key generation from per-key seeds: the reference's key pair for the fixture's seeds, the oracle's on a seeded batch,
+    and a generated key signs and verifies (matrix expanded from its rho on the device)"""
+    import torch
+    G = load_golden('dilithium_ref.txt')
+    par, eb = G[f'{tag}_params'], int(G[f'{tag}_eta_bits'][0])
+    d = eng.dilithium(par)
+    rng = np.random.default_rng(4)
+    B = 67
+    seeds = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    seeds[0] = np.asarray(G[f'{tag}_kg_seed0'], dtype=np.uint8); seeds[B - 1] = np.asarray(G[f'{tag}_kg_seed1'], dtype=np.uint8)
+    out = [x.cpu().numpy() for x in d.keygen(torch.from_numpy(seeds).cuda(), eb)]
+    names = ('s1_', 's2_', 't', 'rho', 'K', 'tr', 't1_')
+    for row, i in ((0, 0), (B - 1, 1)):
+        for got, name in zip(out, names):
+            assert np.array_equal(got[row].reshape(-1), G[f'{tag}_kg_{name}{i}']), (tag, i, name)
+    for row in (1, 40, 64):
+        o = O.dilithium_keygen(par, eb, seeds[row])
+        for got, want, name in zip(out, o, names):
+            assert np.array_equal(got[row].reshape(-1), want), (row, name)
+    s1, s2, t, rho, K, tr, t1 = (x[40] for x in out)
+    k, l = int(par[3]), int(par[4])
+    A = eng.expand_matrix(torch.from_numpy(rho[None, :].copy()).cuda(), k * l, int(par[1]), int(par[2])).cpu().numpy().reshape(-1)
+    d.set_privkey(s1.reshape(-1), s2.reshape(-1), t.reshape(-1), K, tr, A)
+    d.set_pubkey(t1.reshape(-1), rho, A)
+    msgs = torch.from_numpy(rng.integers(0, 256, size=(9, 64), dtype=np.uint8)).cuda()
+    sigs, siglens, trials = d.sign(msgs, fixed_len=64)
+    assert d.verify(msgs, sigs, siglens, fixed_len=64).cpu().tolist() == [0] * 9
+    d.close()
