@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
@@ -689,6 +689,98 @@ static int gen_tesla(const char *dir)
     return rc;
 }
 
+/* ---------------------------------------------------------------- RLWE-Enc ---- */
+#include "schemes/enc/rlwe_enc/rlwe_enc.h"
+#include "schemes/enc/rlwe_enc/rlwe_enc_params.h"
+
+static void rlwe_swap_prng(safecrypto_t *sc, prng_ctx_t *p)
+{
+    sc->prng_ctx[0] = p;
+    sc->sc_gauss->prng_ctx = p;
+    ((cdf64_full_view_t *)sc->sc_gauss->gauss)->prng_ctx = p;
+}
+
+/* rlwe_enc_keygen / _encrypt / _decrypt (src/schemes/enc/rlwe_enc/rlwe_enc.c:425-493, 511-631, 633-707) take all their
+ * randomness from sc->prng_ctx[0] (prng_32 words for a and r2, one prng_64 per Gaussian sample through the CDF sampler): same
+ * tape technique as BLISS.  Key generation: n/2 + 2n + n/16 words; encryption: 6n words.  The build has
+ * RLWE_ENC_ENABLE_NTT_TRANSMISSION defined (rlwe_enc.h:24): c1 travels in the NTT domain. */
+static int rlwe_case(FILE *f, int set, int nkeys, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "rlwe%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_ENC_RLWE, set, flags);
+    if (!sc) return 1;
+    const rlwe_set_t *P = set ? &param_rlwe_enc_1 : &param_rlwe_enc_0;       /* the config struct is private to rlwe_enc.c */
+    const int n = P->n;
+    int32_t par[12] = { P->set, P->q, P->q_bits, P->n, P->n_bits, P->m_scale, P->o_scale_0, P->o_scale_1, 0, 0, 0, 0 };
+    float fl[2] = { P->sig, 13.0f };
+    memcpy(&par[8], fl, 8);                                        /* sigma and the tail cut (rlwe_enc.c:134-136) as raw float bits */
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 12);
+    rec_u64(f, (snprintf(name, sizeof name, "%s_cdf", tag), name), (const uint64_t *)((cdf64_full_view_t *)sc->sc_gauss->gauss)->cdf,
+            (size_t)((cdf64_full_view_t *)sc->sc_gauss->gauss)->cdf_size);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0x51e0c000ULL + set;
+    for (int kg = 0; kg < nkeys; kg++) {
+        uint8_t seed[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        rlwe_swap_prng(sc, mine);
+        if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_kg_tape%d", tag, kg); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_kg_a%d", tag, kg); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+        snprintf(name, sizeof name, "%s_kg_p%d", tag, kg); rec_i16(f, name, (const int16_t *)sc->pubkey->key + n, n);
+        snprintf(name, sizeof name, "%s_kg_r2_%d", tag, kg); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+        free(tape);
+        rlwe_swap_prng(sc, orig);
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    /* the last generated key pair stays loaded for the encryption cases */
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t msg[128], seed[32];
+        for (int i = 0; i < n / 8; i++) msg[i] = (m == 0) ? 0x00 : (m == 1) ? 0xff : (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        rlwe_swap_prng(sc, mine);
+        uint8_t *ct = NULL, *dec = NULL; size_t ctlen = 0, declen = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_public_encrypt(sc, (size_t)n / 8, msg, &ctlen, &ct)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        if (SC_FUNC_SUCCESS != safecrypto_private_decrypt(sc, ctlen, ct, &declen, &dec)) return 1;
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, (size_t)n / 8);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_ct%d", tag, m); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_dec%d", tag, m); rec_u8(f, name, dec, declen);
+        free(dec); dec = NULL; declen = 0;                /* a non-zero length makes the packer expect a caller buffer (packer.c:142,153-157) */
+        /* decryption is a plain function of the bytes: a ciphertext of random bytes exercises coefficients >= q */
+        for (size_t i = 0; i < ctlen; i++) ct[i] = (uint8_t)splitmix64();
+        if (SC_FUNC_SUCCESS != safecrypto_private_decrypt(sc, ctlen, ct, &declen, &dec)) return 1;
+        snprintf(name, sizeof name, "%s_randct%d", tag, m); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_randdec%d", tag, m); rec_u8(f, name, dec, declen);
+        free(tape); free(ct); free(dec);
+        rlwe_swap_prng(sc, orig);
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_rlwe(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/rlwe_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = rlwe_case(f, 0, 3, 6);
+    rc |= rlwe_case(f, 1, 2, 4);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -976,7 +1068,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -988,5 +1080,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);
     if (all || !strcmp(argv[1], "drbg")) rc |= gen_drbg(argv[2]);
     if (all || !strcmp(argv[1], "tesla")) rc |= gen_tesla(argv[2]);
+    if (all || !strcmp(argv[1], "rlwe")) rc |= gen_rlwe(argv[2]);
     return rc;
 }

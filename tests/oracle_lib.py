@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle_rlwe.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -94,6 +94,12 @@ def lib():
         L.orc_tesla_sign.argtypes = [i32p, i32p, i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         L.orc_tesla_verify.argtypes = [i32p, i32p, i32p, i32p, i32p, u8p, C.c_size_t, u8p, C.c_size_t]
+        for fn in ('orc_rlwe_kg_words', 'orc_rlwe_enc_words', 'orc_rlwe_ct_bytes'):
+            getattr(L, fn).restype = C.c_size_t
+            getattr(L, fn).argtypes = [i32p]
+        L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
+        L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
+        L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
         f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
         f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
         L.orc_falcon_gm.restype = C.POINTER(C.c_double)
@@ -372,6 +378,41 @@ def tesla_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_tesla_verify(key.par, key.a1, key.a2, key.t1, key.t2, m, ml, s, s.size)
+
+
+class Rlwe:
+    """Ring-LWE encryption parameter set + sampler table (oracle/sc_oracle_rlwe.c)"""
+
+    def __init__(self, par):
+        self.par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+        self.q, self.q_bits, self.n = int(par[1]), int(par[2]), int(par[3])
+        sig, tail = (float(x) for x in self.par[8:10].view(np.float32))
+        self.sigma, self.tail = sig, tail
+        self.cdf = cdt_table(tail, sig)
+        self.kg_words = lib().orc_rlwe_kg_words(self.par)
+        self.enc_words = lib().orc_rlwe_enc_words(self.par)
+        self.ct_bytes = lib().orc_rlwe_ct_bytes(self.par)
+
+    def keygen(self, tape):
+        a, p, r2 = (np.zeros(self.n, dtype=np.int16) for _ in range(3))
+        tp = _tape(tape)
+        rc = lib().orc_rlwe_keygen(self.par, self.cdf, self.cdf.size, tp, tp.size, a, p, r2)
+        return rc, a, p, r2
+
+    def encrypt(self, a, p, msg, tape):
+        f = lambda x: np.ascontiguousarray(np.asarray(x), dtype=np.int16)
+        ct = np.zeros(self.ct_bytes, dtype=np.uint8)
+        m = np.ascontiguousarray(np.frombuffer(bytes(msg), dtype=np.uint8))
+        assert m.size == self.n // 8
+        tp = _tape(tape)
+        rc = lib().orc_rlwe_encrypt(self.par, self.cdf, self.cdf.size, f(a), f(p), m, tp, tp.size, ct)
+        return rc, bytes(ct)
+
+    def decrypt(self, r2, ct):
+        c = np.ascontiguousarray(np.frombuffer(bytes(ct), dtype=np.uint8))
+        msg = np.zeros(self.n // 8, dtype=np.uint8)
+        rc = lib().orc_rlwe_decrypt(self.par, np.ascontiguousarray(np.asarray(r2), dtype=np.int16), c, c.size, msg)
+        return rc, bytes(msg)
 
 
 def kyber_keygen(par, seed):
