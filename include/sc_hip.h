@@ -19,7 +19,7 @@
  *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
  *     sc_hip_last_error) when no gfx950 device / kernel image is available
  *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs are immutable after
- *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t) owns the
+ *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t) owns the
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
  */
@@ -274,6 +274,41 @@ int sc_hip_tesla_sign(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, si
 /* replaces: safecrypto_verify -> ring_tesla_verify (ring_tesla.c:922-1040); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_tesla_verify(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
+/* ---- RLWE-Enc: batched Ring-LWE encryption / decryption under one key pair, batched key generation ---- */
+
+/* rlwe_set_t fields (src/schemes/enc/rlwe_enc/rlwe_enc_params.h:37-61, values rlwe_enc_params.c:23-41); tail = 13.0, the cut
+ * rlwe_enc_create hands to create_sampler (rlwe_enc.c:134-136).  Sets: {0, 7681, 13, 256, 8, 3840, 1920, 5760, 4.51f} and
+ * {1, 12289, 14, 512, 9, 6144, 3072, 9216, 4.86f}. */
+typedef struct sc_hip_rlwe_params {
+    int32_t set, q, q_bits, n, n_bits, m_scale, o_scale_0, o_scale_1;
+    float sigma, tail;
+    int32_t pad[2];
+} sc_hip_rlwe_params_t;
+typedef struct sc_hip_rlwe sc_hip_rlwe_t;
+
+int  sc_hip_rlwe_create(sc_hip_ctx_t *ctx, const sc_hip_rlwe_params_t *params, sc_hip_rlwe_t **h);
+void sc_hip_rlwe_destroy(sc_hip_rlwe_t *h);
+/* a, p: the public key as the reference stores it (SINT16[n] each, NTT domain: sc->pubkey->key, rlwe_enc.c:560-561); r2: the
+ * private key (SINT16[n], NTT domain, :673).  Host pointers. */
+int  sc_hip_rlwe_set_pubkey(sc_hip_rlwe_t *h, const int16_t *a, const int16_t *p);
+int  sc_hip_rlwe_set_privkey(sc_hip_rlwe_t *h, const int16_t *r2);
+size_t sc_hip_rlwe_msg_bytes(const sc_hip_rlwe_t *h);          /* n/8: one plaintext block (rlwe_enc.c:546-549) */
+size_t sc_hip_rlwe_ct_bytes(const sc_hip_rlwe_t *h);           /* 2 n q_bits / 8 */
+size_t sc_hip_rlwe_enc_words(const sc_hip_rlwe_t *h);          /* 6n CSPRNG pool words per encryption (3n prng_64 draws) */
+size_t sc_hip_rlwe_keygen_words(const sc_hip_rlwe_t *h);       /* n/2 + 2n + n/16 words per key pair */
+/* replaces: safecrypto_public_encrypt -> rlwe_enc_encrypt (src/schemes/enc/rlwe_enc/rlwe_enc.c:511-631) for `batch` n-bit
+ * messages.  d_tapes[i * tape_stride ...]: the prng_32 word stream of sc->prng_ctx[0] for message i (8-byte aligned, even stride;
+ * sc_hip_drbg_words produces it from seeds).  Ciphertext i = c1 (NTT domain, the reference's RLWE_ENC_ENABLE_NTT_TRANSMISSION
+ * build, rlwe_enc.h:24) | c2, q_bits per coefficient MSB first - byte for byte the reference's output for the same words.
+ * ct_stride: multiple of 4. */
+int sc_hip_rlwe_encrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_tapes, size_t tape_stride,
+                        uint8_t *d_ct, size_t ct_stride, void *stream);
+/* replaces: safecrypto_private_decrypt -> rlwe_enc_decrypt (rlwe_enc.c:633-707); any 2 n q_bits / 8 bytes are accepted, as there */
+int sc_hip_rlwe_decrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_msgs, size_t msg_stride, void *stream);
+/* replaces: safecrypto_keygen -> rlwe_enc_keygen with a_gen / r1_gen / r2_gen (rlwe_enc.c:205-290, 425-493) for `batch`
+ * independent key pairs, one tape each; outputs [batch][n] SINT16 in the reference's storage format (a, p = r1 - a r2, r2) */
+int sc_hip_rlwe_keygen(sc_hip_rlwe_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, int16_t *d_a, int16_t *d_p, int16_t *d_r2, void *stream);
 
 /* ---- Kyber (round 1, q = 7681): batched CPA encryption / decryption under one key ------------ */
 

@@ -1,0 +1,430 @@
+// rlwe.hip - batched Ring-LWE encryption (RLWE-Enc) on MI355X behind the C ABI of include/sc_hip.h.
+//
+// Replaces, for a batch of messages under one key pair, rlwe_enc_encrypt / rlwe_enc_decrypt and, for a batch of independent
+// key pairs, rlwe_enc_keygen with a_gen / r1_gen / r2_gen (src/schemes/enc/rlwe_enc/rlwe_enc.c:511-631, 633-707, 425-493,
+// 205-290; parameter sets rlwe_enc_params.c:23-41; raw coding: q_bits per coefficient, MSB first).  The reference is built with
+// RLWE_ENC_ENABLE_NTT_TRANSMISSION (rlwe_enc.h:24): c1 = a o NTT(e1) + NTT(e2) travels in the NTT domain, c2 = INTT(p o NTT(e1))
+// + e3 + m_scale * bits in the coefficient domain.
+//
+// Randomness: the prng_32 word stream ("tape") of sc->prng_ctx[0], as for BLISS-B and ring-TESLA (or expanded on the device
+// with sc_hip_drbg_words): 6n words per encryption (3n Gaussian samples, one prng_64 = two words, high word first, through the
+// 64-bit CDF sampler, gaussian_cdf.c:639-659), n/2 + 2n + n/16 words per key pair.
+//
+// Mapping: ONE fused kernel per operation.  A polynomial lives in 16 registers of n/16 lanes (ntt_core.h), 4 (n = 256) or 2
+// (n = 512) messages per wavefront; the samples are drawn straight into the transform's input layout, both transforms, the two
+// key products, the inverse transform, the message encoding and the bit packing happen without a trip through HBM: per
+// encryption the kernel reads the 24n-byte tape and the n/8-byte message and writes the 2 n q_bits / 8-byte ciphertext.
+// q < 2^14 for both parameter sets, so everything runs in the small-modulus arithmetic (modarith.h MODE_MAD).  The sampler is
+// the guide-table search of the batched CDT kernel (sc_hip.hip): 64-entry table + 258-entry guide in LDS.
+#include "engine_internal.h"
+#include "ntt_core.h"
+
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+struct RlP { int32_t set, q, q_bits, n, n_bits, m_scale, o_scale_0, o_scale_1; float sigma, tail; int32_t pad[2]; };   // rlwe_set_t (rlwe_enc_params.h:37-61)
+
+constexpr int MAXTAB = 256;
+
+struct RlArgs {
+    const uint32_t *zf, *zfp, *zi, *zip;
+    ModK k;
+    uint32_t c0, c0p, c1, c1p;              // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs)
+    const uint64_t *cdf; const uint16_t *guide; int tab_size;
+    const uint32_t *key_a, *key_p, *key_r2; // NTT domain, engine order (position lp*16 + r holds index bitrev(lp*16 + r)), canonical
+    unsigned long long batch;
+    const uint8_t *msgs_in; uint8_t *msgs_out; size_t msg_stride;
+    const uint32_t *tapes; size_t tape_stride;
+    const uint8_t *ct_in; uint8_t *ct_out; size_t ct_stride;
+    int16_t *kg_a, *kg_p, *kg_r2;
+    int32_t m_scale, o0, o1;
+};
+
+__host__ __device__ constexpr int brv4(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
+
+struct Sampler {
+    const uint64_t *tab; const uint16_t *guide;
+    // gaussian_cdf_sample_64 (gaussian_cdf.c:639-659): largest b with cdf[b] < u, sign from the LSB of the same draw
+    __device__ __forceinline__ int32_t one(uint64_t u) const
+    {
+        const uint32_t t = (uint32_t)(u >> 56);
+        uint32_t lo = guide[t], hi = guide[t + 1];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi + 1) >> 1;
+            if (tab[mid] < u) lo = mid; else hi = mid - 1;
+        }
+        return (u & 1) ? (int32_t)lo : -(int32_t)lo;
+    }
+};
+
+// n Gaussian samples of one polynomial, drawn into the round-0 layout (register r of lane lp = coefficient r*LP + lp), as
+// residues in [0, q).  words: the 2n tape words of this vector (8-byte aligned).
+template <int LP>
+__device__ __forceinline__ void sample_poly(uint32_t (&x)[16], const uint32_t *words, bool valid, int lp, const Sampler &S, uint32_t q)
+{
+    uint2 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[r] = valid ? *reinterpret_cast<const uint2 *>(words + 2 * (r * LP + lp)) : make_uint2(0u, 0u);
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int32_t s = S.one(((uint64_t)w[r].x << 32) | w[r].y);                 // prng_64: high word first (prng.c:963-978)
+        x[r] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+    }
+}
+
+__device__ __forceinline__ uint32_t canon(uint32_t v, const ModK &k)               // any value below 2^23 -> [0, q)
+{ return csub(Mod<MODE_MAD>::mulc(v, 1u, k.one_p, k), k.q); }
+
+// Pack one polynomial staged in LDS (natural index order, canonical values) as QB-bit big-endian fields into `dst` (4-byte
+// aligned).  Word w takes bits [32w, 32w+32) of the stream: at most four consecutive coefficients.
+template <int N, int LP, int QB>
+__device__ __forceinline__ void pack_poly(const uint32_t *stage, uint8_t *dst, bool valid, int lp)
+{
+    constexpr int WORDS = N * QB / 32;
+    static_assert(N * QB % 32 == 0 && 3 * QB >= 31 && QB <= 16, "packing window");
+    for (int w = lp; w < WORDS; w += LP) {
+        const int i0 = (32 * w) / QB, o = 32 * w - i0 * QB;
+        uint64_t acc = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) acc = (acc << QB) | (uint64_t)((i0 + t < N) ? stage[i0 + t] : 0u);
+        const uint32_t v = (uint32_t)(acc >> (4 * QB - o - 32));
+        if (valid) reinterpret_cast<uint32_t *>(dst)[w] = __builtin_bswap32(v);
+    }
+}
+
+#define RL_PROLOGUE                                                                                                  \
+    using Y = Lay<L>;                                                                                                \
+    constexpr int N = Y::N, LP = Y::LP, PW = Y::PW;                                                                  \
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];                                                  \
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;                                                       \
+    const int pw = lane / LP, lp = lane % LP;                                                                        \
+    uint32_t *lds_poly = lds + wid * 1024 + pw * N;                                                                  \
+    const int blp = (int)(__builtin_bitreverse32((uint32_t)lp) >> (32 - (L - 4)));                                   \
+    const ModK k = a.k;                                                                                              \
+    const unsigned long long groups = (a.batch + PW - 1) / PW;                                                       \
+    const unsigned long long gstride = (unsigned long long)gridDim.x * 4;
+
+#define RL_TABLES                                                                                                    \
+    __shared__ uint64_t s_tab[MAXTAB];                                                                               \
+    __shared__ uint16_t s_guide[260];                                                                                \
+    for (int i = threadIdx.x; i < a.tab_size; i += blockDim.x) s_tab[i] = a.cdf[i];                                  \
+    for (int i = threadIdx.x; i < 258; i += blockDim.x) s_guide[i] = a.guide[i];                                     \
+    __syncthreads();                                                                                                 \
+    const Sampler S{ s_tab, s_guide };
+
+// rlwe_enc_encrypt, rlwe_enc.c:511-631
+template <int L, int QB>
+__global__ __launch_bounds__(256) void rlwe_encrypt_kernel(RlArgs a)
+{
+    RL_PROLOGUE
+    RL_TABLES
+    TwSet<L> twf, twi;
+    twf.load(a.zf, a.zfp, lp);
+    twi.load(a.zi, a.zip, lp);
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+        const unsigned long long item = g * PW + pw;
+        const bool valid = item < a.batch;
+        const uint32_t *tape = a.tapes + (valid ? (size_t)item * a.tape_stride : 0);
+        uint32_t x[16], t1[16], t2[16];
+        // e1 -> NTT(e1) (lazy, engine order); the two key products
+        sample_poly<LP>(x, tape, valid, lp, S, k.q);
+        fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
+        {
+            const uint4 *pa = reinterpret_cast<const uint4 *>(a.key_a + lp * 16), *pp = reinterpret_cast<const uint4 *>(a.key_p + lp * 16);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint4 va = pa[c], vp = pp[c];
+                const uint32_t ka[4] = { va.x, va.y, va.z, va.w }, kp[4] = { vp.x, vp.y, vp.z, vp.w };
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    t1[4 * c + e] = mulmod_small(x[4 * c + e], ka[e], k);        // < 2q(L+1) * q < 2^32
+                    t2[4 * c + e] = mulmod_small(x[4 * c + e], kp[e], k);
+                }
+            }
+        }
+        // c1 = a o NTT(e1) + NTT(e2), NTT domain, canonical (:593-602)
+        sample_poly<LP>(x, tape + 2 * N, valid, lp, S, k.q);
+        fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
+#pragma unroll
+        for (int r = 0; r < 16; r++) t1[r] = canon(t1[r] + x[r], k);
+        // c2 = INTT(p o NTT(e1)) + Encode(m) + e3 (:604-609)
+        inv_core<L, MODE_MAD>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+        sample_poly<LP>(x, tape + 4 * N, valid, lp, S, k.q);
+        const uint8_t *msg = a.msgs_in + (valid ? (size_t)item * a.msg_stride : 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = r * LP + lp;
+            const uint32_t bit = valid ? ((uint32_t)msg[j >> 3] >> (7 - (j & 7))) & 1u : 0u;
+            t2[r] = csub(csub(t2[r] + x[r] + bit * (uint32_t)a.m_scale, k.q2), k.q);     // < q + q + m_scale < 4q
+        }
+        uint8_t *ct = a.ct_out + (valid ? (size_t)item * a.ct_stride : 0);
+        // c1 sits at engine position lp*16 + r = natural index brv4(r)*LP + blp
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds_poly[brv4(r) * LP + blp] = t1[r];
+        wave_lds_fence();
+        pack_poly<N, LP, QB>(lds_poly, ct, valid, lp);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 16; r++) lds_poly[r * LP + lp] = t2[r];
+        wave_lds_fence();
+        pack_poly<N, LP, QB>(lds_poly, ct + N * QB / 8, valid, lp);
+        wave_lds_fence();
+    }
+}
+
+// rlwe_enc_decrypt, rlwe_enc.c:633-707
+template <int L, int QB>
+__global__ __launch_bounds__(256) void rlwe_decrypt_kernel(RlArgs a)
+{
+    RL_PROLOGUE
+    constexpr int CTW = 2 * N * QB / 32;                        // ciphertext words
+    static_assert(CTW < N, "the ciphertext is staged in the polynomial's LDS image");
+    TwSet<L> twi;
+    twi.load(a.zi, a.zip, lp);
+    uint32_t kr[16];
+    {
+        const uint4 *pr = reinterpret_cast<const uint4 *>(a.key_r2 + lp * 16);
+#pragma unroll
+        for (int c = 0; c < 4; c++) { const uint4 v = pr[c]; kr[4 * c] = v.x; kr[4 * c + 1] = v.y; kr[4 * c + 2] = v.z; kr[4 * c + 3] = v.w; }
+    }
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+        const unsigned long long item = g * PW + pw;
+        const bool valid = item < a.batch;
+        const uint32_t *ct = reinterpret_cast<const uint32_t *>(a.ct_in + (valid ? (size_t)item * a.ct_stride : 0));
+        for (int w = lp; w < CTW; w += LP) lds_poly[w] = valid ? __builtin_bswap32(ct[w]) : 0u;
+        if (lp == 0) lds_poly[CTW] = 0;                          // the word after the stream is read (and shifted out) by the last field
+        wave_lds_fence();
+        auto field = [&](int i) -> uint32_t {                     // coefficient i of the 2n-coefficient stream
+            const int bo = i * QB, wi = bo >> 5, o = bo & 31;
+            const uint64_t win = ((uint64_t)lds_poly[wi] << 32) | lds_poly[wi + 1];
+            return (uint32_t)(win >> (64 - o - QB)) & ((1u << QB) - 1u);
+        };
+        uint32_t x[16], c2[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            x[r] = mulmod_small(field(brv4(r) * LP + blp), kr[r], k);               // c1 (NTT domain, < 2^QB) o r2 -> [0, 2q)
+            c2[r] = field(N + r * LP + lp);
+        }
+        wave_lds_fence();
+        inv_core<L, MODE_MAD>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+        uint8_t *out = a.msgs_out + (valid ? (size_t)item * a.msg_stride : 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int32_t v = (int32_t)canon(x[r] + c2[r], k);
+            const unsigned long long m = __ballot(v > a.o0 && v < a.o1);             // lane = pw*LP + lp  <->  bit r*LP + lp of message pw
+            const uint32_t piece = __builtin_bitreverse32((uint32_t)(m >> (pw * LP))) >> (32 - LP);   // MSB-first, LP bits
+            if (valid && lp == r) {
+                if (LP == 16) { out[2 * r] = (uint8_t)(piece >> 8); out[2 * r + 1] = (uint8_t)piece; }
+                else { out[4 * r] = (uint8_t)(piece >> 24); out[4 * r + 1] = (uint8_t)(piece >> 16); out[4 * r + 2] = (uint8_t)(piece >> 8); out[4 * r + 3] = (uint8_t)piece; }
+            }
+        }
+    }
+}
+
+// rlwe_enc_keygen with a_gen / r1_gen / r2_gen, rlwe_enc.c:205-290, 425-493: one key pair per polynomial slot
+template <int L>
+__global__ __launch_bounds__(256) void rlwe_keygen_kernel(RlArgs a)
+{
+    RL_PROLOGUE
+    RL_TABLES
+    TwSet<L> twf;
+    twf.load(a.zf, a.zfp, lp);
+    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+        const unsigned long long item = g * PW + pw;
+        const bool valid = item < a.batch;
+        const uint32_t *tape = a.tapes + (valid ? (size_t)item * a.tape_stride : 0);
+        uint32_t ah[16], r1h[16], x[16];
+        // a: 16-bit halves of n/2 words, reduced mod q (:205-225)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = r * LP + lp;
+            const uint32_t w = valid ? tape[j >> 1] : 0u;
+            ah[r] = reduce_i32_small((int32_t)((j & 1) ? (w >> 16) : (w & 0xffffu)), k);
+        }
+        fwd_core<L, MODE_MAD, true>(ah, twf, lds_poly, lp, k);
+#pragma unroll
+        for (int r = 0; r < 16; r++) ah[r] = canon(ah[r], k);
+        // r1: Gaussian (:227-244)
+        sample_poly<LP>(r1h, tape + N / 2, valid, lp, S, k.q);
+        fwd_core<L, MODE_MAD, true>(r1h, twf, lds_poly, lp, k);
+        // r2: two-bit fields, 3 -> -1, 1 -> +1, else 0 (:246-285)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = r * LP + lp;
+            const uint32_t w = valid ? tape[N / 2 + 2 * N + (j >> 4)] : 0u;
+            const uint32_t f = (w >> (2 * (j & 15))) & 3u;
+            x[r] = (f == 3u) ? k.q - 1u : (f & 1u);
+        }
+        fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
+        // p = r1 - a r2 (:475-482); everything is stored as the reference stores it: SINT16, reference NTT order, canonical
+        const size_t base = (size_t)item * N;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t r2c = canon(x[r], k);
+            const uint32_t t = mulmod_small(ah[r], r2c, k);                         // [0, 2q)
+            const uint32_t pv = canon(r1h[r] + k.q2 - t, k);
+            const int i = brv4(r) * LP + blp;
+            if (valid) { a.kg_a[base + i] = (int16_t)ah[r]; a.kg_p[base + i] = (int16_t)pv; a.kg_r2[base + i] = (int16_t)r2c; }
+        }
+    }
+}
+
+}  // namespace
+
+struct sc_hip_rlwe {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    sc_hip_cdt *cdt;
+    RlP P;
+    uint32_t *d_keys;         // a | p | r2, engine order
+    bool have_pub, have_priv;
+};
+
+extern "C" void sc_hip_rlwe_destroy(sc_hip_rlwe_t *h)
+{
+    if (!h) return;
+    if (h->d_keys) (void)hipFree(h->d_keys);
+    if (h->cdt) sc_hip_cdt_destroy(h->cdt);
+    if (h->plan) sc_hip_plan_destroy(h->plan);
+    delete h;
+}
+
+extern "C" int sc_hip_rlwe_create(sc_hip_ctx_t *ctx, const sc_hip_rlwe_params_t *params, sc_hip_rlwe_t **out)
+{
+    if (!ctx || !params || !out) return fail("rlwe_create: null argument");
+    static_assert(sizeof(RlP) == sizeof(sc_hip_rlwe_params_t), "parameter struct layout");
+    RlP P; memcpy(&P, params, sizeof P);
+    if (!((P.n == 256 && P.q_bits == 13) || (P.n == 512 && P.q_bits == 14)) || (1 << P.n_bits) != P.n)
+        return fail("rlwe_create: (n, q_bits) must be (256, 13) or (512, 14) - the reference's parameter sets");
+    if (P.q < 3 || P.q >= (1 << 14) || P.q >= (1 << P.q_bits)) return fail("rlwe_create: q must be below 2^14 and fit q_bits");
+    if (P.m_scale < 0 || P.m_scale >= P.q || P.o_scale_0 < 0 || P.o_scale_1 > 65535) return fail("rlwe_create: scale parameters out of range");
+    sc_hip_rlwe *h = new sc_hip_rlwe;
+    memset(h, 0, sizeof *h);
+    h->ctx = ctx; h->P = P;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &h->plan) != SC_HIP_SUCCESS) { sc_hip_rlwe_destroy(h); return SC_HIP_FAILURE; }
+    if (sc_hip_cdt_create(ctx, P.tail, P.sigma, &h->cdt) != SC_HIP_SUCCESS) { sc_hip_rlwe_destroy(h); return SC_HIP_FAILURE; }
+    if (h->cdt->size > MAXTAB) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: tail*sigma gives a table above 256 entries"); }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&h->d_keys, 3 * (size_t)P.n * 4) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: device allocation failed"); }
+    *out = h;
+    return SC_HIP_SUCCESS;
+}
+
+// reference NTT order (SINT16, any representative) -> engine order, canonical
+static void rl_to_engine(const sc_hip_rlwe *h, const int16_t *src, uint32_t *dst)
+{
+    const int n = h->P.n, L = h->P.n_bits, q = h->P.q;
+    for (int j = 0; j < n; j++) {
+        uint32_t i = 0;
+        for (int b = 0; b < L; b++) i |= (((uint32_t)j >> b) & 1u) << (L - 1 - b);
+        int32_t v = src[i] % q;
+        dst[j] = (uint32_t)(v < 0 ? v + q : v);
+    }
+}
+
+extern "C" int sc_hip_rlwe_set_pubkey(sc_hip_rlwe_t *h, const int16_t *a, const int16_t *p)
+{
+    if (!h || !a || !p) return fail("rlwe_set_pubkey: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t n = (size_t)h->P.n;
+    std::vector<uint32_t> t(2 * n);
+    rl_to_engine(h, a, t.data()); rl_to_engine(h, p, t.data() + n);
+    HIPCHK(hipMemcpy(h->d_keys, t.data(), 2 * n * 4, hipMemcpyHostToDevice));
+    h->have_pub = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_rlwe_set_privkey(sc_hip_rlwe_t *h, const int16_t *r2)
+{
+    if (!h || !r2) return fail("rlwe_set_privkey: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t n = (size_t)h->P.n;
+    std::vector<uint32_t> t(n);
+    rl_to_engine(h, r2, t.data());
+    HIPCHK(hipMemcpy(h->d_keys + 2 * n, t.data(), n * 4, hipMemcpyHostToDevice));
+    h->have_priv = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_rlwe_ct_bytes(const sc_hip_rlwe_t *h) { return h ? 2 * (size_t)h->P.n * h->P.q_bits / 8 : 0; }
+extern "C" size_t sc_hip_rlwe_msg_bytes(const sc_hip_rlwe_t *h) { return h ? (size_t)h->P.n / 8 : 0; }
+extern "C" size_t sc_hip_rlwe_enc_words(const sc_hip_rlwe_t *h) { return h ? 6 * (size_t)h->P.n : 0; }
+extern "C" size_t sc_hip_rlwe_keygen_words(const sc_hip_rlwe_t *h) { return h ? (size_t)h->P.n / 2 + 2 * (size_t)h->P.n + (size_t)h->P.n / 16 : 0; }
+
+static void rl_args(const sc_hip_rlwe *h, size_t batch, RlArgs &a)
+{
+    const sc_hip_plan *p = h->plan;
+    const int n = p->n;
+    memset(&a, 0, sizeof a);
+    a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.k = p->k[1];
+    a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
+    a.cdf = h->cdt->d_cdf; a.guide = h->cdt->d_guide; a.tab_size = h->cdt->size;
+    a.key_a = h->d_keys; a.key_p = h->d_keys + n; a.key_r2 = h->d_keys + 2 * n;
+    a.batch = batch;
+    a.m_scale = h->P.m_scale; a.o0 = h->P.o_scale_0; a.o1 = h->P.o_scale_1;
+}
+
+static unsigned rl_blocks(const sc_hip_rlwe *h, size_t batch)
+{
+    const size_t pw = 1024 / (size_t)h->P.n, groups = (batch + pw - 1) / pw;
+    size_t blocks = (groups + 3) / 4;
+    const size_t cap = (size_t)h->ctx->cus * 8;                 // persistent waves: the per-lane twiddles are loaded once
+    if (blocks > cap) blocks = cap;
+    return (unsigned)(blocks ? blocks : 1);
+}
+
+static bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+extern "C" int sc_hip_rlwe_encrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_tapes, size_t tape_stride,
+                                   uint8_t *d_ct, size_t ct_stride, void *stream)
+{
+    if (!h) return fail("rlwe_encrypt: null handle");
+    if (!h->have_pub) return fail("rlwe_encrypt: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_msgs || !d_tapes || !d_ct) return fail("rlwe_encrypt: null device pointer");
+    if (msg_stride < sc_hip_rlwe_msg_bytes(h) || tape_stride < sc_hip_rlwe_enc_words(h) || ct_stride < sc_hip_rlwe_ct_bytes(h)) return fail("rlwe_encrypt: stride below the record size");
+    if (!aligned(d_tapes, 8) || (tape_stride & 1) || !aligned(d_ct, 4) || (ct_stride & 3)) return fail("rlwe_encrypt: tapes must be 8-byte aligned (even stride), ciphertexts 4-byte aligned");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    RlArgs a; rl_args(h, batch, a);
+    a.msgs_in = d_msgs; a.msg_stride = msg_stride; a.tapes = d_tapes; a.tape_stride = tape_stride; a.ct_out = d_ct; a.ct_stride = ct_stride;
+    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_encrypt_kernel<8, 13>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rlwe_encrypt_kernel<9, 14>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_rlwe_decrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_msgs, size_t msg_stride, void *stream)
+{
+    if (!h) return fail("rlwe_decrypt: null handle");
+    if (!h->have_priv) return fail("rlwe_decrypt: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_ct || !d_msgs) return fail("rlwe_decrypt: null device pointer");
+    if (msg_stride < sc_hip_rlwe_msg_bytes(h) || ct_stride < sc_hip_rlwe_ct_bytes(h)) return fail("rlwe_decrypt: stride below the record size");
+    if (!aligned(d_ct, 4) || (ct_stride & 3)) return fail("rlwe_decrypt: ciphertexts must be 4-byte aligned");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    RlArgs a; rl_args(h, batch, a);
+    a.ct_in = d_ct; a.ct_stride = ct_stride; a.msgs_out = d_msgs; a.msg_stride = msg_stride;
+    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_decrypt_kernel<8, 13>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rlwe_decrypt_kernel<9, 14>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_rlwe_keygen(sc_hip_rlwe_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, int16_t *d_a, int16_t *d_p, int16_t *d_r2, void *stream)
+{
+    if (!h) return fail("rlwe_keygen: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_tapes || !d_a || !d_p || !d_r2) return fail("rlwe_keygen: null device pointer");
+    if (tape_stride < sc_hip_rlwe_keygen_words(h)) return fail("rlwe_keygen: tape stride below the words a key pair consumes");
+    if (!aligned(d_tapes, 8) || (tape_stride & 1)) return fail("rlwe_keygen: tapes must be 8-byte aligned with an even stride");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    RlArgs a; rl_args(h, batch, a);
+    a.tapes = d_tapes; a.tape_stride = tape_stride; a.kg_a = d_a; a.kg_p = d_p; a.kg_r2 = d_r2;
+    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_keygen_kernel<8>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((rlwe_keygen_kernel<9>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}

@@ -30,6 +30,8 @@ SYMBOLS = [
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
+    'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
+    'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
     'sc_hip_time_op',
 ]
 # include/sc_hip_vtable.h
@@ -158,6 +160,17 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_rlwe_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_rlwe_destroy.argtypes = [vp]
+    L.sc_hip_rlwe_destroy.restype = None
+    L.sc_hip_rlwe_set_pubkey.argtypes = [vp, vp, vp]
+    L.sc_hip_rlwe_set_privkey.argtypes = [vp, vp]
+    for fn in ('sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes', 'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words'):
+        getattr(L, fn).argtypes = [vp]
+        getattr(L, fn).restype = sz
+    L.sc_hip_rlwe_encrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp, sz, vp]
+    L.sc_hip_rlwe_decrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp]
+    L.sc_hip_rlwe_keygen.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
     L.sc_hip_mlwe_expand_matrix.argtypes = [vp, sz, vp, sz, sz, C.c_int, i32, C.c_int, vp, vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
@@ -229,6 +242,9 @@ class Engine:
 
     def tesla(self, params):
         return Tesla(self, params)
+
+    def rlwe(self, params):
+        return Rlwe(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -692,6 +708,66 @@ class Tesla:
         _chk(self.L, self.L.sc_hip_tesla_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'tesla_verify')
         return verdicts
+
+
+class Rlwe:
+    """Batched Ring-LWE encryption under one key pair and batched key generation (rlwe_enc_encrypt / _decrypt / _keygen
+    counterpart).  params: the 12 words {set, q, q_bits, n, n_bits, m_scale, o_scale_0, o_scale_1, f32 sigma, f32 tail, 0, 0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 12
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_rlwe_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_rlwe_create')
+        self.h = h
+        self.n = int(self.par[3])
+        self.msg_bytes = self.L.sc_hip_rlwe_msg_bytes(h)
+        self.ct_bytes = self.L.sc_hip_rlwe_ct_bytes(h)
+        self.enc_words = self.L.sc_hip_rlwe_enc_words(h)
+        self.keygen_words = self.L.sc_hip_rlwe_keygen_words(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_rlwe_destroy(self.h)
+            self.h = None
+
+    def set_pubkey(self, a, p):
+        import numpy as np
+        f = lambda x: np.ascontiguousarray(np.asarray(x), dtype=np.int16)
+        a, p = f(a), f(p)
+        assert a.size == self.n and p.size == self.n
+        _chk(self.L, self.L.sc_hip_rlwe_set_pubkey(self.h, _ptr(a), _ptr(p)), 'rlwe_set_pubkey')
+
+    def set_privkey(self, r2):
+        import numpy as np
+        r2 = np.ascontiguousarray(np.asarray(r2), dtype=np.int16)
+        assert r2.size == self.n
+        _chk(self.L, self.L.sc_hip_rlwe_set_privkey(self.h, _ptr(r2)), 'rlwe_set_privkey')
+
+    def encrypt(self, msgs, tapes):
+        """msgs uint8 [batch][n/8], tapes int32/uint32 [batch][>= 6n] (device) -> ciphertexts uint8 [batch][ct_bytes]"""
+        import torch
+        batch = msgs.shape[0]
+        ct = torch.empty((batch, self.ct_bytes), dtype=torch.uint8, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_rlwe_encrypt(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(tapes), _rows(tapes), _ptr(ct), self.ct_bytes, _stream()), 'rlwe_encrypt')
+        return ct
+
+    def decrypt(self, ct):
+        import torch
+        batch = ct.shape[0]
+        msgs = torch.empty((batch, self.msg_bytes), dtype=torch.uint8, device=ct.device)
+        _chk(self.L, self.L.sc_hip_rlwe_decrypt(self.h, batch, _ptr(ct), _rows(ct), _ptr(msgs), self.msg_bytes, _stream()), 'rlwe_decrypt')
+        return msgs
+
+    def keygen(self, tapes):
+        """tapes [batch][>= keygen_words] -> a, p, r2 int16 [batch][n] in the reference's storage format"""
+        import torch
+        batch, dev = tapes.shape[0], tapes.device
+        a, p, r2 = (torch.empty((batch, self.n), dtype=torch.int16, device=dev) for _ in range(3))
+        _chk(self.L, self.L.sc_hip_rlwe_keygen(self.h, batch, _ptr(tapes), _rows(tapes), _ptr(a), _ptr(p), _ptr(r2), _stream()), 'rlwe_keygen')
+        return a, p, r2
 
 
 class Falcon:
