@@ -301,7 +301,7 @@ size_t sc_hip_rlwe_keygen_words(const sc_hip_rlwe_t *h);       /* n/2 + 2n + n/1
  * messages.  d_tapes[i * tape_stride ...]: the prng_32 word stream of sc->prng_ctx[0] for message i (8-byte aligned, even stride;
  * sc_hip_drbg_words produces it from seeds).  Ciphertext i = c1 (NTT domain, the reference's RLWE_ENC_ENABLE_NTT_TRANSMISSION
  * build, rlwe_enc.h:24) | c2, q_bits per coefficient MSB first - byte for byte the reference's output for the same words.
- * ct_stride: multiple of 4. */
+ * msg_stride, ct_stride: multiples of 4 (4-byte aligned rows). */
 int sc_hip_rlwe_encrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_tapes, size_t tape_stride,
                         uint8_t *d_ct, size_t ct_stride, void *stream);
 /* replaces: safecrypto_private_decrypt -> rlwe_enc_decrypt (rlwe_enc.c:633-707); any 2 n q_bits / 8 bytes are accepted, as there */

@@ -88,6 +88,8 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
     for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
         const uint32_t job = g * PW + pw;
         const bool valid = job < a.njobs;
+        // a job past the end is pointed at job 0 and its results are never stored: every load below stays unconditional (a
+        // predicated load compiles to a branch with a full s_waitcnt inside, which serialises the requests)
         const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
         const uint32_t item = aidx;           // slot index
         uint32_t x[16];
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
         if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) {
             const int32_t *src = a.in + ((size_t)item * a.per + sub) * N + lp;
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = valid ? reduce_i32(src[r * LP], k) : 0u;
+            for (int r = 0; r < 16; r++) x[r] = reduce_i32(src[r * LP], k);        // unconditional: an out-of-range job reads job 0 (see the loop head)
             fwd_core<L8, MODE_U32, true>(x, tw, lds_poly, lp, k);
             uint32_t *dst = a.out_int + ((size_t)item * a.per + sub) * N + lp * 16;
 #pragma unroll
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
                 const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + (size_t)item * a.key_item_stride + ((size_t)sub * a.l + j) * N + lp * 16);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const uint4 vy = valid ? py[c] : make_uint4(0, 0, 0, 0), va = pa[c];
+                    const uint4 vy = py[c], va = pa[c];
                     x[4 * c + 0] = csub(x[4 * c + 0] + montmul(vy.x, va.x, k), k.q2);
                     x[4 * c + 1] = csub(x[4 * c + 1] + montmul(vy.y, va.y, k), k.q2);
                     x[4 * c + 2] = csub(x[4 * c + 2] + montmul(vy.z, va.z, k), k.q2);
@@ -132,16 +134,26 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)sub * N + lp * 16);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
-                const uint4 vc = valid ? pc[c] : make_uint4(0, 0, 0, 0), vk = pk[c];
+                const uint4 vc = pc[c], vk = pk[c];
                 x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
                 x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
             }
         }
+        const size_t pk_off = ((size_t)item * a.kk + sub) * N + lp;     // [item][k][n] arrays
+        const size_t pl_off = ((size_t)item * a.l + sub) * N + lp;      // [item][l][n] arrays
+        // the epilogue's second operand is requested before the transform, not after it
+        int32_t pre[16];
+        uint8_t preh[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if (OP == DOP_CZ) pre[r] = a.y[pl_off + r * LP];
+            if (OP == DOP_CS2 || OP == DOP_CT1) pre[r] = a.w[pk_off + r * LP];
+            if (OP == DOP_CT0) pre[r] = a.r[pk_off + r * LP];
+            if (OP == DOP_CT1) preh[r] = a.h[pk_off + r * LP];
+        }
         inv_core<L8, MODE_U32>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
         if (!valid) continue;
 
-        const size_t pk_off = ((size_t)item * a.kk + sub) * N + lp;     // [item][k][n] arrays
-        const size_t pl_off = ((size_t)item * a.l + sub) * N + lp;      // [item][l][n] arrays
         if (OP == DOP_MATVEC) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             bool bad = false;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const uint32_t yy = reduce_i32(a.y[pl_off + r * LP], k);
+                const uint32_t yy = reduce_i32(pre[r], k);
                 const uint32_t zz = csub(csub(x[r] + yy, k.q2), k.q);
                 a.z[pl_off + r * LP] = (int32_t)zz;
                 bad |= norm_bad(zz, k.q, (uint32_t)a.gamma1_beta);
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             bool bad = false;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t ww = (uint32_t)pre[r];
                 const uint32_t rr = csub(ww + k.q - x[r], k.q);
                 a.r[pk_off + r * LP] = (int32_t)rr;
                 int32_t a0;
@@ -178,7 +190,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 bad |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta);
-                const uint32_t rr = (uint32_t)a.r[pk_off + r * LP];
+                const uint32_t rr = (uint32_t)pre[r];
                 const uint32_t s = csub(rr + x[r], k.q);        // wcs2 + ct0 (dilithium.c:1714-1715)
                 int32_t a0;
                 // make_hint (dilithium.c:1258-1284): r = s, z = q - ct0, (r + z) mod q == rr
@@ -194,11 +206,11 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             const int32_t m = ((int32_t)k.q - 1) / a.alpha, m_mask = m - 1;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const uint32_t ww = (uint32_t)a.w[pk_off + r * LP];
+                const uint32_t ww = (uint32_t)pre[r];
                 const uint32_t t = csub(ww + k.q - x[r], k.q);
                 int32_t a0;
                 int32_t a1 = (int32_t)round_alpha(t, a0, a.alpha, a.am, (int32_t)k.q);
-                if (a.h[pk_off + r * LP] == 1) { if (a0 > 0) a1++; else a1--; }
+                if (preh[r] == 1) { if (a0 > 0) a1++; else a1--; }
                 if (a1 < 0) a1 += m;
                 a.w1[pk_off + r * LP] = (uint8_t)(a1 & m_mask);
             }

@@ -15,7 +15,7 @@
 // key products, the inverse transform, the message encoding and the bit packing happen without a trip through HBM: per
 // encryption the kernel reads the 24n-byte tape and the n/8-byte message and writes the 2 n q_bits / 8-byte ciphertext.
 // q < 2^14 for both parameter sets, so everything runs in the small-modulus arithmetic (modarith.h MODE_MAD).  The sampler is
-// the guide-table search of the batched CDT kernel (sc_hip.hip): 64-entry table + 258-entry guide in LDS.
+// a guide-table search (64-entry table + 4096-entry guide in LDS, see Sampler below).
 #include "engine_internal.h"
 #include "ntt_core.h"
 
@@ -27,7 +27,7 @@ namespace {
 
 struct RlP { int32_t set, q, q_bits, n, n_bits, m_scale, o_scale_0, o_scale_1; float sigma, tail; int32_t pad[2]; };   // rlwe_set_t (rlwe_enc_params.h:37-61)
 
-constexpr int MAXTAB = 256;
+constexpr int MAXTAB = 256;           // sampler table entries (values fit the guide's 8-bit fields)
 
 struct RlArgs {
     const uint32_t *zf, *zfp, *zi, *zip;
@@ -45,34 +45,67 @@ struct RlArgs {
 
 __host__ __device__ constexpr int brv4(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
+// gaussian_cdf_sample_64 (gaussian_cdf.c:536-553, 639-659): the largest b with cdf[b] < u (0 if none), sign from the LSB of the
+// same draw.  A 4096-entry guide on the top 12 bits of u gives lo = max{b : cdf[b] < t 2^52} and cnt = max{b : cdf[b] <
+// (t+1) 2^52} - lo, so the answer is lo + #{b in (lo, lo+cnt] : cdf[b] < u}.  For sigma ~ 4.5-4.9 all but the last few of the
+// 4096 buckets have cnt <= 2: two unconditional probes (the table is padded with two all-ones entries, and entries above
+// lo + cnt are >= (t+1) 2^52 > u, so probing them adds nothing); the rare wider bucket takes the halving search.
 struct Sampler {
     const uint64_t *tab; const uint16_t *guide;
-    // gaussian_cdf_sample_64 (gaussian_cdf.c:639-659): largest b with cdf[b] < u, sign from the LSB of the same draw
-    __device__ __forceinline__ int32_t one(uint64_t u) const
+    __device__ __forceinline__ int32_t wide(uint64_t u, uint32_t lo, uint32_t hi) const
     {
-        const uint32_t t = (uint32_t)(u >> 56);
-        uint32_t lo = guide[t], hi = guide[t + 1];
         while (lo < hi) {
             const uint32_t mid = (lo + hi + 1) >> 1;
             if (tab[mid] < u) lo = mid; else hi = mid - 1;
         }
-        return (u & 1) ? (int32_t)lo : -(int32_t)lo;
+        return (int32_t)lo;
     }
 };
 
 // n Gaussian samples of one polynomial, drawn into the round-0 layout (register r of lane lp = coefficient r*LP + lp), as
-// residues in [0, q).  words: the 2n tape words of this vector (8-byte aligned).
-template <int LP>
-__device__ __forceinline__ void sample_poly(uint32_t (&x)[16], const uint32_t *words, bool valid, int lp, const Sampler &S, uint32_t q)
+// residues in [0, q).  w: the lane's 16 draws (two tape words each, high word first: prng_64, prng.c:963-978).
+__device__ __forceinline__ void sample_regs(uint32_t (&x)[16], const uint2 (&w)[16], const Sampler &S, uint32_t q)
 {
-    uint2 w[16];
+    uint32_t widest = 0;
+    // four draws at a time (guide reads, then the eight probes): enough LDS reads in flight to cover their latency without
+    // the 100+ live registers the fully unrolled form costs
 #pragma unroll
-    for (int r = 0; r < 16; r++) w[r] = valid ? *reinterpret_cast<const uint2 *>(words + 2 * (r * LP + lp)) : make_uint2(0u, 0u);
+    for (int c = 0; c < 16; c += 4) {
+        uint32_t g[4];
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int32_t s = S.one(((uint64_t)w[r].x << 32) | w[r].y);                 // prng_64: high word first (prng.c:963-978)
-        x[r] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+        for (int e = 0; e < 4; e++) g[e] = S.guide[w[c + e].x >> 20];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint64_t u = ((uint64_t)w[c + e].x << 32) | w[c + e].y;
+            const uint32_t lo = g[e] & 0xffu;
+            const uint32_t a = lo + (uint32_t)(S.tab[lo + 1] < u) + (uint32_t)(S.tab[lo + 2] < u);
+            widest = max(widest, g[e]);
+            const int32_t s = (w[c + e].y & 1u) ? (int32_t)a : -(int32_t)a;
+            x[c + e] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (__builtin_expect(widest >= (3u << 8), 0)) {                                  // some bucket of this lane holds more than two candidates
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t g = S.guide[w[r].x >> 20], lo = g & 0xffu, cnt = g >> 8;
+            if (cnt > 2) {
+                const uint64_t u = ((uint64_t)w[r].x << 32) | w[r].y;
+                const int32_t a = S.wide(u, lo, lo + cnt);
+                const int32_t s = (w[r].y & 1u) ? a : -a;
+                x[r] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+            }
+        }
+    }
+}
+
+// Loads are UNCONDITIONAL: a lane whose item is past the end of the batch is pointed at item 0 instead (its results are never
+// stored).  A predicated load becomes a branch with a full s_waitcnt inside, which serialises the 16 requests.
+template <int LP>
+__device__ __forceinline__ void load_draws(uint2 (&w)[16], const uint32_t *words, int lp)
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) w[r] = *reinterpret_cast<const uint2 *>(words + 2 * (r * LP + lp));
 }
 
 __device__ __forceinline__ uint32_t canon(uint32_t v, const ModK &k)               // any value below 2^23 -> [0, q)
@@ -108,67 +141,97 @@ __device__ __forceinline__ void pack_poly(const uint32_t *stage, uint8_t *dst, b
     const unsigned long long gstride = (unsigned long long)gridDim.x * 4;
 
 #define RL_TABLES                                                                                                    \
-    __shared__ uint64_t s_tab[MAXTAB];                                                                               \
-    __shared__ uint16_t s_guide[260];                                                                                \
-    for (int i = threadIdx.x; i < a.tab_size; i += blockDim.x) s_tab[i] = a.cdf[i];                                  \
-    for (int i = threadIdx.x; i < 258; i += blockDim.x) s_guide[i] = a.guide[i];                                     \
-    __syncthreads();                                                                                                 \
+    __shared__ uint64_t s_tab[MAXTAB + 2];                                                                           \
+    __shared__ uint16_t s_guide[4096];                                                                               \
+    for (int i = threadIdx.x; i < a.tab_size + 2; i += blockDim.x) s_tab[i] = i < a.tab_size ? a.cdf[i] : ~0ull;     \
+    for (int i = threadIdx.x; i < 2048; i += blockDim.x) reinterpret_cast<uint32_t *>(s_guide)[i] = reinterpret_cast<const uint32_t *>(a.guide)[i]; \
     const Sampler S{ s_tab, s_guide };
 
-// rlwe_enc_encrypt, rlwe_enc.c:511-631
+// All three kernels are persistent-wave loops that would otherwise be a chain load -> compute -> load -> ... per wave at one or
+// two waves per SIMD, i.e. run at the HBM latency.  They are software-pipelined like the NTT kernels (sc_hip.hip): the words
+// the NEXT step needs are requested before the current step's arithmetic starts (one polynomial's draws = 32 registers ahead).
+
+// rlwe_enc_encrypt, rlwe_enc.c:511-631.  Register budget: the two key products a o NTT(e1), p o NTT(e1) (both below 2q < 2^15)
+// are parked as one packed word per coefficient in a lane-private LDS slot while e2 is sampled and transformed, and only one
+// polynomial's draws are held at a time, so two waves fit a SIMD without spills for both n.
+#ifndef RL_ENC_WAVES
+#define RL_ENC_WAVES(L) 2            /* measured: 3 waves (168 registers) spills and is 20-30% slower */
+#endif
 template <int L, int QB>
-__global__ __launch_bounds__(256) void rlwe_encrypt_kernel(RlArgs a)
+__global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlArgs a)
 {
     RL_PROLOGUE
     RL_TABLES
+    __shared__ __attribute__((aligned(16))) uint32_t s_keys[2 * N];       // a | p, engine order
+    __shared__ uint32_t s_park[4][16 * 64];                                 // per wave: slot r*64 + lane
+    __shared__ uint32_t s_msg[4][N / 8];                                    // per wave: PW messages of N/32 words
+    for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) s_keys[i] = a.key_a[i];
+    __syncthreads();
     TwSet<L> twf, twi;
     twf.load(a.zf, a.zfp, lp);
     twi.load(a.zi, a.zip, lp);
-    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+    unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
+    if (g >= groups) return;
+    uint8_t *msg_lds = reinterpret_cast<uint8_t *>(&s_msg[wid][pw * (N / 32)]);
+    uint32_t *park = &s_park[wid][lane];
+    uint2 wn[16];
+    {
+        const unsigned long long item = g * PW + pw;
+        load_draws<LP>(wn, a.tapes + (item < a.batch ? (size_t)item * a.tape_stride : 0), lp);
+    }
+    for (; g < groups; g += gstride) {
         const unsigned long long item = g * PW + pw;
         const bool valid = item < a.batch;
         const uint32_t *tape = a.tapes + (valid ? (size_t)item * a.tape_stride : 0);
-        uint32_t x[16], t1[16], t2[16];
-        // e1 -> NTT(e1) (lazy, engine order); the two key products
-        sample_poly<LP>(x, tape, valid, lp, S, k.q);
+        uint32_t x[16];
+        // e1 -> NTT(e1) (lazy, engine order) -> the two key products, parked.  e2's draws and the message are in flight meanwhile.
+        sample_regs(x, wn, S, k.q);
+        load_draws<LP>(wn, tape + 2 * N, lp);
+        const uint32_t mword = reinterpret_cast<const uint32_t *>(a.msgs_in + (valid ? (size_t)item * a.msg_stride : 0))[lp & (N / 32 - 1)];
         fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
         {
-            const uint4 *pa = reinterpret_cast<const uint4 *>(a.key_a + lp * 16), *pp = reinterpret_cast<const uint4 *>(a.key_p + lp * 16);
+            const uint4 *pa = reinterpret_cast<const uint4 *>(s_keys + lp * 16), *pp = reinterpret_cast<const uint4 *>(s_keys + N + lp * 16);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const uint4 va = pa[c], vp = pp[c];
                 const uint32_t ka[4] = { va.x, va.y, va.z, va.w }, kp[4] = { vp.x, vp.y, vp.z, vp.w };
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    t1[4 * c + e] = mulmod_small(x[4 * c + e], ka[e], k);        // < 2q(L+1) * q < 2^32
-                    t2[4 * c + e] = mulmod_small(x[4 * c + e], kp[e], k);
-                }
+                for (int e = 0; e < 4; e++)                                         // x < 2q(L+1), key < q: products below 2^32
+                    park[(4 * c + e) * 64] = mulmod_small(x[4 * c + e], ka[e], k) | (mulmod_small(x[4 * c + e], kp[e], k) << 16);
             }
         }
-        // c1 = a o NTT(e1) + NTT(e2), NTT domain, canonical (:593-602)
-        sample_poly<LP>(x, tape + 2 * N, valid, lp, S, k.q);
+        // c1 = a o NTT(e1) + NTT(e2), NTT domain, canonical (:593-602); e3's draws in flight
+        sample_regs(x, wn, S, k.q);
+        load_draws<LP>(wn, tape + 4 * N, lp);
         fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
-#pragma unroll
-        for (int r = 0; r < 16; r++) t1[r] = canon(t1[r] + x[r], k);
-        // c2 = INTT(p o NTT(e1)) + Encode(m) + e3 (:604-609)
-        inv_core<L, MODE_MAD>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-        sample_poly<LP>(x, tape + 4 * N, valid, lp, S, k.q);
-        const uint8_t *msg = a.msgs_in + (valid ? (size_t)item * a.msg_stride : 0);
+        uint8_t *ct = a.ct_out + (valid ? (size_t)item * a.ct_stride : 0);
+        uint32_t t2[16];
+        wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int j = r * LP + lp;
-            const uint32_t bit = valid ? ((uint32_t)msg[j >> 3] >> (7 - (j & 7))) & 1u : 0u;
-            t2[r] = csub(csub(t2[r] + x[r] + bit * (uint32_t)a.m_scale, k.q2), k.q);     // < q + q + m_scale < 4q
+            const uint32_t pk = park[r * 64];
+            t2[r] = pk >> 16;
+            lds_poly[brv4(r) * LP + blp] = canon((pk & 0xffffu) + x[r], k);       // engine position lp*16 + r = natural index brv4(r)*LP + blp
         }
-        uint8_t *ct = a.ct_out + (valid ? (size_t)item * a.ct_stride : 0);
-        // c1 sits at engine position lp*16 + r = natural index brv4(r)*LP + blp
-#pragma unroll
-        for (int r = 0; r < 16; r++) lds_poly[brv4(r) * LP + blp] = t1[r];
         wave_lds_fence();
         pack_poly<N, LP, QB>(lds_poly, ct, valid, lp);
         wave_lds_fence();
+        // c2 = INTT(p o NTT(e1)) + Encode(m) + e3 (:604-609); the next group's e1 draws in flight
+        inv_core<L, MODE_MAD>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+        sample_regs(x, wn, S, k.q);
+        {
+            const unsigned long long ng = g + gstride, nitem = ng * PW + pw;
+            const bool nvalid = ng < groups && nitem < a.batch;
+            load_draws<LP>(wn, a.tapes + (nvalid ? (size_t)nitem * a.tape_stride : 0), lp);
+        }
+        if (lp < N / 32) reinterpret_cast<uint32_t *>(msg_lds)[lp] = mword;
+        wave_lds_fence();
 #pragma unroll
-        for (int r = 0; r < 16; r++) lds_poly[r * LP + lp] = t2[r];
+        for (int r = 0; r < 16; r++) {
+            const int j = r * LP + lp;
+            const uint32_t bit = ((uint32_t)msg_lds[j >> 3] >> (7 - (j & 7))) & 1u;
+            lds_poly[j] = csub(csub(t2[r] + x[r] + bit * (uint32_t)a.m_scale, k.q2), k.q);     // < q + q + m_scale < 4q
+        }
         wave_lds_fence();
         pack_poly<N, LP, QB>(lds_poly, ct + N * QB / 8, valid, lp);
         wave_lds_fence();
@@ -181,6 +244,7 @@ __global__ __launch_bounds__(256) void rlwe_decrypt_kernel(RlArgs a)
 {
     RL_PROLOGUE
     constexpr int CTW = 2 * N * QB / 32;                        // ciphertext words
+    constexpr int KW = (CTW + LP - 1) / LP;                     // per lane
     static_assert(CTW < N, "the ciphertext is staged in the polynomial's LDS image");
     TwSet<L> twi;
     twi.load(a.zi, a.zip, lp);
@@ -190,13 +254,25 @@ __global__ __launch_bounds__(256) void rlwe_decrypt_kernel(RlArgs a)
 #pragma unroll
         for (int c = 0; c < 4; c++) { const uint4 v = pr[c]; kr[4 * c] = v.x; kr[4 * c + 1] = v.y; kr[4 * c + 2] = v.z; kr[4 * c + 3] = v.w; }
     }
-    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+    unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
+    if (g >= groups) return;
+    uint32_t cn[KW];
+    auto fetch = [&](unsigned long long gg) {
+        const unsigned long long item = gg * PW + pw;
+        const bool ok = gg < groups && item < a.batch;
+        const uint32_t *ct = reinterpret_cast<const uint32_t *>(a.ct_in + (ok ? (size_t)item * a.ct_stride : 0));
+#pragma unroll
+        for (int i = 0; i < KW; i++) cn[i] = ct[min(lp + LP * i, CTW - 1)];                  // unconditional (see load_draws)
+    };
+    fetch(g);
+    for (; g < groups; g += gstride) {
         const unsigned long long item = g * PW + pw;
         const bool valid = item < a.batch;
-        const uint32_t *ct = reinterpret_cast<const uint32_t *>(a.ct_in + (valid ? (size_t)item * a.ct_stride : 0));
-        for (int w = lp; w < CTW; w += LP) lds_poly[w] = valid ? __builtin_bswap32(ct[w]) : 0u;
+#pragma unroll
+        for (int i = 0; i < KW; i++) if (lp + LP * i < CTW) lds_poly[lp + LP * i] = __builtin_bswap32(cn[i]);
         if (lp == 0) lds_poly[CTW] = 0;                          // the word after the stream is read (and shifted out) by the last field
         wave_lds_fence();
+        fetch(g + gstride);                                       // the next group's ciphertexts are in flight during the transform
         auto field = [&](int i) -> uint32_t {                     // coefficient i of the 2n-coefficient stream
             const int bo = i * QB, wi = bo >> 5, o = bo & 31;
             const uint64_t win = ((uint64_t)lds_poly[wi] << 32) | lds_poly[wi + 1];
@@ -230,32 +306,47 @@ __global__ __launch_bounds__(256) void rlwe_keygen_kernel(RlArgs a)
 {
     RL_PROLOGUE
     RL_TABLES
+    __syncthreads();
     TwSet<L> twf;
     twf.load(a.zf, a.zfp, lp);
-    for (unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid; g < groups; g += gstride) {
+    unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
+    if (g >= groups) return;
+    uint32_t an[16];                                              // the a-words of the group about to be processed
+    auto fetch_a = [&](unsigned long long gg) {
+        const unsigned long long item = gg * PW + pw;
+        const bool ok = gg < groups && item < a.batch;
+        const uint32_t *tape = a.tapes + (ok ? (size_t)item * a.tape_stride : 0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) an[r] = tape[(r * LP + lp) >> 1];                        // unconditional (see load_draws)
+    };
+    fetch_a(g);
+    for (; g < groups; g += gstride) {
         const unsigned long long item = g * PW + pw;
         const bool valid = item < a.batch;
         const uint32_t *tape = a.tapes + (valid ? (size_t)item * a.tape_stride : 0);
-        uint32_t ah[16], r1h[16], x[16];
-        // a: 16-bit halves of n/2 words, reduced mod q (:205-225)
+        uint32_t ah[16], r1h[16], x[16], rw[16];
+        uint2 w[16];
+        // a: 16-bit halves of n/2 words, reduced mod q (:205-225); the Gaussian draws and the r2 words in flight
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int j = r * LP + lp;
-            const uint32_t w = valid ? tape[j >> 1] : 0u;
-            ah[r] = reduce_i32_small((int32_t)((j & 1) ? (w >> 16) : (w & 0xffffu)), k);
+            ah[r] = reduce_i32_small((int32_t)((j & 1) ? (an[r] >> 16) : (an[r] & 0xffffu)), k);
         }
+        load_draws<LP>(w, tape + N / 2, lp);
+#pragma unroll
+        for (int r = 0; r < 16; r++) rw[r] = tape[N / 2 + 2 * N + ((r * LP + lp) >> 4)];
         fwd_core<L, MODE_MAD, true>(ah, twf, lds_poly, lp, k);
 #pragma unroll
         for (int r = 0; r < 16; r++) ah[r] = canon(ah[r], k);
-        // r1: Gaussian (:227-244)
-        sample_poly<LP>(r1h, tape + N / 2, valid, lp, S, k.q);
+        // r1: Gaussian (:227-244); the next group's a-words in flight
+        sample_regs(r1h, w, S, k.q);
+        fetch_a(g + gstride);
         fwd_core<L, MODE_MAD, true>(r1h, twf, lds_poly, lp, k);
         // r2: two-bit fields, 3 -> -1, 1 -> +1, else 0 (:246-285)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int j = r * LP + lp;
-            const uint32_t w = valid ? tape[N / 2 + 2 * N + (j >> 4)] : 0u;
-            const uint32_t f = (w >> (2 * (j & 15))) & 3u;
+            const uint32_t f = (rw[r] >> (2 * (j & 15))) & 3u;
             x[r] = (f == 3u) ? k.q - 1u : (f & 1u);
         }
         fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
@@ -280,6 +371,7 @@ struct sc_hip_rlwe {
     sc_hip_cdt *cdt;
     RlP P;
     uint32_t *d_keys;         // a | p | r2, engine order
+    uint16_t *d_guide;        // 4096 entries: lo | cnt << 8 (see Sampler)
     bool have_pub, have_priv;
 };
 
@@ -287,6 +379,7 @@ extern "C" void sc_hip_rlwe_destroy(sc_hip_rlwe_t *h)
 {
     if (!h) return;
     if (h->d_keys) (void)hipFree(h->d_keys);
+    if (h->d_guide) (void)hipFree(h->d_guide);
     if (h->cdt) sc_hip_cdt_destroy(h->cdt);
     if (h->plan) sc_hip_plan_destroy(h->plan);
     delete h;
@@ -307,7 +400,22 @@ extern "C" int sc_hip_rlwe_create(sc_hip_ctx_t *ctx, const sc_hip_rlwe_params_t 
     if (sc_hip_plan_create(ctx, P.q, P.n, &h->plan) != SC_HIP_SUCCESS) { sc_hip_rlwe_destroy(h); return SC_HIP_FAILURE; }
     if (sc_hip_cdt_create(ctx, P.tail, P.sigma, &h->cdt) != SC_HIP_SUCCESS) { sc_hip_rlwe_destroy(h); return SC_HIP_FAILURE; }
     if (h->cdt->size > MAXTAB) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: tail*sigma gives a table above 256 entries"); }
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&h->d_keys, 3 * (size_t)P.n * 4) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: device allocation failed"); }
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc((void **)&h->d_keys, 3 * (size_t)P.n * 4) != hipSuccess ||
+        hipMalloc((void **)&h->d_guide, 4096 * 2) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: device allocation failed"); }
+    {
+        const std::vector<uint64_t> &cdf = h->cdt->cdf;
+        const int size = h->cdt->size;
+        std::vector<uint16_t> g(4096);
+        int lo = 0;                                                              // max{b : cdf[b] < t 2^52}, 0 if none; monotone in t
+        for (int t = 0; t < 4096; t++) {
+            while (lo + 1 < size && cdf[lo + 1] < ((uint64_t)t << 52)) lo++;
+            int hi = lo;                                                         // max{b : cdf[b] < (t+1) 2^52}; every entry is below 2^64
+            if (t == 4095) hi = size - 1;
+            else while (hi + 1 < size && cdf[hi + 1] < ((uint64_t)(t + 1) << 52)) hi++;
+            g[t] = (uint16_t)(lo | ((hi - lo) << 8));
+        }
+        if (hipMemcpy(h->d_guide, g.data(), 4096 * 2, hipMemcpyHostToDevice) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: cannot upload the sampler guide"); }
+    }
     *out = h;
     return SC_HIP_SUCCESS;
 }
@@ -361,19 +469,28 @@ static void rl_args(const sc_hip_rlwe *h, size_t batch, RlArgs &a)
     a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.k = p->k[1];
     a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
-    a.cdf = h->cdt->d_cdf; a.guide = h->cdt->d_guide; a.tab_size = h->cdt->size;
+    a.cdf = h->cdt->d_cdf; a.guide = h->d_guide; a.tab_size = h->cdt->size;
     a.key_a = h->d_keys; a.key_p = h->d_keys + n; a.key_r2 = h->d_keys + 2 * n;
     a.batch = batch;
     a.m_scale = h->P.m_scale; a.o0 = h->P.o_scale_0; a.o1 = h->P.o_scale_1;
 }
 
-static unsigned rl_blocks(const sc_hip_rlwe *h, size_t batch)
+// persistent waves: the grid is what the device holds at once (tables, keys and per-lane twiddles are loaded once per wave)
+template <typename K>
+static hipError_t rl_launch(K kernel, const sc_hip_rlwe *h, size_t batch, const RlArgs &a, void *stream)
 {
+    static int per_cu = 0;                                      // one static per kernel instantiation
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        per_cu = nb;
+    }
     const size_t pw = 1024 / (size_t)h->P.n, groups = (batch + pw - 1) / pw;
     size_t blocks = (groups + 3) / 4;
-    const size_t cap = (size_t)h->ctx->cus * 8;                 // persistent waves: the per-lane twiddles are loaded once
+    const size_t cap = (size_t)h->ctx->cus * (size_t)per_cu;
     if (blocks > cap) blocks = cap;
-    return (unsigned)(blocks ? blocks : 1);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(blocks ? blocks : 1)), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError();
 }
 
 static bool aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
@@ -386,13 +503,12 @@ extern "C" int sc_hip_rlwe_encrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_msgs || !d_tapes || !d_ct) return fail("rlwe_encrypt: null device pointer");
     if (msg_stride < sc_hip_rlwe_msg_bytes(h) || tape_stride < sc_hip_rlwe_enc_words(h) || ct_stride < sc_hip_rlwe_ct_bytes(h)) return fail("rlwe_encrypt: stride below the record size");
-    if (!aligned(d_tapes, 8) || (tape_stride & 1) || !aligned(d_ct, 4) || (ct_stride & 3)) return fail("rlwe_encrypt: tapes must be 8-byte aligned (even stride), ciphertexts 4-byte aligned");
+    if (!aligned(d_tapes, 8) || (tape_stride & 1) || !aligned(d_ct, 4) || (ct_stride & 3) || !aligned(d_msgs, 4) || (msg_stride & 3))
+        return fail("rlwe_encrypt: tapes must be 8-byte aligned (even stride), messages and ciphertexts 4-byte aligned (strides multiples of 4)");
     HIPCHK(hipSetDevice(h->ctx->device));
     RlArgs a; rl_args(h, batch, a);
     a.msgs_in = d_msgs; a.msg_stride = msg_stride; a.tapes = d_tapes; a.tape_stride = tape_stride; a.ct_out = d_ct; a.ct_stride = ct_stride;
-    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_encrypt_kernel<8, 13>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((rlwe_encrypt_kernel<9, 14>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    HIPCHK(hipGetLastError());
+    HIPCHK(h->P.n == 256 ? rl_launch(rlwe_encrypt_kernel<8, 13>, h, batch, a, stream) : rl_launch(rlwe_encrypt_kernel<9, 14>, h, batch, a, stream));
     return SC_HIP_SUCCESS;
 }
 
@@ -407,9 +523,7 @@ extern "C" int sc_hip_rlwe_decrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t
     HIPCHK(hipSetDevice(h->ctx->device));
     RlArgs a; rl_args(h, batch, a);
     a.ct_in = d_ct; a.ct_stride = ct_stride; a.msgs_out = d_msgs; a.msg_stride = msg_stride;
-    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_decrypt_kernel<8, 13>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((rlwe_decrypt_kernel<9, 14>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    HIPCHK(hipGetLastError());
+    HIPCHK(h->P.n == 256 ? rl_launch(rlwe_decrypt_kernel<8, 13>, h, batch, a, stream) : rl_launch(rlwe_decrypt_kernel<9, 14>, h, batch, a, stream));
     return SC_HIP_SUCCESS;
 }
 
@@ -423,8 +537,6 @@ extern "C" int sc_hip_rlwe_keygen(sc_hip_rlwe_t *h, size_t batch, const uint32_t
     HIPCHK(hipSetDevice(h->ctx->device));
     RlArgs a; rl_args(h, batch, a);
     a.tapes = d_tapes; a.tape_stride = tape_stride; a.kg_a = d_a; a.kg_p = d_p; a.kg_r2 = d_r2;
-    if (h->P.n == 256) hipLaunchKernelGGL((rlwe_keygen_kernel<8>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((rlwe_keygen_kernel<9>), dim3(rl_blocks(h, batch)), dim3(256), 0, (hipStream_t)stream, a);
-    HIPCHK(hipGetLastError());
+    HIPCHK(h->P.n == 256 ? rl_launch(rlwe_keygen_kernel<8>, h, batch, a, stream) : rl_launch(rlwe_keygen_kernel<9>, h, batch, a, stream));
     return SC_HIP_SUCCESS;
 }
