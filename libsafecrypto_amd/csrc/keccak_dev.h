@@ -30,6 +30,13 @@ __device__ __forceinline__ uint64_t rol64(uint64_t x, int n)
     return ((uint64_t)nhi << 32) | nlo;
 }
 
+// gfx950 has V_BITOP3_B32 (any three-input boolean function in one instruction): the five-way column parity of theta is two of
+// them per 32-bit half instead of four XORs, and a chi term a ^ (~b & c) is one instead of two.  The compiler forms them from
+// 32-bit expressions but not from the split halves of 64-bit ones, so the permutation is written on explicit halves:
+// about 190 instructions per round instead of 270.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t chi3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xD2); }   // a ^ (~b & c)
+
 template <bool STD>
 __device__ __forceinline__ void keccak_permute_regs(uint64_t (&s)[25])
 {
@@ -41,32 +48,47 @@ __device__ __forceinline__ void keccak_permute_regs(uint64_t (&s)[25])
         0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL };
     constexpr int ROTC[24] = { 1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44 };
     constexpr int PILN[24] = { 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1 };
+    uint32_t lo[25], hi[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) { lo[i] = (uint32_t)s[i]; hi[i] = (uint32_t)(s[i] >> 32); }
 #pragma unroll 1
     for (int r = 0; r < 24; r++) {
-        uint64_t bc[5], t;
-#pragma unroll
-        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
+        uint32_t bl[5], bh[5];
 #pragma unroll
         for (int i = 0; i < 5; i++) {
-            t = bc[(i + 4) % 5] ^ rol64(bc[(i + 1) % 5], 1);
-#pragma unroll
-            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
+            bl[i] = xor3(xor3(lo[i], lo[i + 5], lo[i + 10]), lo[i + 15], lo[i + 20]);
+            bh[i] = xor3(xor3(hi[i], hi[i + 5], hi[i + 10]), hi[i + 15], hi[i + 20]);
         }
-        t = s[1];
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int p = (i + 4) % 5, n = (i + 1) % 5;
+            const uint32_t tl = bl[p] ^ __builtin_amdgcn_alignbit(bl[n], bh[n], 31), th = bh[p] ^ __builtin_amdgcn_alignbit(bh[n], bl[n], 31);   // rol 1
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) { lo[j + i] ^= tl; hi[j + i] ^= th; }
+        }
+        uint32_t tl = lo[1], th = hi[1];
 #pragma unroll
         for (int i = 0; i < 24; i++) {
-            const uint64_t nx = s[PILN[i]];
-            s[PILN[i]] = rol64(t, ROTC[i]);
-            t = nx;
+            const uint32_t nl = lo[PILN[i]], nh = hi[PILN[i]];
+            uint32_t a = tl, b = th;
+            int n = ROTC[i];
+            if (n >= 32) { a = th; b = tl; n -= 32; }
+            if (n == 0) { lo[PILN[i]] = a; hi[PILN[i]] = b; }
+            else { lo[PILN[i]] = __builtin_amdgcn_alignbit(a, b, 32 - n); hi[PILN[i]] = __builtin_amdgcn_alignbit(b, a, 32 - n); }
+            tl = nl; th = nh;
         }
 #pragma unroll
         for (int jj = 0; jj < 5; jj++) {
             const int j = STD ? 5 * jj : jj;                    // tinysha3.c:186-235 uses 0,1,2,3,4
-            uint64_t c0 = s[j], c1 = s[j + 1], c2 = s[j + 2], c3 = s[j + 3], c4 = s[j + 4];
-            s[j] ^= (~c1) & c2; s[j + 1] ^= (~c2) & c3; s[j + 2] ^= (~c3) & c4; s[j + 3] ^= (~c4) & c0; s[j + 4] ^= (~c0) & c1;
+            const uint32_t c0 = lo[j], c1 = lo[j + 1], c2 = lo[j + 2], c3 = lo[j + 3], c4 = lo[j + 4];
+            lo[j] = chi3(c0, c1, c2); lo[j + 1] = chi3(c1, c2, c3); lo[j + 2] = chi3(c2, c3, c4); lo[j + 3] = chi3(c3, c4, c0); lo[j + 4] = chi3(c4, c0, c1);
+            const uint32_t d0 = hi[j], d1 = hi[j + 1], d2 = hi[j + 2], d3 = hi[j + 3], d4 = hi[j + 4];
+            hi[j] = chi3(d0, d1, d2); hi[j + 1] = chi3(d1, d2, d3); hi[j + 2] = chi3(d2, d3, d4); hi[j + 3] = chi3(d3, d4, d0); hi[j + 4] = chi3(d4, d0, d1);
         }
-        s[0] ^= RC[r];
+        lo[0] ^= (uint32_t)RC[r]; hi[0] ^= (uint32_t)(RC[r] >> 32);
     }
+#pragma unroll
+    for (int i = 0; i < 25; i++) s[i] = ((uint64_t)hi[i] << 32) | lo[i];
 }
 
 // NT = threads per workgroup (LDS stride of the state words)

@@ -87,7 +87,14 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
     const uint32_t groups = (a.njobs + PW - 1) / PW;
     for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
         const uint32_t job = g * PW + pw;
-        const bool valid = job < a.njobs;
+        bool valid = job < a.njobs;
+        // signing: an attempt an earlier test already rejected needs no further work (its r / hint arrays are never read: the
+        // finish kernel only looks at slots whose flags stayed 0).  The wave skips the group when none of its four jobs is live.
+        if (OP == DOP_CS2 || OP == DOP_CT0) {
+            const uint32_t fl = a.flags[valid ? job / (uint32_t)a.per : 0];
+            valid = valid && (OP == DOP_CS2 ? (fl & 1u) == 0 : fl == 0);
+            if (__ballot(valid) == 0) continue;
+        }
         // a job past the end is pointed at job 0 and its results are never stored: every load below stays unconditional (a
         // predicated load compiles to a branch with a full s_waitcnt inside, which serialises the requests)
         const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
