@@ -214,6 +214,33 @@ def bliss_kyber_extra(eng, torch):
             sys.stderr.write(f'ring-tesla cpu baseline failed: {e}\n')
     out['ring_tesla_0'] = rt
     ts.close()
+    # RLWE-Enc (sets 0 and 1): fused encrypt / decrypt kernels, 6n CSPRNG words per encryption resident in HBM
+    G = load_golden('rlwe_ref.txt')
+    for tag, set_ in (('rlwe0', 0), ('rlwe1', 1)):
+        r = eng.rlwe(G[f'{tag}_params'])
+        r.set_pubkey(G[f'{tag}_kg_a0'], G[f'{tag}_kg_p0']); r.set_privkey(G[f'{tag}_kg_r2_0'])
+        B = 262144
+        msgs = torch.randint(0, 256, (B, r.msg_bytes), dtype=torch.uint8, device='cuda', generator=g)
+        tapes = torch.randint(-2**31, 2**31 - 1, (B, r.enc_words), dtype=torch.int32, device='cuda', generator=g)
+        ct = r.encrypt(msgs, tapes); torch.cuda.synchronize()
+        te, td = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); ct = r.encrypt(msgs, tapes); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); mm = r.decrypt(ct); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+        wrong = int((mm != msgs).any(dim=1).sum())          # the scheme's own decryption-failure rate (same blocks fail in the reference)
+        assert wrong < B // 10000
+        re = {'workload': f'RLWE-Enc set {set_} (n={r.n}) encrypt / decrypt, batch {B}, {r.msg_bytes}-byte blocks, one key pair, per-message CSPRNG word tapes resident in HBM',
+              'encrypt_ops_per_s': B / min(te), 'decrypt_ops_per_s': B / min(td), 'tape_read_GB_per_s': B * r.enc_words * 4 / min(te) / 1e9, 'decryption_failures': wrong}
+        if os.path.exists(drv):
+            try:
+                c = json.loads(subprocess.check_output([drv, 'bench_rlwe', str(set_), '2'], timeout=60, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+                re['cpu_reference'] = {'encrypt_ops_per_s': c['encrypt_per_sec'], 'decrypt_ops_per_s': c['decrypt_per_sec'], 'cores': 1, 'kind': 'reference',
+                                       'sample': f'2 s of safecrypto_public_encrypt + 1 s of safecrypto_private_decrypt, set {set_}, one key pair, 1 thread'}
+            except Exception as e:
+                sys.stderr.write(f'rlwe cpu baseline failed: {e}\n')
+        out[f'rlwe_enc_{set_}'] = re
+        del msgs, tapes, ct
+        r.close()
     return out
 
 

@@ -11,6 +11,7 @@
  * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
+ *        ref_driver bench_rlwe <set> <seconds>   (single-thread safecrypto_public_encrypt / safecrypto_private_decrypt, RLWE-Enc)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
@@ -1060,9 +1061,41 @@ static int bench_kem(int set, double seconds)
     return 0;
 }
 
+/* single-thread rlwe_enc_encrypt / rlwe_enc_decrypt through safecrypto_public_encrypt / safecrypto_private_decrypt */
+static int bench_enc(int set, double seconds)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_ENC_RLWE, set, flags);
+    if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const size_t mlen = (set ? param_rlwe_enc_1.n : param_rlwe_enc_0.n) / 8;
+    enum { POOL = 64 };
+    UINT8 msg[128], *ct[POOL]; size_t ctlen[POOL];
+    memset(ct, 0, sizeof ct);
+    sm_state = 0xbe7c4ULL;
+    uint64_t nenc = 0, ndec = 0;
+    double t0 = now_s(), t1;
+    do {
+        for (int i = 0; i < POOL; i++) {
+            for (size_t b = 0; b < mlen; b += 8) { uint64_t v = splitmix64(); memcpy(msg + b, &v, 8); }
+            free(ct[i]); ct[i] = NULL; ctlen[i] = 0;
+            if (SC_FUNC_SUCCESS != safecrypto_public_encrypt(sc, mlen, msg, &ctlen[i], &ct[i])) return 1;
+        }
+        nenc += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds);
+    const double te = t1 - t0;
+    t0 = now_s();
+    do {
+        for (int i = 0; i < POOL; i++) { UINT8 *m2 = NULL; size_t m2len = 0; if (SC_FUNC_SUCCESS != safecrypto_private_decrypt(sc, ctlen[i], ct[i], &m2len, &m2)) return 1; free(m2); }
+        ndec += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds / 2);
+    printf("{\"set\": %d, \"encrypt_per_sec\": %.1f, \"decrypt_per_sec\": %.1f, \"encryptions\": %llu}\n", set, nenc / te, ndec / (t1 - t0), (unsigned long long)nenc);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 4 && !strcmp(argv[1], "bench_kyber")) return bench_kem(atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_rlwe")) return bench_enc(atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_sig(SC_SCHEME_SIG_DILITHIUM, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));

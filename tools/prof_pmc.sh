@@ -1,13 +1,14 @@
 #!/bin/bash
-# PMC counters (one pass per group) of one tool run:  tools/prof_pmc.sh <tag> <kernel-substring> <python script> [args...]
+# PMC counters (one pass per group, each under its own timeout) of one tool run:
+#   tools/prof_pmc.sh <tag> <kernel-substring> <python script> [args...]
 export TMPDIR=/tmp
 TAG=$1; shift
 KSUB=$1; shift
 OUT=gpurun_out/pmc_$TAG
 mkdir -p $OUT
-for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE FETCH_SIZE WRITE_SIZE"; do
+for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $grp | tr ' ' '_')
-  rocprofv3 --pmc $grp --output-format csv -d $OUT/$name -- python3 "$@" > /dev/null 2> $OUT/err_$name.txt
+  timeout 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/$name -- python3 "$@" > /dev/null 2> $OUT/err_$name.txt
   python3 - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
