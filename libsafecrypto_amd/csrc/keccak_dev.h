@@ -161,4 +161,120 @@ struct Sponge {
     }
 };
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Two lanes per hash instance.  A lane-per-instance kernel over B messages runs B/64 wavefronts; when that is fewer than half
+// the SIMDs of the chip (16 K messages = 256 wavefronts on 1024 SIMDs) the kernel runs at the latency of one wavefront's
+// serial chain of permutations while most SIMDs idle.  Sponge2 gives each instance the lanes (2m, 2m+1): lane h holds the 32-bit
+// half h of every state word, so a round is 126 instructions per wavefront instead of 192 (the column parities and chi act on
+// halves independently; a rotate needs the partner's half - one DPP move - and the SAME v_alignbit form on both lanes), and
+// twice as many wavefronts carry the batch.  Total work goes up by ~30 %, so this only pays while SIMDs are idle.
+// Both lanes of a pair call every method with identical arguments.  State in LDS: half h of word w of pair m at st[w*NT + 2m + h].
+__device__ __forceinline__ uint32_t partner_half(uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]: swap adjacent lanes
+}
+
+template <bool STD>
+__device__ __forceinline__ void keccak_permute_halves(uint32_t (&x)[25], int h)
+{
+    constexpr uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
+        0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
+        0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
+        0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL };
+    constexpr int ROTC[24] = { 1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44 };
+    constexpr int PILN[24] = { 10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1 };
+    // 64-bit rotate left by n (0 < n < 64, n != 32) of the word whose halves are (own, partner): lo' = alignbit(lo, hi, 32-n),
+    // hi' = alignbit(hi, lo, 32-n) for n < 32 - the same expression in terms of (own, partner) on both lanes; operands swap for n > 32
+    auto rot = [](uint32_t own, uint32_t par, int n) -> uint32_t {
+        return n < 32 ? __builtin_amdgcn_alignbit(own, par, 32 - n) : __builtin_amdgcn_alignbit(par, own, 64 - n);
+    };
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) {
+        uint32_t bc[5];
+#pragma unroll
+        for (int i = 0; i < 5; i++) bc[i] = xor3(xor3(x[i], x[i + 5], x[i + 10]), x[i + 15], x[i + 20]);
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+            const int p = (i + 4) % 5, n = (i + 1) % 5;
+            const uint32_t t = bc[p] ^ rot(bc[n], partner_half(bc[n]), 1);
+#pragma unroll
+            for (int j = 0; j < 25; j += 5) x[j + i] ^= t;
+        }
+        uint32_t t = x[1];
+#pragma unroll
+        for (int i = 0; i < 24; i++) {
+            const uint32_t nx = x[PILN[i]];
+            x[PILN[i]] = rot(t, partner_half(t), ROTC[i]);
+            t = nx;
+        }
+#pragma unroll
+        for (int jj = 0; jj < 5; jj++) {
+            const int j = STD ? 5 * jj : jj;                    // tinysha3.c:186-235 uses 0,1,2,3,4
+            const uint32_t c0 = x[j], c1 = x[j + 1], c2 = x[j + 2], c3 = x[j + 3], c4 = x[j + 4];
+            x[j] = chi3(c0, c1, c2); x[j + 1] = chi3(c1, c2, c3); x[j + 2] = chi3(c2, c3, c4); x[j + 3] = chi3(c3, c4, c0); x[j + 4] = chi3(c4, c0, c1);
+        }
+        x[0] ^= h ? (uint32_t)(RC[r] >> 32) : (uint32_t)RC[r];
+    }
+}
+
+// NT = threads per workgroup (even); NT/2 instances per workgroup
+template <int NT, bool STD = false>
+struct Sponge2 {
+    uint32_t *st;          // LDS: &state[pair base], i.e. word w of half h at st[w*NT + h]
+    int rate, pos, h;
+
+    __device__ __forceinline__ void init(uint32_t *lds_state, int tid, int rate_bytes)
+    {
+        st = lds_state + (tid & ~1); rate = rate_bytes; pos = 0; h = tid & 1;
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT + h] = 0;
+    }
+    __device__ __forceinline__ void permute()
+    {
+        uint32_t x[25];
+#pragma unroll
+        for (int w = 0; w < 25; w++) x[w] = st[w * NT + h];
+        keccak_permute_halves<STD>(x, h);
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT + h] = x[w];
+    }
+    __device__ __forceinline__ void absorb_byte(uint8_t b)
+    {
+        if (((pos >> 2) & 1) == h) st[(pos >> 3) * NT + h] ^= (uint32_t)b << (8 * (pos & 3));
+        if (++pos == rate) { permute(); pos = 0; }
+    }
+    // pos must be a multiple of 8 (rates are multiples of 8)
+    __device__ __forceinline__ void absorb_u64(uint64_t v)
+    {
+        st[(pos >> 3) * NT + h] ^= (uint32_t)(v >> (32 * h));
+        pos += 8;
+        if (pos == rate) { permute(); pos = 0; }
+    }
+    __device__ __forceinline__ void absorb(const uint8_t *p, size_t len)
+    {
+        size_t i = 0;
+        while (i < len && (pos & 7)) absorb_byte(p[i++]);
+        if ((((uintptr_t)(p + i)) & 7) == 0)
+            for (; i + 8 <= len; i += 8) absorb_u64(*reinterpret_cast<const uint64_t *>(p + i));
+        for (; i < len; i++) absorb_byte(p[i]);
+    }
+    __device__ __forceinline__ void finalize(uint32_t pad = 0x1F)
+    {
+        if (((pos >> 2) & 1) == h) st[(pos >> 3) * NT + h] ^= pad << (8 * (pos & 3));
+        if ((((rate - 1) >> 2) & 1) == h) st[((rate - 1) >> 3) * NT + h] ^= 0x80u << (8 * ((rate - 1) & 3));
+        permute();
+        pos = 0;
+    }
+    // both lanes return the byte (read from the owning half in LDS)
+    __device__ __forceinline__ uint8_t squeeze_byte()
+    {
+        if (pos == rate) { permute(); pos = 0; }
+        const uint8_t b = (uint8_t)(st[(pos >> 3) * NT + ((pos >> 2) & 1)] >> (8 * (pos & 3)));
+        pos++;
+        return b;
+    }
+};
+
 }  // namespace sc
