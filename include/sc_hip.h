@@ -61,9 +61,9 @@ int     sc_hip_plan_n(const sc_hip_plan_t *plan);
 int32_t sc_hip_plan_root(const sc_hip_plan_t *plan);           /* g                         */
 /* host copies of the reference-format tables (w[i]=g^i, r[i]=((q-1)/n) g^i), n entries each */
 int  sc_hip_plan_tables(const sc_hip_plan_t *plan, int32_t *h_w, int32_t *h_r);
-/* selects the modular-multiply code path: 0 = auto (3 for q < 2^14, else 2),
- * 1 = 24-bit Shoup (q < 2^23), 2 = 32-bit Shoup (q < 2^30), 3 = small-modulus multiply-add form (q < 2^14).
- * For measurement; results are identical. */
+/* selects the modular-multiply code path: 0 = auto (4 where it applies, 3 for other q < 2^14, else 2),
+ * 1 = 24-bit Shoup (q < 2^23), 2 = 32-bit Shoup (q < 2^30), 3 = small-modulus multiply-add form (q < 2^14),
+ * 4 = the same on signed lazy residues (n = 256 and 36 q^2 < 2^31, i.e. q = 7681).  For measurement; results are identical. */
 int  sc_hip_plan_set_arith(sc_hip_plan_t *plan, int mode);
 
 /* ---- batched transforms, device pointers ------------------------------------------- */

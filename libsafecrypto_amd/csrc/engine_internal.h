@@ -40,10 +40,11 @@ struct sc_hip_plan {
     int32_t q;
     int n, L;
     int32_t g;
-    int mode;                     // MODE_U24 / MODE_U32 in use
+    int mode;                     // MODE_U24 / MODE_U32 / MODE_MAD / MODE_SMAD in use
     bool lazy24, lazy32;
     std::vector<int32_t> w, r;    // reference-format tables (host)
     uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
+    uint32_t *d_tab_s;            // MODE_SMAD (q = 7681, n = 256): centred twiddles, signed companions; same layout
     sc::ModK k[2];
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
     uint32_t c_mont[2][4];        // scale = n^-1 * 2^32

@@ -15,7 +15,7 @@
 
 namespace sc {
 
-enum { MODE_U24 = 1, MODE_U32 = 2, MODE_MAD = 3 };
+enum { MODE_U24 = 1, MODE_U32 = 2, MODE_MAD = 3, MODE_SMAD = 4 };
 
 // Per-modulus scalars, passed by value as kernel arguments (they end up in SGPRs).
 struct ModK {
@@ -75,6 +75,40 @@ template <> struct Mod<MODE_MAD> {
         return mul_u24(a, w) + (uint32_t)mul_i24((int32_t)qh, -(int32_t)k.q);
     }
 };
+
+// Signed small-modulus mode (36 q^2 < 2^31: q = 7681).  Values are SIGNED lazy residues: a Barrett / Shoup quotient estimate that
+// is off by one in either direction leaves r in [-q, 2q), and nothing forces r back into [0, 2q) - so a butterfly is
+// (a + t, a - t) with no 2q bias, an input reduction is two instructions, and the pointwise product needs no canonical operand.
+// Twiddles are centred (|w| <= q/2) with signed companions floor(w 2^32 / q).  Bounds: forward values stay below 18q in magnitude
+// (inputs in [-q, 2q), eight stages of growth by at most 2q), so every product of a value with a twiddle or with another reduced
+// value is below 18q * 2q < 2^31; inverse sums double per stage and stay below 2q 2^8 < 2^23 (the 24-bit multiply-add operand).
+template <> struct Mod<MODE_SMAD> {
+    static constexpr uint64_t BETA = 1ull << 32;
+    // a signed with |a| < 2^23, w centred, wp = floor(w 2^32 / q) as int32  ->  a*w mod q in [-q, 2q)
+    static __device__ __forceinline__ uint32_t mulc(uint32_t a, uint32_t w, uint32_t wp, const ModK &k)
+    {
+        const int32_t qh = __mulhi((int32_t)a, (int32_t)wp);
+        return (uint32_t)mul_i24((int32_t)a, (int32_t)w) + (uint32_t)mul_i24(qh, -(int32_t)k.q);
+    }
+};
+
+// any int32 -> signed residue in [-q, 2q): two instructions (|qh| <= 2^31 / q < 2^19 fits the 24-bit operand)
+__device__ __forceinline__ uint32_t reduce_signed(int32_t x, const ModK &k)
+{
+    const int32_t qh = __mulhi(x, (int32_t)k.m32);
+    return (uint32_t)x + (uint32_t)mul_i24(qh, -(int32_t)k.q);
+}
+
+// signed x, y with |x y| < 2^31  ->  x*y mod q in [-q, 2q)
+__device__ __forceinline__ uint32_t mulmod_ssmall(uint32_t x, uint32_t y, const ModK &k)
+{
+    const int32_t t = (int32_t)x * (int32_t)y;
+    const int32_t qh = __mulhi(t, (int32_t)k.m32);
+    return (uint32_t)t + (uint32_t)mul_i24(qh, -(int32_t)k.q);
+}
+
+// signed residue in [-q, 2q) -> canonical [0, q)
+__device__ __forceinline__ uint32_t canon_signed(uint32_t r, const ModK &k) { return csub(csub(r + k.q, k.q2), k.q); }
 
 // arbitrary int32 -> [0, 2q).  qh = floor(x m32 / 2^32) is floor(x/q) or one more, so r = x - qh q lies in [-q, 2q);
 // read as unsigned, the smaller of r and r + q is the representative in [0, 2q).

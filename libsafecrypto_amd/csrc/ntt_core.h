@@ -100,6 +100,12 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
         const int idx = (1 << (3 - T)) - 1 + (r >> (T + 1));
         // small-modulus mode: forward values stay below 2q(L+1) < 2^18.1, so value * twiddle fits 32 bits and a Barrett step on the
         // product needs no per-twiddle companion (15-30 fewer live registers per wave: one more wave per SIMD)
+        if constexpr (MODE == MODE_SMAD) {       // signed lazy residues (modarith.h): no bias, no companion
+            const uint32_t t = mulmod_ssmall(x[r | (1 << T)], tw[idx], k), a = x[r];
+            x[r] = a + t;
+            x[r | (1 << T)] = a - t;
+            continue;
+        }
         const uint32_t t = (MODE == MODE_MAD) ? mulmod_small(x[r | (1 << T)], tw[idx], k) : Mod<MODE>::mulc(x[r | (1 << T)], tw[idx], twp[idx], k);
         const uint32_t a = x[r];
         if (LAZY) {                      // values grow by < 2q per stage, never reduced
@@ -119,13 +125,16 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
 template <int MODE, int T, int G>
 __device__ __forceinline__ void gs_stage(uint32_t (&x)[16], const uint32_t (&tw)[15], const uint32_t (&twp)[15], const ModK &k)
 {
-    static_assert(G < 0 || MODE == MODE_MAD, "growing sums need the small-modulus mode");
+    static_assert(G < 0 || MODE == MODE_MAD || MODE == MODE_SMAD, "growing sums need a small-modulus mode");
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & (1 << T)) continue;
         const int idx = (1 << (3 - T)) - 1 + (r >> (T + 1));
         const uint32_t a = x[r], b = x[r | (1 << T)];
-        if constexpr (G >= 0) {
+        if constexpr (MODE == MODE_SMAD) {       // signed: the sums grow (below 2q 2^stage in magnitude), the difference needs no bias
+            x[r] = a + b;
+            x[r | (1 << T)] = Mod<MODE>::mulc(a - b, tw[idx], twp[idx], k);
+        } else if constexpr (G >= 0) {
             const uint32_t d = a + (k.q2 << G) - b;
             x[r] = a + b;
             x[r | (1 << T)] = Mod<MODE>::mulc(d, tw[idx], twp[idx], k);
@@ -143,6 +152,18 @@ __device__ __forceinline__ void gs_stage(uint32_t (&x)[16], const uint32_t (&tw)
 template <int MODE, int G>
 __device__ __forceinline__ void gs_last_stage(uint32_t (&x)[16], uint32_t c0, uint32_t c0p, uint32_t c1, uint32_t c1p, const ModK &k)
 {
+    if constexpr (MODE == MODE_SMAD) {
+        // signed sums of magnitude <= 2q 2^8 = 512 q: biased by 512 q (a multiple of q) they are below 2^23 and non-negative, and the
+        // unsigned multiply-add product with the (unsigned, canonical) scale constants finishes as in MODE_MAD
+        const uint32_t bias = k.q << 9;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t a = x[r], b = x[r | 8];
+            x[r] = csub(Mod<MODE_MAD>::mulc(a + b + bias, c0, c0p, k), k.q);
+            x[r | 8] = csub(Mod<MODE_MAD>::mulc(a - b + bias, c1, c1p, k), k.q);
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 8; r++) {
         const uint32_t a = x[r], b = x[r | 8];
@@ -212,8 +233,9 @@ __device__ __forceinline__ void inv_core(uint32_t (&x)[16], const TwSet<L> &tw, 
 {
     using Y = Lay<L>;
     // small-modulus mode: the last 8 stages (rounds 1 and 0) let the sums grow; the L-8 stages of round 2 stay reduced
-    constexpr bool GROW = MODE == MODE_MAD;
+    constexpr bool GROW = MODE == MODE_MAD || MODE == MODE_SMAD;
     static_assert(!GROW || Y::ns(1) == 4, "growth bookkeeping assumes 4 + 4 stages in rounds 1 and 0");
+    static_assert(MODE != MODE_SMAD || Y::NR == 2, "the signed mode's bounds are worked out for n = 256");
     if constexpr (Y::NR == 3) {
         gs_round<MODE, Y::ns(2), false, -1>(x, tw.t2, tw.t2p, k);
         exchange<Y::b0(2), Y::b0(1)>(x, lds_poly, lp);

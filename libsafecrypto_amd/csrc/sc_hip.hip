@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         const size_t base = (size_t)poly * N;
         uint32_t x[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
+        for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_SMAD) ? reduce_signed(nx[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
 
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
@@ -116,8 +116,11 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t v = x[r];
-                if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
-                v = csub(v, k.q);
+                if (MODE == MODE_SMAD) v = canon_signed(reduce_signed((int32_t)v, k), k);
+                else {
+                    if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
+                    v = csub(v, k.q);
+                }
                 if (valid) dst[brv4(r) * LP] = (int32_t)v;
             }
             continue;
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         if (OP == OP_MULNTT) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(x[r], reduce_signed(nb[r], k), k);               // |x| < 18q, |y| <= 2q: below 2^31
+                else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
                 else x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
             }
             prefetch();
@@ -134,12 +138,13 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         if (OP == OP_MUL) {
             uint32_t y[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
+            for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_SMAD) ? reduce_signed(nb[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
             prefetch();
-            fwd_core<L, MODE, false>(y, twf, lds_poly, lp, k);      // [0,2q)
+            fwd_core<L, MODE, (MODE == MODE_SMAD)>(y, twf, lds_poly, lp, k);      // [0,2q) (signed mode: lazy, reduced below)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(y[r], k.q), k);
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(x[r], reduce_signed((int32_t)y[r], k), k);
+                else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(y[r], k.q), k);
                 else x[r] = montmul(x[r], y[r], k);
             }
         }
@@ -315,7 +320,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
 
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
-    p->mv_ws = nullptr; p->mv_cap = 0;
+    p->mv_ws = nullptr; p->mv_cap = 0; p->d_tab_s = nullptr;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
     p->w[0] = 1;
@@ -366,6 +371,27 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     p->mode = MODE_U32;
     // q < 2^14 (7681, 12289): the 3-instruction multiply-add form with growing inverse sums (modarith.h MODE_MAD, ntt_core.h)
     if (Q < (1ull << 14)) p->mode = MODE_MAD;
+    // 36 q^2 < 2^31 and n = 256 (q = 7681): signed lazy residues, no butterfly bias, two-instruction input reductions (MODE_SMAD)
+    if (n == 256 && 36ull * Q * Q < (1ull << 31)) {
+        std::vector<uint32_t> h(4 * (size_t)n, 0u);
+        auto centre = [&](uint64_t w) -> int64_t { return w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w; };
+        auto sshoup = [&](int64_t w) -> uint32_t {                 // floor(w 2^32 / q) as a two's-complement 32-bit value
+            __int128 num = (__int128)w << 32;
+            __int128 fl = num / (__int128)Q;
+            if (num % (__int128)Q != 0 && num < 0) fl -= 1;
+            return (uint32_t)(int32_t)fl;
+        };
+        for (int kx = 0; kx < n; kx++) {
+            const int64_t f = centre(zf[kx]), iv = centre(zi[kx]);
+            h[kx] = (uint32_t)(int32_t)f;          h[n + kx] = sshoup(f);
+            h[2 * n + kx] = (uint32_t)(int32_t)iv; h[3 * n + kx] = sshoup(iv);
+        }
+        if (hipMalloc(&p->d_tab_s, h.size() * 4) != hipSuccess || hipMemcpy(p->d_tab_s, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            sc_hip_plan_destroy(p);
+            return fail("plan_create: cannot upload the signed twiddle tables");
+        }
+        p->mode = MODE_SMAD;
+    }
     *out = p;
     return SC_HIP_SUCCESS;
 }
@@ -374,6 +400,7 @@ extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
 {
     if (!p) return;
     for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)hipFree(p->d_tab[i]);
+    if (p->d_tab_s) (void)hipFree(p->d_tab_s);
     if (p->mv_ws) (void)hipFree(p->mv_ws);
     delete p;
 }
@@ -390,10 +417,11 @@ extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t 
 extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
-    if (mode == 0) mode = (uint64_t)p->q < (1ull << 14) ? MODE_MAD : MODE_U32;
+    if (mode == 0) mode = p->d_tab_s ? MODE_SMAD : (uint64_t)p->q < (1ull << 14) ? MODE_MAD : MODE_U32;
+    if (mode == MODE_SMAD && !p->d_tab_s) return fail("plan_set_arith: the signed small-modulus path needs n = 256 and 36 q^2 < 2^31");
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
     if (mode == MODE_MAD && (uint64_t)p->q >= (1ull << 14)) return fail("plan_set_arith: the multiply-add path needs q < 2^14");
-    if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD) return fail("plan_set_arith: mode must be 0, 1, 2 or 3");
+    if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD) return fail("plan_set_arith: mode must be 0, 1, 2, 3 or 4");
     p->mode = mode;
     return SC_HIP_SUCCESS;
 }
@@ -417,6 +445,7 @@ static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
 template <int L, int OP>
 static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
 {
+    if constexpr (L == 8) { if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s); }
     if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
         if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
@@ -446,9 +475,9 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int n = p->n;
     NttArgs a;
     a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
-    a.zf = p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.zf = (p->mode == MODE_SMAD) ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
-    const uint32_t *c = (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus product leaves no 2^-32
+    const uint32_t *c = (op == OP_INV || p->mode == MODE_MAD || p->mode == MODE_SMAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
     const int pw = 1024 / n;                                  // polynomials per wave
