@@ -231,6 +231,13 @@ struct Sponge2 {
 #pragma unroll
         for (int w = 0; w < 25; w++) st[w * NT + h] = 0;
     }
+    // resume from a stored state (25 64-bit words) taken at a block boundary
+    __device__ __forceinline__ void load(uint32_t *lds_state, int tid, int rate_bytes, const uint64_t *__restrict__ src)
+    {
+        st = lds_state + (tid & ~1); rate = rate_bytes; pos = 0; h = tid & 1;
+#pragma unroll
+        for (int w = 0; w < 25; w++) st[w * NT + h] = (uint32_t)(src[w] >> (32 * h));
+    }
     __device__ __forceinline__ void permute()
     {
         uint32_t x[25];

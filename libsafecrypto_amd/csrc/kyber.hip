@@ -199,6 +199,66 @@ __global__ __launch_bounds__(KHT) void ky_h_kernel(uint32_t batch, const uint8_t
     for (int b = 0; b < 32; b++) o[b] = sp.squeeze_byte();
 }
 
+// The same two kernels with two lanes per message (Sponge2, keccak_dev.h; the CTR-mode generator's blocks alternate between the
+// lanes).  Used while the one-lane kernels have no more wavefronts than the chip has SIMDs: both are serial chains (H: 30
+// permutations; G: 2 permutations + 118 AES-256 blocks through LDS tables) and run at the latency of one wavefront.
+__global__ __launch_bounds__(KHT) void ky_g2_kernel(uint32_t batch, const uint8_t *__restrict__ m, const uint64_t *__restrict__ gstate, const uint8_t *__restrict__ tail, uint32_t tail_len,
+                                                    uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C)
+{
+    __shared__ uint32_t st[25 * KHT];
+    __shared__ AesLds L;
+    L.fill(C);
+    __syncthreads();
+    const uint32_t i = (blockIdx.x * KHT + threadIdx.x) >> 1;
+    const uint32_t hh = threadIdx.x & 1;
+    Sponge2<KHT> sp; sp.load(st, threadIdx.x, 72, gstate);
+    if (i >= batch) return;
+    sp.absorb(tail, tail_len);
+    sp.absorb(m + (size_t)i * 32, 32);
+    sp.finalize(0x06);
+    uint8_t md[32];
+    for (int b = 0; b < 32; b++) md[b] = sp.squeeze_byte();
+    Drbg d;
+    d.init(md, 32, C, L);
+    uint4 *o = reinterpret_cast<uint4 *>(krd + (size_t)i * 96);
+    uint32_t w[4], mine[4] = { 0, 0, 0, 0 };
+    d.counter += hh;                                                  // lane hh produces blocks hh, hh + 2, ...
+    for (int b = (int)hh; b < 6; b += 2) {
+        d.block(w, L); d.counter++;
+        o[b] = make_uint4(w[0], w[1], w[2], w[3]);
+        if (b == 2 || b == 3) { mine[0] = w[0]; mine[1] = w[1]; mine[2] = w[2]; mine[3] = w[3]; }
+    }
+    // r = blocks 2 (lane 0) and 3 (lane 1) of K_bar | r | d
+    uint32_t r32[8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { const uint32_t other = partner_half(mine[e]); r32[e] = hh ? other : mine[e]; r32[4 + e] = hh ? mine[e] : other; }
+    uint8_t r[32];
+    for (int b = 0; b < 32; b++) r[b] = (uint8_t)(r32[b >> 2] >> (8 * (b & 3)));
+    d.init(r, 32, C, L);
+    d.counter += hh;
+    uint4 *no = reinterpret_cast<uint4 *>(noise + (size_t)i * noise_stride);
+    for (uint32_t b = hh; b < noise_blocks; b += 2) { d.block(w, L); d.counter++; no[b] = make_uint4(w[0], w[1], w[2], w[3]); }
+}
+
+__global__ __launch_bounds__(KHT) void ky_h2_kernel(uint32_t batch, const uint8_t *__restrict__ krd, const int32_t *__restrict__ u, const int32_t *__restrict__ v,
+                                                    const uint8_t *__restrict__ dsrc, size_t d_stride, uint8_t *__restrict__ keys, KyP P)
+{
+    __shared__ uint32_t st[25 * KHT];
+    const uint32_t i = (blockIdx.x * KHT + threadIdx.x) >> 1;
+    Sponge2<KHT> sp; sp.init(st, threadIdx.x, 72);
+    if (i >= batch) return;
+    const uint64_t *kb = reinterpret_cast<const uint64_t *>(krd + (size_t)i * 96);
+    for (int w = 0; w < 4; w++) sp.absorb_u64(kb[w]);
+    const int kn = P.k * P.n;
+    const int4 *pu = reinterpret_cast<const int4 *>(u + (size_t)i * kn), *pv = reinterpret_cast<const int4 *>(v + (size_t)i * P.n);
+    for (int g = 0; g < kn / 4; g++) { const int4 c = pu[g]; sp.absorb_u64((uint64_t)(c.x & 0xFFFF) | ((uint64_t)(c.y & 0xFFFF) << 16) | ((uint64_t)(c.z & 0xFFFF) << 32) | ((uint64_t)(c.w & 0xFFFF) << 48)); }
+    for (int g = 0; g < P.n / 4; g++) { const int4 c = pv[g]; sp.absorb_u64((uint64_t)(c.x & 0xFFFF) | ((uint64_t)(c.y & 0xFFFF) << 16) | ((uint64_t)(c.z & 0xFFFF) << 32) | ((uint64_t)(c.w & 0xFFFF) << 48)); }
+    sp.absorb(dsrc + (size_t)i * d_stride, 32);
+    sp.finalize(0x06);
+    uint8_t *o = keys + (size_t)i * 32;
+    for (int b = 0; b < 32; b++) { const uint8_t x = sp.squeeze_byte(); if ((threadIdx.x & 1) == 0) o[b] = x; }
+}
+
 // ciphertext = u (d_u bits per coefficient) | v (d_v bits) MSB first, then d (kyber_kem.c:888-896).  Eight coefficients of
 // width d are exactly d bytes: one lane packs one such group (u groups first, then v groups, then the 32 bytes of d by the
 // last 32 lanes of the message's range).
@@ -453,13 +513,20 @@ static int ky_kem_check(sc_hip_kyber *h, size_t batch, const char *who)
     return SC_HIP_SUCCESS;
 }
 
+// two lanes per message while the one-lane hash kernels would not give every SIMD a wavefront
+static bool ky_two_lanes(const sc_hip_kyber *h, size_t batch) { return batch <= (size_t)h->ctx->cus * 4 * 64; }
+
 // G -> (K_bar, r, d), noise; CPA encryption of m under r; into h->ku, h->kv
 static int ky_kem_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, hipStream_t s)
 {
     const uint32_t B = (uint32_t)batch;
     const size_t ns = ky_noise_stride(h);
-    hipLaunchKernelGGL(ky_g_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
-                       (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
+    if (ky_two_lanes(h, batch))
+        hipLaunchKernelGGL(ky_g2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
+                           (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
+    else
+        hipLaunchKernelGGL(ky_g_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
+                           (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
     HIPCHK(hipGetLastError());
     return sc_hip_kyber_cpa_enc(h, batch, d_m, h->noise, ns, h->ku, h->kv, s);
 }
@@ -477,7 +544,8 @@ extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const ui
     hipStream_t s = (hipStream_t)stream;
     const uint32_t B = (uint32_t)batch;
     if (ky_kem_core(h, batch, d_m, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
+    if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
+    else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
     const size_t nb = batch * (size_t)((h->P.k + 1) * N / 8 + 32);
     hipLaunchKernelGGL(ky_pack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
     HIPCHK(hipGetLastError());
@@ -502,7 +570,8 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
     if (sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
     if (ky_kem_core(h, batch, h->mbuf, s)) return SC_HIP_FAILURE;
     const size_t body = sc_hip_kyber_ct_bytes(h) - 32;
-    hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
+    if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
+    else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
