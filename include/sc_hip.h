@@ -251,7 +251,7 @@ int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, 
 
 /* ---- ring-TESLA: batched sign / verify under one key ---------------------------------------- */
 
-/* ring_tesla_set_t fields (src/schemes/sig/ring_tesla/ring_tesla_params.h:43-67, values ring_tesla_params.c:22-40; set 0) */
+/* ring_tesla_set_t fields (src/schemes/sig/ring_tesla/ring_tesla_params.h:43-67, values ring_tesla_params.c:22-40; sets 0 and 1) */
 typedef struct sc_hip_tesla_params {
     int32_t n, n_bits, q, q_bits, b, b_bits, omega, d, bound, u, set, pad;
 } sc_hip_tesla_params_t;

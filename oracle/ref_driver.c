@@ -686,6 +686,7 @@ static int gen_tesla(const char *dir)
     FILE *f = fopen(path, "w");
     if (!f) return 1;
     int rc = tesla_case(f, 0, 8);
+    rc |= tesla_case(f, 1, 5);
     fclose(f);
     return rc;
 }

@@ -42,41 +42,43 @@ def pack(msgs, tapes, tape_words):
             torch.from_numpy(tb.view(np.int32)).cuda(), torch.from_numpy(tl).cuda())
 
 
-def open_key(eng, G):
-    key = O.TeslaKey.from_golden(G, 'tesla0')
+def open_key(eng, G, tag='tesla0'):
+    key = O.TeslaKey.from_golden(G, tag)
     t = eng.tesla(key.par)
     t.set_key(key.a1, key.a2, key.s, key.e1, key.e2, key.t1, key.t2)
     return key, t
 
 
-def test_sign_verify_reproduce_reference(eng, G):
+@pytest.mark.parametrize('tag,nmsg', [('tesla0', 8), ('tesla1', 5)])
+def test_sign_verify_reproduce_reference(eng, G, tag, nmsg):
     import torch
-    key, t = open_key(eng, G)
-    msgs = [bytes(np.asarray(G[f'tesla0_msg{m}'], dtype=np.uint8)) for m in range(8)]
-    tapes = [u32(G[f'tesla0_tape{m}']) for m in range(8)]
-    mb, ml, tb, tl = pack(msgs, tapes, 4096)
+    key, t = open_key(eng, G, tag)
+    msgs = [bytes(np.asarray(G[f'{tag}_msg{m}'], dtype=np.uint8)) for m in range(nmsg)]
+    tapes = [u32(G[f'{tag}_tape{m}']) for m in range(nmsg)]
+    mb, ml, tb, tl = pack(msgs, tapes, 8192)
     sigs, siglens, trials, status = t.sign(mb, tb, mlens=ml, tape_lens=tl)
     torch.cuda.synchronize()
-    assert status.cpu().tolist() == [1] * 8
-    assert trials.cpu().tolist() == [int(x) for x in G['tesla0_trials']]
+    assert status.cpu().tolist() == [1] * nmsg
+    assert trials.cpu().tolist() == [int(x) for x in G[f'{tag}_trials']]
     sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
-    for m in range(8):
-        assert bytes(sh[m, :lh[m]]) == bytes(np.asarray(G[f'tesla0_sig{m}'], dtype=np.uint8)), m
-    assert t.verify(mb, sigs, siglens, mlens=ml).cpu().tolist() == [0] * 8
-    bad = sigs.clone(); bad[:, key.sig_bytes // 3] ^= 0x08                       # the fixture's tampering: still accepted by the reference
-    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [int(G['tesla0_verify'][2 * m + 1]) for m in range(8)] == [0] * 8
+    for m in range(nmsg):
+        assert bytes(sh[m, :lh[m]]) == bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8)), m
+    assert t.verify(mb, sigs, siglens, mlens=ml).cpu().tolist() == [0] * nmsg
+    bad = sigs.clone(); bad[:, key.sig_bytes // 3] ^= 0x08                       # the fixture's tampering: the reference's verdicts, whatever they are
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [int(G[f'{tag}_verify'][2 * m + 1]) for m in range(nmsg)]
     bad = sigs.clone(); bad[:, key.sig_bytes - 1] ^= 1                           # the digest
-    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * nmsg
     bad = sigs.clone(); bad[:, 0] ^= 0x40                                        # z[0] outside the rejection bound
-    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    assert t.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [1] * nmsg
     mb2 = mb.clone(); mb2[:, 0] ^= 1
-    assert t.verify(mb2, sigs, siglens, mlens=ml).cpu().tolist() == [1] * 8
+    assert t.verify(mb2, sigs, siglens, mlens=ml).cpu().tolist() == [1] * nmsg
     t.close()
 
 
-def test_batch_vs_oracle_seeded_tapes(eng, G):
+@pytest.mark.parametrize('tag', ['tesla0', 'tesla1'])
+def test_batch_vs_oracle_seeded_tapes(eng, G, tag):
     import torch
-    key, t = open_key(eng, G)
+    key, t = open_key(eng, G, tag)
     rng = np.random.default_rng(5)
     B, W = 300, 12 * 512
     msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 90)), dtype=np.uint8)) for _ in range(B)]
