@@ -447,6 +447,49 @@ static int bliss_case(FILE *f, int set, int nmsg)
     return 0;
 }
 
+/* bliss_b_keygen (bliss_b.c:1124-1264) draws g, then f until NTT(f) is invertible, from sc->prng_ctx[0] through
+ * poly_32_uniform_rand (poly_32.c:132-156: one prng_32 word per placement attempt, bit 0 = sign, bits 1.. = position).  The first
+ * three key pairs are kept whatever they took, then the first one whose f had to be drawn again (~4 % of key pairs). */
+static int bliss_keygen_case(FILE *f, int set, int nkeep)
+{
+    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "bliss%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
+    if (!sc) return 1;
+    const bliss_set_t *P = sc->bliss->params;
+    const int n = P->n;
+    int32_t nz[2] = { P->nz[0], P->nz[1] };
+    snprintf(name, sizeof name, "%s_kg_nz", tag); rec_i32(f, name, nz, 2);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xb1155c60ULL + set;
+    int kept = 0, have_long = 0;
+    for (int cand = 0; cand < 2000 && kept < nkeep; cand++) {
+        uint8_t seed[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        const int is_long = words > (size_t)(3 * (nz[0] + nz[1]) + 3 * (nz[0] + nz[1]) / 4);      /* three polynomials' worth of draws */
+        if (kept < nkeep - 1 || (is_long && !have_long)) {
+            if (is_long) have_long = 1;
+            int32_t *tape = malloc(sizeof(int32_t) * words);
+            for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+            snprintf(name, sizeof name, "%s_kg_tape%d", tag, kept); rec_i32(f, name, tape, words);
+            snprintf(name, sizeof name, "%s_kg_f%d", tag, kept); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+            snprintf(name, sizeof name, "%s_kg_g%d", tag, kept); rec_i16(f, name, (const int16_t *)sc->privkey->key + n, n);
+            snprintf(name, sizeof name, "%s_kg_a%d", tag, kept); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+            free(tape);
+            kept++;
+        }
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    safecrypto_destroy(sc);
+    return kept == nkeep && have_long ? 0 : 1;
+}
+
 static int gen_bliss(const char *dir)
 {
     char path[512];
@@ -454,6 +497,7 @@ static int gen_bliss(const char *dir)
     FILE *f = fopen(path, "w");
     if (!f) return 1;
     int rc = bliss_case(f, 1, 9);
+    rc |= bliss_keygen_case(f, 1, 4);
     fclose(f);
     return rc;
 }

@@ -227,3 +227,56 @@ done:
     free(z); free(wt);
     return rc;
 }
+
+/* poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) on the tape: c[j] coefficients of value +-(c_len - j), one prng_32 word
+ * per placement attempt (bit 0: sign, the bits above: position), occupied positions are drawn again.  Returns 1 on underrun. */
+static int uniform_rand_tape(tape_t *T, int32_t *v, int n, const int *c, int c_len)
+{
+    for (int i = 0; i < n; i++) v[i] = 0;
+    for (int j = 0; j < c_len; j++) {
+        int i = 0;
+        while (i < c[j]) {
+            const uint32_t r = t32(T);
+            if (T->underrun) return 1;
+            const uint32_t idx = (r >> 1) & (uint32_t)(n - 1);
+            if (v[idx] == 0) { v[idx] = (r & 1) ? j - c_len : c_len - j; i++; }
+        }
+    }
+    return 0;
+}
+
+/* bliss_b_keygen, bliss_b.c:1124-1264 (no sparse multiplier, single thread): g <- uniform, g = 2g + 1 (at coefficient 0), t = NTT(g);
+ * f <- uniform until NTT(f) has no zero coefficient; a = normalise(t o (-NTT(f)^-1)).  par as for signing (n = par[0], q = par[1]);
+ * nz0, nz1 = bliss_set_t::nz.  Outputs as the reference stores them (SINT16; a in the NTT domain).  Returns 0, the words consumed and the
+ * number of f drawn; 2 = tape exhausted. */
+int orc_bliss_keygen(const int32_t *par, int nz0, int nz1, const uint32_t *tape, size_t tape_len, int16_t *f16, int16_t *g16, int16_t *a16,
+                     size_t *consumed, int32_t *attempts)
+{
+    const int n = par[0], q = par[1];
+    const int c[2] = { nz0, nz1 };
+    int32_t *w = malloc(sizeof(int32_t) * (size_t)n * 6), *r = w + n, *g = r + n, *f = g + n, *t = f + n, *u = t + n;
+    tape_t T = { tape, tape_len, 0, 0, 0, 0 };
+    int rc = 2;
+    *attempts = 0;
+    if (orc_make_tables(q, n, w, r)) { free(w); return 1; }
+    if (uniform_rand_tape(&T, g, n, c, 2)) goto done;
+    for (int i = 0; i < n; i++) g[i] *= 2;
+    g[0] += 1;
+    for (int i = 0; i < n; i++) g16[i] = (int16_t)g[i];                     /* the key stores g after the in-place 2g + 1 (:1175-1176, 1232-1235) */
+    orc_fwd_ntt(t, n, q, g, w); orc_normalize(t, (size_t)n, q);
+    for (;;) {
+        if (uniform_rand_tape(&T, f, n, c, 2)) goto done;
+        (*attempts)++;
+        orc_fwd_ntt(u, n, q, f, w);
+        if (orc_invert(u, (size_t)n, q) == 0) break;
+    }
+    for (int i = 0; i < n; i++) u[i] = -u[i];
+    orc_mul_pointwise(u, n, q, t, u);
+    orc_normalize(u, (size_t)n, q);
+    for (int i = 0; i < n; i++) { f16[i] = (int16_t)f[i]; a16[i] = (int16_t)u[i]; }
+    rc = 0;
+done:
+    *consumed = T.pos;
+    free(w);
+    return rc;
+}

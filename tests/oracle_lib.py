@@ -72,6 +72,7 @@ def lib():
         L.orc_bliss_sign.argtypes = [i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
+        L.orc_bliss_keygen.argtypes = [i32p, C.c_int, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
         L.orc_kyber_keygen.argtypes = [i32p, u8p, C.c_size_t, i32p, i32p, i32p, u8p, u8p]
@@ -378,6 +379,16 @@ def tesla_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_tesla_verify(key.par, key.a1, key.a2, key.t1, key.t2, m, ml, s, s.size)
+
+
+def bliss_keygen(par, nz, tape):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    n = int(par[0])
+    f, g, a = (np.zeros(n, dtype=np.int16) for _ in range(3))
+    used, att = C.c_size_t(0), C.c_int32(0)
+    tp = _tape(tape)
+    rc = lib().orc_bliss_keygen(par, int(nz[0]), int(nz[1]), tp, tp.size, f, g, a, C.byref(used), C.byref(att))
+    return rc, f, g, a, used.value, att.value
 
 
 class Rlwe:

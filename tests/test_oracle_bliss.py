@@ -45,3 +45,17 @@ def test_verify_matches_reference_verdicts(G):
         bad = bytearray(sig); bad[len(bad) // 3] ^= 0x04
         assert O.bliss_verify(key, m, bytes(bad)) == int(G['bliss1_verify'][2 * i + 1]) == 1
         assert O.bliss_verify(key, m + b'!', sig) == 1
+
+
+def test_keygen_matches_reference(G):
+    """bliss_b_keygen on the reference's own CSPRNG words: f, g, a equal, every word consumed; case 3 had to draw f again"""
+    par, nz = G['bliss1_params'], G['bliss1_kg_nz']
+    atts = []
+    for k in range(4):
+        tape = G[f'bliss1_kg_tape{k}']
+        rc, f, g, a, used, att = O.bliss_keygen(par, nz, tape)
+        assert rc == 0 and used == len(tape), k
+        assert np.array_equal(f, G[f'bliss1_kg_f{k}']) and np.array_equal(g, G[f'bliss1_kg_g{k}']) and np.array_equal(a, G[f'bliss1_kg_a{k}']), k
+        atts.append(att)
+    assert atts[:3] == [1, 1, 1] and atts[3] > 1
+    assert O.bliss_keygen(par, nz, G['bliss1_kg_tape3'][:500])[0] == 2
