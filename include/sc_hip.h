@@ -249,6 +249,14 @@ int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, si
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* replaces: safecrypto_keygen -> bliss_b_keygen (src/schemes/sig/bliss_b/bliss_b.c:1124-1264) for `batch` independent key pairs.  Key
+ * pair i consumes tape i (the prng_32 word stream of sc->prng_ctx[0]: poly_32_uniform_rand, src/utils/arith/poly_32.c:132-156, one word
+ * per placement attempt; a non-invertible NTT(f) costs another polynomial's worth - allow ~6 (nz0 + nz1) words).  nz0, nz1 =
+ * bliss_set_t::nz (bliss_params.c).  Outputs [batch][n] SINT16 as the reference stores them: f, g (after the in-place 2g + 1), a (NTT
+ * domain, the first n entries of the public key).  d_attempts (optional): candidates f drawn; d_status[i]: 1 generated, 2 tape exhausted. */
+int sc_hip_bliss_keygen(sc_hip_bliss_t *h, size_t batch, int nz0, int nz1, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                        int16_t *d_f, int16_t *d_g, int16_t *d_a, uint32_t *d_attempts, uint32_t *d_status, void *stream);
+
 /* ---- ring-TESLA: batched sign / verify under one key ---------------------------------------- */
 
 /* ring_tesla_set_t fields (src/schemes/sig/ring_tesla/ring_tesla_params.h:43-67, values ring_tesla_params.c:22-40; sets 0 and 1) */

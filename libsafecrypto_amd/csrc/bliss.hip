@@ -419,6 +419,82 @@ __global__ void bl_vz_kernel(const int32_t *v, int16_t *z, size_t len, BlissP P)
     z[i] = (int16_t)tmp;
 }
 
+// ---- key generation (bliss_b_keygen, bliss_b.c:1124-1264) ------------------------------------------------------------------
+// poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) is a serial placement loop over one CSPRNG word per attempt (bit 0:
+// sign, the bits above: position; an occupied position costs the word and is drawn again): one lane per key pair, the polynomial
+// as a private byte column in LDS.  with_g != 0 (first round): g is drawn first, stored as the key stores it (2g + 1 at
+// coefficient 0, :1175-1176) and staged for its transform; then one candidate f.  need: 1 = candidate staged, 2 = tape exhausted.
+__global__ __launch_bounds__(HT) void bl_kg_sample_kernel(const uint32_t *active, uint32_t nact, int with_g, const uint32_t *tapes, size_t tape_stride,
+                                                          const uint32_t *tape_lens, uint32_t *pos, uint32_t *status, uint32_t *need,
+                                                          int16_t *g16, int32_t *tg, int32_t *tf, int n, int nz0, int nz1)
+{
+    extern __shared__ int8_t col[];                                // n * HT
+    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t *w = tapes + (size_t)item * tape_stride;
+    const uint32_t len = tape_lens ? tape_lens[item] : (uint32_t)tape_stride;
+    uint32_t p = pos[item];
+    int8_t *mine = col + threadIdx.x;
+    const int c[2] = { nz0, nz1 };
+    auto draw = [&]() -> bool {
+        for (int i = 0; i < n; i++) mine[i * HT] = 0;
+        for (int j = 0; j < 2; j++) {
+            int i = 0;
+            while (i < c[j]) {
+                if (p >= len) return false;
+                const uint32_t r = w[p++];
+                const uint32_t idx = (r >> 1) & (uint32_t)(n - 1);
+                if (mine[idx * HT] == 0) { mine[idx * HT] = (int8_t)((r & 1) ? j - 2 : 2 - j); i++; }
+            }
+        }
+        return true;
+    };
+    bool ok = true;
+    if (with_g) {
+        ok = draw();
+        if (ok) for (int i = 0; i < n; i++) { const int32_t v = 2 * (int32_t)mine[i * HT] + (i == 0); g16[(size_t)item * n + i] = (int16_t)v; tg[(size_t)aidx * n + i] = v; }
+    }
+    if (ok) ok = draw();
+    if (ok) for (int i = 0; i < n; i++) tf[(size_t)aidx * n + i] = mine[i * HT];
+    else for (int i = 0; i < n; i++) { tf[(size_t)aidx * n + i] = 1; if (with_g) tg[(size_t)aidx * n + i] = 0; }      // keeps the dense transforms defined
+    pos[item] = p;
+    need[aidx] = ok ? 1u : 2u;
+    if (!ok) status[item] = 2;
+}
+
+// dense copy of NTT(2g+1) of the active key pairs (the numerator of the division)
+__global__ void bl_kg_gather_kernel(const uint32_t *active, uint32_t nact, const int32_t *th, int32_t *num, int n)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    num[t] = th[(size_t)item * n + i];
+}
+
+// rc == 0: NTT(f) was invertible, num = NTT(2g+1) / NTT(f): a = normalise(-num) (:1197-1209), f and a stored, status 1;
+// otherwise the key pair goes to the next round (a fresh f).  One wavefront per active key pair.
+__global__ __launch_bounds__(256) void bl_kg_finish_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const int32_t *rc, const int32_t *num,
+                                                           const int32_t *tf, int16_t *f16, int16_t *a16, uint32_t *status, uint32_t *attempts,
+                                                           uint32_t *next_active, uint32_t *next_count, int n, int32_t q)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx;
+    if (need[aidx] == 2) return;
+    if (lane == 0) attempts[item] += 1;
+    if (rc[aidx] != 0) { if (lane == 0) next_active[atomicAdd(next_count, 1u)] = item; return; }
+    for (int i = lane; i < n; i += 64) {
+        int32_t x = num[(size_t)aidx * n + i] % q;
+        if (x < 0) x += q;
+        a16[(size_t)item * n + i] = (int16_t)(x ? q - x : 0);
+        f16[(size_t)item * n + i] = (int16_t)tf[(size_t)aidx * n + i];
+    }
+    if (lane == 0) status[item] = 1;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -613,5 +689,55 @@ extern "C" int sc_hip_bliss_verify(sc_hip_bliss_t *b, size_t batch, const uint8_
         hipLaunchKernelGGL(bl_oracle1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len,
                            b->z, b->cidx, (uint32_t *)nullptr, 1, d_verdicts, P);
     HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_keygen -> bliss_b_keygen (bliss_b.c:1124-1264) for `batch` independent key pairs; key pair i draws from tape i
+// (the prng_32 word stream of sc->prng_ctx[0]; sc_hip_drbg_words makes it from a seed).  nz0, nz1 = bliss_set_t::nz.  Outputs
+// [batch][n] SINT16 as the reference stores them: f, g (= 2g + 1), a (NTT domain).  d_status[i]: 1 generated, 2 tape exhausted.
+extern "C" int sc_hip_bliss_keygen(sc_hip_bliss_t *b, size_t batch, int nz0, int nz1, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                   int16_t *d_f, int16_t *d_g, int16_t *d_a, uint32_t *d_attempts, uint32_t *d_status, void *stream)
+{
+    if (!b) return fail("bliss_keygen: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("bliss_keygen: batch too large");
+    if (!d_tapes || !d_f || !d_g || !d_a || !d_status) return fail("bliss_keygen: null buffer");
+    const int n = b->P.n;
+    if (nz0 < 0 || nz1 < 0 || nz0 + nz1 > n / 2) return fail("bliss_keygen: nz out of range");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    const size_t pn = batch * (size_t)n * 4;
+    DevBuf th, tg, tf, uh, num, pos, need, rc, act0, act1, cnt, att;
+    if (th.get(pn) || tg.get(pn) || tf.get(pn) || uh.get(pn) || num.get(pn) || pos.get(batch * 4) || need.get(batch * 4) || rc.get(batch * 4) ||
+        act0.get(batch * 4) || act1.get(batch * 4) || cnt.get(64) || att.get(batch * 4)) return SC_HIP_FAILURE;
+    uint32_t *attempts = d_attempts ? d_attempts : att.as<uint32_t>();
+    HIPCHK(hipMemsetAsync(pos.p, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(attempts, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
+    uint32_t nact = B;
+    const uint32_t *active = nullptr;
+    for (uint32_t round = 0; nact > 0; round++) {
+        if (round > 1000) return fail("bliss_keygen: the search for an invertible f did not terminate");
+        uint32_t *next = (round & 1) ? act1.as<uint32_t>() : act0.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(cnt.p, 0, 4, s));
+        hipLaunchKernelGGL(bl_kg_sample_kernel, dim3((nact + HT - 1) / HT), dim3(HT), (size_t)n * HT, s, active, nact, round == 0 ? 1 : 0, d_tapes, tape_stride, d_tape_lens,
+                           pos.as<uint32_t>(), d_status, need.as<uint32_t>(), d_g, tg.as<int32_t>(), tf.as<int32_t>(), n, nz0, nz1);
+        HIPCHK(hipGetLastError());
+        if (round == 0 && sc_hip_ntt_fwd(b->plan, nact, tg.as<int32_t>(), th.as<int32_t>(), s)) return SC_HIP_FAILURE;       // round 0: dense index == key index
+        if (sc_hip_ntt_fwd(b->plan, nact, tf.as<int32_t>(), uh.as<int32_t>(), s)) return SC_HIP_FAILURE;
+        const size_t ne = (size_t)nact * n;
+        hipLaunchKernelGGL(bl_kg_gather_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, th.as<int32_t>(), num.as<int32_t>(), n);
+        HIPCHK(hipGetLastError());
+        if (sc_hip_ntt_div(b->plan, nact, (size_t)n, num.as<int32_t>(), uh.as<int32_t>(), rc.as<int32_t>(), s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(bl_kg_finish_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, need.as<uint32_t>(), rc.as<int32_t>(), num.as<int32_t>(), tf.as<int32_t>(),
+                           d_f, d_a, d_status, attempts, next, cnt.as<uint32_t>(), n, b->P.q);
+        HIPCHK(hipGetLastError());
+        uint32_t c = 0;
+        HIPCHK(hipMemcpyAsync(&c, cnt.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nact = c;
+        active = next;
+    }
     return SC_HIP_SUCCESS;
 }

@@ -22,7 +22,7 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -134,6 +134,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sig_bytes.restype = sz
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_bliss_keygen.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
     L.sc_hip_ntt_invert.argtypes = [vp, sz, sz, vp, vp, vp]
     L.sc_hip_ntt_div.argtypes = [vp, sz, sz, vp, vp, vp, vp]
@@ -659,6 +660,18 @@ class Bliss:
         _chk(self.L, self.L.sc_hip_bliss_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
         return verdicts
+
+    def keygen(self, nz, tapes, tape_lens=None):
+        """batched bliss_b_keygen: tapes [batch][words] (device) -> f, g, a int16 [batch][n], attempts, status"""
+        import torch
+        batch, dev = tapes.shape[0], tapes.device
+        n = int(self.par[0])
+        f, g, a = (torch.zeros((batch, n), dtype=torch.int16, device=dev) for _ in range(3))
+        attempts = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        _chk(self.L, self.L.sc_hip_bliss_keygen(self.h, batch, int(nz[0]), int(nz[1]), _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else C.c_void_p(),
+                                                _ptr(f), _ptr(g), _ptr(a), _ptr(attempts), _ptr(status), _stream()), 'bliss_keygen')
+        return f, g, a, attempts, status
 
 
 class Tesla:

@@ -128,3 +128,48 @@ def test_full_config4_shape_properties(eng, G):
         rc, es, _, _ = O.bliss_sign(key, bytes(mh[i]), th[i])
         assert rc == 0 and bytes(sh[i, :lh[i]]) == es
     b.close()
+
+
+def test_keygen_reproduces_reference_and_oracle(eng, G):
+    """batched bliss_b_keygen: the reference's key pairs from its own CSPRNG words (one of them drew f again), seeded tapes against
+    the oracle (restarts included), a short tape reported, and the generated keys sign / verify"""
+    import torch
+    par, nz = G['bliss1_params'], G['bliss1_kg_nz']
+    n = int(par[0])
+    b = eng.bliss(par)
+    W = 2048
+    ref = [(G[f'bliss1_kg_tape{k}'].astype(np.int64) & 0xFFFFFFFF).astype(np.uint32) for k in range(4)]
+    rng = np.random.default_rng(77)
+    B = 600
+    tapes = rng.integers(0, 2**32, size=(B, W), dtype=np.uint64).astype(np.uint32)
+    lens = np.full(B, W, dtype=np.int32)
+    for k in range(4):
+        tapes[k, :len(ref[k])] = ref[k]; lens[k] = len(ref[k])
+    lens[5] = 200                                                     # not even g
+    lens[6] = 250                                                     # g and part of f at most
+    f, g, a, att, st = b.keygen(nz, torch.from_numpy(tapes.view(np.int32)).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    f, g, a, att, st = (x.cpu().numpy() for x in (f, g, a, att, st))
+    for k in range(4):
+        assert st[k] == 1 and np.array_equal(f[k], G[f'bliss1_kg_f{k}']) and np.array_equal(g[k], G[f'bliss1_kg_g{k}']) and np.array_equal(a[k], G[f'bliss1_kg_a{k}']), k
+    assert att[3] > 1 and list(att[:3]) == [1, 1, 1]
+    restarts = 0
+    for i in range(B):
+        rc, of, og, oa, used, oatt = O.bliss_keygen(par, nz, tapes[i, :lens[i]])
+        assert (rc == 0) == (st[i] == 1) and (rc == 2) == (st[i] == 2), i
+        if rc == 0:
+            assert np.array_equal(f[i], of) and np.array_equal(g[i], og) and np.array_equal(a[i], oa) and att[i] == oatt, i
+            restarts += oatt > 1
+    assert st[5] == 2 and st[6] == 2 and restarts >= 5                # ~4 % of key pairs need a second f
+    # a generated key pair works: sign and verify under it
+    b.set_key(f[10], g[10], a[10])
+    gt = torch.Generator(device='cuda'); gt.manual_seed(3)
+    msgs = torch.randint(0, 256, (64, 32), dtype=torch.uint8, device='cuda', generator=gt)
+    stp = torch.randint(-2**31, 2**31 - 1, (64, 4 * 2048 + 64), dtype=torch.int32, device='cuda', generator=gt)
+    sigs, siglens, trials, status = b.sign(msgs, stp, fixed_len=32)
+    ok = status == 1
+    assert int(ok.sum()) >= 60 and int(b.verify(msgs, sigs, siglens, fixed_len=32)[ok].sum()) == 0
+    key = O.BlissKey(par, f[10], g[10], a[10])
+    sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
+    assert O.bliss_verify(key, bytes(msgs[0].cpu().numpy()), bytes(sh[0, :lh[0]])) == 0
+    b.close()
