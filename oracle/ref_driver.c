@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_rlwe <set> <seconds>   (single-thread safecrypto_public_encrypt / safecrypto_private_decrypt, RLWE-Enc)
@@ -827,6 +827,71 @@ static int gen_rlwe(const char *dir)
     return rc;
 }
 
+/* ----------------------------------------------------------------- ENS-KEM ---- */
+#include "schemes/kem/ens/ens_kem.h"
+#include "schemes/kem/ens/ens_kem_params.h"
+
+/* ens_kem_encapsulation / _decapsulation (src/schemes/kem/ens/ens_kem.c:785-865, 867-960) under a key pair made by the reference's
+ * keygen (data): public h and private g are SINT16 in the NTT domain, centred; 1/g mod 2 is bit-reversed and packed (:191-211).
+ * Encapsulation draws r and e through poly_32_uniform_rand with the set's 12 coefficient counts from sc->prng_ctx[0]: tape technique. */
+static int ens_case(FILE *f, int set, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "ens%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_ENS, set, flags);
+    if (!sc) return 1;
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    const ens_kem_set_t *P = set == 0 ? &param_ens_kem_0 : set == 1 ? &param_ens_kem_1 : set == 2 ? &param_ens_kem_2 : &param_ens_kem_3;
+    const int n = P->n;
+    int32_t par[20] = { P->set, P->q, P->q_bits, P->n, P->n_bits, 0, 0 };
+    for (int i = 0; i < 13; i++) par[7 + i] = P->coeff_rnd[i];
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 20);
+    snprintf(name, sizeof name, "%s_h", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    snprintf(name, sizeof name, "%s_g", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+    snprintf(name, sizeof name, "%s_inv_g", tag); rec_i32(f, name, (const int32_t *)((const int16_t *)sc->privkey->key + n), (size_t)n / 32);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xe25c000ULL + set;
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t seed[32];
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *ct = NULL, *key = NULL, *k2 = NULL; size_t ctlen = 0, klen = 0, k2len = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_encapsulation(sc, &ct, &ctlen, &key, &klen)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, ct, ctlen, &k2, &k2len)) return 1;
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_ct%d", tag, m); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_key%d", tag, m); rec_u8(f, name, key, klen);
+        snprintf(name, sizeof name, "%s_dec%d", tag, m); rec_u8(f, name, k2, k2len);
+        free(k2); k2 = NULL; k2len = 0;
+        for (size_t i = 0; i < ctlen; i++) ct[i] = (uint8_t)splitmix64();         /* decapsulation is a plain function of the bytes */
+        if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, ct, ctlen, &k2, &k2len)) return 1;
+        snprintf(name, sizeof name, "%s_randct%d", tag, m); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_randdec%d", tag, m); rec_u8(f, name, k2, k2len);
+        free(tape); free(ct); free(key); free(k2);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    safecrypto_destroy(sc);
+    return 0;
+}
+
+static int gen_ens(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/ens_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = ens_case(f, 0, 5);
+    rc |= ens_case(f, 2, 3);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -1146,7 +1211,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -1159,5 +1224,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "drbg")) rc |= gen_drbg(argv[2]);
     if (all || !strcmp(argv[1], "tesla")) rc |= gen_tesla(argv[2]);
     if (all || !strcmp(argv[1], "rlwe")) rc |= gen_rlwe(argv[2]);
+    if (all || !strcmp(argv[1], "ens")) rc |= gen_ens(argv[2]);
     return rc;
 }

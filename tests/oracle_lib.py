@@ -15,7 +15,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle_rlwe.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle_rlwe.c', 'sc_oracle_ens.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -101,6 +101,11 @@ def lib():
         L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
+        for fn in ('orc_ens_ct_bytes', 'orc_ens_key_bytes'):
+            getattr(L, fn).restype = C.c_size_t
+            getattr(L, fn).argtypes = [i32p]
+        L.orc_ens_encaps.argtypes = [i32p, i16p, u32p, C.c_size_t, u8p, u8p, C.POINTER(C.c_size_t)]
+        L.orc_ens_decaps.argtypes = [i32p, i16p, u32p, u8p, C.c_size_t, u8p]
         f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS')
         f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
         L.orc_falcon_gm.restype = C.POINTER(C.c_double)
@@ -379,6 +384,30 @@ def tesla_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_tesla_verify(key.par, key.a1, key.a2, key.t1, key.t2, m, ml, s, s.size)
+
+
+class Ens:
+    """ENS-KEM parameter set (oracle/sc_oracle_ens.c)"""
+
+    def __init__(self, par):
+        self.par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+        self.q, self.q_bits, self.n = int(par[1]), int(par[2]), int(par[3])
+        self.ct_bytes = lib().orc_ens_ct_bytes(self.par)
+        self.key_bytes = lib().orc_ens_key_bytes(self.par)
+
+    def encaps(self, h, tape):
+        ct = np.zeros(self.ct_bytes, dtype=np.uint8); key = np.zeros(self.key_bytes, dtype=np.uint8)
+        used = C.c_size_t(0)
+        tp = _tape(tape)
+        rc = lib().orc_ens_encaps(self.par, np.ascontiguousarray(np.asarray(h), dtype=np.int16), tp, tp.size, ct, key, C.byref(used))
+        return rc, bytes(ct), bytes(key), used.value
+
+    def decaps(self, g, inv_g, ct):
+        c = np.ascontiguousarray(np.frombuffer(bytes(ct), dtype=np.uint8))
+        key = np.zeros(self.key_bytes, dtype=np.uint8)
+        ig = np.ascontiguousarray((np.asarray(inv_g).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32))
+        rc = lib().orc_ens_decaps(self.par, np.ascontiguousarray(np.asarray(g), dtype=np.int16), ig, c, c.size, key)
+        return rc, bytes(key)
 
 
 def bliss_keygen(par, nz, tape):
