@@ -19,7 +19,7 @@
  *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
  *     sc_hip_last_error) when no gfx950 device / kernel image is available
  *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs are immutable after
- *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t) owns the
+ *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t) owns the
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
  */
@@ -317,6 +317,32 @@ int sc_hip_rlwe_decrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_ct, siz
 /* replaces: safecrypto_keygen -> rlwe_enc_keygen with a_gen / r1_gen / r2_gen (rlwe_enc.c:205-290, 425-493) for `batch`
  * independent key pairs, one tape each; outputs [batch][n] SINT16 in the reference's storage format (a, p = r1 - a r2, r2) */
 int sc_hip_rlwe_keygen(sc_hip_rlwe_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, int16_t *d_a, int16_t *d_p, int16_t *d_r2, void *stream);
+
+/* ---- ENS-KEM: batched encapsulation / decapsulation under one key pair ------------------------------ */
+
+/* ens_kem_set_t fields (src/schemes/kem/ens/ens_kem_params.h:30-47, values ens_kem_params.c:23-61): set, q, q_bits, n, n_bits and the
+ * 13 coefficient counts coeff_rnd (the first 12 are used: coeff_rnd[j] coefficients of value +-(12 - j), ens_kem.c:817-818) */
+typedef struct sc_hip_ens_params {
+    int32_t set, q, q_bits, n, n_bits, pad0, pad1, coeff_rnd[13];
+} sc_hip_ens_params_t;
+typedef struct sc_hip_ens sc_hip_ens_t;
+
+int  sc_hip_ens_create(sc_hip_ctx_t *ctx, const sc_hip_ens_params_t *params, sc_hip_ens_t **h);
+void sc_hip_ens_destroy(sc_hip_ens_t *h);
+/* the keys as the reference holds them (ens_kem.c:609-618, 757-762): h = sc->pubkey->key (SINT16[n], NTT domain, centred); g = the first n
+ * SINT16 of sc->privkey->key, inv_g = the n/32 words behind them (1/g mod 2, bit-reversed and packed, :191-211).  Host pointers. */
+int  sc_hip_ens_set_pubkey(sc_hip_ens_t *h, const int16_t *hh);
+int  sc_hip_ens_set_privkey(sc_hip_ens_t *h, const int16_t *g, const uint32_t *inv_g);
+size_t sc_hip_ens_ct_bytes(const sc_hip_ens_t *h);             /* n q_bits / 8 */
+size_t sc_hip_ens_key_bytes(const sc_hip_ens_t *h);            /* n / 8 */
+/* replaces: safecrypto_encapsulation -> ens_kem_encapsulation (src/schemes/kem/ens/ens_kem.c:785-865) `batch` times.  Operation i draws
+ * r and e from tape i (the prng_32 word stream of sc->prng_ctx[0] through poly_32_uniform_rand: one word per placement attempt, ~1.2 x
+ * the number of non-zero coefficients per polynomial); d_used (optional): words consumed; d_status: 1 done, 2 tape exhausted.
+ * Ciphertexts and keys equal the reference's for the same words. */
+int sc_hip_ens_encaps(sc_hip_ens_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                      uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, size_t key_stride, uint32_t *d_used, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_decapsulation -> ens_kem_decapsulation (ens_kem.c:867-960); any n q_bits / 8 bytes are accepted, as there */
+int sc_hip_ens_decaps(sc_hip_ens_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, size_t key_stride, void *stream);
 
 /* ---- Kyber (round 1, q = 7681): batched CPA encryption / decryption under one key ------------ */
 

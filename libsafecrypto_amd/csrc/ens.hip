@@ -1,0 +1,260 @@
+// ens.hip - batched ENS-KEM encapsulation / decapsulation on MI355X behind the C ABI of include/sc_hip.h.
+//
+// Replaces, for a batch of operations under one key pair, ens_kem_encapsulation / ens_kem_decapsulation
+// (src/schemes/kem/ens/ens_kem.c:785-865, 867-960) with generate_ciphertext (:280-318), poly_32_uniform_rand
+// (src/utils/arith/poly_32.c:132-156) and z2_conv_mod2 (src/utils/arith/poly_z2.c:354-376); parameter sets ens_kem_params.c:23-61
+// (q = 12289, n = 512 / 1024), raw coding (q_bits per coefficient, MSB first).  Keys are the reference's (its keygen inverts g modulo 2
+// and modulo q on the CPU): h and g SINT16 in the NTT domain, 1/g mod 2 bit-reversed and packed (:191-211).
+//
+// Randomness: the prng_32 word stream ("tape") of sc->prng_ctx[0]: r, then e, each through the sparse placement loop (one word per
+// attempt, occupied positions drawn again - so the words consumed vary per operation and are reported).
+//
+// Mapping: the placement loops are serial - one lane per operation, the polynomial as a byte column in LDS; the product h r (g t) on the
+// plan's fused NTT -> pointwise -> INTT kernel with the key as a broadcast operand; one thread per four coefficients packs / unpacks
+// the 14-bit fields (7 bytes); decapsulation's convolution in Z2[x] is one workgroup per operation: the parities of g t are gathered with
+// __ballot into an LDS bit string, thread i forms output bit i from the n/32 words of the key's bit string rotated by i + 1.
+#include "engine_internal.h"
+
+#include <string.h>
+
+using namespace sc;
+
+namespace {
+
+constexpr int HT = 64;
+
+struct EnsP { int32_t set, q, q_bits, n, n_bits, pad0, pad1, coeff_rnd[13]; };      // ens_kem_set_t fields (ens_kem_params.h:30-47)
+
+struct EnsC { int32_t c[12]; };
+
+// r and e of one encapsulation (ens_kem.c:817-818).  status: 1 drawn, 2 tape exhausted.
+__global__ __launch_bounds__(HT) void ens_sample_kernel(uint32_t batch, const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens, EnsC C,
+                                                        int32_t *r, int32_t *e, uint32_t *used, uint32_t *status, int n)
+{
+    extern __shared__ int8_t col[];                                // n * HT
+    const uint32_t i = blockIdx.x * HT + threadIdx.x;
+    if (i >= batch) return;
+    const uint32_t *w = tapes + (size_t)i * tape_stride;
+    const uint32_t len = tape_lens ? tape_lens[i] : (uint32_t)tape_stride;
+    uint32_t p = 0;
+    int8_t *mine = col + threadIdx.x;
+    bool ok = true;
+    for (int which = 0; which < 2 && ok; which++) {
+        for (int k = 0; k < n; k++) mine[k * HT] = 0;
+        for (int j = 0; j < 12 && ok; j++) {
+            int cnt = 0;
+            while (cnt < C.c[j]) {
+                if (p >= len) { ok = false; break; }
+                const uint32_t x = w[p++];
+                const uint32_t idx = (x >> 1) & (uint32_t)(n - 1);
+                if (mine[idx * HT] == 0) { mine[idx * HT] = (int8_t)((x & 1) ? j - 12 : 12 - j); cnt++; }
+            }
+        }
+        int32_t *dst = (which ? e : r) + (size_t)i * n;
+        for (int k = 0; k < n; k++) dst[k] = ok ? (int32_t)mine[k * HT] : 0;
+    }
+    if (!ok) for (int k = 0; k < n; k++) e[(size_t)i * n + k] = 0;
+    used[i] = p;
+    status[i] = ok ? 1u : 2u;
+}
+
+// t = normalise(2 centre(h r) + e), packed; key = the parities of e (ens_kem.c:305-315, 833-852).  One thread per four coefficients.
+__global__ void ens_enc_finish_kernel(uint32_t batch, const int32_t *hr, const int32_t *e, const uint32_t *status, uint8_t *ct, size_t ct_stride, uint8_t *keys, size_t key_stride,
+                                      int n, int32_t q, int q_bits)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = n / 4;
+    const uint32_t i = (uint32_t)(t / per); const int gq = (int)(t % per);
+    if (i >= batch || status[i] != 1) return;
+    uint64_t acc = 0; uint32_t kb = 0;
+    for (int k = 0; k < 4; k++) {
+        const size_t idx = (size_t)i * n + 4 * gq + k;
+        int32_t v = hr[idx];
+        if (v > q / 2) v -= q;
+        v = 2 * v + e[idx];
+        v %= q; if (v < 0) v += q;
+        acc = (acc << q_bits) | (uint64_t)(uint32_t)v;
+        kb = (kb << 1) | (uint32_t)(e[idx] & 1);
+    }
+    const int nbytes = 4 * q_bits / 8;                             // 7 for 14-bit coefficients
+    uint8_t *o = ct + (size_t)i * ct_stride + (size_t)gq * nbytes;
+    for (int b = 0; b < nbytes; b++) o[b] = (uint8_t)(acc >> (8 * (nbytes - 1 - b)));
+    // four key bits per thread: two neighbouring threads share a byte - the even one writes it
+    const uint32_t other = (uint32_t)__shfl_xor((int)kb, 1);
+    if ((gq & 1) == 0) keys[(size_t)i * key_stride + (gq >> 1)] = (uint8_t)((kb << 4) | other);
+}
+
+__global__ void ens_unpack_kernel(uint32_t batch, const uint8_t *ct, size_t ct_stride, int32_t *t, int n, int q_bits)
+{
+    const size_t th = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = n / 4;
+    const uint32_t i = (uint32_t)(th / per); const int gq = (int)(th % per);
+    if (i >= batch) return;
+    const int nbytes = 4 * q_bits / 8;
+    const uint8_t *s = ct + (size_t)i * ct_stride + (size_t)gq * nbytes;
+    uint64_t acc = 0;
+    for (int b = 0; b < nbytes; b++) acc = (acc << 8) | s[b];
+    const uint32_t mask = (1u << q_bits) - 1u;
+    int32_t *o = t + (size_t)i * n + 4 * gq;
+    for (int k = 0; k < 4; k++) o[k] = (int32_t)((uint32_t)(acc >> (q_bits * (3 - k))) & mask);
+}
+
+// key = ((g t mod q, centred) mod 2) * (1/g mod 2) in Z2[x]/(x^n - 1) as z2_conv_mod2 computes it (ens_kem.c:926-946, poly_z2.c:354-376):
+// bit i = parity(x AND rot_{i+1}(b)) with both bit strings MSB first and rot a right rotation of the whole n-bit string.
+// One workgroup (n threads) per operation.
+__global__ void ens_dec_finish_kernel(const int32_t *gt, const uint32_t *inv_g, uint8_t *keys, size_t key_stride, int n, int32_t q)
+{
+    __shared__ uint32_t xs[32], bs[32], outw[32];
+    const uint32_t i = blockIdx.x;
+    const int tid = threadIdx.x, W = n / 32;
+    int32_t v = gt[(size_t)i * n + tid] % q;
+    if (v < 0) v += q;
+    if (v > (q >> 1)) v -= q;
+    const unsigned long long m = __ballot(v & 1);                  // lane l of the wavefront <-> coefficient 64*wave + l
+    if ((tid & 63) == 0) {
+        xs[2 * (tid >> 6)] = __builtin_bitreverse32((uint32_t)m);          // coefficient 32w + k at bit 31 - k
+        xs[2 * (tid >> 6) + 1] = __builtin_bitreverse32((uint32_t)(m >> 32));
+    }
+    if (tid < W) bs[tid] = inv_g[tid];
+    __syncthreads();
+    const int s = tid + 1, ws = (s >> 5) % W, bsft = s & 31;           // rotate right by s = tid + 1 positions
+    uint32_t acc = 0;
+    for (int j = 0; j < W; j++) {
+        const int j0 = (j - ws + W) % W, j1 = (j0 - 1 + W) % W;
+        const uint32_t word = bsft ? ((bs[j1] << (32 - bsft)) | (bs[j0] >> bsft)) : bs[j0];
+        acc ^= xs[j] & word;
+    }
+    const uint32_t bit = (uint32_t)__builtin_popcount(acc) & 1u;
+    const unsigned long long om = __ballot(bit);
+    if ((tid & 63) == 0) {
+        outw[2 * (tid >> 6)] = __builtin_bitreverse32((uint32_t)om);
+        outw[2 * (tid >> 6) + 1] = __builtin_bitreverse32((uint32_t)(om >> 32));
+    }
+    __syncthreads();
+    if (tid < n / 8) keys[(size_t)i * key_stride + tid] = (uint8_t)(outw[tid >> 2] >> (24 - 8 * (tid & 3)));
+}
+
+}  // namespace
+
+struct sc_hip_ens {
+    sc_hip_ctx *ctx;
+    sc_hip_plan *plan;
+    EnsP P;
+    int32_t *d_h, *d_g;
+    uint32_t *d_inv_g;
+    bool have_pub, have_priv;
+};
+
+extern "C" void sc_hip_ens_destroy(sc_hip_ens_t *h)
+{
+    if (!h) return;
+    void *ptrs[] = { h->d_h, h->d_g, h->d_inv_g };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->plan) sc_hip_plan_destroy(h->plan);
+    delete h;
+}
+
+extern "C" int sc_hip_ens_create(sc_hip_ctx_t *ctx, const sc_hip_ens_params_t *params, sc_hip_ens_t **out)
+{
+    if (!ctx || !params || !out) return fail("ens_create: null argument");
+    static_assert(sizeof(EnsP) == sizeof(sc_hip_ens_params_t), "parameter struct layout");
+    EnsP P; memcpy(&P, params, sizeof P);
+    if ((P.n != 512 && P.n != 1024) || (1 << P.n_bits) != P.n) return fail("ens_create: n must be 512 or 1024");
+    if (P.q_bits < 8 || P.q_bits > 16 || (4 * P.q_bits) % 8 || P.q < 3 || P.q >= (1 << P.q_bits)) return fail("ens_create: q, q_bits out of range (four coefficients must pack into whole bytes)");
+    int total = 0;
+    for (int j = 0; j < 12; j++) { if (P.coeff_rnd[j] < 0) return fail("ens_create: negative coefficient count"); total += P.coeff_rnd[j]; }
+    if (total > P.n / 2) return fail("ens_create: more than n/2 non-zero coefficients");
+    sc_hip_ens *h = new sc_hip_ens;
+    memset(h, 0, sizeof *h);
+    h->ctx = ctx; h->P = P;
+    if (sc_hip_plan_create(ctx, P.q, P.n, &h->plan) != SC_HIP_SUCCESS) { sc_hip_ens_destroy(h); return SC_HIP_FAILURE; }
+    *out = h;
+    return SC_HIP_SUCCESS;
+}
+
+static int ens_upload16(int32_t **dst, const int16_t *src, size_t n)
+{
+    std::vector<int32_t> t(n);
+    for (size_t i = 0; i < n; i++) t[i] = src[i];
+    if (!*dst) HIPCHK(hipMalloc((void **)dst, n * 4));
+    HIPCHK(hipMemcpy(*dst, t.data(), n * 4, hipMemcpyHostToDevice));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_ens_set_pubkey(sc_hip_ens_t *h, const int16_t *hh)
+{
+    if (!h || !hh) return fail("ens_set_pubkey: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (ens_upload16(&h->d_h, hh, (size_t)h->P.n)) return SC_HIP_FAILURE;
+    h->have_pub = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_ens_set_privkey(sc_hip_ens_t *h, const int16_t *g, const uint32_t *inv_g)
+{
+    if (!h || !g || !inv_g) return fail("ens_set_privkey: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    if (ens_upload16(&h->d_g, g, (size_t)h->P.n)) return SC_HIP_FAILURE;
+    if (!h->d_inv_g) HIPCHK(hipMalloc((void **)&h->d_inv_g, (size_t)h->P.n / 8));
+    HIPCHK(hipMemcpy(h->d_inv_g, inv_g, (size_t)h->P.n / 8, hipMemcpyHostToDevice));
+    h->have_priv = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_ens_ct_bytes(const sc_hip_ens_t *h) { return h ? (size_t)h->P.n * h->P.q_bits / 8 : 0; }
+extern "C" size_t sc_hip_ens_key_bytes(const sc_hip_ens_t *h) { return h ? (size_t)h->P.n / 8 : 0; }
+
+extern "C" int sc_hip_ens_encaps(sc_hip_ens_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                 uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, size_t key_stride, uint32_t *d_used, uint32_t *d_status, void *stream)
+{
+    if (!h) return fail("ens_encaps: null handle");
+    if (!h->have_pub) return fail("ens_encaps: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("ens_encaps: batch too large");
+    if (!d_tapes || !d_ct || !d_keys || !d_status) return fail("ens_encaps: null buffer");
+    if (ct_stride < sc_hip_ens_ct_bytes(h) || key_stride < sc_hip_ens_key_bytes(h)) return fail("ens_encaps: stride below the record size");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int n = h->P.n;
+    const uint32_t B = (uint32_t)batch;
+    const size_t pn = batch * (size_t)n * 4;
+    DevBuf r, e, t, used;
+    if (r.get(pn) || e.get(pn) || t.get(pn) || used.get(batch * 4)) return SC_HIP_FAILURE;
+    EnsC C;
+    for (int j = 0; j < 12; j++) C.c[j] = h->P.coeff_rnd[j];
+    hipLaunchKernelGGL(ens_sample_kernel, dim3((B + HT - 1) / HT), dim3(HT), (size_t)n * HT, s, B, d_tapes, tape_stride, d_tape_lens, C, r.as<int32_t>(), e.as<int32_t>(),
+                       d_used ? d_used : used.as<uint32_t>(), d_status, n);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(h->plan, batch, r.as<int32_t>(), h->d_h, t.as<int32_t>(), s)) return SC_HIP_FAILURE;
+    const size_t nt = batch * (size_t)(n / 4);
+    hipLaunchKernelGGL(ens_enc_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, t.as<int32_t>(), e.as<int32_t>(), d_status, d_ct, ct_stride, d_keys, key_stride,
+                       n, h->P.q, h->P.q_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));                               // the temporaries above are released on return
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_ens_decaps(sc_hip_ens_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, size_t key_stride, void *stream)
+{
+    if (!h) return fail("ens_decaps: null handle");
+    if (!h->have_priv) return fail("ens_decaps: no private key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 2048) return fail("ens_decaps: batch too large");
+    if (!d_ct || !d_keys) return fail("ens_decaps: null buffer");
+    if (ct_stride < sc_hip_ens_ct_bytes(h) || key_stride < sc_hip_ens_key_bytes(h)) return fail("ens_decaps: stride below the record size");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int n = h->P.n;
+    const uint32_t B = (uint32_t)batch;
+    const size_t pn = batch * (size_t)n * 4;
+    DevBuf t, gt;
+    if (t.get(pn) || gt.get(pn)) return SC_HIP_FAILURE;
+    const size_t nt = batch * (size_t)(n / 4);
+    hipLaunchKernelGGL(ens_unpack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, t.as<int32_t>(), n, h->P.q_bits);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(h->plan, batch, t.as<int32_t>(), h->d_g, gt.as<int32_t>(), s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ens_dec_finish_kernel, dim3(B), dim3(n), 0, s, gt.as<int32_t>(), h->d_inv_g, d_keys, key_stride, n, h->P.q);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    return SC_HIP_SUCCESS;
+}

@@ -31,6 +31,8 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
+    'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
+    'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
     'sc_hip_time_op',
 ]
@@ -161,6 +163,16 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_ens_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_ens_destroy.argtypes = [vp]
+    L.sc_hip_ens_destroy.restype = None
+    L.sc_hip_ens_set_pubkey.argtypes = [vp, vp]
+    L.sc_hip_ens_set_privkey.argtypes = [vp, vp, vp]
+    for fn in ('sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes'):
+        getattr(L, fn).argtypes = [vp]
+        getattr(L, fn).restype = sz
+    L.sc_hip_ens_encaps.argtypes = [vp, sz, vp, sz, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.sc_hip_ens_decaps.argtypes = [vp, sz, vp, sz, vp, sz, vp]
     L.sc_hip_rlwe_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_rlwe_destroy.argtypes = [vp]
     L.sc_hip_rlwe_destroy.restype = None
@@ -246,6 +258,9 @@ class Engine:
 
     def rlwe(self, params):
         return Rlwe(self, params)
+
+    def ens(self, params):
+        return Ens(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -721,6 +736,60 @@ class Tesla:
         _chk(self.L, self.L.sc_hip_tesla_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'tesla_verify')
         return verdicts
+
+
+class Ens:
+    """Batched ENS-KEM encapsulation / decapsulation under one key pair (ens_kem_encapsulation / _decapsulation counterpart).
+    params: the 20 words {set, q, q_bits, n, n_bits, 0, 0, coeff_rnd[13]}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 20
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ens_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_ens_create')
+        self.h = h
+        self.n = int(self.par[3])
+        self.ct_bytes = self.L.sc_hip_ens_ct_bytes(h)
+        self.key_bytes = self.L.sc_hip_ens_key_bytes(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_ens_destroy(self.h)
+            self.h = None
+
+    def set_pubkey(self, h):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
+        assert a.size == self.n
+        _chk(self.L, self.L.sc_hip_ens_set_pubkey(self.h, _ptr(a)), 'ens_set_pubkey')
+
+    def set_privkey(self, g, inv_g):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(g), dtype=np.int16)
+        b = np.ascontiguousarray((np.asarray(inv_g).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32))
+        assert a.size == self.n and b.size == self.n // 32
+        _chk(self.L, self.L.sc_hip_ens_set_privkey(self.h, _ptr(a), _ptr(b)), 'ens_set_privkey')
+
+    def encaps(self, tapes, tape_lens=None):
+        """tapes [batch][words] (device) -> ciphertexts, keys, words used, status"""
+        import torch
+        batch, dev = tapes.shape[0], tapes.device
+        ct = torch.zeros((batch, self.ct_bytes), dtype=torch.uint8, device=dev)
+        keys = torch.zeros((batch, self.key_bytes), dtype=torch.uint8, device=dev)
+        used = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        _chk(self.L, self.L.sc_hip_ens_encaps(self.h, batch, _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else C.c_void_p(),
+                                              _ptr(ct), self.ct_bytes, _ptr(keys), self.key_bytes, _ptr(used), _ptr(status), _stream()), 'ens_encaps')
+        return ct, keys, used, status
+
+    def decaps(self, ct):
+        import torch
+        batch = ct.shape[0]
+        keys = torch.zeros((batch, self.key_bytes), dtype=torch.uint8, device=ct.device)
+        _chk(self.L, self.L.sc_hip_ens_decaps(self.h, batch, _ptr(ct), _rows(ct), _ptr(keys), self.key_bytes, _stream()), 'ens_decaps')
+        return keys
 
 
 class Rlwe:

@@ -11,6 +11,7 @@
  * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
+ *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
  *        ref_driver bench_rlwe <set> <seconds>   (single-thread safecrypto_public_encrypt / safecrypto_private_decrypt, RLWE-Enc)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
@@ -1144,10 +1145,10 @@ static int bench_sig(sc_scheme_e scheme, int set, double seconds)
     return 0;
 }
 
-static int bench_kem(int set, double seconds)
+static int bench_kem(sc_scheme_e scheme, int set, double seconds)
 {
     UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
     if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     enum { POOL = 64 };
     UINT8 *ct[POOL], *key[POOL]; size_t ctlen[POOL], keylen[POOL];
@@ -1204,7 +1205,8 @@ static int bench_enc(int set, double seconds)
 
 int main(int argc, char **argv)
 {
-    if (argc == 4 && !strcmp(argv[1], "bench_kyber")) return bench_kem(atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_kyber")) return bench_kem(SC_SCHEME_KEM_KYBER, atoi(argv[2]), atof(argv[3]));
+    if (argc == 4 && !strcmp(argv[1], "bench_ens")) return bench_kem(SC_SCHEME_KEM_ENS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_rlwe")) return bench_enc(atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_dil")) return bench_sig(SC_SCHEME_SIG_DILITHIUM, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_falcon")) return bench_sig(SC_SCHEME_SIG_FALCON, atoi(argv[2]), atof(argv[3]));

@@ -1,0 +1,121 @@
+"""GPU parity for batched ENS-KEM (C ABI: sc_hip_ens_*): ciphertexts and keys byte-identical to what the reference produced under
+its own key pairs from the same CSPRNG words (tests/golden/ens_ref.txt), and to the pinned oracle on seeded tapes; encapsulate ->
+decapsulate agreement at a large batch."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = [('ens0', 5), ('ens2', 3)]
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from libsafecrypto_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('ens_ref.txt')
+
+
+def u32(a):
+    return (np.asarray(a).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+
+
+def dev(a):
+    import torch
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+
+
+def open_key(eng, G, tag):
+    k = eng.ens(G[f'{tag}_params'])
+    k.set_pubkey(G[f'{tag}_h']); k.set_privkey(G[f'{tag}_g'], G[f'{tag}_inv_g'])
+    return k
+
+
+@pytest.mark.parametrize('tag,nmsg', CASES)
+def test_reference_ciphertexts_and_keys(eng, G, tag, nmsg):
+    import torch
+    k = open_key(eng, G, tag)
+    W = 2048
+    tapes = np.zeros((nmsg, W), dtype=np.uint32); lens = np.zeros(nmsg, dtype=np.int32)
+    for m in range(nmsg):
+        t = u32(G[f'{tag}_tape{m}']); tapes[m, :len(t)] = t; lens[m] = len(t)
+    ct, keys, used, st = k.encaps(dev(tapes), dev(lens))
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [1] * nmsg and used.cpu().tolist() == lens.tolist()
+    for m in range(nmsg):
+        assert bytes(ct[m].cpu().numpy()) == bytes(np.asarray(G[f'{tag}_ct{m}'], dtype=np.uint8)), m
+        assert bytes(keys[m].cpu().numpy()) == bytes(np.asarray(G[f'{tag}_key{m}'], dtype=np.uint8)), m
+    k2 = k.decaps(ct)
+    assert torch.equal(k2, keys)
+    rnd = np.stack([np.asarray(G[f'{tag}_randct{m}'], dtype=np.uint8) for m in range(nmsg)])
+    kr = k.decaps(dev(rnd)).cpu().numpy()
+    for m in range(nmsg):
+        assert bytes(kr[m]) == bytes(np.asarray(G[f'{tag}_randdec{m}'], dtype=np.uint8)), m
+    k.close()
+
+
+@pytest.mark.parametrize('tag,batch', [('ens0', 203), ('ens2', 70)])
+def test_seeded_batch_matches_oracle(eng, G, tag, batch):
+    import torch
+    E = O.Ens(G[f'{tag}_params'])
+    k = open_key(eng, G, tag)
+    rng = np.random.default_rng(0xe25 + batch)
+    W = 3000
+    tapes = rng.integers(0, 2**32, size=(batch, W), dtype=np.uint64).astype(np.uint32)
+    lens = np.full(batch, W, dtype=np.int32)
+    lens[3] = 100                                                  # r cannot be completed
+    lens[4] = 450 if E.n == 512 else 900                          # r fits, e does not
+    ct, keys, used, st = k.encaps(dev(tapes), dev(lens))
+    torch.cuda.synchronize()
+    ctn, kn, un, sn = (x.cpu().numpy() for x in (ct, keys, used, st))
+    for i in range(batch):
+        rc, oc, ok, ou = E.encaps(G[f'{tag}_h'], tapes[i, :lens[i]])
+        assert (rc, int(sn[i])) in ((0, 1), (2, 2)), i
+        if rc == 0:
+            assert bytes(ctn[i]) == oc and bytes(kn[i]) == ok and un[i] == ou, i
+    assert sn[3] == 2 and sn[4] == 2
+    junk = rng.integers(0, 256, size=(batch, k.ct_bytes), dtype=np.uint8)
+    kj = k.decaps(dev(junk)).cpu().numpy()
+    for i in range(0, batch, 7):
+        assert bytes(kj[i]) == E.decaps(G[f'{tag}_g'], G[f'{tag}_inv_g'], bytes(junk[i]))[1], i
+    k.close()
+
+
+def test_round_trip_large_batch(eng, G):
+    import torch
+    k = open_key(eng, G, 'ens0')
+    B = 32768
+    g = torch.Generator(device='cuda'); g.manual_seed(5)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, 1024), dtype=torch.int32, device='cuda', generator=g)
+    ct, keys, used, st = k.encaps(tapes)
+    k2 = k.decaps(ct)
+    torch.cuda.synchronize()
+    assert int((st == 1).sum()) == B
+    same = (k2 == keys).all(dim=1)
+    assert int(same.sum()) >= B - B // 1000                       # the scheme's own failure rate, if any
+    k.close()
+
+
+def test_errors_are_reported(eng, G):
+    import torch
+    from libsafecrypto_amd import EngineError
+    par = np.asarray(G['ens0_params']).copy()
+    bad = par.copy(); bad[3] = 256
+    with pytest.raises(EngineError):
+        eng.ens(bad)
+    k = eng.ens(par)
+    with pytest.raises(EngineError):
+        k.encaps(torch.zeros((4, 1024), dtype=torch.int32, device='cuda'))
+    with pytest.raises(EngineError):
+        k.decaps(torch.zeros((4, k.ct_bytes), dtype=torch.uint8, device='cuda'))
+    k.close()
