@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -893,6 +893,73 @@ static int gen_ens(const char *dir)
     return rc;
 }
 
+/* ----------------------------------------------------------------- DLP-IBE ---- */
+#include "schemes/ibe/dlp/dlp_ibe.h"
+#include "schemes/ibe/dlp/dlp_ibe_params.h"
+
+static void rec_f64(FILE *f, const char *name, const double *v, size_t n);     /* defined with the Falcon records below */
+
+/* dlp_ibe_extract (src/schemes/ibe/dlp/dlp_ibe.c:874-1043, enhanced extract): H(id) by SHAKE128 (:805-816), inv_ntt_32_32_large,
+ * gaussian_sample_with_tree over the master tree (load_skey of the master key, :394-425), center_32, 17-bit signed raw coding.
+ * The master key pair is the reference's (data: the tree as doubles); the sampler draws from sc->prng_ctx[0]: tape technique. */
+static int dlp_case(FILE *f, int set, int nids)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "dlp%d", set);
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_IBE_DLP, set, flags);
+    if (!sc) return 1;
+    FILE *devnull = fopen("/dev/null", "w");
+    FILE *saved = stdout, *saved_err = stderr;
+    stdout = devnull; stderr = devnull;                               /* the key generator prints its polynomials */
+    const int krc = safecrypto_keygen(sc);
+    stdout = saved; stderr = saved_err;
+    if (SC_FUNC_SUCCESS != krc) return 1;
+    const dlp_ibe_set_t *P = sc->dlp_ibe->params;
+    const int n = P->n, logn = P->n_bits;
+    uint32_t ub = (uint32_t)(6 * 1.17 * sqrt((DOUBLE)P->q / (DOUBLE)(2 * n)));
+    int ubits = 0; while ((1u << ubits) < ub) ubits++;             /* sc_ceil_log2 */
+    ubits += 8;
+    int32_t par[8] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->n_bits, set, ubits, 0, 0 };
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
+    snprintf(name, sizeof name, "%s_tree", tag); rec_f64(f, name, sc->dlp_ibe->master_tree, (size_t)(logn + 5) * n);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xd1b000ULL + set;
+    for (int m = 0; m < nids; m++) {
+        uint8_t id[80], seed[32];
+        size_t idlen = (m == 0) ? 1 : (m == 1) ? 80 : 17;
+        for (size_t i = 0; i < idlen; i++) id[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *sk = NULL; size_t sklen = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_ibe_extract(sc, idlen, id, &sklen, &sk)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_id%d", tag, m); rec_u8(f, name, id, idlen);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "%s_sk%d", tag, m); rec_u8(f, name, sk, sklen);
+        free(tape); free(sk);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    safecrypto_destroy(sc);
+    fclose(devnull);
+    return 0;
+}
+
+static int gen_dlp(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/dlp_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = dlp_case(f, 0, 4);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -1213,7 +1280,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -1227,5 +1294,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "tesla")) rc |= gen_tesla(argv[2]);
     if (all || !strcmp(argv[1], "rlwe")) rc |= gen_rlwe(argv[2]);
     if (all || !strcmp(argv[1], "ens")) rc |= gen_ens(argv[2]);
+    if (all || !strcmp(argv[1], "dlp")) rc |= gen_dlp(argv[2]);
     return rc;
 }

@@ -327,3 +327,36 @@ void orc_falcon_leaf_sigmas(const double *sk, int n, int logn, float *out)
     size_t k = 0;
     leaves_rec(sk + 4 * (size_t)n, (unsigned)logn, out, &k);
 }
+
+/* ---- DLP-IBE extract (src/schemes/ibe/dlp/dlp_ibe.c:874-1043 with DLP_IBE_USE_ENHANCED_EXTRACT = 1, H_NTT_OPTIMISATION, XOF oracle) ----
+ * par = {n, q, q_bits, n_bits, set, ubits, 0, 0}; tree = sc->dlp_ibe->master_tree (load_skey layout, as Falcon's sk).
+ * id_function (:805-816): SHAKE128(id) -> n little-endian words, masked to q_bits, minus q when >= q; the result is taken as an NTT-domain
+ * vector (inv_ntt_32_32_large, :939); gaussian_sample_with_tree(..., s1 = NULL, s2 = v) (:981); center_32; ubits-bit signed raw coding. */
+int orc_dlp_extract(const int32_t *par, const double *tree, const uint8_t *id, size_t idlen, const uint32_t *tape, size_t tape_len, uint8_t *sk)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], logn = par[3], ubits = par[5];
+    int32_t *w = malloc(sizeof(int32_t) * (size_t)n * 5), *r = w + n, *c = r + n, *s1 = c + n, *v = s1 + n;
+    if (orc_make_tables(q, n, w, r)) { free(w); return 1; }
+    shake_t sh;
+    shake_init(&sh, 128);
+    shake_absorb(&sh, id, idlen);
+    shake_final(&sh);
+    const uint32_t mask = (1u << q_bits) - 1;
+    for (int i = 0; i < n; i++) {
+        uint8_t b[4];
+        shake_squeeze(&sh, b, 4);
+        int32_t y = (int32_t)(((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) & mask);
+        y -= (y >= q) * q;
+        c[i] = y;
+    }
+    orc_inv_ntt(c, n, q, c, w, r);
+    const int rc = orc_falcon_sample(tree, n, q, logn, c, tape, tape_len, s1, v);
+    if (rc) { free(w); return rc; }
+    orc_center(v, (size_t)n, q);
+    const size_t bytes = ((size_t)n * ubits + 7) / 8;
+    memset(sk, 0, bytes);
+    size_t bp = 0;
+    for (int i = 0; i < n; i++) for (int b = ubits - 1; b >= 0; b--, bp++) sk[bp >> 3] |= (uint8_t)((((uint32_t)v[i] >> b) & 1u) << (7 - (bp & 7)));
+    free(w);
+    return 0;
+}

@@ -101,6 +101,7 @@ def lib():
         L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
+        L.orc_dlp_extract.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u32p, C.c_size_t, u8p]
         for fn in ('orc_ens_ct_bytes', 'orc_ens_key_bytes'):
             getattr(L, fn).restype = C.c_size_t
             getattr(L, fn).argtypes = [i32p]
@@ -408,6 +409,15 @@ class Ens:
         ig = np.ascontiguousarray((np.asarray(inv_g).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32))
         rc = lib().orc_ens_decaps(self.par, np.ascontiguousarray(np.asarray(g), dtype=np.int16), ig, c, c.size, key)
         return rc, bytes(key)
+
+
+def dlp_extract(par, tree, ident, tape):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    sk = np.zeros(int(par[0]) * int(par[5]) // 8, dtype=np.uint8)
+    i, il = _msgbuf(ident)
+    tp = _tape(tape)
+    rc = lib().orc_dlp_extract(par, np.ascontiguousarray(tree, dtype=np.float64), i, il, tp, tp.size, sk)
+    return rc, bytes(sk)
 
 
 def bliss_keygen(par, nz, tape):

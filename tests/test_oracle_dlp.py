@@ -1,0 +1,22 @@
+"""CPU: the oracle's DLP-IBE extract (oracle/sc_oracle_falcon.c: orc_dlp_extract) against user secret keys the reference itself
+extracted under its own master key from the same CSPRNG words (tests/golden/dlp_ref.txt, generator oracle/ref_driver.c)."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('dlp_ref.txt')
+
+
+def test_extract_matches_reference(G):
+    par = G['dlp0_params']
+    tree = np.asarray(G['dlp0_tree'], dtype=np.int64).view(np.float64)
+    for m in range(4):
+        ident = bytes(np.asarray(G[f'dlp0_id{m}'], dtype=np.uint8))
+        rc, sk = O.dlp_extract(par, tree, ident, G[f'dlp0_tape{m}'])
+        assert rc == 0 and sk == bytes(np.asarray(G[f'dlp0_sk{m}'], dtype=np.uint8)), m
+    assert O.dlp_extract(par, tree, ident, G['dlp0_tape3'][:100])[0] != 0
