@@ -405,6 +405,15 @@ int sc_hip_falcon_sign(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, 
 int sc_hip_falcon_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* replaces: safecrypto_ibe_extract -> dlp_ibe_extract (src/schemes/ibe/dlp/dlp_ibe.c:874-1043: enhanced extract, XOF id oracle :805-816, H(id) in
+ * the NTT domain :935-940) for `batch` identities under one master key.  h: a handle created with the DLP-IBE parameters {n, q = 4206593,
+ * q_bits = 23, n_bits, set, bd unused} and loaded (sc_hip_falcon_set_privkey) with sc->dlp_ibe->master_tree - the master key expanded by the same
+ * load_skey as Falcon's (dlp_ibe.c:394-425).  ubits = 8 + ceil_log2(floor(6 * 1.17 * sqrt(q / 2n))) (:916-917; 17 for both sets).  Tapes as for
+ * Falcon signing (4n CSPRNG words per identity).  d_sk: n * ubits / 8 bytes each - the reference's user secret key for the same words.
+ * d_status[i]: 1 extracted, 2 tape exhausted. */
+int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *h, size_t batch, int ubits, const uint8_t *d_ids, size_t id_stride, const uint32_t *d_idlens, uint32_t fixed_len,
+                           const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sk, size_t sk_stride, uint32_t *d_status, void *stream);
+
 /* KEM level, with the reference's build options (SHA3-512 with its own permutation, AES CTR-DRBG for oracle bytes and noise):
  * extra public-key material that only enters the G hash - t: the coefficient-domain vector as stored (first k*n words of
  * sc->pubkey->key, kyber_kem.c:636-650), rho: the 32-byte matrix seed */

@@ -512,8 +512,9 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
 }
 
 // ---- hash to ring (falcon.c:534-591): SHAKE128 with the reference's permutation, n little-endian 32-bit words --------
+// dlp != 0: the DLP-IBE id oracle (dlp_ibe.c:805-816) - same stream, but q is SUBTRACTED when y >= q
 __global__ __launch_bounds__(HT) void fal_hash1_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
-                                                      int32_t *__restrict__ c, FalP P)
+                                                      int32_t *__restrict__ c, FalP P, int dlp)
 {
     __shared__ uint64_t st[25 * HT];
     const uint32_t b = blockIdx.x * HT + threadIdx.x;
@@ -526,6 +527,7 @@ __global__ __launch_bounds__(HT) void fal_hash1_kernel(uint32_t batch, const uin
     int32_t *cb = c + (size_t)b * P.n;
     auto map = [&](uint32_t y) -> int32_t {
         y &= mask;
+        if (dlp) return (int32_t)(y - (y >= q ? q : 0u));
         y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
         return (int32_t)y;
     };
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(HT) void fal_hash1_kernel(uint32_t batch, const uin
 // The same with two lanes per message (Sponge2, keccak_dev.h): lane h of a pair owns the 32-bit half h of every state word, i.e.
 // every second draw.  Used while the one-lane form would leave SIMDs without a wavefront (see fal_launch_hash).
 __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
-                                                      int32_t *__restrict__ c, FalP P)
+                                                      int32_t *__restrict__ c, FalP P, int dlp)
 {
     __shared__ uint32_t st[25 * HT];
     const uint32_t b = (blockIdx.x * HT + threadIdx.x) >> 1;
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uin
     int32_t *cb = c + (size_t)b * P.n;
     auto map = [&](uint32_t y) -> int32_t {
         y &= mask;
+        if (dlp) return (int32_t)(y - (y >= q ? q : 0u));
         y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
         return (int32_t)y;
     };
@@ -715,6 +718,27 @@ void make_gm(std::vector<double> &gm)
         }
     }
     gm[2] = -0.0; gm[3] = 1.0;
+}
+
+
+// dlp_ibe_extract's output coding (dlp_ibe.c:991-1006): v centred (already a small signed integer), ubits bits per coefficient,
+// two's complement, MSB first.  One thread per eight coefficients = ubits bytes.
+// status: the sampler leaves 2 where the tape ran out; everything else is packed and marked 1.
+__global__ void dlp_pack_kernel(uint32_t batch, const int32_t *__restrict__ v, uint32_t *__restrict__ status, uint8_t *__restrict__ sk, size_t sk_stride, int n, int ubits)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = n / 8;
+    const uint32_t i = (uint32_t)(t / per); const int g = (int)(t % per);
+    if (i >= batch || status[i] == 2) return;
+    const int32_t *src = v + (size_t)i * n + 8 * g;
+    uint8_t *o = sk + (size_t)i * sk_stride + (size_t)g * ubits;
+    uint64_t acc = 0; int nb = 0, w = 0;
+    const uint32_t mask = (1u << ubits) - 1u;
+    for (int e = 0; e < 8; e++) {
+        acc = (acc << ubits) | (uint64_t)((uint32_t)src[e] & mask); nb += ubits;
+        while (nb >= 8) { o[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+    }
+    if (g == 0) status[i] = 1;
 }
 
 }  // namespace
@@ -919,8 +943,8 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
     hipStream_t s = (hipStream_t)stream;
     const uint32_t B = (uint32_t)batch;
     uint32_t *status = d_status ? d_status : f->status;
-    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
@@ -942,11 +966,41 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
     hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P);
-    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_ibe_extract -> dlp_ibe_extract (src/schemes/ibe/dlp/dlp_ibe.c:874-1043; enhanced extract, XOF id oracle, NTT-domain H(id))
+// for `batch` identities under one master key.  The handle is a Falcon-shaped one created with the DLP-IBE parameters (n, q = 4206593,
+// q_bits = 23, n_bits) whose private key is sc->dlp_ibe->master_tree (load_skey layout).  ubits = 8 + ceil_log2(floor(6 * 1.17 * sqrt(q / 2n)))
+// (dlp_ibe.c:916-917).  d_sk: [batch][sk_stride] bytes, n * ubits / 8 each; d_status: 1 extracted, 2 tape exhausted.
+extern "C" int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *f, size_t batch, int ubits, const uint8_t *d_ids, size_t id_stride, const uint32_t *d_idlens, uint32_t fixed_len,
+                                      const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sk, size_t sk_stride, uint32_t *d_status, void *stream)
+{
+    if (fal_check_common(f, batch, "dlp_ibe_extract")) return SC_HIP_FAILURE;
+    if (!f->have_sk) return fail("dlp_ibe_extract: no master tree loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_ids || !d_tapes || !d_sk) return fail("dlp_ibe_extract: null buffer");
+    if (ubits < 2 || ubits > 32 || sk_stride < (size_t)f->P.n * (size_t)ubits / 8) return fail("dlp_ibe_extract: bad ubits or sk_stride");
+    if (tape_stride > 0xffffffffu) return fail("dlp_ibe_extract: tape too long");
+    if (((uintptr_t)d_tapes & 15) != 0 || (tape_stride & 3) != 0) return fail("dlp_ibe_extract: tapes must be 16-byte aligned rows (tape_stride a multiple of 4 words)");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    uint32_t *status = d_status ? d_status : f->status;
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_ids, id_stride, d_idlens, fixed_len, f->c, f->P, 1);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_ids, id_stride, d_idlens, fixed_len, f->c, f->P, 1);
+    HIPCHK(hipGetLastError());
+    if (sc_hip_ntt_inv(f->plan, batch, f->c, f->c, s)) return SC_HIP_FAILURE;                     // H(id) is taken as an NTT-domain vector (dlp_ibe.c:935-940)
+    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
+    const size_t nt = batch * (size_t)(f->P.n / 8);
+    hipLaunchKernelGGL(dlp_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, f->s2, status, d_sk, sk_stride, f->P.n, ubits);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

@@ -31,6 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
+    'sc_hip_dlp_ibe_extract',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
@@ -163,6 +164,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_ens_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_ens_destroy.argtypes = [vp]
     L.sc_hip_ens_destroy.restype = None
@@ -885,6 +887,20 @@ class Falcon:
         a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
         assert a.size == self.n
         _chk(self.L, self.L.sc_hip_falcon_set_pubkey(self.h, _ptr(a)), 'falcon_set_pubkey')
+
+    def dlp_extract(self, ubits, ids, tapes, idlens=None, fixed_len=0, tape_lens=None):
+        """DLP-IBE extract (the handle holds the DLP-IBE parameters and the master tree): ids uint8 [batch][stride], tapes [batch][>= 4n]
+        -> user secret keys uint8 [batch][n * ubits / 8], status"""
+        import torch
+        batch, dev = ids.shape[0], ids.device
+        nbytes = self.n * ubits // 8
+        sk = torch.zeros((batch, nbytes), dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_dlp_ibe_extract(self.h, batch, int(ubits), _ptr(ids), _rows(ids), _ptr(idlens) if idlens is not None else nul, fixed_len,
+                                                   _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul, _ptr(sk), nbytes, _ptr(status), _stream()),
+             'dlp_ibe_extract')
+        return sk, status
 
     def sample(self, c, tapes, tape_lens=None, want_s1=True):
         """c int32 [batch][n], tapes int32/uint32 [batch][>= 4n] (device) -> s1, s2 int32 [batch][n], status"""

@@ -12,6 +12,7 @@
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
+ *        ref_driver bench_dlp <set> <seconds>    (single-thread safecrypto_ibe_extract, DLP-IBE)
  *        ref_driver bench_rlwe <set> <seconds>   (single-thread safecrypto_public_encrypt / safecrypto_private_decrypt, RLWE-Enc)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
@@ -1270,8 +1271,37 @@ static int bench_enc(int set, double seconds)
     return 0;
 }
 
+/* single-thread dlp_ibe_extract through safecrypto_ibe_extract under one master key */
+static int bench_dlp(int set, double seconds)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_IBE_DLP, set, flags);
+    if (!sc) return 1;
+    FILE *devnull = fopen("/dev/null", "w"), *saved = stdout, *saved_err = stderr;
+    stdout = devnull; stderr = devnull;
+    const int krc = safecrypto_keygen(sc);
+    stdout = saved; stderr = saved_err;
+    if (SC_FUNC_SUCCESS != krc) return 1;
+    uint64_t nex = 0;
+    uint8_t id[16];
+    sm_state = 0xd1bbeULL;
+    double t0 = now_s(), t1;
+    do {
+        for (int i = 0; i < 16; i++) {
+            uint64_t v = splitmix64(); memcpy(id, &v, 8); v = splitmix64(); memcpy(id + 8, &v, 8);
+            UINT8 *sk = NULL; size_t sklen = 0;
+            if (SC_FUNC_SUCCESS != safecrypto_ibe_extract(sc, 16, id, &sklen, &sk)) return 1;
+            free(sk);
+        }
+        nex += 16; t1 = now_s();
+    } while (t1 - t0 < seconds);
+    printf("{\"set\": %d, \"extract_per_sec\": %.1f, \"extractions\": %llu}\n", set, nex / (t1 - t0), (unsigned long long)nex);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc == 4 && !strcmp(argv[1], "bench_dlp")) return bench_dlp(atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_kyber")) return bench_kem(SC_SCHEME_KEM_KYBER, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_ens")) return bench_kem(SC_SCHEME_KEM_ENS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_rlwe")) return bench_enc(atoi(argv[2]), atof(argv[3]));
