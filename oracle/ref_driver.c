@@ -921,9 +921,10 @@ static int dlp_case(FILE *f, int set, int nids)
     uint32_t ub = (uint32_t)(6 * 1.17 * sqrt((DOUBLE)P->q / (DOUBLE)(2 * n)));
     int ubits = 0; while ((1u << ubits) < ub) ubits++;             /* sc_ceil_log2 */
     ubits += 8;
-    int32_t par[8] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->n_bits, set, ubits, 0, 0 };
+    int32_t par[8] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->n_bits, set, ubits, (int32_t)P->m_scale, (int32_t)P->l };
     snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
     snprintf(name, sizeof name, "%s_tree", tag); rec_f64(f, name, sc->dlp_ibe->master_tree, (size_t)(logn + 5) * n);
+    snprintf(name, sizeof name, "%s_h_ntt", tag); rec_i32(f, name, (const int32_t *)sc->pubkey->key + n, n);
     prng_ctx_t *orig = sc->prng_ctx[0];
     sm_state = 0xd1b000ULL + set;
     for (int m = 0; m < nids; m++) {
@@ -941,7 +942,31 @@ static int dlp_case(FILE *f, int set, int nids)
         snprintf(name, sizeof name, "%s_id%d", tag, m); rec_u8(f, name, id, idlen);
         snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
         snprintf(name, sizeof name, "%s_sk%d", tag, m); rec_u8(f, name, sk, sklen);
-        free(tape); free(sk);
+        free(tape);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+        /* dlp_ibe_encrypt to this identity (dlp_ibe.c:1140-1370: n/32 prng_32 words for the key bits, then n prng_var(6) draws for e1, e2, e3)
+         * and dlp_ibe_decrypt (:1372-1520) with the user key just extracted (loaded through dlp_ibe_secret_key, which keeps its NTT) */
+        if (SC_FUNC_SUCCESS != safecrypto_secret_key(sc, sklen, sk)) return 1;
+        snprintf(name, sizeof name, "%s_uk_ntt%d", tag, m); rec_i32(f, name, sc->dlp_ibe->user_key + n, n);
+        free(sk);
+        uint8_t msg[128];
+        for (int i = 0; i < n / 8; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        mine = seeded_prng(seed, 32); twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *ct = NULL, *dec = NULL; size_t ctlen = 0, declen = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_ibe_public_encrypt(sc, idlen, id, (size_t)n / 8, msg, &ctlen, &ct)) return 1;
+        /* prng_var keeps unread bits in its reservoir: the twin is advanced by whole words, one more than the byte count says when bits are left */
+        const size_t ewords = (size_t)((prng_get_out_bytes(mine) + 3) / 4) + 1;
+        int32_t *etape = malloc(sizeof(int32_t) * ewords);
+        for (size_t i = 0; i < ewords; i++) etape[i] = (int32_t)prng_32(twin);
+        if (SC_FUNC_SUCCESS != safecrypto_private_decrypt(sc, ctlen, ct, &declen, &dec)) return 1;
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, (size_t)n / 8);
+        snprintf(name, sizeof name, "%s_etape%d", tag, m); rec_i32(f, name, etape, ewords);
+        snprintf(name, sizeof name, "%s_ct%d", tag, m); rec_u8(f, name, ct, ctlen);
+        snprintf(name, sizeof name, "%s_dec%d", tag, m); rec_u8(f, name, dec, declen);
+        free(etape); free(ct); free(dec);
         sc->prng_ctx[0] = orig;
         prng_destroy(mine); prng_destroy(twin);
     }

@@ -360,3 +360,108 @@ int orc_dlp_extract(const int32_t *par, const double *tree, const uint8_t *id, s
     free(w);
     return 0;
 }
+
+/* ---- DLP-IBE encrypt / decrypt (dlp_ibe.c:1140-1370, 1372-1520; SC_IBE_MESSAGE_LENGTH_N, XOF oracles, H_NTT_OPTIMISATION) ----
+ * par = {n, q, q_bits, n_bits, set, ubits, m_scale, l}.  h_ntt: the second half of the public key (NTT(h), SINT32); uk_ntt: the NTT of the
+ * user key as dlp_ibe_secret_key keeps it (centred, :1100-1104).  Randomness (tape = prng_32 word stream of sc->prng_ctx[0]): n/32 words of
+ * key bits (LSB first), then n prng_var(6) draws (prng.c:1017-1048 reservoir): bit 0 / 1 = |e1| / sign, 2 / 3 = e2, 4 / 5 = e3.
+ * Ciphertext: u (q_bits, signed) | v >> l (q_bits - l, signed) | message XOR SHAKE128(k as n bytes)[0, n/8), MSB first. */
+typedef struct { const uint32_t *w; size_t len, pos; uint32_t var_buf; int var_bits; int underrun; } dtape_t;
+static uint32_t d32(dtape_t *t) { if (t->pos >= t->len) { t->underrun = 1; return 0; } return t->w[t->pos++]; }
+static uint32_t dvar(dtape_t *t, int n)
+{
+    uint32_t ret = t->var_buf;
+    if (t->var_bits < n) {
+        const int bits = n - t->var_bits;
+        ret <<= bits;
+        t->var_buf = d32(t);
+        ret |= t->var_buf & ((1u << bits) - 1u);
+        t->var_buf >>= bits;
+        t->var_bits = 32 - bits;
+    } else {
+        t->var_buf >>= n;
+        t->var_bits -= n;
+    }
+    return ret & ((1u << n) - 1u);
+}
+
+static void dlp_id(int32_t *c, int n, int q, int q_bits, const uint8_t *id, size_t idlen)
+{
+    shake_t sh;
+    shake_init(&sh, 128);
+    shake_absorb(&sh, id, idlen);
+    shake_final(&sh);
+    const uint32_t mask = (1u << q_bits) - 1;
+    for (int i = 0; i < n; i++) {
+        uint8_t b[4];
+        shake_squeeze(&sh, b, 4);
+        int32_t y = (int32_t)(((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) & mask);
+        c[i] = y - (y >= q) * q;
+    }
+}
+
+static void dlp_pad(uint8_t *k, int n)                         /* k_function_xof, dlp_ibe.c:850-862: k (n bytes of 0 / 1) -> n/8 bytes in place */
+{
+    shake_t sh;
+    shake_init(&sh, 128);
+    shake_absorb(&sh, k, (size_t)n);
+    shake_final(&sh);
+    shake_squeeze(&sh, k, (size_t)n / 8);
+}
+
+size_t orc_dlp_ct_bytes(const int32_t *par) { return ((size_t)par[0] * (size_t)(2 * par[2] - par[7]) + 7) / 8 + (size_t)par[0] / 8; }
+
+int orc_dlp_encrypt(const int32_t *par, const int32_t *h_ntt, const uint8_t *id, size_t idlen, const uint8_t *msg, const uint32_t *tape, size_t tape_len, uint8_t *ct)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], m_scale = par[6], l = par[7], q2 = q >> 1;
+    int32_t *w = malloc(sizeof(int32_t) * (size_t)n * 9), *r = w + n, *c = r + n, *e1 = c + n, *e2 = e1 + n, *e3 = e2 + n, *u = e3 + n, *v = u + n, *ek = v + n;
+    uint8_t *k = malloc((size_t)n);
+    dtape_t T = { tape, tape_len, 0, 0, 0, 0 };
+    int rc = 2;
+    if (orc_make_tables(q, n, w, r)) { free(w); free(k); return 1; }
+    dlp_id(c, n, q, q_bits, id, idlen);
+    for (int i = 0; i < n; i += 32) { uint32_t x = d32(&T); for (int j = 0; j < 32; j++) { k[i + j] = x & 1; x >>= 1; } }
+    for (int i = 0; i < n; i++) ek[i] = (k[i] & 1) * m_scale;
+    for (int i = 0; i < n; i++) {
+        uint32_t b = dvar(&T, 6);
+        e1[i] = (int32_t)(b & 1); b >>= 1; if (b & 1) e1[i] = -e1[i]; b >>= 1;
+        e2[i] = (int32_t)(b & 1); b >>= 1; if (b & 1) e2[i] = -e2[i]; b >>= 1;
+        e3[i] = (int32_t)(b & 1); b >>= 1; if (b & 1) e3[i] = -e3[i];
+    }
+    if (T.underrun) goto done;
+    orc_polymul_ntt(u, n, q, e3, h_ntt, w, r);                                    /* e3 * h, canonical */
+    orc_polymul_ntt(v, n, q, e3, c, w, r);                                        /* e3 * H(id) (H(id) is an NTT-domain vector) */
+    for (int i = 0; i < n; i++) { u[i] += q2 + e1[i]; v[i] += q2 + e2[i] + ek[i]; }
+    orc_normalize(u, (size_t)n, q); orc_normalize(v, (size_t)n, q);
+    for (int i = 0; i < n; i++) { u[i] -= q2; v[i] -= q2; v[i] >>= l; }
+    dlp_pad(k, n);
+    memset(ct, 0, orc_dlp_ct_bytes(par));
+    size_t bp = 0;
+    for (int i = 0; i < n; i++) for (int b = q_bits - 1; b >= 0; b--, bp++) ct[bp >> 3] |= (uint8_t)((((uint32_t)u[i] >> b) & 1u) << (7 - (bp & 7)));
+    for (int i = 0; i < n; i++) for (int b = q_bits - l - 1; b >= 0; b--, bp++) ct[bp >> 3] |= (uint8_t)((((uint32_t)v[i] >> b) & 1u) << (7 - (bp & 7)));
+    for (int i = 0; i < n / 8; i++) ct[(bp >> 3) + i] = (uint8_t)(k[i] ^ msg[i]);
+    rc = 0;
+done:
+    free(w); free(k);
+    return rc;
+}
+
+int orc_dlp_decrypt(const int32_t *par, const int32_t *uk_ntt, const uint8_t *ct, size_t ctlen, uint8_t *msg)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], l = par[7], q2 = q >> 1, q4 = q >> 2, vb = q_bits - l;
+    if (ctlen < orc_dlp_ct_bytes(par)) return 1;
+    int32_t *w = malloc(sizeof(int32_t) * (size_t)n * 4), *r = w + n, *u = r + n, *v = u + n;
+    uint8_t *k = malloc((size_t)n);
+    if (orc_make_tables(q, n, w, r)) { free(w); free(k); return 1; }
+    size_t bp = 0;
+    for (int i = 0; i < n; i++) { uint32_t x = 0; for (int b = 0; b < q_bits; b++, bp++) x = (x << 1) | ((ct[bp >> 3] >> (7 - (bp & 7))) & 1u); u[i] = (int32_t)(x << (32 - q_bits)) >> (32 - q_bits); }
+    for (int i = 0; i < n; i++) { uint32_t x = 0; for (int b = 0; b < vb; b++, bp++) x = (x << 1) | ((ct[bp >> 3] >> (7 - (bp & 7))) & 1u); v[i] = ((int32_t)(x << (32 - vb)) >> (32 - vb)) << l; }
+    orc_polymul_ntt(u, n, q, u, uk_ntt, w, r);
+    for (int i = 0; i < n; i++) v[i] -= u[i];
+    orc_normalize(v, (size_t)n, q);
+    for (int i = 0; i < n; i++) { const int32_t x = v[i] + q4; k[i] = (x >= q2 && x < q) ? 1 : 0; }
+    dlp_pad(k, n);
+    for (int i = 0; i < n / 8; i++) msg[i] = (uint8_t)(ct[(bp >> 3) + i] ^ k[i]);
+    free(w); free(k);
+    return 0;
+}

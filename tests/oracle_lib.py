@@ -101,6 +101,10 @@ def lib():
         L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
+        L.orc_dlp_ct_bytes.restype = C.c_size_t
+        L.orc_dlp_ct_bytes.argtypes = [i32p]
+        L.orc_dlp_encrypt.argtypes = [i32p, i32p, u8p, C.c_size_t, u8p, u32p, C.c_size_t, u8p]
+        L.orc_dlp_decrypt.argtypes = [i32p, i32p, u8p, C.c_size_t, u8p]
         L.orc_dlp_extract.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.float64, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u32p, C.c_size_t, u8p]
         for fn in ('orc_ens_ct_bytes', 'orc_ens_key_bytes'):
             getattr(L, fn).restype = C.c_size_t
@@ -418,6 +422,24 @@ def dlp_extract(par, tree, ident, tape):
     tp = _tape(tape)
     rc = lib().orc_dlp_extract(par, np.ascontiguousarray(tree, dtype=np.float64), i, il, tp, tp.size, sk)
     return rc, bytes(sk)
+
+
+def dlp_encrypt(par, h_ntt, ident, msg, tape):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    ct = np.zeros(lib().orc_dlp_ct_bytes(par), dtype=np.uint8)
+    i, il = _msgbuf(ident)
+    m = np.ascontiguousarray(np.frombuffer(bytes(msg), dtype=np.uint8))
+    tp = _tape(tape)
+    rc = lib().orc_dlp_encrypt(par, np.ascontiguousarray(np.asarray(h_ntt), dtype=np.int32), i, il, m, tp, tp.size, ct)
+    return rc, bytes(ct)
+
+
+def dlp_decrypt(par, uk_ntt, ct):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    c = np.ascontiguousarray(np.frombuffer(bytes(ct), dtype=np.uint8))
+    msg = np.zeros(int(par[0]) // 8, dtype=np.uint8)
+    rc = lib().orc_dlp_decrypt(par, np.ascontiguousarray(np.asarray(uk_ntt), dtype=np.int32), c, c.size, msg)
+    return rc, bytes(msg)
 
 
 def bliss_keygen(par, nz, tape):

@@ -20,3 +20,17 @@ def test_extract_matches_reference(G):
         rc, sk = O.dlp_extract(par, tree, ident, G[f'dlp0_tape{m}'])
         assert rc == 0 and sk == bytes(np.asarray(G[f'dlp0_sk{m}'], dtype=np.uint8)), m
     assert O.dlp_extract(par, tree, ident, G['dlp0_tape3'][:100])[0] != 0
+
+
+def test_encrypt_decrypt_match_reference(G):
+    par = G['dlp0_params']
+    for m in range(4):
+        ident = bytes(np.asarray(G[f'dlp0_id{m}'], dtype=np.uint8))
+        msg = bytes(np.asarray(G[f'dlp0_msg{m}'], dtype=np.uint8))
+        ref = bytes(np.asarray(G[f'dlp0_ct{m}'], dtype=np.uint8))
+        rc, ct = O.dlp_encrypt(par, G['dlp0_h_ntt'], ident, msg, G[f'dlp0_etape{m}'])
+        assert rc == 0 and ct == ref, m
+        rc, dec = O.dlp_decrypt(par, G[f'dlp0_uk_ntt{m}'], ref)
+        assert rc == 0 and dec == bytes(np.asarray(G[f'dlp0_dec{m}'], dtype=np.uint8)) == msg, m
+    assert O.dlp_encrypt(par, G['dlp0_h_ntt'], ident, msg, G['dlp0_etape3'][:50])[0] == 2
+    assert O.dlp_decrypt(par, G['dlp0_uk_ntt3'], ref[:-1])[0] == 1
