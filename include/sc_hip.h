@@ -19,7 +19,7 @@
  *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
  *     sc_hip_last_error) when no gfx950 device / kernel image is available
  *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs are immutable after
- *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t) owns the
+ *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t, _dlp_t) owns the
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
  */
@@ -317,6 +317,33 @@ int sc_hip_rlwe_decrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t *d_ct, siz
 /* replaces: safecrypto_keygen -> rlwe_enc_keygen with a_gen / r1_gen / r2_gen (rlwe_enc.c:205-290, 425-493) for `batch`
  * independent key pairs, one tape each; outputs [batch][n] SINT16 in the reference's storage format (a, p = r1 - a r2, r2) */
 int sc_hip_rlwe_keygen(sc_hip_rlwe_t *h, size_t batch, const uint32_t *d_tapes, size_t tape_stride, int16_t *d_a, int16_t *d_p, int16_t *d_r2, void *stream);
+
+/* ---- DLP-IBE: batched encrypt (per-message identity) / decrypt (one user key); extract is sc_hip_dlp_ibe_extract above ---- */
+
+/* dlp_ibe_set_t fields (src/schemes/ibe/dlp/dlp_ibe_params.h:106-125, values dlp_ibe_params.c:22-40: q = 4206593, q_bits = 23, m_scale =
+ * 0x201800, l = 18 / 17) and ubits, the width of a packed user-key coefficient (dlp_ibe.c:916-917) */
+typedef struct sc_hip_dlp_params {
+    int32_t n, q, q_bits, n_bits, set, ubits, m_scale, l;
+} sc_hip_dlp_params_t;
+typedef struct sc_hip_dlp sc_hip_dlp_t;
+
+int  sc_hip_dlp_create(sc_hip_ctx_t *ctx, const sc_hip_dlp_params_t *params, sc_hip_dlp_t **h);
+void sc_hip_dlp_destroy(sc_hip_dlp_t *h);
+/* h_ntt: the second half of sc->pubkey->key (NTT(h), SINT32[n], dlp_ibe.c:1190-1191); uk_ntt: sc->dlp_ibe->user_key + n, the NTT of the user
+ * secret key as dlp_ibe_secret_key leaves it (:1100-1104).  Host pointers. */
+int  sc_hip_dlp_set_pubkey(sc_hip_dlp_t *h, const int32_t *h_ntt);
+int  sc_hip_dlp_set_user_key(sc_hip_dlp_t *h, const int32_t *uk_ntt);
+size_t sc_hip_dlp_msg_bytes(const sc_hip_dlp_t *h);            /* n / 8 (SC_IBE_MESSAGE_LENGTH_N) */
+size_t sc_hip_dlp_ct_bytes(const sc_hip_dlp_t *h);             /* n (2 q_bits - l) / 8 + n / 8 */
+size_t sc_hip_dlp_enc_words(const sc_hip_dlp_t *h);            /* CSPRNG words one encryption can touch */
+/* replaces: safecrypto_ibe_public_encrypt -> dlp_ibe_encrypt (src/schemes/ibe/dlp/dlp_ibe.c:1140-1370) for `batch` (identity, message) pairs;
+ * tape i = the prng_32 word stream of sc->prng_ctx[0] for message i (key bits, then the prng_var(6) reservoir draws).  Ciphertexts equal the
+ * reference's for the same words.  d_status[i]: 1 done, 2 tape exhausted. */
+int sc_hip_dlp_encrypt(sc_hip_dlp_t *h, size_t batch, const uint8_t *d_ids, size_t id_stride, const uint32_t *d_idlens, uint32_t fixed_len,
+                       const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                       uint8_t *d_ct, size_t ct_stride, uint32_t *d_status, void *stream);
+/* replaces: safecrypto_private_decrypt -> dlp_ibe_decrypt (dlp_ibe.c:1372-1520) under the loaded user key */
+int sc_hip_dlp_decrypt(sc_hip_dlp_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_msgs, size_t msg_stride, void *stream);
 
 /* ---- ENS-KEM: batched encapsulation / decapsulation under one key pair ------------------------------ */
 

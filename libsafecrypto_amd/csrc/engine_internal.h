@@ -24,6 +24,31 @@ struct DevBuf {
 };
 }
 
+namespace sc {
+// grow-only device workspace kept by a scheme handle: repeated calls at the same batch size allocate nothing
+struct Workspace {
+    char *p = nullptr;
+    size_t cap = 0, used = 0;
+    int reserve(size_t bytes)
+    {
+        used = 0;
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void **)&p, bytes) != hipSuccess) return fail("device workspace allocation failed");
+        cap = bytes;
+        return 0;
+    }
+    template <typename T> T *take(size_t count)                  // 256-byte aligned slices of the reservation
+    {
+        T *r = reinterpret_cast<T *>(p + used);
+        used += (count * sizeof(T) + 255) & ~(size_t)255;
+        return r;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
+};
+}
+
 #define HIPCHK(expr)                                                                              \
     do {                                                                                          \
         hipError_t e_ = (expr);                                                                   \

@@ -143,6 +143,7 @@ struct sc_hip_ens {
     int32_t *d_h, *d_g;
     uint32_t *d_inv_g;
     bool have_pub, have_priv;
+    sc::Workspace ws;
 };
 
 extern "C" void sc_hip_ens_destroy(sc_hip_ens_t *h)
@@ -150,6 +151,7 @@ extern "C" void sc_hip_ens_destroy(sc_hip_ens_t *h)
     if (!h) return;
     void *ptrs[] = { h->d_h, h->d_g, h->d_inv_g };
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->ws.release();
     if (h->plan) sc_hip_plan_destroy(h->plan);
     delete h;
 }
@@ -164,8 +166,7 @@ extern "C" int sc_hip_ens_create(sc_hip_ctx_t *ctx, const sc_hip_ens_params_t *p
     int total = 0;
     for (int j = 0; j < 12; j++) { if (P.coeff_rnd[j] < 0) return fail("ens_create: negative coefficient count"); total += P.coeff_rnd[j]; }
     if (total > P.n / 2) return fail("ens_create: more than n/2 non-zero coefficients");
-    sc_hip_ens *h = new sc_hip_ens;
-    memset(h, 0, sizeof *h);
+    sc_hip_ens *h = new sc_hip_ens();
     h->ctx = ctx; h->P = P;
     if (sc_hip_plan_create(ctx, P.q, P.n, &h->plan) != SC_HIP_SUCCESS) { sc_hip_ens_destroy(h); return SC_HIP_FAILURE; }
     *out = h;
@@ -218,19 +219,19 @@ extern "C" int sc_hip_ens_encaps(sc_hip_ens_t *h, size_t batch, const uint32_t *
     const int n = h->P.n;
     const uint32_t B = (uint32_t)batch;
     const size_t pn = batch * (size_t)n * 4;
-    DevBuf r, e, t, used;
-    if (r.get(pn) || e.get(pn) || t.get(pn) || used.get(batch * 4)) return SC_HIP_FAILURE;
+    if (h->ws.reserve(3 * (pn + 256) + batch * 4 + 256)) return SC_HIP_FAILURE;
+    int32_t *r = h->ws.take<int32_t>(batch * n), *e = h->ws.take<int32_t>(batch * n), *t = h->ws.take<int32_t>(batch * n);
+    uint32_t *used = h->ws.take<uint32_t>(batch);
     EnsC C;
     for (int j = 0; j < 12; j++) C.c[j] = h->P.coeff_rnd[j];
-    hipLaunchKernelGGL(ens_sample_kernel, dim3((B + HT - 1) / HT), dim3(HT), (size_t)n * HT, s, B, d_tapes, tape_stride, d_tape_lens, C, r.as<int32_t>(), e.as<int32_t>(),
-                       d_used ? d_used : used.as<uint32_t>(), d_status, n);
+    hipLaunchKernelGGL(ens_sample_kernel, dim3((B + HT - 1) / HT), dim3(HT), (size_t)n * HT, s, B, d_tapes, tape_stride, d_tape_lens, C, r, e,
+                       d_used ? d_used : used, d_status, n);
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(h->plan, batch, r.as<int32_t>(), h->d_h, t.as<int32_t>(), s)) return SC_HIP_FAILURE;
+    if (sc::polymul_ntt_bcast(h->plan, batch, r, h->d_h, t, s)) return SC_HIP_FAILURE;
     const size_t nt = batch * (size_t)(n / 4);
-    hipLaunchKernelGGL(ens_enc_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, t.as<int32_t>(), e.as<int32_t>(), d_status, d_ct, ct_stride, d_keys, key_stride,
+    hipLaunchKernelGGL(ens_enc_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, t, e, d_status, d_ct, ct_stride, d_keys, key_stride,
                        n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));                               // the temporaries above are released on return
     return SC_HIP_SUCCESS;
 }
 
@@ -247,14 +248,13 @@ extern "C" int sc_hip_ens_decaps(sc_hip_ens_t *h, size_t batch, const uint8_t *d
     const int n = h->P.n;
     const uint32_t B = (uint32_t)batch;
     const size_t pn = batch * (size_t)n * 4;
-    DevBuf t, gt;
-    if (t.get(pn) || gt.get(pn)) return SC_HIP_FAILURE;
+    if (h->ws.reserve(2 * (pn + 256))) return SC_HIP_FAILURE;
+    int32_t *t = h->ws.take<int32_t>(batch * n), *gt = h->ws.take<int32_t>(batch * n);
     const size_t nt = batch * (size_t)(n / 4);
-    hipLaunchKernelGGL(ens_unpack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, t.as<int32_t>(), n, h->P.q_bits);
+    hipLaunchKernelGGL(ens_unpack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, t, n, h->P.q_bits);
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(h->plan, batch, t.as<int32_t>(), h->d_g, gt.as<int32_t>(), s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(ens_dec_finish_kernel, dim3(B), dim3(n), 0, s, gt.as<int32_t>(), h->d_inv_g, d_keys, key_stride, n, h->P.q);
+    if (sc::polymul_ntt_bcast(h->plan, batch, t, h->d_g, gt, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(ens_dec_finish_kernel, dim3(B), dim3(n), 0, s, gt, h->d_inv_g, d_keys, key_stride, n, h->P.q);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s));
     return SC_HIP_SUCCESS;
 }

@@ -31,7 +31,8 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_dlp_ibe_extract',
+    'sc_hip_dlp_ibe_extract', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
@@ -165,6 +166,16 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
+    L.sc_hip_dlp_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_dlp_destroy.argtypes = [vp]
+    L.sc_hip_dlp_destroy.restype = None
+    L.sc_hip_dlp_set_pubkey.argtypes = [vp, vp]
+    L.sc_hip_dlp_set_user_key.argtypes = [vp, vp]
+    for fn in ('sc_hip_dlp_msg_bytes', 'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words'):
+        getattr(L, fn).argtypes = [vp]
+        getattr(L, fn).restype = sz
+    L.sc_hip_dlp_encrypt.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, sz, vp, vp, sz, vp, vp]
+    L.sc_hip_dlp_decrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp]
     L.sc_hip_ens_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_ens_destroy.argtypes = [vp]
     L.sc_hip_ens_destroy.restype = None
@@ -263,6 +274,9 @@ class Engine:
 
     def ens(self, params):
         return Ens(self, params)
+
+    def dlp(self, params):
+        return Dlp(self, params)
 
     def dilithium(self, params):
         return Dilithium(self, params)
@@ -738,6 +752,58 @@ class Tesla:
         _chk(self.L, self.L.sc_hip_tesla_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'tesla_verify')
         return verdicts
+
+
+class Dlp:
+    """Batched DLP-IBE encrypt (identity per message) / decrypt (one user key).  params: {n, q, q_bits, n_bits, set, ubits, m_scale, l}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 8
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_dlp_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_dlp_create')
+        self.h = h
+        self.n = int(self.par[0])
+        self.msg_bytes = self.L.sc_hip_dlp_msg_bytes(h)
+        self.ct_bytes = self.L.sc_hip_dlp_ct_bytes(h)
+        self.enc_words = self.L.sc_hip_dlp_enc_words(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_dlp_destroy(self.h)
+            self.h = None
+
+    def set_pubkey(self, h_ntt):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(h_ntt), dtype=np.int32)
+        assert a.size == self.n
+        _chk(self.L, self.L.sc_hip_dlp_set_pubkey(self.h, _ptr(a)), 'dlp_set_pubkey')
+
+    def set_user_key(self, uk_ntt):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(uk_ntt), dtype=np.int32)
+        assert a.size == self.n
+        _chk(self.L, self.L.sc_hip_dlp_set_user_key(self.h, _ptr(a)), 'dlp_set_user_key')
+
+    def encrypt(self, ids, msgs, tapes, idlens=None, fixed_len=0, tape_lens=None):
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        ct = torch.zeros((batch, self.ct_bytes), dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_dlp_encrypt(self.h, batch, _ptr(ids), _rows(ids), _ptr(idlens) if idlens is not None else nul, fixed_len, _ptr(msgs), _rows(msgs),
+                                               _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul, _ptr(ct), self.ct_bytes, _ptr(status), _stream()),
+             'dlp_encrypt')
+        return ct, status
+
+    def decrypt(self, ct):
+        import torch
+        batch = ct.shape[0]
+        msgs = torch.zeros((batch, self.msg_bytes), dtype=torch.uint8, device=ct.device)
+        _chk(self.L, self.L.sc_hip_dlp_decrypt(self.h, batch, _ptr(ct), _rows(ct), _ptr(msgs), self.msg_bytes, _stream()), 'dlp_decrypt')
+        return msgs
 
 
 class Ens:

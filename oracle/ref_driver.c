@@ -1320,7 +1320,32 @@ static int bench_dlp(int set, double seconds)
         }
         nex += 16; t1 = now_s();
     } while (t1 - t0 < seconds);
-    printf("{\"set\": %d, \"extract_per_sec\": %.1f, \"extractions\": %llu}\n", set, nex / (t1 - t0), (unsigned long long)nex);
+    const double tex = t1 - t0;
+    /* encrypt to / decrypt for one identity */
+    UINT8 *sk = NULL; size_t sklen = 0;
+    if (SC_FUNC_SUCCESS != safecrypto_ibe_extract(sc, 16, id, &sklen, &sk) || SC_FUNC_SUCCESS != safecrypto_secret_key(sc, sklen, sk)) return 1;
+    const size_t mlen = (set ? param_dlp_ibe_1.n : param_dlp_ibe_0.n) / 8;
+    enum { POOL = 32 };
+    UINT8 msg[128], *ct[POOL]; size_t ctlen[POOL];
+    memset(ct, 0, sizeof ct);
+    uint64_t nenc = 0, ndec = 0;
+    t0 = now_s();
+    do {
+        for (int i = 0; i < POOL; i++) {
+            for (size_t b = 0; b < mlen; b += 8) { uint64_t v = splitmix64(); memcpy(msg + b, &v, 8); }
+            free(ct[i]); ct[i] = NULL; ctlen[i] = 0;
+            if (SC_FUNC_SUCCESS != safecrypto_ibe_public_encrypt(sc, 16, id, mlen, msg, &ctlen[i], &ct[i])) return 1;
+        }
+        nenc += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds / 2);
+    const double te = t1 - t0;
+    t0 = now_s();
+    do {
+        for (int i = 0; i < POOL; i++) { UINT8 *m2 = NULL; size_t m2len = 0; if (SC_FUNC_SUCCESS != safecrypto_private_decrypt(sc, ctlen[i], ct[i], &m2len, &m2)) return 1; free(m2); }
+        ndec += POOL; t1 = now_s();
+    } while (t1 - t0 < seconds / 2);
+    printf("{\"set\": %d, \"extract_per_sec\": %.1f, \"encrypt_per_sec\": %.1f, \"decrypt_per_sec\": %.1f, \"extractions\": %llu}\n", set, nex / tex, nenc / te,
+           ndec / (t1 - t0), (unsigned long long)nex);
     return 0;
 }
 

@@ -85,3 +85,51 @@ def test_extract_both_lane_mappings_agree(eng, G):
         rc, osk = O.dlp_extract(par, tree, bytes(ids[i].cpu().numpy()), (tapes[i].cpu().numpy().astype(np.int64) & 0xFFFFFFFF).astype(np.uint32))
         assert rc == 0 and bytes(sk[i].cpu().numpy()) == osk
     f.close()
+
+
+def test_encrypt_decrypt_reproduce_reference_and_oracle(eng, G):
+    """dlp_ibe_encrypt / _decrypt: the reference's ciphertexts from its own CSPRNG words, seeded batches against the oracle (one identity
+    per message), decryption under the matching user key, a short tape reported"""
+    import torch
+    par = np.asarray(G['dlp0_params'])
+    d = eng.dlp(par)
+    d.set_pubkey(G['dlp0_h_ntt'])
+    n = d.n
+    rng = np.random.default_rng(0xd1e)
+    B = 75
+    W = d.enc_words + 3
+    ids = [bytes(np.asarray(G[f'dlp0_id{m}'], dtype=np.uint8)) for m in range(4)]
+    ids += [ids[2]] * (B - 4)                                    # the rest go to identity 2, whose user key is loaded below
+    msgs = rng.integers(0, 256, size=(B, n // 8), dtype=np.uint8)
+    tapes = rng.integers(0, 2**32, size=(B, W), dtype=np.uint64).astype(np.uint32)
+    lens = np.full(B, W, dtype=np.int32)
+    for m in range(4):
+        t = u32(G[f'dlp0_etape{m}']); tapes[m, :len(t)] = t; lens[m] = len(t)
+        msgs[m] = np.asarray(G[f'dlp0_msg{m}'], dtype=np.uint8)
+    lens[9] = 60                                                  # runs out inside the reservoir draws
+    ib = np.zeros((B, 80), dtype=np.uint8); il = np.zeros(B, dtype=np.int32)
+    for i, x in enumerate(ids):
+        ib[i, :len(x)] = np.frombuffer(x, dtype=np.uint8); il[i] = len(x)
+    ct, st = d.encrypt(torch.from_numpy(ib).cuda(), torch.from_numpy(msgs).cuda(), torch.from_numpy(tapes.view(np.int32)).cuda(),
+                       idlens=torch.from_numpy(il).cuda(), tape_lens=torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    ctn, stn = ct.cpu().numpy(), st.cpu().numpy()
+    for m in range(4):
+        assert stn[m] == 1 and bytes(ctn[m]) == bytes(np.asarray(G[f'dlp0_ct{m}'], dtype=np.uint8)), m
+    assert stn[9] == 2
+    for i in range(4, B):
+        if i == 9:
+            continue
+        rc, oc = O.dlp_encrypt(par, G['dlp0_h_ntt'], ids[i], bytes(msgs[i]), tapes[i])
+        assert rc == 0 and stn[i] == 1 and bytes(ctn[i]) == oc, i
+    d.set_user_key(G['dlp0_uk_ntt2'])
+    dec = d.decrypt(ct).cpu().numpy()
+    for i in [2] + list(range(4, B)):
+        if i == 9:
+            continue
+        assert bytes(dec[i]) == bytes(msgs[i]) == O.dlp_decrypt(par, G['dlp0_uk_ntt2'], bytes(ctn[i]))[1], i
+    junk = rng.integers(0, 256, size=(16, d.ct_bytes), dtype=np.uint8)
+    dj = d.decrypt(torch.from_numpy(junk).cuda()).cpu().numpy()
+    for i in range(16):
+        assert bytes(dj[i]) == O.dlp_decrypt(par, G['dlp0_uk_ntt2'], bytes(junk[i]))[1], i
+    d.close()
