@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -986,6 +986,66 @@ static int gen_dlp(const char *dir)
     return rc;
 }
 
+/* ------------------------------------------------------- ENS / DLP signatures ---- */
+#include "schemes/sig/ens_dlp/ens_dlp_sig.h"
+#include "schemes/sig/ens_dlp/ens_dlp_sig_params.h"
+
+/* ens_dlp_sig_verify (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1564-1665, without message recovery): signatures are made by the reference's own
+ * signer (its O(n^2) Klein sampler over a single-precision Gram-Schmidt matrix stays on the CPU); the fixture carries the public h
+ * (SINT16, coefficient domain), messages, signatures and the reference's verdicts on them and on tampered copies. */
+static int ensdlp_case(FILE *f, sc_scheme_e scheme, const char *tag, int set, const ens_dlp_sig_set_t *P, int nmsg)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96];
+    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    if (!sc) return 1;
+    FILE *devnull = fopen("/dev/null", "w"), *saved = stdout, *saved_err = stderr;
+    stdout = devnull; stderr = devnull;
+    const int krc = safecrypto_keygen(sc);
+    stdout = saved; stderr = saved_err;
+    if (SC_FUNC_SUCCESS != krc) return 1;
+    const int n = P->n;
+    int32_t par[8] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->n_bits, set, 0, 0, 0 };
+    float bd = P->bd;
+    memcpy(&par[5], &bd, 4);
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
+    snprintf(name, sizeof name, "%s_h", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    int32_t *verdicts = malloc(sizeof(int32_t) * nmsg * 3);
+    sm_state = 0xe25d000ULL + set + (scheme == SC_SCHEME_SIG_DLP ? 64 : 0);
+    for (int m = 0; m < nmsg; m++) {
+        uint8_t msg[150];
+        size_t mlen = (m == 0) ? 1 : (m == 1) ? 150 : 33;
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        uint8_t *sig = NULL; size_t siglen = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+        snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+        verdicts[3 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        sig[siglen / 2] ^= 0x01;                                        /* a low bit of one coefficient: the norm barely moves */
+        verdicts[3 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        sig[siglen / 2] ^= 0x01; sig[3] ^= 0x80;                        /* a high bit: far outside the bound */
+        verdicts[3 * m + 2] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+        free(sig);
+    }
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 3);
+    free(verdicts);
+    safecrypto_destroy(sc);
+    fclose(devnull);
+    return 0;
+}
+
+static int gen_ensdlp(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/ensdlp_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = ensdlp_case(f, SC_SCHEME_SIG_ENS, "enssig0", 0, &param_ens_sig_0, 5);
+    rc |= ensdlp_case(f, SC_SCHEME_SIG_DLP, "dlpsig1", 1, &param_dlp_sig_1, 4);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -1360,7 +1420,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_bliss")) return bench_sig(SC_SCHEME_SIG_BLISS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -1375,5 +1435,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "rlwe")) rc |= gen_rlwe(argv[2]);
     if (all || !strcmp(argv[1], "ens")) rc |= gen_ens(argv[2]);
     if (all || !strcmp(argv[1], "dlp")) rc |= gen_dlp(argv[2]);
+    if (all || !strcmp(argv[1], "ensdlp")) rc |= gen_ensdlp(argv[2]);
     return rc;
 }

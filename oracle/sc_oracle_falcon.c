@@ -465,3 +465,33 @@ int orc_dlp_decrypt(const int32_t *par, const int32_t *uk_ntt, const uint8_t *ct
     free(w); free(k);
     return 0;
 }
+
+/* ---- ENS / DLP signature verification (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1564-1665, without message recovery) ----
+ * par = {n, q, q_bits, n_bits, set, bd as float bits, 0, 0}; h: the public key (SINT16, coefficient domain).  s1 = the signature's n
+ * q_bits-bit signed fields (not centred); t = H(m) by SHAKE128 with q SUBTRACTED when >= q (:728-742); s2 = centre(t - h s1);
+ * ||(s1, s2)|| in single precision from the top index down (:1536-1562).  0 = valid. */
+int orc_ensdlp_verify(const int32_t *par, const int16_t *h, const uint8_t *msg, size_t mlen, const uint8_t *sig, size_t siglen)
+{
+    const int n = par[0], q = par[1], q_bits = par[2];
+    float bd; memcpy(&bd, &par[5], 4);
+    if (siglen * 8 < (size_t)n * (size_t)q_bits) return 1;
+    int32_t *w = malloc(sizeof(int32_t) * 7 * (size_t)n), *r = w + n, *c = r + n, *s1 = c + n, *s2 = s1 + n, *h32 = s2 + n, *t = h32 + n;
+    int rc = 1;
+    if (orc_make_tables(q, n, w, r)) goto done;
+    size_t bp = 0;
+    for (int i = 0; i < n; i++) {
+        uint32_t v = 0;
+        for (int b = 0; b < q_bits; b++, bp++) v = (v << 1) | ((sig[bp >> 3] >> (7 - (bp & 7))) & 1u);
+        s1[i] = (int32_t)(v << (32 - q_bits)) >> (32 - q_bits);
+    }
+    dlp_id(c, n, q, q_bits, msg, mlen);
+    for (int i = 0; i < n; i++) { h32[i] = h[i]; t[i] = s1[i]; }
+    orc_normalize(h32, (size_t)n, q); orc_normalize(t, (size_t)n, q);
+    orc_polymul(t, n, q, t, h32, w, r);
+    for (int i = 0; i < n; i++) s2[i] = c[i] - t[i];
+    orc_center(s2, (size_t)n, q);
+    rc = norm_fails(bd, s1, s2, n) ? 1 : 0;
+done:
+    free(w);
+    return rc;
+}

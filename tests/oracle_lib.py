@@ -101,6 +101,7 @@ def lib():
         L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
+        L.orc_ensdlp_verify.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_dlp_ct_bytes.restype = C.c_size_t
         L.orc_dlp_ct_bytes.argtypes = [i32p]
         L.orc_dlp_encrypt.argtypes = [i32p, i32p, u8p, C.c_size_t, u8p, u32p, C.c_size_t, u8p]
@@ -422,6 +423,13 @@ def dlp_extract(par, tree, ident, tape):
     tp = _tape(tape)
     rc = lib().orc_dlp_extract(par, np.ascontiguousarray(tree, dtype=np.float64), i, il, tp, tp.size, sk)
     return rc, bytes(sk)
+
+
+def ensdlp_verify(par, h, msg, sig):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    m, ml = _msgbuf(msg)
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    return lib().orc_ensdlp_verify(par, np.ascontiguousarray(np.asarray(h), dtype=np.int16), m, ml, s, s.size)
 
 
 def dlp_encrypt(par, h_ntt, ident, msg, tape):
