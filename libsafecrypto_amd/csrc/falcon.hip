@@ -647,19 +647,19 @@ __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, con
 }
 
 // ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------
+// bits: field width (Falcon q_bits - 2; ENS / DLP signatures q_bits); centre == 0: the signed field is taken as it is (ens_dlp_sig.c:1617-1618)
 __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
-                                  uint32_t *__restrict__ verdict, FalP P)
+                                  uint32_t *__restrict__ verdict, FalP P, int bits, int centre)
 {
     // one lane per PAIR of coefficients; with the 12-bit coding of both parameter sets a pair is exactly three bytes
     const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int hn = P.n / 2;
     const uint32_t b = (uint32_t)(tt / hn); const int e = (int)(tt % hn) * 2;
     if (b >= batch) return;
-    const int bits = P.q_bits - 2;
     int32_t *o = s2 + (size_t)b * P.n + e;
     if ((size_t)siglens[b] * 8 < (size_t)P.n * bits) { if (e == 0) verdict[b] = 1; o[0] = o[1] = 0; return; }
     const uint8_t *s = sigs + (size_t)b * sig_stride;
-    if (bits == 12) {
+    if (bits == 12 && centre) {
         const uint8_t *p = s + (e / 2) * 3;
         const uint32_t w = ((uint32_t)p[0] << 16) | ((uint32_t)p[1] << 8) | p[2];
         o[0] = centre_mod((int32_t)((w >> 12) << 20) >> 20, P.q);
@@ -669,7 +669,8 @@ __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ si
     for (int h = 0; h < 2; h++) {
         uint32_t val = 0;
         for (int k = 0; k < bits; k++) { const uint32_t bp = (uint32_t)(e + h) * bits + k; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
-        o[h] = centre_mod((int32_t)(val << (32 - bits)) >> (32 - bits), P.q);
+        const int32_t sv = (int32_t)(val << (32 - bits)) >> (32 - bits);
+        o[h] = centre ? centre_mod(sv, P.q) : sv;
     }
 }
 
@@ -965,7 +966,7 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P);
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
@@ -1001,6 +1002,34 @@ extern "C" int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *f, size_t batch, int ubit
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
     const size_t nt = batch * (size_t)(f->P.n / 8);
     hipLaunchKernelGGL(dlp_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, f->s2, status, d_sk, sk_stride, f->P.n, ubits);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_verify -> ens_dlp_sig_verify (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1564-1665, ENS and DLP signatures without message
+// recovery) for `batch` messages under one public key.  The handle is a Falcon-shaped one created with the scheme's parameters {n, q, q_bits,
+// n_bits, set, bd} (ens_dlp_sig_params.c:23-62; n = 512 / 1024) and loaded with h (sc_hip_falcon_set_pubkey: the first n SINT16 of the public key).
+// Same arithmetic as Falcon verification - s2 = centre(H(m) - h s1), single-precision norm from the top index down - with the signature's n fields
+// q_bits wide and uncentred, and the hash subtracting q when >= q (:728-742).  d_verdicts[i] = 0 valid / 1 invalid.
+extern "C" int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (fal_check_common(f, batch, "ens_dlp_sig_verify")) return SC_HIP_FAILURE;
+    if (!f->have_pk) return fail("ens_dlp_sig_verify: no public key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("ens_dlp_sig_verify: null buffer");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t B = (uint32_t)batch;
+    const size_t ne = batch * (size_t)f->P.n;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits, 0);
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
+    HIPCHK(hipGetLastError());
+    if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;          // the signature's s1 sits in the s2 buffer: the roles are swapped
+    hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

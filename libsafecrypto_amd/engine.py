@@ -31,7 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_dlp_ibe_extract', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
@@ -165,6 +165,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_ens_dlp_sig_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_dlp_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_dlp_destroy.argtypes = [vp]
@@ -953,6 +954,15 @@ class Falcon:
         a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
         assert a.size == self.n
         _chk(self.L, self.L.sc_hip_falcon_set_pubkey(self.h, _ptr(a)), 'falcon_set_pubkey')
+
+    def ens_dlp_verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        """ENS / DLP signature verification (the handle holds that scheme's parameters and public key)"""
+        import torch
+        batch = msgs.shape[0]
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_ens_dlp_sig_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                      _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'ens_dlp_sig_verify')
+        return verdicts
 
     def dlp_extract(self, ubits, ids, tapes, idlens=None, fixed_len=0, tape_lens=None):
         """DLP-IBE extract (the handle holds the DLP-IBE parameters and the master tree): ids uint8 [batch][stride], tapes [batch][>= 4n]
