@@ -241,6 +241,59 @@ def bliss_kyber_extra(eng, torch):
         out[f'rlwe_enc_{set_}'] = re
         del msgs, tapes, ct
         r.close()
+    # ENS-KEM set 0 and DLP-IBE set 0 (extract / encrypt / decrypt): the remaining NTT clients of SURVEY 8(f)3 that are served
+    import numpy as np
+    G = load_golden('ens_ref.txt')
+    k = eng.ens(G['ens0_params']); k.set_pubkey(G['ens0_h']); k.set_privkey(G['ens0_g'], G['ens0_inv_g'])
+    B = 65536
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, 1024), dtype=torch.int32, device='cuda', generator=g)
+    k.encaps(tapes); torch.cuda.synchronize()
+    te, td = [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); ct, keys, used, st = k.encaps(tapes); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); k2 = k.decaps(ct); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+    assert int((st == 1).sum()) == B and int((k2 == keys).all(dim=1).sum()) >= B - B // 1000
+    ek = {'workload': f'ENS-KEM set 0 (n=512, q=12289) encapsulation / decapsulation, batch {B}, one key pair, per-operation CSPRNG word tapes resident in HBM',
+          'encaps_ops_per_s': B / min(te), 'decaps_ops_per_s': B / min(td)}
+    if os.path.exists(drv):
+        try:
+            c = json.loads(subprocess.check_output([drv, 'bench_ens', '0', '2'], timeout=60, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            ek['cpu_reference'] = {'encaps_ops_per_s': c['encaps_per_sec'], 'decaps_ops_per_s': c['decaps_per_sec'], 'cores': 1, 'kind': 'reference',
+                                   'sample': '2 s of safecrypto_encapsulation + 1 s of safecrypto_decapsulation, set 0, one key pair, 1 thread'}
+        except Exception as e:
+            sys.stderr.write(f'ens cpu baseline failed: {e}\n')
+    out['ens_kem_0'] = ek
+    del tapes, ct
+    k.close()
+    G = load_golden('dlp_ref.txt')
+    par = np.asarray(G['dlp0_params'])
+    n, q, q_bits, n_bits, set_, ubits = (int(x) for x in par[:6])
+    f = eng.falcon(np.array([n, q, q_bits, n_bits, 0, 0, 0, 0], dtype=np.int32))
+    f.set_privkey(np.asarray(G['dlp0_tree'], dtype=np.int64).view(np.float64))
+    d = eng.dlp(par); d.set_pubkey(G['dlp0_h_ntt']); d.set_user_key(G['dlp0_uk_ntt2'])
+    ident = np.asarray(G['dlp0_id2'], dtype=np.uint8)
+    B = 65536
+    ids = torch.from_numpy(np.tile(ident, (B, 1))).cuda()
+    xt = torch.randint(-2**31, 2**31 - 1, (B, 4 * n), dtype=torch.int32, device='cuda', generator=g)
+    msgs = torch.randint(0, 256, (B, d.msg_bytes), dtype=torch.uint8, device='cuda', generator=g)
+    f.dlp_extract(ubits, ids, xt, fixed_len=len(ident)); d.encrypt(ids, msgs, xt, fixed_len=len(ident)); torch.cuda.synchronize()
+    tx, te, td = [], [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); sk, st = f.dlp_extract(ubits, ids, xt, fixed_len=len(ident)); torch.cuda.synchronize(); tx.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); ct, es = d.encrypt(ids, msgs, xt, fixed_len=len(ident)); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); mm = d.decrypt(ct); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+    assert int((st == 1).sum()) == B and int((mm != msgs).any(dim=1).sum()) < B // 10000
+    di = {'workload': f'DLP-IBE set 0 (n=512, q=4206593) extract (f64 tree sampler) / encrypt / decrypt, batch {B}, one master key, one identity, tapes resident in HBM',
+          'extract_ops_per_s': B / min(tx), 'encrypt_ops_per_s': B / min(te), 'decrypt_ops_per_s': B / min(td)}
+    if os.path.exists(drv):
+        try:
+            c = json.loads(subprocess.check_output([drv, 'bench_dlp', '0', '3'], timeout=120, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            di['cpu_reference'] = {'extract_ops_per_s': c['extract_per_sec'], 'encrypt_ops_per_s': c['encrypt_per_sec'], 'decrypt_ops_per_s': c['decrypt_per_sec'], 'cores': 1,
+                                   'kind': 'reference', 'sample': '3 s of safecrypto_ibe_extract + 1.5 s each of encrypt / decrypt, set 0, 1 thread'}
+        except Exception as e:
+            sys.stderr.write(f'dlp cpu baseline failed: {e}\n')
+    out['dlp_ibe_0'] = di
+    f.close(); d.close()
     return out
 
 
