@@ -193,6 +193,11 @@ int sc_hip_poly_mul_scalar(sc_hip_ctx_t *ctx, size_t len, const int32_t *d_in, i
 int sc_hip_poly_mod_negate(sc_hip_ctx_t *ctx, size_t len, int32_t q, const int32_t *d_in, int32_t *d_out, void *stream);
 int sc_hip_poly_add_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, int32_t *d_polys, const int32_t *d_scalars, void *stream);
 int sc_hip_poly_cmp_not_equal(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+/* replaces: utils_arith_poly_t uniform_32 = poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156; callers bliss_b.c:1174,1187, ens_kem.c:631,642,
+ * 817-818) for `batch` polynomials: h_c[j] coefficients of value +-(c_len - j), placed by one CSPRNG word per attempt (tape b = the prng_32 stream of
+ * the context the reference passes).  n: a power of two <= 1024.  d_used / d_status optional (words consumed; 1 done, 2 tape exhausted -> zeros). */
+int sc_hip_poly_uniform(sc_hip_ctx_t *ctx, size_t batch, int n, const uint16_t *h_c, int c_len, const uint32_t *d_tapes, size_t tape_stride,
+                        const uint32_t *d_tape_lens, int32_t *d_out, uint32_t *d_used, uint32_t *d_status, void *stream);
 /* replaces: utils_arith_vectors absmax_32 / scalar_32 (src/utils/arith/vectors.c:25-60) per polynomial: max |v_j| ; sum t_j u_j
  * (SINT32, wrapping) */
 int sc_hip_vec_absmax(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_v, int32_t *d_out, void *stream);

@@ -59,6 +59,36 @@ __global__ void add_scalar_kernel(int32_t *__restrict__ p, size_t batch, size_t 
     if (b < batch) p[b * n] = (int32_t)((uint32_t)p[b * n] + (uint32_t)scalars[b]);
 }
 
+// poly_32_uniform_rand (poly_32.c:132-156): c[j] coefficients of value +-(c_len - j), one CSPRNG word per placement attempt (bit 0: sign,
+// the bits above: position; an occupied position costs the word and is drawn again).  Serial by construction: one lane per polynomial,
+// the polynomial as a private byte column in LDS.  used[b]: words consumed; a tape that runs out leaves status 2 and a zero polynomial.
+struct UniC { int32_t c[16]; int c_len; };
+__global__ __launch_bounds__(64) void uniform_kernel(size_t batch, int n, UniC C, const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
+                                                     int32_t *__restrict__ out, uint32_t *__restrict__ used, uint32_t *__restrict__ status)
+{
+    extern __shared__ int8_t ucol[];                               // n * 64
+    const size_t b = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    const uint32_t *w = tapes + b * tape_stride;
+    const uint32_t len = tape_lens ? tape_lens[b] : (uint32_t)tape_stride;
+    int8_t *mine = ucol + threadIdx.x;
+    for (int k = 0; k < n; k++) mine[k * 64] = 0;
+    uint32_t p = 0;
+    bool ok = true;
+    for (int j = 0; j < C.c_len && ok; j++) {
+        int cnt = 0;
+        while (cnt < C.c[j]) {
+            if (p >= len) { ok = false; break; }
+            const uint32_t x = w[p++];
+            const uint32_t idx = (x >> 1) & (uint32_t)(n - 1);
+            if (mine[idx * 64] == 0) { mine[idx * 64] = (int8_t)((x & 1) ? j - C.c_len : C.c_len - j); cnt++; }
+        }
+    }
+    for (int k = 0; k < n; k++) out[b * (size_t)n + k] = ok ? (int32_t)mine[k * 64] : 0;
+    if (used) used[b] = p;
+    if (status) status[b] = ok ? 1u : 2u;
+}
+
 enum { RD_CMP = 0, RD_ABSMAX = 1, RD_SCALAR = 2 };
 
 // one wavefront per polynomial
@@ -225,6 +255,28 @@ extern "C" int sc_hip_vec_absmax(sc_hip_ctx_t *ctx, size_t batch, size_t n, cons
 { return run_reduce<RD_ABSMAX>(ctx, batch, n, d_v, nullptr, d_out, stream, "vec_absmax"); }
 extern "C" int sc_hip_vec_scalar(sc_hip_ctx_t *ctx, size_t batch, size_t n, const int32_t *d_t, const int32_t *d_u, int32_t *d_out, void *stream)
 { return run_reduce<RD_SCALAR>(ctx, batch, n, d_t, d_u, d_out, stream, "vec_scalar"); }
+
+// replaces: utils_arith_poly_t uniform_32 = poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) for `batch` polynomials, polynomial b fed by
+// tape b (the prng_32 word stream of the context the reference passes in).  h_c / c_len: the coefficient-count list (BLISS nz: 2 entries, ENS-KEM 12).
+extern "C" int sc_hip_poly_uniform(sc_hip_ctx_t *ctx, size_t batch, int n, const uint16_t *h_c, int c_len, const uint32_t *d_tapes, size_t tape_stride,
+                                   const uint32_t *d_tape_lens, int32_t *d_out, uint32_t *d_used, uint32_t *d_status, void *stream)
+{
+    if (!ctx) return fail("poly_uniform: null context");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_c || !d_tapes || !d_out) return fail("poly_uniform: null buffer");
+    if (n < 2 || n > 1024 || (n & (n - 1))) return fail("poly_uniform: n must be a power of two up to 1024 (the index is masked with n - 1)");
+    if (c_len < 1 || c_len > 16) return fail("poly_uniform: 1..16 coefficient classes");
+    UniC C = {};
+    C.c_len = c_len;
+    size_t total = 0;
+    for (int j = 0; j < c_len; j++) { C.c[j] = h_c[j]; total += h_c[j]; }
+    if (total > (size_t)n) return fail("poly_uniform: more non-zero coefficients than positions (the reference would not return)");
+    HIPCHK(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(uniform_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), (size_t)n * 64, (hipStream_t)stream, batch, n, C, d_tapes, tape_stride, d_tape_lens,
+                       d_out, d_used, d_status);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
 
 // ---- host-buffer variants (H2D, kernel, D2H; synchronous) used by the reference-shaped vtable --------------------------------
 

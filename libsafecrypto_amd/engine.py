@@ -31,7 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
@@ -165,6 +165,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_poly_uniform.argtypes = [vp, sz, C.c_int, vp, C.c_int, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_ens_dlp_sig_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_dlp_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -272,6 +273,18 @@ class Engine:
 
     def rlwe(self, params):
         return Rlwe(self, params)
+
+    def poly_uniform(self, n, c, tapes, tape_lens=None):
+        """utils_arith_poly_t uniform_32 for a batch: tapes [batch][words] (device) -> polynomials int32 [batch][n], words used, status"""
+        import numpy as np, torch
+        cc = np.ascontiguousarray(np.asarray(c), dtype=np.uint16)
+        batch, dev = tapes.shape[0], tapes.device
+        out = torch.zeros((batch, n), dtype=torch.int32, device=dev)
+        used = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        _chk(self.L, self.L.sc_hip_poly_uniform(self.h, batch, n, _ptr(cc), cc.size, _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else C.c_void_p(),
+                                                _ptr(out), _ptr(used), _ptr(status), _stream()), 'poly_uniform')
+        return out, used, status
 
     def ens(self, params):
         return Ens(self, params)

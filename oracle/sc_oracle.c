@@ -331,3 +331,21 @@ void orc_batch_polymul_ntt(int32_t *out, const int32_t *a, const int32_t *bhat, 
     }
     free(fa);
 }
+
+/* poly_32.c:132-156 on a word tape: returns 0 and the words consumed, 2 when the tape runs out */
+int orc_poly_uniform(int32_t *v, int n, const uint16_t *c, int c_len, const uint32_t *tape, size_t tape_len, size_t *consumed)
+{
+    size_t pos = 0;
+    for (int i = 0; i < n; i++) v[i] = 0;
+    for (int j = 0; j < c_len; j++) {
+        int i = 0;
+        while (i < c[j]) {
+            if (pos >= tape_len) { *consumed = pos; return 2; }
+            const uint32_t r = tape[pos++];
+            const uint32_t idx = (r >> 1) & (uint32_t)(n - 1);
+            if (v[idx] == 0) { v[idx] = (r & 1) ? j - c_len : c_len - j; i++; }
+        }
+    }
+    *consumed = pos;
+    return 0;
+}

@@ -101,6 +101,7 @@ def lib():
         L.orc_rlwe_keygen.argtypes = [i32p, u64p, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p]
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
+        L.orc_poly_uniform.argtypes = [i32p, C.c_int, np.ctypeslib.ndpointer(dtype=np.uint16, flags='C_CONTIGUOUS'), C.c_int, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.orc_ensdlp_verify.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_dlp_ct_bytes.restype = C.c_size_t
         L.orc_dlp_ct_bytes.argtypes = [i32p]
@@ -423,6 +424,15 @@ def dlp_extract(par, tree, ident, tape):
     tp = _tape(tape)
     rc = lib().orc_dlp_extract(par, np.ascontiguousarray(tree, dtype=np.float64), i, il, tp, tp.size, sk)
     return rc, bytes(sk)
+
+
+def poly_uniform(n, c, tape):
+    v = np.zeros(n, dtype=np.int32)
+    cc = np.ascontiguousarray(np.asarray(c), dtype=np.uint16)
+    used = C.c_size_t(0)
+    tp = _tape(tape)
+    rc = lib().orc_poly_uniform(v, n, cc, cc.size, tp, tp.size, C.byref(used))
+    return rc, v, used.value
 
 
 def ensdlp_verify(par, h, msg, sig):

@@ -117,3 +117,25 @@ def test_batches_vs_oracle(eng):
     buf = torch.zeros(1004, dtype=torch.int32, device='cuda'); buf[:1003] = dev(flat)
     assert np.array_equal(eng.poly_mul_scalar(buf[:1003], 77777).cpu().numpy(), o)
     plan.close()
+
+
+@pytest.mark.parametrize('n,c', [(512, [0, 154]), (256, [38, 140]), (512, [1, 1, 3, 5, 8, 12, 17, 24, 31, 38, 44, 47]), (1024, [0, 0, 0, 0, 1, 3, 9, 22, 46, 80, 118, 150])])
+def test_poly_uniform_matches_oracle(eng, n, c):
+    """utils_arith_poly_t uniform_32 (poly_32_uniform_rand) with the coefficient lists of BLISS-B and ENS-KEM: polynomial, words consumed, underrun"""
+    import torch
+    rng = np.random.default_rng(n + len(c))
+    B, W = 130, 2 * sum(c) + 40
+    tapes = rng.integers(0, 2**32, size=(B, W), dtype=np.uint64).astype(np.uint32)
+    lens = np.full(B, W, dtype=np.int32)
+    lens[5] = sum(c) // 2                                        # cannot finish
+    out, used, st = eng.poly_uniform(n, c, torch.from_numpy(tapes.view(np.int32)).cuda(), torch.from_numpy(lens).cuda())
+    torch.cuda.synchronize()
+    on, un, sn = out.cpu().numpy(), used.cpu().numpy(), st.cpu().numpy()
+    for i in range(B):
+        rc, v, u = O.poly_uniform(n, c, tapes[i, :lens[i]])
+        assert (rc, int(sn[i])) in ((0, 1), (2, 2)) and un[i] == u, i
+        assert np.array_equal(on[i], v if rc == 0 else np.zeros(n, dtype=np.int32)), i
+    assert sn[5] == 2
+    k = len(c)
+    for j, cnt in enumerate(c):                                   # the value histogram is the list itself
+        assert int((np.abs(on[0]) == k - j).sum()) == cnt
