@@ -392,6 +392,7 @@ struct sc_hip_dilithium {
     DilP P;
     bool have_priv, have_pub;
     uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
+    uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
     size_t cap;
@@ -471,7 +472,7 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
 {
     if (!d) return;
     free_ws(d);
-    void *ptrs[] = { d->d_A, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
+    void *ptrs[] = { d->d_A, d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     sc_hip_plan_destroy(d->plan);
     delete d;
@@ -502,6 +503,10 @@ static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
     if (!d->d_A) HIPCHK(hipMalloc((void **)&d->d_A, bytes));
     HIPCHK(hipMemcpy(tmp, h_Ahat, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, nullptr, tmp, d->d_A, np, d->plan->k[1], d->plan->r2, d->plan->r2p);
+    if (d->P.l >= 2 && d->P.l <= 5) {
+        if (!d->d_As) HIPCHK(hipMalloc((void **)&d->d_As, 2 * bytes));
+        hipLaunchKernelGGL(dil_to_internal_shoup, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, nullptr, tmp, d->d_As, d->d_As + np * N, np, d->plan->k[1]);
+    }
     return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
 }
 
@@ -637,9 +642,15 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
         HIPCHK(hipGetLastError());
         DilNtt a = base_args(d);
         a.in = d->y; a.out_int = d->yh;
-        if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-        a.key = d->d_A;
-        if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        if (d->d_As && !getenv("SC_HIP_DIL_UNFUSED")) {             // w = A y with NTT(y) kept in registers
+            a.key = d->d_As; a.keyp = d->d_As + (size_t)k * l * N;
+            if (mlwe_launch_yaw(d->ctx, a, nslots, s)) return SC_HIP_FAILURE;
+            a.keyp = nullptr;
+        } else {
+            if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
+            a.key = d->d_A;
+            if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        }
         hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, nslots, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
         a.in = d->c; a.out_int = d->ch;
@@ -691,9 +702,15 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
     a.in = d->z; a.out_int = d->yh;
-    if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
-    a.key = d->d_A;
-    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    if (d->d_As && !getenv("SC_HIP_DIL_UNFUSED")) {
+        a.key = d->d_As; a.keyp = d->d_As + (size_t)k * l * N;
+        if (mlwe_launch_yaw(d->ctx, a, B, s)) return SC_HIP_FAILURE;
+        a.keyp = nullptr;
+    } else {
+        if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
+        a.key = d->d_A;
+        if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    }
     a.in = d->c; a.out_int = d->ch;
     if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
     a.key = d->d_t1s;

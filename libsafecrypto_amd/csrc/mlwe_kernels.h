@@ -62,6 +62,7 @@ struct DilNtt {
     uint32_t *out_int;                    // DOP_FWD_INT / KEYPREP: internal-order canonical (KEYPREP: Montgomery form)
     const uint32_t *yh;                   // [item][l][n] internal
     const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
+    const uint32_t *keyp;                 // dil_yaw_kernel only: Shoup companions floor(key 2^32 / q) of a PLAIN (non-Montgomery) matrix
     size_t key_item_stride;               // words between the matrices of consecutive items (0: one matrix for the whole batch)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
     const int32_t *y;                     // [item][l][n] natural (mask)
@@ -225,6 +226,88 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
     }
 }
 
+// w = A y for one attempt per 16-lane group, NTT(y) never leaving the registers: the LL forward transforms of y, then for each of the kk rows
+// the LL products with the (constant, L2-resident) matrix row, one inverse transform and the MATVEC epilogue (w, high_order_bits).
+// Replaces the pair <FWD_INT> + <MATVEC> where the matrix is the same for the whole batch: that pair writes NTT(y) to HBM and reads it back
+// kk times (the product kernel runs at the L2 bandwidth of those re-reads); here the four attempts of a wavefront also share every matrix load.
+// The matrix is in PLAIN form with Shoup companions (4-instruction products, terms in [0, 2q) summed without reduction: LL <= 5 terms stay
+// below 2^27), which the separate kernels could not afford (it doubles the matrix traffic they are bound by).
+template <int LL>
+__global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pw = lane / LP, lp = lane % LP;
+    uint32_t *lds_poly = lds + wid * 1024 + pw * N;
+    const ModK k = a.k;
+    TwSet<L8> twi;
+    twi.load(a.zi, a.zip, lp);
+    const uint32_t groups = (a.njobs + PW - 1) / PW;              // njobs = attempts
+    for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
+        const uint32_t slot = g * PW + pw;
+        const bool valid = slot < a.njobs;
+        const uint32_t s = valid ? slot : 0;                        // unconditional loads: an attempt past the end reads attempt 0, stores nothing
+        uint32_t yh[LL][16];
+        // the forward twiddles are (re)loaded per attempt group (L1/L2 hits) and die before the row loop: 30 registers the LL * 16 words of NTT(y)
+        // need more; the opaque copy of the pointer keeps the compiler from hoisting the loads out of the persistent loop
+        const uint32_t *zf = a.zf, *zfp = a.zfp;
+        asm volatile("" : "+s"(zf), "+s"(zfp));
+        TwSet<L8> twf;
+        twf.load(zf, zfp, lp);
+#pragma unroll
+        for (int j = 0; j < LL; j++) {
+            const int32_t *src = a.in + ((size_t)s * LL + j) * N + lp;
+            uint32_t x[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = reduce_i32(src[r * LP], k);
+            fwd_core<L8, MODE_U32, true>(x, twf, lds_poly, lp, k);
+#pragma unroll
+            for (int r = 0; r < 16; r++) yh[j][r] = csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+        }
+        for (int i = 0; i < a.kk; i++) {
+            uint32_t x[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = 0;
+#pragma unroll
+            for (int j = 0; j < LL; j++) {
+                const size_t ko = ((size_t)i * LL + j) * N + lp * 16;
+                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + ko), *pp = reinterpret_cast<const uint4 *>(a.keyp + ko);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint4 va = pa[c], vp = pp[c];
+                    x[4 * c + 0] += Mod<MODE_U32>::mulc(yh[j][4 * c + 0], va.x, vp.x, k);
+                    x[4 * c + 1] += Mod<MODE_U32>::mulc(yh[j][4 * c + 1], va.y, vp.y, k);
+                    x[4 * c + 2] += Mod<MODE_U32>::mulc(yh[j][4 * c + 2], va.z, vp.z, k);
+                    x[4 * c + 3] += Mod<MODE_U32>::mulc(yh[j][4 * c + 3], va.w, vp.w, k);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k);
+            inv_core<L8, MODE_U32>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
+            if (!valid) continue;
+            const size_t off = ((size_t)slot * a.kk + i) * N + lp;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                int32_t a0;
+                a.w[off + r * LP] = (int32_t)x[r];
+                if (a.w1) a.w1[off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
+            }
+        }
+    }
+}
+
+// the constant matrix for dil_yaw_kernel: natural-order NTT-domain input -> internal order, plain canonical values + Shoup companions
+static __global__ void dil_to_internal_shoup(const int32_t *in, uint32_t *out, uint32_t *outp, size_t npoly, ModK k)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoly * N) return;
+    const size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
+    const uint32_t nat = __builtin_bitreverse32(j) >> 24;
+    const uint32_t v = csub(reduce_i32(in[p * N + nat], k), k.q);
+    out[i] = v;
+    outp[i] = (uint32_t)(((uint64_t)v << 32) / k.q);
+}
+
 // natural-order NTT-domain array -> internal order, Montgomery form (for the expanded matrix A)
 // rows/cols != 0: the input is [cols][rows][n] and is transposed on the way (out is always [rows][cols][n])
 static __global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p, int rows = 0, int cols = 0)
@@ -263,6 +346,25 @@ static int mlwe_launch(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, int per, hipS
     const size_t cap = (size_t)ctx->cus * 8;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((dil_ntt_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// fused NTT(y) -> A NTT(y) -> INTT for `nitems` attempts (l = 2..5); returns SC_HIP_FAILURE for other l (the caller falls back to the pair)
+static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream_t s)
+{
+    a.njobs = nitems; a.per = 1;
+    if (nitems == 0) return SC_HIP_SUCCESS;
+    size_t blocks = ((size_t)nitems + 15) / 16;
+    const size_t cap = (size_t)ctx->cus * 4;
+    if (blocks > cap) blocks = cap;
+    switch (a.l) {
+    case 2: hipLaunchKernelGGL((dil_yaw_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((dil_yaw_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 4: hipLaunchKernelGGL((dil_yaw_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((dil_yaw_kernel<5>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    default: return SC_HIP_FAILURE;
+    }
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
