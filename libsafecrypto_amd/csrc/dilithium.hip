@@ -656,13 +656,8 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
         a.in = d->c; a.out_int = d->ch;
         if (launch_dil<DOP_FWD_INT>(d, a, nslots, 1, s)) return SC_HIP_FAILURE;
         a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-        if (!getenv("SC_HIP_DIL_UNFUSED")) {
-            a.key = d->d_s2; a.key2 = d->d_t0;
-            if (launch_dil<DOP_CS2T0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        } else {
-            a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-            a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        }
+        a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
         hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
                            d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
         HIPCHK(hipGetLastError());

@@ -47,7 +47,7 @@ __device__ __forceinline__ bool norm_bad(uint32_t v, uint32_t q, uint32_t b)
 // NTT-shaped kernels (n = 256: 16 lanes per polynomial, 4 polynomials per wave, 32-bit Shoup path)
 // ------------------------------------------------------------------------------------------------
 
-enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CZ = 2, DOP_CS2 = 3, DOP_CT0 = 4, DOP_CT1 = 5, DOP_KEYPREP = 6, DOP_CS2T0 = 7 };
+enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CZ = 2, DOP_CS2 = 3, DOP_CT0 = 4, DOP_CT1 = 5, DOP_KEYPREP = 6 };
 
 struct DilNtt {
     const uint32_t *zf, *zfp, *zi, *zip;
@@ -62,7 +62,6 @@ struct DilNtt {
     uint32_t *out_int;                    // DOP_FWD_INT / KEYPREP: internal-order canonical (KEYPREP: Montgomery form)
     const uint32_t *yh;                   // [item][l][n] internal
     const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
-    const uint32_t *key2;                 // DOP_CS2T0: the second key vector (t0), same form as key
     const uint32_t *keyp;                 // dil_yaw_kernel only: Shoup companions floor(key 2^32 / q) of a PLAIN (non-Montgomery) matrix
     size_t key_item_stride;               // words between the matrices of consecutive items (0: one matrix for the whole batch)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
@@ -92,12 +91,10 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
         bool valid = job < a.njobs;
         // signing: an attempt an earlier test already rejected needs no further work (its r / hint arrays are never read: the
         // finish kernel only looks at slots whose flags stayed 0).  The wave skips the group when none of its four jobs is live.
-        uint32_t fl0 = 0;
-        if (OP == DOP_CS2 || OP == DOP_CT0 || OP == DOP_CS2T0) {
+        if (OP == DOP_CS2 || OP == DOP_CT0) {
             const uint32_t fl = a.flags[valid ? job / (uint32_t)a.per : 0];
-            valid = valid && (OP == DOP_CT0 ? fl == 0 : (fl & 1u) == 0);
+            valid = valid && (OP == DOP_CS2 ? (fl & 1u) == 0 : fl == 0);
             if (__ballot(valid) == 0) continue;
-            fl0 = fl;
         }
         // a job past the end is pointed at job 0 and its results are never stored: every load below stays unconditional (a
         // predicated load compiles to a branch with a full s_waitcnt inside, which serialises the requests)
@@ -158,7 +155,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             if (OP == DOP_CZ) pre[r] = a.y[pl_off + r * LP];
-            if (OP == DOP_CS2 || OP == DOP_CT1 || OP == DOP_CS2T0) pre[r] = a.w[pk_off + r * LP];
+            if (OP == DOP_CS2 || OP == DOP_CT1) pre[r] = a.w[pk_off + r * LP];
             if (OP == DOP_CT0) pre[r] = a.r[pk_off + r * LP];
             if (OP == DOP_CT1) preh[r] = a.h[pk_off + r * LP];
         }
@@ -195,49 +192,6 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
                 bad |= norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
             }
             if (bad) atomicOr(&a.flags[item], 2u);
-        } else if (OP == DOP_CS2T0) {
-            // r = w - c s2 with its test, then - for rows of attempts that are still alive - c t0, its test and the hints, r never leaving the
-            // registers (the separate <CS2>, <CT0> kernels write r to HBM and read it back)
-            bool bad = false;
-            uint32_t rr[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                rr[r] = csub((uint32_t)pre[r] + k.q - x[r], k.q);
-                int32_t a0;
-                round_alpha(rr[r], a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + (int32_t)k.q) : (uint32_t)a0;       // low_order_bits
-                bad |= norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
-            }
-            if (bad) atomicOr(&a.flags[item], 2u);
-            const bool live2 = !bad && (fl0 & ~1u) == 0;             // (valid holds here) other rows may have failed meanwhile: an optimisation, not a requirement
-            if (__ballot(live2) == 0) continue;
-            {
-                const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)item * N + lp * 16);
-                const uint4 *pk = reinterpret_cast<const uint4 *>(a.key2 + (size_t)sub * N + lp * 16);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint4 vc = pc[c], vk = pk[c];
-                    x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
-                    x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
-                }
-            }
-            inv_core<L8, MODE_U32>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-            if (!live2) continue;
-            bool bad2 = false;
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                bad2 |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta);
-                const uint32_t s = csub(rr[r] + x[r], k.q);      // wcs2 + ct0 (dilithium.c:1714-1715)
-                int32_t a0;
-                const uint32_t hi_s = round_alpha(s, a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t hi_r = round_alpha(rr[r], a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t hb = hi_s != hi_r;
-                a.h[pk_off + r * LP] = (uint8_t)hb;
-                cnt += hb;
-            }
-            if (bad2) atomicOr(&a.flags[item], 4u);
-            if (cnt) atomicAdd(&a.ones[item], cnt);
         } else if (OP == DOP_CT0) {           // ct0 ; ||ct0||inf < gamma2 - beta ; hint = [HighBits(r + ct0) != HighBits(r)]
             bool bad = false;
             uint32_t cnt = 0;
