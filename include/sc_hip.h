@@ -89,6 +89,10 @@ int sc_hip_polymul_ntt(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, co
 /* fused product of two coefficient-domain polynomials: out = a*b mod (x^n+1, q), canonical
  * (fwd, fwd, mul_32_pointwise, inv: ring_tesla.c:752-910 pattern). */
 int sc_hip_polymul(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
+/* `steps` back-to-back sc_hip_polymul_ntt calls on the same buffers as ONE HIP graph launch (captured on first use for these arguments, cached in
+ * the plan, replayed afterwards); `stream` must not be the null stream.  Falls back to the plain loop if the capture is refused.  For launch-bound
+ * loops: at ~37 us per kernel the host cost of a plain call is ~5 % of the wall time. */
+int sc_hip_polymul_ntt_steps(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, int steps, void *stream);
 
 /* replaces: normalize_32 / center_32 (ntt_template.c.in:1777-1901), in place allowed */
 int sc_hip_normalize(sc_hip_plan_t *plan, size_t len, const int32_t *d_in, int32_t *d_out, void *stream);

@@ -76,6 +76,8 @@ struct sc_hip_plan {
     uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
     uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order
     size_t mv_cap;
+    void *g_exec;                 // sc_hip_polymul_ntt_steps: cached executable graph and what it was captured for
+    const int32_t *g_a, *g_b; int32_t *g_out; size_t g_batch; int g_steps;
 };
 
 namespace sc {

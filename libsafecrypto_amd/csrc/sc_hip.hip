@@ -321,6 +321,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
     p->mv_ws = nullptr; p->mv_cap = 0; p->d_tab_s = nullptr;
+    p->g_exec = nullptr; p->g_a = p->g_b = nullptr; p->g_out = nullptr; p->g_batch = 0; p->g_steps = 0;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
     p->w[0] = 1;
@@ -401,6 +402,7 @@ extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
     if (!p) return;
     for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)hipFree(p->d_tab[i]);
     if (p->d_tab_s) (void)hipFree(p->d_tab_s);
+    if (p->g_exec) (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec);
     if (p->mv_ws) (void)hipFree(p->mv_ws);
     delete p;
 }
@@ -712,6 +714,43 @@ extern "C" int sc_hip_normalize_host(sc_hip_plan_t *p, size_t len, const int32_t
 { return host_ew(p, EW_NORMALIZE, len, h_in, nullptr, h_out); }
 extern "C" int sc_hip_center_host(sc_hip_plan_t *p, size_t len, const int32_t *h_in, int32_t *h_out)
 { return host_ew(p, EW_CENTER, len, h_in, nullptr, h_out); }
+
+// ---- a launch-bound loop as one HIP graph ------------------------------------------------------
+
+// `steps` back-to-back fused products (the same call as sc_hip_polymul_ntt, on the same buffers) captured once into a HIP graph and replayed:
+// at 37 us per kernel the per-launch host cost of a loop of plain calls is ~5 % of the wall time.  The executable graph is cached in the plan for
+// the (buffers, batch, steps) it was captured with.  `stream` must be a real stream (stream capture does not work on the null stream); if anything
+// in the capture fails the plain loop runs instead - same result either way.
+extern "C" int sc_hip_polymul_ntt_steps(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, int steps, void *stream)
+{
+    if (!p) return fail("polymul_ntt_steps: null plan");
+    if (steps <= 0) return SC_HIP_SUCCESS;
+    HIPCHK(hipSetDevice(p->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const bool same = p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps;
+    if (s && !same) {
+        if (p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }
+        if (run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;      // first-use initialisation outside the capture
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            int rc = SC_HIP_SUCCESS;
+            for (int i = 0; i < steps && rc == SC_HIP_SUCCESS; i++) rc = run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream);
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            hipGraphExec_t exec = nullptr;
+            if (rc == SC_HIP_SUCCESS && e == hipSuccess && graph && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                p->g_exec = exec; p->g_a = d_a; p->g_b = d_bhat; p->g_out = d_out; p->g_batch = batch; p->g_steps = steps;
+            }
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        (void)hipGetLastError();
+    }
+    if (s && p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps) {
+        if (hipGraphLaunch((hipGraphExec_t)p->g_exec, s) == hipSuccess) return SC_HIP_SUCCESS;
+        (void)hipGetLastError();
+    }
+    for (int i = 0; i < steps; i++) if (run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    return SC_HIP_SUCCESS;
+}
 
 // ---- timing --------------------------------------------------------------------------------
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
@@ -165,6 +165,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_polymul_ntt_steps.argtypes = [vp, sz, vp, vp, vp, C.c_int, vp]
     L.sc_hip_poly_uniform.argtypes = [vp, sz, C.c_int, vp, C.c_int, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_ens_dlp_sig_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
@@ -434,6 +435,11 @@ class NttPlan:
     def polymul_ntt(self, a, bhat, out=None):
         out = self._out(a, out)
         _chk(self.L, self.L.sc_hip_polymul_ntt(self.h, self._batch(a), _ptr(a), _ptr(bhat), _ptr(out), _stream()), 'polymul_ntt')
+        return out
+
+    def polymul_ntt_steps(self, a, bhat, out, steps):
+        """`steps` fused products on the same buffers as one HIP graph launch on torch's current (non-default) stream"""
+        _chk(self.L, self.L.sc_hip_polymul_ntt_steps(self.h, self._batch(a), _ptr(a), _ptr(bhat), _ptr(out), int(steps), _stream()), 'polymul_ntt_steps')
         return out
 
     def polymul(self, a, b, out=None):
