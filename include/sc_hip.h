@@ -458,6 +458,24 @@ int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *h, size_t batch, int ubits, const ui
 int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                               const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* ---- ENS / DLP signing -------------------------------------------------------------------------------------------------------------------
+ * replaces: safecrypto_sign -> ens_dlp_sig_sign (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315; ENS and DLP signatures without message recovery)
+ * for a batch of messages under one private key.  The signer is Klein's sampler (gaussian_lattice_sample_flt, src/utils/arith/gpv.c:2409-2492) over
+ * the expanded basis and its single-precision Gram-Schmidt orthogonalisation, which the reference context already holds
+ * (sc->ens_dlp_sig->b / b_gs / b_gs_inv_norm, built by create_gpv_matrices, ens_dlp_sig.c:364-421) and hands over at key load.
+ * params = the scheme's {n, q, q_bits, n_bits, set, bd} (ens_dlp_sig_params.c:23-62; n = 256 / 512 / 1024; bd unused by the signer). */
+typedef struct sc_hip_ens_dlp_signer sc_hip_ens_dlp_signer_t;
+int  sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_ens_dlp_signer_t **h);
+void sc_hip_ens_dlp_signer_destroy(sc_hip_ens_dlp_signer_t *h);
+/* host pointers: b SINT32 [2n][2n], b_gs FLOAT [2n][2n], b_gs_inv_norm FLOAT [2n] */
+int  sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const int32_t *b, const float *b_gs, const float *b_gs_inv_norm);
+size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h);        /* n * q_bits / 8 */
+size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h);   /* 4n: one prng_64 per basis row */
+/* d_tapes row i: the prng_32 word stream of sc->prng_ctx[0] during signature i (8-byte aligned rows, tape_stride even and >= 4n);
+ * d_status[i]: 1 signed, 2 tape shorter than 4n words, 3 the sampler state left the 32-bit range (not reachable with a valid key) */
+int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                            const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_status, void *stream);
+
 /* KEM level, with the reference's build options (SHA3-512 with its own permutation, AES CTR-DRBG for oracle bytes and noise):
  * extra public-key material that only enters the G hash - t: the coefficient-domain vector as stored (first k*n words of
  * sc->pubkey->key, kyber_kem.c:636-650), rho: the 32-byte matrix seed */

@@ -742,6 +742,111 @@ __global__ void dlp_pack_kernel(uint32_t batch, const int32_t *__restrict__ v, u
     if (g == 0) status[i] = 1;
 }
 
+// ---- ENS / DLP signing: Klein's sampler over the expanded basis (gpv.c:2409-2492, gaussian_lattice_sample_flt, flags = 0) -------------------
+//
+// From the last basis row down:  d = <ci, b_gs[j]> / ||b_gs[j]||^2,  z = CDT_j(prng_64) + (SINT32)d,  ci -= z b[j].  The dot product is a
+// SEQUENTIAL single-precision sum over k = 0 .. 2n-1 of (FLOAT)ci[k] * b_gs[j][k] (dot_s64_flt, gpv.c:843-855) and single-precision addition does
+// not associate, so one lane owns one signature and walks k in order; what is parallel is the batch.  The update of row j and the dot product of
+// row j-1 are one sweep over ci (one read and one write of the 2n-word state per row).  ci is held as int32 [2n][B] (a wavefront reads 256
+// contiguous bytes per k); the reference's SINT64 is never needed for a valid key, and that is CHECKED: each lane carries a bound M >= max|ci|,
+// raised by |z| max|b| per row, recomputed exactly from the state when it nears 2^31, and a lane whose state really would leave int32 stops with
+// status 3 instead of wrapping.  Basis row, Gram-Schmidt row, 1/||.|| and the row's CDT are wave-uniform: scalar loads.
+struct KleinArgs {
+    uint32_t batch; uint32_t B;            // signatures, padded column count (a multiple of 64)
+    int n, n2;
+    const int32_t *__restrict__ c;         // [batch][n]: H(m)
+    const int32_t *__restrict__ b;         // [2n][2n]
+    const float *__restrict__ bgs;         // [2n][2n]
+    const float *__restrict__ inv;         // [2n]
+    const uint64_t *__restrict__ tabs;     // [2n] << ts_log
+    const uint32_t *__restrict__ sizes;    // [2n]
+    int ts_log;
+    uint32_t maxb;
+    const uint32_t *__restrict__ tapes; uint32_t tape_stride; const uint32_t *__restrict__ tape_lens;
+    int32_t *__restrict__ ci;              // [2n][B]
+    uint32_t *__restrict__ status;
+};
+
+constexpr int KU = 16;                     // sweep unroll: loads in flight per lane
+
+__global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
+{
+    const uint32_t col = blockIdx.x * 64 + threadIdx.x;
+    const bool valid = col < A.batch;
+    const uint32_t item = valid ? col : 0;                      // padding lanes rerun item 0 in their own columns and report nothing
+    const int n = A.n, n2 = A.n2;
+    const size_t B = A.B;
+    int32_t *__restrict__ ci = A.ci + col;
+    const uint32_t *tape = A.tapes + (size_t)item * A.tape_stride;
+    const bool short_tape = A.tape_lens && A.tape_lens[item] < 2u * (uint32_t)n2;
+
+    float dot = 0.f;
+    {
+        const int32_t *cr = A.c + (size_t)item * n;
+        const float *g = A.bgs + (size_t)(n2 - 1) * n2;
+        for (int k = 0; k < n; k++) { const int32_t v = cr[k]; ci[(size_t)k * B] = v; dot += (float)v * g[k]; }
+        for (int k = n; k < n2; k++) { ci[(size_t)k * B] = 0; dot += 0.f * g[k]; }
+    }
+    uint64_t M = 0x7fffffffu >> 1;                               // H(m) < 2^q_bits + q < 2^30
+    bool dead = false;
+    for (int j = n2 - 1; j >= 0; j--) {
+        const float inv = A.inv[j];
+        const float d = dot * inv * inv;
+        const uint2 w = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - j));
+        const uint64_t x = ((uint64_t)w.x << 32) | w.y;
+        const uint64_t *__restrict__ cdf = A.tabs + ((size_t)j << A.ts_log);
+        const int size = (int)A.sizes[j];
+        uint32_t a = 0;
+        for (int e = 1; e < size; e++) a += (cdf[e] < x) ? 1u : 0u;
+        int32_t z = ((x & 1) ? (int32_t)a : -(int32_t)a) + (int32_t)d;
+        const uint64_t az = (uint64_t)(z < 0 ? -(int64_t)z : (int64_t)z) * A.maxb;
+        bool risky = !dead && M + az > 0x7fffffffull;
+        if (__any(risky)) {                                      // rare: replace the running bound by the exact maximum
+            uint32_t m = 0;
+            for (int k = 0; k < n2; k++) { const int32_t v = ci[(size_t)k * B]; const uint32_t av = (uint32_t)(v < 0 ? -v : v); m = av > m ? av : m; }
+            if (risky) { M = m; if (M + az > 0x7fffffffull) dead = true; }
+        }
+        if (dead) z = 0;
+        M += dead ? 0 : az;
+        // read through a float lvalue so that the stores to ci (int) cannot alias it and the row stays on the scalar unit
+        const float *__restrict__ brow = reinterpret_cast<const float *>(A.b) + (size_t)j * n2;
+        const float *__restrict__ grow = A.bgs + (size_t)(j > 0 ? j - 1 : 0) * n2;
+        dot = 0.f;
+        for (int k = 0; k < n2; k += KU) {
+            int32_t v[KU];
+#pragma unroll
+            for (int u = 0; u < KU; u++) v[u] = ci[(size_t)(k + u) * B];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                v[u] -= z * __float_as_int(brow[k + u]);
+                ci[(size_t)(k + u) * B] = v[u];
+                dot += (float)v[u] * grow[k + u];
+            }
+        }
+    }
+    if (valid) A.status[col] = short_tape ? 2u : dead ? 3u : 1u;
+}
+
+// s1 = centre(ci[n, 2n)) (ens_dlp_sig.c:1273), n q_bits-bit two's complement fields, MSB first (entropy_poly_encode_32, SC_ENTROPY_NONE).
+// One thread per eight coefficients = q_bits bytes.  Signatures whose status is not 1 are zero-filled.
+__global__ void klein_pack_kernel(uint32_t batch, uint32_t B, const int32_t *__restrict__ ci, const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, size_t sig_stride,
+                                  int n, int q, int q_bits)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)(t / batch);                              // consecutive threads = consecutive signatures: coalesced reads of the state
+    const uint32_t i = (uint32_t)(t % batch);
+    if (g >= n / 8) return;
+    const bool ok = status[i] == 1;
+    uint8_t *o = sigs + (size_t)i * sig_stride + (size_t)g * q_bits;
+    uint64_t acc = 0; int nb = 0, w = 0;
+    const uint32_t mask = (1u << q_bits) - 1u;
+    for (int e = 0; e < 8; e++) {
+        const int32_t v = ok ? centre_mod(ci[(size_t)(n + 8 * g + e) * B + i], q) : 0;
+        acc = (acc << q_bits) | (uint64_t)((uint32_t)v & mask); nb += q_bits;
+        while (nb >= 8) { o[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
+    }
+}
+
 }  // namespace
 
 struct sc_hip_falcon {
@@ -787,7 +892,8 @@ extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_param
     static_assert(sizeof(FalP) == sizeof(sc_hip_falcon_params_t), "parameter struct layout");
     FalP P; memcpy(&P, params, sizeof P);
     if (P.set == 1) return fail("falcon_create: the ternary ring (set 1, x^n - x^(n/2) + 1) is not served");
-    if ((P.n != 512 && P.n != 1024) || (1 << P.n_bits) != P.n) return fail("falcon_create: n must be 512 or 1024 with n_bits = log2 n");
+    // n = 256 exists for the DLP signature set 0 verifier (ens_dlp_sig_params.c:45-53) and loads a public key only
+    if ((P.n != 256 && P.n != 512 && P.n != 1024) || (1 << P.n_bits) != P.n) return fail("falcon_create: n must be 256 (verify only), 512 or 1024 with n_bits = log2 n");
     if (P.q_bits < 4 || P.q_bits > 30 || P.q < 3 || P.q >= (1 << P.q_bits)) return fail("falcon_create: bad q / q_bits");
     sc_hip_plan *plan = nullptr;
     if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
@@ -829,6 +935,7 @@ static void leaf_sigmas(const double *tree, unsigned logn, std::vector<float> &o
 // b00 | b01 | b10 | b11 in FFT form, then the normalised LDL tree; (n_bits + 5) * n doubles
 extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk)
 {
+    if (f && f->P.n < 512) return fail("falcon_set_privkey: the tree sampler serves n = 512 and 1024");
     if (!f || !sk) return fail("falcon_set_privkey: null argument");
     HIPCHK(hipSetDevice(f->ctx->device));
     const size_t n = f->P.n, total = (size_t)(f->P.n_bits + 5) * n;
@@ -1030,6 +1137,120 @@ extern "C" int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *f, size_t batch, const
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;          // the signature's s1 sits in the s2 buffer: the roles are swapped
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+
+// ---- ENS / DLP signing ------------------------------------------------------------------------------------------------------------------
+struct sc_hip_ens_dlp_signer {
+    sc_hip_ctx *ctx;
+    FalP P;
+    bool have_key;
+    int32_t *d_b; float *d_bgs, *d_inv; uint64_t *d_tabs; uint32_t *d_sizes; int ts_log; uint32_t maxb;
+    sc::Workspace ws;
+};
+
+extern "C" int sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_ens_dlp_signer_t **out)
+{
+    if (!ctx || !params || !out) return fail("ens_dlp_signer_create: null argument");
+    FalP P; memcpy(&P, params, sizeof P);
+    if ((P.n != 256 && P.n != 512 && P.n != 1024) || (1 << P.n_bits) != P.n) return fail("ens_dlp_signer_create: n must be 256, 512 or 1024 with n_bits = log2 n");
+    if (P.q_bits < 4 || P.q_bits > 29 || P.q < 3 || P.q >= (1 << P.q_bits)) return fail("ens_dlp_signer_create: bad q / q_bits");
+    sc_hip_ens_dlp_signer *h = new sc_hip_ens_dlp_signer();
+    h->ctx = ctx; h->P = P;
+    *out = h;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" void sc_hip_ens_dlp_signer_destroy(sc_hip_ens_dlp_signer_t *h)
+{
+    if (!h) return;
+    void *ptrs[] = { h->d_b, h->d_bgs, h->d_inv, h->d_tabs, h->d_sizes };
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->ws.release();
+    delete h;
+}
+
+// b, b_gs, b_gs_inv_norm: what create_gpv_matrices (ens_dlp_sig.c:364-421) leaves in sc->ens_dlp_sig (keep_matrices = 1): the expanded basis
+// (SINT32 [2n][2n]), its single-precision Gram-Schmidt orthogonalisation (FLOAT [2n][2n]) and 1 / ||b_gs[j]|| (FLOAT [2n]); host pointers.
+// Builds the 2n per-row CDTs the reference recreates inside every signature (create_sampler per row, gpv.c:2445-2452; sigma_j = s_f / ||b_gs[j]||
+// with s_f = 2 / b_gs_inv_norm[0] rounded to FLOAT, ens_dlp_sig.c:1253; tail 10; long-double table as gaussian_cdf_create_64).
+extern "C" int sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const int32_t *b, const float *b_gs, const float *b_gs_inv_norm)
+{
+    if (!h || !b || !b_gs || !b_gs_inv_norm) return fail("ens_dlp_signer_set_key: null argument");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t n2 = 2 * (size_t)h->P.n;
+    const float sig0 = (float)(2.0L / (long double)b_gs_inv_norm[0]);
+    const double s_f = sig0;
+    std::vector<float> sg(n2);
+    std::vector<uint32_t> sizes(n2);
+    int ts_log = 1;
+    for (size_t j = 0; j < n2; j++) {
+        sg[j] = (float)(s_f * (double)b_gs_inv_norm[j]);
+        const int sz = sc_hip_cdt_table_size(10.0f, sg[j]);
+        if (sz < 2 || sz > 4096) return fail("ens_dlp_signer_set_key: a row's sampler table is out of range (degenerate Gram-Schmidt norms)");
+        sizes[j] = (uint32_t)sz;
+        while ((1 << ts_log) < sz) ts_log++;
+    }
+    std::vector<uint64_t> tabs(n2 << ts_log, ~0ull);
+    for (size_t j = 0; j < n2; j++)
+        if (sc_hip_cdt_build_table(10.0f, sg[j], &tabs[j << ts_log], (int)sizes[j]) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    uint32_t maxb = 1;
+    for (size_t i = 0; i < n2 * n2; i++) { const int64_t v = b[i]; const uint32_t a = (uint32_t)(v < 0 ? -v : v); maxb = a > maxb ? a : maxb; }
+    void *old[] = { h->d_b, h->d_bgs, h->d_inv, h->d_tabs, h->d_sizes };
+    for (void *p : old) if (p) (void)hipFree(p);
+    h->d_b = nullptr; h->d_bgs = h->d_inv = nullptr; h->d_tabs = nullptr; h->d_sizes = nullptr; h->have_key = false;
+    HIPCHK(hipMalloc((void **)&h->d_b, n2 * n2 * 4));
+    HIPCHK(hipMalloc((void **)&h->d_bgs, n2 * n2 * 4));
+    HIPCHK(hipMalloc((void **)&h->d_inv, n2 * 4));
+    HIPCHK(hipMalloc((void **)&h->d_tabs, tabs.size() * 8));
+    HIPCHK(hipMalloc((void **)&h->d_sizes, n2 * 4));
+    HIPCHK(hipMemcpy(h->d_b, b, n2 * n2 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_bgs, b_gs, n2 * n2 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_inv, b_gs_inv_norm, n2 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_sizes, sizes.data(), n2 * 4, hipMemcpyHostToDevice));
+    h->ts_log = ts_log; h->maxb = maxb; h->have_key = true;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h) { return h ? ((size_t)h->P.n * (size_t)h->P.q_bits + 7) / 8 : 0; }
+extern "C" size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h) { return h ? 4 * (size_t)h->P.n : 0; }
+
+// replaces: safecrypto_sign -> ens_dlp_sig_sign (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315, ENS and DLP signatures without message recovery)
+// for `batch` messages under one private key: t = H(m) (SHAKE128, :728-742), Klein's sampler (gaussian_lattice_sample_flt, gpv.c:2409-2492),
+// s1 = centre(ci[n, 2n)), n q_bits-bit signed fields.  d_tapes row i = the prng_32 word stream of sc->prng_ctx[0] during signature i: one prng_64
+// (two words, high word first) per basis row = 4n words; rows 8-byte aligned.  d_status: 1 signed, 2 tape too short, 3 the sampler state left 32 bits.
+extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_status, void *stream)
+{
+    if (!h) return fail("ens_dlp_sig_sign: null handle");
+    if (!h->have_key) return fail("ens_dlp_sig_sign: no key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffc0u) return fail("ens_dlp_sig_sign: batch too large");
+    if (!d_msgs || !d_tapes || !d_sigs || !d_status) return fail("ens_dlp_sig_sign: null buffer");
+    const size_t n = (size_t)h->P.n, n2 = 2 * n;
+    if (tape_stride < 2 * n2 || tape_stride > 0xffffffffu || (tape_stride & 1) != 0 || ((uintptr_t)d_tapes & 7) != 0)
+        return fail("ens_dlp_sig_sign: tapes must be 8-byte aligned rows of at least 4n words (even tape_stride)");
+    if (sig_stride < sc_hip_ens_dlp_sig_bytes(h)) return fail("ens_dlp_sig_sign: sig_stride too small");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t B = (batch + 63) & ~(size_t)63;
+    if (h->ws.reserve(B * n2 * 4 + batch * n * 4 + 1024)) return SC_HIP_FAILURE;
+    int32_t *ci = h->ws.take<int32_t>(B * n2);
+    int32_t *c = h->ws.take<int32_t>(batch * n);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = (uint32_t)batch;
+    if (batch <= (size_t)h->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
+    HIPCHK(hipGetLastError());
+    KleinArgs A;
+    A.batch = nb; A.B = (uint32_t)B; A.n = (int)n; A.n2 = (int)n2; A.c = c; A.b = h->d_b; A.bgs = h->d_bgs; A.inv = h->d_inv; A.tabs = h->d_tabs; A.sizes = h->d_sizes;
+    A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status;
+    hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
+    HIPCHK(hipGetLastError());
+    const size_t nt = batch * (n / 8);
+    hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

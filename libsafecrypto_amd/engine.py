@@ -31,7 +31,8 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key',
+    'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
@@ -168,6 +169,15 @@ def load_library(path=LIB_PATH):
     L.sc_hip_polymul_ntt_steps.argtypes = [vp, sz, vp, vp, vp, C.c_int, vp]
     L.sc_hip_poly_uniform.argtypes = [vp, sz, C.c_int, vp, C.c_int, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_ens_dlp_sig_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_ens_dlp_signer_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_ens_dlp_signer_destroy.argtypes = [vp]
+    L.sc_hip_ens_dlp_signer_destroy.restype = None
+    L.sc_hip_ens_dlp_signer_set_key.argtypes = [vp, vp, vp, vp]
+    L.sc_hip_ens_dlp_sig_bytes.argtypes = [vp]
+    L.sc_hip_ens_dlp_sig_bytes.restype = sz
+    L.sc_hip_ens_dlp_sig_tape_words.argtypes = [vp]
+    L.sc_hip_ens_dlp_sig_tape_words.restype = sz
+    L.sc_hip_ens_dlp_sig_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_dlp_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_dlp_destroy.argtypes = [vp]
@@ -289,6 +299,9 @@ class Engine:
 
     def ens(self, params):
         return Ens(self, params)
+
+    def ens_dlp_signer(self, params):
+        return EnsDlpSigner(self, params)
 
     def dlp(self, params):
         return Dlp(self, params)
@@ -938,6 +951,49 @@ class Rlwe:
         a, p, r2 = (torch.empty((batch, self.n), dtype=torch.int16, device=dev) for _ in range(3))
         _chk(self.L, self.L.sc_hip_rlwe_keygen(self.h, batch, _ptr(tapes), _rows(tapes), _ptr(a), _ptr(p), _ptr(r2), _stream()), 'rlwe_keygen')
         return a, p, r2
+
+
+class EnsDlpSigner:
+    """Batched ENS / DLP signing under one private key (ens_dlp_sig_sign counterpart): Klein's sampler over the expanded basis and its
+    single-precision Gram-Schmidt orthogonalisation.  params: the 8 words {n, q, q_bits, n_bits, set, f32 bd, 0, 0}."""
+
+    def __init__(self, eng, params):
+        import numpy as np
+        self.eng, self.L = eng, eng.L
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        assert self.par.size == 8
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ens_dlp_signer_create(eng.h, _ptr(self.par), C.byref(h)), 'sc_hip_ens_dlp_signer_create')
+        self.h = h
+        self.n = int(self.par[0])
+        self.sig_bytes = self.L.sc_hip_ens_dlp_sig_bytes(h)
+        self.tape_words = self.L.sc_hip_ens_dlp_sig_tape_words(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_ens_dlp_signer_destroy(self.h)
+            self.h = None
+
+    def set_key(self, b, b_gs, inv_norm):
+        """host arrays as the reference context holds them: b int32 [2n, 2n], b_gs float32 [2n, 2n], inv_norm float32 [2n]"""
+        import numpy as np
+        b = np.ascontiguousarray(np.asarray(b), dtype=np.int32)
+        g = np.ascontiguousarray(np.asarray(b_gs), dtype=np.float32)
+        v = np.ascontiguousarray(np.asarray(inv_norm), dtype=np.float32)
+        assert b.size == 4 * self.n * self.n and g.size == b.size and v.size == 2 * self.n
+        _chk(self.L, self.L.sc_hip_ens_dlp_signer_set_key(self.h, _ptr(b), _ptr(g), _ptr(v)), 'ens_dlp_signer_set_key')
+
+    def sign(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        """msgs uint8 [batch][stride], tapes int32/uint32 [batch][>= 4n] -> signatures uint8 [batch][n * q_bits / 8], status"""
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        sigs = torch.zeros((batch, self.sig_bytes), dtype=torch.uint8, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ens_dlp_sig_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                    _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
+                                                    _ptr(sigs), self.sig_bytes, _ptr(status), _stream()), 'ens_dlp_sig_sign')
+        return sigs, status
 
 
 class Falcon:

@@ -1010,14 +1010,41 @@ static int ensdlp_case(FILE *f, sc_scheme_e scheme, const char *tag, int set, co
     memcpy(&par[5], &bd, 4);
     snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
     snprintf(name, sizeof name, "%s_h", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    /* the signer's inputs (ens_dlp_sig_sign, ens_dlp_sig.c:1171-1315): f | g | F | G, and what create_gpv_matrices (:364-421) derived from them -
+     * all of b_gs_inv_norm and a strided sample of b and b_gs (4 n^2 entries each) as float / int bit patterns, to pin the restated expansion */
+    snprintf(name, sizeof name, "%s_fgFG", tag); rec_i32(f, name, (const int32_t *)sc->privkey->key, (size_t)4 * n);
+    snprintf(name, sizeof name, "%s_inv_norm", tag); rec_i32(f, name, (const int32_t *)sc->ens_dlp_sig->b_gs_inv_norm, (size_t)2 * n);
+    {
+        const size_t tot = (size_t)4 * n * n, cnt = (tot + 1020) / 1021;
+        int32_t *smp = malloc(sizeof(int32_t) * cnt * 2);
+        for (size_t i = 0, k = 0; i < tot; i += 1021, k++) {
+            smp[k] = sc->ens_dlp_sig->b[i];
+            memcpy(&smp[cnt + k], &((const float *)sc->ens_dlp_sig->b_gs)[i], 4);
+        }
+        snprintf(name, sizeof name, "%s_b_sample", tag); rec_i32(f, name, smp, cnt);
+        snprintf(name, sizeof name, "%s_bgs_sample", tag); rec_i32(f, name, smp + cnt, cnt);
+        free(smp);
+    }
     int32_t *verdicts = malloc(sizeof(int32_t) * nmsg * 3);
     sm_state = 0xe25d000ULL + set + (scheme == SC_SCHEME_SIG_DLP ? 64 : 0);
+    prng_ctx_t *orig = sc->prng_ctx[0];
     for (int m = 0; m < nmsg; m++) {
-        uint8_t msg[150];
+        uint8_t msg[150], seed[32];
         size_t mlen = (m == 0) ? 1 : (m == 1) ? 150 : 33;
         for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
         uint8_t *sig = NULL; size_t siglen = 0;
+        /* the Klein sampler draws one prng_64 per basis row from sc->prng_ctx[0] (gpv.c:2409-2492): tape technique */
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
         if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        free(tape);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
         snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
         snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
         verdicts[3 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
@@ -1042,6 +1069,7 @@ static int gen_ensdlp(const char *dir)
     if (!f) return 1;
     int rc = ensdlp_case(f, SC_SCHEME_SIG_ENS, "enssig0", 0, &param_ens_sig_0, 5);
     rc |= ensdlp_case(f, SC_SCHEME_SIG_DLP, "dlpsig1", 1, &param_dlp_sig_1, 4);
+    rc |= ensdlp_case(f, SC_SCHEME_SIG_DLP, "dlpsig0", 0, &param_dlp_sig_0, 4);
     fclose(f);
     return rc;
 }

@@ -495,3 +495,120 @@ done:
     free(w);
     return rc;
 }
+
+/* ---- ENS / DLP signing (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315, without message recovery) --------------------------------------
+ * The signer is Klein's sampler over the 2n x 2n basis B = [[A(g), -A(f)], [A(G), -A(F)]] and its SINGLE-precision Gram-Schmidt
+ * orthogonalisation (GSO_TYPE = FLOAT, ens_dlp_sig.h:26-37), both kept in the context by create_gpv_matrices (:364-421). */
+
+/* gpv_expand_basis + poly_limb_anticirculant (gpv.c:687-760): row i of A(p) is x^i p mod (x^n + 1).  The scratch matrix is allocated (zeroed) once
+ * and only the entries of coefficients up to deg(p) are written, so a polynomial whose top coefficients are zero leaves the PREVIOUS polynomial's
+ * entries standing there (order g, f, G, F) - restated as it behaves. */
+int orc_ensdlp_expand_basis(int n, const int32_t *fgFG, int32_t *b)
+{
+    const size_t N = (size_t)n, N2 = 2 * N;
+    int32_t *A = calloc(N * N, sizeof(int32_t));
+    const int32_t *polys[4] = { fgFG + N, fgFG, fgFG + 3 * N, fgFG + 2 * N };          /* g, f, G, F */
+    for (int m = 0; m < 4; m++) {
+        const int32_t *p = polys[m];
+        size_t deg = N - 1;
+        while (p[deg] == 0 && deg > 0) deg--;                                           /* poly_32_degree, poly_32.c:176-188 */
+        for (size_t i = 0; i < N; i++) {
+            for (size_t j = i; j <= deg + i && j < N; j++) A[i * N + j] = p[j - i];
+            for (size_t j = 0; j + N <= deg + i; j++) A[i * N + j] = -p[j + N - i];
+        }
+        const size_t r0 = (m >= 2) ? N : 0, c0 = (m & 1) ? N : 0;
+        for (size_t i = 0; i < N; i++)
+            for (size_t j = 0; j < N; j++) b[(r0 + i) * N2 + c0 + j] = (m & 1) ? -A[i * N + j] : A[i * N + j];
+    }
+    free(A);
+    return 0;
+}
+
+static float dotf(const float *a, const float *b, size_t n) { float d = 0; for (size_t k = 0; k < n; k++) d += a[k] * b[k]; return d; }
+
+/* modified_gram_schmidt_fast_flt (gpv.c:1021-1117) and gpv_precompute_inv_flt (:977-984): b_gs is 2n x 2n, inv_norm 2n */
+void orc_ensdlp_gso(int n, int q, const int32_t *fgFG, float *b_gs, float *inv_norm)
+{
+    const size_t N = (size_t)n, N2 = 2 * N;
+    const int32_t *f = fgFG, *g = fgFG + N;
+    float *v = malloc(sizeof(float) * 2 * N2), *v1 = v + N2;
+    float C_k, D_k;
+    for (size_t i = 0; i < N; i++) { b_gs[i] = (float)g[i]; b_gs[N + i] = (float)-f[i]; }
+    for (int half = 0; half < 2; half++) {
+        const size_t base = half ? N : 0;
+        if (half) {
+            const float D_k_inv = 1 / D_k;
+            for (size_t i = 0; i < N; i++) {
+                b_gs[N * N2 + N + i] = b_gs[(N - 1) * N2 + N - 1 - i] * (float)q * D_k_inv;
+                b_gs[N * N2 + i] = -b_gs[(N - 1) * N2 + N2 - 1 - i] * (float)q * D_k_inv;
+            }
+        }
+        const float *r0 = b_gs + base * N2;
+        for (size_t i = 0; i + 1 < N; i++) { v[i] = r0[i + 1]; v[N + i] = r0[i + N + 1]; }
+        v[N - 1] = -r0[0];
+        v[N2 - 1] = -r0[N];
+        memcpy(v1, v, sizeof(float) * N2);
+        C_k = dotf(r0, v1, N2);
+        D_k = half ? dotf(r0, r0, N2) : dotf(v, v, N2);
+        for (size_t i = base + 1; i < base + N; i++) {
+            const float aux = C_k / D_k;
+            float *ri = b_gs + i * N2;
+            const float *rp = ri - N2;
+            ri[0] = -rp[N - 1] + aux * v[N - 1];
+            ri[N] = -rp[N2 - 1] + aux * v[N2 - 1];
+            for (size_t j = 1; j < N; j++) {
+                ri[j] = rp[j - 1] - aux * v[j - 1];
+                ri[N + j] = rp[N + j - 1] - aux * v[N + j - 1];
+            }
+            for (size_t j = 0; j < N2; j++) v[j] -= aux * rp[j];
+            const float C_ko = C_k, D_ko = D_k;
+            C_k = dotf(ri, v1, N2);
+            D_k = D_ko - C_ko * C_ko / D_ko;
+        }
+    }
+    for (size_t j = 0; j < N2; j++) {
+        const double sqr = dotf(b_gs + j * N2, b_gs + j * N2, N2);
+        inv_norm[j] = (float)(1.0 / sqrt(sqr));
+    }
+    free(v);
+}
+
+/* gaussian_lattice_sample_flt (gpv.c:2409-2492) with flags = 0: from the last basis row down, d = <ci, b_gs[j]> / ||b_gs[j]||^2 (a
+ * sequential single-precision sum over SINT64 -> FLOAT conversions), a FRESH 64-bit CDT sampler of sigma_j = s_f / ||b_gs[j]|| (tail 10) per row,
+ * z = sample + (SINT32)d (truncation, not floor), ci -= z b[j].  Then s1 = centre(ci[n, 2n)), n q_bits-bit signed fields.
+ * tape = the prng_32 word stream of sc->prng_ctx[0] (one prng_64 per row: 4n words).  Returns 0, 2 if the tape is too short. */
+int orc_ensdlp_sign(const int32_t *par, const int32_t *b, const float *b_gs, const float *inv_norm, const uint8_t *msg, size_t mlen,
+                    const uint32_t *tape, size_t tape_len, uint8_t *sig)
+{
+    const int n = par[0], q = par[1], q_bits = par[2];
+    const size_t N = (size_t)n, N2 = 2 * N;
+    int32_t *c = malloc(sizeof(int32_t) * N);
+    int64_t *ci = malloc(sizeof(int64_t) * N2);
+    dlp_id(c, n, q, q_bits, msg, mlen);
+    for (size_t j = 0; j < N; j++) { ci[j] = c[j]; ci[N + j] = 0; }
+    const float sig0 = (float)(2.0L / inv_norm[0]);                                  /* ens_dlp_sig.c:1253 */
+    const double s_f = sig0;
+    ftape_t tp = { tape, tape_len, 0, 0 };
+    uint64_t cdf[4096];
+    for (size_t j = N2; j--;) {
+        const float *row = b_gs + j * N2;
+        float dot = 0;
+        for (size_t k = 0; k < N2; k++) dot += (float)ci[k] * row[k];
+        const float d = dot * inv_norm[j] * inv_norm[j];
+        const float sg = (float)(s_f * inv_norm[j]);
+        const int size = 1 << orc_cdt_bits(10.0f, sg);
+        if (size > 4096) { free(c); free(ci); return 1; }
+        orc_cdt_create(10.0f, sg, cdf, size);
+        const int64_t z = (int64_t)orc_cdt_sample(f64w(&tp), cdf, size) + (int32_t)d;
+        const int32_t *brow = b + j * N2;
+        for (size_t i = N2; i--;) ci[i] -= z * brow[i];
+    }
+    for (size_t j = 0; j < N; j++) c[j] = (int32_t)ci[N + j];
+    orc_center(c, N, q);
+    const size_t bytes = (N * (size_t)q_bits + 7) / 8;
+    memset(sig, 0, bytes);
+    size_t bp = 0;
+    for (size_t i = 0; i < N; i++) for (int bb = q_bits - 1; bb >= 0; bb--, bp++) sig[bp >> 3] |= (uint8_t)((((uint32_t)c[i] >> bb) & 1u) << (7 - (bp & 7)));
+    free(c); free(ci);
+    return tp.underrun ? 2 : 0;
+}

@@ -102,6 +102,11 @@ def lib():
         L.orc_rlwe_encrypt.argtypes = [i32p, u64p, C.c_int, i16p, i16p, u8p, u32p, C.c_size_t, u8p]
         L.orc_rlwe_decrypt.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p]
         L.orc_poly_uniform.argtypes = [i32p, C.c_int, np.ctypeslib.ndpointer(dtype=np.uint16, flags='C_CONTIGUOUS'), C.c_int, u32p, C.c_size_t, C.POINTER(C.c_size_t)]
+        f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags='C_CONTIGUOUS')
+        L.orc_ensdlp_expand_basis.argtypes = [C.c_int, i32p, i32p]
+        L.orc_ensdlp_gso.argtypes = [C.c_int, C.c_int, i32p, f32p, f32p]
+        L.orc_ensdlp_gso.restype = None
+        L.orc_ensdlp_sign.argtypes = [i32p, i32p, f32p, f32p, u8p, C.c_size_t, u32p, C.c_size_t, u8p]
         L.orc_ensdlp_verify.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u8p, C.c_size_t]
         L.orc_dlp_ct_bytes.restype = C.c_size_t
         L.orc_dlp_ct_bytes.argtypes = [i32p]
@@ -440,6 +445,26 @@ def ensdlp_verify(par, h, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_ensdlp_verify(par, np.ascontiguousarray(np.asarray(h), dtype=np.int16), m, ml, s, s.size)
+
+
+def ensdlp_basis(n, q, fgFG):
+    """(b, b_gs, inv_norm) as create_gpv_matrices leaves them in the reference context: int32 [2n, 2n], float32 [2n, 2n], float32 [2n]"""
+    k = np.ascontiguousarray(np.asarray(fgFG), dtype=np.int32)
+    b = np.zeros((2 * n, 2 * n), dtype=np.int32)
+    bgs = np.zeros((2 * n, 2 * n), dtype=np.float32)
+    inv = np.zeros(2 * n, dtype=np.float32)
+    lib().orc_ensdlp_expand_basis(n, k, b.reshape(-1))
+    lib().orc_ensdlp_gso(n, q, k, bgs.reshape(-1), inv)
+    return b, bgs, inv
+
+
+def ensdlp_sign(par, b, bgs, inv, msg, tape):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    m, ml = _msgbuf(msg)
+    tp = _tape(tape)
+    sig = np.zeros((int(par[0]) * int(par[2]) + 7) // 8, dtype=np.uint8)
+    rc = lib().orc_ensdlp_sign(par, b.reshape(-1), bgs.reshape(-1), inv, m, ml, tp, tp.size, sig)
+    return rc, bytes(sig)
 
 
 def dlp_encrypt(par, h_ntt, ident, msg, tape):

@@ -22,7 +22,7 @@ def G():
     return load_golden('ensdlp_ref.txt')
 
 
-@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4)])
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
 def test_verdicts_match_reference_and_oracle(eng, G, tag, nmsg):
     import torch
     par, h = np.asarray(G[f'{tag}_params']), G[f'{tag}_h']
@@ -57,3 +57,76 @@ def test_verdicts_match_reference_and_oracle(eng, G, tag, nmsg):
     assert v.cpu().tolist() == want
     assert want.count(0) >= nmsg
     f.close()
+
+
+def _rows(items, stride):
+    buf = np.zeros((len(items), stride), dtype=np.uint8); lens = np.zeros(len(items), dtype=np.int32)
+    for i, x in enumerate(items):
+        buf[i, :len(x)] = np.frombuffer(x, dtype=np.uint8); lens[i] = len(x)
+    return buf, lens
+
+
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
+def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg):
+    """sc_hip_ens_dlp_sig_sign (Klein's sampler, one lane per signature) byte for byte against the reference's signatures given its PRNG word
+    tape, and against the oracle on further seeded messages / tapes; batch 77 crosses a wavefront boundary with a ragged tail."""
+    import torch
+    par = np.asarray(G[f'{tag}_params'])
+    n, q = int(par[0]), int(par[1])
+    b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
+    s = eng.ens_dlp_signer(par)
+    s.set_key(b, bgs, inv)
+    assert s.tape_words == 4 * n and s.sig_bytes == n * int(par[2]) // 8
+    rng = np.random.default_rng(23)
+    msgs, tapes, want = [], [], []
+    for m in range(nmsg):
+        msgs.append(bytes(np.asarray(G[f'{tag}_msg{m}'], dtype=np.uint8)))
+        tapes.append(np.asarray(G[f'{tag}_tape{m}'], dtype=np.int64).astype(np.uint32))
+        want.append(bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8)))
+    while len(msgs) < 77:
+        msg = bytes(rng.integers(0, 256, size=int(rng.integers(0, 150)), dtype=np.uint8))
+        tp = rng.integers(0, 1 << 32, size=4 * n, dtype=np.uint64).astype(np.uint32)
+        rc, sig = O.ensdlp_sign(par, b, bgs, inv, msg, tp)
+        assert rc == 0
+        msgs.append(msg); tapes.append(tp); want.append(sig)
+    mb, ml = _rows(msgs, 160)
+    tb = np.stack(tapes).view(np.int32)
+    tl = np.full(len(msgs), 4 * n, dtype=np.int32)
+    tl[-1] = 4 * n - 1                                           # one word short: status 2, no signature
+    sigs, status = s.sign(torch.from_numpy(mb).cuda(), torch.from_numpy(tb).cuda(), mlens=torch.from_numpy(ml).cuda(), tape_lens=torch.from_numpy(tl).cuda())
+    torch.cuda.synchronize()
+    st = status.cpu().tolist()
+    assert st[:-1] == [1] * (len(msgs) - 1) and st[-1] == 2
+    got = sigs.cpu().numpy()
+    for i in range(len(msgs) - 1):
+        assert bytes(got[i]) == want[i], i
+    assert not got[-1].any()
+    # what was signed verifies under the public key (the Falcon-shaped verifier handle)
+    hp = par.copy(); hp[4] = 0
+    f = eng.falcon(hp)
+    f.set_pubkey(G[f'{tag}_h'])
+    sl = torch.full((len(msgs),), s.sig_bytes, dtype=torch.int32, device='cuda')
+    v = f.ens_dlp_verify(torch.from_numpy(mb).cuda(), sigs, sl, mlens=torch.from_numpy(ml).cuda())
+    assert v.cpu().tolist()[:-1] == [0] * (len(msgs) - 1)
+    f.close()
+    s.close()
+
+
+def test_signer_rejects_bad_arguments(eng, G):
+    import torch
+    from libsafecrypto_amd import EngineError
+    par = np.asarray(G['dlpsig0_params'])
+    n, q = int(par[0]), int(par[1])
+    bad = par.copy(); bad[0] = 128
+    with pytest.raises(EngineError):
+        eng.ens_dlp_signer(bad)
+    s = eng.ens_dlp_signer(par)
+    msgs = torch.zeros((2, 16), dtype=torch.uint8, device='cuda')
+    tapes = torch.zeros((2, 4 * n), dtype=torch.int32, device='cuda')
+    with pytest.raises(EngineError):
+        s.sign(msgs, tapes, fixed_len=4)                         # no key loaded
+    b, bgs, inv = O.ensdlp_basis(n, q, G['dlpsig0_fgFG'])
+    s.set_key(b, bgs, inv)
+    with pytest.raises(EngineError):
+        s.sign(msgs, tapes[:, :4 * n - 2].contiguous(), fixed_len=4)      # rows shorter than 4n words
+    s.close()

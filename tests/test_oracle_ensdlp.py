@@ -1,12 +1,14 @@
 """CPU: the oracle's ENS / DLP signature verification (orc_ensdlp_verify) against the reference's verdicts on its own signatures and
-on tampered copies (tests/golden/ensdlp_ref.txt, generator oracle/ref_driver.c)."""
+on tampered copies, and the oracle's signer (basis expansion, single-precision Gram-Schmidt, Klein sampler: orc_ensdlp_expand_basis / _gso /
+_sign) against the reference's matrices and its signatures byte for byte, given the same PRNG word tape
+(tests/golden/ensdlp_ref.txt, generator oracle/ref_driver.c)."""
 import numpy as np
 import pytest
 
 from tests.golden_io import load_golden
 from tests import oracle_lib as O
 
-CASES = [('enssig0', 5), ('dlpsig1', 4)]
+CASES = [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)]
 
 
 @pytest.fixture(scope='module')
@@ -29,3 +31,28 @@ def test_verdicts_match_reference(G, tag, nmsg):
         sig[3] ^= 0x80
         assert O.ensdlp_verify(par, h, msg + b'x', bytes(sig)) == 1
         assert O.ensdlp_verify(par, h, msg, bytes(sig[:-1])) == 1
+
+
+@pytest.mark.parametrize('tag,nmsg', CASES)
+def test_matrices_match_reference(G, tag, nmsg):
+    """b, b_gs (strided samples, bit patterns) and every 1/||b_gs[j]|| as create_gpv_matrices left them in the reference context"""
+    par = G[f'{tag}_params']
+    n, q = int(par[0]), int(par[1])
+    b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
+    assert np.array_equal(inv.view(np.int32), np.asarray(G[f'{tag}_inv_norm'], dtype=np.int32))
+    assert np.array_equal(b.reshape(-1)[::1021], np.asarray(G[f'{tag}_b_sample'], dtype=np.int32))
+    assert np.array_equal(bgs.reshape(-1)[::1021].view(np.int32), np.asarray(G[f'{tag}_bgs_sample'], dtype=np.int32))
+
+
+@pytest.mark.parametrize('tag,nmsg', CASES)
+def test_signatures_match_reference(G, tag, nmsg):
+    par = G[f'{tag}_params']
+    n, q = int(par[0]), int(par[1])
+    b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
+    for m in range(nmsg):
+        msg = bytes(np.asarray(G[f'{tag}_msg{m}'], dtype=np.uint8))
+        want = bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8))
+        tape = np.asarray(G[f'{tag}_tape{m}'], dtype=np.int64).astype(np.uint32)
+        rc, sig = O.ensdlp_sign(par, b, bgs, inv, msg, tape)
+        assert rc == 0 and sig == want, m
+        assert O.ensdlp_sign(par, b, bgs, inv, msg, tape[:-1])[0] == 2          # tape one word short
