@@ -294,6 +294,34 @@ def bliss_kyber_extra(eng, torch):
             sys.stderr.write(f'dlp cpu baseline failed: {e}\n')
     out['dlp_ibe_0'] = di
     f.close(); d.close()
+    # ENS signature set 0 (n=512): Klein's sampler over the 1024 x 1024 basis, keyed from f | g | F | G
+    G = load_golden('ensdlp_ref.txt')
+    par = np.asarray(G['enssig0_params'])
+    n = int(par[0])
+    sg = eng.ens_dlp_signer(par); sg.set_privkey(G['enssig0_fgFG'])
+    hp = par.copy(); hp[4] = 0
+    vf = eng.falcon(hp); vf.set_pubkey(G['enssig0_h'])
+    B = 16384
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    xt = torch.randint(-2**31, 2**31 - 1, (B, 4 * n), dtype=torch.int32, device='cuda', generator=g)
+    sl = torch.full((B,), sg.sig_bytes, dtype=torch.int32, device='cuda')
+    sigs, st = sg.sign(msgs, xt, fixed_len=64); torch.cuda.synchronize()
+    ts, tv = [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); sigs, st = sg.sign(msgs, xt, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); vd = vf.ens_dlp_verify(msgs, sigs, sl, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+    assert int((st == 1).sum()) == B and int((vd == 0).sum()) == B          # every signature made verifies
+    es = {'workload': f'ENS signature set 0 (n=512, q=12289) sign (Klein sampler, 2n = 1024 sequential basis rows) / verify, batch {B}, one key pair, 64-byte messages, tapes resident in HBM',
+          'sign_ops_per_s': B / min(ts), 'verify_ops_per_s': B / min(tv)}
+    if os.path.exists(drv):
+        try:
+            c = json.loads(subprocess.check_output([drv, 'bench_enssig', '0', '3'], timeout=120, stderr=subprocess.DEVNULL).decode().strip().splitlines()[-1])
+            es['cpu_reference'] = {'sign_ops_per_s': c['sign_per_sec'], 'verify_ops_per_s': c['verify_per_sec'], 'cores': 1, 'kind': 'reference',
+                                   'sample': '3 s of safecrypto_sign + 0.75 s of safecrypto_verify, set 0, one key pair, 1 thread'}
+        except Exception as e:
+            sys.stderr.write(f'ens sig cpu baseline failed: {e}\n')
+    out['ens_sig_0'] = es
+    sg.close(); vf.close()
     return out
 
 

@@ -469,6 +469,9 @@ int  sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_
 void sc_hip_ens_dlp_signer_destroy(sc_hip_ens_dlp_signer_t *h);
 /* host pointers: b SINT32 [2n][2n], b_gs FLOAT [2n][2n], b_gs_inv_norm FLOAT [2n] */
 int  sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const int32_t *b, const float *b_gs, const float *b_gs_inv_norm);
+/* the same from the private key alone: f | g | F | G (SINT32, 4n words = sc->privkey->key); derives the three matrices as create_gpv_matrices does
+ * (gpv_expand_basis, modified_gram_schmidt_fast_flt, gpv_precompute_inv_flt: src/utils/arith/gpv.c:709-760, 1021-1117, 977-984), on the host at key load */
+int  sc_hip_ens_dlp_signer_set_privkey(sc_hip_ens_dlp_signer_t *h, const int32_t *fgFG);
 size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h);        /* n * q_bits / 8 */
 size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h);   /* 4n: one prng_64 per basis row */
 /* d_tapes row i: the prng_32 word stream of sc->prng_ctx[0] during signature i (8-byte aligned rows, tape_stride even and >= 4n);

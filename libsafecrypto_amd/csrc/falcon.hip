@@ -789,6 +789,9 @@ __global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
     }
     uint64_t M = 0x7fffffffu >> 1;                               // H(m) < 2^q_bits + q < 2^30
     bool dead = false;
+    int32_t cur[KU], nxt[KU];                                    // run-ahead: chunk k + KU is requested before chunk k is worked on,
+#pragma unroll                                                   // and the next row's first chunk before this row's sample is drawn
+    for (int u = 0; u < KU; u++) cur[u] = ci[(size_t)u * B];
     for (int j = n2 - 1; j >= 0; j--) {
         const float inv = A.inv[j];
         const float d = dot * inv * inv;
@@ -812,19 +815,132 @@ __global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
         const float *__restrict__ brow = reinterpret_cast<const float *>(A.b) + (size_t)j * n2;
         const float *__restrict__ grow = A.bgs + (size_t)(j > 0 ? j - 1 : 0) * n2;
         dot = 0.f;
-        for (int k = 0; k < n2; k += KU) {
-            int32_t v[KU];
+        for (int k = 0; k < n2; k += 2 * KU) {                   // two chunks per trip, two register sets: no copies between them
 #pragma unroll
-            for (int u = 0; u < KU; u++) v[u] = ci[(size_t)(k + u) * B];
+            for (int u = 0; u < KU; u++) nxt[u] = ci[(size_t)(k + KU + u) * B];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
-                v[u] -= z * __float_as_int(brow[k + u]);
-                ci[(size_t)(k + u) * B] = v[u];
-                dot += (float)v[u] * grow[k + u];
+                const int32_t v = cur[u] - z * __float_as_int(brow[k + u]);
+                ci[(size_t)(k + u) * B] = v;
+                dot += (float)v * grow[k + u];
+            }
+            const int kn = (k + 2 * KU < n2) ? k + 2 * KU : 0;   // after the last chunk: the first chunk (already final for this row)
+#pragma unroll
+            for (int u = 0; u < KU; u++) cur[u] = ci[(size_t)(kn + u) * B];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int32_t v = nxt[u] - z * __float_as_int(brow[k + KU + u]);
+                ci[(size_t)(k + KU + u) * B] = v;
+                dot += (float)v * grow[k + KU + u];
             }
         }
     }
     if (valid) A.status[col] = short_tape ? 2u : dead ? 3u : 1u;
+}
+
+// The production form: G lanes per signature, the sampler state held in REGISTERS.  The lane-per-signature kernel above needs 64 signatures per
+// wavefront (16384 signatures are 256 wavefronts on 1024 SIMDs) and streams the whole state through HBM once per basis row.  Here lane r of a
+// signature owns the elements k = r mod G: the update, the int -> float conversion and the product with the Gram-Schmidt row run G wide, and only
+// the ADDITIONS keep the reference's order - the running sum travels round the signature's lanes, lane r adding its product to what lane r-1 hands
+// it (v_add_f32 with a row_ror DPP operand, G dependent instructions per G elements; in the i-th of them lane i-1 holds the true partial sum, the
+// other lanes compute values nobody reads).  A lane's share of the 2n-word state is 2n/G = NCH words of registers, so the sweep touches no memory
+// of its own and only s1 is written at the end.  G = 16, 8 or 4: the lanes of a signature sit 16/G apart inside a DPP row (16/G signatures
+// interleaved per row, 64/G per wavefront) and the running sum moves with row_ror:(16/G), so each ring closes on itself.  The DPP
+// additions are the cost (every wavefront spends 2n of them per basis row whatever G is), so fewer lanes per signature = fewer wavefronts = less
+// work, as long as enough wavefronts remain to fill the SIMDs: the host picks G from the batch size, bounded below by 128 state registers per lane.
+// The basis row and the Gram-Schmidt row of a step are the same 16n bytes for every signature and known in advance: the wavefront fetches the NEXT
+// step's rows with 16-byte loads at the top of a step, parks them in registers while the sweep runs out of LDS (its private double buffer,
+// 2 x 16n bytes), and writes them to the other buffer afterwards - no load is waited on inside the sweep, which is fully unrolled (static
+// register indices).
+template <int G>
+__device__ __forceinline__ float chain_g(float acc, float p)
+{
+#pragma unroll
+    for (int i = 0; i < G; i++) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x120 + 16 / G, 0xF, 0xF, false)) + p;
+    return acc;                                                  // in the signature's last lane: acc_in(last lane) + p[0] + ... + p[G-1], left to right
+}
+
+template <int G, int NCH>
+__global__ __launch_bounds__(64) void kleinr_kernel(KleinArgs A)
+{
+    constexpr int n2 = NCH * G, n = n2 / 2, NV = n2 / 256, S = 16 / G;       // NV float4 per lane per row; S signatures per DPP row
+    __shared__ float4 rows[2][2][n2 / 4];                        // [buffer][basis | Gram-Schmidt][k / 4]
+    const uint32_t lane = threadIdx.x, r = (lane & 15) / S;
+    const uint32_t col = blockIdx.x * (64 / G) + (lane >> 4) * S + (lane & (S - 1));
+    const bool valid = col < A.batch;
+    const uint32_t item = valid ? col : 0;
+    const uint32_t *tape = A.tapes + (size_t)item * A.tape_stride;
+    const bool short_tape = A.tape_lens && A.tape_lens[item] < 2u * (uint32_t)n2;
+    const float4 *__restrict__ bmat = reinterpret_cast<const float4 *>(A.b);      // int bit patterns, moved as floats
+    const float4 *__restrict__ gmat = reinterpret_cast<const float4 *>(A.bgs);
+    uint64_t ring = 0;                                           // the lanes of this signature
+#pragma unroll
+    for (int i = 0; i < G; i++) ring |= 1ull << ((lane & 48) + (lane & (S - 1)) + S * i);
+
+    int32_t st[NCH];
+    float dot = 0.f;
+    {
+        const int32_t *cr = A.c + (size_t)item * n + r;
+        const float *g = A.bgs + (size_t)(n2 - 1) * n2 + r;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            st[c] = (c < NCH / 2) ? cr[G * c] : 0;
+            dot = chain_g<G>(dot, (float)st[c] * g[G * c]);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            rows[1][0][lane + 64 * i] = bmat[(size_t)(n2 - 1) * (n2 / 4) + lane + 64 * i];
+            rows[1][1][lane + 64 * i] = gmat[(size_t)(n2 - 2) * (n2 / 4) + lane + 64 * i];
+        }
+        __syncthreads();
+    }
+    uint64_t M = 0x7fffffffu >> 1;
+    bool dead = false;
+#pragma unroll 1
+    for (int j = n2 - 1; j >= 0; j--) {
+        const int buf = j & 1;                                   // n2 - 1 is odd: the first step reads buffer 1
+        float4 pb[NV], pg[NV];                                   // rows of step j - 1: basis row j - 1, Gram-Schmidt row j - 2
+        const size_t rb = (size_t)(j > 0 ? j - 1 : 0) * (n2 / 4), rg = (size_t)(j > 1 ? j - 2 : 0) * (n2 / 4);
+#pragma unroll
+        for (int i = 0; i < NV; i++) { pb[i] = bmat[rb + lane + 64 * i]; pg[i] = gmat[rg + lane + 64 * i]; }
+        const float inv = A.inv[j];
+        const float d = __shfl(dot, (int)(lane | (16 - S))) * inv * inv;
+        const uint2 w = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - j));
+        const uint64_t x = ((uint64_t)w.x << 32) | w.y;
+        const uint64_t *__restrict__ cdf = A.tabs + ((size_t)j << A.ts_log);
+        const int size = (int)A.sizes[j];
+        uint32_t a = 0;
+        for (int e = 1; e < size; e++) a += (cdf[e] < x) ? 1u : 0u;
+        int32_t z = ((x & 1) ? (int32_t)a : -(int32_t)a) + (int32_t)d;
+        const uint64_t az = (uint64_t)(z < 0 ? -(int64_t)z : (int64_t)z) * A.maxb;
+        bool risky = !dead && M + az > 0x7fffffffull;
+        if (__any(risky)) {                                      // rare: replace the running bound by the exact maximum of this lane's elements
+            uint32_t m = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const int32_t v = st[c]; const uint32_t av = (uint32_t)(v < 0 ? -v : v); m = av > m ? av : m; }
+            if (risky) M = m;
+            if (__ballot(risky && M + az > 0x7fffffffull) & ring) dead = true;
+        }
+        if (dead) z = 0;
+        M += dead ? 0 : az;
+        const float *__restrict__ brow = reinterpret_cast<const float *>(rows[buf][0]) + r;
+        const float *__restrict__ grow = reinterpret_cast<const float *>(rows[buf][1]) + r;
+        dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            st[c] -= z * __float_as_int(brow[G * c]);
+            dot = chain_g<G>(dot, (float)st[c] * grow[G * c]);
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) { rows[buf ^ 1][0][lane + 64 * i] = pb[i]; rows[buf ^ 1][1][lane + 64 * i] = pg[i]; }
+        __syncthreads();
+    }
+    if (valid) {
+        int32_t *__restrict__ out = A.ci + col;                  // [2n][B]; only s1 = the second half is needed
+#pragma unroll
+        for (int c = NCH / 2; c < NCH; c++) out[(size_t)(G * c + r) * A.B] = st[c];
+        if (r == 0) A.status[col] = short_tape ? 2u : dead ? 3u : 1u;
+    }
 }
 
 // s1 = centre(ci[n, 2n)) (ens_dlp_sig.c:1273), n q_bits-bit two's complement fields, MSB first (entropy_poly_encode_32, SC_ENTROPY_NONE).
@@ -1215,6 +1331,73 @@ extern "C" int sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const i
     return SC_HIP_SUCCESS;
 }
 
+// The same from the private key alone (f | g | F | G, SINT32, 4n words = sc->privkey->key): what create_gpv_matrices (ens_dlp_sig.c:364-421) does at key
+// load, on the host as there - gpv_expand_basis (gpv.c:709-760; its scratch matrix is zeroed once and only written up to each polynomial's degree, so
+// a polynomial with zero top coefficients inherits the previous one's entries: order g, f, G, F), modified_gram_schmidt_fast_flt (gpv.c:1021-1117) and
+// gpv_precompute_inv_flt (:977-984), every operation rounded to single precision in the reference's order (this file is built with -ffp-contract=off).
+static float dot_seq(const float *a, const float *b, size_t n) { float d = 0; for (size_t k = 0; k < n; k++) d += a[k] * b[k]; return d; }
+
+extern "C" int sc_hip_ens_dlp_signer_set_privkey(sc_hip_ens_dlp_signer_t *h, const int32_t *fgFG)
+{
+    if (!h || !fgFG) return fail("ens_dlp_signer_set_privkey: null argument");
+    const size_t N = (size_t)h->P.n, N2 = 2 * N;
+    std::vector<int32_t> b(N2 * N2), A(N * N, 0);
+    const int32_t *polys[4] = { fgFG + N, fgFG, fgFG + 3 * N, fgFG + 2 * N };            // g, f, G, F
+    for (int m = 0; m < 4; m++) {
+        const int32_t *p = polys[m];
+        size_t deg = N - 1;
+        while (p[deg] == 0 && deg > 0) deg--;
+        for (size_t i = 0; i < N; i++) {
+            for (size_t j = i; j <= deg + i && j < N; j++) A[i * N + j] = p[j - i];
+            for (size_t j = 0; j + N <= deg + i; j++) A[i * N + j] = -p[j + N - i];
+        }
+        const size_t r0 = (m >= 2) ? N : 0, c0 = (m & 1) ? N : 0;
+        for (size_t i = 0; i < N; i++)
+            for (size_t j = 0; j < N; j++) b[(r0 + i) * N2 + c0 + j] = (m & 1) ? -A[i * N + j] : A[i * N + j];
+    }
+    std::vector<float> gs(N2 * N2), inv(N2), v(N2), v1(N2);
+    const int32_t *f = fgFG, *g = fgFG + N;
+    for (size_t i = 0; i < N; i++) { gs[i] = (float)g[i]; gs[N + i] = (float)-f[i]; }
+    float C_k = 0, D_k = 0;
+    for (int half = 0; half < 2; half++) {
+        const size_t base = half ? N : 0;
+        if (half) {
+            const float D_k_inv = 1 / D_k;
+            for (size_t i = 0; i < N; i++) {
+                gs[N * N2 + N + i] = gs[(N - 1) * N2 + N - 1 - i] * (float)h->P.q * D_k_inv;
+                gs[N * N2 + i] = -gs[(N - 1) * N2 + N2 - 1 - i] * (float)h->P.q * D_k_inv;
+            }
+        }
+        const float *r0 = &gs[base * N2];
+        for (size_t i = 0; i + 1 < N; i++) { v[i] = r0[i + 1]; v[N + i] = r0[i + N + 1]; }
+        v[N - 1] = -r0[0];
+        v[N2 - 1] = -r0[N];
+        v1 = v;
+        C_k = dot_seq(r0, v1.data(), N2);
+        D_k = half ? dot_seq(r0, r0, N2) : dot_seq(v.data(), v.data(), N2);
+        for (size_t i = base + 1; i < base + N; i++) {
+            const float aux = C_k / D_k;
+            float *ri = &gs[i * N2];
+            const float *rp = ri - N2;
+            ri[0] = -rp[N - 1] + aux * v[N - 1];
+            ri[N] = -rp[N2 - 1] + aux * v[N2 - 1];
+            for (size_t j = 1; j < N; j++) {
+                ri[j] = rp[j - 1] - aux * v[j - 1];
+                ri[N + j] = rp[N + j - 1] - aux * v[N + j - 1];
+            }
+            for (size_t j = 0; j < N2; j++) v[j] -= aux * rp[j];
+            const float C_ko = C_k, D_ko = D_k;
+            C_k = dot_seq(ri, v1.data(), N2);
+            D_k = D_ko - C_ko * C_ko / D_ko;
+        }
+    }
+    for (size_t j = 0; j < N2; j++) {
+        const double sqr = dot_seq(&gs[j * N2], &gs[j * N2], N2);
+        inv[j] = (float)(1.0 / sqrt(sqr));
+    }
+    return sc_hip_ens_dlp_signer_set_key(h, b.data(), gs.data(), inv.data());
+}
+
 extern "C" size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h) { return h ? ((size_t)h->P.n * (size_t)h->P.q_bits + 7) / 8 : 0; }
 extern "C" size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h) { return h ? 4 * (size_t)h->P.n : 0; }
 
@@ -1247,7 +1430,27 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     KleinArgs A;
     A.batch = nb; A.B = (uint32_t)B; A.n = (int)n; A.n2 = (int)n2; A.c = c; A.b = h->d_b; A.bgs = h->d_bgs; A.inv = h->d_inv; A.tabs = h->d_tabs; A.sizes = h->d_sizes;
     A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status;
-    hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
+    // lanes per signature: 16 while a lane per signature would leave SIMDs idle (test hook: SC_HIP_KLEIN_LANES = 1 / 16)
+    // lanes per signature.  Register form: the fewest (down to 128 state words per lane) that still give every SIMD two wavefronts.
+    // Test hook SC_HIP_KLEIN_LANES: 1 = the lane-per-signature kernel (state in memory), 4 / 8 / 16 = the register form with that many lanes.
+    int G = 16, in_regs = 1;
+    const int gmin = (int)(n / 64);                              // 4 / 8 / 16 for n = 256 / 512 / 1024
+    while (G > gmin && batch * (size_t)(G / 2) / 64 >= (size_t)h->ctx->cus * 4 * 2) G /= 2;
+    if (const char *e = getenv("SC_HIP_KLEIN_LANES")) {
+        const int v = atoi(e);
+        if (v == 1) { G = 1; in_regs = 0; }
+        if ((v == 4 || v == 8 || v == 16) && v >= gmin) G = v;
+    }
+    if (in_regs) {
+        const dim3 grid((unsigned)(B / (64 / G)));
+        if (n == 256 && G == 4) hipLaunchKernelGGL((kleinr_kernel<4, 128>), grid, dim3(64), 0, s, A);
+        else if (n == 256 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 64>), grid, dim3(64), 0, s, A);
+        else if (n == 256) hipLaunchKernelGGL((kleinr_kernel<16, 32>), grid, dim3(64), 0, s, A);
+        else if (n == 512 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 128>), grid, dim3(64), 0, s, A);
+        else if (n == 512) hipLaunchKernelGGL((kleinr_kernel<16, 64>), grid, dim3(64), 0, s, A);
+        else hipLaunchKernelGGL((kleinr_kernel<16, 128>), grid, dim3(64), 0, s, A);
+    }
+    else hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
     HIPCHK(hipGetLastError());
     const size_t nt = batch * (n / 8);
     hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);

@@ -31,7 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key',
+    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey',
     'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
@@ -173,6 +173,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_ens_dlp_signer_destroy.argtypes = [vp]
     L.sc_hip_ens_dlp_signer_destroy.restype = None
     L.sc_hip_ens_dlp_signer_set_key.argtypes = [vp, vp, vp, vp]
+    L.sc_hip_ens_dlp_signer_set_privkey.argtypes = [vp, vp]
     L.sc_hip_ens_dlp_sig_bytes.argtypes = [vp]
     L.sc_hip_ens_dlp_sig_bytes.restype = sz
     L.sc_hip_ens_dlp_sig_tape_words.argtypes = [vp]
@@ -982,6 +983,13 @@ class EnsDlpSigner:
         v = np.ascontiguousarray(np.asarray(inv_norm), dtype=np.float32)
         assert b.size == 4 * self.n * self.n and g.size == b.size and v.size == 2 * self.n
         _chk(self.L, self.L.sc_hip_ens_dlp_signer_set_key(self.h, _ptr(b), _ptr(g), _ptr(v)), 'ens_dlp_signer_set_key')
+
+    def set_privkey(self, fgFG):
+        """f | g | F | G (int32, 4n): the matrices are derived at key load as the reference's create_gpv_matrices does"""
+        import numpy as np
+        k = np.ascontiguousarray(np.asarray(fgFG), dtype=np.int32)
+        assert k.size == 4 * self.n
+        _chk(self.L, self.L.sc_hip_ens_dlp_signer_set_privkey(self.h, _ptr(k)), 'ens_dlp_signer_set_privkey')
 
     def sign(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
         """msgs uint8 [batch][stride], tapes int32/uint32 [batch][>= 4n] -> signatures uint8 [batch][n * q_bits / 8], status"""

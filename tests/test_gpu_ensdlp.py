@@ -67,10 +67,16 @@ def _rows(items, stride):
 
 
 @pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
-def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg):
+@pytest.mark.parametrize("lanes", ["1", "4", "8", "16", ""])
+def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes, monkeypatch):
     """sc_hip_ens_dlp_sig_sign (Klein's sampler, one lane per signature) byte for byte against the reference's signatures given its PRNG word
-    tape, and against the oracle on further seeded messages / tapes; batch 77 crosses a wavefront boundary with a ragged tail."""
+    tape, and against the oracle on further seeded messages / tapes; batch 77 crosses a wavefront boundary with a ragged tail.  Both forms of the
+    kernel (a lane per signature with the state in memory; 4 / 8 / 16 lanes per signature with the state in registers) are forced in turn, then the default choice."""
     import torch
+    if lanes:
+        monkeypatch.setenv('SC_HIP_KLEIN_LANES', lanes)        # 1: a lane per signature, state in memory; 4 / 8 / 16 lanes: state in registers
+    else:
+        monkeypatch.delenv('SC_HIP_KLEIN_LANES', raising=False)
     par = np.asarray(G[f'{tag}_params'])
     n, q = int(par[0]), int(par[1])
     b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
@@ -109,6 +115,26 @@ def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg):
     v = f.ens_dlp_verify(torch.from_numpy(mb).cuda(), sigs, sl, mlens=torch.from_numpy(ml).cuda())
     assert v.cpu().tolist()[:-1] == [0] * (len(msgs) - 1)
     f.close()
+    s.close()
+
+
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
+def test_signer_keyed_from_private_key_alone(eng, G, tag, nmsg):
+    """sc_hip_ens_dlp_signer_set_privkey derives the basis, its Gram-Schmidt matrix and the row norms from f | g | F | G itself (the product's own
+    host code, not the oracle's): the reference's signatures come out byte for byte"""
+    import torch
+    par = np.asarray(G[f'{tag}_params'])
+    n = int(par[0])
+    s = eng.ens_dlp_signer(par)
+    s.set_privkey(G[f'{tag}_fgFG'])
+    msgs = [bytes(np.asarray(G[f'{tag}_msg{m}'], dtype=np.uint8)) for m in range(nmsg)]
+    mb, ml = _rows(msgs, 160)
+    tb = np.stack([np.asarray(G[f'{tag}_tape{m}'], dtype=np.int64).astype(np.uint32) for m in range(nmsg)]).view(np.int32)
+    sigs, status = s.sign(torch.from_numpy(mb).cuda(), torch.from_numpy(tb).cuda(), mlens=torch.from_numpy(ml).cuda())
+    torch.cuda.synchronize()
+    assert status.cpu().tolist() == [1] * nmsg
+    for m in range(nmsg):
+        assert bytes(sigs[m].cpu().numpy()) == bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8)), m
     s.close()
 
 

@@ -11,6 +11,8 @@ from tests import oracle_lib as O
 tag = sys.argv[1] if len(sys.argv) > 1 else 'enssig0'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+if len(sys.argv) > 4:
+    os.environ["SC_HIP_KLEIN_LANES"] = sys.argv[4]
 G = load_golden('ensdlp_ref.txt')
 par = np.asarray(G[f'{tag}_params'])
 n, q = int(par[0]), int(par[1])
