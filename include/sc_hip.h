@@ -452,9 +452,9 @@ int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *h, size_t batch, int ubits, const ui
 
 /* replaces: safecrypto_verify -> ens_dlp_sig_verify (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1564-1665; SC_SCHEME_SIG_ENS / _DLP without message
  * recovery) for `batch` messages under one public key.  h: a handle created with the scheme's parameters {n, q, q_bits, n_bits, set, bd}
- * (ens_dlp_sig_params.c:23-62, n = 512 / 1024) and loaded (sc_hip_falcon_set_pubkey) with the first n SINT16 of sc->pubkey->key.  Signatures are the
- * reference's wire format (n fields of q_bits bits, signed, MSB first); signing - the O(n^2) Klein sampler over a single-precision Gram-Schmidt
- * matrix, 2n strictly sequential steps - stays with the reference.  d_verdicts[i] = 0 valid / 1 invalid. */
+ * (ens_dlp_sig_params.c:23-62, n = 256 / 512 / 1024) and loaded (sc_hip_falcon_set_pubkey) with the first n SINT16 of sc->pubkey->key.  Signatures are
+ * the reference's wire format (n fields of q_bits bits, signed, MSB first); the signer is sc_hip_ens_dlp_sig_sign below.
+ * d_verdicts[i] = 0 valid / 1 invalid. */
 int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                               const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 

@@ -990,9 +990,9 @@ static int gen_dlp(const char *dir)
 #include "schemes/sig/ens_dlp/ens_dlp_sig.h"
 #include "schemes/sig/ens_dlp/ens_dlp_sig_params.h"
 
-/* ens_dlp_sig_verify (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1564-1665, without message recovery): signatures are made by the reference's own
- * signer (its O(n^2) Klein sampler over a single-precision Gram-Schmidt matrix stays on the CPU); the fixture carries the public h
- * (SINT16, coefficient domain), messages, signatures and the reference's verdicts on them and on tampered copies. */
+/* ens_dlp_sig_sign / ens_dlp_sig_verify (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315, 1564-1665, without message recovery): the fixture
+ * carries the reference's key pair (h as SINT16 in the coefficient domain; f | g | F | G), what create_gpv_matrices derived from it, messages, the
+ * PRNG word tape each signature consumed, the signatures, and the reference's verdicts on them and on tampered copies. */
 static int ensdlp_case(FILE *f, sc_scheme_e scheme, const char *tag, int set, const ens_dlp_sig_set_t *P, int nmsg)
 {
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };

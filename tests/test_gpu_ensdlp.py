@@ -1,5 +1,6 @@
-"""GPU parity for batched ENS / DLP signature verification (sc_hip_ens_dlp_sig_verify on a Falcon-shaped handle): the reference's verdicts on
-its own signatures and on tampered copies (tests/golden/ensdlp_ref.txt), the oracle's on further tampering."""
+"""GPU parity for batched ENS / DLP signatures.  Verification (sc_hip_ens_dlp_sig_verify on a Falcon-shaped handle): the reference's verdicts on
+its own signatures and on tampered copies (tests/golden/ensdlp_ref.txt), the oracle's on further tampering.  Signing (sc_hip_ens_dlp_sig_sign):
+the reference's signatures byte for byte given its PRNG word tape, the oracle's on seeded inputs."""
 import numpy as np
 import pytest
 
@@ -69,7 +70,7 @@ def _rows(items, stride):
 @pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
 @pytest.mark.parametrize("lanes", ["1", "4", "8", "16", ""])
 def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes, monkeypatch):
-    """sc_hip_ens_dlp_sig_sign (Klein's sampler, one lane per signature) byte for byte against the reference's signatures given its PRNG word
+    """sc_hip_ens_dlp_sig_sign (Klein's sampler) byte for byte against the reference's signatures given its PRNG word
     tape, and against the oracle on further seeded messages / tapes; batch 77 crosses a wavefront boundary with a ragged tail.  Both forms of the
     kernel (a lane per signature with the state in memory; 4 / 8 / 16 lanes per signature with the state in registers) are forced in turn, then the default choice."""
     import torch
