@@ -506,6 +506,13 @@ int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_seeds,
 int sc_hip_dilithium_keygen(sc_hip_dilithium_t *h, size_t batch, int eta_bits, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
                             int32_t *d_s1, int32_t *d_s2, int32_t *d_t, uint8_t *d_rho, uint8_t *d_K, uint8_t *d_tr, int32_t *d_t1, void *stream);
 
+/* replaces: safecrypto_verify -> dilithium_verify (src/schemes/sig/dilithium/dilithium.c:2073-2260) for a batch of signatures EACH under its own public
+ * key ("16384 distinct keys").  d_t1 [batch][k][n] int32 and d_rho [batch][32]: the keys as dilithium_pubkey_load leaves them
+ * (t1 | rho, dilithium.c:824,904).  The matrix of every key is regenerated from rho on the device; no handle key needs to be loaded. */
+int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *h, size_t batch, const int32_t *d_t1, const uint8_t *d_rho,
+                                 const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                 const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

@@ -41,14 +41,14 @@ struct DilP {                             // dilithium_set_t (dilithium_params.h
 
 // mu = SHAKE256(tr || M)  (collision_resistant_hash_message, module_lwe.c:182-198)
 __global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uint8_t *msgs, size_t stride, const uint32_t *lens,
-                                                    uint32_t fixed_len, uint8_t *mu, uint32_t count)
+                                                    uint32_t fixed_len, uint8_t *mu, uint32_t count, uint32_t tr_stride = 0)
 {
     __shared__ uint64_t st[25 * HT];
     const uint32_t item = blockIdx.x * HT + threadIdx.x;
     const bool valid = item < count;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
     if (!valid) return;
-    sp.absorb(tr, 48);
+    sp.absorb(tr + (size_t)item * tr_stride, 48);                 // tr_stride = 48: a key per item
     const uint32_t len = lens ? lens[item] : fixed_len;
     sp.absorb(msgs + (size_t)item * stride, len);
     sp.finalize();
@@ -404,6 +404,7 @@ struct sc_hip_dilithium {
     uint32_t *yh, *ch;
     uint8_t *msg_dev, *sig_dev;
     size_t msg_cap, sig_cap;
+    sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
 };
 
 static void free_ws(sc_hip_dilithium *d)
@@ -472,6 +473,7 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
 {
     if (!d) return;
     free_ws(d);
+    d->kws.release();
     void *ptrs[] = { d->d_A, d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)hipFree(p);
     sc_hip_plan_destroy(d->plan);
@@ -786,6 +788,72 @@ __global__ __launch_bounds__(HT) void shake_test_kernel(int rate, const uint8_t 
     for (uint32_t i = 0; i < outlen; i++) out[i] = sp.squeeze_byte();
 }
 }  // namespace
+
+// t1 . 2^d for a batch of public keys (dilithium.c:2163-2166), ahead of the key-preparation transform
+__global__ void dil_shift_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, size_t count, int d)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i] << d;
+}
+
+// replaces: safecrypto_verify -> dilithium_verify (dilithium.c:2073-2260) for `batch` signatures, EACH under its own public key (SURVEY 8(d) config 3,
+// "16384 distinct keys"): d_t1 [batch][k][n] int32 and d_rho [batch][32] are the keys as dilithium_pubkey_load leaves them (:904).  Per item the
+// matrix is regenerated from rho on the device (the reference's CTR-DRBG, create_rand_product_32_csprng's order, module_lwe.c:588-748), tr =
+// CRH(rho, t1) and NTT(t1 . 2^d) are derived, then the same kernels as the one-key path run with a key stride: 4 k l n bytes of matrix are read
+// per signature instead of being shared by the batch.  d_verdicts[i] = 0 valid / 1 invalid.
+extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch, const int32_t *d_t1, const uint8_t *d_rho,
+                                            const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                            const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (!d) return fail("dilithium_verify_keys: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 4096) return fail("dilithium_verify_keys: batch too large");
+    if (!d_t1 || !d_rho || !d_sigs || !d_siglens || !d_verdicts) return fail("dilithium_verify_keys: null buffer");
+    if (!d_msgs && (d_mlens || fixed_len)) return fail("dilithium_verify_keys: null message buffer");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    if (ensure_ws(d, batch, batch)) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    const DilP &P = d->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k, l = P.l;
+    if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return fail("dilithium_verify_keys: sig_stride too small");
+    const size_t kn = (size_t)k * N, npoly = batch * (size_t)k * l;
+    // grow-only workspace kept by the handle (a per-call hipMalloc of ~60 KB per item costs more than the kernels)
+    if (d->kws.reserve(2 * npoly * N * 4 + 2 * batch * kn * 4 + batch * 48 + 2048)) return SC_HIP_FAILURE;
+    int32_t *ab = d->kws.take<int32_t>(npoly * N), *t1s = d->kws.take<int32_t>(batch * kn);
+    uint32_t *am = d->kws.take<uint32_t>(npoly * N), *t1h = d->kws.take<uint32_t>(batch * kn);
+    uint8_t *trb = d->kws.take<uint8_t>(batch * 48);
+    // per-item key material
+    if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
+    hipLaunchKernelGGL(dil_shift_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t1, t1s, batch * kn, P.d);
+    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d_rho, d_t1, (uint32_t)kn, P.q_bits - P.d, trb, B);
+    HIPCHK(hipGetLastError());
+    DilNtt a = base_args(d);
+    a.in = t1s; a.out_int = t1h;
+    if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
+    // the signature side, as sc_hip_dilithium_verify
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    const unsigned hb = (B + HT - 1) / HT;
+    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
+    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
+                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
+    hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, trb, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, 48u);
+    HIPCHK(hipGetLastError());
+    a = base_args(d);
+    a.in = d->z; a.out_int = d->yh;
+    if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
+    a.key = am; a.key_item_stride = (size_t)k * l * N;
+    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    a.in = d->c; a.out_int = d->ch;
+    if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
+    a.key = t1h; a.key_item_stride = kn;
+    if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, d->c, 1, d_verdicts);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
 
 extern "C" int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *h_in, size_t len, uint8_t *h_out, size_t outlen)
 {

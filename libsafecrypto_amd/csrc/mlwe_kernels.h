@@ -63,7 +63,7 @@ struct DilNtt {
     const uint32_t *yh;                   // [item][l][n] internal
     const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
     const uint32_t *keyp;                 // dil_yaw_kernel only: Shoup companions floor(key 2^32 / q) of a PLAIN (non-Montgomery) matrix
-    size_t key_item_stride;               // words between the matrices of consecutive items (0: one matrix for the whole batch)
+    size_t key_item_stride;               // words between the matrices / key vectors of consecutive items (0: one key for the whole batch)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
     const int32_t *y;                     // [item][l][n] natural (mask)
     int32_t *w;                           // [item][k][n] natural canonical
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             }
         } else {
             const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)item * N + lp * 16);
-            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)sub * N + lp * 16);
+            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)item * a.key_item_stride + (size_t)sub * N + lp * 16);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const uint4 vc = pc[c], vk = pk[c];

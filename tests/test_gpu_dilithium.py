@@ -155,3 +155,73 @@ def test_keygen_vs_reference(eng, tag):
     sigs, siglens, trials = d.sign(msgs, fixed_len=64)
     assert d.verify(msgs, sigs, siglens, fixed_len=64).cpu().tolist() == [0] * 9
     d.close()
+
+
+def _sign_under_generated_keys(eng, par, eb, nkeys, per_key, seed):
+    """nkeys key pairs from the batched key generator; per_key 64-byte messages signed under each (one key load per key)"""
+    import torch
+    from types import SimpleNamespace
+    d = eng.dilithium(par)
+    rng = np.random.default_rng(seed)
+    seeds = torch.from_numpy(rng.integers(0, 256, size=(nkeys, 32), dtype=np.uint8)).cuda()
+    s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, eb)
+    k, l = int(par[3]), int(par[4])
+    A = eng.expand_matrix(rho, k * l, int(par[1]), int(par[2]))
+    g = torch.Generator(device='cuda'); g.manual_seed(seed)
+    msgs = torch.randint(0, 256, (nkeys * per_key, 64), dtype=torch.uint8, device='cuda', generator=g)
+    sigs = torch.zeros((nkeys * per_key, d.sig_stride), dtype=torch.uint8, device='cuda')
+    siglens = torch.zeros(nkeys * per_key, dtype=torch.int32, device='cuda')
+    keys = []
+    for i in range(nkeys):
+        h = [x[i].cpu().numpy().reshape(-1) for x in (s1, s2, t, K, tr, t1, rho, A)]
+        d.set_privkey(h[0], h[1], h[2], h[3], h[4], h[7])
+        sl = slice(i * per_key, (i + 1) * per_key)
+        sg, ln, _ = d.sign(msgs[sl], fixed_len=64)
+        sigs[sl, :sg.shape[1]] = sg; siglens[sl] = ln
+        keys.append(SimpleNamespace(par=np.ascontiguousarray(np.asarray(par), dtype=np.int32), t1=np.ascontiguousarray(h[5], dtype=np.int32),
+                                    rho=np.ascontiguousarray(h[6], dtype=np.uint8), Ahat=np.ascontiguousarray(h[7], dtype=np.int32)))
+    t1_items = t1.reshape(nkeys, -1).repeat_interleave(per_key, dim=0).contiguous()
+    rho_items = rho.repeat_interleave(per_key, dim=0).contiguous()
+    return d, keys, msgs, sigs, siglens, t1_items, rho_items
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_verify_under_distinct_keys(eng, G, tag):
+    """sc_hip_dilithium_verify_keys: every item carries its own public key (t1, rho); the matrix, tr and NTT(t1 2^d) are derived per item on the
+    device.  Signatures made under 11 generated keys verify; tampered signatures / messages and a signature presented with ANOTHER item's key get
+    the oracle's verdict."""
+    import torch
+    par, eb = G[f'{tag}_params'], int(G[f'{tag}_eta_bits'][0])
+    nk, per = 11, 6
+    d, keys, msgs, sigs, siglens, t1i, rhoi = _sign_under_generated_keys(eng, par, eb, nk, per, 77)
+    B = nk * per
+    assert d.verify_keys(t1i, rhoi, msgs, sigs, siglens, fixed_len=64).cpu().tolist() == [0] * B
+    bad_s = sigs.clone(); bad_s[1::4, 700] ^= 0x10
+    bad_m = msgs.clone(); bad_m[2::4, 9] ^= 0x01
+    t1x, rhox = t1i.clone(), rhoi.clone()
+    t1x[3::4] = t1i.roll(per, 0)[3::4]; rhox[3::4] = rhoi.roll(per, 0)[3::4]          # the neighbouring key
+    got = d.verify_keys(t1x, rhox, bad_m, bad_s, siglens, fixed_len=64).cpu().tolist()
+    mh, sh, lh = bad_m.cpu().numpy(), bad_s.cpu().numpy(), siglens.cpu().numpy()
+    for i in range(B):
+        ki = i // per if i % 4 != 3 else ((i - per) % B) // per
+        want = O.dilithium_verify(keys[ki], bytes(mh[i]), bytes(sh[i, :lh[i]]))
+        assert got[i] == want, i
+        assert want == (0 if i % 4 == 0 else 1)
+    d.close()
+
+
+def test_verify_distinct_keys_full_config3(eng, G):
+    """BASELINE config 3, the distinct-key leg: 16384 items of 64 bytes, each with its own (t1, rho) buffer slot (64 generated keys x 256 messages).
+    Everything verifies; flipping a signature bit rejects exactly those items; agrees with the one-key path on the same data."""
+    import torch
+    par, eb = G['dil3_params'], int(G['dil3_eta_bits'][0])
+    d, keys, msgs, sigs, siglens, t1i, rhoi = _sign_under_generated_keys(eng, par, eb, 64, 256, 5)
+    B = 64 * 256
+    assert int(d.verify_keys(t1i, rhoi, msgs, sigs, siglens, fixed_len=64).sum()) == 0
+    bad = sigs.clone(); bad[::9, 1234] ^= 0x04
+    assert torch.equal(d.verify_keys(t1i, rhoi, msgs, bad, siglens, fixed_len=64).bool().cpu(), (torch.arange(B) % 9 == 0))
+    d.set_pubkey(keys[63].t1, keys[63].rho, keys[63].Ahat)
+    one = d.verify(msgs[-256:], bad[-256:], siglens[-256:], fixed_len=64)
+    many = d.verify_keys(t1i[-256:], rhoi[-256:], msgs[-256:], bad[-256:], siglens[-256:], fixed_len=64)
+    assert torch.equal(one, many)
+    d.close()
