@@ -513,6 +513,14 @@ int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *h, size_t batch, const int3
                                  const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                  const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
+/* replaces: safecrypto_sign -> dilithium_sign (dilithium.c:1397-1698) for a batch of messages EACH under its own private key.  Keys in the key pair's
+ * layouts (dilithium.c:810-823; what sc_hip_dilithium_keygen writes): d_s1 [batch][l][n], d_s2, d_t [batch][k][n] int32; d_rho, d_K [batch][32];
+ * d_tr [batch][48].  Outputs as sc_hip_dilithium_sign. */
+int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *h, size_t batch, const int32_t *d_s1, const int32_t *d_s2, const int32_t *d_t,
+                               const uint8_t *d_rho, const uint8_t *d_K, const uint8_t *d_tr,
+                               const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                               uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
+
 /* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
  * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
  * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */

@@ -116,14 +116,14 @@ __global__ void dil_kg_t_kernel(const int32_t *as1, const int32_t *s2, int32_t *
 
 // y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244)
 __global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *slot_item, const uint32_t *slot_kappa, uint32_t nslots, const uint8_t *K,
-                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q)
+                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride = 0)
 {
     __shared__ uint64_t st[25 * HT];
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
     if (aidx >= nslots) return;
     sp.absorb(mu + (size_t)slot_item[aidx] * 48, 48);
-    sp.absorb(K, 32);
+    sp.absorb(K + (size_t)slot_item[aidx] * K_stride, 32);      // K_stride = 32: a key per message
     const uint32_t kp = slot_kappa[aidx] & 0xFFFFu;            // UINT16 kappa (dilithium.c:1421)
     sp.absorb_byte((uint8_t)(kp >> 8)); sp.absorb_byte((uint8_t)(kp & 0xFF));
     sp.finalize();
@@ -599,11 +599,29 @@ extern "C" size_t sc_hip_dilithium_sig_max(const sc_hip_dilithium_t *d)
 
 // d_msgs: [batch][msg_stride] bytes, d_mlens: per-message lengths (NULL: every message is fixed_len bytes);
 // d_sigs: [batch][sig_stride] bytes (sig_stride >= sc_hip_dilithium_sig_max), d_siglens / d_trials: uint32 [batch]
+// the signer's key material on the device: one key for the whole batch (strides 0) or one per message
+struct DilSignKeys {
+    const uint32_t *A, *As;               // matrix: Montgomery internal form; plain | Shoup form for the fused kernel (null: unfused pair)
+    const uint32_t *s1, *s2, *t0;         // NTT, internal order, Montgomery form
+    const uint8_t *K, *tr;
+    bool per_item;
+};
+
+static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                     uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
+
 extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
                                      uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream)
 {
     if (!d) return fail("dilithium_sign: null handle");
     if (!d->have_priv) return fail("dilithium_sign: no private key loaded");
+    const DilSignKeys ks = { d->d_A, getenv("SC_HIP_DIL_UNFUSED") ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false };
+    return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+}
+
+static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
+                     uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 16) return fail("dilithium_sign: batch too large");
     if (!d_msgs && (d_mlens || fixed_len)) return fail("dilithium_sign: null message buffer");
@@ -625,7 +643,7 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
     const int k = P.k, l = P.l;
     HIPCHK(hipMemsetAsync(d->kappa, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : d->trials;
-    hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d->d_tr_priv, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
+    hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, ks.tr, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, ks.per_item ? 48u : 0u);
     HIPCHK(hipGetLastError());
 
     uint32_t nact = B;
@@ -640,26 +658,28 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
         HIPCHK(hipMemsetAsync(d->cnt, 0, 4, s));
         hipLaunchKernelGGL(dil_slots_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nact, S, d->kappa, d->slot_item, d->slot_kappa);
         const unsigned hb = (nslots + HT - 1) / HT;
-        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, d->slot_kappa, nslots, d->d_K, d->mu, d->y, l * P.n, P.gamma1, P.q);
+        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, d->slot_kappa, nslots, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u);
         HIPCHK(hipGetLastError());
         DilNtt a = base_args(d);
         a.in = d->y; a.out_int = d->yh;
-        if (d->d_As && !getenv("SC_HIP_DIL_UNFUSED")) {             // w = A y with NTT(y) kept in registers
-            a.key = d->d_As; a.keyp = d->d_As + (size_t)k * l * N;
+        a.key_of = d->slot_item;                                    // per-message keys: the key of a slot is its message's
+        if (ks.As && !ks.per_item) {                                // w = A y with NTT(y) kept in registers
+            a.key = ks.As; a.keyp = ks.As + (size_t)k * l * N;
             if (mlwe_launch_yaw(d->ctx, a, nslots, s)) return SC_HIP_FAILURE;
             a.keyp = nullptr;
         } else {
             if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-            a.key = d->d_A;
+            a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0;
             if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+            a.key_item_stride = 0;
         }
         hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, nslots, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
         a.in = d->c; a.out_int = d->ch;
         if (launch_dil<DOP_FWD_INT>(d, a, nslots, 1, s)) return SC_HIP_FAILURE;
-        a.key = d->d_s1; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-        a.key = d->d_s2; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        a.key = d->d_t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        a.key = ks.s1; a.key_item_stride = ks.per_item ? (size_t)l * N : 0; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
+        a.key = ks.s2; a.key_item_stride = ks.per_item ? (size_t)k * N : 0; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
+        a.key = ks.t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
         hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
                            d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
         HIPCHK(hipGetLastError());
@@ -788,6 +808,52 @@ __global__ __launch_bounds__(HT) void shake_test_kernel(int rate, const uint8_t 
     for (uint32_t i = 0; i < outlen; i++) out[i] = sp.squeeze_byte();
 }
 }  // namespace
+
+// t0 of every key from t (decompose, module_lwe.c:89-104), canonical in [0, q): what sc_hip_dilithium_set_privkey does on the host for one key
+__global__ void dil_t0_kernel(const int32_t *__restrict__ t, int32_t *__restrict__ t0, size_t count, int d, int32_t q)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const int32_t mask = (1 << d) - 1, sign = 1 << d, thresh = 1 << (d - 1);
+    int32_t x = t[i] & mask;
+    x -= (x > thresh) * sign;
+    t0[i] = (x >= 0) ? x : x + q;
+}
+
+// replaces: safecrypto_sign -> dilithium_sign (dilithium.c:1397-1698) for `batch` messages, EACH under its own private key (SURVEY 8(d) config 3,
+// "16384 distinct keys").  Keys in the layouts sc_hip_dilithium_keygen writes (= the key pair's, dilithium.c:810-823): d_s1 [batch][l][n],
+// d_s2, d_t [batch][k][n] int32; d_rho, d_K [batch][32]; d_tr [batch][48].  Per key the matrix is regenerated from rho and s1, s2, t0 are transformed
+// on the device; the rejection loop then runs as for one key, every attempt reading its message's key (17 + k l polynomials per attempt instead of a
+// shared set, and the unfused NTT(y) / matrix-product pair since the fused kernel keeps ONE matrix in Shoup form).
+extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, const int32_t *d_s1, const int32_t *d_s2, const int32_t *d_t,
+                                          const uint8_t *d_rho, const uint8_t *d_K, const uint8_t *d_tr,
+                                          const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                          uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream)
+{
+    if (!d) return fail("dilithium_sign_keys: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffffu / 4096) return fail("dilithium_sign_keys: batch too large");
+    if (!d_s1 || !d_s2 || !d_t || !d_rho || !d_K || !d_tr) return fail("dilithium_sign_keys: null key buffer");
+    HIPCHK(hipSetDevice(d->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const DilP &P = d->P;
+    const uint32_t B = (uint32_t)batch;
+    const int k = P.k, l = P.l;
+    const size_t kn = (size_t)k * N, ln = (size_t)l * N, npoly = batch * (size_t)k * l;
+    if (d->kws.reserve(2 * npoly * N * 4 + batch * (ln + 3 * kn) * 4 + 4096)) return SC_HIP_FAILURE;
+    int32_t *ab = d->kws.take<int32_t>(npoly * N), *t0n = d->kws.take<int32_t>(batch * kn);
+    uint32_t *am = d->kws.take<uint32_t>(npoly * N), *s1h = d->kws.take<uint32_t>(batch * ln), *s2h = d->kws.take<uint32_t>(batch * kn), *t0h = d->kws.take<uint32_t>(batch * kn);
+    if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
+    hipLaunchKernelGGL(dil_t0_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t, t0n, batch * kn, P.d, P.q);
+    HIPCHK(hipGetLastError());
+    DilNtt a = base_args(d);
+    a.in = d_s1; a.out_int = s1h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s)) return SC_HIP_FAILURE;
+    a.in = d_s2; a.out_int = s2h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
+    a.in = t0n; a.out_int = t0h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
+    const DilSignKeys ks = { am, nullptr, s1h, s2h, t0h, d_K, d_tr, true };
+    return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+}
 
 // t1 . 2^d for a batch of public keys (dilithium.c:2163-2166), ahead of the key-preparation transform
 __global__ void dil_shift_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, size_t count, int d)

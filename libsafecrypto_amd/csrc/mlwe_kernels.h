@@ -64,6 +64,7 @@ struct DilNtt {
     const uint32_t *key;                  // matrix [k][l][n] or key vector [per][n], internal order, Montgomery form
     const uint32_t *keyp;                 // dil_yaw_kernel only: Shoup companions floor(key 2^32 / q) of a PLAIN (non-Montgomery) matrix
     size_t key_item_stride;               // words between the matrices / key vectors of consecutive items (0: one key for the whole batch)
+    const uint32_t *key_of;               // with a key stride: the key index of each slot (signing: slot -> message); null = the slot index itself
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
     const int32_t *y;                     // [item][l][n] natural (mask)
     int32_t *w;                           // [item][k][n] natural canonical
@@ -122,12 +123,13 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
         }
 
         // NTT-domain product(s) in internal order (16 contiguous words per lane)
+        const uint32_t kidx = (a.key_item_stride && a.key_of) ? a.key_of[item] : item;
         if (OP == DOP_MATVEC) {
 #pragma unroll
             for (int r = 0; r < 16; r++) x[r] = 0;
             for (int j = 0; j < a.l; j++) {
                 const uint4 *py = reinterpret_cast<const uint4 *>(a.yh + ((size_t)item * a.l + j) * N + lp * 16);
-                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + (size_t)item * a.key_item_stride + ((size_t)sub * a.l + j) * N + lp * 16);
+                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + (size_t)kidx * a.key_item_stride + ((size_t)sub * a.l + j) * N + lp * 16);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint4 vy = py[c], va = pa[c];
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             }
         } else {
             const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)item * N + lp * 16);
-            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)item * a.key_item_stride + (size_t)sub * N + lp * 16);
+            const uint4 *pk = reinterpret_cast<const uint4 *>(a.key + (size_t)kidx * a.key_item_stride + (size_t)sub * N + lp * 16);
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const uint4 vc = pc[c], vk = pk[c];

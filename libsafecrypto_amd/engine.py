@@ -18,7 +18,7 @@ SYMBOLS = [
     'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
     'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
-    'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_verify_keys', 'sc_hip_dilithium_sign_host',
+    'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_verify_keys', 'sc_hip_dilithium_sign_keys', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_shake_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
@@ -120,6 +120,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_dilithium_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dilithium_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dilithium_verify_keys.argtypes = [vp, sz, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_dilithium_sign_keys.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_shake_host.argtypes = [vp, C.c_int, C.c_int, vp, sz, vp, sz]
@@ -641,6 +642,20 @@ class Dilithium:
         _chk(self.L, self.L.sc_hip_dilithium_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(),
                                                     fixed_len, _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'dilithium_verify')
         return verdicts
+
+    def sign_keys(self, s1, s2, t, rho, K, tr, msgs, mlens=None, fixed_len=0):
+        """every message under its own private key; key tensors (device, contiguous) in the layouts keygen() returns"""
+        import torch
+        batch = msgs.shape[0]
+        for x in (s1, s2, t, rho, K, tr):
+            assert x.shape[0] == batch and x.is_contiguous()
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=msgs.device)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
+        trials = torch.zeros(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_dilithium_sign_keys(self.h, batch, _ptr(s1), _ptr(s2), _ptr(t), _ptr(rho), _ptr(K), _ptr(tr), _ptr(msgs), _rows(msgs),
+                                                       _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len, _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials),
+                                                       _stream()), 'dilithium_sign_keys')
+        return sigs, siglens, trials
 
     def verify_keys(self, t1, rho, msgs, sigs, siglens, mlens=None, fixed_len=0):
         """every signature under its own public key: t1 int32 [batch][k*n], rho uint8 [batch][32] (device)"""

@@ -225,3 +225,59 @@ def test_verify_distinct_keys_full_config3(eng, G):
     many = d.verify_keys(t1i[-256:], rhoi[-256:], msgs[-256:], bad[-256:], siglens[-256:], fixed_len=64)
     assert torch.equal(one, many)
     d.close()
+
+
+@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+def test_sign_under_distinct_keys(eng, G, tag):
+    """sc_hip_dilithium_sign_keys: every message under its own private key (the key generator's output buffers go straight in).  Byte for byte the
+    oracle's signature under that key, attempts included; ragged message lengths; then the distinct-key verifier accepts all of them."""
+    import torch
+    par, eb = G[f'{tag}_params'], int(G[f'{tag}_eta_bits'][0])
+    d = eng.dilithium(par)
+    rng = np.random.default_rng(99)
+    B = 70
+    seeds = torch.from_numpy(rng.integers(0, 256, size=(B, 32), dtype=np.uint8)).cuda()
+    s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, eb)
+    k, l = int(par[3]), int(par[4])
+    lens = rng.integers(0, 150, size=B).astype(np.int32)
+    mb = rng.integers(0, 256, size=(B, 152), dtype=np.uint8)
+    msgs, ml = torch.from_numpy(mb).cuda(), torch.from_numpy(lens).cuda()
+    sigs, siglens, trials = d.sign_keys(s1, s2, t, rho, K, tr, msgs, mlens=ml)
+    torch.cuda.synchronize()
+    A = eng.expand_matrix(rho, k * l, int(par[1]), int(par[2])).cpu().numpy()
+    h = [x.cpu().numpy() for x in (s1, s2, t, rho, K, tr, t1)]
+    sh, lh, th = sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy()
+    for i in range(0, B, 3):
+        key = O.DilKey(par, h[0][i].reshape(-1), h[1][i].reshape(-1), h[2][i].reshape(-1), h[3][i], h[4][i], h[5][i], h[6][i].reshape(-1), A[i].reshape(-1))
+        es, et = O.dilithium_sign(key, bytes(mb[i, :lens[i]]))
+        assert bytes(sh[i, :lh[i]]) == es and int(th[i]) == et, i
+    assert int(th.max()) > 3
+    v = d.verify_keys(t1.reshape(B, -1).contiguous(), rho, msgs, sigs, siglens, mlens=ml)
+    assert v.cpu().tolist() == [0] * B
+    d.close()
+
+
+def test_sign_distinct_keys_full_config3(eng, G):
+    """BASELINE config 3, the distinct-key leg at full size: 16384 generated key pairs, one 64-byte message each.  Everything verifies under its own
+    key and nothing under its neighbour's; the one-key signer reproduces a sample under the same keys."""
+    import torch
+    par, eb = G['dil3_params'], int(G['dil3_eta_bits'][0])
+    d = eng.dilithium(par)
+    B = 16384
+    g = torch.Generator(device='cuda'); g.manual_seed(8)
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, eb)
+    sigs, siglens, trials = d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64)
+    assert 2.5 < float(trials.float().mean()) < 4.5
+    t1f = t1.reshape(B, -1).contiguous()
+    assert int(d.verify_keys(t1f, rho, msgs, sigs, siglens, fixed_len=64).sum()) == 0
+    assert int(d.verify_keys(t1f.roll(1, 0).contiguous(), rho.roll(1, 0).contiguous(), msgs, sigs, siglens, fixed_len=64).sum()) == B
+    k, l = int(par[3]), int(par[4])
+    for i in (0, 7777, B - 1):
+        A = eng.expand_matrix(rho[i:i + 1], k * l, int(par[1]), int(par[2])).cpu().numpy().reshape(-1)
+        h = [x[i].cpu().numpy().reshape(-1) for x in (s1, s2, t, K, tr)]
+        d.set_privkey(h[0], h[1], h[2], h[3], h[4], A)
+        sg, ln, _ = d.sign(msgs[i:i + 1], fixed_len=64)
+        assert torch.equal(sg[0, :int(ln[0])], sigs[i, :int(siglens[i])])
+    d.close()

@@ -29,4 +29,10 @@ for name, fn in (('one key', lambda: d.verify(msgs, sigs, siglens, fixed_len=64)
     for _ in range(5):
         t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print(f'dilithium-III verify, {name}: batch {batch}, {min(ts) * 1e3:.2f} ms, {batch / min(ts):,.0f} verify/s')
+for name, fn in (('one key', lambda: d.sign(msgs, fixed_len=64)), ('key per item', lambda: d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64))):
+    fn(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    print(f'dilithium-III sign, {name}: batch {batch}, {min(ts) * 1e3:.2f} ms, {batch / min(ts):,.0f} sign/s')
 print(f'(keygen of {batch} keys: {tk * 1e3:.1f} ms)')
