@@ -1070,6 +1070,7 @@ static int gen_ensdlp(const char *dir)
     int rc = ensdlp_case(f, SC_SCHEME_SIG_ENS, "enssig0", 0, &param_ens_sig_0, 5);
     rc |= ensdlp_case(f, SC_SCHEME_SIG_DLP, "dlpsig1", 1, &param_dlp_sig_1, 4);
     rc |= ensdlp_case(f, SC_SCHEME_SIG_DLP, "dlpsig0", 0, &param_dlp_sig_0, 4);
+    rc |= ensdlp_case(f, SC_SCHEME_SIG_ENS, "enssig1", 1, &param_ens_sig_1, 3);
     fclose(f);
     return rc;
 }

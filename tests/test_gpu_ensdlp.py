@@ -23,7 +23,7 @@ def G():
     return load_golden('ensdlp_ref.txt')
 
 
-@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4), ('enssig1', 3)])
 def test_verdicts_match_reference_and_oracle(eng, G, tag, nmsg):
     import torch
     par, h = np.asarray(G[f'{tag}_params']), G[f'{tag}_h']
@@ -67,7 +67,7 @@ def _rows(items, stride):
     return buf, lens
 
 
-@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4), ('enssig1', 3)])
 @pytest.mark.parametrize("lanes", ["1", "4", "8", "16", ""])
 def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes, monkeypatch):
     """sc_hip_ens_dlp_sig_sign (Klein's sampler) byte for byte against the reference's signatures given its PRNG word
@@ -119,7 +119,7 @@ def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes, monkeyp
     s.close()
 
 
-@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)])
+@pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4), ('enssig1', 3)])
 def test_signer_keyed_from_private_key_alone(eng, G, tag, nmsg):
     """sc_hip_ens_dlp_signer_set_privkey derives the basis, its Gram-Schmidt matrix and the row norms from f | g | F | G itself (the product's own
     host code, not the oracle's): the reference's signatures come out byte for byte"""

@@ -8,7 +8,7 @@ import pytest
 from tests.golden_io import load_golden
 from tests import oracle_lib as O
 
-CASES = [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4)]
+CASES = [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4), ('enssig1', 3)]
 
 
 @pytest.fixture(scope='module')
