@@ -849,8 +849,8 @@ __global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
 // additions are the cost (every wavefront spends 2n of them per basis row whatever G is), so fewer lanes per signature = fewer wavefronts = less
 // work, as long as enough wavefronts remain to fill the SIMDs: the host picks G from the batch size, bounded below by 128 state registers per lane.
 // The basis row and the Gram-Schmidt row of a step are the same 16n bytes for every signature and known in advance: the wavefront fetches the NEXT
-// step's rows with 16-byte loads at the top of a step, parks them in registers while the sweep runs out of LDS (its private double buffer,
-// 2 x 16n bytes), and writes them to the other buffer afterwards - no load is waited on inside the sweep, which is fully unrolled (static
+// step's rows with 16-byte loads at the top of a step, parks them in registers while the sweep runs out of LDS (a double buffer of 2 x 16n bytes
+// shared by the workgroup's four wavefronts, each fetching a quarter), and writes them to the other buffer afterwards - no load is waited on inside the sweep, which is fully unrolled (static
 // register indices).
 template <int G>
 __device__ __forceinline__ float chain_g(float acc, float p)
@@ -860,13 +860,16 @@ __device__ __forceinline__ float chain_g(float acc, float p)
     return acc;                                                  // in the signature's last lane: acc_in(last lane) + p[0] + ... + p[G-1], left to right
 }
 
+constexpr int KW = 4;                      // wavefronts per workgroup: they share the LDS copy of the step's rows (loaded once, a quarter each)
+
 template <int G, int NCH>
-__global__ __launch_bounds__(64) void kleinr_kernel(KleinArgs A)
+__global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
 {
-    constexpr int n2 = NCH * G, n = n2 / 2, NV = n2 / 256, S = 16 / G;       // NV float4 per lane per row; S signatures per DPP row
-    __shared__ float4 rows[2][2][n2 / 4];                        // [buffer][basis | Gram-Schmidt][k / 4]
-    const uint32_t lane = threadIdx.x, r = (lane & 15) / S;
-    const uint32_t col = blockIdx.x * (64 / G) + (lane >> 4) * S + (lane & (S - 1));
+    constexpr int n2 = NCH * G, n = n2 / 2, S = 16 / G;          // S signatures per DPP row
+    constexpr int RV = n2 / 4, NV = (RV + 64 * KW - 1) / (64 * KW);      // float4 per row; per thread
+    __shared__ float4 rows[2][2][RV];                            // [buffer][basis | Gram-Schmidt][k / 4]
+    const uint32_t tid = threadIdx.x, lane = tid & 63, r = (lane & 15) / S;
+    const uint32_t col = (blockIdx.x * KW + (tid >> 6)) * (64 / G) + (lane >> 4) * S + (lane & (S - 1));
     const bool valid = col < A.batch;
     const uint32_t item = valid ? col : 0;
     const uint32_t *tape = A.tapes + (size_t)item * A.tape_stride;
@@ -889,8 +892,8 @@ __global__ __launch_bounds__(64) void kleinr_kernel(KleinArgs A)
         }
 #pragma unroll
         for (int i = 0; i < NV; i++) {
-            rows[1][0][lane + 64 * i] = bmat[(size_t)(n2 - 1) * (n2 / 4) + lane + 64 * i];
-            rows[1][1][lane + 64 * i] = gmat[(size_t)(n2 - 2) * (n2 / 4) + lane + 64 * i];
+            const uint32_t e = tid + 64 * KW * i;
+            if (e < RV) { rows[1][0][e] = bmat[(size_t)(n2 - 1) * RV + e]; rows[1][1][e] = gmat[(size_t)(n2 - 2) * RV + e]; }
         }
         __syncthreads();
     }
@@ -900,9 +903,9 @@ __global__ __launch_bounds__(64) void kleinr_kernel(KleinArgs A)
     for (int j = n2 - 1; j >= 0; j--) {
         const int buf = j & 1;                                   // n2 - 1 is odd: the first step reads buffer 1
         float4 pb[NV], pg[NV];                                   // rows of step j - 1: basis row j - 1, Gram-Schmidt row j - 2
-        const size_t rb = (size_t)(j > 0 ? j - 1 : 0) * (n2 / 4), rg = (size_t)(j > 1 ? j - 2 : 0) * (n2 / 4);
+        const size_t rb = (size_t)(j > 0 ? j - 1 : 0) * RV, rg = (size_t)(j > 1 ? j - 2 : 0) * RV;
 #pragma unroll
-        for (int i = 0; i < NV; i++) { pb[i] = bmat[rb + lane + 64 * i]; pg[i] = gmat[rg + lane + 64 * i]; }
+        for (int i = 0; i < NV; i++) { const uint32_t e = (tid + 64 * KW * i) % RV; pb[i] = bmat[rb + e]; pg[i] = gmat[rg + e]; }     // unconditional (wraps when RV < 256)
         const float inv = A.inv[j];
         const float d = __shfl(dot, (int)(lane | (16 - S))) * inv * inv;
         const uint2 w = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - j));
@@ -932,7 +935,10 @@ __global__ __launch_bounds__(64) void kleinr_kernel(KleinArgs A)
             dot = chain_g<G>(dot, (float)st[c] * grow[G * c]);
         }
 #pragma unroll
-        for (int i = 0; i < NV; i++) { rows[buf ^ 1][0][lane + 64 * i] = pb[i]; rows[buf ^ 1][1][lane + 64 * i] = pg[i]; }
+        for (int i = 0; i < NV; i++) {
+            const uint32_t e = tid + 64 * KW * i;
+            if (e < RV) { rows[buf ^ 1][0][e] = pb[i]; rows[buf ^ 1][1][e] = pg[i]; }
+        }
         __syncthreads();
     }
     if (valid) {
@@ -1442,13 +1448,13 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
         if ((v == 4 || v == 8 || v == 16) && v >= gmin) G = v;
     }
     if (in_regs) {
-        const dim3 grid((unsigned)(B / (64 / G)));
-        if (n == 256 && G == 4) hipLaunchKernelGGL((kleinr_kernel<4, 128>), grid, dim3(64), 0, s, A);
-        else if (n == 256 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 64>), grid, dim3(64), 0, s, A);
-        else if (n == 256) hipLaunchKernelGGL((kleinr_kernel<16, 32>), grid, dim3(64), 0, s, A);
-        else if (n == 512 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 128>), grid, dim3(64), 0, s, A);
-        else if (n == 512) hipLaunchKernelGGL((kleinr_kernel<16, 64>), grid, dim3(64), 0, s, A);
-        else hipLaunchKernelGGL((kleinr_kernel<16, 128>), grid, dim3(64), 0, s, A);
+        const dim3 grid((unsigned)((B / (64 / G) + KW - 1) / KW));
+        if (n == 256 && G == 4) hipLaunchKernelGGL((kleinr_kernel<4, 128>), grid, dim3(64 * KW), 0, s, A);
+        else if (n == 256 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 64>), grid, dim3(64 * KW), 0, s, A);
+        else if (n == 256) hipLaunchKernelGGL((kleinr_kernel<16, 32>), grid, dim3(64 * KW), 0, s, A);
+        else if (n == 512 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 128>), grid, dim3(64 * KW), 0, s, A);
+        else if (n == 512) hipLaunchKernelGGL((kleinr_kernel<16, 64>), grid, dim3(64 * KW), 0, s, A);
+        else hipLaunchKernelGGL((kleinr_kernel<16, 128>), grid, dim3(64 * KW), 0, s, A);
     }
     else hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
     HIPCHK(hipGetLastError());
