@@ -66,12 +66,19 @@ __global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, cons
     if (key >= count) return;
     rho += (size_t)key * 32; t1 += (size_t)key * len; out48 += (size_t)key * 48;
     for (int i = 0; i < 32; i++) sp.absorb_byte(rho[i]);
+    // the MSB-first bit string is cut into bytes; eight bytes at a time go into the state as one little-endian word (the stream stays 8-byte
+    // aligned: 32 bytes of rho, a rate of 17 words) instead of eight read-modify-write rounds on the LDS state
     uint32_t acc = 0; int nb = 0;
+    uint64_t word = 0; int wb = 0;
     for (uint32_t i = 0; i < len; i++) {
         acc = (acc << bits) | ((uint32_t)t1[i] & ((1u << bits) - 1)); nb += bits;
-        while (nb >= 8) { sp.absorb_byte((uint8_t)(acc >> (nb - 8))); nb -= 8; }
+        while (nb >= 8) {
+            word |= (uint64_t)(uint8_t)(acc >> (nb - 8)) << (8 * wb); nb -= 8;
+            if (++wb == 8) { sp.absorb_u64(word); word = 0; wb = 0; }
+        }
         acc &= (1u << nb) - 1;
     }
+    for (int i = 0; i < wb; i++) sp.absorb_byte((uint8_t)(word >> (8 * i)));
     if (nb) sp.absorb_byte((uint8_t)(acc << (8 - nb)));
     sp.finalize();
     for (int i = 0; i < 48; i++) out48[i] = sp.squeeze_byte();
