@@ -424,6 +424,7 @@ extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
     if (mode == MODE_MAD && (uint64_t)p->q >= (1ull << 14)) return fail("plan_set_arith: the multiply-add path needs q < 2^14");
     if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD) return fail("plan_set_arith: mode must be 0, 1, 2, 3 or 4");
+    if (mode != p->mode && p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }     // a captured loop holds the old kernel
     p->mode = mode;
     return SC_HIP_SUCCESS;
 }

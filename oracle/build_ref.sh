@@ -26,7 +26,8 @@ fi
 rm -rf "$B"; mkdir -p "$B/gen/utils/arith" "$B/obj" "$OUT"
 CC="${CC:-gcc}"
 DEFS="-D_GNU_SOURCE -DHAVE_64BIT -DHAVE_128BIT -DUSE_SAFECRYPTO_INTEGER_MP -DUSE_SAFECRYPTO_FLOAT_MP \
- -DSHA3_UNROLLED -DHAVE___BUILTIN_CTZ -DHAVE___BUILTIN_CLZ -DCONFIGURE_INVOCATION=\"manual\" -DECRYPT_API=\"ecrypt-sync.h\""
+ -DSHA3_UNROLLED -DHAVE___BUILTIN_CTZ -DHAVE___BUILTIN_CLZ -DCONFIGURE_INVOCATION=\"manual\" -DECRYPT_API=\"ecrypt-sync.h\" \
+ -DNTT_NEEDS_16813057 -DNTT_NEEDS_134348801"   # the last two: keep the tables of the DLP-IBE expanded sets 6 / 7 in the library (fixtures only)
 INC="-I$B/gen -I$B/gen/utils/arith -I$REF/src/utils/arith -I$REF/include -I$REF/src -I$REF/src/utils/crypto -I$REF"
 CFLAGS="-O2 -std=gnu11 -fcommon -fPIC -w $DEFS $INC"
 

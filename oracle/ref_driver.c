@@ -26,6 +26,9 @@
 #define NTT_NEEDS_12289
 #define NTT_NEEDS_8399873
 #define NTT_NEEDS_51750913
+#define NTT_NEEDS_4206593
+#define NTT_NEEDS_16813057
+#define NTT_NEEDS_134348801
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -180,10 +183,13 @@ static int gen_ntt_large(const char *dir)
     snprintf(path, sizeof path, "%s/ntt_large_ref.txt", dir);
     FILE *f = fopen(path, "w");
     if (!f) return 1;
-    const struct { int32_t q; int n; const SINT32 *w, *r; } cf[2] = {
-        { 51750913, 512, w51750913_n512, r51750913_n512 }, { 51750913, 1024, w51750913_n1024, r51750913_n1024 } };
+    /* every modulus the `_large` transforms are used with: ring-TESLA-1 / DLP-IBE 2, 5 (26 bits), DLP-IBE 0, 1 (23 bits), 6 (25 bits), 7 (28 bits) */
+    const struct { int32_t q; int n; const SINT32 *w, *r; } cf[6] = {
+        { 51750913, 512, w51750913_n512, r51750913_n512 }, { 51750913, 1024, w51750913_n1024, r51750913_n1024 },
+        { 4206593, 512, w4206593_n512, r4206593_n512 }, { 4206593, 1024, w4206593_n1024, r4206593_n1024 },
+        { 16813057, 512, w16813057_n512, r16813057_n512 }, { 134348801, 1024, w134348801_n1024, r134348801_n1024 } };
     const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < 6; c++) {
         const int q = cf[c].q, n = cf[c].n, NP = 2;
         ntt_params_t p; init_reduce(&p, n, q);
         int32_t *a = malloc(sizeof(int32_t) * n * NP), *b = malloc(sizeof(int32_t) * n * NP), *o = malloc(sizeof(int32_t) * n * NP), *fa = malloc(sizeof(int32_t) * n), *fb = malloc(sizeof(int32_t) * n);

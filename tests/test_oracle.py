@@ -135,7 +135,7 @@ def test_cdt_table_and_samples_vs_reference(tag, tail, sigma):
     assert np.abs(v).max() < cdf.size          # unit_sampling.c:194-222 bound
 
 
-@pytest.mark.parametrize('q,n', [(51750913, 512), (51750913, 1024)])
+@pytest.mark.parametrize('q,n', [(51750913, 512), (51750913, 1024), (4206593, 512), (4206593, 1024), (16813057, 512), (134348801, 1024)])
 def test_large_modulus_variants_vs_reference(q, n):
     """fwd_ntt_32_32_large / inv_ntt_32_32_large of the reference (26-bit modulus, ENS / DLP / ring-TESLA-1) - the oracle's
     transforms are the same functions mod q, compared after normalize_32 (tests/golden/ntt_large_ref.txt)"""
