@@ -988,6 +988,7 @@ static int gen_dlp(const char *dir)
     FILE *f = fopen(path, "w");
     if (!f) return 1;
     int rc = dlp_case(f, 0, 4);
+    rc |= dlp_case(f, 1, 4);                                           /* n = 1024 */
     fclose(f);
     return rc;
 }

@@ -12,25 +12,27 @@ def G():
     return load_golden('dlp_ref.txt')
 
 
-def test_extract_matches_reference(G):
-    par = G['dlp0_params']
-    tree = np.asarray(G['dlp0_tree'], dtype=np.int64).view(np.float64)
+@pytest.mark.parametrize('T', ['dlp0', 'dlp1'])
+def test_extract_matches_reference(G, T):
+    par = G[T + '_params']
+    tree = np.asarray(G[T + '_tree'], dtype=np.int64).view(np.float64)
     for m in range(4):
-        ident = bytes(np.asarray(G[f'dlp0_id{m}'], dtype=np.uint8))
-        rc, sk = O.dlp_extract(par, tree, ident, G[f'dlp0_tape{m}'])
-        assert rc == 0 and sk == bytes(np.asarray(G[f'dlp0_sk{m}'], dtype=np.uint8)), m
-    assert O.dlp_extract(par, tree, ident, G['dlp0_tape3'][:100])[0] != 0
+        ident = bytes(np.asarray(G[f'{T}_id{m}'], dtype=np.uint8))
+        rc, sk = O.dlp_extract(par, tree, ident, G[f'{T}_tape{m}'])
+        assert rc == 0 and sk == bytes(np.asarray(G[f'{T}_sk{m}'], dtype=np.uint8)), m
+    assert O.dlp_extract(par, tree, ident, G[T + '_tape3'][:100])[0] != 0
 
 
-def test_encrypt_decrypt_match_reference(G):
-    par = G['dlp0_params']
+@pytest.mark.parametrize('T', ['dlp0', 'dlp1'])
+def test_encrypt_decrypt_match_reference(G, T):
+    par = G[T + '_params']
     for m in range(4):
-        ident = bytes(np.asarray(G[f'dlp0_id{m}'], dtype=np.uint8))
-        msg = bytes(np.asarray(G[f'dlp0_msg{m}'], dtype=np.uint8))
-        ref = bytes(np.asarray(G[f'dlp0_ct{m}'], dtype=np.uint8))
-        rc, ct = O.dlp_encrypt(par, G['dlp0_h_ntt'], ident, msg, G[f'dlp0_etape{m}'])
+        ident = bytes(np.asarray(G[f'{T}_id{m}'], dtype=np.uint8))
+        msg = bytes(np.asarray(G[f'{T}_msg{m}'], dtype=np.uint8))
+        ref = bytes(np.asarray(G[f'{T}_ct{m}'], dtype=np.uint8))
+        rc, ct = O.dlp_encrypt(par, G[T + '_h_ntt'], ident, msg, G[f'{T}_etape{m}'])
         assert rc == 0 and ct == ref, m
-        rc, dec = O.dlp_decrypt(par, G[f'dlp0_uk_ntt{m}'], ref)
-        assert rc == 0 and dec == bytes(np.asarray(G[f'dlp0_dec{m}'], dtype=np.uint8)) == msg, m
-    assert O.dlp_encrypt(par, G['dlp0_h_ntt'], ident, msg, G['dlp0_etape3'][:50])[0] == 2
-    assert O.dlp_decrypt(par, G['dlp0_uk_ntt3'], ref[:-1])[0] == 1
+        rc, dec = O.dlp_decrypt(par, G[f'{T}_uk_ntt{m}'], ref)
+        assert rc == 0 and dec == bytes(np.asarray(G[f'{T}_dec{m}'], dtype=np.uint8)) == msg, m
+    assert O.dlp_encrypt(par, G[T + '_h_ntt'], ident, msg, G[T + '_etape3'][:50])[0] == 2
+    assert O.dlp_decrypt(par, G[T + '_uk_ntt3'], ref[:-1])[0] == 1
