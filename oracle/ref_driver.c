@@ -506,6 +506,8 @@ static int gen_bliss(const char *dir)
     if (!f) return 1;
     int rc = bliss_case(f, 1, 9);
     rc |= bliss_keygen_case(f, 1, 4);
+    rc |= bliss_case(f, 3, 4);                                         /* BLISS-B-III and -IV: other kappa, sigma, d, p, bounds */
+    rc |= bliss_case(f, 4, 4);
     fclose(f);
     return rc;
 }

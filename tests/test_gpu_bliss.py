@@ -173,3 +173,40 @@ def test_keygen_reproduces_reference_and_oracle(eng, G):
     sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
     assert O.bliss_verify(key, bytes(msgs[0].cpu().numpy()), bytes(sh[0, :lh[0]])) == 0
     b.close()
+
+
+@pytest.mark.parametrize('tag', ['bliss3', 'bliss4'])
+def test_other_parameter_sets(eng, G, tag):
+    """BLISS-B-III and -IV (kappa 30 / 39, sigma 250 / 271, d 9 / 8, other norm bounds): the reference's signatures and attempts from its tapes,
+    seeded tapes against the oracle, device verdicts against the reference's and the oracle's"""
+    import torch
+    key = O.BlissKey.from_golden(G, tag)
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    cs = cases(G, tag)
+    rng = np.random.default_rng(31)
+    ms = [c[0] for c in cs] + [bytes(rng.integers(0, 256, size=int(rng.integers(1, 90)), dtype=np.uint8)) for _ in range(60)]
+    ts = [c[1] for c in cs] + [rng.integers(0, 1 << 32, size=6200, dtype=np.uint64).astype(np.uint32) for _ in range(60)]
+    width = max(len(t) for t in ts) + 8
+    msgs, mlens, tapes, tlens = pack(ms, ts, width)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    torch.cuda.synchronize()
+    sh, lh, st, tr = sigs.cpu().numpy(), siglens.cpu().numpy(), status.cpu().tolist(), trials.cpu().tolist()
+    for i, (_, _, sig, t) in enumerate(cs):
+        assert st[i] == 1 and bytes(sh[i, :lh[i]]) == sig and tr[i] == t, i
+    for i in range(len(cs), len(ms)):
+        rc, want, wt, _ = O.bliss_sign(key, ms[i], ts[i])
+        assert (st[i] == 1) == (rc == 0), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == want and tr[i] == wt, i
+    ok = [i for i in range(len(ms)) if st[i] == 1]
+    assert len(ok) > len(ms) * 3 // 4
+    v = b.verify(msgs, sigs, siglens, mlens=mlens).cpu().tolist()
+    assert all(v[i] == 0 for i in ok)
+    bad = sigs.clone(); bad[:, int(lh[0]) // 3] ^= 0x04
+    vb = b.verify(msgs, bad, siglens, mlens=mlens).cpu().tolist()
+    bh = bad.cpu().numpy()
+    for i in ok[:16]:
+        assert vb[i] == O.bliss_verify(key, ms[i], bytes(bh[i, :lh[i]])), i
+    for i in range(len(cs)):
+        assert vb[i] == int(G[f'{tag}_verify'][2 * i + 1])
+    b.close()

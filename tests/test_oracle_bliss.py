@@ -59,3 +59,15 @@ def test_keygen_matches_reference(G):
         atts.append(att)
     assert atts[:3] == [1, 1, 1] and atts[3] > 1
     assert O.bliss_keygen(par, nz, G['bliss1_kg_tape3'][:500])[0] == 2
+
+
+@pytest.mark.parametrize('tag', ['bliss3', 'bliss4'])
+def test_other_parameter_sets_match_reference(G, tag):
+    """BLISS-B-III and -IV (other kappa, sigma, d, p and norm bounds): the reference's signatures, attempts, word consumption and verdicts"""
+    key = O.BlissKey.from_golden(G, tag)
+    for i, m, tape, sig, trials in cases(G, tag):
+        rc, got, tr, used = O.bliss_sign(key, m, tape)
+        assert rc == 0 and got == sig and tr == trials and used == len(tape), i
+        assert O.bliss_verify(key, m, sig) == int(G[f'{tag}_verify'][2 * i]) == 0
+        bad = bytearray(sig); bad[len(bad) // 3] ^= 0x04
+        assert O.bliss_verify(key, m, bytes(bad)) == int(G[f'{tag}_verify'][2 * i + 1])
