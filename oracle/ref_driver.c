@@ -376,6 +376,8 @@ static int gen_dilithium(const char *dir)
     if (!f) return 1;
     int rc = dilithium_case(f, 3, 12);
     rc |= dilithium_case(f, 1, 4);
+    rc |= dilithium_case(f, 0, 3);                                     /* the remaining sets: (k, l) = (3, 2) and (5, 4) */
+    rc |= dilithium_case(f, 2, 3);
     fclose(f);
     return rc;
 }
@@ -668,6 +670,7 @@ static int gen_kyber(const char *dir)
     if (!f) return 1;
     int rc = kyber_case(f, 1, 6);
     rc |= kyber_case(f, 2, 2);
+    rc |= kyber_case(f, 0, 2);                                         /* k = 2 */
     fclose(f);
     return rc;
 }

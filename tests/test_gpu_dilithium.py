@@ -52,7 +52,7 @@ def test_device_xof_is_the_references_permutation(eng):
                                              'dba6b1551cd5eac169615555dbf22a67')     # captured from the reference build
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_sign_reproduces_reference_signatures(eng, G, tag):
     key = O.DilKey.from_golden(G, tag)
     d = make(eng, key)
@@ -64,7 +64,7 @@ def test_sign_reproduces_reference_signatures(eng, G, tag):
     d.close()
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_verify_matches_reference_verdicts(eng, G, tag):
     key = O.DilKey.from_golden(G, tag)
     d = make(eng, key)
@@ -125,7 +125,7 @@ def test_device_buffers_full_config3_properties(eng, G):
     d.close()
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_keygen_vs_reference(eng, tag):
     """batched key generation from per-key seeds: the reference's key pair for the fixture's seeds, the oracle's on a seeded batch,
     and a generated key signs and verifies (matrix expanded from its rho on the device)"""
@@ -185,7 +185,7 @@ def _sign_under_generated_keys(eng, par, eb, nkeys, per_key, seed):
     return d, keys, msgs, sigs, siglens, t1_items, rho_items
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_verify_under_distinct_keys(eng, G, tag):
     """sc_hip_dilithium_verify_keys: every item carries its own public key (t1, rho); the matrix, tr and NTT(t1 2^d) are derived per item on the
     device.  Signatures made under 11 generated keys verify; tampered signatures / messages and a signature presented with ANOTHER item's key get
@@ -227,7 +227,7 @@ def test_verify_distinct_keys_full_config3(eng, G):
     d.close()
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_sign_under_distinct_keys(eng, G, tag):
     """sc_hip_dilithium_sign_keys: every message under its own private key (the key generator's output buffers go straight in).  Byte for byte the
     oracle's signature under that key, attempts included; ragged message lengths; then the distinct-key verifier accepts all of them."""

@@ -24,7 +24,7 @@ def make(eng, G, tag):
     return ky
 
 
-@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2), ('kyber0', 2)])
 def test_enc_dec_vs_reference(eng, tag, nmsg):
     import torch
     G = load_golden('kyber_ref.txt')
@@ -62,7 +62,7 @@ def test_batch_vs_oracle_and_roundtrip(eng):
     ky.close()
 
 
-@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2), ('kyber0', 2)])
 def test_kem_vs_reference(eng, tag, nmsg):
     """safecrypto_encapsulation / safecrypto_decapsulation on the device: G hash, DRBG oracle bytes and noise, CPA encryption,
     H hash, packing - the reference's ciphertext bytes and shared keys for the same key pair and m"""
@@ -105,7 +105,7 @@ def test_kem_batch_vs_oracle(eng):
     ky.close()
 
 
-@pytest.mark.parametrize('tag', ['kyber1', 'kyber2'])
+@pytest.mark.parametrize('tag', ['kyber1', 'kyber2', 'kyber0'])
 def test_keygen_vs_reference(eng, tag):
     """batched key generation from per-key seeds: every component of the reference's key pair for the fixture's seeds, the oracle's
     on a seeded batch, and a generated key pair encapsulates / decapsulates"""

@@ -40,7 +40,7 @@ def test_reference_permutation_known_answer():
     assert out != hashlib.shake_256(msg).digest(64)
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_key_consistency(G, tag):
     """t1 of the public key is decompose(t) and tr = CRH(rho, t1) (dilithium.c keygen, module_lwe.c:140-180)"""
     key = O.DilKey.from_golden(G, tag)
@@ -54,7 +54,7 @@ def test_key_consistency(G, tag):
     assert np.array_equal(tr, key.tr)
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_sign_reproduces_reference_signatures(G, tag):
     key = O.DilKey.from_golden(G, tag)
     for i, m, sig in msgs(G, tag):
@@ -63,7 +63,7 @@ def test_sign_reproduces_reference_signatures(G, tag):
         assert trials == int(G[f'{tag}_trials'][i])
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_verify_matches_reference_verdicts(G, tag):
     key = O.DilKey.from_golden(G, tag)
     for i, m, sig in msgs(G, tag):
@@ -74,7 +74,7 @@ def test_verify_matches_reference_verdicts(G, tag):
         assert O.dilithium_verify(key, m + b'x', sig) == 1
 
 
-@pytest.mark.parametrize('tag', ['dil3', 'dil1'])
+@pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_keygen_vs_reference(tag):
     """safecrypto_keygen with the context CSPRNG seeded: s1, s2, t, rho, K, tr, t1 of the reference's key pair"""
     G = load_golden('dilithium_ref.txt')

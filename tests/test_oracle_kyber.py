@@ -7,7 +7,7 @@ from tests.golden_io import load_golden
 from tests import oracle_lib as O
 
 
-@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2), ('kyber0', 2)])
 def test_enc_dec_vs_reference(tag, nmsg):
     G = load_golden('kyber_ref.txt')
     par = G[f'{tag}_params']
@@ -18,7 +18,7 @@ def test_enc_dec_vs_reference(tag, nmsg):
         assert np.array_equal(m, G[f'{tag}_dec{i}']) and np.array_equal(m, G[f'{tag}_m{i}'])
 
 
-@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2)])
+@pytest.mark.parametrize('tag,nmsg', [('kyber1', 6), ('kyber2', 2), ('kyber0', 2)])
 def test_kem_vs_reference(tag, nmsg):
     """safecrypto_encapsulation / safecrypto_decapsulation: ciphertext bytes and shared keys for the same key pair and m"""
     G = load_golden('kyber_ref.txt')
@@ -33,7 +33,7 @@ def test_kem_vs_reference(tag, nmsg):
         assert O.kyber_kem_dec(*args, bytes(bad)) == u8(G[f'{tag}_kem_decbad{i}'])
 
 
-@pytest.mark.parametrize('tag', ['kyber1', 'kyber2'])
+@pytest.mark.parametrize('tag', ['kyber1', 'kyber2', 'kyber0'])
 def test_keygen_vs_reference(tag):
     """safecrypto_keygen with the context CSPRNG seeded: every component of the key pair; and the matrix expansion from rho"""
     G = load_golden('kyber_ref.txt')
