@@ -901,6 +901,8 @@ static int gen_ens(const char *dir)
     if (!f) return 1;
     int rc = ens_case(f, 0, 5);
     rc |= ens_case(f, 2, 3);
+    rc |= ens_case(f, 1, 3);                                           /* the other coefficient distributions of each ring */
+    rc |= ens_case(f, 3, 3);
     fclose(f);
     return rc;
 }

@@ -9,7 +9,7 @@ from tests import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
-CASES = [('ens0', 5), ('ens2', 3)]
+CASES = [('ens0', 5), ('ens2', 3), ('ens1', 3), ('ens3', 3)]
 
 
 @pytest.fixture(scope='module')

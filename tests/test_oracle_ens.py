@@ -6,7 +6,7 @@ import pytest
 from tests.golden_io import load_golden
 from tests import oracle_lib as O
 
-CASES = [('ens0', 5), ('ens2', 3)]
+CASES = [('ens0', 5), ('ens2', 3), ('ens1', 3), ('ens3', 3)]
 
 
 @pytest.fixture(scope='module')
