@@ -89,10 +89,6 @@ int sc_hip_polymul_ntt(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, co
 /* fused product of two coefficient-domain polynomials: out = a*b mod (x^n+1, q), canonical
  * (fwd, fwd, mul_32_pointwise, inv: ring_tesla.c:752-910 pattern). */
 int sc_hip_polymul(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream);
-/* `steps` back-to-back sc_hip_polymul_ntt calls on the same buffers as ONE HIP graph launch (captured on first use for these arguments, cached in
- * the plan, replayed afterwards); `stream` must not be the null stream.  Falls back to the plain loop if the capture is refused.  For launch-bound
- * loops: at ~37 us per kernel the host cost of a plain call is ~5 % of the wall time. */
-int sc_hip_polymul_ntt_steps(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, int steps, void *stream);
 
 /* replaces: normalize_32 / center_32 (ntt_template.c.in:1777-1901), in place allowed */
 int sc_hip_normalize(sc_hip_plan_t *plan, size_t len, const int32_t *d_in, int32_t *d_out, void *stream);
@@ -424,6 +420,10 @@ int  sc_hip_falcon_set_privkey(sc_hip_falcon_t *h, const double *sk);
 /* pk: h in the coefficient domain, SINT16[n] (first half of sc->pubkey->key, falcon.c:772-780) */
 int  sc_hip_falcon_set_pubkey(sc_hip_falcon_t *h, const int16_t *pk);
 size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *h);      /* n * (q_bits - 2) / 8 */
+/* how the tree sampler is laid over the machine; results are identical (the same double operations in the same order).  0 (default) = 64:
+ * a wavefront owns 8 signatures, tree levels below 128 coefficients in LDS; 1: a lane per signature, 8: 8 lanes per signature, working
+ * polynomials interleaved across the batch in HBM (the first generation, kept for comparison and for the parity tests) */
+int  sc_hip_falcon_set_mapping(sc_hip_falcon_t *h, int lanes);
 
 /* replaces: gaussian_sample_with_tree (src/utils/arith/gpv.c:2961-3090, ter == 0) for `batch` targets d_c int32 [batch][n].
  * Randomness as for BLISS: d_tapes uint32 [batch][tape_stride] holds each target's CSPRNG pool words (4n are consumed:
@@ -521,11 +521,6 @@ int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *h, size_t batch, const int32_
                                const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
 
-/* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation
- * tinysha3.c runs under -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h);
- * standard != 0 selects the FIPS 202 permutation instead.  Test hook. */
-int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *h_in, size_t len, uint8_t *h_out, size_t outlen);
-
 /* ---- host-buffer convenience (H2D, kernel, D2H; synchronous) ---------------------------- */
 int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
 int sc_hip_ntt_inv_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
@@ -537,13 +532,6 @@ int sc_hip_center_host(sc_hip_plan_t *plan, size_t len, const int32_t *h_in, int
 int sc_hip_ntt_invert_host(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *h_v, int32_t *h_rc);
 int sc_hip_ntt_div_host(sc_hip_plan_t *plan, size_t batch, size_t n, int32_t *h_num, const int32_t *h_den, int32_t *h_rc);
 int sc_hip_mult_sparse_host(sc_hip_ctx_t *ctx, size_t batch, int n, int omega, const void *h_t, int t_is_16, const int32_t *h_pos, int32_t *h_out);
-
-/* ---- timing helper ---------------------------------------------------------------------- */
-/* Runs `iters` back-to-back launches of one op (0 fwd, 1 inv, 2 polymul_ntt, 3 polymul) on
- * `stream`, bracketed by hipEvents recorded on that same stream; returns the average
- * per-launch milliseconds in *ms.  Used by bench.py for the roofline figure. */
-int sc_hip_time_op(sc_hip_plan_t *plan, int op, size_t batch, const int32_t *d_a, const int32_t *d_b,
-                   int32_t *d_out, void *stream, int iters, float *ms);
 
 #ifdef __cplusplus
 }

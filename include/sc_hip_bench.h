@@ -1,0 +1,37 @@
+/*
+ * sc_hip_bench.h - measurement and self-test hooks of libsc_hip.so.  NOT part of the drop-in ABI (include/sc_hip.h,
+ * include/sc_hip_vtable.h): nothing here replaces a reference interface, a libsafecrypto integration never calls these.
+ * They exist for bench.py, tools/ and tests/ and may change between rounds.
+ */
+#ifndef SC_HIP_BENCH_H
+#define SC_HIP_BENCH_H
+#include "sc_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* `steps` back-to-back sc_hip_polymul_ntt calls on the same buffers as ONE HIP graph launch (captured on first use for these arguments,
+ * cached in the plan, replayed afterwards); `stream` must not be the null stream and d_out must not alias an input.  Falls back to the
+ * plain loop if the capture is refused.  For launch-bound loops: at ~37 us per kernel the host cost of a plain call is ~5 % of the wall
+ * time.  Calls on one plan must not overlap (the cached graph belongs to the plan). */
+int sc_hip_polymul_ntt_steps(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, int steps, void *stream);
+
+/* Runs `iters` back-to-back launches of one op (0 fwd, 1 inv, 2 polymul_ntt, 3 polymul) on `stream`, bracketed by hipEvents recorded on
+ * that same stream; returns the average per-launch milliseconds in *ms.  bench.py's roofline figure. */
+int sc_hip_time_op(sc_hip_plan_t *plan, int op, size_t batch, const int32_t *d_a, const int32_t *d_b,
+                   int32_t *d_out, void *stream, int iters, float *ms);
+
+/* the reference's XOF on the device (src/utils/crypto/xof.c: SHAKE128/256 framing around the permutation tinysha3.c runs under
+ * -DSHA3_UNROLLED, which is not Keccak-f[1600] - see csrc/keccak_dev.h); standard != 0 selects the FIPS 202 permutation instead
+ * (self-test of the sponge framing against hashlib) */
+int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *h_in, size_t len, uint8_t *h_out, size_t outlen);
+
+/* the default mapping of the Falcon tree sampler with per-phase cycle counters: h_cycles[6] = shader cycles summed over the wavefronts for
+ * transform + targets | tree levels in HBM | the level-128 node | tree levels in LDS | register sub-trees | lattice point + inverse transforms */
+int sc_hip_falcon_sample_profile(sc_hip_falcon_t *h, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride,
+                                 int32_t *d_s1, int32_t *d_s2, unsigned long long *h_cycles, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SC_HIP_BENCH_H */

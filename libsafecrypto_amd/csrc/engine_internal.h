@@ -1,6 +1,7 @@
 // engine_internal.h - host-side structures shared by the translation units of libsc_hip.so.
 #pragma once
 #include "../../include/sc_hip.h"
+#include "../../include/sc_hip_bench.h"
 #include "modarith.h"
 
 #include <hip/hip_runtime.h>

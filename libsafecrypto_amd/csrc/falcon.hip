@@ -66,15 +66,26 @@ __device__ __forceinline__ double cdt_pick(const uint64_t *__restrict__ cdf, uin
     return (double)v;
 }
 
-struct Leaf {                 // leaf tables in visiting order + this signature's word stream
+template <int TSL>
+struct Leaf {                 // leaf tables in visiting order + this signature's word stream (both read where they lie, in HBM / L2)
     const uint64_t *__restrict__ tabs;
     const uint32_t *__restrict__ tape;
     uint32_t idx;
+    // the leaf's two samples (gpv.c:2671-2686: two prng_64, high word first) and on to the next leaf
+    __device__ __forceinline__ void pick2(double &d0, double &d1)
+    {
+        const uint64_t *cdf = tabs + ((size_t)idx << TSL);
+        const uint4 w = *reinterpret_cast<const uint4 *>(tape + 4 * (size_t)idx);      // tape rows are 16-byte aligned
+        const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
+        d0 = cdt_pick<TSL>(cdf, x0);
+        d1 = cdt_pick<TSL>(cdf, x1);
+        idx++;
+    }
 };
 
 // ---- register-resident bottom of the tree (gpv.c:2663-2714 on 2^L coefficients) ------------------------------------
 
-template <int L, int TSL> struct FFS {
+template <int L, class LF> struct FFS {
     static constexpr int N = 1 << L, HN = N / 2, QN = HN / 2;
     static __device__ __forceinline__ void split(double (&f0)[HN], double (&f1)[HN], const double (&f)[N], const double *__restrict__ gm)
     {
@@ -102,11 +113,11 @@ template <int L, int TSL> struct FFS {
         }
     }
     static __device__ __forceinline__ void run(double (&z0)[N], double (&z1)[N], const double *__restrict__ tree, const double (&t0)[N], const double (&t1)[N],
-                                               const double *__restrict__ gm, Leaf &lf)
+                                               const double *__restrict__ gm, LF &lf)
     {
         double a0[HN], a1[HN], w0[HN], w1[HN], tmp[N];
         split(a0, a1, t1, gm);
-        FFS<L - 1, TSL>::run(w0, w1, tree + N + treesize(L - 1), a0, a1, gm, lf);
+        FFS<L - 1, LF>::run(w0, w1, tree + N + treesize(L - 1), a0, a1, gm, lf);
         merge(z1, w0, w1, gm);
 #pragma unroll
         for (int u = 0; u < HN; u++) {
@@ -115,21 +126,19 @@ template <int L, int TSL> struct FFS {
             tmp[u] = tr + t0[u]; tmp[u + HN] = ti + t0[u + HN];
         }
         split(a0, a1, tmp, gm);
-        FFS<L - 1, TSL>::run(w0, w1, tree + N, a0, a1, gm, lf);
+        FFS<L - 1, LF>::run(w0, w1, tree + N, a0, a1, gm, lf);
         merge(z0, w0, w1, gm);
     }
 };
 
-template <int TSL> struct FFS<0, TSL> {
+template <class LF> struct FFS<0, LF> {
     static __device__ __forceinline__ void run(double (&z0)[1], double (&z1)[1], const double *__restrict__, const double (&t0)[1], const double (&t1)[1],
-                                               const double *__restrict__, Leaf &lf)
+                                               const double *__restrict__, LF &lf)
     {
-        const uint64_t *cdf = lf.tabs + ((size_t)lf.idx << TSL);
-        const uint4 w = *reinterpret_cast<const uint4 *>(lf.tape + 4 * (size_t)lf.idx);      // tape rows are 16-byte aligned
-        const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
-        z0[0] = floor(t0[0]) + cdt_pick<TSL>(cdf, x0);
-        z1[0] = floor(t1[0]) + cdt_pick<TSL>(cdf, x1);
-        lf.idx++;
+        double p0, p1;
+        lf.pick2(p0, p1);
+        z0[0] = floor(t0[0]) + p0;
+        z1[0] = floor(t1[0]) + p1;
     }
 };
 
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
     sweep_sync<G>();
 
     // ---- fast Fourier sampling, depth first, the second-half tree (tree1) before the first (gpv.c:2693-2711)
-    Leaf lf = { tabs, tapes + (size_t)b * tape_stride, 0 };
+    Leaf<TSL> lf = { tabs, tapes + (size_t)b * tape_stride, 0 };
     Walk w = { n, logn, 0 };
     uint32_t toff = 0;                           // offset of the current node's tree block
     int l = logn;
@@ -405,8 +414,8 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
                     const uint32_t pt0 = w.t0(l), pt1 = w.t1(l), pz0 = w.z0(l), pz1 = w.z1(l);
 #pragma unroll
                     for (int i = 0; i < (1 << FK); i++) { t0r[i] = col.ld(pt0 + i); t1r[i] = col.ld(pt1 + i); }
-                    Leaf mine = lf;                                    // a copy: lf.idx stays wave-uniform (scalar table loads)
-                    FFS<FK, TSL>::run(z0r, z1r, tree + toff, t0r, t1r, gm, mine);
+                    Leaf<TSL> mine = lf;                               // a copy: lf.idx stays wave-uniform (scalar table loads)
+                    FFS<FK, Leaf<TSL>>::run(z0r, z1r, tree + toff, t0r, t1r, gm, mine);
 #pragma unroll
                     for (int i = 0; i < (1 << FK); i++) { col.st(pz0 + i, z0r[i]); col.st(pz1 + i, z1r[i]); }
                 }
@@ -509,6 +518,520 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
             o2[i] = (int32_t)-r1;
         }
     }
+}
+
+// ---- the production form for batches up to a few tens of thousands: 8 signatures per wavefront, the lower tree in LDS ---------------------
+//
+// A wavefront owns 8 signatures from beginning to end.  Their working polynomials live in HBM in the plain layout (signature b's element e at
+// ws[b*6n + e]) and are touched in two ways:
+//   * WAVE mode - all 64 lanes sweep the 8 signatures' polynomials as one index space (signature-major, so every access of the wavefront is
+//     one contiguous run inside one signature) - for everything that is >= 64 wide: the three transforms, the basis products and the tree
+//     levels above LM (qn = 2^(l-2) >= 64 pairs per sweep).
+//   * GROUP mode - 8 lanes per signature, 8 signatures side by side - for the tree from level LM down, whose whole state (the children's
+//     inputs and outputs of every level below LM: 3 * 2^LM doubles per signature) lives in LDS: the ~120 node visits below LM, three dependent
+//     sweeps each, pay LDS latency instead of an HBM round trip, and none of their traffic reaches HBM.  Only the level-LM node's own targets
+//     (read) and results (written) are in HBM.  The 8-coefficient sub-trees at the bottom run in registers, the same on every lane of a group.
+// Per signature the tree therefore moves 9 rows of n doubles through HBM per level ABOVE LM only (3 levels for n = 1024, 2 for n = 512)
+// instead of 7 / 6 levels.  Values are computed by the same operations in the same order as in the other mappings: the doubles are unchanged.
+constexpr int LM = 7;                          // sub-tree level whose descendants live in LDS
+constexpr int SPW = 8;                         // signatures per wavefront (= 64 / lanes per signature in group mode)
+constexpr int LDS_SIG = 3 << LM;               // doubles of LDS per signature: X (2^LM: the level-LM node's children's inputs) | scratch (2 * 2^LM)
+
+struct Lin {                                   // plain layout in HBM
+    double *p;
+    __device__ __forceinline__ double ld(uint32_t e) const { return p[e]; }
+    __device__ __forceinline__ void st(uint32_t e, double v) const { p[e] = v; }
+};
+struct LdsG {                                  // LDS, group mode: element e of the lane's signature s at (e / 8) * 64 + s * 8 + e % 8 (p = base + s * 8):
+    double *p;                                 // the 8 lanes of a group on 8 consecutive elements + 8 groups = 64 consecutive doubles
+    __device__ __forceinline__ uint32_t at(uint32_t e) const { return ((e >> 3) << 6) | (e & 7); }
+    __device__ __forceinline__ double ld(uint32_t e) const { return p[at(e)]; }
+    __device__ __forceinline__ void st(uint32_t e, double v) const { p[at(e)] = v; }
+};
+
+struct LdsF {                                  // LDS, wave mode: a polynomial being transformed; one double of padding after every 8 keeps the three
+    double *p;                                 // access patterns of the radix-8 passes (strides 64, 8 and 1 complex points) off each other's banks
+    __device__ __forceinline__ uint32_t at(uint32_t e) const { return e + (e >> 3); }
+    __device__ __forceinline__ double ld(uint32_t e) const { return p[at(e)]; }
+    __device__ __forceinline__ void st(uint32_t e, double v) const { p[at(e)] = v; }
+};
+
+__device__ __forceinline__ void wave_sync()   // the lanes of ONE wavefront hand data to each other through memory / LDS between sweeps
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The sweeps below serve both modes.  G lanes (lane index g) share NS signatures' worth of pairs: pair index v in [0, NS * qn) is pair
+// u = v % qn of signature v / qn, whose elements sit `per` doubles behind the previous signature's (group mode: NS = 1, the accessor already
+// points at the lane's signature).  SU pairs per lane are loaded before any is used.  GD: the pair count may not fill the last trip (only
+// the 16-coefficient level in group mode); everywhere else the loads are unconditional - a guarded load is a branch with a wait inside.
+
+// falcon_fft.c:694-739 with source and destination in (possibly) different places
+template <int G, int SU, int NS, bool GD, class D, class S>
+__device__ __forceinline__ void split_sw(const D &d, uint32_t f0, uint32_t f1, const S &s, uint32_t f, uint32_t g, int l, uint32_t per, const double *__restrict__ gm)
+{
+    const uint32_t hn = (1u << l) >> 1, qn = hn >> 1, tot = NS * qn;
+    for (uint32_t v0 = 0; v0 < tot; v0 += SU * G) {
+        double ar[SU], ai[SU], br[SU], bi[SU], gr[SU], gi[SU];
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                ar[k] = s.ld(so + f + 2 * u); ai[k] = s.ld(so + f + 2 * u + hn); br[k] = s.ld(so + f + 2 * u + 1); bi[k] = s.ld(so + f + 2 * u + 1 + hn);
+                gr[k] = gm[(u + hn) << 1]; gi[k] = gm[((u + hn) << 1) + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                double tr = ar[k] + br[k], ti = ai[k] + bi[k];
+                d.st(so + f0 + u, tr * 0.5); d.st(so + f0 + u + qn, ti * 0.5);
+                tr = ar[k] - br[k]; ti = ai[k] - bi[k];
+                cmul(tr, ti, tr, ti, gr[k], -gi[k]);
+                d.st(so + f1 + u, tr * 0.5); d.st(so + f1 + u + qn, ti * 0.5);
+            }
+        }
+    }
+}
+
+// falcon_fft.c:742-785
+template <int G, int SU, int NS, bool GD, class D, class S>
+__device__ __forceinline__ void merge_sw(const D &d, uint32_t f, const S &s, uint32_t f0, uint32_t f1, uint32_t g, int l, uint32_t per, const double *__restrict__ gm)
+{
+    const uint32_t hn = (1u << l) >> 1, qn = hn >> 1, tot = NS * qn;
+    for (uint32_t v0 = 0; v0 < tot; v0 += SU * G) {
+        double ar[SU], ai[SU], cr[SU], ci[SU], gr[SU], gi[SU];
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                ar[k] = s.ld(so + f0 + u); ai[k] = s.ld(so + f0 + u + qn); cr[k] = s.ld(so + f1 + u); ci[k] = s.ld(so + f1 + u + qn);
+                gr[k] = gm[(u + hn) << 1]; gi[k] = gm[((u + hn) << 1) + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < SU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                double br, bi;
+                cmul(br, bi, cr[k], ci[k], gr[k], gi[k]);
+                d.st(so + f + 2 * u, ar[k] + br); d.st(so + f + 2 * u + hn, ai[k] + bi);
+                d.st(so + f + 2 * u + 1, ar[k] - br); d.st(so + f + 2 * u + 1 + hn, ai[k] - bi);
+            }
+        }
+    }
+}
+
+// back from the first child (gpv.c:2701-2707): z1 = merge(child) ; x = (t1 - z1) * L + t0 ; the second child's inputs = split(x) - one sweep.
+// ch: the child's results (two halves at cho, cho + hm); t: this node's targets; zo: where z1 goes; ci: where the second child's inputs go.
+template <int G, int FU, int NS, bool GD, class CH, class TT, class ZO, class CI>
+__device__ __forceinline__ void mid_sw(const CH &ch, uint32_t cho, const TT &t, uint32_t pt0, uint32_t pt1, const ZO &zo, uint32_t pz1, const CI &ci, uint32_t pc,
+                                       uint32_t g, int l, uint32_t per, const double *__restrict__ gm, const double *__restrict__ L)
+{
+    const uint32_t hm = (1u << l) >> 1, qn = hm >> 1, tot = NS * qn;
+    for (uint32_t v0 = 0; v0 < tot; v0 += FU * G) {
+        double ar[FU], ai[FU], cr[FU], cim[FU], p1[FU][4], p0[FU][4], gr[FU], gi[FU], lv[FU][4];
+#pragma unroll
+        for (int k = 0; k < FU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                ar[k] = ch.ld(so + cho + u); ai[k] = ch.ld(so + cho + u + qn); cr[k] = ch.ld(so + cho + hm + u); cim[k] = ch.ld(so + cho + hm + u + qn);
+                p1[k][0] = t.ld(so + pt1 + 2 * u); p1[k][1] = t.ld(so + pt1 + 2 * u + hm); p1[k][2] = t.ld(so + pt1 + 2 * u + 1); p1[k][3] = t.ld(so + pt1 + 2 * u + 1 + hm);
+                p0[k][0] = t.ld(so + pt0 + 2 * u); p0[k][1] = t.ld(so + pt0 + 2 * u + hm); p0[k][2] = t.ld(so + pt0 + 2 * u + 1); p0[k][3] = t.ld(so + pt0 + 2 * u + 1 + hm);
+                gr[k] = gm[(u + hm) << 1]; gi[k] = gm[((u + hm) << 1) + 1];
+                lv[k][0] = L[2 * u]; lv[k][1] = L[2 * u + hm]; lv[k][2] = L[2 * u + 1]; lv[k][3] = L[2 * u + 1 + hm];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < FU; k++) {
+            const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
+            if (!GD || v < tot) {
+                double br, bi;
+                cmul(br, bi, cr[k], cim[k], gr[k], gi[k]);
+                const double e_r = ar[k] + br, e_i = ai[k] + bi, o_r = ar[k] - br, o_i = ai[k] - bi;     // z1 at complex slots 2u, 2u+1
+                zo.st(so + pz1 + 2 * u, e_r); zo.st(so + pz1 + 2 * u + hm, e_i);
+                zo.st(so + pz1 + 2 * u + 1, o_r); zo.st(so + pz1 + 2 * u + 1 + hm, o_i);
+                double xr = p1[k][0] - e_r, xi = p1[k][1] - e_i;
+                cmul(xr, xi, xr, xi, lv[k][0], lv[k][1]);
+                xr = xr + p0[k][0]; xi = xi + p0[k][1];
+                double yr = p1[k][2] - o_r, yi = p1[k][3] - o_i;
+                cmul(yr, yi, yr, yi, lv[k][2], lv[k][3]);
+                yr = yr + p0[k][2]; yi = yi + p0[k][3];
+                double tr = xr + yr, ti = xi + yi;
+                ci.st(so + pc + u, tr * 0.5); ci.st(so + pc + u + qn, ti * 0.5);
+                tr = xr - yr; ti = xi - yi;
+                cmul(tr, ti, tr, ti, gr[k], -gi[k]);
+                ci.st(so + pc + hm + u, tr * 0.5); ci.st(so + pc + hm + u + qn, ti * 0.5);
+            }
+        }
+    }
+}
+
+// The transforms in wave mode: as fft_pass / ifft_pass above (R butterfly stages per sweep in registers), the groups of NS polynomials (`per`
+// elements apart) as one index space shared by the 64 lanes, PG groups per lane in flight.  They run on two polynomials at a time staged in
+// LDS (LdsF below): a transform then costs one HBM read and one HBM write of the polynomial instead of one of each per pass.
+template <int R, int PG, int NS, class A>
+__device__ __forceinline__ void fft_pass_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, uint32_t hn, int u, const double *__restrict__ gm)
+{
+    constexpr int P = 1 << R;
+    const int lq = __builtin_ctz(hn) - u - (R - 1), lgr = __builtin_ctz(hn) - R;       // Q = hn >> (u + R - 1); groups per signature = hn >> R
+    const uint32_t Q = 1u << lq, groups = 1u << lgr, tot = NS * groups, m = 1u << u;   // tot is a multiple of PG * 64 for n >= 512
+    for (uint32_t t0 = 0; t0 < tot; t0 += PG * 64) {
+        double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t t = t0 + k * 64 + lane, grp = t & (groups - 1), i1 = grp >> lq;
+            j0[k] = (t >> lgr) * per + f + ((i1 << R) << lq) + (grp & (Q - 1));
+#pragma unroll
+            for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lq)); xi[k][a] = c.ld(j0[k] + (a << lq) + hn); }
+#pragma unroll
+            for (int e = 0; e < P - 1; e++) {                                             // stage s: 2^s twiddles, block (i1 << s) + j of stage u + s
+                const int s = 31 - __builtin_clz((unsigned)e + 1u), j = e + 1 - (1 << s);
+                const uint32_t tw = ((m << s) + (i1 << s) + (uint32_t)j) << 1;
+                wr[k][e] = gm[tw]; wi[k][e] = gm[tw + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int sp = P >> (s + 1);
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+                    if (a & sp) continue;
+                    const int ti = (1 << s) - 1 + (a >> (R - s));
+                    double yr, yi;
+                    cmul(yr, yi, xr[k][a + sp], xi[k][a + sp], wr[k][ti], wi[k][ti]);
+                    const double ar = xr[k][a], ai = xi[k][a];
+                    xr[k][a] = ar + yr; xi[k][a] = ai + yi;
+                    xr[k][a + sp] = ar - yr; xi[k][a + sp] = ai - yi;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lq), xr[k][a]); c.st(j0[k] + (a << lq) + hn, xi[k][a]); }
+        }
+    }
+    wave_sync();
+}
+
+template <int NS, class A>
+__device__ __forceinline__ void fft_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, int logn, const double *__restrict__ gm)
+{
+    const uint32_t hn = (1u << logn) >> 1;
+    int u = 1;
+    for (; u + 2 < logn; u += 3) fft_pass_w<3, 1, NS>(c, lane, f, per, hn, u, gm);
+    if (u + 1 < logn) fft_pass_w<2, 2, NS>(c, lane, f, per, hn, u, gm);
+    else if (u < logn) fft_pass_w<1, 2, NS>(c, lane, f, per, hn, u, gm);
+}
+
+template <int R, int PG, int NS, class A>
+__device__ __forceinline__ void ifft_pass_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, uint32_t hn, int lt, uint32_t hm0, const double *__restrict__ gm)
+{
+    constexpr int P = 1 << R;
+    const int lgr = __builtin_ctz(hn) - R;
+    const uint32_t tt0 = 1u << lt, groups = 1u << lgr, tot = NS * groups;
+    for (uint32_t t0 = 0; t0 < tot; t0 += PG * 64) {
+        double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+            const uint32_t t = t0 + k * 64 + lane, grp = t & (groups - 1), iB = grp >> lt;
+            j0[k] = (t >> lgr) * per + f + ((iB << R) << lt) + (grp & (tt0 - 1));
+#pragma unroll
+            for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lt)); xi[k][a] = c.ld(j0[k] + (a << lt) + hn); }
+#pragma unroll
+            for (int e = 0; e < P - 1; e++) {                                             // stage s: P >> (s+1) twiddles, stored from the back (stage R-1 first)
+                const int sr = 31 - __builtin_clz((unsigned)e + 1u), s = R - 1 - sr, j = e + 1 - (1 << sr);
+                const uint32_t tw = ((hm0 >> s) + iB * (uint32_t)(P >> (s + 1)) + (uint32_t)j) << 1;
+                wr[k][e] = gm[tw]; wi[k][e] = gm[tw + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PG; k++) {
+#pragma unroll
+            for (int s = 0; s < R; s++) {
+                const int sp = 1 << s;
+#pragma unroll
+                for (int a = 0; a < P; a++) {
+                    if (a & sp) continue;
+                    const int ti = (1 << (R - 1 - s)) - 1 + (a >> (s + 1));
+                    const double ar = xr[k][a], ai = xi[k][a], br = xr[k][a + sp], bi = xi[k][a + sp];
+                    xr[k][a] = ar + br; xi[k][a] = ai + bi;
+                    const double dr = ar - br, di = ai - bi;
+                    cmul(xr[k][a + sp], xi[k][a + sp], dr, di, wr[k][ti], -wi[k][ti]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lt), xr[k][a]); c.st(j0[k] + (a << lt) + hn, xi[k][a]); }
+        }
+    }
+    wave_sync();
+}
+
+template <int NS, class A>
+__device__ __forceinline__ void ifft_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, int logn, const double *__restrict__ gm)
+{
+    const uint32_t n = 1u << logn, hn = n >> 1;
+    int left = logn - 1, lt = 0;
+    uint32_t hm = n >> 1;
+    for (; left >= 3; left -= 3, lt += 3, hm >>= 3) ifft_pass_w<3, 1, NS>(c, lane, f, per, hn, lt, hm, gm);
+    if (left == 2) ifft_pass_w<2, 2, NS>(c, lane, f, per, hn, lt, hm, gm);
+    else if (left == 1) ifft_pass_w<1, 2, NS>(c, lane, f, per, hn, lt, hm, gm);
+}
+
+// Leaf sampling for the group mode.  The 8 leaves of a register sub-tree need 8 CDF tables (the same for every signature) and 8 x 4 tape
+// words per signature; both are fetched one sub-tree AHEAD (a 16-byte load or two per lane, issued when the previous sub-tree ends and
+// landed long before this one starts) and parked in LDS.  The compare-count of cdt_pick is then shared by the 8 lanes of the group -
+// lane g takes entries g, g + 8, ... - and the partial counts of both samples are added across the group in one register with three
+// DPP steps; every lane ends up with the same two samples.
+template <int TSL>
+struct LeafLds {
+    const uint64_t *tab;         // LDS: [8 leaves][2^TSL entries]
+    const uint32_t *tp;          // LDS: this signature's [8 leaves][4 words]
+    uint32_t g; int k;
+    __device__ __forceinline__ void pick2(double &d0, double &d1)
+    {
+        constexpr int PER = (1 << TSL) / 8;
+        const uint4 w = *reinterpret_cast<const uint4 *>(tp + 4 * k);
+        const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
+        const uint64_t *row = tab + ((size_t)k << TSL) + g;
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint64_t e = row[8 * j];
+            const bool live = j > 0 || g != 0;                           // entry 0 is not part of the search (gaussian_cdf.c:536-553: b starts at 1)
+            cnt += ((live && e < x0) ? 1u : 0u) + ((live && e < x1) ? 0x10000u : 0u);
+        }
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <-> 7 - i of each 8
+        const int32_t a0 = (int32_t)(cnt & 0xFFFFu), a1 = (int32_t)(cnt >> 16);
+        d0 = (double)((x0 & 1) ? a0 : -a0);
+        d1 = (double)((x1 & 1) ? a1 : -a1);
+        k++;
+    }
+};
+
+struct WalkL {
+    uint32_t n; int logn; uint32_t ph;      // ph bit l: the node on the current path at level l is in its second half
+    // HBM offsets inside a signature's 6n doubles (C0 | C1 | Z0 | Z1 | T), levels >= LM: the reference's own pointer layout (gpv.c:2693-2711)
+    __device__ __forceinline__ uint32_t tmp(int l) const { return 6 * n - (2u << l); }
+    __device__ __forceinline__ uint32_t z0(int l) const { return l == logn ? 2 * n : tmp(l + 1); }
+    __device__ __forceinline__ uint32_t z1(int l) const { return l == logn ? 3 * n : tmp(l + 1) + (1u << l); }
+    __device__ __forceinline__ uint32_t t0(int l) const { return l == logn ? 0 : (((ph >> (l + 1)) & 1) ? z0(l + 1) : z1(l + 1)); }
+    __device__ __forceinline__ uint32_t t1(int l) const { return l == logn ? n : t0(l) + (1u << l); }
+    // LDS offsets inside a signature's LDS_SIG doubles: X = [0, 2^LM) holds the inputs of the level-LM node's current child; the scratch
+    // behind it is the same stack as T above, for the levels below LM
+    __device__ __forceinline__ uint32_t ltmp(int l) const { return (uint32_t)LDS_SIG - (2u << l); }                 // l <= LM
+    __device__ __forceinline__ uint32_t lz0(int l) const { return ltmp(l + 1); }                                   // l < LM
+    __device__ __forceinline__ uint32_t lz1(int l) const { return ltmp(l + 1) + (1u << l); }
+    __device__ __forceinline__ uint32_t lt0(int l) const { return l == LM - 1 ? 0u : (((ph >> (l + 1)) & 1) ? lz0(l + 1) : lz1(l + 1)); }
+    __device__ __forceinline__ uint32_t lt1(int l) const { return lt0(l) + (1u << l); }
+};
+
+// gaussian_sample_with_tree, 8 signatures per wavefront (one wavefront per workgroup).  ws: 6n doubles per signature, padded to a multiple of 8
+// signatures.  tape_stride >= 4n (the launcher answers shorter strides itself): a tape that is short is still read to 4n words - inside its
+// own row - and its signature reports status 2 and writes nothing.
+// PROF (measurement builds only, sc_hip_falcon_sample_profile): each wavefront adds the shader cycles it spent in the six phases to prof[0..5].
+template <int TSL, bool PROF>
+__global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, double *__restrict__ ws, const int32_t *__restrict__ c,
+                                                           const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
+                                                           const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
+                                                           int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
+                                                           unsigned long long *__restrict__ prof)
+{
+    __shared__ double lds[SPW * LDS_SIG];
+    __shared__ uint64_t stab[8 << TSL];                                // the current register sub-tree's 8 leaf tables
+    __shared__ __attribute__((aligned(16))) uint32_t stape[SPW * 32];  // and its 8 x 4 tape words per signature
+    unsigned long long pc[6] = { 0, 0, 0, 0, 0, 0 }, tprev = 0;
+    if (PROF) tprev = __builtin_amdgcn_s_memtime();
+#define FAL_STAMP(ph) do { if (PROF) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); pc[ph] += tn_ - tprev; tprev = tn_; } } while (0)
+    constexpr int FK = FK8;
+    const uint32_t lane = threadIdx.x, sg = lane >> 3, g = lane & 7;
+    const uint32_t sig0 = blockIdx.x * SPW;
+    const uint32_t n = (uint32_t)P.n, hn = n >> 1; const int logn = P.n_bits;
+    const uint32_t per = 6 * n;
+    const Lin wv = { ws + (size_t)sig0 * per };                        // wave mode: the 8 signatures, `per` doubles apart
+    const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
+    const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n;
+    // group mode: this lane's signature.  A signature past the end of the batch is computed on item 0's inputs (in its own workspace slot).
+    const uint32_t mysig = sig0 + sg;
+    const bool inb = mysig < batch;
+    const uint32_t item = inb ? mysig : 0;
+    const bool shortt = inb && tape_lens && tape_lens[mysig] < 4 * n;
+    if (shortt && g == 0) status[mysig] = 2;
+    const uint64_t runmask = __ballot(inb && !shortt);                  // bit 8k: signature k of this wavefront writes its results
+    const Lin mine = { wv.p + (size_t)sg * per };
+    const LdsG lg = { lds + sg * 8 };
+    const int ln = logn;                                               // log2 of the elements per signature in the flattened loops
+
+    // ---- FFT(c) and the two target vectors (gpv.c:3040-3054): two signatures at a time through LDS (n doubles each, padded)
+    const LdsF lf2 = { lds };                                          // 2 * (n + n/8) <= SPW * LDS_SIG doubles for n <= 1024
+    for (int pr = 0; pr < SPW; pr += 2) {
+        for (uint32_t t0 = 0; t0 < 2 * n; t0 += 4 * 4 * 64) {
+            int4 cv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = t0 + (j * 64 + lane) * 4, b = sig0 + pr + (t >> ln);
+                cv[j] = *reinterpret_cast<const int4 *>(c + (size_t)(b < batch ? b : 0) * n + (t & (n - 1)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = t0 + (j * 64 + lane) * 4;
+                lf2.st(t, (double)cv[j].x); lf2.st(t + 1, (double)cv[j].y); lf2.st(t + 2, (double)cv[j].z); lf2.st(t + 3, (double)cv[j].w);
+            }
+        }
+        wave_sync();
+        fft_w<2>(lf2, lane, 0, n, logn, gm);
+        for (uint32_t t0 = 0; t0 < 2 * hn; t0 += 4 * 64) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t = t0 + j * 64 + lane, k = t >> (ln - 1), u = t & (hn - 1), e = (pr + k) * per + u;
+                const double ar = lf2.ld(k * n + u), ai = lf2.ld(k * n + u + hn);
+                double r, i;
+                cmul(r, i, ar, ai, b01[u], b01[u + hn]);
+                wv.st(e + C1, r * -ni); wv.st(e + C1 + hn, i * -ni);
+                cmul(r, i, ar, ai, b11[u], b11[u + hn]);
+                wv.st(e + C0, r * ni); wv.st(e + C0 + hn, i * ni);
+            }
+        }
+        wave_sync();
+    }
+    FAL_STAMP(0);
+
+    // ---- fast Fourier sampling, depth first, the second-half tree (tree1) before the first (gpv.c:2693-2711)
+    constexpr int TPL = (1 << TSL) / 8;                                // table entries per lane of a sub-tree's 8 tables
+    uint64_t ptab[TPL]; uint4 ptape = make_uint4(0, 0, 0, 0);
+    const uint32_t *mytape = tapes + (size_t)item * tape_stride;
+    uint32_t leaf = 0;                                                 // first leaf of the next register sub-tree (wave-uniform)
+    auto prefetch = [&](uint32_t first) {
+        if (first < n) {
+            const uint64_t *src = tabs + ((size_t)first << TSL) + lane * TPL;
+#pragma unroll
+            for (int i = 0; i < TPL; i += 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + i); ptab[i] = v.x; ptab[i + 1] = v.y; }
+            ptape = *reinterpret_cast<const uint4 *>(mytape + 4 * (size_t)(first + g));
+        }
+    };
+    prefetch(0);
+    WalkL w = { n, logn, 0 };
+    uint32_t toff = 0;
+    int l = logn;
+    bool entering = true;
+    for (;;) {
+        const uint32_t m = 1u << l, hm = m >> 1;
+        if (entering) {
+            if (l == FK) {
+                // an 8-coefficient sub-tree in registers; every lane of a group computes the same thing from the same (broadcast) LDS words
+#pragma unroll
+                for (int i = 0; i < TPL; i++) stab[lane * TPL + i] = ptab[i];
+                *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
+                wave_sync();
+                double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
+                const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
+#pragma unroll
+                for (int i = 0; i < (1 << FK); i++) { t0r[i] = lg.ld(pt0 + i); t1r[i] = lg.ld(pt1 + i); }
+                LeafLds<TSL> lfl = { stab, stape + sg * 32, g, 0 };
+                FFS<FK, LeafLds<TSL>>::run(z0r, z1r, tree + toff, t0r, t1r, gm, lfl);
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < (1 << FK); i++) { lg.st(pz0 + i, z0r[i]); lg.st(pz1 + i, z1r[i]); }
+                }
+                leaf += 1u << FK;
+                prefetch(leaf);
+                wave_sync();
+                FAL_STAMP(4);
+                entering = false; l++;
+                continue;
+            }
+            if (l > LM) split_sw<64, 2, SPW, false>(wv, w.z1(l), w.z1(l) + hm, wv, w.t1(l), lane, l, per, gm);
+            else if (l == LM) split_sw<8, 2, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, gm);
+            else if (l == LM - 1) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
+            else if (l == LM - 2) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
+            else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
+            wave_sync();
+            FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
+            w.ph &= ~(1u << l);
+            toff += m + treesize(l - 1); l--;
+            continue;
+        }
+        if (!((w.ph >> l) & 1)) {
+            toff -= m + treesize(l - 1);
+            const double *L = tree + toff;
+            if (l > LM) mid_sw<64, 2, SPW, false>(wv, w.tmp(l), wv, w.t0(l), w.t1(l), wv, w.z1(l), wv, w.z0(l), lane, l, per, gm, L);
+            else if (l == LM) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, gm, L);
+            else if (l == LM - 1) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
+            else if (l == LM - 2) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
+            else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
+            wave_sync();
+            FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
+            w.ph |= 1u << l;
+            toff += m; l--;
+            entering = true;
+            continue;
+        }
+        toff -= m;
+        if (l > LM) merge_sw<64, 2, SPW, false>(wv, w.z0(l), wv, w.tmp(l), w.tmp(l) + hm, lane, l, per, gm);
+        else if (l == LM) merge_sw<8, 2, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
+        else if (l == LM - 1) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
+        else if (l == LM - 2) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
+        else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
+        wave_sync();
+        FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
+        w.ph &= ~(1u << l);
+        if (l == logn) break;
+        l++;
+    }
+
+    // ---- lattice point (gpv.c:3064-3076): c0 <- z0*b00 + z1*b10 ; c1 <- z1*b11 + z0*b01, the inverse transforms and the roundings: one
+    // signature at a time, its two polynomials side by side in LDS
+    const double sc2 = ldexp(2.0, -logn);                           // falcon_fft.c:370-377
+    for (int k = 0; k < SPW; k++) {
+        for (uint32_t u0 = 0; u0 < hn; u0 += 4 * 64) {
+            double z0r[4], z0i[4], z1r[4], z1i[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t e = k * per + u0 + j * 64 + lane;
+                z0r[j] = wv.ld(e + Z0); z0i[j] = wv.ld(e + Z0 + hn); z1r[j] = wv.ld(e + Z1); z1i[j] = wv.ld(e + Z1 + hn);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t u = u0 + j * 64 + lane;
+                double pr, pi, qr, qi;
+                cmul(pr, pi, z0r[j], z0i[j], b00[u], b00[u + hn]);
+                cmul(qr, qi, z1r[j], z1i[j], b10[u], b10[u + hn]);
+                lf2.st(u, pr + qr); lf2.st(u + hn, pi + qi);
+                cmul(pr, pi, z0r[j], z0i[j], b01[u], b01[u + hn]);
+                cmul(qr, qi, z1r[j], z1i[j], b11[u], b11[u + hn]);
+                lf2.st(n + u, qr + pr); lf2.st(n + u + hn, qi + pi);
+            }
+        }
+        wave_sync();
+        ifft_w<2>(lf2, lane, 0, n, logn, gm);
+        if ((runmask >> (8 * k)) & 1) {
+            const size_t ob = (size_t)(sig0 + k) * n;
+            for (uint32_t i0 = 0; i0 < n; i0 += 4 * 64) {
+                int32_t cv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) cv[j] = c[ob + i0 + j * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t i = i0 + j * 64 + lane;
+                    const long long r0 = (long long)rint(lf2.ld(i) * sc2), r1 = (long long)rint(lf2.ld(n + i) * sc2);
+                    if (s1) s1[ob + i] = (int32_t)((long long)cv[j] - r0);
+                    s2[ob + i] = (int32_t)-r1;
+                }
+            }
+        }
+        wave_sync();
+    }
+    FAL_STAMP(5);
+    if (PROF && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) atomicAdd(prof + i, pc[i]);
+    }
+#undef FAL_STAMP
 }
 
 // ---- hash to ring (falcon.c:534-591): SHAKE128 with the reference's permutation, n little-endian 32-bit words --------
@@ -978,7 +1501,7 @@ struct sc_hip_falcon {
     bool have_sk, have_pk;
     double *d_sk, *d_gm;
     uint64_t *d_tabs; int ts_log;
-    int force_g;                 // 0 = choose by batch size; 1 / 8 = lanes per signature (test hook, SC_HIP_FALCON_LANES)
+    int force_g;                 // sc_hip_falcon_set_mapping: 0 / 64 = 8 signatures per wavefront, lower tree in LDS; 1 / 8 = lanes per signature, state in HBM
     int32_t *d_hhat;
     size_t cap;
     double *ws;
@@ -998,7 +1521,7 @@ static int fal_ensure_ws(sc_hip_falcon *f, size_t batch)
     if (batch <= f->cap) return SC_HIP_SUCCESS;
     fal_free_ws(f);
     const size_t n = f->P.n;
-    HIPCHK(hipMalloc((void **)&f->ws, batch * 6 * n * sizeof(double)));
+    HIPCHK(hipMalloc((void **)&f->ws, ((batch + SPW - 1) / SPW * SPW) * 6 * n * sizeof(double)));       // the 8-per-wavefront mapping pads to whole wavefronts
     HIPCHK(hipMalloc((void **)&f->c, batch * n * 4));
     HIPCHK(hipMalloc((void **)&f->s1, batch * n * 4));
     HIPCHK(hipMalloc((void **)&f->s2, batch * n * 4));
@@ -1023,7 +1546,6 @@ extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_param
     sc_hip_falcon *f = new sc_hip_falcon;
     memset(f, 0, sizeof *f);
     f->ctx = ctx; f->plan = plan; f->P = P;
-    if (const char *e = getenv("SC_HIP_FALCON_LANES")) { const int v = atoi(e); f->force_g = (v == 1 || v == 8) ? v : 0; }
     std::vector<double> gm;
     make_gm(gm);
     if (hipMalloc((void **)&f->d_gm, gm.size() * sizeof(double)) != hipSuccess ||
@@ -1032,6 +1554,14 @@ extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_param
         return fail("falcon_create: device allocation failed");
     }
     *out = f;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_falcon_set_mapping(sc_hip_falcon_t *f, int lanes)
+{
+    if (!f) return fail("falcon_set_mapping: null handle");
+    if (lanes != 0 && lanes != 1 && lanes != 8 && lanes != 64) return fail("falcon_set_mapping: lanes must be 0 (default), 1, 8 or 64");
+    f->force_g = lanes;
     return SC_HIP_SUCCESS;
 }
 
@@ -1111,13 +1641,33 @@ extern "C" size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *f)
 }
 
 static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s)
+                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s, unsigned long long *d_prof = nullptr)
 {
-    HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     const double ni = 1.0 / (double)(long)f->P.q;                    /* fpr_inverse_of, falcon_fft.h:57-60 */
-    // up to one lane-per-signature wavefront per CU the walk is latency-bound (measured crossover on MI355X between 16 K and
-    // 32 K signatures): spread each signature over 8 lanes
-    const bool wide = f->force_g ? f->force_g == 8 : batch <= (size_t)f->ctx->cus * 64;
+    if (tape_stride < 4 * (size_t)f->P.n) {                          // no tape can hold the 4n words a signature draws
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_status, 2, batch, s));
+        return SC_HIP_SUCCESS;
+    }
+    HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
+    // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
+    if (f->force_g == 0 || f->force_g == 64) {
+        const dim3 grid8((unsigned)((batch + SPW - 1) / SPW)), block8(64);
+#define FAL_W8A(TSL, PR) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR>), grid8, block8, 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
+                                            f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
+#define FAL_W8(TSL) do { if (d_prof) FAL_W8A(TSL, true); else FAL_W8A(TSL, false); } while (0)
+        switch (f->ts_log) {
+        case 4: FAL_W8(4); break;
+        case 5: FAL_W8(5); break;
+        case 6: FAL_W8(6); break;
+        default: return fail("falcon: unsupported leaf table size");
+        }
+#undef FAL_W8
+#undef FAL_W8A
+        HIPCHK(hipGetLastError());
+        return SC_HIP_SUCCESS;
+    }
+    // the two batch-interleaved mappings: a lane per signature, or 8 lanes per signature (the state in HBM either way)
+    const bool wide = f->force_g == 8;
     const size_t threads = wide ? batch * 8 : batch;
     const dim3 grid((unsigned)((threads + ST - 1) / ST)), block(ST);
 #define FAL_LAUNCH(TSL, G) hipLaunchKernelGGL((fal_sample_kernel<TSL, G>), grid, block, 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
@@ -1155,6 +1705,29 @@ extern "C" int sc_hip_falcon_sample(sc_hip_falcon_t *f, size_t batch, const int3
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
     return fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, d_tape_lens, d_s1, d_s2, d_status ? d_status : f->status, (hipStream_t)stream);
+}
+
+// measurement hook (include/sc_hip_bench.h): the default mapping's sampler with per-phase cycle counters; h_cycles[6] = shader cycles summed over the
+// wavefronts: transform + targets | tree levels in HBM | the level-LM node | tree levels in LDS | register sub-trees | lattice point + inverse transforms
+extern "C" int sc_hip_falcon_sample_profile(sc_hip_falcon_t *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride,
+                                            int32_t *d_s1, int32_t *d_s2, unsigned long long *h_cycles, void *stream)
+{
+    if (fal_check_common(f, batch, "falcon_sample_profile")) return SC_HIP_FAILURE;
+    if (!f->have_sk || !d_c || !d_tapes || !d_s2 || !h_cycles || batch == 0) return fail("falcon_sample_profile: bad argument");
+    if (((uintptr_t)d_c & 15) != 0 || ((uintptr_t)d_tapes & 15) != 0 || (tape_stride & 3) != 0) return fail("falcon_sample_profile: 16-byte aligned rows");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    sc::DevBuf pb;
+    if (pb.get(6 * sizeof(unsigned long long))) return SC_HIP_FAILURE;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(pb.p, 0, 6 * sizeof(unsigned long long), s));
+    const int keep = f->force_g; f->force_g = 64;
+    const int rc = fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, nullptr, d_s1, d_s2, f->status, s, pb.as<unsigned long long>());
+    f->force_g = keep;
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(h_cycles, pb.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return SC_HIP_SUCCESS;
 }
 
 extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,

@@ -19,26 +19,27 @@ SYMBOLS = [
     'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_verify_keys', 'sc_hip_dilithium_sign_keys', 'sc_hip_dilithium_sign_host',
-    'sc_hip_dilithium_verify_host', 'sc_hip_shake_host', 'sc_hip_dilithium_keygen',
+    'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
-    'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify',
+    'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_polymul_ntt_steps', 'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey',
+    'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey',
     'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
-    'sc_hip_time_op',
 ]
+# include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
+BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors']
 
@@ -223,6 +224,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_falcon_set_pubkey.argtypes = [vp, vp]
     L.sc_hip_falcon_sig_bytes.argtypes = [vp]
     L.sc_hip_falcon_sig_bytes.restype = sz
+    L.sc_hip_falcon_set_mapping.argtypes = [vp, C.c_int]
+    L.sc_hip_falcon_sample_profile.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_falcon_sample.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_falcon_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
     L.sc_hip_falcon_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
@@ -1063,6 +1066,20 @@ class Falcon:
         a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
         assert a.size == self.n
         _chk(self.L, self.L.sc_hip_falcon_set_pubkey(self.h, _ptr(a)), 'falcon_set_pubkey')
+
+    def sample_profile(self, c, tapes):
+        """measurement hook: the default mapping's sampler, returns (s1, s2, cycles[6]) - shader cycles per phase summed over wavefronts"""
+        import numpy as np, torch
+        batch, dev = c.shape[0], c.device
+        s1 = torch.empty((batch, self.n), dtype=torch.int32, device=dev)
+        s2 = torch.empty((batch, self.n), dtype=torch.int32, device=dev)
+        cyc = np.zeros(6, dtype=np.uint64)
+        _chk(self.L, self.L.sc_hip_falcon_sample_profile(self.h, batch, _ptr(c), _ptr(tapes), _rows(tapes), _ptr(s1), _ptr(s2), _ptr(cyc), _stream()), 'falcon_sample_profile')
+        return s1, s2, cyc
+
+    def set_mapping(self, lanes):
+        """0 / 64: 8 signatures per wavefront, lower tree in LDS (default); 1, 8: lanes per signature, state in HBM"""
+        _chk(self.L, self.L.sc_hip_falcon_set_mapping(self.h, int(lanes)), 'falcon_set_mapping')
 
     def ens_dlp_verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
         """ENS / DLP signature verification (the handle holds that scheme's parameters and public key)"""

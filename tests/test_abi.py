@@ -26,6 +26,10 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f'{s} declared in include/sc_hip.h but not exported'
     assert sorted(engine.SYMBOLS) == syms          # the Python binding covers the whole header
+    bsyms = _header_symbols('sc_hip_bench.h')
+    assert sorted(engine.BENCH_SYMBOLS) == bsyms
+    for s in bsyms:
+        assert hasattr(lib, s), f'{s} declared in include/sc_hip_bench.h but not exported'
     vsyms = [s for s in _header_symbols('sc_hip_vtable.h') if s not in ('sc_hip_ntt_params', 'sc_hip_ntt32_vtable')]
     assert sorted(engine.VTABLE_SYMBOLS) == vsyms
     for s in vsyms:

@@ -111,25 +111,73 @@ def test_batch_vs_oracle_seeded(eng, G):
     f.close()
 
 
-@pytest.mark.parametrize('lanes', ['1', '8'])
-def test_both_lane_mappings_reproduce_reference(eng, G, lanes, monkeypatch):
-    """the engine picks 1 or 8 lanes per signature by batch size; both mappings are forced here (SC_HIP_FALCON_LANES is read
-    when the handle is created) and must give the reference's s1, s2 and, on a seeded batch, the oracle's"""
+@pytest.mark.parametrize('lanes', [1, 8, 64])
+def test_every_mapping_reproduces_reference(eng, G, lanes):
+    """three ways of laying the sampler over the machine (sc_hip_falcon_set_mapping: a lane per signature, 8 lanes per signature,
+    8 signatures per wavefront with the lower tree in LDS - the default); each must give the reference's s1, s2 and, on a seeded
+    ragged batch, the oracle's, for n = 1024 and n = 512"""
     import torch
-    monkeypatch.setenv('SC_HIP_FALCON_LANES', lanes)
+    for tag in ('falcon2', 'falcon0'):
+        key, f = open_key(eng, G, tag)
+        f.set_mapping(lanes)
+        c = np.asarray(G[f'{tag}_c0'], dtype=np.int32)[None, :]
+        tp = u32(G[f'{tag}_ctape0'])[None, :]
+        s1, s2, status = f.sample(torch.from_numpy(c).cuda(), torch.from_numpy(tp.view(np.int32)).cuda())
+        assert np.array_equal(s1[0].cpu().numpy(), np.asarray(G[f'{tag}_s1_0'], dtype=np.int32))
+        assert np.array_equal(s2[0].cpu().numpy(), np.asarray(G[f'{tag}_s2_0'], dtype=np.int32))
+        rng = np.random.default_rng(lanes)
+        B = 77                                                   # ragged: the last wavefront is partly empty in every mapping
+        cs = rng.integers(0, key.q, size=(B, key.n), dtype=np.int32)
+        tps = rng.integers(0, 2**32, size=(B, 4 * key.n), dtype=np.uint64).astype(np.uint32)
+        tl = np.full(B, 4 * key.n, dtype=np.int32); tl[5] = 17; tl[76] = 4 * key.n - 1
+        s1, s2, status = f.sample(torch.from_numpy(cs).cuda(), torch.from_numpy(tps.view(np.int32)).cuda(), tape_lens=torch.from_numpy(tl).cuda())
+        s1, s2, st = s1.cpu().numpy(), s2.cpu().numpy(), status.cpu().numpy()
+        assert st[5] == 2 and st[76] == 2 and int((st == 0).sum()) == B - 2
+        for i in (0, 1, 4, 6, 38, 72, 75):
+            rc, o1, o2 = O.falcon_sample(key, cs[i], tps[i])
+            assert rc == 0 and np.array_equal(s1[i], o1) and np.array_equal(s2[i], o2), (tag, i)
+        f.close()
+
+
+def test_tapes_narrower_than_a_signature_needs(eng, G):
+    """a tape row pitch below 4n words: every signature reports status 2, nothing is read past a row"""
+    import torch
+    key, f = open_key(eng, G, 'falcon0')
+    B = 9
+    cs = np.zeros((B, key.n), dtype=np.int32)
+    tps = np.zeros((B, 4 * key.n - 4), dtype=np.int32)
+    s1, s2, status = f.sample(torch.from_numpy(cs).cuda(), torch.from_numpy(tps).cuda())
+    assert status.cpu().tolist() == [2] * B
+    f.close()
+
+
+def test_full_size_config5(eng, G):
+    """BASELINE configs[4] as stated: Falcon-1024 (reference set 2), batch 8192, the default mapping (no override).  A strided sample of
+    the signatures equals the oracle's byte for byte, every signature verifies, every flipped message is rejected, and the two first-
+    generation mappings agree with the default one on the whole batch."""
+    import torch
     key, f = open_key(eng, G, 'falcon2')
-    c = np.asarray(G['falcon2_c0'], dtype=np.int32)[None, :]
-    tp = u32(G['falcon2_ctape0'])[None, :]
-    s1, s2, status = f.sample(torch.from_numpy(c).cuda(), torch.from_numpy(tp.view(np.int32)).cuda())
-    assert np.array_equal(s1[0].cpu().numpy(), np.asarray(G['falcon2_s1_0'], dtype=np.int32))
-    assert np.array_equal(s2[0].cpu().numpy(), np.asarray(G['falcon2_s2_0'], dtype=np.int32))
-    rng = np.random.default_rng(int(lanes))
-    B = 77                                                   # ragged: the last wavefront is partly empty in either mapping
-    cs = rng.integers(0, key.q, size=(B, key.n), dtype=np.int32)
-    tps = rng.integers(0, 2**32, size=(B, 4 * key.n), dtype=np.uint64).astype(np.uint32)
-    s1, s2, status = f.sample(torch.from_numpy(cs).cuda(), torch.from_numpy(tps.view(np.int32)).cuda())
-    s1, s2 = s1.cpu().numpy(), s2.cpu().numpy()
-    for i in (0, 1, 38, 76):
-        rc, o1, o2 = O.falcon_sample(key, cs[i], tps[i])
-        assert rc == 0 and np.array_equal(s1[i], o1) and np.array_equal(s2[i], o2), i
+    B = 8192
+    g = torch.Generator(device='cuda'); g.manual_seed(55)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * key.n), dtype=torch.int32, device='cuda', generator=g)
+    sigs, siglens, status = f.sign(msgs, tapes, fixed_len=64)
+    torch.cuda.synchronize()
+    st, lh = status.cpu().numpy(), siglens.cpu().numpy()
+    ok = st == 1
+    assert set(np.unique(st)) <= {1, 4} and ok.sum() >= B - B // 200        # 4 = the reference's norm-bound failure (it does not retry)
+    mh, th, sh = msgs.cpu().numpy(), tapes.cpu().numpy().view(np.uint32), sigs.cpu().numpy()
+    for i in list(range(0, B, 601)) + [B - 1]:
+        rc, sig = O.falcon_sign(key, bytes(mh[i]), th[i])
+        assert (rc, st[i]) in ((0, 1), (1, 4)), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == sig, i
+    v = f.verify(msgs, sigs, siglens, fixed_len=64).cpu().numpy()
+    assert np.array_equal(v[ok], np.zeros(int(ok.sum()), dtype=v.dtype)) and (v[~ok] == 1).all()
+    m2 = msgs.clone(); m2[:, 63] ^= 0x80
+    assert int(f.verify(m2, sigs, siglens, fixed_len=64).min()) == 1
+    for lanes in (1, 8):
+        f.set_mapping(lanes)
+        s2_, l2_, st2_ = f.sign(msgs, tapes, fixed_len=64)
+        assert torch.equal(s2_, sigs) and torch.equal(l2_, siglens) and torch.equal(st2_, status), lanes
     f.close()
