@@ -783,33 +783,42 @@ __device__ __forceinline__ void ifft_w(const A &c, uint32_t lane, uint32_t f, ui
 
 // Leaf sampling for the group mode.  The 8 leaves of a register sub-tree need 8 CDF tables (the same for every signature) and 8 x 4 tape
 // words per signature; both are fetched one sub-tree AHEAD (a 16-byte load or two per lane, issued when the previous sub-tree ends and
-// landed long before this one starts) and parked in LDS.  The compare-count of cdt_pick is then shared by the 8 lanes of the group -
-// lane g takes entries g, g + 8, ... - and the partial counts of both samples are added across the group in one register with three
-// DPP steps; every lane ends up with the same two samples.
+// landed long before this one starts) and parked in LDS.  The samples depend on nothing the walk computes, so all 16 of a sub-tree are
+// drawn before its recursion starts: the compare-count of cdt_pick is shared by the 8 lanes of the group - lane g takes entries g, g + 8,
+// ... - and the partial counts of both samples are added across the group in one register with three DPP steps; every lane ends up with
+// the same samples, and the recursion (the same on every lane of the group) finds them in registers.
 template <int TSL>
-struct LeafLds {
-    const uint64_t *tab;         // LDS: [8 leaves][2^TSL entries]
-    const uint32_t *tp;          // LDS: this signature's [8 leaves][4 words]
-    uint32_t g; int k;
-    __device__ __forceinline__ void pick2(double &d0, double &d1)
+struct LeafPre {
+    double d[16];
+    int k;
+    __device__ __forceinline__ void draw(const uint64_t *tab, const uint32_t *tp, uint32_t g)       // tab: LDS [8][2^TSL]; tp: LDS, this signature's [8][4]
     {
         constexpr int PER = (1 << TSL) / 8;
-        const uint4 w = *reinterpret_cast<const uint4 *>(tp + 4 * k);
-        const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
-        const uint64_t *row = tab + ((size_t)k << TSL) + g;
-        uint32_t cnt = 0;
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const uint64_t e = row[8 * j];
-            const bool live = j > 0 || g != 0;                           // entry 0 is not part of the search (gaussian_cdf.c:536-553: b starts at 1)
-            cnt += ((live && e < x0) ? 1u : 0u) + ((live && e < x1) ? 0x10000u : 0u);
+        for (int lf = 0; lf < 8; lf++) {
+            const uint4 w = *reinterpret_cast<const uint4 *>(tp + 4 * lf);
+            const uint64_t x0 = ((uint64_t)w.x << 32) | w.y, x1 = ((uint64_t)w.z << 32) | w.w;
+            const uint64_t *row = tab + ((size_t)lf << TSL) + g;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const uint64_t e = row[8 * j];
+                const bool live = j > 0 || g != 0;                       // entry 0 is not part of the search (gaussian_cdf.c:536-553: b starts at 1)
+                cnt += ((live && e < x0) ? 1u : 0u) + ((live && e < x1) ? 0x10000u : 0u);
+            }
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <-> 7 - i of each 8
+            const int32_t a0 = (int32_t)(cnt & 0xFFFFu), a1 = (int32_t)(cnt >> 16);
+            d[2 * lf] = (double)((x0 & 1) ? a0 : -a0);
+            d[2 * lf + 1] = (double)((x1 & 1) ? a1 : -a1);
         }
-        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-        cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <-> 7 - i of each 8
-        const int32_t a0 = (int32_t)(cnt & 0xFFFFu), a1 = (int32_t)(cnt >> 16);
-        d0 = (double)((x0 & 1) ? a0 : -a0);
-        d1 = (double)((x1 & 1) ? a1 : -a1);
+        k = 0;
+    }
+    __device__ __forceinline__ void pick2(double &d0, double &d1)
+    {
+        // k is a compile-time constant at every use (the recursion is fully unrolled)
+        d0 = d[2 * k]; d1 = d[2 * k + 1];
         k++;
     }
 };
@@ -845,6 +854,8 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     __shared__ double lds[SPW * LDS_SIG];
     __shared__ uint64_t stab[8 << TSL];                                // the current register sub-tree's 8 leaf tables
     __shared__ __attribute__((aligned(16))) uint32_t stape[SPW * 32];  // and its 8 x 4 tape words per signature
+    __shared__ double stree[(LM + 1) << LM];                           // the LDL tree block of the current level-LM node (falcon_ldl.h:56-71: treesize(LM) doubles)
+    __shared__ double sgm[2 << LM];                                    // the roots the levels <= LM use: complex entries [0, 2^LM)
     unsigned long long pc[6] = { 0, 0, 0, 0, 0, 0 }, tprev = 0;
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #define FAL_STAMP(ph) do { if (PROF) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); pc[ph] += tn_ - tprev; tprev = tn_; } } while (0)
@@ -865,6 +876,8 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     const uint64_t runmask = __ballot(inb && !shortt);                  // bit 8k: signature k of this wavefront writes its results
     const Lin mine = { wv.p + (size_t)sg * per };
     const LdsG lg = { lds + sg * 8 };
+    for (uint32_t i = lane; i < (2u << LM); i += 64) sgm[i] = gm[i];
+    uint32_t toffLM = 0;                                               // tree offset of the current level-LM node
     const int ln = logn;                                               // log2 of the elements per signature in the flattened loops
 
     // ---- FFT(c) and the two target vectors (gpv.c:3040-3054): two signatures at a time through LDS (n doubles each, padded)
@@ -932,8 +945,9 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
 #pragma unroll
                 for (int i = 0; i < (1 << FK); i++) { t0r[i] = lg.ld(pt0 + i); t1r[i] = lg.ld(pt1 + i); }
-                LeafLds<TSL> lfl = { stab, stape + sg * 32, g, 0 };
-                FFS<FK, LeafLds<TSL>>::run(z0r, z1r, tree + toff, t0r, t1r, gm, lfl);
+                LeafPre<TSL> lfl;
+                lfl.draw(stab, stape + sg * 32, g);
+                FFS<FK, LeafPre<TSL>>::run(z0r, z1r, stree + (toff - toffLM), t0r, t1r, gm, lfl);
                 if (g == 0) {
 #pragma unroll
                     for (int i = 0; i < (1 << FK); i++) { lg.st(pz0 + i, z0r[i]); lg.st(pz1 + i, z1r[i]); }
@@ -946,10 +960,14 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 continue;
             }
             if (l > LM) split_sw<64, 2, SPW, false>(wv, w.z1(l), w.z1(l) + hm, wv, w.t1(l), lane, l, per, gm);
-            else if (l == LM) split_sw<8, 2, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, gm);
-            else if (l == LM - 1) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
-            else if (l == LM - 2) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
-            else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, gm);
+            else if (l == LM) {
+                toffLM = toff;
+                for (uint32_t i = lane * 2; i < treesize(LM); i += 128) *reinterpret_cast<double2 *>(stree + i) = *reinterpret_cast<const double2 *>(tree + toff + i);
+                split_sw<8, 2, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, sgm);
+            }
+            else if (l == LM - 1) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+            else if (l == LM - 2) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+            else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
             wave_sync();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph &= ~(1u << l);
@@ -959,11 +977,12 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
         if (!((w.ph >> l) & 1)) {
             toff -= m + treesize(l - 1);
             const double *L = tree + toff;
+            const double *LL = stree + (toff - toffLM);                // the same block in LDS (levels <= LM)
             if (l > LM) mid_sw<64, 2, SPW, false>(wv, w.tmp(l), wv, w.t0(l), w.t1(l), wv, w.z1(l), wv, w.z0(l), lane, l, per, gm, L);
-            else if (l == LM) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, gm, L);
-            else if (l == LM - 1) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
-            else if (l == LM - 2) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
-            else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, gm, L);
+            else if (l == LM) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, sgm, LL);
+            else if (l == LM - 1) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+            else if (l == LM - 2) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+            else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
             wave_sync();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph |= 1u << l;
@@ -973,10 +992,10 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
         }
         toff -= m;
         if (l > LM) merge_sw<64, 2, SPW, false>(wv, w.z0(l), wv, w.tmp(l), w.tmp(l) + hm, lane, l, per, gm);
-        else if (l == LM) merge_sw<8, 2, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
-        else if (l == LM - 1) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
-        else if (l == LM - 2) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
-        else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, gm);
+        else if (l == LM) merge_sw<8, 2, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+        else if (l == LM - 1) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+        else if (l == LM - 2) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+        else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
         wave_sync();
         FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
         w.ph &= ~(1u << l);
