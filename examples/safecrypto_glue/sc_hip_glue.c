@@ -1,0 +1,238 @@
+/* sc_hip_glue.c - see sc_hip_glue.h.  Compiled against libsafecrypto's headers; every layout it relies on is the reference's own. */
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sc_hip_glue.h"
+#include "utils/arith/arith.h"
+#include "utils/arith/ntt.h"
+#include "utils/arith/module_lwe.h"
+#include "utils/sampling/sampling.h"
+#include "utils/crypto/prng.h"
+#include "schemes/sig/dilithium/dilithium.h"
+#include "schemes/sig/dilithium/dilithium_params.h"
+
+#include "sc_hip.h"
+#include "sc_hip_vtable.h"
+
+/* the mirrors must BE the reference's structs: checked where both definitions are visible */
+_Static_assert(sizeof(sc_hip_utils_arith_ntt_t) == sizeof(utils_arith_ntt_t), "utils_arith_ntt_t mirror");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, modn_32) == offsetof(utils_arith_ntt_t, modn_32), "modn_32");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, mul_32_pointwise) == offsetof(utils_arith_ntt_t, mul_32_pointwise), "mul_32_pointwise");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, fft_32_16) == offsetof(utils_arith_ntt_t, fft_32_16), "fft_32_16");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, pwr_32) == offsetof(utils_arith_ntt_t, pwr_32), "pwr_32");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, flip_32) == offsetof(utils_arith_ntt_t, flip_32), "flip_32");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, normalize_32) == offsetof(utils_arith_ntt_t, normalize_32), "normalize_32");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, fwd_ntt_32_32) == offsetof(utils_arith_ntt_t, fwd_ntt_32_32), "fwd_ntt_32_32");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, inv_ntt_32_16_large) == offsetof(utils_arith_ntt_t, inv_ntt_32_16_large), "inv_ntt_32_16_large");
+_Static_assert(offsetof(sc_hip_utils_arith_ntt_t, slots_limb) == offsetof(utils_arith_ntt_t, modn_limb), "limb third");
+_Static_assert(sizeof(sc_hip_utils_arith_poly_t) == sizeof(utils_arith_poly_t), "utils_arith_poly_t mirror");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, copy_32) == offsetof(utils_arith_poly_t, copy_32), "copy_32");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, mul_32_scalar) == offsetof(utils_arith_poly_t, mul_32_scalar), "mul_32_scalar");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, add_32) == offsetof(utils_arith_poly_t, add_32), "add_32");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, sub_single_32) == offsetof(utils_arith_poly_t, sub_single_32), "sub_single_32");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, mod_negate_32) == offsetof(utils_arith_poly_t, mod_negate_32), "mod_negate_32");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, cmp_not_equal_32) == offsetof(utils_arith_poly_t, cmp_not_equal_32), "cmp_not_equal_32");
+_Static_assert(offsetof(sc_hip_utils_arith_poly_t, uniform_32) == offsetof(utils_arith_poly_t, uniform_32), "uniform_32");
+_Static_assert(sizeof(sc_hip_utils_arith_vec_t) == sizeof(utils_arith_vec_t), "utils_arith_vec_t mirror");
+_Static_assert(sizeof(sc_hip_utils_sampling_t) == sizeof(utils_sampling_t), "utils_sampling_t mirror");
+_Static_assert(offsetof(sc_hip_utils_sampling_t, vector_32) == offsetof(utils_sampling_t, vector_32), "vector_32");
+_Static_assert(offsetof(sc_hip_utils_sampling_t, gauss) == offsetof(utils_sampling_t, gauss), "gauss");
+_Static_assert(offsetof(sc_hip_utils_sampling_t, prng_ctx) == offsetof(utils_sampling_t, prng_ctx), "prng_ctx");
+_Static_assert(offsetof(sc_hip_utils_sampling_t, discard) == offsetof(utils_sampling_t, discard), "discard");
+_Static_assert(sizeof(sc_hip_ntt_params_t) == sizeof(ntt_params_t), "ntt_params_t mirror");
+_Static_assert(offsetof(sc_hip_ntt_params_t, u.ntt32.q) == offsetof(ntt_params_t, u.ntt32.q), "ntt32.q");
+
+/* ---- inner boundary ---------------------------------------------------------------------------------------------------------------- */
+
+struct sc_hip_glue {
+    safecrypto_t *sc;
+    const utils_arith_ntt_t *ntt0; const utils_arith_poly_t *poly0; const utils_arith_vec_t *vec0; utils_sampling_t *gauss0;
+    sc_hip_utils_arith_ntt_t ntt; sc_hip_utils_arith_poly_t poly; sc_hip_utils_arith_vec_t vec;
+    sc_hip_sampler_t *sampler; sc_hip_utils_sampling_t sampling;
+};
+
+/* the private struct behind a 64-bit CDF sampler's `gauss` pointer (src/utils/sampling/gaussian_cdf.c:74-81) */
+typedef struct __attribute__((packed)) { UINT64 *cdf; SINT32 cdf_size; SINT32 k; SINT32 use_kl; prng_ctx_t *prng_ctx; } gauss_cdf_64_view_t;
+
+static uint64_t glue_rng64(void *ctx) { return prng_64((prng_ctx_t *)ctx); }
+
+sc_hip_glue_t *sc_hip_glue_attach(safecrypto_t *sc, int device)
+{
+    if (NULL == sc || SC_HIP_SUCCESS != sc_hip_vtable_bind_device(device)) return NULL;
+    sc_hip_glue_t *g = calloc(1, sizeof *g);
+    if (NULL == g) return NULL;
+    g->sc = sc; g->ntt0 = sc->sc_ntt; g->poly0 = sc->sc_poly; g->vec0 = sc->sc_vec; g->gauss0 = sc->sc_gauss;
+    /* what the engine does not serve (scalar slots, 16-bit and limb thirds) stays the context's own backend */
+    if (sc_hip_utils_arith_ntt_fill(&g->ntt, g->ntt0) || sc_hip_utils_arith_poly_fill(&g->poly, g->poly0) || sc_hip_utils_arith_vec_fill(&g->vec)) {
+        free(g);
+        return NULL;
+    }
+    if (NULL != g->ntt0) sc->sc_ntt = (const utils_arith_ntt_t *)&g->ntt;
+    if (NULL != g->poly0) sc->sc_poly = (const utils_arith_poly_t *)&g->poly;
+    if (NULL != g->vec0) sc->sc_vec = (const utils_arith_vec_t *)&g->vec;
+    /* a 64-bit CDF sampler (SC_FLAG_0_SAMPLE_64BIT, CDF_GAUSSIAN_SAMPLING) is served with the context's OWN table, so the samples are
+     * the reference's for the same prng_64 words on any host */
+    if (NULL != g->gauss0 && CDF_GAUSSIAN_SAMPLING == sc->sampling && SAMPLING_64BIT == g->gauss0->precision &&
+        SAMPLING_DISABLE_BOOTSTRAP == g->gauss0->bootstrapped && 0 == g->gauss0->discard) {
+        const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)g->gauss0->gauss;
+        if (SC_HIP_SUCCESS == sc_hip_sampler_create(g->gauss0->tail, g->gauss0->sigma, v->cdf, v->cdf_size, glue_rng64, g->gauss0->prng_ctx, &g->sampler) &&
+            SC_HIP_SUCCESS == sc_hip_utils_sampling_fill(&g->sampling, g->sampler)) {
+            g->sampling.dimension = g->gauss0->dimension;
+            sc->sc_gauss = (utils_sampling_t *)&g->sampling;
+        }
+    }
+    return g;
+}
+
+void sc_hip_glue_refresh_prng(sc_hip_glue_t *g)
+{
+    if (NULL == g || NULL == g->sampler) return;
+    sc_hip_sampler_set_rng(g->sampler, glue_rng64, g->sc->prng_ctx[0]);
+    g->sampling.prng_ctx = g->sc->prng_ctx[0];
+}
+
+void sc_hip_glue_detach(sc_hip_glue_t *g)
+{
+    if (NULL == g) return;
+    g->sc->sc_ntt = g->ntt0; g->sc->sc_poly = g->poly0; g->sc->sc_vec = g->vec0; g->sc->sc_gauss = g->gauss0;
+    if (NULL != g->sampler) sc_hip_sampler_destroy(g->sampler);
+    free(g);
+}
+
+/* ---- outer boundary: Dilithium ---------------------------------------------------------------------------------------------------------- */
+
+/* a maintainer would add one pointer to safecrypto_t; from outside the library a small registry does the same job */
+#define GLUE_MAX 16
+static struct { safecrypto_t *sc; sc_hip_ctx_t *ctx; sc_hip_dilithium_t *dil; int have_priv, have_pub; } g_reg[GLUE_MAX];
+
+static int reg_find(safecrypto_t *sc, int create)
+{
+    int free_slot = -1;
+    for (int i = 0; i < GLUE_MAX; i++) {
+        if (g_reg[i].sc == sc) return i;
+        if (NULL == g_reg[i].sc && free_slot < 0) free_slot = i;
+    }
+    if (!create || free_slot < 0) return -1;
+    memset(&g_reg[free_slot], 0, sizeof g_reg[free_slot]);
+    g_reg[free_slot].sc = sc;
+    return free_slot;
+}
+
+void sc_hip_glue_forget(safecrypto_t *sc)
+{
+    const int i = reg_find(sc, 0);
+    if (i < 0) return;
+    if (g_reg[i].dil) sc_hip_dilithium_destroy(g_reg[i].dil);
+    if (g_reg[i].ctx) sc_hip_ctx_destroy(g_reg[i].ctx);
+    memset(&g_reg[i], 0, sizeof g_reg[i]);
+}
+
+/* the engine handle for this context, its keys loaded from sc->privkey / sc->pubkey (layouts: dilithium.c:810-824) */
+static sc_hip_dilithium_t *dil_handle(safecrypto_t *sc, int need_priv, int need_pub)
+{
+    if (NULL == sc || SC_SCHEME_SIG_DILITHIUM != sc->scheme || NULL == sc->dilithium) return NULL;
+    const int i = reg_find(sc, 1);
+    if (i < 0) return NULL;
+    const dilithium_set_t *P = sc->dilithium->params;
+    const size_t n = P->n, k = P->k, l = P->l;
+    if (NULL == g_reg[i].dil) {
+        if (SC_HIP_SUCCESS != sc_hip_ctx_create(0, &g_reg[i].ctx)) return NULL;
+        sc_hip_dilithium_params_t hp = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->k, (int32_t)P->l, (int32_t)P->d,
+                                         (int32_t)P->weight_of_c, (int32_t)P->gamma_1, (int32_t)P->gamma_1_bits, (int32_t)P->gamma_2,
+                                         (int32_t)P->eta, (int32_t)P->z_bits, (int32_t)P->beta, (int32_t)P->omega, (int32_t)P->omega_bits, (int32_t)P->set };
+        if (SC_HIP_SUCCESS != sc_hip_dilithium_create(g_reg[i].ctx, &hp, &g_reg[i].dil)) { sc_hip_glue_forget(sc); return NULL; }
+    }
+    if ((need_priv && !g_reg[i].have_priv) || (need_pub && !g_reg[i].have_pub)) {
+        const SINT32 *priv = sc->privkey ? (const SINT32 *)sc->privkey->key : NULL, *pub = sc->pubkey ? (const SINT32 *)sc->pubkey->key : NULL;
+        const UINT8 *rho = NULL;
+        if (need_priv && NULL == priv) return NULL;
+        if (need_pub && NULL == pub) return NULL;
+        if (NULL != priv) rho = (const UINT8 *)(priv + (NUM_DILITHIUM_PRIVKEY_K * k + l) * n); else rho = (const UINT8 *)(pub + k * n);
+        /* the matrix, in the order create_rand_product_32_csprng draws it from rho (module_lwe.c:519-547, 641-660; create_csprng :914-940) */
+        SINT32 *A = malloc(sizeof(SINT32) * k * l * n);
+        if (NULL == A) return NULL;
+        prng_ctx_t *csprng = create_csprng(sc, rho, 32);
+        for (size_t j = 0; j < k * l; j++) uniform_random_ring_q_csprng(csprng, A + j * n, n, P->q, P->q_bits);
+        prng_destroy(csprng);
+        int rc = SC_HIP_SUCCESS;
+        if (need_priv && !g_reg[i].have_priv) {
+            const UINT8 *tail = (const UINT8 *)(priv + (NUM_DILITHIUM_PRIVKEY_K * k + l) * n);
+            rc = sc_hip_dilithium_set_privkey(g_reg[i].dil, priv, priv + l * n, priv + (l + k) * n, tail + 32, tail + 64, A);
+            if (SC_HIP_SUCCESS == rc) g_reg[i].have_priv = 1;
+        }
+        if (SC_HIP_SUCCESS == rc && need_pub && !g_reg[i].have_pub) {
+            rc = sc_hip_dilithium_set_pubkey(g_reg[i].dil, pub, (const UINT8 *)(pub + k * n), A);
+            if (SC_HIP_SUCCESS == rc) g_reg[i].have_pub = 1;
+        }
+        free(A);
+        if (SC_HIP_SUCCESS != rc) return NULL;
+    }
+    return g_reg[i].dil;
+}
+
+size_t sc_hip_glue_dilithium_sig_max(safecrypto_t *sc)
+{
+    sc_hip_dilithium_t *d = dil_handle(sc, 0, 0);
+    return d ? sc_hip_dilithium_sig_max(d) : 0;
+}
+
+SINT32 sc_hip_glue_dilithium_sign_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                        UINT8 *sigs, size_t sig_stride, UINT32 *siglens)
+{
+    sc_hip_dilithium_t *d = dil_handle(sc, 1, 0);
+    if (NULL == d) return SC_FUNC_FAILURE;
+    UINT32 *trials = malloc(sizeof(UINT32) * (batch ? batch : 1));
+    if (NULL == trials) return SC_FUNC_FAILURE;
+    const int rc = sc_hip_dilithium_sign_host(d, batch, msgs, msg_stride, mlens, 0, sigs, sig_stride, siglens, trials);
+    if (SC_HIP_SUCCESS == rc) for (size_t i = 0; i < batch; i++) { sc->stats.sig_num++; sc->stats.sig_num_trials += trials[i]; }   /* as dilithium_sign books them */
+    free(trials);
+    return SC_HIP_SUCCESS == rc ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_dilithium_verify_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                          const UINT8 *sigs, size_t sig_stride, const UINT32 *siglens, UINT32 *verdicts)
+{
+    sc_hip_dilithium_t *d = dil_handle(sc, 0, 1);
+    if (NULL == d) return SC_FUNC_FAILURE;
+    return SC_HIP_SUCCESS == sc_hip_dilithium_verify_host(d, batch, msgs, msg_stride, mlens, 0, sigs, sig_stride, siglens, verdicts) ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_dilithium_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen)
+{
+    if (NULL == sigret || NULL == siglen || (NULL == m && m_len > 0)) return SC_FUNC_FAILURE;
+    const size_t cap = sc_hip_glue_dilithium_sig_max(sc);
+    if (0 == cap) return SC_FUNC_FAILURE;
+    UINT8 *tmp = malloc(cap);
+    if (NULL == tmp) return SC_FUNC_FAILURE;
+    UINT32 ml = (UINT32)m_len, sl = 0;
+    UINT8 dummy = 0;
+    if (SC_FUNC_SUCCESS != sc_hip_glue_dilithium_sign_batch(sc, 1, m_len ? m : &dummy, m_len ? m_len : 1, &ml, tmp, cap, &sl)) { free(tmp); return SC_FUNC_FAILURE; }
+    if (NULL == *sigret || 0 == *siglen) {                               /* packer.c:142-176: the callee allocates, the caller frees */
+        *sigret = realloc(tmp, sl ? sl : 1);
+        if (NULL == *sigret) { free(tmp); return SC_FUNC_FAILURE; }
+    } else {
+        if (*siglen < sl) { free(tmp); return SC_FUNC_FAILURE; }
+        memcpy(*sigret, tmp, sl);
+        free(tmp);
+    }
+    *siglen = sl;
+    return SC_FUNC_SUCCESS;
+}
+
+SINT32 sc_hip_glue_dilithium_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen)
+{
+    if (NULL == sigbuf || (NULL == m && m_len > 0)) return SC_FUNC_FAILURE;
+    const size_t cap = sc_hip_glue_dilithium_sig_max(sc);
+    if (0 == cap) return SC_FUNC_FAILURE;
+    /* the engine reads whole rows of sc_hip_dilithium_sig_max() bytes: give it one */
+    UINT8 *row = calloc(1, cap);
+    if (NULL == row) return SC_FUNC_FAILURE;
+    memcpy(row, sigbuf, siglen < cap ? siglen : cap);
+    UINT32 ml = (UINT32)m_len, sl = (UINT32)siglen, verdict = 1;
+    UINT8 dummy = 0;
+    const SINT32 rc = sc_hip_glue_dilithium_verify_batch(sc, 1, m_len ? m : &dummy, m_len ? m_len : 1, &ml, row, cap, &sl, &verdict);
+    free(row);
+    if (SC_FUNC_SUCCESS != rc) return SC_FUNC_FAILURE;
+    return verdict == 0 ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}

@@ -1,0 +1,40 @@
+/*
+ * sc_hip_glue.h - the libsafecrypto-side binding to the MI355X engine: the file a libsafecrypto maintainer adds to the library
+ * (it is compiled AGAINST libsafecrypto's private headers, and linked with -lsc_hip).  Not part of the engine.
+ *
+ *   inner boundary  sc_hip_glue_attach():   points sc->sc_ntt / sc->sc_poly / sc->sc_vec / sc->sc_gauss of an existing context at the
+ *                                           engine's tables (include/sc_hip_vtable.h); the scheme code is untouched and every
+ *                                           polynomial operation it performs runs on the GPU, one polynomial per call.
+ *   outer boundary  sc_hip_glue_*_sign ...: entries with the signatures of the scheme table safecrypto_alg_t
+ *                                           (src/safecrypto_private.h:392-419) that hand the whole operation - hashing, sampling,
+ *                                           rejection loop, packing - to the engine's scheme-level kernels, for one message or a batch.
+ */
+#ifndef SC_HIP_GLUE_H
+#define SC_HIP_GLUE_H
+#include "safecrypto.h"
+#include "safecrypto_private.h"
+
+typedef struct sc_hip_glue sc_hip_glue_t;
+
+/* inner boundary.  device: the HIP device this host thread works on.  Returns NULL when no device is usable (nothing is changed). */
+sc_hip_glue_t *sc_hip_glue_attach(safecrypto_t *sc, int device);
+/* puts the context's own tables back (call before safecrypto_destroy) */
+void sc_hip_glue_detach(sc_hip_glue_t *g);
+/* the sampler's PRNG follows sc->prng_ctx[0]; call after swapping that pointer */
+void sc_hip_glue_refresh_prng(sc_hip_glue_t *g);
+
+/* outer boundary, Dilithium: same signatures as the `signing` / `verification` rows (safecrypto_private.h:362-366), same
+ * buffer rules as the reference's packer (packer.c:142-176): *sigret == NULL or *siglen == 0 -> a buffer is malloc'ed for the caller */
+SINT32 sc_hip_glue_dilithium_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
+SINT32 sc_hip_glue_dilithium_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen);
+/* the batched form that sits beside safecrypto_sign: `batch` messages of msg_stride bytes (lengths mlens[i]) under sc's key,
+ * signatures into sigs[i * sig_stride], lengths into siglens[i] */
+SINT32 sc_hip_glue_dilithium_sign_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                        UINT8 *sigs, size_t sig_stride, UINT32 *siglens);
+SINT32 sc_hip_glue_dilithium_verify_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                          const UINT8 *sigs, size_t sig_stride, const UINT32 *siglens, UINT32 *verdicts);
+size_t sc_hip_glue_dilithium_sig_max(safecrypto_t *sc);
+/* drops the engine handle cached for this context (keys changed, or before safecrypto_destroy) */
+void sc_hip_glue_forget(safecrypto_t *sc);
+
+#endif

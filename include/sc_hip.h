@@ -174,6 +174,9 @@ int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *h, size_t batch, const uint
 
 /* replaces: pwr_32 (src/utils/arith/ntt_template.c.in:1689-1720) elementwise: d_out[i] = d_x[i]^e mod q, canonical; e >= 0 */
 int sc_hip_ntt_pwr(sc_hip_plan_t *plan, size_t len, const int32_t *d_x, int32_t e, int32_t *d_out, void *stream);
+/* replaces: flip_32 = ntt32_flip_generic (src/utils/arith/ntt.c:584-604) for `batch` polynomials of the plan's n: out[0] = -in[0], out[i] = in[n-i],
+ * then one conditional +q and one conditional -q per coefficient (inputs in (-q, 2q) come out canonical).  d_out must not alias d_in. */
+int sc_hip_ntt_flip(sc_hip_plan_t *plan, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream);
 /* replaces: invert_32 (ntt_template.c.in:1722-1747) for `batch` arrays of n coefficients (any n >= 1; the plan supplies q), in place: v <- v^(q-2).
  * d_rc[i] = 0 (SC_FUNC_SUCCESS) or 1 (SC_FUNC_FAILURE: polynomial i has a coefficient = 0 mod q; as in the reference the
  * coefficients before the first such one are inverted and the rest left untouched).  Outputs canonical. */

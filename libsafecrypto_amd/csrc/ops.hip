@@ -52,6 +52,19 @@ __global__ __launch_bounds__(256) void flat_kernel(const int32_t *__restrict__ i
     if (blockIdx.x == 0 && threadIdx.x < (len & 3)) { const size_t i = nv * 4 + threadIdx.x; out[i] = f(in[i]); }
 }
 
+// ntt32_flip_generic (src/utils/arith/ntt.c:584-604; the tail of every inverse transform of the reference, also a slot of its own): v[0] <- -v[0],
+// v[i] <-> v[n-i], then ONE conditional +q and ONE conditional -q per coefficient - not a full reduction: inputs are expected in (-q, 2q)
+__global__ __launch_bounds__(256) void flip_kernel(const int32_t *__restrict__ in, int32_t *__restrict__ out, size_t batch, uint32_t n, int32_t q)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= batch * n) return;
+    const size_t b = t / n; const uint32_t i = (uint32_t)(t % n);
+    int32_t x = (i == 0) ? (int32_t)(0u - (uint32_t)in[b * n]) : in[b * n + (n - i)];
+    x += q * (int32_t)((uint32_t)x >> 31);
+    x -= q * (int32_t)(x >= q);
+    out[t] = x;
+}
+
 // poly_32.c:38-43: coefficient 0 of every polynomial
 __global__ void add_scalar_kernel(int32_t *__restrict__ p, size_t batch, size_t n, const int32_t *__restrict__ scalars)
 {
@@ -223,6 +236,17 @@ extern "C" int sc_hip_ntt_pwr(sc_hip_plan_t *p, size_t len, const int32_t *d_x, 
     if (!p) return fail("ntt_pwr: null plan");
     if (e < 0) return fail("ntt_pwr: negative exponent");
     return run_flat<FL_PWR>(p->ctx, p->k[1], p->r2, p->r2p, len, d_x, e, d_out, stream, "ntt_pwr");
+}
+extern "C" int sc_hip_ntt_flip(sc_hip_plan_t *p, size_t batch, const int32_t *d_in, int32_t *d_out, void *stream)
+{
+    if (!p) return fail("ntt_flip: null plan");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_in || !d_out || d_in == d_out) return fail("ntt_flip: null buffer, or output aliasing the input (the permutation is not done in place)");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const size_t tot = batch * (size_t)p->n;
+    hipLaunchKernelGGL(flip_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, batch, (uint32_t)p->n, p->q);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
 }
 extern "C" int sc_hip_ntt_invert(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *d_v, int32_t *d_rc, void *stream)
 { return run_invert(p, batch, n, d_v, nullptr, d_rc, stream, "ntt_invert"); }

@@ -25,7 +25,7 @@ SYMBOLS = [
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
-    'sc_hip_ntt_pwr', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
+    'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
@@ -41,7 +41,8 @@ SYMBOLS = [
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
 BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile']
 # include/sc_hip_vtable.h
-VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors']
+VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
+                  'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
 
 
 class EngineError(RuntimeError):
@@ -144,6 +145,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_keygen.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
+    L.sc_hip_ntt_flip.argtypes = [vp, sz, vp, vp, vp]
     L.sc_hip_ntt_invert.argtypes = [vp, sz, sz, vp, vp, vp]
     L.sc_hip_ntt_div.argtypes = [vp, sz, sz, vp, vp, vp, vp]
     L.sc_hip_mult_sparse.argtypes = [vp, sz, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -492,6 +494,13 @@ class NttPlan:
     def pwr(self, x, e, out=None):
         out = self._out(x, out)
         _chk(self.L, self.L.sc_hip_ntt_pwr(self.h, x.numel(), _ptr(x), int(e), _ptr(out), _stream()), 'ntt_pwr')
+        return out
+
+    def flip(self, x):
+        """flip_32 (ntt32_flip_generic) of x [batch][n]"""
+        import torch
+        out = torch.empty_like(x)
+        _chk(self.L, self.L.sc_hip_ntt_flip(self.h, self._batch(x), _ptr(x), _ptr(out), _stream()), 'ntt_flip')
         return out
 
     def invert(self, v):

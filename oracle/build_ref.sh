@@ -80,5 +80,16 @@ $CC -shared -o "$OUT/libsafecrypto_ref.so" "$B"/obj/*.o -lm -lpthread
 # 5. our driver (our source, reference headers at build time only)
 $CC -O2 -std=gnu11 -w $DEFS $INC "$HERE/ref_driver.c" -o "$OUT/ref_driver" \
     -L"$OUT" -lsafecrypto_ref -Wl,-rpath,'$ORIGIN' -lm -lpthread
+# 6. the drop-in proof (examples/safecrypto_glue: the libsafecrypto-side binding + a driver; our sources, reference headers at build time only),
+#    linked with the reference library AND the engine; it only runs where there is a GPU (tests/test_gpu_dropin.py)
+ENG="$HERE/../libsafecrypto_amd/lib"
+GLUE="$HERE/../examples/safecrypto_glue"
+if [ -f "$ENG/libsc_hip.so" ]; then
+    $CC -O2 -std=gnu11 -w $DEFS $INC -I"$HERE/../include" -I"$GLUE" "$GLUE/dropin_driver.c" "$GLUE/sc_hip_glue.c" -o "$OUT/dropin_driver" \
+        -L"$OUT" -lsafecrypto_ref -L"$ENG" -lsc_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,'$ORIGIN/../../libsafecrypto_amd/lib' \
+        -Wl,-rpath-link,/opt/rocm/lib -Wl,-rpath,/opt/rocm/lib -lm -lpthread
+else
+    echo "build_ref: libsc_hip.so not built yet - skipping dropin_driver"
+fi
 [ -n "${SC_REF_KEEP:-}" ] || rm -rf "$B"
 echo "build_ref: OK -> $OUT"
