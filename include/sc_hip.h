@@ -18,10 +18,14 @@
  *     reference's fwd_ntt_32_* followed by normalize_32
  *   - there is NO CPU fallback: every compute entry fails (returns 1, message through
  *     sc_hip_last_error) when no gfx950 device / kernel image is available
- *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs are immutable after
- *     creation and may be shared; a scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t, _dlp_t) owns the
+ *   - threading follows the reference (one safecrypto_t per thread, src/safecrypto.c): plans and CDTs may be shared between threads
+ *     and streams - their tables are immutable after creation; sc_hip_matvec keeps its scratch in the plan and orders overlapping
+ *     calls itself (host mutex + device event); sc_hip_plan_set_arith is configuration, to be called before the plan is used
+ *     concurrently.  A scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t, _dlp_t) owns the
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
+ *   - device memory that held key material, masks, noise or CSPRNG output is zeroed before it is freed, and the per-call secrets of
+ *     sign / decapsulate / encrypt calls are zeroed on the call's stream behind its kernels (the reference zeroes sc->temp the same way)
  */
 #ifndef SC_HIP_H
 #define SC_HIP_H
@@ -475,6 +479,9 @@ int  sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const int32_t *b,
 /* the same from the private key alone: f | g | F | G (SINT32, 4n words = sc->privkey->key); derives the three matrices as create_gpv_matrices does
  * (gpv_expand_basis, modified_gram_schmidt_fast_flt, gpv_precompute_inv_flt: src/utils/arith/gpv.c:709-760, 1021-1117, 977-984), on the host at key load */
 int  sc_hip_ens_dlp_signer_set_privkey(sc_hip_ens_dlp_signer_t *h, const int32_t *fgFG);
+/* lanes per signature of Klein's sampler: 0 (default) chosen from the batch size; 1 = a lane per signature with the state in HBM, 4 / 8 / 16 = that
+ * many lanes with the state in registers (>= n / 64).  Results are identical. */
+int  sc_hip_ens_dlp_signer_set_mapping(sc_hip_ens_dlp_signer_t *h, int lanes);
 size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h);        /* n * q_bits / 8 */
 size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h);   /* 4n: one prng_64 per basis row */
 /* d_tapes row i: the prng_32 word stream of sc->prng_ctx[0] during signature i (8-byte aligned rows, tape_stride even and >= 4n);

@@ -520,7 +520,7 @@ static void bl_free_ws(sc_hip_bliss *b)
 {
     void *ptrs[] = { b->st.pos, b->st.var_buf, b->st.iter, b->st.cur, b->st.status, b->st.var_bits, b->act[0], b->act[1], b->cnt, b->need, b->sbase, b->ok,
                      b->trials, b->tu, b->tin, b->v, b->cidx, b->z };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     memset(&b->st, 0, sizeof b->st);
     b->act[0] = b->act[1] = b->cnt = b->need = b->sbase = b->ok = b->trials = nullptr;
     b->tu = b->tin = b->v = b->cidx = nullptr; b->z = nullptr; b->cap = 0;
@@ -562,9 +562,9 @@ extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
 {
     if (!b) return;
     bl_free_ws(b);
-    if (b->d_f) (void)hipFree(b->d_f);
-    if (b->d_g) (void)hipFree(b->d_g);
-    if (b->d_a) (void)hipFree(b->d_a);
+    if (b->d_f) (void)sc::wipe_free(b->d_f);
+    if (b->d_g) (void)sc::wipe_free(b->d_g);
+    if (b->d_a) (void)sc::wipe_free(b->d_a);
     sc_hip_cdt_destroy(b->cdt);
     sc_hip_plan_destroy(b->plan);
     delete b;
@@ -654,6 +654,8 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
         active = next;
     }
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+    // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
+    sc::wipe_async(b->tu, s); sc::wipe_async(b->tin, s); sc::wipe_async(b->v, s); sc::wipe_async(b->z, s);
     return SC_HIP_SUCCESS;
 }
 

@@ -350,7 +350,10 @@ __global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sig
     if (item >= count) return;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
     const uint8_t *s = sigs + (size_t)item * sig_stride;
-    const uint32_t total = siglens[item] * 8;
+    // an (untrusted) length beyond the row is invalid, and nothing is ever read past the row: positions are bounded by `total`
+    const uint32_t slen = siglens[item];
+    const bool too_long = slen > sig_stride;
+    const uint32_t total = (uint32_t)(too_long ? sig_stride : slen) * 8;
     const uint32_t zbits = (uint32_t)(P.l * P.n * P.z_bits);
     auto get = [&](uint32_t pos, int bits) -> uint32_t {                // bits <= 16, the caller has checked pos + bits <= total
         const uint32_t b0 = pos >> 3;
@@ -360,8 +363,9 @@ __global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sig
     uint8_t *hh = h + (size_t)item * kn;
     for (int i = lane * 16; i < kn; i += 64 * 16) *reinterpret_cast<uint4 *>(hh + i) = make_uint4(0, 0, 0, 0);
     seen[wv][lane] = 0;
-    bool err = total < zbits + (uint32_t)P.omega_bits;
-    const uint32_t no = err ? 0 : get(zbits, P.omega_bits);
+    bool err = too_long || total < zbits + (uint32_t)P.omega_bits;
+    uint32_t no = err ? 0 : get(zbits, P.omega_bits);
+    if (no > (uint32_t)P.omega) { err = true; no = 0; }                 // more hints than check_hint_ones allows: invalid whatever they are
     const uint32_t hbase = zbits + (uint32_t)P.omega_bits, cbase = hbase + no * (uint32_t)h_bits;
     if (!err && total < cbase + 2u * (uint32_t)P.n) err = true;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -412,13 +416,14 @@ struct sc_hip_dilithium {
     uint8_t *msg_dev, *sig_dev;
     size_t msg_cap, sig_cap;
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
+    int tune_slots, tune_unfused;                     // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product
 };
 
 static void free_ws(sc_hip_dilithium *d)
 {
     void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->flags, d->ones, d->trials, d->act[0], d->act[1], d->cnt, d->slot_item, d->slot_kappa,
                      d->acc_slot, d->y, d->w, d->c, d->z, d->r, d->yh, d->ch };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     d->mu = d->w1 = d->h = nullptr; d->kappa = d->flags = d->ones = d->trials = d->act[0] = d->act[1] = d->cnt = d->slot_item = d->slot_kappa = nullptr;
     d->acc_slot = nullptr; d->y = d->w = d->c = d->z = d->r = nullptr; d->yh = d->ch = nullptr;
     d->cap = 0; d->slot_cap = 0;
@@ -482,7 +487,7 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
     free_ws(d);
     d->kws.release();
     void *ptrs[] = { d->d_A, d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(d->plan);
     delete d;
 }
@@ -573,14 +578,21 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
     if (batch > 0x7fffffffu / 32) return fail("matvec: batch too large");
     if (!d_Ahat || !d_y || !d_t) return fail("matvec: null device pointer");
     HIPCHK(hipSetDevice(p->ctx->device));
+    // The scratch (NTT(y) and the matrix in internal order) belongs to the plan, and plans are shared between threads and streams: calls are
+    // serialised on the host by the plan's mutex and on the device by an event - a call on another stream waits for the previous product to
+    // finish with the scratch, and the scratch is only freed once nothing uses it.
+    std::lock_guard<std::mutex> mv_lock(p->mv_mu);
+    hipStream_t s = (hipStream_t)stream;
     const size_t need = ((size_t)kk * l + batch * (size_t)l) * N * 4;
     if (need > p->mv_cap) {
-        if (p->mv_ws) (void)hipFree(p->mv_ws);
+        if (p->mv_event) HIPCHK(hipEventSynchronize((hipEvent_t)p->mv_event));
+        if (p->mv_ws) (void)sc::wipe_free(p->mv_ws);
         p->mv_ws = nullptr; p->mv_cap = 0;
         HIPCHK(hipMalloc((void **)&p->mv_ws, need));
         p->mv_cap = need;
     }
-    hipStream_t s = (hipStream_t)stream;
+    if (!p->mv_event) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->mv_event = e; }
+    else HIPCHK(hipStreamWaitEvent(s, (hipEvent_t)p->mv_event, 0));
     uint32_t *A_int = p->mv_ws, *yh = p->mv_ws + (size_t)kk * l * N;
     const size_t np = (size_t)kk * l;
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, s, d_Ahat, A_int, np, p->k[1], p->r2, p->r2p,
@@ -593,6 +605,15 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
     a.in = d_y; a.out_int = yh; a.yh = yh; a.key = A_int; a.w = d_t; a.w1 = nullptr;
     if (launch_dil<DOP_FWD_INT>(&tmp, a, (uint32_t)batch, l, s)) return SC_HIP_FAILURE;
     if (launch_dil<DOP_MATVEC>(&tmp, a, (uint32_t)batch, kk, s)) return SC_HIP_FAILURE;
+    HIPCHK(hipEventRecord((hipEvent_t)p->mv_event, s));
+    return SC_HIP_SUCCESS;
+}
+
+// measurement hook (include/sc_hip_bench.h)
+extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
+{
+    if (!d) return fail("dilithium_set_tuning: null handle");
+    d->tune_slots = slots_per_message; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -622,7 +643,7 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
 {
     if (!d) return fail("dilithium_sign: null handle");
     if (!d->have_priv) return fail("dilithium_sign: no private key loaded");
-    const DilSignKeys ks = { d->d_A, getenv("SC_HIP_DIL_UNFUSED") ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false };
+    const DilSignKeys ks = { d->d_A, d->tune_unfused ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false };
     return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
 }
 
@@ -637,11 +658,11 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     HIPCHK(hipSetDevice(d->ctx->device));
     // Attempts evaluated side by side per round ("slots").  More slots per message mean fewer rounds (each round costs the latency
     // of the lane-per-attempt hash kernels plus a host synchronisation) but more attempts thrown away after the first success.
-    // Measured on MI355X (tools/bench_dilithium.py, SC_HIP_DIL_SLOTS=1..8): about 48 K slots per round is the sweet spot - 8 per
+    // Measured on MI355X (tools/bench_dilithium.py, sc_hip_dilithium_set_tuning slots = 1..8): about 48 K slots per round is the sweet spot - 8 per
     // message for small batches, 3 at 16 K messages, 1 from 48 K messages up; as the batch thins out the same slots go deeper.
     size_t slot_target = batch * 8 < 49152 ? batch * 8 : 49152;
     if (slot_target < batch) slot_target = batch;
-    if (const char *e = getenv("SC_HIP_DIL_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= 32) slot_target = batch * (size_t)v; }
+    if (d->tune_slots >= 1 && d->tune_slots <= 32) slot_target = batch * (size_t)d->tune_slots;
     if (slot_target < 4096) slot_target = 4096;
     if (ensure_ws(d, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
@@ -653,7 +674,7 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, ks.tr, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, ks.per_item ? 48u : 0u);
     HIPCHK(hipGetLastError());
 
-    uint32_t nact = B;
+    uint32_t nact = B, wiped_slots = 0;
     const uint32_t *active = nullptr;                 // round 0: identity
     for (uint32_t round = 0; nact > 0; round++) {
         if (round > 4000) return fail("dilithium_sign: rejection loop did not terminate");
@@ -699,7 +720,12 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         HIPCHK(hipStreamSynchronize(s));
         nact = cnt;
         active = next;
+        if (nslots > wiped_slots) wiped_slots = nslots;
     }
+    // the masks y (with z they give s1), w = A y, the rejected candidates z and the remainders r do not outlive the call (dilithium.c:1964-1975)
+    const size_t ws_ = wiped_slots;
+    HIPCHK(hipMemsetAsync(d->y, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->yh, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->z, 0, ws_ * l * P.n * 4, s));
+    HIPCHK(hipMemsetAsync(d->w, 0, ws_ * k * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->r, 0, ws_ * k * P.n * 4, s));
     return SC_HIP_SUCCESS;
 }
 
@@ -731,7 +757,7 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
     a.in = d->z; a.out_int = d->yh;
-    if (d->d_As && !getenv("SC_HIP_DIL_UNFUSED")) {
+    if (d->d_As && !d->tune_unfused) {
         a.key = d->d_As; a.keyp = d->d_As + (size_t)k * l * N;
         if (mlwe_launch_yaw(d->ctx, a, B, s)) return SC_HIP_FAILURE;
         a.keyp = nullptr;
@@ -754,7 +780,7 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
 static int stage(void **dev, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return SC_HIP_SUCCESS;
-    if (*dev) (void)hipFree(*dev);
+    if (*dev) (void)sc::wipe_free(*dev);
     *dev = nullptr; *cap = 0;
     HIPCHK(hipMalloc(dev, bytes));
     *cap = bytes;
@@ -859,7 +885,9 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     a.in = d_s2; a.out_int = s2h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
     a.in = t0n; a.out_int = t0h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
     const DilSignKeys ks = { am, nullptr, s1h, s2h, t0h, d_K, d_tr, true };
-    return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    const int rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    d->kws.wipe(s);                                                 // the per-item NTT(s1), NTT(s2), NTT(t0)
+    return rc;
 }
 
 // t1 . 2^d for a batch of public keys (dilithium.c:2163-2166), ahead of the key-preparation transform

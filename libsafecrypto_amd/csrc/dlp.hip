@@ -216,8 +216,8 @@ struct sc_hip_dlp {
 extern "C" void sc_hip_dlp_destroy(sc_hip_dlp_t *h)
 {
     if (!h) return;
-    if (h->d_h_ntt) (void)hipFree(h->d_h_ntt);
-    if (h->d_uk_ntt) (void)hipFree(h->d_uk_ntt);
+    if (h->d_h_ntt) (void)sc::wipe_free(h->d_h_ntt);
+    if (h->d_uk_ntt) (void)sc::wipe_free(h->d_uk_ntt);
     h->ws.release();
     if (h->plan) sc_hip_plan_destroy(h->plan);
     delete h;
@@ -294,6 +294,7 @@ extern "C" int sc_hip_dlp_encrypt(sc_hip_dlp_t *h, size_t batch, const uint8_t *
     const size_t nt = batch * (size_t)(n / 8);
     hipLaunchKernelGGL(dlp_enc_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, u, v, aux, d_status, d_ct, ct_stride, P);
     HIPCHK(hipGetLastError());
+    h->ws.wipe(s);                                                  // the ephemeral e3, the key bits (aux) and their products
     return SC_HIP_SUCCESS;
 }
 
@@ -320,5 +321,6 @@ extern "C" int sc_hip_dlp_decrypt(sc_hip_dlp_t *h, size_t batch, const uint8_t *
     const uint32_t tail_off = (uint32_t)((size_t)n * (size_t)(2 * P.q_bits - P.l) / 8);
     hipLaunchKernelGGL(dlp_dec_finish_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, v, us, d_ct, ct_stride, tail_off, d_msgs, msg_stride, P);
     HIPCHK(hipGetLastError());
+    h->ws.wipe(s);                                                  // u * user key
     return SC_HIP_SUCCESS;
 }

@@ -5,6 +5,7 @@
 #include "modarith.h"
 
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -13,13 +14,33 @@ int fail(const std::string &m);      // records the message for sc_hip_last_erro
 }
 
 namespace sc {
+// Device memory that may hold key material, masks, noise or CSPRNG output is zeroed before it goes back to the allocator, as the reference zeroes
+// its temporaries (SC_MEMZERO(sc->temp, ...), dilithium.c:1964-1975, kyber_kem.c:1014) and keys on free: every free in this library is a wiped free.
+inline hipError_t wipe_free(void *p)
+{
+    if (!p) return hipSuccess;
+    size_t sz = 0;
+    if (hipMemPtrGetInfo(p, &sz) == hipSuccess && sz) (void)hipMemset(p, 0, sz);
+    else (void)hipGetLastError();
+    return hipFree(p);
+}
+// the same for a buffer that stays allocated: zero the whole allocation on `stream` behind the work that used it (end of a sign / decapsulation /
+// key generation call: per-call secrets do not outlive the call)
+inline void wipe_async(void *p, hipStream_t stream)
+{
+    if (!p) return;
+    size_t sz = 0;
+    if (hipMemPtrGetInfo(p, &sz) == hipSuccess && sz) (void)hipMemsetAsync(p, 0, sz, stream);
+    else (void)hipGetLastError();
+}
+
 // scoped device temporary (key loads, host-buffer variants): freed on every exit path
 struct DevBuf {
     void *p = nullptr;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p) (void)wipe_free(p); }
     int get(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 4) == hipSuccess ? 0 : fail("device allocation failed"); }
     template <typename T> T *as() const { return static_cast<T *>(p); }
 };
@@ -34,7 +55,7 @@ struct Workspace {
     {
         used = 0;
         if (bytes <= cap) return 0;
-        if (p) (void)hipFree(p);
+        if (p) (void)wipe_free(p);
         p = nullptr; cap = 0;
         if (hipMalloc((void **)&p, bytes) != hipSuccess) return fail("device workspace allocation failed");
         cap = bytes;
@@ -46,7 +67,8 @@ struct Workspace {
         used += (count * sizeof(T) + 255) & ~(size_t)255;
         return r;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = used = 0; }
+    void release() { if (p) (void)wipe_free(p); p = nullptr; cap = used = 0; }
+    void wipe(hipStream_t s) { if (p && used) (void)hipMemsetAsync(p, 0, used < cap ? used : cap, s); }      // per-call secrets: zeroed behind the call's work
 };
 }
 
@@ -68,6 +90,7 @@ struct sc_hip_plan {
     int32_t g;
     int mode;                     // MODE_U24 / MODE_U32 / MODE_MAD / MODE_SMAD in use
     bool lazy24, lazy32;
+    bool mad_ok;                  // the small-modulus multiply-add forms are safe for this (q, n)
     std::vector<int32_t> w, r;    // reference-format tables (host)
     uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
     uint32_t *d_tab_s;            // MODE_SMAD (q = 7681, n = 256): centred twiddles, signed companions; same layout
@@ -75,8 +98,10 @@ struct sc_hip_plan {
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
     uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
     uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
-    uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order
+    uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order; guarded by mv_mu (host) and mv_event (device)
     size_t mv_cap;
+    std::mutex mv_mu;
+    void *mv_event;
     void *g_exec;                 // sc_hip_polymul_ntt_steps: cached executable graph and what it was captured for
     const int32_t *g_a, *g_b; int32_t *g_out; size_t g_batch; int g_steps;
 };

@@ -150,7 +150,7 @@ extern "C" void sc_hip_ens_destroy(sc_hip_ens_t *h)
 {
     if (!h) return;
     void *ptrs[] = { h->d_h, h->d_g, h->d_inv_g };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     h->ws.release();
     if (h->plan) sc_hip_plan_destroy(h->plan);
     delete h;
@@ -232,6 +232,7 @@ extern "C" int sc_hip_ens_encaps(sc_hip_ens_t *h, size_t batch, const uint32_t *
     hipLaunchKernelGGL(ens_enc_finish_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, t, e, d_status, d_ct, ct_stride, d_keys, key_stride,
                        n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
+    h->ws.wipe(s);                                                  // r and e: e's parities are the shared key
     return SC_HIP_SUCCESS;
 }
 
@@ -256,5 +257,6 @@ extern "C" int sc_hip_ens_decaps(sc_hip_ens_t *h, size_t batch, const uint8_t *d
     if (sc::polymul_ntt_bcast(h->plan, batch, t, h->d_g, gt, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ens_dec_finish_kernel, dim3(B), dim3(n), 0, s, gt, h->d_inv_g, d_keys, key_stride, n, h->P.q);
     HIPCHK(hipGetLastError());
+    h->ws.wipe(s);                                                  // g t
     return SC_HIP_SUCCESS;
 }

@@ -1199,7 +1199,7 @@ __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ si
     const uint32_t b = (uint32_t)(tt / hn); const int e = (int)(tt % hn) * 2;
     if (b >= batch) return;
     int32_t *o = s2 + (size_t)b * P.n + e;
-    if ((size_t)siglens[b] * 8 < (size_t)P.n * bits) { if (e == 0) verdict[b] = 1; o[0] = o[1] = 0; return; }
+    if ((size_t)siglens[b] * 8 < (size_t)P.n * bits || siglens[b] > sig_stride) { if (e == 0) verdict[b] = 1; o[0] = o[1] = 0; return; }   // short, or longer than its row
     const uint8_t *s = sigs + (size_t)b * sig_stride;
     if (bits == 12 && centre) {
         const uint8_t *p = s + (e / 2) * 3;
@@ -1531,8 +1531,17 @@ struct sc_hip_falcon {
 static void fal_free_ws(sc_hip_falcon *f)
 {
     void *ptrs[] = { f->ws, f->c, f->s1, f->s2, f->status, f->siglens };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     f->ws = nullptr; f->c = f->s1 = f->s2 = nullptr; f->status = f->siglens = nullptr; f->cap = 0;
+}
+
+// the sampler's working polynomials are products with the secret basis, s1 | s2 the lattice point before packing: zeroed behind a signing call
+static void fal_wipe(sc_hip_falcon *f, size_t batch, hipStream_t s)
+{
+    const size_t n = f->P.n;
+    if (f->ws) (void)hipMemsetAsync(f->ws, 0, ((batch + SPW - 1) / SPW * SPW) * 6 * n * sizeof(double), s);
+    if (f->s1) (void)hipMemsetAsync(f->s1, 0, batch * n * 4, s);
+    if (f->s2) (void)hipMemsetAsync(f->s2, 0, batch * n * 4, s);
 }
 
 static int fal_ensure_ws(sc_hip_falcon *f, size_t batch)
@@ -1589,7 +1598,7 @@ extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
     if (!f) return;
     fal_free_ws(f);
     void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(f->plan);
     delete f;
 }
@@ -1627,7 +1636,7 @@ extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk)
         if (sz >= 2) { if (sc_hip_cdt_build_table(10.0f, sig[i], &tabs[i << ts_log], sz) != SC_HIP_SUCCESS) return SC_HIP_FAILURE; }
         else tabs[i << ts_log] = 0;                                     // a one-entry table always yields 0
     }
-    if (f->d_tabs) { (void)hipFree(f->d_tabs); f->d_tabs = nullptr; }
+    if (f->d_tabs) { (void)sc::wipe_free(f->d_tabs); f->d_tabs = nullptr; }
     HIPCHK(hipMalloc((void **)&f->d_tabs, tabs.size() * 8));
     HIPCHK(hipMemcpy(f->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
     if (!f->d_sk) HIPCHK(hipMalloc((void **)&f->d_sk, total * sizeof(double)));
@@ -1723,7 +1732,9 @@ extern "C" int sc_hip_falcon_sample(sc_hip_falcon_t *f, size_t batch, const int3
     if (((uintptr_t)d_tapes & 15) != 0 || (tape_stride & 3) != 0) return fail("falcon_sample: tapes must be 16-byte aligned rows (tape_stride a multiple of 4 words)");
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
-    return fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, d_tape_lens, d_s1, d_s2, d_status ? d_status : f->status, (hipStream_t)stream);
+    const int rc = fal_launch_sample(f, batch, d_c, d_tapes, tape_stride, d_tape_lens, d_s1, d_s2, d_status ? d_status : f->status, (hipStream_t)stream);
+    fal_wipe(f, batch, (hipStream_t)stream);
+    return rc;
 }
 
 // measurement hook (include/sc_hip_bench.h): the default mapping's sampler with per-phase cycle counters; h_cycles[6] = shader cycles summed over the
@@ -1771,6 +1782,7 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
     HIPCHK(hipGetLastError());
+    fal_wipe(f, batch, s);
     return SC_HIP_SUCCESS;
 }
 
@@ -1781,6 +1793,7 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     if (!f->have_pk) return fail("falcon_verify: no public key loaded");
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("falcon_verify: null buffer");
+    if (sig_stride < sc_hip_falcon_sig_bytes(f)) return fail("falcon_verify: sig_stride smaller than sc_hip_falcon_sig_bytes()");
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
@@ -1824,6 +1837,7 @@ extern "C" int sc_hip_dlp_ibe_extract(sc_hip_falcon_t *f, size_t batch, int ubit
     const size_t nt = batch * (size_t)(f->P.n / 8);
     hipLaunchKernelGGL(dlp_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, B, f->s2, status, d_sk, sk_stride, f->P.n, ubits);
     HIPCHK(hipGetLastError());
+    fal_wipe(f, batch, s);
     return SC_HIP_SUCCESS;
 }
 
@@ -1839,6 +1853,7 @@ extern "C" int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *f, size_t batch, const
     if (!f->have_pk) return fail("ens_dlp_sig_verify: no public key loaded");
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("ens_dlp_sig_verify: null buffer");
+    if (sig_stride < ((size_t)f->P.n * (size_t)f->P.q_bits + 7) / 8) return fail("ens_dlp_sig_verify: sig_stride smaller than a signature (n q_bits / 8 bytes)");
     HIPCHK(hipSetDevice(f->ctx->device));
     if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
@@ -1863,6 +1878,7 @@ struct sc_hip_ens_dlp_signer {
     bool have_key;
     int32_t *d_b; float *d_bgs, *d_inv; uint64_t *d_tabs; uint32_t *d_sizes; int ts_log; uint32_t maxb;
     sc::Workspace ws;
+    int force_lanes;             // sc_hip_ens_dlp_signer_set_mapping: 0 = chosen from the batch size
 };
 
 extern "C" int sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_ens_dlp_signer_t **out)
@@ -1877,11 +1893,19 @@ extern "C" int sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falc
     return SC_HIP_SUCCESS;
 }
 
+extern "C" int sc_hip_ens_dlp_signer_set_mapping(sc_hip_ens_dlp_signer_t *h, int lanes)
+{
+    if (!h) return fail("ens_dlp_signer_set_mapping: null handle");
+    if (lanes != 0 && lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16) return fail("ens_dlp_signer_set_mapping: lanes must be 0 (default), 1, 4, 8 or 16");
+    h->force_lanes = lanes;
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" void sc_hip_ens_dlp_signer_destroy(sc_hip_ens_dlp_signer_t *h)
 {
     if (!h) return;
     void *ptrs[] = { h->d_b, h->d_bgs, h->d_inv, h->d_tabs, h->d_sizes };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     h->ws.release();
     delete h;
 }
@@ -1913,7 +1937,7 @@ extern "C" int sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const i
     uint32_t maxb = 1;
     for (size_t i = 0; i < n2 * n2; i++) { const int64_t v = b[i]; const uint32_t a = (uint32_t)(v < 0 ? -v : v); maxb = a > maxb ? a : maxb; }
     void *old[] = { h->d_b, h->d_bgs, h->d_inv, h->d_tabs, h->d_sizes };
-    for (void *p : old) if (p) (void)hipFree(p);
+    for (void *p : old) if (p) (void)sc::wipe_free(p);
     h->d_b = nullptr; h->d_bgs = h->d_inv = nullptr; h->d_tabs = nullptr; h->d_sizes = nullptr; h->have_key = false;
     HIPCHK(hipMalloc((void **)&h->d_b, n2 * n2 * 4));
     HIPCHK(hipMalloc((void **)&h->d_bgs, n2 * n2 * 4));
@@ -2028,17 +2052,13 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     KleinArgs A;
     A.batch = nb; A.B = (uint32_t)B; A.n = (int)n; A.n2 = (int)n2; A.c = c; A.b = h->d_b; A.bgs = h->d_bgs; A.inv = h->d_inv; A.tabs = h->d_tabs; A.sizes = h->d_sizes;
     A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status;
-    // lanes per signature: 16 while a lane per signature would leave SIMDs idle (test hook: SC_HIP_KLEIN_LANES = 1 / 16)
     // lanes per signature.  Register form: the fewest (down to 128 state words per lane) that still give every SIMD two wavefronts.
-    // Test hook SC_HIP_KLEIN_LANES: 1 = the lane-per-signature kernel (state in memory), 4 / 8 / 16 = the register form with that many lanes.
+    // sc_hip_ens_dlp_signer_set_mapping: 1 = the lane-per-signature kernel (state in memory), 4 / 8 / 16 = the register form with that many lanes.
     int G = 16, in_regs = 1;
     const int gmin = (int)(n / 64);                              // 4 / 8 / 16 for n = 256 / 512 / 1024
     while (G > gmin && batch * (size_t)(G / 2) / 64 >= (size_t)h->ctx->cus * 4 * 2) G /= 2;
-    if (const char *e = getenv("SC_HIP_KLEIN_LANES")) {
-        const int v = atoi(e);
-        if (v == 1) { G = 1; in_regs = 0; }
-        if ((v == 4 || v == 8 || v == 16) && v >= gmin) G = v;
-    }
+    if (h->force_lanes == 1) { G = 1; in_regs = 0; }
+    if ((h->force_lanes == 4 || h->force_lanes == 8 || h->force_lanes == 16) && h->force_lanes >= gmin) G = h->force_lanes;
     if (in_regs) {
         const dim3 grid((unsigned)((B / (64 / G) + KW - 1) / KW));
         if (n == 256 && G == 4) hipLaunchKernelGGL((kleinr_kernel<4, 128>), grid, dim3(64 * KW), 0, s, A);
@@ -2053,5 +2073,6 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     const size_t nt = batch * (n / 8);
     hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
+    h->ws.wipe(s);                                                  // the sampler state (the lattice point before packing)
     return SC_HIP_SUCCESS;
 }

@@ -330,7 +330,7 @@ static int ky_ensure(sc_hip_kyber *h, size_t batch)
 {
     if (batch <= h->cap) return SC_HIP_SUCCESS;
     void *old[] = { h->r, h->e1, h->e2, h->u0, h->v0, h->yh };
-    for (void *p : old) if (p) (void)hipFree(p);
+    for (void *p : old) if (p) (void)sc::wipe_free(p);
     h->r = h->e1 = h->e2 = h->u0 = h->v0 = nullptr; h->yh = nullptr; h->cap = 0;
     const size_t kn = (size_t)h->P.k * N;
     HIPCHK(hipMalloc((void **)&h->r, batch * kn * 4)); HIPCHK(hipMalloc((void **)&h->e1, batch * kn * 4)); HIPCHK(hipMalloc((void **)&h->e2, batch * N * 4));
@@ -360,7 +360,7 @@ extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
 {
     if (!h) return;
     void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(h->plan);
     delete h;
 }
@@ -429,6 +429,9 @@ extern "C" int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8
     const size_t ne = batch * (size_t)(k + 1) * N;
     hipLaunchKernelGGL(ky_enc_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, h->u0, h->v0, h->e1, h->e2, d_m, B, d_u, d_v, P);
     HIPCHK(hipGetLastError());
+    // the ephemeral secret r and the noise do not outlive the call (kyber_kem.c:1014, module_lwe.c:1397-1400)
+    const size_t kb = batch * (size_t)k * N * 4;
+    HIPCHK(hipMemsetAsync(h->r, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e1, 0, kb, s)); HIPCHK(hipMemsetAsync(h->yh, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e2, 0, batch * N * 4, s));
     return SC_HIP_SUCCESS;
 }
 
@@ -455,6 +458,7 @@ extern "C" int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ky_dec_finish_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, s, d_v, h->v0, d_m, B, P);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(h->v0, 0, batch * N * 4, s));                   // s . u: with v it is the plaintext
     return SC_HIP_SUCCESS;
 }
 
@@ -467,13 +471,21 @@ static int ky_kem_ensure(sc_hip_kyber *h, size_t batch)
 {
     if (batch <= h->kem_cap) return SC_HIP_SUCCESS;
     void *old[] = { h->krd, h->noise, h->mbuf, h->ku, h->kv };
-    for (void *p : old) if (p) (void)hipFree(p);
+    for (void *p : old) if (p) (void)sc::wipe_free(p);
     h->krd = h->noise = h->mbuf = nullptr; h->ku = h->kv = nullptr; h->kem_cap = 0;
     const size_t kn = (size_t)h->P.k * N;
     HIPCHK(hipMalloc((void **)&h->krd, batch * 96)); HIPCHK(hipMalloc((void **)&h->noise, batch * ky_noise_stride(h))); HIPCHK(hipMalloc((void **)&h->mbuf, batch * 32));
     HIPCHK(hipMalloc((void **)&h->ku, batch * kn * 4)); HIPCHK(hipMalloc((void **)&h->kv, batch * N * 4));
     h->kem_cap = batch;
     return SC_HIP_SUCCESS;
+}
+
+// K-bar | r | d, the noise stream and the recovered message do not outlive an encapsulation / decapsulation (kyber_kem.c:1014)
+static void ky_kem_wipe(sc_hip_kyber *h, size_t batch, hipStream_t s)
+{
+    (void)hipMemsetAsync(h->krd, 0, batch * 96, s);
+    (void)hipMemsetAsync(h->noise, 0, batch * ky_noise_stride(h), s);
+    (void)hipMemsetAsync(h->mbuf, 0, batch * 32, s);
 }
 
 // t: the public key's coefficient-domain vector as the reference stores it (first k*n words of sc->pubkey->key, kyber_kem.c:636-650),
@@ -490,7 +502,7 @@ extern "C" int sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, 
     if (pb.get(len)) return SC_HIP_FAILURE;
     uint8_t *d_pre = pb.as<uint8_t>();
     if (!h->d_gstate) HIPCHK(hipMalloc((void **)&h->d_gstate, 25 * 8));
-    if (h->d_gtail) { (void)hipFree(h->d_gtail); h->d_gtail = nullptr; }
+    if (h->d_gtail) { (void)sc::wipe_free(h->d_gtail); h->d_gtail = nullptr; }
     HIPCHK(hipMalloc((void **)&h->d_gtail, len - full + 8));
     HIPCHK(hipMemcpy(d_pre, pre.data(), len, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_gtail, pre.data() + full, len - full, hipMemcpyHostToDevice));
@@ -549,6 +561,7 @@ extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const ui
     const size_t nb = batch * (size_t)((h->P.k + 1) * N / 8 + 32);
     hipLaunchKernelGGL(ky_pack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
     HIPCHK(hipGetLastError());
+    ky_kem_wipe(h, batch, s);
     return SC_HIP_SUCCESS;
 }
 
@@ -573,6 +586,7 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
     if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     HIPCHK(hipGetLastError());
+    ky_kem_wipe(h, batch, s);
     return SC_HIP_SUCCESS;
 }
 

@@ -378,8 +378,8 @@ struct sc_hip_rlwe {
 extern "C" void sc_hip_rlwe_destroy(sc_hip_rlwe_t *h)
 {
     if (!h) return;
-    if (h->d_keys) (void)hipFree(h->d_keys);
-    if (h->d_guide) (void)hipFree(h->d_guide);
+    if (h->d_keys) (void)sc::wipe_free(h->d_keys);
+    if (h->d_guide) (void)sc::wipe_free(h->d_guide);
     if (h->cdt) sc_hip_cdt_destroy(h->cdt);
     if (h->plan) sc_hip_plan_destroy(h->plan);
     delete h;

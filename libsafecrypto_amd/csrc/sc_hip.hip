@@ -320,7 +320,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
 
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
-    p->mv_ws = nullptr; p->mv_cap = 0; p->d_tab_s = nullptr;
+    p->mv_ws = nullptr; p->mv_cap = 0; p->mv_event = nullptr; p->d_tab_s = nullptr;
     p->g_exec = nullptr; p->g_a = p->g_b = nullptr; p->g_out = nullptr; p->g_batch = 0; p->g_steps = 0;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
@@ -371,7 +371,9 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     // so the 4-instruction 32-bit Shoup product beats the 6-instruction 24-bit one for every q
     p->mode = MODE_U32;
     // q < 2^14 (7681, 12289): the 3-instruction multiply-add form with growing inverse sums (modarith.h MODE_MAD, ntt_core.h)
-    if (Q < (1ull << 14)) p->mode = MODE_MAD;
+    // (the pointwise product multiplies a lazy forward value < 2q(L+1) by an operand < q in 32 bits: e.g. q = 15361, n = 512 does not qualify)
+    p->mad_ok = Q < (1ull << 14) && 2ull * Q * (Q - 1) * (uint64_t)(L + 1) < (1ull << 32);
+    if (p->mad_ok) p->mode = MODE_MAD;
     // 36 q^2 < 2^31 and n = 256 (q = 7681): signed lazy residues, no butterfly bias, two-instruction input reductions (MODE_SMAD)
     if (n == 256 && 36ull * Q * Q < (1ull << 31)) {
         std::vector<uint32_t> h(4 * (size_t)n, 0u);
@@ -400,10 +402,11 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
 extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
 {
     if (!p) return;
-    for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)hipFree(p->d_tab[i]);
-    if (p->d_tab_s) (void)hipFree(p->d_tab_s);
+    for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)sc::wipe_free(p->d_tab[i]);
+    if (p->d_tab_s) (void)sc::wipe_free(p->d_tab_s);
     if (p->g_exec) (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec);
-    if (p->mv_ws) (void)hipFree(p->mv_ws);
+    if (p->mv_event) { (void)hipEventSynchronize((hipEvent_t)p->mv_event); (void)hipEventDestroy((hipEvent_t)p->mv_event); }
+    if (p->mv_ws) (void)sc::wipe_free(p->mv_ws);
     delete p;
 }
 extern "C" int32_t sc_hip_plan_q(const sc_hip_plan_t *p) { return p ? p->q : 0; }
@@ -419,10 +422,10 @@ extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t 
 extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
-    if (mode == 0) mode = p->d_tab_s ? MODE_SMAD : (uint64_t)p->q < (1ull << 14) ? MODE_MAD : MODE_U32;
+    if (mode == 0) mode = p->d_tab_s ? MODE_SMAD : p->mad_ok ? MODE_MAD : MODE_U32;
     if (mode == MODE_SMAD && !p->d_tab_s) return fail("plan_set_arith: the signed small-modulus path needs n = 256 and 36 q^2 < 2^31");
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
-    if (mode == MODE_MAD && (uint64_t)p->q >= (1ull << 14)) return fail("plan_set_arith: the multiply-add path needs q < 2^14");
+    if (mode == MODE_MAD && !p->mad_ok) return fail("plan_set_arith: the multiply-add path needs q < 2^14 and 2 q (q - 1) (log2 n + 1) < 2^32");
     if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD) return fail("plan_set_arith: mode must be 0, 1, 2, 3 or 4");
     if (mode != p->mode && p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }     // a captured loop holds the old kernel
     p->mode = mode;
@@ -442,6 +445,7 @@ static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
     }
     const long long cap = (long long)per_cu * g_cus;
     if (blocks > cap) blocks = (int)cap;
+    if (blocks <= 0) return hipSuccess;                       // warm-up call: the occupancy query above is all that was wanted
     hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP>), dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -468,10 +472,10 @@ static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, in
     }
 }
 
-static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream, bool bcast = false)
+static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream, bool bcast = false, bool warm_only = false)
 {
     if (!p) return fail("ntt: null plan");
-    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch == 0 && !warm_only) return SC_HIP_SUCCESS;
     if (!d0 || !dout || ((op == OP_MULNTT || op == OP_MUL) && !d1)) return fail("ntt: null device pointer");
     HIPCHK(hipSetDevice(p->ctx->device));
     const int mi = p->mode == MODE_U24 ? 0 : 1;
@@ -487,6 +491,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const size_t groups = (batch + pw - 1) / pw;
     size_t blocks = (groups + 3) / 4;
     if (blocks > (size_t)1 << 30) blocks = (size_t)1 << 30;
+    if (warm_only) blocks = 0;                                // only the per-instantiation occupancy query runs (launch_ntt_t)
     hipError_t e;
     switch (op) {
     case OP_FWD: e = launch_ntt_op<OP_FWD>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
@@ -597,7 +602,7 @@ extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * size) != hipSuccess ||
         hipMemcpy(c->d_cdf, c->cdf.data(), sizeof(uint64_t) * size, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc((void **)&c->d_guide, sizeof guide) != hipSuccess || hipMemcpy(c->d_guide, guide, sizeof guide, hipMemcpyHostToDevice) != hipSuccess) {
-        if (c->d_cdf) (void)hipFree(c->d_cdf);
+        if (c->d_cdf) (void)sc::wipe_free(c->d_cdf);
         delete c;
         return fail("cdt_create: cannot upload the table");
     }
@@ -616,7 +621,7 @@ extern "C" int sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_
     (*out)->tail = tail; (*out)->sigma = sigma;
     return SC_HIP_SUCCESS;
 }
-extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)hipFree(c->d_cdf); if (c->d_guide) (void)hipFree(c->d_guide); delete c; }
+extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)sc::wipe_free(c->d_cdf); if (c->d_guide) (void)sc::wipe_free(c->d_guide); delete c; }
 extern "C" int sc_hip_cdt_size(const sc_hip_cdt_t *c) { return c ? c->size : 0; }
 extern "C" int sc_hip_cdt_table(const sc_hip_cdt_t *c, uint64_t *h)
 {
@@ -679,7 +684,7 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
         if (rc == SC_HIP_SUCCESS && hipMemcpyAsync(hout + off * (size_t)p->n, d0, cnt * pb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("host op: D2H copy failed");
     }
     for (size_t i = 0; i < ring; i++) if (st[i]) { if (hipStreamSynchronize(st[i]) != hipSuccess && rc == SC_HIP_SUCCESS) rc = fail("host op: stream failed"); (void)hipStreamDestroy(st[i]); }
-    if (dev) (void)hipFree(dev);
+    if (dev) (void)sc::wipe_free(dev);
     for (int i = 0; i < 3; i++) if (pinned[i]) (void)hipHostUnregister(const_cast<void *>(pins[i]));
     return rc;
 }
@@ -701,8 +706,8 @@ extern "C" int sc_hip_cdt_sample_host(sc_hip_cdt_t *c, size_t count, const uint6
     if (hipMalloc(&dv, count * 4) != hipSuccess || hipMemcpy(dx, h_uniform, count * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail("cdt_sample_host: H2D failed");
     if (rc == SC_HIP_SUCCESS) rc = sc_hip_cdt_sample(c, count, dx, centre, dv, nullptr);
     if (rc == SC_HIP_SUCCESS && hipMemcpy(h_out, dv, count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("cdt_sample_host: D2H failed");
-    (void)hipFree(dx);
-    if (dv) (void)hipFree(dv);
+    (void)sc::wipe_free(dx);
+    if (dv) (void)sc::wipe_free(dv);
     return rc;
 }
 
@@ -726,8 +731,8 @@ static int host_ew(sc_hip_plan_t *p, int which, size_t len, const int32_t *h0, c
         else rc = sc_hip_center(p, len, d0, d0, nullptr);
     }
     if (rc == SC_HIP_SUCCESS && hipMemcpy(hout, d0, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("host op: D2H copy failed");
-    (void)hipFree(d0);
-    if (d1) (void)hipFree(d1);
+    (void)sc::wipe_free(d0);
+    if (d1) (void)sc::wipe_free(d1);
     return rc;
 }
 extern "C" int sc_hip_pointwise_host(sc_hip_plan_t *p, size_t len, const int32_t *h_a, const int32_t *h_b, int32_t *h_out)
@@ -749,10 +754,11 @@ extern "C" int sc_hip_polymul_ntt_steps(sc_hip_plan_t *p, size_t batch, const in
     if (steps <= 0) return SC_HIP_SUCCESS;
     HIPCHK(hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
+    if (d_out == d_a || d_out == d_bhat) return fail("polymul_ntt_steps: the output must not alias an input (the steps would feed each other)");
     const bool same = p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps;
     if (s && !same) {
         if (p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }
-        if (run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;      // first-use initialisation outside the capture
+        if (run_ntt(p, OP_MULNTT, 0, d_a, d_bhat, d_out, stream, false, true) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;   // first-use initialisation (occupancy query) outside the capture, no launch
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             int rc = SC_HIP_SUCCESS;

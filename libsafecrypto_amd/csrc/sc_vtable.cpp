@@ -16,7 +16,7 @@
 #include <utility>
 #include <vector>
 
-namespace sc { int fail(const std::string &m); }
+#include "engine_internal.h"
 
 namespace {
 
@@ -49,7 +49,7 @@ bool ensure_ctx(DevState &s, int dev)
 void *scratch(DevState &s, int i, size_t bytes)
 {
     if (bytes <= s.cap[i]) return s.buf[i];
-    if (s.buf[i]) (void)hipFree(s.buf[i]);
+    if (s.buf[i]) (void)sc::wipe_free(s.buf[i]);
     s.buf[i] = nullptr; s.cap[i] = 0;
     const size_t want = bytes < 65536 ? 65536 : bytes;
     if (hipMalloc(&s.buf[i], want) != hipSuccess) { sc::fail("vtable: device scratch allocation failed"); return nullptr; }

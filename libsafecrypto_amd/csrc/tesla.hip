@@ -348,7 +348,7 @@ struct sc_hip_tesla {
 static void ts_free_ws(sc_hip_tesla *t)
 {
     void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->need, t->sbase, t->nz, t->trials, t->acc, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->zs, t->md };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->need = t->sbase = t->nz = t->trials = t->acc = nullptr;
     t->y = t->v1 = t->v2 = t->r1 = t->r2 = t->cidx = t->zs = nullptr; t->md = nullptr; t->cap = t->slot_cap = 0;
 }
@@ -397,7 +397,7 @@ extern "C" void sc_hip_tesla_destroy(sc_hip_tesla_t *t)
     if (!t) return;
     ts_free_ws(t);
     void *ptrs[] = { t->d_a1, t->d_a2, t->d_t1, t->d_t2, t->d_key, t->d_zstate };
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(t->plan);
     delete t;
 }
@@ -488,6 +488,8 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
         active = next;
     }
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+    // the masks y, their products and the rejected candidates do not outlive the call
+    sc::wipe_async(t->y, s); sc::wipe_async(t->v1, s); sc::wipe_async(t->v2, s); sc::wipe_async(t->r1, s); sc::wipe_async(t->r2, s); sc::wipe_async(t->zs, s);
     return SC_HIP_SUCCESS;
 }
 

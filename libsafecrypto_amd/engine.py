@@ -31,7 +31,7 @@ SYMBOLS = [
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
-    'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey',
+    'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey', 'sc_hip_ens_dlp_signer_set_mapping',
     'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
@@ -39,7 +39,7 @@ SYMBOLS = [
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
 ]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile']
+BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_dilithium_set_tuning']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -179,6 +179,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_ens_dlp_signer_destroy.restype = None
     L.sc_hip_ens_dlp_signer_set_key.argtypes = [vp, vp, vp, vp]
     L.sc_hip_ens_dlp_signer_set_privkey.argtypes = [vp, vp]
+    L.sc_hip_ens_dlp_signer_set_mapping.argtypes = [vp, C.c_int]
+    L.sc_hip_dilithium_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.sc_hip_ens_dlp_sig_bytes.argtypes = [vp]
     L.sc_hip_ens_dlp_sig_bytes.restype = sz
     L.sc_hip_ens_dlp_sig_tape_words.argtypes = [vp]
@@ -603,6 +605,10 @@ class Dilithium:
         self.sig_max = self.L.sc_hip_dilithium_sig_max(h)
         self.sig_stride = (self.sig_max + 15) & ~15
 
+    def set_tuning(self, slots_per_message=0, unfused=False):
+        """measurement hook (include/sc_hip_bench.h)"""
+        _chk(self.L, self.L.sc_hip_dilithium_set_tuning(self.h, int(slots_per_message), 1 if unfused else 0), 'dilithium_set_tuning')
+
     def close(self):
         if self.h:
             self.L.sc_hip_dilithium_destroy(self.h)
@@ -1021,6 +1027,10 @@ class EnsDlpSigner:
         v = np.ascontiguousarray(np.asarray(inv_norm), dtype=np.float32)
         assert b.size == 4 * self.n * self.n and g.size == b.size and v.size == 2 * self.n
         _chk(self.L, self.L.sc_hip_ens_dlp_signer_set_key(self.h, _ptr(b), _ptr(g), _ptr(v)), 'ens_dlp_signer_set_key')
+
+    def set_mapping(self, lanes):
+        """0: chosen from the batch size; 1: a lane per signature (state in HBM); 4 / 8 / 16 lanes (state in registers)"""
+        _chk(self.L, self.L.sc_hip_ens_dlp_signer_set_mapping(self.h, int(lanes)), 'ens_dlp_signer_set_mapping')
 
     def set_privkey(self, fgFG):
         """f | g | F | G (int32, 4n): the matrices are derived at key load as the reference's create_gpv_matrices does"""

@@ -281,3 +281,33 @@ def test_sign_distinct_keys_full_config3(eng, G):
         sg, ln, _ = d.sign(msgs[i:i + 1], fixed_len=64)
         assert torch.equal(sg[0, :int(ln[0])], sigs[i, :int(siglens[i])])
     d.close()
+
+
+def test_untrusted_signature_lengths_and_hint_counts(eng, G):
+    """a verifier must not read past a signature's row whatever siglens says, and must reject hint counts above omega before using them
+    (dilithium.c:2085-2123): lengths beyond the row pitch, a hint-count field of all ones, and a row pitch that only just holds z"""
+    import torch
+    tag = 'dil3'
+    d = eng.dilithium(G[f'{tag}_params'])
+    d.set_privkey(*(G[f'{tag}_{x}'] for x in ('s1', 's2', 't', 'K', 'tr', 'Ahat')))
+    d.set_pubkey(G[f'{tag}_t1'], G[f'{tag}_rho'], G[f'{tag}_Ahat'])
+    B = 64
+    g = torch.Generator(device='cuda'); g.manual_seed(9)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    sigs, siglens, _ = d.sign(msgs, fixed_len=64)
+    assert int(d.verify(msgs, sigs, siglens, fixed_len=64).sum()) == 0
+    # lengths that claim more bytes than a row holds: invalid (and the neighbour's bytes are never consulted)
+    long_lens = siglens.clone(); long_lens[::2] = sigs.shape[1] + 200
+    v = d.verify(msgs, sigs, long_lens, fixed_len=64).cpu().numpy()
+    assert (v[::2] == 1).all() and (v[1::2] == 0).all()
+    # a hint count of 2^omega_bits - 1 (> omega): invalid
+    par = np.asarray(G[f'{tag}_params'])
+    n, l, z_bits, omega_bits = int(par[0]), int(par[4]), int(par[11]), int(par[14])
+    zbytes = l * n * z_bits // 8
+    bad = sigs.clone()
+    bad[:, zbytes] |= ((1 << omega_bits) - 1) << (8 - omega_bits)
+    assert int(d.verify(msgs, bad, siglens, fixed_len=64).min()) == 1
+    # rows cut right behind z: every signature is too short for its hints, none may be read past
+    cut = sigs[:, :zbytes].contiguous()
+    assert int(d.verify(msgs, cut, siglens, fixed_len=64).min()) == 1
+    d.close()

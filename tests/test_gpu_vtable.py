@@ -123,3 +123,179 @@ def test_vtable_calls(q, n, is16):
     assert vt.invert_32(P(half), C.byref(p), n) == 1                     # SC_FUNC_FAILURE, stopped at the zero
     assert np.array_equal(half[n // 2:], nz[n // 2:]) and np.array_equal(half[:n // 2], iv[:n // 2])
     assert L.sc_hip_vtable_errors() == e0
+
+
+# ---- the layout-identical tables: utils_arith_ntt_t (77 slots), utils_arith_poly_t (35), utils_arith_vec_t (4), utils_sampling_t ----
+
+VOIDP = C.c_void_p
+
+
+class NTT77(C.Structure):            # utils_arith_ntt_t, src/utils/arith/ntt.h:217-298 (packed; every slot a pointer)
+    _pack_ = 1
+    _fields_ = [('slots_16', VOIDP * 18),
+                ('modn_32', VOIDP), ('muln_32', VOIDP), ('sqrn_32', VOIDP),
+                ('mul_32_sparse', F(None, i32p, C.c_size_t, C.c_uint16, i32p, i32p)), ('mul_32_sparse_16', F(None, i32p, C.c_size_t, C.c_uint16, i16p, i32p)),
+                ('mul_32_pointwise', F(None, i32p, pp, i32p, i32p)), ('mul_32_pointwise_16', F(None, i32p, pp, i32p, i16p)),
+                ('mul_32_scalar', F(None, i32p, pp, i32p, C.c_int32)),
+                ('fft_32_32', F(None, i32p, pp, i32p)), ('fft_32_32_large', F(None, i32p, pp, i32p)),
+                ('fft_32_16', F(None, i32p, pp, i16p)), ('fft_32_16_large', F(None, i32p, pp, i16p)),
+                ('pwr_32', VOIDP),
+                ('invert_32', F(C.c_int32, i32p, pp, C.c_size_t)), ('div_32', F(C.c_int32, i32p, i32p, pp, C.c_size_t)),
+                ('flip_32', F(None, i32p, pp)), ('center_32', F(None, i32p, C.c_size_t, pp)), ('normalize_32', F(None, i32p, C.c_size_t, pp)),
+                ('fwd_ntt_32_32', F(None, i32p, pp, i32p, i32p)), ('inv_ntt_32_32', F(None, i32p, pp, i32p, i32p, i32p)),
+                ('fwd_ntt_32_32_large', F(None, i32p, pp, i32p, i32p)), ('inv_ntt_32_32_large', F(None, i32p, pp, i32p, i32p, i32p)),
+                ('fwd_ntt_32_16', F(None, i32p, pp, i32p, i16p)), ('inv_ntt_32_16', F(None, i32p, pp, i32p, i16p, i16p)),
+                ('fwd_ntt_32_16_large', F(None, i32p, pp, i32p, i16p)), ('inv_ntt_32_16_large', F(None, i32p, pp, i32p, i16p, i16p)),
+                ('slots_limb', VOIDP * 33)]
+
+
+class POLY35(C.Structure):           # utils_arith_poly_t, src/utils/arith/arith.h:74-111
+    _pack_ = 1
+    _fields_ = [('slots_8_16', VOIDP * 15), ('copy_32', VOIDP), ('reset_32', VOIDP), ('add_32_scalar', VOIDP), ('sub_32_scalar', VOIDP),
+                ('mul_32_scalar', F(None, i32p, C.c_size_t, C.c_int32)),
+                ('add_32', F(None, i32p, C.c_size_t, i32p, i32p)), ('sub_32', F(None, i32p, C.c_size_t, i32p, i32p)),
+                ('add_single_32', F(None, i32p, C.c_size_t, i32p)), ('sub_single_32', F(None, i32p, C.c_size_t, i32p)),
+                ('mul_32', VOIDP), ('mod_negate_32', F(None, i32p, C.c_size_t, C.c_int32, i32p)),
+                ('cmp_not_equal_32', F(C.c_int32, i32p, i32p, C.c_size_t)), ('uniform_32', VOIDP), ('degree_32', VOIDP), ('slots_z2', VOIDP * 6)]
+
+
+class VEC4(C.Structure):             # utils_arith_vec_t, arith.h:123-128
+    _pack_ = 1
+    _fields_ = [('absmax_32', F(C.c_int32, i32p, C.c_size_t)), ('scalar_32', F(C.c_int32, i32p, i32p, C.c_size_t)),
+                ('absmax_16', F(C.c_int32, i16p, C.c_size_t)), ('scalar_16', F(C.c_int32, i16p, i16p, C.c_size_t))]
+
+
+def _bitrev(n):
+    bits = n.bit_length() - 1
+    return np.array([int(format(i, f'0{bits}b')[::-1], 2) for i in range(n)])
+
+
+@pytest.mark.parametrize('q,n', [(12289, 512), (8380417, 256), (7681, 256), (12289, 1024)])
+def test_full_ntt_table_new_slots(q, n):
+    """utils_arith_ntt_t-shaped table: 77 slots; the slots round 1 did not serve (flip_32, fft_32_*, mul_32_scalar) against their definitions
+    (ntt.c:584-604, ntt_template.c.in:1144-1244 as a transform of the bit-reversed input, ntt.c:425-468)"""
+    from libsafecrypto_amd import load_library
+    L = load_library()
+    assert C.sizeof(NTT77) == 77 * 8
+    tab = NTT77()
+    marker = (VOIDP * 77)(*[VOIDP(0x1000 + i) for i in range(77)])          # a stand-in base table: unserved slots must come through untouched
+    L.sc_hip_utils_arith_ntt_fill.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.sc_hip_utils_arith_ntt_fill(C.byref(tab), marker) == 0
+    raw = (VOIDP * 77).from_buffer(tab)
+    served = set(range(18 + 3, 18 + 12)) | set(range(18 + 13, 18 + 26))
+    for i in range(77):
+        if i not in served:
+            assert raw[i] == 0x1000 + i, i
+        else:
+            assert raw[i] not in (None, 0x1000 + i), i
+    L.sc_hip_vtable_errors.restype = C.c_ulong
+    e0 = L.sc_hip_vtable_errors()
+    p = Params(); p.n = n; p.u.ntt32.q = q; p.q_dbl = q; p.inv_q_dbl = 1.0 / q
+    w, r = O.tables(q, n)
+    rng = np.random.default_rng(q + n)
+    # flip_32: v[0] = -v[0], v[i] <-> v[n-i], one +q / -q
+    x = rng.integers(-q + 1, 2 * q, size=n).astype(np.int32)
+    v = x.copy()
+    tab.flip_32(P(v), C.byref(p))
+    e = np.empty(n, dtype=np.int64); e[0] = -int(x[0]); e[1:] = x[:0:-1]
+    e = np.where(e < 0, e + q, e); e = np.where(e >= q, e - q, e)
+    assert np.array_equal(v, e.astype(np.int32))
+    # fft_32_32 / fft_32_16: X[k] = sum_m x[m] g^(2mk) of the un-bit-reversed input; with the twist it is the forward transform
+    xn = rng.integers(0, q, size=n).astype(np.int32)
+    br = _bitrev(n)
+    a = xn[br].copy()                                                        # bit-reversed order in, natural order out
+    tw = ((xn.astype(np.int64) * w) % q).astype(np.int32)                    # what fwd_ntt feeds the fft: t o w, shuffled
+    want = O.fwd_ntt(xn[None, :], q, w)[0]
+    b = tw[br].copy()
+    tab.fft_32_32(P(b), C.byref(p), P(w))
+    assert np.array_equal(b, want)
+    b = tw[br].copy()
+    tab.fft_32_16_large(P(b), C.byref(p), w.astype(np.int16).ctypes.data_as(i16p))
+    assert np.array_equal(b, want)
+    # fft is linear and fixes the delta: fft(bitrev(e0)) = all ones
+    d = np.zeros(n, dtype=np.int32); d[0] = 1
+    tab.fft_32_32_large(P(d), C.byref(p), P(w))
+    assert (d == 1).all()
+    del a
+    # mul_32_scalar
+    t = rng.integers(-q, q, size=n).astype(np.int32)
+    out = np.zeros(n, dtype=np.int32)
+    tab.mul_32_scalar(P(out), C.byref(p), P(t), 12345 % q)
+    assert np.array_equal(out, ((t.astype(np.int64) * (12345 % q)) % q).astype(np.int32))
+    assert L.sc_hip_vtable_errors() == e0
+
+
+def test_poly_and_vec_tables():
+    from libsafecrypto_amd import load_library
+    L = load_library()
+    assert C.sizeof(POLY35) == 35 * 8 and C.sizeof(VEC4) == 32
+    pt, vt = POLY35(), VEC4()
+    L.sc_hip_utils_arith_poly_fill.argtypes = [C.c_void_p, C.c_void_p]
+    L.sc_hip_utils_arith_vec_fill.argtypes = [C.c_void_p]
+    assert L.sc_hip_utils_arith_poly_fill(C.byref(pt), None) == 0 and L.sc_hip_utils_arith_vec_fill(C.byref(vt)) == 0
+    L.sc_hip_vtable_errors.restype = C.c_ulong
+    e0 = L.sc_hip_vtable_errors()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 512, 1536):
+        a = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32); b = rng.integers(-2**31, 2**31 - 1, size=n).astype(np.int32)
+        o = np.zeros(n, dtype=np.int32)
+        with np.errstate(over='ignore'):
+            pt.add_32(P(o), n, P(a), P(b)); assert np.array_equal(o, a + b)
+            pt.sub_32(P(o), n, P(a), P(b)); assert np.array_equal(o, a - b)
+            c = a.copy(); pt.add_single_32(P(c), n, P(b)); assert np.array_equal(c, a + b)
+            c = a.copy(); pt.sub_single_32(P(c), n, P(b)); assert np.array_equal(c, a - b)
+            c = a.copy(); pt.mul_32_scalar(P(c), n, -77); assert np.array_equal(c, a * np.int32(-77))
+            pt.mod_negate_32(P(o), n, 12289, P(a)); assert np.array_equal(o, np.int32(12289) - a)
+            assert pt.cmp_not_equal_32(P(a), P(a.copy()), n) == 0
+            c = a.copy(); c[n // 2] ^= 4
+            assert pt.cmp_not_equal_32(P(a), P(c), n) != 0
+            s = rng.integers(-3000, 3000, size=n).astype(np.int32); t = rng.integers(-3000, 3000, size=n).astype(np.int32)
+            assert vt.absmax_32(P(s), n) == int(np.abs(s).max())
+            assert vt.scalar_32(P(s), P(t), n) == int(np.sum(s.astype(np.int64) * t).astype(np.int64).astype(np.int32))
+            s16, t16 = s.astype(np.int16), t.astype(np.int16)
+            assert vt.absmax_16(s16.ctypes.data_as(i16p), n) == int(np.abs(s).max())
+            assert vt.scalar_16(s16.ctypes.data_as(i16p), t16.ctypes.data_as(i16p), n) == int(np.sum(s.astype(np.int64) * t).astype(np.int64).astype(np.int32))
+    assert L.sc_hip_vtable_errors() == e0
+
+
+def test_sampler_table_pulls_words_in_order():
+    """utils_sampling_t-shaped table: vector_32 draws n words from the callback, in order, and maps them through the CDT"""
+    from libsafecrypto_amd import load_library
+    L = load_library()
+
+    class SAMP(C.Structure):         # utils_sampling_t, src/utils/sampling/sampling.h:68-86 (packed)
+        _pack_ = 1
+    SAMP._fields_ = [('create', VOIDP), ('destroy', F(C.c_int32, C.POINTER(VOIDP))), ('get_prng', VOIDP), ('sample', F(C.c_int32, VOIDP)),
+                     ('vector_16', F(C.c_int32, C.POINTER(SAMP), i16p, C.c_size_t, C.c_int32)), ('vector_32', F(C.c_int32, C.POINTER(SAMP), i32p, C.c_size_t, C.c_int32)),
+                     ('precision', C.c_int32), ('dimension', C.c_int32), ('bootstrapped', C.c_int32), ('tail', C.c_float), ('sigma', C.c_float), ('sigma2', C.c_float),
+                     ('gauss', VOIDP), ('prng_ctx', VOIDP), ('discard', C.c_uint32), ('bootstrap', VOIDP)]
+    assert C.sizeof(SAMP) == 100
+    words = np.random.default_rng(77).integers(0, 2**63, size=4096, dtype=np.uint64)
+    state = {'i': 0}
+    RNG = F(C.c_uint64, VOIDP)
+
+    def draw(_ctx):
+        v = int(words[state['i']]); state['i'] += 1
+        return v
+    cb = RNG(draw)
+    h = VOIDP()
+    L.sc_hip_sampler_create.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int, RNG, C.c_void_p, C.POINTER(VOIDP)]
+    assert L.sc_hip_sampler_create(13.42, 215.0, None, 0, cb, None, C.byref(h)) == 0, L.sc_hip_last_error()
+    tab = SAMP()
+    L.sc_hip_utils_sampling_fill.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.sc_hip_utils_sampling_fill(C.byref(tab), h) == 0
+    table = O.cdt_table(13.42, 215.0)
+    v = np.zeros(512, dtype=np.int32)
+    assert tab.vector_32(C.byref(tab), P(v), 512, 0) == 0 and state['i'] == 512
+    assert np.array_equal(v, O.cdt_sample(words[:512], table))
+    v16 = np.zeros(100, dtype=np.int16)
+    assert tab.vector_16(C.byref(tab), v16.ctypes.data_as(i16p), 100, 3) == 0 and state['i'] == 612
+    assert np.array_equal(v16.astype(np.int32), O.cdt_sample(words[512:612], table) + 3)
+    one = tab.sample(tab.gauss)
+    assert one == int(O.cdt_sample(words[612:613], table)[0]) and state['i'] == 613
+    tab.discard = 2                                                      # sample discarding is not served: refused, counted
+    L.sc_hip_vtable_errors.restype = C.c_ulong
+    e0 = L.sc_hip_vtable_errors()
+    assert tab.vector_32(C.byref(tab), P(v), 4, 0) == 1 and L.sc_hip_vtable_errors() == e0 + 1
+    g = VOIDP(tab.gauss)
+    assert tab.destroy(C.byref(g)) == 0 and not g.value

@@ -11,8 +11,6 @@ from tests import oracle_lib as O
 tag = sys.argv[1] if len(sys.argv) > 1 else 'enssig0'
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-if len(sys.argv) > 4:
-    os.environ["SC_HIP_KLEIN_LANES"] = sys.argv[4]
 G = load_golden('ensdlp_ref.txt')
 par = np.asarray(G[f'{tag}_params'])
 n, q = int(par[0]), int(par[1])
@@ -20,6 +18,8 @@ b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
 eng = Engine(0)
 s = eng.ens_dlp_signer(par)
 s.set_key(b, bgs, inv)
+if len(sys.argv) > 4:
+    s.set_mapping(int(sys.argv[4]))
 g = torch.Generator(device='cuda'); g.manual_seed(3)
 msgs = torch.randint(0, 256, (batch, 64), dtype=torch.uint8, device='cuda', generator=g)
 tapes = torch.randint(-2**31, 2**31 - 1, (batch, 4 * n), dtype=torch.int32, device='cuda', generator=g)
