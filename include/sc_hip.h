@@ -253,10 +253,15 @@ size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *h);
  * signature's randomness from its CSPRNG as 32-bit pool words (prng.c:963-1048); the engine owns no CSPRNG, so each
  * message comes with that word stream: d_tapes uint32 [batch][tape_stride], d_tape_lens (or NULL: tape_stride words
  * each).  A fresh attempt consumes 4n words, every attempt 1-2 more.  d_status[i]: 1 signed, 2 tape exhausted,
- * 3 empty message (refused by the reference's oracle).  Signatures equal the reference's for the same words. */
+ * 3 empty message (refused by the reference's oracle), 5 undecided: the rejection draw fell within the tie margin of the threshold
+ * 1 / (M exp(-|Sc|^2 / 2 sigma^2) cosh(<z, Sc> / sigma^2)) (bliss_b.c:1420-1428), which the device evaluates with its own f64 exp / cosh
+ * and glibc evaluates with its own - such a message (about one attempt in 10^12 at the default margin 2^-40) is not signed here, the
+ * caller signs it on the reference path.  Signatures equal the reference's for the same words. */
 int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* the relative margin of the status-5 report above (default 2^-40; 0 decides everything on the device; 1 reports every attempt - self-test) */
+int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
 /* replaces: safecrypto_verify -> bliss_b_verify (bliss_b.c:1583-1740); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
@@ -530,6 +535,35 @@ int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *h, size_t batch, const int32_
                                const uint8_t *d_rho, const uint8_t *d_K, const uint8_t *d_tr,
                                const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
+
+/* ---- multi-device driver --------------------------------------------------------------------------------
+ * Independent units shard with no collective: a host batch is cut into contiguous slices (sc_hip_shard_range), one host thread per
+ * worker drives its device (>= 2 streams per device inside the per-device host entry points), results are written at the slice's
+ * offset of the caller's buffers.  devices: HIP device ordinals, one worker each (NULL: 0 .. nworkers-1); an ordinal may repeat. */
+typedef struct sc_hip_multi sc_hip_multi_t;
+typedef struct sc_hip_multi_plan sc_hip_multi_plan_t;
+typedef struct sc_hip_multi_dilithium sc_hip_multi_dilithium_t;
+void sc_hip_shard_range(size_t total, int parts, int index, size_t *begin, size_t *count);   /* slice `index` of `parts`: sizes differ by at most one */
+int  sc_hip_multi_create(const int *devices, int nworkers, sc_hip_multi_t **m);
+void sc_hip_multi_destroy(sc_hip_multi_t *m);
+int  sc_hip_multi_workers(const sc_hip_multi_t *m);
+sc_hip_ctx_t *sc_hip_multi_ctx(const sc_hip_multi_t *m, int worker);                         /* a worker's context, for the batched per-device ABI */
+/* the plan replicated on every worker; the *_host transforms of this header over the whole host batch */
+int  sc_hip_multi_plan_create(sc_hip_multi_t *m, int32_t q, int n, sc_hip_multi_plan_t **plan);
+void sc_hip_multi_plan_destroy(sc_hip_multi_plan_t *plan);
+int  sc_hip_multi_ntt_fwd_host(sc_hip_multi_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
+int  sc_hip_multi_ntt_inv_host(sc_hip_multi_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
+int  sc_hip_multi_polymul_ntt_host(sc_hip_multi_plan_t *plan, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out);
+/* Dilithium sign / verify of a host batch under one key pair (replicated to every worker at set_*key); arguments as the one-device *_host entries */
+int  sc_hip_multi_dilithium_create(sc_hip_multi_t *m, const sc_hip_dilithium_params_t *params, sc_hip_multi_dilithium_t **h);
+void sc_hip_multi_dilithium_destroy(sc_hip_multi_dilithium_t *h);
+int  sc_hip_multi_dilithium_set_privkey(sc_hip_multi_dilithium_t *h, const int32_t *s1, const int32_t *s2, const int32_t *t, const uint8_t *K, const uint8_t *tr, const int32_t *Ahat);
+int  sc_hip_multi_dilithium_set_pubkey(sc_hip_multi_dilithium_t *h, const int32_t *t1, const uint8_t *rho, const int32_t *Ahat);
+size_t sc_hip_multi_dilithium_sig_max(const sc_hip_multi_dilithium_t *h);
+int  sc_hip_multi_dilithium_sign_host(sc_hip_multi_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                      uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials);
+int  sc_hip_multi_dilithium_verify_host(sc_hip_multi_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                        const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
 
 /* ---- host-buffer convenience (H2D, kernel, D2H; synchronous) ---------------------------- */
 int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);

@@ -5,4 +5,4 @@ The product is the C-ABI shared library libsafecrypto_amd/lib/libsc_hip.so (incl
 This Python package is only the thin host binding used by tests and bench.py; torch is used
 for device memory and streams, never for the arithmetic.
 """
-from .engine import Engine, NttPlan, CdtSampler, Dilithium, Bliss, Falcon, Tesla, Rlwe, Ens, Dlp, EnsDlpSigner, Kyber, load_library, LIB_PATH, EngineError, build_cdt_table  # noqa: F401
+from .engine import Engine, NttPlan, CdtSampler, Dilithium, Bliss, Falcon, Tesla, Rlwe, Ens, Dlp, EnsDlpSigner, Kyber, load_library, LIB_PATH, EngineError, build_cdt_table, Multi, shard_range  # noqa: F401

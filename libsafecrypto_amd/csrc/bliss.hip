@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
                                                         const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
                                                         const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
                                                         const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, BlissP P)
+                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
@@ -296,6 +296,10 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     const double rr = T.dbl();
     if (lane == 0) { s.pos[item] = T.pos; s.var_buf[item] = T.var_buf; s.var_bits[item] = T.var_bits; }
     if (T.underrun) { if (lane == 0) { s.status[item] = 2; siglens[item] = 0; } return; }
+    // exp / cosh here are the device's f64 functions, the reference's are glibc's: the two thresholds may differ in the last bits.  A draw closer to
+    // the threshold than tie_rel (2^-40 relative: ~13 bits above what either library can be off by) is NOT decided here - it would decide the rest
+    // of the signature's tape - but reported (status 5) for the caller to sign that message on the reference path.  Expected once per ~10^12 attempts.
+    if (fabs(rr - thresh) <= tie_rel * thresh) { if (lane == 0) { s.status[item] = 5; siglens[item] = 0; } return; }
     if (rr > thresh) { reject(); return; }
 
     // signature_gen (bliss_b.c:1045-1075; its Barrett multiplier is built from q, not p - kept) + check_norms (:1010-1043)
@@ -514,6 +518,7 @@ struct sc_hip_bliss {
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
     int32_t *tu, *tin, *v, *cidx;
     int16_t *z;
+    double tie_rel;              // accept / reject draws closer to the threshold than this (relative) are reported, not decided: status 5
 };
 
 static void bl_free_ws(sc_hip_bliss *b)
@@ -554,7 +559,18 @@ extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_
     sc_hip_bliss *b = new sc_hip_bliss;
     memset(b, 0, sizeof *b);
     b->ctx = ctx; b->plan = plan; b->cdt = cdt; b->P = P;
+    b->tie_rel = 0x1p-40;
     *out = b;
+    return SC_HIP_SUCCESS;
+}
+
+// the margin inside which the accept / reject draw is reported (status 5) instead of decided; 2^-40 by default.  A margin of 1 reports every
+// attempt that reaches the test (self-test of the reporting path).
+extern "C" int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *b, double relative)
+{
+    if (!b) return fail("bliss_set_tie_margin: null handle");
+    if (!(relative >= 0.0) || relative > 1.0) return fail("bliss_set_tie_margin: margin must be in [0, 1]");
+    b->tie_rel = relative;
     return SC_HIP_SUCCESS;
 }
 
@@ -645,7 +661,7 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
             hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, d_msgs, msg_stride, d_mlens, fixed_len, b->z, b->cidx, b->ok,
                                0, (uint32_t *)nullptr, P);
         hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, d_tapes, tape_stride, d_tape_lens,
-                           b->d_f, b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P);
+                           b->d_f, b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P, b->tie_rel);
         HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));

@@ -22,7 +22,7 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -38,6 +38,10 @@ SYMBOLS = [
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
     'sc_hip_rlwe_enc_words', 'sc_hip_rlwe_keygen_words', 'sc_hip_rlwe_encrypt', 'sc_hip_rlwe_decrypt', 'sc_hip_rlwe_keygen',
 ]
+SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy', 'sc_hip_multi_workers', 'sc_hip_multi_ctx', 'sc_hip_multi_plan_create', 'sc_hip_multi_plan_destroy',
+            'sc_hip_multi_ntt_fwd_host', 'sc_hip_multi_ntt_inv_host', 'sc_hip_multi_polymul_ntt_host', 'sc_hip_multi_dilithium_create', 'sc_hip_multi_dilithium_destroy',
+            'sc_hip_multi_dilithium_set_privkey', 'sc_hip_multi_dilithium_set_pubkey', 'sc_hip_multi_dilithium_sig_max', 'sc_hip_multi_dilithium_sign_host',
+            'sc_hip_multi_dilithium_verify_host']
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
 BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_dilithium_set_tuning']
 # include/sc_hip_vtable.h
@@ -143,6 +147,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sig_bytes.restype = sz
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
+    L.sc_hip_bliss_set_tie_margin.argtypes = [vp, C.c_double]
     L.sc_hip_bliss_keygen.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
     L.sc_hip_ntt_flip.argtypes = [vp, sz, vp, vp, vp]
@@ -229,6 +234,29 @@ def load_library(path=LIB_PATH):
     L.sc_hip_falcon_sig_bytes.argtypes = [vp]
     L.sc_hip_falcon_sig_bytes.restype = sz
     L.sc_hip_falcon_set_mapping.argtypes = [vp, C.c_int]
+    L.sc_hip_shard_range.argtypes = [sz, C.c_int, C.c_int, C.POINTER(sz), C.POINTER(sz)]
+    L.sc_hip_shard_range.restype = None
+    L.sc_hip_multi_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.sc_hip_multi_destroy.argtypes = [vp]
+    L.sc_hip_multi_destroy.restype = None
+    L.sc_hip_multi_workers.argtypes = [vp]
+    L.sc_hip_multi_ctx.argtypes = [vp, C.c_int]
+    L.sc_hip_multi_ctx.restype = vp
+    L.sc_hip_multi_plan_create.argtypes = [vp, i32, C.c_int, C.POINTER(vp)]
+    L.sc_hip_multi_plan_destroy.argtypes = [vp]
+    L.sc_hip_multi_plan_destroy.restype = None
+    for name in ('sc_hip_multi_ntt_fwd_host', 'sc_hip_multi_ntt_inv_host'):
+        getattr(L, name).argtypes = [vp, sz, vp, vp]
+    L.sc_hip_multi_polymul_ntt_host.argtypes = [vp, sz, vp, vp, vp]
+    L.sc_hip_multi_dilithium_create.argtypes = [vp, vp, C.POINTER(vp)]
+    L.sc_hip_multi_dilithium_destroy.argtypes = [vp]
+    L.sc_hip_multi_dilithium_destroy.restype = None
+    L.sc_hip_multi_dilithium_set_privkey.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.sc_hip_multi_dilithium_set_pubkey.argtypes = [vp, vp, vp, vp]
+    L.sc_hip_multi_dilithium_sig_max.argtypes = [vp]
+    L.sc_hip_multi_dilithium_sig_max.restype = sz
+    L.sc_hip_multi_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
+    L.sc_hip_multi_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_falcon_sample_profile.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_falcon_sample.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_falcon_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
@@ -259,6 +287,89 @@ def _rows(t):
     """row stride (in elements) of a [batch][row] tensor; a size-1 leading dimension may carry any stride"""
     assert t.dim() == 2 and t.stride(1) == 1
     return t.stride(0) if t.shape[0] > 1 else t.shape[1]
+
+
+def shard_range(total, parts, index):
+    """sc_hip_shard_range: (begin, count) of slice `index` of `parts` (host-only, no device needed)"""
+    L = load_library()
+    b, c = C.c_size_t(), C.c_size_t()
+    L.sc_hip_shard_range(total, parts, index, C.byref(b), C.byref(c))
+    return b.value, c.value
+
+
+class Multi:
+    """The in-library multi-device driver (sc_hip_multi_*): one host thread per worker, contiguous slices of a host batch, no collective.
+    devices: HIP device ordinals, one worker each (an ordinal may repeat)."""
+
+    def __init__(self, devices):
+        import numpy as np
+        self.L = load_library()
+        d = np.ascontiguousarray(np.asarray(devices), dtype=np.int32)
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_multi_create(_ptr(d), d.size, C.byref(h)), 'sc_hip_multi_create')
+        self.h = h
+        self.workers = self.L.sc_hip_multi_workers(h)
+        self._plans, self._dil = {}, None
+
+    def close(self):
+        for p in self._plans.values():
+            self.L.sc_hip_multi_plan_destroy(p)
+        self._plans = {}
+        if self._dil:
+            self.L.sc_hip_multi_dilithium_destroy(self._dil); self._dil = None
+        if self.h:
+            self.L.sc_hip_multi_destroy(self.h); self.h = None
+
+    def _plan(self, q, n):
+        if (q, n) not in self._plans:
+            p = C.c_void_p()
+            _chk(self.L, self.L.sc_hip_multi_plan_create(self.h, q, n, C.byref(p)), 'sc_hip_multi_plan_create')
+            self._plans[(q, n)] = p
+        return self._plans[(q, n)]
+
+    def polymul_ntt_host(self, q, a, bhat):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.int32); bhat = np.ascontiguousarray(bhat, dtype=np.int32)
+        out = np.empty_like(a)
+        _chk(self.L, self.L.sc_hip_multi_polymul_ntt_host(self._plan(q, a.shape[1]), a.shape[0], _ptr(a), _ptr(bhat), _ptr(out)), 'multi_polymul_ntt_host')
+        return out
+
+    def ntt_host(self, q, a, inverse=False):
+        import numpy as np
+        a = np.ascontiguousarray(a, dtype=np.int32)
+        out = np.empty_like(a)
+        f = self.L.sc_hip_multi_ntt_inv_host if inverse else self.L.sc_hip_multi_ntt_fwd_host
+        _chk(self.L, f(self._plan(q, a.shape[1]), a.shape[0], _ptr(a), _ptr(out)), 'multi_ntt_host')
+        return out
+
+    def dilithium(self, params, s1, s2, t, K, tr, Ahat, t1, rho):
+        import numpy as np
+        par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        d = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_multi_dilithium_create(self.h, _ptr(par), C.byref(d)), 'sc_hip_multi_dilithium_create')
+        self._dil = d
+        c32 = lambda x: np.ascontiguousarray(np.asarray(x), dtype=np.int32)
+        c8 = lambda x: np.ascontiguousarray(np.asarray(x), dtype=np.uint8)
+        A, a1, a2, at, aK, atr, at1, arho = c32(Ahat), c32(s1), c32(s2), c32(t), c8(K), c8(tr), c32(t1), c8(rho)      # converted copies must outlive the calls
+        _chk(self.L, self.L.sc_hip_multi_dilithium_set_privkey(d, _ptr(a1), _ptr(a2), _ptr(at), _ptr(aK), _ptr(atr), _ptr(A)), 'multi_dilithium_set_privkey')
+        _chk(self.L, self.L.sc_hip_multi_dilithium_set_pubkey(d, _ptr(at1), _ptr(arho), _ptr(A)), 'multi_dilithium_set_pubkey')
+        self.sig_max = self.L.sc_hip_multi_dilithium_sig_max(d)
+
+    def dilithium_sign_host(self, msgs, fixed_len):
+        """msgs uint8 [batch][stride] (numpy) -> signatures uint8 [batch][sig_max], lengths, trials"""
+        import numpy as np
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8)
+        n = msgs.shape[0]
+        sigs = np.zeros((n, self.sig_max), dtype=np.uint8); sl = np.zeros(n, dtype=np.uint32); tr = np.zeros(n, dtype=np.uint32)
+        _chk(self.L, self.L.sc_hip_multi_dilithium_sign_host(self._dil, n, _ptr(msgs), msgs.shape[1], C.c_void_p(), fixed_len, _ptr(sigs), self.sig_max, _ptr(sl), _ptr(tr)), 'multi_dilithium_sign_host')
+        return sigs, sl, tr
+
+    def dilithium_verify_host(self, msgs, fixed_len, sigs, siglens):
+        import numpy as np
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8); sigs = np.ascontiguousarray(sigs, dtype=np.uint8); sl = np.ascontiguousarray(siglens, dtype=np.uint32)
+        v = np.ones(msgs.shape[0], dtype=np.uint32)
+        _chk(self.L, self.L.sc_hip_multi_dilithium_verify_host(self._dil, msgs.shape[0], _ptr(msgs), msgs.shape[1], C.c_void_p(), fixed_len, _ptr(sigs), sigs.shape[1], _ptr(sl), _ptr(v)), 'multi_dilithium_verify_host')
+        return v
 
 
 class Engine:
@@ -734,6 +845,10 @@ class Bliss:
         self.n = int(self.par[0])
         self.sig_bytes = self.L.sc_hip_bliss_sig_bytes(h)
         self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def set_tie_margin(self, relative):
+        """relative margin around the rejection threshold inside which a draw is reported (status 5) instead of decided; default 2^-40"""
+        _chk(self.L, self.L.sc_hip_bliss_set_tie_margin(self.h, float(relative)), 'bliss_set_tie_margin')
 
     def close(self):
         if self.h:

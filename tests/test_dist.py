@@ -63,3 +63,14 @@ def test_two_rank_sharding_matches_single_process(tmp_path):
     assert np.array_equal(np.concatenate(parts), full)     # host-side concatenation, no collective
     rng_ = [tuple(np.load(tmp_path / f'range{r_}.npy')) for r_ in range(world)]
     assert rng_ == [shard_range(batch, r_, world) for r_ in range(world)]
+
+
+def test_library_shard_range_is_the_same_rule():
+    """sc_hip_shard_range (the C driver's cut, host-only) tiles a batch exactly as shard.py's rule does"""
+    from libsafecrypto_amd import engine
+    for total in (0, 1, 7, 203, 16384, 65537):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lo, hi = shard_range(total, r, world)
+                assert engine.shard_range(total, world, r) == (lo, hi - lo)
+    assert engine.shard_range(10, 0, 0) == (0, 0) and engine.shard_range(10, 2, 5) == (0, 0)     # nonsense arguments: an empty slice

@@ -210,3 +210,32 @@ def test_other_parameter_sets(eng, G, tag):
     for i in range(len(cs)):
         assert vb[i] == int(G[f'{tag}_verify'][2 * i + 1])
     b.close()
+
+
+def test_rejection_near_tie_is_reported_not_decided(eng, G):
+    """the accept / reject comparison uses the device's f64 exp / cosh where the reference uses glibc's: a draw within the tie margin of the
+    threshold is reported (status 5) instead of decided.  At the default margin (2^-40) no fixture tape nor any of 20000 seeded signatures
+    reports it and every byte still equals the reference's; at margin 1 every attempt that reaches the test reports it; at margin 0 nothing
+    ever does."""
+    import torch
+    key = O.BlissKey.from_golden(G, 'bliss1')
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    cs = cases(G)
+    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], 4200)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    assert status.cpu().tolist() == [1] * len(cs)
+    g = torch.Generator(device='cuda'); g.manual_seed(41)
+    B = 20000
+    m2 = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    t2 = torch.randint(-2**31, 2**31 - 1, (B, 4 * 2048 + 64), dtype=torch.int32, device='cuda', generator=g)
+    s_def, l_def, _, st_def = b.sign(m2, t2, fixed_len=64)
+    assert int((st_def == 5).sum()) == 0 and int((st_def == 1).sum()) >= B - 20
+    b.set_tie_margin(0.0)
+    s_0, l_0, _, st_0 = b.sign(m2, t2, fixed_len=64)
+    assert torch.equal(st_0, st_def) and torch.equal(s_0, s_def) and torch.equal(l_0, l_def)
+    b.set_tie_margin(1.0)                                            # |r - thresh| <= thresh always holds for r in (0, 1), thresh >= 1 / (M cosh) ... : reported
+    sig1, len1, _, st1 = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    assert set(st1.cpu().tolist()) == {5} and int(len1.sum()) == 0
+    with pytest.raises(Exception):
+        b.set_tie_margin(2.0)
+    b.close()
