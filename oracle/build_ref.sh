@@ -23,7 +23,7 @@ B="${SC_REF_BUILD:-/tmp/sc_ref_build}"
 if [ ! -d "$REF/src" ]; then
     echo "build_ref: $REF not present - keeping prebuilt oracle/_ref (if any)"; exit 0
 fi
-rm -rf "$B"; mkdir -p "$B/gen/utils/arith" "$B/obj" "$OUT"
+rm -rf "$B"; mkdir -p "$B/gen/utils/arith" "$OUT"
 CC="${CC:-gcc}"
 DEFS="-D_GNU_SOURCE -DHAVE_64BIT -DHAVE_128BIT -DUSE_SAFECRYPTO_INTEGER_MP -DUSE_SAFECRYPTO_FLOAT_MP \
  -DSHA3_UNROLLED -DHAVE___BUILTIN_CTZ -DHAVE___BUILTIN_CLZ -DCONFIGURE_INVOCATION=\"manual\" -DECRYPT_API=\"ecrypt-sync.h\" \
@@ -67,19 +67,39 @@ $CC -O2 -w $DEFS $INC "$REF/build_tools/ntt_table_gen/main.c" \
       if [ -f "$d/$f" ]; then echo "$d/$f"; fi; done; done | sort -u | grep -v -e ntt_avx -e isaac/rand.c ) > "$B/srcs.txt"
 compile_one() {
     local s=$1 o
-    o="$B/obj/$(echo "${s#./}" | tr '/' '_' | sed 's/\.c$/.o/')"
+    o="$OBJ/$(echo "${s#./}" | tr '/' '_' | sed 's/\.c$/.o/')"
     $CC $CFLAGS -c "$REF/src/$s" -o "$o" 2> "$o.err" || { echo "FAIL $s"; cat "$o.err"; return 1; }
 }
-export -f compile_one; export CC CFLAGS REF B
-xargs -P "$(nproc)" -I{} bash -c 'compile_one {}' < "$B/srcs.txt"
-for f in "$B"/gen/utils/arith/ntt_*.c; do
-    $CC $CFLAGS -c "$f" -o "$B/obj/gen_$(basename "${f%.c}").o"
-done
-$CC -shared -o "$OUT/libsafecrypto_ref.so" "$B"/obj/*.o -lm -lpthread
-
-# 5. our driver (our source, reference headers at build time only)
-$CC -O2 -std=gnu11 -w $DEFS $INC "$HERE/ref_driver.c" -o "$OUT/ref_driver" \
-    -L"$OUT" -lsafecrypto_ref -Wl,-rpath,'$ORIGIN' -lm -lpthread
+export -f compile_one
+# one library + driver per build flavour: the plain build (what the fixtures are generated with) and the AVX2 build of SURVEY 8(d)'s CPU protocol
+build_flavour() { # suffix extra-flags
+    local sfx=$1 extra=$2
+    export OBJ="$B/obj$sfx"; mkdir -p "$OBJ"
+    export CFLAGS="-O2 -std=gnu11 -fcommon -fPIC -w $DEFS $extra $INC"
+    export CC REF B
+    xargs -P "$(nproc)" -I{} bash -c 'compile_one {}' < "$B/srcs.txt"
+    for f in "$B"/gen/utils/arith/ntt_*.c; do
+        case "$f" in *ntt_avx.c) [ -n "$sfx" ] || continue;; esac
+        $CC $CFLAGS -c "$f" -o "$OBJ/gen_$(basename "${f%.c}").o"
+    done
+    $CC -shared -o "$OUT/libsafecrypto_ref$sfx.so" "$OBJ"/*.o -lm -lpthread
+    # 5. our driver (our source, reference headers at build time only)
+    $CC -O2 -std=gnu11 -w $DEFS $extra $INC "$HERE/ref_driver.c" -o "$OUT/ref_driver$sfx" \
+        -L"$OUT" -lsafecrypto_ref$sfx -Wl,-rpath,'$ORIGIN' -lm -lpthread
+}
+build_flavour "" ""
+if grep -q avx2 /proc/cpuinfo; then
+    {   # the AVX2 instance of the template, as gen_ntt.sh:95-103 makes it
+      printf '#include "utils/arith/ntt.h"\n#ifndef USE_RUNTIME_NTT_TABLES\n#include "utils/arith/ntt_tables.h"\n#endif\n'
+      printf '#include "utils/arith/sc_math.h"\n#include <stdio.h>\n#include "utils/arith/ntt_avx.h"\n#include <immintrin.h>\n'
+      cpp -CC -P -nostdinc -E "$A/ntt_template.c.in" -DNTT_NAME_EXT="avx" -D_ENABLE_AVX2_INTRINSICS -D_NTT_MK1
+    } > "$B/gen/utils/arith/ntt_avx.c"
+    {
+      printf '#pragma once\n#include "safecrypto_types.h"\n#include "utils/arith/limb.h"\n'
+      cpp -CC -P -nostdinc -E "$A/ntt_template.h.in" -DNTT_NAME_EXT="avx" -D_ENABLE_AVX2_INTRINSICS -D_NTT_MK1
+    } > "$B/gen/utils/arith/ntt_avx.h"
+    build_flavour "_avx2" "-mavx2 -DHAVE_AVX2 -DHAVE_AVX" || echo "build_ref: AVX2 flavour failed - the plain build stands"
+fi
 # 6. the drop-in proof (examples/safecrypto_glue: the libsafecrypto-side binding + a driver; our sources, reference headers at build time only),
 #    linked with the reference library AND the engine; it only runs where there is a GPU (tests/test_gpu_dropin.py)
 ENG="$HERE/../libsafecrypto_amd/lib"

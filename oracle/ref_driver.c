@@ -1281,7 +1281,12 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
  * fwd_ntt -> mul_32_pointwise -> inv_ntt per polynomial, over a resident pool of polynomials. */
 static int bench_ntt(int32_t q, int n, double seconds)
 {
+    /* the backend a scheme context gets by default from this build: floating point, or AVX2 in the -mavx2 -DHAVE_AVX2 build (dilithium.c:184-191) */
+#ifdef HAVE_AVX2
+    const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_AVX);
+#else
     const utils_arith_ntt_t *ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+#endif
     ntt_params_t p;
     const int POOL = 1024;
     int32_t *w = malloc(sizeof(int32_t) * n), *r = malloc(sizeof(int32_t) * n);

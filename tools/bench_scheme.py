@@ -1,0 +1,83 @@
+"""One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls]` runs one warm-up call and `calls` timed calls of
+   dil_sign | dil_verify | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | polymul | cdt
+on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call."""
+import sys, os, time, json
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import numpy as np
+import torch
+from libsafecrypto_amd import Engine
+from tests.golden_io import load_golden
+
+
+def main():
+    leg = sys.argv[1]
+    calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    eng = Engine(0)
+    g = torch.Generator(device='cuda'); g.manual_seed(3)
+    if leg.startswith('dil'):
+        G = load_golden('dilithium_ref.txt'); tag, B = 'dil3', 16384
+        d = eng.dilithium(G[f'{tag}_params'])
+        d.set_privkey(*(G[f'{tag}_{x}'] for x in ('s1', 's2', 't', 'K', 'tr', 'Ahat'))); d.set_pubkey(G[f'{tag}_t1'], G[f'{tag}_rho'], G[f'{tag}_Ahat'])
+        msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+        sigs, siglens, _ = d.sign(msgs, fixed_len=64); torch.cuda.synchronize()
+        made = 1
+        fn = (lambda: d.sign(msgs, fixed_len=64)) if leg == 'dil_sign' else (lambda: d.verify(msgs, sigs, siglens, fixed_len=64))
+        if leg == 'dil_verify':
+            fn(); made = 1                       # the sign above is a different leg: counted by the caller through kernel names
+    elif leg.startswith('bliss'):
+        G = load_golden('bliss_ref.txt'); B = 16384
+        b = eng.bliss(G['bliss1_params']); b.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
+        msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+        tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * 2048 + 64), dtype=torch.int32, device='cuda', generator=g)
+        sigs, siglens, _, _ = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+        made = 1
+        fn = (lambda: b.sign(msgs, tapes, fixed_len=64)) if leg == 'bliss_sign' else (lambda: b.verify(msgs, sigs, siglens, fixed_len=64))
+        if leg == 'bliss_verify':
+            fn()
+    elif leg.startswith('falcon'):
+        G = load_golden('falcon_ref.txt'); tag, B = 'falcon2', 8192
+        f = eng.falcon(G[f'{tag}_params'])
+        f.set_privkey(np.asarray(G[f'{tag}_sk'], dtype=np.int64).view(np.float64)); f.set_pubkey(G[f'{tag}_h'])
+        msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+        tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
+        sigs, siglens, _ = f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+        made = 1
+        fn = (lambda: f.sign(msgs, tapes, fixed_len=64)) if leg == 'falcon_sign' else (lambda: f.verify(msgs, sigs, siglens, fixed_len=64))
+        if leg == 'falcon_verify':
+            fn()
+    elif leg == 'kyber_encaps':
+        G = load_golden('kyber_ref.txt'); B = 65536
+        ky = eng.kyber(G['kyber1_params']); ky.set_pubkey(G['kyber1_t_ntt'], G['kyber1_Agen']); ky.set_kem_pubkey(G['kyber1_t'], G['kyber1_rho'])
+        m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+        ky.encaps(m); torch.cuda.synchronize(); made = 1
+        fn = lambda: ky.encaps(m)
+    elif leg == 'tesla_sign':
+        G = load_golden('tesla_ref.txt'); B = 16384
+        ts = eng.tesla(G['tesla0_params']); ts.set_key(*(G[f'tesla0_{x}'] for x in ('a1', 'a2', 's', 'e1', 'e2', 't1', 't2')))
+        msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+        tapes = torch.randint(-2**31, 2**31 - 1, (B, 24 * 512), dtype=torch.int32, device='cuda', generator=g)
+        ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); made = 1
+        fn = lambda: ts.sign(msgs, tapes, fixed_len=64)
+    elif leg == 'polymul':
+        q, n, B = 7681, 256, 65536
+        p = eng.plan(q, n)
+        a = torch.randint(0, q, (B, n), dtype=torch.int32, device='cuda', generator=g); bh = torch.randint(0, q, (B, n), dtype=torch.int32, device='cuda', generator=g)
+        out = torch.empty_like(a)
+        p.polymul_ntt(a, bh, out); torch.cuda.synchronize(); made = 1
+        fn = lambda: p.polymul_ntt(a, bh, out)
+    elif leg == 'cdt':
+        B = 1 << 26
+        s = eng.sampler(13.42, 215.0)
+        u = torch.randint(-2**63, 2**63 - 1, (B,), dtype=torch.int64, device='cuda', generator=g)
+        o = s.sample(u); torch.cuda.synchronize(); made = 1
+        fn = lambda: s.sample(u)
+    else:
+        raise SystemExit('unknown leg')
+    ts_ = []
+    for _ in range(calls):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts_.append(time.perf_counter() - t0)
+    print(json.dumps({'leg': leg, 'batch': B, 'calls_of_this_leg': made + calls, 'ms_per_call_min': min(ts_) * 1e3, 'ops_per_s': B / min(ts_)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()
