@@ -416,7 +416,7 @@ struct sc_hip_dilithium {
     uint8_t *msg_dev, *sig_dev;
     size_t msg_cap, sig_cap;
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
-    int tune_slots, tune_unfused;                     // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product
+    int tune_slots, tune_unfused, tune_growth;                     // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product
 };
 
 static void free_ws(sc_hip_dilithium *d)
@@ -613,7 +613,7 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
-    d->tune_slots = slots_per_message; d->tune_unfused = unfused ? 1 : 0;
+    d->tune_slots = slots_per_message & 0xFF; d->tune_growth = (slots_per_message >> 8) & 0xFF; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -663,7 +663,7 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     size_t slot_target = batch * 8 < 49152 ? batch * 8 : 49152;
     if (slot_target < batch) slot_target = batch;
     if (d->tune_slots >= 1 && d->tune_slots <= 32) slot_target = batch * (size_t)d->tune_slots;
-    if (slot_target < 4096) slot_target = 4096;
+    if (slot_target < 4096 && !d->tune_growth) slot_target = 4096;
     if (ensure_ws(d, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const DilP &P = d->P;
@@ -680,6 +680,11 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         if (round > 4000) return fail("dilithium_sign: rejection loop did not terminate");
         uint32_t S = (uint32_t)(d->slot_cap / nact);
         if (S > 32) S = 32;
+        if (d->tune_growth > 0) {                                     // experiment: cap the depth at S0 * growth^round
+            uint64_t lim = (uint64_t)(slot_target / batch ? slot_target / batch : 1);
+            for (uint32_t r = 0; r < round && lim < 32; r++) lim *= (uint64_t)d->tune_growth;
+            if (S > lim) S = (uint32_t)lim;
+        }
         if (S < 1) S = 1;
         const uint32_t nslots = nact * S;
         uint32_t *next = d->act[round & 1];
