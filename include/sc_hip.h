@@ -260,6 +260,14 @@ size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *h);
 int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* the same with a key pair PER MESSAGE (distinct keys; 3 KB of key material per signature instead of a cache-resident set): d_f, d_g, d_a
+ * SINT16 [batch][n] rows in the key pair's own layouts - what sc_hip_bliss_keygen writes (f, 2g+1, a in the NTT domain).  No key needs to be loaded. */
+int sc_hip_bliss_sign_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_f, const int16_t *d_g, const int16_t *d_a,
+                           const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                           const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                           uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+int sc_hip_bliss_verify_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_a, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                             const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 /* the relative margin of the status-5 report above (default 2^-40; 0 decides everything on the device; 1 reports every attempt - self-test) */
 int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
 /* replaces: safecrypto_verify -> bliss_b_verify (bliss_b.c:1583-1740); d_verdicts[i] = 0 valid / 1 invalid */
@@ -505,6 +513,14 @@ size_t sc_hip_kyber_ct_bytes(const sc_hip_kyber_t *h);                       /* 
 int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
 /* replaces: safecrypto_decapsulation -> kyber_kem_decapsulation (kyber_kem.c:930-1040); needs set_privkey too */
 int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
+
+/* the same two with a key PER VALUE (distinct keys), in the layouts sc_hip_kyber_keygen writes: d_t, d_t_ntt, d_s_ntt int32
+ * [batch][k][n], d_rho [batch][32].  Every value's matrix is expanded from its rho and its G prefix absorbed from its own (rho, t); no key
+ * needs to be loaded into the handle.  Staging costs k*k*n*8 bytes of device memory per value. */
+int sc_hip_kyber_kem_encaps_keys(sc_hip_kyber_t *h, size_t batch, const int32_t *d_t, const int32_t *d_t_ntt, const uint8_t *d_rho,
+                                 const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
+int sc_hip_kyber_kem_decaps_keys(sc_hip_kyber_t *h, size_t batch, const int32_t *d_s_ntt, const int32_t *d_t, const int32_t *d_t_ntt, const uint8_t *d_rho,
+                                 const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream);
 
 /* replaces: safecrypto_keygen -> kyber_kem_keygen (kyber_kem.c:575-670; kyber_cpa_keygen, module_lwe.c:1189-1266) for `batch` key pairs.
  * Key i draws what the reference draws from sc->prng_ctx[0] - rho, the noise of s and e, z, in that order - from a CTR-DRBG seeded

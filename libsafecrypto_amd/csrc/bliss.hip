@@ -99,13 +99,16 @@ __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, 
 }
 
 // dense copy of the current t for the NTT product
-__global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n)
+// (a key per message: the active messages' public keys a, SINT16 rows, are gathered beside it as the product's second operand)
+__global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n,
+                                const int16_t *a_items = nullptr, int32_t *ain = nullptr)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     tin[t] = (need[aidx] == 2) ? 0 : tu[((size_t)item * 2 + cur[item]) * n + i];
+    if (a_items) ain[t] = (int32_t)a_items[(size_t)item * n + i];
 }
 
 // round_and_drop, bliss_b.c:681-703
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
                                                         const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
                                                         const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
                                                         const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel)
+                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         if (lane == 0) { s.iter[item] = it + 1; next_active[atomicAdd(next_count, 1u)] = item; }
     };
     if (!ok[aidx]) { reject(); return; }                                  // oracle failed: continue (bliss_b.c:1395-1397)
+    f += (size_t)item * key_stride; g += (size_t)item * key_stride;      // key_stride = n: a private key per message
 
     // greedy_sc
     for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
@@ -516,7 +520,7 @@ struct sc_hip_bliss {
     size_t cap;
     St st;
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
-    int32_t *tu, *tin, *v, *cidx;
+    int32_t *tu, *tin, *v, *cidx, *ain;
     int16_t *z;
     double tie_rel;              // accept / reject draws closer to the threshold than this (relative) are reported, not decided: status 5
 };
@@ -524,11 +528,11 @@ struct sc_hip_bliss {
 static void bl_free_ws(sc_hip_bliss *b)
 {
     void *ptrs[] = { b->st.pos, b->st.var_buf, b->st.iter, b->st.cur, b->st.status, b->st.var_bits, b->act[0], b->act[1], b->cnt, b->need, b->sbase, b->ok,
-                     b->trials, b->tu, b->tin, b->v, b->cidx, b->z };
+                     b->trials, b->tu, b->tin, b->v, b->cidx, b->z, b->ain };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     memset(&b->st, 0, sizeof b->st);
     b->act[0] = b->act[1] = b->cnt = b->need = b->sbase = b->ok = b->trials = nullptr;
-    b->tu = b->tin = b->v = b->cidx = nullptr; b->z = nullptr; b->cap = 0;
+    b->tu = b->tin = b->v = b->cidx = b->ain = nullptr; b->z = nullptr; b->cap = 0;
 }
 
 static int bl_ensure_ws(sc_hip_bliss *b, size_t batch)
@@ -539,7 +543,7 @@ static int bl_ensure_ws(sc_hip_bliss *b, size_t batch)
 #define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
     WS(b->st.pos, batch * 4); WS(b->st.var_buf, batch * 4); WS(b->st.iter, batch * 4); WS(b->st.cur, batch * 4); WS(b->st.status, batch * 4); WS(b->st.var_bits, batch * 4);
     WS(b->act[0], batch * 4); WS(b->act[1], batch * 4); WS(b->cnt, 64); WS(b->need, batch * 4); WS(b->sbase, batch * 4); WS(b->ok, batch * 4); WS(b->trials, batch * 4);
-    WS(b->tu, batch * 2 * n * 4); WS(b->tin, batch * n * 4); WS(b->v, batch * n * 4); WS(b->cidx, batch * (size_t)b->P.kappa * 4); WS(b->z, batch * n * 2);
+    WS(b->tu, batch * 2 * n * 4); WS(b->tin, batch * n * 4); WS(b->v, batch * n * 4); WS(b->cidx, batch * (size_t)b->P.kappa * 4); WS(b->z, batch * n * 2); WS(b->ain, batch * n * 4);
 #undef WS
     b->cap = batch;
     return SC_HIP_SUCCESS;
@@ -613,12 +617,35 @@ extern "C" size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *b)
     return ((size_t)b->P.n * (b->P.z1_bits + b->P.z2_bits) + (size_t)b->P.kappa * b->P.n_bits + 7) / 8;
 }
 
+// one key for the batch (kf / kg / ka16 null: the handle's), or a key per message: kf, kg, ka16 = SINT16 [batch][n] rows as sc_hip_bliss_keygen writes them
+static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
+                        const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+
 extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                  const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                                  uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
 {
     if (!b) return fail("bliss_sign: null handle");
     if (!b->have_key || !b->d_f) return fail("bliss_sign: no private key loaded");
+    return bl_sign_core(b, nullptr, nullptr, nullptr, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream);
+}
+
+// replaces: safecrypto_sign -> bliss_b_sign for a batch of messages EACH under its own key pair (distinct keys)
+extern "C" int sc_hip_bliss_sign_keys(sc_hip_bliss_t *b, size_t batch, const int16_t *d_f, const int16_t *d_g, const int16_t *d_a,
+                                      const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                      const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                      uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!b) return fail("bliss_sign_keys: null handle");
+    if (!d_f || !d_g || !d_a) return fail("bliss_sign_keys: null key buffer");
+    return bl_sign_core(b, d_f, d_g, d_a, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream);
+}
+
+static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
+                        const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 2048) return fail("bliss_sign: batch too large");
     if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("bliss_sign: null buffer");
@@ -649,9 +676,9 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
         hipLaunchKernelGGL(bl_sample_kernel, dim3((unsigned)sblocks), dim3(256), sizeof(uint64_t) * (size_t)b->cdt->size, s, active, nact, b->need, b->sbase, st.cur,
                            d_tapes, tape_stride, b->cdt->d_cdf, b->cdt->size, b->tu, n);
         const size_t ne = (size_t)nact * n;
-        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, b->tu, b->tin, n);
+        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, b->tu, b->tin, n, ka16, b->ain);
         HIPCHK(hipGetLastError());
-        if (sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+        if (ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
         hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, b->tu, b->v, b->z, P);
         // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
         if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
@@ -661,7 +688,8 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
             hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, d_msgs, msg_stride, d_mlens, fixed_len, b->z, b->cidx, b->ok,
                                0, (uint32_t *)nullptr, P);
         hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, d_tapes, tape_stride, d_tape_lens,
-                           b->d_f, b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P, b->tie_rel);
+                           kf ? kf : b->d_f, kg ? kg : b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P, b->tie_rel,
+                           kf ? (size_t)n : (size_t)0);
         HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));
@@ -675,11 +703,35 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
     return SC_HIP_SUCCESS;
 }
 
+static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                          const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 extern "C" int sc_hip_bliss_verify(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                    const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
 {
     if (!b) return fail("bliss_verify: null handle");
     if (!b->have_key) return fail("bliss_verify: no public key loaded");
+    return bl_verify_core(b, nullptr, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_verdicts, stream);
+}
+
+// replaces: safecrypto_verify -> bliss_b_verify for a batch of signatures EACH under its own public key (d_a: SINT16 [batch][n], NTT domain)
+extern "C" int sc_hip_bliss_verify_keys(sc_hip_bliss_t *b, size_t batch, const int16_t *d_a, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                        const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (!b) return fail("bliss_verify_keys: null handle");
+    if (!d_a) return fail("bliss_verify_keys: null key buffer");
+    return bl_verify_core(b, d_a, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_verdicts, stream);
+}
+
+__global__ void bl_widen_kernel(const int16_t *in, int32_t *out, size_t len)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) out[i] = (int32_t)in[i];
+}
+
+static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                          const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 2048) return fail("bliss_verify: batch too large");
     if (!d_msgs || !d_sigs || !d_siglens || !d_verdicts) return fail("bliss_verify: null buffer");
@@ -696,7 +748,11 @@ extern "C" int sc_hip_bliss_verify(sc_hip_bliss_t *b, size_t batch, const uint8_
     hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
     hipLaunchKernelGGL(bl_vnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, b->tin, b->z, B, d_verdicts, P);
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(b->plan, batch, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+    if (ka16) {
+        hipLaunchKernelGGL(bl_widen_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, ka16, b->ain, ne);
+        HIPCHK(hipGetLastError());
+        if (sc_hip_polymul_ntt(b->plan, batch, b->tin, b->ain, b->v, s)) return SC_HIP_FAILURE;
+    } else if (sc::polymul_ntt_bcast(b->plan, batch, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(bl_vparity_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, b->v, ne, P.q);
     hipLaunchKernelGGL(bl_vcidx_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b->v, b->cidx, B, P);
     hipLaunchKernelGGL(bl_vz_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, b->v, b->z, ne, P);

@@ -147,17 +147,31 @@ __global__ void ky_gprefix_kernel(const uint8_t *__restrict__ prefix, uint32_t f
 }
 
 // G and the two DRBG expansions, one lane per message: krd [batch][96] = K_bar | r | d ; noise [batch][noise_stride]
+// PK: a public key per message - the prefix rho | t (16 bits per coefficient) is absorbed from the message's own key (rho [batch][32],
+// t [batch][k*n] as sc_hip_kyber_keygen writes them) instead of resuming from the one key's saved state
+template <class SP>
+__device__ __forceinline__ void ky_absorb_key(SP &sp, const uint8_t *__restrict__ rho, const int32_t *__restrict__ t, int kn)
+{
+    const uint64_t *r = reinterpret_cast<const uint64_t *>(rho);
+    for (int w = 0; w < 4; w++) sp.absorb_u64(r[w]);
+    const int4 *pt = reinterpret_cast<const int4 *>(t);
+    for (int g = 0; g < kn / 4; g++) { const int4 c = pt[g]; sp.absorb_u64((uint64_t)(c.x & 0xFFFF) | ((uint64_t)(c.y & 0xFFFF) << 16) | ((uint64_t)(c.z & 0xFFFF) << 32) | ((uint64_t)(c.w & 0xFFFF) << 48)); }
+}
+
+template <bool PK>
 __global__ __launch_bounds__(KHT) void ky_g_kernel(uint32_t batch, const uint8_t *__restrict__ m, const uint64_t *__restrict__ gstate, const uint8_t *__restrict__ tail, uint32_t tail_len,
-                                                   uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C)
+                                                   uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C,
+                                                   const uint8_t *__restrict__ rho, const int32_t *__restrict__ tk, int kn)
 {
     __shared__ uint64_t st[25 * KHT];
     __shared__ AesLds L;
     L.fill(C);
     __syncthreads();
     const uint32_t i = blockIdx.x * KHT + threadIdx.x;
-    Sponge<KHT> sp; sp.load(st, threadIdx.x, 72, gstate);
+    Sponge<KHT> sp;
+    if (PK) sp.init(st, threadIdx.x, 72); else sp.load(st, threadIdx.x, 72, gstate);
     if (i >= batch) return;
-    sp.absorb(tail, tail_len);
+    if (PK) ky_absorb_key(sp, rho + (size_t)i * 32, tk + (size_t)i * kn, kn); else sp.absorb(tail, tail_len);
     sp.absorb(m + (size_t)i * 32, 32);
     sp.finalize(0x06);
     uint8_t md[32];
@@ -202,8 +216,10 @@ __global__ __launch_bounds__(KHT) void ky_h_kernel(uint32_t batch, const uint8_t
 // The same two kernels with two lanes per message (Sponge2, keccak_dev.h; the CTR-mode generator's blocks alternate between the
 // lanes).  Used while the one-lane kernels have no more wavefronts than the chip has SIMDs: both are serial chains (H: 30
 // permutations; G: 2 permutations + 118 AES-256 blocks through LDS tables) and run at the latency of one wavefront.
+template <bool PK>
 __global__ __launch_bounds__(KHT) void ky_g2_kernel(uint32_t batch, const uint8_t *__restrict__ m, const uint64_t *__restrict__ gstate, const uint8_t *__restrict__ tail, uint32_t tail_len,
-                                                    uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C)
+                                                    uint8_t *__restrict__ krd, uint8_t *__restrict__ noise, size_t noise_stride, uint32_t noise_blocks, DrbgConst C,
+                                                    const uint8_t *__restrict__ rho, const int32_t *__restrict__ tk, int kn)
 {
     __shared__ uint32_t st[25 * KHT];
     __shared__ AesLds L;
@@ -211,9 +227,10 @@ __global__ __launch_bounds__(KHT) void ky_g2_kernel(uint32_t batch, const uint8_
     __syncthreads();
     const uint32_t i = (blockIdx.x * KHT + threadIdx.x) >> 1;
     const uint32_t hh = threadIdx.x & 1;
-    Sponge2<KHT> sp; sp.load(st, threadIdx.x, 72, gstate);
+    Sponge2<KHT> sp;
+    if (PK) sp.init(st, threadIdx.x, 72); else sp.load(st, threadIdx.x, 72, gstate);
     if (i >= batch) return;
-    sp.absorb(tail, tail_len);
+    if (PK) ky_absorb_key(sp, rho + (size_t)i * 32, tk + (size_t)i * kn, kn); else sp.absorb(tail, tail_len);
     sp.absorb(m + (size_t)i * 32, 32);
     sp.finalize(0x06);
     uint8_t md[32];
@@ -324,7 +341,13 @@ struct sc_hip_kyber {
     uint64_t *d_gstate; uint8_t *d_gtail; uint32_t gtail_len;      // G's per-key prefix: sponge state after its whole blocks + the rest
     size_t kem_cap;
     uint8_t *krd, *noise, *mbuf; int32_t *ku, *kv;
+    // a key per message: the matrices / t / s of the batch in the kernels' internal Montgomery form (staged per call)
+    size_t keys_cap; bool keys_priv;
+    int32_t *pk_gen; uint32_t *pk_A, *pk_t, *pk_s;
 };
+
+// the key operands of one CPA call: the handle's one key (strides 0) or a key per message
+struct KyKeys { const uint32_t *A, *t, *s; size_t sA, st; };
 
 static int ky_ensure(sc_hip_kyber *h, size_t batch)
 {
@@ -359,7 +382,7 @@ extern "C" int sc_hip_kyber_create(sc_hip_ctx_t *ctx, const sc_hip_kyber_params_
 extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
 {
     if (!h) return;
-    void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv };
+    void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv, h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(h->plan);
     delete h;
@@ -401,11 +424,20 @@ extern "C" int sc_hip_kyber_set_privkey(sc_hip_kyber_t *h, const int32_t *s_ntt)
 
 extern "C" size_t sc_hip_kyber_noise_bytes(const sc_hip_kyber_t *h) { return h ? (size_t)(2 * h->P.k + 1) * N * h->P.eta / 4 : 0; }
 
+static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const uint8_t *d_m, const uint8_t *d_noise, size_t noise_stride, int32_t *d_u, int32_t *d_v, void *stream);
+static int ky_cpa_dec_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const int32_t *d_u, const int32_t *d_v, uint8_t *d_m, void *stream);
+
 extern "C" int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, const uint8_t *d_noise, size_t noise_stride,
                                     int32_t *d_u, int32_t *d_v, void *stream)
 {
     if (!h) return fail("kyber_cpa_enc: null handle");
     if (!h->have_pub) return fail("kyber_cpa_enc: no public key loaded");
+    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0 };
+    return ky_cpa_enc_core(h, K, batch, d_m, d_noise, noise_stride, d_u, d_v, stream);
+}
+
+static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const uint8_t *d_m, const uint8_t *d_noise, size_t noise_stride, int32_t *d_u, int32_t *d_v, void *stream)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 4096) return fail("kyber_cpa_enc: batch too large");
     if (!d_m || !d_noise || !d_u || !d_v) return fail("kyber_cpa_enc: null device pointer");
@@ -422,9 +454,9 @@ extern "C" int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8
     DilNtt a = mlwe_base_args(h->plan, k, k, 1 << 20);
     a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
     if (mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = h->d_A; a.w = h->u0; a.w1 = nullptr;
+    a.key = K.A; a.key_item_stride = K.sA; a.w = h->u0; a.w1 = nullptr;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = h->d_t; a.w = h->v0; a.kk = 1;
+    a.key = K.t; a.key_item_stride = K.st; a.w = h->v0; a.kk = 1;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     const size_t ne = batch * (size_t)(k + 1) * N;
     hipLaunchKernelGGL(ky_enc_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, h->u0, h->v0, h->e1, h->e2, d_m, B, d_u, d_v, P);
@@ -439,6 +471,12 @@ extern "C" int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32
 {
     if (!h) return fail("kyber_cpa_dec: null handle");
     if (!h->have_priv) return fail("kyber_cpa_dec: no private key loaded");
+    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0 };
+    return ky_cpa_dec_core(h, K, batch, d_u, d_v, d_m, stream);
+}
+
+static int ky_cpa_dec_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const int32_t *d_u, const int32_t *d_v, uint8_t *d_m, void *stream)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 4096) return fail("kyber_cpa_dec: batch too large");
     if (!d_m || !d_u || !d_v) return fail("kyber_cpa_dec: null device pointer");
@@ -454,7 +492,7 @@ extern "C" int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32
     DilNtt a = mlwe_base_args(h->plan, 1, k, 1 << 20);
     a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
     if (mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = h->d_s; a.w = h->v0; a.w1 = nullptr;
+    a.key = K.s; a.key_item_stride = K.st; a.w = h->v0; a.w1 = nullptr;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ky_dec_finish_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, s, d_v, h->v0, d_m, B, P);
     HIPCHK(hipGetLastError());
@@ -529,24 +567,38 @@ static int ky_kem_check(sc_hip_kyber *h, size_t batch, const char *who)
 static bool ky_two_lanes(const sc_hip_kyber *h, size_t batch) { return batch <= (size_t)h->ctx->cus * 4 * 64; }
 
 // G -> (K_bar, r, d), noise; CPA encryption of m under r; into h->ku, h->kv
-static int ky_kem_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, hipStream_t s)
+// (rho, tk non-null: a public key per message, K its staged operands)
+static int ky_kem_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, hipStream_t s, const KyKeys *K = nullptr, const uint8_t *rho = nullptr, const int32_t *tk = nullptr)
 {
     const uint32_t B = (uint32_t)batch;
     const size_t ns = ky_noise_stride(h);
-    if (ky_two_lanes(h, batch))
-        hipLaunchKernelGGL(ky_g2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
-                           (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
-    else
-        hipLaunchKernelGGL(ky_g_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns,
-                           (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16), sc::drbg_const());
+    const uint32_t nblk = (uint32_t)(sc_hip_kyber_noise_bytes(h) / 16);
+    const int kn = h->P.k * N;
+    const dim3 g2((2 * B + KHT - 1) / KHT), g1((B + KHT - 1) / KHT);
+    if (rho) {
+        if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_g2_kernel<true>, g2, dim3(KHT), 0, s, B, d_m, nullptr, nullptr, 0u, h->krd, h->noise, ns, nblk, sc::drbg_const(), rho, tk, kn);
+        else hipLaunchKernelGGL(ky_g_kernel<true>, g1, dim3(KHT), 0, s, B, d_m, nullptr, nullptr, 0u, h->krd, h->noise, ns, nblk, sc::drbg_const(), rho, tk, kn);
+    } else {
+        if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_g2_kernel<false>, g2, dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns, nblk, sc::drbg_const(), nullptr, nullptr, kn);
+        else hipLaunchKernelGGL(ky_g_kernel<false>, g1, dim3(KHT), 0, s, B, d_m, h->d_gstate, h->d_gtail, h->gtail_len, h->krd, h->noise, ns, nblk, sc::drbg_const(), nullptr, nullptr, kn);
+    }
     HIPCHK(hipGetLastError());
+    if (K) return ky_cpa_enc_core(h, *K, batch, d_m, h->noise, ns, h->ku, h->kv, s);
     return sc_hip_kyber_cpa_enc(h, batch, d_m, h->noise, ns, h->ku, h->kv, s);
 }
 
 // replaces: kyber_kem_encapsulation (kyber_kem.c:855-928); d_m [batch][32] = the bytes prng_mem(sc->prng_ctx[0], m, 32) returns
+static int ky_encaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream, const KyKeys *K, const uint8_t *rho, const int32_t *tk);
+static int ky_decaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream, const KyKeys *K, const uint8_t *rho, const int32_t *tk);
+
 extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream)
 {
     if (ky_kem_check(h, batch, "kyber_kem_encaps")) return SC_HIP_FAILURE;
+    return ky_encaps_core(h, batch, d_m, d_ct, ct_stride, d_keys, stream, nullptr, nullptr, nullptr);
+}
+
+static int ky_encaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream, const KyKeys *K, const uint8_t *rho, const int32_t *tk)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_m || !d_ct || !d_keys) return fail("kyber_kem_encaps: null buffer");
     if (ct_stride < sc_hip_kyber_ct_bytes(h)) return fail("kyber_kem_encaps: ct_stride smaller than sc_hip_kyber_ct_bytes()");
@@ -555,7 +607,7 @@ extern "C" int sc_hip_kyber_kem_encaps(sc_hip_kyber_t *h, size_t batch, const ui
     if (ky_kem_ensure(h, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t B = (uint32_t)batch;
-    if (ky_kem_core(h, batch, d_m, s)) return SC_HIP_FAILURE;
+    if (ky_kem_core(h, batch, d_m, s, K, rho, tk)) return SC_HIP_FAILURE;
     if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
     else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
     const size_t nb = batch * (size_t)((h->P.k + 1) * N / 8 + 32);
@@ -570,6 +622,11 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
 {
     if (ky_kem_check(h, batch, "kyber_kem_decaps")) return SC_HIP_FAILURE;
     if (!h->have_priv) return fail("kyber_kem_decaps: no private key loaded");
+    return ky_decaps_core(h, batch, d_ct, ct_stride, d_keys, stream, nullptr, nullptr, nullptr);
+}
+
+static int ky_decaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream, const KyKeys *K, const uint8_t *rho, const int32_t *tk)
+{
     if (batch == 0) return SC_HIP_SUCCESS;
     if (!d_ct || !d_keys) return fail("kyber_kem_decaps: null buffer");
     if (ct_stride < sc_hip_kyber_ct_bytes(h)) return fail("kyber_kem_decaps: ct_stride smaller than sc_hip_kyber_ct_bytes()");
@@ -580,14 +637,81 @@ extern "C" int sc_hip_kyber_kem_decaps(sc_hip_kyber_t *h, size_t batch, const ui
     const size_t ne = batch * (size_t)((h->P.k + 1) * N / 8);
     hipLaunchKernelGGL(ky_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, h->ku, h->kv, h->P);
     HIPCHK(hipGetLastError());
-    if (sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
-    if (ky_kem_core(h, batch, h->mbuf, s)) return SC_HIP_FAILURE;
+    if (K ? ky_cpa_dec_core(h, *K, batch, h->ku, h->kv, h->mbuf, s) : sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
+    if (ky_kem_core(h, batch, h->mbuf, s, K, rho, tk)) return SC_HIP_FAILURE;
     const size_t body = sc_hip_kyber_ct_bytes(h) - 32;
     if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, d_ct + body, ct_stride, d_keys, h->P);
     HIPCHK(hipGetLastError());
     ky_kem_wipe(h, batch, s);
     return SC_HIP_SUCCESS;
+}
+
+
+// ---- a key per message ------------------------------------------------------------------------------------------------------
+
+// stage the batch's keys: every matrix from its rho (transposed for encryption, module_lwe.c:700-720), NTT(t) and NTT(s) into the
+// kernels' internal Montgomery form
+static int ky_stage_keys(sc_hip_kyber *h, size_t batch, const int32_t *d_t_ntt, const uint8_t *d_rho, const int32_t *d_s_ntt, hipStream_t s, KyKeys *K)
+{
+    const KyP &P = h->P;
+    const int k = P.k;
+    const size_t kk = (size_t)k * k, kn = (size_t)k * N;
+    if (batch > h->keys_cap || (d_s_ntt && !h->keys_priv)) {
+        void *old[] = { h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
+        for (void *p : old) if (p) (void)sc::wipe_free(p);
+        h->pk_gen = nullptr; h->pk_A = h->pk_t = h->pk_s = nullptr; h->keys_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->pk_gen, batch * kk * N * 4)); HIPCHK(hipMalloc((void **)&h->pk_A, batch * kk * N * 4));
+        HIPCHK(hipMalloc((void **)&h->pk_t, batch * kn * 4));
+        if (d_s_ntt) HIPCHK(hipMalloc((void **)&h->pk_s, batch * kn * 4));
+        h->keys_cap = batch; h->keys_priv = d_s_ntt != nullptr;
+    }
+    if (sc_hip_mlwe_expand_matrix(h->ctx, batch, d_rho, 32, 32, k * k, P.q, P.q_bits, h->pk_gen, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kk * N + 255) / 256)), dim3(256), 0, s, h->pk_gen, h->pk_A, batch * kk, h->plan->k[1], h->plan->r2, h->plan->r2p, k, k);
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t_ntt, h->pk_t, batch * (size_t)k, h->plan->k[1], h->plan->r2, h->plan->r2p, 0, 0);
+    if (d_s_ntt)
+        hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_s_ntt, h->pk_s, batch * (size_t)k, h->plan->k[1], h->plan->r2, h->plan->r2p, 0, 0);
+    HIPCHK(hipGetLastError());
+    K->A = h->pk_A; K->t = h->pk_t; K->s = h->pk_s; K->sA = kk * N; K->st = kn;
+    return SC_HIP_SUCCESS;
+}
+
+static int ky_keys_check(sc_hip_kyber *h, size_t batch, const char *who)
+{
+    if (!h) return fail(std::string(who) + ": null handle");
+    if (((h->P.k * N * h->P.d_u + N * h->P.d_v) & 7) != 0) return fail(std::string(who) + ": ciphertext body is not a whole number of bytes");
+    if (batch > 0x7fffffffu / 4096 / (size_t)h->P.k) return fail(std::string(who) + ": batch too large");
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_encapsulation -> kyber_kem_encapsulation (kyber_kem.c:855-928) for `batch` values EACH under its own public
+// key, in the layouts sc_hip_kyber_keygen writes: d_t, d_t_ntt int32 [batch][k][n], d_rho [batch][32]
+extern "C" int sc_hip_kyber_kem_encaps_keys(sc_hip_kyber_t *h, size_t batch, const int32_t *d_t, const int32_t *d_t_ntt, const uint8_t *d_rho,
+                                            const uint8_t *d_m, uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream)
+{
+    if (ky_keys_check(h, batch, "kyber_kem_encaps_keys")) return SC_HIP_FAILURE;
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_t || !d_t_ntt || !d_rho) return fail("kyber_kem_encaps_keys: null key buffer");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    KyKeys K;
+    if (ky_stage_keys(h, batch, d_t_ntt, d_rho, nullptr, (hipStream_t)stream, &K)) return SC_HIP_FAILURE;
+    return ky_encaps_core(h, batch, d_m, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);
+}
+
+// replaces: safecrypto_decapsulation -> kyber_kem_decapsulation (kyber_kem.c:930-1040) for `batch` ciphertexts EACH under its own
+// key pair (d_s_ntt int32 [batch][k][n] besides the public parts)
+extern "C" int sc_hip_kyber_kem_decaps_keys(sc_hip_kyber_t *h, size_t batch, const int32_t *d_s_ntt, const int32_t *d_t, const int32_t *d_t_ntt, const uint8_t *d_rho,
+                                            const uint8_t *d_ct, size_t ct_stride, uint8_t *d_keys, void *stream)
+{
+    if (ky_keys_check(h, batch, "kyber_kem_decaps_keys")) return SC_HIP_FAILURE;
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_s_ntt || !d_t || !d_t_ntt || !d_rho) return fail("kyber_kem_decaps_keys: null key buffer");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    KyKeys K;
+    if (ky_stage_keys(h, batch, d_t_ntt, d_rho, d_s_ntt, (hipStream_t)stream, &K)) return SC_HIP_FAILURE;
+    const int rc = ky_decaps_core(h, batch, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);
+    (void)hipMemsetAsync(h->pk_s, 0, batch * (size_t)h->P.k * N * 4, (hipStream_t)stream);       // the staged secret keys do not outlive the call
+    return rc;
 }
 
 

@@ -311,13 +311,13 @@ static __global__ void dil_to_internal_shoup(const int32_t *in, uint32_t *out, u
 }
 
 // natural-order NTT-domain array -> internal order, Montgomery form (for the expanded matrix A)
-// rows/cols != 0: the input is [cols][rows][n] and is transposed on the way (out is always [rows][cols][n])
+// rows/cols != 0: the input is a sequence of [cols][rows][n] matrices, each transposed on the way (out: [rows][cols][n] each)
 static __global__ void dil_to_internal_mont(const int32_t *in, uint32_t *out, size_t npoly, ModK k, uint32_t r2, uint32_t r2p, int rows = 0, int cols = 0)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npoly * N) return;
     size_t p = i / N; const uint32_t j = (uint32_t)(i % N);
-    if (rows) p = (p % (size_t)cols) * (size_t)rows + p / (size_t)cols;
+    if (rows) { const size_t rc = (size_t)rows * cols, q = p % rc; p = p - q + (q % (size_t)cols) * (size_t)rows + q / (size_t)cols; }   // per matrix
     const uint32_t nat = __builtin_bitreverse32(j) >> 24;
     uint32_t v = reduce_i32(in[p * N + nat], k);
     out[i] = csub(Mod<MODE_U32>::mulc(v, r2, r2p, k), k.q);

@@ -21,8 +21,8 @@ SYMBOLS = [
     'sc_hip_dilithium_sig_max', 'sc_hip_dilithium_sign', 'sc_hip_dilithium_verify', 'sc_hip_dilithium_verify_keys', 'sc_hip_dilithium_sign_keys', 'sc_hip_dilithium_sign_host',
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
-    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin',
+    'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -148,6 +148,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_set_tie_margin.argtypes = [vp, C.c_double]
+    L.sc_hip_bliss_sign_keys.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_bliss_verify_keys.argtypes = [vp, sz, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_keygen.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_ntt_pwr.argtypes = [vp, sz, vp, i32, vp, vp]
     L.sc_hip_ntt_flip.argtypes = [vp, sz, vp, vp, vp]
@@ -166,6 +168,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_kyber_ct_bytes.restype = sz
     L.sc_hip_kyber_kem_encaps.argtypes = [vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_kyber_kem_decaps.argtypes = [vp, sz, vp, sz, vp, vp]
+    L.sc_hip_kyber_kem_encaps_keys.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, vp, vp]
+    L.sc_hip_kyber_kem_decaps_keys.argtypes = [vp, sz, vp, vp, vp, vp, vp, sz, vp, vp]
     L.sc_hip_dilithium_keygen.argtypes = [vp, sz, C.c_int, vp, sz, sz, vp, vp, vp, vp, vp, vp, vp, vp]
     L.sc_hip_kyber_keygen.argtypes = [vp, sz, vp, sz, sz, vp, vp, vp, vp, vp, vp]
     L.sc_hip_tesla_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -885,6 +889,32 @@ class Bliss:
                                                 _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify')
         return verdicts
 
+    def sign_keys(self, f, g, a, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        """a key pair per message: f, g, a int16 [batch][n] device tensors (what keygen() returns)"""
+        import torch
+        batch = msgs.shape[0]
+        dev = msgs.device
+        for k in (f, g, a):
+            assert k.dtype == torch.int16 and k.is_contiguous() and tuple(k.shape) == (batch, int(self.par[0]))
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        trials = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_bliss_sign_keys(self.h, batch, _ptr(f), _ptr(g), _ptr(a), _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                   _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
+                                                   _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'bliss_sign_keys')
+        return sigs, siglens, trials, status
+
+    def verify_keys(self, a, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        assert a.dtype == torch.int16 and a.is_contiguous() and tuple(a.shape) == (batch, int(self.par[0]))
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_bliss_verify_keys(self.h, batch, _ptr(a), _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                     _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'bliss_verify_keys')
+        return verdicts
+
     def keygen(self, nz, tapes, tape_lens=None):
         """batched bliss_b_keygen: tapes [batch][words] (device) -> f, g, a int16 [batch][n], attempts, status"""
         import torch
@@ -1332,6 +1362,32 @@ class Kyber:
         batch = ct.shape[0]
         keys = torch.empty((batch, 32), dtype=torch.uint8, device=ct.device)
         _chk(self.L, self.L.sc_hip_kyber_kem_decaps(self.h, batch, _ptr(ct), _rows(ct), _ptr(keys), _stream()), 'kyber_kem_decaps')
+        return keys
+
+    def _key_rows(self, batch, *polys):
+        import torch
+        for x in polys:
+            assert x.dtype == torch.int32 and x.is_contiguous() and tuple(x.shape) == (batch, self.k, self.n)
+
+    def encaps_keys(self, t, t_ntt, rho, m):
+        """a public key per value: t, t_ntt int32 [batch][k][n], rho uint8 [batch][32] (what keygen() returns), m uint8 [batch][32]"""
+        import torch
+        batch = m.shape[0]
+        self._key_rows(batch, t, t_ntt)
+        assert rho.dtype == torch.uint8 and rho.is_contiguous() and tuple(rho.shape) == (batch, 32)
+        ctb = self.L.sc_hip_kyber_ct_bytes(self.h)
+        ct = torch.empty((batch, ctb), dtype=torch.uint8, device=m.device)
+        keys = torch.empty((batch, 32), dtype=torch.uint8, device=m.device)
+        _chk(self.L, self.L.sc_hip_kyber_kem_encaps_keys(self.h, batch, _ptr(t), _ptr(t_ntt), _ptr(rho), _ptr(m), _ptr(ct), ctb, _ptr(keys), _stream()), 'kyber_kem_encaps_keys')
+        return ct, keys
+
+    def decaps_keys(self, s_ntt, t, t_ntt, rho, ct):
+        import torch
+        batch = ct.shape[0]
+        self._key_rows(batch, s_ntt, t, t_ntt)
+        assert rho.dtype == torch.uint8 and rho.is_contiguous() and tuple(rho.shape) == (batch, 32)
+        keys = torch.empty((batch, 32), dtype=torch.uint8, device=ct.device)
+        _chk(self.L, self.L.sc_hip_kyber_kem_decaps_keys(self.h, batch, _ptr(s_ntt), _ptr(t), _ptr(t_ntt), _ptr(rho), _ptr(ct), _rows(ct), _ptr(keys), _stream()), 'kyber_kem_decaps_keys')
         return keys
 
     def enc(self, m, noise):

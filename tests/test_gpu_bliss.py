@@ -239,3 +239,50 @@ def test_rejection_near_tie_is_reported_not_decided(eng, G):
     with pytest.raises(Exception):
         b.set_tie_margin(2.0)
     b.close()
+
+
+def test_distinct_keys_per_message(eng, G):
+    """SURVEY 8(d) distinct keys: 256 key pairs from the batched keygen, one message under each.  Every signature equals the
+    oracle's under THAT key; the one-key entry point gives the same bytes for the rows that share its key; a signature does not
+    verify under its neighbour's key"""
+    import torch
+    par, nz = G['bliss1_params'], G['bliss1_kg_nz']
+    b = eng.bliss(par)
+    B, W = 256, 3 * 2048 + 64
+    rng = np.random.default_rng(2024)
+    kt = rng.integers(0, 2**32, size=(B, 2048), dtype=np.uint64).astype(np.uint32)
+    f, g, a, att, st = b.keygen(nz, torch.from_numpy(kt.view(np.int32)).cuda())
+    assert int((st == 1).sum()) == B
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8)) for _ in range(B)]
+    tapes = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+    tapes[9] = tapes[9][:1500]
+    m_d, ml_d, t_d, tl_d = pack(msgs, tapes, W)
+    sigs, siglens, trials, status = b.sign_keys(f, g, a, m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+    torch.cuda.synchronize()
+    fh, gh, ah = f.cpu().numpy(), g.cpu().numpy(), a.cpu().numpy()
+    sh, lh, sth, tr = sigs.cpu().numpy(), siglens.cpu().numpy(), status.cpu().numpy(), trials.cpu().numpy()
+    assert sth[9] == 2
+    multi = 0
+    for i in range(B):
+        if i == 9:
+            continue
+        key = O.BlissKey(par, fh[i], gh[i], ah[i])
+        rc, es, et, _ = O.bliss_sign(key, msgs[i], tapes[i])
+        assert (rc == 0) == (sth[i] == 1), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == es and tr[i] == et, i
+            multi += et >= 2
+            if i % 16 == 0:
+                assert O.bliss_verify(key, msgs[i], es) == 0
+    assert multi > 20
+    ok = status == 1
+    v = b.verify_keys(a, m_d, sigs, siglens, mlens=ml_d)
+    assert int(v[ok].sum()) == 0 and int((v[~ok] == 0).sum()) == 0
+    # a neighbour's public key rejects
+    v2 = b.verify_keys(torch.roll(a, 1, 0).contiguous(), m_d, sigs, siglens, mlens=ml_d)
+    assert int((v2 == 0).sum()) == 0
+    # the one-key entry point under key 3 reproduces row 3
+    b.set_key(fh[3], gh[3], ah[3])
+    s1, l1, _, st1 = b.sign(m_d[3:4], t_d[3:4], mlens=ml_d[3:4], tape_lens=tl_d[3:4])
+    assert int(st1[0]) == 1 and bytes(s1[0, :int(l1[0])].cpu().numpy()) == bytes(sh[3, :lh[3]])
+    b.close()

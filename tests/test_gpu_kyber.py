@@ -135,3 +135,38 @@ def test_keygen_vs_reference(eng, tag):
     ct, keys = ky.encaps(m)
     assert torch.equal(ky.decaps(ct), keys)
     ky.close()
+
+
+@pytest.mark.parametrize('tag', ['kyber1', 'kyber2'])
+def test_kem_distinct_keys_per_value(eng, tag):
+    """SURVEY 8(d) distinct keys: 200 key pairs from the batched keygen, one encapsulation under each.  Ciphertext and shared key
+    equal the oracle's under THAT key (its matrix expanded from its own rho); decapsulation under the matching private keys returns
+    the keys, under shifted private keys it does not; the one-key entry points agree on a row"""
+    import torch
+    G = load_golden('kyber_ref.txt')
+    par = G[f'{tag}_params']
+    k, q, qb = int(par[5]), int(par[1]), int(par[2])
+    ky = eng.kyber(par)
+    rng = np.random.default_rng(41)
+    B = 200
+    seeds = torch.from_numpy(rng.integers(0, 256, size=(B, 32), dtype=np.uint8)).cuda()
+    s_ntt, t, t_ntt, rho, z = ky.keygen(seeds)
+    m = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    ct, keys = ky.encaps_keys(t, t_ntt, rho, torch.from_numpy(m).cuda())
+    dk = ky.decaps_keys(s_ntt, t, t_ntt, rho, ct)
+    assert torch.equal(dk, keys)
+    sh, th, tnh, rh, cth, kh = (x.cpu().numpy() for x in (s_ntt, t, t_ntt, rho, ct, keys))
+    for i in (0, 1, 63, 64, 127, 199):
+        A = O.expand_matrix(rh[i], k * k, q, qb)
+        oc, ok = O.kyber_kem_enc(par, th[i].reshape(-1), tnh[i].reshape(-1), rh[i], A, m[i])
+        assert cth[i].tobytes() == oc and kh[i].tobytes() == ok, i
+        assert O.kyber_kem_dec(par, sh[i].reshape(-1), th[i].reshape(-1), tnh[i].reshape(-1), rh[i], A, oc) == ok
+    wrong = ky.decaps_keys(torch.roll(s_ntt, 1, 0).contiguous(), t, t_ntt, rho, ct)
+    assert int((wrong == keys).all(dim=1).sum()) == 0
+    # the one-key path under key 5 gives row 5
+    A5 = O.expand_matrix(rh[5], k * k, q, qb)
+    ky.set_pubkey(tnh[5].reshape(-1), A5); ky.set_privkey(sh[5].reshape(-1)); ky.set_kem_pubkey(th[5].reshape(-1), rh[5])
+    c1, k1 = ky.encaps(torch.from_numpy(m[5:6]).cuda())
+    assert torch.equal(c1[0], ct[5]) and torch.equal(k1[0], keys[5])
+    assert torch.equal(ky.decaps(ct[5:6].contiguous())[0], keys[5])
+    ky.close()
