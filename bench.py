@@ -285,6 +285,18 @@ def bliss_extra(eng, torch, cpu_seconds):
                    f'{min(cpu_seconds, 3.0):.0f} s of safecrypto_sign + safecrypto_verify, set 1 (64-bit CDT), 64-byte messages, one key, 1 thread')
     if ref:
         out['cpu_reference'] = ref
+    # SURVEY 8(d) distinct keys: a key pair per message (3 KB of key material per signature instead of one cache-resident key)
+    kt = torch.randint(-2**31, 2**31 - 1, (B, 2048), dtype=torch.int32, device='cuda', generator=g)
+    f, gk, a, _, kst = b.keygen(G['bliss1_kg_nz'], kt)
+    if int((kst == 1).sum()) == B:
+        b.sign_keys(f, gk, a, msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+        tk, tkv = [], []
+        for _ in range(5):
+            t0 = time.perf_counter(); s2, l2, _, st2 = b.sign_keys(f, gk, a, msgs, tapes, fixed_len=64); torch.cuda.synchronize(); tk.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); v2 = b.verify_keys(a, msgs, s2, l2, fixed_len=64); torch.cuda.synchronize(); tkv.append(time.perf_counter() - t0)
+        assert int(v2[st2 == 1].sum()) == 0
+        out['distinct_keys'] = {'workload': 'the same batch with a key pair per message (keys from the batched keygen, resident in HBM)',
+                                'sign_ops_per_s': B / min(tk), 'verify_ops_per_s': B / min(tkv), 'key_bytes_per_signature': 3 * 512 * 2}
     b.close()
     return {'bliss_b_1': out}
 
@@ -322,6 +334,18 @@ def kyber_tesla_more_extra(eng, torch, cpu_on):
                    '3 s of safecrypto_encapsulation + 1.5 s of safecrypto_decapsulation, set 1, one key, 1 thread')
     if ref:
         kem['cpu_reference'] = ref
+    # SURVEY 8(d) distinct keys: a key pair per value, generated by the batched keygen (matrix expansion from each rho is part of the timed call)
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+    s_ntt, tk, t_ntt, rho, _ = ky.keygen(seeds)
+    ctk, kk = ky.encaps_keys(tk, t_ntt, rho, m); torch.cuda.synchronize()
+    te, td = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); ctk, kk = ky.encaps_keys(tk, t_ntt, rho, m); torch.cuda.synchronize(); te.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); k3 = ky.decaps_keys(s_ntt, tk, t_ntt, rho, ctk); torch.cuda.synchronize(); td.append(time.perf_counter() - t0)
+    assert torch.equal(k3, kk)
+    kem['distinct_keys'] = {'workload': 'the same batch with a key pair per value (keys from the batched keygen, resident in HBM; each matrix expanded from its rho inside the call)',
+                            'encaps_ops_per_s': B / min(te), 'decaps_ops_per_s': B / min(td), 'key_bytes_per_value': 2 * 3 * 256 * 4 + 32}
+    del s_ntt, tk, t_ntt, rho, ctk, kk, k3
     out['kyber_1_kem'] = kem
     ky.close()
     # ring-TESLA set 0 (n=512, q=8399873)

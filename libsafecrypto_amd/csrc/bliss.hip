@@ -75,26 +75,38 @@ __global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, con
     need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + 4u * (uint32_t)n;
 }
 
-// get_vector_32(t), get_vector_32(u): sample s of the attempt uses tape words 2s (high) and 2s+1 (low)
+// get_vector_32(t), get_vector_32(u): sample s of the attempt uses tape words 2s (high) and 2s+1 (low).  A lane draws two adjacent samples
+// (one 16-byte tape read, one 8-byte store); the table search is the guide + S probes of cdt_guide.h (S = 0: the halving search).
+template <int S>
 __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *cur,
-                                                        const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, int size, int32_t *tu, int n)
+                                                        const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, const uint16_t *gd, CdtGuide g, int size, int32_t *tu, int n)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
-    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
+    for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
+    if (S) for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
     __syncthreads();
-    const size_t total = (size_t)nact * 2 * n, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t total = (size_t)nact * n, stride = (size_t)gridDim.x * blockDim.x;              // pairs of samples
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const uint32_t aidx = (uint32_t)(t / (2 * (size_t)n)); const int sidx = (int)(t % (2 * (size_t)n));
+        const uint32_t aidx = (uint32_t)(t / (size_t)n); const int sidx = 2 * (int)(t % (size_t)n);
         if (need[aidx] != 1) continue;
         const uint32_t item = active ? active[aidx] : aidx;
         const uint32_t *tp = tapes + (size_t)item * tape_stride + sbase[aidx] + 2 * sidx;
-        const uint64_t u = ((uint64_t)tp[0] << 32) | tp[1];
-        uint32_t a = 0;
-        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
-        const int32_t v = (u & 1) ? (int32_t)a : -(int32_t)a;
+        uint32_t w[4];
+        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
+        else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
+        int32_t v[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const uint64_t u = ((uint64_t)w[2 * e] << 32) | w[2 * e + 1];
+            uint32_t a = 0;
+            if (S) a = cdt_lookup<(S > 3 ? 0 : S)>(u, tab, guide, g);
+            else for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
+            v[e] = (u & 1) ? (int32_t)a : -(int32_t)a;
+        }
         const uint32_t c = cur[item];
         const int which = sidx < n ? (int)c : (int)(c ^ 1);
-        tu[((size_t)item * 2 + which) * n + (sidx % n)] = v;
+        *reinterpret_cast<int2 *>(tu + ((size_t)item * 2 + which) * n + (sidx % n)) = make_int2(v[0], v[1]);
     }
 }
 
@@ -672,9 +684,13 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, d_tape_lens, (uint32_t)tape_stride, n, b->need, b->sbase, d_siglens, d_mlens);
         const size_t nsamp = (size_t)nact * 2 * n;
         size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
-        if (sblocks > (size_t)b->ctx->cus * 4) sblocks = (size_t)b->ctx->cus * 4;
-        hipLaunchKernelGGL(bl_sample_kernel, dim3((unsigned)sblocks), dim3(256), sizeof(uint64_t) * (size_t)b->cdt->size, s, active, nact, b->need, b->sbase, st.cur,
-                           d_tapes, tape_stride, b->cdt->d_cdf, b->cdt->size, b->tu, n);
+        const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
+        if (sblocks > (size_t)b->ctx->cus * (sper > 4 ? 4 : sper)) sblocks = (size_t)b->ctx->cus * (sper > 4 ? 4 : sper);
+        const CdtGuide &cg = b->cdt->g;
+#define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
+                           d_tapes, tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, b->tu, n)
+        switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#undef BL_SAMPLE
         const size_t ne = (size_t)nact * n;
         hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, b->tu, b->tin, n, ka16, b->ain);
         HIPCHK(hipGetLastError());

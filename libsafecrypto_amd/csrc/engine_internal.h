@@ -8,9 +8,12 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include "cdt_guide.h"
 
 namespace sc {
 int fail(const std::string &m);      // records the message for sc_hip_last_error, returns SC_HIP_FAILURE
+void cdt_build_guide(const std::vector<uint64_t> &cdf, CdtGuide *g, std::vector<uint16_t> *guide, std::vector<uint64_t> *probe_table);
+size_t cdt_lds_bytes(const sc_hip_cdt *c);      // table + padding + guide: the dynamic LDS of a kernel that samples from c
 }
 
 namespace sc {
@@ -115,6 +118,7 @@ struct sc_hip_cdt {
     float tail, sigma;
     int size;
     std::vector<uint64_t> cdf;
-    uint64_t *d_cdf;
-    uint16_t *d_guide;            // 257(+1) entries: max{b : cdf[b] < t*2^56}
+    uint64_t *d_cdf;              // size entries + CDT_PAD of 2^64 - 1 (g.S != 0: 2^64 - 1 also behind the first entry of the closing run, cdt_guide.h)
+    uint16_t *d_guide;            // g.total bins (cdt_guide.h); g.S = 0: no usable guide, the kernels fall back to the halving search
+    CdtGuide g;
 };

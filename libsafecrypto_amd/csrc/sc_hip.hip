@@ -10,6 +10,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include "cdt_guide.h"
 
 using namespace sc;
 
@@ -209,39 +210,50 @@ __global__ __launch_bounds__(256) void ew_kernel(const int32_t *__restrict__ a, 
 }
 
 // CDT sampler.  The reference's halving search (gaussian_cdf.c:536-553) returns, for a monotone table, the largest index b
-// with cdf[b] < x (0 if there is none); the sign is the LSB of the same word (:658).  The same value is found faster through
-// a 257-entry guide table on the top byte of x: guide[t] = max{b : cdf[b] < t*2^56}, so the answer lies in
-// [guide[t], guide[t+1]] - one or two probes for a Gaussian table instead of log2(size).  Table (<= 32 KB) and guide in LDS,
-// two samples per lane per iteration (16-byte loads, 8-byte stores).
-__device__ __forceinline__ int32_t cdt_one(uint64_t u, const uint64_t *tab, const uint16_t *guide, int32_t centre)
+// with cdf[b] < x (0 if there is none); the sign is the LSB of the same word (:658).  The same value comes from one guide read
+// and S independent table reads (cdt_guide.h); table and guide in LDS, four samples per lane per iteration (16-byte loads and stores).
+template <int S>
+__device__ __forceinline__ int32_t cdt_one(uint64_t u, const uint64_t *tab, const uint16_t *guide, const CdtGuide &g, int32_t centre)
 {
-    const uint32_t t = (uint32_t)(u >> 56);
-    uint32_t lo = guide[t], hi = guide[t + 1];
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi + 1) >> 1;
-        if (tab[mid] < u) lo = mid; else hi = mid - 1;
-    }
-    return ((u & 1) ? (int32_t)lo : -(int32_t)lo) + centre;
+    const uint32_t r = cdt_lookup<S>(u, tab, guide, g);
+    return ((u & 1) ? (int32_t)r : -(int32_t)r) + centre;
 }
 
-__global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, const uint64_t *__restrict__ x,
+template <int S>
+__global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, CdtGuide g, const uint64_t *__restrict__ x,
                                                   int32_t *__restrict__ out, size_t count, int32_t centre)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
-    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size);
-    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
-    for (int i = threadIdx.x; i < 258; i += blockDim.x) guide[i] = gd[i];
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
+    for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
+    for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
     __syncthreads();
-    const size_t stride = (size_t)gridDim.x * blockDim.x, pairs = count / 2;
-    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 7) == 0);
+    const size_t stride = (size_t)gridDim.x * blockDim.x, quads = count / 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (vec) {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pairs; i += stride) {
-            const ulonglong2 u = reinterpret_cast<const ulonglong2 *>(x)[i];
-            reinterpret_cast<int2 *>(out)[i] = make_int2(cdt_one(u.x, tab, guide, centre), cdt_one(u.y, tab, guide, centre));
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) {
+            const ulonglong2 u = reinterpret_cast<const ulonglong2 *>(x)[2 * i], w = reinterpret_cast<const ulonglong2 *>(x)[2 * i + 1];
+            reinterpret_cast<int4 *>(out)[i] = make_int4(cdt_one<S>(u.x, tab, guide, g, centre), cdt_one<S>(u.y, tab, guide, g, centre),
+                                                         cdt_one<S>(w.x, tab, guide, g, centre), cdt_one<S>(w.y, tab, guide, g, centre));
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && (count & 1)) out[count - 1] = cdt_one(x[count - 1], tab, guide, centre);
+        if (blockIdx.x == 0 && threadIdx.x < (count & 3)) { const size_t i = quads * 4 + threadIdx.x; out[i] = cdt_one<S>(x[i], tab, guide, g, centre); }
     } else {
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = cdt_one(x[i], tab, guide, centre);
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = cdt_one<S>(x[i], tab, guide, g, centre);
+    }
+}
+
+// no usable guide (a table some bin of which holds more than 7 entries): the halving search itself
+__global__ __launch_bounds__(256) void cdt_halving_kernel(const uint64_t *__restrict__ cdf, int size, const uint64_t *__restrict__ x, int32_t *__restrict__ out, size_t count, int32_t centre)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    for (int i = threadIdx.x; i < size; i += blockDim.x) tab[i] = cdf[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t u = x[i];
+        uint32_t a = 0;
+        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
+        out[i] = ((u & 1) ? (int32_t)a : -(int32_t)a) + centre;
     }
 }
 
@@ -578,6 +590,73 @@ extern "C" int sc_hip_cdt_build_table(float tail, float sigma, uint64_t *cdf, in
     return SC_HIP_SUCCESS;
 }
 
+// The guide of cdt_guide.h for a monotone table: the first bin layout (coarsest first) no bin of which holds more than 3 switch points,
+// else the one with the smallest maximum; the result is checked against the halving search at every switch point and its neighbours
+// before it is accepted (g->S = 0: none accepted).
+static uint32_t cdt_halving(const std::vector<uint64_t> &cdf, uint64_t x)
+{
+    uint32_t a = 0;
+    for (uint32_t st = (uint32_t)cdf.size() >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (cdf[b] < x) a = b; }
+    return a;
+}
+void sc::cdt_build_guide(const std::vector<uint64_t> &cdf, CdtGuide *out, std::vector<uint16_t> *guide, std::vector<uint64_t> *probe)
+{
+    // the closing run of equal entries below 2^64 - 1
+    size_t last = cdf.size();
+    while (last > 1 && cdf[last - 1] == ~0ULL) last--;                    // cdf[last - 1]: the largest entry below 2^64 - 1 (index 0 if there is none)
+    size_t first = last - 1;
+    while (first > 1 && cdf[first - 1] == cdf[last - 1]) first--;
+    const bool run = last - 1 > first && first >= 1;
+    const uint64_t sat = run ? cdf[first] : ~0ULL;
+    const size_t live = run ? first + 1 : cdf.size();                      // entries the guide counts
+    static const int layouts[][3] = { { 8, 4, 3 }, { 10, 5, 4 }, { 11, 5, 5 }, { 12, 6, 5 }, { 12, 6, 6 }, { 13, 7, 6 } };       // LB, K, MB
+    const size_t size = cdf.size();
+    CdtGuide best; memset(&best, 0, sizeof best);
+    std::vector<uint16_t> bg;
+    for (const auto &L : layouts) {
+        CdtGuide g;
+        g.lb_shift = 32u - (uint32_t)L[0]; g.K = (uint32_t)L[1]; g.MB = (uint32_t)L[2]; g.tail_thr = ~0u << (32 - L[1]);
+        g.lin = 1u << L[0]; g.total = g.lin + ((64u - g.K) << g.MB); g.S = 0;
+        std::vector<uint32_t> cnt(g.total + 1, 0);
+        for (size_t b = 1; b < live; b++) {
+            if (cdf[b] == ~0ULL) continue;                                         // never below any x
+            const uint64_t xb = cdf[b] + 1;
+            cnt[cdt_guide_bin((uint32_t)(xb >> 32), (uint32_t)xb, g)]++;
+        }
+        std::vector<uint16_t> gd((g.total + 2) & ~1u, 0);
+        uint32_t acc = 0, smax = 0;
+        for (uint32_t i = 0; i < g.total; i++) { gd[i] = (uint16_t)acc; acc += cnt[i]; if (cnt[i] > smax) smax = cnt[i]; }
+        g.S = smax ? smax : 1;
+        g.sat_hi = (uint32_t)(sat >> 32); g.sat_lo = (uint32_t)sat; g.jump = run ? (uint32_t)(last - 1) : 0u;
+        if (best.S == 0 || g.S < best.S) { best = g; bg = gd; }
+        if (best.S <= 3) break;
+    }
+    if (best.S > 7) best.S = 0;
+    // acceptance test on the host: every switch point and both neighbours, the extremes of x
+    if (best.S) {
+        auto fast = [&](uint64_t x) {
+            const uint32_t b0 = bg[cdt_guide_bin((uint32_t)(x >> 32), (uint32_t)x, best)];
+            uint32_t r = b0;
+            for (uint32_t j = 1; j <= best.S; j++) { const size_t k = (size_t)b0 + j; r += (k < live && cdf[k] < x) ? 1u : 0u; }
+            return (x > sat) ? best.jump : r;
+        };
+        bool ok = fast(0) == cdt_halving(cdf, 0) && fast(~0ULL) == cdt_halving(cdf, ~0ULL) && fast(1) == cdt_halving(cdf, 1);
+        uint64_t lcg = 0x9E3779B97F4A7C15ULL;
+        for (size_t b = 0; b < size && ok; b++) {
+            for (int d = -1; d <= 1; d++) { const uint64_t x = cdf[b] + (uint64_t)(int64_t)d; if (fast(x) != cdt_halving(cdf, x)) ok = false; }
+            lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+            if (fast(lcg) != cdt_halving(cdf, lcg) || fast(~(lcg >> (b & 63))) != cdt_halving(cdf, ~(lcg >> (b & 63)))) ok = false;
+        }
+        if (!ok) best.S = 0;
+    }
+    if (!best.S) { bg.assign(2, 0); best.total = 1; }
+    *out = best; *guide = bg;
+    // what the kernels read: the table itself for the halving search, cut behind the run's first entry for the probes; CDT_PAD entries of 2^64 - 1 behind it
+    probe->assign(cdf.begin(), cdf.end());
+    if (best.S) for (size_t b = live; b < size; b++) (*probe)[b] = ~0ULL;
+    probe->resize(size + CDT_PAD, ~0ULL);
+}
+
 extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h_cdf, int size, sc_hip_cdt_t **out)
 {
     if (!ctx || !out || !h_cdf) return fail("cdt_create_from_table: null argument");
@@ -587,22 +666,14 @@ extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h
     c->ctx = ctx; c->tail = 0.f; c->sigma = 0.f; c->size = size;
     c->cdf.assign(h_cdf, h_cdf + size);
     c->d_cdf = nullptr; c->d_guide = nullptr;
-    // guide[t] = max{b : cdf[b] < t * 2^56} (0 if none), t = 0..256 (t = 256 stands for 2^64: every entry qualifies that is < 2^64)
-    uint16_t guide[258];
-    {
-        int b = 0;
-        for (int t = 0; t <= 256; t++) {
-            if (t == 256) { guide[t] = (uint16_t)(size - 1); break; }
-            const uint64_t lim = (uint64_t)t << 56;
-            while (b + 1 < size && h_cdf[b + 1] < lim) b++;
-            guide[t] = (uint16_t)((t == 0) ? 0 : ((h_cdf[b] < lim) ? b : 0));
-        }
-        guide[257] = guide[256];
-    }
-    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * size) != hipSuccess ||
-        hipMemcpy(c->d_cdf, c->cdf.data(), sizeof(uint64_t) * size, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void **)&c->d_guide, sizeof guide) != hipSuccess || hipMemcpy(c->d_guide, guide, sizeof guide, hipMemcpyHostToDevice) != hipSuccess) {
+    std::vector<uint16_t> guide;
+    std::vector<uint64_t> padded;
+    sc::cdt_build_guide(c->cdf, &c->g, &guide, &padded);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * padded.size()) != hipSuccess ||
+        hipMemcpy(c->d_cdf, padded.data(), sizeof(uint64_t) * padded.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc((void **)&c->d_guide, guide.size() * 2) != hipSuccess || hipMemcpy(c->d_guide, guide.data(), guide.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
         if (c->d_cdf) (void)sc::wipe_free(c->d_cdf);
+        if (c->d_guide) (void)sc::wipe_free(c->d_guide);
         delete c;
         return fail("cdt_create: cannot upload the table");
     }
@@ -623,6 +694,7 @@ extern "C" int sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_
 }
 extern "C" void sc_hip_cdt_destroy(sc_hip_cdt_t *c) { if (!c) return; if (c->d_cdf) (void)sc::wipe_free(c->d_cdf); if (c->d_guide) (void)sc::wipe_free(c->d_guide); delete c; }
 extern "C" int sc_hip_cdt_size(const sc_hip_cdt_t *c) { return c ? c->size : 0; }
+size_t sc::cdt_lds_bytes(const sc_hip_cdt *c) { return sizeof(uint64_t) * ((size_t)c->size + CDT_PAD) + (((size_t)c->g.total + 2) & ~(size_t)1) * 2; }
 extern "C" int sc_hip_cdt_table(const sc_hip_cdt_t *c, uint64_t *h)
 {
     if (!c || !h) return fail("cdt_table: null argument");
@@ -637,10 +709,19 @@ extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *
     HIPCHK(hipSetDevice(c->ctx->device));
     size_t blocks = (count + 256 * 32 - 1) / (256 * 32);       // >= 32 samples per lane amortise the table load
     if (blocks == 0) blocks = 1;
-    const size_t cap = (size_t)c->ctx->cus * 4;
+    const size_t lds = sc::cdt_lds_bytes(c);
+    const size_t per_cu = lds ? (size_t)(160 * 1024) / lds : 8;
+    const size_t cap = (size_t)c->ctx->cus * (per_cu > 8 ? 8 : (per_cu ? per_cu : 1));
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(cdt_kernel, dim3((unsigned)blocks), dim3(256), sizeof(uint64_t) * (size_t)c->size + 520, (hipStream_t)stream,
-                       c->d_cdf, c->d_guide, c->size, d_uniform, d_out, count, centre);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gr((unsigned)blocks), bl(256);
+    switch (c->g.S) {
+    case 0: hipLaunchKernelGGL(cdt_halving_kernel, gr, bl, sizeof(uint64_t) * (size_t)c->size, s, c->d_cdf, c->size, d_uniform, d_out, count, centre); break;
+    case 1: hipLaunchKernelGGL(cdt_kernel<1>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    case 2: hipLaunchKernelGGL(cdt_kernel<2>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    case 3: hipLaunchKernelGGL(cdt_kernel<3>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    default: hipLaunchKernelGGL(cdt_kernel<0>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    }
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
