@@ -96,10 +96,11 @@ struct sc_hip_plan {
     bool mad_ok;                  // the small-modulus multiply-add forms are safe for this (q, n)
     std::vector<int32_t> w, r;    // reference-format tables (host)
     uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
-    uint32_t *d_tab_s;            // MODE_SMAD (q = 7681, n = 256): centred twiddles, signed companions; same layout
+    uint32_t *d_tab_s;            // MODE_SMAD (q = 7681 at n = 256; q < 14654 at n = 512, 1024): centred twiddles, signed companions; same layout
     sc::ModK k[2];
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
     uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
+    uint32_t c_inv_s[4];          // MODE_SMAD: the n^-1 scale constants centred, signed companions
     uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
     uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order; guarded by mv_mu (host) and mv_event (device)
     size_t mv_cap;

@@ -79,9 +79,13 @@ template <> struct Mod<MODE_MAD> {
 // Signed small-modulus mode (36 q^2 < 2^31: q = 7681).  Values are SIGNED lazy residues: a Barrett / Shoup quotient estimate that
 // is off by one in either direction leaves r in [-q, 2q), and nothing forces r back into [0, 2q) - so a butterfly is
 // (a + t, a - t) with no 2q bias, an input reduction is two instructions, and the pointwise product needs no canonical operand.
-// Twiddles are centred (|w| <= q/2) with signed companions floor(w 2^32 / q).  Bounds: forward values stay below 18q in magnitude
-// (inputs in [-q, 2q), eight stages of growth by at most 2q), so every product of a value with a twiddle or with another reduced
-// value is below 18q * 2q < 2^31; inverse sums double per stage and stay below 2q 2^8 < 2^23 (the 24-bit multiply-add operand).
+// Twiddles are centred (|w| <= q/2) with signed companions floor(w 2^32 / q).  Bounds, n = 256 (36 q^2 < 2^31: q = 7681): forward values stay
+// below 18q in magnitude (inputs in [-q, 2q), eight stages of growth by at most 2q), so every product of a value with a twiddle or with another
+// reduced value is below 18q * 2q < 2^31; inverse sums double per stage and stay below 2q 2^8 < 2^23 (the 24-bit multiply-add operand).
+// n = 512, 1024 (L = 9, 10 stages; q^2 L < 2^31: q < 14654, so 7681 and 12289): the value the last forward stage multiplies is below 2q L and a
+// twiddle below q/2, product below q^2 L < 2^31; the transform's outputs (below 2q(L+1)) are reduced to [-q, 2q) before the pointwise product
+// (4 q^2 < 2^31); the L-8 stages of the first inverse round leave sums of up to 2q 2^(L-8), which are reduced again so that the eight growing
+// stages that follow start from 2q as for n = 256 (512 q < 2^23 needs q < 2^14).
 template <> struct Mod<MODE_SMAD> {
     static constexpr uint64_t BETA = 1ull << 32;
     // a signed with |a| < 2^23, w centred, wp = floor(w 2^32 / q) as int32  ->  a*w mod q in [-q, 2q)
@@ -91,6 +95,15 @@ template <> struct Mod<MODE_SMAD> {
         return (uint32_t)mul_i24((int32_t)a, (int32_t)w) + (uint32_t)mul_i24(qh, -(int32_t)k.q);
     }
 };
+
+// a in [0, 2^24) (a biased sum), w centred, wp its signed companion -> a*w mod q in [0, 2q): the last inverse stage of the signed mode.  The
+// quotient estimate |qh| <= a/2 < 2^23 fits the 24-bit multiply-add whatever q < 2^14 is (with a canonical constant it reaches a itself, which
+// only fits for 1024 q < 2^23, i.e. q = 7681); the product a*w is taken modulo 2^32 by the full multiplier, which issues at the same rate.
+__device__ __forceinline__ uint32_t mulc_pos_centred(uint32_t a, uint32_t w, uint32_t wp, const ModK &k)
+{
+    const int32_t qh = __mulhi((int32_t)a, (int32_t)wp);
+    return a * w + (uint32_t)mul_i24(qh, -(int32_t)k.q);
+}
 
 // any int32 -> signed residue in [-q, 2q): two instructions (|qh| <= 2^31 / q < 2^19 fits the 24-bit operand)
 __device__ __forceinline__ uint32_t reduce_signed(int32_t x, const ModK &k)

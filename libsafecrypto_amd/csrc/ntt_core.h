@@ -153,14 +153,14 @@ template <int MODE, int G>
 __device__ __forceinline__ void gs_last_stage(uint32_t (&x)[16], uint32_t c0, uint32_t c0p, uint32_t c1, uint32_t c1p, const ModK &k)
 {
     if constexpr (MODE == MODE_SMAD) {
-        // signed sums of magnitude <= 2q 2^8 = 512 q: biased by 512 q (a multiple of q) they are below 2^23 and non-negative, and the
-        // unsigned multiply-add product with the (unsigned, canonical) scale constants finishes as in MODE_MAD
+        // signed sums of magnitude <= 2q 2^8 = 512 q: biased by 512 q (a multiple of q) they are non-negative and below 1024 q < 2^24; the
+        // scale constants come centred with signed companions (modarith.h mulc_pos_centred), the result lands in [0, 2q)
         const uint32_t bias = k.q << 9;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t a = x[r], b = x[r | 8];
-            x[r] = csub(Mod<MODE_MAD>::mulc(a + b + bias, c0, c0p, k), k.q);
-            x[r | 8] = csub(Mod<MODE_MAD>::mulc(a - b + bias, c1, c1p, k), k.q);
+            x[r] = csub(mulc_pos_centred(a + b + bias, c0, c0p, k), k.q);
+            x[r | 8] = csub(mulc_pos_centred(a - b + bias, c1, c1p, k), k.q);
         }
         return;
     }
@@ -235,9 +235,13 @@ __device__ __forceinline__ void inv_core(uint32_t (&x)[16], const TwSet<L> &tw, 
     // small-modulus mode: the last 8 stages (rounds 1 and 0) let the sums grow; the L-8 stages of round 2 stay reduced
     constexpr bool GROW = MODE == MODE_MAD || MODE == MODE_SMAD;
     static_assert(!GROW || Y::ns(1) == 4, "growth bookkeeping assumes 4 + 4 stages in rounds 1 and 0");
-    static_assert(MODE != MODE_SMAD || Y::NR == 2, "the signed mode's bounds are worked out for n = 256");
     if constexpr (Y::NR == 3) {
         gs_round<MODE, Y::ns(2), false, -1>(x, tw.t2, tw.t2p, k);
+        if constexpr (MODE == MODE_SMAD) {       // the registers this round left as sums (up to 2q 2^ns) go back to [-q, 2q) - see modarith.h
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (!(r & (1 << (Y::ns(2) - 1)))) x[r] = reduce_signed((int32_t)x[r], k);
+        }
         exchange<Y::b0(2), Y::b0(1)>(x, lds_poly, lp);
     }
     gs_round<MODE, Y::ns(1), false, (GROW ? 0 : -1)>(x, tw.t1, tw.t1p, k);

@@ -117,8 +117,11 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t v = x[r];
-                if (MODE == MODE_SMAD) v = canon_signed(reduce_signed((int32_t)v, k), k);
-                else {
+                if (MODE == MODE_SMAD) {          // |v| < 2q(L+1) <= 22q: + 32q, unsigned Barrett step to [0, 2q), one conditional subtraction
+                    v += k.q << 5;
+                    v += (uint32_t)mul_i24((int32_t)__umulhi(v, k.m32), -(int32_t)k.q);
+                    v = csub(v, k.q);
+                } else {
                     if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
                     v = csub(v, k.q);
                 }
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         if (OP == OP_MULNTT) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(x[r], reduce_signed(nb[r], k), k);               // |x| < 18q, |y| <= 2q: below 2^31
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall((L > 8) ? reduce_signed((int32_t)x[r], k) : x[r], reduce_signed(nb[r], k), k);   // n = 256: |x| < 18q, |y| <= 2q: below 2^31
                 else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
                 else x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
             }
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
             fwd_core<L, MODE, (MODE == MODE_SMAD)>(y, twf, lds_poly, lp, k);      // [0,2q) (signed mode: lazy, reduced below)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(x[r], reduce_signed((int32_t)y[r], k), k);
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall((L > 8) ? reduce_signed((int32_t)x[r], k) : x[r], reduce_signed((int32_t)y[r], k), k);
                 else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(y[r], k.q), k);
                 else x[r] = montmul(x[r], y[r], k);
             }
@@ -387,7 +390,8 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     p->mad_ok = Q < (1ull << 14) && 2ull * Q * (Q - 1) * (uint64_t)(L + 1) < (1ull << 32);
     if (p->mad_ok) p->mode = MODE_MAD;
     // 36 q^2 < 2^31 and n = 256 (q = 7681): signed lazy residues, no butterfly bias, two-instruction input reductions (MODE_SMAD)
-    if (n == 256 && 36ull * Q * Q < (1ull << 31)) {
+    // n = 512, 1024 and q^2 L < 2^31 (q = 7681, 12289): the same with two extra reductions (bounds in modarith.h)
+    if ((n == 256 && 36ull * Q * Q < (1ull << 31)) || (n > 256 && Q < (1ull << 14) && Q * Q * (uint64_t)L < (1ull << 31))) {
         std::vector<uint32_t> h(4 * (size_t)n, 0u);
         auto centre = [&](uint64_t w) -> int64_t { return w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w; };
         auto sshoup = [&](int64_t w) -> uint32_t {                 // floor(w 2^32 / q) as a two's-complement 32-bit value
@@ -405,6 +409,8 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
             sc_hip_plan_destroy(p);
             return fail("plan_create: cannot upload the signed twiddle tables");
         }
+        const int64_t cs0 = centre(ninv), cs1 = centre(mulmod(ninv, zi[1], Q));
+        p->c_inv_s[0] = (uint32_t)(int32_t)cs0; p->c_inv_s[1] = sshoup(cs0); p->c_inv_s[2] = (uint32_t)(int32_t)cs1; p->c_inv_s[3] = sshoup(cs1);
         p->mode = MODE_SMAD;
     }
     *out = p;
@@ -435,7 +441,7 @@ extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
     if (mode == 0) mode = p->d_tab_s ? MODE_SMAD : p->mad_ok ? MODE_MAD : MODE_U32;
-    if (mode == MODE_SMAD && !p->d_tab_s) return fail("plan_set_arith: the signed small-modulus path needs n = 256 and 36 q^2 < 2^31");
+    if (mode == MODE_SMAD && !p->d_tab_s) return fail("plan_set_arith: the signed small-modulus path needs 36 q^2 < 2^31 (n = 256) or q^2 log2(n) < 2^31 and q < 2^14 (n = 512, 1024)");
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
     if (mode == MODE_MAD && !p->mad_ok) return fail("plan_set_arith: the multiply-add path needs q < 2^14 and 2 q (q - 1) (log2 n + 1) < 2^32");
     if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD) return fail("plan_set_arith: mode must be 0, 1, 2, 3 or 4");
@@ -464,7 +470,7 @@ static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
 template <int L, int OP>
 static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
 {
-    if constexpr (L == 8) { if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s); }
+    if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
     if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
         if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
@@ -496,7 +502,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
     a.zf = (p->mode == MODE_SMAD) ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
-    const uint32_t *c = (op == OP_INV || p->mode == MODE_MAD || p->mode == MODE_SMAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
+    const uint32_t *c = p->mode == MODE_SMAD ? p->c_inv_s : (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
     const int pw = 1024 / n;                                  // polynomials per wave
