@@ -91,7 +91,7 @@ struct sc_hip_plan {
     int32_t q;
     int n, L;
     int32_t g;
-    int mode;                     // MODE_U24 / MODE_U32 / MODE_MAD / MODE_SMAD in use
+    int mode;                     // MODE_U24 / MODE_U32 / MODE_MAD / MODE_SMAD / MODE_S32 in use
     bool lazy24, lazy32;
     bool mad_ok;                  // the small-modulus multiply-add forms are safe for this (q, n)
     std::vector<int32_t> w, r;    // reference-format tables (host)
@@ -100,7 +100,9 @@ struct sc_hip_plan {
     sc::ModK k[2];
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p
     uint32_t c_mont[2][4];        // scale = n^-1 * 2^32
-    uint32_t c_inv_s[4];          // MODE_SMAD: the n^-1 scale constants centred, signed companions
+    uint32_t c_inv_s[4];          // MODE_SMAD / MODE_S32: the n^-1 scale constants centred, signed companions
+    uint32_t c_mont_s[4];         // MODE_S32: the same for n^-1 2^32
+    bool smad_ok, s32_ok;
     uint32_t r2, r2p;             // 2^32 mod q (as a U32-mode Shoup pair)
     uint32_t *mv_ws;              // sc_hip_matvec scratch: NTT(y) and the matrix in internal order; guarded by mv_mu (host) and mv_event (device)
     size_t mv_cap;

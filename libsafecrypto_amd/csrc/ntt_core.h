@@ -108,6 +108,11 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
         }
         const uint32_t t = (MODE == MODE_MAD) ? mulmod_small(x[r | (1 << T)], tw[idx], k) : Mod<MODE>::mulc(x[r | (1 << T)], tw[idx], twp[idx], k);
         const uint32_t a = x[r];
+        if constexpr (MODE == MODE_S32) {        // signed lazy residues, 32-bit multiplier (modarith.h)
+            x[r] = a + t;
+            x[r | (1 << T)] = a - t;
+            continue;
+        }
         if (LAZY) {                      // values grow by < 2q per stage, never reduced
             x[r] = a + t;
             x[r | (1 << T)] = a + k.q2 - t;
@@ -125,13 +130,13 @@ __device__ __forceinline__ void ct_stage(uint32_t (&x)[16], const uint32_t (&tw)
 template <int MODE, int T, int G>
 __device__ __forceinline__ void gs_stage(uint32_t (&x)[16], const uint32_t (&tw)[15], const uint32_t (&twp)[15], const ModK &k)
 {
-    static_assert(G < 0 || MODE == MODE_MAD || MODE == MODE_SMAD, "growing sums need a small-modulus mode");
+    static_assert(G < 0 || MODE == MODE_MAD || MODE == MODE_SMAD || MODE == MODE_S32, "growing sums need a small-modulus or signed mode");
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         if (r & (1 << T)) continue;
         const int idx = (1 << (3 - T)) - 1 + (r >> (T + 1));
         const uint32_t a = x[r], b = x[r | (1 << T)];
-        if constexpr (MODE == MODE_SMAD) {       // signed: the sums grow (below 2q 2^stage in magnitude), the difference needs no bias
+        if constexpr (MODE == MODE_SMAD || MODE == MODE_S32) {       // signed: the sums grow (below 2q 2^stage in magnitude), the difference needs no bias
             x[r] = a + b;
             x[r | (1 << T)] = Mod<MODE>::mulc(a - b, tw[idx], twp[idx], k);
         } else if constexpr (G >= 0) {
@@ -161,6 +166,18 @@ __device__ __forceinline__ void gs_last_stage(uint32_t (&x)[16], uint32_t c0, ui
             const uint32_t a = x[r], b = x[r | 8];
             x[r] = csub(mulc_pos_centred(a + b + bias, c0, c0p, k), k.q);
             x[r | 8] = csub(mulc_pos_centred(a - b + bias, c1, c1p, k), k.q);
+        }
+        return;
+    }
+    if constexpr (MODE == MODE_S32) {
+        // signed sums of magnitude <= 32q, biased by 32q (a multiple of q): non-negative and below 2^31; centred scale constants with signed
+        // companions leave the product in [0, 3q/2)
+        const uint32_t bias = k.q << 5;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t a = x[r], b = x[r | 8];
+            x[r] = csub(Mod<MODE_S32>::mulc(a + b + bias, c0, c0p, k), k.q);
+            x[r | 8] = csub(Mod<MODE_S32>::mulc(a - b + bias, c1, c1p, k), k.q);
         }
         return;
     }
@@ -233,7 +250,7 @@ __device__ __forceinline__ void inv_core(uint32_t (&x)[16], const TwSet<L> &tw, 
 {
     using Y = Lay<L>;
     // small-modulus mode: the last 8 stages (rounds 1 and 0) let the sums grow; the L-8 stages of round 2 stay reduced
-    constexpr bool GROW = MODE == MODE_MAD || MODE == MODE_SMAD;
+    constexpr bool GROW = MODE == MODE_MAD || MODE == MODE_SMAD || MODE == MODE_S32;
     static_assert(!GROW || Y::ns(1) == 4, "growth bookkeeping assumes 4 + 4 stages in rounds 1 and 0");
     if constexpr (Y::NR == 3) {
         gs_round<MODE, Y::ns(2), false, -1>(x, tw.t2, tw.t2p, k);
@@ -242,9 +259,14 @@ __device__ __forceinline__ void inv_core(uint32_t (&x)[16], const TwSet<L> &tw, 
             for (int r = 0; r < 16; r++)
                 if (!(r & (1 << (Y::ns(2) - 1)))) x[r] = reduce_signed((int32_t)x[r], k);
         }
+        // (the 32-bit signed mode has room for them: at most 4 B after two stages, 64 B after the round that follows)
         exchange<Y::b0(2), Y::b0(1)>(x, lds_poly, lp);
     }
     gs_round<MODE, Y::ns(1), false, (GROW ? 0 : -1)>(x, tw.t1, tw.t1p, k);
+    if constexpr (MODE == MODE_S32) {            // the eight registers whose last product is more than one stage back (up to 16 B, 64 B for n = 1024)
+#pragma unroll
+        for (int r = 0; r < 8; r++) x[r] = reduce_s32((int32_t)x[r], k);
+    }
     exchange<Y::b0(1), Y::b0(0)>(x, lds_poly, lp);
     gs_round<MODE, 4, true, (GROW ? 4 : -1)>(x, tw.t0, tw.t0p, k);
     gs_last_stage<MODE, (GROW ? 7 : -1)>(x, c0, c0p, c1, c1p, k);

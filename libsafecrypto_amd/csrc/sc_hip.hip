@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         const size_t base = (size_t)poly * N;
         uint32_t x[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_SMAD) ? reduce_signed(nx[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
+        for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_SMAD) ? reduce_signed(nx[r], k) : (MODE == MODE_S32) ? reduce_s32(nx[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
 
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
                     v += k.q << 5;
                     v += (uint32_t)mul_i24((int32_t)__umulhi(v, k.m32), -(int32_t)k.q);
                     v = csub(v, k.q);
-                } else {
+                } else if (MODE == MODE_S32) v = canon_s32(v, k);
+                else {
                     if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
                     v = csub(v, k.q);
                 }
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 if (MODE == MODE_SMAD) x[r] = mulmod_ssmall((L > 8) ? reduce_signed((int32_t)x[r], k) : x[r], reduce_signed(nb[r], k), k);   // n = 256: |x| < 18q, |y| <= 2q: below 2^31
+                else if (MODE == MODE_S32) x[r] = montmul_s32(x[r], reduce_s32(nb[r], k), k);                       // 22q * 3q/2 < 2^31
                 else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
                 else x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
             }
@@ -142,12 +144,13 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         if (OP == OP_MUL) {
             uint32_t y[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_SMAD) ? reduce_signed(nb[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
+            for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_SMAD) ? reduce_signed(nb[r], k) : (MODE == MODE_S32) ? reduce_s32(nb[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
             prefetch();
-            fwd_core<L, MODE, (MODE == MODE_SMAD)>(y, twf, lds_poly, lp, k);      // [0,2q) (signed mode: lazy, reduced below)
+            fwd_core<L, MODE, (MODE == MODE_SMAD || MODE == MODE_S32)>(y, twf, lds_poly, lp, k);      // [0,2q) (signed modes: lazy, reduced below)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 if (MODE == MODE_SMAD) x[r] = mulmod_ssmall((L > 8) ? reduce_signed((int32_t)x[r], k) : x[r], reduce_signed((int32_t)y[r], k), k);
+                else if (MODE == MODE_S32) x[r] = montmul_s32(x[r], reduce_s32((int32_t)y[r], k), k);
                 else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(y[r], k.q), k);
                 else x[r] = montmul(x[r], y[r], k);
             }
@@ -335,7 +338,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
 
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
-    p->mv_ws = nullptr; p->mv_cap = 0; p->mv_event = nullptr; p->d_tab_s = nullptr;
+    p->mv_ws = nullptr; p->mv_cap = 0; p->mv_event = nullptr; p->d_tab_s = nullptr; p->smad_ok = p->s32_ok = false;
     p->g_exec = nullptr; p->g_a = p->g_b = nullptr; p->g_out = nullptr; p->g_batch = 0; p->g_steps = 0;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
@@ -391,7 +394,10 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     if (p->mad_ok) p->mode = MODE_MAD;
     // 36 q^2 < 2^31 and n = 256 (q = 7681): signed lazy residues, no butterfly bias, two-instruction input reductions (MODE_SMAD)
     // n = 512, 1024 and q^2 L < 2^31 (q = 7681, 12289): the same with two extra reductions (bounds in modarith.h)
-    if ((n == 256 && 36ull * Q * Q < (1ull << 31)) || (n > 256 && Q < (1ull << 14) && Q * Q * (uint64_t)L < (1ull << 31))) {
+    const bool smad = (n == 256 && 36ull * Q * Q < (1ull << 31)) || (n > 256 && Q < (1ull << 14) && Q * Q * (uint64_t)L < (1ull << 31));
+    // q < 2^25 (2^24 for n = 512, 1024, whose first inverse round is not reduced): signed lazy residues on the 32-bit multiplier (MODE_S32)
+    p->s32_ok = Q < (1ull << 25) && (n == 256 || Q < (1ull << 24));
+    if (smad || p->s32_ok) {
         std::vector<uint32_t> h(4 * (size_t)n, 0u);
         auto centre = [&](uint64_t w) -> int64_t { return w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w; };
         auto sshoup = [&](int64_t w) -> uint32_t {                 // floor(w 2^32 / q) as a two's-complement 32-bit value
@@ -411,7 +417,11 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
         }
         const int64_t cs0 = centre(ninv), cs1 = centre(mulmod(ninv, zi[1], Q));
         p->c_inv_s[0] = (uint32_t)(int32_t)cs0; p->c_inv_s[1] = sshoup(cs0); p->c_inv_s[2] = (uint32_t)(int32_t)cs1; p->c_inv_s[3] = sshoup(cs1);
-        p->mode = MODE_SMAD;
+        const uint64_t mm0 = mulmod(ninv, R, Q);
+        const int64_t cm0 = centre(mm0), cm1 = centre(mulmod(mm0, zi[1], Q));
+        p->c_mont_s[0] = (uint32_t)(int32_t)cm0; p->c_mont_s[1] = sshoup(cm0); p->c_mont_s[2] = (uint32_t)(int32_t)cm1; p->c_mont_s[3] = sshoup(cm1);
+        p->smad_ok = smad;
+        p->mode = smad ? MODE_SMAD : MODE_S32;
     }
     *out = p;
     return SC_HIP_SUCCESS;
@@ -440,11 +450,12 @@ extern "C" int sc_hip_plan_tables(const sc_hip_plan_t *p, int32_t *h_w, int32_t 
 extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 {
     if (!p) return fail("plan_set_arith: null plan");
-    if (mode == 0) mode = p->d_tab_s ? MODE_SMAD : p->mad_ok ? MODE_MAD : MODE_U32;
-    if (mode == MODE_SMAD && !p->d_tab_s) return fail("plan_set_arith: the signed small-modulus path needs 36 q^2 < 2^31 (n = 256) or q^2 log2(n) < 2^31 and q < 2^14 (n = 512, 1024)");
+    if (mode == 0) mode = p->smad_ok ? MODE_SMAD : p->s32_ok ? MODE_S32 : p->mad_ok ? MODE_MAD : MODE_U32;
+    if (mode == MODE_S32 && !p->s32_ok) return fail("plan_set_arith: the signed 32-bit path needs q < 2^25 (2^24 for n = 512, 1024)");
+    if (mode == MODE_SMAD && !p->smad_ok) return fail("plan_set_arith: the signed small-modulus path needs 36 q^2 < 2^31 (n = 256) or q^2 log2(n) < 2^31 and q < 2^14 (n = 512, 1024)");
     if (mode == MODE_U24 && (uint64_t)p->q >= (1ull << 23)) return fail("plan_set_arith: 24-bit path needs q < 2^23");
     if (mode == MODE_MAD && !p->mad_ok) return fail("plan_set_arith: the multiply-add path needs q < 2^14 and 2 q (q - 1) (log2 n + 1) < 2^32");
-    if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD) return fail("plan_set_arith: mode must be 0, 1, 2, 3 or 4");
+    if (mode != MODE_U24 && mode != MODE_U32 && mode != MODE_MAD && mode != MODE_SMAD && mode != MODE_S32) return fail("plan_set_arith: mode must be 0 .. 5");
     if (mode != p->mode && p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }     // a captured loop holds the old kernel
     p->mode = mode;
     return SC_HIP_SUCCESS;
@@ -471,6 +482,7 @@ template <int L, int OP>
 static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
 {
     if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
+    if (mode == MODE_S32) return launch_ntt_t<L, MODE_S32, true, OP>(a, blocks, s);
     if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
         if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
@@ -500,9 +512,11 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int n = p->n;
     NttArgs a;
     a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
-    a.zf = (p->mode == MODE_SMAD) ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    const bool sgn = p->mode == MODE_SMAD || p->mode == MODE_S32;
+    a.zf = sgn ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
-    const uint32_t *c = p->mode == MODE_SMAD ? p->c_inv_s : (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
+    const uint32_t *c = p->mode == MODE_SMAD ? p->c_inv_s : p->mode == MODE_S32 ? (op == OP_INV ? p->c_inv_s : p->c_mont_s)
+                        : (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
     const int pw = 1024 / n;                                  // polynomials per wave
