@@ -73,11 +73,14 @@ struct DilNtt {
     int32_t *r;                           // [item][k][n]  (w - c s2)
     uint8_t *h;                           // [item][k*n]
     uint32_t *flags, *ones;               // per item
+    int sg;                               // 1: the signed 32-bit arithmetic (MODE_S32, modarith.h) - tables and scale constants are the centred ones
 };
 
-template <int OP>
+// MODE: MODE_S32 (q < 2^25 and 16 l q < 2^31: every reference parameter set) or MODE_U32.  Both produce the same canonical values.
+template <int OP, int MODE>
 __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 {
+    constexpr bool SG = MODE == MODE_S32;
     __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pw = lane / LP, lp = lane % LP;
@@ -106,12 +109,12 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
         if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) {
             const int32_t *src = a.in + ((size_t)item * a.per + sub) * N + lp;
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = reduce_i32(src[r * LP], k);        // unconditional: an out-of-range job reads job 0 (see the loop head)
-            fwd_core<L8, MODE_U32, true>(x, tw, lds_poly, lp, k);
+            for (int r = 0; r < 16; r++) x[r] = SG ? reduce_s32(src[r * LP], k) : reduce_i32(src[r * LP], k);        // unconditional: an out-of-range job reads job 0 (see the loop head)
+            fwd_core<L8, MODE, true>(x, tw, lds_poly, lp, k);
             uint32_t *dst = a.out_int + ((size_t)item * a.per + sub) * N + lp * 16;
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                uint32_t v = csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+                uint32_t v = SG ? canon_s32(x[r], k) : csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
                 if (OP == DOP_KEYPREP) v = csub(Mod<MODE_U32>::mulc(v, a.r2, a.r2p, k), k.q);
                 x[r] = v;
             }
@@ -133,6 +136,11 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint4 vy = py[c], va = pa[c];
+                    if constexpr (SG) {          // terms in (-q, q), summed as they are: |x| < l q
+                        x[4 * c + 0] += montmul_s32(vy.x, va.x, k); x[4 * c + 1] += montmul_s32(vy.y, va.y, k);
+                        x[4 * c + 2] += montmul_s32(vy.z, va.z, k); x[4 * c + 3] += montmul_s32(vy.w, va.w, k);
+                        continue;
+                    }
                     x[4 * c + 0] = csub(x[4 * c + 0] + montmul(vy.x, va.x, k), k.q2);
                     x[4 * c + 1] = csub(x[4 * c + 1] + montmul(vy.y, va.y, k), k.q2);
                     x[4 * c + 2] = csub(x[4 * c + 2] + montmul(vy.z, va.z, k), k.q2);
@@ -145,6 +153,11 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const uint4 vc = pc[c], vk = pk[c];
+                if constexpr (SG) {
+                    x[4 * c + 0] = montmul_s32(vc.x, vk.x, k); x[4 * c + 1] = montmul_s32(vc.y, vk.y, k);
+                    x[4 * c + 2] = montmul_s32(vc.z, vk.z, k); x[4 * c + 3] = montmul_s32(vc.w, vk.w, k);
+                    continue;
+                }
                 x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
                 x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
             }
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             if (OP == DOP_CT0) pre[r] = a.r[pk_off + r * LP];
             if (OP == DOP_CT1) preh[r] = a.h[pk_off + r * LP];
         }
-        inv_core<L8, MODE_U32>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
+        inv_core<L8, MODE>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
         if (!valid) continue;
 
         if (OP == DOP_MATVEC) {
@@ -234,9 +247,12 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 // kk times (the product kernel runs at the L2 bandwidth of those re-reads); here the four attempts of a wavefront also share every matrix load.
 // The matrix is in PLAIN form with Shoup companions (4-instruction products, terms in [0, 2q) summed without reduction: LL <= 5 terms stay
 // below 2^27), which the separate kernels could not afford (it doubles the matrix traffic they are bound by).
-template <int LL>
+// MODE_S32: the transforms run on signed lazy residues; NTT(y) is kept as x + 32q (positive, below 2^31 - the unsigned Shoup product with the
+// plain matrix takes any 32-bit operand) instead of canonical, and the LL <= 5 terms in [0, 2q) go into the inverse transform unreduced.
+template <int LL, int MODE>
 __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
 {
+    constexpr bool SG = MODE == MODE_S32;
     __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pw = lane / LP, lp = lane % LP;
@@ -261,10 +277,10 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
             const int32_t *src = a.in + ((size_t)s * LL + j) * N + lp;
             uint32_t x[16];
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = reduce_i32(src[r * LP], k);
-            fwd_core<L8, MODE_U32, true>(x, twf, lds_poly, lp, k);
+            for (int r = 0; r < 16; r++) x[r] = SG ? reduce_s32(src[r * LP], k) : reduce_i32(src[r * LP], k);
+            fwd_core<L8, MODE, true>(x, twf, lds_poly, lp, k);
 #pragma unroll
-            for (int r = 0; r < 16; r++) yh[j][r] = csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+            for (int r = 0; r < 16; r++) yh[j][r] = SG ? x[r] + (k.q << 5) : csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
         }
         for (int i = 0; i < a.kk; i++) {
             uint32_t x[16];
@@ -283,9 +299,11 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
                     x[4 * c + 3] += Mod<MODE_U32>::mulc(yh[j][4 * c + 3], va.w, vp.w, k);
                 }
             }
+            if constexpr (!SG) {
 #pragma unroll
-            for (int r = 0; r < 16; r++) x[r] = Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k);
-            inv_core<L8, MODE_U32>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
+                for (int r = 0; r < 16; r++) x[r] = Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k);
+            }
+            inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
             if (!valid) continue;
             const size_t off = ((size_t)slot * a.kk + i) * N + lp;
 #pragma unroll
@@ -330,9 +348,14 @@ static inline DilNtt mlwe_base_args(sc_hip_plan *p, int kk, int l, int32_t gamma
     DilNtt a;
     memset(&a, 0, sizeof a);
     const int n = p->n;
-    a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    // signed 32-bit arithmetic where its bounds hold: q < 2^25, and the largest value entering an inverse transform (l terms below q from the
+    // Montgomery products, or l terms below 2q from the fused kernel's Shoup products) times 16 stays below 2^31
+    const int lm = l > kk ? l : kk;
+    a.sg = (p->s32_ok && p->d_tab_s && 32ull * (uint64_t)lm * (uint64_t)p->q < (1ull << 31)) ? 1 : 0;
+    a.zf = a.sg ? p->d_tab_s : p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.k = p->k[1];
-    a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
+    const uint32_t *c = a.sg ? p->c_inv_s : p->c_inv[1];
+    a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     a.r2 = p->r2; a.r2p = p->r2p;
     a.l = l; a.kk = kk;
     a.alpha = 2 * gamma2; a.am = (1 << 30) / a.alpha;
@@ -347,7 +370,8 @@ static int mlwe_launch(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, int per, hipS
     size_t blocks = ((size_t)a.njobs + 15) / 16;
     const size_t cap = (size_t)ctx->cus * 8;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((dil_ntt_kernel<OP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    if (a.sg) hipLaunchKernelGGL((dil_ntt_kernel<OP, MODE_S32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((dil_ntt_kernel<OP, MODE_U32>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -360,13 +384,16 @@ static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream
     size_t blocks = ((size_t)nitems + 15) / 16;
     const size_t cap = (size_t)ctx->cus * 4;
     if (blocks > cap) blocks = cap;
+#define SC_YAW(LLv) do { if (a.sg) hipLaunchKernelGGL((dil_yaw_kernel<LLv, MODE_S32>), dim3((unsigned)blocks), dim3(256), 0, s, a); \
+                        else hipLaunchKernelGGL((dil_yaw_kernel<LLv, MODE_U32>), dim3((unsigned)blocks), dim3(256), 0, s, a); } while (0)
     switch (a.l) {
-    case 2: hipLaunchKernelGGL((dil_yaw_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((dil_yaw_kernel<3>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 4: hipLaunchKernelGGL((dil_yaw_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
-    case 5: hipLaunchKernelGGL((dil_yaw_kernel<5>), dim3((unsigned)blocks), dim3(256), 0, s, a); break;
+    case 2: SC_YAW(2); break;
+    case 3: SC_YAW(3); break;
+    case 4: SC_YAW(4); break;
+    case 5: SC_YAW(5); break;
     default: return SC_HIP_FAILURE;
     }
+#undef SC_YAW
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
