@@ -232,30 +232,42 @@ __global__ void dil_slots_kernel(const uint32_t *active, uint32_t nact, uint32_t
 // Messages with no accepted attempt advance kappa by S and go to the next round's list.
 // One wavefront per active message.  The tail (count, hint positions in ascending order, c) is assembled MSB-first in LDS as
 // big-endian 32-bit words - every field's bit offset follows from a prefix sum of the per-lane hint counts - and leaves as bytes.
-__global__ __launch_bounds__(256) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
+constexpr int FIN_W = 16;                                              // messages (wavefronts) per workgroup of dil_finish_kernel
+__global__ __launch_bounds__(64 * FIN_W) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
                                                          int32_t *acc_slot, const uint8_t *h, const int32_t *c,
                                                          uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
                                                          uint32_t *next_active, uint32_t *next_count, DilP P)
 {
-    __shared__ uint32_t tail[4][128];                                  // <= omega_bits + omega*h_bits + 2n bits = 4096 bits
+    __shared__ uint32_t tail[FIN_W][128];                              // <= omega_bits + omega*h_bits + 2n bits = 4096 bits
+    __shared__ uint32_t rej_n, rej_base;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t aidx = blockIdx.x * 4 + wv;
-    if (aidx >= nact) return;
-    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t aidx = blockIdx.x * FIN_W + wv;
+    const bool live = aidx < nact;
+    const uint32_t item = !live ? 0 : active ? active[aidx] : aidx;
     int found = -1;
-    for (uint32_t a = 0; a < S; a++) {                                 // every lane walks the (few) slots: same answer, no broadcast
-        const uint32_t slot = aidx * S + a;
-        if (found < 0 && flags[slot] == 0 && ones[slot] <= (uint32_t)P.omega) found = (int)a;
-    }
-    __builtin_amdgcn_wave_barrier();
     uint32_t no = 0;
-    if (found >= 0) no = ones[aidx * S + (uint32_t)found];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    for (uint32_t a = lane; a < S; a += 64) { flags[aidx * S + a] = 0; ones[aidx * S + a] = 0; }     // leave the per-slot accumulators clean
-    if (found < 0) {
-        if (lane == 0) { acc_slot[aidx] = -1; kappa[item] += S; next_active[atomicAdd(next_count, 1u)] = item; }
-        return;
+    if (threadIdx.x == 0) rej_n = 0;
+    if (live) {
+        for (uint32_t a = 0; a < S; a++) {                             // every lane walks the (few) slots: same answer, no broadcast
+            const uint32_t slot = aidx * S + a;
+            if (found < 0 && flags[slot] == 0 && ones[slot] <= (uint32_t)P.omega) found = (int)a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (found >= 0) no = ones[aidx * S + (uint32_t)found];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        for (uint32_t a = lane; a < S; a += 64) { flags[aidx * S + a] = 0; ones[aidx * S + a] = 0; }     // leave the per-slot accumulators clean
     }
+    // the messages that go round again are appended to the next round's list with ONE global atomic per workgroup: a wavefront each on the single
+    // counter (12 K of them in the first round of a 16 K batch) serialised in L2 and cost 100 us of the round
+    __syncthreads();
+    const bool again = live && found < 0 && lane == 0;
+    uint32_t rpos = 0;
+    if (again) rpos = atomicAdd(&rej_n, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && rej_n) rej_base = atomicAdd(next_count, rej_n);
+    __syncthreads();
+    if (again) { acc_slot[aidx] = -1; kappa[item] += S; next_active[rej_base + rpos] = item; }
+    if (!live || found < 0) return;
     const uint32_t slot = aidx * S + (uint32_t)found;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
     uint32_t *tw = tail[wv];
@@ -713,7 +725,7 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         a.key = ks.s1; a.key_item_stride = ks.per_item ? (size_t)l * N : 0; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
         a.key = ks.s2; a.key_item_stride = ks.per_item ? (size_t)k * N : 0; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
         a.key = ks.t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
+        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + FIN_W - 1) / FIN_W), dim3(64 * FIN_W), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
                            d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
         HIPCHK(hipGetLastError());
         const size_t zthreads = (size_t)nact * (size_t)(l * P.n / 2);
