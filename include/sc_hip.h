@@ -440,6 +440,12 @@ int  sc_hip_falcon_set_privkey(sc_hip_falcon_t *h, const double *sk);
 /* pk: h in the coefficient domain, SINT16[n] (first half of sc->pubkey->key, falcon.c:772-780) */
 int  sc_hip_falcon_set_pubkey(sc_hip_falcon_t *h, const int16_t *pk);
 size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *h);      /* n * (q_bits - 2) / 8 */
+/* key sets (distinct keys): nkeys expanded private keys / public keys back to back in the layouts above, resident on the device
+ * ((n_bits + 5) n doubles + n leaf tables per private key: 0.4 MB for Falcon-1024).  set_privkey / set_pubkey load a set of one; the one-key calls
+ * use key 0.  sc_hip_falcon_sign_keys / _verify_keys take the key index of every message (d_key_of [batch]); an index outside the set gives
+ * d_status 6 / verdict 1.  The sampler then runs 8 lanes per signature with every key read where it lies (no key material is staged in LDS). */
+int  sc_hip_falcon_set_privkeys(sc_hip_falcon_t *h, size_t nkeys, const double *sk);
+int  sc_hip_falcon_set_pubkeys(sc_hip_falcon_t *h, size_t nkeys, const int16_t *pk);
 /* how the tree sampler is laid over the machine; results are identical (the same double operations in the same order).  0 (default) = 64:
  * a wavefront owns 8 signatures, tree levels below 128 coefficients in LDS; 1: a lane per signature, 8: 8 lanes per signature, working
  * polynomials interleaved across the batch in HBM (the first generation, kept for comparison and for the parity tests) */
@@ -457,6 +463,11 @@ int sc_hip_falcon_sample(sc_hip_falcon_t *h, size_t batch, const int32_t *d_c, c
 int sc_hip_falcon_sign(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                        const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
+int sc_hip_falcon_sign_keys(sc_hip_falcon_t *h, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                            const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                            uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
+int sc_hip_falcon_verify_keys(sc_hip_falcon_t *h, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                              const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 /* replaces: safecrypto_verify -> falcon_sig_verify (falcon.c:955-1040); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_falcon_verify(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);

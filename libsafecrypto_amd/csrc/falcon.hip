@@ -363,7 +363,8 @@ template <int TSL, int G>
 __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B, double *__restrict__ ws, const int32_t *__restrict__ c,
                                                         const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
                                                         const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
-                                                        int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni)
+                                                        int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
+                                                        const uint32_t *__restrict__ key_of, uint32_t nkeys, size_t sk_stride, size_t tab_stride)
 {
     constexpr int FK = (G == 1) ? FK1 : FK8;
     const uint32_t tid = blockIdx.x * ST + threadIdx.x, b = tid / G, g = tid % G;
@@ -371,6 +372,11 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
     const uint32_t n = (uint32_t)P.n; const int logn = P.n_bits;
     const uint32_t have = tape_lens ? tape_lens[b] : (uint32_t)tape_stride;
     if (have < 4 * n) { if (g == 0) status[b] = 2; return; }
+    if (key_of) {                                  // a key per signature out of the handle's key set: basis, tree and leaf tables are this key's
+        const uint32_t kx = key_of[b];
+        if (kx >= nkeys) { if (g == 0) status[b] = 6; return; }
+        sk += (size_t)kx * sk_stride; tabs += (size_t)kx * tab_stride;
+    }
     const Col<G> col = { ws + (size_t)b * G, B };
     const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
     const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n, hn = n >> 1;
@@ -1157,7 +1163,7 @@ __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, con
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = P.n;
     const uint32_t b = blockIdx.x * FW + wv;
     if (b >= batch) return;
-    if (status[b] == 2) { if (lane == 0) siglens[b] = 0; return; }
+    if (status[b] == 2 || status[b] == 6) { if (lane == 0) siglens[b] = 0; return; }      // tape too short / no such key: nothing was sampled
     int32_t *sq = fin_lds + (size_t)wv * n;
     const int32_t *a1 = s1 + (size_t)b * n; int32_t *a2 = s2 + (size_t)b * n;
     for (int i = lane; i < n; i += 64) {
@@ -1520,6 +1526,7 @@ struct sc_hip_falcon {
     bool have_sk, have_pk;
     double *d_sk, *d_gm;
     uint64_t *d_tabs; int ts_log;
+    size_t nkeys, npk;           // keys resident: d_sk [nkeys][(n_bits+5) n], d_tabs [nkeys][n << ts_log], d_hhat [npk][n]; key 0 is "the" key of the one-key calls
     int force_g;                 // sc_hip_falcon_set_mapping: 0 / 64 = 8 signatures per wavefront, lower tree in LDS; 1 / 8 = lanes per signature, state in HBM
     int32_t *d_hhat;
     size_t cap;
@@ -1613,51 +1620,69 @@ static void leaf_sigmas(const double *tree, unsigned logn, std::vector<float> &o
 
 // sk: the expanded private key load_skey leaves in sc->falcon->sk (falcon.c:786-790, falcon_keygen.c:6107-6170):
 // b00 | b01 | b10 | b11 in FFT form, then the normalised LDL tree; (n_bits + 5) * n doubles
-extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk)
+extern "C" int sc_hip_falcon_set_privkey(sc_hip_falcon_t *f, const double *sk) { return sc_hip_falcon_set_privkeys(f, 1, sk); }
+
+// a key set: nkeys expanded private keys back to back; every signature of sc_hip_falcon_sign_keys names one of them
+extern "C" int sc_hip_falcon_set_privkeys(sc_hip_falcon_t *f, size_t nkeys, const double *sk)
 {
     if (f && f->P.n < 512) return fail("falcon_set_privkey: the tree sampler serves n = 512 and 1024");
-    if (!f || !sk) return fail("falcon_set_privkey: null argument");
+    if (!f || !sk || nkeys == 0) return fail("falcon_set_privkey: null argument");
+    if (nkeys > 0xffffffffu) return fail("falcon_set_privkey: too many keys");
     HIPCHK(hipSetDevice(f->ctx->device));
     const size_t n = f->P.n, total = (size_t)(f->P.n_bits + 5) * n;
-    std::vector<float> sig;
-    leaf_sigmas(sk + 4 * n, (unsigned)f->P.n_bits, sig);
+    std::vector<std::vector<float>> sig(nkeys);
     int ts = 2;
-    for (float s : sig) {
-        if (!(s > 0.0f) || !(s < 400.0f)) return fail("falcon_set_privkey: a tree leaf is not a usable standard deviation");
-        const int sz = sc_hip_cdt_table_size(10.0f, s);
-        if (sz > ts) ts = sz;
+    for (size_t kx = 0; kx < nkeys; kx++) {
+        leaf_sigmas(sk + kx * total + 4 * n, (unsigned)f->P.n_bits, sig[kx]);
+        for (float sg : sig[kx]) {
+            if (!(sg > 0.0f) || !(sg < 400.0f)) return fail("falcon_set_privkey: a tree leaf is not a usable standard deviation");
+            const int sz = sc_hip_cdt_table_size(10.0f, sg);
+            if (sz > ts) ts = sz;
+        }
     }
     int ts_log = 4;                                                    // kernels are instantiated for 16, 32 and 64 entries per leaf
     while ((1 << ts_log) < ts) ts_log++;
     if (ts_log > 6) return fail("falcon_set_privkey: a tree leaf needs a CDF table of more than 64 entries (sigma > 6.4)");
-    std::vector<uint64_t> tabs(n << ts_log, ~0ULL);
-    for (size_t i = 0; i < n; i++) {
-        const int sz = sc_hip_cdt_table_size(10.0f, sig[i]);
-        if (sz >= 2) { if (sc_hip_cdt_build_table(10.0f, sig[i], &tabs[i << ts_log], sz) != SC_HIP_SUCCESS) return SC_HIP_FAILURE; }
-        else tabs[i << ts_log] = 0;                                     // a one-entry table always yields 0
-    }
+    const size_t tper = n << ts_log;
+    std::vector<uint64_t> tabs(nkeys * tper, ~0ULL);
+    for (size_t kx = 0; kx < nkeys; kx++)
+        for (size_t i = 0; i < n; i++) {
+            const int sz = sc_hip_cdt_table_size(10.0f, sig[kx][i]);
+            uint64_t *row = &tabs[kx * tper + (i << ts_log)];
+            if (sz >= 2) { if (sc_hip_cdt_build_table(10.0f, sig[kx][i], row, sz) != SC_HIP_SUCCESS) return SC_HIP_FAILURE; }
+            else row[0] = 0;                                            // a one-entry table always yields 0
+        }
     if (f->d_tabs) { (void)sc::wipe_free(f->d_tabs); f->d_tabs = nullptr; }
+    if (f->d_sk) { (void)sc::wipe_free(f->d_sk); f->d_sk = nullptr; }
+    f->have_sk = false; f->nkeys = 0;
     HIPCHK(hipMalloc((void **)&f->d_tabs, tabs.size() * 8));
     HIPCHK(hipMemcpy(f->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
-    if (!f->d_sk) HIPCHK(hipMalloc((void **)&f->d_sk, total * sizeof(double)));
-    HIPCHK(hipMemcpy(f->d_sk, sk, total * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&f->d_sk, nkeys * total * sizeof(double)));
+    HIPCHK(hipMemcpy(f->d_sk, sk, nkeys * total * sizeof(double), hipMemcpyHostToDevice));
     f->ts_log = ts_log;
+    f->nkeys = nkeys;
     f->have_sk = true;
     return SC_HIP_SUCCESS;
 }
 
 // h: the public key in the coefficient domain, SINT16[n] (the first half of sc->pubkey->key, falcon.c:772-780)
-extern "C" int sc_hip_falcon_set_pubkey(sc_hip_falcon_t *f, const int16_t *h)
+extern "C" int sc_hip_falcon_set_pubkey(sc_hip_falcon_t *f, const int16_t *h) { return sc_hip_falcon_set_pubkeys(f, 1, h); }
+
+extern "C" int sc_hip_falcon_set_pubkeys(sc_hip_falcon_t *f, size_t nkeys, const int16_t *h)
 {
-    if (!f || !h) return fail("falcon_set_pubkey: null argument");
+    if (!f || !h || nkeys == 0) return fail("falcon_set_pubkey: null argument");
+    if (nkeys > 0xffffffffu) return fail("falcon_set_pubkey: too many keys");
     HIPCHK(hipSetDevice(f->ctx->device));
     const size_t n = f->P.n;
-    std::vector<int32_t> h32(n);
-    for (size_t i = 0; i < n; i++) { int32_t v = h[i] % f->P.q; if (v < 0) v += f->P.q; h32[i] = v; }
-    if (!f->d_hhat) HIPCHK(hipMalloc((void **)&f->d_hhat, n * 4));
-    HIPCHK(hipMemcpy(f->d_hhat, h32.data(), n * 4, hipMemcpyHostToDevice));
-    if (sc_hip_ntt_fwd(f->plan, 1, f->d_hhat, f->d_hhat, nullptr) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    std::vector<int32_t> h32(nkeys * n);
+    for (size_t i = 0; i < nkeys * n; i++) { int32_t v = h[i] % f->P.q; if (v < 0) v += f->P.q; h32[i] = v; }
+    if (f->d_hhat) { (void)sc::wipe_free(f->d_hhat); f->d_hhat = nullptr; }
+    f->have_pk = false; f->npk = 0;
+    HIPCHK(hipMalloc((void **)&f->d_hhat, nkeys * n * 4));
+    HIPCHK(hipMemcpy(f->d_hhat, h32.data(), nkeys * n * 4, hipMemcpyHostToDevice));
+    if (sc_hip_ntt_fwd(f->plan, nkeys, f->d_hhat, f->d_hhat, nullptr) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
     HIPCHK(hipStreamSynchronize(nullptr));
+    f->npk = nkeys;
     f->have_pk = true;
     return SC_HIP_SUCCESS;
 }
@@ -1669,7 +1694,7 @@ extern "C" size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *f)
 }
 
 static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s, unsigned long long *d_prof = nullptr)
+                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s, unsigned long long *d_prof = nullptr, const uint32_t *d_key_of = nullptr)
 {
     const double ni = 1.0 / (double)(long)f->P.q;                    /* fpr_inverse_of, falcon_fft.h:57-60 */
     if (tape_stride < 4 * (size_t)f->P.n) {                          // no tape can hold the 4n words a signature draws
@@ -1678,7 +1703,7 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     }
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
-    if (f->force_g == 0 || f->force_g == 64) {
+    if (!d_key_of && (f->force_g == 0 || f->force_g == 64)) {
         const dim3 grid8((unsigned)((batch + SPW - 1) / SPW)), block8(64);
 #define FAL_W8A(TSL, PR) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR>), grid8, block8, 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
                                             f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
@@ -1695,11 +1720,13 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
         return SC_HIP_SUCCESS;
     }
     // the two batch-interleaved mappings: a lane per signature, or 8 lanes per signature (the state in HBM either way)
-    const bool wide = f->force_g == 8;
+    // (a key per signature: 8 lanes per signature - the wavefront-per-8 mapping stages ONE key's lower tree and leaf tables in LDS)
+    const bool wide = f->force_g == 8 || (d_key_of && f->force_g != 1);
     const size_t threads = wide ? batch * 8 : batch;
+    const size_t sk_stride = (size_t)(f->P.n_bits + 5) * (size_t)f->P.n, tab_stride = (size_t)f->P.n << f->ts_log;
     const dim3 grid((unsigned)((threads + ST - 1) / ST)), block(ST);
 #define FAL_LAUNCH(TSL, G) hipLaunchKernelGGL((fal_sample_kernel<TSL, G>), grid, block, 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
-                                              f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni)
+                                              f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_key_of, (uint32_t)f->nkeys, sk_stride, tab_stride)
 #define FAL_PICK(TSL) do { if (wide) FAL_LAUNCH(TSL, 8); else FAL_LAUNCH(TSL, 1); } while (0)
     switch (f->ts_log) {
     case 4: FAL_PICK(4); break;
@@ -1760,9 +1787,28 @@ extern "C" int sc_hip_falcon_sample_profile(sc_hip_falcon_t *f, size_t batch, co
     return SC_HIP_SUCCESS;
 }
 
+static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                         const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
+
 extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                   const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                                   uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
+{ return fal_sign_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_status, stream); }
+
+// replaces: safecrypto_sign -> falcon_sig_sign for a batch of messages EACH under one of the keys loaded with sc_hip_falcon_set_privkeys: d_key_of[i] = the key's index
+// (distinct keys).  d_status[i] = 6 for an index outside the key set.
+extern "C" int sc_hip_falcon_sign_keys(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
+{
+    if (!d_key_of) return fail("falcon_sign_keys: null key index buffer");
+    return fal_sign_core(f, batch, d_key_of, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_status, stream);
+}
+
+static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                         const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
 {
     if (fal_check_common(f, batch, "falcon_sign")) return SC_HIP_FAILURE;
     if (!f->have_sk) return fail("falcon_sign: no private key loaded");
@@ -1779,15 +1825,44 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
-    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s)) return SC_HIP_FAILURE;
+    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s, nullptr, d_key_of)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
     HIPCHK(hipGetLastError());
     fal_wipe(f, batch, s);
     return SC_HIP_SUCCESS;
 }
 
+static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                           const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+
 extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                     const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{ return fal_verify_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_verdicts, stream); }
+
+// replaces: safecrypto_verify -> falcon_sig_verify for a batch of signatures EACH under one of the public keys loaded with sc_hip_falcon_set_pubkeys
+extern "C" int sc_hip_falcon_verify_keys(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
+{
+    if (!d_key_of) return fail("falcon_verify_keys: null key index buffer");
+    return fal_verify_core(f, batch, d_key_of, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_verdicts, stream);
+}
+
+// rows[i] = hhat[key_of[i]] (an index outside the key set: zeros, verdict 1)
+__global__ void fal_gather_keys_kernel(uint32_t batch, const uint32_t *__restrict__ key_of, uint32_t nkeys, const int32_t *__restrict__ hhat, int32_t *__restrict__ rows, int n,
+                                       uint32_t *__restrict__ verdicts)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t i = t / (size_t)(n / 4); const int j = (int)(t % (size_t)(n / 4));
+    if (i >= batch) return;
+    const uint32_t kx = key_of[i];
+    int4 v = make_int4(0, 0, 0, 0);
+    if (kx < nkeys) v = reinterpret_cast<const int4 *>(hhat + (size_t)kx * n)[j];
+    else if (j == 0) verdicts[i] = 1;
+    reinterpret_cast<int4 *>(rows + i * (size_t)n)[j] = v;
+}
+
+static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                           const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream)
 {
     if (fal_check_common(f, batch, "falcon_verify")) return SC_HIP_FAILURE;
     if (!f->have_pk) return fail("falcon_verify: no public key loaded");
@@ -1804,7 +1879,12 @@ extern "C" int sc_hip_falcon_verify(sc_hip_falcon_t *f, size_t batch, const uint
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
+    if (d_key_of) {                                                    // the public keys of the batch, gathered into the (otherwise idle) sampler workspace
+        int32_t *rows = reinterpret_cast<int32_t *>(f->ws);
+        hipLaunchKernelGGL(fal_gather_keys_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, s, B, d_key_of, (uint32_t)f->npk, f->d_hhat, rows, f->P.n, d_verdicts);
+        HIPCHK(hipGetLastError());
+        if (sc_hip_polymul_ntt(f->plan, batch, f->s2, rows, f->s1, s)) return SC_HIP_FAILURE;
+    } else if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;

@@ -23,7 +23,7 @@ SYMBOLS = [
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
     'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin',
-    'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_sig_bytes',
+    'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_set_privkeys', 'sc_hip_falcon_set_pubkeys', 'sc_hip_falcon_sign_keys', 'sc_hip_falcon_verify_keys', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
@@ -235,6 +235,10 @@ def load_library(path=LIB_PATH):
     L.sc_hip_falcon_destroy.restype = None
     L.sc_hip_falcon_set_privkey.argtypes = [vp, vp]
     L.sc_hip_falcon_set_pubkey.argtypes = [vp, vp]
+    L.sc_hip_falcon_set_privkeys.argtypes = [vp, sz, vp]
+    L.sc_hip_falcon_set_pubkeys.argtypes = [vp, sz, vp]
+    L.sc_hip_falcon_sign_keys.argtypes = [vp, sz, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.sc_hip_falcon_verify_keys.argtypes = [vp, sz, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_falcon_sig_bytes.argtypes = [vp]
     L.sc_hip_falcon_sig_bytes.restype = sz
     L.sc_hip_falcon_set_mapping.argtypes = [vp, C.c_int]
@@ -1230,6 +1234,43 @@ class Falcon:
         a = np.ascontiguousarray(np.asarray(h), dtype=np.int16)
         assert a.size == self.n
         _chk(self.L, self.L.sc_hip_falcon_set_pubkey(self.h, _ptr(a)), 'falcon_set_pubkey')
+
+    def set_privkeys(self, sks):
+        """a key set: float64 [nkeys][(n_bits+5)*n]"""
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(sks), dtype=np.float64)
+        per = (int(self.par[3]) + 5) * self.n
+        assert a.ndim == 2 and a.shape[1] == per
+        _chk(self.L, self.L.sc_hip_falcon_set_privkeys(self.h, a.shape[0], _ptr(a)), 'falcon_set_privkeys')
+
+    def set_pubkeys(self, hs):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(hs), dtype=np.int16)
+        assert a.ndim == 2 and a.shape[1] == self.n
+        _chk(self.L, self.L.sc_hip_falcon_set_pubkeys(self.h, a.shape[0], _ptr(a)), 'falcon_set_pubkeys')
+
+    def sign_keys(self, key_of, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        """key_of int32 [batch] (device): the index, in the loaded key set, of the key each message is signed under"""
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        assert key_of.dtype == torch.int32 and key_of.numel() == batch and key_of.is_contiguous()
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_falcon_sign_keys(self.h, batch, _ptr(key_of), _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                    _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
+                                                    _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(status), _stream()), 'falcon_sign_keys')
+        return sigs, siglens, status
+
+    def verify_keys(self, key_of, msgs, sigs, siglens, mlens=None, fixed_len=0):
+        import torch
+        batch = msgs.shape[0]
+        assert key_of.dtype == torch.int32 and key_of.numel() == batch and key_of.is_contiguous()
+        verdicts = torch.ones(batch, dtype=torch.int32, device=msgs.device)
+        _chk(self.L, self.L.sc_hip_falcon_verify_keys(self.h, batch, _ptr(key_of), _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
+                                                      _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'falcon_verify_keys')
+        return verdicts
 
     def sample_profile(self, c, tapes):
         """measurement hook: the default mapping's sampler, returns (s1, s2, cycles[6]) - shader cycles per phase summed over wavefronts"""

@@ -15,6 +15,7 @@
  *        ref_driver bench_dlp <set> <seconds>    (single-thread safecrypto_ibe_extract, DLP-IBE)
  *        ref_driver bench_rlwe <set> <seconds>   (single-thread safecrypto_public_encrypt / safecrypto_private_decrypt, RLWE-Enc)
  *        ref_driver bench_dil|bench_falcon|bench_bliss <set> <seconds>
+ *        ref_driver falcon_keys <set> <nkeys> <outfile>
  *                                                (single-thread safecrypto_sign / safecrypto_verify, 64-byte messages)
  *
  * Fixture format (one file per topic): repeated records
@@ -1260,6 +1261,53 @@ static int falcon_case(FILE *f, int set, int nsamp, int nmsg)
     return 0;
 }
 
+/* `nkeys` key pairs from the reference's own keygen, each with its expanded private key, its public key and one signature with the CSPRNG words
+ * signing consumed: the distinct-key parity test runs this on the box it runs on (no fixture of this size is committed).
+ * Usage: ref_driver falcon_keys <set> <nkeys> <outfile> */
+static int falcon_keys(int set, int nkeys, const char *path)
+{
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96];
+    sm_state = 0xfa1c7000ULL + (uint64_t)set;
+    for (int kx = 0; kx < nkeys; kx++) {
+        safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_FALCON, set, flags);
+        if (!sc) return 1;
+        if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+        const falcon_set_t *P = sc->falcon->params;
+        const int n = P->n, logn = P->n_bits;
+        if (kx == 0) {
+            int32_t par[8] = { P->n, P->q, P->q_bits, P->n_bits, set, 0, 0, 0 };
+            float bd = P->bd; memcpy(&par[5], &bd, 4);
+            rec_i32(f, "params", par, 8);
+        }
+        snprintf(name, sizeof name, "k%d_h", kx); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+        snprintf(name, sizeof name, "k%d_sk", kx); rec_f64(f, name, sc->falcon->sk, (size_t)(logn + 5) * n);
+        uint8_t msg[64], seed[32];
+        for (int i = 0; i < 64; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *orig = sc->prng_ctx[0];
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *sig = NULL; size_t siglen = 0;
+        int32_t st = safecrypto_sign(sc, msg, 64, &sig, &siglen);
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "k%d_msg", kx); rec_u8(f, name, msg, 64);
+        snprintf(name, sizeof name, "k%d_tape", kx); rec_i32(f, name, tape, words);
+        snprintf(name, sizeof name, "k%d_sig", kx); rec_u8(f, name, sig, st == SC_FUNC_SUCCESS ? siglen : 0);
+        snprintf(name, sizeof name, "k%d_status", kx); rec_i32(f, name, &st, 1);
+        free(tape); free(sig);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+        safecrypto_destroy(sc);
+    }
+    fclose(f);
+    return 0;
+}
+
 static int gen_falcon(const char *dir)
 {
     char path[512];
@@ -1469,6 +1517,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_enssig")) return bench_sig(SC_SCHEME_SIG_ENS, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_dlpsig")) return bench_sig(SC_SCHEME_SIG_DLP, atoi(argv[2]), atof(argv[3]));
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
+    if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;

@@ -181,3 +181,62 @@ def test_full_size_config5(eng, G):
         s2_, l2_, st2_ = f.sign(msgs, tapes, fixed_len=64)
         assert torch.equal(s2_, sigs) and torch.equal(l2_, siglens) and torch.equal(st2_, status), lanes
     f.close()
+
+
+def test_distinct_keys_from_the_reference_keygen(eng, tmp_path):
+    """SURVEY 8(d) distinct keys: 64 Falcon-512 key pairs generated HERE by the reference's own keygen (oracle/_ref/ref_driver falcon_keys; the
+    binary travels to the GPU box), each with a signature the reference produced under it and the CSPRNG words that took.  The key set is loaded
+    once; a batch naming a key per message reproduces every reference signature, the oracle's on seeded tapes, verifies under the right keys only,
+    and reports an index outside the set"""
+    import os, subprocess, torch
+    drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'ref_driver')
+    if not os.path.exists(drv):
+        pytest.skip('oracle/_ref/ref_driver not built')
+    NK = 64
+    out = os.path.join(str(tmp_path), 'fk.txt')
+    subprocess.check_call([drv, 'falcon_keys', '0', str(NK), out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    K = load_golden(out)
+    keys = [O.FalconKey(K['params'], K[f'k{i}_sk'], K[f'k{i}_h']) for i in range(NK)]
+    n = keys[0].n
+    f = eng.falcon(keys[0].par)
+    f.set_privkeys(np.stack([k.sk for k in keys]))
+    f.set_pubkeys(np.stack([k.h for k in keys]))
+    # (a) the reference's own signature under every key, then (b) three more messages per key on seeded tapes, keys interleaved
+    rng = np.random.default_rng(5)
+    msgs = [bytes(np.asarray(K[f'k{i}_msg'], dtype=np.uint8)) for i in range(NK)]
+    tapes = [u32(K[f'k{i}_tape'])[:4 * n] for i in range(NK)]
+    key_of = list(range(NK))
+    for r in range(3):
+        for i in range(NK):
+            msgs.append(bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8)))
+            tapes.append(rng.integers(0, 2**32, size=4 * n, dtype=np.uint64).astype(np.uint32))
+            key_of.append((i * 7 + r) % NK)
+    msgs.append(b'x'); tapes.append(tapes[0]); key_of.append(NK)              # no such key
+    B = len(msgs)
+    mb, ml = pack_msgs(msgs)
+    ko = torch.tensor(key_of, dtype=torch.int32, device='cuda')
+    tp = torch.from_numpy(np.stack(tapes).view(np.int32)).cuda()
+    sigs, siglens, status = f.sign_keys(ko, mb, tp, mlens=ml)
+    torch.cuda.synchronize()
+    sh, lh, st = sigs.cpu().numpy(), siglens.cpu().numpy(), status.cpu().numpy()
+    assert st[B - 1] == 6 and lh[B - 1] == 0
+    for i in range(NK):
+        want = bytes(np.asarray(K[f'k{i}_sig'], dtype=np.uint8))
+        assert (int(K[f'k{i}_status'][0]) == 0) == (st[i] == 1), i
+        if st[i] == 1:
+            assert bytes(sh[i, :lh[i]]) == want, i
+    for i in range(NK, B - 1):
+        rc, sig = O.falcon_sign(keys[key_of[i]], msgs[i], tapes[i])
+        assert (rc, st[i]) in ((0, 1), (1, 4)), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == sig, i
+    ok = torch.from_numpy(st == 1).cuda()
+    assert int(ok.sum()) >= B - 6
+    v = f.verify_keys(ko, mb, sigs, siglens, mlens=ml)
+    assert int(v[ok].sum()) == 0 and int(v[B - 1]) == 1
+    wrong = ((ko + 1) % NK).to(torch.int32).contiguous()
+    assert int((f.verify_keys(wrong, mb, sigs, siglens, mlens=ml) == 0).sum()) == 0
+    # the one-key calls use key 0 of the set
+    s0, l0, t0 = f.sign(mb[:1], tp[:1], mlens=ml[:1])
+    assert int(t0[0]) == st[0] and bytes(s0[0, :int(l0[0])].cpu().numpy()) == bytes(sh[0, :lh[0]])
+    f.close()
