@@ -254,6 +254,24 @@ def falcon_extra(eng, torch, cpu_seconds, sets=(('falcon2', 2, (8192, 131072)), 
             res['roofline'] = valu_roofline('falcon_sign', r, 64 + 1536 + 16384,
                                             'batch 8192: 64 B message + 16 KB tape in, 1536 B signature out per operation (sampler alone, SURVEY 8(d) row 5: c 4 KB in, s1 + s2 8 KB out); '
                                             'the sampler is a 2n-leaf sequential walk per signature: latency- and f64-issue-bound, its HBM traffic is the spilled working set')
+        if set_ == 2:
+            # SURVEY 8(d) distinct keys: a resident key set, a key index per message (the fixture key loaded 64 times: distinct memory, same values)
+            NK, B = 64, 8192
+            sk = np.asarray(G[f'{tag}_sk'], dtype=np.int64).view(np.float64)
+            f.set_privkeys(np.tile(sk, (NK, 1))); f.set_pubkeys(np.tile(np.asarray(G[f'{tag}_h'], dtype=np.int16), (NK, 1)))
+            msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+            tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
+            ko = (torch.arange(B, device='cuda') % NK).to(torch.int32)
+            f.sign_keys(ko, msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+            ts, tv = [], []
+            for _ in range(3):
+                t0 = time.perf_counter(); sigs, siglens, status = f.sign_keys(ko, msgs, tapes, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+                t0 = time.perf_counter(); v = f.verify_keys(ko, msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+            assert int(v[status == 1].sum()) == 0
+            res['distinct_keys'] = {'workload': f'batch {B}, a key set of {NK} resident keys, key index per message (8 lanes per signature, keys read where they lie)',
+                                    'sign_ops_per_s': B / min(ts), 'verify_ops_per_s': B / min(tv),
+                                    'key_bytes_per_key': int((f.n * 15 + (f.n << 5)) * 8 + 2 * f.n)}
+            del msgs, tapes, sigs
         out[f'falcon_{f.n}'] = res
         f.close()
     return out
