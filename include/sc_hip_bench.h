@@ -31,6 +31,10 @@ int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, const uint8_t *
 int sc_hip_falcon_sample_profile(sc_hip_falcon_t *h, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride,
                                  int32_t *d_s1, int32_t *d_s2, unsigned long long *h_cycles, void *stream);
 
+/* pin the variant of the Falcon sampler's default mapping: signatures per wavefront (8 or 4) and the sub-tree level kept in LDS (7 or 6);
+ * 0, 0: chosen per batch (the production setting).  Results do not depend on it. */
+int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
+
 /* Dilithium signer: (slots_per_message & 0xFF) > 0 fixes the number of attempts evaluated side by side per message in the first round (0: the
  * built-in rule, about 48 K slots per round); ((slots_per_message >> 8) & 0xFF) = g > 0 caps the depth of round r at S0 * g^r instead of letting
  * it fill the slot budget; unfused != 0 runs NTT(y) and the matrix product as two kernels instead of the fused one */

@@ -539,20 +539,35 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
 //     (read) and results (written) are in HBM.  The 8-coefficient sub-trees at the bottom run in registers, the same on every lane of a group.
 // Per signature the tree therefore moves 9 rows of n doubles through HBM per level ABOVE LM only (3 levels for n = 1024, 2 for n = 512)
 // instead of 7 / 6 levels.  Values are computed by the same operations in the same order as in the other mappings: the doubles are unchanged.
-constexpr int LM = 7;                          // sub-tree level whose descendants live in LDS
-constexpr int SPW = 8;                         // signatures per wavefront (= 64 / lanes per signature in group mode)
-constexpr int LDS_SIG = 3 << LM;               // doubles of LDS per signature: X (2^LM: the level-LM node's children's inputs) | scratch (2 * 2^LM)
+// Two knobs, both template parameters of the kernel (the launcher picks, fal_launch_sample):
+//   LM  - the sub-tree level whose descendants live in LDS (7 or 6).  LDS per signature: 3 * 2^LM doubles.
+//   SPW - signatures per wavefront (8 or 4).  Group mode always gives a signature 8 lanes; with SPW = 4 the upper half of the wavefront idles there
+//         and joins in for the wave-mode sweeps.
+// A lone wavefront issues one VALU instruction per ~10 cycles on this part, two on the same SIMD one per ~5 between them (tools/exp_place.hip,
+// profiles/r02_valu_issue_vs_occupancy.txt), and the register sub-trees and LDS levels of this kernel are issue-bound: a second wavefront per SIMD
+// is nearly free for them.  That takes a footprint of at most 20 KB of LDS (8 workgroups per CU): (8, 7) needs 37 KB - one wavefront per SIMD however
+// large the batch; (8, 6) 19.5 KB.  What (8, 6) gains on the issue-bound phases it partly loses on the sweeps that go through HBM (one more level of
+// them, and twice the wavefronts behind the same memory system): +16 % at large batches, -9 % at the BASELINE batch of 8192 (1024 wavefronts either way).
+// SPW = 4 doubles the wavefronts of a small batch, but the group-mode phases cost a wavefront the same whether 8 or 4 groups are live, so the
+// instructions per signature double with it: no gain (measured, kept behind the measurement hook).
+constexpr int SPW_MAX = 8;                     // the workspace is padded to whole wavefronts of the widest variant
 
 struct Lin {                                   // plain layout in HBM
     double *p;
     __device__ __forceinline__ double ld(uint32_t e) const { return p[e]; }
     __device__ __forceinline__ void st(uint32_t e, double v) const { p[e] = v; }
+    // elements e, e + 1 for even e: one 16-byte access (every offset the sweeps pass is even, the workspace is 16-byte aligned)
+    __device__ __forceinline__ double2 ld2(uint32_t e) const { return *reinterpret_cast<const double2 *>(p + e); }
+    __device__ __forceinline__ void st2(uint32_t e, double a, double b) const { *reinterpret_cast<double2 *>(p + e) = make_double2(a, b); }
 };
-struct LdsG {                                  // LDS, group mode: element e of the lane's signature s at (e / 8) * 64 + s * 8 + e % 8 (p = base + s * 8):
-    double *p;                                 // the 8 lanes of a group on 8 consecutive elements + 8 groups = 64 consecutive doubles
-    __device__ __forceinline__ uint32_t at(uint32_t e) const { return ((e >> 3) << 6) | (e & 7); }
+template <int SPW>
+struct LdsG {                                  // LDS, group mode: element e of the lane's signature s at (e / 8) * 8 SPW + s * 8 + e % 8 (p = base + s * 8):
+    double *p;                                 // the 8 lanes of a group on 8 consecutive elements + SPW groups = 8 SPW consecutive doubles
+    __device__ __forceinline__ uint32_t at(uint32_t e) const { return (e >> 3) * (8 * SPW) + (e & 7); }
     __device__ __forceinline__ double ld(uint32_t e) const { return p[at(e)]; }
     __device__ __forceinline__ void st(uint32_t e, double v) const { p[at(e)] = v; }
+    __device__ __forceinline__ double2 ld2(uint32_t e) const { return *reinterpret_cast<const double2 *>(p + at(e)); }
+    __device__ __forceinline__ void st2(uint32_t e, double a, double b) const { *reinterpret_cast<double2 *>(p + at(e)) = make_double2(a, b); }
 };
 
 struct LdsF {                                  // LDS, wave mode: a polynomial being transformed; one double of padding after every 8 keeps the three
@@ -585,7 +600,8 @@ __device__ __forceinline__ void split_sw(const D &d, uint32_t f0, uint32_t f1, c
         for (int k = 0; k < SU; k++) {
             const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
             if (!GD || v < tot) {
-                ar[k] = s.ld(so + f + 2 * u); ai[k] = s.ld(so + f + 2 * u + hn); br[k] = s.ld(so + f + 2 * u + 1); bi[k] = s.ld(so + f + 2 * u + 1 + hn);
+                const double2 re = s.ld2(so + f + 2 * u), im = s.ld2(so + f + 2 * u + hn);
+                ar[k] = re.x; br[k] = re.y; ai[k] = im.x; bi[k] = im.y;
                 gr[k] = gm[(u + hn) << 1]; gi[k] = gm[((u + hn) << 1) + 1];
             }
         }
@@ -624,8 +640,8 @@ __device__ __forceinline__ void merge_sw(const D &d, uint32_t f, const S &s, uin
             if (!GD || v < tot) {
                 double br, bi;
                 cmul(br, bi, cr[k], ci[k], gr[k], gi[k]);
-                d.st(so + f + 2 * u, ar[k] + br); d.st(so + f + 2 * u + hn, ai[k] + bi);
-                d.st(so + f + 2 * u + 1, ar[k] - br); d.st(so + f + 2 * u + 1 + hn, ai[k] - bi);
+                d.st2(so + f + 2 * u, ar[k] + br, ar[k] - br);
+                d.st2(so + f + 2 * u + hn, ai[k] + bi, ai[k] - bi);
             }
         }
     }
@@ -645,8 +661,9 @@ __device__ __forceinline__ void mid_sw(const CH &ch, uint32_t cho, const TT &t, 
             const uint32_t v = v0 + k * G + g, u = v & (qn - 1), so = NS == 1 ? 0u : (v >> (l - 2)) * per;
             if (!GD || v < tot) {
                 ar[k] = ch.ld(so + cho + u); ai[k] = ch.ld(so + cho + u + qn); cr[k] = ch.ld(so + cho + hm + u); cim[k] = ch.ld(so + cho + hm + u + qn);
-                p1[k][0] = t.ld(so + pt1 + 2 * u); p1[k][1] = t.ld(so + pt1 + 2 * u + hm); p1[k][2] = t.ld(so + pt1 + 2 * u + 1); p1[k][3] = t.ld(so + pt1 + 2 * u + 1 + hm);
-                p0[k][0] = t.ld(so + pt0 + 2 * u); p0[k][1] = t.ld(so + pt0 + 2 * u + hm); p0[k][2] = t.ld(so + pt0 + 2 * u + 1); p0[k][3] = t.ld(so + pt0 + 2 * u + 1 + hm);
+                const double2 a1 = t.ld2(so + pt1 + 2 * u), b1 = t.ld2(so + pt1 + 2 * u + hm), a0 = t.ld2(so + pt0 + 2 * u), b0 = t.ld2(so + pt0 + 2 * u + hm);
+                p1[k][0] = a1.x; p1[k][1] = b1.x; p1[k][2] = a1.y; p1[k][3] = b1.y;
+                p0[k][0] = a0.x; p0[k][1] = b0.x; p0[k][2] = a0.y; p0[k][3] = b0.y;
                 gr[k] = gm[(u + hm) << 1]; gi[k] = gm[((u + hm) << 1) + 1];
                 lv[k][0] = L[2 * u]; lv[k][1] = L[2 * u + hm]; lv[k][2] = L[2 * u + 1]; lv[k][3] = L[2 * u + 1 + hm];
             }
@@ -658,8 +675,7 @@ __device__ __forceinline__ void mid_sw(const CH &ch, uint32_t cho, const TT &t, 
                 double br, bi;
                 cmul(br, bi, cr[k], cim[k], gr[k], gi[k]);
                 const double e_r = ar[k] + br, e_i = ai[k] + bi, o_r = ar[k] - br, o_i = ai[k] - bi;     // z1 at complex slots 2u, 2u+1
-                zo.st(so + pz1 + 2 * u, e_r); zo.st(so + pz1 + 2 * u + hm, e_i);
-                zo.st(so + pz1 + 2 * u + 1, o_r); zo.st(so + pz1 + 2 * u + 1 + hm, o_i);
+                zo.st2(so + pz1 + 2 * u, e_r, o_r); zo.st2(so + pz1 + 2 * u + hm, e_i, o_i);
                 double xr = p1[k][0] - e_r, xi = p1[k][1] - e_i;
                 cmul(xr, xi, xr, xi, lv[k][0], lv[k][1]);
                 xr = xr + p0[k][0]; xi = xi + p0[k][1];
@@ -829,7 +845,9 @@ struct LeafPre {
     }
 };
 
+template <int LM>
 struct WalkL {
+    static constexpr int LDS_SIG = 3 << LM;   // doubles of LDS per signature: X (2^LM: the level-LM node's children's inputs) | scratch (2 * 2^LM)
     uint32_t n; int logn; uint32_t ph;      // ph bit l: the node on the current path at level l is in its second half
     // HBM offsets inside a signature's 6n doubles (C0 | C1 | Z0 | Z1 | T), levels >= LM: the reference's own pointer layout (gpv.c:2693-2711)
     __device__ __forceinline__ uint32_t tmp(int l) const { return 6 * n - (2u << l); }
@@ -846,18 +864,23 @@ struct WalkL {
     __device__ __forceinline__ uint32_t lt1(int l) const { return lt0(l) + (1u << l); }
 };
 
-// gaussian_sample_with_tree, 8 signatures per wavefront (one wavefront per workgroup).  ws: 6n doubles per signature, padded to a multiple of 8
+// gaussian_sample_with_tree, SPW signatures per wavefront (one wavefront per workgroup).  ws: 6n doubles per signature, padded to a multiple of 8
 // signatures.  tape_stride >= 4n (the launcher answers shorter strides itself): a tape that is short is still read to 4n words - inside its
 // own row - and its signature reports status 2 and writes nothing.
 // PROF (measurement builds only, sc_hip_falcon_sample_profile): each wavefront adds the shader cycles it spent in the six phases to prof[0..5].
-template <int TSL, bool PROF>
+template <int TSL, bool PROF, int SPW, int LM>
 __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, double *__restrict__ ws, const int32_t *__restrict__ c,
                                                            const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
                                                            const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                            int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
                                                            unsigned long long *__restrict__ prof)
 {
-    __shared__ double lds[SPW * LDS_SIG];
+    constexpr int LDS_SIG = WalkL<LM>::LDS_SIG;
+    constexpr int POLY = 1024 + 128;                                   // a padded polynomial (LdsF) for n <= 1024
+    constexpr int NSF = (SPW * LDS_SIG >= 2 * POLY) ? 2 : 1;           // polynomials transformed side by side
+    constexpr int LDSD = SPW * LDS_SIG > NSF * POLY ? SPW * LDS_SIG : NSF * POLY;
+    constexpr int SU_LM = LM >= 6 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) double lds[LDSD];
     __shared__ uint64_t stab[8 << TSL];                                // the current register sub-tree's 8 leaf tables
     __shared__ __attribute__((aligned(16))) uint32_t stape[SPW * 32];  // and its 8 x 4 tape words per signature
     __shared__ double stree[(LM + 1) << LM];                           // the LDL tree block of the current level-LM node (falcon_ldl.h:56-71: treesize(LM) doubles)
@@ -866,30 +889,32 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #define FAL_STAMP(ph) do { if (PROF) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); pc[ph] += tn_ - tprev; tprev = tn_; } } while (0)
     constexpr int FK = FK8;
-    const uint32_t lane = threadIdx.x, sg = lane >> 3, g = lane & 7;
+    const uint32_t lane = threadIdx.x, g = lane & 7;
+    const bool act = lane < 8 * SPW;                                   // group mode: the lanes that have a signature (all of them for SPW = 8)
+    const uint32_t sg = act ? lane >> 3 : 0;
     const uint32_t sig0 = blockIdx.x * SPW;
     const uint32_t n = (uint32_t)P.n, hn = n >> 1; const int logn = P.n_bits;
     const uint32_t per = 6 * n;
-    const Lin wv = { ws + (size_t)sig0 * per };                        // wave mode: the 8 signatures, `per` doubles apart
+    const Lin wv = { ws + (size_t)sig0 * per };                        // wave mode: the SPW signatures, `per` doubles apart
     const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
     const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n;
     // group mode: this lane's signature.  A signature past the end of the batch is computed on item 0's inputs (in its own workspace slot).
     const uint32_t mysig = sig0 + sg;
     const bool inb = mysig < batch;
     const uint32_t item = inb ? mysig : 0;
-    const bool shortt = inb && tape_lens && tape_lens[mysig] < 4 * n;
+    const bool shortt = act && inb && tape_lens && tape_lens[mysig] < 4 * n;
     if (shortt && g == 0) status[mysig] = 2;
-    const uint64_t runmask = __ballot(inb && !shortt);                  // bit 8k: signature k of this wavefront writes its results
+    const uint64_t runmask = __ballot(act && inb && !shortt);           // bit 8k: signature k of this wavefront writes its results
     const Lin mine = { wv.p + (size_t)sg * per };
-    const LdsG lg = { lds + sg * 8 };
+    const LdsG<SPW> lg = { lds + sg * 8 };
     for (uint32_t i = lane; i < (2u << LM); i += 64) sgm[i] = gm[i];
     uint32_t toffLM = 0;                                               // tree offset of the current level-LM node
     const int ln = logn;                                               // log2 of the elements per signature in the flattened loops
 
-    // ---- FFT(c) and the two target vectors (gpv.c:3040-3054): two signatures at a time through LDS (n doubles each, padded)
-    const LdsF lf2 = { lds };                                          // 2 * (n + n/8) <= SPW * LDS_SIG doubles for n <= 1024
-    for (int pr = 0; pr < SPW; pr += 2) {
-        for (uint32_t t0 = 0; t0 < 2 * n; t0 += 4 * 4 * 64) {
+    // ---- FFT(c) and the two target vectors (gpv.c:3040-3054): NSF signatures at a time through LDS (n doubles each, padded)
+    const LdsF lf2 = { lds };
+    for (int pr = 0; pr < SPW; pr += NSF) {
+        for (uint32_t t0 = 0; t0 < NSF * n; t0 += 4 * 4 * 64) {
             int4 cv[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -899,12 +924,12 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t t = t0 + (j * 64 + lane) * 4;
-                lf2.st(t, (double)cv[j].x); lf2.st(t + 1, (double)cv[j].y); lf2.st(t + 2, (double)cv[j].z); lf2.st(t + 3, (double)cv[j].w);
+                if (NSF == 2 || t < n) { lf2.st(t, (double)cv[j].x); lf2.st(t + 1, (double)cv[j].y); lf2.st(t + 2, (double)cv[j].z); lf2.st(t + 3, (double)cv[j].w); }
             }
         }
         wave_sync();
-        fft_w<2>(lf2, lane, 0, n, logn, gm);
-        for (uint32_t t0 = 0; t0 < 2 * hn; t0 += 4 * 64) {
+        fft_w<NSF>(lf2, lane, 0, n, logn, gm);
+        for (uint32_t t0 = 0; t0 < NSF * hn; t0 += 4 * 64) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t t = t0 + j * 64 + lane, k = t >> (ln - 1), u = t & (hn - 1), e = (pr + k) * per + u;
@@ -930,11 +955,11 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
             const uint64_t *src = tabs + ((size_t)first << TSL) + lane * TPL;
 #pragma unroll
             for (int i = 0; i < TPL; i += 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + i); ptab[i] = v.x; ptab[i + 1] = v.y; }
-            ptape = *reinterpret_cast<const uint4 *>(mytape + 4 * (size_t)(first + g));
+            if (act) ptape = *reinterpret_cast<const uint4 *>(mytape + 4 * (size_t)(first + g));
         }
     };
     prefetch(0);
-    WalkL w = { n, logn, 0 };
+    WalkL<LM> w = { n, logn, 0 };
     uint32_t toff = 0;
     int l = logn;
     bool entering = true;
@@ -945,18 +970,20 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 // an 8-coefficient sub-tree in registers; every lane of a group computes the same thing from the same (broadcast) LDS words
 #pragma unroll
                 for (int i = 0; i < TPL; i++) stab[lane * TPL + i] = ptab[i];
-                *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
+                if (act) *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
                 wave_sync();
-                double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
-                const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
+                if (act) {
+                    double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
+                    const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
 #pragma unroll
-                for (int i = 0; i < (1 << FK); i++) { t0r[i] = lg.ld(pt0 + i); t1r[i] = lg.ld(pt1 + i); }
-                LeafPre<TSL> lfl;
-                lfl.draw(stab, stape + sg * 32, g);
-                FFS<FK, LeafPre<TSL>>::run(z0r, z1r, stree + (toff - toffLM), t0r, t1r, gm, lfl);
-                if (g == 0) {
+                    for (int i = 0; i < (1 << FK); i++) { t0r[i] = lg.ld(pt0 + i); t1r[i] = lg.ld(pt1 + i); }
+                    LeafPre<TSL> lfl;
+                    lfl.draw(stab, stape + sg * 32, g);
+                    FFS<FK, LeafPre<TSL>>::run(z0r, z1r, stree + (toff - toffLM), t0r, t1r, gm, lfl);
+                    if (g == 0) {
 #pragma unroll
-                    for (int i = 0; i < (1 << FK); i++) { lg.st(pz0 + i, z0r[i]); lg.st(pz1 + i, z1r[i]); }
+                        for (int i = 0; i < (1 << FK); i++) { lg.st(pz0 + i, z0r[i]); lg.st(pz1 + i, z1r[i]); }
+                    }
                 }
                 leaf += 1u << FK;
                 prefetch(leaf);
@@ -966,14 +993,18 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 continue;
             }
             if (l > LM) split_sw<64, 2, SPW, false>(wv, w.z1(l), w.z1(l) + hm, wv, w.t1(l), lane, l, per, gm);
-            else if (l == LM) {
-                toffLM = toff;
-                for (uint32_t i = lane * 2; i < treesize(LM); i += 128) *reinterpret_cast<double2 *>(stree + i) = *reinterpret_cast<const double2 *>(tree + toff + i);
-                split_sw<8, 2, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, sgm);
+            else {
+                if (l == LM) {
+                    toffLM = toff;
+                    for (uint32_t i = lane * 2; i < treesize(LM); i += 128) *reinterpret_cast<double2 *>(stree + i) = *reinterpret_cast<const double2 *>(tree + toff + i);
+                }
+                if (act) {
+                    if (l == LM) split_sw<8, SU_LM, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, sgm);
+                    else if (l >= 6) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                    else if (l == 5) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                    else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                }
             }
-            else if (l == LM - 1) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
-            else if (l == LM - 2) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
-            else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
             wave_sync();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph &= ~(1u << l);
@@ -985,10 +1016,12 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
             const double *L = tree + toff;
             const double *LL = stree + (toff - toffLM);                // the same block in LDS (levels <= LM)
             if (l > LM) mid_sw<64, 2, SPW, false>(wv, w.tmp(l), wv, w.t0(l), w.t1(l), wv, w.z1(l), wv, w.z0(l), lane, l, per, gm, L);
-            else if (l == LM) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, sgm, LL);
-            else if (l == LM - 1) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
-            else if (l == LM - 2) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
-            else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+            else if (act) {
+                if (l == LM) mid_sw<8, SU_LM, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, sgm, LL);
+                else if (l >= 6) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+                else if (l == 5) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+                else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+            }
             wave_sync();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph |= 1u << l;
@@ -998,10 +1031,12 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
         }
         toff -= m;
         if (l > LM) merge_sw<64, 2, SPW, false>(wv, w.z0(l), wv, w.tmp(l), w.tmp(l) + hm, lane, l, per, gm);
-        else if (l == LM) merge_sw<8, 2, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-        else if (l == LM - 1) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-        else if (l == LM - 2) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-        else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+        else if (act) {
+            if (l == LM) merge_sw<8, SU_LM, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else if (l >= 6) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else if (l == 5) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+        }
         wave_sync();
         FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
         w.ph &= ~(1u << l);
@@ -1010,46 +1045,52 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     }
 
     // ---- lattice point (gpv.c:3064-3076): c0 <- z0*b00 + z1*b10 ; c1 <- z1*b11 + z0*b01, the inverse transforms and the roundings: one
-    // signature at a time, its two polynomials side by side in LDS
+    // signature at a time, its two polynomials side by side in LDS (NSF = 2) or one after the other
     const double sc2 = ldexp(2.0, -logn);                           // falcon_fft.c:370-377
     for (int k = 0; k < SPW; k++) {
-        for (uint32_t u0 = 0; u0 < hn; u0 += 4 * 64) {
-            double z0r[4], z0i[4], z1r[4], z1i[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t e = k * per + u0 + j * 64 + lane;
-                z0r[j] = wv.ld(e + Z0); z0i[j] = wv.ld(e + Z0 + hn); z1r[j] = wv.ld(e + Z1); z1i[j] = wv.ld(e + Z1 + hn);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t u = u0 + j * 64 + lane;
-                double pr, pi, qr, qi;
-                cmul(pr, pi, z0r[j], z0i[j], b00[u], b00[u + hn]);
-                cmul(qr, qi, z1r[j], z1i[j], b10[u], b10[u + hn]);
-                lf2.st(u, pr + qr); lf2.st(u + hn, pi + qi);
-                cmul(pr, pi, z0r[j], z0i[j], b01[u], b01[u + hn]);
-                cmul(qr, qi, z1r[j], z1i[j], b11[u], b11[u + hn]);
-                lf2.st(n + u, qr + pr); lf2.st(n + u + hn, qi + pi);
-            }
-        }
-        wave_sync();
-        ifft_w<2>(lf2, lane, 0, n, logn, gm);
-        if ((runmask >> (8 * k)) & 1) {
-            const size_t ob = (size_t)(sig0 + k) * n;
-            for (uint32_t i0 = 0; i0 < n; i0 += 4 * 64) {
-                int32_t cv[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) cv[j] = c[ob + i0 + j * 64 + lane];
+        for (int half = 0; half < (NSF == 2 ? 1 : 2); half++) {
+            for (uint32_t u0 = 0; u0 < hn; u0 += 4 * 64) {
+                double z0r[4], z0i[4], z1r[4], z1i[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t i = i0 + j * 64 + lane;
-                    const long long r0 = (long long)rint(lf2.ld(i) * sc2), r1 = (long long)rint(lf2.ld(n + i) * sc2);
-                    if (s1) s1[ob + i] = (int32_t)((long long)cv[j] - r0);
-                    s2[ob + i] = (int32_t)-r1;
+                    const uint32_t e = k * per + u0 + j * 64 + lane;
+                    z0r[j] = wv.ld(e + Z0); z0i[j] = wv.ld(e + Z0 + hn); z1r[j] = wv.ld(e + Z1); z1i[j] = wv.ld(e + Z1 + hn);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t u = u0 + j * 64 + lane;
+                    double pr, pi, qr, qi;
+                    if (NSF == 2 || half == 0) {
+                        cmul(pr, pi, z0r[j], z0i[j], b00[u], b00[u + hn]);
+                        cmul(qr, qi, z1r[j], z1i[j], b10[u], b10[u + hn]);
+                        lf2.st(u, pr + qr); lf2.st(u + hn, pi + qi);
+                    }
+                    if (NSF == 2 || half == 1) {
+                        const uint32_t o = NSF == 2 ? n : 0u;
+                        cmul(pr, pi, z0r[j], z0i[j], b01[u], b01[u + hn]);
+                        cmul(qr, qi, z1r[j], z1i[j], b11[u], b11[u + hn]);
+                        lf2.st(o + u, qr + pr); lf2.st(o + u + hn, qi + pi);
+                    }
                 }
             }
+            wave_sync();
+            ifft_w<NSF>(lf2, lane, 0, n, logn, gm);
+            if ((runmask >> (8 * k)) & 1) {
+                const size_t ob = (size_t)(sig0 + k) * n;
+                for (uint32_t i0 = 0; i0 < n; i0 += 4 * 64) {
+                    int32_t cv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) cv[j] = (NSF == 2 || half == 0) ? c[ob + i0 + j * 64 + lane] : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t i = i0 + j * 64 + lane;
+                        if (NSF == 2 || half == 0) { const long long r0 = (long long)rint(lf2.ld(i) * sc2); if (s1) s1[ob + i] = (int32_t)((long long)cv[j] - r0); }
+                        if (NSF == 2 || half == 1) { const long long r1 = (long long)rint(lf2.ld((NSF == 2 ? n : 0u) + i) * sc2); s2[ob + i] = (int32_t)-r1; }
+                    }
+                }
+            }
+            wave_sync();
         }
-        wave_sync();
     }
     FAL_STAMP(5);
     if (PROF && lane == 0) {
@@ -1527,6 +1568,7 @@ struct sc_hip_falcon {
     double *d_sk, *d_gm;
     uint64_t *d_tabs; int ts_log;
     size_t nkeys, npk;           // keys resident: d_sk [nkeys][(n_bits+5) n], d_tabs [nkeys][n << ts_log], d_hhat [npk][n]; key 0 is "the" key of the one-key calls
+    int var_spw, var_lm;         // sc_hip_falcon_set_variant (measurement hook): 0 = chosen per batch
     int force_g;                 // sc_hip_falcon_set_mapping: 0 / 64 = 8 signatures per wavefront, lower tree in LDS; 1 / 8 = lanes per signature, state in HBM
     int32_t *d_hhat;
     size_t cap;
@@ -1546,7 +1588,7 @@ static void fal_free_ws(sc_hip_falcon *f)
 static void fal_wipe(sc_hip_falcon *f, size_t batch, hipStream_t s)
 {
     const size_t n = f->P.n;
-    if (f->ws) (void)hipMemsetAsync(f->ws, 0, ((batch + SPW - 1) / SPW * SPW) * 6 * n * sizeof(double), s);
+    if (f->ws) (void)hipMemsetAsync(f->ws, 0, ((batch + SPW_MAX - 1) / SPW_MAX * SPW_MAX) * 6 * n * sizeof(double), s);
     if (f->s1) (void)hipMemsetAsync(f->s1, 0, batch * n * 4, s);
     if (f->s2) (void)hipMemsetAsync(f->s2, 0, batch * n * 4, s);
 }
@@ -1556,7 +1598,7 @@ static int fal_ensure_ws(sc_hip_falcon *f, size_t batch)
     if (batch <= f->cap) return SC_HIP_SUCCESS;
     fal_free_ws(f);
     const size_t n = f->P.n;
-    HIPCHK(hipMalloc((void **)&f->ws, ((batch + SPW - 1) / SPW * SPW) * 6 * n * sizeof(double)));       // the 8-per-wavefront mapping pads to whole wavefronts
+    HIPCHK(hipMalloc((void **)&f->ws, ((batch + SPW_MAX - 1) / SPW_MAX * SPW_MAX) * 6 * n * sizeof(double)));       // the 8-per-wavefront mapping pads to whole wavefronts
     HIPCHK(hipMalloc((void **)&f->c, batch * n * 4));
     HIPCHK(hipMalloc((void **)&f->s1, batch * n * 4));
     HIPCHK(hipMalloc((void **)&f->s2, batch * n * 4));
@@ -1597,6 +1639,15 @@ extern "C" int sc_hip_falcon_set_mapping(sc_hip_falcon_t *f, int lanes)
     if (!f) return fail("falcon_set_mapping: null handle");
     if (lanes != 0 && lanes != 1 && lanes != 8 && lanes != 64) return fail("falcon_set_mapping: lanes must be 0 (default), 1, 8 or 64");
     f->force_g = lanes;
+    return SC_HIP_SUCCESS;
+}
+
+// measurement hook (include/sc_hip_bench.h): pin the default mapping's variant - signatures per wavefront (8 / 4) and the sub-tree level kept in LDS (7 / 6); 0, 0 = per batch
+extern "C" int sc_hip_falcon_set_variant(sc_hip_falcon_t *f, int spw, int lm)
+{
+    if (!f) return fail("falcon_set_variant: null handle");
+    if (!((spw == 0 && lm == 0) || (spw == 8 && (lm == 6 || lm == 7)) || (spw == 4 && lm == 6))) return fail("falcon_set_variant: (8, 7), (8, 6), (4, 6) or (0, 0)");
+    f->var_spw = spw; f->var_lm = lm;
     return SC_HIP_SUCCESS;
 }
 
@@ -1704,9 +1755,15 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
     if (!d_key_of && (f->force_g == 0 || f->force_g == 64)) {
-        const dim3 grid8((unsigned)((batch + SPW - 1) / SPW)), block8(64);
-#define FAL_W8A(TSL, PR) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR>), grid8, block8, 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
+        // variant (see the kernel's head): (8, 7) while its one wavefront per SIMD holds the whole batch (8 x 1024 signatures: the BASELINE batch), (8, 6) -
+        // two wavefronts per SIMD - beyond.  Measured, Falcon-1024 sign/s: batch 8192 6.4 M / 5.8 M / 6.1 M for (8, 7) / (8, 6) / (4, 6); 16384 7.3 / 8.3 / 6.9;
+        // 131072 8.4 / 9.7 / 8.2 (profiles/r02_falcon_variants.txt)
+        int spw = f->var_spw, lm = f->var_lm;
+        if (!spw) { spw = 8; lm = (batch + 7) / 8 <= (size_t)f->ctx->cus * 4 ? 7 : 6; }
+        const dim3 grid8((unsigned)((batch + spw - 1) / spw)), block8(64);
+#define FAL_W8B(TSL, PR, S_, L_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_>), grid8, block8, 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
                                             f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
+#define FAL_W8A(TSL, PR) do { if (spw == 8 && lm == 7) FAL_W8B(TSL, PR, 8, 7); else if (spw == 8) FAL_W8B(TSL, PR, 8, 6); else FAL_W8B(TSL, PR, 4, 6); } while (0)
 #define FAL_W8(TSL) do { if (d_prof) FAL_W8A(TSL, true); else FAL_W8A(TSL, false); } while (0)
         switch (f->ts_log) {
         case 4: FAL_W8(4); break;
@@ -1716,6 +1773,7 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
         }
 #undef FAL_W8
 #undef FAL_W8A
+#undef FAL_W8B
         HIPCHK(hipGetLastError());
         return SC_HIP_SUCCESS;
     }

@@ -43,7 +43,7 @@ SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy',
             'sc_hip_multi_dilithium_set_privkey', 'sc_hip_multi_dilithium_set_pubkey', 'sc_hip_multi_dilithium_sig_max', 'sc_hip_multi_dilithium_sign_host',
             'sc_hip_multi_dilithium_verify_host']
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_dilithium_set_tuning']
+BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -266,6 +266,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_multi_dilithium_sign_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_multi_dilithium_verify_host.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp]
     L.sc_hip_falcon_sample_profile.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_falcon_set_variant.argtypes = [vp, C.c_int, C.c_int]
     L.sc_hip_falcon_sample.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_falcon_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
     L.sc_hip_falcon_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
@@ -1271,6 +1272,10 @@ class Falcon:
         _chk(self.L, self.L.sc_hip_falcon_verify_keys(self.h, batch, _ptr(key_of), _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                       _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'falcon_verify_keys')
         return verdicts
+
+    def set_variant(self, spw, lm):
+        """measurement hook: pin the default mapping's variant (signatures per wavefront 8 / 4, LDS sub-tree level 7 / 6); 0, 0 = per batch"""
+        _chk(self.L, self.L.sc_hip_falcon_set_variant(self.h, int(spw), int(lm)), 'falcon_set_variant')
 
     def sample_profile(self, c, tapes):
         """measurement hook: the default mapping's sampler, returns (s1, s2, cycles[6]) - shader cycles per phase summed over wavefronts"""

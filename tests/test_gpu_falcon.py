@@ -111,21 +111,23 @@ def test_batch_vs_oracle_seeded(eng, G):
     f.close()
 
 
-@pytest.mark.parametrize('lanes', [1, 8, 64])
-def test_every_mapping_reproduces_reference(eng, G, lanes):
-    """three ways of laying the sampler over the machine (sc_hip_falcon_set_mapping: a lane per signature, 8 lanes per signature,
-    8 signatures per wavefront with the lower tree in LDS - the default); each must give the reference's s1, s2 and, on a seeded
-    ragged batch, the oracle's, for n = 1024 and n = 512"""
+@pytest.mark.parametrize('lanes,variant', [(1, None), (8, None), (64, (8, 7)), (64, (8, 6)), (64, (4, 6)), (64, (0, 0))])
+def test_every_mapping_reproduces_reference(eng, G, lanes, variant):
+    """the ways of laying the sampler over the machine (sc_hip_falcon_set_mapping: a lane per signature, 8 lanes per signature, a wavefront
+    per 8 or 4 signatures with the tree below 128 or 64 coefficients in LDS - sc_hip_falcon_set_variant; (0, 0) = what the launcher picks);
+    each must give the reference's s1, s2 and, on a seeded ragged batch, the oracle's, for n = 1024 and n = 512"""
     import torch
     for tag in ('falcon2', 'falcon0'):
         key, f = open_key(eng, G, tag)
         f.set_mapping(lanes)
+        if variant:
+            f.set_variant(*variant)
         c = np.asarray(G[f'{tag}_c0'], dtype=np.int32)[None, :]
         tp = u32(G[f'{tag}_ctape0'])[None, :]
         s1, s2, status = f.sample(torch.from_numpy(c).cuda(), torch.from_numpy(tp.view(np.int32)).cuda())
         assert np.array_equal(s1[0].cpu().numpy(), np.asarray(G[f'{tag}_s1_0'], dtype=np.int32))
         assert np.array_equal(s2[0].cpu().numpy(), np.asarray(G[f'{tag}_s2_0'], dtype=np.int32))
-        rng = np.random.default_rng(lanes)
+        rng = np.random.default_rng(lanes + (10 * variant[0] + variant[1] if variant else 0))
         B = 77                                                   # ragged: the last wavefront is partly empty in every mapping
         cs = rng.integers(0, key.q, size=(B, key.n), dtype=np.int32)
         tps = rng.integers(0, 2**32, size=(B, 4 * key.n), dtype=np.uint64).astype(np.uint32)
