@@ -158,9 +158,18 @@ template <int MODE, int G>
 __device__ __forceinline__ void gs_last_stage(uint32_t (&x)[16], uint32_t c0, uint32_t c0p, uint32_t c1, uint32_t c1p, const ModK &k)
 {
     if constexpr (MODE == MODE_SMAD) {
-        // signed sums of magnitude <= 2q 2^8 = 512 q: biased by 512 q (a multiple of q) they are non-negative and below 1024 q < 2^24; the
-        // scale constants come centred with signed companions (modarith.h mulc_pos_centred), the result lands in [0, 2q)
+        // signed sums of magnitude <= 2q 2^8 = 512 q: biased by 512 q (a multiple of q) they are non-negative and below 1024 q < 2^24; for
+        // q >= 8192 the scale constants come centred with signed companions (modarith.h mulc_pos_centred), the result lands in [0, 2q)
         const uint32_t bias = k.q << 9;
+        if (k.q < 8192u) {       // 1024 q < 2^23 (q = 7681): canonical constants, all three products on the 24-bit multiplier (measured 1.7 % faster per fused launch)
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint32_t a = x[r], b = x[r | 8];
+                x[r] = csub(Mod<MODE_MAD>::mulc(a + b + bias, c0, c0p, k), k.q);
+                x[r | 8] = csub(Mod<MODE_MAD>::mulc(a - b + bias, c1, c1p, k), k.q);
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const uint32_t a = x[r], b = x[r | 8];

@@ -515,7 +515,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const bool sgn = p->mode == MODE_SMAD || p->mode == MODE_S32;
     a.zf = sgn ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
-    const uint32_t *c = p->mode == MODE_SMAD ? p->c_inv_s : p->mode == MODE_S32 ? (op == OP_INV ? p->c_inv_s : p->c_mont_s)
+    const uint32_t *c = p->mode == MODE_SMAD ? (p->q < 8192 ? p->c_inv[mi] : p->c_inv_s) : p->mode == MODE_S32 ? (op == OP_INV ? p->c_inv_s : p->c_mont_s)
                         : (op == OP_INV || p->mode == MODE_MAD) ? p->c_inv[mi] : p->c_mont[mi];     // the small-modulus products leave no 2^-32
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
