@@ -613,11 +613,13 @@ def main():
         kern_ms = ev0.elapsed_time(ev1) / args.steps                 # average over the K launches of the timed region
         kern_ms_plain = plan.time_op(2, a, bhat, out, 50)            # the same kernel as 50 plain launches between two events (C loop)
         achieved = BATCH * BYTES_PER_TRIPLE / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_past = None
         tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # per-launch HBM bytes from rocprofv3 --pmc
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get('polymul_ntt_n256_b65536_bytes')
+                tj = json.load(open(tp))
+                traffic = tj.get('polymul_ntt_n256_b65536_bytes')
+                traffic_past = tj.get('polymul_ntt_n256_b1048576_bytes')
             except Exception:
                 traffic = None
         # the same kernel over a working set far past the Infinity Cache (3 x 1 GiB): what the HBM itself sustains for this access pattern
@@ -630,7 +632,7 @@ def main():
             ms2 = plan.time_op(2, a2, b2, o2, 10)
             g2 = PAST_L3_BATCH * BYTES_PER_TRIPLE / (ms2 * 1e-3) / 1e9
             past = {'achieved_past_l3': g2, 'frac_past_l3': g2 / HBM_PEAK_GBS, 'past_l3_batch': PAST_L3_BATCH, 'past_l3_working_set_GiB': 3 * PAST_L3_BATCH * N * 4 / 2**30,
-                    'past_l3_kernel_ms': ms2, 'past_l3_NTT_per_s': 2.0 * PAST_L3_BATCH / (ms2 * 1e-3)}
+                    'past_l3_kernel_ms': ms2, 'past_l3_NTT_per_s': 2.0 * PAST_L3_BATCH / (ms2 * 1e-3), 'traffic_past_l3': traffic_past}
             del a2, b2, o2
         except Exception as e:
             past = {'achieved_past_l3': None, 'past_l3_error': str(e)}
