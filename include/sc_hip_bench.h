@@ -32,7 +32,8 @@ int sc_hip_falcon_sample_profile(sc_hip_falcon_t *h, size_t batch, const int32_t
                                  int32_t *d_s1, int32_t *d_s2, unsigned long long *h_cycles, void *stream);
 
 /* pin the variant of the Falcon sampler's default mapping: signatures per wavefront (8 or 4) and the sub-tree level kept in LDS (7 or 6);
- * 0, 0: chosen per batch (the production setting).  Results do not depend on it. */
+ * spw may carry the wavefronts per workgroup in bits 8-9 (1 or 2; 2 needs n = 1024 and the (8, 7) variant).  0, 0: chosen per batch (the production
+ * setting).  Results do not depend on it. */
 int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
 
 /* Dilithium signer: (slots_per_message & 0xFF) > 0 fixes the number of attempts evaluated side by side per message in the first round (0: the

@@ -577,12 +577,15 @@ struct LdsF {                                  // LDS, wave mode: a polynomial b
     __device__ __forceinline__ void st(uint32_t e, double v) const { p[at(e)] = v; }
 };
 
+template <int NW> __device__ __forceinline__ void group_sync();   // NW wavefronts of one workgroup hand data to each other between sweeps
 __device__ __forceinline__ void wave_sync()   // the lanes of ONE wavefront hand data to each other through memory / LDS between sweeps
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+template <> __device__ __forceinline__ void group_sync<1>() { wave_sync(); }
+template <> __device__ __forceinline__ void group_sync<2>() { __syncthreads(); }       // workgroup-scope release / barrier / acquire
 
 // The sweeps below serve both modes.  G lanes (lane index g) share NS signatures' worth of pairs: pair index v in [0, NS * qn) is pair
 // u = v % qn of signature v / qn, whose elements sit `per` doubles behind the previous signature's (group mode: NS = 1, the accessor already
@@ -695,17 +698,17 @@ __device__ __forceinline__ void mid_sw(const CH &ch, uint32_t cho, const TT &t, 
 // The transforms in wave mode: as fft_pass / ifft_pass above (R butterfly stages per sweep in registers), the groups of NS polynomials (`per`
 // elements apart) as one index space shared by the 64 lanes, PG groups per lane in flight.  They run on two polynomials at a time staged in
 // LDS (LdsF below): a transform then costs one HBM read and one HBM write of the polynomial instead of one of each per pass.
-template <int R, int PG, int NS, class A>
+template <int R, int PG, int NS, int TPB, class A>
 __device__ __forceinline__ void fft_pass_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, uint32_t hn, int u, const double *__restrict__ gm)
 {
     constexpr int P = 1 << R;
     const int lq = __builtin_ctz(hn) - u - (R - 1), lgr = __builtin_ctz(hn) - R;       // Q = hn >> (u + R - 1); groups per signature = hn >> R
     const uint32_t Q = 1u << lq, groups = 1u << lgr, tot = NS * groups, m = 1u << u;   // tot is a multiple of PG * 64 for n >= 512
-    for (uint32_t t0 = 0; t0 < tot; t0 += PG * 64) {
+    for (uint32_t t0 = 0; t0 < tot; t0 += PG * TPB) {
         double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
 #pragma unroll
         for (int k = 0; k < PG; k++) {
-            const uint32_t t = t0 + k * 64 + lane, grp = t & (groups - 1), i1 = grp >> lq;
+            const uint32_t t = t0 + k * TPB + lane, grp = t & (groups - 1), i1 = grp >> lq;
             j0[k] = (t >> lgr) * per + f + ((i1 << R) << lq) + (grp & (Q - 1));
 #pragma unroll
             for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lq)); xi[k][a] = c.ld(j0[k] + (a << lq) + hn); }
@@ -736,30 +739,30 @@ __device__ __forceinline__ void fft_pass_w(const A &c, uint32_t lane, uint32_t f
             for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lq), xr[k][a]); c.st(j0[k] + (a << lq) + hn, xi[k][a]); }
         }
     }
-    wave_sync();
+    group_sync<TPB / 64>();
 }
 
-template <int NS, class A>
+template <int NS, int TPB, class A>
 __device__ __forceinline__ void fft_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, int logn, const double *__restrict__ gm)
 {
     const uint32_t hn = (1u << logn) >> 1;
     int u = 1;
-    for (; u + 2 < logn; u += 3) fft_pass_w<3, 1, NS>(c, lane, f, per, hn, u, gm);
-    if (u + 1 < logn) fft_pass_w<2, 2, NS>(c, lane, f, per, hn, u, gm);
-    else if (u < logn) fft_pass_w<1, 2, NS>(c, lane, f, per, hn, u, gm);
+    for (; u + 2 < logn; u += 3) fft_pass_w<3, 1, NS, TPB>(c, lane, f, per, hn, u, gm);
+    if (u + 1 < logn) fft_pass_w<2, 2, NS, TPB>(c, lane, f, per, hn, u, gm);
+    else if (u < logn) fft_pass_w<1, 2, NS, TPB>(c, lane, f, per, hn, u, gm);
 }
 
-template <int R, int PG, int NS, class A>
+template <int R, int PG, int NS, int TPB, class A>
 __device__ __forceinline__ void ifft_pass_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, uint32_t hn, int lt, uint32_t hm0, const double *__restrict__ gm)
 {
     constexpr int P = 1 << R;
     const int lgr = __builtin_ctz(hn) - R;
     const uint32_t tt0 = 1u << lt, groups = 1u << lgr, tot = NS * groups;
-    for (uint32_t t0 = 0; t0 < tot; t0 += PG * 64) {
+    for (uint32_t t0 = 0; t0 < tot; t0 += PG * TPB) {
         double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
 #pragma unroll
         for (int k = 0; k < PG; k++) {
-            const uint32_t t = t0 + k * 64 + lane, grp = t & (groups - 1), iB = grp >> lt;
+            const uint32_t t = t0 + k * TPB + lane, grp = t & (groups - 1), iB = grp >> lt;
             j0[k] = (t >> lgr) * per + f + ((iB << R) << lt) + (grp & (tt0 - 1));
 #pragma unroll
             for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lt)); xi[k][a] = c.ld(j0[k] + (a << lt) + hn); }
@@ -789,18 +792,18 @@ __device__ __forceinline__ void ifft_pass_w(const A &c, uint32_t lane, uint32_t 
             for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lt), xr[k][a]); c.st(j0[k] + (a << lt) + hn, xi[k][a]); }
         }
     }
-    wave_sync();
+    group_sync<TPB / 64>();
 }
 
-template <int NS, class A>
+template <int NS, int TPB, class A>
 __device__ __forceinline__ void ifft_w(const A &c, uint32_t lane, uint32_t f, uint32_t per, int logn, const double *__restrict__ gm)
 {
     const uint32_t n = 1u << logn, hn = n >> 1;
     int left = logn - 1, lt = 0;
     uint32_t hm = n >> 1;
-    for (; left >= 3; left -= 3, lt += 3, hm >>= 3) ifft_pass_w<3, 1, NS>(c, lane, f, per, hn, lt, hm, gm);
-    if (left == 2) ifft_pass_w<2, 2, NS>(c, lane, f, per, hn, lt, hm, gm);
-    else if (left == 1) ifft_pass_w<1, 2, NS>(c, lane, f, per, hn, lt, hm, gm);
+    for (; left >= 3; left -= 3, lt += 3, hm >>= 3) ifft_pass_w<3, 1, NS, TPB>(c, lane, f, per, hn, lt, hm, gm);
+    if (left == 2) ifft_pass_w<2, 2, NS, TPB>(c, lane, f, per, hn, lt, hm, gm);
+    else if (left == 1) ifft_pass_w<1, 2, NS, TPB>(c, lane, f, per, hn, lt, hm, gm);
 }
 
 // Leaf sampling for the group mode.  The 8 leaves of a register sub-tree need 8 CDF tables (the same for every signature) and 8 x 4 tape
@@ -868,8 +871,12 @@ struct WalkL {
 // signatures.  tape_stride >= 4n (the launcher answers shorter strides itself): a tape that is short is still read to 4n words - inside its
 // own row - and its signature reports status 2 and writes nothing.
 // PROF (measurement builds only, sc_hip_falcon_sample_profile): each wavefront adds the shader cycles it spent in the six phases to prof[0..5].
-template <int TSL, bool PROF, int SPW, int LM>
-__global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, double *__restrict__ ws, const int32_t *__restrict__ c,
+// NW = 2 (n = 1024, SPW = 8 only): the workgroup is TWO wavefronts on the same 8 signatures - the wave-mode sweeps and the transforms are shared by 128
+// lanes, group mode gives a signature 16 lanes (8 in each wavefront), the register sub-trees run on the first wavefront while the second waits.  A
+// wavefront alone on a SIMD issues one instruction per ~10 cycles, so at the BASELINE batch (8192 signatures = 1024 workgroups) the second wavefront
+// of every workgroup lands on a SIMD that would otherwise idle and halves the instruction stream of everything that is not a register sub-tree.
+template <int TSL, bool PROF, int SPW, int LM, int NW>
+__global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, double *__restrict__ ws, const int32_t *__restrict__ c,
                                                            const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
                                                            const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                            int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
@@ -880,6 +887,8 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     constexpr int NSF = (SPW * LDS_SIG >= 2 * POLY) ? 2 : 1;           // polynomials transformed side by side
     constexpr int LDSD = SPW * LDS_SIG > NSF * POLY ? SPW * LDS_SIG : NSF * POLY;
     constexpr int SU_LM = LM >= 6 ? 2 : 1;
+    constexpr int TPB = 64 * NW, GL = 8 * NW;                          // lanes of the workgroup; lanes per signature in group mode
+    static_assert(NW == 1 || (NW == 2 && SPW == 8 && LM == 7), "two wavefronts per workgroup: 8 signatures, 128-coefficient sub-trees in LDS");
     __shared__ __attribute__((aligned(16))) double lds[LDSD];
     __shared__ uint64_t stab[8 << TSL];                                // the current register sub-tree's 8 leaf tables
     __shared__ __attribute__((aligned(16))) uint32_t stape[SPW * 32];  // and its 8 x 4 tape words per signature
@@ -889,9 +898,10 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #define FAL_STAMP(ph) do { if (PROF) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); pc[ph] += tn_ - tprev; tprev = tn_; } } while (0)
     constexpr int FK = FK8;
-    const uint32_t lane = threadIdx.x, g = lane & 7;
-    const bool act = lane < 8 * SPW;                                   // group mode: the lanes that have a signature (all of them for SPW = 8)
-    const uint32_t sg = act ? lane >> 3 : 0;
+    const uint32_t lane = threadIdx.x, wv_id = lane >> 6, l64 = lane & 63, g = (l64 & 7) + 8 * wv_id;       // lane: index in the workgroup
+    const bool act = l64 < 8 * SPW;                                    // group mode: the lanes that have a signature (all of them for SPW = 8)
+    const bool w0 = wv_id == 0;
+    const uint32_t sg = act ? l64 >> 3 : 0;
     const uint32_t sig0 = blockIdx.x * SPW;
     const uint32_t n = (uint32_t)P.n, hn = n >> 1; const int logn = P.n_bits;
     const uint32_t per = 6 * n;
@@ -907,32 +917,33 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     const uint64_t runmask = __ballot(act && inb && !shortt);           // bit 8k: signature k of this wavefront writes its results
     const Lin mine = { wv.p + (size_t)sg * per };
     const LdsG<SPW> lg = { lds + sg * 8 };
-    for (uint32_t i = lane; i < (2u << LM); i += 64) sgm[i] = gm[i];
+    for (uint32_t i = lane; i < (2u << LM); i += TPB) sgm[i] = gm[i];
     uint32_t toffLM = 0;                                               // tree offset of the current level-LM node
     const int ln = logn;                                               // log2 of the elements per signature in the flattened loops
 
     // ---- FFT(c) and the two target vectors (gpv.c:3040-3054): NSF signatures at a time through LDS (n doubles each, padded)
     const LdsF lf2 = { lds };
     for (int pr = 0; pr < SPW; pr += NSF) {
-        for (uint32_t t0 = 0; t0 < NSF * n; t0 += 4 * 4 * 64) {
-            int4 cv[4];
+        constexpr int JN = 4 / NW;                                     // 16-byte loads per lane and trip
+        for (uint32_t t0 = 0; t0 < NSF * n; t0 += 4 * JN * TPB) {
+            int4 cv[JN];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = t0 + (j * 64 + lane) * 4, b = sig0 + pr + (t >> ln);
+            for (int j = 0; j < JN; j++) {
+                const uint32_t t = t0 + (j * TPB + lane) * 4, b = sig0 + pr + (t >> ln);
                 cv[j] = *reinterpret_cast<const int4 *>(c + (size_t)(b < batch ? b : 0) * n + (t & (n - 1)));
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = t0 + (j * 64 + lane) * 4;
+            for (int j = 0; j < JN; j++) {
+                const uint32_t t = t0 + (j * TPB + lane) * 4;
                 if (NSF == 2 || t < n) { lf2.st(t, (double)cv[j].x); lf2.st(t + 1, (double)cv[j].y); lf2.st(t + 2, (double)cv[j].z); lf2.st(t + 3, (double)cv[j].w); }
             }
         }
-        wave_sync();
-        fft_w<NSF>(lf2, lane, 0, n, logn, gm);
-        for (uint32_t t0 = 0; t0 < NSF * hn; t0 += 4 * 64) {
+        group_sync<NW>();
+        fft_w<NSF, TPB>(lf2, lane, 0, n, logn, gm);
+        for (uint32_t t0 = 0; t0 < NSF * hn; t0 += JN * TPB) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t = t0 + j * 64 + lane, k = t >> (ln - 1), u = t & (hn - 1), e = (pr + k) * per + u;
+            for (int j = 0; j < JN; j++) {
+                const uint32_t t = t0 + j * TPB + lane, k = t >> (ln - 1), u = t & (hn - 1), e = (pr + k) * per + u;
                 const double ar = lf2.ld(k * n + u), ai = lf2.ld(k * n + u + hn);
                 double r, i;
                 cmul(r, i, ar, ai, b01[u], b01[u + hn]);
@@ -941,7 +952,7 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 wv.st(e + C0, r * ni); wv.st(e + C0 + hn, i * ni);
             }
         }
-        wave_sync();
+        group_sync<NW>();
     }
     FAL_STAMP(0);
 
@@ -951,7 +962,7 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     const uint32_t *mytape = tapes + (size_t)item * tape_stride;
     uint32_t leaf = 0;                                                 // first leaf of the next register sub-tree (wave-uniform)
     auto prefetch = [&](uint32_t first) {
-        if (first < n) {
+        if (first < n && w0) {
             const uint64_t *src = tabs + ((size_t)first << TSL) + lane * TPL;
 #pragma unroll
             for (int i = 0; i < TPL; i += 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + i); ptab[i] = v.x; ptab[i + 1] = v.y; }
@@ -968,11 +979,13 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
         if (entering) {
             if (l == FK) {
                 // an 8-coefficient sub-tree in registers; every lane of a group computes the same thing from the same (broadcast) LDS words
+                if (w0) {
 #pragma unroll
-                for (int i = 0; i < TPL; i++) stab[lane * TPL + i] = ptab[i];
-                if (act) *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
-                wave_sync();
-                if (act) {
+                    for (int i = 0; i < TPL; i++) stab[lane * TPL + i] = ptab[i];
+                    if (act) *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
+                }
+                group_sync<NW>();
+                if (act && w0) {
                     double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
                     const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
 #pragma unroll
@@ -987,25 +1000,26 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                 }
                 leaf += 1u << FK;
                 prefetch(leaf);
-                wave_sync();
+                group_sync<NW>();
                 FAL_STAMP(4);
                 entering = false; l++;
                 continue;
             }
-            if (l > LM) split_sw<64, 2, SPW, false>(wv, w.z1(l), w.z1(l) + hm, wv, w.t1(l), lane, l, per, gm);
+            if (l > LM) split_sw<TPB, 2, SPW, false>(wv, w.z1(l), w.z1(l) + hm, wv, w.t1(l), lane, l, per, gm);
             else {
                 if (l == LM) {
                     toffLM = toff;
-                    for (uint32_t i = lane * 2; i < treesize(LM); i += 128) *reinterpret_cast<double2 *>(stree + i) = *reinterpret_cast<const double2 *>(tree + toff + i);
+                    for (uint32_t i = lane * 2; i < treesize(LM); i += 2 * TPB) *reinterpret_cast<double2 *>(stree + i) = *reinterpret_cast<const double2 *>(tree + toff + i);
                 }
                 if (act) {
-                    if (l == LM) split_sw<8, SU_LM, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, sgm);
-                    else if (l >= 6) split_sw<8, 2, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
-                    else if (l == 5) split_sw<8, 1, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
-                    else split_sw<8, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                    // pairs per sweep 2^(l-2): 32, 16, 8, 4 for l = 7..4; GL lanes take SU each, guarded where the lanes outnumber the pairs
+                    if (l == LM) split_sw<GL, SU_LM, 1, false>(lg, 0u, hm, mine, w.t1(l), g, l, per, sgm);
+                    else if (l >= 6) split_sw<GL, 2 / NW, 1, false>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                    else if (l == 5) split_sw<GL, 1, 1, NW == 2>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
+                    else split_sw<GL, 1, 1, true>(lg, w.lz1(l), w.lz1(l) + hm, lg, w.lt1(l), g, l, per, sgm);
                 }
             }
-            wave_sync();
+            group_sync<NW>();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph &= ~(1u << l);
             toff += m + treesize(l - 1); l--;
@@ -1015,14 +1029,14 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
             toff -= m + treesize(l - 1);
             const double *L = tree + toff;
             const double *LL = stree + (toff - toffLM);                // the same block in LDS (levels <= LM)
-            if (l > LM) mid_sw<64, 2, SPW, false>(wv, w.tmp(l), wv, w.t0(l), w.t1(l), wv, w.z1(l), wv, w.z0(l), lane, l, per, gm, L);
+            if (l > LM) mid_sw<TPB, 2, SPW, false>(wv, w.tmp(l), wv, w.t0(l), w.t1(l), wv, w.z1(l), wv, w.z0(l), lane, l, per, gm, L);
             else if (act) {
-                if (l == LM) mid_sw<8, SU_LM, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, sgm, LL);
-                else if (l >= 6) mid_sw<8, 2, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
-                else if (l == 5) mid_sw<8, 1, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
-                else mid_sw<8, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+                if (l == LM) mid_sw<GL, SU_LM, 1, false>(lg, w.ltmp(l), mine, w.t0(l), w.t1(l), mine, w.z1(l), lg, 0u, g, l, per, sgm, LL);
+                else if (l >= 6) mid_sw<GL, 2 / NW, 1, false>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+                else if (l == 5) mid_sw<GL, 1, 1, NW == 2>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
+                else mid_sw<GL, 1, 1, true>(lg, w.ltmp(l), lg, w.lt0(l), w.lt1(l), lg, w.lz1(l), lg, w.lz0(l), g, l, per, sgm, LL);
             }
-            wave_sync();
+            group_sync<NW>();
             FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
             w.ph |= 1u << l;
             toff += m; l--;
@@ -1030,14 +1044,14 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
             continue;
         }
         toff -= m;
-        if (l > LM) merge_sw<64, 2, SPW, false>(wv, w.z0(l), wv, w.tmp(l), w.tmp(l) + hm, lane, l, per, gm);
+        if (l > LM) merge_sw<TPB, 2, SPW, false>(wv, w.z0(l), wv, w.tmp(l), w.tmp(l) + hm, lane, l, per, gm);
         else if (act) {
-            if (l == LM) merge_sw<8, SU_LM, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-            else if (l >= 6) merge_sw<8, 2, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-            else if (l == 5) merge_sw<8, 1, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
-            else merge_sw<8, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            if (l == LM) merge_sw<GL, SU_LM, 1, false>(mine, w.z0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else if (l >= 6) merge_sw<GL, 2 / NW, 1, false>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else if (l == 5) merge_sw<GL, 1, 1, NW == 2>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
+            else merge_sw<GL, 1, 1, true>(lg, w.lz0(l), lg, w.ltmp(l), w.ltmp(l) + hm, g, l, per, sgm);
         }
-        wave_sync();
+        group_sync<NW>();
         FAL_STAMP(l > LM ? 1 : l == LM ? 2 : 3);
         w.ph &= ~(1u << l);
         if (l == logn) break;
@@ -1049,16 +1063,17 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
     const double sc2 = ldexp(2.0, -logn);                           // falcon_fft.c:370-377
     for (int k = 0; k < SPW; k++) {
         for (int half = 0; half < (NSF == 2 ? 1 : 2); half++) {
-            for (uint32_t u0 = 0; u0 < hn; u0 += 4 * 64) {
-                double z0r[4], z0i[4], z1r[4], z1i[4];
+            constexpr int JF = 4 / NW;
+            for (uint32_t u0 = 0; u0 < hn; u0 += JF * TPB) {
+                double z0r[JF], z0i[JF], z1r[JF], z1i[JF];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t e = k * per + u0 + j * 64 + lane;
+                for (int j = 0; j < JF; j++) {
+                    const uint32_t e = k * per + u0 + j * TPB + lane;
                     z0r[j] = wv.ld(e + Z0); z0i[j] = wv.ld(e + Z0 + hn); z1r[j] = wv.ld(e + Z1); z1i[j] = wv.ld(e + Z1 + hn);
                 }
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t u = u0 + j * 64 + lane;
+                for (int j = 0; j < JF; j++) {
+                    const uint32_t u = u0 + j * TPB + lane;
                     double pr, pi, qr, qi;
                     if (NSF == 2 || half == 0) {
                         cmul(pr, pi, z0r[j], z0i[j], b00[u], b00[u + hn]);
@@ -1073,23 +1088,23 @@ __global__ __launch_bounds__(64) void fal_sample_w8_kernel(uint32_t batch, doubl
                     }
                 }
             }
-            wave_sync();
-            ifft_w<NSF>(lf2, lane, 0, n, logn, gm);
+            group_sync<NW>();
+            ifft_w<NSF, TPB>(lf2, lane, 0, n, logn, gm);
             if ((runmask >> (8 * k)) & 1) {
                 const size_t ob = (size_t)(sig0 + k) * n;
-                for (uint32_t i0 = 0; i0 < n; i0 += 4 * 64) {
-                    int32_t cv[4];
+                for (uint32_t i0 = 0; i0 < n; i0 += JF * TPB) {
+                    int32_t cv[JF];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) cv[j] = (NSF == 2 || half == 0) ? c[ob + i0 + j * 64 + lane] : 0;
+                    for (int j = 0; j < JF; j++) cv[j] = (NSF == 2 || half == 0) ? c[ob + i0 + j * TPB + lane] : 0;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t i = i0 + j * 64 + lane;
+                    for (int j = 0; j < JF; j++) {
+                        const uint32_t i = i0 + j * TPB + lane;
                         if (NSF == 2 || half == 0) { const long long r0 = (long long)rint(lf2.ld(i) * sc2); if (s1) s1[ob + i] = (int32_t)((long long)cv[j] - r0); }
                         if (NSF == 2 || half == 1) { const long long r1 = (long long)rint(lf2.ld((NSF == 2 ? n : 0u) + i) * sc2); s2[ob + i] = (int32_t)-r1; }
                     }
                 }
             }
-            wave_sync();
+            group_sync<NW>();
         }
     }
     FAL_STAMP(5);
@@ -1568,7 +1583,7 @@ struct sc_hip_falcon {
     double *d_sk, *d_gm;
     uint64_t *d_tabs; int ts_log;
     size_t nkeys, npk;           // keys resident: d_sk [nkeys][(n_bits+5) n], d_tabs [nkeys][n << ts_log], d_hhat [npk][n]; key 0 is "the" key of the one-key calls
-    int var_spw, var_lm;         // sc_hip_falcon_set_variant (measurement hook): 0 = chosen per batch
+    int var_spw, var_lm, var_nw; // sc_hip_falcon_set_variant (measurement hook): 0 = chosen per batch
     int force_g;                 // sc_hip_falcon_set_mapping: 0 / 64 = 8 signatures per wavefront, lower tree in LDS; 1 / 8 = lanes per signature, state in HBM
     int32_t *d_hhat;
     size_t cap;
@@ -1646,8 +1661,9 @@ extern "C" int sc_hip_falcon_set_mapping(sc_hip_falcon_t *f, int lanes)
 extern "C" int sc_hip_falcon_set_variant(sc_hip_falcon_t *f, int spw, int lm)
 {
     if (!f) return fail("falcon_set_variant: null handle");
-    if (!((spw == 0 && lm == 0) || (spw == 8 && (lm == 6 || lm == 7)) || (spw == 4 && lm == 6))) return fail("falcon_set_variant: (8, 7), (8, 6), (4, 6) or (0, 0)");
-    f->var_spw = spw; f->var_lm = lm;
+    { const int sp = spw & 0xFF, nwv = spw >> 8;
+      if (!((sp == 0 && lm == 0) || (sp == 8 && (lm == 6 || lm == 7)) || (sp == 4 && lm == 6)) || nwv < 0 || nwv > 2) return fail("falcon_set_variant: (8, 7), (8, 6), (4, 6) or (0, 0); wavefronts per workgroup (spw >> 8) 0, 1 or 2"); }
+    f->var_spw = spw & 0xFF; f->var_lm = lm; f->var_nw = (spw >> 8) & 3;      // spw | nw << 8: nw = 1 / 2 wavefronts per workgroup (0: per batch)
     return SC_HIP_SUCCESS;
 }
 
@@ -1760,10 +1776,14 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
         // 131072 8.4 / 9.7 / 8.2 (profiles/r02_falcon_variants.txt)
         int spw = f->var_spw, lm = f->var_lm;
         if (!spw) { spw = 8; lm = (batch + 7) / 8 <= (size_t)f->ctx->cus * 4 ? 7 : 6; }
-        const dim3 grid8((unsigned)((batch + spw - 1) / spw)), block8(64);
-#define FAL_W8B(TSL, PR, S_, L_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_>), grid8, block8, 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
+        // two wavefronts per workgroup (n = 1024, the (8, 7) variant): while the batch leaves SIMDs without a wavefront
+        int nw = f->var_nw ? f->var_nw : ((spw == 8 && lm == 7 && f->P.n == 1024) ? 2 : 1);
+        if (!(spw == 8 && lm == 7 && f->P.n == 1024)) nw = 1;
+        const dim3 grid8((unsigned)((batch + spw - 1) / spw));
+#define FAL_W8B(TSL, PR, S_, L_, N_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_, N_>), grid8, dim3(64 * N_), 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
                                             f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
-#define FAL_W8A(TSL, PR) do { if (spw == 8 && lm == 7) FAL_W8B(TSL, PR, 8, 7); else if (spw == 8) FAL_W8B(TSL, PR, 8, 6); else FAL_W8B(TSL, PR, 4, 6); } while (0)
+#define FAL_W8A(TSL, PR) do { if (spw == 8 && lm == 7 && nw == 2) FAL_W8B(TSL, PR, 8, 7, 2); else if (spw == 8 && lm == 7) FAL_W8B(TSL, PR, 8, 7, 1); \
+                              else if (spw == 8) FAL_W8B(TSL, PR, 8, 6, 1); else FAL_W8B(TSL, PR, 4, 6, 1); } while (0)
 #define FAL_W8(TSL) do { if (d_prof) FAL_W8A(TSL, true); else FAL_W8A(TSL, false); } while (0)
         switch (f->ts_log) {
         case 4: FAL_W8(4); break;

@@ -111,10 +111,11 @@ def test_batch_vs_oracle_seeded(eng, G):
     f.close()
 
 
-@pytest.mark.parametrize('lanes,variant', [(1, None), (8, None), (64, (8, 7)), (64, (8, 6)), (64, (4, 6)), (64, (0, 0))])
+@pytest.mark.parametrize('lanes,variant', [(1, None), (8, None), (64, (8 | 1 << 8, 7)), (64, (8 | 2 << 8, 7)), (64, (8, 6)), (64, (4, 6)), (64, (0, 0))])
 def test_every_mapping_reproduces_reference(eng, G, lanes, variant):
     """the ways of laying the sampler over the machine (sc_hip_falcon_set_mapping: a lane per signature, 8 lanes per signature, a wavefront
-    per 8 or 4 signatures with the tree below 128 or 64 coefficients in LDS - sc_hip_falcon_set_variant; (0, 0) = what the launcher picks);
+    per 8 or 4 signatures with the tree below 128 or 64 coefficients in LDS, one or two wavefronts per workgroup (spw | nw << 8) -
+    sc_hip_falcon_set_variant; (0, 0) = what the launcher picks);
     each must give the reference's s1, s2 and, on a seeded ragged batch, the oracle's, for n = 1024 and n = 512"""
     import torch
     for tag in ('falcon2', 'falcon0'):

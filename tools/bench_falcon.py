@@ -42,7 +42,7 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'variants':       # the default mapping's four variants and the launcher's choice
         for s, bsz in ((2, 8192), (2, 16384), (2, 32768), (2, 131072), (0, 8192), (0, 16384), (0, 131072)):
-            for v in ((8, 7), (8, 6), (4, 6), (0, 0)):
+            for v in ((8 | 1 << 8, 7), (8 | 2 << 8, 7), (8, 6), (0, 0)):
                 print(json.dumps(run(s, bsz, lanes=64, variant=v)), flush=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'sweep':          # every mapping at the configuration's batch and at larger ones

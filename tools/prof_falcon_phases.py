@@ -23,7 +23,7 @@ def run(set_, batch, variant=(0, 0)):
     t0 = time.perf_counter(); f.sample(c, tapes); torch.cuda.synchronize(); plain = time.perf_counter() - t0
     f.sample_profile(c, tapes)
     t0 = time.perf_counter(); s1, s2, cyc = f.sample_profile(c, tapes); torch.cuda.synchronize(); prof = time.perf_counter() - t0
-    spw = variant[0] if variant[0] else (4 if batch <= 8192 else 8)
+    spw = (variant[0] & 0xFF) if variant[0] else 8
     waves = (batch + spw - 1) // spw
     per = cyc.astype(np.float64) / waves
     out = {'set': set_, 'n': f.n, 'batch': batch, 'variant': list(variant), 'sample_ms': plain * 1e3, 'sample_ms_instrumented': prof * 1e3, 'wavefronts': waves,
@@ -35,5 +35,5 @@ def run(set_, batch, variant=(0, 0)):
 
 if __name__ == '__main__':
     for s, b in ((2, 8192), (2, 65536)):
-        for v in ((8, 7), (8, 6), (4, 6)):
+        for v in ((8 | 1 << 8, 7), (8 | 2 << 8, 7)):
             print(json.dumps(run(s, b, v)), flush=True)
