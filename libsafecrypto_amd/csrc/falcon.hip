@@ -840,6 +840,12 @@ struct LeafPre {
         }
         k = 0;
     }
+    __device__ __forceinline__ void take(const double *p)             // the 16 samples another wavefront drew (LDS)
+    {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) { const double2 v = *reinterpret_cast<const double2 *>(p + i); d[i] = v.x; d[i + 1] = v.y; }
+        k = 0;
+    }
     __device__ __forceinline__ void pick2(double &d0, double &d1)
     {
         // k is a compile-time constant at every use (the recursion is fully unrolled)
@@ -894,6 +900,7 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
     __shared__ __attribute__((aligned(16))) uint32_t stape[SPW * 32];  // and its 8 x 4 tape words per signature
     __shared__ double stree[(LM + 1) << LM];                           // the LDL tree block of the current level-LM node (falcon_ldl.h:56-71: treesize(LM) doubles)
     __shared__ double sgm[2 << LM];                                    // the roots the levels <= LM use: complex entries [0, 2^LM)
+    __shared__ __attribute__((aligned(16))) double ssmp[NW == 2 ? 2 * SPW * 16 : 2];   // NW = 2: the 16 samples per signature of the current and the next register sub-tree
     unsigned long long pc[6] = { 0, 0, 0, 0, 0, 0 }, tprev = 0;
     if (PROF) tprev = __builtin_amdgcn_s_memtime();
 #define FAL_STAMP(ph) do { if (PROF) { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); pc[ph] += tn_ - tprev; tprev = tn_; } } while (0)
@@ -901,6 +908,7 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
     const uint32_t lane = threadIdx.x, wv_id = lane >> 6, l64 = lane & 63, g = (l64 & 7) + 8 * wv_id;       // lane: index in the workgroup
     const bool act = l64 < 8 * SPW;                                    // group mode: the lanes that have a signature (all of them for SPW = 8)
     const bool w0 = wv_id == 0;
+    const bool smp = wv_id == NW - 1;                                  // the wavefront that fetches leaf tables / tape words and (NW = 2) draws the samples
     const uint32_t sg = act ? l64 >> 3 : 0;
     const uint32_t sig0 = blockIdx.x * SPW;
     const uint32_t n = (uint32_t)P.n, hn = n >> 1; const int logn = P.n_bits;
@@ -962,14 +970,33 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
     const uint32_t *mytape = tapes + (size_t)item * tape_stride;
     uint32_t leaf = 0;                                                 // first leaf of the next register sub-tree (wave-uniform)
     auto prefetch = [&](uint32_t first) {
-        if (first < n && w0) {
-            const uint64_t *src = tabs + ((size_t)first << TSL) + lane * TPL;
+        if (first < n && smp) {
+            const uint64_t *src = tabs + ((size_t)first << TSL) + l64 * TPL;
 #pragma unroll
             for (int i = 0; i < TPL; i += 2) { const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src + i); ptab[i] = v.x; ptab[i + 1] = v.y; }
-            if (act) ptape = *reinterpret_cast<const uint4 *>(mytape + 4 * (size_t)(first + g));
+            if (act) ptape = *reinterpret_cast<const uint4 *>(mytape + 4 * (size_t)(first + (l64 & 7)));
         }
     };
+    // NW = 2: the second wavefront draws the samples, one register sub-tree AHEAD of the first wavefront's recursion (they depend on nothing the walk
+    // computes): tables and tape words of sub-tree i + 1 -> LDS -> 16 samples per signature -> ssmp[(i + 1) & 1], while the first wavefront runs sub-tree i
+    // on ssmp[i & 1].  The recursion then has half the instructions of a sub-tree visit, the other half runs beside it on another SIMD.
+    auto draw_ahead = [&](uint32_t sub) {                              // sampling wavefront only: ptab / ptape hold sub-tree `sub`
+#pragma unroll
+        for (int i = 0; i < TPL; i++) stab[l64 * TPL + i] = ptab[i];
+        *reinterpret_cast<uint4 *>(stape + l64 * 4) = ptape;
+        wave_sync();
+        LeafPre<TSL> lfl;
+        lfl.draw(stab, stape + sg * 32, l64 & 7);
+        if ((l64 & 7) == 0) {
+            double *dst = ssmp + ((sub & 1) * SPW + sg) * 16;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) *reinterpret_cast<double2 *>(dst + i) = make_double2(lfl.d[i], lfl.d[i + 1]);
+        }
+        wave_sync();                                                   // stab / stape are free again
+    };
     prefetch(0);
+    if (NW == 2 && smp) { draw_ahead(0); prefetch(1u << FK); }
+    uint32_t sub = 0;                                                  // index of the next register sub-tree
     WalkL<LM> w = { n, logn, 0 };
     uint32_t toff = 0;
     int l = logn;
@@ -979,27 +1006,29 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
         if (entering) {
             if (l == FK) {
                 // an 8-coefficient sub-tree in registers; every lane of a group computes the same thing from the same (broadcast) LDS words
-                if (w0) {
+                if (NW == 1) {
 #pragma unroll
                     for (int i = 0; i < TPL; i++) stab[lane * TPL + i] = ptab[i];
                     if (act) *reinterpret_cast<uint4 *>(stape + lane * 4) = ptape;
+                    wave_sync();
                 }
-                group_sync<NW>();
                 if (act && w0) {
                     double t0r[1 << FK], t1r[1 << FK], z0r[1 << FK], z1r[1 << FK];
                     const uint32_t pt0 = w.lt0(l), pt1 = w.lt1(l), pz0 = w.lz0(l), pz1 = w.lz1(l);
 #pragma unroll
                     for (int i = 0; i < (1 << FK); i++) { t0r[i] = lg.ld(pt0 + i); t1r[i] = lg.ld(pt1 + i); }
                     LeafPre<TSL> lfl;
-                    lfl.draw(stab, stape + sg * 32, g);
+                    if (NW == 1) lfl.draw(stab, stape + sg * 32, g);
+                    else lfl.take(ssmp + ((sub & 1) * SPW + sg) * 16);       // written during the previous visit, before its closing barrier
                     FFS<FK, LeafPre<TSL>>::run(z0r, z1r, stree + (toff - toffLM), t0r, t1r, gm, lfl);
                     if (g == 0) {
 #pragma unroll
                         for (int i = 0; i < (1 << FK); i++) { lg.st(pz0 + i, z0r[i]); lg.st(pz1 + i, z1r[i]); }
                     }
                 }
-                leaf += 1u << FK;
-                prefetch(leaf);
+                leaf += 1u << FK; sub++;
+                if (NW == 1) prefetch(leaf);
+                else if (smp && leaf < n) { draw_ahead(sub); prefetch(leaf + (1u << FK)); }      // the samples of the NEXT visit
                 group_sync<NW>();
                 FAL_STAMP(4);
                 entering = false; l++;
@@ -1771,13 +1800,12 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
     if (!d_key_of && (f->force_g == 0 || f->force_g == 64)) {
-        // variant (see the kernel's head): (8, 7) while its one wavefront per SIMD holds the whole batch (8 x 1024 signatures: the BASELINE batch), (8, 6) -
-        // two wavefronts per SIMD - beyond.  Measured, Falcon-1024 sign/s: batch 8192 6.4 M / 5.8 M / 6.1 M for (8, 7) / (8, 6) / (4, 6); 16384 7.3 / 8.3 / 6.9;
-        // 131072 8.4 / 9.7 / 8.2 (profiles/r02_falcon_variants.txt)
+        // variant (see the kernel's head).  n = 1024: (8, 7) with two wavefronts per workgroup at every batch size - measured sign M/s for (8, 7) one wavefront /
+        // (8, 7) two wavefronts / (8, 6): batch 4096 3.8 / 4.6 / 3.7, 8192 6.4 / 7.6 / 5.9, 16384 7.2 / 8.8 / 8.7, 32768 7.6 / 9.0 / 9.0, 131072 8.1 / 10.2 / 10.0
+        // (profiles/r02_falcon_variants.txt).  n = 512 (one wavefront per workgroup only): (8, 7) while one wavefront per SIMD holds the batch, (8, 6) beyond.
         int spw = f->var_spw, lm = f->var_lm;
-        if (!spw) { spw = 8; lm = (batch + 7) / 8 <= (size_t)f->ctx->cus * 4 ? 7 : 6; }
-        // two wavefronts per workgroup (n = 1024, the (8, 7) variant): while the batch leaves SIMDs without a wavefront
-        int nw = f->var_nw ? f->var_nw : ((spw == 8 && lm == 7 && f->P.n == 1024) ? 2 : 1);
+        if (!spw) { spw = 8; lm = (f->P.n == 1024 || (batch + 7) / 8 <= (size_t)f->ctx->cus * 4) ? 7 : 6; }
+        int nw = f->var_nw ? f->var_nw : 2;
         if (!(spw == 8 && lm == 7 && f->P.n == 1024)) nw = 1;
         const dim3 grid8((unsigned)((batch + spw - 1) / spw));
 #define FAL_W8B(TSL, PR, S_, L_, N_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_, N_>), grid8, dim3(64 * N_), 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
