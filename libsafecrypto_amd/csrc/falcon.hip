@@ -708,7 +708,8 @@ __device__ __forceinline__ void fft_pass_w(const A &c, uint32_t lane, uint32_t f
         double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
 #pragma unroll
         for (int k = 0; k < PG; k++) {
-            const uint32_t t = t0 + k * TPB + lane, grp = t & (groups - 1), i1 = grp >> lq;
+            const uint32_t tt = t0 + k * TPB + lane, t = (TPB > 64 && tt >= tot) ? 0u : tt;      // two wavefronts on a short polynomial: the spare lanes redo group 0 and store nothing
+            const uint32_t grp = t & (groups - 1), i1 = grp >> lq;
             j0[k] = (t >> lgr) * per + f + ((i1 << R) << lq) + (grp & (Q - 1));
 #pragma unroll
             for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lq)); xi[k][a] = c.ld(j0[k] + (a << lq) + hn); }
@@ -735,8 +736,10 @@ __device__ __forceinline__ void fft_pass_w(const A &c, uint32_t lane, uint32_t f
                     xr[k][a + sp] = ar - yr; xi[k][a + sp] = ai - yi;
                 }
             }
+            if (TPB == 64 || t0 + k * TPB + lane < tot) {
 #pragma unroll
-            for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lq), xr[k][a]); c.st(j0[k] + (a << lq) + hn, xi[k][a]); }
+                for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lq), xr[k][a]); c.st(j0[k] + (a << lq) + hn, xi[k][a]); }
+            }
         }
     }
     group_sync<TPB / 64>();
@@ -762,7 +765,8 @@ __device__ __forceinline__ void ifft_pass_w(const A &c, uint32_t lane, uint32_t 
         double xr[PG][P], xi[PG][P], wr[PG][P - 1], wi[PG][P - 1]; uint32_t j0[PG];
 #pragma unroll
         for (int k = 0; k < PG; k++) {
-            const uint32_t t = t0 + k * TPB + lane, grp = t & (groups - 1), iB = grp >> lt;
+            const uint32_t tq = t0 + k * TPB + lane, t = (TPB > 64 && tq >= tot) ? 0u : tq;
+            const uint32_t grp = t & (groups - 1), iB = grp >> lt;
             j0[k] = (t >> lgr) * per + f + ((iB << R) << lt) + (grp & (tt0 - 1));
 #pragma unroll
             for (int a = 0; a < P; a++) { xr[k][a] = c.ld(j0[k] + (a << lt)); xi[k][a] = c.ld(j0[k] + (a << lt) + hn); }
@@ -788,8 +792,10 @@ __device__ __forceinline__ void ifft_pass_w(const A &c, uint32_t lane, uint32_t 
                     cmul(xr[k][a + sp], xi[k][a + sp], dr, di, wr[k][ti], -wi[k][ti]);
                 }
             }
+            if (TPB == 64 || t0 + k * TPB + lane < tot) {
 #pragma unroll
-            for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lt), xr[k][a]); c.st(j0[k] + (a << lt) + hn, xi[k][a]); }
+                for (int a = 0; a < P; a++) { c.st(j0[k] + (a << lt), xr[k][a]); c.st(j0[k] + (a << lt) + hn, xi[k][a]); }
+            }
         }
     }
     group_sync<TPB / 64>();
@@ -877,7 +883,7 @@ struct WalkL {
 // signatures.  tape_stride >= 4n (the launcher answers shorter strides itself): a tape that is short is still read to 4n words - inside its
 // own row - and its signature reports status 2 and writes nothing.
 // PROF (measurement builds only, sc_hip_falcon_sample_profile): each wavefront adds the shader cycles it spent in the six phases to prof[0..5].
-// NW = 2 (n = 1024, SPW = 8 only): the workgroup is TWO wavefronts on the same 8 signatures - the wave-mode sweeps and the transforms are shared by 128
+// NW = 2 (SPW = 8, LM = 7 only): the workgroup is TWO wavefronts on the same 8 signatures - the wave-mode sweeps and the transforms are shared by 128
 // lanes, group mode gives a signature 16 lanes (8 in each wavefront), the register sub-trees run on the first wavefront while the second waits.  A
 // wavefront alone on a SIMD issues one instruction per ~10 cycles, so at the BASELINE batch (8192 signatures = 1024 workgroups) the second wavefront
 // of every workgroup lands on a SIMD that would otherwise idle and halves the instruction stream of everything that is not a register sub-tree.
@@ -1800,13 +1806,13 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
     if (!d_key_of && (f->force_g == 0 || f->force_g == 64)) {
-        // variant (see the kernel's head).  n = 1024: (8, 7) with two wavefronts per workgroup at every batch size - measured sign M/s for (8, 7) one wavefront /
-        // (8, 7) two wavefronts / (8, 6): batch 4096 3.8 / 4.6 / 3.7, 8192 6.4 / 7.6 / 5.9, 16384 7.2 / 8.8 / 8.7, 32768 7.6 / 9.0 / 9.0, 131072 8.1 / 10.2 / 10.0
-        // (profiles/r02_falcon_variants.txt).  n = 512 (one wavefront per workgroup only): (8, 7) while one wavefront per SIMD holds the batch, (8, 6) beyond.
+        // variant (see the kernel's head): (8, 7) with two wavefronts per workgroup at every batch size - measured sign M/s for (8, 7) one wavefront /
+        // (8, 7) two wavefronts / (8, 6), n = 1024: batch 4096 3.8 / 4.6 / 3.7, 8192 6.4 / 7.6 / 5.9, 16384 7.2 / 8.8 / 8.7, 32768 7.6 / 9.0 / 9.0, 131072 8.1 / 10.2 / 10.0;
+        // n = 512: 4096 7.7 / 8.8 / 7.2, 8192 12.7 / 14.8 / 11.2, 16384 14.7 / 17.5 / 17.2, 131072 17.5 / 21.7 / 21.0 (profiles/r02_falcon_variants.txt)
         int spw = f->var_spw, lm = f->var_lm;
-        if (!spw) { spw = 8; lm = (f->P.n == 1024 || (batch + 7) / 8 <= (size_t)f->ctx->cus * 4) ? 7 : 6; }
+        if (!spw) { spw = 8; lm = 7; }
         int nw = f->var_nw ? f->var_nw : 2;
-        if (!(spw == 8 && lm == 7 && f->P.n == 1024)) nw = 1;
+        if (!(spw == 8 && lm == 7)) nw = 1;
         const dim3 grid8((unsigned)((batch + spw - 1) / spw));
 #define FAL_W8B(TSL, PR, S_, L_, N_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_, N_>), grid8, dim3(64 * N_), 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
                                             f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
