@@ -741,7 +741,8 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     }
     // the masks y (with z they give s1), w = A y, the rejected candidates z and the remainders r do not outlive the call (dilithium.c:1964-1975)
     const size_t ws_ = wiped_slots;
-    HIPCHK(hipMemsetAsync(d->y, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->yh, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->z, 0, ws_ * l * P.n * 4, s));
+    HIPCHK(hipMemsetAsync(d->y, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->z, 0, ws_ * l * P.n * 4, s));
+    if (!(ks.As && !ks.per_item)) HIPCHK(hipMemsetAsync(d->yh, 0, ws_ * l * P.n * 4, s));        // NTT(y): only the unfused path writes it (the fused kernel keeps it in registers)
     HIPCHK(hipMemsetAsync(d->w, 0, ws_ * k * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->r, 0, ws_ * k * P.n * 4, s));
     return SC_HIP_SUCCESS;
 }
