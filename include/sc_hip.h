@@ -443,7 +443,9 @@ size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *h);      /* n * (q_bits - 
 /* key sets (distinct keys): nkeys expanded private keys / public keys back to back in the layouts above, resident on the device
  * ((n_bits + 5) n doubles + n leaf tables per private key: 0.4 MB for Falcon-1024).  set_privkey / set_pubkey load a set of one; the one-key calls
  * use key 0.  sc_hip_falcon_sign_keys / _verify_keys take the key index of every message (d_key_of [batch]); an index outside the set gives
- * d_status 6 / verdict 1.  The sampler then runs 8 lanes per signature with every key read where it lies (no key material is staged in LDS). */
+ * d_status 6 / verdict 1.  Submit messages GROUPED BY KEY where possible: a run of 8 consecutive messages (aligned to 8) under one key is signed by the
+ * same kernel as a one-key batch (7.0 M sign/s at batch 8192 over 64 keys); a group of 8 that mixes keys runs 8 lanes per signature with every key read
+ * where it lies (2.6 M sign/s when no two neighbours share a key).  The bytes are the same either way. */
 int  sc_hip_falcon_set_privkeys(sc_hip_falcon_t *h, size_t nkeys, const double *sk);
 int  sc_hip_falcon_set_pubkeys(sc_hip_falcon_t *h, size_t nkeys, const int16_t *pk);
 /* how the tree sampler is laid over the machine; results are identical (the same double operations in the same order).  0 (default) = 64:

@@ -364,7 +364,7 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
                                                         const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
                                                         const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                         int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
-                                                        const uint32_t *__restrict__ key_of, uint32_t nkeys, size_t sk_stride, size_t tab_stride)
+                                                        const uint32_t *__restrict__ key_of, uint32_t nkeys, size_t sk_stride, size_t tab_stride, int only_deferred)
 {
     constexpr int FK = (G == 1) ? FK1 : FK8;
     const uint32_t tid = blockIdx.x * ST + threadIdx.x, b = tid / G, g = tid % G;
@@ -372,6 +372,10 @@ __global__ __launch_bounds__(ST) void fal_sample_kernel(uint32_t batch, size_t B
     const uint32_t n = (uint32_t)P.n; const int logn = P.n_bits;
     const uint32_t have = tape_lens ? tape_lens[b] : (uint32_t)tape_stride;
     if (have < 4 * n) { if (g == 0) status[b] = 2; return; }
+    if (only_deferred) {                           // behind the wavefront-per-8 kernel: only the signatures it handed over (status 7)
+        if (status[b] != 7) return;
+        if (g == 0) status[b] = 0;
+    }
     if (key_of) {                                  // a key per signature out of the handle's key set: basis, tree and leaf tables are this key's
         const uint32_t kx = key_of[b];
         if (kx >= nkeys) { if (g == 0) status[b] = 6; return; }
@@ -892,7 +896,8 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
                                                            const uint32_t *__restrict__ tapes, size_t tape_stride, const uint32_t *__restrict__ tape_lens,
                                                            const double *__restrict__ sk, const double *__restrict__ gm, const uint64_t *__restrict__ tabs,
                                                            int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint32_t *__restrict__ status, FalP P, double ni,
-                                                           unsigned long long *__restrict__ prof)
+                                                           unsigned long long *__restrict__ prof,
+                                                           const uint32_t *__restrict__ key_of, uint32_t nkeys, size_t sk_stride, size_t tab_stride)
 {
     constexpr int LDS_SIG = WalkL<LM>::LDS_SIG;
     constexpr int POLY = 1024 + 128;                                   // a padded polynomial (LdsF) for n <= 1024
@@ -920,12 +925,21 @@ __global__ __launch_bounds__(64 * NW) void fal_sample_w8_kernel(uint32_t batch, 
     const uint32_t n = (uint32_t)P.n, hn = n >> 1; const int logn = P.n_bits;
     const uint32_t per = 6 * n;
     const Lin wv = { ws + (size_t)sig0 * per };                        // wave mode: the SPW signatures, `per` doubles apart
-    const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
     const uint32_t C0 = 0, C1 = n, Z0 = 2 * n, Z1 = 3 * n;
     // group mode: this lane's signature.  A signature past the end of the batch is computed on item 0's inputs (in its own workspace slot).
     const uint32_t mysig = sig0 + sg;
     const bool inb = mysig < batch;
     const uint32_t item = inb ? mysig : 0;
+    // a key set: this form serves a workgroup whose signatures all name the same (valid) key - the leaf tables and the lower tree staged in LDS are one
+    // key's.  Any other workgroup hands its signatures (status 7) to the 8-lanes-per-signature kernel the launcher runs behind this one.
+    if (key_of) {
+        const uint32_t k0 = key_of[sig0 < batch ? sig0 : batch - 1];
+        const bool odd = act && inb && key_of[mysig] != k0;
+        const bool defer = (NW == 2 ? (bool)__syncthreads_or(odd ? 1 : 0) : __ballot(odd) != 0) || k0 >= nkeys;
+        if (defer) { if (act && inb && g == 0) status[mysig] = 7; return; }
+        sk += (size_t)k0 * sk_stride; tabs += (size_t)k0 * tab_stride;
+    }
+    const double *b00 = sk, *b01 = sk + n, *b10 = sk + 2 * n, *b11 = sk + 3 * n, *tree = sk + 4 * n;
     const bool shortt = act && inb && tape_lens && tape_lens[mysig] < 4 * n;
     if (shortt && g == 0) status[mysig] = 2;
     const uint64_t runmask = __ballot(act && inb && !shortt);           // bit 8k: signature k of this wavefront writes its results
@@ -1805,7 +1819,9 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     }
     HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
-    if (!d_key_of && (f->force_g == 0 || f->force_g == 64)) {
+    const size_t sk_stride = (size_t)(f->P.n_bits + 5) * (size_t)f->P.n, tab_stride = (size_t)f->P.n << f->ts_log;
+    const bool w8 = f->force_g == 0 || f->force_g == 64;
+    if (w8) {
         // variant (see the kernel's head): (8, 7) with two wavefronts per workgroup at every batch size - measured sign M/s for (8, 7) one wavefront /
         // (8, 7) two wavefronts / (8, 6), n = 1024: batch 4096 3.8 / 4.6 / 3.7, 8192 6.4 / 7.6 / 5.9, 16384 7.2 / 8.8 / 8.7, 32768 7.6 / 9.0 / 9.0, 131072 8.1 / 10.2 / 10.0;
         // n = 512: 4096 7.7 / 8.8 / 7.2, 8192 12.7 / 14.8 / 11.2, 16384 14.7 / 17.5 / 17.2, 131072 17.5 / 21.7 / 21.0 (profiles/r02_falcon_variants.txt)
@@ -1815,7 +1831,7 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
         if (!(spw == 8 && lm == 7)) nw = 1;
         const dim3 grid8((unsigned)((batch + spw - 1) / spw));
 #define FAL_W8B(TSL, PR, S_, L_, N_) hipLaunchKernelGGL((fal_sample_w8_kernel<TSL, PR, S_, L_, N_>), grid8, dim3(64 * N_), 0, s, (uint32_t)batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
-                                            f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof)
+                                            f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_prof, d_key_of, (uint32_t)f->nkeys, sk_stride, tab_stride)
 #define FAL_W8A(TSL, PR) do { if (spw == 8 && lm == 7 && nw == 2) FAL_W8B(TSL, PR, 8, 7, 2); else if (spw == 8 && lm == 7) FAL_W8B(TSL, PR, 8, 7, 1); \
                               else if (spw == 8) FAL_W8B(TSL, PR, 8, 6, 1); else FAL_W8B(TSL, PR, 4, 6, 1); } while (0)
 #define FAL_W8(TSL) do { if (d_prof) FAL_W8A(TSL, true); else FAL_W8A(TSL, false); } while (0)
@@ -1829,16 +1845,16 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
 #undef FAL_W8A
 #undef FAL_W8B
         HIPCHK(hipGetLastError());
-        return SC_HIP_SUCCESS;
+        if (!d_key_of) return SC_HIP_SUCCESS;
+        // a key set: the workgroups whose 8 signatures do not share one key left theirs (status 7) to the kernel below
     }
     // the two batch-interleaved mappings: a lane per signature, or 8 lanes per signature (the state in HBM either way)
-    // (a key per signature: 8 lanes per signature - the wavefront-per-8 mapping stages ONE key's lower tree and leaf tables in LDS)
     const bool wide = f->force_g == 8 || (d_key_of && f->force_g != 1);
     const size_t threads = wide ? batch * 8 : batch;
-    const size_t sk_stride = (size_t)(f->P.n_bits + 5) * (size_t)f->P.n, tab_stride = (size_t)f->P.n << f->ts_log;
+    const int only_deferred = (w8 && d_key_of) ? 1 : 0;
     const dim3 grid((unsigned)((threads + ST - 1) / ST)), block(ST);
 #define FAL_LAUNCH(TSL, G) hipLaunchKernelGGL((fal_sample_kernel<TSL, G>), grid, block, 0, s, (uint32_t)batch, batch, f->ws, d_c, d_tapes, tape_stride, d_tape_lens, \
-                                              f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_key_of, (uint32_t)f->nkeys, sk_stride, tab_stride)
+                                              f->d_sk, f->d_gm, f->d_tabs, d_s1, d_s2, d_status, f->P, ni, d_key_of, (uint32_t)f->nkeys, sk_stride, tab_stride, only_deferred)
 #define FAL_PICK(TSL) do { if (wide) FAL_LAUNCH(TSL, 8); else FAL_LAUNCH(TSL, 1); } while (0)
     switch (f->ts_log) {
     case 4: FAL_PICK(4); break;

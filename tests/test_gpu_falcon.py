@@ -239,6 +239,23 @@ def test_distinct_keys_from_the_reference_keygen(eng, tmp_path):
     assert int(v[ok].sum()) == 0 and int(v[B - 1]) == 1
     wrong = ((ko + 1) % NK).to(torch.int32).contiguous()
     assert int((f.verify_keys(wrong, mb, sigs, siglens, mlens=ml) == 0).sum()) == 0
+    # messages grouped by key (runs of 8 and more: the wavefront-per-8 form serves a workgroup whose signatures share a key) with a ragged run in the
+    # middle (those workgroups fall back to the 8-lanes-per-signature form): same bytes as signing each message alone under its key
+    runs = [(k, 16) for k in range(0, NK, 3)] + [(5, 3), (9, 13)] + [(k, 8) for k in range(1, NK, 7)]
+    gk = [k for k, cnt in runs for _ in range(cnt)]
+    GB = len(gk)
+    gm = [bytes(rng.integers(0, 256, size=40, dtype=np.uint8)) for _ in range(GB)]
+    gt = rng.integers(0, 2**32, size=(GB, 4 * n), dtype=np.uint64).astype(np.uint32)
+    gmb, gml = pack_msgs(gm)
+    gko = torch.tensor(gk, dtype=torch.int32, device='cuda')
+    gs, gl, gst = f.sign_keys(gko, gmb, torch.from_numpy(gt.view(np.int32)).cuda(), mlens=gml)
+    gsh, glh, gsth = gs.cpu().numpy(), gl.cpu().numpy(), gst.cpu().numpy()
+    for i in list(range(0, GB, 5)) + list(range(GB - 20, GB)):
+        rc, sig = O.falcon_sign(keys[gk[i]], gm[i], gt[i])
+        assert (rc, gsth[i]) in ((0, 1), (1, 4)), i
+        if rc == 0:
+            assert bytes(gsh[i, :glh[i]]) == sig, i
+    assert int(f.verify_keys(gko, gmb, gs, gl, mlens=gml)[torch.from_numpy(gsth == 1).cuda()].sum()) == 0
     # the one-key calls use key 0 of the set
     s0, l0, t0 = f.sign(mb[:1], tp[:1], mlens=ml[:1])
     assert int(t0[0]) == st[0] and bytes(s0[0, :int(l0[0])].cpu().numpy()) == bytes(sh[0, :lh[0]])
