@@ -79,3 +79,26 @@ def test_large_batch_vs_oracle_and_edges(eng):
     assert np.array_equal(got, O.cdt_sample(u, cdf))
     assert abs(float(got.std()) - sigma) < 1.0 and abs(float(got.mean())) < 0.5
     s.close()
+
+
+@pytest.mark.parametrize('tail,sigma', [(13.42, 19.53), (13.42, 271.0), (13.42, 250.0), (10.0, 1.3), (10.0, 6.3), (12.0, 30.0), (13.0, 3.2)])
+def test_guide_layouts_vs_oracle(eng, tail, sigma):
+    """the sampler's guide (csrc/cdt_guide.h) picks a different bin layout and probe count per table - one probe for sigma ~ 20, three for the BLISS
+    sigmas, the runtime-count loop for the narrow Falcon-leaf-like tables, the closing run of equal entries where the table has one: every table entry
+    and its two neighbours, the extremes, the words just below / above each power of two of the tail probability, and a random batch, against the
+    oracle's halving search on the table built on this host"""
+    import torch
+    s = eng.sampler(tail, sigma)
+    cdf = O.cdt_table(tail, sigma)
+    assert np.array_equal(s.table(), cdf)
+    rng = np.random.default_rng(int(sigma * 100))
+    words = [0, 1, 2, 2**64 - 1, 2**64 - 2, 2**63, 2**63 - 1, 2**63 + 1]
+    for e in cdf.tolist():
+        words += [max(e - 1, 0), e, min(e + 1, 2**64 - 1)]
+    for k in range(1, 64):
+        words += [2**64 - (1 << k), 2**64 - (1 << k) - 1, 2**64 - (1 << k) + 1, (1 << k) - 1, 1 << k]
+    u = np.concatenate([np.array(words, dtype=np.uint64), rng.integers(0, 2**64 - 1, size=1 << 18, dtype=np.uint64, endpoint=True)])
+    got = s.sample(torch.from_numpy(u.view(np.int64)).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.cdt_sample(u, cdf))
+    assert np.array_equal(s.sample(torch.from_numpy(u[1:].copy().view(np.int64)).cuda(), centre=-3).cpu().numpy(), O.cdt_sample(u[1:], cdf) - 3)   # the unaligned path
+    s.close()
