@@ -192,7 +192,32 @@ __device__ __forceinline__ int32_t sparse_at(const T *t, const int32_t *c, int o
     return acc;
 }
 
+// the same with the positions already in registers (a wavefront reuses them for every coefficient of three polynomials): pos[k] for k < omega <= MAXW
+constexpr int MAXW = 32;
+struct Pos { int p[MAXW]; };
+__device__ __forceinline__ void load_pos(Pos &P_, const int32_t *c, int omega)
+{
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) P_.p[k] = k < omega ? c[k] : 0;
+}
+template <typename T>
+__device__ __forceinline__ int32_t sparse_reg(const T *t, const Pos &P_, int omega, int n, int j)
+{
+    int32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < MAXW; k++) {
+        if (k < omega) {                                               // wave-uniform
+            const int d = j - P_.p[k];
+            const int32_t v = (int32_t)t[d & (n - 1)];                  // d < 0: index d + n (n a power of two), sign +
+            acc += d < 0 ? v : -v;
+        }
+    }
+    return acc;
+}
+
 __device__ __forceinline__ int32_t norm_q(int32_t x, int32_t q) { int32_t r = x % q; return r < 0 ? r + q : r; }     // normalize_32
+// normalize_32 of a value known to lie in (-q, 2q): no division (x % q by a run-time q is some forty instructions)
+__device__ __forceinline__ int32_t norm_near(int32_t x, int32_t q) { x += (x >> 31) & q; return x >= q ? x - q : x; }
 
 // test_w (ring_tesla.c:542-578) on a normalised value
 __device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
@@ -216,17 +241,19 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
     const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (slot >= nslots) return;
     if (need[slot] == 2) { if (lane == 0) acc[slot] = 0; return; }
-    const int32_t *c = cidx + (size_t)slot * P.omega;
+    Pos pos; load_pos(pos, cidx + (size_t)slot * P.omega, P.omega);
+    // Every value normalised below is a centred residue (at most (q-1)/2 in magnitude) or a mask coefficient (at most b) plus omega key coefficients of
+    // 16 bits: inside (-q, q) because omega * 2^15 < q / 2 and b < q / 2 (checked by sc_hip_tesla_create) - normalize_32 without the division.
     // the reference tests w1, then w2, then z and leaves at the first failure (ring_tesla.c:852-880): so does the wavefront
     int32_t bad = 0;
     for (int j = lane; j < n; j += 64) {
-        const int32_t a = norm_q(centre_q(v1[(size_t)slot * n + j], P.q) - sparse_at(ks + n, c, P.omega, n, j), P.q);
+        const int32_t a = norm_near(centre_q(v1[(size_t)slot * n + j], P.q) - sparse_reg(ks + n, pos, P.omega, n, j), P.q);
         bad |= w_bad(a, P) ? 1 : 0;
     }
     bad = wave_or(bad);
     if (!bad) {
         for (int j = lane; j < n; j += 64) {
-            const int32_t b = norm_q(centre_q(v2[(size_t)slot * n + j], P.q) - sparse_at(ks + 2 * n, c, P.omega, n, j), P.q);
+            const int32_t b = norm_near(centre_q(v2[(size_t)slot * n + j], P.q) - sparse_reg(ks + 2 * n, pos, P.omega, n, j), P.q);
             bad |= w_bad(b, P) ? 1 : 0;
         }
         bad = wave_or(bad);
@@ -235,7 +262,7 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
     if (!bad) {
         for (int j = lane; j < n; j += 64) {
             const size_t k = (size_t)slot * n + j;
-            const int32_t z = centre_q(norm_q(sparse_at(ks, c, P.omega, n, j) + y[k], P.q), P.q);
+            const int32_t z = centre_q(norm_near(sparse_reg(ks, pos, P.omega, n, j) + y[k], P.q), P.q);
             zout[k] = z;
             bad |= (z < -th || z > th) ? 1 : 0;
         }
@@ -315,16 +342,17 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const ui
 }
 
 // w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products
-__global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *t1, const int32_t *t2, const int32_t *cidx, TsP P)
+__global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *t1, const int32_t *t2, const int32_t *cidx, TsP P, sc::ModK mk)
 {
     const int lane = threadIdx.x & 63, n = P.n;
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= batch) return;
-    const int32_t *c = cidx + (size_t)item * P.omega;
+    Pos pos; load_pos(pos, cidx + (size_t)item * P.omega, P.omega);
     for (int j = lane; j < n; j += 64) {
         const size_t k = (size_t)item * n + j;
-        w1[k] = norm_q(w1[k] - sparse_at(t1, c, P.omega, n, j), P.q);
-        w2[k] = norm_q(w2[k] - sparse_at(t2, c, P.omega, n, j), P.q);
+        // any int32 -> [0, q) by a Barrett step (modarith.h) instead of the division normalize_32 compiles to
+        w1[k] = (int32_t)sc::csub(sc::reduce_i32(w1[k] - sparse_reg(t1, pos, P.omega, n, j), mk), mk.q);
+        w2[k] = (int32_t)sc::csub(sc::reduce_i32(w2[k] - sparse_reg(t2, pos, P.omega, n, j), mk), mk.q);
     }
 }
 
@@ -377,6 +405,7 @@ extern "C" int sc_hip_tesla_create(sc_hip_ctx_t *ctx, const sc_hip_tesla_params_
     static_assert(sizeof(TsP) == sizeof(sc_hip_tesla_params_t), "parameter struct layout");
     TsP P; memcpy(&P, params, sizeof P);
     if (P.n != 512 || (1 << P.n_bits) != P.n) return fail("tesla_create: n must be 512");
+    if (P.omega > MAXW || (long long)P.omega * 32768 >= P.q / 2 || P.b >= P.q / 2) return fail("tesla_create: omega above 32, or omega * 2^15 or b not below q / 2 (the decide kernel's division-free normalisation)");
     if (P.omega < 1 || P.omega > 64 || P.d < 2 || P.d > 30 || P.q_bits < 8 || P.q_bits > 30 || P.b_bits < 1 || P.b_bits > 30 || P.q < 3) return fail("tesla_create: parameters out of range");
     sc_hip_plan *plan = nullptr;
     if (sc_hip_plan_create(ctx, P.q, P.n, &plan) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
@@ -514,7 +543,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P);
+    hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P, t->plan->k[1]);
     hipLaunchKernelGGL(ts_round_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->r1, t->r2, t->nz, 0, P);
     hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, 1u, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                        t->d_zstate, t->zblocks, (uint8_t *)nullptr, 1, d_verdicts, d_sigs, sig_stride, md_off, P);
