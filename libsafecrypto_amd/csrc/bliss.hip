@@ -612,12 +612,12 @@ extern "C" int sc_hip_bliss_set_key(sc_hip_bliss_t *b, const int16_t *f, const i
     std::vector<int32_t> a32(n);
     for (size_t i = 0; i < n; i++) a32[i] = a[i];
     if (!b->d_a) HIPCHK(hipMalloc((void **)&b->d_a, n * 4));
-    HIPCHK(hipMemcpy(b->d_a, a32.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(b->d_a, a32.data(), n * 4));
     if (f) {
         if (!b->d_f) HIPCHK(hipMalloc((void **)&b->d_f, n * 2));
         if (!b->d_g) HIPCHK(hipMalloc((void **)&b->d_g, n * 2));
-        HIPCHK(hipMemcpy(b->d_f, f, n * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(b->d_g, g, n * 2, hipMemcpyHostToDevice));
+        HIPCHK(sc::copy_in(b->d_f, f, n * 2));
+        HIPCHK(sc::copy_in(b->d_g, g, n * 2));
     }
     b->have_key = true;
     return SC_HIP_SUCCESS;

@@ -512,7 +512,7 @@ static int key_ntt(sc_hip_dilithium *d, const int32_t *h_polys, size_t npoly, ui
     if (tb.get(bytes)) return SC_HIP_FAILURE;
     int32_t *tmp = tb.as<int32_t>();
     if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
-    HIPCHK(hipMemcpy(tmp, h_polys, bytes, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(tmp, h_polys, bytes));
     DilNtt a = base_args(d);
     a.in = tmp; a.out_int = *dst;
     int rc = launch_dil<DOP_KEYPREP>(d, a, (uint32_t)npoly, 1, nullptr);
@@ -527,7 +527,7 @@ static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
     if (tb.get(bytes)) return SC_HIP_FAILURE;
     int32_t *tmp = tb.as<int32_t>();
     if (!d->d_A) HIPCHK(hipMalloc((void **)&d->d_A, bytes));
-    HIPCHK(hipMemcpy(tmp, h_Ahat, bytes, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(tmp, h_Ahat, bytes));
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, nullptr, tmp, d->d_A, np, d->plan->k[1], d->plan->r2, d->plan->r2p);
     if (d->P.l >= 2 && d->P.l <= 5) {
         if (!d->d_As) HIPCHK(hipMalloc((void **)&d->d_As, 2 * bytes));
@@ -550,8 +550,8 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
     if (!d->d_K) HIPCHK(hipMalloc((void **)&d->d_K, 32));
     if (!d->d_tr_priv) HIPCHK(hipMalloc((void **)&d->d_tr_priv, 48));
-    HIPCHK(hipMemcpy(d->d_K, K, 32, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d->d_tr_priv, tr, 48, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(d->d_K, K, 32));
+    HIPCHK(sc::copy_in(d->d_tr_priv, tr, 48));
     d->have_priv = true;
     return SC_HIP_SUCCESS;
 }
@@ -567,11 +567,11 @@ extern "C" int sc_hip_dilithium_set_pubkey(sc_hip_dilithium_t *d, const int32_t 
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
     if (!d->d_rho) HIPCHK(hipMalloc((void **)&d->d_rho, 32));
     if (!d->d_tr_pub) HIPCHK(hipMalloc((void **)&d->d_tr_pub, 48));
-    HIPCHK(hipMemcpy(d->d_rho, rho, 32, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(d->d_rho, rho, 32));
     DevBuf t1b;
     if (t1b.get(t1s.size() * 4)) return SC_HIP_FAILURE;
     int32_t *dt1 = t1b.as<int32_t>();
-    HIPCHK(hipMemcpy(dt1, t1, t1s.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(dt1, t1, t1s.size() * 4));
     hipLaunchKernelGGL(dil_crh_t1_kernel, dim3(1), dim3(HT), 0, nullptr, d->d_rho, dt1, (uint32_t)t1s.size(), d->P.q_bits - d->P.d, d->d_tr_pub, 1u);
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium_set_pubkey: CRH kernel failed");
     d->have_pub = (rc == SC_HIP_SUCCESS);
@@ -815,13 +815,13 @@ extern "C" int sc_hip_dilithium_sign_host(sc_hip_dilithium_t *d, size_t batch, c
     const size_t moff = (batch * msg_stride + 7) & ~(size_t)7, sbytes = batch * sig_stride, soff = (sbytes + 7) & ~(size_t)7;
     if (stage((void **)&d->msg_dev, &d->msg_cap, moff + batch * 4 + 8) || stage((void **)&d->sig_dev, &d->sig_cap, soff + batch * 8 + 8)) return SC_HIP_FAILURE;
     uint32_t *dl = (uint32_t *)(d->msg_dev + moff), *dsl = (uint32_t *)(d->sig_dev + soff), *dtr = dsl + batch;
-    if (h_msgs && batch * msg_stride) HIPCHK(hipMemcpy(d->msg_dev, h_msgs, batch * msg_stride, hipMemcpyHostToDevice));
-    if (h_mlens) HIPCHK(hipMemcpy(dl, h_mlens, batch * 4, hipMemcpyHostToDevice));
+    if (h_msgs && batch * msg_stride) HIPCHK(sc::copy_in(d->msg_dev, h_msgs, batch * msg_stride));
+    if (h_mlens) HIPCHK(sc::copy_in(dl, h_mlens, batch * 4));
     int rc = sc_hip_dilithium_sign(d, batch, d->msg_dev, msg_stride, h_mlens ? dl : nullptr, fixed_len, d->sig_dev, sig_stride, dsl, dtr, nullptr);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(h_sigs, d->sig_dev, sbytes, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_siglens, dsl, batch * 4, hipMemcpyDeviceToHost));
-    if (h_trials) HIPCHK(hipMemcpy(h_trials, dtr, batch * 4, hipMemcpyDeviceToHost));
+    HIPCHK(sc::copy_out(h_sigs, d->sig_dev, sbytes));
+    HIPCHK(sc::copy_out(h_siglens, dsl, batch * 4));
+    if (h_trials) HIPCHK(sc::copy_out(h_trials, dtr, batch * 4));
     return SC_HIP_SUCCESS;
 }
 
@@ -835,14 +835,14 @@ extern "C" int sc_hip_dilithium_verify_host(sc_hip_dilithium_t *d, size_t batch,
     const size_t moff = (batch * msg_stride + 7) & ~(size_t)7, sbytes = batch * sig_stride, soff = (sbytes + 7) & ~(size_t)7;
     if (stage((void **)&d->msg_dev, &d->msg_cap, moff + batch * 4 + 8) || stage((void **)&d->sig_dev, &d->sig_cap, soff + batch * 8 + 8)) return SC_HIP_FAILURE;
     uint32_t *dl = (uint32_t *)(d->msg_dev + moff), *dsl = (uint32_t *)(d->sig_dev + soff), *dv = dsl + batch;
-    if (h_msgs && batch * msg_stride) HIPCHK(hipMemcpy(d->msg_dev, h_msgs, batch * msg_stride, hipMemcpyHostToDevice));
-    if (h_mlens) HIPCHK(hipMemcpy(dl, h_mlens, batch * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d->sig_dev, h_sigs, sbytes, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(dsl, h_siglens, batch * 4, hipMemcpyHostToDevice));
+    if (h_msgs && batch * msg_stride) HIPCHK(sc::copy_in(d->msg_dev, h_msgs, batch * msg_stride));
+    if (h_mlens) HIPCHK(sc::copy_in(dl, h_mlens, batch * 4));
+    HIPCHK(sc::copy_in(d->sig_dev, h_sigs, sbytes));
+    HIPCHK(sc::copy_in(dsl, h_siglens, batch * 4));
     int rc = sc_hip_dilithium_verify(d, batch, d->msg_dev, msg_stride, h_mlens ? dl : nullptr, fixed_len, d->sig_dev, sig_stride, dsl, dv, nullptr);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(nullptr));
-    HIPCHK(hipMemcpy(h_verdicts, dv, batch * 4, hipMemcpyDeviceToHost));
+    HIPCHK(sc::copy_out(h_verdicts, dv, batch * 4));
     return SC_HIP_SUCCESS;
 }
 
@@ -982,12 +982,12 @@ extern "C" int sc_hip_shake_host(sc_hip_ctx_t *ctx, int bits, int standard, cons
     DevBuf ib, ob;
     if (ib.get(len + 8) || ob.get(outlen + 8)) return SC_HIP_FAILURE;
     uint8_t *din = ib.as<uint8_t>(), *dout = ob.as<uint8_t>();
-    if (len) HIPCHK(hipMemcpy(din, h_in, len, hipMemcpyHostToDevice));
+    if (len) HIPCHK(sc::copy_in(din, h_in, len));
     const int rate = 200 - 2 * bits / 8;
     if (standard) hipLaunchKernelGGL(shake_test_kernel<true>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
     else hipLaunchKernelGGL(shake_test_kernel<false>, dim3(1), dim3(HT), 0, nullptr, rate, din, (uint32_t)len, dout, (uint32_t)outlen);
     int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("shake_host: kernel failed");
-    if (rc == SC_HIP_SUCCESS) HIPCHK(hipMemcpy(h_out, dout, outlen, hipMemcpyDeviceToHost));
+    if (rc == SC_HIP_SUCCESS) HIPCHK(sc::copy_out(h_out, dout, outlen));
     return rc;
 }
 

@@ -240,7 +240,7 @@ extern "C" int sc_hip_dlp_create(sc_hip_ctx_t *ctx, const sc_hip_dlp_params_t *p
 static int dlp_upload(int32_t **dst, const int32_t *src, size_t n)
 {
     if (!*dst) HIPCHK(hipMalloc((void **)dst, n * 4));
-    HIPCHK(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(*dst, src, n * 4));
     return SC_HIP_SUCCESS;
 }
 

@@ -12,8 +12,58 @@
 
 namespace sc {
 int fail(const std::string &m);      // records the message for sc_hip_last_error, returns SC_HIP_FAILURE
+// set by the multi-device driver on its worker threads: the caller's buffers are pinned ONCE for all workers by the driver (multi.cpp); the per-device
+// host entry must not register its slice as well - neighbouring slices share a page, and the workers would register and release overlapping pages
+// concurrently
+extern thread_local bool t_skip_host_pin;
 void cdt_build_guide(const std::vector<uint64_t> &cdf, CdtGuide *g, std::vector<uint16_t> *guide, std::vector<uint64_t> *probe_table);
 size_t cdt_lds_bytes(const sc_hip_cdt *c);      // table + padding + guide: the dynamic LDS of a kernel that samples from c
+}
+
+namespace sc {
+// Copies between the caller's (pageable) memory and the device.  The HIP runtime moves a pageable buffer of more than 1 MiB by pinning the caller's
+// pages in place for the duration of the copy ("HSA Copy Using Pinned resource" in its log) and anything smaller through its own pinned staging
+// buffer.  The in-place path is the one a long-lived process cannot rely on here: with it, one run in eight of the GPU test suite (heap buffers of
+// 4-16 MiB allocated, copied and freed in a loop) died with "Memory access fault by GPU ... on address <a host heap address>" inside a later copy; with
+// every copy staged, none in forty (profiles/r02_pageable_copy_fault.txt).  So the library never hands the runtime a pageable
+// piece above the staging threshold: large buffers it pins itself, explicitly and for exactly the call (hipHostRegister / hipHostUnregister in
+// host_roundtrip and the multi-device driver), everything else goes through these helpers.
+constexpr size_t HOST_PIECE = (size_t)1 << 20;
+inline hipError_t copy_in(void *dev, const void *host, size_t bytes)
+{
+    for (size_t o = 0; o < bytes; o += HOST_PIECE) {
+        const hipError_t e = hipMemcpy((char *)dev + o, (const char *)host + o, bytes - o < HOST_PIECE ? bytes - o : HOST_PIECE, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+inline hipError_t copy_out(void *host, const void *dev, size_t bytes)
+{
+    for (size_t o = 0; o < bytes; o += HOST_PIECE) {
+        const hipError_t e = hipMemcpy((char *)host + o, (const char *)dev + o, bytes - o < HOST_PIECE ? bytes - o : HOST_PIECE, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+// the same on a stream (for a pageable buffer the runtime stages each piece before it returns, so this orders with the stream but does not overlap)
+inline hipError_t copy_in_async(void *dev, const void *host, size_t bytes, hipStream_t s, bool pinned)
+{
+    if (pinned) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+    for (size_t o = 0; o < bytes; o += HOST_PIECE) {
+        const hipError_t e = hipMemcpyAsync((char *)dev + o, (const char *)host + o, bytes - o < HOST_PIECE ? bytes - o : HOST_PIECE, hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+inline hipError_t copy_out_async(void *host, const void *dev, size_t bytes, hipStream_t s, bool pinned)
+{
+    if (pinned) return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    for (size_t o = 0; o < bytes; o += HOST_PIECE) {
+        const hipError_t e = hipMemcpyAsync((char *)host + o, (const char *)dev + o, bytes - o < HOST_PIECE ? bytes - o : HOST_PIECE, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
 }
 
 namespace sc {

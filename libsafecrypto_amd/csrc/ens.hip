@@ -178,7 +178,7 @@ static int ens_upload16(int32_t **dst, const int16_t *src, size_t n)
     std::vector<int32_t> t(n);
     for (size_t i = 0; i < n; i++) t[i] = src[i];
     if (!*dst) HIPCHK(hipMalloc((void **)dst, n * 4));
-    HIPCHK(hipMemcpy(*dst, t.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(*dst, t.data(), n * 4));
     return SC_HIP_SUCCESS;
 }
 
@@ -197,7 +197,7 @@ extern "C" int sc_hip_ens_set_privkey(sc_hip_ens_t *h, const int16_t *g, const u
     HIPCHK(hipSetDevice(h->ctx->device));
     if (ens_upload16(&h->d_g, g, (size_t)h->P.n)) return SC_HIP_FAILURE;
     if (!h->d_inv_g) HIPCHK(hipMalloc((void **)&h->d_inv_g, (size_t)h->P.n / 8));
-    HIPCHK(hipMemcpy(h->d_inv_g, inv_g, (size_t)h->P.n / 8, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(h->d_inv_g, inv_g, (size_t)h->P.n / 8));
     h->have_priv = true;
     return SC_HIP_SUCCESS;
 }

@@ -1690,7 +1690,7 @@ extern "C" int sc_hip_falcon_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_param
     std::vector<double> gm;
     make_gm(gm);
     if (hipMalloc((void **)&f->d_gm, gm.size() * sizeof(double)) != hipSuccess ||
-        hipMemcpy(f->d_gm, gm.data(), gm.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) {
+        sc::copy_in(f->d_gm, gm.data(), gm.size() * sizeof(double)) != hipSuccess) {
         sc_hip_falcon_destroy(f);
         return fail("falcon_create: device allocation failed");
     }
@@ -1772,9 +1772,9 @@ extern "C" int sc_hip_falcon_set_privkeys(sc_hip_falcon_t *f, size_t nkeys, cons
     if (f->d_sk) { (void)sc::wipe_free(f->d_sk); f->d_sk = nullptr; }
     f->have_sk = false; f->nkeys = 0;
     HIPCHK(hipMalloc((void **)&f->d_tabs, tabs.size() * 8));
-    HIPCHK(hipMemcpy(f->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(f->d_tabs, tabs.data(), tabs.size() * 8));
     HIPCHK(hipMalloc((void **)&f->d_sk, nkeys * total * sizeof(double)));
-    HIPCHK(hipMemcpy(f->d_sk, sk, nkeys * total * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(f->d_sk, sk, nkeys * total * sizeof(double)));
     f->ts_log = ts_log;
     f->nkeys = nkeys;
     f->have_sk = true;
@@ -1795,7 +1795,7 @@ extern "C" int sc_hip_falcon_set_pubkeys(sc_hip_falcon_t *f, size_t nkeys, const
     if (f->d_hhat) { (void)sc::wipe_free(f->d_hhat); f->d_hhat = nullptr; }
     f->have_pk = false; f->npk = 0;
     HIPCHK(hipMalloc((void **)&f->d_hhat, nkeys * n * 4));
-    HIPCHK(hipMemcpy(f->d_hhat, h32.data(), nkeys * n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(f->d_hhat, h32.data(), nkeys * n * 4));
     if (sc_hip_ntt_fwd(f->plan, nkeys, f->d_hhat, f->d_hhat, nullptr) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
     HIPCHK(hipStreamSynchronize(nullptr));
     f->npk = nkeys;
@@ -2152,11 +2152,11 @@ extern "C" int sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const i
     HIPCHK(hipMalloc((void **)&h->d_inv, n2 * 4));
     HIPCHK(hipMalloc((void **)&h->d_tabs, tabs.size() * 8));
     HIPCHK(hipMalloc((void **)&h->d_sizes, n2 * 4));
-    HIPCHK(hipMemcpy(h->d_b, b, n2 * n2 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_bgs, b_gs, n2 * n2 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_inv, b_gs_inv_norm, n2 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_tabs, tabs.data(), tabs.size() * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_sizes, sizes.data(), n2 * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(h->d_b, b, n2 * n2 * 4));
+    HIPCHK(sc::copy_in(h->d_bgs, b_gs, n2 * n2 * 4));
+    HIPCHK(sc::copy_in(h->d_inv, b_gs_inv_norm, n2 * 4));
+    HIPCHK(sc::copy_in(h->d_tabs, tabs.data(), tabs.size() * 8));
+    HIPCHK(sc::copy_in(h->d_sizes, sizes.data(), n2 * 4));
     h->ts_log = ts_log; h->maxb = maxb; h->have_key = true;
     return SC_HIP_SUCCESS;
 }

@@ -397,7 +397,7 @@ static int ky_load(sc_hip_kyber *h, const int32_t *host, size_t npoly, uint32_t 
     if (tb.get(bytes)) return SC_HIP_FAILURE;
     int32_t *tmp = tb.as<int32_t>();
     if (!*dst) HIPCHK(hipMalloc((void **)dst, bytes));
-    HIPCHK(hipMemcpy(tmp, host, bytes, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(tmp, host, bytes));
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, nullptr, tmp, *dst, npoly, h->plan->k[1], h->plan->r2, h->plan->r2p, rows, cols);
     return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber key load: kernel failed");
 }
@@ -542,8 +542,8 @@ extern "C" int sc_hip_kyber_set_kem_pubkey(sc_hip_kyber_t *h, const int32_t *t, 
     if (!h->d_gstate) HIPCHK(hipMalloc((void **)&h->d_gstate, 25 * 8));
     if (h->d_gtail) { (void)sc::wipe_free(h->d_gtail); h->d_gtail = nullptr; }
     HIPCHK(hipMalloc((void **)&h->d_gtail, len - full + 8));
-    HIPCHK(hipMemcpy(d_pre, pre.data(), len, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->d_gtail, pre.data() + full, len - full, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(d_pre, pre.data(), len));
+    HIPCHK(sc::copy_in(h->d_gtail, pre.data() + full, len - full));
     h->gtail_len = (uint32_t)(len - full);
     hipLaunchKernelGGL(ky_gprefix_kernel, dim3(1), dim3(KHT), 0, nullptr, d_pre, (uint32_t)full, h->d_gstate);
     const int rc = (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("kyber_set_kem_pubkey: kernel failed");

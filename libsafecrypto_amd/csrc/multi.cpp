@@ -51,6 +51,20 @@ extern "C" int sc_hip_multi_workers(const sc_hip_multi_t *m) { return m ? (int)m
 extern "C" sc_hip_ctx_t *sc_hip_multi_ctx(const sc_hip_multi_t *m, int worker) { return (m && worker >= 0 && worker < (int)m->ctx.size()) ? m->ctx[(size_t)worker] : nullptr; }
 
 namespace {
+// The caller's whole buffer pinned once, on the calling thread, for all workers (portable: usable from every device's context).  A buffer that cannot
+// be registered (already pinned by the caller, or not registrable) is left as it is: the copies then take the runtime's staged path.
+struct HostPin {
+    void *p = nullptr;
+    HostPin(const void *ptr, size_t bytes)
+    {
+        if (ptr && bytes && hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterPortable) == hipSuccess) p = const_cast<void *>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    HostPin(const HostPin &) = delete;
+    HostPin &operator=(const HostPin &) = delete;
+};
+
 // runs job(worker, begin, count) on one host thread per worker; an error message of a worker thread is carried back to the caller's thread
 template <class F>
 int fan_out(const sc_hip_multi *m, size_t total, F job)
@@ -65,6 +79,7 @@ int fan_out(const sc_hip_multi *m, size_t total, F job)
         th.emplace_back([&, w, b, c]() {
             if (c == 0) return;
             if (hipSetDevice(m->dev[(size_t)w]) != hipSuccess) { rc[(size_t)w] = SC_HIP_FAILURE; err[(size_t)w] = "multi: hipSetDevice failed"; return; }
+            sc::t_skip_host_pin = true;                           // slices are never registered by the workers (engine_internal.h)
             rc[(size_t)w] = job(w, b, c);
             if (rc[(size_t)w] != SC_HIP_SUCCESS) err[(size_t)w] = sc_hip_last_error();
         });
@@ -101,18 +116,21 @@ extern "C" int sc_hip_multi_ntt_fwd_host(sc_hip_multi_plan_t *p, size_t batch, c
 {
     if (!p || !h_in || !h_out) return sc::fail("multi_ntt_fwd_host: null argument");
     const size_t n = (size_t)sc_hip_plan_n(p->plan[0]);
+    HostPin pi(h_in, batch * n * 4), po(h_out != h_in ? h_out : nullptr, batch * n * 4);
     return fan_out(p->m, batch, [&](int w, size_t b, size_t c) { return sc_hip_ntt_fwd_host(p->plan[(size_t)w], c, h_in + b * n, h_out + b * n); });
 }
 extern "C" int sc_hip_multi_ntt_inv_host(sc_hip_multi_plan_t *p, size_t batch, const int32_t *h_in, int32_t *h_out)
 {
     if (!p || !h_in || !h_out) return sc::fail("multi_ntt_inv_host: null argument");
     const size_t n = (size_t)sc_hip_plan_n(p->plan[0]);
+    HostPin pi(h_in, batch * n * 4), po(h_out != h_in ? h_out : nullptr, batch * n * 4);
     return fan_out(p->m, batch, [&](int w, size_t b, size_t c) { return sc_hip_ntt_inv_host(p->plan[(size_t)w], c, h_in + b * n, h_out + b * n); });
 }
 extern "C" int sc_hip_multi_polymul_ntt_host(sc_hip_multi_plan_t *p, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out)
 {
     if (!p || !h_a || !h_bhat || !h_out) return sc::fail("multi_polymul_ntt_host: null argument");
     const size_t n = (size_t)sc_hip_plan_n(p->plan[0]);
+    HostPin pa(h_a, batch * n * 4), pb(h_bhat != h_a ? h_bhat : nullptr, batch * n * 4), po((h_out != h_a && h_out != h_bhat) ? h_out : nullptr, batch * n * 4);
     return fan_out(p->m, batch, [&](int w, size_t b, size_t c) { return sc_hip_polymul_ntt_host(p->plan[(size_t)w], c, h_a + b * n, h_bhat + b * n, h_out + b * n); });
 }
 

@@ -314,11 +314,11 @@ static int invert_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_v, c
     const size_t bytes = batch * n * 4;
     DevBuf v, d, rc;
     if (v.get(bytes) || rc.get(batch * 4) || (h_den && d.get(bytes))) return SC_HIP_FAILURE;
-    HIPCHK(hipMemcpy(v.p, h_v, bytes, hipMemcpyHostToDevice));
-    if (h_den) HIPCHK(hipMemcpy(d.p, h_den, bytes, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(v.p, h_v, bytes));
+    if (h_den) HIPCHK(sc::copy_in(d.p, h_den, bytes));
     if (run_invert(p, batch, n, (int32_t *)v.p, h_den ? (const int32_t *)d.p : nullptr, (int32_t *)rc.p, nullptr, who)) return SC_HIP_FAILURE;
-    HIPCHK(hipMemcpy(h_v, v.p, bytes, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(h_rc, rc.p, batch * 4, hipMemcpyDeviceToHost));
+    HIPCHK(sc::copy_out(h_v, v.p, bytes));
+    HIPCHK(sc::copy_out(h_rc, rc.p, batch * 4));
     return SC_HIP_SUCCESS;
 }
 extern "C" int sc_hip_ntt_invert_host(sc_hip_plan_t *p, size_t batch, size_t n, int32_t *h_v, int32_t *h_rc)
@@ -335,11 +335,11 @@ extern "C" int sc_hip_mult_sparse_host(sc_hip_ctx_t *ctx, size_t batch, int n, i
     const size_t tb = batch * (size_t)n * (t_is_16 ? 2 : 4), pb = batch * (size_t)omega * 4, ob = batch * (size_t)n * 4;
     DevBuf t, pos, out;
     if (t.get(tb) || pos.get(pb) || out.get(ob)) return SC_HIP_FAILURE;
-    HIPCHK(hipMemcpy(t.p, h_t, tb, hipMemcpyHostToDevice));
-    if (pb) HIPCHK(hipMemcpy(pos.p, h_pos, pb, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(t.p, h_t, tb));
+    if (pb) HIPCHK(sc::copy_in(pos.p, h_pos, pb));
     const int rc = t_is_16 ? sc_hip_mult_sparse_16(ctx, batch, n, omega, (const int16_t *)t.p, (const int32_t *)pos.p, (int32_t *)out.p, nullptr)
                            : sc_hip_mult_sparse(ctx, batch, n, omega, (const int32_t *)t.p, (const int32_t *)pos.p, (int32_t *)out.p, nullptr);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(h_out, out.p, ob, hipMemcpyDeviceToHost));
+    HIPCHK(sc::copy_out(h_out, out.p, ob));
     return SC_HIP_SUCCESS;
 }

@@ -414,7 +414,7 @@ extern "C" int sc_hip_rlwe_create(sc_hip_ctx_t *ctx, const sc_hip_rlwe_params_t 
             else while (hi + 1 < size && cdf[hi + 1] < ((uint64_t)(t + 1) << 52)) hi++;
             g[t] = (uint16_t)(lo | ((hi - lo) << 8));
         }
-        if (hipMemcpy(h->d_guide, g.data(), 4096 * 2, hipMemcpyHostToDevice) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: cannot upload the sampler guide"); }
+        if (sc::copy_in(h->d_guide, g.data(), 4096 * 2) != hipSuccess) { sc_hip_rlwe_destroy(h); return fail("rlwe_create: cannot upload the sampler guide"); }
     }
     *out = h;
     return SC_HIP_SUCCESS;
@@ -439,7 +439,7 @@ extern "C" int sc_hip_rlwe_set_pubkey(sc_hip_rlwe_t *h, const int16_t *a, const 
     const size_t n = (size_t)h->P.n;
     std::vector<uint32_t> t(2 * n);
     rl_to_engine(h, a, t.data()); rl_to_engine(h, p, t.data() + n);
-    HIPCHK(hipMemcpy(h->d_keys, t.data(), 2 * n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(h->d_keys, t.data(), 2 * n * 4));
     h->have_pub = true;
     return SC_HIP_SUCCESS;
 }
@@ -451,7 +451,7 @@ extern "C" int sc_hip_rlwe_set_privkey(sc_hip_rlwe_t *h, const int16_t *r2)
     const size_t n = (size_t)h->P.n;
     std::vector<uint32_t> t(n);
     rl_to_engine(h, r2, t.data());
-    HIPCHK(hipMemcpy(h->d_keys + 2 * n, t.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(h->d_keys + 2 * n, t.data(), n * 4));
     h->have_priv = true;
     return SC_HIP_SUCCESS;
 }

@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void cdt_halving_kernel(const uint64_t *__rest
 #include "engine_internal.h"
 
 static thread_local std::string g_err;
+thread_local bool sc::t_skip_host_pin = false;
 static int g_cus = 256;
 int sc::fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
 using sc::fail;
@@ -369,7 +370,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
         }
         p->d_tab[mi] = nullptr;
         if (hipMalloc(&p->d_tab[mi], h.size() * 4) != hipSuccess ||
-            hipMemcpy(p->d_tab[mi], h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            sc::copy_in(p->d_tab[mi], h.data(), h.size() * 4) != hipSuccess) {
             delete p;
             return fail("plan_create: cannot upload twiddle tables");
         }
@@ -411,7 +412,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
             h[kx] = (uint32_t)(int32_t)f;          h[n + kx] = sshoup(f);
             h[2 * n + kx] = (uint32_t)(int32_t)iv; h[3 * n + kx] = sshoup(iv);
         }
-        if (hipMalloc(&p->d_tab_s, h.size() * 4) != hipSuccess || hipMemcpy(p->d_tab_s, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        if (hipMalloc(&p->d_tab_s, h.size() * 4) != hipSuccess || sc::copy_in(p->d_tab_s, h.data(), h.size() * 4) != hipSuccess) {
             sc_hip_plan_destroy(p);
             return fail("plan_create: cannot upload the signed twiddle tables");
         }
@@ -690,8 +691,8 @@ extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h
     std::vector<uint64_t> padded;
     sc::cdt_build_guide(c->cdf, &c->g, &guide, &padded);
     if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&c->d_cdf, sizeof(uint64_t) * padded.size()) != hipSuccess ||
-        hipMemcpy(c->d_cdf, padded.data(), sizeof(uint64_t) * padded.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc((void **)&c->d_guide, guide.size() * 2) != hipSuccess || hipMemcpy(c->d_guide, guide.data(), guide.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        sc::copy_in(c->d_cdf, padded.data(), sizeof(uint64_t) * padded.size()) != hipSuccess ||
+        hipMalloc((void **)&c->d_guide, guide.size() * 2) != hipSuccess || sc::copy_in(c->d_guide, guide.data(), guide.size() * 2) != hipSuccess) {
         if (c->d_cdf) (void)sc::wipe_free(c->d_cdf);
         if (c->d_guide) (void)sc::wipe_free(c->d_guide);
         delete c;
@@ -768,7 +769,17 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
     const void *pins[3] = { h0, h1, hout != h0 && hout != h1 ? hout : nullptr };
     bool pinned[3] = { false, false, false };
     for (int i = 0; i < 3; i++)
-        if (pins[i]) { pinned[i] = hipHostRegister(const_cast<void *>(pins[i]), bytes, hipHostRegisterDefault) == hipSuccess; if (!pinned[i]) (void)hipGetLastError(); }
+        // (small transfers are not worth a registration, and a buffer of a few KB shares its pages with whatever the caller's heap put beside it)
+        if (pins[i] && !sc::t_skip_host_pin && bytes >= ((size_t)1 << 20)) { pinned[i] = hipHostRegister(const_cast<void *>(pins[i]), bytes, hipHostRegisterDefault) == hipSuccess; if (!pinned[i]) (void)hipGetLastError(); }
+    // a buffer this call pinned, one the multi-device driver pinned for its workers, or one the caller allocated pinned moves in whole chunks;
+    // anything else in pieces the runtime stages (engine_internal.h)
+    bool direct[3];
+    for (int i = 0; i < 3; i++) {
+        const void *q = i == 2 ? (const void *)hout : pins[i];
+        hipPointerAttribute_t at;
+        direct[i] = (i < 2 && pinned[i]) || (i == 2 && (pinned[2] || (hout == h0 && pinned[0]) || (hout == h1 && pinned[1])));
+        if (!direct[i] && q) { if (hipPointerGetAttributes(&at, q) == hipSuccess) direct[i] = at.type == hipMemoryTypeHost; else (void)hipGetLastError(); }
+    }
     hipStream_t st[NB] = { nullptr, nullptr, nullptr };
     int32_t *dev = nullptr;
     int rc = SC_HIP_SUCCESS;
@@ -779,10 +790,10 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
         const size_t slot = c % ring, off = c * chunk, cnt = (off + chunk <= batch) ? chunk : batch - off;
         int32_t *d0 = dev + slot * nops * chunk * (size_t)p->n, *d1 = h1 ? d0 + chunk * (size_t)p->n : nullptr;
         hipStream_t s = st[slot];
-        if (hipMemcpyAsync(d0, h0 + off * (size_t)p->n, cnt * pb, hipMemcpyHostToDevice, s) != hipSuccess ||
-            (h1 && hipMemcpyAsync(d1, h1 + off * (size_t)p->n, cnt * pb, hipMemcpyHostToDevice, s) != hipSuccess)) { rc = fail("host op: H2D copy failed"); break; }
+        if (sc::copy_in_async(d0, h0 + off * (size_t)p->n, cnt * pb, s, direct[0]) != hipSuccess ||
+            (h1 && sc::copy_in_async(d1, h1 + off * (size_t)p->n, cnt * pb, s, direct[1]) != hipSuccess)) { rc = fail("host op: H2D copy failed"); break; }
         rc = run_ntt(p, op, cnt, d0, d1, d0, s);
-        if (rc == SC_HIP_SUCCESS && hipMemcpyAsync(hout + off * (size_t)p->n, d0, cnt * pb, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail("host op: D2H copy failed");
+        if (rc == SC_HIP_SUCCESS && sc::copy_out_async(hout + off * (size_t)p->n, d0, cnt * pb, s, direct[2]) != hipSuccess) rc = fail("host op: D2H copy failed");
     }
     for (size_t i = 0; i < ring; i++) if (st[i]) { if (hipStreamSynchronize(st[i]) != hipSuccess && rc == SC_HIP_SUCCESS) rc = fail("host op: stream failed"); (void)hipStreamDestroy(st[i]); }
     if (dev) (void)sc::wipe_free(dev);
@@ -804,9 +815,9 @@ extern "C" int sc_hip_cdt_sample_host(sc_hip_cdt_t *c, size_t count, const uint6
     uint64_t *dx = nullptr; int32_t *dv = nullptr;
     HIPCHK(hipMalloc(&dx, count * 8));
     int rc = SC_HIP_SUCCESS;
-    if (hipMalloc(&dv, count * 4) != hipSuccess || hipMemcpy(dx, h_uniform, count * 8, hipMemcpyHostToDevice) != hipSuccess) rc = fail("cdt_sample_host: H2D failed");
+    if (hipMalloc(&dv, count * 4) != hipSuccess || sc::copy_in(dx, h_uniform, count * 8) != hipSuccess) rc = fail("cdt_sample_host: H2D failed");
     if (rc == SC_HIP_SUCCESS) rc = sc_hip_cdt_sample(c, count, dx, centre, dv, nullptr);
-    if (rc == SC_HIP_SUCCESS && hipMemcpy(h_out, dv, count * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("cdt_sample_host: D2H failed");
+    if (rc == SC_HIP_SUCCESS && sc::copy_out(h_out, dv, count * 4) != hipSuccess) rc = fail("cdt_sample_host: D2H failed");
     (void)sc::wipe_free(dx);
     if (dv) (void)sc::wipe_free(dv);
     return rc;
@@ -822,16 +833,16 @@ static int host_ew(sc_hip_plan_t *p, int which, size_t len, const int32_t *h0, c
     int32_t *d0 = nullptr, *d1 = nullptr;
     HIPCHK(hipMalloc(&d0, bytes));
     int rc = SC_HIP_SUCCESS;
-    if (hipMemcpy(d0, h0, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+    if (sc::copy_in(d0, h0, bytes) != hipSuccess) rc = fail("host op: H2D copy failed");
     if (rc == SC_HIP_SUCCESS && which == EW_POINTWISE) {
-        if (hipMalloc(&d1, bytes) != hipSuccess || hipMemcpy(d1, h1, bytes, hipMemcpyHostToDevice) != hipSuccess) rc = fail("host op: H2D copy failed");
+        if (hipMalloc(&d1, bytes) != hipSuccess || sc::copy_in(d1, h1, bytes) != hipSuccess) rc = fail("host op: H2D copy failed");
     }
     if (rc == SC_HIP_SUCCESS) {
         if (which == EW_POINTWISE) rc = sc_hip_pointwise(p, len, d0, d1, d0, nullptr);
         else if (which == EW_NORMALIZE) rc = sc_hip_normalize(p, len, d0, d0, nullptr);
         else rc = sc_hip_center(p, len, d0, d0, nullptr);
     }
-    if (rc == SC_HIP_SUCCESS && hipMemcpy(hout, d0, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("host op: D2H copy failed");
+    if (rc == SC_HIP_SUCCESS && sc::copy_out(hout, d0, bytes) != hipSuccess) rc = fail("host op: D2H copy failed");
     (void)sc::wipe_free(d0);
     if (d1) (void)sc::wipe_free(d1);
     return rc;

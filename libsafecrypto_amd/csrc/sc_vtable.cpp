@@ -69,7 +69,7 @@ PlanX *plan_for(DevState &s, int dev, int32_t q, size_t n)
     if (sc_hip_plan_tables(px.plan, w.data(), r.data()) != SC_HIP_SUCCESS) { sc_hip_plan_destroy(px.plan); return nullptr; }
     u[0] = 1;
     for (size_t i = 1; i < n; i++) u[i] = q - w[n - i];
-    if (hipMalloc((void **)&px.d_untwist, n * 4) != hipSuccess || hipMemcpy(px.d_untwist, u.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    if (hipMalloc((void **)&px.d_untwist, n * 4) != hipSuccess || sc::copy_in(px.d_untwist, u.data(), n * 4) != hipSuccess) {
         sc_hip_plan_destroy(px.plan);
         sc::fail("vtable: cannot upload the untwist table");
         return nullptr;
@@ -82,8 +82,8 @@ struct Bound {                                   // the calling thread's device,
     Bound() : dev(t_dev), s(g_dev[t_dev]), lk(g_dev[t_dev].mu) { (void)hipSetDevice(dev); }
 };
 
-bool up(void *d, const void *h, size_t bytes) { return hipMemcpy(d, h, bytes, hipMemcpyHostToDevice) == hipSuccess || (sc::fail("vtable: H2D copy failed"), false); }
-bool down(void *h, const void *d, size_t bytes) { return hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost) == hipSuccess || (sc::fail("vtable: D2H copy failed"), false); }
+bool up(void *d, const void *h, size_t bytes) { return sc::copy_in(d, h, bytes) == hipSuccess || (sc::fail("vtable: H2D copy failed"), false); }
+bool down(void *h, const void *d, size_t bytes) { return sc::copy_out(h, d, bytes) == hipSuccess || (sc::fail("vtable: D2H copy failed"), false); }
 
 // ---- utils_arith_ntt_t slots -----------------------------------------------------------------------------------------------------------------
 

@@ -434,7 +434,7 @@ extern "C" void sc_hip_tesla_destroy(sc_hip_tesla_t *t)
 static int ts_upload32(int32_t **dst, const int32_t *src, size_t n)
 {
     if (!*dst) HIPCHK(hipMalloc((void **)dst, n * 4));
-    HIPCHK(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(sc::copy_in(*dst, src, n * 4));
     return SC_HIP_SUCCESS;
 }
 
@@ -450,9 +450,9 @@ extern "C" int sc_hip_tesla_set_key(sc_hip_tesla_t *t, const int32_t *a1, const 
     if (ts_upload32(&t->d_a1, a1, n) || ts_upload32(&t->d_a2, a2, n)) return SC_HIP_FAILURE;
     if (s) {
         if (!t->d_key) HIPCHK(hipMalloc((void **)&t->d_key, 3 * n * 2));
-        HIPCHK(hipMemcpy(t->d_key, s, n * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(t->d_key + n, e1, n * 2, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(t->d_key + 2 * n, e2, n * 2, hipMemcpyHostToDevice));
+        HIPCHK(sc::copy_in(t->d_key, s, n * 2));
+        HIPCHK(sc::copy_in(t->d_key + n, e1, n * 2));
+        HIPCHK(sc::copy_in(t->d_key + 2 * n, e2, n * 2));
         t->have_priv = true;
     }
     if (t1) {
