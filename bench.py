@@ -283,6 +283,7 @@ def falcon_extra(eng, torch, cpu_seconds, sets=(('falcon2', 2, (8192, 131072)), 
 
 def bliss_extra(eng, torch, cpu_seconds):
     """BASELINE configs[3]: BLISS-B-I sign with the CDT sampler on the GPU, batch 16384; key from the reference's keygen (fixture)"""
+    import numpy as np
     from tests.golden_io import load_golden
     G = load_golden('bliss_ref.txt')
     b = eng.bliss(G['bliss1_params']); b.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
@@ -319,6 +320,18 @@ def bliss_extra(eng, torch, cpu_seconds):
         assert int(v2[st2 == 1].sum()) == 0
         out['distinct_keys'] = {'workload': 'the same batch with a key pair per message (keys from the batched keygen, resident in HBM)',
                                 'sign_ops_per_s': B / min(tk), 'verify_ops_per_s': B / min(tkv), 'key_bytes_per_signature': 3 * 512 * 2}
+    # the signatures in the reference's SC_ENTROPY_HUFFMAN_STATIC coding (SC_FLAG_0_ENTROPY_HUFFMAN; the code tables are the reference's data, from the fixture)
+    H = load_golden('bliss_huff_ref.txt')
+    pick = lambda k: ((H[f'huff{k}_code'].astype(np.int64) & 0xFFFFFFFF).astype(np.uint32), H[f'huff{k}_bits'].astype(np.uint16))
+    b.set_entropy((pick(6), pick(2)))
+    b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+    th, thv = [], []
+    for _ in range(5):
+        t0 = time.perf_counter(); s3, l3, _, st3 = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); th.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); v3 = b.verify(msgs, s3, l3, fixed_len=64); torch.cuda.synchronize(); thv.append(time.perf_counter() - t0)
+    assert int(v3[st3 == 1].sum()) == 0 and torch.equal(st3, status)
+    out['huffman_coded'] = {'workload': 'the same batch with the signatures entropy-coded as the reference codes them (static Huffman tables for t and z)',
+                            'sign_ops_per_s': B / min(th), 'verify_ops_per_s': B / min(thv), 'mean_signature_bytes': float(l3[st3 == 1].float().mean()), 'raw_signature_bytes': 986}
     b.close()
     return {'bliss_b_1': out}
 

@@ -270,6 +270,18 @@ int sc_hip_bliss_verify_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_a
                              const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 /* the relative margin of the status-5 report above (default 2^-40; 0 decides everything on the device; 1 reports every attempt - self-test) */
 int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
+/* replaces: sc->coding_signature.type (bliss_b.c:197-200, set from SC_FLAG_0_ENTROPY_HUFFMAN by safecrypto_create).  type 0 = SC_ENTROPY_NONE: the
+ * signature's t, z and indices as raw z1_bits / z2_bits / n_bits fields (the default).  type 1 = SC_ENTROPY_HUFFMAN_STATIC: t and z coded as
+ * entropy_poly_encode_32 / _16 code them with SIGNED_COEFF (src/utils/entropy/entropy.c:70-112,147-190; entropy_huffman.c:22-57,155-190): the low
+ * max(bits - 7, 0) bits of |v| raw, |v| >> beta as a codeword of a static prefix code, a sign bit unless v = 0; the indices stay raw; one MSB-first stream
+ * (packer.c:299-351).  The code tables are data of the reference (src/utils/entropy/huffman.h: huff_code_gaussian_<k>[].code / .bits), so the caller hands
+ * over the two its coder would walk - for t: k = min(z1_bits, 7) - 1, for z: k = min(z2_bits, 7) - 1, k = 2 when that is below 3 (entropy_huffman.c:27-31) -
+ * as codes[depth], bits[depth]; they must form a complete prefix code.  From then on the sign calls write coded signatures (d_siglens[i] varies, below
+ * sc_hip_bliss_sig_bytes(), which stays the row size to provide; d_status[i] = 6: a coefficient outside the code's alphabet - the reference's
+ * encode_huffman fails on it too - or a coded signature longer than the row) and the verify calls read them (a stream that ends early is invalid).
+ * The arithmetic coder (SC_ENTROPY_BAC) is not served. */
+int sc_hip_bliss_set_entropy(sc_hip_bliss_t *h, int type, const uint32_t *codes_t, const uint16_t *bits_t, uint32_t depth_t,
+                             const uint32_t *codes_z, const uint16_t *bits_z, uint32_t depth_z);
 /* replaces: safecrypto_verify -> bliss_b_verify (bliss_b.c:1583-1740); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);

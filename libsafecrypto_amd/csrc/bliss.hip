@@ -16,8 +16,10 @@
 #include "engine_internal.h"
 #include "keccak_dev.h"
 
+#include <algorithm>
 #include <math.h>
 #include <string.h>
+#include <vector>
 
 using namespace sc;
 
@@ -424,7 +426,7 @@ __global__ void bl_vcidx_kernel(int32_t *v, const int32_t *cidx, uint32_t count,
     if (item >= count) return;
     const int32_t two_q = 2 * P.q;
     for (int k = 0; k < P.kappa; k++) {
-        int32_t *p = v + (size_t)item * P.n + cidx[(size_t)item * P.kappa + k];
+        int32_t *p = v + (size_t)item * P.n + (cidx[(size_t)item * P.kappa + k] & (P.n - 1));     // (a signature too short to hold its indices leaves them unset)
         *p = barrett((int64_t)*p + P.q, (1 << 30) / two_q, two_q);
     }
 }
@@ -437,6 +439,178 @@ __global__ void bl_vz_kernel(const int32_t *v, int16_t *z, size_t len, BlissP P)
     tmp -= (tmp >= P.p) * P.p;
     tmp += (tmp < 0) * P.p;
     z[i] = (int16_t)tmp;
+}
+
+// ---- SC_ENTROPY_HUFFMAN_STATIC coding of the signature ---------------------------------------------------------------------------
+// sc->coding_signature.type = SC_ENTROPY_HUFFMAN_STATIC (bliss_b.c:197-200): t and z go through entropy_poly_encode_32 / _16 with SIGNED_COEFF
+// (src/utils/entropy/entropy.c:70-112, 147-190): per coefficient the beta = max(bits - 7, 0) low bits of |v| raw, |v| >> beta as a codeword of a static
+// prefix code (entropy_huffman.c:22-57, 155-190; huffman.c:386-403), a sign bit unless v = 0; the kappa indices stay raw n_bits fields; one MSB-first bit
+// stream flushed to whole bytes (packer.c:299-351).  The code tables are the reference's data (src/utils/entropy/huffman.h) and come in through
+// sc_hip_bliss_set_entropy.  Coding is a pure format conversion of the raw signature, done as a pass of its own behind the signer / in front of the verifier.
+struct HuffT {
+    const uint32_t *code, *len;      // per symbol: codeword (right-aligned) and its length
+    const uint32_t *dleft, *dls;     // decoding order (shortest first): codeword left-aligned in 32 bits; length | symbol << 8
+    const uint32_t *lut;             // indexed by the next lutbits bits of the stream: length | symbol << 8 of the codeword that starts there, 0 = longer than lutbits
+    uint32_t depth, lutbits;
+};
+constexpr int HUFF_LUT_BITS = 10;
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane)
+{
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(v, o); if (lane >= o) v += u; }
+    return v;
+}
+// `len` (< 64) bits of tok, MSB first, at bit offset off of a big-endian word stream; words at or past capw are dropped (the length check catches them)
+__device__ __forceinline__ void lds_put_bits(uint32_t *out, uint32_t capw, uint32_t off, uint64_t tok, uint32_t len)
+{
+    if (len == 0) return;
+    const uint64_t T = tok << (64 - len);
+    const uint32_t w = off >> 5, sh = off & 31;
+    const uint64_t U = T >> sh;
+    const uint32_t a = (uint32_t)(U >> 32), b = (uint32_t)U, c = sh ? ((uint32_t)T << (32 - sh)) : 0u;
+    if (a && w < capw) atomicOr(&out[w], a);
+    if (b && w + 1 < capw) atomicOr(&out[w + 1], b);
+    if (c && w + 2 < capw) atomicOr(&out[w + 2], c);
+}
+__device__ __forceinline__ uint32_t lds_get_bits(const uint32_t *raw, uint32_t off, int bits)      // bits <= 32; raw has one spare word behind the data
+{
+    const uint32_t w = off >> 5, sh = off & 31;
+    const uint64_t two = ((uint64_t)raw[w] << 32) | raw[w + 1];
+    return (uint32_t)(two >> (64 - sh - bits)) & (bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u));
+}
+
+// one wavefront per signed message: the raw row into LDS, every lane makes the tokens of its coefficients, an exclusive scan of their lengths places
+// them, LDS atomics assemble the stream, the coded row replaces the raw one.  status 6: a coefficient outside the code's alphabet (encode_huffman's
+// SC_OUT_OF_BOUNDS) or a coded signature longer than the row.
+__global__ __launch_bounds__(256) void bl_huff_pack_kernel(uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *status, uint32_t count, BlissP P,
+                                                           HuffT t1, HuffT t2, uint32_t capw)
+{
+    extern __shared__ uint32_t hlds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = P.n;
+    const uint32_t item = blockIdx.x * 4 + wave;
+    if (item >= count || status[item] != 1) return;
+    const uint32_t rawbytes = (uint32_t)(n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits + 7) >> 3, raww = (rawbytes + 3) / 4 + 1;
+    uint32_t *raw = hlds + (size_t)wave * (raww + capw), *out = raw + raww;
+    uint8_t *row = sigs + (size_t)item * sig_stride;
+    for (uint32_t w = lane; w < raww; w += 64) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) { const uint32_t i = 4 * w + b; v = (v << 8) | (i < rawbytes ? row[i] : 0u); }
+        raw[w] = v;
+    }
+    for (uint32_t w = lane; w < capw; w += 64) out[w] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    uint32_t base = 0; bool bad = false;
+    for (int part = 0; part < 2; part++) {
+        const int bits = part ? P.z2_bits : P.z1_bits, beta = bits > 7 ? bits - 7 : 0;
+        const HuffT &T = part ? t2 : t1;
+        const uint32_t first = part ? (uint32_t)(n * P.z1_bits) : 0u;
+        for (int c = 0; c < n / 64; c++) {
+            const int j = lane + 64 * c;
+            const uint32_t f = lds_get_bits(raw, first + (uint32_t)(j * bits), bits);
+            const int32_t v = (int32_t)(f << (32 - bits)) >> (32 - bits);
+            const uint32_t a = (uint32_t)(v < 0 ? -v : v), sym = a >> beta, sb = v != 0;
+            uint64_t tok = 0; uint32_t len = 0;
+            if (sym < T.depth) {
+                const uint32_t cl = T.len[sym];
+                tok = ((uint64_t)(a & ((1u << beta) - 1u)) << (cl + sb)) | ((uint64_t)T.code[sym] << sb) | (uint64_t)(v < 0);
+                len = (uint32_t)beta + cl + sb;
+            } else bad = true;
+            const uint32_t incl = wave_incl_scan(len, lane);
+            lds_put_bits(out, capw, base + incl - len, tok, len);
+            base += __shfl(incl, 63);
+        }
+    }
+    {
+        const uint32_t first = (uint32_t)(n * (P.z1_bits + P.z2_bits));
+        const uint32_t len = lane < P.kappa ? (uint32_t)P.n_bits : 0u;
+        const uint64_t tok = lane < P.kappa ? lds_get_bits(raw, first + (uint32_t)(lane * P.n_bits), P.n_bits) : 0u;
+        const uint32_t incl = wave_incl_scan(len, lane);
+        lds_put_bits(out, capw, base + incl - len, tok, len);
+        base += __shfl(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    const uint32_t nbytes = (base + 7) >> 3;
+    const bool fail = __any(bad) || nbytes > sig_stride || (nbytes + 3) / 4 > capw;
+    const uint32_t keep = fail ? 0u : nbytes, clear = rawbytes > keep ? rawbytes : keep;
+    for (uint32_t i = lane; i < clear; i += 64) row[i] = i < keep ? (uint8_t)(out[i >> 2] >> (24 - 8 * (i & 3))) : (uint8_t)0;
+    if (lane == 0) { siglens[item] = keep; if (fail) status[item] = 6; }
+}
+
+// MSB-first reader over one signature row, one per lane
+struct BitR {
+    const uint8_t *p; uint32_t nbits, row_bytes, pos, fetched; uint64_t acc; int have; bool over;
+    __device__ __forceinline__ uint32_t peek32()
+    {
+        if (have <= 32) {
+            uint32_t w = 0;
+            if (fetched + 4 <= row_bytes && ((uintptr_t)(p + fetched) & 3) == 0) w = __builtin_bswap32(*reinterpret_cast<const uint32_t *>(p + fetched));   // (bytes past the signature's end, if read, are never consumed unnoticed: take() flags it)
+            else for (int b = 0; b < 4; b++) { const uint32_t i = fetched + b; w = (w << 8) | (i < row_bytes ? p[i] : 0u); }
+            fetched += 4;
+            acc |= (uint64_t)w << (32 - have);
+            have += 32;
+        }
+        return (uint32_t)(acc >> 32);
+    }
+    __device__ __forceinline__ void take(int k) { acc <<= k; have -= k; pos += (uint32_t)k; if (pos > nbits) over = true; }
+    __device__ __forceinline__ uint32_t get(int k) { if (k == 0) return 0; const uint32_t v = peek32() >> (32 - k); take(k); return v; }
+};
+__device__ __forceinline__ int32_t huff_get(BitR &r, int bits, const uint32_t *lut, uint32_t lutbits, const uint32_t *dleft, const uint32_t *dls, uint32_t depth)
+{
+    const int beta = bits > 7 ? bits - 7 : 0;
+    uint32_t a = r.get(beta);
+    const uint32_t pk = r.peek32();
+    uint32_t e = lut[pk >> (32 - lutbits)];
+    if (e == 0) {                                                           // a codeword longer than the table's index: walk the candidates, shortest first
+        uint32_t i = 0;
+        for (; i + 1 < depth; i++) if (((pk ^ dleft[i]) >> (32 - (dls[i] & 0xFFu))) == 0) break;     // a complete prefix code: the last candidate needs no test
+        e = dls[i];
+    }
+    r.take((int)(e & 0xFFu));
+    a |= (e >> 8) << beta;
+    return (a != 0 && r.get(1)) ? -(int32_t)a : (int32_t)a;
+}
+
+// replaces bl_unpack_kernel when the signatures are coded: a variable-length stream decodes serially, so one lane per signature (entropy_poly_decode_32 /
+// _16 + the raw indices, bliss_b.c:1641-1657); decoding tables in LDS (a 10-bit lookup resolves all but the rare long codewords), t and z leave the lane
+// in 16-byte pieces.  Only the first lpw lanes of a wavefront take a signature: the host spreads a batch over enough wavefronts to give every SIMD two
+// (a wavefront costs the same per instruction with 8 lanes active as with 64, and its lanes diverge less).  A stream that ends early is invalid (the
+// reference's pack_decode of the indices fails).
+__global__ __launch_bounds__(64) void bl_huff_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, uint32_t lpw, int32_t *t, int16_t *z,
+                                                            int32_t *cidx, uint32_t *verdict, BlissP P, HuffT t1, HuffT t2)
+{
+    __shared__ uint32_t tl[4][256];
+    __shared__ uint32_t lut[2][1 << HUFF_LUT_BITS];
+    for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+        tl[0][i] = i < t1.depth ? t1.dleft[i] : 0; tl[1][i] = i < t1.depth ? t1.dls[i] : 0;
+        tl[2][i] = i < t2.depth ? t2.dleft[i] : 0; tl[3][i] = i < t2.depth ? t2.dls[i] : 0;
+    }
+    for (uint32_t i = threadIdx.x; i < (1u << t1.lutbits); i += 64) lut[0][i] = t1.lut[i];
+    for (uint32_t i = threadIdx.x; i < (1u << t2.lutbits); i += 64) lut[1][i] = t2.lut[i];
+    __syncthreads();
+    const uint32_t item = blockIdx.x * lpw + threadIdx.x;
+    if (threadIdx.x >= lpw || item >= count) return;
+    const int n = P.n;
+    const uint32_t sl = siglens[item];
+    BitR r{ sigs + (size_t)item * sig_stride, (uint32_t)((sl < sig_stride ? sl : sig_stride) * 8), (uint32_t)sig_stride, 0, 0, 0, 0, false };
+    int4 *tp = reinterpret_cast<int4 *>(t + (size_t)item * n);
+    for (int j = 0; j < n; j += 4) {
+        int4 q;
+        q.x = huff_get(r, P.z1_bits, lut[0], t1.lutbits, tl[0], tl[1], t1.depth); q.y = huff_get(r, P.z1_bits, lut[0], t1.lutbits, tl[0], tl[1], t1.depth);
+        q.z = huff_get(r, P.z1_bits, lut[0], t1.lutbits, tl[0], tl[1], t1.depth); q.w = huff_get(r, P.z1_bits, lut[0], t1.lutbits, tl[0], tl[1], t1.depth);
+        tp[j >> 2] = q;
+    }
+    int4 *zp = reinterpret_cast<int4 *>(z + (size_t)item * n);
+    for (int j = 0; j < n; j += 8) {
+        uint32_t h[4];
+        for (int e = 0; e < 4; e++) {
+            const uint32_t lo = (uint32_t)huff_get(r, P.z2_bits, lut[1], t2.lutbits, tl[2], tl[3], t2.depth) & 0xFFFFu;
+            const uint32_t hi = (uint32_t)huff_get(r, P.z2_bits, lut[1], t2.lutbits, tl[2], tl[3], t2.depth) & 0xFFFFu;
+            h[e] = lo | (hi << 16);
+        }
+        zp[j >> 3] = make_int4((int)h[0], (int)h[1], (int)h[2], (int)h[3]);
+    }
+    for (int k = 0; k < P.kappa; k++) cidx[(size_t)item * P.kappa + k] = (int32_t)r.get(P.n_bits);
+    if (r.over) verdict[item] = 1;
 }
 
 // ---- key generation (bliss_b_keygen, bliss_b.c:1124-1264) ------------------------------------------------------------------
@@ -534,6 +708,9 @@ struct sc_hip_bliss {
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
     int32_t *tu, *tin, *v, *cidx, *ain;
     int16_t *z;
+    int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy)
+    uint32_t *d_huff;            // the two code tables and their decoding orders, one allocation
+    HuffT ht[2];
     double tie_rel;              // accept / reject draws closer to the threshold than this (relative) are reported, not decided: status 5
 };
 
@@ -590,6 +767,68 @@ extern "C" int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *b, double relative)
     return SC_HIP_SUCCESS;
 }
 
+// sc->coding_signature.type for the handle (bliss_b.c:197-200): 0 = SC_ENTROPY_NONE, 1 = SC_ENTROPY_HUFFMAN_STATIC with the two tables the reference's coder
+// would pick for z1_bits and z2_bits (entropy_huffman.c:22-34: huff_table_gaussian_<min(bits, 7) - 1>, _2 below 4 bits) as (code, bits) per symbol
+extern "C" int sc_hip_bliss_set_entropy(sc_hip_bliss_t *b, int type, const uint32_t *codes_t, const uint16_t *bits_t, uint32_t depth_t,
+                                        const uint32_t *codes_z, const uint16_t *bits_z, uint32_t depth_z)
+{
+    if (!b) return fail("bliss_set_entropy: null handle");
+    if (type != 0 && type != 1) return fail("bliss_set_entropy: type must be 0 (none) or 1 (static Huffman); the arithmetic coder is not served");
+    if (type == 0) { b->entropy = 0; return SC_HIP_SUCCESS; }
+    if (!codes_t || !bits_t || !codes_z || !bits_z) return fail("bliss_set_entropy: null table");
+    const uint32_t depth[2] = { depth_t, depth_z };
+    const uint32_t *codes[2] = { codes_t, codes_z };
+    const uint16_t *bits[2] = { bits_t, bits_z };
+    const int fbits[2] = { b->P.z1_bits, b->P.z2_bits };
+    std::vector<uint32_t> h;
+    size_t at[2];
+    uint32_t lutbits[2];
+    for (int t = 0; t < 2; t++) {
+        if (depth[t] < 2 || depth[t] > 256) return fail("bliss_set_entropy: table depth must be 2..256");
+        const int beta = fbits[t] > 7 ? fbits[t] - 7 : 0;
+        // a prefix code, complete (every bit string decodes - the decoder's last candidate is taken untested), codewords of at most 32 bits, tokens below 64
+        double kraft = 0.0;
+        for (uint32_t i = 0; i < depth[t]; i++) {
+            const uint32_t L = bits[t][i];
+            if (L < 1 || L > 32 || beta + (int)L + 1 >= 64 || (L < 32 && (codes[t][i] >> L))) return fail("bliss_set_entropy: bad codeword");
+            kraft += ldexp(1.0, -(int)L);
+            for (uint32_t j = 0; j < i; j++) {
+                const uint32_t Lj = bits[t][j], m = L < Lj ? L : Lj;
+                if ((codes[t][i] >> (L - m)) == (codes[t][j] >> (Lj - m))) return fail("bliss_set_entropy: not a prefix code");
+            }
+        }
+        if (kraft != 1.0) return fail("bliss_set_entropy: the code is not complete");
+        at[t] = h.size();
+        std::vector<uint32_t> order(depth[t]);
+        for (uint32_t i = 0; i < depth[t]; i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return bits[t][x] < bits[t][y]; });
+        for (uint32_t i = 0; i < depth[t]; i++) h.push_back(codes[t][i]);
+        for (uint32_t i = 0; i < depth[t]; i++) h.push_back(bits[t][i]);
+        for (uint32_t i = 0; i < depth[t]; i++) h.push_back(codes[t][order[i]] << (32 - bits[t][order[i]]));
+        for (uint32_t i = 0; i < depth[t]; i++) h.push_back((uint32_t)bits[t][order[i]] | (order[i] << 8));
+        uint32_t maxlen = 0;
+        for (uint32_t i = 0; i < depth[t]; i++) maxlen = bits[t][i] > maxlen ? bits[t][i] : maxlen;
+        lutbits[t] = maxlen < (uint32_t)HUFF_LUT_BITS ? maxlen : (uint32_t)HUFF_LUT_BITS;
+        for (uint32_t idx = 0; idx < (1u << lutbits[t]); idx++) {
+            uint32_t e = 0;
+            for (uint32_t i = 0; i < depth[t] && !e; i++)
+                if (bits[t][i] <= lutbits[t] && (idx >> (lutbits[t] - bits[t][i])) == codes[t][i]) e = (uint32_t)bits[t][i] | (i << 8);
+            h.push_back(e);
+        }
+    }
+    if (b->P.n % 64) return fail("bliss_set_entropy: n must be a multiple of 64");
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (b->d_huff) { (void)hipFree(b->d_huff); b->d_huff = nullptr; }
+    HIPCHK(hipMalloc((void **)&b->d_huff, h.size() * 4));
+    HIPCHK(sc::copy_in(b->d_huff, h.data(), h.size() * 4));
+    for (int t = 0; t < 2; t++) {
+        const uint32_t *base = b->d_huff + at[t];
+        b->ht[t] = HuffT{ base, base + depth[t], base + 2 * depth[t], base + 3 * depth[t], base + 4 * depth[t], depth[t], lutbits[t] };
+    }
+    b->entropy = 1;
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
 {
     if (!b) return;
@@ -597,6 +836,7 @@ extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
     if (b->d_f) (void)sc::wipe_free(b->d_f);
     if (b->d_g) (void)sc::wipe_free(b->d_g);
     if (b->d_a) (void)sc::wipe_free(b->d_a);
+    if (b->d_huff) (void)hipFree(b->d_huff);
     sc_hip_cdt_destroy(b->cdt);
     sc_hip_plan_destroy(b->plan);
     delete b;
@@ -713,6 +953,14 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         nact = cnt;
         active = next;
     }
+    if (b->entropy) {
+        const uint32_t rawbytes = (uint32_t)sc_hip_bliss_sig_bytes(b), raww = (rawbytes + 3) / 4 + 1;
+        uint32_t capw = (uint32_t)((sig_stride + 3) / 4);
+        if (capw > 2 * raww) capw = 2 * raww;                       // a coded signature twice the raw size is refused (status 6) rather than given more LDS
+        hipLaunchKernelGGL(bl_huff_pack_kernel, dim3((B + 3) / 4), dim3(256), sizeof(uint32_t) * 4 * (size_t)(raww + capw), s, d_sigs, sig_stride, d_siglens, st.status, B, P,
+                           b->ht[0], b->ht[1], capw);
+        HIPCHK(hipGetLastError());
+    }
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
     // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
     sc::wipe_async(b->tu, s); sc::wipe_async(b->tin, s); sc::wipe_async(b->v, s); sc::wipe_async(b->z, s);
@@ -761,7 +1009,12 @@ static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, 
     const int n = P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
     const size_t nu = batch * (size_t)(2 * n + P.kappa), ne = batch * (size_t)n;
-    hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
+    if (b->entropy) {
+        uint32_t lpw = 64;                                            // signatures per wavefront: every SIMD two wavefronts where the batch allows
+        while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 8) lpw >>= 1;
+        hipLaunchKernelGGL(bl_huff_unpack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, B, lpw, b->tin, b->z, b->cidx, d_verdicts, P, b->ht[0], b->ht[1]);
+    }
+    else hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
     hipLaunchKernelGGL(bl_vnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, b->tin, b->z, B, d_verdicts, P);
     HIPCHK(hipGetLastError());
     if (ka16) {

@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|bliss_huff|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -394,11 +394,13 @@ typedef struct __attribute__((packed)) { UINT64 *cdf; SINT32 cdf_size; SINT32 k;
  * (prng_64 = two words, prng_var = a bit reservoir refilled by prng_32; src/utils/crypto/prng.c:963-1048).
  * For each message the context's CSPRNG is replaced by a freshly seeded one and a twin with the same seed
  * is read with prng_32 only: that is the "random tape" the signature is a pure function of. */
-static int bliss_case(FILE *f, int set, int nmsg)
+static int bliss_case(FILE *f, int set, int nmsg, int huffman)
 {
-    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE, SC_FLAG_NONE };
+    /* huffman: sc->coding_signature.type = SC_ENTROPY_HUFFMAN_STATIC (bliss_b.c:197-200) - the same signing path, the signature's t and z coded by
+     * entropy_poly_encode_32 / _16 (src/utils/entropy/entropy.c:70-112, entropy_huffman.c) instead of as raw fields */
+    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE | (huffman ? SC_FLAG_0_ENTROPY_HUFFMAN : 0), SC_FLAG_NONE };
     char name[96], tag[32];
-    snprintf(tag, sizeof tag, "bliss%d", set);
+    snprintf(tag, sizeof tag, huffman ? "blissh%d" : "bliss%d", set);
     safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
@@ -413,7 +415,7 @@ static int bliss_case(FILE *f, int set, int nmsg)
     snprintf(name, sizeof name, "%s_a", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
     int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
     prng_ctx_t *orig = sc->prng_ctx[0];
-    sm_state = 0xb1155000ULL + set;
+    sm_state = 0xb1155000ULL + set + (huffman ? 0x100 : 0);
     /* candidates are drawn until nmsg are kept: the first nmsg-3 whatever they need, then three that took >= 3 attempts
      * (a second fresh pair of Gaussian vectors) */
     int kept = 0, long_ones = 0;
@@ -507,10 +509,34 @@ static int gen_bliss(const char *dir)
     snprintf(path, sizeof path, "%s/bliss_ref.txt", dir);
     FILE *f = fopen(path, "w");
     if (!f) return 1;
-    int rc = bliss_case(f, 1, 9);
+    int rc = bliss_case(f, 1, 9, 0);
     rc |= bliss_keygen_case(f, 1, 4);
-    rc |= bliss_case(f, 3, 4);                                         /* BLISS-B-III and -IV: other kappa, sigma, d, p, bounds */
-    rc |= bliss_case(f, 4, 4);
+    rc |= bliss_case(f, 3, 4, 0);                                      /* BLISS-B-III and -IV: other kappa, sigma, d, p, bounds */
+    rc |= bliss_case(f, 4, 4, 0);
+    fclose(f);
+    return rc;
+}
+
+/* Huffman-coded signatures (SC_FLAG_0_ENTROPY_HUFFMAN) and the static code tables the coder walks, as data: the tables are literals in
+ * src/utils/entropy/huffman.h ("Generated from Matlab/Octave"), not the output of an algorithm the library contains */
+#include "utils/entropy/huffman.h"
+static int gen_bliss_huff(const char *dir)
+{
+    char path[512], name[64];
+    snprintf(path, sizeof path, "%s/bliss_huff_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    const huffman_table_t *tabs[5] = { huff_table_gaussian_2, huff_table_gaussian_3, huff_table_gaussian_4, huff_table_gaussian_5, huff_table_gaussian_6 };
+    for (int t = 0; t < 5; t++) {
+        int32_t code[64], bits[64], meta[2] = { (int32_t)tabs[t]->depth, (int32_t)tabs[t]->max_bits };
+        for (UINT32 i = 0; i < tabs[t]->depth; i++) { code[i] = (int32_t)tabs[t]->codes[i].code; bits[i] = tabs[t]->codes[i].bits; }
+        snprintf(name, sizeof name, "huff%d_meta", t + 2); rec_i32(f, name, meta, 2);
+        snprintf(name, sizeof name, "huff%d_code", t + 2); rec_i32(f, name, code, tabs[t]->depth);
+        snprintf(name, sizeof name, "huff%d_bits", t + 2); rec_i32(f, name, bits, tabs[t]->depth);
+    }
+    int rc = bliss_case(f, 1, 6, 1);
+    rc |= bliss_case(f, 4, 4, 1);                                      /* z2_bits = 4: the 3-bit table for z */
+    rc |= bliss_case(f, 2, 3, 1);                                      /* z2_bits = 2 */
     fclose(f);
     return rc;
 }
@@ -1519,13 +1545,14 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|bliss_huff|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
+    if (all || !strcmp(argv[1], "bliss_huff")) rc |= gen_bliss_huff(argv[2]);
     if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
     if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
     if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);

@@ -228,6 +228,75 @@ done:
     return rc;
 }
 
+/* ---- SC_ENTROPY_HUFFMAN_STATIC coding of the signature (bliss_b.c:1447-1461 / 1641-1657 with sc->coding_signature.type = HUFFMAN_STATIC) ----
+ * entropy_poly_encode_32 / _16, signed (src/utils/entropy/entropy.c:70-112, 147-190): beta = max(bits - 7, 0) low bits of |v| raw, |v| >> beta
+ * through a static prefix code (entropy_huffman.c:22-57, 155-190; huffman.c:386-403), then a sign bit unless v = 0; the kappa indices stay raw
+ * n_bits fields; MSB-first bit stream, flushed to whole bytes (packer.c:299-351).  The code tables are data of the reference
+ * (src/utils/entropy/huffman.h) and come in as (code, bits) per symbol: table 1 serves t (z1_bits), table 2 serves z (z2_bits).
+ * Both directions are pure format conversions between the raw signature orc_bliss_sign writes and the coded one. */
+static int huff_put(bw_t *w, int32_t v, int bits, const uint32_t *code, const uint16_t *len, uint32_t depth)
+{
+    const int beta = bits > 7 ? bits - 7 : 0;
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    if (beta) bw_put(w, a & ((1u << beta) - 1u), beta);
+    if ((a >> beta) >= depth) return 1;                                   /* encode_huffman: SC_OUT_OF_BOUNDS */
+    bw_put(w, code[a >> beta], len[a >> beta]);
+    if (v != 0) bw_put(w, v < 0, 1);
+    return 0;
+}
+typedef struct { const uint8_t *buf; size_t bits, pos; int over; } br_t;
+static uint32_t br_get(br_t *r, int bits)
+{
+    uint32_t v = 0;
+    for (int b = 0; b < bits; b++, r->pos++) {
+        if (r->pos >= r->bits) { r->over = 1; v <<= 1; continue; }
+        v = (v << 1) | ((r->buf[r->pos >> 3] >> (7 - (r->pos & 7))) & 1u);
+    }
+    return v;
+}
+static int32_t huff_get(br_t *r, int bits, const uint32_t *code, const uint16_t *len, uint32_t depth)
+{
+    const int beta = bits > 7 ? bits - 7 : 0;
+    uint32_t a = beta ? br_get(r, beta) : 0, acc = 0;
+    int have = 0;
+    for (;;) {                                                            /* decode_huffman (huffman.c:405-445): walk until a codeword matches */
+        acc = (acc << 1) | br_get(r, 1); have++;
+        if (r->over || have > 32) { r->over = 1; return 0; }
+        uint32_t s;
+        for (s = 0; s < depth; s++) if (len[s] == have && code[s] == acc) break;
+        if (s < depth) { a |= s << beta; break; }
+    }
+    if (a != 0 && br_get(r, 1)) return -(int32_t)a;
+    return (int32_t)a;
+}
+int orc_bliss_sig_to_huffman(const int32_t *par, const uint8_t *raw, size_t rawlen, const uint32_t *c1, const uint16_t *l1, uint32_t d1,
+                             const uint32_t *c2, const uint16_t *l2, uint32_t d2, uint8_t *out, size_t *outlen)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    if (rawlen * 8 < (size_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits)) return 1;
+    br_t r = { raw, rawlen * 8, 0, 0 };
+    bw_t w = { out, 0 };
+    int bad = 0;
+    for (int i = 0; i < P.n; i++) { const uint32_t v = br_get(&r, P.z1_bits); bad |= huff_put(&w, (int32_t)(v << (32 - P.z1_bits)) >> (32 - P.z1_bits), P.z1_bits, c1, l1, d1); }
+    for (int i = 0; i < P.n; i++) { const uint32_t v = br_get(&r, P.z2_bits); bad |= huff_put(&w, (int32_t)(v << (32 - P.z2_bits)) >> (32 - P.z2_bits), P.z2_bits, c2, l2, d2); }
+    for (int i = 0; i < P.kappa; i++) bw_put(&w, br_get(&r, P.n_bits), P.n_bits);
+    *outlen = (w.bitpos + 7) >> 3;
+    return bad;
+}
+/* returns 1 when the coded stream ends early (the reference's pack_decode of the indices then fails, bliss_b.c:1646-1651) */
+int orc_bliss_sig_from_huffman(const int32_t *par, const uint8_t *in, size_t inlen, const uint32_t *c1, const uint16_t *l1, uint32_t d1,
+                               const uint32_t *c2, const uint16_t *l2, uint32_t d2, uint8_t *raw, size_t *rawlen)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    br_t r = { in, inlen * 8, 0, 0 };
+    bw_t w = { raw, 0 };
+    for (int i = 0; i < P.n; i++) bw_put(&w, (uint32_t)huff_get(&r, P.z1_bits, c1, l1, d1), P.z1_bits);
+    for (int i = 0; i < P.n; i++) bw_put(&w, (uint32_t)huff_get(&r, P.z2_bits, c2, l2, d2), P.z2_bits);
+    for (int i = 0; i < P.kappa; i++) bw_put(&w, br_get(&r, P.n_bits), P.n_bits);
+    *rawlen = (w.bitpos + 7) >> 3;
+    return r.over;
+}
+
 /* poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) on the tape: c[j] coefficients of value +-(c_len - j), one prng_32 word
  * per placement attempt (bit 0: sign, the bits above: position), occupied positions are drawn again.  Returns 1 on underrun. */
 static int uniform_rand_tape(tape_t *T, int32_t *v, int n, const int *c, int c_len)

@@ -72,6 +72,9 @@ def lib():
         L.orc_bliss_sign.argtypes = [i32p, i16p, i16p, i16p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, C.POINTER(C.c_size_t),
                                      C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]
         L.orc_bliss_verify.argtypes = [i32p, i16p, u8p, C.c_size_t, u8p, C.c_size_t]
+        u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags='C_CONTIGUOUS')
+        L.orc_bliss_sig_to_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
+        L.orc_bliss_sig_from_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_bliss_keygen.argtypes = [i32p, C.c_int, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
@@ -227,6 +230,30 @@ def bliss_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
     return lib().orc_bliss_verify(key.par, key.a, m, ml, s, s.size)
+
+
+def huffman_tables(G, z1_bits, z2_bits):
+    """the two static code tables a BLISS signature is coded with, picked as entropy_huffman.c:22-34 picks them (signed: the table of
+    min(bits, 7) - 1 bits; 2 bits for anything below 4), as ((code, bits), (code, bits)) from the fixture's huffN_* records"""
+    def pick(bits):
+        hb = min(bits, 7)
+        t = {7: 6, 6: 5, 5: 4, 4: 3}.get(hb, 2)
+        return (np.ascontiguousarray(G[f'huff{t}_code'].astype(np.int64) & 0xFFFFFFFF, dtype=np.uint32), np.ascontiguousarray(G[f'huff{t}_bits'], dtype=np.uint16))
+    return pick(z1_bits), pick(z2_bits)
+
+
+def bliss_sig_to_huffman(key, raw, tabs):
+    (c1, l1), (c2, l2) = tabs
+    r = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
+    rc = lib().orc_bliss_sig_to_huffman(key.par, r, r.size, c1, l1, c1.size, c2, l2, c2.size, out, C.byref(n))
+    return rc, bytes(out[:n.value])
+
+
+def bliss_sig_from_huffman(key, coded, tabs):
+    (c1, l1), (c2, l2) = tabs
+    r = np.ascontiguousarray(np.frombuffer(bytes(coded), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
+    rc = lib().orc_bliss_sig_from_huffman(key.par, r if r.size else np.zeros(1, dtype=np.uint8), r.size, c1, l1, c1.size, c2, l2, c2.size, out, C.byref(n))
+    return rc, bytes(out[:n.value])
 
 
 class DilKey:

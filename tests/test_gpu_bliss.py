@@ -286,3 +286,79 @@ def test_distinct_keys_per_message(eng, G):
     s1, l1, _, st1 = b.sign(m_d[3:4], t_d[3:4], mlens=ml_d[3:4], tape_lens=tl_d[3:4])
     assert int(st1[0]) == 1 and bytes(s1[0, :int(l1[0])].cpu().numpy()) == bytes(sh[3, :lh[3]])
     b.close()
+
+
+@pytest.mark.parametrize('tag', ['blissh1', 'blissh4', 'blissh2'])
+def test_huffman_coded_signatures_reproduce_the_reference(eng, tag):
+    """SC_FLAG_0_ENTROPY_HUFFMAN (tests/golden/bliss_huff_ref.txt: the reference's coded signatures and its static code tables): the engine's coded
+    signatures are the reference's byte for byte, they verify, the fixture's tampering is caught as the reference catches it"""
+    import torch
+    H = load_golden('bliss_huff_ref.txt')
+    key = O.BlissKey.from_golden(H, tag)
+    tabs = O.huffman_tables(H, int(key.par[9]), int(key.par[10]))
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a); b.set_entropy(tabs)
+    cs = cases(H, tag)
+    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], max(len(c[1]) for c in cs) + 8)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    torch.cuda.synchronize()
+    sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
+    assert status.cpu().tolist() == [1] * len(cs)
+    for i, (_, _, sig, tr) in enumerate(cs):
+        assert bytes(sh[i, :lh[i]]) == sig, (tag, i)
+        assert int(trials[i]) == tr
+        assert not sh[i, lh[i]:b.sig_bytes].any()                     # nothing of the raw form is left behind the coded one
+    assert b.verify(msgs, sigs, siglens, mlens=mlens).cpu().tolist() == [0] * len(cs)
+    bad = sigs.clone()
+    for i in range(len(cs)):
+        bad[i, int(lh[i]) // 3] ^= 0x04
+    assert b.verify(msgs, bad, siglens, mlens=mlens).cpu().tolist() == [int(H[f'{tag}_verify'][2 * i + 1]) for i in range(len(cs))] == [1] * len(cs)
+    short = siglens.clone(); short[0] = siglens[0] // 2; short[1] = 0
+    assert b.verify(msgs, sigs, short, mlens=mlens).cpu().tolist()[:3] == [1, 1, 0]
+    b.set_entropy(None)                                              # back to raw fields on the same handle
+    raw, rl, _, st = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    assert st.cpu().tolist() == [1] * len(cs) and set(rl.cpu().tolist()) == {b.sig_bytes}
+    rh = raw.cpu().numpy()
+    for i in range(len(cs)):
+        rc, coded = O.bliss_sig_to_huffman(key, bytes(rh[i, :b.sig_bytes]), tabs)
+        assert rc == 0 and coded == cs[i][2]
+    b.close()
+
+
+def test_huffman_batch_vs_oracle_and_bad_tables(eng):
+    """1000 seeded messages: coded signatures equal the oracle's coding of the oracle's raw signatures, round trip through the verifier, distinct
+    keys go through the same coder; tables that are not a complete prefix code are refused"""
+    import torch
+    from libsafecrypto_amd import EngineError
+    H = load_golden('bliss_huff_ref.txt')
+    key = O.BlissKey.from_golden(H, 'blissh1')
+    tabs = O.huffman_tables(H, 12, 3)
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a); b.set_entropy(tabs)
+    rng = np.random.default_rng(5)
+    B, W = 1000, 3 * 2048 + 64
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8)) for _ in range(B)]
+    tapes = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+    tapes[5] = tapes[5][:1500]
+    m_d, ml_d, t_d, tl_d = pack(msgs, tapes, W)
+    sigs, siglens, trials, status = b.sign(m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+    torch.cuda.synchronize()
+    sh, lh, st = sigs.cpu().numpy(), siglens.cpu().numpy(), status.cpu().numpy()
+    assert st[5] == 2 and lh[5] == 0
+    n_ok = 0
+    for i in range(0, B, 7):
+        rc, raw, _, _ = O.bliss_sign(key, msgs[i], tapes[i])
+        assert (rc == 0) == (st[i] == 1), i
+        if rc == 0:
+            rc2, coded = O.bliss_sig_to_huffman(key, raw, tabs)
+            assert rc2 == 0 and bytes(sh[i, :lh[i]]) == coded, i
+            n_ok += 1
+    assert n_ok > 100
+    ok = st == 1
+    assert 700 < lh[ok].mean() < 800 and lh[ok].max() < b.sig_bytes     # 986 bytes raw
+    v = b.verify(m_d, sigs, siglens, mlens=ml_d).cpu().numpy()
+    assert np.all(v[ok] == 0) and np.all(v[~ok] == 1)
+    (c1, l1), (c2, l2) = tabs
+    for broken in (((c1[:-1], l1[:-1]), (c2, l2)),                        # incomplete
+                   ((c1, l1), (np.array([1, 1, 1, 1], dtype=np.uint32), np.array([1, 2, 3, 3], dtype=np.uint16)))):   # 1 is a prefix of 11... duplicates
+        with pytest.raises(EngineError):
+            b.set_entropy(broken)
+    b.close()
