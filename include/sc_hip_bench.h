@@ -41,6 +41,11 @@ int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
  * it fill the slot budget; unfused != 0 runs NTT(y) and the matrix product as two kernels instead of the fused one */
 int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, int unfused);
 
+/* BLISS-B signer: 1 (default) = after a message's first pair of attempts its later pairs are evaluated side by side (the tape position of an attempt does
+ * not depend on any value, so pair p starts from a state the host computes; the lowest successful attempt is the signature); 0 = the reference's loop
+ * round by round.  Signatures, attempt counts and statuses do not depend on it. */
+int sc_hip_bliss_set_speculation(sc_hip_bliss_t *h, int on);
+
 #ifdef __cplusplus
 }
 #endif

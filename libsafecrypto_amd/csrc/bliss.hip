@@ -58,9 +58,10 @@ struct Tape {                // one message's CSPRNG word stream + the prng_var 
     __device__ __forceinline__ double dbl() { const uint32_t a = var(27), b = var(26); return (a * 67108864.0 + b) * 1.11022302462516e-16; }
 };
 
-struct St {                  // per-message state arrays (device)
-    uint32_t *pos, *var_buf, *iter, *cur, *status;
-    int32_t *var_bits;
+struct St {                  // per-item state arrays (device).  An item is a message - or, in the speculative phase of a signing call, one later PAIR of
+    uint32_t *pos, *var_buf, *iter, *cur, *status;      // attempts of a message (bl_sign_core): msg_of then maps the item to the message whose inputs
+    int32_t *var_bits;                                  // (text, tape, key) it reads; null = the item is the message
+    const uint32_t *msg_of;
 };
 
 // start of an attempt (bliss_b.c:1366-1373): odd attempts swap t and u, even ones draw 2n fresh samples
@@ -69,10 +70,10 @@ __global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, con
 {
     const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (aidx >= nact) return;
-    const uint32_t item = active ? active[aidx] : aidx;
-    if (mlens && mlens[item] == 0) { s.status[item] = 3; siglens[item] = 0; need[aidx] = 2; return; }       // oracle() refuses an empty message
+    const uint32_t item = active ? active[aidx] : aidx, src = s.msg_of ? s.msg_of[item] : item;
+    if (mlens && mlens[src] == 0) { s.status[item] = 3; siglens[item] = 0; need[aidx] = 2; return; }        // oracle() refuses an empty message
     if (s.iter[item] & 1) { s.cur[item] ^= 1; need[aidx] = 0; return; }
-    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item];
+    const uint32_t len = tape_lens ? tape_lens[src] : tape_stride, pos = s.pos[item];
     if (pos + 4u * (uint32_t)n > len) { s.status[item] = 2; siglens[item] = 0; need[aidx] = 2; return; }     // tape exhausted
     need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + 4u * (uint32_t)n;
 }
@@ -81,7 +82,8 @@ __global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, con
 // (one 16-byte tape read, one 8-byte store); the table search is the guide + S probes of cdt_guide.h (S = 0: the halving search).
 template <int S>
 __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *cur,
-                                                        const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, const uint16_t *gd, CdtGuide g, int size, int32_t *tu, int n)
+                                                        const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, const uint16_t *gd, CdtGuide g, int size, int32_t *tu, int n,
+                                                        const uint32_t *msg_of)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
     uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, 
         const uint32_t aidx = (uint32_t)(t / (size_t)n); const int sidx = 2 * (int)(t % (size_t)n);
         if (need[aidx] != 1) continue;
         const uint32_t item = active ? active[aidx] : aidx;
-        const uint32_t *tp = tapes + (size_t)item * tape_stride + sbase[aidx] + 2 * sidx;
+        const uint32_t *tp = tapes + (size_t)(msg_of ? msg_of[item] : item) * tape_stride + sbase[aidx] + 2 * sidx;
         uint32_t w[4];
         if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
         else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
@@ -115,14 +117,14 @@ __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, 
 // dense copy of the current t for the NTT product
 // (a key per message: the active messages' public keys a, SINT16 rows, are gathered beside it as the product's second operand)
 __global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n,
-                                const int16_t *a_items = nullptr, int32_t *ain = nullptr)
+                                const int16_t *a_items = nullptr, int32_t *ain = nullptr, const uint32_t *msg_of = nullptr)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     tin[t] = (need[aidx] == 2) ? 0 : tu[((size_t)item * 2 + cur[item]) * n + i];
-    if (a_items) ain[t] = (int32_t)a_items[(size_t)item * n + i];
+    if (a_items) ain[t] = (int32_t)a_items[(size_t)(msg_of ? msg_of[item] : item) * n + i];
 }
 
 // round_and_drop, bliss_b.c:681-703
@@ -147,7 +149,7 @@ __global__ void bl_round_kernel(const uint32_t *active, uint32_t nact, const uin
 // byte pairs; the first kappa distinct ones.  mode 0: write them; mode 1 (verify): compare with the signature's.
 __global__ __launch_bounds__(HT) void bl_oracle1_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride,
                                                        const uint32_t *mlens, uint32_t fixed_len, const int16_t *z, int32_t *cidx, uint32_t *ok,
-                                                       int mode, uint32_t *verdict, BlissP P)
+                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr)
 {
     __shared__ uint64_t st[25 * HT];
     __shared__ uint32_t fl[32 * HT];
@@ -155,10 +157,10 @@ __global__ __launch_bounds__(HT) void bl_oracle1_kernel(const uint32_t *active, 
     Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
     if (aidx >= nact) return;
     if (need && need[aidx] == 2) { if (ok) ok[aidx] = 0; return; }
-    const uint32_t item = active ? active[aidx] : aidx;
-    const uint32_t mlen = mlens ? mlens[item] : fixed_len;
+    const uint32_t item = active ? active[aidx] : aidx, src = msg_of ? msg_of[item] : item;
+    const uint32_t mlen = mlens ? mlens[src] : fixed_len;
     if (mlen == 0) { if (mode == 0) ok[aidx] = 0; else verdict[item] = 1; return; }
-    const uint8_t *m = msgs + (size_t)item * msg_stride;
+    const uint8_t *m = msgs + (size_t)src * msg_stride;
     const uint8_t *zb = reinterpret_cast<const uint8_t *>(z + (size_t)aidx * P.n);
     uint32_t *myfl = fl + threadIdx.x;
     for (int w = 0; w < (P.n + 31) / 32; w++) myfl[w * HT] = 0;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(HT) void bl_oracle1_kernel(const uint32_t *active, 
 // Used while the one-lane form has no more wavefronts than the chip has SIMDs.
 __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride,
                                                        const uint32_t *mlens, uint32_t fixed_len, const int16_t *z, int32_t *cidx, uint32_t *ok,
-                                                       int mode, uint32_t *verdict, BlissP P)
+                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr)
 {
     __shared__ uint32_t st[25 * HT];
     __shared__ uint32_t fl[32 * (HT / 2)];
@@ -201,10 +203,10 @@ __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, 
     Sponge2<HT> sp; sp.init(st, threadIdx.x, 72);
     if (aidx >= nact) return;
     if (need && need[aidx] == 2) { if (ok && first) ok[aidx] = 0; return; }
-    const uint32_t item = active ? active[aidx] : aidx;
-    const uint32_t mlen = mlens ? mlens[item] : fixed_len;
+    const uint32_t item = active ? active[aidx] : aidx, src = msg_of ? msg_of[item] : item;
+    const uint32_t mlen = mlens ? mlens[src] : fixed_len;
     if (mlen == 0) { if (first) { if (mode == 0) ok[aidx] = 0; else verdict[item] = 1; } return; }
-    const uint8_t *m = msgs + (size_t)item * msg_stride;
+    const uint8_t *m = msgs + (size_t)src * msg_stride;
     const uint8_t *zb = reinterpret_cast<const uint8_t *>(z + (size_t)aidx * P.n);
     uint32_t *myfl = fl + (threadIdx.x >> 1);                      // both lanes keep the same bitmap (same values, same addresses)
     for (int w = 0; w < (P.n + 31) / 32; w++) myfl[w * (HT / 2)] = 0;
@@ -254,21 +256,30 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
                                                         const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
                                                         const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
                                                         const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride)
+                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride, uint32_t max_iter)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
     const uint32_t aidx = blockIdx.x * 4 + wid;
     if (aidx >= nact) return;
     if (need[aidx] == 2) return;                                          // tape exhausted: already reported
-    const uint32_t item = active ? active[aidx] : aidx;
+    const uint32_t item = active ? active[aidx] : aidx, src = s.msg_of ? s.msg_of[item] : item;
     int32_t *x = xy + (size_t)wid * 2 * n, *y = x + n;
     const uint32_t it = s.iter[item];
+    // max_iter = 2: the item is one pair of attempts (a fresh one and the one that re-uses its vectors); when both fail the item ends with status 7 and the
+    // host resolves the message from its later pairs (bl_sign_core).  max_iter = 0: the reference's open-ended loop.
     auto reject = [&]() {
-        if (lane == 0) { s.iter[item] = it + 1; next_active[atomicAdd(next_count, 1u)] = item; }
+        if (lane != 0) return;
+        s.iter[item] = it + 1;
+        if (max_iter && it + 1 >= max_iter) { s.status[item] = 7; siglens[item] = 0; }
+        else next_active[atomicAdd(next_count, 1u)] = item;
     };
-    if (!ok[aidx]) { reject(); return; }                                  // oracle failed: continue (bliss_b.c:1395-1397)
-    f += (size_t)item * key_stride; g += (size_t)item * key_stride;      // key_stride = n: a private key per message
+    if (!ok[aidx]) {                                                      // oracle failed: continue (bliss_b.c:1395-1397) WITHOUT the attempt's reservoir draws -
+        if (max_iter) { if (lane == 0) { s.status[item] = 8; siglens[item] = 0; } }   // the later pairs' tape positions no longer hold: status 8, the message is redone in order
+        else reject();
+        return;
+    }
+    f += (size_t)src * key_stride; g += (size_t)src * key_stride;        // key_stride = n: a private key per message
 
     // greedy_sc
     for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
@@ -295,7 +306,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     }
 
     // the CSPRNG reservoir of this message (every lane computes the same scalar sequence; lane 0 writes it back)
-    Tape T{ tapes + (size_t)item * tape_stride, tape_lens ? tape_lens[item] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
+    Tape T{ tapes + (size_t)src * tape_stride, tape_lens ? tape_lens[src] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
     const uint32_t cur = s.cur[item];
     int32_t *t = tu + ((size_t)item * 2 + cur) * n, *u = tu + ((size_t)item * 2 + (cur ^ 1)) * n;
     const bool sub = T.var(1) != 0;
@@ -708,6 +719,8 @@ struct sc_hip_bliss {
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
     int32_t *tu, *tin, *v, *cidx, *ain;
     int16_t *z;
+    bool speculate;              // later pairs of attempts side by side (bl_sign_core); false = the reference's loop round by round
+    St st2; int32_t *tu2; uint8_t *sigs2; uint32_t *siglens2, *trials2, *msg_of2; size_t cap2, stride2;     // the pairs' state, vectors and output rows
     int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy)
     uint32_t *d_huff;            // the two code tables and their decoding orders, one allocation
     HuffT ht[2];
@@ -753,6 +766,7 @@ extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_
     memset(b, 0, sizeof *b);
     b->ctx = ctx; b->plan = plan; b->cdt = cdt; b->P = P;
     b->tie_rel = 0x1p-40;
+    b->speculate = true;
     *out = b;
     return SC_HIP_SUCCESS;
 }
@@ -829,10 +843,20 @@ extern "C" int sc_hip_bliss_set_entropy(sc_hip_bliss_t *b, int type, const uint3
     return SC_HIP_SUCCESS;
 }
 
+static void bl_free_ws2(sc_hip_bliss *b);
+// measurement / test hook (include/sc_hip_bench.h): 0 = the reference's loop round by round, 1 = the later pairs of attempts side by side (default)
+extern "C" int sc_hip_bliss_set_speculation(sc_hip_bliss_t *b, int on)
+{
+    if (!b) return fail("bliss_set_speculation: null handle");
+    b->speculate = on != 0;
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
 {
     if (!b) return;
     bl_free_ws(b);
+    bl_free_ws2(b);
     if (b->d_f) (void)sc::wipe_free(b->d_f);
     if (b->d_g) (void)sc::wipe_free(b->d_g);
     if (b->d_a) (void)sc::wipe_free(b->d_a);
@@ -894,6 +918,146 @@ extern "C" int sc_hip_bliss_sign_keys(sc_hip_bliss_t *b, size_t batch, const int
     return bl_sign_core(b, d_f, d_g, d_a, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream);
 }
 
+// ---- the rejection loop, and the later pairs of attempts side by side ------------------------------------------------------------------------
+// What one run of the round loop works on: a set of items (messages, or pairs of attempts of messages), their state, vectors and output rows.
+struct BlRun {
+    St st; int32_t *tu; uint8_t *sigs; size_t sig_stride; uint32_t *siglens, *trials;
+    uint32_t items; const uint32_t *active0; uint32_t max_iter;
+};
+struct BlIn {
+    const int16_t *kf, *kg, *ka16; const uint8_t *msgs; size_t msg_stride; const uint32_t *mlens; uint32_t fixed_len;
+    const uint32_t *tapes; size_t tape_stride; const uint32_t *tape_lens;
+};
+
+static int bl_rounds(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStream_t s)
+{
+    const BlissP &P = b->P;
+    const int n = P.n;
+    const St &st = r.st;
+    uint32_t nact = r.items;
+    const uint32_t *active = r.active0;
+    for (uint32_t round = 0; nact > 0; round++) {
+        if (round > 100000) return fail("bliss_sign: rejection loop did not terminate");
+        uint32_t *next = b->act[round & 1];
+        HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
+        hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, b->need, b->sbase, r.siglens, in.mlens);
+        const size_t nsamp = (size_t)nact * 2 * n;
+        size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
+        const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
+        if (sblocks > (size_t)b->ctx->cus * (sper > 4 ? 4 : sper)) sblocks = (size_t)b->ctx->cus * (sper > 4 ? 4 : sper);
+        const CdtGuide &cg = b->cdt->g;
+#define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
+                           in.tapes, in.tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, r.tu, n, st.msg_of)
+        switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#undef BL_SAMPLE
+        const size_t ne = (size_t)nact * n;
+        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, r.tu, b->tin, n, in.ka16, b->ain, st.msg_of);
+        HIPCHK(hipGetLastError());
+        if (in.ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+        hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, r.tu, b->v, b->z, P);
+        // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
+        if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
+            hipLaunchKernelGGL(bl_oracle2_kernel, dim3((2 * nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
+                               0, (uint32_t *)nullptr, P, st.msg_of);
+        else
+            hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
+                               0, (uint32_t *)nullptr, P, st.msg_of);
+        hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, in.tapes, in.tape_stride, in.tape_lens,
+                           in.kf ? in.kf : b->d_f, in.kg ? in.kg : b->d_g, r.tu, b->v, b->z, b->cidx, r.sigs, r.sig_stride, r.siglens, r.trials, next, b->cnt, P, b->tie_rel,
+                           in.kf ? (size_t)n : (size_t)0, r.max_iter);
+        HIPCHK(hipGetLastError());
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nact = cnt;
+        active = next;
+    }
+    return SC_HIP_SUCCESS;
+}
+
+// The reference's loop is sequential in the attempts of one message, but only PAIRS of attempts depend on each other: attempt 2p draws fresh vectors, attempt
+// 2p+1 re-uses them modified (bliss_b.c:1366-1373); and an attempt's position on the CSPRNG word tape does not depend on any VALUE: a fresh attempt takes
+// 4n words, every attempt 1 + 27 + 26 reservoir bits (prng_var: a 32-bit word whenever the reservoir runs short).  So pair p of a message can start from a
+// state the host computes by running the reservoir's bit count forward - and the pairs of a message can run side by side, the lowest-numbered successful
+// attempt being the signature (what the sequential loop stops at).  (An attempt whose oracle fails skips its reservoir draws, :1395-1397 - it never does in
+// practice; such a message is redone in order, status 8 below.)
+struct ResSim {
+    uint32_t pos = 0, lrp = 0; int vb = 0;
+    void attempt(bool fresh, uint32_t n)
+    {
+        if (fresh) pos += 4 * n;
+        const int req[3] = { 1, 27, 26 };
+        for (int nreq : req) { if (vb < nreq) { const int bits = nreq - vb; lrp = pos; pos++; vb = 32 - bits; } else vb -= nreq; }
+    }
+};
+constexpr int BL_PAIRS = 4;                    // later pairs of a message evaluated side by side
+struct PairInit { uint32_t pos[BL_PAIRS], lrp[BL_PAIRS]; int32_t vb[BL_PAIRS]; };
+
+__global__ void bl_collect_kernel(const uint32_t *status, uint32_t count, uint32_t want, uint32_t *list, uint32_t *cnt)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && status[i] == want) list[atomicAdd(cnt, 1u)] = i;
+}
+// item j * pp + k = pair p0 + k of message list[j]
+__global__ void bl_pair_init_kernel(const uint32_t *list, uint32_t nu, uint32_t pp, PairInit pi, St v, uint32_t *msg_of, const uint32_t *tapes, size_t tape_stride,
+                                    const uint32_t *tape_lens, uint32_t *siglens, uint32_t *trials)
+{
+    const uint32_t vid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vid >= nu * pp) return;
+    const uint32_t m = list[vid / pp], k = vid % pp;
+    const uint32_t len = tape_lens ? tape_lens[m] : (uint32_t)tape_stride;
+    msg_of[vid] = m;
+    v.pos[vid] = pi.pos[k]; v.var_bits[vid] = pi.vb[k]; v.iter[vid] = 0; v.cur[vid] = 0; siglens[vid] = 0; trials[vid] = 0;
+    uint32_t buf = 0, status = 0;
+    if (pi.vb[k] > 0) { if (pi.lrp[k] < len) buf = tapes[(size_t)m * tape_stride + pi.lrp[k]] >> (32 - pi.vb[k]); else status = 2; }   // (the tape ended in an earlier pair)
+    v.var_buf[vid] = buf; v.status[vid] = status;
+}
+// one wavefront per message of the list: the first of its pairs that did not fail twice decides it
+__global__ __launch_bounds__(64) void bl_resolve_kernel(const uint32_t *msg_of, uint32_t pp, uint32_t p0, const uint32_t *vstatus, const uint8_t *vsigs, const uint32_t *vsiglens,
+                                                        const uint32_t *vtrials, size_t sig_stride, uint32_t *status, uint8_t *sigs, uint32_t *siglens, uint32_t *trials)
+{
+    const uint32_t j = blockIdx.x, m = msg_of[j * pp];
+    uint32_t k = 0;
+    while (k < pp && vstatus[j * pp + k] == 7) k++;
+    if (k == pp) return;                                              // every pair failed twice: the message stays at status 7 and gets the next pairs
+    const uint32_t vid = j * pp + k, st = vstatus[vid];
+    if (st == 1) {
+        const uint32_t len = vsiglens[vid];
+        for (uint32_t i = threadIdx.x; i < len; i += 64) sigs[(size_t)m * sig_stride + i] = vsigs[(size_t)vid * sig_stride + i];
+        if (threadIdx.x == 0) { siglens[m] = len; trials[m] = 2 * (p0 + k) + vtrials[vid]; }
+    } else if (threadIdx.x == 0) siglens[m] = 0;
+    if (threadIdx.x == 0) status[m] = st;
+}
+__global__ void bl_reset_kernel(const uint32_t *list, uint32_t count, St s)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t m = list[i];
+    s.pos[m] = 0; s.var_buf[m] = 0; s.var_bits[m] = 0; s.iter[m] = 0; s.cur[m] = 0; s.status[m] = 0;
+}
+
+static void bl_free_ws2(sc_hip_bliss *b)
+{
+    void *ptrs[] = { b->st2.pos, b->st2.var_buf, b->st2.iter, b->st2.cur, b->st2.status, b->st2.var_bits, b->tu2, b->sigs2, b->siglens2, b->trials2, b->msg_of2 };
+    for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
+    memset(&b->st2, 0, sizeof b->st2);
+    b->tu2 = nullptr; b->sigs2 = nullptr; b->siglens2 = b->trials2 = b->msg_of2 = nullptr; b->cap2 = 0; b->stride2 = 0;
+}
+static int bl_ensure_ws2(sc_hip_bliss *b, size_t items, size_t sig_stride)
+{
+    if (items <= b->cap2 && sig_stride <= b->stride2) return SC_HIP_SUCCESS;
+    if (items < b->cap2) items = b->cap2;
+    if (sig_stride < b->stride2) sig_stride = b->stride2;
+    bl_free_ws2(b);
+    const size_t n = b->P.n;
+#define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
+    WS(b->st2.pos, items * 4); WS(b->st2.var_buf, items * 4); WS(b->st2.iter, items * 4); WS(b->st2.cur, items * 4); WS(b->st2.status, items * 4); WS(b->st2.var_bits, items * 4);
+    WS(b->tu2, items * 2 * n * 4); WS(b->sigs2, items * sig_stride); WS(b->siglens2, items * 4); WS(b->trials2, items * 4); WS(b->msg_of2, items * 4);
+#undef WS
+    b->cap2 = items; b->stride2 = sig_stride;
+    return SC_HIP_SUCCESS;
+}
+
 static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
                         const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
@@ -909,49 +1073,58 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     hipStream_t s = (hipStream_t)stream;
     const BlissP &P = b->P;
     const uint32_t B = (uint32_t)batch;
-    const int n = P.n;
     St st = b->st;
+    st.msg_of = nullptr;
     HIPCHK(hipMemsetAsync(st.pos, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_buf, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_bits, 0, batch * 4, s));
     HIPCHK(hipMemsetAsync(st.iter, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.cur, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.status, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : b->trials;
     HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
-    uint32_t nact = B;
-    const uint32_t *active = nullptr;
-    for (uint32_t round = 0; nact > 0; round++) {
-        if (round > 100000) return fail("bliss_sign: rejection loop did not terminate");
-        uint32_t *next = b->act[round & 1];
+    const BlIn in{ kf, kg, ka16, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens };
+    const bool spec = b->speculate;
+    // every message: its first pair of attempts (all of them when the handle runs the plain loop)
+    if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, B, nullptr, spec ? 2u : 0u }, in, s)) return SC_HIP_FAILURE;
+    if (spec) {
+        ResSim sim;
+        sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);                 // pair 0 is behind us
+        uint32_t *ulist = b->act[0];                                  // (the round loop is idle here: its two lists are free)
+        for (uint32_t p0 = 1;; ) {
+            if (p0 > 50000) return fail("bliss_sign: rejection loop did not terminate");
+            uint32_t nu = 0;
+            HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
+            hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, 7u, ulist, b->cnt);
+            HIPCHK(hipMemcpyAsync(&nu, b->cnt, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            if (nu == 0) break;
+            uint32_t pp = BL_PAIRS;
+            while (pp > 1 && (size_t)nu * pp > batch) pp >>= 1;       // the per-round arrays are sized for the batch
+            PairInit pi{};
+            for (uint32_t k = 0; k < pp; k++) {
+                pi.pos[k] = sim.pos; pi.lrp[k] = sim.lrp; pi.vb[k] = sim.vb;
+                sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);
+            }
+            const uint32_t nv = nu * pp;
+            if (bl_ensure_ws2(b, nv, sig_stride)) return SC_HIP_FAILURE;
+            St v = b->st2;
+            hipLaunchKernelGGL(bl_pair_init_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, ulist, nu, pp, pi, v, b->msg_of2, d_tapes, tape_stride, d_tape_lens, b->siglens2, b->trials2);
+            HIPCHK(hipGetLastError());
+            v.msg_of = b->msg_of2;
+            if (bl_rounds(b, BlRun{ v, b->tu2, b->sigs2, sig_stride, b->siglens2, b->trials2, nv, nullptr, 2u }, in, s)) return SC_HIP_FAILURE;
+            hipLaunchKernelGGL(bl_resolve_kernel, dim3(nu), dim3(64), 0, s, b->msg_of2, pp, p0, v.status, b->sigs2, b->siglens2, b->trials2, sig_stride, st.status, d_sigs, d_siglens, trials);
+            HIPCHK(hipGetLastError());
+            p0 += pp;
+        }
+        // messages an oracle failure threw off the precomputed tape positions: from the start, in order
+        uint32_t n8 = 0;
         HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
-        hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, d_tape_lens, (uint32_t)tape_stride, n, b->need, b->sbase, d_siglens, d_mlens);
-        const size_t nsamp = (size_t)nact * 2 * n;
-        size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
-        const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
-        if (sblocks > (size_t)b->ctx->cus * (sper > 4 ? 4 : sper)) sblocks = (size_t)b->ctx->cus * (sper > 4 ? 4 : sper);
-        const CdtGuide &cg = b->cdt->g;
-#define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
-                           d_tapes, tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, b->tu, n)
-        switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
-#undef BL_SAMPLE
-        const size_t ne = (size_t)nact * n;
-        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, b->tu, b->tin, n, ka16, b->ain);
-        HIPCHK(hipGetLastError());
-        if (ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, b->tu, b->v, b->z, P);
-        // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
-        if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
-            hipLaunchKernelGGL(bl_oracle2_kernel, dim3((2 * nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, d_msgs, msg_stride, d_mlens, fixed_len, b->z, b->cidx, b->ok,
-                               0, (uint32_t *)nullptr, P);
-        else
-            hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, d_msgs, msg_stride, d_mlens, fixed_len, b->z, b->cidx, b->ok,
-                               0, (uint32_t *)nullptr, P);
-        hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, d_tapes, tape_stride, d_tape_lens,
-                           kf ? kf : b->d_f, kg ? kg : b->d_g, b->tu, b->v, b->z, b->cidx, d_sigs, sig_stride, d_siglens, trials, next, b->cnt, P, b->tie_rel,
-                           kf ? (size_t)n : (size_t)0);
-        HIPCHK(hipGetLastError());
-        uint32_t cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, 8u, b->act[1], b->cnt);
+        HIPCHK(hipMemcpyAsync(&n8, b->cnt, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        nact = cnt;
-        active = next;
+        if (n8) {
+            uint32_t *redo = b->act[1];                                // (the round loop's first round reads this list and writes act[0]; later rounds alternate)
+            hipLaunchKernelGGL(bl_reset_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, redo, n8, st);
+            HIPCHK(hipGetLastError());
+            if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, n8, redo, 0u }, in, s)) return SC_HIP_FAILURE;
+        }
     }
     if (b->entropy) {
         const uint32_t rawbytes = (uint32_t)sc_hip_bliss_sig_bytes(b), raww = (rawbytes + 3) / 4 + 1;
@@ -964,6 +1137,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
     // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
     sc::wipe_async(b->tu, s); sc::wipe_async(b->tin, s); sc::wipe_async(b->v, s); sc::wipe_async(b->z, s);
+    if (b->tu2) sc::wipe_async(b->tu2, s);
     return SC_HIP_SUCCESS;
 }
 

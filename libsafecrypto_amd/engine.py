@@ -43,7 +43,7 @@ SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy',
             'sc_hip_multi_dilithium_set_privkey', 'sc_hip_multi_dilithium_set_pubkey', 'sc_hip_multi_dilithium_sig_max', 'sc_hip_multi_dilithium_sign_host',
             'sc_hip_multi_dilithium_verify_host']
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning']
+BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -148,6 +148,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_set_tie_margin.argtypes = [vp, C.c_double]
+    L.sc_hip_bliss_set_speculation.argtypes = [vp, C.c_int]
     L.sc_hip_bliss_set_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
     L.sc_hip_bliss_sign_keys.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify_keys.argtypes = [vp, sz, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
@@ -859,6 +860,10 @@ class Bliss:
     def set_tie_margin(self, relative):
         """relative margin around the rejection threshold inside which a draw is reported (status 5) instead of decided; default 2^-40"""
         _chk(self.L, self.L.sc_hip_bliss_set_tie_margin(self.h, float(relative)), 'bliss_set_tie_margin')
+
+    def set_speculation(self, on):
+        """measurement / test hook: False = the reference's rejection loop round by round; True (default) = a message's later pairs of attempts side by side"""
+        _chk(self.L, self.L.sc_hip_bliss_set_speculation(self.h, 1 if on else 0), 'bliss_set_speculation')
 
     def set_entropy(self, tables):
         """the coding of the signatures (sc->coding_signature.type): None = raw fields; ((codes_t, bits_t), (codes_z, bits_z)) = SC_ENTROPY_HUFFMAN_STATIC with

@@ -362,3 +362,42 @@ def test_huffman_batch_vs_oracle_and_bad_tables(eng):
         with pytest.raises(EngineError):
             b.set_entropy(broken)
     b.close()
+
+
+def test_pairs_side_by_side_equal_the_loop_in_order(eng, G):
+    """the signer evaluates a message's later pairs of attempts side by side (tape positions computed ahead); signatures, attempt counts and statuses
+    must equal the round-by-round loop's and the oracle's - also when the tape ends inside the very pair a message would have signed in"""
+    import torch
+    key = O.BlissKey.from_golden(G, 'bliss4')                  # BLISS-B-IV: the lowest acceptance rate of the sets (M = 1.61)
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    rng = np.random.default_rng(2024)
+    B, W = 3000, 9 * 2048 + 80
+    msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 80)), dtype=np.uint8)) for _ in range(B)]
+    tapes = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+
+    def run(on):
+        b.set_speculation(on)
+        m_d, ml_d, t_d, tl_d = pack(msgs, tapes, W)
+        sigs, siglens, trials, status = b.sign(m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+        torch.cuda.synchronize()
+        return sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy(), status.cpu().numpy()
+
+    _, _, t_first, st_first = run(True)
+    assert (st_first == 1).all() and int(t_first.max()) >= 5
+    # messages that signed in attempt 3 or later (their second pair or beyond): end the tape inside, at the end of, and just behind the fresh
+    # attempt they needed (attempt 2p of pair p starts near word 2048 p)
+    late = [i for i in range(B) if t_first[i] >= 3][:30]
+    assert len(late) >= 20
+    for k, i in enumerate(late):
+        p = (int(t_first[i]) - 1) // 2
+        tapes[i] = tapes[i][:[2048 * p + 100, 2048 * p + 2047, 2048 * (p + 1) + p, 2048 * (p + 1) + 2 * p + 1, 2048 * (p + 1) + 2 * p + 6][k % 5]]
+    (s1, l1, t1, st1), (s0, l0, t0, st0) = run(True), run(False)
+    assert np.array_equal(st1, st0) and np.array_equal(l1, l0) and np.array_equal(t1, t0)
+    assert all(bytes(s1[i, :l1[i]]) == bytes(s0[i, :l0[i]]) for i in range(B))
+    assert set(np.unique(st1)) <= {1, 2} and (st1[late] == 2).sum() >= 10 and (st1[late] == 1).sum() >= 3
+    for i in late + [i for i in range(B) if t1[i] >= 3 and i not in late][:15] + list(range(0, B, 101)):
+        rc, es, et, _ = O.bliss_sign(key, msgs[i], tapes[i])
+        assert (rc == 0) == (st1[i] == 1) and (rc != 2 or st1[i] == 2), i
+        if rc == 0:
+            assert bytes(s1[i, :l1[i]]) == es and t1[i] == et, i
+    b.close()
