@@ -567,15 +567,23 @@ struct BitR {
 };
 __device__ __forceinline__ int32_t huff_get(BitR &r, int bits, const uint32_t *lut, uint32_t lutbits, const uint32_t *dleft, const uint32_t *dls, uint32_t depth)
 {
-    const int beta = bits > 7 ? bits - 7 : 0;
-    uint32_t a = r.get(beta);
+    const int beta = bits > 7 ? bits - 7 : 0;                               // (beta + the lookup's index + the sign bit fit one 32-bit look-ahead: beta <= 17)
     const uint32_t pk = r.peek32();
-    uint32_t e = lut[pk >> (32 - lutbits)];
-    if (e == 0) {                                                           // a codeword longer than the table's index: walk the candidates, shortest first
-        uint32_t i = 0;
-        for (; i + 1 < depth; i++) if (((pk ^ dleft[i]) >> (32 - (dls[i] & 0xFFu))) == 0) break;     // a complete prefix code: the last candidate needs no test
-        e = dls[i];
+    uint32_t a = beta ? pk >> (32 - beta) : 0u;
+    const uint32_t rest = pk << beta;
+    uint32_t e = lut[rest >> (32 - lutbits)];
+    if (e) {                                                                 // raw bits, codeword and sign bit out of one look-ahead
+        const uint32_t len = e & 0xFFu;
+        a |= (e >> 8) << beta;
+        const uint32_t neg = (rest << len) >> 31;
+        r.take(beta + (int)len + (a != 0));
+        return (a != 0 && neg) ? -(int32_t)a : (int32_t)a;
     }
+    r.take(beta);                                                            // a codeword longer than the table's index: walk the candidates, shortest first
+    const uint32_t pk2 = r.peek32();
+    uint32_t i = 0;
+    for (; i + 1 < depth; i++) if (((pk2 ^ dleft[i]) >> (32 - (dls[i] & 0xFFu))) == 0) break;     // a complete prefix code: the last candidate needs no test
+    e = dls[i];
     r.take((int)(e & 0xFFu));
     a |= (e >> 8) << beta;
     return (a != 0 && r.get(1)) ? -(int32_t)a : (int32_t)a;
