@@ -43,7 +43,8 @@ int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, in
 
 /* BLISS-B signer: 1 (default) = after a message's first pair of attempts its later pairs are evaluated side by side (the tape position of an attempt does
  * not depend on any value, so pair p starts from a state the host computes; the lowest successful attempt is the signature); 0 = the reference's loop
- * round by round.  Signatures, attempt counts and statuses do not depend on it. */
+ * round by round; 2 = as 1, but every third message that goes on to its later pairs is sent through the redo path (the one a failed oracle call
+ * would take: state reset, the loop in order) - a self-test.  Signatures, attempt counts and statuses do not depend on it. */
 int sc_hip_bliss_set_speculation(sc_hip_bliss_t *h, int on);
 
 #ifdef __cplusplus

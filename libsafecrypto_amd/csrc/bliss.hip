@@ -727,7 +727,7 @@ struct sc_hip_bliss {
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
     int32_t *tu, *tin, *v, *cidx, *ain;
     int16_t *z;
-    bool speculate;              // later pairs of attempts side by side (bl_sign_core); false = the reference's loop round by round
+    int speculate;               // 1: later pairs of attempts side by side (bl_sign_core); 0: the reference's loop round by round; 2: self-test of the redo path
     St st2; int32_t *tu2; uint8_t *sigs2; uint32_t *siglens2, *trials2, *msg_of2; size_t cap2, stride2;     // the pairs' state, vectors and output rows
     int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy)
     uint32_t *d_huff;            // the two code tables and their decoding orders, one allocation
@@ -774,7 +774,7 @@ extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_
     memset(b, 0, sizeof *b);
     b->ctx = ctx; b->plan = plan; b->cdt = cdt; b->P = P;
     b->tie_rel = 0x1p-40;
-    b->speculate = true;
+    b->speculate = 1;
     *out = b;
     return SC_HIP_SUCCESS;
 }
@@ -856,7 +856,8 @@ static void bl_free_ws2(sc_hip_bliss *b);
 extern "C" int sc_hip_bliss_set_speculation(sc_hip_bliss_t *b, int on)
 {
     if (!b) return fail("bliss_set_speculation: null handle");
-    b->speculate = on != 0;
+    if (on < 0 || on > 2) return fail("bliss_set_speculation: 0, 1 or 2");
+    b->speculate = on;
     return SC_HIP_SUCCESS;
 }
 
@@ -1036,6 +1037,12 @@ __global__ __launch_bounds__(64) void bl_resolve_kernel(const uint32_t *msg_of, 
     } else if (threadIdx.x == 0) siglens[m] = 0;
     if (threadIdx.x == 0) status[m] = st;
 }
+// self-test (sc_hip_bliss_set_speculation(h, 2)): every third message that goes on to its later pairs is declared off its precomputed tape positions
+__global__ void bl_force_redo_kernel(uint32_t *status, uint32_t count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && status[i] == 7 && i % 3 == 0) status[i] = 8;
+}
 __global__ void bl_reset_kernel(const uint32_t *list, uint32_t count, St s)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1088,10 +1095,11 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     uint32_t *trials = d_trials ? d_trials : b->trials;
     HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
     const BlIn in{ kf, kg, ka16, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens };
-    const bool spec = b->speculate;
+    const bool spec = b->speculate != 0;
     // every message: its first pair of attempts (all of them when the handle runs the plain loop)
     if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, B, nullptr, spec ? 2u : 0u }, in, s)) return SC_HIP_FAILURE;
     if (spec) {
+        if (b->speculate == 2) hipLaunchKernelGGL(bl_force_redo_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B);
         ResSim sim;
         sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);                 // pair 0 is behind us
         uint32_t *ulist = b->act[0];                                  // (the round loop is idle here: its two lists are free)

@@ -862,8 +862,9 @@ class Bliss:
         _chk(self.L, self.L.sc_hip_bliss_set_tie_margin(self.h, float(relative)), 'bliss_set_tie_margin')
 
     def set_speculation(self, on):
-        """measurement / test hook: False = the reference's rejection loop round by round; True (default) = a message's later pairs of attempts side by side"""
-        _chk(self.L, self.L.sc_hip_bliss_set_speculation(self.h, 1 if on else 0), 'bliss_set_speculation')
+        """measurement / test hook: 0 / False = the reference's rejection loop round by round; 1 / True (default) = a message's later pairs of attempts side by
+        side; 2 = as 1 with every third such message sent through the in-order redo path"""
+        _chk(self.L, self.L.sc_hip_bliss_set_speculation(self.h, int(on)), 'bliss_set_speculation')
 
     def set_entropy(self, tables):
         """the coding of the signatures (sc->coding_signature.type): None = raw fields; ((codes_t, bits_t), (codes_z, bits_z)) = SC_ENTROPY_HUFFMAN_STATIC with

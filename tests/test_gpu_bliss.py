@@ -382,7 +382,7 @@ def test_pairs_side_by_side_equal_the_loop_in_order(eng, G):
         torch.cuda.synchronize()
         return sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy(), status.cpu().numpy()
 
-    _, _, t_first, st_first = run(True)
+    _, _, t_first, st_first = run(1)
     assert (st_first == 1).all() and int(t_first.max()) >= 5
     # messages that signed in attempt 3 or later (their second pair or beyond): end the tape inside, at the end of, and just behind the fresh
     # attempt they needed (attempt 2p of pair p starts near word 2048 p)
@@ -391,9 +391,13 @@ def test_pairs_side_by_side_equal_the_loop_in_order(eng, G):
     for k, i in enumerate(late):
         p = (int(t_first[i]) - 1) // 2
         tapes[i] = tapes[i][:[2048 * p + 100, 2048 * p + 2047, 2048 * (p + 1) + p, 2048 * (p + 1) + 2 * p + 1, 2048 * (p + 1) + 2 * p + 6][k % 5]]
-    (s1, l1, t1, st1), (s0, l0, t0, st0) = run(True), run(False)
+    (s1, l1, t1, st1), (s0, l0, t0, st0), (s2, l2, t2, st2) = run(1), run(0), run(2)
     assert np.array_equal(st1, st0) and np.array_equal(l1, l0) and np.array_equal(t1, t0)
     assert all(bytes(s1[i, :l1[i]]) == bytes(s0[i, :l0[i]]) for i in range(B))
+    # mode 2 sends a third of the late messages through the redo path (state reset, the loop in order): the same again
+    assert np.array_equal(st2, st0) and np.array_equal(l2, l0) and np.array_equal(t2, t0)
+    assert all(bytes(s2[i, :l2[i]]) == bytes(s0[i, :l0[i]]) for i in range(B))
+    assert sum(1 for i in range(0, B, 3) if t0[i] >= 3) >= 20
     assert set(np.unique(st1)) <= {1, 2} and (st1[late] == 2).sum() >= 10 and (st1[late] == 1).sum() >= 3
     for i in late + [i for i in range(B) if t1[i] >= 3 and i not in late][:15] + list(range(0, B, 101)):
         rc, es, et, _ = O.bliss_sign(key, msgs[i], tapes[i])
