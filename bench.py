@@ -28,6 +28,11 @@ import subprocess
 import sys
 import time
 
+# pageable host<->device copies of this process are staged by the runtime, not pinned in place (tests/conftest.py, profiles/r02_pageable_copy_fault.txt);
+# read when the HIP runtime initialises, so set before torch is imported; an explicit setting in the environment wins
+os.environ.setdefault('GPU_PINNED_XFER_SIZE', '4096')
+os.environ.setdefault('GPU_PINNED_MIN_XFER_SIZE', '4194304')
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
