@@ -70,14 +70,27 @@ __global__ __launch_bounds__(HT) void dil_crh_t1_kernel(const uint8_t *rho, cons
     // aligned: 32 bytes of rho, a rate of 17 words) instead of eight read-modify-write rounds on the LDS state
     uint32_t acc = 0; int nb = 0;
     uint64_t word = 0; int wb = 0;
-    for (uint32_t i = 0; i < len; i++) {
-        acc = (acc << bits) | ((uint32_t)t1[i] & ((1u << bits) - 1)); nb += bits;
+    // (a lane walks its own key: its loads are 16 bytes wide and the next one is in flight while the current four coefficients are packed - the
+    // walk is otherwise a chain of dependent 4-byte loads 6 KB apart between lanes, which tripled the kernel's time over its 13 permutations)
+    auto put = [&](int32_t c) {
+        acc = (acc << bits) | ((uint32_t)c & ((1u << bits) - 1)); nb += bits;
         while (nb >= 8) {
             word |= (uint64_t)(uint8_t)(acc >> (nb - 8)) << (8 * wb); nb -= 8;
             if (++wb == 8) { sp.absorb_u64(word); word = 0; wb = 0; }
         }
         acc &= (1u << nb) - 1;
+    };
+    uint32_t i = 0;
+    if ((len & 3) == 0 && (reinterpret_cast<uintptr_t>(t1) & 15) == 0 && len >= 4) {
+        const int4 *t4 = reinterpret_cast<const int4 *>(t1);
+        int4 cur = t4[0];
+        for (; i + 4 <= len; i += 4) {
+            const int4 nxt = t4[i + 4 < len ? (i >> 2) + 1 : (i >> 2)];
+            put(cur.x); put(cur.y); put(cur.z); put(cur.w);
+            cur = nxt;
+        }
     }
+    for (; i < len; i++) put(t1[i]);
     for (int i = 0; i < wb; i++) sp.absorb_byte((uint8_t)(word >> (8 * i)));
     if (nb) sp.absorb_byte((uint8_t)(acc << (8 - nb)));
     sp.finalize();
@@ -428,6 +441,8 @@ struct sc_hip_dilithium {
     uint8_t *msg_dev, *sig_dev;
     size_t msg_cap, sig_cap;
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
+    hipStream_t side, side2;                          // verify_keys / sign_keys: per-key chains that depend on nothing of each other run beside each other
+    hipEvent_t ev_fork, ev_join, ev_join2;
     int tune_slots, tune_unfused, tune_growth;                     // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product
 };
 
@@ -498,6 +513,11 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
     if (!d) return;
     free_ws(d);
     d->kws.release();
+    if (d->side) (void)hipStreamDestroy(d->side);
+    if (d->side2) (void)hipStreamDestroy(d->side2);
+    if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
+    if (d->ev_join) (void)hipEventDestroy(d->ev_join);
+    if (d->ev_join2) (void)hipEventDestroy(d->ev_join2);
     void *ptrs[] = { d->d_A, d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(d->plan);
@@ -645,6 +665,7 @@ struct DilSignKeys {
     const uint32_t *s1, *s2, *t0;         // NTT, internal order, Montgomery form
     const uint8_t *K, *tr;
     bool per_item;
+    hipEvent_t matrix_ready;              // non-null: A is being written on another stream; the first kernel that reads it waits for this
 };
 
 static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
@@ -655,7 +676,7 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
 {
     if (!d) return fail("dilithium_sign: null handle");
     if (!d->have_priv) return fail("dilithium_sign: no private key loaded");
-    const DilSignKeys ks = { d->d_A, d->tune_unfused ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false };
+    const DilSignKeys ks = { d->d_A, d->tune_unfused ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false, nullptr };
     return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
 }
 
@@ -715,6 +736,7 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         } else {
             if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
             a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0;
+            if (ks.matrix_ready && round == 0) HIPCHK(hipStreamWaitEvent(s, ks.matrix_ready, 0));
             if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
             a.key_item_stride = 0;
         }
@@ -894,16 +916,29 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     if (d->kws.reserve(2 * npoly * N * 4 + batch * (ln + 3 * kn) * 4 + 4096)) return SC_HIP_FAILURE;
     int32_t *ab = d->kws.take<int32_t>(npoly * N), *t0n = d->kws.take<int32_t>(batch * kn);
     uint32_t *am = d->kws.take<uint32_t>(npoly * N), *s1h = d->kws.take<uint32_t>(batch * ln), *s2h = d->kws.take<uint32_t>(batch * kn), *t0h = d->kws.take<uint32_t>(batch * kn);
-    if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
+    // the matrix comes out of the CTR-DRBG one lane per key (a sequential cipher stream: ~0.6 ms at 16 K keys on a quarter of the SIMDs) and nothing needs
+    // it before the first matrix product: it is expanded on a stream of the handle's own while the caller's stream prepares the secrets, hashes the
+    // messages and expands the first round's masks (another chain bound by its own length); the first matrix product waits for it
+    if (!d->side) {
+        HIPCHK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(d->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, d->side)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, d->side, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
+    HIPCHK(hipEventRecord(d->ev_join, d->side));
     hipLaunchKernelGGL(dil_t0_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t, t0n, batch * kn, P.d, P.q);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
-    a.in = d_s1; a.out_int = s1h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s)) return SC_HIP_FAILURE;
-    a.in = d_s2; a.out_int = s2h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
-    a.in = t0n; a.out_int = t0h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
-    const DilSignKeys ks = { am, nullptr, s1h, s2h, t0h, d_K, d_tr, true };
-    const int rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    int rc = SC_HIP_SUCCESS;
+    a.in = d_s1; a.out_int = s1h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s)) rc = SC_HIP_FAILURE;
+    a.in = d_s2; a.out_int = s2h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
+    a.in = t0n; a.out_int = t0h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
+    const DilSignKeys ks = { am, nullptr, s1h, s2h, t0h, d_K, d_tr, true, d->ev_join };
+    if (rc == SC_HIP_SUCCESS) rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    (void)hipStreamWaitEvent(s, d->ev_join, 0);                    // (again, in case the signing did not get as far as its first matrix product)
     d->kws.wipe(s);                                                 // the per-item NTT(s1), NTT(s2), NTT(t0)
     return rc;
 }
@@ -938,37 +973,64 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return fail("dilithium_verify_keys: sig_stride too small");
     const size_t kn = (size_t)k * N, npoly = batch * (size_t)k * l;
     // grow-only workspace kept by the handle (a per-call hipMalloc of ~60 KB per item costs more than the kernels)
-    if (d->kws.reserve(2 * npoly * N * 4 + 2 * batch * kn * 4 + batch * 48 + 2048)) return SC_HIP_FAILURE;
+    if (d->kws.reserve(npoly * N * 4 + 2 * batch * kn * 4 + batch * 48 + 2048)) return SC_HIP_FAILURE;
     int32_t *ab = d->kws.take<int32_t>(npoly * N), *t1s = d->kws.take<int32_t>(batch * kn);
-    uint32_t *am = d->kws.take<uint32_t>(npoly * N), *t1h = d->kws.take<uint32_t>(batch * kn);
+    uint32_t *t1h = d->kws.take<uint32_t>(batch * kn);
     uint8_t *trb = d->kws.take<uint8_t>(batch * 48);
-    // per-item key material
+    // Three chains that depend on nothing of each other until the matrix product: (1) the matrix of every key out of its CTR-DRBG - the cipher fills the
+    // machine's LDS pipes for ~0.65 ms at 16 K keys; (2) tr = CRH(rho, t1) -> mu, one lane per key, 13 + a few sequential permutations: bound by its own
+    // length (~0.4 ms), it wants few issue slots but wants them early; (3) the signature side and t1 . 2^d with their transforms: memory-bound kernels
+    // that progress beside the cipher at a fifth of their speed and are done when it is.  (1) stays on the caller's stream, (2) and (3) get a stream
+    // each of the handle's own; the matrix product waits for (3), the challenge at the very end for (2).
+    if (!d->side) {
+        HIPCHK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d->ev_join, hipEventDisableTiming));
+    }
+    if (!d->ev_join2) HIPCHK(hipEventCreateWithFlags(&d->ev_join2, hipEventDisableTiming));
+    if (!d->side2) HIPCHK(hipStreamCreateWithFlags(&d->side2, hipStreamNonBlocking));
+    hipStream_t s3 = d->side2;
+    hipStream_t s2 = d->side;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    HIPCHK(hipEventRecord(d->ev_fork, s));                               // everything the caller queued before (its inputs) is ahead of both streams
+    HIPCHK(hipStreamWaitEvent(s2, d->ev_fork, 0));
+    HIPCHK(hipStreamWaitEvent(s3, d->ev_fork, 0));
+    // chain (2) first: its few wavefronts should be resident before the cipher's 7680 take every slot
+    const unsigned hb = (B + HT - 1) / HT;
+    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s3, d_rho, d_t1, (uint32_t)kn, P.q_bits - P.d, trb, B);
+    hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s3, trb, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, 48u);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(d->ev_join2, s3));
+    // caller's stream: the matrix.  It is used once per key, so it is never converted: the matrix product reads it as the expansion wrote it (natural order,
+    // plain) and the Montgomery factor travels on NTT(z) instead (DilNtt::key_nat) - a pass over 30 KB per key less than the signer's form.
     if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, s, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
-    hipLaunchKernelGGL(dil_shift_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t1, t1s, batch * kn, P.d);
-    hipLaunchKernelGGL(dil_crh_t1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, d_rho, d_t1, (uint32_t)kn, P.q_bits - P.d, trb, B);
+    // chain (3): the signature side as in sc_hip_dilithium_verify, t1 . 2^d and its transform; chain (2) below
+    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
+    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s2, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
+                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s2, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
+    hipLaunchKernelGGL(dil_shift_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s2, d_t1, t1s, batch * kn, P.d);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
     a.in = t1s; a.out_int = t1h;
-    if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) return SC_HIP_FAILURE;
-    // the signature side, as sc_hip_dilithium_verify
-    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    const unsigned hb = (B + HT - 1) / HT;
-    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
-    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
-                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
-    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
-    hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, trb, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, 48u);
-    HIPCHK(hipGetLastError());
+    if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s2)) return SC_HIP_FAILURE;
     a = base_args(d);
     a.in = d->z; a.out_int = d->yh;
-    if (launch_dil<DOP_FWD_INT>(d, a, B, l, s)) return SC_HIP_FAILURE;
-    a.key = am; a.key_item_stride = (size_t)k * l * N;
-    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s2)) return SC_HIP_FAILURE;      // NTT(z) R: the factor the plain matrix does not carry
+    a = base_args(d);
     a.in = d->c; a.out_int = d->ch;
-    if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
+    if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s2)) return SC_HIP_FAILURE;
+    HIPCHK(hipEventRecord(d->ev_join, s2));
+    HIPCHK(hipStreamWaitEvent(s, d->ev_join, 0));
+    a = base_args(d);
+    a.in = d->z; a.out_int = d->yh;
+    a.key = reinterpret_cast<const uint32_t *>(ab); a.key_item_stride = (size_t)k * l * N; a.key_nat = 1;
+    if (launch_dil<DOP_MATVEC>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    a.key_nat = 0;
+    a.in = d->c; a.out_int = d->ch;
     a.key = t1h; a.key_item_stride = kn;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
+    HIPCHK(hipStreamWaitEvent(s, d->ev_join2, 0));
     hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, d->c, 1, d_verdicts);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;

@@ -78,7 +78,7 @@ namespace {
 __global__ __launch_bounds__(256) void drbg_expand_kernel(uint32_t batch, const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len,
                                                           uint8_t *__restrict__ out, size_t out_stride, uint32_t nblk, int words, DrbgConst C)
 {
-    __shared__ AesLds L;
+    __shared__ AesLdsWide L;
     L.fill(C);
     __syncthreads();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void drbg_expand_kernel(uint32_t batch, const 
 __global__ __launch_bounds__(256) void drbg_matrix_kernel(uint32_t nkeys, uint32_t npoly, const uint8_t *__restrict__ rho, size_t rho_stride, uint32_t rho_len,
                                                           int32_t *__restrict__ out, int32_t q, uint32_t mask, DrbgConst C)
 {
-    __shared__ AesLds L;
+    __shared__ AesLdsWide L;
     L.fill(C);
     __syncthreads();
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;

@@ -10,8 +10,8 @@
 // same stream through a pool filled with 64-bit little-endian draws split HIGH word first (prng.c:95-143), i.e. the words of
 // every 16-byte block come out as w1, w0, w3, w2.
 //
-// AES is FIPS-197 AES-256 (the reference uses Gladman's implementation, src/utils/crypto/aes): T-table form, one 1 KB table
-// Te0[x] = (2s, s, s, 3s) and the S-box in LDS (filled by the workgroup from the S-box passed in DrbgConst), round keys in
+// AES is FIPS-197 AES-256 (the reference uses Gladman's implementation, src/utils/crypto/aes): T-table form, the table
+// Te0[x] = (2s, s, s, 3s) in LDS (filled by the workgroup from the S-box passed in DrbgConst; the S-box is read out of its second byte), round keys in
 // registers.  State columns are little-endian words (byte r of a word = row r).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -24,25 +24,32 @@ struct DrbgConst {
     uint8_t init_bytes[48];       // AES_0(3) | AES_0(2) | AES_0(1)
 };
 
-struct AesLds {
-    uint32_t te0[256];
-    uint32_t sb[256];             // S-box, one entry per dword (conflict-friendlier than bytes)
+// REP copies of the T-table, copy (lane mod REP) for lane: with REP = 32 every lane of a half-wavefront reads its own LDS bank and the 208 table
+// look-ups of a block are conflict-free (two passes per wavefront) instead of ~5 deep on random indices - the bulk expansions (a matrix per key) are
+// bound by exactly these look-ups.  REP = 1 keeps the 2 KB form for kernels whose LDS goes to hash states.  The S-box is byte 1 of Te0[x].
+template <int REP>
+struct AesLdsT {
+    uint32_t te0[256 * REP];
     // every lane of the workgroup takes part; call once, then __syncthreads()
     __device__ void fill(const DrbgConst &c)
     {
-        for (int x = threadIdx.x; x < 256; x += blockDim.x) {
-            const uint32_t s = c.sbox[x], s2 = ((s << 1) ^ ((s >> 7) * 0x11b)) & 0xff, s3 = s2 ^ s;
-            te0[x] = s2 | (s << 8) | (s << 16) | (s3 << 24);
-            sb[x] = s;
+        for (int e = threadIdx.x; e < 256 * REP; e += blockDim.x) {
+            const uint32_t s = c.sbox[e / REP], s2 = ((s << 1) ^ ((s >> 7) * 0x11b)) & 0xff, s3 = s2 ^ s;
+            te0[e] = s2 | (s << 8) | (s << 16) | (s3 << 24);
         }
     }
+    __device__ __forceinline__ uint32_t t(uint32_t x) const { return te0[x * REP + (threadIdx.x & (REP - 1))]; }
+    __device__ __forceinline__ uint32_t sb(uint32_t x) const { return (t(x) >> 8) & 0xffu; }
 };
+using AesLds = AesLdsT<1>;
+using AesLdsWide = AesLdsT<32>;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
 
 struct Aes256 {
     uint32_t rk[60];
-    __device__ __forceinline__ void set_key(const uint32_t key[8], const AesLds &L)
+    template <class LT>
+    __device__ __forceinline__ void set_key(const uint32_t key[8], const LT &L)
     {
 #pragma unroll
         for (int i = 0; i < 8; i++) rk[i] = key[i];
@@ -52,30 +59,31 @@ struct Aes256 {
             uint32_t t = rk[i - 1];
             if (i % 8 == 0) {
                 t = (t >> 8) | (t << 24);                                                     // RotWord on a little-endian word
-                t = L.sb[t & 0xff] | (L.sb[(t >> 8) & 0xff] << 8) | (L.sb[(t >> 16) & 0xff] << 16) | (L.sb[t >> 24] << 24);
+                t = L.sb(t & 0xff) | (L.sb((t >> 8) & 0xff) << 8) | (L.sb((t >> 16) & 0xff) << 16) | (L.sb(t >> 24) << 24);
                 t ^= rc;
                 rc = ((rc << 1) ^ ((rc >> 7) * 0x11b)) & 0xff;
             } else if (i % 8 == 4) {
-                t = L.sb[t & 0xff] | (L.sb[(t >> 8) & 0xff] << 8) | (L.sb[(t >> 16) & 0xff] << 16) | (L.sb[t >> 24] << 24);
+                t = L.sb(t & 0xff) | (L.sb((t >> 8) & 0xff) << 8) | (L.sb((t >> 16) & 0xff) << 16) | (L.sb(t >> 24) << 24);
             }
             rk[i] = rk[i - 8] ^ t;
         }
     }
-    __device__ __forceinline__ void encrypt(const uint32_t in[4], uint32_t out[4], const AesLds &L) const
+    template <class LT>
+    __device__ __forceinline__ void encrypt(const uint32_t in[4], uint32_t out[4], const LT &L) const
     {
         uint32_t s0 = in[0] ^ rk[0], s1 = in[1] ^ rk[1], s2 = in[2] ^ rk[2], s3 = in[3] ^ rk[3];
 #pragma unroll
         for (int r = 1; r < 14; r++) {
-            const uint32_t t0 = L.te0[s0 & 0xff] ^ rotl32(L.te0[(s1 >> 8) & 0xff], 8) ^ rotl32(L.te0[(s2 >> 16) & 0xff], 16) ^ rotl32(L.te0[s3 >> 24], 24) ^ rk[4 * r];
-            const uint32_t t1 = L.te0[s1 & 0xff] ^ rotl32(L.te0[(s2 >> 8) & 0xff], 8) ^ rotl32(L.te0[(s3 >> 16) & 0xff], 16) ^ rotl32(L.te0[s0 >> 24], 24) ^ rk[4 * r + 1];
-            const uint32_t t2 = L.te0[s2 & 0xff] ^ rotl32(L.te0[(s3 >> 8) & 0xff], 8) ^ rotl32(L.te0[(s0 >> 16) & 0xff], 16) ^ rotl32(L.te0[s1 >> 24], 24) ^ rk[4 * r + 2];
-            const uint32_t t3 = L.te0[s3 & 0xff] ^ rotl32(L.te0[(s0 >> 8) & 0xff], 8) ^ rotl32(L.te0[(s1 >> 16) & 0xff], 16) ^ rotl32(L.te0[s2 >> 24], 24) ^ rk[4 * r + 3];
+            const uint32_t t0 = L.t(s0 & 0xff) ^ rotl32(L.t((s1 >> 8) & 0xff), 8) ^ rotl32(L.t((s2 >> 16) & 0xff), 16) ^ rotl32(L.t(s3 >> 24), 24) ^ rk[4 * r];
+            const uint32_t t1 = L.t(s1 & 0xff) ^ rotl32(L.t((s2 >> 8) & 0xff), 8) ^ rotl32(L.t((s3 >> 16) & 0xff), 16) ^ rotl32(L.t(s0 >> 24), 24) ^ rk[4 * r + 1];
+            const uint32_t t2 = L.t(s2 & 0xff) ^ rotl32(L.t((s3 >> 8) & 0xff), 8) ^ rotl32(L.t((s0 >> 16) & 0xff), 16) ^ rotl32(L.t(s1 >> 24), 24) ^ rk[4 * r + 2];
+            const uint32_t t3 = L.t(s3 & 0xff) ^ rotl32(L.t((s0 >> 8) & 0xff), 8) ^ rotl32(L.t((s1 >> 16) & 0xff), 16) ^ rotl32(L.t(s2 >> 24), 24) ^ rk[4 * r + 3];
             s0 = t0; s1 = t1; s2 = t2; s3 = t3;
         }
-        out[0] = (L.sb[s0 & 0xff] | (L.sb[(s1 >> 8) & 0xff] << 8) | (L.sb[(s2 >> 16) & 0xff] << 16) | (L.sb[s3 >> 24] << 24)) ^ rk[56];
-        out[1] = (L.sb[s1 & 0xff] | (L.sb[(s2 >> 8) & 0xff] << 8) | (L.sb[(s3 >> 16) & 0xff] << 16) | (L.sb[s0 >> 24] << 24)) ^ rk[57];
-        out[2] = (L.sb[s2 & 0xff] | (L.sb[(s3 >> 8) & 0xff] << 8) | (L.sb[(s0 >> 16) & 0xff] << 16) | (L.sb[s1 >> 24] << 24)) ^ rk[58];
-        out[3] = (L.sb[s3 & 0xff] | (L.sb[(s0 >> 8) & 0xff] << 8) | (L.sb[(s1 >> 16) & 0xff] << 16) | (L.sb[s2 >> 24] << 24)) ^ rk[59];
+        out[0] = (L.sb(s0 & 0xff) | (L.sb((s1 >> 8) & 0xff) << 8) | (L.sb((s2 >> 16) & 0xff) << 16) | (L.sb(s3 >> 24) << 24)) ^ rk[56];
+        out[1] = (L.sb(s1 & 0xff) | (L.sb((s2 >> 8) & 0xff) << 8) | (L.sb((s3 >> 16) & 0xff) << 16) | (L.sb(s0 >> 24) << 24)) ^ rk[57];
+        out[2] = (L.sb(s2 & 0xff) | (L.sb((s3 >> 8) & 0xff) << 8) | (L.sb((s0 >> 16) & 0xff) << 16) | (L.sb(s1 >> 24) << 24)) ^ rk[58];
+        out[3] = (L.sb(s3 & 0xff) | (L.sb((s0 >> 8) & 0xff) << 8) | (L.sb((s1 >> 16) & 0xff) << 16) | (L.sb(s2 >> 24) << 24)) ^ rk[59];
     }
 };
 
@@ -83,7 +91,8 @@ struct Drbg {
     Aes256 aes;
     uint32_t counter;
     // seed: len >= 1 bytes, read circularly (prng_get_func.c:108-119)
-    __device__ __forceinline__ void init(const uint8_t *seed, uint32_t len, const DrbgConst &c, const AesLds &L)
+    template <class LT>
+    __device__ __forceinline__ void init(const uint8_t *seed, uint32_t len, const DrbgConst &c, const LT &L)
     {
         uint32_t idx = 0, ctr = 0, key[8];
         for (int i = 0; i < 4; i++) { ctr |= (uint32_t)seed[idx] << (8 * i); if (++idx == len) idx = 0; }
@@ -97,7 +106,8 @@ struct Drbg {
         aes.set_key(key, L);
     }
     // the next 16 bytes of the stream as four little-endian words
-    __device__ __forceinline__ void block(uint32_t out[4], const AesLds &L)
+    template <class LT>
+    __device__ __forceinline__ void block(uint32_t out[4], const LT &L)
     {
         const uint32_t in[4] = { counter, counter, counter, counter };
         counter++;

@@ -1,5 +1,5 @@
 """One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls]` runs one warm-up call and `calls` timed calls of
-   dil_sign | dil_verify | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | polymul | cdt
+   dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | polymul | cdt
 on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call."""
 import sys, os, time, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
@@ -24,6 +24,13 @@ def main():
         fn = (lambda: d.sign(msgs, fixed_len=64)) if leg == 'dil_sign' else (lambda: d.verify(msgs, sigs, siglens, fixed_len=64))
         if leg == 'dil_verify':
             fn(); made = 1                       # the sign above is a different leg: counted by the caller through kernel names
+        if leg in ('dil_verify_keys', 'dil_sign_keys'):          # a key pair per message (generated on the device from seeds)
+            seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+            s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, int(G[f'{tag}_eta_bits'][0]))
+            t1f = t1.reshape(B, -1).contiguous()
+            ks, kl = d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64)[:2]; torch.cuda.synchronize()
+            fn = (lambda: d.verify_keys(t1f, rho, msgs, ks, kl, fixed_len=64)) if leg == 'dil_verify_keys' else (lambda: d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64))
+            fn(); made = 1
     elif leg.startswith('bliss'):
         G = load_golden('bliss_ref.txt'); B = 16384
         b = eng.bliss(G['bliss1_params']); b.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
