@@ -665,6 +665,7 @@ struct DilSignKeys {
     const uint32_t *s1, *s2, *t0;         // NTT, internal order, Montgomery form
     const uint8_t *K, *tr;
     bool per_item;
+    bool A_nat;                           // A is in natural order and plain form (as the expansion writes it): NTT(y) then carries the Montgomery factor (DilNtt::key_nat)
     hipEvent_t matrix_ready;              // non-null: A is being written on another stream; the first kernel that reads it waits for this
 };
 
@@ -676,7 +677,7 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
 {
     if (!d) return fail("dilithium_sign: null handle");
     if (!d->have_priv) return fail("dilithium_sign: no private key loaded");
-    const DilSignKeys ks = { d->d_A, d->tune_unfused ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false, nullptr };
+    const DilSignKeys ks = { d->d_A, d->tune_unfused ? nullptr : d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_K, d->d_tr_priv, false, false, nullptr };
     return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
 }
 
@@ -734,11 +735,11 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
             if (mlwe_launch_yaw(d->ctx, a, nslots, s)) return SC_HIP_FAILURE;
             a.keyp = nullptr;
         } else {
-            if (launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-            a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0;
+            if (ks.A_nat ? launch_dil<DOP_KEYPREP>(d, a, nslots, l, s) : launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
+            a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0; a.key_nat = ks.A_nat ? 1 : 0;
             if (ks.matrix_ready && round == 0) HIPCHK(hipStreamWaitEvent(s, ks.matrix_ready, 0));
             if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-            a.key_item_stride = 0;
+            a.key_item_stride = 0; a.key_nat = 0;
         }
         hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, nslots, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
@@ -913,12 +914,15 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     const uint32_t B = (uint32_t)batch;
     const int k = P.k, l = P.l;
     const size_t kn = (size_t)k * N, ln = (size_t)l * N, npoly = batch * (size_t)k * l;
-    if (d->kws.reserve(2 * npoly * N * 4 + batch * (ln + 3 * kn) * 4 + 4096)) return SC_HIP_FAILURE;
-    int32_t *ab = d->kws.take<int32_t>(npoly * N), *t0n = d->kws.take<int32_t>(batch * kn);
-    uint32_t *am = d->kws.take<uint32_t>(npoly * N), *s1h = d->kws.take<uint32_t>(batch * ln), *s2h = d->kws.take<uint32_t>(batch * kn), *t0h = d->kws.take<uint32_t>(batch * kn);
-    // the matrix comes out of the CTR-DRBG one lane per key (a sequential cipher stream: ~0.6 ms at 16 K keys on a quarter of the SIMDs) and nothing needs
-    // it before the first matrix product: it is expanded on a stream of the handle's own while the caller's stream prepares the secrets, hashes the
-    // messages and expands the first round's masks (another chain bound by its own length); the first matrix product waits for it
+    if (d->kws.reserve(npoly * N * 4 + batch * (ln + 3 * kn) * 4 + 4096)) return SC_HIP_FAILURE;
+    int32_t *t0n = d->kws.take<int32_t>(batch * kn);
+    uint32_t *s1h = d->kws.take<uint32_t>(batch * ln), *s2h = d->kws.take<uint32_t>(batch * kn), *t0h = d->kws.take<uint32_t>(batch * kn);
+    const size_t secret_end = d->kws.mark();                        // what is zeroed behind the call; the matrix below is public
+    int32_t *ab = d->kws.take<int32_t>(npoly * N);
+    // the matrix comes out of the CTR-DRBG (~0.65 ms of cipher at 16 K keys) and nothing needs it before the first matrix product: it is expanded on a
+    // stream of the handle's own while the caller's stream prepares the secrets, hashes the messages and expands the first round's masks (a chain bound by
+    // its own length); the first matrix product waits for it.  It stays as the expansion wrote it - natural order, plain form - and NTT(y) carries the
+    // Montgomery factor instead (DilNtt::key_nat): no conversion pass over 30 KB per key.
     if (!d->side) {
         HIPCHK(hipStreamCreateWithFlags(&d->side, hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&d->ev_fork, hipEventDisableTiming));
@@ -927,7 +931,6 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     HIPCHK(hipEventRecord(d->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
     if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, d->side)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((npoly * N + 255) / 256)), dim3(256), 0, d->side, ab, am, npoly, d->plan->k[1], d->plan->r2, d->plan->r2p, 0, 0);
     HIPCHK(hipEventRecord(d->ev_join, d->side));
     hipLaunchKernelGGL(dil_t0_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t, t0n, batch * kn, P.d, P.q);
     HIPCHK(hipGetLastError());
@@ -936,10 +939,10 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     a.in = d_s1; a.out_int = s1h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s)) rc = SC_HIP_FAILURE;
     a.in = d_s2; a.out_int = s2h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
     a.in = t0n; a.out_int = t0h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
-    const DilSignKeys ks = { am, nullptr, s1h, s2h, t0h, d_K, d_tr, true, d->ev_join };
+    const DilSignKeys ks = { reinterpret_cast<const uint32_t *>(ab), nullptr, s1h, s2h, t0h, d_K, d_tr, true, true, d->ev_join };
     if (rc == SC_HIP_SUCCESS) rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
     (void)hipStreamWaitEvent(s, d->ev_join, 0);                    // (again, in case the signing did not get as far as its first matrix product)
-    d->kws.wipe(s);                                                 // the per-item NTT(s1), NTT(s2), NTT(t0)
+    d->kws.wipe_upto(secret_end, s);                                // the per-item t0, NTT(s1), NTT(s2), NTT(t0)
     return rc;
 }
 

@@ -122,6 +122,9 @@ struct Workspace {
     }
     void release() { if (p) (void)wipe_free(p); p = nullptr; cap = used = 0; }
     void wipe(hipStream_t s) { if (p && used) (void)hipMemsetAsync(p, 0, used < cap ? used : cap, s); }      // per-call secrets: zeroed behind the call's work
+    // the same for the slices taken so far only (take the secret slices first, call this, then take the public ones: zeroing costs bandwidth)
+    size_t mark() const { return used; }
+    void wipe_upto(size_t m, hipStream_t s) { if (p && m) (void)hipMemsetAsync(p, 0, m < cap ? m : cap, s); }
 };
 }
 
