@@ -344,10 +344,16 @@ struct sc_hip_kyber {
     // a key per message: the matrices / t / s of the batch in the kernels' internal Montgomery form (staged per call)
     size_t keys_cap; bool keys_priv;
     int32_t *pk_gen; uint32_t *pk_A, *pk_t, *pk_s;
+    hipStream_t side; hipEvent_t ev_fork, ev_join;     // a key per item: the matrices are expanded on a stream of the handle's own beside the hashing of the messages
 };
 
 // the key operands of one CPA call: the handle's one key (strides 0) or a key per message
-struct KyKeys { const uint32_t *A, *t, *s; size_t sA, st; };
+struct KyKeys {
+    const uint32_t *A, *t, *s; size_t sA, st;      // internal order, Montgomery form; strides between items (0: one key for the batch)
+    hipEvent_t ready;                               // non-null: A is being written on another stream; the first product that reads it waits for this
+    bool nat;                                       // a key per item: A as the expansion wrote it ([col][row][n], natural order, plain), t and s the key pair's own
+                                                    // NTT-domain arrays - read in place by the products (DilNtt::key_nat), the transform of the other operand carries the Montgomery factor
+};
 
 static int ky_ensure(sc_hip_kyber *h, size_t batch)
 {
@@ -384,6 +390,9 @@ extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
     if (!h) return;
     void *ptrs[] = { h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv, h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     sc_hip_plan_destroy(h->plan);
     delete h;
 }
@@ -432,7 +441,7 @@ extern "C" int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8
 {
     if (!h) return fail("kyber_cpa_enc: null handle");
     if (!h->have_pub) return fail("kyber_cpa_enc: no public key loaded");
-    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0 };
+    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0, nullptr, false };
     return ky_cpa_enc_core(h, K, batch, d_m, d_noise, noise_stride, d_u, d_v, stream);
 }
 
@@ -453,10 +462,11 @@ static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     HIPCHK(hipGetLastError());
     DilNtt a = mlwe_base_args(h->plan, k, k, 1 << 20);
     a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
-    if (mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = K.A; a.key_item_stride = K.sA; a.w = h->u0; a.w1 = nullptr;
+    if (K.nat ? mlwe_launch<DOP_KEYPREP>(h->ctx, a, B, k, s) : mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
+    a.key = K.A; a.key_item_stride = K.sA; a.w = h->u0; a.w1 = nullptr; a.key_nat = K.nat ? 2 : 0;
+    if (K.ready) HIPCHK(hipStreamWaitEvent(s, K.ready, 0));
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = K.t; a.key_item_stride = K.st; a.w = h->v0; a.kk = 1;
+    a.key = K.t; a.key_item_stride = K.st; a.w = h->v0; a.kk = 1; a.key_nat = K.nat ? 1 : 0;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     const size_t ne = batch * (size_t)(k + 1) * N;
     hipLaunchKernelGGL(ky_enc_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, h->u0, h->v0, h->e1, h->e2, d_m, B, d_u, d_v, P);
@@ -471,7 +481,7 @@ extern "C" int sc_hip_kyber_cpa_dec(sc_hip_kyber_t *h, size_t batch, const int32
 {
     if (!h) return fail("kyber_cpa_dec: null handle");
     if (!h->have_priv) return fail("kyber_cpa_dec: no private key loaded");
-    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0 };
+    const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0, nullptr, false };
     return ky_cpa_dec_core(h, K, batch, d_u, d_v, d_m, stream);
 }
 
@@ -491,8 +501,8 @@ static int ky_cpa_dec_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     HIPCHK(hipGetLastError());
     DilNtt a = mlwe_base_args(h->plan, 1, k, 1 << 20);
     a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
-    if (mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = K.s; a.key_item_stride = K.st; a.w = h->v0; a.w1 = nullptr;
+    if (K.nat ? mlwe_launch<DOP_KEYPREP>(h->ctx, a, B, k, s) : mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
+    a.key = K.s; a.key_item_stride = K.st; a.w = h->v0; a.w1 = nullptr; a.key_nat = K.nat ? 1 : 0;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(ky_dec_finish_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, s, d_v, h->v0, d_m, B, P);
     HIPCHK(hipGetLastError());
@@ -657,22 +667,27 @@ static int ky_stage_keys(sc_hip_kyber *h, size_t batch, const int32_t *d_t_ntt, 
     const KyP &P = h->P;
     const int k = P.k;
     const size_t kk = (size_t)k * k, kn = (size_t)k * N;
-    if (batch > h->keys_cap || (d_s_ntt && !h->keys_priv)) {
-        void *old[] = { h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
-        for (void *p : old) if (p) (void)sc::wipe_free(p);
-        h->pk_gen = nullptr; h->pk_A = h->pk_t = h->pk_s = nullptr; h->keys_cap = 0;
-        HIPCHK(hipMalloc((void **)&h->pk_gen, batch * kk * N * 4)); HIPCHK(hipMalloc((void **)&h->pk_A, batch * kk * N * 4));
-        HIPCHK(hipMalloc((void **)&h->pk_t, batch * kn * 4));
-        if (d_s_ntt) HIPCHK(hipMalloc((void **)&h->pk_s, batch * kn * 4));
-        h->keys_cap = batch; h->keys_priv = d_s_ntt != nullptr;
+    if (batch > h->keys_cap) {
+        if (h->pk_gen) (void)hipFree(h->pk_gen);                         // (public: the expanded matrices)
+        h->pk_gen = nullptr; h->keys_cap = 0;
+        HIPCHK(hipMalloc((void **)&h->pk_gen, batch * kk * N * 4));
+        h->keys_cap = batch;
     }
-    if (sc_hip_mlwe_expand_matrix(h->ctx, batch, d_rho, 32, 32, k * k, P.q, P.q_bits, h->pk_gen, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kk * N + 255) / 256)), dim3(256), 0, s, h->pk_gen, h->pk_A, batch * kk, h->plan->k[1], h->plan->r2, h->plan->r2p, k, k);
-    hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t_ntt, h->pk_t, batch * (size_t)k, h->plan->k[1], h->plan->r2, h->plan->r2p, 0, 0);
-    if (d_s_ntt)
-        hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_s_ntt, h->pk_s, batch * (size_t)k, h->plan->k[1], h->plan->r2, h->plan->r2p, 0, 0);
-    HIPCHK(hipGetLastError());
-    K->A = h->pk_A; K->t = h->pk_t; K->s = h->pk_s; K->sA = kk * N; K->st = kn;
+    // the matrix of every key from its rho; nothing is converted or copied: the products read the expansion's output and the key pair's own t_ntt / s_ntt
+    // arrays in place (natural order, plain form - DilNtt::key_nat)
+    // The expansion (cipher-bound, ~0.6 ms at 64 K keys) needs nothing but rho and is needed by nothing before the encryption's first product - behind
+    // the hash G(pk, m) and the noise expansion, which are chains bound by their own length: it runs on a stream of the handle's own.
+    if (!h->side) {
+        HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(h->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    if (sc_hip_mlwe_expand_matrix(h->ctx, batch, d_rho, 32, 32, k * k, P.q, P.q_bits, h->pk_gen, h->side)) return SC_HIP_FAILURE;
+    HIPCHK(hipEventRecord(h->ev_join, h->side));
+    K->A = reinterpret_cast<const uint32_t *>(h->pk_gen); K->t = reinterpret_cast<const uint32_t *>(d_t_ntt); K->s = reinterpret_cast<const uint32_t *>(d_s_ntt);
+    K->sA = kk * N; K->st = kn; K->nat = true; K->ready = h->ev_join;
     return SC_HIP_SUCCESS;
 }
 
@@ -695,7 +710,9 @@ extern "C" int sc_hip_kyber_kem_encaps_keys(sc_hip_kyber_t *h, size_t batch, con
     HIPCHK(hipSetDevice(h->ctx->device));
     KyKeys K;
     if (ky_stage_keys(h, batch, d_t_ntt, d_rho, nullptr, (hipStream_t)stream, &K)) return SC_HIP_FAILURE;
-    return ky_encaps_core(h, batch, d_m, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);
+    const int rc = ky_encaps_core(h, batch, d_m, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);
+    (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0);     // (again, in case the core returned before its first product)
+    return rc;
 }
 
 // replaces: safecrypto_decapsulation -> kyber_kem_decapsulation (kyber_kem.c:930-1040) for `batch` ciphertexts EACH under its own
@@ -709,8 +726,8 @@ extern "C" int sc_hip_kyber_kem_decaps_keys(sc_hip_kyber_t *h, size_t batch, con
     HIPCHK(hipSetDevice(h->ctx->device));
     KyKeys K;
     if (ky_stage_keys(h, batch, d_t_ntt, d_rho, d_s_ntt, (hipStream_t)stream, &K)) return SC_HIP_FAILURE;
-    const int rc = ky_decaps_core(h, batch, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);
-    (void)hipMemsetAsync(h->pk_s, 0, batch * (size_t)h->P.k * N * 4, (hipStream_t)stream);       // the staged secret keys do not outlive the call
+    const int rc = ky_decaps_core(h, batch, d_ct, ct_stride, d_keys, stream, &K, d_rho, d_t);      // (no copy of the secret keys is made: they are read in place)
+    (void)hipStreamWaitEvent((hipStream_t)stream, h->ev_join, 0);
     return rc;
 }
 

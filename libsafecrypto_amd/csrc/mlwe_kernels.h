@@ -65,8 +65,9 @@ struct DilNtt {
     const uint32_t *keyp;                 // dil_yaw_kernel only: Shoup companions floor(key 2^32 / q) of a PLAIN (non-Montgomery) matrix
     size_t key_item_stride;               // words between the matrices / key vectors of consecutive items (0: one key for the whole batch)
     const uint32_t *key_of;               // with a key stride: the key index of each slot (signing: slot -> message); null = the slot index itself
-    int key_nat;                          // DOP_MATVEC: the matrix is in NATURAL order and PLAIN form, canonical in [0, q) - as the CSPRNG expansion writes it;
-                                          // the other operand (yh) must then carry the Montgomery factor (DOP_KEYPREP's output form)
+    int key_nat;                          // DOP_MATVEC: the matrix is in NATURAL order and PLAIN form (any int32 representative) - as the CSPRNG expansion and
+                                          // the key pair hold it; the other operand (yh) must then carry the Montgomery factor (DOP_KEYPREP's output form).
+                                          // 1: polynomial (row, col) at [row][col]; 2: at [col][row] (the transposed product of encryption)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
     const int32_t *y;                     // [item][l][n] natural (mask)
     int32_t *w;                           // [item][k][n] natural canonical
@@ -137,14 +138,15 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
                 if (a.key_nat) {
                     // internal index 16 lp + r is natural index bitrev8(16 lp + r) = 16 bitrev4(r) + bitrev4(lp): the 16 lanes of a polynomial read 64
                     // contiguous bytes per load.  montmul(y R, a) = y a: a matrix that is used once per key is never converted or re-laid-out.
-                    const uint32_t *pn = a.key + (size_t)kidx * a.key_item_stride + ((size_t)sub * a.l + j) * N + (__builtin_bitreverse32((uint32_t)lp) >> 28);
+                    const size_t poly = a.key_nat == 2 ? (size_t)j * a.kk + sub : (size_t)sub * a.l + j;
+                    const uint32_t *pn = a.key + (size_t)kidx * a.key_item_stride + poly * N + (__builtin_bitreverse32((uint32_t)lp) >> 28);
                     uint32_t vy[16];
 #pragma unroll
                     for (int c = 0; c < 4; c++) { const uint4 q = py[c]; vy[4 * c] = q.x; vy[4 * c + 1] = q.y; vy[4 * c + 2] = q.z; vy[4 * c + 3] = q.w; }
 #pragma unroll
                     for (int r = 0; r < 16; r++) {
                         constexpr int BR4[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
-                        const uint32_t va = pn[BR4[r] * 16];
+                        const uint32_t va = SG ? reduce_s32((int32_t)pn[BR4[r] * 16], k) : reduce_i32((int32_t)pn[BR4[r] * 16], k);
                         if constexpr (SG) x[r] += montmul_s32(vy[r], va, k);
                         else x[r] = csub(x[r] + montmul(vy[r], va, k), k.q2);
                     }

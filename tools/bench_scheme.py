@@ -58,6 +58,14 @@ def main():
         m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
         ky.encaps(m); torch.cuda.synchronize(); made = 1
         fn = lambda: ky.encaps(m)
+    elif leg == 'kyber_encaps_keys':                      # a key pair per value (keys from the batched keygen)
+        G = load_golden('kyber_ref.txt'); B = 65536
+        ky = eng.kyber(G['kyber1_params'])
+        m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+        seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+        s_ntt, tk, t_ntt, rho, _ = ky.keygen(seeds)
+        ky.encaps_keys(tk, t_ntt, rho, m); torch.cuda.synchronize(); made = 1
+        fn = lambda: ky.encaps_keys(tk, t_ntt, rho, m)
     elif leg == 'tesla_sign':
         G = load_golden('tesla_ref.txt'); B = 16384
         ts = eng.tesla(G['tesla0_params']); ts.set_key(*(G[f'tesla0_{x}'] for x in ('a1', 'a2', 's', 'e1', 'e2', 't1', 't2')))
