@@ -44,7 +44,8 @@ struct AesLdsT {
 using AesLds = AesLdsT<1>;
 using AesLdsWide = AesLdsT<32>;
 
-__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, 32 - n); }
+__device__ __forceinline__ uint32_t x3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }      // three-way XOR in one instruction
 
 struct Aes256 {
     uint32_t rk[60];
@@ -74,10 +75,10 @@ struct Aes256 {
         uint32_t s0 = in[0] ^ rk[0], s1 = in[1] ^ rk[1], s2 = in[2] ^ rk[2], s3 = in[3] ^ rk[3];
 #pragma unroll
         for (int r = 1; r < 14; r++) {
-            const uint32_t t0 = L.t(s0 & 0xff) ^ rotl32(L.t((s1 >> 8) & 0xff), 8) ^ rotl32(L.t((s2 >> 16) & 0xff), 16) ^ rotl32(L.t(s3 >> 24), 24) ^ rk[4 * r];
-            const uint32_t t1 = L.t(s1 & 0xff) ^ rotl32(L.t((s2 >> 8) & 0xff), 8) ^ rotl32(L.t((s3 >> 16) & 0xff), 16) ^ rotl32(L.t(s0 >> 24), 24) ^ rk[4 * r + 1];
-            const uint32_t t2 = L.t(s2 & 0xff) ^ rotl32(L.t((s3 >> 8) & 0xff), 8) ^ rotl32(L.t((s0 >> 16) & 0xff), 16) ^ rotl32(L.t(s1 >> 24), 24) ^ rk[4 * r + 2];
-            const uint32_t t3 = L.t(s3 & 0xff) ^ rotl32(L.t((s0 >> 8) & 0xff), 8) ^ rotl32(L.t((s1 >> 16) & 0xff), 16) ^ rotl32(L.t(s2 >> 24), 24) ^ rk[4 * r + 3];
+            const uint32_t t0 = x3(x3(L.t(s0 & 0xff), rotl32(L.t((s1 >> 8) & 0xff), 8), rotl32(L.t((s2 >> 16) & 0xff), 16)), rotl32(L.t(s3 >> 24), 24), rk[4 * r]);
+            const uint32_t t1 = x3(x3(L.t(s1 & 0xff), rotl32(L.t((s2 >> 8) & 0xff), 8), rotl32(L.t((s3 >> 16) & 0xff), 16)), rotl32(L.t(s0 >> 24), 24), rk[4 * r + 1]);
+            const uint32_t t2 = x3(x3(L.t(s2 & 0xff), rotl32(L.t((s3 >> 8) & 0xff), 8), rotl32(L.t((s0 >> 16) & 0xff), 16)), rotl32(L.t(s1 >> 24), 24), rk[4 * r + 2]);
+            const uint32_t t3 = x3(x3(L.t(s3 & 0xff), rotl32(L.t((s0 >> 8) & 0xff), 8), rotl32(L.t((s1 >> 16) & 0xff), 16)), rotl32(L.t(s2 >> 24), 24), rk[4 * r + 3]);
             s0 = t0; s1 = t1; s2 = t2; s3 = t3;
         }
         out[0] = (L.sb(s0 & 0xff) | (L.sb((s1 >> 8) & 0xff) << 8) | (L.sb((s2 >> 16) & 0xff) << 16) | (L.sb(s3 >> 24) << 24)) ^ rk[56];
