@@ -256,6 +256,18 @@ def test_distinct_keys_from_the_reference_keygen(eng, tmp_path):
         if rc == 0:
             assert bytes(gsh[i, :glh[i]]) == sig, i
     assert int(f.verify_keys(gko, gmb, gs, gl, mlens=gml)[torch.from_numpy(gsth == 1).cuda()].sum()) == 0
+    # fixed-length messages and full tapes (no length arrays), keys interleaved so that the call regroups the batch by key: the same signatures as the
+    # same messages presented grouped by key (which are signed where they lie)
+    FB = 8 * NK + 5
+    fm = torch.from_numpy(rng.integers(0, 256, size=(FB, 48), dtype=np.uint8)).cuda()
+    ft = torch.from_numpy(rng.integers(0, 2**32, size=(FB, 4 * n), dtype=np.uint64).astype(np.uint32).view(np.int32)).cuda()
+    fk = (torch.arange(FB, device='cuda') * 5 % NK).to(torch.int32)
+    s_il, l_il, st_il = f.sign_keys(fk, fm, ft, fixed_len=48)
+    order = torch.argsort(fk.to(torch.int64), stable=True)
+    s_gr, l_gr, st_gr = f.sign_keys(fk[order].contiguous(), fm[order].contiguous(), ft[order].contiguous(), fixed_len=48)
+    assert torch.equal(st_il[order], st_gr) and torch.equal(l_il[order], l_gr) and int((st_gr == 1).sum()) >= FB - 8
+    assert torch.equal(s_il[order], s_gr)
+    assert int(f.verify_keys(fk, fm, s_il, l_il, fixed_len=48)[st_il == 1].sum()) == 0
     # the one-key calls use key 0 of the set
     s0, l0, t0 = f.sign(mb[:1], tp[:1], mlens=ml[:1])
     assert int(t0[0]) == st[0] and bytes(s0[0, :int(l0[0])].cpu().numpy()) == bytes(sh[0, :lh[0]])
