@@ -285,6 +285,19 @@ def test_distinct_keys_per_message(eng, G):
     b.set_key(fh[3], gh[3], ah[3])
     s1, l1, _, st1 = b.sign(m_d[3:4], t_d[3:4], mlens=ml_d[3:4], tape_lens=tl_d[3:4])
     assert int(st1[0]) == 1 and bytes(s1[0, :int(l1[0])].cpu().numpy()) == bytes(sh[3, :lh[3]])
+    # the same batch with the signatures entropy-coded: the coder sits behind / in front of the per-key calls as well
+    H = load_golden('bliss_huff_ref.txt')
+    tabs = O.huffman_tables(H, int(par[9]), int(par[10]))
+    b.set_entropy(tabs)
+    hs, hl, _, hst = b.sign_keys(f, g, a, m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+    assert torch.equal(hst, status)
+    hsh, hlh = hs.cpu().numpy(), hl.cpu().numpy()
+    for i in range(0, B, 5):
+        if sth[i] == 1:
+            rc, coded = O.bliss_sig_to_huffman(O.BlissKey(par, fh[i], gh[i], ah[i]), bytes(sh[i, :lh[i]]), tabs)
+            assert rc == 0 and bytes(hsh[i, :hlh[i]]) == coded, i
+    hv = b.verify_keys(a, m_d, hs, hl, mlens=ml_d)
+    assert int(hv[ok].sum()) == 0 and int((hv[~ok] == 0).sum()) == 0
     b.close()
 
 
