@@ -53,13 +53,13 @@ def main():
         if leg == 'falcon_verify':
             fn()
     elif leg == 'kyber_encaps':
-        G = load_golden('kyber_ref.txt'); B = 65536
+        G = load_golden('kyber_ref.txt'); B = int(os.environ.get("KY_B", "65536"))
         ky = eng.kyber(G['kyber1_params']); ky.set_pubkey(G['kyber1_t_ntt'], G['kyber1_Agen']); ky.set_kem_pubkey(G['kyber1_t'], G['kyber1_rho'])
         m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
         ky.encaps(m); torch.cuda.synchronize(); made = 1
         fn = lambda: ky.encaps(m)
     elif leg == 'kyber_encaps_keys':                      # a key pair per value (keys from the batched keygen)
-        G = load_golden('kyber_ref.txt'); B = 65536
+        G = load_golden('kyber_ref.txt'); B = int(os.environ.get("KY_B", "65536"))
         ky = eng.kyber(G['kyber1_params'])
         m = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
         seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
