@@ -260,6 +260,10 @@ size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *h);
 int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* how many CSPRNG words the reference has drawn from sc->prng_ctx[0] when the `attempts`-th attempt of a signature ends (prng.c:963-1048: 4n words per fresh
+ * attempt - every other one - and 1 + 27 + 26 reservoir bits per attempt, a word whenever the reservoir runs short): the tape length a signature of that many
+ * attempts needs.  Host arithmetic; no device is touched. */
+size_t sc_hip_bliss_tape_words(int n, unsigned attempts);
 /* the same with a key pair PER MESSAGE (distinct keys; 3 KB of key material per signature instead of a cache-resident set): d_f, d_g, d_a
  * SINT16 [batch][n] rows in the key pair's own layouts - what sc_hip_bliss_keygen writes (f, 2g+1, a in the NTT domain).  No key needs to be loaded. */
 int sc_hip_bliss_sign_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_f, const int16_t *d_g, const int16_t *d_a,

@@ -999,6 +999,16 @@ struct ResSim {
         for (int nreq : req) { if (vb < nreq) { const int bits = nreq - vb; lrp = pos; pos++; vb = 32 - bits; } else vb -= nreq; }
     }
 };
+// the CSPRNG words bliss_b_sign has drawn when its `attempts`-th attempt ends (what a tape must hold for a signature that takes that many): host arithmetic
+// only - the same bookkeeping that places the later pairs
+extern "C" size_t sc_hip_bliss_tape_words(int n, unsigned attempts)
+{
+    if (n <= 0) return 0;
+    ResSim sim;
+    for (unsigned k = 0; k < attempts; k++) sim.attempt((k & 1u) == 0, (uint32_t)n);
+    return sim.pos;
+}
+
 constexpr int BL_PAIRS = 4;                    // later pairs of a message evaluated side by side
 struct PairInit { uint32_t pos[BL_PAIRS], lrp[BL_PAIRS]; int32_t vb[BL_PAIRS]; };
 

@@ -107,3 +107,33 @@ def test_huffman_tables_are_prefix_codes():
         assert all(len(w) == int(b) for w, b in zip(words, bits))
         assert not any(a != b and b.startswith(a) for a in words for b in words)
         assert abs(sum(2.0 ** -len(w) for w in words) - 1.0) < 1e-12        # complete: every bit string decodes
+
+
+def test_tape_bookkeeping_of_the_library_matches_the_reference():
+    """host logic of the engine (no device): sc_hip_bliss_tape_words(n, attempts) - the reservoir bookkeeping that lets the signer place a message's later
+    pairs of attempts on its tape - equals the number of CSPRNG words the reference drew for a signature of that many attempts (the fixtures' tapes are cut
+    to exactly what safecrypto_sign consumed) and what the oracle consumes on long seeded tapes"""
+    import ctypes
+    from libsafecrypto_amd import engine
+    lib = ctypes.CDLL(engine.LIB_PATH)
+    lib.sc_hip_bliss_tape_words.argtypes = [ctypes.c_int, ctypes.c_uint]; lib.sc_hip_bliss_tape_words.restype = ctypes.c_size_t
+    seen = set()
+    for fx, tags in (('bliss_ref.txt', ('bliss1', 'bliss3', 'bliss4')), ('bliss_huff_ref.txt', ('blissh1', 'blissh4', 'blissh2'))):
+        F = load_golden(fx)
+        for tag in tags:
+            n = int(F[f'{tag}_params'][0])
+            for i, m, tape, sig, trials in cases(F, tag):
+                assert lib.sc_hip_bliss_tape_words(n, trials) == len(tape), (tag, i, trials)
+                seen.add(trials)
+    assert max(seen) >= 4 and min(seen) == 1
+    G = load_golden('bliss_ref.txt')
+    key = O.BlissKey.from_golden(G, 'bliss4')
+    rng = np.random.default_rng(3)
+    deep = 0
+    for _ in range(60):
+        tape = rng.integers(0, 2**32, size=12 * 2048 + 100, dtype=np.uint64).astype(np.uint32)
+        rc, _, tr, used = O.bliss_sign(key, bytes(rng.integers(0, 256, size=20, dtype=np.uint8)), tape)
+        assert rc == 0 and lib.sc_hip_bliss_tape_words(key.n, tr) == used
+        deep += tr >= 3
+    assert deep >= 5
+    assert lib.sc_hip_bliss_tape_words(512, 0) == 0 and lib.sc_hip_bliss_tape_words(0, 3) == 0
