@@ -24,6 +24,10 @@
  *     concurrently.  A scheme handle (sc_hip_dilithium_t, _bliss_t, _tesla_t, _kyber_t, _falcon_t, _rlwe_t, _ens_t, _dlp_t) owns the
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
+ *   - a batched call may run parts of its work on streams of the handle's own beside the caller's (the calls with a key per item do: independent
+ *     per-key chains, forked and joined by events inside the call); everything it does is ordered after what the caller queued on `stream`
+ *     before the call and before what the caller queues after it, as if it ran on `stream` alone.  Rejection loops (sign calls) read one
+ *     4-byte counter per round back to the host, so those calls return with most of their work done
  *   - device memory that held key material, masks, noise or CSPRNG output is zeroed before it is freed, and the per-call secrets of
  *     sign / decapsulate / encrypt calls are zeroed on the call's stream behind its kernels (the reference zeroes sc->temp the same way)
  */
