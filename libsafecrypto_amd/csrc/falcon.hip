@@ -1955,8 +1955,8 @@ __global__ void fal_key_hist_kernel(uint32_t batch, const uint32_t *__restrict__
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch) { const uint32_t k = key_of[i]; atomicAdd(&hist[k < nkeys ? k : nkeys], 1u); }       // bucket nkeys: indices outside the key set (status 6 later)
 }
-// one workgroup: cursor[k] = first position of key k.  Every key's run starts on a multiple of 8 (the gaps are filled with repeats of neighbours' items - no:
-// they stay holes and are not signed): a run that straddled two workgroups would send both to the slow kernel.
+// one workgroup: cursor[k] = first position of key k.  Every key's run is padded to a multiple of 8 positions, so that it starts on a workgroup boundary
+// (a run that straddled two workgroups would send both to the slow kernel); the padding positions stay holes and are not signed.
 __global__ __launch_bounds__(1024) void fal_key_scan_kernel(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ cursor, uint32_t *__restrict__ total)
 {
     __shared__ uint32_t part[1024];
