@@ -1012,10 +1012,14 @@ extern "C" size_t sc_hip_bliss_tape_words(int n, unsigned attempts)
 constexpr int BL_PAIRS = 4;                    // later pairs of a message evaluated side by side
 struct PairInit { uint32_t pos[BL_PAIRS], lrp[BL_PAIRS]; int32_t vb[BL_PAIRS]; };
 
-__global__ void bl_collect_kernel(const uint32_t *status, uint32_t count, uint32_t want, uint32_t *list, uint32_t *cnt)
+// the messages that go on to their later pairs (status 7 -> list7, cnt[0]) and the ones to be redone in order (status 8 -> list8, cnt[1]): one pass, one read-back
+__global__ void bl_collect_kernel(const uint32_t *status, uint32_t count, uint32_t *list7, uint32_t *list8, uint32_t *cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count && status[i] == want) list[atomicAdd(cnt, 1u)] = i;
+    if (i >= count) return;
+    const uint32_t st = status[i];
+    if (st == 7) list7[atomicAdd(&cnt[0], 1u)] = i;
+    else if (st == 8) list8[atomicAdd(&cnt[1], 1u)] = i;
 }
 // item j * pp + k = pair p0 + k of message list[j]
 __global__ void bl_pair_init_kernel(const uint32_t *list, uint32_t nu, uint32_t pp, PairInit pi, St v, uint32_t *msg_of, const uint32_t *tapes, size_t tape_stride,
@@ -1113,13 +1117,16 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         ResSim sim;
         sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);                 // pair 0 is behind us
         uint32_t *ulist = b->act[0];                                  // (the round loop is idle here: its two lists are free)
+        uint32_t n8 = 0;
         for (uint32_t p0 = 1;; ) {
             if (p0 > 50000) return fail("bliss_sign: rejection loop did not terminate");
-            uint32_t nu = 0;
-            HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
-            hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, 7u, ulist, b->cnt);
-            HIPCHK(hipMemcpyAsync(&nu, b->cnt, 4, hipMemcpyDeviceToHost, s));
+            uint32_t both[2] = { 0, 0 };
+            HIPCHK(hipMemsetAsync(b->cnt, 0, 8, s));
+            hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, ulist, b->act[1], b->cnt);
+            HIPCHK(hipMemcpyAsync(both, b->cnt, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            const uint32_t nu = both[0];
+            n8 = both[1];                                             // (status 8 stays: the last pass, the one that finds no 7, leaves the whole list in act[1])
             if (nu == 0) break;
             uint32_t pp = BL_PAIRS;
             while (pp > 1 && (size_t)nu * pp > batch) pp >>= 1;       // the per-round arrays are sized for the batch
@@ -1140,11 +1147,6 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             p0 += pp;
         }
         // messages an oracle failure threw off the precomputed tape positions: from the start, in order
-        uint32_t n8 = 0;
-        HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
-        hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, 8u, b->act[1], b->cnt);
-        HIPCHK(hipMemcpyAsync(&n8, b->cnt, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
         if (n8) {
             uint32_t *redo = b->act[1];                                // (the round loop's first round reads this list and writes act[0]; later rounds alternate)
             hipLaunchKernelGGL(bl_reset_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, redo, n8, st);
