@@ -16,9 +16,12 @@ time and the gather of the per-rank scheme rates.  The scheme-level legs (BASELI
 sign / verify, BLISS-B-I sign, Falcon-1024 sign) run on every rank as well and are reported per GPU and summed.
 
 `roofline` blocks: the headline's is HBM (algorithmic bytes / HIP-event kernel time / 8 TB/s, at the BASELINE size and at a working
-set far past the 256 MiB Infinity Cache); the scheme legs' are VALU (wave-level VALU instructions per operation, counted by rocprofv3
---pmc SQ_INSTS_VALU and committed in profiles/r02_scheme_pmc.json, x the operations per second measured live, against the chip's
-614 G wave-instructions/s integer issue rate) with the measured HBM bytes per operation beside the algorithmic ones.
+set far past the 256 MiB Infinity Cache); the scheme legs' are VALU: wave-level VALU instructions and HBM bytes per operation counted by
+rocprofv3 --pmc over the SAME leg in a child process of this run (tools/pmc_leg.py; the verify legs load signatures made by a separate
+process, so no signing kernel is in their counts), x the operations per second measured here, against the chip's issue ceiling of one
+wave64 instruction per 2 cycles per SIMD (1228.8 G wave-instr/s at 2.4 GHz - the guide's 157.3 TF vector peak; tools/exp_valu_cycles.hip
+measured which instructions reach it and which take 4 cycles: profiles/r03_valu_issue_cycles.txt).  No `frac` may exceed 1 (asserted).
+The north-star figures (Dilithium-III, BLISS-B-I, Falcon-1024) are repeated compactly under `north_star`, the LAST key of the line.
 """
 import argparse
 import json
@@ -39,8 +42,13 @@ sys.path.insert(0, ROOT)
 Q, N, BATCH = 7681, 256, 65536
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 BYTES_PER_TRIPLE = 12 * N        # read a (4n) + read bhat (4n) + write c (4n)  
-# integer VALU issue: one wave64 instruction per 4 cycles per SIMD (profiles/r01_int_valu_rates.txt: 33 T lane-ops/s measured, 39 T at 2.4 GHz)
-VALU_PEAK_GWI = 256 * 4 * 2.4 / 4.0          # G wave-instructions / s, chip-wide
+# VALU issue ceiling, chip-wide, in G wave-instructions / s (profiles/r03_valu_issue_cycles.txt, measured with s_memtime on this part):
+#   2 cycles per wave64 instruction per SIMD for v_add / v_sub / v_xor / v_and / v_bitop3 / v_fma_f32 ... (2.24-2.5 measured at >= 2 waves per SIMD),
+#   4 cycles for multiplies, v_alignbit, v_min / v_max, v_mad, 64-bit and packed operations (4.2 measured); one wave alone: 5-6 cycles either way.
+# `peak` is the 2-cycle ceiling (what MI355X_MICROARCH.md's 157.3 TF vector peak implies), so every VALU `frac` is a lower bound of the issue
+# utilisation of a kernel that mixes both classes; `frac_4cycle_ceiling` is the same figure against the other class's ceiling.
+VALU_PEAK_GWI = 256 * 4 * 2.4 / 2.0
+VALU_PEAK_GWI_4CYC = 256 * 4 * 2.4 / 4.0
 PAST_L3_BATCH = 1 << 20          # 3 x 1 GiB of operands: 12x the Infinity Cache
 
 DRV = os.path.join(ROOT, 'oracle', '_ref', 'ref_driver')
@@ -134,33 +142,71 @@ def _cpu_ref(mode, set_, sec, keys, sample):
         return None
 
 
-_PMC = None
+_PMC_COMMITTED = None
+PMC_LIVE = True                  # --no-live-pmc: use the committed counts (profiles/r03_scheme_pmc.json) instead of profiling the legs in this run
+PMC_BUDGET_S = 240.0             # the counter passes (3 child processes per leg) stop being started once this much has been spent on them
+_pmc_spent = 0.0
 
 
 def _pmc(leg):
-    global _PMC
-    if _PMC is None:
+    """counters of one leg: live (a child process of this run under rocprofv3 --pmc), else the committed pass of the same tool"""
+    global _PMC_COMMITTED, _pmc_spent
+    if PMC_LIVE and _pmc_spent < PMC_BUDGET_S:
         try:
-            _PMC = json.load(open(os.path.join(ROOT, 'profiles', 'r02_scheme_pmc.json')))
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            import pmc_leg
+            t0 = time.perf_counter()
+            r = pmc_leg.profile_leg(leg, calls=2)
+            _pmc_spent += time.perf_counter() - t0
+            if r.get('ok'):
+                r['source'] = 'live: ' + r.pop('method')
+                return r
+            sys.stderr.write(f'live PMC pass of {leg} failed: {r.get("error")}\n')
+        except Exception as e:
+            sys.stderr.write(f'live PMC pass of {leg} failed: {e}\n')
+    if _PMC_COMMITTED is None:
+        try:
+            _PMC_COMMITTED = json.load(open(os.path.join(ROOT, 'profiles', 'r03_scheme_pmc.json')))
         except Exception:
-            _PMC = {}
-    return _PMC.get(leg)
+            _PMC_COMMITTED = {}
+    r = _PMC_COMMITTED.get(leg)
+    if r:
+        r = dict(r)
+        r['source'] = 'committed: profiles/r03_scheme_pmc.json (tools/pmc_leg.py run by tools/prof_schemes_r3.sh on an earlier box) - NOT this run'
+    return r
 
 
-def valu_roofline(leg, ops_per_s, algorithmic_bytes_per_op, note):
-    """VALU roofline of a scheme leg: instructions per operation from the committed PMC pass x the rate measured now"""
+def valu_roofline(leg, ops_per_s, algorithmic_bytes_per_op, note, top=4):
+    """VALU roofline of a scheme leg: instructions and HBM bytes per operation from a counter pass over the same leg x the rate measured now"""
     p = _pmc(leg)
     if not p:
         return {'bound': 'valu', 'achieved': None, 'peak': VALU_PEAK_GWI, 'unit': 'G wave-instr/s', 'frac': None, 'traffic': None,
-                'note': 'profiles/r02_scheme_pmc.json has no entry for this leg'}
+                'note': 'no counter pass for this leg (rocprofv3 unavailable and no committed profile)'}
     wi = p['valu_wave_instructions_per_op']
     ach = wi * ops_per_s / 1e9
+    kern = {}
+    for name, k in list(p.get('kernels', {}).items())[:top]:
+        kern[name] = {'share_of_kernel_cycles': k['shader_cycles_per_call'] / p['shader_cycles_per_call_sum_of_kernels'],
+                      'valu_instr_per_simd_cycle': k['valu_instr_per_simd_cycle'], 'wave_cycles_waiting_frac': k['wave_cycles_waiting_frac'],
+                      'launches_per_call': k['launches_per_call']}
     return {'bound': 'valu', 'achieved': ach, 'peak': VALU_PEAK_GWI, 'unit': 'G wave-instr/s', 'frac': ach / VALU_PEAK_GWI,
+            'frac_4cycle_ceiling': ach / VALU_PEAK_GWI_4CYC,
             'traffic': p['hbm_bytes_per_op_2xfetch_plus_write'], 'traffic_unit': 'HBM bytes per operation (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE)',
             'algorithmic_bytes_per_op': algorithmic_bytes_per_op, 'valu_wave_instructions_per_op': wi,
+            'valu_instr_per_simd_cycle_in_kernels': p.get('valu_instr_per_simd_cycle'),
+            'valu_instr_per_simd_cycle_ceilings': {'2_cycle_class': 0.5, '4_cycle_class': 0.25, 'measured': 'profiles/r03_valu_issue_cycles.txt: 0.40-0.43 / 0.235'},
             'hbm_GBs_at_this_rate': p['hbm_bytes_per_op_2xfetch_plus_write'] * ops_per_s / 1e9,
-            'source': 'profiles/r02_scheme_pmc.json (rocprofv3 --pmc SQ_INSTS_VALU | FETCH_SIZE | WRITE_SIZE, separate passes) x ops/s measured in this run',
-            'note': note}
+            'dominant_kernels': kern, 'source': p.get('source'), 'note': note}
+
+
+def _timed(torch, fn, reps):
+    """(best host seconds, best HIP-event milliseconds on the current stream) of fn() + synchronize"""
+    th, te = [], []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record(); out = fn(); e1.record(); torch.cuda.synchronize(); th.append(time.perf_counter() - t0)
+        te.append(e0.elapsed_time(e1))
+    return min(th), min(te), out
 
 
 def dilithium_extra(eng, torch, cpu_seconds, distinct=True):
@@ -177,14 +223,13 @@ def dilithium_extra(eng, torch, cpu_seconds, distinct=True):
     msgs = torch.randint(0, 256, (batch, 64), dtype=torch.uint8, device='cuda', generator=g)
     sigs, siglens, trials = d.sign(msgs, fixed_len=64)
     torch.cuda.synchronize()
-    ts, tv = [], []
-    for _ in range(5):
-        t0 = time.perf_counter(); sigs, siglens, trials = d.sign(msgs, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        t0 = time.perf_counter(); v = d.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+    ts, ts_ev, (sigs, siglens, trials) = _timed(torch, lambda: d.sign(msgs, fixed_len=64), 5)
+    tv, tv_ev, v = _timed(torch, lambda: d.verify(msgs, sigs, siglens, fixed_len=64), 5)
     assert int(v.sum()) == 0, 'bench signatures failed verification'
     out = {'workload': 'BASELINE configs[2]: Dilithium-III (n=256, q=8380417, k=6, l=5) sign + verify, batch 16384, 64-byte messages, one key',
-           'sign_ops_per_s': batch / min(ts), 'verify_ops_per_s': batch / min(tv), 'sign_ms_per_batch': min(ts) * 1e3,
-           'verify_ms_per_batch': min(tv) * 1e3, 'mean_attempts_per_signature': float(trials.float().mean()), 'dtype': 'u32'}
+           'sign_ops_per_s': batch / ts, 'verify_ops_per_s': batch / tv, 'sign_ms_per_batch': ts * 1e3, 'verify_ms_per_batch': tv * 1e3,
+           'sign_ms_hip_events': ts_ev, 'verify_ms_hip_events': tv_ev,
+           'mean_attempts_per_signature': float(trials.float().mean()), 'dtype': 'u32'}
     out['roofline'] = valu_roofline('dil_sign', out['sign_ops_per_s'], 64 + 3370,
                                     'sign: 64 B message in + 3370 B signature out per operation; the work is ~3.2 attempts of 35 Keccak permutations, 11 transforms and 30 '
                                     'pointwise products each - instruction-bound, not HBM-bound')
@@ -240,13 +285,11 @@ def falcon_extra(eng, torch, cpu_seconds, sets=(('falcon2', 2, (8192, 131072)), 
             msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
             tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
             f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
-            ts, tv = [], []
-            for _ in range(3):
-                t0 = time.perf_counter(); sigs, siglens, status = f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-                t0 = time.perf_counter(); v = f.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+            ts, ts_ev, (sigs, siglens, status) = _timed(torch, lambda: f.sign(msgs, tapes, fixed_len=64), 3)
+            tv, tv_ev, v = _timed(torch, lambda: f.verify(msgs, sigs, siglens, fixed_len=64), 3)
             ok = status == 1
             assert int(v[ok].sum()) == 0 and int(ok.sum()) > B - B // 100
-            res[f'batch_{B}'] = {'sign_ops_per_s': B / min(ts), 'verify_ops_per_s': B / min(tv), 'sign_ms_per_batch': min(ts) * 1e3}
+            res[f'batch_{B}'] = {'sign_ops_per_s': B / ts, 'verify_ops_per_s': B / tv, 'sign_ms_per_batch': ts * 1e3, 'sign_ms_hip_events': ts_ev, 'verify_ms_hip_events': tv_ev}
             del msgs, tapes, sigs
         ref = _cpu_ref('bench_falcon', set_, min(cpu_seconds, 4.0), {'sign_ops_per_s': 'sign_per_sec', 'verify_ops_per_s': 'verify_per_sec'},
                        f'{min(cpu_seconds, 4.0):.0f} s of safecrypto_sign + safecrypto_verify, set {set_}, 64-byte messages, one key, 1 thread')
@@ -297,18 +340,18 @@ def bliss_extra(eng, torch, cpu_seconds):
     msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
     tapes = torch.randint(-2**31, 2**31 - 1, (B, W), dtype=torch.int32, device='cuda', generator=g)
     b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
-    ts, tv = [], []
-    for _ in range(5):
-        t0 = time.perf_counter(); sigs, siglens, trials, status = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        t0 = time.perf_counter(); v = b.verify(msgs, sigs, siglens, fixed_len=64); torch.cuda.synchronize(); tv.append(time.perf_counter() - t0)
+    ts, ts_ev, (sigs, siglens, trials, status) = _timed(torch, lambda: b.sign(msgs, tapes, fixed_len=64), 5)
+    tv, tv_ev, v = _timed(torch, lambda: b.verify(msgs, sigs, siglens, fixed_len=64), 5)
     ok = status == 1
     assert int(v[ok].sum()) == 0 and int(ok.sum()) > B - 20
     attempts = float(trials[ok].float().mean())
     out = {'workload': 'BASELINE configs[3]: BLISS-B-I (n=512, q=12289) sign with the CDT sampler on the GPU, batch 16384, 64-byte messages, '
-                       'per-message CSPRNG word tapes resident in HBM', 'sign_ops_per_s': B / min(ts), 'verify_ops_per_s': B / min(tv),
+                       'per-message CSPRNG word tapes resident in HBM', 'sign_ops_per_s': B / ts, 'verify_ops_per_s': B / tv,
+           'sign_ms_hip_events': ts_ev, 'verify_ms_hip_events': tv_ev,
            'mean_attempts_per_signature': attempts, 'undecided_near_ties': int((status == 5).sum()), 'dtype': 'u32'}
     out['roofline'] = valu_roofline('bliss_sign', out['sign_ops_per_s'], 64 + 986 + 8 * 1024 * (attempts + 1) / 2,
                                     'per signature: 64 B message + 986 B signature + 8 KB of uniform words per fresh pair of Gaussian vectors (12 B per sample in the sampler kernel)')
+    out['roofline_verify'] = valu_roofline('bliss_verify', out['verify_ops_per_s'], 64 + 986 + 1, 'verify: message + signature in, one verdict out')
     ref = _cpu_ref('bench_bliss', 1, min(cpu_seconds, 3.0), {'sign_ops_per_s': 'sign_per_sec', 'verify_ops_per_s': 'verify_per_sec'},
                    f'{min(cpu_seconds, 3.0):.0f} s of safecrypto_sign + safecrypto_verify, set 1 (64-bit CDT), 64-byte messages, one key, 1 thread')
     if ref:
@@ -535,6 +578,43 @@ def cdt_extra(eng, torch):
             'algorithmic_bytes_per_sample': 12, **out}
 
 
+def north_star_summary(extra):
+    """BASELINE configs[2..4] in a few hundred bytes each (the full blocks are under `extra`)"""
+    def rl(b):
+        if not b:
+            return None
+        return {k: b.get(k) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_4cycle_ceiling', 'traffic', 'algorithmic_bytes_per_op', 'valu_wave_instructions_per_op')} | \
+               {'counters': 'live' if str(b.get('source', '')).startswith('live') else 'committed'}
+    out = {}
+    d = extra.get('dilithium3')
+    if d and 'sign_ops_per_s' in d:
+        out['dilithium3_b16384'] = {'sign_ops_per_s': d['sign_ops_per_s'], 'verify_ops_per_s': d['verify_ops_per_s'], 'sign_ms_hip_events': d.get('sign_ms_hip_events'),
+                                    'verify_ms_hip_events': d.get('verify_ms_hip_events'),
+                                    'cpu_thread_sign_ops_per_s': (d.get('cpu_reference') or {}).get('sign_ops_per_s'), 'cpu_thread_verify_ops_per_s': (d.get('cpu_reference') or {}).get('verify_ops_per_s'),
+                                    'sign_speedup_vs_cpu_thread': d.get('sign_speedup_vs_cpu_thread'), 'distinct_keys_sign_ops_per_s': (d.get('distinct_keys') or {}).get('sign_ops_per_s'),
+                                    'distinct_keys_verify_ops_per_s': (d.get('distinct_keys') or {}).get('verify_ops_per_s'),
+                                    'roofline_sign': rl(d.get('roofline')), 'roofline_verify': rl(d.get('roofline_verify'))}
+    b = extra.get('bliss_b_1')
+    if b and 'sign_ops_per_s' in b:
+        out['bliss_b_1_b16384'] = {'sign_ops_per_s': b['sign_ops_per_s'], 'verify_ops_per_s': b['verify_ops_per_s'], 'sign_ms_hip_events': b.get('sign_ms_hip_events'),
+                                   'cpu_thread_sign_ops_per_s': (b.get('cpu_reference') or {}).get('sign_ops_per_s'), 'roofline_sign': rl(b.get('roofline'))}
+    f = extra.get('falcon_1024')
+    if f and 'batch_8192' in f:
+        out['falcon_1024_b8192'] = {'sign_ops_per_s': f['batch_8192']['sign_ops_per_s'], 'verify_ops_per_s': f['batch_8192']['verify_ops_per_s'],
+                                    'sign_ms_hip_events': f['batch_8192'].get('sign_ms_hip_events'),
+                                    'cpu_thread_sign_ops_per_s': (f.get('cpu_reference') or {}).get('sign_ops_per_s'), 'roofline_sign': rl(f.get('roofline'))}
+    return out
+
+
+def check_fracs(node, path='line'):
+    """no roofline fraction anywhere in the line may exceed 1 (a 1.23 went out unnoticed)"""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if k.startswith('frac') and isinstance(v, (int, float)) and k != 'frac_4cycle_ceiling':
+                assert 0.0 <= v <= 1.0, f'{path}.{k} = {v}: a roofline fraction above 1 means the numerator or the peak is wrong'
+            check_fracs(v, path + '.' + k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -543,13 +623,16 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the contract line (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--no-live-pmc', action='store_true', help='scheme rooflines from the committed counter pass instead of rocprofv3 child processes of this run')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
+    global PMC_LIVE
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
+    PMC_LIVE = not args.no_live_pmc and world == 1
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
@@ -697,6 +780,8 @@ def main():
                 res['extra']['kyber_tesla_more'] = {'error': str(e)}
         if cpu_on:
             res['cpu_baseline'] = cpu_baseline(args.cpu_seconds)
+        res['north_star'] = north_star_summary(res['extra'])          # LAST key: the driver keeps the tail of the line
+        check_fracs(res)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

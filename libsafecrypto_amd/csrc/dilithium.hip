@@ -30,6 +30,9 @@ using namespace sc_mlwe;
 namespace {
 
 constexpr int HT = 64;                    // threads per workgroup of the one-thread-per-message kernels
+constexpr int EXP_T = 64;                 // ExpandMask (state in registers).  Measured: 256-thread workgroups (a wavefront per SIMD of a CU) are SLOWER - 400 against 375 us at 49152
+                                          // attempts, 361 against 298 us at 12800 - a lone wavefront wants a CU to itself
+constexpr int CH_T = 64;                  // challenge hash (128: 182 against 126 us at 49152 attempts)
 
 struct DilP {                             // dilithium_set_t (dilithium_params.h:60-93), the fields used here
     int32_t n, q, q_bits, k, l, d, weight, gamma1, gamma1_bits, gamma2, eta, z_bits, beta, omega, omega_bits, set;
@@ -134,85 +137,161 @@ __global__ void dil_kg_t_kernel(const int32_t *as1, const int32_t *s2, int32_t *
     t1[i] = (v - x) >> d;
 }
 
-// y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244)
-__global__ __launch_bounds__(HT) void dil_expand_kernel(const uint32_t *slot_item, const uint32_t *slot_kappa, uint32_t nslots, const uint8_t *K,
-                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride = 0)
+// The signer's round state lives on the device: rs[0] = messages still unsigned, rs[1] = attempts per message this round ("slots" per
+// message), rs[2] = rs[0] * rs[1].  Written by dil_round_kernel at the head of a round from the count the previous round's last kernel left,
+// so a signing call queues its rounds back to back without a host read-back between them.
+enum { RS_NACT = 0, RS_S = 1, RS_NSLOTS = 2 };
+
+__global__ void dil_round_kernel(uint32_t *rs, uint32_t *next_count, uint32_t first_nact, uint32_t slot_cap, uint32_t s_max)
 {
-    __shared__ uint64_t st[25 * HT];
-    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
-    Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
-    if (aidx >= nslots) return;
-    sp.absorb(mu + (size_t)slot_item[aidx] * 48, 48);
-    sp.absorb(K + (size_t)slot_item[aidx] * K_stride, 32);      // K_stride = 32: a key per message
-    const uint32_t kp = slot_kappa[aidx] & 0xFFFFu;            // UINT16 kappa (dilithium.c:1421)
-    sp.absorb_byte((uint8_t)(kp >> 8)); sp.absorb_byte((uint8_t)(kp & 0xFF));
-    sp.finalize();
+    if (threadIdx.x | blockIdx.x) return;
+    const uint32_t nact = first_nact ? first_nact : *next_count;
+    uint32_t S = nact ? slot_cap / nact : 0;
+    if (S > s_max) S = s_max;
+    if (nact && S < 1) S = 1;
+    rs[RS_NACT] = nact; rs[RS_S] = S; rs[RS_NSLOTS] = nact * S;
+    *next_count = 0;
+}
+
+// y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244): SHAKE256(mu || K || kappa_hi || kappa_lo) -> 20-bit fields, rejection below 2 gamma_1 - 2.
+// One lane per attempt.  The input is 82 bytes - one block - and the squeeze walks whole blocks, so the sponge needs no dynamic addressing:
+// the state stays in registers from beginning to end (no LDS round trip per permutation, no LDS limit on residency).
+__global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, const uint32_t *active, const uint32_t *kappa, const uint8_t *K,
+                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride, uint32_t *slot_item)
+{
+    const uint32_t aidx = blockIdx.x * EXP_T + threadIdx.x;
+    const uint32_t S = rs[RS_S];
+    if (aidx >= rs[RS_NSLOTS]) return;
+    // slot aidx = (message index in the round's list) * S + attempt: message active[aidx / S], kappa = the message's base + aidx % S
+    const uint32_t item = active ? active[aidx / S] : aidx / S;
+    slot_item[aidx] = item;
+    const uint32_t kp = (kappa[item] + aidx % S) & 0xFFFFu;            // UINT16 kappa (dilithium.c:1421)
+    uint64_t s[25];
+    const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)item * 48);     // the workspace's own array: aligned
+    const uint8_t *kb = K + (size_t)item * K_stride;                   // K_stride = 32: a key per message (the caller's buffer: any alignment)
+#pragma unroll
+    for (int w = 0; w < 6; w++) s[w] = m8[w];
+    if ((reinterpret_cast<uintptr_t>(kb) & 7) == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) s[6 + w] = reinterpret_cast<const uint64_t *>(kb)[w];
+    } else {
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v |= (uint64_t)kb[8 * w + b] << (8 * b);
+            s[6 + w] = v;
+        }
+    }
+    s[10] = (uint64_t)(kp >> 8) | ((uint64_t)(kp & 0xFF) << 8) | (0x1Full << 16);     // kappa high byte first, then the SHAKE pad
+#pragma unroll
+    for (int w = 11; w < 25; w++) s[w] = 0;
+    s[16] ^= 0x80ull << 56;                                              // rate 136: last byte of word 16
+    keccak_permute_regs<false>(s);
     const uint32_t thresh = (uint32_t)(2 * gamma1 - 2);
     const int32_t add = q + gamma1 - 1;
     int32_t *yy = y + (size_t)aidx * limit;
     // The 5-byte groups of the reference (two 20-bit samples: b0 | b1<<8 | (b2&15)<<16 and b2>>4 | b3<<4 | b4<<12, module_lwe.c:218-236)
-    // are consecutive 20-bit fields of the squeezed stream read as a little-endian bit string.  The 17 words of a block are
-    // taken from the state in one go and fed through a bit buffer 32 bits at a time - no per-byte LDS round trip.
-    int j = 0;
+    // are consecutive 20-bit fields of the squeezed stream read as a little-endian bit string.
+    int j = 0;                                                          // limit = l n: a multiple of 4
+    int32_t q0 = 0, q1 = 0, q2 = 0;
     uint64_t buf = 0; int nb = 0;
     while (j < limit) {
-        uint64_t blk[17];
-#pragma unroll
-        for (int w = 0; w < 17; w++) blk[w] = sp.st[w * HT];
 #pragma unroll
         for (int w = 0; w < 17; w++) {
 #pragma unroll
             for (int hlf = 0; hlf < 2; hlf++) {
-                buf |= (uint64_t)(uint32_t)(blk[w] >> (32 * hlf)) << nb; nb += 32;
+                buf |= (uint64_t)(uint32_t)(s[w] >> (32 * hlf)) << nb; nb += 32;
                 while (nb >= 20) {
                     const uint32_t smp = (uint32_t)buf & 0xFFFFFu;
                     buf >>= 20; nb -= 20;
-                    if (smp < thresh && j < limit) yy[j++] = add - (int32_t)smp;
+                    // a lane's samples leave four at a time: every lane of a store instruction writes to a line of its own, and a 4-byte piece of it
+                    // costs the memory system as much as a 16-byte one
+                    if (smp < thresh && j < limit) {
+                        const int32_t v = add - (int32_t)smp;
+                        const int e = j & 3;
+                        q0 = e == 0 ? v : q0; q1 = e == 1 ? v : q1; q2 = e == 2 ? v : q2;
+                        if (e == 3) *reinterpret_cast<int4 *>(yy + (j & ~3)) = make_int4(q0, q1, q2, v);
+                        j++;
+                    }
                 }
             }
         }
-        if (j < limit) sp.permute();
+        if (j < limit) keccak_permute_regs<false>(s);
     }
 }
 
 // c = H(mu, w1): SHAKE128 -> 8 sign bytes + 60 position bytes -> kyber_oracle_core
-// (dilithium.c:1011-1036, module_lwe.c:1115-1141).  mode 0: write c; mode 1 (verify): compare with the signature's c.
-__global__ __launch_bounds__(HT) void dil_challenge_kernel(const uint32_t *slot_item, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
-                                                           int w1len, int weight, int32_t *c, int mode, uint32_t *verdict)
+// (dilithium.c:1011-1036, module_lwe.c:1115-1141).  SIGN: one lane per attempt of the round (count from the round state), c written as n signed
+// bytes per attempt; !SIGN (verify): one lane per signature, compared with the signature's c.
+// The hash input mu || w1 is 6 + 32 k whole 64-bit words: it is absorbed 21 words (one SHAKE128 block) at a time with the state in registers, and the
+// next block's words are requested before the current block is permuted - a lane walks its own 1.5 KB of w1, and a sponge that fetched word by
+// word paid the latency of every one of those loads in sequence.  Only the 72 output bytes are addressed dynamically (through LDS).
+template <bool SIGN>
+__global__ __launch_bounds__(CH_T) void dil_challenge_kernel(const uint32_t *rs, const uint32_t *slot_item, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
+                                                           int w1len, int weight, int8_t *c8, const int32_t *c32, uint32_t *verdict)
 {
-    __shared__ uint64_t st[25 * HT];
-    __shared__ int8_t cc[HT * N];
-    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
-    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    __shared__ uint64_t ob[9 * CH_T];
+    __shared__ int8_t cc[CH_T * N];
+    const uint32_t aidx = blockIdx.x * CH_T + threadIdx.x;
+    if (SIGN) nact = rs[RS_NSLOTS];
+    if (blockIdx.x * CH_T >= nact) return;                                       // (whole workgroup)
     const bool valid = aidx < nact;
     const uint32_t item = valid ? aidx : 0;                                    // slot: index of w1 / c
     const uint32_t mitem = valid ? (slot_item ? slot_item[aidx] : aidx) : 0;   // message: index of mu
-    int8_t *mine = cc + threadIdx.x;          // per-lane private column: coefficient i at mine[i*HT] (no systematic bank conflict)
+    const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)mitem * 48), *w8 = reinterpret_cast<const uint64_t *>(w1 + (size_t)item * w1len);
+    const int total = 6 + w1len / 8;                                           // words of input
+    auto word = [&](int gi) -> uint64_t {                                      // unconditional loads (a guarded one is a branch with a wait inside)
+        const int ci = gi < total ? gi : total - 1;
+        const uint64_t v = ci < 6 ? m8[ci] : w8[ci - 6];
+        return gi < total ? v : 0;
+    };
+    uint64_t s[25], cur[21];
+#pragma unroll
+    for (int w = 0; w < 25; w++) s[w] = 0;
+#pragma unroll
+    for (int w = 0; w < 21; w++) cur[w] = word(w);
+    int base = 0;
+    for (; base + 21 <= total; base += 21) {
+        uint64_t nxt[21];
+#pragma unroll
+        for (int w = 0; w < 21; w++) nxt[w] = word(base + 21 + w);
+#pragma unroll
+        for (int w = 0; w < 21; w++) s[w] ^= cur[w];
+        keccak_permute_regs<false>(s);
+#pragma unroll
+        for (int w = 0; w < 21; w++) cur[w] = nxt[w];
+    }
+    const int rem = total - base;                                              // 0..20 words of the last block, then the pad
+#pragma unroll
+    for (int w = 0; w < 21; w++) { s[w] ^= cur[w]; if (w == rem) s[w] ^= 0x1F; }
+    s[20] ^= 0x80ull << 56;
+    keccak_permute_regs<false>(s);
+#pragma unroll
+    for (int w = 0; w < 9; w++) ob[w * CH_T + threadIdx.x] = s[w];
+    auto out_byte = [&](int i) -> uint32_t { return (uint32_t)(ob[(i >> 3) * CH_T + threadIdx.x] >> (8 * (i & 7))) & 0xFFu; };
+    int8_t *mine = cc + threadIdx.x;          // per-lane private column: coefficient i at mine[i*CH_T] (no systematic bank conflict)
     if (valid) {
-        sp.absorb(mu + (size_t)mitem * 48, 48);
-        sp.absorb(w1 + (size_t)item * w1len, (size_t)w1len);
-        sp.finalize();
         const int nwb = (weight + 7) >> 3;
-        uint8_t signs[16];
-        for (int i = 0; i < nwb; i++) signs[i] = sp.squeeze_byte();
-        for (int i = 0; i < N; i++) mine[i * HT] = 0;
+        for (int i = 0; i < N; i++) mine[i * CH_T] = 0;
+        int pos = nwb;
         uint32_t sj = 0, mask = 1;
         for (int i = N - weight; i < N; i++) {
-            uint32_t b = sp.squeeze_byte();
+            uint32_t b = out_byte(pos++);
             while (b > (uint32_t)i) b >>= 1;
-            mine[i * HT] = mine[b * HT];
-            uint8_t sgn = 0;
-#pragma unroll
-            for (int t = 0; t < 16; t++) if ((uint32_t)t == sj) sgn = signs[t];
-            mine[b * HT] = (sgn & mask) ? -1 : 1;
+            mine[i * CH_T] = mine[b * CH_T];
+            mine[b * CH_T] = (out_byte((int)sj) & mask) ? -1 : 1;
             mask <<= 1;
             if (mask == 256) { mask = 1; sj++; }
         }
-        if (mode == 0) {
-            for (int i = 0; i < N; i++) c[(size_t)item * N + i] = mine[i * HT];
+        if (SIGN) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(c8 + (size_t)item * N);
+            for (int i = 0; i < N; i += 4)
+                dst[i >> 2] = (uint32_t)(uint8_t)mine[i * CH_T] | ((uint32_t)(uint8_t)mine[(i + 1) * CH_T] << 8) | ((uint32_t)(uint8_t)mine[(i + 2) * CH_T] << 16) |
+                              ((uint32_t)(uint8_t)mine[(i + 3) * CH_T] << 24);
         } else {
             uint32_t neq = 0;
-            for (int i = 0; i < N; i++) neq |= (uint32_t)(c[(size_t)item * N + i] != mine[i * HT]);
+            for (int i = 0; i < N; i++) neq |= (uint32_t)(c32[(size_t)item * N + i] != mine[i * CH_T]);
             if (neq) verdict[item] = 1;
         }
     }
@@ -230,113 +309,271 @@ struct BitW {
     __device__ __forceinline__ void flush() { if (nb) { p[nbytes++] = (uint8_t)(acc << (8 - nb)); nb = 0; } }
 };
 
-// one slot table per round: slot aidx*S + a  ->  (message active[aidx], kappa base + a)
-__global__ void dil_slots_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *kappa, uint32_t *slot_item, uint32_t *slot_kappa)
-{
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nact * S) return;
-    const uint32_t item = active ? active[s / S] : s / S;
-    slot_item[s] = item;
-    slot_kappa[s] = kappa[item] + s % S;
-}
+// Everything of an attempt behind the challenge hash, and the decision over a message's attempts, in ONE kernel - one wavefront per message that is
+// still unsigned, walking the S attempts ("slots") of its round in kappa order and stopping at the first that passes (the attempt the reference's
+// sequential loop stops at, dilithium.c:1566-1725):
+//   NTT(c) once, kept in registers; z = y + c s1 (l inverse transforms, four polynomials side by side on the 16-lane groups of the wavefront) and
+//   ||z||inf < gamma_1 - beta; r = w - c s2 and ||LowBits(r)||inf < gamma_2 - beta; c t0 with ||c t0||inf < gamma_2 - beta and the hints
+//   [HighBits(r + c t0) != HighBits(r)], at most omega of them; then the signature - z centred in z_bits per coefficient, the hint count and
+//   positions, c in two bits per coefficient, MSB first (dilithium.c:1803, 1914-1945; packer.c:299-351) - straight from LDS / registers.
+// An attempt that fails a test costs nothing after that test, attempts behind the accepted one cost nothing at all, and z, r, the hints and NTT(c)
+// never exist in HBM (the five kernels this replaces passed them between each other: 25 KB per attempt).  The masks y and w = A y of the
+// message's S slots - the per-call secrets (dilithium.c:1964-1975) - are zeroed here, by their last reader, instead of by memsets behind the call.
+// Messages with no accepted attempt advance kappa by S and are appended to the next round's list (one global atomic per workgroup).
+struct DilFin {
+    const int8_t *c8;                     // [slot][n]
+    const uint32_t *s1, *s2, *t0;         // NTT-domain key vectors, internal order, Montgomery form
+    size_t s1_stride, k_stride;           // words between the key vectors of consecutive MESSAGES (0: one key for the batch)
+    const uint32_t *active;               // the round's message list (null: identity)
+    const uint32_t *rs;
+    uint32_t *kappa;
+    uint8_t *sigs; size_t sig_stride; uint32_t *siglens, *trials;
+    uint32_t *next_active, *next_count;
+    uint32_t *yh_wipe;                    // NTT(y) [slot][l][n] where the unfused transform / product pair left it in HBM (null: it stayed in registers)
+    DilP P;
+};
 
-// accept / reject (dilithium.c:1655-1725) over the S speculative attempts of a message, lowest kappa first, + the
-// signature tail of the accepted attempt: num_ones, hint positions, c (2 bits each) (dilithium.c:1926-1945).
-// Messages with no accepted attempt advance kappa by S and go to the next round's list.
-// One wavefront per active message.  The tail (count, hint positions in ascending order, c) is assembled MSB-first in LDS as
-// big-endian 32-bit words - every field's bit offset follows from a prefix sum of the per-lane hint counts - and leaves as bytes.
-constexpr int FIN_W = 16;                                              // messages (wavefronts) per workgroup of dil_finish_kernel
-__global__ __launch_bounds__(64 * FIN_W) void dil_finish_kernel(const uint32_t *active, uint32_t nact, uint32_t S, uint32_t *flags, uint32_t *ones, uint32_t *kappa,
-                                                         int32_t *acc_slot, const uint8_t *h, const int32_t *c,
-                                                         uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                         uint32_t *next_active, uint32_t *next_count, DilP P)
+static inline size_t cfin_wave_words(const DilP &P) { return 1024u + 256u + 256u * (size_t)P.l + 128u + 64u + 64u * (size_t)P.k; }
+
+// the operands of one pass (four polynomials side by side): a key polynomial's 16 words and the 16 coefficients of w or y the epilogue needs
+struct FinOps { uint4 key[4]; int32_t pre[16]; };
+
+// L2P / K2P: l > 4 / k > 4, i.e. the z stage / the r and c t0 stages take two passes.  The passes of an attempt run in the order r, z, c t0 (the
+// r test rejects most often); each pass requests the NEXT pass's operands before its own inverse transform - also across a stage boundary, where
+// they are wasted if the test fails - because a wavefront walking its message's attempts is otherwise a chain of exposed HBM / L2 round trips.
+template <int MODE, bool L2P, bool K2P>
+__global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
 {
-    __shared__ uint32_t tail[FIN_W][128];                              // <= omega_bits + omega*h_bits + 2n bits = 4096 bits
-    __shared__ uint32_t rej_n, rej_base;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t aidx = blockIdx.x * FIN_W + wv;
-    const bool live = aidx < nact;
-    const uint32_t item = !live ? 0 : active ? active[aidx] : aidx;
-    int found = -1;
-    uint32_t no = 0;
-    if (threadIdx.x == 0) rej_n = 0;
-    if (live) {
-        for (uint32_t a = 0; a < S; a++) {                             // every lane walks the (few) slots: same answer, no broadcast
-            const uint32_t slot = aidx * S + a;
-            if (found < 0 && flags[slot] == 0 && ones[slot] <= (uint32_t)P.omega) found = (int)a;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (found >= 0) no = ones[aidx * S + (uint32_t)found];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-        for (uint32_t a = lane; a < S; a += 64) { flags[aidx * S + a] = 0; ones[aidx * S + a] = 0; }     // leave the per-slot accumulators clean
-    }
-    // the messages that go round again are appended to the next round's list with ONE global atomic per workgroup: a wavefront each on the single
-    // counter (12 K of them in the first round of a 16 K batch) serialised in L2 and cost 100 us of the round
+    constexpr bool SG = MODE == MODE_S32;
+    extern __shared__ __attribute__((aligned(16))) uint32_t fin_lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int pw = lane / LP, lp = lane % LP;
+    const DilP &P = f.P;
+    const int l = P.l, kk = P.k;
+    uint32_t *wbase = fin_lds + 4 + (size_t)wid * (1024u + 256u + 256u * l + 128u + 64u + 64u * kk);
+    uint32_t *lds_poly = wbase + pw * N;                                // the transforms' exchange image (ntt_core.h)
+    uint32_t *chl = wbase + 1024;                                       // NTT(c), internal order (the four groups hold the same 16 words per lane: kept once, in LDS)
+    uint32_t *zl = chl + 256;                                           // z of the current attempt, natural order [l][n]
+    uint32_t *tw = zl + 256 * l;                                        // signature tail, big-endian words
+    uint32_t *cb = tw + 128;                                            // c as n signed bytes
+    uint8_t *hl = reinterpret_cast<uint8_t *>(cb + 64);                 // hints [k][n]
+    const ModK k = a.k;
+    const uint32_t nact = f.rs[RS_NACT], S = f.rs[RS_S];
+    const uint32_t aidx = blockIdx.x * 4 + wid;
+    const bool live = aidx < nact;                                      // wave-uniform
+    if (threadIdx.x == 0) fin_lds[0] = 0;
     __syncthreads();
+    int found = -1;
+    uint32_t item = 0;
+    if (live) {
+        item = f.active ? f.active[aidx] : aidx;
+        TwSet<L8> twi;
+        twi.load(a.zi, a.zip, lp);
+        const uint32_t *s1k = f.s1 + (size_t)item * f.s1_stride + lp * 16, *s2k = f.s2 + (size_t)item * f.k_stride + lp * 16, *t0k = f.t0 + (size_t)item * f.k_stride + lp * 16;
+        const uint32_t *c32 = reinterpret_cast<const uint32_t *>(f.c8) + (size_t)aidx * S * 64 + lane;
+        uint32_t creg = c32[0];
+        for (uint32_t at = 0; at < S && found < 0; at++) {
+            const uint32_t slot = aidx * S + at;
+            FinOps o[2];
+            uint32_t x[16];
+            // pass (stage, p): group pw handles polynomial t = 4 p + pw of the stage; a group without one repeats polynomial 0 and stores nothing
+            auto issue = [&](FinOps &d, const uint32_t *key, const int32_t *arr, int per, int p) {
+                const int t = 4 * p + pw, tt = t < per ? t : 0;
+                const uint4 *pk = reinterpret_cast<const uint4 *>(key + (size_t)tt * N);
+#pragma unroll
+                for (int c = 0; c < 4; c++) d.key[c] = pk[c];
+                if (arr == a.w) {                                       // w is stored in 16-byte pieces (DilNtt::w_chunked)
+                    const int4 *pa = reinterpret_cast<const int4 *>(arr + ((size_t)slot * per + tt) * N) + lp;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { const int4 v = pa[16 * c]; d.pre[4 * c] = v.x; d.pre[4 * c + 1] = v.y; d.pre[4 * c + 2] = v.z; d.pre[4 * c + 3] = v.w; }
+                } else if (arr) {
+                    const int32_t *pa = arr + ((size_t)slot * per + tt) * N + lp;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) d.pre[r] = pa[r * LP];
+                }
+            };
+            auto product = [&](const FinOps &d) {                       // x = c o key (internal order: 16 contiguous words per lane)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint4 vk = d.key[c], vc = reinterpret_cast<const uint4 *>(chl + lp * 16)[c];
+                    if constexpr (SG) {
+                        x[4 * c + 0] = montmul_s32(vc.x, vk.x, k); x[4 * c + 1] = montmul_s32(vc.y, vk.y, k);
+                        x[4 * c + 2] = montmul_s32(vc.z, vk.z, k); x[4 * c + 3] = montmul_s32(vc.w, vk.w, k);
+                    } else {
+                        x[4 * c + 0] = montmul(vc.x, vk.x, k); x[4 * c + 1] = montmul(vc.y, vk.y, k);
+                        x[4 * c + 2] = montmul(vc.z, vk.z, k); x[4 * c + 3] = montmul(vc.w, vk.w, k);
+                    }
+                }
+            };
+            issue(o[0], s2k, a.w, kk, 0);
+            cb[lane] = creg;
+            if (at + 1 < S) creg = c32[(size_t)(at + 1) * 64];              // the next attempt's c, should this one fail
+            wave_lds_fence();
+            {
+                const int8_t *cbb = reinterpret_cast<const int8_t *>(cb);
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int32_t v = cbb[r * LP + lp];
+                    x[r] = SG ? (uint32_t)v : (v < 0 ? k.q - 1u : (uint32_t)v);
+                }
+                // the forward twiddles are loaded per attempt and die before the passes below (as in dil_yaw_kernel)
+                const uint32_t *zf = a.zf, *zfp = a.zfp;
+                asm volatile("" : "+s"(zf), "+s"(zfp));
+                TwSet<L8> twf;
+                twf.load(zf, zfp, lp);
+                fwd_core<L8, MODE, true>(x, twf, lds_poly, lp, k);
+#pragma unroll
+                for (int r = 0; r < 16; r++) x[r] = SG ? canon_s32(x[r], k) : csub(Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k), k.q);
+                if (pw == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) reinterpret_cast<uint4 *>(chl + lp * 16)[c] = make_uint4(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3]);
+                }
+                wave_lds_fence();
+            }
+            bool bad = false;
+            uint32_t rr[2][16];
+            // ---- r = w - c s2; ||LowBits(r)||inf < gamma_2 - beta (dilithium.c:1671-1700)
+            auto epi_r = [&](const FinOps &d, int p) {
+                const bool act = 4 * p + pw < kk;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const uint32_t v = csub((uint32_t)d.pre[r] + k.q - x[r], k.q);
+                    rr[p][r] = v;
+                    int32_t a0;
+                    round_alpha(v, a0, a.alpha, a.am, (int32_t)k.q);
+                    const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + (int32_t)k.q) : (uint32_t)a0;       // low_order_bits
+                    bad |= act && norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
+                }
+            };
+            constexpr int Z0 = K2P ? 0 : 1, Z1 = 1 - Z0, T0 = L2P ? Z0 : Z1, T1 = 1 - T0;     // which operand set the stages' first passes find their operands in
+            product(o[0]);
+            if constexpr (K2P) issue(o[1], s2k, a.w, kk, 1); else issue(o[1], s1k, a.y, l, 0);
+            inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+            epi_r(o[0], 0);
+            if constexpr (K2P) {
+                product(o[1]);
+                issue(o[0], s1k, a.y, l, 0);
+                inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                epi_r(o[1], 1);
+            }
+            bool ok = __ballot(bad) == 0;
+            if (ok) {
+                // ---- z = y + c s1, normalised; ||z||inf < gamma_1 - beta (dilithium.c:1655-1669)
+                auto epi_z = [&](const FinOps &d, int p) {
+                    const int t = 4 * p + pw;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t zz = csub(csub(x[r] + reduce_i32(d.pre[r], k), k.q2), k.q);
+                        if (t < l) { zl[t * N + r * LP + lp] = zz; bad |= norm_bad(zz, k.q, (uint32_t)a.gamma1_beta); }
+                    }
+                };
+                product(o[Z0]);
+                if constexpr (L2P) issue(o[Z1], s1k, a.y, l, 1); else issue(o[Z1], t0k, nullptr, kk, 0);
+                inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                epi_z(o[Z0], 0);
+                if constexpr (L2P) {
+                    product(o[Z1]);
+                    issue(o[Z0], t0k, nullptr, kk, 0);
+                    inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                    epi_z(o[Z1], 1);
+                }
+                ok = __ballot(bad) == 0;
+            }
+            uint32_t ones = 0;
+            if (ok) {
+                // ---- c t0; ||c t0||inf < gamma_2 - beta; hints (make_hint, dilithium.c:1258-1284, 1702-1725)
+                uint32_t cnt = 0;
+                auto epi_t = [&](int p) {
+                    const int t = 4 * p + pw;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const uint32_t sum = csub(rr[p][r] + x[r], k.q);        // (w - c s2) + c t0
+                        int32_t a0;
+                        const uint32_t hb = round_alpha(sum, a0, a.alpha, a.am, (int32_t)k.q) != round_alpha(rr[p][r], a0, a.alpha, a.am, (int32_t)k.q);
+                        if (t < kk) { bad |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta); hl[t * N + r * LP + lp] = (uint8_t)hb; cnt += hb; }
+                    }
+                };
+                product(o[T0]);
+                if constexpr (K2P) issue(o[T1], t0k, nullptr, kk, 1);
+                inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                epi_t(0);
+                if constexpr (K2P) {
+                    product(o[T1]);
+                    inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                    epi_t(1);
+                }
+                for (int o_ = 32; o_ > 0; o_ >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o_);
+                ones = cnt;
+                ok = __ballot(bad) == 0 && ones <= (uint32_t)P.omega;
+            }
+            if (!ok) continue;
+            // ---- accepted: the signature
+            found = (int)at;
+            wave_lds_fence();
+            uint8_t *out = f.sigs + (size_t)item * f.sig_stride;
+            {
+                const int32_t half = ((int32_t)k.q - 1) >> 1;
+                const int pairs = l * N / 2, nbytes = 2 * P.z_bits / 8;
+                const uint64_t m = (1ull << P.z_bits) - 1;
+                for (int pr = lane; pr < pairs; pr += 64) {
+                    int32_t v0 = (int32_t)zl[2 * pr], v1 = (int32_t)zl[2 * pr + 1];
+                    if (v0 > half) v0 -= (int32_t)k.q;
+                    if (v1 > half) v1 -= (int32_t)k.q;
+                    const uint64_t bits = (((uint64_t)(uint32_t)v0 & m) << P.z_bits) | ((uint64_t)(uint32_t)v1 & m);     // 2 z_bits bits, MSB first
+                    uint8_t *dst = out + (size_t)pr * nbytes;
+                    for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * (nbytes - 1 - b)));
+                }
+            }
+            // tail: count, hint positions in ascending order, c - assembled MSB-first in LDS as big-endian 32-bit words, every field's bit offset
+            // from a prefix sum of the per-lane hint counts
+            const int kn = kk * P.n, h_bits = 8 + ((kk + 1) >> 1);
+            tw[lane] = 0; tw[lane + 64] = 0;
+            wave_lds_fence();
+            auto put = [&](uint32_t off, uint32_t v, int bits) {                // bits <= 16: at most two words
+                const uint32_t w = off >> 5; const int sh = 32 - (int)(off & 31) - bits;
+                if (sh >= 0) atomicOr(&tw[w], v << sh);
+                else { atomicOr(&tw[w], v >> (-sh)); atomicOr(&tw[w + 1], v << (32 + sh)); }
+            };
+            if (lane == 0) put(0, ones, P.omega_bits);
+            const int chunk = kn / 64;                                          // kn = k * 256
+            const uint8_t *hh = hl + lane * chunk;
+            uint32_t mine = 0;
+            for (int i = 0; i < chunk; i++) mine += hh[i];
+            uint32_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+            uint32_t rank = incl - mine;
+            for (int i = 0; i < chunk; i++)
+                if (hh[i]) { put((uint32_t)P.omega_bits + rank * (uint32_t)h_bits, (uint32_t)(lane * chunk + i), h_bits); rank++; }
+            const uint32_t cbase = (uint32_t)P.omega_bits + ones * (uint32_t)h_bits;
+            {
+                const uint32_t v = cb[lane];                                    // c[4 lane .. 4 lane + 3]: two bits each, -1 -> 3 (dilithium.c:1939-1945)
+                const uint32_t b = ((v & 3u) << 6) | (((v >> 8) & 3u) << 4) | (((v >> 16) & 3u) << 2) | ((v >> 24) & 3u);
+                put(cbase + 8u * (uint32_t)lane, b, 8);
+            }
+            wave_lds_fence();
+            const uint32_t tbits = cbase + 2u * (uint32_t)P.n, tbytes = (tbits + 7) / 8, zbytes = (uint32_t)(l * P.n * P.z_bits / 8);
+            for (uint32_t i = lane; i < tbytes; i += 64) out[zbytes + i] = (uint8_t)(tw[i >> 2] >> (24 - 8 * (i & 3)));
+            if (lane == 0) { f.trials[item] = f.kappa[item] + at + 1; f.siglens[item] = zbytes + tbytes; }
+        }
+        // the masks and w = A y of this message's S slots do not outlive the round
+        {
+            uint4 *zy = reinterpret_cast<uint4 *>(const_cast<int32_t *>(a.y) + (size_t)aidx * S * l * N), *zw = reinterpret_cast<uint4 *>(a.w + (size_t)aidx * S * kk * N);
+            const uint32_t ny = S * (uint32_t)l * (N / 4), nw = S * (uint32_t)kk * (N / 4);
+            for (uint32_t i = lane; i < ny; i += 64) zy[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = lane; i < nw; i += 64) zw[i] = make_uint4(0, 0, 0, 0);
+            if (f.yh_wipe) {
+                uint4 *zh = reinterpret_cast<uint4 *>(f.yh_wipe + (size_t)aidx * S * l * N);
+                for (uint32_t i = lane; i < ny; i += 64) zh[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    }
     const bool again = live && found < 0 && lane == 0;
     uint32_t rpos = 0;
-    if (again) rpos = atomicAdd(&rej_n, 1u);
+    if (again) rpos = atomicAdd(&fin_lds[0], 1u);
     __syncthreads();
-    if (threadIdx.x == 0 && rej_n) rej_base = atomicAdd(next_count, rej_n);
+    if (threadIdx.x == 0 && fin_lds[0]) fin_lds[1] = atomicAdd(f.next_count, fin_lds[0]);
     __syncthreads();
-    if (again) { acc_slot[aidx] = -1; kappa[item] += S; next_active[rej_base + rpos] = item; }
-    if (!live || found < 0) return;
-    const uint32_t slot = aidx * S + (uint32_t)found;
-    const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
-    uint32_t *tw = tail[wv];
-    tw[lane] = 0; tw[lane + 64] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    auto put = [&](uint32_t off, uint32_t v, int bits) {                // bits <= 16: at most two words
-        const uint32_t w = off >> 5; const int sh = 32 - (int)(off & 31) - bits;
-        if (sh >= 0) atomicOr(&tw[w], v << sh);
-        else { atomicOr(&tw[w], v >> (-sh)); atomicOr(&tw[w + 1], v << (32 + sh)); }
-    };
-    if (lane == 0) put(0, no, P.omega_bits);
-    // hints: lane owns bytes [lane*chunk, (lane+1)*chunk) of h; positions go out in ascending order
-    const int chunk = kn / 64;                                          // kn = k*256
-    const uint8_t *hh = h + (size_t)slot * kn + (size_t)lane * chunk;
-    uint32_t mine = 0;
-    for (int i = 0; i < chunk; i++) mine += hh[i];
-    uint32_t incl = mine;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
-    uint32_t rank = incl - mine;
-    for (int i = 0; i < chunk; i++)
-        if (hh[i]) { put((uint32_t)P.omega_bits + rank * (uint32_t)h_bits, (uint32_t)(lane * chunk + i), h_bits); rank++; }
-    const uint32_t cbase = (uint32_t)P.omega_bits + no * (uint32_t)h_bits;
-    const int32_t *ci = c + (size_t)slot * P.n;
-    for (int i = lane * 4; i < P.n; i += 256) {
-        const int4 v = *reinterpret_cast<const int4 *>(ci + i);
-        const uint32_t b = (((uint32_t)v.x & 3u) << 6) | (((uint32_t)v.y & 3u) << 4) | (((uint32_t)v.z & 3u) << 2) | ((uint32_t)v.w & 3u);
-        put(cbase + 2u * (uint32_t)i, b, 8);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const uint32_t tbits = cbase + 2u * (uint32_t)P.n, tbytes = (tbits + 7) / 8, zbytes = (uint32_t)(P.l * P.n * P.z_bits / 8);
-    uint8_t *out = sigs + (size_t)item * sig_stride + zbytes;
-    for (uint32_t i = lane; i < tbytes; i += 64) out[i] = (uint8_t)(tw[i >> 2] >> (24 - 8 * (i & 3)));
-    if (lane == 0) { acc_slot[aidx] = (int32_t)slot; trials[item] = kappa[item] + (uint32_t)found + 1; siglens[item] = zbytes + tbytes; }
-}
-
-// z part of the signature of the messages accepted this round: centre (ntt32_center) and raw z_bits per coefficient,
-// two coefficients per thread (2*z_bits = 40 bits = 5 bytes)  (dilithium.c:1803,1914-1917)
-__global__ void dil_packz_kernel(const uint32_t *active, uint32_t nact, const int32_t *acc_slot, const int32_t *z,
-                                 uint8_t *sigs, size_t sig_stride, int ln, int z_bits, int32_t q)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int pairs = ln / 2;
-    const size_t aidx = t / pairs; const int pr = (int)(t % pairs);
-    if (aidx >= nact) return;
-    const int32_t slot = acc_slot[aidx];
-    if (slot < 0) return;
-    const uint32_t item = active ? active[aidx] : (uint32_t)aidx;
-    const int32_t half = (q - 1) >> 1;
-    int32_t v0 = z[(size_t)slot * ln + 2 * pr], v1 = z[(size_t)slot * ln + 2 * pr + 1];
-    if (v0 > half) v0 -= q;
-    if (v1 > half) v1 -= q;
-    const uint64_t m = (1ull << z_bits) - 1;
-    const uint64_t bits = (((uint64_t)(uint32_t)v0 & m) << z_bits) | ((uint64_t)(uint32_t)v1 & m);     // 2*z_bits bits, MSB first
-    const int nbytes = 2 * z_bits / 8;
-    uint8_t *dst = sigs + (size_t)item * sig_stride + (size_t)pr * nbytes;
-    for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * (nbytes - 1 - b)));
+    if (again) { f.kappa[item] += S; f.next_active[fin_lds[1] + rpos] = item; }
 }
 
 // verify: unpack z (-> canonical), hints, c; structural checks (dilithium.c:2065-2123)
@@ -431,28 +668,27 @@ struct sc_hip_dilithium {
     uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
-    size_t cap;
+    size_t cap;                                       // per message / per signature (verify): mu, kappa, trials, act, z, h, c, ch
     uint8_t *mu, *w1, *h;
-    size_t slot_cap;
-    uint32_t *kappa, *flags, *ones, *trials, *act[2], *cnt, *slot_item, *slot_kappa;
-    int32_t *acc_slot;
-    int32_t *y, *w, *c, *z, *r;
+    size_t slot_cap;                                  // per attempt of a signing round: y, w, w1, c8, yh, slot_item
+    uint32_t *kappa, *trials, *act[2], *cnt, *rs, *slot_item;
+    int8_t *c8;
+    int32_t *y, *w, *c, *z;
     uint32_t *yh, *ch;
     uint8_t *msg_dev, *sig_dev;
     size_t msg_cap, sig_cap;
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
     hipStream_t side, side2;                          // verify_keys / sign_keys: per-key chains that depend on nothing of each other run beside each other
     hipEvent_t ev_fork, ev_join, ev_join2;
-    int tune_slots, tune_unfused, tune_growth;                     // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product
+    int tune_slots, tune_unfused, tune_sync;                       // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
 };
 
 static void free_ws(sc_hip_dilithium *d)
 {
-    void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->flags, d->ones, d->trials, d->act[0], d->act[1], d->cnt, d->slot_item, d->slot_kappa,
-                     d->acc_slot, d->y, d->w, d->c, d->z, d->r, d->yh, d->ch };
+    void *ptrs[] = { d->mu, d->w1, d->h, d->kappa, d->trials, d->act[0], d->act[1], d->cnt, d->rs, d->slot_item, d->c8, d->y, d->w, d->c, d->z, d->yh, d->ch };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
-    d->mu = d->w1 = d->h = nullptr; d->kappa = d->flags = d->ones = d->trials = d->act[0] = d->act[1] = d->cnt = d->slot_item = d->slot_kappa = nullptr;
-    d->acc_slot = nullptr; d->y = d->w = d->c = d->z = d->r = nullptr; d->yh = d->ch = nullptr;
+    d->mu = d->w1 = d->h = nullptr; d->kappa = d->trials = d->act[0] = d->act[1] = d->cnt = d->rs = d->slot_item = nullptr;
+    d->c8 = nullptr; d->y = d->w = d->c = d->z = nullptr; d->yh = d->ch = nullptr;
     d->cap = 0; d->slot_cap = 0;
 }
 
@@ -465,15 +701,12 @@ static int ensure_ws(sc_hip_dilithium *d, size_t batch, size_t slots)
     free_ws(d);
     const size_t n = d->P.n, k = d->P.k, l = d->P.l;
 #define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
-    WS(d->mu, batch * 48); WS(d->kappa, batch * 4); WS(d->trials, batch * 4); WS(d->act[0], batch * 4); WS(d->act[1], batch * 4); WS(d->cnt, 64);
-    WS(d->acc_slot, batch * 4);
-    WS(d->slot_item, slots * 4); WS(d->slot_kappa, slots * 4); WS(d->flags, slots * 4); WS(d->ones, slots * 4);
-    WS(d->w1, slots * k * n); WS(d->h, slots * k * n);
-    WS(d->y, slots * l * n * 4); WS(d->w, slots * k * n * 4); WS(d->c, slots * n * 4); WS(d->z, slots * l * n * 4); WS(d->r, slots * k * n * 4);
-    WS(d->yh, slots * l * n * 4); WS(d->ch, slots * n * 4);
+    WS(d->mu, batch * 48); WS(d->kappa, batch * 4); WS(d->trials, batch * 4); WS(d->act[0], batch * 4); WS(d->act[1], batch * 4); WS(d->cnt, 64); WS(d->rs, 64);
+    WS(d->h, batch * k * n); WS(d->c, batch * n * 4); WS(d->z, batch * l * n * 4); WS(d->ch, batch * n * 4);          // the verifier's: one per signature
+    WS(d->slot_item, slots * 4); WS(d->c8, slots * n);
+    WS(d->w1, slots * k * n);
+    WS(d->y, slots * l * n * 4); WS(d->w, slots * k * n * 4); WS(d->yh, slots * l * n * 4);
 #undef WS
-    HIPCHK(hipMemset(d->flags, 0, slots * 4));
-    HIPCHK(hipMemset(d->ones, 0, slots * 4));
     d->cap = batch; d->slot_cap = slots;
     return SC_HIP_SUCCESS;
 }
@@ -482,7 +715,7 @@ static DilNtt base_args(sc_hip_dilithium *d)
 {
     DilNtt a = mlwe_base_args(d->plan, d->P.k, d->P.l, d->P.gamma2);
     a.gamma1_beta = d->P.gamma1 - d->P.beta; a.gamma2_beta = d->P.gamma2 - d->P.beta; a.d = d->P.d;
-    a.yh = d->yh; a.ch = d->ch; a.y = d->y; a.w = d->w; a.w1 = d->w1; a.z = d->z; a.r = d->r; a.h = d->h; a.flags = d->flags; a.ones = d->ones;
+    a.yh = d->yh; a.ch = d->ch; a.y = d->y; a.w = d->w; a.w1 = d->w1; a.z = d->z; a.h = d->h;
     return a;
 }
 
@@ -645,7 +878,7 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
-    d->tune_slots = slots_per_message & 0xFF; d->tune_growth = (slots_per_message >> 8) & 0xFF; d->tune_unfused = unfused ? 1 : 0;
+    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -681,6 +914,24 @@ extern "C" int sc_hip_dilithium_sign(sc_hip_dilithium_t *d, size_t batch, const 
     return sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
 }
 
+// rounds to queue before the first look at the count of unsigned messages: the schedule run forward with a (pessimistic) rejection probability of
+// 3/4 per attempt until less than half a message is expected to be left
+static uint32_t plan_rounds(size_t batch, size_t slot_cap, uint32_t s_max)
+{
+    double n = (double)batch;
+    uint32_t r = 0;
+    while (n >= 0.5 && r < 64) {
+        const double live = n < 1.0 ? 1.0 : n;
+        double S = (double)slot_cap / live;
+        if (S > s_max) S = s_max;
+        if (S < 1) S = 1;
+        double f = 1.0;
+        for (int i = 0; i < (int)S; i++) f *= 0.75;
+        n *= f; r++;
+    }
+    return r ? r : 1;
+}
+
 static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
                      uint32_t fixed_len, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream)
 {
@@ -691,82 +942,75 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     if (sig_stride < sc_hip_dilithium_sig_max(d)) return fail("dilithium_sign: sig_stride smaller than sc_hip_dilithium_sig_max()");
     HIPCHK(hipSetDevice(d->ctx->device));
     // Attempts evaluated side by side per round ("slots").  More slots per message mean fewer rounds (each round costs the latency
-    // of the lane-per-attempt hash kernels plus a host synchronisation) but more attempts thrown away after the first success.
+    // of the lane-per-attempt hash kernels) but more attempts thrown away after the first success.
     // Measured on MI355X (tools/bench_dilithium.py, sc_hip_dilithium_set_tuning slots = 1..8): about 48 K slots per round is the sweet spot - 8 per
     // message for small batches, 3 at 16 K messages, 1 from 48 K messages up; as the batch thins out the same slots go deeper.
     size_t slot_target = batch * 8 < 49152 ? batch * 8 : 49152;
     if (slot_target < batch) slot_target = batch;
     if (d->tune_slots >= 1 && d->tune_slots <= 32) slot_target = batch * (size_t)d->tune_slots;
-    if (slot_target < 4096 && !d->tune_growth) slot_target = 4096;
+    if (slot_target < 4096) slot_target = 4096;
     if (ensure_ws(d, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const DilP &P = d->P;
-    const uint32_t B = (uint32_t)batch;
+    const uint32_t B = (uint32_t)batch, cap = (uint32_t)d->slot_cap, s_max = 32;
     const int k = P.k, l = P.l;
     HIPCHK(hipMemsetAsync(d->kappa, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : d->trials;
     hipLaunchKernelGGL(dil_mu_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, ks.tr, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B, ks.per_item ? 48u : 0u);
     HIPCHK(hipGetLastError());
 
-    uint32_t nact = B, wiped_slots = 0;
-    const uint32_t *active = nullptr;                 // round 0: identity
-    for (uint32_t round = 0; nact > 0; round++) {
-        if (round > 4000) return fail("dilithium_sign: rejection loop did not terminate");
-        uint32_t S = (uint32_t)(d->slot_cap / nact);
-        if (S > 32) S = 32;
-        if (d->tune_growth > 0) {                                     // experiment: cap the depth at S0 * growth^round
-            uint64_t lim = (uint64_t)(slot_target / batch ? slot_target / batch : 1);
-            for (uint32_t r = 0; r < round && lim < 32; r++) lim *= (uint64_t)d->tune_growth;
-            if (S > lim) S = (uint32_t)lim;
+    // The round loop runs on the device: every kernel of a round takes its sizes from the round state (rs), which the round's first kernel derives
+    // from the count its predecessor's last kernel left behind; grids are sized for the slot budget and the surplus workgroups leave at once.  The
+    // host queues as many rounds as the schedule is expected to need, looks at the count once, and adds single rounds while messages are left.
+    const size_t fin_lds = (4 + 4 * cfin_wave_words(P)) * sizeof(uint32_t);
+    DilFin f;
+    f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
+    f.s1_stride = ks.per_item ? (size_t)l * N : 0; f.k_stride = ks.per_item ? (size_t)k * N : 0;
+    f.yh_wipe = (ks.As && !ks.per_item) ? nullptr : d->yh;
+    f.rs = d->rs; f.kappa = d->kappa; f.sigs = d_sigs; f.sig_stride = sig_stride; f.siglens = d_siglens; f.trials = trials; f.next_count = d->cnt; f.P = P;
+    const unsigned eb = (cap + EXP_T - 1) / EXP_T, hb = (cap + CH_T - 1) / CH_T;
+    uint32_t round = 0, todo = d->tune_sync ? 1 : plan_rounds(batch, cap, s_max), left = B;
+    while (left > 0) {
+        for (uint32_t i = 0; i < todo; i++, round++) {
+            if (round > 4000) return fail("dilithium_sign: rejection loop did not terminate");
+            const uint32_t *active = round ? d->act[(round - 1) & 1] : nullptr;     // round 0: identity
+            f.active = active; f.next_active = d->act[round & 1];
+            hipLaunchKernelGGL(dil_round_kernel, dim3(1), dim3(1), 0, s, d->rs, d->cnt, round ? 0u : B, cap, s_max);
+            hipLaunchKernelGGL(dil_expand_kernel, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item);
+            HIPCHK(hipGetLastError());
+            DilNtt a = base_args(d);
+            a.in = d->y; a.out_int = d->yh;
+            a.njobs_dev = d->rs + RS_NSLOTS; a.w_chunked = 1;
+            a.key_of = d->slot_item;                                    // per-message keys: the key of a slot is its message's
+            if (ks.As && !ks.per_item) {                                // w = A y with NTT(y) kept in registers
+                a.key = ks.As; a.keyp = ks.As + (size_t)k * l * N;
+                if (mlwe_launch_yaw(d->ctx, a, cap, s)) return SC_HIP_FAILURE;
+                a.keyp = nullptr;
+            } else {
+                if (ks.A_nat ? launch_dil<DOP_KEYPREP>(d, a, cap, l, s) : launch_dil<DOP_FWD_INT>(d, a, cap, l, s)) return SC_HIP_FAILURE;
+                a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0; a.key_nat = ks.A_nat ? 1 : 0;
+                if (ks.matrix_ready && round == 0) HIPCHK(hipStreamWaitEvent(s, ks.matrix_ready, 0));
+                if (launch_dil<DOP_MATVEC>(d, a, cap, k, s)) return SC_HIP_FAILURE;
+                a.key_item_stride = 0; a.key_nat = 0;
+            }
+            hipLaunchKernelGGL(dil_challenge_kernel<true>, dim3(hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
+            HIPCHK(hipGetLastError());
+            // one wavefront per message that may still be unsigned: the host only knows the count at its last look
+            const unsigned fb = (left + 3) / 4;
+#define SC_CFIN(M) do { if (l > 4 && k > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, true, true>), dim3(fb), dim3(256), fin_lds, s, a, f); \
+                        else if (l > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, true, false>), dim3(fb), dim3(256), fin_lds, s, a, f); \
+                        else if (k > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, false, true>), dim3(fb), dim3(256), fin_lds, s, a, f); \
+                        else hipLaunchKernelGGL((dil_cfin_kernel<M, false, false>), dim3(fb), dim3(256), fin_lds, s, a, f); } while (0)
+            if (a.sg) SC_CFIN(MODE_S32); else SC_CFIN(MODE_U32);
+#undef SC_CFIN
+            HIPCHK(hipGetLastError());
         }
-        if (S < 1) S = 1;
-        const uint32_t nslots = nact * S;
-        uint32_t *next = d->act[round & 1];
-        HIPCHK(hipMemsetAsync(d->cnt, 0, 4, s));
-        hipLaunchKernelGGL(dil_slots_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nact, S, d->kappa, d->slot_item, d->slot_kappa);
-        const unsigned hb = (nslots + HT - 1) / HT;
-        hipLaunchKernelGGL(dil_expand_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, d->slot_kappa, nslots, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u);
-        HIPCHK(hipGetLastError());
-        DilNtt a = base_args(d);
-        a.in = d->y; a.out_int = d->yh;
-        a.key_of = d->slot_item;                                    // per-message keys: the key of a slot is its message's
-        if (ks.As && !ks.per_item) {                                // w = A y with NTT(y) kept in registers
-            a.key = ks.As; a.keyp = ks.As + (size_t)k * l * N;
-            if (mlwe_launch_yaw(d->ctx, a, nslots, s)) return SC_HIP_FAILURE;
-            a.keyp = nullptr;
-        } else {
-            if (ks.A_nat ? launch_dil<DOP_KEYPREP>(d, a, nslots, l, s) : launch_dil<DOP_FWD_INT>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-            a.key = ks.A; a.key_item_stride = ks.per_item ? (size_t)k * l * N : 0; a.key_nat = ks.A_nat ? 1 : 0;
-            if (ks.matrix_ready && round == 0) HIPCHK(hipStreamWaitEvent(s, ks.matrix_ready, 0));
-            if (launch_dil<DOP_MATVEC>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-            a.key_item_stride = 0; a.key_nat = 0;
-        }
-        hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, d->slot_item, nslots, d->mu, d->w1, k * P.n, P.weight, d->c, 0, (uint32_t *)nullptr);
-        HIPCHK(hipGetLastError());
-        a.in = d->c; a.out_int = d->ch;
-        if (launch_dil<DOP_FWD_INT>(d, a, nslots, 1, s)) return SC_HIP_FAILURE;
-        a.key = ks.s1; a.key_item_stride = ks.per_item ? (size_t)l * N : 0; if (launch_dil<DOP_CZ>(d, a, nslots, l, s)) return SC_HIP_FAILURE;
-        a.key = ks.s2; a.key_item_stride = ks.per_item ? (size_t)k * N : 0; if (launch_dil<DOP_CS2>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        a.key = ks.t0; if (launch_dil<DOP_CT0>(d, a, nslots, k, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(dil_finish_kernel, dim3((nact + FIN_W - 1) / FIN_W), dim3(64 * FIN_W), 0, s, active, nact, S, d->flags, d->ones, d->kappa, d->acc_slot, d->h, d->c,
-                           d_sigs, sig_stride, d_siglens, trials, next, d->cnt, P);
-        HIPCHK(hipGetLastError());
-        const size_t zthreads = (size_t)nact * (size_t)(l * P.n / 2);
-        hipLaunchKernelGGL(dil_packz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, active, nact, d->acc_slot, d->z,
-                           d_sigs, sig_stride, l * P.n, P.z_bits, P.q);
-        HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, d->cnt, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        nact = cnt;
-        active = next;
-        if (nslots > wiped_slots) wiped_slots = nslots;
+        left = cnt;
+        todo = 1;
     }
-    // the masks y (with z they give s1), w = A y, the rejected candidates z and the remainders r do not outlive the call (dilithium.c:1964-1975)
-    const size_t ws_ = wiped_slots;
-    HIPCHK(hipMemsetAsync(d->y, 0, ws_ * l * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->z, 0, ws_ * l * P.n * 4, s));
-    if (!(ks.As && !ks.per_item)) HIPCHK(hipMemsetAsync(d->yh, 0, ws_ * l * P.n * 4, s));        // NTT(y): only the unfused path writes it (the fused kernel keeps it in registers)
-    HIPCHK(hipMemsetAsync(d->w, 0, ws_ * k * P.n * 4, s)); HIPCHK(hipMemsetAsync(d->r, 0, ws_ * k * P.n * 4, s));
     return SC_HIP_SUCCESS;
 }
 
@@ -811,7 +1055,7 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
     a.key = d->d_t1s;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, d->c, 1, d_verdicts);
+    hipLaunchKernelGGL(dil_challenge_kernel<false>, dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -1034,7 +1278,7 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     a.key = t1h; a.key_item_stride = kn;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
     HIPCHK(hipStreamWaitEvent(s, d->ev_join2, 0));
-    hipLaunchKernelGGL(dil_challenge_kernel, dim3(hb), dim3(HT), 0, s, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, d->c, 1, d_verdicts);
+    hipLaunchKernelGGL(dil_challenge_kernel<false>, dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

@@ -47,7 +47,7 @@ __device__ __forceinline__ bool norm_bad(uint32_t v, uint32_t q, uint32_t b)
 // NTT-shaped kernels (n = 256: 16 lanes per polynomial, 4 polynomials per wave, 32-bit Shoup path)
 // ------------------------------------------------------------------------------------------------
 
-enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CZ = 2, DOP_CS2 = 3, DOP_CT0 = 4, DOP_CT1 = 5, DOP_KEYPREP = 6 };
+enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CT1 = 5, DOP_KEYPREP = 6 };
 
 struct DilNtt {
     const uint32_t *zf, *zfp, *zi, *zip;
@@ -55,6 +55,8 @@ struct DilNtt {
     uint32_t c0, c0p, c1, c1p;            // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs): Montgomery-form keys need no 2^32 fix
     uint32_t r2, r2p;                     // 2^32 mod q (Shoup pair)
     uint32_t njobs;                       // slots * per (every per-attempt array is indexed by slot)
+    const uint32_t *njobs_dev;            // non-null: the number of ITEMS (slots) is read from device memory (the signer's round state, written by the
+                                          // previous round's last kernel: no host read-back between rounds); njobs then only sizes the grid
     int per;                              // polynomials per item handled by this launch
     int l, kk;
     int32_t alpha, am, gamma1_beta, gamma2_beta, d;
@@ -73,9 +75,12 @@ struct DilNtt {
     int32_t *w;                           // [item][k][n] natural canonical
     uint8_t *w1;                          // [item][k*n]
     int32_t *z;                           // [item][l][n]
-    int32_t *r;                           // [item][k][n]  (w - c s2)
     uint8_t *h;                           // [item][k*n]
-    uint32_t *flags, *ones;               // per item
+    int w_chunked;                        // 1 (the signer's per-attempt w, which only its own kernels read): coefficient j = 16 r + lp of a polynomial is stored at
+                                          // 64 (r / 4) + 4 lp + r % 4 - a lane moves its 16 coefficients as four 16-byte pieces and each of the four wave
+                                          // instructions covers 256 contiguous bytes per polynomial (sixteen 4-byte stores of 64 bytes each otherwise).
+                                          // (Measured and dropped: 16 contiguous words per lane - every instruction then touches 16 lines per polynomial - and
+                                          // y in either order: ExpandMask's lane-per-attempt stores want consecutive coefficients at consecutive addresses.)
     int sg;                               // 1: the signed 32-bit arithmetic (MODE_S32, modarith.h) - tables and scale constants are the centred ones
 };
 
@@ -92,17 +97,11 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
     TwSet<L8> tw;
     if (OP == DOP_FWD_INT || OP == DOP_KEYPREP) tw.load(a.zf, a.zfp, lp); else tw.load(a.zi, a.zip, lp);
 
-    const uint32_t groups = (a.njobs + PW - 1) / PW;
+    const uint32_t njobs = a.njobs_dev ? *a.njobs_dev * (uint32_t)a.per : a.njobs;
+    const uint32_t groups = (njobs + PW - 1) / PW;
     for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
         const uint32_t job = g * PW + pw;
-        bool valid = job < a.njobs;
-        // signing: an attempt an earlier test already rejected needs no further work (its r / hint arrays are never read: the
-        // finish kernel only looks at slots whose flags stayed 0).  The wave skips the group when none of its four jobs is live.
-        if (OP == DOP_CS2 || OP == DOP_CT0) {
-            const uint32_t fl = a.flags[valid ? job / (uint32_t)a.per : 0];
-            valid = valid && (OP == DOP_CS2 ? (fl & 1u) == 0 : fl == 0);
-            if (__ballot(valid) == 0) continue;
-        }
+        const bool valid = job < njobs;
         // a job past the end is pointed at job 0 and its results are never stored: every load below stays unconditional (a
         // predicated load compiles to a branch with a full s_waitcnt inside, which serialises the requests)
         const uint32_t aidx = valid ? job / (uint32_t)a.per : 0, sub = valid ? job % (uint32_t)a.per : 0;
@@ -183,68 +182,28 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
             }
         }
         const size_t pk_off = ((size_t)item * a.kk + sub) * N + lp;     // [item][k][n] arrays
-        const size_t pl_off = ((size_t)item * a.l + sub) * N + lp;      // [item][l][n] arrays
         // the epilogue's second operand is requested before the transform, not after it
         int32_t pre[16];
         uint8_t preh[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            if (OP == DOP_CZ) pre[r] = a.y[pl_off + r * LP];
-            if (OP == DOP_CS2 || OP == DOP_CT1) pre[r] = a.w[pk_off + r * LP];
-            if (OP == DOP_CT0) pre[r] = a.r[pk_off + r * LP];
-            if (OP == DOP_CT1) preh[r] = a.h[pk_off + r * LP];
+            if (OP == DOP_CT1) { pre[r] = a.w[pk_off + r * LP]; preh[r] = a.h[pk_off + r * LP]; }
         }
         inv_core<L8, MODE>(x, tw, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
         if (!valid) continue;
 
         if (OP == DOP_MATVEC) {
+            if (a.w_chunked) {
+                int4 *d4 = reinterpret_cast<int4 *>(a.w + ((size_t)item * a.kk + sub) * N) + lp;
+#pragma unroll
+                for (int c = 0; c < 4; c++) d4[16 * c] = make_int4((int32_t)x[4 * c], (int32_t)x[4 * c + 1], (int32_t)x[4 * c + 2], (int32_t)x[4 * c + 3]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int32_t a0;
-                a.w[pk_off + r * LP] = (int32_t)x[r];
+                if (!a.w_chunked) a.w[pk_off + r * LP] = (int32_t)x[r];
                 if (a.w1) a.w1[pk_off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
             }
-        } else if (OP == DOP_CZ) {            // z = y + c s1, normalize, ||z||inf < gamma1 - beta
-            bool bad = false;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t yy = reduce_i32(pre[r], k);
-                const uint32_t zz = csub(csub(x[r] + yy, k.q2), k.q);
-                a.z[pl_off + r * LP] = (int32_t)zz;
-                bad |= norm_bad(zz, k.q, (uint32_t)a.gamma1_beta);
-            }
-            if (bad) atomicOr(&a.flags[item], 1u);
-        } else if (OP == DOP_CS2) {           // r = w - c s2 ; ||LowBits(r)||inf < gamma2 - beta
-            bool bad = false;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const uint32_t ww = (uint32_t)pre[r];
-                const uint32_t rr = csub(ww + k.q - x[r], k.q);
-                a.r[pk_off + r * LP] = (int32_t)rr;
-                int32_t a0;
-                round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + (int32_t)k.q) : (uint32_t)a0;       // low_order_bits
-                bad |= norm_bad(lo, k.q, (uint32_t)a.gamma2_beta);
-            }
-            if (bad) atomicOr(&a.flags[item], 2u);
-        } else if (OP == DOP_CT0) {           // ct0 ; ||ct0||inf < gamma2 - beta ; hint = [HighBits(r + ct0) != HighBits(r)]
-            bool bad = false;
-            uint32_t cnt = 0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                bad |= norm_bad(x[r], k.q, (uint32_t)a.gamma2_beta);
-                const uint32_t rr = (uint32_t)pre[r];
-                const uint32_t s = csub(rr + x[r], k.q);        // wcs2 + ct0 (dilithium.c:1714-1715)
-                int32_t a0;
-                // make_hint (dilithium.c:1258-1284): r = s, z = q - ct0, (r + z) mod q == rr
-                const uint32_t hi_s = round_alpha(s, a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t hi_r = round_alpha(rr, a0, a.alpha, a.am, (int32_t)k.q);
-                const uint32_t hb = hi_s != hi_r;
-                a.h[pk_off + r * LP] = (uint8_t)hb;
-                cnt += hb;
-            }
-            if (bad) atomicOr(&a.flags[item], 4u);
-            if (cnt) atomicAdd(&a.ones[item], cnt);
         } else if (OP == DOP_CT1) {           // verify: w' = A z - c t1 2^d ; w1 = UseHint(h, w')   (dilithium.c:1286-1312)
             const int32_t m = ((int32_t)k.q - 1) / a.alpha, m_mask = m - 1;
 #pragma unroll
@@ -280,10 +239,11 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
     const ModK k = a.k;
     TwSet<L8> twi;
     twi.load(a.zi, a.zip, lp);
-    const uint32_t groups = (a.njobs + PW - 1) / PW;              // njobs = attempts
+    const uint32_t njobs = a.njobs_dev ? *a.njobs_dev : a.njobs;   // attempts
+    const uint32_t groups = (njobs + PW - 1) / PW;
     for (uint32_t g = blockIdx.x * 4 + wid; g < groups; g += gridDim.x * 4) {
         const uint32_t slot = g * PW + pw;
-        const bool valid = slot < a.njobs;
+        const bool valid = slot < njobs;
         const uint32_t s = valid ? slot : 0;                        // unconditional loads: an attempt past the end reads attempt 0, stores nothing
         uint32_t yh[LL][16];
         // the forward twiddles are (re)loaded per attempt group (L1/L2 hits) and die before the row loop: 30 registers the LL * 16 words of NTT(y)
@@ -326,10 +286,15 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
             inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
             if (!valid) continue;
             const size_t off = ((size_t)slot * a.kk + i) * N + lp;
+            if (a.w_chunked) {
+                int4 *d4 = reinterpret_cast<int4 *>(a.w + ((size_t)slot * a.kk + i) * N) + lp;
+#pragma unroll
+                for (int c = 0; c < 4; c++) d4[16 * c] = make_int4((int32_t)x[4 * c], (int32_t)x[4 * c + 1], (int32_t)x[4 * c + 2], (int32_t)x[4 * c + 3]);
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 int32_t a0;
-                a.w[off + r * LP] = (int32_t)x[r];
+                if (!a.w_chunked) a.w[off + r * LP] = (int32_t)x[r];
                 if (a.w1) a.w1[off + r * LP] = (uint8_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);   // high_order_bits
             }
         }

@@ -1,6 +1,10 @@
-"""One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls]` runs one warm-up call and `calls` timed calls of
+"""One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls] [signature file]` runs one warm-up call and `calls`
+timed calls of
    dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | polymul | cdt
-on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call."""
+on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call.
+A verify leg never signs in the profiled process: given a signature file that does not exist yet it signs, writes the file and stops (the unprofiled
+preparation run); given one that exists it loads the signatures and only verifies - so a counter pass over the leg contains the leg's kernels alone
+(round 2's verify figures had the signing kernels mixed in: VERDICT r02 weak 1a)."""
 import sys, os, time, json
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import numpy as np
@@ -12,6 +16,20 @@ from tests.golden_io import load_golden
 def main():
     leg = sys.argv[1]
     calls = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    sigfile = sys.argv[3] if len(sys.argv) > 3 else None
+
+    def sigs_from(sign):
+        """signatures for a verify leg: from the file when it is there, else signed here (and written + exit when a file name was given)"""
+        if sigfile and os.path.exists(sigfile):
+            z = np.load(sigfile)
+            return torch.from_numpy(z['sigs']).cuda(), torch.from_numpy(z['siglens']).cuda()
+        out = sign()
+        torch.cuda.synchronize()
+        if sigfile:
+            np.savez(sigfile, sigs=out[0].cpu().numpy(), siglens=out[1].cpu().numpy())
+            print(json.dumps({'leg': leg, 'prepared': sigfile}), flush=True)
+            sys.exit(0)
+        return out[0], out[1]
     eng = Engine(0)
     g = torch.Generator(device='cuda'); g.manual_seed(3)
     if leg.startswith('dil'):
@@ -19,11 +37,14 @@ def main():
         d = eng.dilithium(G[f'{tag}_params'])
         d.set_privkey(*(G[f'{tag}_{x}'] for x in ('s1', 's2', 't', 'K', 'tr', 'Ahat'))); d.set_pubkey(G[f'{tag}_t1'], G[f'{tag}_rho'], G[f'{tag}_Ahat'])
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
-        sigs, siglens, _ = d.sign(msgs, fixed_len=64); torch.cuda.synchronize()
         made = 1
-        fn = (lambda: d.sign(msgs, fixed_len=64)) if leg == 'dil_sign' else (lambda: d.verify(msgs, sigs, siglens, fixed_len=64))
-        if leg == 'dil_verify':
-            fn(); made = 1                       # the sign above is a different leg: counted by the caller through kernel names
+        if leg == 'dil_sign':
+            d.sign(msgs, fixed_len=64); torch.cuda.synchronize()
+            fn = lambda: d.sign(msgs, fixed_len=64)
+        elif leg == 'dil_verify':
+            sigs, siglens = sigs_from(lambda: d.sign(msgs, fixed_len=64))
+            fn = lambda: d.verify(msgs, sigs, siglens, fixed_len=64)
+            fn()
         if leg in ('dil_verify_keys', 'dil_sign_keys'):          # a key pair per message (generated on the device from seeds)
             seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
             s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, int(G[f'{tag}_eta_bits'][0]))
@@ -36,10 +57,13 @@ def main():
         b = eng.bliss(G['bliss1_params']); b.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * 2048 + 64), dtype=torch.int32, device='cuda', generator=g)
-        sigs, siglens, _, _ = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
         made = 1
-        fn = (lambda: b.sign(msgs, tapes, fixed_len=64)) if leg == 'bliss_sign' else (lambda: b.verify(msgs, sigs, siglens, fixed_len=64))
-        if leg == 'bliss_verify':
+        if leg == 'bliss_sign':
+            b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+            fn = lambda: b.sign(msgs, tapes, fixed_len=64)
+        else:
+            sigs, siglens = sigs_from(lambda: b.sign(msgs, tapes, fixed_len=64))
+            fn = lambda: b.verify(msgs, sigs, siglens, fixed_len=64)
             fn()
     elif leg.startswith('falcon'):
         G = load_golden('falcon_ref.txt'); tag, B = 'falcon2', 8192
@@ -47,10 +71,13 @@ def main():
         f.set_privkey(np.asarray(G[f'{tag}_sk'], dtype=np.int64).view(np.float64)); f.set_pubkey(G[f'{tag}_h'])
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
-        sigs, siglens, _ = f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
         made = 1
-        fn = (lambda: f.sign(msgs, tapes, fixed_len=64)) if leg == 'falcon_sign' else (lambda: f.verify(msgs, sigs, siglens, fixed_len=64))
-        if leg == 'falcon_verify':
+        if leg == 'falcon_sign':
+            f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+            fn = lambda: f.sign(msgs, tapes, fixed_len=64)
+        else:
+            sigs, siglens = sigs_from(lambda: f.sign(msgs, tapes, fixed_len=64))
+            fn = lambda: f.verify(msgs, sigs, siglens, fixed_len=64)
             fn()
     elif leg == 'kyber_encaps':
         G = load_golden('kyber_ref.txt'); B = int(os.environ.get("KY_B", "65536"))
