@@ -266,6 +266,152 @@ static void outer_dilithium(int set)
     safecrypto_destroy(sc);
 }
 
+/* outer boundary, the other signature schemes: sc_hip_glue_<scheme>_sign / _verify against safecrypto_sign / safecrypto_verify from the same CSPRNG state,
+ * and the batched entries */
+typedef SINT32 (*sign_fn)(safecrypto_t *, const UINT8 *, size_t, UINT8 **, size_t *);
+typedef SINT32 (*verify_fn)(safecrypto_t *, const UINT8 *, size_t, const UINT8 *, size_t);
+static void outer_signature(const char *name, sc_scheme_e scheme, int set, UINT32 flag0, sign_fn gsign, verify_fn gverify, int tamper_must_fail)
+{
+    char label[200], detail[256];
+    UINT32 flags[2] = { flag0, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) { snprintf(label, sizeof label, "outer %s: create/keygen", name); report(label, 0, ""); return; }
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    int same = 1, cross = 1, bufs = 1, made = 0;
+    sm_state = 0x0ce7e500ULL + (uint64_t)scheme * 16 + set;
+    for (int m = 0; m < NMSG; m++) {
+        uint8_t msg[96], seed[32];
+        const size_t mlen = (m == 0) ? 1 : (m == 1) ? 96 : 64;
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        UINT8 *s_ref = NULL, *s_hip = NULL; size_t l_ref = 0, l_hip = 0;
+        prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32);
+        swap_prng(sc, NULL, p1);
+        const int r_ref = safecrypto_sign(sc, msg, mlen, &s_ref, &l_ref);
+        swap_prng(sc, NULL, p2);
+        const int r_hip = gsign(sc, msg, mlen, &s_hip, &l_hip);
+        swap_prng(sc, NULL, orig);
+        prng_destroy(p1); prng_destroy(p2);
+        if (r_ref != r_hip) same = 0;                                     /* Falcon: the reference fails on its norm bound, so must the engine */
+        if (SC_FUNC_SUCCESS == r_ref && SC_FUNC_SUCCESS == r_hip) {
+            made++;
+            if (l_ref != l_hip || memcmp(s_ref, s_hip, l_ref)) same = 0;
+            if (SC_FUNC_SUCCESS != gverify(sc, msg, mlen, s_ref, l_ref)) cross = 0;            /* reference signature, engine verifier */
+            if (SC_FUNC_SUCCESS != safecrypto_verify(sc, msg, mlen, s_hip, l_hip)) cross = 0;   /* engine signature, reference verifier */
+            s_hip[l_hip / 3] ^= 0x04;
+            const int v_ref = safecrypto_verify(sc, msg, mlen, s_hip, l_hip), v_hip = gverify(sc, msg, mlen, s_hip, l_hip);
+            if ((v_ref == SC_FUNC_SUCCESS) != (v_hip == SC_FUNC_SUCCESS)) cross = 0;
+            if (tamper_must_fail && v_hip == SC_FUNC_SUCCESS) cross = 0;
+            if (m == 2) {                                                  /* caller-supplied and undersized buffers */
+                UINT8 *own = malloc(l_ref + 64); size_t ol = l_ref + 64;
+                prng_ctx_t *p3 = seeded_prng(seed, 32);
+                swap_prng(sc, NULL, p3);
+                if (SC_FUNC_SUCCESS != gsign(sc, msg, mlen, &own, &ol) || ol != l_ref || memcmp(own, s_ref, ol)) bufs = 0;
+                ol = 8;
+                if (SC_FUNC_SUCCESS == gsign(sc, msg, mlen, &own, &ol)) bufs = 0;
+                swap_prng(sc, NULL, orig);
+                prng_destroy(p3);
+                free(own);
+            }
+        }
+        free(s_ref); free(s_hip);
+    }
+    snprintf(detail, sizeof detail, "%d of %d messages signed by both", made, NMSG);
+    snprintf(label, sizeof label, "outer boundary, %s: sc_hip_glue sign == safecrypto_sign from the same CSPRNG state", name); report(label, same && made >= NMSG - 2, detail);
+    snprintf(label, sizeof label, "outer boundary, %s: cross verification and tampered signatures", name); report(label, cross, "");
+    snprintf(label, sizeof label, "outer boundary, %s: caller-supplied and undersized buffers", name); report(label, bufs, "");
+    /* a batch: tapes drawn from one CSPRNG in message order; every signature verifies under the reference, message 0 equals the one-message call from the same state */
+    enum { B = 192 };
+    const size_t cap = sc_hip_glue_sig_bytes(sc), row = (cap + 15) & ~(size_t)15;
+    UINT8 *msgs = malloc(B * 64), *sigs = calloc(B, row ? row : 1);
+    UINT32 *mlens = malloc(B * 4), *siglens = calloc(B, 4), *st = calloc(B, 4), *verd = malloc(B * 4);
+    for (size_t i = 0; i < B * 64; i++) msgs[i] = (uint8_t)splitmix64();
+    for (int i = 0; i < B; i++) mlens[i] = (i == 1) ? 1 : 64;
+    uint8_t seed[32];
+    for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+    const unsigned attempts = (SC_SCHEME_SIG_RING_TESLA == scheme) ? 24 : 8;
+    prng_ctx_t *pb = seeded_prng(seed, 32), *p1 = seeded_prng(seed, 32);
+    swap_prng(sc, NULL, pb);
+    double t0 = now();
+    const int rc = sc_hip_glue_sign_batch(sc, B, msgs, 64, mlens, attempts, sigs, row, siglens, st);
+    const double t_hip = now() - t0;
+    swap_prng(sc, NULL, p1);
+    UINT8 *s0 = NULL; size_t l0 = 0;
+    const int r0 = gsign(sc, msgs, mlens[0], &s0, &l0);
+    swap_prng(sc, NULL, orig);
+    prng_destroy(pb); prng_destroy(p1);
+    int ok = (rc == SC_FUNC_SUCCESS), signed_ = 0;
+    for (int i = 0; i < B && ok; i++) {
+        if (st[i] != 1) continue;
+        signed_++;
+        if (SC_FUNC_SUCCESS != safecrypto_verify(sc, msgs + 64 * i, mlens[i], sigs + (size_t)i * row, siglens[i])) ok = 0;
+    }
+    if (ok && st[0] == 1 && (r0 != SC_FUNC_SUCCESS || l0 != siglens[0] || memcmp(s0, sigs, l0))) ok = 0;
+    snprintf(detail, sizeof detail, "%d of %d signed (%.1f ms, host buffers), all verified by safecrypto_verify", signed_, (int)B, t_hip * 1e3);
+    snprintf(label, sizeof label, "outer boundary, %s: a batch of %d through sc_hip_glue_sign_batch", name, (int)B); report(label, ok && signed_ >= B - B / 8, detail);
+    int vok = (SC_FUNC_SUCCESS == sc_hip_glue_verify_batch(sc, B, msgs, 64, mlens, sigs, row, siglens, verd));
+    for (int i = 0; i < B && vok; i++) if ((st[i] == 1) != (verd[i] == 0)) vok = 0;
+    snprintf(label, sizeof label, "outer boundary, %s: the batch verifies through sc_hip_glue_verify_batch", name); report(label, vok, "");
+    free(s0); free(msgs); free(sigs); free(mlens); free(siglens); free(st); free(verd);
+    sc_hip_glue_forget(sc);
+    safecrypto_destroy(sc);
+}
+
+/* outer boundary, Kyber: encapsulation / decapsulation rows; prng_mem consumption is exact, so a batch equals the same number of sequential calls */
+static void outer_kyber(int set)
+{
+    char label[200], detail[256];
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+    if (!sc || SC_FUNC_SUCCESS != safecrypto_keygen(sc)) { report("outer kyber: create/keygen", 0, ""); return; }
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    enum { B = 256 };
+    const size_t ctb = sc_hip_glue_kyber_ct_bytes(sc), row = (ctb + 15) & ~(size_t)15;
+    uint8_t seed[32];
+    sm_state = 0x0c1be700ULL + set;
+    for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+    prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32), *p3 = seeded_prng(seed, 32);
+    UINT8 *cts = calloc(B, row ? row : 1), *keys = calloc(B, 32), *keys2 = calloc(B, 32);
+    swap_prng(sc, NULL, p1);
+    double t0 = now();
+    int rc = sc_hip_glue_kyber_encapsulation_batch(sc, B, cts, row, keys);
+    const double t_hip = now() - t0;
+    int same = (rc == SC_FUNC_SUCCESS && ctb > 0), dec = 1, one = 1;
+    swap_prng(sc, NULL, p2);
+    t0 = now();
+    for (int i = 0; i < B && same; i++) {
+        UINT8 *c = NULL, *k = NULL, *k2 = NULL; size_t cl = 0, kl = 0, k2l = 0;
+        if (SC_FUNC_SUCCESS != safecrypto_encapsulation(sc, &c, &cl, &k, &kl) || cl != ctb || kl != 32 || memcmp(c, cts + (size_t)i * row, cl) || memcmp(k, keys + 32 * i, 32)) same = 0;
+        if (same && i < 8) {                                              /* the reference decapsulates the engine's ciphertext; the engine the reference's */
+            if (SC_FUNC_SUCCESS != safecrypto_decapsulation(sc, cts + (size_t)i * row, ctb, &k2, &k2l) || k2l != 32 || memcmp(k2, k, 32)) dec = 0;
+            UINT8 *k3 = NULL; size_t k3l = 0;
+            if (SC_FUNC_SUCCESS != sc_hip_glue_kyber_decapsulation(sc, c, cl, &k3, &k3l) || k3l != 32 || memcmp(k3, k, 32)) dec = 0;
+            free(k3);
+        }
+        free(c); free(k); free(k2);
+    }
+    const double t_ref = now() - t0;
+    swap_prng(sc, NULL, p3);
+    {   /* the one-value row with both buffer conventions */
+        UINT8 *c = NULL, *k = NULL; size_t cl = 0, kl = 0;
+        if (SC_FUNC_SUCCESS != sc_hip_glue_kyber_encapsulation(sc, &c, &cl, &k, &kl) || cl != ctb || kl != 32 || memcmp(c, cts, cl) || memcmp(k, keys, 32)) one = 0;
+        UINT8 small[8], *ps = small; size_t sl = sizeof small;
+        if (one && SC_FUNC_SUCCESS == sc_hip_glue_kyber_decapsulation(sc, c, cl, &ps, &sl)) one = 0;     /* 8-byte key buffer: refused */
+        free(c); free(k);
+    }
+    swap_prng(sc, NULL, orig);
+    rc = sc_hip_glue_kyber_decapsulation_batch(sc, B, cts, row, keys2);
+    if (rc != SC_FUNC_SUCCESS || memcmp(keys, keys2, 32 * B)) dec = 0;
+    snprintf(detail, sizeof detail, "%d values: engine %.1f ms (host buffers, first call), reference %.1f ms", (int)B, t_hip * 1e3, t_ref * 1e3);
+    snprintf(label, sizeof label, "outer boundary, Kyber set %d: a batch of %d == %d calls of safecrypto_encapsulation (ciphertexts and keys)", set, (int)B, (int)B); report(label, same, detail);
+    snprintf(label, sizeof label, "outer boundary, Kyber set %d: decapsulation, both directions and the batch", set); report(label, dec, "");
+    snprintf(label, sizeof label, "outer boundary, Kyber set %d: sc_hip_glue_kyber_encapsulation == the batch's first value; undersized key buffer refused", set); report(label, one, "");
+    prng_destroy(p1); prng_destroy(p2); prng_destroy(p3);
+    free(cts); free(keys); free(keys2);
+    sc_hip_glue_forget(sc);
+    safecrypto_destroy(sc);
+}
+
 int main(int argc, char **argv)
 {
     (void)argc; (void)argv;
@@ -282,6 +428,10 @@ int main(int argc, char **argv)
     keygen_scheme("Kyber KEM set 1", SC_SCHEME_KEM_KYBER, 1, SC_FLAG_NONE);
     keygen_scheme("BLISS-B-I", SC_SCHEME_SIG_BLISS, 1, SC_FLAG_0_SAMPLE_64BIT);
     outer_dilithium(3);
+    outer_signature("BLISS-B-I", SC_SCHEME_SIG_BLISS, 1, SC_FLAG_0_SAMPLE_64BIT, sc_hip_glue_bliss_b_sign, sc_hip_glue_bliss_b_verify, 1);
+    outer_signature("ring-TESLA set 0", SC_SCHEME_SIG_RING_TESLA, 0, SC_FLAG_NONE, sc_hip_glue_ring_tesla_sign, sc_hip_glue_ring_tesla_verify, 0);
+    outer_signature("Falcon-512", SC_SCHEME_SIG_FALCON, 0, SC_FLAG_NONE, sc_hip_glue_falcon_sign, sc_hip_glue_falcon_verify, 1);
+    outer_kyber(1);
     printf("{\"summary\": true, \"checks\": %d, \"failed\": %d, \"vtable_errors\": %lu, \"seconds\": %.2f}\n", g_checks, g_fail, sc_hip_vtable_errors(), now() - t0);
     return g_fail ? 1 : 0;
 }

@@ -11,6 +11,14 @@
 #include "utils/crypto/prng.h"
 #include "schemes/sig/dilithium/dilithium.h"
 #include "schemes/sig/dilithium/dilithium_params.h"
+#include "schemes/sig/bliss_b/bliss_b.h"
+#include "schemes/sig/bliss_b/bliss_params.h"
+#include "schemes/sig/ring_tesla/ring_tesla.h"
+#include "schemes/sig/ring_tesla/ring_tesla_params.h"
+#include "schemes/sig/falcon/falcon.h"
+#include "schemes/sig/falcon/falcon_params.h"
+#include "schemes/kem/kyber/kyber_kem.h"
+#include "schemes/kem/kyber/kyber_kem_params.h"
 
 #include "sc_hip.h"
 #include "sc_hip_vtable.h"
@@ -104,7 +112,8 @@ void sc_hip_glue_detach(sc_hip_glue_t *g)
 
 /* a maintainer would add one pointer to safecrypto_t; from outside the library a small registry does the same job */
 #define GLUE_MAX 16
-static struct { safecrypto_t *sc; sc_hip_ctx_t *ctx; sc_hip_dilithium_t *dil; int have_priv, have_pub; } g_reg[GLUE_MAX];
+static struct { safecrypto_t *sc; sc_hip_ctx_t *ctx; sc_hip_dilithium_t *dil; int have_priv, have_pub;
+                sc_hip_bliss_t *bliss; sc_hip_tesla_t *tesla; sc_hip_falcon_t *falcon; sc_hip_kyber_t *kyber; } g_reg[GLUE_MAX];
 
 static int reg_find(safecrypto_t *sc, int create)
 {
@@ -124,6 +133,10 @@ void sc_hip_glue_forget(safecrypto_t *sc)
     const int i = reg_find(sc, 0);
     if (i < 0) return;
     if (g_reg[i].dil) sc_hip_dilithium_destroy(g_reg[i].dil);
+    if (g_reg[i].bliss) sc_hip_bliss_destroy(g_reg[i].bliss);
+    if (g_reg[i].tesla) sc_hip_tesla_destroy(g_reg[i].tesla);
+    if (g_reg[i].falcon) sc_hip_falcon_destroy(g_reg[i].falcon);
+    if (g_reg[i].kyber) sc_hip_kyber_destroy(g_reg[i].kyber);
     if (g_reg[i].ctx) sc_hip_ctx_destroy(g_reg[i].ctx);
     memset(&g_reg[i], 0, sizeof g_reg[i]);
 }
@@ -235,4 +248,295 @@ SINT32 sc_hip_glue_dilithium_verify(safecrypto_t *sc, const UINT8 *m, size_t m_l
     free(row);
     if (SC_FUNC_SUCCESS != rc) return SC_FUNC_FAILURE;
     return verdict == 0 ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+/* ---- outer boundary: BLISS-B, ring-TESLA, Falcon, Kyber --------------------------------------------------------------------------------------- */
+
+/* hands `len` bytes to the caller under the packer's buffer rules (packer.c:142-176): *ret == NULL or *retlen == 0 -> malloc'ed for the caller */
+static SINT32 emit(const UINT8 *buf, size_t len, UINT8 **ret, size_t *retlen)
+{
+    if (NULL == ret || NULL == retlen) return SC_FUNC_FAILURE;
+    if (NULL == *ret || 0 == *retlen) {
+        UINT8 *p = malloc(len ? len : 1);
+        if (NULL == p) return SC_FUNC_FAILURE;
+        memcpy(p, buf, len);
+        *ret = p;
+    } else {
+        if (*retlen < len) return SC_FUNC_FAILURE;
+        memcpy(*ret, buf, len);
+    }
+    *retlen = len;
+    return SC_FUNC_SUCCESS;
+}
+
+static int reg_ctx(safecrypto_t *sc)
+{
+    const int i = reg_find(sc, 1);
+    if (i < 0) return -1;
+    if (NULL == g_reg[i].ctx && SC_HIP_SUCCESS != sc_hip_ctx_create(0, &g_reg[i].ctx)) return -1;
+    return i;
+}
+
+/* engine handles, keys loaded from the context on first use */
+static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
+{
+    if (NULL == sc || SC_SCHEME_SIG_BLISS != sc->scheme || NULL == sc->bliss || NULL == sc->pubkey || NULL == sc->pubkey->key) return NULL;
+    if (SC_ENTROPY_NONE != sc->coding_signature.type) return NULL;
+    if (need_priv && (NULL == sc->sc_gauss || CDF_GAUSSIAN_SAMPLING != sc->sampling || SAMPLING_64BIT != sc->sc_gauss->precision)) return NULL;
+    if (need_priv && (NULL == sc->privkey || NULL == sc->privkey->key)) return NULL;
+    const int i = reg_ctx(sc);
+    if (i < 0) return NULL;
+    if (NULL == g_reg[i].bliss || (need_priv && !g_reg[i].have_priv)) {
+        const bliss_set_t *P = sc->bliss->params;
+        sc_hip_bliss_params_t hp;
+        memset(&hp, 0, sizeof hp);
+        hp.n = P->n; hp.q = P->q; hp.q_bits = P->q_bits; hp.n_bits = P->n_bits; hp.d = P->d; hp.p = P->p; hp.kappa = P->kappa; hp.b_inf = P->b_inf;
+        hp.b_l2 = (int32_t)P->b_l2; hp.z1_bits = P->z1_bits; hp.z2_bits = P->z2_bits; hp.set = P->set; hp.sigma = P->sig; hp.m = P->m; hp.tail = 13.42f;   /* bliss_b.c:342-344 */
+        if (NULL == g_reg[i].bliss && SC_HIP_SUCCESS != sc_hip_bliss_create(g_reg[i].ctx, &hp, &g_reg[i].bliss)) return NULL;
+        const SINT16 *priv = (sc->privkey && sc->privkey->key) ? (const SINT16 *)sc->privkey->key : NULL;
+        if (SC_HIP_SUCCESS != sc_hip_bliss_set_key(g_reg[i].bliss, priv, priv ? priv + P->n : NULL, (const SINT16 *)sc->pubkey->key)) return NULL;
+        g_reg[i].have_priv = priv != NULL; g_reg[i].have_pub = 1;
+    }
+    return g_reg[i].bliss;
+}
+
+static sc_hip_tesla_t *tesla_handle(safecrypto_t *sc)
+{
+    if (NULL == sc || SC_SCHEME_SIG_RING_TESLA != sc->scheme || NULL == sc->ring_tesla) return NULL;
+    if (SC_ENTROPY_NONE != sc->coding_signature.type) return NULL;
+    const int i = reg_ctx(sc);
+    if (i < 0) return NULL;
+    if (NULL == g_reg[i].tesla) {
+        const ring_tesla_set_t *P = sc->ring_tesla->params;
+        sc_hip_tesla_params_t hp = { (int32_t)P->n, (int32_t)P->n_bits, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->b, (int32_t)P->b_bits, (int32_t)P->omega,
+                                     (int32_t)P->d, (int32_t)P->bound, (int32_t)P->u, (int32_t)P->set, 0 };
+        if (SC_HIP_SUCCESS != sc_hip_tesla_create(g_reg[i].ctx, &hp, &g_reg[i].tesla)) return NULL;
+        const SINT16 *priv = (sc->privkey && sc->privkey->key) ? (const SINT16 *)sc->privkey->key : NULL;
+        const SINT32 *pub = (sc->pubkey && sc->pubkey->key) ? (const SINT32 *)sc->pubkey->key : NULL;
+        const size_t n = P->n;
+        if (SC_HIP_SUCCESS != sc_hip_tesla_set_key(g_reg[i].tesla, 0 == P->set ? a1_0 : a1_1, 0 == P->set ? a2_0 : a2_1, priv, priv ? priv + n : NULL,
+                                                   priv ? priv + 2 * n : NULL, pub, pub ? pub + n : NULL)) { sc_hip_tesla_destroy(g_reg[i].tesla); g_reg[i].tesla = NULL; return NULL; }
+        g_reg[i].have_priv = priv != NULL; g_reg[i].have_pub = pub != NULL;
+    }
+    return g_reg[i].tesla;
+}
+
+static sc_hip_falcon_t *falcon_handle(safecrypto_t *sc)
+{
+    if (NULL == sc || SC_SCHEME_SIG_FALCON != sc->scheme || NULL == sc->falcon) return NULL;
+    if (SC_ENTROPY_NONE != sc->coding_signature.type) return NULL;
+    const int i = reg_ctx(sc);
+    if (i < 0) return NULL;
+    if (NULL == g_reg[i].falcon) {
+        const falcon_set_t *P = sc->falcon->params;
+        sc_hip_falcon_params_t hp;
+        memset(&hp, 0, sizeof hp);
+        hp.n = P->n; hp.q = P->q; hp.q_bits = P->q_bits; hp.n_bits = P->n_bits; hp.set = P->set; hp.bd = P->bd;
+        if (SC_HIP_SUCCESS != sc_hip_falcon_create(g_reg[i].ctx, &hp, &g_reg[i].falcon)) return NULL;
+        int ok = 1;
+        if (sc->privkey && sc->privkey->key && sc->falcon->sk) { ok = SC_HIP_SUCCESS == sc_hip_falcon_set_privkey(g_reg[i].falcon, (const double *)sc->falcon->sk); g_reg[i].have_priv = ok; }
+        if (ok && sc->pubkey && sc->pubkey->key) { ok = SC_HIP_SUCCESS == sc_hip_falcon_set_pubkey(g_reg[i].falcon, (const SINT16 *)sc->pubkey->key); g_reg[i].have_pub = ok; }
+        if (!ok) { sc_hip_falcon_destroy(g_reg[i].falcon); g_reg[i].falcon = NULL; return NULL; }
+    }
+    return g_reg[i].falcon;
+}
+
+static sc_hip_kyber_t *kyber_handle(safecrypto_t *sc, int need_priv)
+{
+    if (NULL == sc || SC_SCHEME_KEM_KYBER != sc->scheme || NULL == sc->kyber || NULL == sc->pubkey || NULL == sc->pubkey->key) return NULL;
+    if (SC_ENTROPY_NONE != sc->coding_encryption.type) return NULL;
+    if (need_priv && (NULL == sc->privkey || NULL == sc->privkey->key)) return NULL;
+    const int i = reg_ctx(sc);
+    if (i < 0) return NULL;
+    const kyber_set_t *P = sc->kyber->params;
+    const size_t n = P->n, k = P->k;
+    if (NULL == g_reg[i].kyber) {
+        sc_hip_kyber_params_t hp;
+        memset(&hp, 0, sizeof hp);
+        hp.n = (int32_t)P->n; hp.q = (int32_t)P->q; hp.q_bits = (int32_t)P->q_bits; hp.q_inv = (uint32_t)P->q_inv; hp.q_norm = (int32_t)P->q_norm; hp.k = (int32_t)P->k;
+        hp.eta = (int32_t)P->eta; hp.d_u = (int32_t)P->d_u; hp.d_v = (int32_t)P->d_v; hp.d_t = (int32_t)P->d_t; hp.set = (int32_t)P->set;
+        if (SC_HIP_SUCCESS != sc_hip_kyber_create(g_reg[i].ctx, &hp, &g_reg[i].kyber)) return NULL;
+        /* public key (kyber_kem.c:636-650): t | NTT(t) | rho; the matrix in the order create_rand_product draws it from rho (module_lwe.c:519-547) */
+        const SINT32 *t = (const SINT32 *)sc->pubkey->key, *t_ntt = t + k * n;
+        const UINT8 *rho = (const UINT8 *)(t_ntt + k * n);
+        SINT32 *A = malloc(sizeof(SINT32) * k * k * n);
+        if (NULL == A) return NULL;
+        prng_ctx_t *csprng = create_csprng(sc, rho, 32);
+        for (size_t j = 0; j < k * k; j++) uniform_random_ring_q_csprng(csprng, A + j * n, n, P->q, P->q_bits);
+        prng_destroy(csprng);
+        const int ok = SC_HIP_SUCCESS == sc_hip_kyber_set_pubkey(g_reg[i].kyber, t_ntt, A) && SC_HIP_SUCCESS == sc_hip_kyber_set_kem_pubkey(g_reg[i].kyber, t, rho);
+        free(A);
+        if (!ok) { sc_hip_kyber_destroy(g_reg[i].kyber); g_reg[i].kyber = NULL; return NULL; }
+        g_reg[i].have_pub = 1;
+    }
+    if (need_priv && !g_reg[i].have_priv) {
+        if (SC_HIP_SUCCESS != sc_hip_kyber_set_privkey(g_reg[i].kyber, (const SINT32 *)sc->privkey->key)) return NULL;    /* NTT(s), kyber_kem.c:624-639 */
+        g_reg[i].have_priv = 1;
+    }
+    return g_reg[i].kyber;
+}
+
+size_t sc_hip_glue_sig_bytes(safecrypto_t *sc)
+{
+    if (NULL == sc) return 0;
+    if (SC_SCHEME_SIG_BLISS == sc->scheme) { sc_hip_bliss_t *h = bliss_handle(sc, 0); return h ? sc_hip_bliss_sig_bytes(h) : 0; }
+    if (SC_SCHEME_SIG_RING_TESLA == sc->scheme) { sc_hip_tesla_t *h = tesla_handle(sc); return h ? sc_hip_tesla_sig_bytes(h) : 0; }
+    if (SC_SCHEME_SIG_FALCON == sc->scheme) { sc_hip_falcon_t *h = falcon_handle(sc); return h ? sc_hip_falcon_sig_bytes(h) : 0; }
+    return 0;
+}
+
+size_t sc_hip_glue_tape_words(safecrypto_t *sc, unsigned attempts)
+{
+    if (NULL == sc) return 0;
+    if (SC_SCHEME_SIG_BLISS == sc->scheme && sc->bliss) return sc_hip_bliss_tape_words((int)sc->bliss->params->n, attempts);
+    if (SC_SCHEME_SIG_RING_TESLA == sc->scheme && sc->ring_tesla) return (size_t)sc->ring_tesla->params->n * attempts;     /* n words per attempt (ring_tesla.c:790-800) */
+    if (SC_SCHEME_SIG_FALCON == sc->scheme && sc->falcon) return 4 * (size_t)sc->falcon->params->n;                         /* two prng_64 per tree leaf, no retry */
+    return 0;
+}
+
+SINT32 sc_hip_glue_sign_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens, unsigned attempts,
+                              UINT8 *sigs, size_t sig_stride, UINT32 *siglens, UINT32 *status)
+{
+    if (NULL == sc || NULL == sigs || NULL == siglens || NULL == status || 0 == attempts) return SC_FUNC_FAILURE;
+    if (0 == batch) return SC_FUNC_SUCCESS;
+    size_t words = sc_hip_glue_tape_words(sc, attempts);
+    if (0 == words) return SC_FUNC_FAILURE;
+    words = (words + 3) & ~(size_t)3;
+    UINT32 *tapes = malloc(sizeof(UINT32) * words * batch), *trials = malloc(sizeof(UINT32) * batch);
+    if (NULL == tapes || NULL == trials) { free(tapes); free(trials); return SC_FUNC_FAILURE; }
+    for (size_t i = 0; i < words * batch; i++) tapes[i] = prng_32(sc->prng_ctx[0]);          /* message 0's words first, as successive safecrypto_sign calls would draw them */
+    int rc = SC_HIP_FAILURE;
+    if (SC_SCHEME_SIG_BLISS == sc->scheme) {
+        sc_hip_bliss_t *h = bliss_handle(sc, 1);
+        if (h) rc = sc_hip_bliss_sign_host(h, batch, msgs, msg_stride, mlens, 0, tapes, words, NULL, sigs, sig_stride, siglens, trials, status);
+    } else if (SC_SCHEME_SIG_RING_TESLA == sc->scheme) {
+        sc_hip_tesla_t *h = tesla_handle(sc);
+        if (h) rc = sc_hip_tesla_sign_host(h, batch, msgs, msg_stride, mlens, 0, tapes, words, NULL, sigs, sig_stride, siglens, trials, status);
+    } else if (SC_SCHEME_SIG_FALCON == sc->scheme) {
+        sc_hip_falcon_t *h = falcon_handle(sc);
+        for (size_t i = 0; i < batch; i++) trials[i] = 1;
+        if (h) rc = sc_hip_falcon_sign_host(h, batch, msgs, msg_stride, mlens, 0, tapes, words, NULL, sigs, sig_stride, siglens, status);
+    }
+    if (SC_HIP_SUCCESS == rc) for (size_t i = 0; i < batch; i++) if (1 == status[i]) { sc->stats.sig_num++; sc->stats.sig_num_trials += trials[i]; }
+    memset(tapes, 0, sizeof(UINT32) * words * batch);
+    free(tapes); free(trials);
+    return SC_HIP_SUCCESS == rc ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_verify_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                const UINT8 *sigs, size_t sig_stride, const UINT32 *siglens, UINT32 *verdicts)
+{
+    if (NULL == sc || NULL == sigs || NULL == siglens || NULL == verdicts) return SC_FUNC_FAILURE;
+    int rc = SC_HIP_FAILURE;
+    if (SC_SCHEME_SIG_BLISS == sc->scheme) { sc_hip_bliss_t *h = bliss_handle(sc, 0); if (h) rc = sc_hip_bliss_verify_host(h, batch, msgs, msg_stride, mlens, 0, sigs, sig_stride, siglens, verdicts); }
+    else if (SC_SCHEME_SIG_RING_TESLA == sc->scheme) { sc_hip_tesla_t *h = tesla_handle(sc); if (h) rc = sc_hip_tesla_verify_host(h, batch, msgs, msg_stride, mlens, 0, sigs, sig_stride, siglens, verdicts); }
+    else if (SC_SCHEME_SIG_FALCON == sc->scheme) { sc_hip_falcon_t *h = falcon_handle(sc); if (h) rc = sc_hip_falcon_verify_host(h, batch, msgs, msg_stride, mlens, 0, sigs, sig_stride, siglens, verdicts); }
+    return SC_HIP_SUCCESS == rc ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+/* one message through the batch entry: the reference's loop in miniature - more tape when the attempts drawn for did not suffice */
+static SINT32 sign_one(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen)
+{
+    if (NULL == sigret || NULL == siglen || (NULL == m && m_len > 0)) return SC_FUNC_FAILURE;
+    const size_t cap = sc_hip_glue_sig_bytes(sc);
+    if (0 == cap) return SC_FUNC_FAILURE;
+    const size_t row = (cap + 15) & ~(size_t)15, mrow = (m_len + 8) & ~(size_t)7;
+    UINT8 *tmp = calloc(1, row + mrow);                                   /* signature row | the message in a row of its own (the engine reads whole rows) */
+    if (NULL == tmp) return SC_FUNC_FAILURE;
+    if (m_len) memcpy(tmp + row, m, m_len);
+    UINT32 ml = (UINT32)m_len, sl = 0, st = 0;
+    /* 8 attempts of tape cover all but ~1 signature in 10^4 (BLISS-B accepts ~ 1 in 1.6, ring-TESLA ~ 1 in 3); a short tape is reported, never guessed around */
+    const SINT32 rc = sc_hip_glue_sign_batch(sc, 1, tmp + row, mrow, &ml, SC_SCHEME_SIG_RING_TESLA == sc->scheme ? 24 : 8, tmp, row, &sl, &st);
+    SINT32 out = SC_FUNC_FAILURE;
+    if (SC_FUNC_SUCCESS == rc && 1 == st) out = emit(tmp, sl, sigret, siglen);
+    free(tmp);
+    return out;
+}
+static SINT32 verify_one(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen)
+{
+    if (NULL == sigbuf || (NULL == m && m_len > 0)) return SC_FUNC_FAILURE;
+    const size_t cap = sc_hip_glue_sig_bytes(sc);
+    if (0 == cap) return SC_FUNC_FAILURE;
+    const size_t row = (cap + 15) & ~(size_t)15, mrow = (m_len + 8) & ~(size_t)7;
+    UINT8 *tmp = calloc(1, row + mrow);
+    if (NULL == tmp) return SC_FUNC_FAILURE;
+    memcpy(tmp, sigbuf, siglen < row ? siglen : row);
+    if (m_len) memcpy(tmp + row, m, m_len);
+    UINT32 ml = (UINT32)m_len, sl = (UINT32)siglen, verdict = 1;
+    const SINT32 rc = sc_hip_glue_verify_batch(sc, 1, tmp + row, mrow, &ml, tmp, row, &sl, &verdict);
+    free(tmp);
+    return (SC_FUNC_SUCCESS == rc && 0 == verdict) ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_bliss_b_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen)
+{ return (sc && SC_SCHEME_SIG_BLISS == sc->scheme) ? sign_one(sc, m, m_len, sigret, siglen) : SC_FUNC_FAILURE; }
+SINT32 sc_hip_glue_bliss_b_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen)
+{ return (sc && SC_SCHEME_SIG_BLISS == sc->scheme) ? verify_one(sc, m, m_len, sigbuf, siglen) : SC_FUNC_FAILURE; }
+SINT32 sc_hip_glue_ring_tesla_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen)
+{ return (sc && SC_SCHEME_SIG_RING_TESLA == sc->scheme) ? sign_one(sc, m, m_len, sigret, siglen) : SC_FUNC_FAILURE; }
+SINT32 sc_hip_glue_ring_tesla_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen)
+{ return (sc && SC_SCHEME_SIG_RING_TESLA == sc->scheme) ? verify_one(sc, m, m_len, sigbuf, siglen) : SC_FUNC_FAILURE; }
+SINT32 sc_hip_glue_falcon_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen)
+{ return (sc && SC_SCHEME_SIG_FALCON == sc->scheme) ? sign_one(sc, m, m_len, sigret, siglen) : SC_FUNC_FAILURE; }
+SINT32 sc_hip_glue_falcon_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen)
+{ return (sc && SC_SCHEME_SIG_FALCON == sc->scheme) ? verify_one(sc, m, m_len, sigbuf, siglen) : SC_FUNC_FAILURE; }
+
+size_t sc_hip_glue_kyber_ct_bytes(safecrypto_t *sc)
+{
+    sc_hip_kyber_t *h = kyber_handle(sc, 0);
+    return h ? sc_hip_kyber_ct_bytes(h) : 0;
+}
+
+SINT32 sc_hip_glue_kyber_encapsulation_batch(safecrypto_t *sc, size_t batch, UINT8 *cts, size_t ct_stride, UINT8 *keys)
+{
+    sc_hip_kyber_t *h = kyber_handle(sc, 0);
+    if (NULL == h || NULL == cts || NULL == keys) return SC_FUNC_FAILURE;
+    if (0 == batch) return SC_FUNC_SUCCESS;
+    UINT8 *m = malloc(32 * batch);
+    if (NULL == m) return SC_FUNC_FAILURE;
+    for (size_t i = 0; i < batch; i++) prng_mem(sc->prng_ctx[0], m + 32 * i, 32);             /* kyber_kem.c:856: what each safecrypto_encapsulation call would draw */
+    const int rc = sc_hip_kyber_kem_encaps_host(h, batch, m, cts, ct_stride, keys);
+    memset(m, 0, 32 * batch);
+    free(m);
+    if (SC_HIP_SUCCESS == rc) sc->stats.encapsulate_num += batch;
+    return SC_HIP_SUCCESS == rc ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_kyber_decapsulation_batch(safecrypto_t *sc, size_t batch, const UINT8 *cts, size_t ct_stride, UINT8 *keys)
+{
+    sc_hip_kyber_t *h = kyber_handle(sc, 1);
+    if (NULL == h || NULL == cts || NULL == keys) return SC_FUNC_FAILURE;
+    const int rc = sc_hip_kyber_kem_decaps_host(h, batch, cts, ct_stride, keys);
+    if (SC_HIP_SUCCESS == rc) sc->stats.decapsulate_num += batch;
+    return SC_HIP_SUCCESS == rc ? SC_FUNC_SUCCESS : SC_FUNC_FAILURE;
+}
+
+SINT32 sc_hip_glue_kyber_encapsulation(safecrypto_t *sc, UINT8 **c, size_t *c_len, UINT8 **k, size_t *k_len)
+{
+    const size_t ctb = sc_hip_glue_kyber_ct_bytes(sc);
+    if (0 == ctb || NULL == c || NULL == c_len || NULL == k || NULL == k_len) return SC_FUNC_FAILURE;
+    const size_t row = (ctb + 15) & ~(size_t)15;
+    UINT8 *ct = calloc(1, row), key[32];
+    if (NULL == ct) return SC_FUNC_FAILURE;
+    SINT32 rc = sc_hip_glue_kyber_encapsulation_batch(sc, 1, ct, row, key);
+    if (SC_FUNC_SUCCESS == rc) rc = emit(ct, ctb, c, c_len);
+    if (SC_FUNC_SUCCESS == rc) rc = emit(key, 32, k, k_len);
+    memset(key, 0, sizeof key);
+    free(ct);
+    return rc;
+}
+
+SINT32 sc_hip_glue_kyber_decapsulation(safecrypto_t *sc, const UINT8 *c, size_t c_len, UINT8 **k, size_t *k_len)
+{
+    const size_t ctb = sc_hip_glue_kyber_ct_bytes(sc);
+    if (0 == ctb || NULL == c || NULL == k || NULL == k_len || c_len < ctb) return SC_FUNC_FAILURE;
+    const size_t row = (ctb + 15) & ~(size_t)15;
+    UINT8 *ct = calloc(1, row), key[32];
+    if (NULL == ct) return SC_FUNC_FAILURE;
+    memcpy(ct, c, ctb);
+    SINT32 rc = sc_hip_glue_kyber_decapsulation_batch(sc, 1, ct, row, key);
+    if (SC_FUNC_SUCCESS == rc) rc = emit(key, 32, k, k_len);
+    memset(key, 0, sizeof key);
+    free(ct);
+    return rc;
 }

@@ -34,6 +34,34 @@ SINT32 sc_hip_glue_dilithium_sign_batch(safecrypto_t *sc, size_t batch, const UI
 SINT32 sc_hip_glue_dilithium_verify_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
                                           const UINT8 *sigs, size_t sig_stride, const UINT32 *siglens, UINT32 *verdicts);
 size_t sc_hip_glue_dilithium_sig_max(safecrypto_t *sc);
+/* outer boundary, the other schemes the north star names - the `signing` / `verification` / `encapsulation` / `decapsulation` rows of safecrypto_alg_t
+ * (src/safecrypto_private.h:392-419; table src/safecrypto.c:188-215, dispatch :1108-1139) with exactly those signatures, the whole operation on the
+ * device.  Keys are read where the reference keeps them (sc->privkey->key / sc->pubkey->key: bliss_b.c:1220-1245, ring_tesla.c:703-730, falcon.c:772-790 and
+ * sc->falcon->sk, kyber_kem.c:624-650); randomness is drawn from sc->prng_ctx[0] - the CSPRNG words a signature consumes as prng_32 words (the engine's
+ * "tape"), Kyber's m with the reference's own prng_mem call.  A signature equals safecrypto_sign's for the same CSPRNG state whenever that state has an
+ * empty bit reservoir (a freshly seeded generator - prng_var's left-over bits of an earlier call are invisible from outside prng.c); the generator is
+ * advanced by the whole tape drawn, which for the rejection-sampling signers is more than the reference would have consumed.
+ * Output buffers follow packer.c:142-176 like the Dilithium entries.  Raw coding only (SC_ENTROPY_NONE); BLISS-B needs the 64-bit CDF sampler
+ * (SC_FLAG_0_SAMPLE_64BIT, what the engine implements); anything else returns SC_FUNC_FAILURE and the caller stays on the reference path. */
+SINT32 sc_hip_glue_bliss_b_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
+SINT32 sc_hip_glue_bliss_b_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen);
+SINT32 sc_hip_glue_ring_tesla_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
+SINT32 sc_hip_glue_ring_tesla_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen);
+SINT32 sc_hip_glue_falcon_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
+SINT32 sc_hip_glue_falcon_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen);
+SINT32 sc_hip_glue_kyber_encapsulation(safecrypto_t *sc, UINT8 **c, size_t *c_len, UINT8 **k, size_t *k_len);
+SINT32 sc_hip_glue_kyber_decapsulation(safecrypto_t *sc, const UINT8 *c, size_t c_len, UINT8 **k, size_t *k_len);
+/* the batched forms beside them: `batch` messages of msg_stride bytes under sc's key, a CSPRNG tape per message drawn from sc->prng_ctx[0] in message
+ * order (tape_words each: sc_hip_glue_tape_words()); status[i] as the engine reports it (1 signed; 2 tape too short - ask for more attempts) */
+size_t sc_hip_glue_sig_bytes(safecrypto_t *sc);                                 /* row size of the raw-coded signature (BLISS-B, ring-TESLA, Falcon) */
+size_t sc_hip_glue_tape_words(safecrypto_t *sc, unsigned attempts);             /* CSPRNG words a signature of `attempts` attempts consumes */
+SINT32 sc_hip_glue_sign_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens, unsigned attempts,
+                              UINT8 *sigs, size_t sig_stride, UINT32 *siglens, UINT32 *status);
+SINT32 sc_hip_glue_verify_batch(safecrypto_t *sc, size_t batch, const UINT8 *msgs, size_t msg_stride, const UINT32 *mlens,
+                                const UINT8 *sigs, size_t sig_stride, const UINT32 *siglens, UINT32 *verdicts);
+SINT32 sc_hip_glue_kyber_encapsulation_batch(safecrypto_t *sc, size_t batch, UINT8 *cts, size_t ct_stride, UINT8 *keys);   /* keys [batch][32]; m drawn per value */
+SINT32 sc_hip_glue_kyber_decapsulation_batch(safecrypto_t *sc, size_t batch, const UINT8 *cts, size_t ct_stride, UINT8 *keys);
+size_t sc_hip_glue_kyber_ct_bytes(safecrypto_t *sc);
 /* drops the engine handle cached for this context (keys changed, or before safecrypto_destroy) */
 void sc_hip_glue_forget(safecrypto_t *sc);
 

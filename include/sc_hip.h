@@ -69,9 +69,13 @@ int     sc_hip_plan_n(const sc_hip_plan_t *plan);
 int32_t sc_hip_plan_root(const sc_hip_plan_t *plan);           /* g                         */
 /* host copies of the reference-format tables (w[i]=g^i, r[i]=((q-1)/n) g^i), n entries each */
 int  sc_hip_plan_tables(const sc_hip_plan_t *plan, int32_t *h_w, int32_t *h_r);
-/* selects the modular-multiply code path: 0 = auto (4 where it applies, 3 for other q < 2^14, else 2),
- * 1 = 24-bit Shoup (q < 2^23), 2 = 32-bit Shoup (q < 2^30), 3 = small-modulus multiply-add form (q < 2^14),
- * 4 = the same on signed lazy residues (n = 256 and 36 q^2 < 2^31, i.e. q = 7681).  For measurement; results are identical. */
+/* selects the modular-multiply code path (csrc/modarith.h); for measurement and tests - every path returns the same canonical values:
+ *   1 = 24-bit Shoup products (q < 2^23)                     2 = 32-bit Shoup products, unsigned lazy residues (q < 2^30)
+ *   3 = small-modulus multiply-add form (q < 2^14 and 2 q (q-1) (log2 n + 1) < 2^32)
+ *   4 = the same on SIGNED lazy residues (n = 256: 36 q^2 < 2^31, i.e. q = 7681; n = 512, 1024: q^2 log2 n < 2^31 and q < 2^14, i.e. 7681, 12289)
+ *   5 = signed lazy residues on the 32-bit multiplier (q < 2^25; q < 2^24 for n = 512, 1024: Dilithium's 8380417, ring-TESLA's 8399873, ...)
+ *   0 = auto, the rule sc_hip_plan_create applies: 4 where it holds, else 5 where it holds, else 3 where it holds, else 2.
+ * A mode whose bound the plan's (q, n) does not meet is refused (SC_HIP_FAILURE). */
 int  sc_hip_plan_set_arith(sc_hip_plan_t *plan, int mode);
 
 /* ---- batched transforms, device pointers ------------------------------------------- */
@@ -614,7 +618,71 @@ int  sc_hip_multi_dilithium_sign_host(sc_hip_multi_dilithium_t *h, size_t batch,
 int  sc_hip_multi_dilithium_verify_host(sc_hip_multi_dilithium_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
                                         const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
 
+/* BLISS-B, Falcon, ring-TESLA sign / verify and Kyber encapsulation / decapsulation of a host batch under one key (replicated to every worker by the
+ * set_* call); arguments as the one-device *_host entries below.  BASELINE configs[3] ("BLISS-B-I ... 1 -> 8 MI355X shard") and configs[4]
+ * ("Falcon-1024 ... 8 x MI355X") in one process. */
+typedef struct sc_hip_multi_bliss sc_hip_multi_bliss_t;
+typedef struct sc_hip_multi_falcon sc_hip_multi_falcon_t;
+typedef struct sc_hip_multi_tesla sc_hip_multi_tesla_t;
+typedef struct sc_hip_multi_kyber sc_hip_multi_kyber_t;
+int  sc_hip_multi_bliss_create(sc_hip_multi_t *m, const sc_hip_bliss_params_t *params, sc_hip_multi_bliss_t **h);
+void sc_hip_multi_bliss_destroy(sc_hip_multi_bliss_t *h);
+int  sc_hip_multi_bliss_set_key(sc_hip_multi_bliss_t *h, const int16_t *f, const int16_t *g, const int16_t *a);
+size_t sc_hip_multi_bliss_sig_bytes(const sc_hip_multi_bliss_t *h);
+int  sc_hip_multi_bliss_sign_host(sc_hip_multi_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                  const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                                  uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status);
+int  sc_hip_multi_bliss_verify_host(sc_hip_multi_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                    const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int  sc_hip_multi_falcon_create(sc_hip_multi_t *m, const sc_hip_falcon_params_t *params, sc_hip_multi_falcon_t **h);
+void sc_hip_multi_falcon_destroy(sc_hip_multi_falcon_t *h);
+int  sc_hip_multi_falcon_set_privkey(sc_hip_multi_falcon_t *h, const double *sk);
+int  sc_hip_multi_falcon_set_pubkey(sc_hip_multi_falcon_t *h, const int16_t *pk);
+size_t sc_hip_multi_falcon_sig_bytes(const sc_hip_multi_falcon_t *h);
+int  sc_hip_multi_falcon_sign_host(sc_hip_multi_falcon_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                   const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                                   uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_status);
+int  sc_hip_multi_falcon_verify_host(sc_hip_multi_falcon_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                     const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int  sc_hip_multi_tesla_create(sc_hip_multi_t *m, const sc_hip_tesla_params_t *params, sc_hip_multi_tesla_t **h);
+void sc_hip_multi_tesla_destroy(sc_hip_multi_tesla_t *h);
+int  sc_hip_multi_tesla_set_key(sc_hip_multi_tesla_t *h, const int32_t *a1, const int32_t *a2, const int16_t *s, const int16_t *e1, const int16_t *e2,
+                                const int32_t *t1, const int32_t *t2);
+size_t sc_hip_multi_tesla_sig_bytes(const sc_hip_multi_tesla_t *h);
+int  sc_hip_multi_tesla_sign_host(sc_hip_multi_tesla_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                  const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                                  uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status);
+int  sc_hip_multi_tesla_verify_host(sc_hip_multi_tesla_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                    const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int  sc_hip_multi_kyber_create(sc_hip_multi_t *m, const sc_hip_kyber_params_t *params, sc_hip_multi_kyber_t **h);
+void sc_hip_multi_kyber_destroy(sc_hip_multi_kyber_t *h);
+int  sc_hip_multi_kyber_set_pubkey(sc_hip_multi_kyber_t *h, const int32_t *t_ntt, const int32_t *Agen, const int32_t *t, const uint8_t *rho);   /* set_pubkey + set_kem_pubkey */
+int  sc_hip_multi_kyber_set_privkey(sc_hip_multi_kyber_t *h, const int32_t *s_ntt);
+size_t sc_hip_multi_kyber_ct_bytes(const sc_hip_multi_kyber_t *h);
+int  sc_hip_multi_kyber_kem_encaps_host(sc_hip_multi_kyber_t *h, size_t batch, const uint8_t *h_m, uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys);
+int  sc_hip_multi_kyber_kem_decaps_host(sc_hip_multi_kyber_t *h, size_t batch, const uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys);
+
 /* ---- host-buffer convenience (H2D, kernel, D2H; synchronous) ---------------------------- */
+/* the shape safecrypto_sign / safecrypto_verify (src/safecrypto.c:1108-1139 -> bliss_b.c:1266,1583; falcon.c:808,955; ring_tesla.c:752,922) and
+ * safecrypto_encapsulation / safecrypto_decapsulation (-> kyber_kem.c:855,930) have, for a batch in the caller's memory; arguments as the device
+ * entries above with host pointers, h_status / h_trials as d_status / d_trials there */
+int sc_hip_bliss_sign_host(sc_hip_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                           const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                           uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status);
+int sc_hip_bliss_verify_host(sc_hip_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                             const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int sc_hip_tesla_sign_host(sc_hip_tesla_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                           const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                           uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status);
+int sc_hip_tesla_verify_host(sc_hip_tesla_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                             const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int sc_hip_falcon_sign_host(sc_hip_falcon_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                            const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                            uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_status);
+int sc_hip_falcon_verify_host(sc_hip_falcon_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                              const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts);
+int sc_hip_kyber_kem_encaps_host(sc_hip_kyber_t *h, size_t batch, const uint8_t *h_m, uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys);
+int sc_hip_kyber_kem_decaps_host(sc_hip_kyber_t *h, size_t batch, const uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys);
 int sc_hip_ntt_fwd_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
 int sc_hip_ntt_inv_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_in, int32_t *h_out);
 int sc_hip_polymul_ntt_host(sc_hip_plan_t *plan, size_t batch, const int32_t *h_a, const int32_t *h_bhat, int32_t *h_out);

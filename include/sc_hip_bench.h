@@ -37,9 +37,14 @@ int sc_hip_falcon_sample_profile(sc_hip_falcon_t *h, size_t batch, const int32_t
 int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
 
 /* Dilithium signer: (slots_per_message & 0xFF) > 0 fixes the number of attempts evaluated side by side per message in the first round (0: the
- * built-in rule, about 48 K slots per round); ((slots_per_message >> 8) & 0xFF) = g > 0 caps the depth of round r at S0 * g^r instead of letting
- * it fill the slot budget; unfused != 0 runs NTT(y) and the matrix product as two kernels instead of the fused one */
+ * built-in rule, about 48 K slots per round); bit 8 set: the host looks at the count of unsigned messages after EVERY round (round 2's loop) instead
+ * of queueing the planned rounds back to back; unfused != 0 runs NTT(y) and the matrix product as two kernels instead of the fused one */
 int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, int unfused);
+
+/* process-wide: on = 0 stops the library from registering (pinning) caller memory in its host-buffer entries - every transfer then takes the
+ * runtime's staged path; 1 (default) registers the whole pages inside the caller's buffers; 2 registers the caller's ranges as they are, edge pages
+ * included (what round 2 did).  For bisecting transfer problems (profiles/r03_host_pin_bisect.txt). */
+void sc_hip_bench_set_host_pin(int on);
 
 /* BLISS-B signer: 1 (default) = after a message's first pair of attempts its later pairs are evaluated side by side (the tape position of an attempt does
  * not depend on any value, so pair p starts from a state the host computes; the lowest successful attempt is the signature); 0 = the reference's loop

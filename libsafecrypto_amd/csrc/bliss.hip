@@ -1286,3 +1286,26 @@ extern "C" int sc_hip_bliss_keygen(sc_hip_bliss_t *b, size_t batch, int nz0, int
     }
     return SC_HIP_SUCCESS;
 }
+
+// ---- host-buffer convenience (the shape safecrypto_sign / safecrypto_verify have, for a batch; sc::sign_host in engine_internal.h) ----
+
+extern "C" int sc_hip_bliss_sign_host(sc_hip_bliss_t *b, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                      const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                                      uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status)
+{
+    if (!b) return fail("bliss_sign_host: null handle");
+    return sc::sign_host(b->ctx->device, batch, h_msgs, msg_stride, h_mlens, h_tapes, tape_stride, h_tape_lens, h_sigs, sig_stride, h_siglens, h_trials, h_status,
+        [&](const uint8_t *m, const uint32_t *ml, const uint32_t *t, const uint32_t *tl, uint8_t *sg, uint32_t *sl, uint32_t *tr, uint32_t *st) {
+            return sc_hip_bliss_sign(b, batch, m, msg_stride, ml, fixed_len, t, tape_stride, tl, sg, sig_stride, sl, tr, st, nullptr);
+        });
+}
+
+extern "C" int sc_hip_bliss_verify_host(sc_hip_bliss_t *b, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                        const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts)
+{
+    if (!b) return fail("bliss_verify_host: null handle");
+    return sc::verify_host(b->ctx->device, batch, h_msgs, msg_stride, h_mlens, h_sigs, sig_stride, h_siglens, h_verdicts,
+        [&](const uint8_t *m, const uint32_t *ml, const uint8_t *sg, const uint32_t *sl, uint32_t *v) {
+            return sc_hip_bliss_verify(b, batch, m, msg_stride, ml, fixed_len, sg, sig_stride, sl, v, nullptr);
+        });
+}

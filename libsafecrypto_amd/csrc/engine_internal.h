@@ -12,13 +12,21 @@
 
 namespace sc {
 int fail(const std::string &m);      // records the message for sc_hip_last_error, returns SC_HIP_FAILURE
-// set by the multi-device driver on its worker threads: the caller's buffers are pinned ONCE for all workers by the driver (multi.cpp); the per-device
-// host entry must not register its slice as well - neighbouring slices share a page, and the workers would register and release overlapping pages
-// concurrently
+// set by the multi-device driver on its worker threads: the caller's buffers are pinned ONCE for all workers by the driver (multi.cpp) and the per-device
+// host entry uses the driver's registrations (t_driver_pins) instead of registering its slice - neighbouring slices share a page, and the workers
+// would register and release overlapping pages concurrently
+struct HostPins;
 extern thread_local bool t_skip_host_pin;
+extern thread_local const HostPins *t_driver_pins;
 void cdt_build_guide(const std::vector<uint64_t> &cdf, CdtGuide *g, std::vector<uint16_t> *guide, std::vector<uint64_t> *probe_table);
 size_t cdt_lds_bytes(const sc_hip_cdt *c);      // table + padding + guide: the dynamic LDS of a kernel that samples from c
 }
+
+#define HIPCHK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return sc::fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
 
 namespace sc {
 // Copies between the caller's (pageable) memory and the device.  The HIP runtime moves a pageable buffer of more than 1 MiB by pinning the caller's
@@ -63,6 +71,92 @@ inline hipError_t copy_out_async(void *host, const void *dev, size_t bytes, hipS
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
+}
+}
+
+namespace sc {
+// Explicit pinning of caller memory for the length of one call.  Only WHOLE pages that lie entirely inside the caller's buffers are registered: a heap
+// buffer's first and last page are shared with whatever the allocator put beside it - possibly memory the runtime (or another thread of this library)
+// has pinned or will pin on its own account - and registering / unregistering a range that overlaps such a page is the one thing the explicit path
+// must never do (the root cause of the intermittent "Memory access fault by GPU" was never isolated; the candidates were the two
+// places that registered unaligned caller ranges).  Ranges that overlap or touch (in / out buffers of an in-place or partially overlapping call) are
+// merged and registered once.  The edge fragments (< one page at each end) and anything too small to be worth a registration move through the
+// runtime's staged path (copy_in_async / copy_out_async below with pinned = false).
+struct HostPins {
+    struct Range { uintptr_t lo, hi; };
+    std::vector<Range> want, held;
+    unsigned flags = hipHostRegisterDefault;
+    static constexpr uintptr_t PAGE = 4096;
+    static constexpr size_t MIN_BYTES = (size_t)1 << 20;
+    static int &mode() { static int m = 1; return m; }                    // measurement hook (sc_hip_bench_set_host_pin): 0 off, 1 whole interior pages, 2 round 2's unaligned ranges
+    static bool enabled() { return mode() != 0; }
+    HostPins() = default;
+    HostPins(const HostPins &) = delete;
+    HostPins &operator=(const HostPins &) = delete;
+    void add(const void *p, size_t bytes) { if (p && bytes) want.push_back({ (uintptr_t)p, (uintptr_t)p + bytes }); }
+    void commit(unsigned register_flags = hipHostRegisterDefault)
+    {
+        flags = register_flags;
+        if (!enabled() || t_skip_host_pin) return;
+        // merge what overlaps or shares a page, then keep the whole pages inside
+        for (size_t i = 0; i < want.size(); i++)
+            for (size_t j = i + 1; j < want.size();) {
+                const uintptr_t li = want[i].lo & ~(PAGE - 1), hi_i = (want[i].hi + PAGE - 1) & ~(PAGE - 1);
+                if (want[j].lo < hi_i && want[j].hi > li) {
+                    want[i].lo = want[i].lo < want[j].lo ? want[i].lo : want[j].lo; want[i].hi = want[i].hi > want[j].hi ? want[i].hi : want[j].hi;
+                    want.erase(want.begin() + (long)j); j = i + 1;
+                } else j++;
+            }
+        for (const Range &r : want) {
+            const bool raw = mode() == 2;                                  // bisecting only: the caller's range as it is, edge pages included
+            const uintptr_t lo = raw ? r.lo : (r.lo + PAGE - 1) & ~(PAGE - 1), hi = raw ? r.hi : r.hi & ~(PAGE - 1);
+            if (hi <= lo || hi - lo < MIN_BYTES) continue;
+            if (hipHostRegister((void *)lo, hi - lo, flags) == hipSuccess) held.push_back({ lo, hi });
+            else (void)hipGetLastError();                                  // already pinned by the caller, or not registrable: staged / direct by attribute
+        }
+    }
+    // the part of [p, p + bytes) that lies inside a registered range (at most one: the ranges are disjoint); false if none
+    bool inside(const void *p, size_t bytes, uintptr_t *lo, uintptr_t *hi) const
+    {
+        const uintptr_t a = (uintptr_t)p, b = a + bytes;
+        for (const Range &r : held)
+            if (a < r.hi && b > r.lo) { *lo = a > r.lo ? a : r.lo; *hi = b < r.hi ? b : r.hi; return true; }
+        return false;
+    }
+    ~HostPins() { for (const Range &r : held) (void)hipHostUnregister((void *)r.lo); }
+};
+// a transfer between a caller buffer and the device: the part inside `pins` (or all of it when the caller allocated the buffer pinned) goes direct,
+// the rest in staged pieces
+inline hipError_t copy_in_pinned(void *dev, const void *host, size_t bytes, hipStream_t s, const HostPins *pins, bool caller_pinned)
+{
+    if (caller_pinned) return hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, s);
+    uintptr_t lo, hi;
+    if (!pins || !pins->inside(host, bytes, &lo, &hi)) return copy_in_async(dev, host, bytes, s, false);
+    const uintptr_t a = (uintptr_t)host, b = a + bytes;
+    hipError_t e = hipSuccess;
+    if (lo > a) e = copy_in_async(dev, host, lo - a, s, false);
+    if (e == hipSuccess) e = hipMemcpyAsync((char *)dev + (lo - a), (const void *)lo, hi - lo, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess && b > hi) e = copy_in_async((char *)dev + (hi - a), (const void *)hi, b - hi, s, false);
+    return e;
+}
+inline hipError_t copy_out_pinned(void *host, const void *dev, size_t bytes, hipStream_t s, const HostPins *pins, bool caller_pinned)
+{
+    if (caller_pinned) return hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s);
+    uintptr_t lo, hi;
+    if (!pins || !pins->inside(host, bytes, &lo, &hi)) return copy_out_async(host, dev, bytes, s, false);
+    const uintptr_t a = (uintptr_t)host, b = a + bytes;
+    hipError_t e = hipSuccess;
+    if (lo > a) e = copy_out_async(host, dev, lo - a, s, false);
+    if (e == hipSuccess) e = hipMemcpyAsync((void *)lo, (const char *)dev + (lo - a), hi - lo, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && b > hi) e = copy_out_async((void *)hi, (const char *)dev + (hi - a), b - hi, s, false);
+    return e;
+}
+inline bool caller_allocated_pinned(const void *p)
+{
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess) return at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return false;
 }
 }
 
@@ -128,11 +222,63 @@ struct Workspace {
 };
 }
 
-#define HIPCHK(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return sc::fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
-    } while (0)
+namespace sc {
+// Host-buffer forms of the batched scheme calls (the shape safecrypto_sign / safecrypto_verify / safecrypto_encapsulation have, for a batch): the
+// caller's arrays are staged into device memory that lives for the call, the device entry runs on the null stream, the results come back.  These are
+// conveniences for callers without device buffers of their own (the libsafecrypto-side glue, the multi-device driver) and are PCIe-bound: a BLISS
+// signature comes with 33 KB of CSPRNG words.  Device temporaries are zeroed before they are freed (DevBuf).
+template <class Call>
+int sign_host(int device, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+              const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+              uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_trials, uint32_t *h_status, Call call)
+{
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_sigs || !h_siglens || !h_status) return fail("sign_host: null output buffer");
+    if (!h_tapes) return fail("sign_host: null tape buffer");
+    if (!h_msgs && msg_stride) return fail("sign_host: null message buffer");
+    HIPCHK(hipSetDevice(device));
+    DevBuf m, ml, t, tl, sg, meta;
+    if (m.get(batch * msg_stride + 8) || ml.get(batch * 4) || t.get(batch * tape_stride * 4 + 8) || tl.get(batch * 4) || sg.get(batch * sig_stride + 8) || meta.get(batch * 12))
+        return SC_HIP_FAILURE;
+    if (h_msgs && msg_stride) HIPCHK(copy_in(m.p, h_msgs, batch * msg_stride));
+    if (h_mlens) HIPCHK(copy_in(ml.p, h_mlens, batch * 4));
+    HIPCHK(copy_in(t.p, h_tapes, batch * tape_stride * 4));
+    if (h_tape_lens) HIPCHK(copy_in(tl.p, h_tape_lens, batch * 4));
+    uint32_t *d_siglens = meta.as<uint32_t>(), *d_trials = d_siglens + batch, *d_status = d_trials + batch;
+    HIPCHK(hipMemset(sg.p, 0, batch * sig_stride));
+    HIPCHK(hipMemset(meta.p, 0, batch * 12));
+    const int rc = call(m.as<uint8_t>(), h_mlens ? ml.as<uint32_t>() : nullptr, t.as<uint32_t>(), h_tape_lens ? tl.as<uint32_t>() : nullptr,
+                        sg.as<uint8_t>(), d_siglens, d_trials, d_status);
+    if (rc != SC_HIP_SUCCESS) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(copy_out(h_sigs, sg.p, batch * sig_stride));
+    HIPCHK(copy_out(h_siglens, d_siglens, batch * 4));
+    if (h_trials) HIPCHK(copy_out(h_trials, d_trials, batch * 4));
+    HIPCHK(copy_out(h_status, d_status, batch * 4));
+    return SC_HIP_SUCCESS;
+}
+template <class Call>
+int verify_host(int device, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens,
+                const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts, Call call)
+{
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_sigs || !h_siglens || !h_verdicts) return fail("verify_host: null buffer");
+    if (!h_msgs && msg_stride) return fail("verify_host: null message buffer");
+    HIPCHK(hipSetDevice(device));
+    DevBuf m, ml, sg, meta;
+    if (m.get(batch * msg_stride + 8) || ml.get(batch * 4) || sg.get(batch * sig_stride + 8) || meta.get(batch * 8)) return SC_HIP_FAILURE;
+    if (h_msgs && msg_stride) HIPCHK(copy_in(m.p, h_msgs, batch * msg_stride));
+    if (h_mlens) HIPCHK(copy_in(ml.p, h_mlens, batch * 4));
+    HIPCHK(copy_in(sg.p, h_sigs, batch * sig_stride));
+    uint32_t *d_siglens = meta.as<uint32_t>(), *d_verdicts = d_siglens + batch;
+    HIPCHK(copy_in(d_siglens, h_siglens, batch * 4));
+    const int rc = call(m.as<uint8_t>(), h_mlens ? ml.as<uint32_t>() : nullptr, sg.as<uint8_t>(), d_siglens, d_verdicts);
+    if (rc != SC_HIP_SUCCESS) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(copy_out(h_verdicts, d_verdicts, batch * 4));
+    return SC_HIP_SUCCESS;
+}
+}
 
 struct sc_hip_ctx {
     int device;

@@ -2436,3 +2436,26 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     h->ws.wipe(s);                                                  // the sampler state (the lattice point before packing)
     return SC_HIP_SUCCESS;
 }
+
+// ---- host-buffer convenience (sc::sign_host / sc::verify_host in engine_internal.h); Falcon reports no attempt count (it never retries) ----
+
+extern "C" int sc_hip_falcon_sign_host(sc_hip_falcon_t *f, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                       const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,
+                                       uint8_t *h_sigs, size_t sig_stride, uint32_t *h_siglens, uint32_t *h_status)
+{
+    if (!f) return fail("falcon_sign_host: null handle");
+    return sc::sign_host(f->ctx->device, batch, h_msgs, msg_stride, h_mlens, h_tapes, tape_stride, h_tape_lens, h_sigs, sig_stride, h_siglens, nullptr, h_status,
+        [&](const uint8_t *m, const uint32_t *ml, const uint32_t *tp, const uint32_t *tl, uint8_t *sg, uint32_t *sl, uint32_t *, uint32_t *st) {
+            return sc_hip_falcon_sign(f, batch, m, msg_stride, ml, fixed_len, tp, tape_stride, tl, sg, sig_stride, sl, st, nullptr);
+        });
+}
+
+extern "C" int sc_hip_falcon_verify_host(sc_hip_falcon_t *f, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
+                                         const uint8_t *h_sigs, size_t sig_stride, const uint32_t *h_siglens, uint32_t *h_verdicts)
+{
+    if (!f) return fail("falcon_verify_host: null handle");
+    return sc::verify_host(f->ctx->device, batch, h_msgs, msg_stride, h_mlens, h_sigs, sig_stride, h_siglens, h_verdicts,
+        [&](const uint8_t *m, const uint32_t *ml, const uint8_t *sg, const uint32_t *sl, uint32_t *v) {
+            return sc_hip_falcon_verify(f, batch, m, msg_stride, ml, fixed_len, sg, sig_stride, sl, v, nullptr);
+        });
+}

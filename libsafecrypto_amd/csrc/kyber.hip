@@ -777,3 +777,39 @@ extern "C" int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_
     HIPCHK(hipStreamSynchronize(s));                                   // the scoped temporaries are released on return
     return SC_HIP_SUCCESS;
 }
+
+// ---- host-buffer convenience (the shape safecrypto_encapsulation / safecrypto_decapsulation have, for a batch) ----
+
+extern "C" int sc_hip_kyber_kem_encaps_host(sc_hip_kyber_t *h, size_t batch, const uint8_t *h_m, uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys)
+{
+    if (!h) return fail("kyber_kem_encaps_host: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_m || !h_ct || !h_keys) return fail("kyber_kem_encaps_host: null buffer");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    DevBuf m, ct, keys;
+    if (m.get(batch * 32) || ct.get(batch * ct_stride + 8) || keys.get(batch * 32)) return SC_HIP_FAILURE;
+    HIPCHK(sc::copy_in(m.p, h_m, batch * 32));
+    HIPCHK(hipMemset(ct.p, 0, batch * ct_stride));
+    const int rc = sc_hip_kyber_kem_encaps(h, batch, m.as<uint8_t>(), ct.as<uint8_t>(), ct_stride, keys.as<uint8_t>(), nullptr);
+    if (rc != SC_HIP_SUCCESS) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(sc::copy_out(h_ct, ct.p, batch * ct_stride));
+    HIPCHK(sc::copy_out(h_keys, keys.p, batch * 32));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_kyber_kem_decaps_host(sc_hip_kyber_t *h, size_t batch, const uint8_t *h_ct, size_t ct_stride, uint8_t *h_keys)
+{
+    if (!h) return fail("kyber_kem_decaps_host: null handle");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!h_ct || !h_keys) return fail("kyber_kem_decaps_host: null buffer");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    DevBuf ct, keys;
+    if (ct.get(batch * ct_stride + 8) || keys.get(batch * 32)) return SC_HIP_FAILURE;
+    HIPCHK(sc::copy_in(ct.p, h_ct, batch * ct_stride));
+    const int rc = sc_hip_kyber_kem_decaps(h, batch, ct.as<uint8_t>(), ct_stride, keys.as<uint8_t>(), nullptr);
+    if (rc != SC_HIP_SUCCESS) return rc;
+    HIPCHK(hipStreamSynchronize(nullptr));
+    HIPCHK(sc::copy_out(h_keys, keys.p, batch * 32));
+    return SC_HIP_SUCCESS;
+}

@@ -228,15 +228,27 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 // below 2^27), which the separate kernels could not afford (it doubles the matrix traffic they are bound by).
 // MODE_S32: the transforms run on signed lazy residues; NTT(y) is kept as x + 32q (positive, below 2^31 - the unsigned Shoup product with the
 // plain matrix takes any 32-bit operand) instead of canonical, and the LL <= 5 terms in [0, 2q) go into the inverse transform unreduced.
-template <int LL, int MODE>
+// ALDS: the matrix (plain values | Shoup companions, 2 kk LL KB) is copied into LDS once per (persistent) workgroup and every product reads it from there:
+// with two wavefronts per SIMD the L2 round trip of the 8 matrix loads per (row, column) was what the wavefronts waited for (49 % of their cycles in
+// s_waitcnt, tools/prof_kernel_pmc.sh).  The host picks it when the matrix and the transforms' exchange image fit twice into a CU's 160 KB.
+template <int LL, int MODE, bool ALDS>
 __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
 {
     constexpr bool SG = MODE == MODE_S32;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];          // [4 * 1024] exchange images, then (ALDS) the matrix and its companions
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int pw = lane / LP, lp = lane % LP;
     uint32_t *lds_poly = lds + wid * 1024 + pw * N;
     const ModK k = a.k;
+    const uint32_t *Am = a.key, *Ap = a.keyp;
+    if constexpr (ALDS) {
+        const uint32_t words = (uint32_t)a.kk * LL * N;
+        uint4 *dm = reinterpret_cast<uint4 *>(lds + 4 * 1024), *dp = dm + words / 4;
+        const uint4 *sm = reinterpret_cast<const uint4 *>(a.key), *sp = reinterpret_cast<const uint4 *>(a.keyp);
+        for (uint32_t i = threadIdx.x; i < words / 4; i += 256) { dm[i] = sm[i]; dp[i] = sp[i]; }
+        __syncthreads();
+        Am = lds + 4 * 1024; Ap = Am + words;
+    }
     TwSet<L8> twi;
     twi.load(a.zi, a.zip, lp);
     const uint32_t njobs = a.njobs_dev ? *a.njobs_dev : a.njobs;   // attempts
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
 #pragma unroll
             for (int j = 0; j < LL; j++) {
                 const size_t ko = ((size_t)i * LL + j) * N + lp * 16;
-                const uint4 *pa = reinterpret_cast<const uint4 *>(a.key + ko), *pp = reinterpret_cast<const uint4 *>(a.keyp + ko);
+                const uint4 *pa = reinterpret_cast<const uint4 *>(Am + ko), *pp = reinterpret_cast<const uint4 *>(Ap + ko);
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const uint4 va = pa[c], vp = pp[c];
@@ -367,10 +379,16 @@ static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream
     a.njobs = nitems; a.per = 1;
     if (nitems == 0) return SC_HIP_SUCCESS;
     size_t blocks = ((size_t)nitems + 15) / 16;
-    const size_t cap = (size_t)ctx->cus * 4;
+    const size_t cap = (size_t)ctx->cus * 2;                       // two 256-thread workgroups per CU (256 registers per lane)
     if (blocks > cap) blocks = cap;
-#define SC_YAW(LLv) do { if (a.sg) hipLaunchKernelGGL((dil_yaw_kernel<LLv, MODE_S32>), dim3((unsigned)blocks), dim3(256), 0, s, a); \
-                        else hipLaunchKernelGGL((dil_yaw_kernel<LLv, MODE_U32>), dim3((unsigned)blocks), dim3(256), 0, s, a); } while (0)
+    const size_t ex = 4 * 1024 * sizeof(uint32_t), mat = (size_t)2 * a.kk * a.l * N * sizeof(uint32_t);
+    const bool alds = 2 * (ex + mat) <= 160 * 1024;              // both resident workgroups of a CU hold a copy
+#define SC_YAW_(LLv, M, AL) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dil_yaw_kernel<LLv, M, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ex + (AL ? 80 * 1024 - ex : 0)))); attr_done = true; } \
+        hipLaunchKernelGGL((dil_yaw_kernel<LLv, M, AL>), dim3((unsigned)blocks), dim3(256), AL ? ex + mat : ex, s, a); } while (0)
+#define SC_YAW(LLv) do { if (a.sg) { if (alds) SC_YAW_(LLv, MODE_S32, true); else SC_YAW_(LLv, MODE_S32, false); } \
+                        else { if (alds) SC_YAW_(LLv, MODE_U32, true); else SC_YAW_(LLv, MODE_U32, false); } } while (0)
     switch (a.l) {
     case 2: SC_YAW(2); break;
     case 3: SC_YAW(3); break;
@@ -379,6 +397,7 @@ static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream
     default: return SC_HIP_FAILURE;
     }
 #undef SC_YAW
+#undef SC_YAW_
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

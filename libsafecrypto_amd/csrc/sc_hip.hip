@@ -271,6 +271,8 @@ __global__ __launch_bounds__(256) void cdt_halving_kernel(const uint64_t *__rest
 
 static thread_local std::string g_err;
 thread_local bool sc::t_skip_host_pin = false;
+thread_local const sc::HostPins *sc::t_driver_pins = nullptr;
+extern "C" void sc_hip_bench_set_host_pin(int on) { sc::HostPins::mode() = on; }
 static int g_cus = 256;
 int sc::fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
 using sc::fail;
@@ -765,21 +767,20 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
     if (chunk > batch) chunk = batch;
     const size_t nchunks = (batch + chunk - 1) / chunk, bytes = batch * pb;
     const int nops = h1 ? 2 : 1;
-    // pin what is not pinned already (hout may alias h0: in-place calls)
-    const void *pins[3] = { h0, h1, hout != h0 && hout != h1 ? hout : nullptr };
-    bool pinned[3] = { false, false, false };
-    for (int i = 0; i < 3; i++)
-        // (small transfers are not worth a registration, and a buffer of a few KB shares its pages with whatever the caller's heap put beside it)
-        if (pins[i] && !sc::t_skip_host_pin && bytes >= ((size_t)1 << 20)) { pinned[i] = hipHostRegister(const_cast<void *>(pins[i]), bytes, hipHostRegisterDefault) == hipSuccess; if (!pinned[i]) (void)hipGetLastError(); }
-    // a buffer this call pinned, one the multi-device driver pinned for its workers, or one the caller allocated pinned moves in whole chunks;
-    // anything else in pieces the runtime stages (engine_internal.h)
-    bool direct[3];
-    for (int i = 0; i < 3; i++) {
-        const void *q = i == 2 ? (const void *)hout : pins[i];
-        hipPointerAttribute_t at;
-        direct[i] = (i < 2 && pinned[i]) || (i == 2 && (pinned[2] || (hout == h0 && pinned[0]) || (hout == h1 && pinned[1])));
-        if (!direct[i] && q) { if (hipPointerGetAttributes(&at, q) == hipSuccess) direct[i] = at.type == hipMemoryTypeHost; else (void)hipGetLastError(); }
+    // whole interior pages of the caller's buffers are registered for the call, overlapping buffers once (sc::HostPins); a buffer the multi-device
+    // driver pinned for its workers or one the caller allocated pinned moves direct as it is; everything else in pieces the runtime stages
+    sc::HostPins own;
+    const sc::HostPins *use = sc::t_driver_pins;                   // a worker of the multi-device driver: the driver's registrations, none of its own
+    bool cp[3] = { false, false, false };
+    if (!use) {
+        cp[0] = sc::caller_allocated_pinned(h0); cp[1] = h1 && sc::caller_allocated_pinned(h1); cp[2] = sc::caller_allocated_pinned(hout);
+        if (!cp[0]) own.add(h0, bytes);
+        if (h1 && !cp[1]) own.add(h1, bytes);
+        if (!cp[2]) own.add(hout, bytes);
+        own.commit();
+        use = &own;
     }
+    const sc::HostPins &pins = *use;
     hipStream_t st[NB] = { nullptr, nullptr, nullptr };
     int32_t *dev = nullptr;
     int rc = SC_HIP_SUCCESS;
@@ -790,15 +791,14 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
         const size_t slot = c % ring, off = c * chunk, cnt = (off + chunk <= batch) ? chunk : batch - off;
         int32_t *d0 = dev + slot * nops * chunk * (size_t)p->n, *d1 = h1 ? d0 + chunk * (size_t)p->n : nullptr;
         hipStream_t s = st[slot];
-        if (sc::copy_in_async(d0, h0 + off * (size_t)p->n, cnt * pb, s, direct[0]) != hipSuccess ||
-            (h1 && sc::copy_in_async(d1, h1 + off * (size_t)p->n, cnt * pb, s, direct[1]) != hipSuccess)) { rc = fail("host op: H2D copy failed"); break; }
+        if (sc::copy_in_pinned(d0, h0 + off * (size_t)p->n, cnt * pb, s, &pins, cp[0]) != hipSuccess ||
+            (h1 && sc::copy_in_pinned(d1, h1 + off * (size_t)p->n, cnt * pb, s, &pins, cp[1]) != hipSuccess)) { rc = fail("host op: H2D copy failed"); break; }
         rc = run_ntt(p, op, cnt, d0, d1, d0, s);
-        if (rc == SC_HIP_SUCCESS && sc::copy_out_async(hout + off * (size_t)p->n, d0, cnt * pb, s, direct[2]) != hipSuccess) rc = fail("host op: D2H copy failed");
+        if (rc == SC_HIP_SUCCESS && sc::copy_out_pinned(hout + off * (size_t)p->n, d0, cnt * pb, s, &pins, cp[2]) != hipSuccess) rc = fail("host op: D2H copy failed");
     }
     for (size_t i = 0; i < ring; i++) if (st[i]) { if (hipStreamSynchronize(st[i]) != hipSuccess && rc == SC_HIP_SUCCESS) rc = fail("host op: stream failed"); (void)hipStreamDestroy(st[i]); }
     if (dev) (void)sc::wipe_free(dev);
-    for (int i = 0; i < 3; i++) if (pinned[i]) (void)hipHostUnregister(const_cast<void *>(pins[i]));
-    return rc;
+    return rc;                                                      // (the registrations end with `pins`)
 }
 extern "C" int sc_hip_ntt_fwd_host(sc_hip_plan_t *p, size_t batch, const int32_t *h_in, int32_t *h_out)
 { return host_roundtrip(p, OP_FWD, batch, h_in, nullptr, h_out); }

@@ -42,8 +42,12 @@ SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy',
             'sc_hip_multi_ntt_fwd_host', 'sc_hip_multi_ntt_inv_host', 'sc_hip_multi_polymul_ntt_host', 'sc_hip_multi_dilithium_create', 'sc_hip_multi_dilithium_destroy',
             'sc_hip_multi_dilithium_set_privkey', 'sc_hip_multi_dilithium_set_pubkey', 'sc_hip_multi_dilithium_sig_max', 'sc_hip_multi_dilithium_sign_host',
             'sc_hip_multi_dilithium_verify_host']
+SYMBOLS += [f'sc_hip_{k}_{f}_host' for k in ('bliss', 'tesla', 'falcon') for f in ('sign', 'verify')] + ['sc_hip_kyber_kem_encaps_host', 'sc_hip_kyber_kem_decaps_host']
+SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('create', 'destroy', 'set_key', 'sig_bytes', 'sign_host', 'verify_host')]
+SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
+SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
+BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -79,6 +83,10 @@ def load_library(path=LIB_PATH):
     import torch  # noqa: F401
     L = C.CDLL(path)
     vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    L.sc_hip_bench_set_host_pin.argtypes = [C.c_int]
+    L.sc_hip_bench_set_host_pin.restype = None
+    if os.environ.get('SC_TEST_HOST_PIN') in ('0', '2'):     # test harness only (tools/dbg/bisect_pin.sh): the library itself reads no environment
+        L.sc_hip_bench_set_host_pin(int(os.environ['SC_TEST_HOST_PIN']))
     L.sc_hip_last_error.restype = C.c_char_p
     L.sc_hip_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.sc_hip_ctx_destroy.argtypes = [vp]
@@ -322,9 +330,18 @@ class Multi:
         _chk(self.L, self.L.sc_hip_multi_create(_ptr(d), d.size, C.byref(h)), 'sc_hip_multi_create')
         self.h = h
         self.workers = self.L.sc_hip_multi_workers(h)
-        self._plans, self._dil = {}, None
+        self._plans, self._dil, self._schemes = {}, None, []
+
+    def scheme(self, kind, params):
+        """kind: 'bliss' | 'falcon' | 'tesla' | 'kyber' - the scheme handle replicated on every worker (sc_hip_multi_<kind>_*)"""
+        m = MultiScheme(self, kind, params)
+        self._schemes.append(m)
+        return m
 
     def close(self):
+        for m in self._schemes:
+            m.close()
+        self._schemes = []
         for p in self._plans.values():
             self.L.sc_hip_multi_plan_destroy(p)
         self._plans = {}
@@ -383,6 +400,101 @@ class Multi:
         v = np.ones(msgs.shape[0], dtype=np.uint32)
         _chk(self.L, self.L.sc_hip_multi_dilithium_verify_host(self._dil, msgs.shape[0], _ptr(msgs), msgs.shape[1], C.c_void_p(), fixed_len, _ptr(sigs), sigs.shape[1], _ptr(sl), _ptr(v)), 'multi_dilithium_verify_host')
         return v
+
+
+class MultiScheme:
+    """BLISS-B / Falcon / ring-TESLA / Kyber under one key on every worker of a Multi; host batches (numpy) are sharded by the library.
+    With one worker this is the one-device *_host entry (sc_hip_<kind>_sign_host, ...) behind one fan-out thread."""
+
+    def __init__(self, multi, kind, params):
+        import numpy as np
+        assert kind in ('bliss', 'falcon', 'tesla', 'kyber')
+        self.multi, self.L, self.kind = multi, multi.L, kind
+        self.par = np.ascontiguousarray(np.asarray(params), dtype=np.int32)
+        self.f = lambda name: getattr(self.L, f'sc_hip_multi_{kind}_{name}')
+        h = C.c_void_p()
+        _chk(self.L, self.f('create')(multi.h, _ptr(self.par), C.byref(h)), f'sc_hip_multi_{kind}_create')
+        self.h = h
+        self.f('destroy').restype = None
+        self.f('destroy').argtypes = [C.c_void_p]
+        sz, vp, u32 = C.c_size_t, C.c_void_p, C.c_uint32
+        if kind == 'kyber':
+            self.f('ct_bytes').restype = sz; self.f('ct_bytes').argtypes = [vp]
+            self.f('kem_encaps_host').argtypes = [vp, sz, vp, vp, sz, vp]
+            self.f('kem_decaps_host').argtypes = [vp, sz, vp, sz, vp]
+        else:
+            self.f('sig_bytes').restype = sz; self.f('sig_bytes').argtypes = [vp]
+            self.f('sign_host').argtypes = [vp, sz, vp, sz, vp, u32, vp, sz, vp, vp, sz, vp, vp] + ([vp] if kind != 'falcon' else [])
+            self.f('verify_host').argtypes = [vp, sz, vp, sz, vp, u32, vp, sz, vp, vp]
+
+    def close(self):
+        if self.h:
+            self.f('destroy')(self.h)
+            self.h = None
+
+    def set_key(self, *a, **kw):
+        import numpy as np
+        c = lambda x, dt: np.ascontiguousarray(np.asarray(x), dtype=dt) if x is not None else None
+        p = lambda x: _ptr(x) if x is not None else C.c_void_p()
+        if self.kind == 'bliss':
+            arrs = [c(a[0], np.int16), c(a[1], np.int16), c(a[2], np.int16)]
+            _chk(self.L, self.f('set_key')(self.h, *[p(x) for x in arrs]), 'multi_bliss_set_key')
+        elif self.kind == 'tesla':
+            dts = [np.int32, np.int32, np.int16, np.int16, np.int16, np.int32, np.int32]
+            arrs = [c(x, dt) for x, dt in zip(a, dts)]
+            _chk(self.L, self.f('set_key')(self.h, *[p(x) for x in arrs]), 'multi_tesla_set_key')
+        elif self.kind == 'falcon':
+            sk, pk = c(kw.get('sk'), np.float64), c(kw.get('pk'), np.int16)
+            if sk is not None:
+                _chk(self.L, self.f('set_privkey')(self.h, _ptr(sk)), 'multi_falcon_set_privkey')
+            if pk is not None:
+                _chk(self.L, self.f('set_pubkey')(self.h, _ptr(pk)), 'multi_falcon_set_pubkey')
+        else:
+            t_ntt, Agen, t, rho, s_ntt = (kw.get(k) for k in ('t_ntt', 'Agen', 't', 'rho', 's_ntt'))
+            arrs = [c(t_ntt, np.int32), c(Agen, np.int32), c(t, np.int32), c(rho, np.uint8)]
+            _chk(self.L, self.f('set_pubkey')(self.h, *[p(x) for x in arrs]), 'multi_kyber_set_pubkey')
+            if s_ntt is not None:
+                sa = c(s_ntt, np.int32)
+                _chk(self.L, self.f('set_privkey')(self.h, _ptr(sa)), 'multi_kyber_set_privkey')
+        if self.kind == 'kyber':
+            self.ct_bytes = self.f('ct_bytes')(self.h)
+        else:
+            self.sig_bytes = self.f('sig_bytes')(self.h)
+            self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def sign_host(self, msgs, fixed_len, tapes):
+        """msgs uint8 [B][stride], tapes uint32 [B][W] (numpy) -> sigs uint8 [B][sig_stride], siglens, trials (None for Falcon), status"""
+        import numpy as np
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8); tapes = np.ascontiguousarray(tapes, dtype=np.uint32)
+        n = msgs.shape[0]
+        sigs = np.zeros((n, self.sig_stride), dtype=np.uint8); sl = np.zeros(n, dtype=np.uint32); tr = np.zeros(n, dtype=np.uint32); st = np.zeros(n, dtype=np.uint32)
+        args = [self.h, n, _ptr(msgs), msgs.shape[1], C.c_void_p(), fixed_len, _ptr(tapes), tapes.shape[1], C.c_void_p(), _ptr(sigs), self.sig_stride, _ptr(sl)]
+        args += [_ptr(st)] if self.kind == 'falcon' else [_ptr(tr), _ptr(st)]
+        _chk(self.L, self.f('sign_host')(*args), f'multi_{self.kind}_sign_host')
+        return sigs, sl, (None if self.kind == 'falcon' else tr), st
+
+    def verify_host(self, msgs, fixed_len, sigs, siglens):
+        import numpy as np
+        msgs = np.ascontiguousarray(msgs, dtype=np.uint8); sigs = np.ascontiguousarray(sigs, dtype=np.uint8); sl = np.ascontiguousarray(siglens, dtype=np.uint32)
+        v = np.ones(msgs.shape[0], dtype=np.uint32)
+        _chk(self.L, self.f('verify_host')(self.h, msgs.shape[0], _ptr(msgs), msgs.shape[1], C.c_void_p(), fixed_len, _ptr(sigs), sigs.shape[1], _ptr(sl), _ptr(v)), f'multi_{self.kind}_verify_host')
+        return v
+
+    def encaps_host(self, m):
+        import numpy as np
+        m = np.ascontiguousarray(m, dtype=np.uint8)
+        n = m.shape[0]
+        stride = (self.ct_bytes + 15) & ~15
+        ct = np.zeros((n, stride), dtype=np.uint8); keys = np.zeros((n, 32), dtype=np.uint8)
+        _chk(self.L, self.f('kem_encaps_host')(self.h, n, _ptr(m), _ptr(ct), stride, _ptr(keys)), 'multi_kyber_kem_encaps_host')
+        return ct, keys
+
+    def decaps_host(self, ct):
+        import numpy as np
+        ct = np.ascontiguousarray(ct, dtype=np.uint8)
+        keys = np.zeros((ct.shape[0], 32), dtype=np.uint8)
+        _chk(self.L, self.f('kem_decaps_host')(self.h, ct.shape[0], _ptr(ct), ct.shape[1], _ptr(keys)), 'multi_kyber_kem_decaps_host')
+        return keys
 
 
 class Engine:

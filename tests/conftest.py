@@ -8,8 +8,9 @@ import pytest
 # a test that copies 4 MiB or more: test_gpu_ntt seeded batches, test_gpu_ops batches); with the two settings below, 0 of 40
 # (profiles/r02_pageable_copy_fault.txt).  They are read when the runtime initialises, so they are set here, before anything imports torch; an
 # explicit setting in the environment wins.  The library itself never gives the runtime such a copy (csrc/engine_internal.h: copy_in / copy_out).
-os.environ.setdefault('GPU_PINNED_XFER_SIZE', '4096')
-os.environ.setdefault('GPU_PINNED_MIN_XFER_SIZE', '4194304')
+if os.environ.get('SC_TEST_NO_PIN_ENV') != '1':              # tools/dbg/bisect_pin.sh runs the suite without them (profiles/r03_host_pin_bisect.txt)
+    os.environ.setdefault('GPU_PINNED_XFER_SIZE', '4096')
+    os.environ.setdefault('GPU_PINNED_MIN_XFER_SIZE', '4194304')
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -48,6 +48,21 @@ def pack(msgs, tapes, tape_words):
 
 
 def test_sign_reproduces_reference_signatures(eng, G):
+    reproduce(eng, G)
+
+
+def test_fresh_key_and_signatures_from_the_reference_run_here(eng, tmp_path):
+    """the reference run on the spot (oracle/_ref/ref_driver bliss): an OS-seeded key pair per parameter set nobody has seen, its signatures
+    and the CSPRNG words each took; the engine reproduces BLISS-B-I's byte for byte"""
+    import os, subprocess
+    drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'ref_driver')
+    if not os.path.exists(drv):
+        pytest.skip('oracle/_ref/ref_driver not built')
+    subprocess.check_call([drv, 'bliss', str(tmp_path)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    reproduce(eng, load_golden(str(tmp_path / 'bliss_ref.txt')))
+
+
+def reproduce(eng, G):
     import torch
     key = O.BlissKey.from_golden(G, 'bliss1')
     b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
@@ -124,9 +139,12 @@ def test_full_config4_shape_properties(eng, G):
     v = b.verify(bad, sigs, siglens, fixed_len=64)
     assert torch.equal((v != 0).cpu() | ~ok.cpu(), (torch.arange(B) % 3 == 0) | ~ok.cpu())
     mh, th, sh, lh = msgs.cpu().numpy(), tapes.cpu().numpy().view(np.uint32), sigs.cpu().numpy(), siglens.cpu().numpy()
-    for i in (0, 8191, 16383):
-        rc, es, _, _ = O.bliss_sign(key, bytes(mh[i]), th[i])
-        assert rc == 0 and bytes(sh[i, :lh[i]]) == es
+    st, tr = status.cpu().numpy(), trials.cpu().numpy()
+    for i in list(range(0, B, 47)) + [B - 1]:                  # 350 of the 16384 signatures, byte for byte against the oracle
+        rc, es, et, _ = O.bliss_sign(key, bytes(mh[i]), th[i])
+        assert (rc == 0) == (st[i] == 1), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == es and int(tr[i]) == et, i
     b.close()
 
 

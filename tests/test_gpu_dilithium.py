@@ -118,11 +118,40 @@ def test_device_buffers_full_config3_properties(eng, G):
     assert torch.equal(d.verify(bad_m, sigs, siglens, fixed_len=64).bool().cpu(), (torch.arange(B) % 7 == 0))
     bad_s = sigs.clone(); bad_s[::5, 1000] ^= 0x40
     assert torch.equal(d.verify(msgs, bad_s, siglens, fixed_len=64).bool().cpu(), (torch.arange(B) % 5 == 0))
-    mh, sh, lh = msgs.cpu().numpy(), sigs.cpu().numpy(), siglens.cpu().numpy()
-    for i in (0, 4097, 16383):
-        es, _ = O.dilithium_sign(key, bytes(mh[i]))
-        assert bytes(sh[i, :lh[i]]) == es
+    mh, sh, lh, th = msgs.cpu().numpy(), sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy()
+    sample = list(range(0, B, 31)) + [B - 1]                 # 530 of the 16384 signatures, byte for byte against the oracle (attempt counts included)
+    for i in sample:
+        es, et = O.dilithium_sign(key, bytes(mh[i]))
+        assert bytes(sh[i, :lh[i]]) == es and int(th[i]) == et, i
     d.close()
+
+
+def _ref_driver():
+    import os
+    drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'ref_driver')
+    if not os.path.exists(drv):
+        pytest.skip('oracle/_ref/ref_driver not built')
+    return drv
+
+
+def test_fresh_keys_and_signatures_from_the_reference_run_here(eng, tmp_path):
+    """the reference itself, run on the box the test runs on (oracle/_ref/ref_driver travels as a binary): fresh OS-seeded key pairs for all four
+    parameter sets, its signatures and verdicts - a fixture nobody has seen before.  The engine reproduces every signature byte for byte."""
+    import subprocess
+    subprocess.check_call([_ref_driver(), 'dilithium', str(tmp_path)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    L = load_golden(str(tmp_path / 'dilithium_ref.txt'))
+    total = 0
+    for tag in ('dil3', 'dil1', 'dil0', 'dil2'):
+        key = O.DilKey.from_golden(L, tag)
+        d = make(eng, key)
+        gm = golden_msgs(L, tag)
+        sigs, trials = d.sign_host([m for m, _, _ in gm])
+        for i, (m, sig, tr) in enumerate(gm):
+            assert sigs[i] == sig and trials[i] == tr, (tag, i)
+        assert d.verify_host([m for m, _, _ in gm], [s_ for _, s_, _ in gm]) == [0] * len(gm)
+        total += len(gm)
+        d.close()
+    assert total >= 20
 
 
 @pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])

@@ -47,3 +47,78 @@ def test_multi_driver_matches_one_device(workers):
     v = m.dilithium_verify_host(msgs, 64, bad, sl)
     assert (v[::3] == 1).all() and (np.delete(v, np.s_[::3]) == 0).all()
     d.close(); eng.close(); m.close()
+
+
+@pytest.mark.parametrize('workers', [1, 3])
+def test_multi_bliss_falcon_tesla_kyber_match_one_device(workers):
+    """BASELINE configs[3] / [4] in one process (sc_hip_multi_bliss_* / _falcon_* / _tesla_* / _kyber_*): a host batch cut over the workers gives the
+    bytes the one-device engine gives for the whole batch - which the other GPU tests pin to the reference.  One worker = the one-device *_host entries."""
+    import torch
+    from libsafecrypto_amd import Engine, Multi
+    rng = np.random.default_rng(40 + workers)
+    eng = Engine(0)
+    m = Multi([0] * workers)
+    u32 = lambda a: (np.asarray(a).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    dev = lambda a: torch.from_numpy(a).cuda()
+
+    # ---- BLISS-B-I: 205 messages, tapes of three fresh attempts
+    G = load_golden('bliss_ref.txt')
+    B, W = 205, 3 * 2048 + 64
+    msgs = rng.integers(0, 256, size=(B, 64), dtype=np.uint8)
+    tapes = rng.integers(0, 2**32, size=(B, W), dtype=np.uint64).astype(np.uint32)
+    b1 = eng.bliss(G['bliss1_params']); b1.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
+    s1, l1, t1, st1 = (x.cpu().numpy() for x in b1.sign(dev(msgs), dev(tapes.view(np.int32)), fixed_len=64))
+    mb = m.scheme('bliss', G['bliss1_params']); mb.set_key(G['bliss1_f'], G['bliss1_g'], G['bliss1_a'])
+    s, l, t, st = mb.sign_host(msgs, 64, tapes)
+    assert np.array_equal(st, st1.astype(np.uint32)) and np.array_equal(l, l1.astype(np.uint32)) and np.array_equal(t, t1.astype(np.uint32))
+    assert np.array_equal(s[:, :mb.sig_bytes], s1[:, :mb.sig_bytes]) and int((st == 1).sum()) > B - 3
+    v = mb.verify_host(msgs, 64, s, l)
+    assert (v[st == 1] == 0).all()
+    bad = s.copy(); bad[::4, 300] ^= 2
+    assert (mb.verify_host(msgs, 64, bad, l)[::4] == 1).all()
+    b1.close()
+
+    # ---- Falcon-512: 130 messages
+    G = load_golden('falcon_ref.txt')
+    par = G['falcon0_params']; n = int(par[0])
+    sk = np.asarray(G['falcon0_sk'], dtype=np.int64).view(np.float64)
+    B = 130
+    msgs = rng.integers(0, 256, size=(B, 64), dtype=np.uint8)
+    tapes = rng.integers(0, 2**32, size=(B, 4 * n), dtype=np.uint64).astype(np.uint32)
+    f1 = eng.falcon(par); f1.set_privkey(sk); f1.set_pubkey(G['falcon0_h'])
+    s1, l1, st1 = (x.cpu().numpy() for x in f1.sign(dev(msgs), dev(tapes.view(np.int32)), fixed_len=64))
+    mf = m.scheme('falcon', par); mf.set_key(sk=sk, pk=G['falcon0_h'])
+    s, l, _, st = mf.sign_host(msgs, 64, tapes)
+    assert np.array_equal(st, st1.astype(np.uint32)) and np.array_equal(l, l1.astype(np.uint32)) and np.array_equal(s[:, :mf.sig_bytes], s1[:, :mf.sig_bytes])
+    v = mf.verify_host(msgs, 64, s, l)
+    assert (v[st == 1] == 0).all() and int((st == 1).sum()) > B - 3
+    m2 = msgs.copy(); m2[::5, 7] ^= 1
+    assert (mf.verify_host(m2, 64, s, l)[::5] == 1).all()
+    f1.close()
+
+    # ---- ring-TESLA set 0: 77 messages, tapes of 24 attempts
+    G = load_golden('tesla_ref.txt')
+    keys = [G[f'tesla0_{x}'] for x in ('a1', 'a2', 's', 'e1', 'e2', 't1', 't2')]
+    B = 77
+    msgs = rng.integers(0, 256, size=(B, 64), dtype=np.uint8)
+    tapes = rng.integers(0, 2**32, size=(B, 24 * 512), dtype=np.uint64).astype(np.uint32)
+    t1_ = eng.tesla(G['tesla0_params']); t1_.set_key(*keys)
+    s1, l1, tr1, st1 = (x.cpu().numpy() for x in t1_.sign(dev(msgs), dev(tapes.view(np.int32)), fixed_len=64))
+    mt = m.scheme('tesla', G['tesla0_params']); mt.set_key(*keys)
+    s, l, tr, st = mt.sign_host(msgs, 64, tapes)
+    assert np.array_equal(st, st1.astype(np.uint32)) and np.array_equal(tr, tr1.astype(np.uint32)) and np.array_equal(s[:, :mt.sig_bytes], s1[:, :mt.sig_bytes])
+    assert (mt.verify_host(msgs, 64, s, l)[st == 1] == 0).all() and int((st == 1).sum()) > B - 3
+    t1_.close()
+
+    # ---- Kyber set 1 KEM: 333 values
+    G = load_golden('kyber_ref.txt')
+    B = 333
+    mm = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    k1 = eng.kyber(G['kyber1_params']); k1.set_pubkey(G['kyber1_t_ntt'], G['kyber1_Agen']); k1.set_privkey(G['kyber1_s_ntt']); k1.set_kem_pubkey(G['kyber1_t'], G['kyber1_rho'])
+    ct1, key1 = (x.cpu().numpy() for x in k1.encaps(dev(mm)))
+    mk = m.scheme('kyber', G['kyber1_params']); mk.set_key(t_ntt=G['kyber1_t_ntt'], Agen=G['kyber1_Agen'], t=G['kyber1_t'], rho=G['kyber1_rho'], s_ntt=G['kyber1_s_ntt'])
+    ct, key = mk.encaps_host(mm)
+    assert np.array_equal(ct[:, :mk.ct_bytes], ct1[:, :mk.ct_bytes]) and np.array_equal(key, key1)
+    assert np.array_equal(mk.decaps_host(ct), key)
+    k1.close()
+    m.close(); eng.close()
