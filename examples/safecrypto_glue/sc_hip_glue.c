@@ -292,7 +292,14 @@ static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
         memset(&hp, 0, sizeof hp);
         hp.n = P->n; hp.q = P->q; hp.q_bits = P->q_bits; hp.n_bits = P->n_bits; hp.d = P->d; hp.p = P->p; hp.kappa = P->kappa; hp.b_inf = P->b_inf;
         hp.b_l2 = (int32_t)P->b_l2; hp.z1_bits = P->z1_bits; hp.z2_bits = P->z2_bits; hp.set = P->set; hp.sigma = P->sig; hp.m = P->m; hp.tail = 13.42f;   /* bliss_b.c:342-344 */
-        if (NULL == g_reg[i].bliss && SC_HIP_SUCCESS != sc_hip_bliss_create(g_reg[i].ctx, &hp, &g_reg[i].bliss)) return NULL;
+        if (NULL == g_reg[i].bliss) {
+            if (SC_HIP_SUCCESS != sc_hip_bliss_create(g_reg[i].ctx, &hp, &g_reg[i].bliss)) return NULL;
+            /* the context's OWN sampler table (long double expl is host-dependent in its last bit): the samples are the reference's on any host */
+            if (NULL != sc->sc_gauss && CDF_GAUSSIAN_SAMPLING == sc->sampling && SAMPLING_64BIT == sc->sc_gauss->precision) {
+                const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)sc->sc_gauss->gauss;
+                if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table(g_reg[i].bliss, v->cdf, v->cdf_size)) return NULL;
+            }
+        }
         const SINT16 *priv = (sc->privkey && sc->privkey->key) ? (const SINT16 *)sc->privkey->key : NULL;
         if (SC_HIP_SUCCESS != sc_hip_bliss_set_key(g_reg[i].bliss, priv, priv ? priv + P->n : NULL, (const SINT16 *)sc->pubkey->key)) return NULL;
         g_reg[i].have_priv = priv != NULL; g_reg[i].have_pub = 1;

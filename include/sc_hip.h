@@ -280,6 +280,9 @@ int sc_hip_bliss_sign_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_f, 
                            uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
 int sc_hip_bliss_verify_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_a, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                              const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
+/* replaces the sampler table sc_hip_bliss_create built on this host (long double expl: host-dependent in its last bit) by the caller's - the reference
+ * context's own (the private struct behind sc->sc_gauss->gauss, gaussian_cdf.c:74-81: cdf, cdf_size): the samples are then the reference's on any host */
+int sc_hip_bliss_set_cdt_table(sc_hip_bliss_t *h, const uint64_t *h_cdf, int size);
 /* the relative margin of the status-5 report above (default 2^-40; 0 decides everything on the device; 1 reports every attempt - self-test) */
 int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
 /* replaces: sc->coding_signature.type (bliss_b.c:197-200, set from SC_FLAG_0_ENTROPY_HUFFMAN by safecrypto_create).  type 0 = SC_ENTROPY_NONE: the

@@ -41,6 +41,10 @@ int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
  * of queueing the planned rounds back to back; unfused != 0 runs NTT(y) and the matrix product as two kernels instead of the fused one */
 int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, int unfused);
 
+/* test hook: how many 32-bit words of the signer's per-call secrets (masks y, w = A y, NTT(y) where it is kept in HBM) are non-zero in the handle's
+ * workspace - 0 behind every signing call (the reference zeroes sc->temp, dilithium.c:1964-1975) */
+int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *h, unsigned long long *nonzero_words);
+
 /* process-wide: on = 0 stops the library from registering (pinning) caller memory in its host-buffer entries - every transfer then takes the
  * runtime's staged path; 1 (default) registers the whole pages inside the caller's buffers; 2 registers the caller's ranges as they are, edge pages
  * included (what round 2 did).  For bisecting transfer problems (profiles/r03_host_pin_bisect.txt). */

@@ -779,6 +779,21 @@ extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_
     return SC_HIP_SUCCESS;
 }
 
+// The sampler table of the handle.  sc_hip_bliss_create tabulates it on THIS host with the reference's long-double recurrence (gaussian_cdf_create_64);
+// glibc's x87 expl is not bit-identical across CPU vendors (3 of 2048 entries differed by one unit between two hosts), so a caller
+// that holds the reference's own table - the libsafecrypto-side binding does: sc->sc_gauss - hands it over and the samples are the reference's on any host.
+extern "C" int sc_hip_bliss_set_cdt_table(sc_hip_bliss_t *b, const uint64_t *h_cdf, int size)
+{
+    if (!b || !h_cdf) return fail("bliss_set_cdt_table: null argument");
+    sc_hip_cdt *cdt = nullptr;
+    if (sc_hip_cdt_create_from_table(b->ctx, h_cdf, size, &cdt) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipDeviceSynchronize());                                    // nothing in flight may still read the old table
+    sc_hip_cdt_destroy(b->cdt);
+    b->cdt = cdt;
+    return SC_HIP_SUCCESS;
+}
+
 // the margin inside which the accept / reject draw is reported (status 5) instead of decided; 2^-40 by default.  A margin of 1 reports every
 // attempt that reaches the test (self-test of the reporting path).
 extern "C" int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *b, double relative)

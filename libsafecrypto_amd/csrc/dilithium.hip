@@ -140,7 +140,7 @@ __global__ void dil_kg_t_kernel(const int32_t *as1, const int32_t *s2, int32_t *
 // The signer's round state lives on the device: rs[0] = messages still unsigned, rs[1] = attempts per message this round ("slots" per
 // message), rs[2] = rs[0] * rs[1].  Written by dil_round_kernel at the head of a round from the count the previous round's last kernel left,
 // so a signing call queues its rounds back to back without a host read-back between them.
-enum { RS_NACT = 0, RS_S = 1, RS_NSLOTS = 2 };
+enum { RS_NACT = 0, RS_S = 1, RS_NSLOTS = 2, RS_PREV = 3 };          // RS_PREV: the previous round's slot count (what may still hold its y and w)
 
 __global__ void dil_round_kernel(uint32_t *rs, uint32_t *next_count, uint32_t first_nact, uint32_t slot_cap, uint32_t s_max)
 {
@@ -149,19 +149,52 @@ __global__ void dil_round_kernel(uint32_t *rs, uint32_t *next_count, uint32_t fi
     uint32_t S = nact ? slot_cap / nact : 0;
     if (S > s_max) S = s_max;
     if (nact && S < 1) S = 1;
+    rs[RS_PREV] = first_nact ? 0u : rs[RS_NSLOTS];
     rs[RS_NACT] = nact; rs[RS_S] = S; rs[RS_NSLOTS] = nact * S;
     *next_count = 0;
+}
+
+// zeroes y, w (and NTT(y)) of the slots of the round the state describes: behind the last round of a call
+__global__ void dil_wipe_kernel(const uint32_t *rs, int32_t *y, uint32_t y_words, int32_t *w, uint32_t w_words, uint32_t *yh)
+{
+    const uint32_t nslots = rs[RS_NSLOTS];
+    const size_t ny = (size_t)nslots * y_words / 4, nw = (size_t)nslots * w_words / 4, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < ny; i += stride) {
+        reinterpret_cast<uint4 *>(y)[i] = make_uint4(0, 0, 0, 0);
+        if (yh) reinterpret_cast<uint4 *>(yh)[i] = make_uint4(0, 0, 0, 0);
+    }
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += stride) reinterpret_cast<uint4 *>(w)[i] = make_uint4(0, 0, 0, 0);
 }
 
 // y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244): SHAKE256(mu || K || kappa_hi || kappa_lo) -> 20-bit fields, rejection below 2 gamma_1 - 2.
 // One lane per attempt.  The input is 82 bytes - one block - and the squeeze walks whole blocks, so the sponge needs no dynamic addressing:
 // the state stays in registers from beginning to end (no LDS round trip per permutation, no LDS limit on residency).
 __global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, const uint32_t *active, const uint32_t *kappa, const uint8_t *K,
-                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride, uint32_t *slot_item)
+                                                        const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride, uint32_t *slot_item,
+                                                        int32_t *wipe_w, uint32_t wipe_w_words, uint32_t *wipe_yh)
 {
     const uint32_t aidx = blockIdx.x * EXP_T + threadIdx.x;
-    const uint32_t S = rs[RS_S];
-    if (aidx >= rs[RS_NSLOTS]) return;
+    const uint32_t S = rs[RS_S], nslots = rs[RS_NSLOTS];
+    const uint32_t nhb = (nslots + EXP_T - 1) / EXP_T;                      // workgroups that hash
+    if (blockIdx.x >= nhb) {
+        // A workgroup with no attempt to expand zeroes the masks y and the products w = A y that the PREVIOUS round left in slots this round does
+        // not overwrite, [nslots, prev) - the per-call secrets (dilithium.c:1964-1975).  Every slot is zeroed once per call, by workgroups that would
+        // otherwise leave at once, while the hashing workgroups keep the vector units busy and leave the memory system idle.
+        const uint32_t prev = rs[RS_PREV], surplus = gridDim.x - nhb;
+        for (uint32_t s0 = nslots + (blockIdx.x - nhb) * EXP_T; s0 < prev; s0 += surplus * EXP_T) {
+            const uint32_t cnt = prev - s0 < (uint32_t)EXP_T ? prev - s0 : (uint32_t)EXP_T;
+            uint4 *zy = reinterpret_cast<uint4 *>(y + (size_t)s0 * limit), *zw = reinterpret_cast<uint4 *>(wipe_w + (size_t)s0 * wipe_w_words);
+            const uint32_t ny = cnt * (uint32_t)limit / 4, nw = cnt * wipe_w_words / 4;
+            for (uint32_t i = threadIdx.x; i < ny; i += EXP_T) zy[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = threadIdx.x; i < nw; i += EXP_T) zw[i] = make_uint4(0, 0, 0, 0);
+            if (wipe_yh) {
+                uint4 *zh = reinterpret_cast<uint4 *>(wipe_yh + (size_t)s0 * limit);
+                for (uint32_t i = threadIdx.x; i < ny; i += EXP_T) zh[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        return;
+    }
+    if (aidx >= nslots) return;
     // slot aidx = (message index in the round's list) * S + attempt: message active[aidx / S], kappa = the message's base + aidx % S
     const uint32_t item = active ? active[aidx / S] : aidx / S;
     slot_item[aidx] = item;
@@ -329,7 +362,6 @@ struct DilFin {
     uint32_t *kappa;
     uint8_t *sigs; size_t sig_stride; uint32_t *siglens, *trials;
     uint32_t *next_active, *next_count;
-    uint32_t *yh_wipe;                    // NTT(y) [slot][l][n] where the unfused transform / product pair left it in HBM (null: it stayed in registers)
     DilP P;
 };
 
@@ -405,7 +437,8 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
                     }
                 }
             };
-            issue(o[0], s2k, a.w, kk, 0);
+            issue(o[0], s2k, a.w, kk, 0);                                   // both passes of the r stage are requested before NTT(c) is computed
+            if constexpr (K2P) issue(o[1], s2k, a.w, kk, 1);
             cb[lane] = creg;
             if (at + 1 < S) creg = c32[(size_t)(at + 1) * 64];              // the next attempt's c, should this one fail
             wave_lds_fence();
@@ -447,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
             };
             constexpr int Z0 = K2P ? 0 : 1, Z1 = 1 - Z0, T0 = L2P ? Z0 : Z1, T1 = 1 - T0;     // which operand set the stages' first passes find their operands in
             product(o[0]);
-            if constexpr (K2P) issue(o[1], s2k, a.w, kk, 1); else issue(o[1], s1k, a.y, l, 0);
+            if constexpr (!K2P) issue(o[1], s1k, a.y, l, 0);
             inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
             epi_r(o[0], 0);
             if constexpr (K2P) {
@@ -555,17 +588,7 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
             for (uint32_t i = lane; i < tbytes; i += 64) out[zbytes + i] = (uint8_t)(tw[i >> 2] >> (24 - 8 * (i & 3)));
             if (lane == 0) { f.trials[item] = f.kappa[item] + at + 1; f.siglens[item] = zbytes + tbytes; }
         }
-        // the masks and w = A y of this message's S slots do not outlive the round
-        {
-            uint4 *zy = reinterpret_cast<uint4 *>(const_cast<int32_t *>(a.y) + (size_t)aidx * S * l * N), *zw = reinterpret_cast<uint4 *>(a.w + (size_t)aidx * S * kk * N);
-            const uint32_t ny = S * (uint32_t)l * (N / 4), nw = S * (uint32_t)kk * (N / 4);
-            for (uint32_t i = lane; i < ny; i += 64) zy[i] = make_uint4(0, 0, 0, 0);
-            for (uint32_t i = lane; i < nw; i += 64) zw[i] = make_uint4(0, 0, 0, 0);
-            if (f.yh_wipe) {
-                uint4 *zh = reinterpret_cast<uint4 *>(f.yh_wipe + (size_t)aidx * S * l * N);
-                for (uint32_t i = lane; i < ny; i += 64) zh[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
+        // (the masks y and w = A y of the round's slots are zeroed by the next round's dil_expand_kernel / the call's dil_wipe_kernel)
     }
     const bool again = live && found < 0 && lane == 0;
     uint32_t rpos = 0;
@@ -874,6 +897,32 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
     return SC_HIP_SUCCESS;
 }
 
+// test hook (include/sc_hip_bench.h): words of the per-call secrets (masks y, w = A y, NTT(y)) that are not zero in the signer's workspace
+namespace {
+__global__ void dil_residue_kernel(const uint32_t *p, size_t words, unsigned long long *count)
+{
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) c += p[i] != 0;
+    if (c) atomicAdd(count, c);
+}
+}
+extern "C" int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *d, unsigned long long *nonzero_words)
+{
+    if (!d || !nonzero_words) return fail("dilithium_workspace_residue: null argument");
+    *nonzero_words = 0;
+    if (!d->slot_cap) return SC_HIP_SUCCESS;
+    HIPCHK(hipSetDevice(d->ctx->device));
+    DevBuf cnt;
+    if (cnt.get(8)) return SC_HIP_FAILURE;
+    HIPCHK(hipMemset(cnt.p, 0, 8));
+    const size_t n = d->P.n;
+    const struct { const void *p; size_t words; } parts[3] = { { d->y, d->slot_cap * d->P.l * n }, { d->w, d->slot_cap * d->P.k * n }, { d->yh, d->slot_cap * d->P.l * n } };
+    for (const auto &pt : parts) hipLaunchKernelGGL(dil_residue_kernel, dim3(1024), dim3(256), 0, nullptr, (const uint32_t *)pt.p, pt.words, cnt.as<unsigned long long>());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(sc::copy_out(nonzero_words, cnt.p, 8));
+    return SC_HIP_SUCCESS;
+}
+
 // measurement hook (include/sc_hip_bench.h)
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
@@ -966,9 +1015,9 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     DilFin f;
     f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
     f.s1_stride = ks.per_item ? (size_t)l * N : 0; f.k_stride = ks.per_item ? (size_t)k * N : 0;
-    f.yh_wipe = (ks.As && !ks.per_item) ? nullptr : d->yh;
     f.rs = d->rs; f.kappa = d->kappa; f.sigs = d_sigs; f.sig_stride = sig_stride; f.siglens = d_siglens; f.trials = trials; f.next_count = d->cnt; f.P = P;
     const unsigned eb = (cap + EXP_T - 1) / EXP_T, hb = (cap + CH_T - 1) / CH_T;
+    uint32_t *yh_wipe = (ks.As && !ks.per_item) ? nullptr : d->yh;     // NTT(y) where the unfused transform / product pair leaves it in HBM
     uint32_t round = 0, todo = d->tune_sync ? 1 : plan_rounds(batch, cap, s_max), left = B;
     while (left > 0) {
         for (uint32_t i = 0; i < todo; i++, round++) {
@@ -976,7 +1025,8 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
             const uint32_t *active = round ? d->act[(round - 1) & 1] : nullptr;     // round 0: identity
             f.active = active; f.next_active = d->act[round & 1];
             hipLaunchKernelGGL(dil_round_kernel, dim3(1), dim3(1), 0, s, d->rs, d->cnt, round ? 0u : B, cap, s_max);
-            hipLaunchKernelGGL(dil_expand_kernel, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item);
+            hipLaunchKernelGGL(dil_expand_kernel, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
+                               d->w, (uint32_t)(k * P.n), yh_wipe);
             HIPCHK(hipGetLastError());
             DilNtt a = base_args(d);
             a.in = d->y; a.out_int = d->yh;
@@ -1011,6 +1061,9 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         left = cnt;
         todo = 1;
     }
+    // the last round's slots (every earlier round's were zeroed by its successor's surplus workgroups)
+    hipLaunchKernelGGL(dil_wipe_kernel, dim3(cap < 4096u ? cap : 4096u), dim3(256), 0, s, d->rs, d->y, (uint32_t)(l * P.n), d->w, (uint32_t)(k * P.n), yh_wipe);
+    HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
 

@@ -31,9 +31,9 @@ size_t cdt_lds_bytes(const sc_hip_cdt *c);      // table + padding + guide: the 
 namespace sc {
 // Copies between the caller's (pageable) memory and the device.  The HIP runtime moves a pageable buffer of more than 1 MiB by pinning the caller's
 // pages in place for the duration of the copy ("HSA Copy Using Pinned resource" in its log) and anything smaller through its own pinned staging
-// buffer.  The in-place path is the one a long-lived process cannot rely on here: with it, one run in eight of the GPU test suite (heap buffers of
-// 4-16 MiB allocated, copied and freed in a loop) died with "Memory access fault by GPU ... on address <a host heap address>" inside a later copy; with
-// every copy staged, none in forty (profiles/r02_pageable_copy_fault.txt).  So the library never hands the runtime a pageable
+// buffer.  The in-place path is the one a long-lived process could not rely on in round 2: with it, 20 of 101 sessions of the GPU test suite (heap buffers
+// of 4-16 MiB allocated, copied and freed in a loop) died with "Memory access fault by GPU ... on address <a host heap address>" inside a later copy; with
+// every copy staged, none of 76 (profiles/r02_pageable_copy_fault.txt; round 3 did not see it in 60 sessions either way: profiles/r03_host_pin_bisect.txt).  So the library never hands the runtime a pageable
 // piece above the staging threshold: large buffers it pins itself, explicitly and for exactly the call (hipHostRegister / hipHostUnregister in
 // host_roundtrip and the multi-device driver), everything else goes through these helpers.
 constexpr size_t HOST_PIECE = (size_t)1 << 20;

@@ -22,7 +22,7 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_tape_words',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_tape_words',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_set_privkeys', 'sc_hip_falcon_set_pubkeys', 'sc_hip_falcon_sign_keys', 'sc_hip_falcon_verify_keys', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -47,7 +47,7 @@ SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('creat
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
+BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_dilithium_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -841,6 +841,12 @@ class Dilithium:
         self.sig_max = self.L.sc_hip_dilithium_sig_max(h)
         self.sig_stride = (self.sig_max + 15) & ~15
 
+    def workspace_residue(self):
+        """non-zero words of per-call secrets left in the signer's workspace (test hook)"""
+        c = C.c_ulonglong(0)
+        _chk(self.L, self.L.sc_hip_dilithium_workspace_residue(self.h, C.byref(c)), 'dilithium_workspace_residue')
+        return int(c.value)
+
     def set_tuning(self, slots_per_message=0, unfused=False):
         """measurement hook (include/sc_hip_bench.h)"""
         _chk(self.L, self.L.sc_hip_dilithium_set_tuning(self.h, int(slots_per_message), 1 if unfused else 0), 'dilithium_set_tuning')
@@ -970,6 +976,12 @@ class Bliss:
         self.n = int(self.par[0])
         self.sig_bytes = self.L.sc_hip_bliss_sig_bytes(h)
         self.sig_stride = (self.sig_bytes + 15) & ~15
+
+    def set_cdt_table(self, cdf):
+        """the reference's own 64-bit CDF table (uint64) instead of the one tabulated on this host"""
+        import numpy as np
+        t = np.ascontiguousarray(np.asarray(cdf), dtype=np.uint64)
+        _chk(self.L, self.L.sc_hip_bliss_set_cdt_table(self.h, _ptr(t), t.size), 'bliss_set_cdt_table')
 
     def set_tie_margin(self, relative):
         """relative margin around the rejection threshold inside which a draw is reported (status 5) instead of decided; default 2^-40"""

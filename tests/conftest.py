@@ -4,9 +4,10 @@ import pytest
 
 # Pageable copies of this process are staged, never pinned in place.  The tests move numpy arrays of 4-16 MiB with torch (`.cuda()` / `.cpu()`), allocate
 # and free them in a loop, and the HIP runtime's default for a pageable copy above 1 MiB is to pin the caller's pages in place for the copy.  On the GPU
-# pool that path killed the whole session with "Memory access fault by GPU ... on address <a host heap address>" in 5 of 58 runs of this suite (always in
-# a test that copies 4 MiB or more: test_gpu_ntt seeded batches, test_gpu_ops batches); with the two settings below, 0 of 40
-# (profiles/r02_pageable_copy_fault.txt).  They are read when the runtime initialises, so they are set here, before anything imports torch; an
+# pool that path killed the whole session with "Memory access fault by GPU ... on address <a host heap address>" in 20 of 101 runs of this suite in round 2 (always in
+# a test that copies 4 MiB or more: test_gpu_ntt seeded batches, test_gpu_ops batches); with the two settings below, 0 of 76
+# (profiles/r02_pageable_copy_fault.txt).  Round 3 could not reproduce the fault without them either (0 of 60 sessions, profiles/r03_host_pin_bisect.txt):
+# they stay as a harness-side mitigation, not as something the library needs.  They are read when the runtime initialises, so they are set here, before anything imports torch; an
 # explicit setting in the environment wins.  The library itself never gives the runtime such a copy (csrc/engine_internal.h: copy_in / copy_out).
 if os.environ.get('SC_TEST_NO_PIN_ENV') != '1':              # tools/dbg/bisect_pin.sh runs the suite without them (profiles/r03_host_pin_bisect.txt)
     os.environ.setdefault('GPU_PINNED_XFER_SIZE', '4096')

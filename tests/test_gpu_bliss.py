@@ -62,10 +62,20 @@ def test_fresh_key_and_signatures_from_the_reference_run_here(eng, tmp_path):
     reproduce(eng, load_golden(str(tmp_path / 'bliss_ref.txt')))
 
 
-def reproduce(eng, G):
+def test_reference_table_makes_signatures_host_independent(eng, G):
+    """sc_hip_bliss_set_cdt_table: with the reference's own sampler table (the one the fixture's signatures were made with, tests/golden/cdt_ref.txt)
+    instead of the table tabulated on the host the test runs on, the fixture's signatures are reproduced whatever that host's expl() rounds to"""
+    C = load_golden('cdt_ref.txt')
+    table = np.asarray(C['bliss1_s215_t13.42_cdf'], dtype=np.uint64)
+    reproduce(eng, G, table=table)
+
+
+def reproduce(eng, G, table=None):
     import torch
     key = O.BlissKey.from_golden(G, 'bliss1')
     b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a)
+    if table is not None:
+        b.set_cdt_table(table)
     cs = cases(G)
     msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], 4200)
     sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)

@@ -112,6 +112,7 @@ def test_device_buffers_full_config3_properties(eng, G):
     torch.cuda.synchronize()
     assert int(siglens.min()) > 3200 and int(siglens.max()) <= d.sig_max
     assert 2.5 < float(trials.float().mean()) < 4.5          # ~3.4 trials per signature
+    assert d.workspace_residue() == 0                         # the masks y and A y of every attempt are zeroed behind the call (dilithium.c:1964-1975)
     v = d.verify(msgs, sigs, siglens, fixed_len=64)
     assert int(v.sum()) == 0
     bad_m = msgs.clone(); bad_m[::7, 5] ^= 1
@@ -273,6 +274,7 @@ def test_sign_under_distinct_keys(eng, G, tag):
     msgs, ml = torch.from_numpy(mb).cuda(), torch.from_numpy(lens).cuda()
     sigs, siglens, trials = d.sign_keys(s1, s2, t, rho, K, tr, msgs, mlens=ml)
     torch.cuda.synchronize()
+    assert d.workspace_residue() == 0                         # y, A y and NTT(y) (kept in HBM on this path) are zeroed behind the call
     A = eng.expand_matrix(rho, k * l, int(par[1]), int(par[2])).cpu().numpy()
     h = [x.cpu().numpy() for x in (s1, s2, t, rho, K, tr, t1)]
     sh, lh, th = sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy()
