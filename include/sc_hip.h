@@ -592,6 +592,26 @@ int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *h, size_t batch, const int32_
                                const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, void *stream);
 
+/* ---- static-Huffman coding of signatures that are one polynomial (+ raw bytes) ---------------------------------------------------------------
+ * replaces: entropy_poly_encode_32 / _decode_32(..., SIGNED_COEFF, SC_ENTROPY_HUFFMAN_STATIC, ...) followed by raw entropy_poly_encode_8 fields in the same
+ * MSB-first stream (src/utils/entropy/entropy.c:70-112,114-145; entropy_huffman.c:22-57,155-190; packer.c:299-351) as the signers use them with
+ * SC_FLAG_0_ENTROPY_HUFFMAN: Falcon's s2 (n fields of q_bits - 2 bits, falcon.c:892-903 / 984-993), the ENS / DLP signatures' s1 (n fields of q_bits bits,
+ * ens_dlp_sig.c:1275-1287), ring-TESLA's z and digest (n fields of q_bits bits + 64 bytes, ring_tesla.c:880-890).  A format conversion of rows in device
+ * memory, run behind sc_hip_<scheme>_sign (raw rows -> coded rows, in place) and in front of sc_hip_<scheme>_verify (coded -> raw rows in a second
+ * buffer).  codes / bits: the reference's static table for the field width (src/utils/entropy/huffman.h, huff_table_gaussian_<min(field_bits, 7) - 1>,
+ * _2 below 4 bits: data of the reference, handed over as for sc_hip_bliss_set_entropy); it must be a complete prefix code. */
+typedef struct sc_hip_huffman sc_hip_huffman_t;
+int  sc_hip_huffman_create(sc_hip_ctx_t *ctx, const uint32_t *codes, const uint16_t *bits, uint32_t depth, int field_bits, sc_hip_huffman_t **h);
+void sc_hip_huffman_destroy(sc_hip_huffman_t *h);
+/* d_rows [batch][row_stride]: raw signatures (n fields, then tail_bytes bytes) -> coded, in place; d_lens[i] = coded length.  d_status (may be NULL):
+ * only rows with d_status[i] == 1 are coded; 6 is written for a coefficient outside the table's alphabet or a coded row longer than row_stride */
+int sc_hip_huffman_encode_rows(sc_hip_huffman_t *h, size_t batch, uint8_t *d_rows, size_t row_stride, uint32_t *d_lens, uint32_t *d_status,
+                               int n, int tail_bytes, void *stream);
+/* coded rows -> raw rows in d_out (a buffer of its own, out_stride >= the raw size), d_outlens[i] = raw length, d_bad[i] (may be NULL) = 1 when the
+ * stream ends before the last field (the reference's decoder fails there) */
+int sc_hip_huffman_decode_rows(sc_hip_huffman_t *h, size_t batch, const uint8_t *d_rows, size_t row_stride, const uint32_t *d_lens,
+                               uint8_t *d_out, size_t out_stride, uint32_t *d_outlens, uint32_t *d_bad, int n, int tail_bytes, void *stream);
+
 /* ---- multi-device driver --------------------------------------------------------------------------------
  * Independent units shard with no collective: a host batch is cut into contiguous slices (sc_hip_shard_range), one host thread per
  * worker drives its device (>= 2 streams per device inside the per-device host entry points), results are written at the slice's

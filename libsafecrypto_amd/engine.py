@@ -42,6 +42,7 @@ SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy',
             'sc_hip_multi_ntt_fwd_host', 'sc_hip_multi_ntt_inv_host', 'sc_hip_multi_polymul_ntt_host', 'sc_hip_multi_dilithium_create', 'sc_hip_multi_dilithium_destroy',
             'sc_hip_multi_dilithium_set_privkey', 'sc_hip_multi_dilithium_set_pubkey', 'sc_hip_multi_dilithium_sig_max', 'sc_hip_multi_dilithium_sign_host',
             'sc_hip_multi_dilithium_verify_host']
+SYMBOLS += ['sc_hip_huffman_create', 'sc_hip_huffman_destroy', 'sc_hip_huffman_encode_rows', 'sc_hip_huffman_decode_rows']
 SYMBOLS += [f'sc_hip_{k}_{f}_host' for k in ('bliss', 'tesla', 'falcon') for f in ('sign', 'verify')] + ['sc_hip_kyber_kem_encaps_host', 'sc_hip_kyber_kem_decaps_host']
 SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('create', 'destroy', 'set_key', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
@@ -402,6 +403,46 @@ class Multi:
         return v
 
 
+class HuffmanRows:
+    """Static-Huffman coding of signature rows that are one polynomial of `field_bits`-bit signed fields + raw tail bytes (sc_hip_huffman_*):
+    Falcon, ENS / DLP signatures, ring-TESLA with SC_FLAG_0_ENTROPY_HUFFMAN.  codes / bits: the reference's static table for the field width."""
+
+    def __init__(self, eng, codes, bits, field_bits):
+        import numpy as np
+        self.eng, self.L, self.field_bits = eng, eng.L, int(field_bits)
+        c = np.ascontiguousarray(np.asarray(codes), dtype=np.uint32); b = np.ascontiguousarray(np.asarray(bits), dtype=np.uint16)
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_huffman_create(eng.h, _ptr(c), _ptr(b), c.size, self.field_bits, C.byref(h)), 'sc_hip_huffman_create')
+        self.h = h
+        self.L.sc_hip_huffman_destroy.restype = None
+        self.L.sc_hip_huffman_destroy.argtypes = [C.c_void_p]
+        sz, vp = C.c_size_t, C.c_void_p
+        self.L.sc_hip_huffman_encode_rows.argtypes = [vp, sz, vp, sz, vp, vp, C.c_int, C.c_int, vp]
+        self.L.sc_hip_huffman_decode_rows.argtypes = [vp, sz, vp, sz, vp, vp, sz, vp, vp, C.c_int, C.c_int, vp]
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_huffman_destroy(self.h)
+            self.h = None
+
+    def encode(self, rows, lens, n, tail=0, status=None):
+        """rows uint8 [B][stride] (device, raw signatures; coded in place), lens int32 [B] (device, receives the coded lengths)"""
+        _chk(self.L, self.L.sc_hip_huffman_encode_rows(self.h, rows.shape[0], _ptr(rows), _rows(rows), _ptr(lens), _ptr(status) if status is not None else C.c_void_p(),
+                                                       n, tail, _stream()), 'huffman_encode_rows')
+        return rows, lens
+
+    def decode(self, rows, lens, n, tail=0):
+        """coded rows (device) -> raw rows [B][raw bytes rounded up to 16], raw lengths, malformed flags"""
+        import torch
+        B = rows.shape[0]
+        rawb = (n * self.field_bits + 7) // 8 + tail
+        stride = (rawb + 15) & ~15
+        out = torch.zeros((B, stride), dtype=torch.uint8, device=rows.device)
+        ol = torch.zeros(B, dtype=torch.int32, device=rows.device); bad = torch.zeros(B, dtype=torch.int32, device=rows.device)
+        _chk(self.L, self.L.sc_hip_huffman_decode_rows(self.h, B, _ptr(rows), _rows(rows), _ptr(lens), _ptr(out), stride, _ptr(ol), _ptr(bad), n, tail, _stream()), 'huffman_decode_rows')
+        return out, ol, bad
+
+
 class MultiScheme:
     """BLISS-B / Falcon / ring-TESLA / Kyber under one key on every worker of a Multi; host batches (numpy) are sharded by the library.
     With one worker this is the one-device *_host entry (sc_hip_<kind>_sign_host, ...) behind one fan-out thread."""
@@ -518,6 +559,9 @@ class Engine:
 
     def kyber(self, params):
         return Kyber(self, params)
+
+    def huffman_rows(self, codes, bits, field_bits):
+        return HuffmanRows(self, codes, bits, field_bits)
 
     def bliss(self, params):
         return Bliss(self, params)

@@ -297,6 +297,29 @@ int orc_bliss_sig_from_huffman(const int32_t *par, const uint8_t *in, size_t inl
     return r.over;
 }
 
+/* The same coding for a signature that is ONE polynomial of n signed `bits`-bit fields followed by `tail` raw bytes in the same bit stream: Falcon's s2
+ * (falcon.c:892-903), the ENS / DLP signatures' s1 (ens_dlp_sig.c:1275-1287), ring-TESLA's z + 64 digest bytes (ring_tesla.c:880-890). */
+int orc_huff_row_encode(const uint8_t *raw, size_t rawlen, int n, int bits, int tail, const uint32_t *code, const uint16_t *len, uint32_t depth, uint8_t *out, size_t *outlen)
+{
+    if (rawlen * 8 < (size_t)n * (size_t)bits + 8 * (size_t)tail) return 1;
+    br_t r = { raw, rawlen * 8, 0, 0 };
+    bw_t w = { out, 0 };
+    int bad = 0;
+    for (int i = 0; i < n; i++) { const uint32_t v = br_get(&r, bits); bad |= huff_put(&w, (int32_t)(v << (32 - bits)) >> (32 - bits), bits, code, len, depth); }
+    for (int i = 0; i < tail; i++) bw_put(&w, br_get(&r, 8), 8);
+    *outlen = (w.bitpos + 7) >> 3;
+    return bad;
+}
+int orc_huff_row_decode(const uint8_t *in, size_t inlen, int n, int bits, int tail, const uint32_t *code, const uint16_t *len, uint32_t depth, uint8_t *raw, size_t *rawlen)
+{
+    br_t r = { in, inlen * 8, 0, 0 };
+    bw_t w = { raw, 0 };
+    for (int i = 0; i < n; i++) bw_put(&w, (uint32_t)huff_get(&r, bits, code, len, depth), bits);
+    for (int i = 0; i < tail; i++) bw_put(&w, br_get(&r, 8), 8);
+    *rawlen = (w.bitpos + 7) >> 3;
+    return r.over;
+}
+
 /* poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) on the tape: c[j] coefficients of value +-(c_len - j), one prng_32 word
  * per placement attempt (bit 0: sign, the bits above: position), occupied positions are drawn again.  Returns 1 on underrun. */
 static int uniform_rand_tape(tape_t *T, int32_t *v, int n, const int *c, int c_len)

@@ -75,6 +75,8 @@ def lib():
         u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags='C_CONTIGUOUS')
         L.orc_bliss_sig_to_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_bliss_sig_from_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
+        L.orc_huff_row_encode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
+        L.orc_huff_row_decode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_bliss_keygen.argtypes = [i32p, C.c_int, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
         L.orc_kyber_cpa_enc.argtypes = [i32p, i32p, i32p, u8p, u8p, i32p, i32p]
         L.orc_kyber_cpa_dec.argtypes = [i32p, i32p, i32p, i32p, u8p]
@@ -254,6 +256,28 @@ def bliss_sig_from_huffman(key, coded, tabs):
     r = np.ascontiguousarray(np.frombuffer(bytes(coded), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
     rc = lib().orc_bliss_sig_from_huffman(key.par, r if r.size else np.zeros(1, dtype=np.uint8), r.size, c1, l1, c1.size, c2, l2, c2.size, out, C.byref(n))
     return rc, bytes(out[:n.value])
+
+
+def huffman_table_for(H, bits):
+    """the static table entropy_huffman.c:27-31 walks for fields of `bits` bits: huff_table_gaussian_<min(bits, 7) - 1>, _2 below 4 bits"""
+    k = min(bits, 7) - 1
+    if k < 3:
+        k = 2
+    return ((np.asarray(H[f'huff{k}_code']).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32), np.asarray(H[f'huff{k}_bits']).astype(np.uint16))
+
+
+def huff_row_encode(raw, n, bits, tail, tab):
+    code, ln = tab
+    r = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8)); out = np.zeros(2 * r.size + 64, dtype=np.uint8); m = C.c_size_t(0)
+    rc = lib().orc_huff_row_encode(r, r.size, n, bits, tail, code, ln, code.size, out, C.byref(m))
+    return rc, bytes(out[:m.value])
+
+
+def huff_row_decode(coded, n, bits, tail, tab):
+    code, ln = tab
+    r = np.ascontiguousarray(np.frombuffer(bytes(coded), dtype=np.uint8)); out = np.zeros((n * bits + 7) // 8 + tail + 64, dtype=np.uint8); m = C.c_size_t(0)
+    rc = lib().orc_huff_row_decode(r if r.size else np.zeros(1, dtype=np.uint8), r.size, n, bits, tail, code, ln, code.size, out, C.byref(m))
+    return rc, bytes(out[:m.value])
 
 
 class DilKey:

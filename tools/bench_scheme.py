@@ -1,6 +1,7 @@
 """One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls] [signature file]` runs one warm-up call and `calls`
 timed calls of
-   dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | polymul | cdt
+   dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | ens_sign |
+   rlwe_encrypt | polymul | cdt
 on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call.
 A verify leg never signs in the profiled process: given a signature file that does not exist yet it signs, writes the file and stops (the unprofiled
 preparation run); given one that exists it loads the signatures and only verifies - so a counter pass over the leg contains the leg's kernels alone
@@ -100,6 +101,21 @@ def main():
         tapes = torch.randint(-2**31, 2**31 - 1, (B, 24 * 512), dtype=torch.int32, device='cuda', generator=g)
         ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); made = 1
         fn = lambda: ts.sign(msgs, tapes, fixed_len=64)
+    elif leg == 'ens_sign':                               # ENS signature set 0: Klein's sampler (kleinr_kernel), as bench.py's ens_sig_0
+        G = load_golden('ensdlp_ref.txt'); B = 16384
+        par = np.asarray(G['enssig0_params']); n = int(par[0])
+        sg = eng.ens_dlp_signer(par); sg.set_privkey(G['enssig0_fgFG'])
+        msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+        xt = torch.randint(-2**31, 2**31 - 1, (B, 4 * n), dtype=torch.int32, device='cuda', generator=g)
+        sg.sign(msgs, xt, fixed_len=64); torch.cuda.synchronize(); made = 1
+        fn = lambda: sg.sign(msgs, xt, fixed_len=64)
+    elif leg == 'rlwe_encrypt':                           # RLWE-Enc set 0 encrypt, as bench.py's rlwe_enc_0
+        G = load_golden('rlwe_ref.txt'); B = 262144
+        r = eng.rlwe(G['rlwe0_params']); r.set_pubkey(G['rlwe0_kg_a0'], G['rlwe0_kg_p0'])
+        msgs = torch.randint(0, 256, (B, r.msg_bytes), dtype=torch.uint8, device='cuda', generator=g)
+        tapes = torch.randint(-2**31, 2**31 - 1, (B, r.enc_words), dtype=torch.int32, device='cuda', generator=g)
+        r.encrypt(msgs, tapes); torch.cuda.synchronize(); made = 1
+        fn = lambda: r.encrypt(msgs, tapes)
     elif leg == 'polymul':
         q, n, B = 7681, 256, 65536
         p = eng.plan(q, n)
