@@ -1057,6 +1057,12 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             if (bl_rounds(b, BlRun{ v, b->tu2, b->sigs2, sig_stride, b->siglens2, b->trials2, nv, nullptr, 2u }, in, s)) return SC_HIP_FAILURE;
             hipLaunchKernelGGL(bl_resolve_kernel, dim3(nu), dim3(64), 0, s, b->msg_of2, pp, p0, v.status, b->sigs2, b->siglens2, b->trials2, sig_stride, st.status, d_sigs, d_siglens, trials);
             HIPCHK(hipGetLastError());
+            // the later pairs' candidate signatures - valid signatures under fresh randomness, all but one per message discarded - their vectors and their
+            // bookkeeping do not outlive the call either: zeroed as far as this pass used them
+            HIPCHK(hipMemsetAsync(b->sigs2, 0, (size_t)nv * sig_stride, s));
+            HIPCHK(hipMemsetAsync(b->siglens2, 0, (size_t)nv * 4, s));
+            HIPCHK(hipMemsetAsync(b->trials2, 0, (size_t)nv * 4, s));
+            HIPCHK(hipMemsetAsync(b->tu2, 0, (size_t)nv * 2 * P.n * 4, s));
             p0 += pp;
         }
         // messages an oracle failure threw off the precomputed tape positions: from the start, in order
@@ -1077,8 +1083,9 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     }
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
     // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
-    sc::wipe_async(b->tu, s); sc::wipe_async(b->tin, s); sc::wipe_async(b->v, s); sc::wipe_async(b->z, s);
-    if (b->tu2) sc::wipe_async(b->tu2, s);
+    // (zeroed as far as this batch used them: the arrays are sized for the largest batch the handle has seen)
+    HIPCHK(hipMemsetAsync(b->tu, 0, batch * 2 * P.n * 4, s)); HIPCHK(hipMemsetAsync(b->tin, 0, batch * P.n * 4, s));
+    HIPCHK(hipMemsetAsync(b->v, 0, batch * P.n * 4, s)); HIPCHK(hipMemsetAsync(b->z, 0, batch * P.n * 2, s));
     return SC_HIP_SUCCESS;
 }
 

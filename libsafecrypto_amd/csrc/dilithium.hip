@@ -885,16 +885,18 @@ extern "C" int sc_hip_matvec(sc_hip_plan_t *p, size_t batch, int kk, int l, int 
     const size_t np = (size_t)kk * l;
     hipLaunchKernelGGL(dil_to_internal_mont, dim3((unsigned)((np * N + 255) / 256)), dim3(256), 0, s, d_Ahat, A_int, np, p->k[1], p->r2, p->r2p,
                        transposed ? kk : 0, transposed ? l : 0);
-    HIPCHK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) { (void)hipEventRecord((hipEvent_t)p->mv_event, s); return fail("matvec: kernel launch failed"); }
     sc_hip_dilithium tmp;
     memset(&tmp, 0, sizeof tmp);
     tmp.ctx = p->ctx; tmp.plan = p; tmp.P.n = 256; tmp.P.q = p->q; tmp.P.k = kk; tmp.P.l = l; tmp.P.gamma2 = 1 << 20;
     DilNtt a = base_args(&tmp);
     a.in = d_y; a.out_int = yh; a.yh = yh; a.key = A_int; a.w = d_t; a.w1 = nullptr;
-    if (launch_dil<DOP_FWD_INT>(&tmp, a, (uint32_t)batch, l, s)) return SC_HIP_FAILURE;
-    if (launch_dil<DOP_MATVEC>(&tmp, a, (uint32_t)batch, kk, s)) return SC_HIP_FAILURE;
-    HIPCHK(hipEventRecord((hipEvent_t)p->mv_event, s));
-    return SC_HIP_SUCCESS;
+    // the event marks the END of this call's use of the scratch on every path out of here once work has been queued: a later call on another stream must
+    // never wait on a stale event and overwrite the scratch under a partly queued product
+    int rc = launch_dil<DOP_FWD_INT>(&tmp, a, (uint32_t)batch, l, s);
+    if (rc == SC_HIP_SUCCESS) rc = launch_dil<DOP_MATVEC>(&tmp, a, (uint32_t)batch, kk, s);
+    if (hipEventRecord((hipEvent_t)p->mv_event, s) != hipSuccess && rc == SC_HIP_SUCCESS) rc = fail("matvec: hipEventRecord failed");
+    return rc;
 }
 
 // test hook (include/sc_hip_bench.h): words of the per-call secrets (masks y, w = A y, NTT(y)) that are not zero in the signer's workspace
@@ -1180,6 +1182,20 @@ __global__ __launch_bounds__(HT) void shake_test_kernel(int rate, const uint8_t 
 }
 }  // namespace
 
+// the calls with a key per item fork work onto streams of the handle's own: whatever path leaves such a call, the caller's stream waits for everything
+// that was queued on them (an early return must not leave side work running beside the caller's next call on the same workspace)
+namespace {
+struct JoinGuard {
+    hipStream_t s, side[2];
+    hipEvent_t ev[2];
+    ~JoinGuard()
+    {
+        for (int i = 0; i < 2; i++)
+            if (side[i] && ev[i]) { if (hipEventRecord(ev[i], side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, ev[i], 0); else (void)hipGetLastError(); }
+    }
+};
+}
+
 // t0 of every key from t (decompose, module_lwe.c:89-104), canonical in [0, q): what sc_hip_dilithium_set_privkey does on the host for one key
 __global__ void dil_t0_kernel(const int32_t *__restrict__ t, int32_t *__restrict__ t0, size_t count, int d, int32_t q)
 {
@@ -1227,6 +1243,7 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     }
     HIPCHK(hipEventRecord(d->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(d->side, d->ev_fork, 0));
+    JoinGuard join{ s, { d->side, nullptr }, { d->ev_join, nullptr } };
     if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, d->side)) return SC_HIP_FAILURE;
     HIPCHK(hipEventRecord(d->ev_join, d->side));
     hipLaunchKernelGGL(dil_t0_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s, d_t, t0n, batch * kn, P.d, P.q);
@@ -1295,6 +1312,7 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     HIPCHK(hipEventRecord(d->ev_fork, s));                               // everything the caller queued before (its inputs) is ahead of both streams
     HIPCHK(hipStreamWaitEvent(s2, d->ev_fork, 0));
     HIPCHK(hipStreamWaitEvent(s3, d->ev_fork, 0));
+    JoinGuard join{ s, { s2, s3 }, { d->ev_join, d->ev_join2 } };
     // chain (2) first: its few wavefronts should be resident before the cipher's 7680 take every slot
     const unsigned hb = (B + HT - 1) / HT;
     hipLaunchKernelGGL(dil_crh_t1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s3, d_rho, d_t1, (uint32_t)kn, P.q_bits - P.d, trb, B);

@@ -78,11 +78,13 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
     // in0 is read in the layout the first transform wants
     const int off0 = (OP == OP_INV) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp);
     int32_t nx[16];                                      // raw words of the group about to be processed
+    // loads are unconditional: a group past the end of the batch reads polynomial 0 and is never stored (a guarded load is an exec-mask save, a branch
+    // and a restore per instruction: 80 scalar instructions per trip of the fused kernel)
     {
         const unsigned long long poly = g * PW + pw;
-        const int32_t *src = a.in0 + (size_t)poly * N + off0;
+        const int32_t *src = a.in0 + (size_t)(poly < a.batch ? poly : 0) * N + off0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) nx[r] = (poly < a.batch) ? src[(OP == OP_INV ? brv4(r) : r) * LP] : 0;
+        for (int r = 0; r < 16; r++) nx[r] = src[(OP == OP_INV ? brv4(r) : r) * LP];
     }
 
     for (; g < groups; g += gstride) {
@@ -96,17 +98,17 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
         if (OP == OP_MULNTT || OP == OP_MUL) {
-            const int32_t *srcb = a.in1 + (a.in1_bcast ? 0 : base) + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
+            const int32_t *srcb = a.in1 + ((a.in1_bcast || !valid) ? 0 : base) + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
-            for (int r = 0; r < 16; r++) nb[r] = valid ? srcb[(OP == OP_MULNTT ? brv4(r) : r) * LP] : 0;
+            for (int r = 0; r < 16; r++) nb[r] = srcb[(OP == OP_MULNTT ? brv4(r) : r) * LP];
         }
         // first operand of the next group (run-ahead)
         auto prefetch = [&]() {
             const unsigned long long npoly = (g + gstride) * PW + pw;
             const bool nvalid = (g + gstride < groups) && (npoly < a.batch);
-            const int32_t *src = a.in0 + (size_t)npoly * N + off0;
+            const int32_t *src = a.in0 + (size_t)(nvalid ? npoly : 0) * N + off0;
 #pragma unroll
-            for (int r = 0; r < 16; r++) nx[r] = nvalid ? src[(OP == OP_INV ? brv4(r) : r) * LP] : 0;
+            for (int r = 0; r < 16; r++) nx[r] = src[(OP == OP_INV ? brv4(r) : r) * LP];
         };
         if (OP == OP_FWD || OP == OP_INV) prefetch();
 
