@@ -18,6 +18,8 @@
 #include "huffman_dev.h"
 
 #include <algorithm>
+#include <initializer_list>
+#include <utility>
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -67,8 +69,11 @@ struct St {                  // per-item state arrays (device).  An item is a me
 
 // start of an attempt (bliss_b.c:1366-1373): odd attempts swap t and u, even ones draw 2n fresh samples
 __global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, const uint32_t *tape_lens, uint32_t tape_stride, int n,
-                                uint32_t *need, uint32_t *sbase, uint32_t *siglens, const uint32_t *mlens)
+                                uint32_t *need, uint32_t *sbase, uint32_t *siglens, const uint32_t *mlens, const uint32_t *nd)
 {
+    // nd: the round's item count where the device knows it and the host does not (the round behind one whose outcome was not read back): nact is
+    // then the host's upper bound, the grid is sized for it and the surplus leaves at once
+    if (nd) nact = min(nact, *nd);
     const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx, src = s.msg_of ? s.msg_of[item] : item;
@@ -79,30 +84,42 @@ __global__ void bl_begin_kernel(const uint32_t *active, uint32_t nact, St s, con
     need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + 4u * (uint32_t)n;
 }
 
-// get_vector_32(t), get_vector_32(u): sample s of the attempt uses tape words 2s (high) and 2s+1 (low).  A lane draws two adjacent samples
-// (one 16-byte tape read, one 8-byte store); the table search is the guide + S probes of cdt_guide.h (S = 0: the halving search).
+// get_vector_32(t), get_vector_32(u): sample s of the attempt uses tape words 2s (high) and 2s+1 (low).  A wavefront takes 256 consecutive samples of
+// one item per step - a lane four of them: 32 bytes of tape in, one 16-byte store out - so everything about the item (does it draw, where on its tape,
+// which of its two vectors is current) is wave-uniform and read once per 2 KB of tape rather than once per lane and pair of samples; the table search is
+// the guide + S probes of cdt_guide.h (S = 0: the halving search).
 template <int S>
 __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *cur,
                                                         const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, const uint16_t *gd, CdtGuide g, int size, int32_t *tu, int n,
-                                                        const uint32_t *msg_of)
+                                                        const uint32_t *msg_of, const uint32_t *nd)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    if (nd) nact = min(nact, *nd);
+    const int lps = 31 - __clz(2 * n / 256);                          // log2 of the steps per item (n = 256: 2 steps, n = 512: 4)
+    const size_t steps = (size_t)nact << lps, nwaves = (size_t)gridDim.x * 4;
+    if ((size_t)blockIdx.x * 4 >= steps) return;
     uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
     for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
     if (S) for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
     __syncthreads();
-    const size_t total = (size_t)nact * n, stride = (size_t)gridDim.x * blockDim.x;              // pairs of samples
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        const uint32_t aidx = (uint32_t)(t / (size_t)n); const int sidx = 2 * (int)(t % (size_t)n);
+    const int lane = threadIdx.x & 63;
+    for (size_t ws = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); ws < steps; ws += nwaves) {
+        const uint32_t aidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ws >> lps));
         if (need[aidx] != 1) continue;
         const uint32_t item = active ? active[aidx] : aidx;
+        const int sidx = (((int)ws & ((1 << lps) - 1)) << 8) + 4 * lane;              // first of the lane's four samples, 0 .. 2n-1
         const uint32_t *tp = tapes + (size_t)(msg_of ? msg_of[item] : item) * tape_stride + sbase[aidx] + 2 * sidx;
-        uint32_t w[4];
-        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
-        else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
-        int32_t v[2];
+        uint32_t w[8];
+        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) {
+            const uint4 q0 = reinterpret_cast<const uint4 *>(tp)[0], q1 = reinterpret_cast<const uint4 *>(tp)[1];
+            w[0] = q0.x; w[1] = q0.y; w[2] = q0.z; w[3] = q0.w; w[4] = q1.x; w[5] = q1.y; w[6] = q1.z; w[7] = q1.w;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
+            for (int e = 0; e < 8; e++) w[e] = tp[e];
+        }
+        int32_t v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
             const uint64_t u = ((uint64_t)w[2 * e] << 32) | w[2 * e + 1];
             uint32_t a = 0;
             if (S) a = cdt_lookup<(S > 3 ? 0 : S)>(u, tab, guide, g);
@@ -111,17 +128,19 @@ __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, 
         }
         const uint32_t c = cur[item];
         const int which = sidx < n ? (int)c : (int)(c ^ 1);
-        *reinterpret_cast<int2 *>(tu + ((size_t)item * 2 + which) * n + (sidx % n)) = make_int2(v[0], v[1]);
+        *reinterpret_cast<int4 *>(tu + ((size_t)item * 2 + which) * n + (sidx & (n - 1))) = make_int4(v[0], v[1], v[2], v[3]);
     }
 }
 
 // dense copy of the current t for the NTT product
 // (a key per message: the active messages' public keys a, SINT16 rows, are gathered beside it as the product's second operand)
 __global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n,
-                                const int16_t *a_items = nullptr, int32_t *ain = nullptr, const uint32_t *msg_of = nullptr)
+                                const int16_t *a_items = nullptr, int32_t *ain = nullptr, const uint32_t *msg_of = nullptr, const uint32_t *nd = nullptr)
 {
+    if (nd) nact = min(nact, *nd);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    const int ln = 31 - __clz(n);                                         // n is a power of two (bliss_create): no 64-bit division per element
+    const uint32_t aidx = (uint32_t)(t >> ln); const int i = (int)(t & (size_t)(n - 1));
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     tin[t] = (need[aidx] == 2) ? 0 : tu[((size_t)item * 2 + cur[item]) * n + i];
@@ -129,11 +148,13 @@ __global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uin
 }
 
 // round_and_drop, bliss_b.c:681-703
-__global__ void bl_round_kernel(const uint32_t *active, uint32_t nact, const uint32_t *cur, const int32_t *tu, int32_t *v, int16_t *z, BlissP P)
+__global__ void bl_round_kernel(const uint32_t *active, uint32_t nact, const uint32_t *cur, const int32_t *tu, int32_t *v, int16_t *z, BlissP P, const uint32_t *nd)
 {
+    if (nd) nact = min(nact, *nd);
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = P.n;
-    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    const int ln = 31 - __clz(n);                                         // n is a power of two (bliss_create): no 64-bit division per element
+    const uint32_t aidx = (uint32_t)(t >> ln); const int i = (int)(t & (size_t)(n - 1));
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     const int32_t u = tu[((size_t)item * 2 + (cur[item] ^ 1)) * n + i];
@@ -150,10 +171,11 @@ __global__ void bl_round_kernel(const uint32_t *active, uint32_t nact, const uin
 // byte pairs; the first kappa distinct ones.  mode 0: write them; mode 1 (verify): compare with the signature's.
 __global__ __launch_bounds__(HT) void bl_oracle1_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride,
                                                        const uint32_t *mlens, uint32_t fixed_len, const int16_t *z, int32_t *cidx, uint32_t *ok,
-                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr)
+                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr, const uint32_t *nd = nullptr)
 {
     __shared__ uint64_t st[25 * HT];
     __shared__ uint32_t fl[32 * HT];
+    if (nd) nact = min(nact, *nd);
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
     if (aidx >= nact) return;
@@ -195,10 +217,11 @@ __global__ __launch_bounds__(HT) void bl_oracle1_kernel(const uint32_t *active, 
 // Used while the one-lane form has no more wavefronts than the chip has SIMDs.
 __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *msgs, size_t msg_stride,
                                                        const uint32_t *mlens, uint32_t fixed_len, const int16_t *z, int32_t *cidx, uint32_t *ok,
-                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr)
+                                                       int mode, uint32_t *verdict, BlissP P, const uint32_t *msg_of = nullptr, const uint32_t *nd = nullptr)
 {
     __shared__ uint32_t st[25 * HT];
     __shared__ uint32_t fl[32 * (HT / 2)];
+    if (nd) nact = min(nact, *nd);
     const uint32_t aidx = (blockIdx.x * HT + threadIdx.x) >> 1;
     const bool first = (threadIdx.x & 1) == 0;                     // the lane of the pair that writes results
     Sponge2<HT> sp; sp.init(st, threadIdx.x, 72);
@@ -218,7 +241,8 @@ __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, 
     for (int r = 0; r < 65536 && !done; r++) {
         sp.init(st, threadIdx.x, 72);
         sp.absorb(m, mlen);
-        sp.absorb(zb, 2 * (size_t)P.n);
+        if ((sp.pos & 7) == 0) sp.template absorb_words<9>(reinterpret_cast<const uint32_t *>(zb), P.n / 4);      // z rows are n int16: 8-byte aligned
+        else sp.absorb(zb, 2 * (size_t)P.n);
         sp.absorb_byte((uint8_t)(r >> 8)); sp.absorb_byte((uint8_t)(r & 0xFF));
         sp.finalize(0x06);
         for (int i = 0; i < 64 && !done; i += 2) {
@@ -238,8 +262,20 @@ __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, 
     else if (!done || neq) verdict[item] = 1;
 }
 
-__device__ __forceinline__ int32_t wave_sum(int32_t v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-__device__ __forceinline__ int32_t wave_max(int32_t v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+// Wave-wide sum / maximum, the same value in every lane.  Four DPP steps fold a row of 16 lanes (swap neighbours, swap pairs, mirror the halves of 8,
+// mirror the row) and four v_readlane + scalar adds fold the rows: no LDS crossbar round trip (six dependent ds_bpermute per reduction as __shfl_xor
+// compiles them; greedy_sc does one reduction per challenge index on the critical path of the one-wavefront-per-message decision).
+template <typename F>
+__device__ __forceinline__ int32_t wave_fold(int32_t v, F op)
+{
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));          // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));          // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));         // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));         // row_mirror
+    return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int32_t wave_sum(int32_t v) { return wave_fold(v, [](int32_t a, int32_t b) { return a + b; }); }
+__device__ __forceinline__ int32_t wave_max(int32_t v) { return wave_fold(v, [](int32_t a, int32_t b) { return max(a, b); }); }
 
 struct BitW {
     uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
@@ -257,9 +293,11 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
                                                         const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
                                                         const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
                                                         const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride, uint32_t max_iter)
+                                                        uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride, uint32_t max_iter,
+                                                        const uint32_t *nd)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
+    if (nd) nact = min(nact, *nd);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
     const uint32_t aidx = blockIdx.x * 4 + wid;
     if (aidx >= nact) return;
@@ -285,23 +323,34 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     // greedy_sc
     for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // the lane's coefficients of f and g do not change over the kappa steps: read once (n <= 512: eight per lane), as is the next step's index
+    constexpr int MAXC = 8;
+    int32_t fr[MAXC], gr[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) { const int j = lane + 64 * c; fr[c] = c < C ? (int32_t)f[j] : 0; gr[c] = c < C ? (int32_t)g[j] : 0; }
+    int inext = cidx[(size_t)aidx * P.kappa];
     for (int k = 0; k < P.kappa; k++) {
-        const int i = cidx[(size_t)aidx * P.kappa + k];
+        const int i = inext;
+        if (k + 1 < P.kappa) inext = cidx[(size_t)aidx * P.kappa + k + 1];
         int32_t sgn = 0;
-        for (int c = 0; c < C; c++) {
-            const int j = lane + 64 * c;
-            int idx = i + j; int32_t sg = 1;
-            if (idx >= n) { idx -= n; sg = -1; }
-            sgn += sg * ((int32_t)f[j] * x[idx] + (int32_t)g[j] * y[idx]);
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            if (c < C) {
+                int idx = i + lane + 64 * c; int32_t sg = 1;
+                if (idx >= n) { idx -= n; sg = -1; }
+                sgn += sg * (fr[c] * x[idx] + gr[c] * y[idx]);
+            }
         }
         sgn = wave_sum(sgn);
-        for (int c = 0; c < C; c++) {
-            const int j = lane + 64 * c;
-            int idx = i + j; int32_t sg = 1;
-            if (idx >= n) { idx -= n; sg = -1; }
-            if (sgn > 0) sg = -sg;
-            x[idx] += sg * (int32_t)f[j];
-            y[idx] += sg * (int32_t)g[j];
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) {
+            if (c < C) {
+                int idx = i + lane + 64 * c; int32_t sg = 1;
+                if (idx >= n) { idx -= n; sg = -1; }
+                if (sgn > 0) sg = -sg;
+                x[idx] += sg * fr[c];
+                y[idx] += sg * gr[c];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
@@ -607,7 +656,8 @@ __global__ __launch_bounds__(HT) void bl_kg_sample_kernel(const uint32_t *active
 __global__ void bl_kg_gather_kernel(const uint32_t *active, uint32_t nact, const int32_t *th, int32_t *num, int n)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t aidx = (uint32_t)(t / n); const int i = (int)(t % n);
+    const int ln = 31 - __clz(n);                                         // n is a power of two (bliss_create): no 64-bit division per element
+    const uint32_t aidx = (uint32_t)(t >> ln); const int i = (int)(t & (size_t)(n - 1));
     if (aidx >= nact) return;
     const uint32_t item = active ? active[aidx] : aidx;
     num[t] = th[(size_t)item * n + i];
@@ -851,43 +901,93 @@ struct BlIn {
     const uint32_t *tapes; size_t tape_stride; const uint32_t *tape_lens;
 };
 
-static int bl_rounds(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStream_t s)
+// several arrays zeroed by one launch (a hipMemsetAsync each costs a launch gap of its own: seven in front of a signing call, four behind each pass)
+struct ZeroList { uint8_t *p[8]; size_t bytes[8]; int count; };
+__global__ void bl_zero_kernel(ZeroList L)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x, t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int a = 0; a < L.count; a++) {
+        uint4 *q = reinterpret_cast<uint4 *>(L.p[a]);                 // (hipMalloc'd bases: 16-byte aligned)
+        const size_t n16 = L.bytes[a] / 16;
+        for (size_t i = t0; i < n16; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+        if (t0 < (L.bytes[a] & 15)) L.p[a][n16 * 16 + t0] = 0;
+    }
+}
+static int bl_zero(sc_hip_bliss_t *b, std::initializer_list<std::pair<void *, size_t>> arrays, hipStream_t s)
+{
+    ZeroList L{};
+    size_t most = 0;
+    for (const auto &a : arrays) {
+        if (!a.first || !a.second) continue;
+        if (L.count == 8) return fail("bliss: zero list too long");
+        L.p[L.count] = static_cast<uint8_t *>(a.first); L.bytes[L.count] = a.second; L.count++;
+        if (a.second > most) most = a.second;
+    }
+    if (!L.count) return SC_HIP_SUCCESS;
+    size_t blocks = (most / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > (size_t)b->ctx->cus * 8) blocks = (size_t)b->ctx->cus * 8;
+    hipLaunchKernelGGL(bl_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, L);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// one round over the list `active` (null: identity).  nact is the number of items, or - with nd, the device-side count - the host's upper bound on it:
+// the grids are sized for the bound and the kernels read the count.
+static int bl_round_launch(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStream_t s, const uint32_t *active, uint32_t nact, const uint32_t *nd,
+                           uint32_t *next, uint32_t *next_cnt)
 {
     const BlissP &P = b->P;
     const int n = P.n;
     const St &st = r.st;
+    hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, b->need, b->sbase, r.siglens, in.mlens, nd);
+    const size_t nsamp = (size_t)nact * 2 * n;
+    size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
+    const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
+    if (sblocks > (size_t)b->ctx->cus * (sper > 4 ? 4 : sper)) sblocks = (size_t)b->ctx->cus * (sper > 4 ? 4 : sper);
+    const CdtGuide &cg = b->cdt->g;
+#define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
+                       in.tapes, in.tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, r.tu, n, st.msg_of, nd)
+    switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#undef BL_SAMPLE
+    const size_t ne = (size_t)nact * n;
+    hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, r.tu, b->tin, n, in.ka16, b->ain, st.msg_of, nd);
+    HIPCHK(hipGetLastError());
+    // (with a device-side count the product runs over the bound: rows past the count hold what an earlier round left there and are read by nobody)
+    if (in.ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, r.tu, b->v, b->z, P, nd);
+    // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
+    if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
+        hipLaunchKernelGGL(bl_oracle2_kernel, dim3((2 * nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
+                           0, (uint32_t *)nullptr, P, st.msg_of, nd);
+    else
+        hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
+                           0, (uint32_t *)nullptr, P, st.msg_of, nd);
+    hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, in.tapes, in.tape_stride, in.tape_lens,
+                       in.kf ? in.kf : b->d_f, in.kg ? in.kg : b->d_g, r.tu, b->v, b->z, b->cidx, r.sigs, r.sig_stride, r.siglens, r.trials, next, next_cnt, P, b->tie_rel,
+                       in.kf ? (size_t)n : (size_t)0, r.max_iter, nd);
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+static int bl_rounds(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStream_t s)
+{
+    if (r.items == 0) return SC_HIP_SUCCESS;
+    if (r.max_iter == 2) {
+        // An item is one pair of attempts: two rounds, and an item that fails both ends with status 7 - there is no third.  The second round's list and
+        // its count stay on the device (its kernels read them; grids sized for the first round's count), so nothing is read back here: a read-back
+        // idles the device for 40-50 us, a fifth of such a round.
+        HIPCHK(hipMemsetAsync(b->cnt, 0, 8, s));
+        if (bl_round_launch(b, r, in, s, r.active0, r.items, nullptr, b->act[0], b->cnt)) return SC_HIP_FAILURE;
+        return bl_round_launch(b, r, in, s, b->act[0], r.items, b->cnt, b->act[1], b->cnt + 1);
+    }
     uint32_t nact = r.items;
     const uint32_t *active = r.active0;
     for (uint32_t round = 0; nact > 0; round++) {
         if (round > 100000) return fail("bliss_sign: rejection loop did not terminate");
         uint32_t *next = b->act[round & 1];
         HIPCHK(hipMemsetAsync(b->cnt, 0, 4, s));
-        hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, b->need, b->sbase, r.siglens, in.mlens);
-        const size_t nsamp = (size_t)nact * 2 * n;
-        size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
-        const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
-        if (sblocks > (size_t)b->ctx->cus * (sper > 4 ? 4 : sper)) sblocks = (size_t)b->ctx->cus * (sper > 4 ? 4 : sper);
-        const CdtGuide &cg = b->cdt->g;
-#define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
-                           in.tapes, in.tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, r.tu, n, st.msg_of)
-        switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
-#undef BL_SAMPLE
-        const size_t ne = (size_t)nact * n;
-        hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, r.tu, b->tin, n, in.ka16, b->ain, st.msg_of);
-        HIPCHK(hipGetLastError());
-        if (in.ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, r.tu, b->v, b->z, P);
-        // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
-        if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
-            hipLaunchKernelGGL(bl_oracle2_kernel, dim3((2 * nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
-                               0, (uint32_t *)nullptr, P, st.msg_of);
-        else
-            hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
-                               0, (uint32_t *)nullptr, P, st.msg_of);
-        hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, in.tapes, in.tape_stride, in.tape_lens,
-                           in.kf ? in.kf : b->d_f, in.kg ? in.kg : b->d_g, r.tu, b->v, b->z, b->cidx, r.sigs, r.sig_stride, r.siglens, r.trials, next, b->cnt, P, b->tie_rel,
-                           in.kf ? (size_t)n : (size_t)0, r.max_iter);
-        HIPCHK(hipGetLastError());
+        if (bl_round_launch(b, r, in, s, active, nact, nullptr, next, b->cnt)) return SC_HIP_FAILURE;
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, b->cnt, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -1000,6 +1100,13 @@ static int bl_ensure_ws2(sc_hip_bliss *b, size_t items, size_t sig_stride)
     return SC_HIP_SUCCESS;
 }
 
+// the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates of a call
+static int bl_wipe_vectors(sc_hip_bliss_t *b, size_t batch, hipStream_t s)
+{
+    const size_t n = (size_t)b->P.n;
+    return bl_zero(b, { { b->tu, batch * 2 * n * 4 }, { b->tin, batch * n * 4 }, { b->v, batch * n * 4 }, { b->z, batch * n * 2 } }, s);
+}
+
 static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
                         const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
@@ -1017,12 +1124,14 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     const uint32_t B = (uint32_t)batch;
     St st = b->st;
     st.msg_of = nullptr;
-    HIPCHK(hipMemsetAsync(st.pos, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_buf, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.var_bits, 0, batch * 4, s));
-    HIPCHK(hipMemsetAsync(st.iter, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.cur, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.status, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : b->trials;
-    HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
+    if (bl_zero(b, { { st.pos, batch * 4 }, { st.var_buf, batch * 4 }, { st.var_bits, batch * 4 }, { st.iter, batch * 4 }, { st.cur, batch * 4 }, { st.status, batch * 4 } }, s))
+        return SC_HIP_FAILURE;
+    HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));               // (the caller's array: any alignment)
     const BlIn in{ kf, kg, ka16, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens };
     const bool spec = b->speculate != 0;
+    bool dirty = true;                                                // the handle's vector arrays hold this call's secrets
+    bool status_out = false;                                          // the caller's status array holds the final statuses
     // every message: its first pair of attempts (all of them when the handle runs the plain loop)
     if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, B, nullptr, spec ? 2u : 0u }, in, s)) return SC_HIP_FAILURE;
     if (spec) {
@@ -1037,6 +1146,13 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             HIPCHK(hipMemsetAsync(b->cnt, 0, 8, s));
             hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, ulist, b->act[1], b->cnt);
             HIPCHK(hipMemcpyAsync(both, b->cnt, 8, hipMemcpyDeviceToHost, s));
+            if (p0 > 1 && dirty) {
+                // behind a pass of later pairs this look almost always finds nobody left: the call's closing wipes are queued in front of the wait, so
+                // the device zeroes while the host waits for the two counts (should a message be left, the arrays are simply used and zeroed again)
+                if (bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
+                dirty = false;
+                if (d_status && !b->entropy) { HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s)); status_out = true; }
+            }
             HIPCHK(hipStreamSynchronize(s));
             const uint32_t nu = both[0];
             n8 = both[1];                                             // (status 8 stays: the last pass, the one that finds no 7, leaves the whole list in act[1])
@@ -1055,14 +1171,13 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             HIPCHK(hipGetLastError());
             v.msg_of = b->msg_of2;
             if (bl_rounds(b, BlRun{ v, b->tu2, b->sigs2, sig_stride, b->siglens2, b->trials2, nv, nullptr, 2u }, in, s)) return SC_HIP_FAILURE;
+            dirty = true; status_out = false;
             hipLaunchKernelGGL(bl_resolve_kernel, dim3(nu), dim3(64), 0, s, b->msg_of2, pp, p0, v.status, b->sigs2, b->siglens2, b->trials2, sig_stride, st.status, d_sigs, d_siglens, trials);
             HIPCHK(hipGetLastError());
             // the later pairs' candidate signatures - valid signatures under fresh randomness, all but one per message discarded - their vectors and their
             // bookkeeping do not outlive the call either: zeroed as far as this pass used them
-            HIPCHK(hipMemsetAsync(b->sigs2, 0, (size_t)nv * sig_stride, s));
-            HIPCHK(hipMemsetAsync(b->siglens2, 0, (size_t)nv * 4, s));
-            HIPCHK(hipMemsetAsync(b->trials2, 0, (size_t)nv * 4, s));
-            HIPCHK(hipMemsetAsync(b->tu2, 0, (size_t)nv * 2 * P.n * 4, s));
+            if (bl_zero(b, { { b->sigs2, (size_t)nv * sig_stride }, { b->siglens2, (size_t)nv * 4 }, { b->trials2, (size_t)nv * 4 }, { b->tu2, (size_t)nv * 2 * P.n * 4 } }, s))
+                return SC_HIP_FAILURE;
             p0 += pp;
         }
         // messages an oracle failure threw off the precomputed tape positions: from the start, in order
@@ -1071,6 +1186,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             hipLaunchKernelGGL(bl_reset_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, redo, n8, st);
             HIPCHK(hipGetLastError());
             if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, n8, redo, 0u }, in, s)) return SC_HIP_FAILURE;
+            dirty = true; status_out = false;
         }
     }
     if (b->entropy) {
@@ -1081,11 +1197,10 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
                            b->ht[0], b->ht[1], capw);
         HIPCHK(hipGetLastError());
     }
-    if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+    if (d_status && !status_out) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
     // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
     // (zeroed as far as this batch used them: the arrays are sized for the largest batch the handle has seen)
-    HIPCHK(hipMemsetAsync(b->tu, 0, batch * 2 * P.n * 4, s)); HIPCHK(hipMemsetAsync(b->tin, 0, batch * P.n * 4, s));
-    HIPCHK(hipMemsetAsync(b->v, 0, batch * P.n * 4, s)); HIPCHK(hipMemsetAsync(b->z, 0, batch * P.n * 2, s));
+    if (dirty && bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
     return SC_HIP_SUCCESS;
 }
 

@@ -267,6 +267,54 @@ struct Sponge2 {
             for (; i + 8 <= len; i += 8) absorb_u64(*reinterpret_cast<const uint64_t *>(p + i));
         for (; i < len; i++) absorb_byte(p[i]);
     }
+    // `nwords` 64-bit words from an 8-byte-aligned source, absorbed at a word-aligned position of a sponge whose rate is RW words: the words of the
+    // NEXT block are requested before the current block is permuted (word by word, a lone wavefront pays a memory round trip per word: 9 per block
+    // of SHA3-512).  Loads are unconditional - an index past the end reads the last word again.
+    template <int RW>
+    __device__ __forceinline__ void absorb_words(const uint32_t *__restrict__ src32, int nwords)
+    {
+        int sw = pos >> 3, w0 = 0;
+        const int last = nwords - 1;
+        uint32_t cur[RW], nx[RW];
+        auto fetch = [&](uint32_t (&d)[RW], int from) {
+#pragma unroll
+            for (int j = 0; j < RW; j++) d[j] = src32[2 * (from + j < last ? from + j : last) + h];
+        };
+        fetch(cur, 0);
+        if (sw != 0) {                                               // up to the end of the block the sponge stands in: through the LDS image
+            const int take = (RW - sw) < nwords ? (RW - sw) : nwords;
+            fetch(nx, take);
+#pragma unroll
+            for (int j = 0; j < RW; j++) if (j < take) st[(sw + j) * NT + h] ^= cur[j];
+            sw += take; w0 = take;
+            if (sw == RW) { permute(); sw = 0; }
+#pragma unroll
+            for (int j = 0; j < RW; j++) cur[j] = nx[j];
+        }
+        if (sw == 0 && nwords - w0 >= RW) {                          // whole blocks: the state stays in registers from block to block
+            uint32_t x[25];
+#pragma unroll
+            for (int w = 0; w < 25; w++) x[w] = st[w * NT + h];
+            while (nwords - w0 >= RW) {
+                fetch(nx, w0 + RW);
+#pragma unroll
+                for (int j = 0; j < RW; j++) x[j] ^= cur[j];
+                keccak_permute_halves<STD>(x, h);
+                w0 += RW;
+#pragma unroll
+                for (int j = 0; j < RW; j++) cur[j] = nx[j];
+            }
+#pragma unroll
+            for (int w = 0; w < 25; w++) st[w * NT + h] = x[w];
+        }
+        if (w0 < nwords) {                                           // fewer than a block left (sw = 0 here, or the source ended inside the first block)
+            const int take = nwords - w0;
+#pragma unroll
+            for (int j = 0; j < RW; j++) if (j < take) st[(sw + j) * NT + h] ^= cur[j];
+            sw += take;
+        }
+        pos = sw * 8;
+    }
     __device__ __forceinline__ void finalize(uint32_t pad = 0x1F)
     {
         if (((pos >> 2) & 1) == h) st[(pos >> 3) * NT + h] ^= pad << (8 * (pos & 3));

@@ -49,7 +49,8 @@ __global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_
 __global__ void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t slot = (uint32_t)(t / P.n); const int i = (int)(t % P.n);
+    const int ln = 31 - __clz(P.n);                                       // n is a power of two
+    const uint32_t slot = (uint32_t)(t >> ln); const int i = (int)(t & (size_t)(P.n - 1));
     if (slot >= nslots) return;
     if (need[slot] != 1) { y[t] = 0; return; }
     const uint32_t aidx = slot / S;
