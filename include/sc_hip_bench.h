@@ -45,6 +45,9 @@ int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, in
  * workspace - 0 behind every signing call (the reference zeroes sc->temp, dilithium.c:1964-1975) */
 int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *h, unsigned long long *nonzero_words);
 
+/* the same for a Falcon handle: the sampler's working polynomials (6n doubles per signature) and the lattice point s1 | s2 before packing */
+int sc_hip_falcon_workspace_residue(sc_hip_falcon_t *h, unsigned long long *nonzero_words);
+
 /* process-wide: on = 0 stops the library from registering (pinning) caller memory in its host-buffer entries - every transfer then takes the
  * runtime's staged path; 1 (default) registers the whole pages inside the caller's buffers; 2 registers the caller's ranges as they are, edge pages
  * included (what round 2 did).  For bisecting transfer problems (profiles/r03_host_pin_bisect.txt). */

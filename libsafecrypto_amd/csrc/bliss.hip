@@ -268,10 +268,10 @@ __global__ __launch_bounds__(HT) void bl_oracle2_kernel(const uint32_t *active, 
 template <typename F>
 __device__ __forceinline__ int32_t wave_fold(int32_t v, F op)
 {
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));          // quad_perm [1,0,3,2]
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));          // quad_perm [2,3,0,1]
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));         // row_half_mirror
-    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xF, 0xF, false));         // row_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));          // quad_perm [1,0,3,2]
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));          // quad_perm [2,3,0,1]
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));         // row_half_mirror
+    v = op(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));         // row_mirror
     return op(op(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), op(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 __device__ __forceinline__ int32_t wave_sum(int32_t v) { return wave_fold(v, [](int32_t a, int32_t b) { return a + b; }); }

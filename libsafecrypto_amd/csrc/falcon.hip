@@ -841,9 +841,9 @@ struct LeafPre {
                 const bool live = j > 0 || g != 0;                       // entry 0 is not part of the search (gaussian_cdf.c:536-553: b starts at 1)
                 cnt += ((live && e < x0) ? 1u : 0u) + ((live && e < x1) ? 0x10000u : 0u);
             }
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <-> 7 - i of each 8
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0xB1, 0xF, 0xF, true);      // quad_perm [1,0,3,2]
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x4E, 0xF, 0xF, true);      // quad_perm [2,3,0,1]
+            cnt += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, 0x141, 0xF, 0xF, true);     // row_half_mirror: lane i <-> 7 - i of each 8
             const int32_t a0 = (int32_t)(cnt & 0xFFFFu), a1 = (int32_t)(cnt >> 16);
             d[2 * lf] = (double)((x0 & 1) ? a0 : -a0);
             d[2 * lf + 1] = (double)((x1 & 1) ? a1 : -a1);
@@ -1184,15 +1184,20 @@ __global__ __launch_bounds__(HT) void fal_hash1_kernel(uint32_t batch, const uin
         y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
         return (int32_t)y;
     };
-    // the 168-byte rate is 21 state words = 42 little-endian 32-bit draws per permutation, read straight from the state
-    for (int i = 0; i < P.n;) {
-#pragma unroll 1
-        for (int w = 0; w < 21 && i < P.n; w++, i += 2) {
-            const uint64_t v = sp.st[w * HT];
-            *reinterpret_cast<int2 *>(cb + i) = make_int2(map((uint32_t)v), map((uint32_t)(v >> 32)));
-        }
-        if (i < P.n) sp.permute();
+    // the 168-byte rate is 21 state words = 42 little-endian 32-bit draws per permutation.  The squeeze walks whole blocks, so the state stays in
+    // registers from here on (n = 1024 is 25 permutations: no LDS round trip in between, the stores of a block leave while the next is computed)
+    uint64_t x[25];
+#pragma unroll
+    for (int w = 0; w < 25; w++) x[w] = sp.st[w * HT];
+    int i = 0;
+    for (; i + 42 <= P.n; i += 42) {                                    // whole blocks: unconditional stores
+#pragma unroll
+        for (int w = 0; w < 21; w++) *reinterpret_cast<int2 *>(cb + i + 2 * w) = make_int2(map((uint32_t)x[w]), map((uint32_t)(x[w] >> 32)));
+        if (i + 42 < P.n) keccak_permute_regs<false>(x);
     }
+#pragma unroll
+    for (int w = 0; w < 21; w++)
+        if (i + 2 * w < P.n) *reinterpret_cast<int2 *>(cb + i + 2 * w) = make_int2(map((uint32_t)x[w]), map((uint32_t)(x[w] >> 32)));
 }
 
 // The same with two lanes per message (Sponge2, keccak_dev.h): lane h of a pair owns the 32-bit half h of every state word, i.e.
@@ -1216,12 +1221,19 @@ __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uin
         y -= (uint32_t)((int32_t)(q - y) >> 31) * q;                 // as written in the reference: ADDS q when y > q
         return (int32_t)y;
     };
-    // the 168-byte rate is 21 state words = 42 little-endian 32-bit draws per permutation, read straight from the state
-    for (int i = 0; i < P.n;) {
-#pragma unroll 1
-        for (int w = 0; w < 21 && i < P.n; w++, i += 2) cb[i + h] = map(sp.st[w * HT + h]);
-        if (i < P.n) sp.permute();
+    // the 168-byte rate is 21 state words = 42 little-endian 32-bit draws per permutation; the state stays in registers over the squeeze (as above)
+    uint32_t x[25];
+#pragma unroll
+    for (int w = 0; w < 25; w++) x[w] = sp.st[w * HT + h];
+    int i = 0;
+    for (; i + 42 <= P.n; i += 42) {                                    // whole blocks: unconditional stores
+#pragma unroll
+        for (int w = 0; w < 21; w++) cb[i + 2 * w + h] = map(x[w]);
+        if (i + 42 < P.n) keccak_permute_halves<false>(x, h);
     }
+#pragma unroll
+    for (int w = 0; w < 21; w++)
+        if (i + 2 * w < P.n) cb[i + 2 * w + h] = map(x[w]);
 }
 
 __device__ __forceinline__ int32_t centre_mod(int32_t x, int32_t q)      // ntt center_32: the representative in [-(q-1)/2, (q-1)/2]
@@ -1261,26 +1273,39 @@ struct BitW {                // generic MSB-first packer (any coefficient width)
 
 // falcon.c:879-905: centre s2, norm test (no retry in the reference), raw (q_bits-2)-bit MSB-first packing of s2.
 // One wavefront per signature; coefficient i = lane + 64 k.
-__global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, const int32_t *__restrict__ s1, int32_t *__restrict__ s2, uint8_t *__restrict__ sigs, size_t sig_stride,
-                                                             uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P)
+// The kernel is also the last reader of what a signing call must not leave behind - the lattice point s1 | s2 before packing and, one kernel back,
+// the sampler's working polynomials (products with the secret basis; ws) - and zeroes them: wavefront b its rows of s1 and s2 and every batch-th
+// kilobyte of the workspace range read as one linear array (whatever layout the sampler's mapping gave it; at any moment the wavefronts write one
+// contiguous region, as a memset would): one launch instead of three memsets behind it.  (The 0.4 GB of zeroes per 8192 signatures cost their
+// ~55 us of HBM write time wherever they are issued - measured here, as memsets, and from the sampler's own epilogue, where they delayed the
+// loads queued behind them by as much as they saved.)
+__global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, int32_t *s1, int32_t *s2, uint8_t *__restrict__ sigs, size_t sig_stride,
+                                                             uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P, double *ws, uint32_t ws_pieces)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t fin_lds[];       // per wave: n squares
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = P.n;
     const uint32_t b = blockIdx.x * FW + wv;
     if (b >= batch) return;
-    if (status[b] == 2 || status[b] == 6) { if (lane == 0) siglens[b] = 0; return; }      // tape too short / no such key: nothing was sampled
+    if (ws) {
+        const size_t total = (size_t)ws_pieces * 3 * n, stride = (size_t)batch * 64;                // 16-byte pieces: 6n doubles per signature slot
+        uint4 *z = reinterpret_cast<uint4 *>(ws);
+        for (size_t i = (size_t)b * 64 + lane; i < total; i += stride) z[i] = make_uint4(0, 0, 0, 0);
+    }
+    int32_t *a1 = s1 + (size_t)b * n, *a2 = s2 + (size_t)b * n;
+    auto wipe_row = [&](int32_t *row) { for (int i = lane; i < n / 4; i += 64) reinterpret_cast<int4 *>(row)[i] = make_int4(0, 0, 0, 0); };
+    if (status[b] == 2 || status[b] == 6) { if (lane == 0) siglens[b] = 0; wipe_row(a1); wipe_row(a2); return; }      // tape too short / no such key: nothing was sampled
     int32_t *sq = fin_lds + (size_t)wv * n;
-    const int32_t *a1 = s1 + (size_t)b * n; int32_t *a2 = s2 + (size_t)b * n;
     for (int i = lane; i < n; i += 64) {
         const int32_t x = a1[i], y = centre_mod(a2[i], P.q);
         a2[i] = y;
+        a1[i] = 0;
         sq[i] = x * x + y * y;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int bad = 0;
     if (lane == 0) bad = norm_fails_lds(sq, n, P.bd) ? 1 : 0;
     bad = __shfl(bad, 0);
-    if (bad) { if (lane == 0) { status[b] = 4; siglens[b] = 0; } return; }
+    if (bad) { if (lane == 0) { status[b] = 4; siglens[b] = 0; } wipe_row(a2); return; }
     uint8_t *out = sigs + (size_t)b * sig_stride;
     const int bits = P.q_bits - 2;
     if (bits == 12) {
@@ -1297,6 +1322,8 @@ __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, con
         siglens[b] = bw.nbytes;
         status[b] = 1;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();      // (the row is read above by other lanes than the ones that zero it)
+    wipe_row(a2);
 }
 
 // ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------
@@ -1870,6 +1897,34 @@ static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c,
     return SC_HIP_SUCCESS;
 }
 
+// test hook (include/sc_hip_bench.h): 32-bit words of the signer's per-call secrets (the sampler's working polynomials, s1 | s2 before packing) that
+// are not zero in the handle's workspace
+namespace {
+__global__ void fal_residue_kernel(const uint32_t *p, size_t words, unsigned long long *count)
+{
+    unsigned long long c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) c += p[i] != 0;
+    if (c) atomicAdd(count, c);
+}
+}
+extern "C" int sc_hip_falcon_workspace_residue(sc_hip_falcon_t *f, unsigned long long *nonzero_words)
+{
+    if (!f || !nonzero_words) return fail("falcon_workspace_residue: null argument");
+    *nonzero_words = 0;
+    if (!f->cap) return SC_HIP_SUCCESS;
+    HIPCHK(hipSetDevice(f->ctx->device));
+    unsigned long long *cnt = nullptr;
+    HIPCHK(hipMalloc((void **)&cnt, 8));
+    (void)hipMemset(cnt, 0, 8);
+    const size_t n = f->P.n;
+    const struct { const void *p; size_t words; } parts[3] = { { f->ws, (f->cap + SPW_MAX - 1) / SPW_MAX * SPW_MAX * 6 * n * 2 }, { f->s1, f->cap * n }, { f->s2, f->cap * n } };
+    for (const auto &pt : parts) hipLaunchKernelGGL(fal_residue_kernel, dim3(1024), dim3(256), 0, nullptr, (const uint32_t *)pt.p, pt.words, cnt);
+    int rc = SC_HIP_SUCCESS;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(nonzero_words, cnt, 8, hipMemcpyDeviceToHost) != hipSuccess) rc = fail("falcon_workspace_residue: device error");
+    (void)hipFree(cnt);
+    return rc;
+}
+
 static int fal_check_common(const sc_hip_falcon *f, size_t batch, const char *who)
 {
     if (!f) return fail(std::string(who) + ": null handle");
@@ -2106,9 +2161,9 @@ static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s, nullptr, d_key_of)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P);
+    hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P,
+                       f->ws, (uint32_t)((batch + SPW_MAX - 1) / SPW_MAX * SPW_MAX));
     HIPCHK(hipGetLastError());
-    fal_wipe(f, batch, s);
     return SC_HIP_SUCCESS;
 }
 

@@ -74,6 +74,7 @@ def test_sign_verify_reproduce_reference(eng, G, set_, nmsg):
     sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
     for m in range(nmsg):
         assert bytes(sh[m, :lh[m]]) == bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8)), m
+    assert f.workspace_residue() == 0        # the sampler's working polynomials and s1 | s2 before packing are zeroed inside the call
     assert f.verify(mb, sigs, siglens, mlens=ml).cpu().tolist() == [int(G[f'{tag}_verify'][2 * m]) for m in range(nmsg)] == [0] * nmsg
     bad = sigs.clone(); bad[:, key.sig_bytes // 3] ^= 0x10          # the fixture's tampering
     assert f.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [int(G[f'{tag}_verify'][2 * m + 1]) for m in range(nmsg)] == [1] * nmsg
@@ -189,6 +190,7 @@ def test_full_size_config5(eng, G):
         assert (rc, st[i]) in ((0, 1), (1, 4)), i
         if rc == 0:
             assert bytes(sh[i, :lh[i]]) == sig, i
+    assert f.workspace_residue() == 0                         # (the sampler and the finishing kernel zero what they are the last readers of)
     v = f.verify(msgs, sigs, siglens, fixed_len=64).cpu().numpy()
     assert np.array_equal(v[ok], np.zeros(int(ok.sum()), dtype=v.dtype)) and (v[~ok] == 1).all()
     m2 = msgs.clone(); m2[:, 63] ^= 0x80
@@ -197,6 +199,7 @@ def test_full_size_config5(eng, G):
         f.set_mapping(lanes)
         s2_, l2_, st2_ = f.sign(msgs, tapes, fixed_len=64)
         assert torch.equal(s2_, sigs) and torch.equal(l2_, siglens) and torch.equal(st2_, status), lanes
+        assert f.workspace_residue() == 0, lanes              # (these mappings leave the workspace to the finishing kernel)
     f.close()
 
 
