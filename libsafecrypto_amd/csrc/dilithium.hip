@@ -22,6 +22,7 @@
 #include "mlwe_kernels.h"
 
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 using namespace sc;
@@ -169,13 +170,20 @@ __global__ void dil_wipe_kernel(const uint32_t *rs, int32_t *y, uint32_t y_words
 // y = ExpandMask(K, mu, kappa)  (module_lwe.c:201-244): SHAKE256(mu || K || kappa_hi || kappa_lo) -> 20-bit fields, rejection below 2 gamma_1 - 2.
 // One lane per attempt.  The input is 82 bytes - one block - and the squeeze walks whole blocks, so the sponge needs no dynamic addressing:
 // the state stays in registers from beginning to end (no LDS round trip per permutation, no LDS limit on residency).
+// TWO: two lanes per attempt - lane h of a pair holds the 32-bit half h of every state word (keccak_permute_halves: 125 instead of 190 vector
+// instructions per round).  The kernel is a chain of ~25 permutations per attempt at less than one wavefront per SIMD for any batch BASELINE names,
+// i.e. it runs at the issue rate of a lone wavefront: what counts is the length of that chain, not the work.  Both lanes parse the squeezed block
+// (each fetches the partner's halves with two DPP moves per word); the even lane stores.
+template <bool TWO>
 __global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, const uint32_t *active, const uint32_t *kappa, const uint8_t *K,
                                                         const uint8_t *mu, int32_t *y, int limit, int32_t gamma1, int32_t q, uint32_t K_stride, uint32_t *slot_item,
                                                         int32_t *wipe_w, uint32_t wipe_w_words, uint32_t *wipe_yh)
 {
-    const uint32_t aidx = blockIdx.x * EXP_T + threadIdx.x;
+    constexpr uint32_t APB = TWO ? EXP_T / 2 : EXP_T;                       // attempts per workgroup
+    const uint32_t aidx = TWO ? (blockIdx.x * EXP_T + threadIdx.x) >> 1 : blockIdx.x * EXP_T + threadIdx.x;
+    const int h = TWO ? (int)(threadIdx.x & 1) : 0;
     const uint32_t S = rs[RS_S], nslots = rs[RS_NSLOTS];
-    const uint32_t nhb = (nslots + EXP_T - 1) / EXP_T;                      // workgroups that hash
+    const uint32_t nhb = (nslots + APB - 1) / APB;                          // workgroups that hash
     if (blockIdx.x >= nhb) {
         // A workgroup with no attempt to expand zeroes the masks y and the products w = A y that the PREVIOUS round left in slots this round does
         // not overwrite, [nslots, prev) - the per-call secrets (dilithium.c:1964-1975).  Every slot is zeroed once per call, by workgroups that would
@@ -197,60 +205,116 @@ __global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, c
     if (aidx >= nslots) return;
     // slot aidx = (message index in the round's list) * S + attempt: message active[aidx / S], kappa = the message's base + aidx % S
     const uint32_t item = active ? active[aidx / S] : aidx / S;
-    slot_item[aidx] = item;
+    if (h == 0) slot_item[aidx] = item;
     const uint32_t kp = (kappa[item] + aidx % S) & 0xFFFFu;            // UINT16 kappa (dilithium.c:1421)
-    uint64_t s[25];
-    const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)item * 48);     // the workspace's own array: aligned
+    uint64_t s[TWO ? 1 : 25];
+    uint32_t x[TWO ? 25 : 1];
     const uint8_t *kb = K + (size_t)item * K_stride;                   // K_stride = 32: a key per message (the caller's buffer: any alignment)
+    if constexpr (TWO) {
+        const uint32_t *m4 = reinterpret_cast<const uint32_t *>(mu + (size_t)item * 48) + h;     // the workspace's own array: aligned
 #pragma unroll
-    for (int w = 0; w < 6; w++) s[w] = m8[w];
-    if ((reinterpret_cast<uintptr_t>(kb) & 7) == 0) {
+        for (int w = 0; w < 6; w++) x[w] = m4[2 * w];
+        if ((reinterpret_cast<uintptr_t>(kb) & 3) == 0) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) s[6 + w] = reinterpret_cast<const uint64_t *>(kb)[w];
-    } else {
+            for (int w = 0; w < 4; w++) x[6 + w] = reinterpret_cast<const uint32_t *>(kb)[2 * w + h];
+        } else {
 #pragma unroll
-        for (int w = 0; w < 4; w++) {
-            uint64_t v = 0;
+            for (int w = 0; w < 4; w++) {
+                uint32_t v = 0;
 #pragma unroll
-            for (int b = 0; b < 8; b++) v |= (uint64_t)kb[8 * w + b] << (8 * b);
-            s[6 + w] = v;
+                for (int b = 0; b < 4; b++) v |= (uint32_t)kb[8 * w + 4 * h + b] << (8 * b);
+                x[6 + w] = v;
+            }
         }
-    }
-    s[10] = (uint64_t)(kp >> 8) | ((uint64_t)(kp & 0xFF) << 8) | (0x1Full << 16);     // kappa high byte first, then the SHAKE pad
+        x[10] = h ? 0u : ((kp >> 8) | ((kp & 0xFFu) << 8) | (0x1Fu << 16));        // kappa high byte first, then the SHAKE pad
 #pragma unroll
-    for (int w = 11; w < 25; w++) s[w] = 0;
-    s[16] ^= 0x80ull << 56;                                              // rate 136: last byte of word 16
-    keccak_permute_regs<false>(s);
+        for (int w = 11; w < 25; w++) x[w] = 0;
+        if (h) x[16] = 0x80u << 24;                                          // rate 136: last byte of word 16
+        keccak_permute_halves<false>(x, h);
+    } else {
+        const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)item * 48);
+#pragma unroll
+        for (int w = 0; w < 6; w++) s[w] = m8[w];
+        if ((reinterpret_cast<uintptr_t>(kb) & 7) == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) s[6 + w] = reinterpret_cast<const uint64_t *>(kb)[w];
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                uint64_t v = 0;
+#pragma unroll
+                for (int b = 0; b < 8; b++) v |= (uint64_t)kb[8 * w + b] << (8 * b);
+                s[6 + w] = v;
+            }
+        }
+        s[10] = (uint64_t)(kp >> 8) | ((uint64_t)(kp & 0xFF) << 8) | (0x1Full << 16);     // kappa high byte first, then the SHAKE pad
+#pragma unroll
+        for (int w = 11; w < 25; w++) s[w] = 0;
+        s[16] ^= 0x80ull << 56;                                              // rate 136: last byte of word 16
+        keccak_permute_regs<false>(s);
+    }
     const uint32_t thresh = (uint32_t)(2 * gamma1 - 2);
     const int32_t add = q + gamma1 - 1;
     int32_t *yy = y + (size_t)aidx * limit;
     // The 5-byte groups of the reference (two 20-bit samples: b0 | b1<<8 | (b2&15)<<16 and b2>>4 | b3<<4 | b4<<12, module_lwe.c:218-236)
-    // are consecutive 20-bit fields of the squeezed stream read as a little-endian bit string.
-    int j = 0;                                                          // limit = l n: a multiple of 4
-    int32_t q0 = 0, q1 = 0, q2 = 0;
-    uint64_t buf = 0; int nb = 0;
-    while (j < limit) {
+    // are consecutive 20-bit fields of the squeezed stream read as a little-endian bit string.  A 136-byte block is 54.4 fields, so where the fields
+    // sit in a block repeats every five blocks (272 fields = 68 groups of four): the loop body is five blocks with every field's position - and its
+    // place in its group of four - known at compile time (one or two instructions to cut a field out, no bit buffer, no per-field branch).
+    // Rejection is rare (2^20 - (2 gamma_1 - 2) values of 2^20: 0.1 %): a group whose four fields are all accepted leaves as one 16-byte store
+    // (every lane of a store instruction writes to a line of its own, and a 4-byte piece of it costs the memory system as much as a 16-byte one);
+    // only a lane that rejected something, or is four samples from the end, goes field by field.
+    struct __attribute__((packed, aligned(4))) Four { int32_t a, b, c, d; };       // a lane that has rejected a field stores its later groups off 16-byte boundaries
+    int j = 0;
+    int32_t gv[4] = { 0, 0, 0, 0 };
+    bool gok[4] = { false, false, false, false };
+    uint32_t pc[34], carry = 0;
+    auto pieces = [&]() {
 #pragma unroll
         for (int w = 0; w < 17; w++) {
-#pragma unroll
-            for (int hlf = 0; hlf < 2; hlf++) {
-                buf |= (uint64_t)(uint32_t)(s[w] >> (32 * hlf)) << nb; nb += 32;
-                while (nb >= 20) {
-                    const uint32_t smp = (uint32_t)buf & 0xFFFFFu;
-                    buf >>= 20; nb -= 20;
-                    // a lane's samples leave four at a time: every lane of a store instruction writes to a line of its own, and a 4-byte piece of it
-                    // costs the memory system as much as a 16-byte one
-                    if (smp < thresh && j < limit) {
-                        const int32_t v = add - (int32_t)smp;
-                        const int e = j & 3;
-                        q0 = e == 0 ? v : q0; q1 = e == 1 ? v : q1; q2 = e == 2 ? v : q2;
-                        if (e == 3) *reinterpret_cast<int4 *>(yy + (j & ~3)) = make_int4(q0, q1, q2, v);
-                        j++;
-                    }
-                }
-            }
+            if constexpr (TWO) {                                         // half 0 / half 1 of the word, each from the lane of the pair that holds it
+                pc[2 * w] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[w], 0xA0, 0xF, 0xF, true);          // quad_perm [0,0,2,2]
+                pc[2 * w + 1] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[w], 0xF5, 0xF, 0xF, true);      // quad_perm [1,1,3,3]
+            } else { pc[2 * w] = (uint32_t)s[w]; pc[2 * w + 1] = (uint32_t)(s[w] >> 32); }
         }
-        if (j < limit) keccak_permute_regs<false>(s);
+    };
+    auto flush = [&]() {
+        if (gok[0] & gok[1] & gok[2] & gok[3] & (j + 4 <= limit)) {
+            if (h == 0) *reinterpret_cast<Four *>(yy + j) = Four{ gv[0], gv[1], gv[2], gv[3] };
+            j += 4;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                if (gok[e] && j < limit) { if (h == 0) yy[j] = gv[e]; j++; }
+        }
+    };
+    // block PH of the five: r bits of its first field are the top r bits of the previous block's last piece (carry); F0 fields came before it
+    auto block = [&](auto ph) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int r = (8 * PH) % 20, nf = (1088 + r) / 20, F0 = PH == 0 ? 0 : PH == 1 ? 54 : PH == 2 ? 108 : PH == 3 ? 163 : 217;
+        pieces();
+#pragma unroll
+        for (int i = 0; i < nf; i++) {
+            const int st = 20 * i - r;
+            uint32_t f;
+            if (st < 0) f = __builtin_amdgcn_alignbit(pc[0], carry, 32 - r);
+            else {
+                const int p = st >> 5, o = st & 31;
+                f = o <= 12 ? (pc[p] >> o) : __builtin_amdgcn_alignbit(pc[p < 33 ? p + 1 : 33], pc[p], o);
+            }
+            f &= 0xFFFFFu;
+            const int slot = (F0 + i) & 3;
+            gv[slot] = add - (int32_t)f; gok[slot] = f < thresh;
+            if (slot == 3) flush();
+        }
+        carry = pc[33];
+        if (j < limit) { if constexpr (TWO) keccak_permute_halves<false>(x, h); else keccak_permute_regs<false>(s); }
+    };
+    while (j < limit) {
+        block(std::integral_constant<int, 0>{});
+        if (j < limit) block(std::integral_constant<int, 1>{});
+        if (j < limit) block(std::integral_constant<int, 2>{});
+        if (j < limit) block(std::integral_constant<int, 3>{});
+        if (j < limit) block(std::integral_constant<int, 4>{});
     }
 }
 
@@ -260,71 +324,115 @@ __global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, c
 // The hash input mu || w1 is 6 + 32 k whole 64-bit words: it is absorbed 21 words (one SHAKE128 block) at a time with the state in registers, and the
 // next block's words are requested before the current block is permuted - a lane walks its own 1.5 KB of w1, and a sponge that fetched word by
 // word paid the latency of every one of those loads in sequence.  Only the 72 output bytes are addressed dynamically (through LDS).
-template <bool SIGN>
+// TWO: two lanes per hash - lane h of a pair holds the 32-bit half h of every state word (keccak_permute_halves), reads its half of every input word,
+// and the pair shares the column of LDS the challenge polynomial is built in: its zeroing, its conversion and (verify) its comparison are split
+// between the two lanes, the 60 dependent steps of the oracle run on the even one.  Like ExpandMask this kernel is a chain of permutations
+// (11 for Dilithium-III) at a fraction of a wavefront per SIMD: the two-lane form shortens the chain by a third.
+template <bool SIGN, bool TWO>
 __global__ __launch_bounds__(CH_T) void dil_challenge_kernel(const uint32_t *rs, const uint32_t *slot_item, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
                                                            int w1len, int weight, int8_t *c8, const int32_t *c32, uint32_t *verdict)
 {
-    __shared__ uint64_t ob[9 * CH_T];
-    __shared__ int8_t cc[CH_T * N];
-    const uint32_t aidx = blockIdx.x * CH_T + threadIdx.x;
+    constexpr int APB = TWO ? CH_T / 2 : CH_T;                                  // hashes per workgroup
+    __shared__ uint32_t ob[18 * APB];                                          // the 72 output bytes: half hh of word w at ob[(2 w + hh) * APB + column]
+    __shared__ int8_t cc[APB * N];
+    const uint32_t col = TWO ? threadIdx.x >> 1 : threadIdx.x;
+    const int h = TWO ? (int)(threadIdx.x & 1) : 0;
+    const uint32_t aidx = blockIdx.x * APB + col;
     if (SIGN) nact = rs[RS_NSLOTS];
-    if (blockIdx.x * CH_T >= nact) return;                                       // (whole workgroup)
+    if (blockIdx.x * APB >= nact) return;                                        // (whole workgroup)
     const bool valid = aidx < nact;
     const uint32_t item = valid ? aidx : 0;                                    // slot: index of w1 / c
     const uint32_t mitem = valid ? (slot_item ? slot_item[aidx] : aidx) : 0;   // message: index of mu
-    const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)mitem * 48), *w8 = reinterpret_cast<const uint64_t *>(w1 + (size_t)item * w1len);
     const int total = 6 + w1len / 8;                                           // words of input
-    auto word = [&](int gi) -> uint64_t {                                      // unconditional loads (a guarded one is a branch with a wait inside)
-        const int ci = gi < total ? gi : total - 1;
-        const uint64_t v = ci < 6 ? m8[ci] : w8[ci - 6];
-        return gi < total ? v : 0;
-    };
-    uint64_t s[25], cur[21];
+    if constexpr (TWO) {
+        const uint32_t *m4 = reinterpret_cast<const uint32_t *>(mu + (size_t)mitem * 48) + h, *w4 = reinterpret_cast<const uint32_t *>(w1 + (size_t)item * w1len) + h;
+        auto word = [&](int gi) -> uint32_t {                                  // unconditional loads (a guarded one is a branch with a wait inside)
+            const int ci = gi < total ? gi : total - 1;
+            const uint32_t v = ci < 6 ? m4[2 * ci] : w4[2 * (ci - 6)];
+            return gi < total ? v : 0;
+        };
+        uint32_t x[25], cur[21];
 #pragma unroll
-    for (int w = 0; w < 25; w++) s[w] = 0;
+        for (int w = 0; w < 25; w++) x[w] = 0;
 #pragma unroll
-    for (int w = 0; w < 21; w++) cur[w] = word(w);
-    int base = 0;
-    for (; base + 21 <= total; base += 21) {
-        uint64_t nxt[21];
+        for (int w = 0; w < 21; w++) cur[w] = word(w);
+        int base = 0;
+        for (; base + 21 <= total; base += 21) {
+            uint32_t nxt[21];
 #pragma unroll
-        for (int w = 0; w < 21; w++) nxt[w] = word(base + 21 + w);
+            for (int w = 0; w < 21; w++) nxt[w] = word(base + 21 + w);
 #pragma unroll
-        for (int w = 0; w < 21; w++) s[w] ^= cur[w];
+            for (int w = 0; w < 21; w++) x[w] ^= cur[w];
+            keccak_permute_halves<false>(x, h);
+#pragma unroll
+            for (int w = 0; w < 21; w++) cur[w] = nxt[w];
+        }
+        const int rem = total - base;                                          // 0..20 words of the last block, then the pad
+#pragma unroll
+        for (int w = 0; w < 21; w++) { x[w] ^= cur[w]; if (w == rem && h == 0) x[w] ^= 0x1F; }
+        if (h) x[20] ^= 0x80u << 24;
+        keccak_permute_halves<false>(x, h);
+#pragma unroll
+        for (int w = 0; w < 9; w++) ob[(2 * w + h) * APB + col] = x[w];
+    } else {
+        const uint64_t *m8 = reinterpret_cast<const uint64_t *>(mu + (size_t)mitem * 48), *w8 = reinterpret_cast<const uint64_t *>(w1 + (size_t)item * w1len);
+        auto word = [&](int gi) -> uint64_t {                                  // unconditional loads (a guarded one is a branch with a wait inside)
+            const int ci = gi < total ? gi : total - 1;
+            const uint64_t v = ci < 6 ? m8[ci] : w8[ci - 6];
+            return gi < total ? v : 0;
+        };
+        uint64_t s[25], cur[21];
+#pragma unroll
+        for (int w = 0; w < 25; w++) s[w] = 0;
+#pragma unroll
+        for (int w = 0; w < 21; w++) cur[w] = word(w);
+        int base = 0;
+        for (; base + 21 <= total; base += 21) {
+            uint64_t nxt[21];
+#pragma unroll
+            for (int w = 0; w < 21; w++) nxt[w] = word(base + 21 + w);
+#pragma unroll
+            for (int w = 0; w < 21; w++) s[w] ^= cur[w];
+            keccak_permute_regs<false>(s);
+#pragma unroll
+            for (int w = 0; w < 21; w++) cur[w] = nxt[w];
+        }
+        const int rem = total - base;                                          // 0..20 words of the last block, then the pad
+#pragma unroll
+        for (int w = 0; w < 21; w++) { s[w] ^= cur[w]; if (w == rem) s[w] ^= 0x1F; }
+        s[20] ^= 0x80ull << 56;
         keccak_permute_regs<false>(s);
 #pragma unroll
-        for (int w = 0; w < 21; w++) cur[w] = nxt[w];
+        for (int w = 0; w < 9; w++) { ob[(2 * w) * APB + col] = (uint32_t)s[w]; ob[(2 * w + 1) * APB + col] = (uint32_t)(s[w] >> 32); }
     }
-    const int rem = total - base;                                              // 0..20 words of the last block, then the pad
-#pragma unroll
-    for (int w = 0; w < 21; w++) { s[w] ^= cur[w]; if (w == rem) s[w] ^= 0x1F; }
-    s[20] ^= 0x80ull << 56;
-    keccak_permute_regs<false>(s);
-#pragma unroll
-    for (int w = 0; w < 9; w++) ob[w * CH_T + threadIdx.x] = s[w];
-    auto out_byte = [&](int i) -> uint32_t { return (uint32_t)(ob[(i >> 3) * CH_T + threadIdx.x] >> (8 * (i & 7))) & 0xFFu; };
-    int8_t *mine = cc + threadIdx.x;          // per-lane private column: coefficient i at mine[i*CH_T] (no systematic bank conflict)
-    if (valid) {
+    auto out_byte = [&](int i) -> uint32_t { return (ob[(i >> 2) * APB + col] >> (8 * (i & 3))) & 0xFFu; };
+    int8_t *mine = cc + col;                  // the hash's private column: coefficient i at mine[i*APB] (no systematic bank conflict)
+    constexpr int LN = TWO ? 2 : 1;           // lanes that share the column: lane h takes every LN-th piece of the parallel steps
+    for (int i = h; i < N; i += LN) mine[i * APB] = 0;
+    sc_mlwe::wave_lds_fence();
+    if (valid && h == 0) {
         const int nwb = (weight + 7) >> 3;
-        for (int i = 0; i < N; i++) mine[i * CH_T] = 0;
         int pos = nwb;
         uint32_t sj = 0, mask = 1;
         for (int i = N - weight; i < N; i++) {
             uint32_t b = out_byte(pos++);
             while (b > (uint32_t)i) b >>= 1;
-            mine[i * CH_T] = mine[b * CH_T];
-            mine[b * CH_T] = (out_byte((int)sj) & mask) ? -1 : 1;
+            mine[i * APB] = mine[b * APB];
+            mine[b * APB] = (out_byte((int)sj) & mask) ? -1 : 1;
             mask <<= 1;
             if (mask == 256) { mask = 1; sj++; }
         }
+    }
+    sc_mlwe::wave_lds_fence();
+    if (valid) {
         if (SIGN) {
             uint32_t *dst = reinterpret_cast<uint32_t *>(c8 + (size_t)item * N);
-            for (int i = 0; i < N; i += 4)
-                dst[i >> 2] = (uint32_t)(uint8_t)mine[i * CH_T] | ((uint32_t)(uint8_t)mine[(i + 1) * CH_T] << 8) | ((uint32_t)(uint8_t)mine[(i + 2) * CH_T] << 16) |
-                              ((uint32_t)(uint8_t)mine[(i + 3) * CH_T] << 24);
+            for (int i = 4 * h; i < N; i += 4 * LN)
+                dst[i >> 2] = (uint32_t)(uint8_t)mine[i * APB] | ((uint32_t)(uint8_t)mine[(i + 1) * APB] << 8) | ((uint32_t)(uint8_t)mine[(i + 2) * APB] << 16) |
+                              ((uint32_t)(uint8_t)mine[(i + 3) * APB] << 24);
         } else {
             uint32_t neq = 0;
-            for (int i = 0; i < N; i++) neq |= (uint32_t)(c32[(size_t)item * N + i] != mine[i * CH_T]);
+            for (int i = h; i < N; i += LN) neq |= (uint32_t)(c32[(size_t)item * N + i] != mine[i * APB]);
             if (neq) verdict[item] = 1;
         }
     }
@@ -703,7 +811,7 @@ struct sc_hip_dilithium {
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
     hipStream_t side, side2;                          // verify_keys / sign_keys: per-key chains that depend on nothing of each other run beside each other
     hipEvent_t ev_fork, ev_join, ev_join2;
-    int tune_slots, tune_unfused, tune_sync;                       // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
+    int tune_slots, tune_unfused, tune_sync, tune_exp1 = 0;        // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
 };
 
 static void free_ws(sc_hip_dilithium *d)
@@ -929,7 +1037,7 @@ extern "C" int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *d, unsigne
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
-    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_unfused = unfused ? 1 : 0;
+    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -1018,7 +1126,10 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
     f.s1_stride = ks.per_item ? (size_t)l * N : 0; f.k_stride = ks.per_item ? (size_t)k * N : 0;
     f.rs = d->rs; f.kappa = d->kappa; f.sigs = d_sigs; f.sig_stride = sig_stride; f.siglens = d_siglens; f.trials = trials; f.next_count = d->cnt; f.P = P;
-    const unsigned eb = (cap + EXP_T - 1) / EXP_T, hb = (cap + CH_T - 1) / CH_T;
+    // ExpandMask with two lanes per attempt while the one-lane form would leave SIMDs without a second wavefront; one workgroup more than the slot
+    // budget needs, so that there is always one to zero the slots a shrinking round leaves behind
+    const bool exp2 = d->tune_exp1 ? false : (size_t)cap <= (size_t)d->ctx->cus * 4 * 64;
+    const unsigned eb = (unsigned)(((size_t)cap * (exp2 ? 2 : 1) + EXP_T - 1) / EXP_T) + 1, hb = (cap + CH_T - 1) / CH_T;
     uint32_t *yh_wipe = (ks.As && !ks.per_item) ? nullptr : d->yh;     // NTT(y) where the unfused transform / product pair leaves it in HBM
     uint32_t round = 0, todo = d->tune_sync ? 1 : plan_rounds(batch, cap, s_max), left = B;
     while (left > 0) {
@@ -1027,8 +1138,10 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
             const uint32_t *active = round ? d->act[(round - 1) & 1] : nullptr;     // round 0: identity
             f.active = active; f.next_active = d->act[round & 1];
             hipLaunchKernelGGL(dil_round_kernel, dim3(1), dim3(1), 0, s, d->rs, d->cnt, round ? 0u : B, cap, s_max);
-            hipLaunchKernelGGL(dil_expand_kernel, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
-                               d->w, (uint32_t)(k * P.n), yh_wipe);
+            if (exp2) hipLaunchKernelGGL(dil_expand_kernel<true>, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
+                                         d->w, (uint32_t)(k * P.n), yh_wipe);
+            else hipLaunchKernelGGL(dil_expand_kernel<false>, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
+                                    d->w, (uint32_t)(k * P.n), yh_wipe);
             HIPCHK(hipGetLastError());
             DilNtt a = base_args(d);
             a.in = d->y; a.out_int = d->yh;
@@ -1045,7 +1158,8 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
                 if (launch_dil<DOP_MATVEC>(d, a, cap, k, s)) return SC_HIP_FAILURE;
                 a.key_item_stride = 0; a.key_nat = 0;
             }
-            hipLaunchKernelGGL(dil_challenge_kernel<true>, dim3(hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
+            if (exp2) hipLaunchKernelGGL((dil_challenge_kernel<true, true>), dim3(2 * hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
+            else hipLaunchKernelGGL((dil_challenge_kernel<true, false>), dim3(hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
             HIPCHK(hipGetLastError());
             // one wavefront per message that may still be unsigned: the host only knows the count at its last look
             const unsigned fb = (left + 3) / 4;
@@ -1110,7 +1224,9 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     if (launch_dil<DOP_FWD_INT>(d, a, B, 1, s)) return SC_HIP_FAILURE;
     a.key = d->d_t1s;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(dil_challenge_kernel<false>, dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    // (two lanes per hash while the one-lane form would leave SIMDs without a second wavefront)
+    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -1349,7 +1465,9 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     a.key = t1h; a.key_item_stride = kn;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
     HIPCHK(hipStreamWaitEvent(s, d->ev_join2, 0));
-    hipLaunchKernelGGL(dil_challenge_kernel<false>, dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    // (two lanes per hash while the one-lane form would leave SIMDs without a second wavefront)
+    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }

@@ -1276,54 +1276,75 @@ struct BitW {                // generic MSB-first packer (any coefficient width)
 // The kernel is also the last reader of what a signing call must not leave behind - the lattice point s1 | s2 before packing and, one kernel back,
 // the sampler's working polynomials (products with the secret basis; ws) - and zeroes them: wavefront b its rows of s1 and s2 and every batch-th
 // kilobyte of the workspace range read as one linear array (whatever layout the sampler's mapping gave it; at any moment the wavefronts write one
-// contiguous region, as a memset would): one launch instead of three memsets behind it.  (The 0.4 GB of zeroes per 8192 signatures cost their
-// ~55 us of HBM write time wherever they are issued - measured here, as memsets, and from the sampler's own epilogue, where they delayed the
-// loads queued behind them by as much as they saved.)
+// contiguous region, as a memset would).  Order: a wavefront first READS its two rows into registers, then issues its zeroes, then walks its chain
+// of dependent steps on registers and LDS alone - the 0.4 GB of zeroes per 8192 signatures take ~55 us of HBM write time wherever they are issued
+// (here, as three memsets, from the sampler's epilogue: measured), and a load queued behind them waits that long.
 __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, int32_t *s1, int32_t *s2, uint8_t *__restrict__ sigs, size_t sig_stride,
                                                              uint32_t *__restrict__ siglens, uint32_t *__restrict__ status, FalP P, double *ws, uint32_t ws_pieces)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t fin_lds[];       // per wave: n squares
+    extern __shared__ __attribute__((aligned(16))) int32_t fin_lds[];       // per wave: n words (the squares, then the centred s2)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, n = P.n;
     const uint32_t b = blockIdx.x * FW + wv;
     if (b >= batch) return;
+    constexpr int MAXK = 16;                                                // n <= 1024 (falcon_create): coefficients per lane
+    const int K = n >> 6;
+    int32_t *a1 = s1 + (size_t)b * n, *a2 = s2 + (size_t)b * n;
+    int32_t xr[MAXK], yr[MAXK];
+    const uint32_t stt = status[b];
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) { xr[k] = k < K ? a1[lane + 64 * k] : 0; yr[k] = k < K ? a2[lane + 64 * k] : 0; }
+    __builtin_amdgcn_sched_barrier(0);                                       // (the zeroes below must not be hoisted over these loads)
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) if (k < K) { a1[lane + 64 * k] = 0; a2[lane + 64 * k] = 0; }
     if (ws) {
         const size_t total = (size_t)ws_pieces * 3 * n, stride = (size_t)batch * 64;                // 16-byte pieces: 6n doubles per signature slot
         uint4 *z = reinterpret_cast<uint4 *>(ws);
         for (size_t i = (size_t)b * 64 + lane; i < total; i += stride) z[i] = make_uint4(0, 0, 0, 0);
     }
-    int32_t *a1 = s1 + (size_t)b * n, *a2 = s2 + (size_t)b * n;
-    auto wipe_row = [&](int32_t *row) { for (int i = lane; i < n / 4; i += 64) reinterpret_cast<int4 *>(row)[i] = make_int4(0, 0, 0, 0); };
-    if (status[b] == 2 || status[b] == 6) { if (lane == 0) siglens[b] = 0; wipe_row(a1); wipe_row(a2); return; }      // tape too short / no such key: nothing was sampled
+    if (stt == 2 || stt == 6) { if (lane == 0) siglens[b] = 0; return; }      // tape too short / no such key: nothing was sampled
     int32_t *sq = fin_lds + (size_t)wv * n;
-    for (int i = lane; i < n; i += 64) {
-        const int32_t x = a1[i], y = centre_mod(a2[i], P.q);
-        a2[i] = y;
-        a1[i] = 0;
-        sq[i] = x * x + y * y;
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) if (k < K) {
+        const int32_t x = xr[k], y = centre_mod(yr[k], P.q);
+        yr[k] = y;
+        sq[lane + 64 * k] = x * x + y * y;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     int bad = 0;
     if (lane == 0) bad = norm_fails_lds(sq, n, P.bd) ? 1 : 0;
     bad = __shfl(bad, 0);
-    if (bad) { if (lane == 0) { status[b] = 4; siglens[b] = 0; } wipe_row(a2); return; }
+    if (bad) { if (lane == 0) { status[b] = 4; siglens[b] = 0; } return; }
+#pragma unroll
+    for (int k = 0; k < MAXK; k++) if (k < K) sq[lane + 64 * k] = yr[k];    // the centred s2, for the packer (neighbouring coefficients sit in different lanes)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint8_t *out = sigs + (size_t)b * sig_stride;
     const int bits = P.q_bits - 2;
-    if (bits == 12) {
+    if (bits == 12 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        // eight coefficients -> twelve bytes, written as three big-endian words (a row that starts on a word boundary)
+        for (int gq = lane; gq < n / 8; gq += 64) {
+            const int4 lo4 = *reinterpret_cast<const int4 *>(sq + 8 * gq), hi4 = *reinterpret_cast<const int4 *>(sq + 8 * gq + 4);
+            const uint32_t u0 = (uint32_t)lo4.x & 0xFFFu, u1 = (uint32_t)lo4.y & 0xFFFu, u2 = (uint32_t)lo4.z & 0xFFFu, u3 = (uint32_t)lo4.w & 0xFFFu;
+            const uint32_t u4 = (uint32_t)hi4.x & 0xFFFu, u5 = (uint32_t)hi4.y & 0xFFFu, u6 = (uint32_t)hi4.z & 0xFFFu, u7 = (uint32_t)hi4.w & 0xFFFu;
+            uint32_t *ow = reinterpret_cast<uint32_t *>(out) + 3 * gq;
+            ow[0] = __builtin_bswap32((u0 << 20) | (u1 << 8) | (u2 >> 4));
+            ow[1] = __builtin_bswap32(((u2 & 0xFu) << 28) | (u3 << 16) | (u4 << 4) | (u5 >> 8));
+            ow[2] = __builtin_bswap32(((u5 & 0xFFu) << 24) | (u6 << 12) | u7);
+        }
+        if (lane == 0) { siglens[b] = (uint32_t)(n / 2) * 3; status[b] = 1; }
+    } else if (bits == 12) {
         // two coefficients -> three bytes
         for (int p = lane; p < n / 2; p += 64) {
-            const uint32_t u = (uint32_t)a2[2 * p] & 0xFFFu, v = (uint32_t)a2[2 * p + 1] & 0xFFFu;
+            const uint32_t u = (uint32_t)sq[2 * p] & 0xFFFu, v = (uint32_t)sq[2 * p + 1] & 0xFFFu;
             out[3 * p] = (uint8_t)(u >> 4); out[3 * p + 1] = (uint8_t)(((u & 0xFu) << 4) | (v >> 8)); out[3 * p + 2] = (uint8_t)(v & 0xFFu);
         }
         if (lane == 0) { siglens[b] = (uint32_t)(n / 2) * 3; status[b] = 1; }
     } else if (lane == 0) {
         BitW bw = { out, 0, 0, 0 };
-        for (int i = 0; i < n; i++) bw.put((uint32_t)a2[i], bits);
+        for (int i = 0; i < n; i++) bw.put((uint32_t)sq[i], bits);
         bw.flush();
         siglens[b] = bw.nbytes;
         status[b] = 1;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier();      // (the row is read above by other lanes than the ones that zero it)
-    wipe_row(a2);
 }
 
 // ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------

@@ -75,6 +75,10 @@ def test_sign_verify_reproduce_reference(eng, G, set_, nmsg):
     for m in range(nmsg):
         assert bytes(sh[m, :lh[m]]) == bytes(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8)), m
     assert f.workspace_residue() == 0        # the sampler's working polynomials and s1 | s2 before packing are zeroed inside the call
+    f.sig_stride = key.sig_bytes + 1         # rows that do not start on word boundaries take the byte-wise packer: same bytes
+    sg2, sl2, _ = f.sign(mb, torch.from_numpy(tp.view(np.int32)).cuda(), mlens=ml)
+    assert torch.equal(sl2, siglens) and all(bytes(sg2[m, :lh[m]].cpu().numpy()) == bytes(sh[m, :lh[m]]) for m in range(nmsg))
+    f.sig_stride = (key.sig_bytes + 15) & ~15
     assert f.verify(mb, sigs, siglens, mlens=ml).cpu().tolist() == [int(G[f'{tag}_verify'][2 * m]) for m in range(nmsg)] == [0] * nmsg
     bad = sigs.clone(); bad[:, key.sig_bytes // 3] ^= 0x10          # the fixture's tampering
     assert f.verify(mb, bad, siglens, mlens=ml).cpu().tolist() == [int(G[f'{tag}_verify'][2 * m + 1]) for m in range(nmsg)] == [1] * nmsg
