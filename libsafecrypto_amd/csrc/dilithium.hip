@@ -330,7 +330,7 @@ __global__ __launch_bounds__(EXP_T) void dil_expand_kernel(const uint32_t *rs, c
 // (11 for Dilithium-III) at a fraction of a wavefront per SIMD: the two-lane form shortens the chain by a third.
 template <bool SIGN, bool TWO>
 __global__ __launch_bounds__(CH_T) void dil_challenge_kernel(const uint32_t *rs, const uint32_t *slot_item, uint32_t nact, const uint8_t *mu, const uint8_t *w1,
-                                                           int w1len, int weight, int8_t *c8, const int32_t *c32, uint32_t *verdict)
+                                                           int w1len, int weight, int8_t *c8, const int32_t *c32, uint32_t *verdict, uint32_t two_max)
 {
     constexpr int APB = TWO ? CH_T / 2 : CH_T;                                  // hashes per workgroup
     __shared__ uint32_t ob[18 * APB];                                          // the 72 output bytes: half hh of word w at ob[(2 w + hh) * APB + column]
@@ -338,7 +338,12 @@ __global__ __launch_bounds__(CH_T) void dil_challenge_kernel(const uint32_t *rs,
     const uint32_t col = TWO ? threadIdx.x >> 1 : threadIdx.x;
     const int h = TWO ? (int)(threadIdx.x & 1) : 0;
     const uint32_t aidx = blockIdx.x * APB + col;
-    if (SIGN) nact = rs[RS_NSLOTS];
+    if (SIGN) {
+        // the signer queues both forms every round and the round's size, which only the device knows, picks one: two lanes per hash while that keeps
+        // the kernel at no more than about a wavefront per SIMD (measured at 49152 attempts: 125 us one lane, 133 two; at 13 K: 112 and 82)
+        nact = rs[RS_NSLOTS];
+        if (TWO ? nact > two_max : nact <= two_max) return;
+    }
     if (blockIdx.x * APB >= nact) return;                                        // (whole workgroup)
     const bool valid = aidx < nact;
     const uint32_t item = valid ? aidx : 0;                                    // slot: index of w1 / c
@@ -708,26 +713,48 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
 }
 
 // verify: unpack z (-> canonical), hints, c; structural checks (dilithium.c:2065-2123)
-__global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits, int32_t q,
+// One workgroup per signature, a lane per EIGHT coefficients: 8 z_bits bits are z_bits whole bytes (20 for every reference parameter set: five words
+// where the row starts on a word boundary), out as two 16-byte stores.  (One lane per pair of coefficients - five byte loads, two 4-byte stores, a
+// 64-bit division for its indices - took 51 of the verifier's 378 us at batch 16384.)
+// ZB: z_bits at compile time (the word a field starts in is then a constant: the group's words stay in registers); 0 = any width, at run time
+template <int ZB>
+__global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits_rt, int32_t q,
                                    uint32_t gamma1_beta, uint32_t *verdict)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int pairs = ln / 2;
-    const size_t item = t / pairs; const int pr = (int)(t % pairs);
-    if (item >= count) return;
-    const int nbytes = 2 * z_bits / 8;
-    const uint8_t *src = sigs + item * sig_stride + (size_t)pr * nbytes;
-    uint64_t bits = 0;
-    for (int b = 0; b < nbytes; b++) bits = (bits << 8) | src[b];
-    const uint64_t m = (1ull << z_bits) - 1;
-    int32_t v[2] = { (int32_t)((bits >> z_bits) & m), (int32_t)(bits & m) };
+    const int z_bits = ZB ? ZB : z_bits_rt;
+    const uint32_t item = blockIdx.x;
+    const int grp = threadIdx.x;
+    if (item >= count || grp >= ln / 8) return;
+    const uint8_t *src = sigs + (size_t)item * sig_stride + (size_t)grp * z_bits;
+    uint32_t W[8];                                                      // the group's bytes as big-endian words (z_bits <= 24 bytes -> 6 words, one spare)
+    const int nw = (z_bits + 3) / 4;
+    if ((reinterpret_cast<uintptr_t>(src) & 3) == 0 && (z_bits & 3) == 0) {
+#pragma unroll
+        for (int w = 0; w < 6; w++) W[w] = w < nw ? __builtin_bswap32(reinterpret_cast<const uint32_t *>(src)[w]) : 0u;
+    } else {
+#pragma unroll
+        for (int w = 0; w < 6; w++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) v = (v << 8) | (4 * w + b < z_bits ? (uint32_t)src[4 * w + b] : 0u);
+            W[w] = v;
+        }
+    }
+    W[6] = W[7] = 0;
+    int32_t out[8];
     bool bad = false;
-    for (int e = 0; e < 2; e++) {
-        int32_t sv = (int32_t)((uint32_t)v[e] << (32 - z_bits)) >> (32 - z_bits);     // signed raw coefficient
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int pos = e * z_bits, w = pos >> 5, o = pos & 31;        // field e: bits [pos, pos + z_bits) of the big-endian string
+        const uint64_t V = ((uint64_t)W[w] << 32) | W[w + 1];
+        const uint32_t raw = (uint32_t)(V >> (64 - o - z_bits)) & ((1u << z_bits) - 1u);
+        const int32_t sv = (int32_t)(raw << (32 - z_bits)) >> (32 - z_bits);           // signed raw coefficient
         const uint32_t zz = (uint32_t)(sv < 0 ? sv + q : sv);                          // normalize_32
-        z[item * ln + 2 * pr + e] = (int32_t)zz;
+        out[e] = (int32_t)zz;
         bad |= norm_bad(zz, (uint32_t)q, gamma1_beta);
     }
+    int4 *dst = reinterpret_cast<int4 *>(z + (size_t)item * ln + 8 * grp);
+    dst[0] = make_int4(out[0], out[1], out[2], out[3]); dst[1] = make_int4(out[4], out[5], out[6], out[7]);
     if (bad) verdict[item] = 1;
 }
 
@@ -1158,8 +1185,10 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
                 if (launch_dil<DOP_MATVEC>(d, a, cap, k, s)) return SC_HIP_FAILURE;
                 a.key_item_stride = 0; a.key_nat = 0;
             }
-            if (exp2) hipLaunchKernelGGL((dil_challenge_kernel<true, true>), dim3(2 * hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
-            else hipLaunchKernelGGL((dil_challenge_kernel<true, false>), dim3(hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr);
+            const uint32_t two_max = d->tune_exp1 ? 0u : (uint32_t)d->ctx->cus * 4 * 36;      // 36864 attempts on 256 CUs
+            const unsigned hb2 = (unsigned)(((size_t)(cap < two_max ? cap : two_max) * 2 + CH_T - 1) / CH_T);
+            if (hb2) hipLaunchKernelGGL((dil_challenge_kernel<true, true>), dim3(hb2), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr, two_max);
+            hipLaunchKernelGGL((dil_challenge_kernel<true, false>), dim3(hb), dim3(CH_T), 0, s, d->rs, d->slot_item, 0u, d->mu, d->w1, k * P.n, P.weight, d->c8, (const int32_t *)nullptr, (uint32_t *)nullptr, two_max);
             HIPCHK(hipGetLastError());
             // one wavefront per message that may still be unsigned: the host only knows the count at its last look
             const unsigned fb = (left + 3) / 4;
@@ -1203,9 +1232,9 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return fail("dilithium_verify: sig_stride too small");
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
     const unsigned hb = (B + HT - 1) / HT;
-    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
-    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
-                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    const unsigned zblock = (unsigned)((l * P.n / 8 + 63) / 64 * 64);                // a lane per eight coefficients, a workgroup per signature
+    if (P.z_bits == 20) hipLaunchKernelGGL(dil_unpackz_kernel<20>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    else hipLaunchKernelGGL(dil_unpackz_kernel<0>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
     hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
     hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
     HIPCHK(hipGetLastError());
@@ -1225,8 +1254,8 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     a.key = d->d_t1s;
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
     // (two lanes per hash while the one-lane form would leave SIMDs without a second wavefront)
-    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
-    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts, 0u);
+    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts, 0u);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
@@ -1439,9 +1468,9 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     // plain) and the Montgomery factor travels on NTT(z) instead (DilNtt::key_nat) - a pass over 30 KB per key less than the signer's form.
     if (sc_hip_mlwe_expand_matrix(d->ctx, batch, d_rho, 32, 32, k * l, P.q, P.q_bits, ab, s)) return SC_HIP_FAILURE;
     // chain (3): the signature side as in sc_hip_dilithium_verify, t1 . 2^d and its transform; chain (2) below
-    const size_t zthreads = (size_t)B * (size_t)(l * P.n / 2);
-    hipLaunchKernelGGL(dil_unpackz_kernel, dim3((unsigned)((zthreads + 255) / 256)), dim3(256), 0, s2, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q,
-                       (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    const unsigned zblock = (unsigned)((l * P.n / 8 + 63) / 64 * 64);
+    if (P.z_bits == 20) hipLaunchKernelGGL(dil_unpackz_kernel<20>, dim3(B), dim3(zblock), 0, s2, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    else hipLaunchKernelGGL(dil_unpackz_kernel<0>, dim3(B), dim3(zblock), 0, s2, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
     hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s2, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
     hipLaunchKernelGGL(dil_shift_kernel, dim3((unsigned)((batch * kn + 255) / 256)), dim3(256), 0, s2, d_t1, t1s, batch * kn, P.d);
     HIPCHK(hipGetLastError());
@@ -1466,8 +1495,8 @@ extern "C" int sc_hip_dilithium_verify_keys(sc_hip_dilithium_t *d, size_t batch,
     if (launch_dil<DOP_CT1>(d, a, B, k, s)) return SC_HIP_FAILURE;
     HIPCHK(hipStreamWaitEvent(s, d->ev_join2, 0));
     // (two lanes per hash while the one-lane form would leave SIMDs without a second wavefront)
-    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
-    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts);
+    if ((size_t)B <= (size_t)d->ctx->cus * 4 * 64) hipLaunchKernelGGL((dil_challenge_kernel<false, true>), dim3((2 * B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts, 0u);
+    else hipLaunchKernelGGL((dil_challenge_kernel<false, false>), dim3((B + CH_T - 1) / CH_T), dim3(CH_T), 0, s, (const uint32_t *)nullptr, (const uint32_t *)nullptr, B, d->mu, d->w1, k * P.n, P.weight, (int8_t *)nullptr, d->c, d_verdicts, 0u);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
