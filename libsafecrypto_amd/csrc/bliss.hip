@@ -41,7 +41,23 @@ __device__ __forceinline__ int32_t barrett(int64_t x, int64_t m, int64_t q) { in
 
 struct Tape {                // one message's CSPRNG word stream + the prng_var reservoir (prng.c:1017-1048)
     const uint32_t *w; uint32_t len, pos, var_buf; int var_bits; bool underrun;
-    __device__ __forceinline__ uint32_t w32() { if (pos >= len) { underrun = true; return 0; } return w[pos++]; }
+    // An attempt's decision draws 1 + 27 + 26 reservoir bits: at most three words, the three at the position the attempt starts from.  They are
+    // requested when the kernel starts (prefetch) instead of one dependent round trip each in the middle of a chain of dependent steps.
+    uint32_t pre[3], pre_at; bool have_pre;
+    __device__ __forceinline__ void prefetch()
+    {
+        pre_at = pos; have_pre = true;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { const uint32_t at = pos + i < len ? pos + i : (len ? len - 1 : 0); pre[i] = len ? w[at] : 0u; }
+    }
+    __device__ __forceinline__ uint32_t w32()
+    {
+        if (pos >= len) { underrun = true; return 0; }
+        const uint32_t d = pos - pre_at;
+        pos++;
+        if (have_pre && d < 3) return d == 0 ? pre[0] : d == 1 ? pre[1] : pre[2];
+        return w[pos - 1];
+    }
     __device__ __forceinline__ uint32_t var(int n)
     {
         uint32_t ret = var_buf;
@@ -328,6 +344,18 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     int32_t fr[MAXC], gr[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; c++) { const int j = lane + 64 * c; fr[c] = c < C ? (int32_t)f[j] : 0; gr[c] = c < C ? (int32_t)g[j] : 0; }
+    // ... and everything else the decision reads from global memory - the reservoir's state and tape words, the attempt's vectors t and u, the
+    // (v and its rounding z further down) - is requested here, in front of the kappa dependent steps of greedy_sc, not after them
+    Tape T{ tapes + (size_t)src * tape_stride, tape_lens ? tape_lens[src] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
+    T.prefetch();
+    const uint32_t cur = s.cur[item];
+    int32_t *t = tu + ((size_t)item * 2 + cur) * n, *u = tu + ((size_t)item * 2 + (cur ^ 1)) * n;
+    int32_t tr[MAXC], ur[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int j = lane + 64 * c;
+        tr[c] = c < C ? t[j] : 0; ur[c] = c < C ? u[j] : 0;
+    }
     int inext = cidx[(size_t)aidx * P.kappa];
     for (int k = 0; k < P.kappa; k++) {
         const int i = inext;
@@ -356,20 +384,29 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     }
 
     // the CSPRNG reservoir of this message (every lane computes the same scalar sequence; lane 0 writes it back)
-    Tape T{ tapes + (size_t)src * tape_stride, tape_lens ? tape_lens[src] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
-    const uint32_t cur = s.cur[item];
-    int32_t *t = tu + ((size_t)item * 2 + cur) * n, *u = tu + ((size_t)item * 2 + (cur ^ 1)) * n;
+    // (T, t, u and the registers tr, ur, vr, zr: loaded above)
     const bool sub = T.var(1) != 0;
     int32_t num = 0, den = 0;
-    for (int c = 0; c < C; c++) {
-        const int j = lane + 64 * c;
-        const int32_t xx = x[j], yy = y[j];
-        const int32_t tt = sub ? t[j] - xx : t[j] + xx, uu = sub ? u[j] - yy : u[j] + yy;
-        t[j] = tt; u[j] = uu;
-        num += xx * xx + yy * yy;
-        den += tt * xx + uu * yy;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c < C) {
+            const int j = lane + 64 * c;
+            const int32_t xx = x[j], yy = y[j];
+            const int32_t tt = sub ? tr[c] - xx : tr[c] + xx, uu = sub ? ur[c] - yy : ur[c] + yy;
+            t[j] = tt; u[j] = uu;
+            tr[c] = tt; ur[c] = uu;
+            num += xx * xx + yy * yy;
+            den += tt * xx + uu * yy;
+        }
     }
     num = wave_sum(num); den = wave_sum(den);
+    // v and its rounding z are needed behind the rejection test: requested here, in front of the exp / cosh arithmetic
+    int32_t vr[MAXC], zr[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int j = lane + 64 * c;
+        vr[c] = c < C ? v[(size_t)aidx * n + j] : 0; zr[c] = c < C ? (int32_t)z[(size_t)aidx * n + j] : 0;
+    }
     const double inv_sig2 = 1.0 / ((double)P.sigma * P.sigma);
     const double thresh = 1.0 / (P.m * exp(-0.5 * inv_sig2 * num) * cosh(inv_sig2 * den));
     const double rr = T.dbl();
@@ -384,18 +421,20 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     // signature_gen (bliss_b.c:1045-1075; its Barrett multiplier is built from q, not p - kept) + check_norms (:1010-1043)
     const int32_t mm = (1 << 30) / P.q, q2 = 2 * P.q, p2 = P.p >> 1;
     int32_t maxt = 0, maxz = 0, nt = 0, nz = 0;
-    for (int c = 0; c < C; c++) {
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c >= C) continue;
         const int j = lane + 64 * c;
-        int32_t tmp = v[(size_t)aidx * n + j] - u[j];
+        int32_t tmp = vr[c] - ur[c];
         tmp += (tmp < 0) * q2;
         tmp -= (tmp >= q2) * q2;
         tmp = ((tmp + (1 << (P.d - 1))) >> P.d);
         tmp = tmp - ((tmp * mm) >> 30) * P.p;
         tmp -= (P.p <= tmp) * P.p;
-        tmp = (int32_t)z[(size_t)aidx * n + j] - tmp;
+        tmp = zr[c] - tmp;
         tmp += (tmp <= -p2) * P.p;
         tmp -= (tmp > p2) * P.p;
-        const int32_t zz = (int32_t)(int16_t)tmp, tt = t[j];
+        const int32_t zz = (int32_t)(int16_t)tmp, tt = tr[c];
         x[j] = tt; y[j] = zz;                                            // staged for the packer
         maxt = max(maxt, max(tt, -tt)); maxz = max(maxz, max(zz, -zz));
         nt += tt * tt; nz += zz * zz;
