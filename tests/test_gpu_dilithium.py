@@ -95,6 +95,32 @@ def test_batch_vs_oracle_seeded(eng, G):
     assert d.verify_host(msgs, sigs) == [0] * 257
     for i in range(0, 257, 32):
         assert O.dilithium_verify(key, msgs[i], sigs[i]) == 0
+    # the forms a batch of this size does not pick by itself give the same bytes: ExpandMask and the challenge hash with one lane per state (what a
+    # batch beyond 64 K attempt slots runs; sc_hip_dilithium_set_tuning bit 9), the host looking at the count after every round (bit 8)
+    for tuning in (1 << 9, 1 << 8, (1 << 9) | (1 << 8)):
+        d.set_tuning(tuning)
+        s2, t2 = d.sign_host(msgs)
+        assert s2 == sigs and t2 == trials, tuning
+    d.set_tuning(0)
+    d.close()
+
+
+def test_signature_rows_off_word_boundaries(eng, G):
+    """a signature buffer whose row pitch is odd: the verifier's z unpacker reads its groups byte by byte instead of word by word - same verdicts"""
+    import torch
+    key = O.DilKey.from_golden(G, 'dil3')
+    d = make(eng, key)
+    g = torch.Generator(device='cuda'); g.manual_seed(77)
+    B = 300
+    msgs = torch.randint(0, 256, (B, 48), dtype=torch.uint8, device='cuda', generator=g)
+    sigs, siglens, _ = d.sign(msgs, fixed_len=48)
+    assert d.verify(msgs, sigs, siglens, fixed_len=48).cpu().tolist() == [0] * B
+    odd = torch.zeros((B, d.sig_stride + 1), dtype=torch.uint8, device='cuda')
+    odd[:, :d.sig_stride] = sigs
+    assert d.verify(msgs, odd, siglens, fixed_len=48).cpu().tolist() == [0] * B
+    odd[7, 100] ^= 1; odd[200, 3000] ^= 0x40
+    v = d.verify(msgs, odd, siglens, fixed_len=48).cpu().tolist()
+    assert v[7] == 1 and v[200] == 1 and sum(v) == 2
     d.close()
 
 
