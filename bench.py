@@ -380,6 +380,18 @@ def bliss_extra(eng, torch, cpu_seconds):
     assert int(v3[st3 == 1].sum()) == 0 and torch.equal(st3, status)
     out['huffman_coded'] = {'workload': 'the same batch with the signatures entropy-coded as the reference codes them (static Huffman tables for t and z)',
                             'sign_ops_per_s': B / min(th), 'verify_ops_per_s': B / min(thv), 'mean_signature_bytes': float(l3[st3 == 1].float().mean()), 'raw_signature_bytes': 986}
+    # ... and under the arithmetic coder (SC_FLAG_0_ENTROPY_BAC; the coder's two distributions are long double arithmetic of the reference's host: from the fixture)
+    A = load_golden('bliss_bac_ref.txt')
+    dist = lambda k: np.ascontiguousarray(np.ascontiguousarray(A[k], dtype=np.int32).view(np.uint64))
+    b.set_entropy_bac(dist('blissb1_dist_t'), dist('blissb1_dist_z'))
+    b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+    ta, tav = [], []
+    for _ in range(3):
+        t0 = time.perf_counter(); s4, l4, _, st4 = b.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); ta.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); v4 = b.verify(msgs, s4, l4, fixed_len=64); torch.cuda.synchronize(); tav.append(time.perf_counter() - t0)
+    assert int(v4[st4 == 1].sum()) == 0 and torch.equal(st4, status)
+    out['arithmetic_coded'] = {'workload': 'the same batch with t and z through the reference\'s binary arithmetic coder (a serial range coder: one lane per signature)',
+                               'sign_ops_per_s': B / min(ta), 'verify_ops_per_s': B / min(tav), 'mean_signature_bytes': float(l4[st4 == 1].float().mean()), 'raw_signature_bytes': 986}
     b.close()
     return {'bliss_b_1': out}
 

@@ -429,6 +429,8 @@ int main(int argc, char **argv)
     keygen_scheme("BLISS-B-I", SC_SCHEME_SIG_BLISS, 1, SC_FLAG_0_SAMPLE_64BIT);
     outer_dilithium(3);
     outer_signature("BLISS-B-I", SC_SCHEME_SIG_BLISS, 1, SC_FLAG_0_SAMPLE_64BIT, sc_hip_glue_bliss_b_sign, sc_hip_glue_bliss_b_verify, 1);
+    outer_signature("BLISS-B-I, signatures under the arithmetic coder", SC_SCHEME_SIG_BLISS, 1, SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_0_ENTROPY_BAC, sc_hip_glue_bliss_b_sign, sc_hip_glue_bliss_b_verify, 1);
+    outer_signature("BLISS-B-IV, signatures in the static Huffman coding", SC_SCHEME_SIG_BLISS, 4, SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_0_ENTROPY_HUFFMAN, sc_hip_glue_bliss_b_sign, sc_hip_glue_bliss_b_verify, 1);
     outer_signature("ring-TESLA set 0", SC_SCHEME_SIG_RING_TESLA, 0, SC_FLAG_NONE, sc_hip_glue_ring_tesla_sign, sc_hip_glue_ring_tesla_verify, 0);
     outer_signature("Falcon-512", SC_SCHEME_SIG_FALCON, 0, SC_FLAG_NONE, sc_hip_glue_falcon_sign, sc_hip_glue_falcon_verify, 1);
     outer_kyber(1);

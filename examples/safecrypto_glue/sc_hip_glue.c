@@ -9,6 +9,7 @@
 #include "utils/arith/module_lwe.h"
 #include "utils/sampling/sampling.h"
 #include "utils/crypto/prng.h"
+#include "utils/entropy/huffman.h"
 #include "schemes/sig/dilithium/dilithium.h"
 #include "schemes/sig/dilithium/dilithium_params.h"
 #include "schemes/sig/bliss_b/bliss_b.h"
@@ -278,10 +279,38 @@ static int reg_ctx(safecrypto_t *sc)
 }
 
 /* engine handles, keys loaded from the context on first use */
+/* the static table entropy_huffman.c:22-34 walks for signed fields of `bits` bits */
+static const huffman_table_t *glue_huff_table(int bits)
+{
+    const int hb = bits < 7 ? bits : 7;
+    return hb == 7 ? huff_table_gaussian_6 : hb == 6 ? huff_table_gaussian_5 : hb == 5 ? huff_table_gaussian_4 : hb == 4 ? huff_table_gaussian_3 : huff_table_gaussian_2;
+}
+/* the context's signature coding on the engine's handle: raw fields, the static Huffman tables of the library, or the arithmetic coder with the two
+ * distributions the context built (bliss_b.c:397-398) */
+static int bliss_coding(safecrypto_t *sc, sc_hip_bliss_t *h)
+{
+    const bliss_set_t *P = sc->bliss->params;
+    if (SC_ENTROPY_NONE == sc->coding_signature.type) return sc_hip_bliss_set_entropy(h, 0, NULL, NULL, 0, NULL, NULL, 0);
+    if (SC_ENTROPY_BAC == sc->coding_signature.type) {
+        if (NULL == sc->dist[2] || NULL == sc->dist[3]) return SC_HIP_FAILURE;
+        return sc_hip_bliss_set_entropy_bac(h, (const uint64_t *)sc->dist[2], (const uint64_t *)sc->dist[3]);
+    }
+    if (SC_ENTROPY_HUFFMAN_STATIC == sc->coding_signature.type) {
+        const huffman_table_t *t[2] = { glue_huff_table(P->z1_bits), glue_huff_table(P->z2_bits) };
+        uint32_t codes[2][64]; uint16_t bits[2][64];
+        for (int k = 0; k < 2; k++) {
+            if (t[k]->depth > 64) return SC_HIP_FAILURE;
+            for (UINT32 i = 0; i < t[k]->depth; i++) { codes[k][i] = t[k]->codes[i].code; bits[k][i] = (uint16_t)t[k]->codes[i].bits; }
+        }
+        return sc_hip_bliss_set_entropy(h, 1, codes[0], bits[0], t[0]->depth, codes[1], bits[1], t[1]->depth);
+    }
+    return SC_HIP_FAILURE;
+}
+
 static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
 {
     if (NULL == sc || SC_SCHEME_SIG_BLISS != sc->scheme || NULL == sc->bliss || NULL == sc->pubkey || NULL == sc->pubkey->key) return NULL;
-    if (SC_ENTROPY_NONE != sc->coding_signature.type) return NULL;
+    if (SC_ENTROPY_NONE != sc->coding_signature.type && SC_ENTROPY_BAC != sc->coding_signature.type && SC_ENTROPY_HUFFMAN_STATIC != sc->coding_signature.type) return NULL;
     if (need_priv && (NULL == sc->sc_gauss || CDF_GAUSSIAN_SAMPLING != sc->sampling || SAMPLING_64BIT != sc->sc_gauss->precision)) return NULL;
     if (need_priv && (NULL == sc->privkey || NULL == sc->privkey->key)) return NULL;
     const int i = reg_ctx(sc);
@@ -299,6 +328,7 @@ static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
                 const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)sc->sc_gauss->gauss;
                 if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table(g_reg[i].bliss, v->cdf, v->cdf_size)) return NULL;
             }
+            if (SC_HIP_SUCCESS != bliss_coding(sc, g_reg[i].bliss)) return NULL;
         }
         const SINT16 *priv = (sc->privkey && sc->privkey->key) ? (const SINT16 *)sc->privkey->key : NULL;
         if (SC_HIP_SUCCESS != sc_hip_bliss_set_key(g_reg[i].bliss, priv, priv ? priv + P->n : NULL, (const SINT16 *)sc->pubkey->key)) return NULL;

@@ -294,9 +294,18 @@ int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
  * as codes[depth], bits[depth]; they must form a complete prefix code.  From then on the sign calls write coded signatures (d_siglens[i] varies, below
  * sc_hip_bliss_sig_bytes(), which stays the row size to provide; d_status[i] = 6: a coefficient outside the code's alphabet - the reference's
  * encode_huffman fails on it too - or a coded signature longer than the row) and the verify calls read them (a stream that ends early is invalid).
- * The arithmetic coder (SC_ENTROPY_BAC) is not served. */
+ * The arithmetic coder (SC_ENTROPY_BAC): sc_hip_bliss_set_entropy_bac below. */
 int sc_hip_bliss_set_entropy(sc_hip_bliss_t *h, int type, const uint32_t *codes_t, const uint16_t *bits_t, uint32_t depth_t,
                              const uint32_t *codes_z, const uint16_t *bits_z, uint32_t depth_z);
+/* replaces: the signature coding of SC_FLAG_0_ENTROPY_BAC (bliss_b.c:198, 397-398, 1453-1463, 1650-1657): t and z each through bac_encode_64_32 / _16
+ * (src/utils/entropy/bac.c:162-258: a byte-aligned block - a 2-byte big-endian length, then that many bytes of a 64-bit binary range coder's output, a
+ * coefficient being `bits` binary decisions whose probabilities are dist[prefix | 1 << k]), the indices raw behind them; decoding by bac_decode_64_32 / _16
+ * (:260-334).  dist_t (2^z1_bits entries) and dist_z (2^z2_bits): the two distributions as entropy_dist_create -> gauss_freq_bac_64 leaves them in
+ * sc->dist[2] and sc->dist[3] (sigma and 0.7; long double arithmetic of the caller's host, so handed over as data like the sampler's table).  From then on
+ * the sign calls write coded signatures (d_status[i] = 6: a coded signature that does not fit its row) and the verify calls read them (anything read past a
+ * signature's end makes it invalid).  sc_hip_bliss_set_entropy(h, 0, ...) switches back to raw fields.  A range coder is serial from a signature's first
+ * bit to its last: one lane per signature. */
+int sc_hip_bliss_set_entropy_bac(sc_hip_bliss_t *h, const uint64_t *dist_t, const uint64_t *dist_z);
 /* replaces: safecrypto_verify -> bliss_b_verify (bliss_b.c:1583-1740); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_bliss_verify(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);

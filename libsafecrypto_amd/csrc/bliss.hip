@@ -647,6 +647,136 @@ __global__ __launch_bounds__(64) void bl_huff_unpack_kernel(const uint8_t *sigs,
     if (r.over) verdict[item] = 1;
 }
 
+// ---- the arithmetic coder (SC_FLAG_0_ENTROPY_BAC; src/utils/entropy/bac.c) -------------------------------------------------------------------------
+// t and z of a signature each become a byte-aligned block - a 2-byte big-endian length, then that many bytes of a 64-bit binary range coder's output
+// (a coefficient is `bits` binary decisions, the probability of a 0 at a node of that tree is dist[prefix | 1 << k]; bac.c:162-258) - and the kappa
+// indices follow raw (bliss_b.c:1453-1463).  A range coder is serial from the first bit of a signature to the last: one lane per signature, the first
+// lpw lanes of a wavefront only (as for the Huffman decoder), the two distributions in LDS where they fit.
+constexpr uint32_t BAC_LDS_ENTRIES = 4096 + 16;                   // z1_bits <= 12 and z2_bits <= 4: every reference parameter set
+struct BacDist { const uint64_t *t, *z; };
+__device__ __forceinline__ const uint64_t *bac_stage(const BacDist &d, int bits_t, int bits_z, uint64_t *lds, const uint64_t **dz)
+{
+    const uint32_t nt = 1u << bits_t, nz = 1u << bits_z;
+    if (nt + nz > BAC_LDS_ENTRIES) { *dz = d.z; return d.t; }       // wider fields than the reference has: the tables stay where they are
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[i] = d.t[i];
+    for (uint32_t i = threadIdx.x; i < nz; i += blockDim.x) lds[nt + i] = d.z[i];
+    __syncthreads();
+    *dz = lds + nt;
+    return lds;
+}
+struct BacOut {                  // the byte stream of one block, with the reference's carry propagation into bytes already written (bac.c:151-160)
+    uint8_t *buf; uint32_t optr, cap; bool ovf;
+    __device__ __forceinline__ void byte(uint32_t ob)
+    {
+        if (optr < cap) buf[optr] = (uint8_t)ob; else ovf = true;
+        for (int i = (int)optr - 1; ob >= 0x100u && i >= 0; i--) { ob >>= 8; if ((uint32_t)i < cap) { ob += buf[i]; buf[i] = (uint8_t)ob; } }
+        optr++;
+    }
+};
+// one block: n fields of `bits` bits read from r; returns the bytes written at out (header included)
+__device__ __forceinline__ uint32_t bac_encode_block(BitR &r, int n, int bits, const uint64_t *dist, uint8_t *out, uint32_t cap, bool *ovf)
+{
+    BacOut o{ out + 2, 0, cap > 2 ? cap - 2 : 0, false };
+    uint64_t b = 0, l = ~0ull;
+    uint32_t data = 0; int ocnt = 0;
+    for (int i = 0; i < n; i++) {
+        const uint32_t f = r.get(bits);
+        const uint32_t iwrd = (f + (1u << (bits - 1))) & ((1u << bits) - 1u);          // offset + the signed field (bac.c:191; entropy.c:95-97)
+        for (int icnt = bits; icnt--;) {
+            uint64_t c = __umul64hi(l, dist[(iwrd & (0xFFFFFFFEu << icnt)) | (1u << icnt)]);
+            if (0 == ((iwrd >> icnt) & 1)) l = c;
+            else { b += c; l -= c; if (b < c) data++; }
+            if (l) while (l < 0x8000000000000000ull) {
+                data = (data << 1) | ((uint32_t)(b >> 63) & 1u); ocnt++;
+                if (ocnt >= 8) { o.byte(data); ocnt = 0; data = 0; }
+                b <<= 1; l <<= 1;
+            }
+        }
+    }
+    while (ocnt < 8) { data = (data << 1) ^ (uint32_t)(b >> 63); b <<= 1; ocnt++; }
+    o.byte(data);
+    while (b != 0) { o.byte((uint32_t)(b >> 56)); b <<= 8; }
+    if (cap >= 2) { out[0] = (uint8_t)(o.optr >> 8); out[1] = (uint8_t)o.optr; }
+    *ovf |= o.ovf || cap < 2 || o.optr > 0xFFFFu;
+    return o.optr + 2;
+}
+// raw signature rows -> coded rows in tmp (row pitch tmp_stride); status 6 for a row that would not fit
+__global__ __launch_bounds__(64) void bl_bac_pack_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *status, uint32_t count, uint32_t lpw, BlissP P, BacDist d,
+                                                         uint8_t *tmp, size_t tmp_stride, uint32_t cap)
+{
+    __shared__ uint64_t lds[BAC_LDS_ENTRIES];
+    const uint64_t *dz; const uint64_t *dt = bac_stage(d, P.z1_bits, P.z2_bits, lds, &dz);
+    const uint32_t item = blockIdx.x * lpw + threadIdx.x;
+    if (threadIdx.x >= lpw || item >= count || status[item] != 1) return;
+    const uint32_t rawbytes = (uint32_t)(((size_t)P.n * (P.z1_bits + P.z2_bits) + (size_t)P.kappa * P.n_bits + 7) / 8);
+    BitR r{ sigs + (size_t)item * sig_stride, rawbytes * 8, (uint32_t)sig_stride, 0, 0, 0, 0, false };
+    uint8_t *out = tmp + (size_t)item * tmp_stride;
+    bool ovf = false;
+    uint32_t at = bac_encode_block(r, P.n, P.z1_bits, dt, out, cap, &ovf);
+    at += bac_encode_block(r, P.n, P.z2_bits, dz, out + (at < cap ? at : cap), at < cap ? cap - at : 0, &ovf);
+    uint64_t acc = 0; int nb = 0;                                      // the indices, MSB first, from a byte boundary
+    for (int k = 0; k < P.kappa; k++) {
+        acc = (acc << P.n_bits) | r.get(P.n_bits); nb += P.n_bits;
+        while (nb >= 8) { if (at < cap) out[at] = (uint8_t)(acc >> (nb - 8)); else ovf = true; at++; nb -= 8; }
+    }
+    if (nb) { if (at < cap) out[at] = (uint8_t)(acc << (8 - nb)); else ovf = true; at++; }
+    if (ovf) { status[item] = 6; siglens[item] = 0; } else siglens[item] = at;
+}
+// coded rows out of tmp into the signature rows (a wavefront per row), the rest of the raw row and the tmp row zeroed
+__global__ __launch_bounds__(256) void bl_bac_move_kernel(uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, const uint32_t *status, uint32_t count, uint8_t *tmp, size_t tmp_stride,
+                                                          uint32_t rawbytes, uint32_t cap)
+{
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (item >= count) return;
+    const uint32_t st = status[item];
+    if (st != 1 && st != 6) return;                                    // (rows the coder did not touch)
+    const uint32_t keep = st == 1 ? siglens[item] : 0u, clear = rawbytes > keep ? rawbytes : keep;
+    uint8_t *row = sigs + (size_t)item * sig_stride, *src = tmp + (size_t)item * tmp_stride;
+    for (uint32_t i = lane; i < clear; i += 64) row[i] = i < keep ? src[i] : (uint8_t)0;
+    for (uint32_t i = lane; i < cap; i += 64) src[i] = 0;
+}
+// coded rows -> t, z, the indices (replaces bl_unpack_kernel; bac_decode_64_32 / _16, bac.c:260-334, bliss_b.c:1650-1657).  The decoder's bit fetch
+// is restated with its state (ibyt, icnt, iptr against the block's stated length): past that length it shifts by a negative count - undefined in C, a
+// shift by the count mod 32 on the x86 the reference runs on.  Anything read past the signature's own end makes it invalid.
+__device__ __forceinline__ void bac_decode_block(BitR &r, int n, int bits, const uint64_t *dist, int32_t *o32, int16_t *o16)
+{
+    uint32_t length = r.get(8) << 8; length |= r.get(8);
+    uint64_t v = (uint64_t)r.get(32) << 32; v |= r.get(32);
+    uint64_t b = 0, l = ~0ull;
+    uint32_t ibyt = 0; int icnt = 0; int32_t iptr = 8;
+    const uint32_t offset = 1u << (bits - 1);
+    for (int i = 0; i < n; i++) {
+        uint32_t owrd = 0;
+        for (int ocnt = bits; ocnt--;) {
+            const uint64_t c = __umul64hi(l, dist[(owrd & (0xFFFFFFFEu << ocnt)) | (1u << ocnt)]);
+            if (v - b < c) l = c;
+            else { b += c; l -= c; owrd |= 1u << ocnt; }
+            while (l < 0x8000000000000000ull) {
+                icnt--;
+                if (icnt < 0 && iptr < (int32_t)length) { ibyt = r.get(8); iptr++; icnt = 7; }
+                v = (v << 1) + ((ibyt >> (icnt & 31)) & 1u);
+                b <<= 1; l <<= 1;
+            }
+        }
+        const int32_t val = (int32_t)(owrd - offset);
+        if (o32) o32[i] = val; else o16[i] = (int16_t)val;
+    }
+}
+__global__ __launch_bounds__(64) void bl_bac_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, uint32_t lpw, int32_t *t, int16_t *z,
+                                                           int32_t *cidx, uint32_t *verdict, BlissP P, BacDist d)
+{
+    __shared__ uint64_t lds[BAC_LDS_ENTRIES];
+    const uint64_t *dz; const uint64_t *dt = bac_stage(d, P.z1_bits, P.z2_bits, lds, &dz);
+    const uint32_t item = blockIdx.x * lpw + threadIdx.x;
+    if (threadIdx.x >= lpw || item >= count) return;
+    const uint32_t sl = siglens[item];
+    BitR r{ sigs + (size_t)item * sig_stride, (uint32_t)((sl < sig_stride ? sl : sig_stride) * 8), (uint32_t)sig_stride, 0, 0, 0, 0, false };
+    bac_decode_block(r, P.n, P.z1_bits, dt, t + (size_t)item * P.n, nullptr);
+    bac_decode_block(r, P.n, P.z2_bits, dz, nullptr, z + (size_t)item * P.n);
+    for (int k = 0; k < P.kappa; k++) cidx[(size_t)item * P.kappa + k] = (int32_t)r.get(P.n_bits);
+    if (r.over) verdict[item] = 1;
+}
+
 // ---- key generation (bliss_b_keygen, bliss_b.c:1124-1264) ------------------------------------------------------------------
 // poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) is a serial placement loop over one CSPRNG word per attempt (bit 0:
 // sign, the bits above: position; an occupied position costs the word and is drawn again): one lane per key pair, the polynomial
@@ -745,7 +875,8 @@ struct sc_hip_bliss {
     int16_t *z;
     int speculate;               // 1: later pairs of attempts side by side (bl_sign_core); 0: the reference's loop round by round; 2: self-test of the redo path
     St st2; int32_t *tu2; uint8_t *sigs2; uint32_t *siglens2, *trials2, *msg_of2; size_t cap2, stride2;     // the pairs' state, vectors and output rows
-    int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy)
+    int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy), 2: SC_ENTROPY_BAC (sc_hip_bliss_set_entropy_bac)
+    uint64_t *d_bac;             // SC_ENTROPY_BAC: the coder's two distributions, 2^z1_bits + 2^z2_bits entries (sc_hip_bliss_set_entropy_bac)
     uint32_t *d_huff;            // the two code tables and their decoding orders, one allocation
     HuffT ht[2];
     double tie_rel;              // accept / reject draws closer to the threshold than this (relative) are reported, not decided: status 5
@@ -826,7 +957,7 @@ extern "C" int sc_hip_bliss_set_entropy(sc_hip_bliss_t *b, int type, const uint3
                                         const uint32_t *codes_z, const uint16_t *bits_z, uint32_t depth_z)
 {
     if (!b) return fail("bliss_set_entropy: null handle");
-    if (type != 0 && type != 1) return fail("bliss_set_entropy: type must be 0 (none) or 1 (static Huffman); the arithmetic coder is not served");
+    if (type != 0 && type != 1) return fail("bliss_set_entropy: type must be 0 (none) or 1 (static Huffman); the arithmetic coder has sc_hip_bliss_set_entropy_bac");
     if (type == 0) { b->entropy = 0; return SC_HIP_SUCCESS; }
     if (!codes_t || !bits_t || !codes_z || !bits_z) return fail("bliss_set_entropy: null table");
     const uint32_t depth[2] = { depth_t, depth_z };
@@ -853,6 +984,24 @@ extern "C" int sc_hip_bliss_set_entropy(sc_hip_bliss_t *b, int type, const uint3
     return SC_HIP_SUCCESS;
 }
 
+// replaces: the signature coding of SC_FLAG_0_ENTROPY_BAC (bliss_b.c:198, 397-398, 1453-1463, 1650-1657; src/utils/entropy/bac.c).  dist_t / dist_z: the
+// coder's distributions for t (2^z1_bits entries) and z (2^z2_bits) as entropy_dist_create / gauss_freq_bac_64 leave them in sc->dist[2], sc->dist[3] -
+// long double arithmetic of the caller's host, handed over as data like the sampler's table (sc_hip_bliss_set_cdt_table).
+extern "C" int sc_hip_bliss_set_entropy_bac(sc_hip_bliss_t *b, const uint64_t *dist_t, const uint64_t *dist_z)
+{
+    if (!b) return fail("bliss_set_entropy_bac: null handle");
+    if (!dist_t || !dist_z) return fail("bliss_set_entropy_bac: null table");
+    if (b->P.z1_bits < 1 || b->P.z1_bits > 16 || b->P.z2_bits < 1 || b->P.z2_bits > 16) return fail("bliss_set_entropy_bac: field widths of 1..16 bits");
+    const size_t nt = (size_t)1 << b->P.z1_bits, nz = (size_t)1 << b->P.z2_bits;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    if (b->d_bac) { (void)hipFree(b->d_bac); b->d_bac = nullptr; }
+    HIPCHK(hipMalloc((void **)&b->d_bac, (nt + nz) * 8));
+    HIPCHK(sc::copy_in(b->d_bac, dist_t, nt * 8));
+    HIPCHK(sc::copy_in(b->d_bac + nt, dist_z, nz * 8));
+    b->entropy = 2;
+    return SC_HIP_SUCCESS;
+}
+
 static void bl_free_ws2(sc_hip_bliss *b);
 // measurement / test hook (include/sc_hip_bench.h): 0 = the reference's loop round by round, 1 = the later pairs of attempts side by side (default)
 extern "C" int sc_hip_bliss_set_speculation(sc_hip_bliss_t *b, int on)
@@ -872,6 +1021,7 @@ extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
     if (b->d_g) (void)sc::wipe_free(b->d_g);
     if (b->d_a) (void)sc::wipe_free(b->d_a);
     if (b->d_huff) (void)hipFree(b->d_huff);
+    if (b->d_bac) (void)hipFree(b->d_bac);
     sc_hip_cdt_destroy(b->cdt);
     sc_hip_plan_destroy(b->plan);
     delete b;
@@ -1228,7 +1378,19 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             dirty = true; status_out = false;
         }
     }
-    if (b->entropy) {
+    if (b->entropy == 2) {
+        // the arithmetic coder: coded rows are built in the rows of b->v (n words each - zeroed with the other vectors below) and moved over the raw ones
+        const uint32_t rawbytes = (uint32_t)sc_hip_bliss_sig_bytes(b);
+        const size_t tmp_stride = (size_t)P.n * 4;
+        const uint32_t cap = (uint32_t)(sig_stride < tmp_stride ? sig_stride : tmp_stride);
+        uint32_t lpw = 64;
+        while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 4) lpw >>= 1;
+        const BacDist bd{ b->d_bac, b->d_bac + ((size_t)1 << P.z1_bits) };
+        hipLaunchKernelGGL(bl_bac_pack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, st.status, B, lpw, P, bd, reinterpret_cast<uint8_t *>(b->v), tmp_stride, cap);
+        hipLaunchKernelGGL(bl_bac_move_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, st.status, B, reinterpret_cast<uint8_t *>(b->v), tmp_stride, rawbytes, cap);
+        HIPCHK(hipGetLastError());
+        dirty = true;
+    } else if (b->entropy) {
         const uint32_t rawbytes = (uint32_t)sc_hip_bliss_sig_bytes(b), raww = (rawbytes + 3) / 4 + 1;
         uint32_t capw = (uint32_t)((sig_stride + 3) / 4);
         if (capw > 2 * raww) capw = 2 * raww;                       // a coded signature twice the raw size is refused (status 6) rather than given more LDS
@@ -1285,7 +1447,12 @@ static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, 
     const int n = P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
     const size_t nu = batch * (size_t)(2 * n + P.kappa), ne = batch * (size_t)n;
-    if (b->entropy) {
+    if (b->entropy == 2) {
+        uint32_t lpw = 64;
+        while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 4) lpw >>= 1;
+        const BacDist bd{ b->d_bac, b->d_bac + ((size_t)1 << P.z1_bits) };
+        hipLaunchKernelGGL(bl_bac_unpack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, B, lpw, b->tin, b->z, b->cidx, d_verdicts, P, bd);
+    } else if (b->entropy) {
         uint32_t lpw = 64;                                            // signatures per wavefront: every SIMD two wavefronts where the batch allows
         while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 8) lpw >>= 1;
         hipLaunchKernelGGL(bl_huff_unpack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, B, lpw, b->tin, b->z, b->cidx, d_verdicts, P, b->ht[0], b->ht[1]);

@@ -22,7 +22,7 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_tape_words',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_set_entropy_bac', 'sc_hip_bliss_tape_words',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_set_privkeys', 'sc_hip_falcon_set_pubkeys', 'sc_hip_falcon_sign_keys', 'sc_hip_falcon_verify_keys', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -161,6 +161,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_tape_words.argtypes = [C.c_int, C.c_uint]
     L.sc_hip_bliss_tape_words.restype = sz
     L.sc_hip_bliss_set_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
+    L.sc_hip_bliss_set_entropy_bac.argtypes = [vp, vp, vp]
     L.sc_hip_bliss_sign_keys.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify_keys.argtypes = [vp, sz, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_keygen.argtypes = [vp, sz, C.c_int, C.c_int, vp, sz, vp, vp, vp, vp, vp, vp, vp]
@@ -1048,6 +1049,13 @@ class Bliss:
         l1, l2 = (np.ascontiguousarray(np.asarray(x), dtype=np.uint16) for x in (l1, l2))
         assert c1.size == l1.size and c2.size == l2.size
         _chk(self.L, self.L.sc_hip_bliss_set_entropy(self.h, 1, _ptr(c1), _ptr(l1), c1.size, _ptr(c2), _ptr(l2), c2.size), 'bliss_set_entropy')
+
+    def set_entropy_bac(self, dist_t, dist_z):
+        """SC_ENTROPY_BAC: the arithmetic coder's two distributions (uint64 [2^z1_bits], [2^z2_bits]) as the reference's context holds them (sc->dist[2], sc->dist[3])"""
+        import numpy as np
+        dt = np.ascontiguousarray(np.asarray(dist_t), dtype=np.uint64); dz = np.ascontiguousarray(np.asarray(dist_z), dtype=np.uint64)
+        assert dt.size == 1 << int(self.par[9]) and dz.size == 1 << int(self.par[10])
+        _chk(self.L, self.L.sc_hip_bliss_set_entropy_bac(self.h, _ptr(dt), _ptr(dz)), 'bliss_set_entropy_bac')
 
     def close(self):
         if self.h:

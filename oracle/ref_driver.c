@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|bliss_huff|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -398,9 +398,11 @@ static int bliss_case(FILE *f, int set, int nmsg, int huffman)
 {
     /* huffman: sc->coding_signature.type = SC_ENTROPY_HUFFMAN_STATIC (bliss_b.c:197-200) - the same signing path, the signature's t and z coded by
      * entropy_poly_encode_32 / _16 (src/utils/entropy/entropy.c:70-112, entropy_huffman.c) instead of as raw fields */
-    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE | (huffman ? SC_FLAG_0_ENTROPY_HUFFMAN : 0), SC_FLAG_NONE };
+    /* huffman == 2: SC_ENTROPY_BAC - t and z through the arithmetic coder (src/utils/entropy/bac.c) with the two distributions bliss_b.c:397-398 builds,
+     * which are recorded as data (gauss_freq_bac_64 is long double arithmetic) */
+    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE | (huffman == 1 ? SC_FLAG_0_ENTROPY_HUFFMAN : huffman == 2 ? SC_FLAG_0_ENTROPY_BAC : 0), SC_FLAG_NONE };
     char name[96], tag[32];
-    snprintf(tag, sizeof tag, huffman ? "blissh%d" : "bliss%d", set);
+    snprintf(tag, sizeof tag, huffman == 1 ? "blissh%d" : huffman == 2 ? "blissb%d" : "bliss%d", set);
     safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
@@ -413,9 +415,13 @@ static int bliss_case(FILE *f, int set, int nmsg, int huffman)
     snprintf(name, sizeof name, "%s_f", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
     snprintf(name, sizeof name, "%s_g", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key + n, n);
     snprintf(name, sizeof name, "%s_a", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    if (huffman == 2) {                                         /* 64-bit entries as pairs of 32-bit words, low word first */
+        snprintf(name, sizeof name, "%s_dist_t", tag); rec_i32(f, name, (const int32_t *)sc->dist[2], (size_t)2 << P->z1_bits);
+        snprintf(name, sizeof name, "%s_dist_z", tag); rec_i32(f, name, (const int32_t *)sc->dist[3], (size_t)2 << P->z2_bits);
+    }
     int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
     prng_ctx_t *orig = sc->prng_ctx[0];
-    sm_state = 0xb1155000ULL + set + (huffman ? 0x100 : 0);
+    sm_state = 0xb1155000ULL + set + (huffman ? 0x100 * huffman : 0);
     /* candidates are drawn until nmsg are kept: the first nmsg-3 whatever they need, then three that took >= 3 attempts
      * (a second fresh pair of Gaussian vectors) */
     int kept = 0, long_ones = 0;
@@ -520,6 +526,19 @@ static int gen_bliss(const char *dir)
 /* Huffman-coded signatures (SC_FLAG_0_ENTROPY_HUFFMAN) and the static code tables the coder walks, as data: the tables are literals in
  * src/utils/entropy/huffman.h ("Generated from Matlab/Octave"), not the output of an algorithm the library contains */
 #include "utils/entropy/huffman.h"
+/* signatures under the arithmetic coder (SC_FLAG_0_ENTROPY_BAC), with the coder's two distributions */
+static int gen_bliss_bac(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/bliss_bac_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = bliss_case(f, 1, 6, 2);
+    rc |= bliss_case(f, 4, 4, 2);                                      /* z2_bits = 4, another sigma */
+    fclose(f);
+    return rc;
+}
+
 static int gen_bliss_huff(const char *dir)
 {
     char path[512], name[64];
@@ -1614,7 +1633,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|bliss_huff|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -1622,6 +1641,7 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
     if (all || !strcmp(argv[1], "bliss_huff")) rc |= gen_bliss_huff(argv[2]);
+    if (all || !strcmp(argv[1], "bliss_bac")) rc |= gen_bliss_bac(argv[2]);
     if (all || !strcmp(argv[1], "huff_rows")) rc |= gen_huff_rows(argv[2]);
     if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
     if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);

@@ -320,6 +320,134 @@ int orc_huff_row_decode(const uint8_t *in, size_t inlen, int n, int bits, int ta
     return r.over;
 }
 
+/* ---- the binary arithmetic coder (SC_ENTROPY_BAC): src/utils/entropy/bac.c ------------------------------------------------------------------
+ * A coefficient is `bits` binary decisions, most significant first; the probability of a 0 at a node of that binary tree is dist[prefix | 1 << k]
+ * (64-bit fixed point), the coder a 64-bit range coder with bit-wise renormalisation and byte output with carry propagation.  A coded polynomial is a
+ * byte-aligned 2-byte big-endian length followed by that many bytes. */
+/* gauss_freq_bac_64, bac.c:83-122: P(lower half | node) of exp(-x^2 / 2 sig^2) over x in [-n/2, n/2), long double arithmetic (host dependent in its
+ * last bits like the CDT tables: compare against the reference on the same host, or take the table as data) */
+void orc_bac_dist(uint64_t *dist, float sig, size_t n)
+{
+    const long double s2 = (long double)(-0.5 / (sig * sig));           /* as written there with FLOAT sig: float * float, -0.5 (a double) / float -> double, kept in a LONGDOUBLE */
+    for (size_t i = 0; i < n; i++) dist[i] = 0;
+    for (size_t i = n >> 1; i >= 1; i >>= 1) {
+        for (size_t j = 0; j < n; j += i + i) {
+            long double a = 0.0, b = 0.0;
+            for (size_t k = 0; k < i; k++) {
+                int32_t x = (int32_t)(j + k) - (int32_t)(n >> 1);
+                a += expl(s2 * (long double)(x * x));
+                x = (int32_t)(i + j + k) - (int32_t)(n >> 1);
+                b += expl(s2 * (long double)(x * x));
+            }
+            a = a / (a + b);
+            uint64_t r = (uint64_t)(0x1.p64L * a);
+            if (r < 4) r = (a > 0.5) ? (uint64_t)-4 : 4;
+            dist[j + i] = r;
+        }
+    }
+}
+static uint64_t bac_mul64hi(uint64_t x, uint64_t y) { return (uint64_t)(((unsigned __int128)x * (unsigned __int128)y) >> 64); }
+/* bac_encode_64_32 / _16, bac.c:162-258 (the two differ in the input type only).  out: a byte-aligned position; returns the bytes written, header included. */
+size_t orc_bac_encode(uint8_t *out, const int32_t *in, size_t inlen, const uint64_t *dist, int bits, int32_t offset)
+{
+    uint8_t *buffer = out + 2;
+    uint64_t b = 0, l = ~0ull;
+    uint32_t data = 0;
+    int ocnt = 0;
+    size_t optr = 0;
+#define BAC_BYTE(val) do { uint32_t ob_ = (val); buffer[optr] = (uint8_t)ob_; for (ptrdiff_t i_ = (ptrdiff_t)optr - 1; ob_ >= 0x100 && i_ >= 0; i_--) { ob_ >>= 8; ob_ += buffer[i_]; buffer[i_] = (uint8_t)ob_; } optr++; } while (0)
+    for (size_t ip = 0; ip < inlen; ip++) {
+        const uint32_t iwrd = (uint32_t)(offset + in[ip]);
+        for (int icnt = bits; icnt--;) {
+            uint64_t c = dist[(iwrd & (0xFFFFFFFEu << icnt)) | (1u << icnt)];
+            c = bac_mul64hi(l, c);
+            if (0 == ((iwrd >> icnt) & 1)) l = c;
+            else { b += c; l -= c; if (b < c) data++; }
+            if (l) while (l < 0x8000000000000000ull) {
+                data <<= 1; data |= (uint32_t)(b >> 63) & 1; ocnt++;
+                if (ocnt >= 8) { BAC_BYTE(data); ocnt = 0; data = 0; }
+                b <<= 1; l <<= 1;
+            }
+        }
+    }
+    while (ocnt < 8) { data = (data << 1) ^ (uint32_t)(b >> 63); b <<= 1; ocnt++; }
+    BAC_BYTE(data);
+    while (b != 0) { buffer[optr++] = (uint8_t)(b >> 56); b <<= 8; }
+#undef BAC_BYTE
+    out[0] = (uint8_t)(optr >> 8); out[1] = (uint8_t)optr;
+    return optr + 2;
+}
+/* bac_decode_64_32 / _16, bac.c:260-334.  in: a byte-aligned position with `avail` bytes behind it (a read past them yields zero bits, as the packer's
+ * failed read does, and sets *over); *used: the bytes consumed.  The shift "(ibyt >> icnt)" runs with icnt < 0 once the stated length is exhausted -
+ * undefined in C, a shift by icnt mod 32 on the x86 the reference runs on: restated as such. */
+void orc_bac_decode(const uint8_t *in, size_t avail, size_t *used, int *over, int32_t *out, size_t outlen, const uint64_t *dist, int bits, int32_t offset)
+{
+    size_t rp = 0;
+#define BAC_RD() (rp < avail ? in[rp++] : (*over = 1, rp++, (uint8_t)0))
+    uint32_t length = (uint32_t)BAC_RD() << 8; length |= BAC_RD();
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v = (v << 8) | BAC_RD();
+    uint64_t b = 0, l = ~0ull;
+    uint32_t ibyt = 0; int icnt = 0; int32_t iptr = 8;
+    for (size_t op = 0; op < outlen; op++) {
+        uint32_t owrd = 0;
+        for (int ocnt = bits; ocnt--;) {
+            uint64_t c = dist[(owrd & (0xFFFFFFFEu << ocnt)) | (1u << ocnt)];
+            c = bac_mul64hi(l, c);
+            if (v - b < c) l = c;
+            else { b += c; l -= c; owrd |= 1u << ocnt; }
+            while (l < 0x8000000000000000ull) {
+                icnt--;
+                if (icnt < 0 && iptr < (int32_t)length) { ibyt = BAC_RD(); iptr++; icnt = 7; }
+                v <<= 1; v += (ibyt >> (icnt & 31)) & 1;
+                b <<= 1; l <<= 1;
+            }
+        }
+        out[op] = (int32_t)(owrd - (uint32_t)offset);
+    }
+#undef BAC_RD
+    *used = rp;
+}
+/* a raw BLISS-B signature (t: n fields of z1_bits, z: n of z2_bits, kappa indices of n_bits, MSB first) <-> the same under SC_FLAG_0_ENTROPY_BAC
+ * (bliss_b.c:1453-1463, 1650-1657: t through distribution 2, z through distribution 3, the indices raw behind them) */
+int orc_bliss_sig_to_bac(const int32_t *par, const uint8_t *raw, size_t rawlen, const uint64_t *dist_t, const uint64_t *dist_z, uint8_t *out, size_t *outlen)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    if (rawlen * 8 < (size_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits)) return 1;
+    br_t r = { raw, rawlen * 8, 0, 0 };
+    int32_t v[1024];
+    for (int i = 0; i < P.n; i++) { const uint32_t f = br_get(&r, P.z1_bits); v[i] = (int32_t)(f << (32 - P.z1_bits)) >> (32 - P.z1_bits); }
+    size_t at = orc_bac_encode(out, v, (size_t)P.n, dist_t, P.z1_bits, 1 << (P.z1_bits - 1));
+    for (int i = 0; i < P.n; i++) { const uint32_t f = br_get(&r, P.z2_bits); v[i] = (int32_t)(f << (32 - P.z2_bits)) >> (32 - P.z2_bits); }
+    at += orc_bac_encode(out + at, v, (size_t)P.n, dist_z, P.z2_bits, 1 << (P.z2_bits - 1));
+    bw_t w = { out + at, 0 };
+    const size_t tailbytes = ((size_t)P.kappa * P.n_bits + 7) / 8;
+    memset(out + at, 0, tailbytes);
+    for (int i = 0; i < P.kappa; i++) bw_put(&w, br_get(&r, P.n_bits), P.n_bits);
+    *outlen = at + tailbytes;
+    return 0;
+}
+/* returns 1 when the stream ends early */
+int orc_bliss_sig_from_bac(const int32_t *par, const uint8_t *in, size_t inlen, const uint64_t *dist_t, const uint64_t *dist_z, uint8_t *raw, size_t *rawlen)
+{
+    blissp_t P; memcpy(&P, par, sizeof P);
+    int32_t v[1024];
+    int over = 0; size_t used = 0, at = 0;
+    const size_t rawbytes = ((size_t)P.n * (P.z1_bits + P.z2_bits) + (size_t)P.kappa * P.n_bits + 7) / 8;
+    memset(raw, 0, rawbytes);
+    bw_t w = { raw, 0 };
+    orc_bac_decode(in, inlen, &used, &over, v, (size_t)P.n, dist_t, P.z1_bits, 1 << (P.z1_bits - 1));
+    for (int i = 0; i < P.n; i++) bw_put(&w, (uint32_t)v[i], P.z1_bits);
+    at = used;
+    orc_bac_decode(in + (at < inlen ? at : inlen), at < inlen ? inlen - at : 0, &used, &over, v, (size_t)P.n, dist_z, P.z2_bits, 1 << (P.z2_bits - 1));
+    for (int i = 0; i < P.n; i++) bw_put(&w, (uint32_t)v[i], P.z2_bits);
+    at += used;
+    br_t r = { in + (at < inlen ? at : inlen), (at < inlen ? inlen - at : 0) * 8, 0, 0 };
+    for (int i = 0; i < P.kappa; i++) bw_put(&w, br_get(&r, P.n_bits), P.n_bits);
+    *rawlen = rawbytes;
+    return over | r.over;
+}
+
 /* poly_32_uniform_rand (src/utils/arith/poly_32.c:132-156) on the tape: c[j] coefficients of value +-(c_len - j), one prng_32 word
  * per placement attempt (bit 0: sign, the bits above: position), occupied positions are drawn again.  Returns 1 on underrun. */
 static int uniform_rand_tape(tape_t *T, int32_t *v, int n, const int *c, int c_len)

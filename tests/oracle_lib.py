@@ -75,6 +75,9 @@ def lib():
         u16p = np.ctypeslib.ndpointer(dtype=np.uint16, flags='C_CONTIGUOUS')
         L.orc_bliss_sig_to_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_bliss_sig_from_huffman.argtypes = [i32p, u8p, C.c_size_t, u32p, u16p, C.c_uint32, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
+        L.orc_bac_dist.argtypes = [u64p, C.c_float, C.c_size_t]; L.orc_bac_dist.restype = None
+        L.orc_bliss_sig_to_bac.argtypes = [i32p, u8p, C.c_size_t, u64p, u64p, u8p, C.POINTER(C.c_size_t)]
+        L.orc_bliss_sig_from_bac.argtypes = [i32p, u8p, C.c_size_t, u64p, u64p, u8p, C.POINTER(C.c_size_t)]
         L.orc_huff_row_encode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_huff_row_decode.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, u32p, u16p, C.c_uint32, u8p, C.POINTER(C.c_size_t)]
         L.orc_bliss_keygen.argtypes = [i32p, C.c_int, C.c_int, u32p, C.c_size_t, i16p, i16p, i16p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
@@ -255,6 +258,31 @@ def bliss_sig_from_huffman(key, coded, tabs):
     (c1, l1), (c2, l2) = tabs
     r = np.ascontiguousarray(np.frombuffer(bytes(coded), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
     rc = lib().orc_bliss_sig_from_huffman(key.par, r if r.size else np.zeros(1, dtype=np.uint8), r.size, c1, l1, c1.size, c2, l2, c2.size, out, C.byref(n))
+    return rc, bytes(out[:n.value])
+
+
+def bac_dists(G, tag):
+    """the arithmetic coder's two distributions (bliss_b.c:397-398) from the fixture's *_dist_t / *_dist_z records (64-bit entries as pairs of words)"""
+    f = lambda k: np.ascontiguousarray(np.ascontiguousarray(G[k], dtype=np.int32).view(np.uint64))
+    return f(f'{tag}_dist_t'), f(f'{tag}_dist_z')
+
+
+def bac_dist(sigma, bits):
+    """gauss_freq_bac_64 (bac.c:83-122) computed here, on this host"""
+    d = np.zeros(1 << bits, dtype=np.uint64)
+    lib().orc_bac_dist(d, float(sigma), d.size)
+    return d
+
+
+def bliss_sig_to_bac(key, raw, dists):
+    r = np.ascontiguousarray(np.frombuffer(bytes(raw), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
+    rc = lib().orc_bliss_sig_to_bac(key.par, r, r.size, dists[0], dists[1], out, C.byref(n))
+    return rc, bytes(out[:n.value])
+
+
+def bliss_sig_from_bac(key, coded, dists):
+    r = np.ascontiguousarray(np.frombuffer(bytes(coded), dtype=np.uint8)); out = np.zeros(8192, dtype=np.uint8); n = C.c_size_t(0)
+    rc = lib().orc_bliss_sig_from_bac(key.par, r if r.size else np.zeros(1, dtype=np.uint8), r.size, dists[0], dists[1], out, C.byref(n))
     return rc, bytes(out[:n.value])
 
 

@@ -405,6 +405,63 @@ def test_huffman_batch_vs_oracle_and_bad_tables(eng):
     b.close()
 
 
+@pytest.mark.parametrize('tag', ['blissb1', 'blissb4'])
+def test_arithmetic_coded_signatures_reproduce_the_reference(eng, tag):
+    """SC_FLAG_0_ENTROPY_BAC (tests/golden/bliss_bac_ref.txt: the reference's coded signatures and the coder's two distributions as its context held
+    them): the engine's coded signatures are the reference's byte for byte, they verify, the fixture's tampering is caught as the reference catches
+    it; then 600 seeded messages against the oracle's coder, the verifier's round trip, and truncated streams"""
+    import torch
+    H = load_golden('bliss_bac_ref.txt')
+    key = O.BlissKey.from_golden(H, tag)
+    dists = O.bac_dists(H, tag)
+    b = eng.bliss(key.par); b.set_key(key.f, key.g, key.a); b.set_entropy_bac(*dists)
+    cs = cases(H, tag)
+    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], max(len(c[1]) for c in cs) + 8)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    torch.cuda.synchronize()
+    sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
+    assert status.cpu().tolist() == [1] * len(cs)
+    for i, (_, _, sig, tr) in enumerate(cs):
+        assert bytes(sh[i, :lh[i]]) == sig, (tag, i)
+        assert int(trials[i]) == tr
+        assert not sh[i, lh[i]:b.sig_bytes].any()                     # nothing of the raw form is left behind the coded one
+    assert b.verify(msgs, sigs, siglens, mlens=mlens).cpu().tolist() == [0] * len(cs)
+    bad = sigs.clone()
+    for i in range(len(cs)):
+        bad[i, int(lh[i]) // 3] ^= 0x04
+    assert b.verify(msgs, bad, siglens, mlens=mlens).cpu().tolist() == [int(H[f'{tag}_verify'][2 * i + 1]) for i in range(len(cs))] == [1] * len(cs)
+    short = siglens.clone(); short[0] = siglens[0] // 2; short[1] = 0
+    assert b.verify(msgs, sigs, short, mlens=mlens).cpu().tolist()[:3] == [1, 1, 0]
+    # a seeded batch against the oracle's coder (pinned to the same fixture on the CPU: tests/test_oracle_bliss.py)
+    rng = np.random.default_rng(11)
+    B, W = 600, 3 * 2048 + 64
+    ms = [bytes(rng.integers(0, 256, size=int(rng.integers(1, 100)), dtype=np.uint8)) for _ in range(B)]
+    tp = [rng.integers(0, 2**32, size=W, dtype=np.uint64).astype(np.uint32) for _ in range(B)]
+    tp[5] = tp[5][:1500]
+    m_d, ml_d, t_d, tl_d = pack(ms, tp, W)
+    sg, sl, _, st = b.sign(m_d, t_d, mlens=ml_d, tape_lens=tl_d)
+    torch.cuda.synchronize()
+    sgh, slh, sth = sg.cpu().numpy(), sl.cpu().numpy(), st.cpu().numpy()
+    assert sth[5] == 2 and slh[5] == 0
+    n_ok = 0
+    for i in range(0, B, 5):
+        rc, raw, _, _ = O.bliss_sign(key, ms[i], tp[i])
+        assert (rc == 0) == (sth[i] == 1), i
+        if rc == 0:
+            rc2, coded = O.bliss_sig_to_bac(key, raw, dists)
+            assert rc2 == 0 and bytes(sgh[i, :slh[i]]) == coded, i
+            n_ok += 1
+    assert n_ok > 80
+    ok = sth == 1
+    assert slh[ok].max() < b.sig_bytes and slh[ok].mean() < 0.95 * b.sig_bytes
+    v = b.verify(m_d, sg, sl, mlens=ml_d).cpu().numpy()
+    assert np.all(v[ok] == 0) and np.all(v[~ok] == 1)
+    b.set_entropy(None)                                              # back to raw fields on the same handle
+    raw, rl, _, st2 = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
+    assert st2.cpu().tolist() == [1] * len(cs) and set(rl.cpu().tolist()) == {b.sig_bytes}
+    b.close()
+
+
 def test_pairs_side_by_side_equal_the_loop_in_order(eng, G):
     """the signer evaluates a message's later pairs of attempts side by side (tape positions computed ahead); signatures, attempt counts and statuses
     must equal the round-by-round loop's and the oracle's - also when the tape ends inside the very pair a message would have signed in"""

@@ -98,6 +98,47 @@ def test_huffman_coded_signatures_match_the_reference(tag):
         assert rc == 1                                          # a stream that ends early
 
 
+@pytest.mark.parametrize('tag', ['blissb1', 'blissb4'])
+def test_arithmetic_coded_signatures_match_the_reference(tag):
+    """SC_FLAG_0_ENTROPY_BAC: the reference's coded signatures (tests/golden/bliss_bac_ref.txt) = the raw signature of the same (key, message, tape)
+    with t and z passed through the arithmetic coder of src/utils/entropy/bac.c under the two distributions the reference built (recorded as data);
+    decoding gives the raw signature back; the reference's verdicts on coded signatures with a flipped bit are reproduced after decoding"""
+    H = load_golden('bliss_bac_ref.txt')
+    key = O.BlissKey.from_golden(H, tag)
+    dists = O.bac_dists(H, tag)
+    assert dists[0].size == 1 << int(key.par[9]) and dists[1].size == 1 << int(key.par[10])
+    raw_len = (key.n * (int(key.par[9]) + int(key.par[10])) + int(key.par[6]) * int(key.par[3]) + 7) // 8
+    for i, m, tape, sig, trials in cases(H, tag):
+        rc, raw, tr, used = O.bliss_sign(key, m, tape)
+        assert rc == 0 and tr == trials and used == len(tape), (tag, i)
+        rc, coded = O.bliss_sig_to_bac(key, raw, dists)
+        assert rc == 0 and coded == sig, (tag, i)
+        assert len(coded) < raw_len
+        rc, back = O.bliss_sig_from_bac(key, sig, dists)
+        assert rc == 0 and back == raw, (tag, i)
+        assert O.bliss_verify(key, m, back) == int(H[f'{tag}_verify'][2 * i]) == 0
+        bad = bytearray(sig); bad[len(bad) // 3] ^= 0x04
+        rc, braw = O.bliss_sig_from_bac(key, bytes(bad), dists)
+        assert (1 if rc else O.bliss_verify(key, m, braw)) == int(H[f'{tag}_verify'][2 * i + 1]) == 1
+        rc, _ = O.bliss_sig_from_bac(key, sig[:len(sig) // 2], dists)
+        assert rc == 1                                          # a stream that ends early
+
+
+def test_arithmetic_coder_distributions():
+    """gauss_freq_bac_64 restated: long double exp() arithmetic, so - like the CDT tables - entries may differ in their last units between hosts;
+    against the fixture made on the dev container's host: equal within 2^-40 relative, and bit for bit on that host"""
+    H = load_golden('bliss_bac_ref.txt')
+    for tag in ('blissb1', 'blissb4'):
+        key = O.BlissKey.from_golden(H, tag)
+        sigma = float(np.asarray(H[f'{tag}_params'], dtype=np.int32)[12:13].view(np.float32)[0])
+        want = O.bac_dists(H, tag)
+        for w, (sg, bits) in zip(want, ((sigma, int(key.par[9])), (0.7, int(key.par[10])))):
+            got = O.bac_dist(sg, bits)
+            assert got[0] == 0 and w[0] == 0
+            rel = np.abs(got[1:].astype(np.float64) - w[1:].astype(np.float64)) / np.maximum(w[1:].astype(np.float64), 1.0)
+            assert rel.max() < 2.0 ** -40, (tag, bits, rel.max())
+
+
 def test_huffman_tables_are_prefix_codes():
     H = load_golden('bliss_huff_ref.txt')
     for t in range(2, 7):
