@@ -34,8 +34,24 @@ struct St { uint32_t *pos, *status; };
 // aidx, tape words [pos + k n, pos + (k+1) n)) and the LOWEST accepted k wins - exactly the attempt the reference's loop would have
 // stopped at.  While most of the batch is active S is 1-2; as the batch thins out the same slot budget goes deeper, so the long
 // tail of the rejection loop (P(accept) ~ 0.32) costs a few rounds instead of twenty.
-__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase, int n)
+// The round loop runs on the device: rs = { messages still unsigned, slots per message, slots } of the round, derived by its first kernel from the count its
+// predecessor's last kernel left behind; every kernel of a round takes its sizes from there (the by-value arguments are the host's upper bounds, which
+// size the grids) - so the host queues the rounds its schedule predicts without looking at a count in between (a look idles the device for 25-50 us).
+enum { TRS_NACT = 0, TRS_S = 1, TRS_NSLOTS = 2 };
+__global__ void ts_rs_kernel(uint32_t *rs, uint32_t *cnt, uint32_t first_nact, uint32_t slot_cap)
 {
+    const uint32_t nact = first_nact ? first_nact : *cnt;
+    uint32_t S = nact ? slot_cap / nact : 0;
+    if (S > 32) S = 32;
+    if (nact && S < 1) S = 1;
+    rs[TRS_NACT] = nact; rs[TRS_S] = S; rs[TRS_NSLOTS] = nact * S;
+    *cnt = 0;
+}
+
+__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase, int n,
+                                const uint32_t *rs)
+{
+    if (rs) { nslots = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
     const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
     if (slot >= nslots) return;
     const uint32_t aidx = slot / S, k = slot % S;
@@ -46,16 +62,40 @@ __global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_
 }
 
 // y = (word & (2^(b_bits+1) - 1)) - b   (ring_tesla.c:818-822)
-__global__ void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P)
+// A wavefront takes 256 consecutive coefficients of one slot per step (a lane four of them: 16 bytes of tape in, 16 bytes out), so the slot's state -
+// does it draw, which message, where on its tape - is wave-uniform and read once per kilobyte rather than per coefficient.
+__global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P,
+                                                   const uint32_t *rs)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int ln = 31 - __clz(P.n);                                       // n is a power of two
-    const uint32_t slot = (uint32_t)(t >> ln); const int i = (int)(t & (size_t)(P.n - 1));
-    if (slot >= nslots) return;
-    if (need[slot] != 1) { y[t] = 0; return; }
-    const uint32_t aidx = slot / S;
-    const uint32_t item = active ? active[aidx] : aidx;
-    y[t] = (int32_t)(tapes[(size_t)item * tape_stride + sbase[slot] + i] & ((1u << (P.b_bits + 1)) - 1u)) - P.b;
+    if (rs) { nslots = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
+    const int lps = 31 - __clz(P.n / 256);                                // log2 of the steps per slot (n a power of two, >= 256: tesla_create)
+    const size_t steps = (size_t)nslots << lps, nwaves = (size_t)gridDim.x * 4;
+    const int lane = threadIdx.x & 63;
+    const uint32_t msk = (1u << (P.b_bits + 1)) - 1u;
+    for (size_t ws = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); ws < steps; ws += nwaves) {
+        const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ws >> lps));
+        const int i = (((int)ws & ((1 << lps) - 1)) << 8) + 4 * lane;
+        int4 *dst = reinterpret_cast<int4 *>(y + (size_t)slot * P.n + i);
+        if (need[slot] != 1) { *dst = make_int4(0, 0, 0, 0); continue; }
+        const uint32_t aidx = slot / S;
+        const uint32_t item = active ? active[aidx] : aidx;
+        const uint32_t *tp = tapes + (size_t)item * tape_stride + sbase[slot] + i;
+        uint32_t w[4];
+        if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
+        else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
+        *dst = make_int4((int32_t)(w[0] & msk) - P.b, (int32_t)(w[1] & msk) - P.b, (int32_t)(w[2] & msk) - P.b, (int32_t)(w[3] & msk) - P.b);
+    }
+}
+
+struct ZeroSix { void *p[6]; size_t n16; };
+__global__ void ts_zero6_kernel(ZeroSix z)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (int a = 0; a < 6; a++) {
+        uint4 *q = reinterpret_cast<uint4 *>(z.p[a]);
+        if (!q) continue;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < z.n16; i += stride) q[i] = make_uint4(0, 0, 0, 0);
+    }
 }
 
 __device__ __forceinline__ int32_t centre_q(int32_t x, int32_t q)   // ntt center_32 on a canonical value
@@ -63,8 +103,10 @@ __device__ __forceinline__ int32_t centre_q(int32_t x, int32_t q)   // ntt cente
 
 // poly_rounding (random_oracle.c:28-40) on both polynomials; cen != 0: the inputs are canonical and are centred first (signing
 // hashes centre(v), ring_tesla.c:843-849; verification hashes normalised w).  nz[aidx] = 1 if any rounded value is non-zero.
-__global__ __launch_bounds__(256) void ts_round_kernel(uint32_t nact, const int32_t *v1, const int32_t *v2, int32_t *r1, int32_t *r2, uint32_t *nz, int cen, TsP P)
+__global__ __launch_bounds__(256) void ts_round_kernel(uint32_t nact, const int32_t *v1, const int32_t *v2, int32_t *r1, int32_t *r2, uint32_t *nz, int cen, TsP P,
+                                                       const uint32_t *rs = nullptr)
 {
+    if (rs) nact = rs[TRS_NSLOTS];
     const int lane = threadIdx.x & 63;
     const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (aidx >= nact) return;
@@ -98,9 +140,11 @@ __device__ __forceinline__ uint32_t rotl(uint32_t x, int k) { return (x << k) | 
 // the recomputed md is compared with it.
 __global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
                                                        uint32_t fixed_len, const int32_t *r1, const int32_t *r2, const uint32_t *nz, const uint64_t *zstate, uint32_t zblocks,
-                                                       uint8_t *md_out, int mode, uint32_t *verdict, const uint8_t *sigs, size_t sig_stride, uint32_t md_off, TsP P)
+                                                       uint8_t *md_out, int mode, uint32_t *verdict, const uint8_t *sigs, size_t sig_stride, uint32_t md_off, TsP P,
+                                                       const uint32_t *rs = nullptr)
 {
     __shared__ uint64_t st[25 * HT];
+    if (rs) { nact = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 72);
     if (aidx >= nact) return;
@@ -138,9 +182,10 @@ __global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, u
 
 // f_function alone: c from a 64-byte digest (md rows for signing, the signature's digest for verification)
 __global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *md_rows, size_t md_stride, uint32_t md_off, int by_item,
-                                                  int32_t *cidx, TsP P)
+                                                  int32_t *cidx, TsP P, const uint32_t *rs = nullptr)
 {
     __shared__ uint32_t used[16 * HT];                                 // n <= 512 flags per lane, bit-packed
+    if (rs) nact = rs[TRS_NSLOTS];
     const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
     if (aidx >= nact) return;
     if (need && need[aidx] == 2) return;
@@ -232,9 +277,11 @@ __device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
 // one wavefront per slot (ring_tesla.c:852-880): w1 = v1 - e1*c, w2 = v2 - e2*c normalised and tested, z = y + s*c centred and
 // tested.  v1, v2 are canonical products; the key polynomials sit in LDS.  acc[slot] = 1 and z[slot] are left for the selection.
 __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const uint32_t *need, const int16_t *key, const int32_t *v1, const int32_t *v2,
-                                                        const int32_t *y, const int32_t *cidx, int32_t *zout, uint32_t *acc, TsP P)
+                                                        const int32_t *y, const int32_t *cidx, int32_t *zout, uint32_t *acc, TsP P, const uint32_t *rs)
 {
     extern __shared__ int16_t ks[];                                    // s | e1 | e2
+    if (rs) nslots = rs[TRS_NSLOTS];
+    if (blockIdx.x * 4 >= nslots) return;                              // (whole workgroup)
     const int n = P.n;
     for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) ks[i] = key[i];
     __syncthreads();
@@ -277,8 +324,9 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
 // any acceptance ends the message with status 2; otherwise the message goes to the next round S attempts further on.
 __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint32_t *acc, St s, const int32_t *zs,
                                                         const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
-                                                        uint32_t *next_active, uint32_t *next_count, TsP P)
+                                                        uint32_t *next_active, uint32_t *next_count, TsP P, const uint32_t *rs)
 {
+    if (rs) { nact = rs[TRS_NACT]; S = rs[TRS_S]; }
     const int lane = threadIdx.x & 63, n = P.n;
     const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (aidx >= nact) return;
@@ -299,7 +347,15 @@ __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, 
     const uint32_t slot = aidx * S + win;
     const int32_t *z = zs + (size_t)slot * n;
     uint8_t *out = sigs + (size_t)item * sig_stride;
-    if (P.q_bits == 24) {
+    if (P.q_bits == 24 && (reinterpret_cast<uintptr_t>(out) & 3) == 0) {
+        // four 24-bit fields are three big-endian words (a row that starts on a word boundary)
+        for (int gq = lane; gq < n / 4; gq += 64) {
+            const int4 v = *reinterpret_cast<const int4 *>(z + 4 * gq);
+            const uint32_t a = (uint32_t)v.x & 0xFFFFFFu, b = (uint32_t)v.y & 0xFFFFFFu, c = (uint32_t)v.z & 0xFFFFFFu, d = (uint32_t)v.w & 0xFFFFFFu;
+            uint32_t *ow = reinterpret_cast<uint32_t *>(out) + 3 * gq;
+            ow[0] = __builtin_bswap32((a << 8) | (b >> 16)); ow[1] = __builtin_bswap32((b << 16) | (c >> 8)); ow[2] = __builtin_bswap32((c << 24) | d);
+        }
+    } else if (P.q_bits == 24) {
         for (int j = lane; j < n; j += 64) {
             const uint32_t v = (uint32_t)z[j];
             out[3 * j] = (uint8_t)(v >> 16); out[3 * j + 1] = (uint8_t)(v >> 8); out[3 * j + 2] = (uint8_t)v;
@@ -369,16 +425,16 @@ struct sc_hip_tesla {
     uint64_t *d_zstate; uint32_t zblocks;
     size_t cap, slot_cap;                // messages / slots (attempts evaluated side by side) the workspace holds
     St st;
-    uint32_t *act[2], *cnt, *need, *sbase, *nz, *trials, *acc;
+    uint32_t *act[2], *cnt, *rs, *need, *sbase, *nz, *trials, *acc;
     int32_t *y, *v1, *v2, *r1, *r2, *cidx, *zs;
     uint8_t *md;
 };
 
 static void ts_free_ws(sc_hip_tesla *t)
 {
-    void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->need, t->sbase, t->nz, t->trials, t->acc, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->zs, t->md };
+    void *ptrs[] = { t->st.pos, t->st.status, t->act[0], t->act[1], t->cnt, t->rs, t->need, t->sbase, t->nz, t->trials, t->acc, t->y, t->v1, t->v2, t->r1, t->r2, t->cidx, t->zs, t->md };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
-    t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->need = t->sbase = t->nz = t->trials = t->acc = nullptr;
+    t->st.pos = t->st.status = nullptr; t->act[0] = t->act[1] = t->cnt = t->rs = t->need = t->sbase = t->nz = t->trials = t->acc = nullptr;
     t->y = t->v1 = t->v2 = t->r1 = t->r2 = t->cidx = t->zs = nullptr; t->md = nullptr; t->cap = t->slot_cap = 0;
 }
 
@@ -391,7 +447,7 @@ static int ts_ensure_ws(sc_hip_tesla *t, size_t batch, size_t slots)
     ts_free_ws(t);
     const size_t n = t->P.n;
 #define WS(ptr, bytes) HIPCHK(hipMalloc((void **)&(ptr), (bytes)))
-    WS(t->st.pos, batch * 4); WS(t->st.status, batch * 4); WS(t->act[0], batch * 4); WS(t->act[1], batch * 4); WS(t->cnt, 64); WS(t->trials, batch * 4);
+    WS(t->st.pos, batch * 4); WS(t->st.status, batch * 4); WS(t->act[0], batch * 4); WS(t->act[1], batch * 4); WS(t->cnt, 64); WS(t->rs, 64); WS(t->trials, batch * 4);
     WS(t->need, slots * 4); WS(t->sbase, slots * 4); WS(t->nz, slots * 4); WS(t->acc, slots * 4);
     WS(t->y, slots * n * 4); WS(t->v1, slots * n * 4); WS(t->v2, slots * n * 4); WS(t->r1, slots * n * 4); WS(t->r2, slots * n * 4); WS(t->zs, slots * n * 4);
     WS(t->cidx, slots * (size_t)t->P.omega * 4); WS(t->md, slots * 64);
@@ -488,38 +544,61 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
     HIPCHK(hipMemsetAsync(st.pos, 0, batch * 4, s)); HIPCHK(hipMemsetAsync(st.status, 0, batch * 4, s));
     uint32_t *trials = d_trials ? d_trials : t->trials;
     HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));
-    uint32_t nact = (uint32_t)batch;
-    const uint32_t *active = nullptr;
-    for (uint32_t round = 0; nact > 0; round++) {
-        if (round >= 9999) break;                                       // the reference's own cap (ring_tesla.c:814); leftovers keep status 0
-        uint32_t S = (uint32_t)(t->slot_cap / nact);
-        if (S > 32) S = 32;
-        if (S < 1) S = 1;
-        const uint32_t nslots = nact * S;
-        uint32_t *next = t->act[round & 1];
-        HIPCHK(hipMemsetAsync(t->cnt, 0, 4, s));
-        hipLaunchKernelGGL(ts_begin_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nslots, S, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, n);
-        const size_t ne = (size_t)nslots * n;
-        hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P);
-        HIPCHK(hipGetLastError());
-        if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
-        if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
-        hipLaunchKernelGGL(ts_round_kernel, dim3((nslots + 3) / 4), dim3(256), 0, s, nslots, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P);
-        hipLaunchKernelGGL(ts_oracle_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, active, nslots, S, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
-                           t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P);
-        hipLaunchKernelGGL(ts_f_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, nslots, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P);
-        hipLaunchKernelGGL(ts_decide_kernel, dim3((nslots + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, nslots, t->need, t->d_key, t->v1, t->v2, t->y, t->cidx, t->zs, t->acc, P);
-        hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P);
-        HIPCHK(hipGetLastError());
+    // Rounds are queued as the schedule predicts them (the slot rule run forward with the scheme's rejection probability, 0.68 per attempt, until fewer than four
+    // messages are expected to be left: three rounds at 16384 messages), then the count is looked at ONCE and single rounds follow while messages are left.
+    const uint32_t cap = (uint32_t)t->slot_cap, B = (uint32_t)batch;
+    uint32_t todo = 0;
+    { double left = (double)batch; while (left >= 4.0 && todo < 64) {     /* (a queued round that finds nobody left still costs two transforms over the slot budget) */ double S = cap / (left < 1.0 ? 1.0 : left); if (S > 32) S = 32; if (S < 1) S = 1; left *= pow(0.68, floor(S)); todo++; } }
+    if (!todo) todo = 1;
+    uint32_t round = 0, left = B;
+    bool planned = true;                                                  // the queued rounds take their sizes from the device; a round behind the look has the host's
+    while (left > 0) {
+        for (uint32_t i = 0; i < todo; i++, round++) {
+            if (round >= 9999) { left = 0; break; }                       // the reference's own cap (ring_tesla.c:814); leftovers keep status 0
+            const uint32_t *active = round ? t->act[(round - 1) & 1] : nullptr;
+            uint32_t *next = t->act[round & 1];
+            const uint32_t *rs = planned ? t->rs : nullptr;
+            uint32_t nact = B, S = 1, nslots = cap;                       // planned: upper bounds (they size the grids)
+            if (planned) hipLaunchKernelGGL(ts_rs_kernel, dim3(1), dim3(1), 0, s, t->rs, t->cnt, round ? 0u : B, cap);
+            else {
+                nact = left; S = cap / nact; if (S > 32) S = 32; if (S < 1) S = 1; nslots = nact * S;
+                HIPCHK(hipMemsetAsync(t->cnt, 0, 4, s));
+            }
+            const size_t ne = (size_t)nslots * n;
+            size_t yb = (ne / 4 + 255) / 256;                             // a lane per four coefficients; persistent beyond 16 workgroups per CU
+            if (yb > (size_t)t->ctx->cus * 16) yb = (size_t)t->ctx->cus * 16;
+            hipLaunchKernelGGL(ts_begin_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nslots, S, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, n, rs);
+            hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs);
+            HIPCHK(hipGetLastError());
+            // (a planned round's products run over the whole slot budget: rows past the round's slots hold what an earlier round left there and are read by nobody)
+            if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
+            if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+            hipLaunchKernelGGL(ts_round_kernel, dim3((nslots + 3) / 4), dim3(256), 0, s, nslots, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P, rs);
+            hipLaunchKernelGGL(ts_oracle_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, active, nslots, S, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
+                               t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P, rs);
+            hipLaunchKernelGGL(ts_f_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, nslots, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P, rs);
+            hipLaunchKernelGGL(ts_decide_kernel, dim3((nslots + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, nslots, t->need, t->d_key, t->v1, t->v2, t->y, t->cidx, t->zs, t->acc, P, rs);
+            hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P, rs);
+            HIPCHK(hipGetLastError());
+        }
+        if (!left) break;
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, t->cnt, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        nact = cnt;
-        active = next;
+        left = cnt;
+        todo = 1; planned = false;
     }
     if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
-    // the masks y, their products and the rejected candidates do not outlive the call
-    sc::wipe_async(t->y, s); sc::wipe_async(t->v1, s); sc::wipe_async(t->v2, s); sc::wipe_async(t->r1, s); sc::wipe_async(t->r2, s); sc::wipe_async(t->zs, s);
+    // the masks y, their products and the rejected candidates do not outlive the call: one launch over the six arrays (as six memsets they cost a
+    // launch gap each); every round's slot count is cut from the handle's slot budget, so that is how far they were written
+    {
+        const size_t used = t->slot_cap * (size_t)n * 4;
+        ZeroSix z6{ { t->y, t->v1, t->v2, t->r1, t->r2, t->zs }, used / 16 };
+        size_t zb = (used / 16 + 255) / 256;
+        if (zb > (size_t)t->ctx->cus * 8) zb = (size_t)t->ctx->cus * 8;
+        hipLaunchKernelGGL(ts_zero6_kernel, dim3((unsigned)(zb ? zb : 1)), dim3(256), 0, s, z6);
+        HIPCHK(hipGetLastError());
+    }
     return SC_HIP_SUCCESS;
 }
 
