@@ -77,7 +77,8 @@ def reproduce(eng, G, table=None):
     if table is not None:
         b.set_cdt_table(table)
     cs = cases(G)
-    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], 4200)
+    # (rows as wide as the longest tape: a key pair made on the spot now and then has a message that took five attempts - three fresh draws, 6150 words)
+    msgs, mlens, tapes, tlens = pack([c[0] for c in cs], [c[1] for c in cs], max(4200, max(len(c[1]) for c in cs) + 8))
     sigs, siglens, trials, status = b.sign(msgs, tapes, mlens=mlens, tape_lens=tlens)
     torch.cuda.synchronize()
     sh, lh = sigs.cpu().numpy(), siglens.cpu().numpy()
