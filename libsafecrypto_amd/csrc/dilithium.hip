@@ -1213,6 +1213,19 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
 }
 
 // d_verdicts[i] = 0 (SC_FUNC_SUCCESS) when signature i verifies, 1 otherwise (test/functional/func_alg_dilithium.c:225)
+namespace {
+// joins the handle's side streams back into the caller's on every exit path of a call that forked them
+struct JoinGuard {
+    hipStream_t s, side[2];
+    hipEvent_t ev[2];
+    ~JoinGuard()
+    {
+        for (int i = 0; i < 2; i++)
+            if (side[i] && ev[i]) { if (hipEventRecord(ev[i], side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, ev[i], 0); else (void)hipGetLastError(); }
+    }
+};
+}
+
 extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
                                        uint32_t fixed_len, const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens,
                                        uint32_t *d_verdicts, void *stream)
@@ -1235,6 +1248,8 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     const unsigned zblock = (unsigned)((l * P.n / 8 + 63) / 64 * 64);                // a lane per eight coefficients, a workgroup per signature
     if (P.z_bits == 20) hipLaunchKernelGGL(dil_unpackz_kernel<20>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
     else hipLaunchKernelGGL(dil_unpackz_kernel<0>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    // (measured and dropped: the tail unpacking and mu = CRH(tr, message) on a stream of the handle's own beside the unpacking of z and the matrix product -
+    // 39 us of kernels off the critical path, but forking and joining cost as much: 354 -> 359 us per 16384 signatures)
     hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
     hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
     HIPCHK(hipGetLastError());
@@ -1330,15 +1345,6 @@ __global__ __launch_bounds__(HT) void shake_test_kernel(int rate, const uint8_t 
 // the calls with a key per item fork work onto streams of the handle's own: whatever path leaves such a call, the caller's stream waits for everything
 // that was queued on them (an early return must not leave side work running beside the caller's next call on the same workspace)
 namespace {
-struct JoinGuard {
-    hipStream_t s, side[2];
-    hipEvent_t ev[2];
-    ~JoinGuard()
-    {
-        for (int i = 0; i < 2; i++)
-            if (side[i] && ev[i]) { if (hipEventRecord(ev[i], side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, ev[i], 0); else (void)hipGetLastError(); }
-    }
-};
 }
 
 // t0 of every key from t (decompose, module_lwe.c:89-104), canonical in [0, q): what sc_hip_dilithium_set_privkey does on the host for one key
