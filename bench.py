@@ -738,15 +738,26 @@ def main():
         kern_ms = ev0.elapsed_time(ev1) / args.steps                 # average over the K launches of the timed region
         kern_ms_plain = plan.time_op(2, a, bhat, out, 50)            # the same kernel as 50 plain launches between two events (C loop)
         achieved = BATCH * BYTES_PER_TRIPLE / (kern_ms * 1e-3) / 1e9
+        # per-launch HBM bytes of this kernel (2 x FETCH_SIZE + WRITE_SIZE): counters collected over a child process of THIS run (tools/pmc_leg.py: the same
+        # fused product at the same batch under rocprofv3 --pmc, one pass per counter as the guide prescribes), else the committed passes of tools/profile_r03.sh
         traffic = traffic_past = None
-        tp = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')      # per-launch HBM bytes from rocprofv3 --pmc
-        if os.path.exists(tp):
+        traffic_source = None
+        pm = _pmc('polymul') if (cpu_on and PMC_LIVE) else None
+        if pm and str(pm.get('source', '')).startswith('live'):
+            traffic = pm['hbm_bytes_per_op_2xfetch_plus_write'] * pm['batch']
+            traffic_source = 'live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python3 tools/bench_scheme.py polymul` as a child of this run'
+        for name in ('r03_pmc_traffic.json', 'pmc_traffic.json'):
+            tp = os.path.join(ROOT, 'profiles', name)
+            if not os.path.exists(tp):
+                continue
             try:
                 tj = json.load(open(tp))
-                traffic = tj.get('polymul_ntt_n256_b65536_bytes')
+                if traffic is None:
+                    traffic = tj.get('polymul_ntt_n256_b65536_bytes'); traffic_source = 'committed: profiles/' + name
                 traffic_past = tj.get('polymul_ntt_n256_b1048576_bytes')
+                break
             except Exception:
-                traffic = None
+                pass
         # the same kernel over a working set far past the Infinity Cache (3 x 1 GiB): what the HBM itself sustains for this access pattern
         past = {}
         try:
@@ -781,7 +792,7 @@ def main():
                                    'batched NTT + pointwise-mul + INTT, batch=65536 per GPU', 'n': N, 'q': Q,
                        'batch_per_gpu': BATCH, 'parallelism': f'shard{world} (independent polynomials, no collective)'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'ntt_kernel<8,*,*,OP_MULNTT>', 'kernel_ms': kern_ms, 'kernel_ms_plain_launches': kern_ms_plain,
                          'algorithmic_bytes_per_launch': BATCH * BYTES_PER_TRIPLE,
                          'note': 'achieved / frac are at the BASELINE batch, whose 192 MiB of operands fit the 256 MiB Infinity Cache when replayed back to back '
