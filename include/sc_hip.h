@@ -143,6 +143,18 @@ int  sc_hip_cdt_table(const sc_hip_cdt_t *cdt, uint64_t *h_cdf);
  * (the reference's prng_64 outputs) supplied by the caller: out[i] = sample(x[i]) + centre. */
 int sc_hip_cdt_sample(sc_hip_cdt_t *cdt, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
 
+/* The sampler at 32-bit precision.
+ * replaces: create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, ...) -> gaussian_cdf_create_32, and get_vector_32 -> gaussian_cdf_sample_32 +
+ * binary_search_32 (src/utils/sampling/gaussian_cdf.c:661-774): a table of 32-bit entries built with FLOAT (float) accumulators, one prng_32 word per
+ * sample, "entry < word", the sign from the word's bit 0.  A handle made here is served by sc_hip_cdt32_sample only (and the other way round); size /
+ * destroy are sc_hip_cdt_size / sc_hip_cdt_destroy.  (The reference's 128- / 192-bit samplers do not terminate a BLISS-B signature in the build of
+ * SURVEY 8(c) - safecrypto_sign loops - and its 256-bit one draws an uninitialised limb, gaussian_cdf.c:519-527: neither can be pinned, neither is served.) */
+int sc_hip_cdt32_build_table(float tail, float sigma, uint32_t *h_cdf, int size);
+int sc_hip_cdt32_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t **cdt);
+int sc_hip_cdt32_create_from_table(sc_hip_ctx_t *ctx, const uint32_t *h_cdf, int size, sc_hip_cdt_t **cdt);
+int sc_hip_cdt32_table(const sc_hip_cdt_t *cdt, uint32_t *h_cdf);
+int sc_hip_cdt32_sample(sc_hip_cdt_t *cdt, size_t count, const uint32_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
+
 /* ---- Dilithium: batched sign / verify under one key --------------------------------------- */
 
 /* the fields of dilithium_set_t the engine needs (src/schemes/sig/dilithium/dilithium_params.h:60-93,

@@ -323,4 +323,5 @@ struct sc_hip_cdt {
     uint64_t *d_cdf;              // size entries + CDT_PAD of 2^64 - 1 (g.S != 0: 2^64 - 1 also behind the first entry of the closing run, cdt_guide.h)
     uint16_t *d_guide;            // g.total bins (cdt_guide.h); g.S = 0: no usable guide, the kernels fall back to the halving search
     CdtGuide g;
+    bool w32 = false;             // a 32-bit precision table widened to the 64-bit form (sc_hip_cdt32_*): searched with widened 32-bit words
 };

@@ -227,6 +227,40 @@ __device__ __forceinline__ int32_t cdt_one(uint64_t u, const uint64_t *tab, cons
     return ((u & 1) ? (int32_t)r : -(int32_t)r) + centre;
 }
 
+// 32-bit precision (gaussian_cdf_sample_32, gaussian_cdf.c:765-774: one prng_32 word per sample, "table entry < word" on 32 bits, the sign from the word's
+// bit 0) rides on the 64-bit search: the handle's table holds entry << 32 | 0xFFFFFFFF and a word x searches as x << 32 | 0xFFFFFFFE | (x & 1) - the
+// same order relation (entry < x on the words; an entry equal to x is not below it) and the same sign bit.
+__device__ __forceinline__ uint64_t widen32(uint32_t x) { return ((uint64_t)x << 32) | 0xFFFFFFFEull | (uint64_t)(x & 1u); }
+
+// HALF: no usable guide - the halving search itself; otherwise S probes behind the guide (S = 0: the guide's own count, as in cdt_kernel<0>)
+template <int S, bool HALF>
+__global__ __launch_bounds__(256) void cdt32_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, CdtGuide g, const uint32_t *__restrict__ x,
+                                                    int32_t *__restrict__ out, size_t count, int32_t centre)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
+    for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
+    if (!HALF) for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
+    __syncthreads();
+    auto one = [&](uint32_t w) -> int32_t {
+        const uint64_t u = widen32(w);
+        if constexpr (!HALF) return cdt_one<S>(u, tab, guide, g, centre);
+        uint32_t a = 0;
+        for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
+        return ((u & 1) ? (int32_t)a : -(int32_t)a) + centre;
+    };
+    const size_t stride = (size_t)gridDim.x * blockDim.x, quads = count / 4;
+    if (((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += stride) {
+            const uint4 w = reinterpret_cast<const uint4 *>(x)[i];
+            reinterpret_cast<int4 *>(out)[i] = make_int4(one(w.x), one(w.y), one(w.z), one(w.w));
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (count & 3)) { const size_t i = quads * 4 + threadIdx.x; out[i] = one(x[i]); }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) out[i] = one(x[i]);
+    }
+}
+
 template <int S>
 __global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, CdtGuide g, const uint64_t *__restrict__ x,
                                                   int32_t *__restrict__ out, size_t count, int32_t centre)
@@ -729,6 +763,7 @@ extern "C" int sc_hip_cdt_table(const sc_hip_cdt_t *c, uint64_t *h)
 extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream)
 {
     if (!c) return fail("cdt_sample: null sampler");
+    if (c->w32) return fail("cdt_sample: the sampler was created at 32-bit precision (sc_hip_cdt32_sample takes its 32-bit words)");
     if (count == 0) return SC_HIP_SUCCESS;
     if (!d_uniform || !d_out) return fail("cdt_sample: null device pointer");
     HIPCHK(hipSetDevice(c->ctx->device));
@@ -746,6 +781,80 @@ extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *
     case 2: hipLaunchKernelGGL(cdt_kernel<2>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
     case 3: hipLaunchKernelGGL(cdt_kernel<3>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
     default: hipLaunchKernelGGL(cdt_kernel<0>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    }
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// ---- the sampler at 32-bit precision (create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, ...): gaussian_cdf_create_32 / gaussian_cdf_sample_32,
+// src/utils/sampling/gaussian_cdf.c:683-774) ----
+extern "C" int sc_hip_cdt32_build_table(float tail, float sigma, uint32_t *cdf, int size)
+{
+    if (!cdf || size != sc_hip_cdt_table_size(tail, sigma) || size < 2) return fail("cdt32_build_table: bad size");
+    // the recurrence of gaussian_cdf.c:719-735 with its types: s, d, e are FLOAT (float); the constants and expl() are wider and every assignment rounds
+    const float d = (float)(1.12837916709551257390 * 0.70710678118654752440 * 4294967296.0 / sigma);      // M_2_SQRTPI * M_SQRT1_2 * 2^32 / sigma: double arithmetic
+    const float e = (float)(-0.5L / (sigma * sigma));
+    float s = (float)(0.5L * d);
+    int i;
+    cdf[0] = 0;
+    for (i = 1; i < size - 1; i++) {
+        cdf[i] = (uint32_t)s;
+        if (cdf[i] == 0) break;
+        s = (float)(s + d * expl(e * ((float)(i * i))));
+    }
+    for (; i < size; i++) cdf[i] = 0xFFFFFFFFu;
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt32_create_from_table(sc_hip_ctx_t *ctx, const uint32_t *h_cdf, int size, sc_hip_cdt_t **out)
+{
+    if (!ctx || !h_cdf || !out) return fail("cdt32_create_from_table: null argument");
+    if (size < 2 || size > 4096 || (size & (size - 1))) return fail("cdt32_create_from_table: size must be a power of two in 2..4096");
+    std::vector<uint64_t> t((size_t)size);
+    for (int i = 0; i < size; i++) t[(size_t)i] = ((uint64_t)h_cdf[i] << 32) | 0xFFFFFFFFull;
+    t[0] = 0;                                                          // (never compared: the search starts above it)
+    if (sc_hip_cdt_create_from_table(ctx, t.data(), size, out) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    (*out)->w32 = true;
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt32_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t **out)
+{
+    if (!ctx || !out) return fail("cdt32_create: null argument");
+    const int size = sc_hip_cdt_table_size(tail, sigma);
+    if (size < 2 || size > 4096) return fail("cdt32_create: tail*sigma must give a table of 2..4096 entries (LDS residency)");
+    std::vector<uint32_t> t((size_t)size);
+    if (sc_hip_cdt32_build_table(tail, sigma, t.data(), size) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    if (sc_hip_cdt32_create_from_table(ctx, t.data(), size, out) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    (*out)->tail = tail; (*out)->sigma = sigma;
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt32_table(const sc_hip_cdt_t *c, uint32_t *h)
+{
+    if (!c || !h) return fail("cdt32_table: null argument");
+    if (!c->w32) return fail("cdt32_table: a 64-bit sampler");
+    for (int i = 0; i < c->size; i++) h[i] = i ? (uint32_t)(c->cdf[(size_t)i] >> 32) : 0u;
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt32_sample(sc_hip_cdt_t *c, size_t count, const uint32_t *d_uniform, int32_t centre, int32_t *d_out, void *stream)
+{
+    if (!c) return fail("cdt32_sample: null sampler");
+    if (!c->w32) return fail("cdt32_sample: the sampler was created at 64-bit precision (sc_hip_cdt_sample takes its 64-bit words)");
+    if (count == 0) return SC_HIP_SUCCESS;
+    if (!d_uniform || !d_out) return fail("cdt32_sample: null device pointer");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    size_t blocks = (count + 256 * 32 - 1) / (256 * 32);
+    if (blocks == 0) blocks = 1;
+    const size_t lds = sc::cdt_lds_bytes(c);
+    const size_t per_cu = lds ? (size_t)(160 * 1024) / lds : 8;
+    const size_t cap = (size_t)c->ctx->cus * (per_cu > 8 ? 8 : (per_cu ? per_cu : 1));
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gr((unsigned)blocks), bl(256);
+    switch (c->g.S) {
+    case 0: hipLaunchKernelGGL((cdt32_kernel<0, true>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    case 1: hipLaunchKernelGGL((cdt32_kernel<1, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    case 2: hipLaunchKernelGGL((cdt32_kernel<2, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    case 3: hipLaunchKernelGGL((cdt32_kernel<3, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    default: hipLaunchKernelGGL((cdt32_kernel<0, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
     }
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;

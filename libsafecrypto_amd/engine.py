@@ -15,6 +15,7 @@ SYMBOLS = [
     'sc_hip_normalize', 'sc_hip_center', 'sc_hip_poly_add', 'sc_hip_poly_sub', 'sc_hip_matvec',
     'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_create_from_table',
     'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
+    'sc_hip_cdt32_build_table', 'sc_hip_cdt32_create', 'sc_hip_cdt32_create_from_table', 'sc_hip_cdt32_table', 'sc_hip_cdt32_sample',
     'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
     'sc_hip_pointwise_host', 'sc_hip_normalize_host', 'sc_hip_center_host',
     'sc_hip_dilithium_create', 'sc_hip_dilithium_destroy', 'sc_hip_dilithium_set_privkey', 'sc_hip_dilithium_set_pubkey',
@@ -121,6 +122,11 @@ def load_library(path=LIB_PATH):
     L.sc_hip_cdt_size.argtypes = [vp]
     L.sc_hip_cdt_table.argtypes = [vp, vp]
     L.sc_hip_cdt_sample.argtypes = [vp, sz, vp, i32, vp, vp]
+    L.sc_hip_cdt32_build_table.argtypes = [C.c_float, C.c_float, vp, C.c_int]
+    L.sc_hip_cdt32_create.argtypes = [vp, C.c_float, C.c_float, C.POINTER(vp)]
+    L.sc_hip_cdt32_create_from_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
+    L.sc_hip_cdt32_table.argtypes = [vp, vp]
+    L.sc_hip_cdt32_sample.argtypes = [vp, sz, vp, i32, vp, vp]
     L.sc_hip_ntt_fwd_host.argtypes = [vp, sz, vp, vp]
     L.sc_hip_ntt_inv_host.argtypes = [vp, sz, vp, vp]
     L.sc_hip_polymul_ntt_host.argtypes = [vp, sz, vp, vp, vp]
@@ -611,6 +617,9 @@ class Engine:
     def sampler(self, tail=None, sigma=None, table=None):
         return CdtSampler(self, tail, sigma, table)
 
+    def sampler32(self, tail=None, sigma=None, table=None):
+        return CdtSampler32(self, tail, sigma, table)
+
     def synchronize(self):
         _chk(self.L, self.L.sc_hip_synchronize(self.h, _stream()), 'sc_hip_synchronize')
 
@@ -868,6 +877,41 @@ class CdtSampler:
         u = np.ascontiguousarray(uniform, dtype=np.uint64)
         out = np.empty(u.size, dtype=np.int32)
         _chk(self.L, self.L.sc_hip_cdt_sample_host(self.h, u.size, _ptr(u), centre, _ptr(out)), 'cdt_sample_host')
+        return out
+
+
+class CdtSampler32:
+    """create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, ...) counterpart: 32-bit table entries, one 32-bit word per sample."""
+
+    def __init__(self, eng, tail=None, sigma=None, table=None):
+        self.eng, self.L = eng, eng.L
+        h = C.c_void_p()
+        if table is not None:
+            import numpy as np
+            t = np.ascontiguousarray(table, dtype=np.uint32)
+            _chk(self.L, self.L.sc_hip_cdt32_create_from_table(eng.h, _ptr(t), t.size, C.byref(h)), 'sc_hip_cdt32_create_from_table')
+        else:
+            _chk(self.L, self.L.sc_hip_cdt32_create(eng.h, tail, sigma, C.byref(h)), 'sc_hip_cdt32_create')
+        self.h = h
+        self.size = self.L.sc_hip_cdt_size(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_cdt_destroy(self.h)
+            self.h = None
+
+    def table(self):
+        import numpy as np
+        t = np.empty(self.size, dtype=np.uint32)
+        _chk(self.L, self.L.sc_hip_cdt32_table(self.h, _ptr(t)), 'cdt32_table')
+        return t
+
+    def sample(self, uniform, centre=0, out=None):
+        """uniform: int32 device tensor holding the u32 words bit-for-bit"""
+        import torch
+        assert uniform.element_size() == 4 and uniform.is_contiguous()
+        out = torch.empty(uniform.numel(), dtype=torch.int32, device=uniform.device) if out is None else out
+        _chk(self.L, self.L.sc_hip_cdt32_sample(self.h, uniform.numel(), _ptr(uniform), centre, _ptr(out), _stream()), 'cdt32_sample')
         return out
 
 

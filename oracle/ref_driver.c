@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -253,6 +253,41 @@ static int cdt_case(FILE *f, float tail, float sigma, int nsamp, const char *tag
     destroy_sampler(&s);
     prng_destroy(p1); prng_destroy(p2);
     return 0;
+}
+
+/* the same at 32-bit precision (SAMPLING_32BIT: gaussian_cdf_create_32 / gaussian_cdf_sample_32, one prng_32 per sample) */
+typedef struct __attribute__((packed)) { UINT32 *cdf; SINT32 cdf_size; } cdf32_view_t;  /* src/utils/sampling/gaussian_cdf.c:84-92 */
+static int cdt32_case(FILE *f, float tail, float sigma, int nsamp, const char *tag)
+{
+    static const uint8_t seed[32] = { 2, 7, 1, 8, 2, 8, 1, 8, 2, 8, 4, 5, 9, 0, 4, 5, 2, 3, 5, 3, 6, 0, 2, 8, 7, 4, 7, 1, 3, 5, 2, 6 };
+    char name[96];
+    prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32);
+    utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, NORMAL_SAMPLES, 512, SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
+    if (!s) return 1;
+    const cdf32_view_t *g = (const cdf32_view_t *)s->gauss;
+    snprintf(name, sizeof name, "%s_tab32", tag); rec_i32(f, name, (const int32_t *)g->cdf, (size_t)g->cdf_size);
+    int32_t *x = malloc(sizeof(int32_t) * nsamp), *v = malloc(sizeof(int32_t) * nsamp);
+    for (int i = 0; i < nsamp; i++) x[i] = (int32_t)prng_32(p2);
+    get_vector_32(s, v, nsamp, 0);
+    snprintf(name, sizeof name, "%s_words32", tag); rec_i32(f, name, x, nsamp);
+    snprintf(name, sizeof name, "%s_samples", tag); rec_i32(f, name, v, nsamp);
+    free(x); free(v);
+    destroy_sampler(&s);
+    prng_destroy(p1); prng_destroy(p2);
+    return 0;
+}
+static int gen_cdt32(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/cdt32_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = 0;
+    rc |= cdt32_case(f, 13.42f, 215.0f, 2048, "bliss1_s215_t13.42");
+    rc |= cdt32_case(f, 12.0f, 100.0f, 1024, "unit_s100_t12");
+    rc |= cdt32_case(f, 10.0f, 1.7f, 512, "leaf_s1.7_t10");
+    fclose(f);
+    return rc;
 }
 
 static int gen_cdt(const char *dir)
@@ -1633,13 +1668,14 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
     if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
+    if (all || !strcmp(argv[1], "cdt32")) rc |= gen_cdt32(argv[2]);
     if (all || !strcmp(argv[1], "bliss_huff")) rc |= gen_bliss_huff(argv[2]);
     if (all || !strcmp(argv[1], "bliss_bac")) rc |= gen_bliss_bac(argv[2]);
     if (all || !strcmp(argv[1], "huff_rows")) rc |= gen_huff_rows(argv[2]);

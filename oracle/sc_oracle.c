@@ -299,6 +299,40 @@ int32_t orc_cdt_sample(uint64_t x, const uint64_t *cdf, int size)
     return (x & 1) ? (int32_t)a : -(int32_t)a;
 }
 
+/* the sampler at 32-bit precision: gaussian_cdf_create_32 (gaussian_cdf.c:683-740) - the same recurrence with FLOAT (float) accumulators: d, e and the
+ * running sum s are floats, the constants doubles, expl() long double, every assignment rounds to float - and gaussian_cdf_sample_32 / binary_search_32
+ * (:661-681, 765-774): one 32-bit word per sample, "entry < word", the sign from the word's bit 0 */
+int orc_cdt32_create(float tail, float sigma, uint32_t *cdf, int size)
+{
+    (void)tail;
+    float s, d, e;
+    d = 1.12837916709551257390 * 0.70710678118654752440 * 4294967296.0 / sigma;   /* M_2_SQRTPI * M_SQRT1_2 * 4294967296.0 / sigma */
+    e = -0.5L / (sigma * sigma);
+    s = 0.5L * d;
+    int i;
+    cdf[0] = 0;
+    for (i = 1; i < size - 1; i++) {
+        cdf[i] = s;
+        if (cdf[i] == 0) break;
+        s += d * expl(e * ((float)(i * i)));
+    }
+    for (; i < size; i++) cdf[i] = 0xFFFFFFFFu;
+    return 0;
+}
+int32_t orc_cdt32_sample(uint32_t x, const uint32_t *cdf, int size)
+{
+    uint32_t a = 0;
+    for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) {
+        uint32_t b = a + st;
+        if (b < (uint32_t)size && cdf[b] < x) a = b;
+    }
+    return (x & 1) ? (int32_t)a : -(int32_t)a;
+}
+void orc_cdt32_sample_vector(int32_t *v, size_t n, const uint32_t *x, const uint32_t *cdf, int size, int32_t centre)
+{
+    for (size_t i = 0; i < n; i++) v[i] = orc_cdt32_sample(x[i], cdf, size) + centre;
+}
+
 /* sampling.c:211-228 with discard == 0: sequential fill, v[i] = sample + centre */
 void orc_cdt_sample_vector(int32_t *v, size_t n, const uint64_t *x, const uint64_t *cdf, int size, int32_t centre)
 {

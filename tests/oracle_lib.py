@@ -9,6 +9,7 @@ _LIB = None
 
 i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags='C_CONTIGUOUS')
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags='C_CONTIGUOUS')
+u32p_g = np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS')
 
 
 def lib():
@@ -52,6 +53,8 @@ def lib():
         L.orc_cdt_bits.restype = C.c_int
         L.orc_cdt_bits.argtypes = [C.c_float, C.c_float]
         L.orc_cdt_create.argtypes = [C.c_float, C.c_float, u64p, C.c_int]
+        L.orc_cdt32_create.argtypes = [C.c_float, C.c_float, u32p_g, C.c_int]
+        L.orc_cdt32_sample_vector.argtypes = [i32p, C.c_size_t, u32p_g, u32p_g, C.c_int, C.c_int32]
         L.orc_cdt_sample.restype = C.c_int32
         L.orc_cdt_sample.argtypes = [C.c_uint64, u64p, C.c_int]
         L.orc_cdt_sample_vector.argtypes = [i32p, C.c_size_t, u64p, u64p, C.c_int, C.c_int32]
@@ -397,6 +400,21 @@ def cdt_table(tail, sigma):
     cdf = np.zeros(1 << bits, dtype=np.uint64)
     lib().orc_cdt_create(tail, sigma, cdf, 1 << bits)
     return cdf
+
+
+def cdt32_table(tail, sigma):
+    """gaussian_cdf_create_32 restated (float accumulators)"""
+    bits = lib().orc_cdt_bits(tail, sigma)
+    cdf = np.zeros(1 << bits, dtype=np.uint32)
+    lib().orc_cdt32_create(tail, sigma, cdf, 1 << bits)
+    return cdf
+
+
+def cdt32_sample(x, cdf, centre=0):
+    x = np.ascontiguousarray(x, dtype=np.uint32); cdf = np.ascontiguousarray(cdf, dtype=np.uint32)
+    v = np.empty(x.size, dtype=np.int32)
+    lib().orc_cdt32_sample_vector(v, x.size, x, cdf, cdf.size, centre)
+    return v
 
 
 def cdt_sample(x, cdf, centre=0):

@@ -65,6 +65,33 @@ def test_table_vs_same_host_reference(eng, tag, tail, sigma, tmp_path):
     s.close()
 
 
+@pytest.mark.parametrize('tag,tail,sigma', CASES)
+def test_32_bit_precision_sampler(eng, tag, tail, sigma):
+    """create_sampler(..., SAMPLING_32BIT, ...): the reference's 32-bit table uploaded as is gives its samples bit for bit; the table the engine builds equals
+    the oracle's on this host; a large ragged batch with the edge words against the oracle's search; the two precisions' handles do not mix"""
+    import torch
+    G = load_golden('cdt32_ref.txt')
+    tab = (np.asarray(G[f'{tag}_tab32']).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    u = (np.asarray(G[f'{tag}_words32']).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    s = eng.sampler32(table=tab)
+    du = torch.from_numpy(u.view(np.int32)).cuda()
+    assert np.array_equal(s.sample(du).cpu().numpy(), G[f'{tag}_samples'])
+    assert np.array_equal(s.sample(du, centre=-3).cpu().numpy(), G[f'{tag}_samples'] - 3)
+    assert np.array_equal(s.table(), tab)
+    rng = np.random.default_rng(32)
+    big = rng.integers(0, 2**32, size=1_000_003, dtype=np.uint64).astype(np.uint32)
+    edges = np.array([0, 1, 2**32 - 1, 2**32 - 2] + [int(tab[i]) + d for i in (1, 2, tab.size // 2, tab.size - 2) for d in (-1, 0, 1) if 0 <= int(tab[i]) + d < 2**32], dtype=np.uint32)
+    big[:edges.size] = edges
+    got = s.sample(torch.from_numpy(big.view(np.int32)).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.cdt32_sample(big, tab))
+    w64 = torch.zeros(8, dtype=torch.int64, device='cuda'); o = torch.zeros(8, dtype=torch.int32, device='cuda')
+    assert eng.L.sc_hip_cdt_sample(s.h, 8, w64.data_ptr(), 0, o.data_ptr(), None) != 0      # a 32-bit handle refuses the 64-bit entry
+    s.close()
+    s2 = eng.sampler32(tail, sigma)
+    assert np.array_equal(s2.table(), O.cdt32_table(tail, sigma))
+    s2.close()
+
+
 def test_large_batch_vs_oracle_and_edges(eng):
     import torch
     tail, sigma = 13.42, 215.0

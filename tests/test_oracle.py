@@ -109,6 +109,29 @@ def test_sparse_mult_matches_dense():
     assert np.array_equal(np.mod(-v.astype(np.int64), q), d)
 
 
+@pytest.mark.parametrize('tag,tail,sigma', [('bliss1_s215_t13.42', 13.42, 215.0), ('unit_s100_t12', 12.0, 100.0), ('leaf_s1.7_t10', 10.0, 1.7)])
+def test_cdt32_table_and_samples_vs_reference(tag, tail, sigma):
+    """the sampler at 32-bit precision (create_sampler(..., SAMPLING_32BIT, ...): tests/golden/cdt32_ref.txt made by ref_driver cdt32): the table - float
+    accumulators, so whatever the host's expl() does in its last bit is rounded away in all but rare entries - and (table, 32-bit word) -> sample"""
+    G = load_golden('cdt32_ref.txt')
+    want = np.asarray(G[f'{tag}_tab32']).astype(np.int64) & 0xFFFFFFFF
+    cdf = O.cdt32_table(tail, sigma)
+    assert np.abs(cdf.astype(np.int64) - want).max() <= 256          # one unit of a float's last place near 2^32
+    ref_drv = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle', '_ref', 'ref_driver')
+    if os.path.exists(ref_drv):       # the reference itself, re-run on this host: exact
+        import subprocess, tempfile
+        with tempfile.TemporaryDirectory() as d:
+            subprocess.check_call([ref_drv, 'cdt32', d])
+            live = load_golden(os.path.join(d, 'cdt32_ref.txt'))
+        assert np.array_equal(cdf.astype(np.int64), np.asarray(live[f'{tag}_tab32']).astype(np.int64) & 0xFFFFFFFF)
+    tab = want.astype(np.uint32)
+    assert tab[0] == 0 and tab[-1] == 0xFFFFFFFF and np.all(np.diff(tab.astype(np.int64)) >= 0)
+    u = (np.asarray(G[f'{tag}_words32']).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+    v = O.cdt32_sample(u, tab)
+    assert np.array_equal(v, G[f'{tag}_samples'])
+    assert np.abs(v).max() < tab.size
+
+
 @pytest.mark.parametrize('tag,tail,sigma', [('bliss1_s215_t13.42', 13.42, 215.0), ('unit_s100_t12', 12.0, 100.0),
                                             ('leaf_s1.7_t10', 10.0, 1.7)])
 def test_cdt_table_and_samples_vs_reference(tag, tail, sigma):
