@@ -77,6 +77,13 @@ def main():
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
         made = 1
+        if os.environ.get('SC_BENCH_FALCON_VARIANT'):              # measurement only: "spw|nw<<8,lm" for sc_hip_falcon_set_variant (include/sc_hip_bench.h)
+            sp, lm = (int(x, 0) for x in os.environ['SC_BENCH_FALCON_VARIANT'].split(','))
+            f.set_variant(sp, lm)
+        if os.environ.get('SC_BENCH_BATCH'):
+            B = int(os.environ['SC_BENCH_BATCH'])
+            msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+            tapes = torch.randint(-2**31, 2**31 - 1, (B, 4 * f.n), dtype=torch.int32, device='cuda', generator=g)
         if leg == 'falcon_sign':
             f.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
             fn = lambda: f.sign(msgs, tapes, fixed_len=64)
