@@ -63,7 +63,7 @@ struct Sampler {
 };
 
 // n Gaussian samples of one polynomial, drawn into the round-0 layout (register r of lane lp = coefficient r*LP + lp), as
-// residues in [0, q).  w: the lane's 16 draws (two tape words each, high word first: prng_64, prng.c:963-978).
+// residues in [0, q] (a zero with the sign bit clear comes out as q).  w: the lane's 16 draws (two tape words each, high word first: prng_64, prng.c:963-978).
 __device__ __forceinline__ void sample_regs(uint32_t (&x)[16], const uint2 (&w)[16], const Sampler &S, uint32_t q)
 {
     uint32_t widest = 0;
@@ -76,12 +76,22 @@ __device__ __forceinline__ void sample_regs(uint32_t (&x)[16], const uint2 (&w)[
         for (int e = 0; e < 4; e++) g[e] = S.guide[w[c + e].x >> 20];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            const uint64_t u = ((uint64_t)w[c + e].x << 32) | w[c + e].y;
             const uint32_t lo = g[e] & 0xffu;
-            const uint32_t a = lo + (uint32_t)(S.tab[lo + 1] < u) + (uint32_t)(S.tab[lo + 2] < u);
+            // a = lo + [tab[lo+1] < u] + [tab[lo+2] < u] as two borrow chains that end in an add-with-carry (six plain add-class instructions; measured 2 % on the kernel), and
+            // the draw's words stay where the load put them (a 64-bit compare wants them swapped into an aligned pair: two moves per draw)
+            const uint2 t1 = *reinterpret_cast<const uint2 *>(S.tab + lo + 1), t2 = *reinterpret_cast<const uint2 *>(S.tab + lo + 2);
+            uint32_t a, scratch;
+            asm("v_sub_co_u32 %1, vcc, %3, %7\n\t"
+                "v_subb_co_u32 %1, vcc, %4, %8, vcc\n\t"
+                "v_addc_co_u32 %0, vcc, 0, %2, vcc\n\t"
+                "v_sub_co_u32 %1, vcc, %5, %7\n\t"
+                "v_subb_co_u32 %1, vcc, %6, %8, vcc\n\t"
+                "v_addc_co_u32 %0, vcc, 0, %0, vcc"
+                : "=&v"(a), "=&v"(scratch)
+                : "v"(lo), "v"(t1.x), "v"(t1.y), "v"(t2.x), "v"(t2.y), "v"(w[c + e].y), "v"(w[c + e].x)
+                : "vcc");
             widest = max(widest, g[e]);
-            const int32_t s = (w[c + e].y & 1u) ? (int32_t)a : -(int32_t)a;
-            x[c + e] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+            x[c + e] = (w[c + e].y & 1u) ? a : q - a;                                  // +a or -a as a residue in [0, q] (q itself stands for 0: the transforms take [0, 2q))
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -91,9 +101,8 @@ __device__ __forceinline__ void sample_regs(uint32_t (&x)[16], const uint2 (&w)[
             const uint32_t g = S.guide[w[r].x >> 20], lo = g & 0xffu, cnt = g >> 8;
             if (cnt > 2) {
                 const uint64_t u = ((uint64_t)w[r].x << 32) | w[r].y;
-                const int32_t a = S.wide(u, lo, lo + cnt);
-                const int32_t s = (w[r].y & 1u) ? a : -a;
-                x[r] = (uint32_t)(s + ((s >> 31) & (int32_t)q));
+                const uint32_t a = (uint32_t)S.wide(u, lo, lo + cnt);
+                x[r] = (w[r].y & 1u) ? a : q - a;
             }
         }
     }
@@ -111,20 +120,42 @@ __device__ __forceinline__ void load_draws(uint2 (&w)[16], const uint32_t *words
 __device__ __forceinline__ uint32_t canon(uint32_t v, const ModK &k)               // any value below 2^23 -> [0, q)
 { return csub(Mod<MODE_MAD>::mulc(v, 1u, k.one_p, k), k.q); }
 
-// Pack one polynomial staged in LDS (natural index order, canonical values) as QB-bit big-endian fields into `dst` (4-byte
-// aligned).  Word w takes bits [32w, 32w+32) of the stream: at most four consecutive coefficients.
-template <int N, int LP, int QB>
-__device__ __forceinline__ void pack_poly(const uint32_t *stage, uint8_t *dst, bool valid, int lp)
+// Bit packing of the ciphertext (QB-bit big-endian fields).  The bit pattern repeats every lcm(32, QB) bits: a GROUP of CW = 32 / gcd coefficients
+// fills GW = QB / gcd whole words (13 bits: 32 coefficients -> 13 words; 14 bits: 16 -> 7), so a lane that packs one group does it with
+// compile-time shifts (3-4 shift-or steps and a byte swap per word) instead of a variable 64-bit window per word.  The polynomial is staged
+// in LDS in natural order with the 16-byte chunks of a group XOR-rotated (pk_pos) so that 16 neighbouring lanes, each reading its own
+// group with 16-byte reads, hit distinct banks.
+template <int QB> struct Pk {
+    static constexpr int G = (QB % 2) ? 1 : ((QB % 4) ? 2 : ((QB % 8) ? 4 : 8));   // gcd(32, QB) for QB <= 16
+    static constexpr int CW = 32 / G, GW = QB / G;
+    static_assert(CW == 32 || CW == 16, "group shapes of the two parameter sets");
+    static __host__ __device__ constexpr int rot(int g) { return CW == 32 ? (g & 7) : ((g >> 2) & 3); }
+    static __host__ __device__ constexpr int pos(int j) { return j ^ (rot(j / CW) << 2); }       // LDS word of coefficient j
+};
+
+// group g of the polynomial staged at `stage` -> GW words at dst32 + g * GW
+template <int QB>
+__device__ __forceinline__ void pack_group(const uint32_t *stage, uint32_t *dst32, bool valid, int g)
 {
-    constexpr int WORDS = N * QB / 32;
-    static_assert(N * QB % 32 == 0 && 3 * QB >= 31 && QB <= 16, "packing window");
-    for (int w = lp; w < WORDS; w += LP) {
-        const int i0 = (32 * w) / QB, o = 32 * w - i0 * QB;
-        uint64_t acc = 0;
+    using P = Pk<QB>;
+    constexpr int CW = P::CW, GW = P::GW;
+    uint32_t c[CW];
+    const int rot = P::rot(g);
 #pragma unroll
-        for (int t = 0; t < 4; t++) acc = (acc << QB) | (uint64_t)((i0 + t < N) ? stage[i0 + t] : 0u);
-        const uint32_t v = (uint32_t)(acc >> (4 * QB - o - 32));
-        if (valid) reinterpret_cast<uint32_t *>(dst)[w] = __builtin_bswap32(v);
+    for (int c4 = 0; c4 < CW / 4; c4++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(stage + g * CW + ((c4 ^ rot) << 2));
+        c[4 * c4] = v.x; c[4 * c4 + 1] = v.y; c[4 * c4 + 2] = v.z; c[4 * c4 + 3] = v.w;
+    }
+    uint32_t *out = dst32 + g * GW;
+#pragma unroll
+    for (int w = 0; w < GW; w++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = (32 * w) / QB; i < CW && QB * i < 32 * (w + 1); i++) {
+            const int sh = 32 * (w + 1) - QB * (i + 1);              // where coefficient i's lowest bit falls in word w (bit 0 = the word's last stream bit)
+            v |= sh >= 0 ? c[i] << (sh & 31) : c[i] >> ((-sh) & 31);
+        }
+        if (valid) out[w] = __builtin_bswap32(v);
     }
 }
 
@@ -155,7 +186,7 @@ __device__ __forceinline__ void pack_poly(const uint32_t *stage, uint8_t *dst, b
 // are parked as one packed word per coefficient in a lane-private LDS slot while e2 is sampled and transformed, and only one
 // polynomial's draws are held at a time, so two waves fit a SIMD without spills for both n.
 #ifndef RL_ENC_WAVES
-#define RL_ENC_WAVES(L) 2            /* measured: 3 waves (168 registers) spills and is 20-30% slower */
+#define RL_ENC_WAVES(L) ((L) == 8 ? 3 : 2)   /* n = 256: 168 registers (a handful of spills) and three waves are 5-6 % faster than 181 and two; n = 512 needs 194 and gains nothing from three */
 #endif
 template <int L, int QB>
 __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlArgs a)
@@ -166,14 +197,65 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
     __shared__ uint32_t s_park[4][16 * 64];                                 // per wave: slot r*64 + lane
     __shared__ uint32_t s_msg[4][N / 8];                                    // per wave: PW messages of N/32 words
     for (int i = threadIdx.x; i < 2 * N; i += blockDim.x) s_keys[i] = a.key_a[i];
+    // Per-lane twiddles (rounds 1, 2) live in LDS, one row per lane-in-polynomial, and are fetched into registers for the duration of
+    // one transform: held for the whole loop they are 45 (n = 256) / 69 (n = 512) registers that decide between two and three waves
+    // per SIMD.  Row: forward round 1 | inverse round 1 | its companions [| the 8 + 8 + 8 of round 2]; a stride of 4 * odd words keeps the
+    // 16-byte reads of 16 neighbouring rows on distinct banks.
+    constexpr int TWS = (Y::NR == 3 ? 72 : 48) + 4;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tw[LP * TWS];
+    TwSet<L> twf, twi;                                                      // round 0 (lane-invariant, scalar registers) stays here
+    {
+        TwSet<L> f, i;
+        f.load(a.zf, a.zfp, lp);
+        i.load(a.zi, a.zip, lp);
+        if (threadIdx.x < LP) {
+            uint32_t *row = s_tw + lp * TWS;
+#pragma unroll
+            for (int j = 0; j < 15; j++) { row[j] = f.t1[j]; row[16 + j] = i.t1[j]; row[32 + j] = i.t1p[j]; }
+            if constexpr (Y::NR == 3) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) { row[48 + j] = f.t2[7 + j]; row[56 + j] = i.t2[7 + j]; row[64 + j] = i.t2p[7 + j]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 15; j++) { twf.t0[j] = f.t0[j]; twf.t0p[j] = f.t0p[j]; twi.t0[j] = i.t0[j]; twi.t0p[j] = i.t0p[j]; }
+    }
     __syncthreads();
-    TwSet<L> twf, twi;
-    twf.load(a.zf, a.zfp, lp);
-    twi.load(a.zi, a.zip, lp);
+    auto fetch15 = [](uint32_t (&d)[15], const uint32_t *src) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[c];
+            d[4 * c] = v.x; d[4 * c + 1] = v.y; d[4 * c + 2] = v.z;
+            if (c < 3) d[4 * c + 3] = v.w;
+        }
+    };
+    auto fetch8 = [](uint32_t (&d)[15], const uint32_t *src) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint4 v = reinterpret_cast<const uint4 *>(src)[c];
+            d[7 + 4 * c] = v.x; d[8 + 4 * c] = v.y; d[9 + 4 * c] = v.z; d[10 + 4 * c] = v.w;
+        }
+    };
+    // the row offset goes through an empty asm so that the reads are not hoisted out of the loop (back into 45-69 resident registers)
+    auto tw_fwd = [&]() {
+        int off = lp * TWS;
+        asm volatile("" : "+v"(off));
+        fetch15(twf.t1, s_tw + off);
+        if constexpr (Y::NR == 3) fetch8(twf.t2, s_tw + off + 48);
+    };
+    auto tw_inv = [&]() {
+        int off = lp * TWS;
+        asm volatile("" : "+v"(off));
+        fetch15(twi.t1, s_tw + off + 16);
+        fetch15(twi.t1p, s_tw + off + 32);
+        if constexpr (Y::NR == 3) { fetch8(twi.t2, s_tw + off + 56); fetch8(twi.t2p, s_tw + off + 64); }
+    };
     unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
     if (g >= groups) return;
     uint8_t *msg_lds = reinterpret_cast<uint8_t *>(&s_msg[wid][pw * (N / 32)]);
     uint32_t *park = &s_park[wid][lane];
+    using PK = Pk<QB>;
+    uint32_t *c1_stage = &s_park[wid][pw * N];
     uint2 wn[16];
     {
         const unsigned long long item = g * PW + pw;
@@ -188,6 +270,7 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         sample_regs(x, wn, S, k.q);
         load_draws<LP>(wn, tape + 2 * N, lp);
         const uint32_t mword = reinterpret_cast<const uint32_t *>(a.msgs_in + (valid ? (size_t)item * a.msg_stride : 0))[lp & (N / 32 - 1)];
+        tw_fwd();
         fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
         {
             const uint4 *pa = reinterpret_cast<const uint4 *>(s_keys + lp * 16), *pp = reinterpret_cast<const uint4 *>(s_keys + N + lp * 16);
@@ -203,6 +286,7 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         // c1 = a o NTT(e1) + NTT(e2), NTT domain, canonical (:593-602); e3's draws in flight
         sample_regs(x, wn, S, k.q);
         load_draws<LP>(wn, tape + 4 * N, lp);
+        tw_fwd();
         fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
         uint8_t *ct = a.ct_out + (valid ? (size_t)item * a.ct_stride : 0);
         uint32_t t2[16];
@@ -211,12 +295,14 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         for (int r = 0; r < 16; r++) {
             const uint32_t pk = park[r * 64];
             t2[r] = pk >> 16;
-            lds_poly[brv4(r) * LP + blp] = canon((pk & 0xffffu) + x[r], k);       // engine position lp*16 + r = natural index brv4(r)*LP + blp
+            x[r] = canon((pk & 0xffffu) + x[r], k);
         }
         wave_lds_fence();
-        pack_poly<N, LP, QB>(lds_poly, ct, valid, lp);
-        wave_lds_fence();
+        // c1 is staged where the products were parked (the wave's 4 KB, one polynomial image per block) and packed together with c2 at the end
+#pragma unroll
+        for (int r = 0; r < 16; r++) c1_stage[PK::pos(brv4(r) * LP + blp)] = x[r];    // engine position lp*16 + r = natural index brv4(r)*LP + blp
         // c2 = INTT(p o NTT(e1)) + Encode(m) + e3 (:604-609); the next group's e1 draws in flight
+        tw_inv();
         inv_core<L, MODE_MAD>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
         sample_regs(x, wn, S, k.q);
         {
@@ -230,10 +316,19 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         for (int r = 0; r < 16; r++) {
             const int j = r * LP + lp;
             const uint32_t bit = ((uint32_t)msg_lds[j >> 3] >> (7 - (j & 7))) & 1u;
-            lds_poly[j] = csub(csub(t2[r] + x[r] + bit * (uint32_t)a.m_scale, k.q2), k.q);     // < q + q + m_scale < 4q
+            lds_poly[PK::pos(j)] = csub(csub(t2[r] + x[r] + bit * (uint32_t)a.m_scale, k.q2), k.q);     // < q + q + 1 + m_scale < 4q
         }
         wave_lds_fence();
-        pack_poly<N, LP, QB>(lds_poly, ct + N * QB / 8, valid, lp);
+        // both polynomials' groups over the block's lanes: 2 * 8 groups on 16 lanes (n = 256, 13 bits), 2 * 32 on 32 lanes in two passes (n = 512, 14 bits)
+        constexpr int GP = N / PK::CW;
+        if constexpr (2 * GP == LP) {
+            const bool second = lp >= GP;
+            pack_group<QB>(second ? lds_poly : c1_stage, reinterpret_cast<uint32_t *>(ct + (second ? N * QB / 8 : 0)), valid, lp & (GP - 1));
+        } else {
+            static_assert(GP == LP, "one group per lane and polynomial");
+            pack_group<QB>(c1_stage, reinterpret_cast<uint32_t *>(ct), valid, lp);
+            pack_group<QB>(lds_poly, reinterpret_cast<uint32_t *>(ct + N * QB / 8), valid, lp);
+        }
         wave_lds_fence();
     }
 }
