@@ -49,6 +49,10 @@ int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *h, unsigned long long
 /* the same for a Falcon handle: the sampler's working polynomials (6n doubles per signature) and the lattice point s1 | s2 before packing */
 int sc_hip_falcon_workspace_residue(sc_hip_falcon_t *h, unsigned long long *nonzero_words);
 
+/* test hook: arithmetic of the RLWE-Enc encrypt kernel - 0 automatic (the signed small-modulus mode where the plan qualifies, as for both of the
+ * reference's parameter sets), 3 the unsigned multiply-add mode every q below 2^14 takes.  Results are identical; the tests run both. */
+int sc_hip_rlwe_set_arith(sc_hip_rlwe_t *h, int mode);
+
 /* process-wide: on = 0 stops the library from registering (pinning) caller memory in its host-buffer entries - every transfer then takes the
  * runtime's staged path; 1 (default) registers the whole pages inside the caller's buffers; 2 registers the caller's ranges as they are, edge pages
  * included (what round 2 did).  For bisecting transfer problems (profiles/r03_host_pin_bisect.txt). */

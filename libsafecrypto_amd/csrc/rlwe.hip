@@ -18,6 +18,7 @@
 // a guide-table search (64-entry table + 4096-entry guide in LDS, see Sampler below).
 #include "engine_internal.h"
 #include "ntt_core.h"
+#include "../../include/sc_hip_bench.h"
 
 #include <string.h>
 
@@ -33,6 +34,8 @@ struct RlArgs {
     const uint32_t *zf, *zfp, *zi, *zip;
     ModK k;
     uint32_t c0, c0p, c1, c1p;              // n^-1 and zeta[1]^-1 n^-1 (Shoup pairs)
+    const uint32_t *szf, *szi, *szip;        // the signed small-modulus mode's tables (centred twiddles, signed companions) when the plan has them
+    uint32_t sc0, sc0p, sc1, sc1p;           // and its scale constants
     const uint64_t *cdf; const uint16_t *guide; int tab_size;
     const uint32_t *key_a, *key_p, *key_r2; // NTT domain, engine order (position lp*16 + r holds index bitrev(lp*16 + r)), canonical
     unsigned long long batch;
@@ -188,10 +191,13 @@ __device__ __forceinline__ void pack_group(const uint32_t *stage, uint32_t *dst3
 #ifndef RL_ENC_WAVES
 #define RL_ENC_WAVES(L) ((L) == 8 ? 3 : 2)   /* n = 256: 168 registers (a handful of spills) and three waves are 5-6 % faster than 181 and two; n = 512 needs 194 and gains nothing from three */
 #endif
-template <int L, int QB>
+// MODE: MODE_SMAD (signed lazy residues, modarith.h: a butterfly is one instruction shorter in both directions) where the plan qualifies - both of the
+// reference's parameter sets do - and MODE_MAD for any other q below 2^14.
+template <int L, int QB, int MODE>
 __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlArgs a)
 {
     RL_PROLOGUE
+    constexpr bool SM = MODE == MODE_SMAD;
     RL_TABLES
     __shared__ __attribute__((aligned(16))) uint32_t s_keys[2 * N];       // a | p, engine order
     __shared__ uint32_t s_park[4][16 * 64];                                 // per wave: slot r*64 + lane
@@ -206,8 +212,8 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
     TwSet<L> twf, twi;                                                      // round 0 (lane-invariant, scalar registers) stays here
     {
         TwSet<L> f, i;
-        f.load(a.zf, a.zfp, lp);
-        i.load(a.zi, a.zip, lp);
+        f.load(SM ? a.szf : a.zf, SM ? a.szf : a.zfp, lp);           // (neither mode's forward butterflies use companions)
+        i.load(SM ? a.szi : a.zi, SM ? a.szip : a.zip, lp);
         if (threadIdx.x < LP) {
             uint32_t *row = s_tw + lp * TWS;
 #pragma unroll
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         load_draws<LP>(wn, tape + 2 * N, lp);
         const uint32_t mword = reinterpret_cast<const uint32_t *>(a.msgs_in + (valid ? (size_t)item * a.msg_stride : 0))[lp & (N / 32 - 1)];
         tw_fwd();
-        fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
+        fwd_core<L, MODE, true>(x, twf, lds_poly, lp, k);
         {
             const uint4 *pa = reinterpret_cast<const uint4 *>(s_keys + lp * 16), *pp = reinterpret_cast<const uint4 *>(s_keys + N + lp * 16);
 #pragma unroll
@@ -279,23 +285,35 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
                 const uint4 va = pa[c], vp = pp[c];
                 const uint32_t ka[4] = { va.x, va.y, va.z, va.w }, kp[4] = { vp.x, vp.y, vp.z, vp.w };
 #pragma unroll
-                for (int e = 0; e < 4; e++)                                         // x < 2q(L+1), key < q: products below 2^32
-                    park[(4 * c + e) * 64] = mulmod_small(x[4 * c + e], ka[e], k) | (mulmod_small(x[4 * c + e], kp[e], k) << 16);
+                for (int e = 0; e < 4; e++) {
+                    if constexpr (SM) {                                             // |x| < 18q (n = 256) or reduced to [-q, 2q) first, key < q: products below 2^31;
+                        const uint32_t xr = (L > 8) ? reduce_signed((int32_t)x[4 * c + e], k) : x[4 * c + e];      // both results in [-q, 2q): the first parked
+                        park[(4 * c + e) * 64] = (mulmod_ssmall(xr, ka[e], k) + k.q) | (mulmod_ssmall(xr, kp[e], k) << 16);   // biased by q (below 3q < 2^16), the second as int16
+                    } else                                                          // x < 2q(L+1), key < q: products below 2^32
+                        park[(4 * c + e) * 64] = mulmod_small(x[4 * c + e], ka[e], k) | (mulmod_small(x[4 * c + e], kp[e], k) << 16);
+                }
             }
         }
         // c1 = a o NTT(e1) + NTT(e2), NTT domain, canonical (:593-602); e3's draws in flight
         sample_regs(x, wn, S, k.q);
         load_draws<LP>(wn, tape + 4 * N, lp);
         tw_fwd();
-        fwd_core<L, MODE_MAD, true>(x, twf, lds_poly, lp, k);
+        fwd_core<L, MODE, true>(x, twf, lds_poly, lp, k);
         uint8_t *ct = a.ct_out + (valid ? (size_t)item * a.ct_stride : 0);
         uint32_t t2[16];
         wave_lds_fence();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t pk = park[r * 64];
-            t2[r] = pk >> 16;
-            x[r] = canon((pk & 0xffffu) + x[r], k);
+            if constexpr (SM) {
+                t2[r] = (uint32_t)((int32_t)pk >> 16);
+                uint32_t v = (pk & 0xffffu) + x[r] + 31u * k.q;                       // (a o E1 + q) + E2, |E2| < 2q(L+1) <= 20q: + 31q makes it positive, below 2^20
+                v += (uint32_t)mul_i24((int32_t)__umulhi(v, k.m32), -(int32_t)k.q);    // [0, 2q)
+                x[r] = csub(v, k.q);
+            } else {
+                t2[r] = pk >> 16;
+                x[r] = canon((pk & 0xffffu) + x[r], k);
+            }
         }
         wave_lds_fence();
         // c1 is staged where the products were parked (the wave's 4 KB, one polynomial image per block) and packed together with c2 at the end
@@ -303,7 +321,8 @@ __global__ __launch_bounds__(256, RL_ENC_WAVES(L)) void rlwe_encrypt_kernel(RlAr
         for (int r = 0; r < 16; r++) c1_stage[PK::pos(brv4(r) * LP + blp)] = x[r];    // engine position lp*16 + r = natural index brv4(r)*LP + blp
         // c2 = INTT(p o NTT(e1)) + Encode(m) + e3 (:604-609); the next group's e1 draws in flight
         tw_inv();
-        inv_core<L, MODE_MAD>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+        if constexpr (SM) inv_core<L, MODE>(t2, twi, lds_poly, lp, k, a.sc0, a.sc0p, a.sc1, a.sc1p);
+        else inv_core<L, MODE>(t2, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
         sample_regs(x, wn, S, k.q);
         {
             const unsigned long long ng = g + gstride, nitem = ng * PW + pw;
@@ -468,6 +487,7 @@ struct sc_hip_rlwe {
     uint32_t *d_keys;         // a | p | r2, engine order
     uint16_t *d_guide;        // 4096 entries: lo | cnt << 8 (see Sampler)
     bool have_pub, have_priv;
+    bool force_mad;           // sc_hip_rlwe_set_arith (test hook)
 };
 
 extern "C" void sc_hip_rlwe_destroy(sc_hip_rlwe_t *h)
@@ -564,6 +584,11 @@ static void rl_args(const sc_hip_rlwe *h, size_t batch, RlArgs &a)
     a.zf = p->d_tab[1]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.k = p->k[1];
     a.c0 = p->c_inv[1][0]; a.c0p = p->c_inv[1][1]; a.c1 = p->c_inv[1][2]; a.c1p = p->c_inv[1][3];
+    if (p->smad_ok) {
+        a.szf = p->d_tab_s; a.szi = p->d_tab_s + 2 * n; a.szip = p->d_tab_s + 3 * n;
+        const uint32_t *c = p->q < 8192 ? p->c_inv[1] : p->c_inv_s;          // as sc_hip.hip picks them for this mode (ntt_core.h gs_last_stage)
+        a.sc0 = c[0]; a.sc0p = c[1]; a.sc1 = c[2]; a.sc1p = c[3];
+    }
     a.cdf = h->cdt->d_cdf; a.guide = h->d_guide; a.tab_size = h->cdt->size;
     a.key_a = h->d_keys; a.key_p = h->d_keys + n; a.key_r2 = h->d_keys + 2 * n;
     a.batch = batch;
@@ -603,7 +628,16 @@ extern "C" int sc_hip_rlwe_encrypt(sc_hip_rlwe_t *h, size_t batch, const uint8_t
     HIPCHK(hipSetDevice(h->ctx->device));
     RlArgs a; rl_args(h, batch, a);
     a.msgs_in = d_msgs; a.msg_stride = msg_stride; a.tapes = d_tapes; a.tape_stride = tape_stride; a.ct_out = d_ct; a.ct_stride = ct_stride;
-    HIPCHK(h->P.n == 256 ? rl_launch(rlwe_encrypt_kernel<8, 13>, h, batch, a, stream) : rl_launch(rlwe_encrypt_kernel<9, 14>, h, batch, a, stream));
+    if (h->plan->smad_ok && !h->force_mad) HIPCHK(h->P.n == 256 ? rl_launch(rlwe_encrypt_kernel<8, 13, MODE_SMAD>, h, batch, a, stream) : rl_launch(rlwe_encrypt_kernel<9, 14, MODE_SMAD>, h, batch, a, stream));
+    else HIPCHK(h->P.n == 256 ? rl_launch(rlwe_encrypt_kernel<8, 13, MODE_MAD>, h, batch, a, stream) : rl_launch(rlwe_encrypt_kernel<9, 14, MODE_MAD>, h, batch, a, stream));
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_rlwe_set_arith(sc_hip_rlwe_t *h, int mode)
+{
+    if (!h) return fail("rlwe_set_arith: null handle");
+    if (mode != 0 && mode != MODE_MAD) return fail("rlwe_set_arith: mode must be 0 (automatic) or 3 (unsigned multiply-add)");
+    h->force_mad = mode == MODE_MAD;
     return SC_HIP_SUCCESS;
 }
 

@@ -49,7 +49,7 @@ SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('creat
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation']
+BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -164,6 +164,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_set_tie_margin.argtypes = [vp, C.c_double]
     L.sc_hip_bliss_set_speculation.argtypes = [vp, C.c_int]
+    L.sc_hip_rlwe_set_arith.argtypes = [vp, C.c_int]
     L.sc_hip_bliss_tape_words.argtypes = [C.c_int, C.c_uint]
     L.sc_hip_bliss_tape_words.restype = sz
     L.sc_hip_bliss_set_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
@@ -1365,6 +1366,10 @@ class Rlwe:
         r2 = np.ascontiguousarray(np.asarray(r2), dtype=np.int16)
         assert r2.size == self.n
         _chk(self.L, self.L.sc_hip_rlwe_set_privkey(self.h, _ptr(r2)), 'rlwe_set_privkey')
+
+    def set_arith(self, mode):
+        """test hook (sc_hip_bench.h): 0 automatic, 3 the unsigned multiply-add form of the encrypt kernel"""
+        _chk(self.L, self.L.sc_hip_rlwe_set_arith(self.h, int(mode)), 'rlwe_set_arith')
 
     def encrypt(self, msgs, tapes):
         """msgs uint8 [batch][n/8], tapes int32/uint32 [batch][>= 6n] (device) -> ciphertexts uint8 [batch][ct_bytes]"""

@@ -50,10 +50,12 @@ def test_keygen_reproduces_reference(eng, G, tag, nkeys, nmsg):
     r.close()
 
 
+@pytest.mark.parametrize('arith', [0, 3])          # automatic (signed small-modulus butterflies) / the unsigned multiply-add form
 @pytest.mark.parametrize('tag,nkeys,nmsg', CASES)
-def test_encrypt_decrypt_reproduce_reference(eng, G, tag, nkeys, nmsg):
+def test_encrypt_decrypt_reproduce_reference(eng, G, tag, nkeys, nmsg, arith):
     import torch
     r = eng.rlwe(G[f'{tag}_params'])
+    r.set_arith(arith)
     k = nkeys - 1
     r.set_pubkey(G[f'{tag}_kg_a{k}'], G[f'{tag}_kg_p{k}'])
     r.set_privkey(G[f'{tag}_kg_r2_{k}'])
@@ -73,12 +75,14 @@ def test_encrypt_decrypt_reproduce_reference(eng, G, tag, nkeys, nmsg):
     r.close()
 
 
+@pytest.mark.parametrize('arith', [0, 3])
 @pytest.mark.parametrize('tag,batch', [('rlwe0', 37), ('rlwe1', 21)])
-def test_seeded_batch_matches_oracle(eng, G, tag, batch):
+def test_seeded_batch_matches_oracle(eng, G, tag, batch, arith):
     """ragged batch (not a multiple of the messages per wavefront), padded strides, keys made on the device"""
     import torch
     R = O.Rlwe(G[f'{tag}_params'])
     r = eng.rlwe(G[f'{tag}_params'])
+    r.set_arith(arith)
     rng = np.random.default_rng(0x51e + batch)
     ktape = rng.integers(0, 1 << 32, size=(3, r.keygen_words + 6), dtype=np.uint64).astype(np.uint32)
     a, p, r2 = (x.cpu().numpy() for x in r.keygen(dev(ktape)))

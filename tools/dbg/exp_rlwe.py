@@ -14,6 +14,7 @@ def one(lib, tag, batch):
     G = load_golden('rlwe_ref.txt')
     eng = E.Engine(0)
     r = eng.rlwe(G[f'{tag}_params'])
+    r.set_arith(int(os.environ.get('RL_ARITH', '0')))
     r.set_pubkey(G[f'{tag}_kg_a0'], G[f'{tag}_kg_p0']); r.set_privkey(G[f'{tag}_kg_r2_0'])
     g = torch.Generator(device='cuda'); g.manual_seed(17)
     msgs = torch.randint(0, 256, (batch, r.msg_bytes), dtype=torch.uint8, device='cuda', generator=g)
