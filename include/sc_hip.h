@@ -554,7 +554,8 @@ int  sc_hip_ens_dlp_signer_set_key(sc_hip_ens_dlp_signer_t *h, const int32_t *b,
  * (gpv_expand_basis, modified_gram_schmidt_fast_flt, gpv_precompute_inv_flt: src/utils/arith/gpv.c:709-760, 1021-1117, 977-984), on the host at key load */
 int  sc_hip_ens_dlp_signer_set_privkey(sc_hip_ens_dlp_signer_t *h, const int32_t *fgFG);
 /* lanes per signature of Klein's sampler: 0 (default) chosen from the batch size; 1 = a lane per signature with the state in HBM, 4 / 8 / 16 = that
- * many lanes with the state in registers (>= n / 64).  Results are identical. */
+ * many lanes with the state in registers (>= n / 64); + 0x100 / + 0x200 pin the register form's table search (entries of the next row held across
+ * the sweep / fetched in their own step; default by batch size).  Results are identical. */
 int  sc_hip_ens_dlp_signer_set_mapping(sc_hip_ens_dlp_signer_t *h, int lanes);
 size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h);        /* n * q_bits / 8 */
 size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h);   /* 4n: one prng_64 per basis row */

@@ -1563,7 +1563,7 @@ __device__ __forceinline__ float chain_g(float acc, float p)
 
 constexpr int KW = 4;                      // wavefronts per workgroup: they share the LDS copy of the step's rows (loaded once, a quarter each)
 
-template <int G, int NCH>
+template <int G, int NCH, bool PF>
 __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
 {
     constexpr int n2 = NCH * G, n = n2 / 2, S = 16 / G;          // S signatures per DPP row
@@ -1600,6 +1600,32 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
     }
     uint64_t M = 0x7fffffffu >> 1;
     bool dead = false;
+    // The row's Gaussian draw depends on nothing the sweep computes.  PF: tape word and table entries of step j - 1 are requested at the top of step j
+    // and turned into the sample behind its sweep - fetched and searched at the top of their own step (the other form) they are two exposed memory
+    // round trips (the tape from HBM, the table from L2) at the head of every one of the 2n dependent steps.  The search is shared by the
+    // signature's G lanes: lane r compares entries r, r + G, ... (64 / G of them in registers; tables are padded with all-ones, and entry 0 is not
+    // part of the search: gaussian_cdf_sample_64 counts b >= 1), and three or four rotate-and-add steps within the DPP row leave the count in every
+    // lane.  The price is 2 * 64 / G + 2 registers held across the sweep (n = 512, 8 lanes: 165 -> 196, two wavefronts per SIMD instead of three);
+    // the host's choice between the forms, with the measurements behind it, is in sc_hip_ens_dlp_sig_sign.
+    constexpr int NE = 64 / G;
+    const uint32_t TS = 1u << A.ts_log;
+    auto ring_sum = [](uint32_t v) -> uint32_t {                  // row_ror by S, 2S, ... 8: every lane ends with the sum over its signature's G lanes
+        if constexpr (S <= 1) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, false);
+        if constexpr (S <= 2) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, false);
+        if constexpr (S <= 4) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);
+        v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);
+        return v;
+    };
+    uint2 wc = *reinterpret_cast<const uint2 *>(tape);              // step n2 - 1: first draw of the tape
+    float invc = A.inv[n2 - 1];
+    uint32_t ac = 0;
+    if constexpr (PF) {
+        const uint64_t x = ((uint64_t)wc.x << 32) | wc.y;
+        const uint64_t *__restrict__ cdf = A.tabs + ((size_t)(n2 - 1) << A.ts_log);
+        uint32_t cnt = 0;
+        for (uint32_t e = r; e < TS; e += G) cnt += (e != 0 && cdf[e] < x) ? 1u : 0u;
+        ac = ring_sum(cnt);
+    }
 #pragma unroll 1
     for (int j = n2 - 1; j >= 0; j--) {
         const int buf = j & 1;                                   // n2 - 1 is odd: the first step reads buffer 1
@@ -1607,14 +1633,25 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
         const size_t rb = (size_t)(j > 0 ? j - 1 : 0) * RV, rg = (size_t)(j > 1 ? j - 2 : 0) * RV;
 #pragma unroll
         for (int i = 0; i < NV; i++) { const uint32_t e = (tid + 64 * KW * i) % RV; pb[i] = bmat[rb + e]; pg[i] = gmat[rg + e]; }     // unconditional (wraps when RV < 256)
-        const float inv = A.inv[j];
+        const int jn = j > 0 ? j - 1 : 0;                        // the next step's draw (step 0 repeats its own: unused)
+        const uint64_t *__restrict__ cdfn = A.tabs + ((size_t)(PF ? jn : j) << A.ts_log);
+        uint2 wn;
+        uint64_t ce[NE];
+        if constexpr (PF) {
+            wn = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - jn));
+#pragma unroll
+            for (int i = 0; i < NE; i++) ce[i] = cdfn[(r + G * i) & (TS - 1)];
+        } else wc = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - j));
+        const float inv = invc;
+        invc = A.inv[jn];
         const float d = __shfl(dot, (int)(lane | (16 - S))) * inv * inv;
-        const uint2 w = *reinterpret_cast<const uint2 *>(tape + 2 * (size_t)(n2 - 1 - j));
-        const uint64_t x = ((uint64_t)w.x << 32) | w.y;
-        const uint64_t *__restrict__ cdf = A.tabs + ((size_t)j << A.ts_log);
-        const int size = (int)A.sizes[j];
-        uint32_t a = 0;
-        for (int e = 1; e < size; e++) a += (cdf[e] < x) ? 1u : 0u;
+        const uint64_t x = ((uint64_t)wc.x << 32) | wc.y;
+        if constexpr (!PF) {                                     // every lane walks the row's table, in its own step (no registers held across the sweep)
+            const int size = (int)A.sizes[j];
+            ac = 0;
+            for (int e = 1; e < size; e++) ac += (cdfn[e] < x) ? 1u : 0u;
+        }
+        const uint32_t a = ac;
         int32_t z = ((x & 1) ? (int32_t)a : -(int32_t)a) + (int32_t)d;
         const uint64_t az = (uint64_t)(z < 0 ? -(int64_t)z : (int64_t)z) * A.maxb;
         bool risky = !dead && M + az > 0x7fffffffull;
@@ -1634,6 +1671,15 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
         for (int c = 0; c < NCH; c++) {
             st[c] -= z * __float_as_int(brow[G * c]);
             dot = chain_g<G>(dot, (float)st[c] * grow[G * c]);
+        }
+        if constexpr (PF) {
+            const uint64_t xn = ((uint64_t)wn.x << 32) | wn.y;
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NE; i++) { const uint32_t e = r + G * i; cnt += (e != 0 && e < TS && ce[i] < xn) ? 1u : 0u; }
+            for (uint32_t e = 64 + r; e < TS; e += G) cnt += (cdfn[e] < xn) ? 1u : 0u;      // tables above 64 entries: the rest, fetched on the spot
+            ac = ring_sum(cnt);
+            wc = wn;
         }
 #pragma unroll
         for (int i = 0; i < NV; i++) {
@@ -2315,6 +2361,7 @@ struct sc_hip_ens_dlp_signer {
     int32_t *d_b; float *d_bgs, *d_inv; uint64_t *d_tabs; uint32_t *d_sizes; int ts_log; uint32_t maxb;
     sc::Workspace ws;
     int force_lanes;             // sc_hip_ens_dlp_signer_set_mapping: 0 = chosen from the batch size
+    int force_pf;                // the same hook: +1 / -1 pin the form of the table search (kleinr_kernel PF), 0 = chosen from the batch size
 };
 
 extern "C" int sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falcon_params_t *params, sc_hip_ens_dlp_signer_t **out)
@@ -2332,8 +2379,12 @@ extern "C" int sc_hip_ens_dlp_signer_create(sc_hip_ctx_t *ctx, const sc_hip_falc
 extern "C" int sc_hip_ens_dlp_signer_set_mapping(sc_hip_ens_dlp_signer_t *h, int lanes)
 {
     if (!h) return fail("ens_dlp_signer_set_mapping: null handle");
-    if (lanes != 0 && lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16) return fail("ens_dlp_signer_set_mapping: lanes must be 0 (default), 1, 4, 8 or 16");
+    const int form = lanes >> 8;                                 // + 0x100: table entries held across the sweep, + 0x200: fetched in their own step (0: by batch)
+    lanes &= 0xff;
+    if ((lanes != 0 && lanes != 1 && lanes != 4 && lanes != 8 && lanes != 16) || form < 0 || form > 2)
+        return fail("ens_dlp_signer_set_mapping: lanes must be 0 (default), 1, 4, 8 or 16, optionally + 0x100 / 0x200 for the form of the table search");
     h->force_lanes = lanes;
+    h->force_pf = form == 1 ? 1 : form == 2 ? -1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -2497,12 +2548,19 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     if ((h->force_lanes == 4 || h->force_lanes == 8 || h->force_lanes == 16) && h->force_lanes >= gmin) G = h->force_lanes;
     if (in_regs) {
         const dim3 grid((unsigned)((B / (64 / G) + KW - 1) / KW));
-        if (n == 256 && G == 4) hipLaunchKernelGGL((kleinr_kernel<4, 128>), grid, dim3(64 * KW), 0, s, A);
-        else if (n == 256 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 64>), grid, dim3(64 * KW), 0, s, A);
-        else if (n == 256) hipLaunchKernelGGL((kleinr_kernel<16, 32>), grid, dim3(64 * KW), 0, s, A);
-        else if (n == 512 && G == 8) hipLaunchKernelGGL((kleinr_kernel<8, 128>), grid, dim3(64 * KW), 0, s, A);
-        else if (n == 512) hipLaunchKernelGGL((kleinr_kernel<16, 64>), grid, dim3(64 * KW), 0, s, A);
-        else hipLaunchKernelGGL((kleinr_kernel<16, 128>), grid, dim3(64 * KW), 0, s, A);
+        // the next row's tape word and table entries held across the sweep (PF) - measured better everywhere (n = 256: 4.6 -> 6.0 M sign/s at 16384, 7.8 -> 9.0 M
+        // at 65536; n = 512: 0.45 -> 0.53 M at 4096; n = 1024: 261 -> 276 k at 16384) except n = 512 on 8 lanes with more than two wavefronts per SIMD to
+        // place, where its 196 registers (165 without) cost the third resident wavefront: 1.72 M against 2.11 M sign/s at 65536
+        const bool pf = h->force_pf ? h->force_pf > 0 : !(n == 512 && G == 8 && batch * (size_t)G / 64 > (size_t)h->ctx->cus * 4 * 2);
+#define SC_KLEIN(GG, NN) do { if (pf) hipLaunchKernelGGL((kleinr_kernel<GG, NN, true>), grid, dim3(64 * KW), 0, s, A); \
+                              else hipLaunchKernelGGL((kleinr_kernel<GG, NN, false>), grid, dim3(64 * KW), 0, s, A); } while (0)
+        if (n == 256 && G == 4) SC_KLEIN(4, 128);
+        else if (n == 256 && G == 8) SC_KLEIN(8, 64);
+        else if (n == 256) SC_KLEIN(16, 32);
+        else if (n == 512 && G == 8) SC_KLEIN(8, 128);
+        else if (n == 512) SC_KLEIN(16, 64);
+        else SC_KLEIN(16, 128);
+#undef SC_KLEIN
     }
     else hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
     HIPCHK(hipGetLastError());

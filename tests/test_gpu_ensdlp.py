@@ -68,7 +68,7 @@ def _rows(items, stride):
 
 
 @pytest.mark.parametrize('tag,nmsg', [('enssig0', 5), ('dlpsig1', 4), ('dlpsig0', 4), ('enssig1', 3)])
-@pytest.mark.parametrize("lanes", [1, 4, 8, 16, 0])
+@pytest.mark.parametrize("lanes", [1, 4, 8, 16, 0, 8 + 0x200, 16 + 0x200])      # + 0x200: the register form with the table fetched in its own step (the large-batch form)
 def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes):
     """sc_hip_ens_dlp_sig_sign (Klein's sampler) byte for byte against the reference's signatures given its PRNG word
     tape, and against the oracle on further seeded messages / tapes; batch 77 crosses a wavefront boundary with a ragged tail.  Both forms of the
@@ -79,7 +79,7 @@ def test_signatures_match_reference_and_oracle(eng, G, tag, nmsg, lanes):
     b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
     s = eng.ens_dlp_signer(par)
     s.set_key(b, bgs, inv)
-    if lanes and lanes != 1 and lanes < n // 64:
+    if lanes and lanes != 1 and (lanes & 0xff) < n // 64:
         pytest.skip('fewer lanes than n / 64 state registers allow')
     s.set_mapping(lanes)                                          # 1: a lane per signature, state in memory; 4 / 8 / 16 lanes: state in registers; 0: default
     assert s.tape_words == 4 * n and s.sig_bytes == n * int(par[2]) // 8
