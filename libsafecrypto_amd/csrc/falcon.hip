@@ -1542,9 +1542,8 @@ __global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
 // The production form: G lanes per signature, the sampler state held in REGISTERS.  The lane-per-signature kernel above needs 64 signatures per
 // wavefront (16384 signatures are 256 wavefronts on 1024 SIMDs) and streams the whole state through HBM once per basis row.  Here lane r of a
 // signature owns the elements k = r mod G: the update, the int -> float conversion and the product with the Gram-Schmidt row run G wide, and only
-// the ADDITIONS keep the reference's order - the running sum travels round the signature's lanes, lane r adding its product to what lane r-1 hands
-// it (v_add_f32 with a row_ror DPP operand, G dependent instructions per G elements; in the i-th of them lane i-1 holds the true partial sum, the
-// other lanes compute values nobody reads).  A lane's share of the 2n-word state is 2n/G = NCH words of registers, so the sweep touches no memory
+// the ADDITIONS keep the reference's order - one lane of the signature adds the G products of a group of elements one after the other (v_add_f32
+// with a row_ror DPP operand, G dependent instructions per G elements; chain_g below).  A lane's share of the 2n-word state is 2n/G = NCH words of registers, so the sweep touches no memory
 // of its own and only s1 is written at the end.  G = 16, 8 or 4: the lanes of a signature sit 16/G apart inside a DPP row (16/G signatures
 // interleaved per row, 64/G per wavefront) and the running sum moves with row_ror:(16/G), so each ring closes on itself.  The DPP
 // additions are the cost (every wavefront spends 2n of them per basis row whatever G is), so fewer lanes per signature = fewer wavefronts = less
@@ -1553,13 +1552,29 @@ __global__ __launch_bounds__(64) void klein_kernel(KleinArgs A)
 // step's rows with 16-byte loads at the top of a step, parks them in registers while the sweep runs out of LDS (a double buffer of 2 x 16n bytes
 // shared by the workgroup's four wavefronts, each fetching a quarter), and writes them to the other buffer afterwards - no load is waited on inside the sweep, which is fully unrolled (static
 // register indices).
+// Round 3: the running sum no longer travels.  It stays in the signature's LAST lane, which adds the products of lanes 0, 1, ..., G-1 in that order,
+// each fetched with a row_ror by the distance to its owner (the DPP operand is the product, computed well ahead, not the sum): the same additions
+// in the same order in that lane - the other lanes add rotated copies nobody reads - but the dependent operand of every addition is a plain
+// register.  With the sum as the DPP operand every one of the 2n additions per row waited out the two wait states a DPP read of a just-written
+// register needs (an s_nop between any two of them: ~15 cycles per addition for a lone wavefront, ~5 now).
+// Written as one block of assembly per product: left to itself the compiler computes all G - 1 rotated copies of every product ahead of the chain
+// (v_mov_b32_dpp into registers of their own - several hundred spills) instead of folding each rotation into its addition.  The s_nop covers the two
+// wait states between the instruction that produced p and the first DPP read of it (the compiler does not look inside the block).
+#define SC_ROR_ADD(n) "v_add_f32_dpp %0, %1, %0 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
 template <int G>
 __device__ __forceinline__ float chain_g(float acc, float p)
 {
-#pragma unroll
-    for (int i = 0; i < G; i++) acc = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), 0x120 + 16 / G, 0xF, 0xF, false)) + p;
-    return acc;                                                  // in the signature's last lane: acc_in(last lane) + p[0] + ... + p[G-1], left to right
+    static_assert(G == 4 || G == 8 || G == 16, "lanes per signature");
+    if constexpr (G == 4)
+        asm("s_nop 1\n\t" SC_ROR_ADD(12) SC_ROR_ADD(8) SC_ROR_ADD(4) "v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    else if constexpr (G == 8)
+        asm("s_nop 1\n\t" SC_ROR_ADD(14) SC_ROR_ADD(12) SC_ROR_ADD(10) SC_ROR_ADD(8) SC_ROR_ADD(6) SC_ROR_ADD(4) SC_ROR_ADD(2) "v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    else
+        asm("s_nop 1\n\t" SC_ROR_ADD(15) SC_ROR_ADD(14) SC_ROR_ADD(13) SC_ROR_ADD(12) SC_ROR_ADD(11) SC_ROR_ADD(10) SC_ROR_ADD(9) SC_ROR_ADD(8) SC_ROR_ADD(7) SC_ROR_ADD(6)
+            SC_ROR_ADD(5) SC_ROR_ADD(4) SC_ROR_ADD(3) SC_ROR_ADD(2) SC_ROR_ADD(1) "v_add_f32 %0, %0, %1" : "+v"(acc) : "v"(p));
+    return acc;                                                  // in the signature's last lane: acc_in + p[0] + ... + p[G-1], left to right
 }
+#undef SC_ROR_ADD
 
 constexpr int KW = 4;                      // wavefronts per workgroup: they share the LDS copy of the step's rows (loaded once, a quarter each)
 
@@ -1605,8 +1620,8 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
     // round trips (the tape from HBM, the table from L2) at the head of every one of the 2n dependent steps.  The search is shared by the
     // signature's G lanes: lane r compares entries r, r + G, ... (64 / G of them in registers; tables are padded with all-ones, and entry 0 is not
     // part of the search: gaussian_cdf_sample_64 counts b >= 1), and three or four rotate-and-add steps within the DPP row leave the count in every
-    // lane.  The price is 2 * 64 / G + 2 registers held across the sweep (n = 512, 8 lanes: 165 -> 196, two wavefronts per SIMD instead of three);
-    // the host's choice between the forms, with the measurements behind it, is in sc_hip_ens_dlp_sig_sign.
+    // lane.  The price is 2 * 64 / G + 2 registers held across the sweep (n = 512, 8 lanes: 167 -> 198, two wavefronts per SIMD instead of three);
+    // measurements of both forms are in sc_hip_ens_dlp_sig_sign.
     constexpr int NE = 64 / G;
     const uint32_t TS = 1u << A.ts_log;
     auto ring_sum = [](uint32_t v) -> uint32_t {                  // row_ror by S, 2S, ... 8: every lane ends with the sum over its signature's G lanes
@@ -2539,19 +2554,22 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     KleinArgs A;
     A.batch = nb; A.B = (uint32_t)B; A.n = (int)n; A.n2 = (int)n2; A.c = c; A.b = h->d_b; A.bgs = h->d_bgs; A.inv = h->d_inv; A.tabs = h->d_tabs; A.sizes = h->d_sizes;
     A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status;
-    // lanes per signature.  Register form: the fewest (down to 128 state words per lane) that still give every SIMD two wavefronts.
+    // lanes per signature.  Register form: the fewest (down to 128 state words per lane) that still give every SIMD a wavefront (two, below).
     // sc_hip_ens_dlp_signer_set_mapping: 1 = the lane-per-signature kernel (state in memory), 4 / 8 / 16 = the register form with that many lanes.
     int G = 16, in_regs = 1;
     const int gmin = (int)(n / 64);                              // 4 / 8 / 16 for n = 256 / 512 / 1024
-    while (G > gmin && batch * (size_t)(G / 2) / 64 >= (size_t)h->ctx->cus * 4 * 2) G /= 2;
+    // (round 3, with the additions off the DPP hazard: half the lanes are worth it as soon as every SIMD still gets ONE wavefront - n = 512 at 8192: 1.60 M
+    // sign/s on 8 lanes against 1.41 M on 16 - except for the step to 4 lanes at n = 256, whose 128 state words per lane against a 512-addition chain want two:
+    // 7.0 M against 7.65 M on 8 lanes at 16384)
+    while (G > gmin && batch * (size_t)(G / 2) / 64 >= (size_t)h->ctx->cus * 4 * ((n == 256 && G == 8) ? 2 : 1)) G /= 2;
     if (h->force_lanes == 1) { G = 1; in_regs = 0; }
     if ((h->force_lanes == 4 || h->force_lanes == 8 || h->force_lanes == 16) && h->force_lanes >= gmin) G = h->force_lanes;
     if (in_regs) {
         const dim3 grid((unsigned)((B / (64 / G) + KW - 1) / KW));
-        // the next row's tape word and table entries held across the sweep (PF) - measured better everywhere (n = 256: 4.6 -> 6.0 M sign/s at 16384, 7.8 -> 9.0 M
-        // at 65536; n = 512: 0.45 -> 0.53 M at 4096; n = 1024: 261 -> 276 k at 16384) except n = 512 on 8 lanes with more than two wavefronts per SIMD to
-        // place, where its 196 registers (165 without) cost the third resident wavefront: 1.72 M against 2.11 M sign/s at 65536
-        const bool pf = h->force_pf ? h->force_pf > 0 : !(n == 512 && G == 8 && batch * (size_t)G / 64 > (size_t)h->ctx->cus * 4 * 2);
+        // the next row's tape word and table entries held across the sweep (PF): measured better at every size since the additions stopped waiting on
+        // DPP hazards (n = 512 at 4096 / 16384 / 65536: 1.06 / 2.34 / 2.60 M sign/s against 0.62 / 2.01 / 2.51 M for the other form on 8 lanes; n = 256 at
+        // 16384: 7.7 against 6.5 M); the other form stays for the tests and as the statement of the loop without the software pipelining
+        const bool pf = h->force_pf >= 0;
 #define SC_KLEIN(GG, NN) do { if (pf) hipLaunchKernelGGL((kleinr_kernel<GG, NN, true>), grid, dim3(64 * KW), 0, s, A); \
                               else hipLaunchKernelGGL((kleinr_kernel<GG, NN, false>), grid, dim3(64 * KW), 0, s, A); } while (0)
         if (n == 256 && G == 4) SC_KLEIN(4, 128);
