@@ -1601,6 +1601,7 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
     {
         const int32_t *cr = A.c + (size_t)item * n + r;
         const float *g = A.bgs + (size_t)(n2 - 1) * n2 + r;
+        asm volatile("s_nop 4");
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             st[c] = (c < NCH / 2) ? cr[G * c] : 0;
@@ -1682,6 +1683,7 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
         const float *__restrict__ brow = reinterpret_cast<const float *>(rows[buf][0]) + r;
         const float *__restrict__ grow = reinterpret_cast<const float *>(rows[buf][1]) + r;
         dot = 0.f;
+        asm volatile("s_nop 4");                                 // chain_g's DPP reads are invisible to the compiler's hazard recogniser: the five wait states a DPP instruction needs behind a write of EXEC (the divergent stores above) - the sweep itself is straight-line
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             st[c] -= z * __float_as_int(brow[G * c]);
