@@ -61,6 +61,7 @@ __global__ __launch_bounds__(HT) void dlp_enc_prep_kernel(uint32_t batch, const 
                                                           int32_t *c, int32_t *e3, uint8_t *aux, uint8_t *ct, size_t ct_stride, uint32_t tail_off, uint32_t *status, DlpP P)
 {
     __shared__ uint64_t st[25 * HT];
+    __shared__ uint32_t kws[32 * HT];                                  // the key words of a lane (n / 32 <= 32), column per lane: combined with e1, e2 below
     const uint32_t i = blockIdx.x * HT + threadIdx.x;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
     if (i >= batch) return;
@@ -86,28 +87,35 @@ __global__ __launch_bounds__(HT) void dlp_enc_prep_kernel(uint32_t batch, const 
     sp.init(st, threadIdx.x, 168);
     for (int k = 0; k < n; k += 32) {
         const uint32_t x = T.w32();
+        kws[(k >> 5) * HT + threadIdx.x] = x;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            sp.absorb_u64(spread8(x >> (8 * b)));
-            uint32_t lo = 0, hi = 0;                                   // the key bit goes to bit 4 of each aux byte
-#pragma unroll
-            for (int j = 0; j < 4; j++) { lo |= ((x >> (8 * b + j)) & 1u) << (8 * j + 4); hi |= ((x >> (8 * b + 4 + j)) & 1u) << (8 * j + 4); }
-            *reinterpret_cast<uint2 *>(ai + k + 8 * b) = make_uint2(lo, hi);
-        }
+        for (int b = 0; b < 4; b++) sp.absorb_u64(spread8(x >> (8 * b)));
     }
     sp.finalize(0x1F);
     const uint8_t *mi = msgs + (size_t)i * msg_stride;
     uint8_t *tail = ct + (size_t)i * ct_stride + tail_off;
     for (int b = 0; b < n / 8; b++) tail[b] = (uint8_t)(sp.squeeze_byte() ^ mi[b]);
     // e1, e2, e3 (:1229-1243)
+    // eight coefficients at a time: the aux bytes are written once, complete (key bit | e2 + 1 | e1 + 1) - OR-ed into bytes this lane had stored
+    // earlier they were n dependent round trips to memory per message, 0.5 ms of the kernel's 0.78 at batch 65536
     int32_t *e3i = e3 + (size_t)i * n;
-    for (int k = 0; k < n; k++) {
-        uint32_t r = T.var(6);
-        int32_t a1 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a1 = -a1; r >>= 1;
-        int32_t a2 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a2 = -a2; r >>= 1;
-        int32_t a3 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a3 = -a3;
-        ai[k] = (uint8_t)(ai[k] | (uint32_t)(a1 + 1) | ((uint32_t)(a2 + 1) << 2));
-        e3i[k] = a3;
+    for (int k = 0; k < n; k += 8) {
+        const uint32_t kb = kws[(k >> 5) * HT + threadIdx.x] >> (k & 31);
+        uint32_t lo = 0, hi = 0;
+        int32_t a3s[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t r = T.var(6);
+            int32_t a1 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a1 = -a1; r >>= 1;
+            int32_t a2 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a2 = -a2; r >>= 1;
+            int32_t a3 = (int32_t)(r & 1u); r >>= 1; if (r & 1u) a3 = -a3;
+            const uint32_t byte = (uint32_t)(a1 + 1) | ((uint32_t)(a2 + 1) << 2) | (((kb >> j) & 1u) << 4);
+            if (j < 4) lo |= byte << (8 * j); else hi |= byte << (8 * (j - 4));
+            a3s[j] = a3;
+        }
+        *reinterpret_cast<uint2 *>(ai + k) = make_uint2(lo, hi);
+        *reinterpret_cast<int4 *>(e3i + k) = make_int4(a3s[0], a3s[1], a3s[2], a3s[3]);
+        *reinterpret_cast<int4 *>(e3i + k + 4) = make_int4(a3s[4], a3s[5], a3s[6], a3s[7]);
     }
     status[i] = T.underrun ? 2u : 1u;
 }
@@ -129,15 +137,17 @@ __global__ void dlp_enc_finish_kernel(uint32_t batch, const int32_t *u, const in
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = P.n / 8;
-    const uint32_t i = (uint32_t)(t / per); const int g = (int)(t % per);
+    const uint32_t i = (uint32_t)(t >> sc::pow2_shift(per)); const int g = (int)(t & (size_t)(per - 1));
     if (i >= batch || status[i] != 1) return;
     const int32_t q = P.q, q2 = q >> 1;
+    const sc::FastMod modq((uint32_t)q);
     int32_t xu[8], xv[8];
     for (int e = 0; e < 8; e++) {
         const size_t idx = (size_t)i * P.n + 8 * g + e;
         const uint32_t a = aux[idx];
-        int32_t uu = (u[idx] + q2 + (int32_t)(a & 3u) - 1) % q; if (uu < 0) uu += q;
-        int32_t vv = (int32_t)(((int64_t)v[idx] + q2 + (int32_t)((a >> 2) & 3u) - 1 + (int64_t)((a >> 4) & 1u) * P.m_scale) % q); if (vv < 0) vv += q;
+        // u, v: products from the transform (canonical, at worst centred): + q keeps the operand non-negative, the sums stay below 2^32 (q < 2^30)
+        const int32_t uu = (int32_t)modq((uint32_t)u[idx] + (uint32_t)q + (uint32_t)q2 + (a & 3u) - 1u);
+        const int32_t vv = (int32_t)modq((uint32_t)v[idx] + (uint32_t)q + (uint32_t)q2 + ((a >> 2) & 3u) - 1u + ((a >> 4) & 1u) * (uint32_t)P.m_scale);
         xu[e] = uu - q2;
         xv[e] = (vv - q2) >> P.l;
     }
@@ -161,7 +171,7 @@ __global__ void dlp_dec_unpack_kernel(uint32_t batch, const uint8_t *ct, size_t 
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = P.n / 8;
-    const uint32_t i = (uint32_t)(t / per); const int g = (int)(t % per);
+    const uint32_t i = (uint32_t)(t >> sc::pow2_shift(per)); const int g = (int)(t & (size_t)(per - 1));
     if (i >= batch) return;
     const uint8_t *s = ct + (size_t)i * ct_stride;
     int32_t xu[8], xv[8];
@@ -180,6 +190,7 @@ __global__ __launch_bounds__(HT) void dlp_dec_finish_kernel(uint32_t batch, cons
     if (i >= batch) return;
     const int n = P.n;
     const int32_t q = P.q, q2 = q >> 1, q4 = q >> 2;
+    const sc::FastMod modq((uint32_t)q);
     const int4 *pv = reinterpret_cast<const int4 *>(v + (size_t)i * n), *pu = reinterpret_cast<const int4 *>(us + (size_t)i * n);
     for (int k = 0; k < n / 8; k++) {
         uint64_t word = 0;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(HT) void dlp_dec_finish_kernel(uint32_t batch, cons
             const int32_t d[4] = { a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w };
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                int32_t x = d[e] % q; if (x < 0) x += q;
+                int32_t x = (int32_t)modq((uint32_t)d[e] + 2u * (uint32_t)q);       // differences of canonical (at worst centred) values: above -2q
                 x += q4;
                 word |= (uint64_t)((x >= q2 && x < q) ? 1u : 0u) << (8 * (4 * hlf + e));
             }

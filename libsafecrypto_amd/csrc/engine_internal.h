@@ -29,6 +29,26 @@ size_t cdt_lds_bytes(const sc_hip_cdt *c);      // table + padding + guide: the 
     } while (0)
 
 namespace sc {
+#ifdef __HIPCC__
+// x mod q for 0 <= x < 2^32 without the divider (the epilogue kernels reduced every coefficient with a runtime `%`: ~30 instructions for 32 bits, ~150 for
+// the 64-bit forms): one reciprocal per thread, then a multiply-high, a multiply-subtract and two conditional subtractions per value.
+// m = floor((2^32 - 1) / q) underestimates 2^32 / q by less than 1 + 1/q, so the quotient estimate is short by at most 2.
+struct FastMod {
+    uint32_t q, m;
+    __device__ explicit FastMod(uint32_t q_) : q(q_), m(0xFFFFFFFFu / q_) {}
+    __device__ __forceinline__ uint32_t operator()(uint32_t x) const
+    {
+        uint32_t r = x - __umulhi(x, m) * q;
+        r = r < r - q ? r : r - q;
+        return r < r - q ? r : r - q;
+    }
+};
+// index = item * per + part for a power of two `per`: the shift instead of a 64-bit division per thread
+__device__ __forceinline__ int pow2_shift(int per) { return 31 - __builtin_clz((unsigned)per); }
+#endif
+}
+
+namespace sc {
 // Copies between the caller's (pageable) memory and the device.  The HIP runtime moves a pageable buffer of more than 1 MiB by pinning the caller's
 // pages in place for the duration of the copy ("HSA Copy Using Pinned resource" in its log) and anything smaller through its own pinned staging
 // buffer.  The in-place path is the one a long-lived process could not rely on in round 2: with it, 20 of 101 sessions of the GPU test suite (heap buffers

@@ -28,34 +28,98 @@ struct EnsP { int32_t set, q, q_bits, n, n_bits, pad0, pad1, coeff_rnd[13]; };  
 struct EnsC { int32_t c[12]; };
 
 // r and e of one encapsulation (ens_kem.c:817-818).  status: 1 drawn, 2 tape exhausted.
+// A lane draws one operation's two polynomials: for j = 0..11, coeff_rnd[j] positions (tape word >> 1 mod n, redrawn while occupied) get +-(12 - j) - a
+// chain of dependent decisions per operation (~300 words per polynomial), so what counts is the latency of one step (no branches: see the window loop).  The polynomial being drawn
+// lives in the lane's own LDS row as signed bytes; the tape is read ENS_LOOK words ahead (the draws consume it
+// strictly in order, so the words a lane will want next are known: fetched word by word at the moment of use, every one of the ~600 draws waited for
+// its own trip to memory - 0.7 ms per batch whatever its size); a finished polynomial leaves through 16-byte stores that the wavefront makes
+// together, row by row (a lane writing its own row touched 64 different lines per store instruction).
+constexpr int ENS_LOOK = 16;
+
 __global__ __launch_bounds__(HT) void ens_sample_kernel(uint32_t batch, const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens, EnsC C,
                                                         int32_t *r, int32_t *e, uint32_t *used, uint32_t *status, int n)
 {
-    extern __shared__ int8_t col[];                                // n * HT
-    const uint32_t i = blockIdx.x * HT + threadIdx.x;
-    if (i >= batch) return;
-    const uint32_t *w = tapes + (size_t)i * tape_stride;
-    const uint32_t len = tape_lens ? tape_lens[i] : (uint32_t)tape_stride;
+    extern __shared__ uint32_t rows[];                             // HT rows of n / 4 words (n = 1024: the 64 KB a workgroup may have)
+    __shared__ int8_t s_lvl[1024 / 2 + 8];                         // s_lvl[a]: the magnitude the (a + 1)-th accepted draw of a polynomial writes (12 - j while the counts of 0..j cover a)
+    const int RS = n / 4;
+    const uint32_t base = blockIdx.x * HT, i = base + threadIdx.x;
+    const bool live = i < batch;
+    const uint32_t *w = tapes + (size_t)(live ? i : 0) * tape_stride;
+    const uint32_t len = live ? (tape_lens ? tape_lens[i] : (uint32_t)tape_stride) : 0u;
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) total += (uint32_t)C.c[j];         // <= n / 2 (checked when the handle is created)
+    for (uint32_t a = threadIdx.x; a <= total + 2; a += HT) {
+        int j = 0; uint32_t c = (uint32_t)C.c[0];
+#pragma unroll
+        for (int t = 1; t <= 12; t++) if (a >= c) { j = t; c += t < 12 ? (uint32_t)C.c[t] : 0u; }
+        s_lvl[a] = (int8_t)(12 - j);
+    }
+    __syncthreads();
+    uint32_t *row32 = rows + threadIdx.x * RS;
+    int8_t *mine = reinterpret_cast<int8_t *>(row32);
     uint32_t p = 0;
-    int8_t *mine = col + threadIdx.x;
-    bool ok = true;
-    for (int which = 0; which < 2 && ok; which++) {
-        for (int k = 0; k < n; k++) mine[k * HT] = 0;
-        for (int j = 0; j < 12 && ok; j++) {
-            int cnt = 0;
-            while (cnt < C.c[j]) {
-                if (p >= len) { ok = false; break; }
-                const uint32_t x = w[p++];
+    bool ok = live;
+    uint32_t look[ENS_LOOK];                                       // look[t]: word p + t of the tape (clamped reads: never past the row)
+    const uint32_t last = len ? len - 1 : 0;
+#pragma unroll
+    for (int t = 0; t < ENS_LOOK; t++) look[t] = w[min((uint32_t)t, last)];
+    for (int which = 0; which < 2; which++) {
+        for (int k = 0; k < n / 4; k++) row32[(k + threadIdx.x) & (n / 4 - 1)] = 0;      // (skewed: the rows are a multiple of the bank count apart)
+        uint32_t tot = 0;                                          // accepted so far
+        int32_t l0 = s_lvl[0], l1 = s_lvl[1];                      // s_lvl[tot], s_lvl[tot + 1]: the level is not looked up on the chain of a draw (below)
+        uint32_t busy = (ok && total != 0) ? 1u : 0u, okw = ok ? 1u : 0u;     // flags as words and bitwise logic: written with bool && the loop came out as a branch per draw
+        while (__any(busy != 0)) {
+            // one window of ENS_LOOK words: consumed in order, the window after it requested first.  No branches inside: a draw is a read of the
+            // position, a read of the level, an unconditional write of (accepted ? the new value : what was there) and three counters
+            uint32_t nxt[ENS_LOOK];
+#pragma unroll
+            for (int t = 0; t < ENS_LOOK; t++) nxt[t] = w[min(p + ENS_LOOK + (uint32_t)t, last)];
+            uint32_t took = 0;
+#pragma unroll
+            for (int t = 0; t < ENS_LOOK; t++) {
+                const uint32_t out = busy & (uint32_t)(p + took >= len);       // tape exhausted before the polynomial is complete
+                okw &= ~out;
+                busy &= ~out;
+                const uint32_t x = look[t];
                 const uint32_t idx = (x >> 1) & (uint32_t)(n - 1);
-                if (mine[idx * HT] == 0) { mine[idx * HT] = (int8_t)((x & 1) ? j - 12 : 12 - j); cnt++; }
+                const int32_t cur = mine[idx], l2 = s_lvl[tot + 2];             // both reads leave together; l2 is what l1 becomes if this draw is accepted
+                const uint32_t acc = busy & (uint32_t)(cur == 0);
+                const int32_t val = (x & 1u) ? -l0 : l0;
+                mine[idx] = (int8_t)(acc ? val : cur);
+                took += busy;
+                tot += acc;
+                l0 = acc ? l1 : l0;
+                l1 = acc ? l2 : l1;
+                busy &= (uint32_t)(tot != total);
+            }
+            ok = okw != 0;
+            // a lane that stopped inside the window keeps its position: shift the window by what was taken (whole windows in the common case)
+            p += took;
+            if (took == ENS_LOOK) {
+#pragma unroll
+                for (int t = 0; t < ENS_LOOK; t++) look[t] = nxt[t];
+            } else if (took) {
+#pragma unroll
+                for (int t = 0; t < ENS_LOOK; t++) look[t] = w[min(p + (uint32_t)t, last)];
             }
         }
-        int32_t *dst = (which ? e : r) + (size_t)i * n;
-        for (int k = 0; k < n; k++) dst[k] = ok ? (int32_t)mine[k * HT] : 0;
+        // the wavefront's rows leave together: 64 lanes x 4 coefficients = 1 KB per store instruction
+        const unsigned long long okm = __ballot(ok);
+        int32_t *dst = which ? e : r;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t it = 0; it < (uint32_t)HT && base + it < batch; it++) {
+            const bool good = (okm >> it) & 1;
+            for (int k4 = threadIdx.x; k4 < n / 4; k4 += HT) {
+                const uint32_t v = good ? rows[it * RS + k4] : 0u;
+                reinterpret_cast<int4 *>(dst + (size_t)(base + it) * n)[k4] = make_int4((int32_t)(int8_t)v, (int32_t)(int8_t)(v >> 8), (int32_t)(int8_t)(v >> 16), (int32_t)(int8_t)(v >> 24));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    if (!ok) for (int k = 0; k < n; k++) e[(size_t)i * n + k] = 0;
-    used[i] = p;
-    status[i] = ok ? 1u : 2u;
+    if (live) { used[i] = p; status[i] = ok ? 1u : 2u; }
 }
 
 // t = normalise(2 centre(h r) + e), packed; key = the parities of e (ens_kem.c:305-315, 833-852).  One thread per four coefficients.
@@ -64,15 +128,16 @@ __global__ void ens_enc_finish_kernel(uint32_t batch, const int32_t *hr, const i
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = n / 4;
-    const uint32_t i = (uint32_t)(t / per); const int gq = (int)(t % per);
+    const uint32_t i = (uint32_t)(t >> sc::pow2_shift(per)); const int gq = (int)(t & (size_t)(per - 1));
     if (i >= batch || status[i] != 1) return;
+    const sc::FastMod modq((uint32_t)q);
     uint64_t acc = 0; uint32_t kb = 0;
     for (int k = 0; k < 4; k++) {
         const size_t idx = (size_t)i * n + 4 * gq + k;
         int32_t v = hr[idx];
         if (v > q / 2) v -= q;
-        v = 2 * v + e[idx];
-        v %= q; if (v < 0) v += q;
+        v = 2 * v + e[idx];                                        // |v| <= q + 12: + 2q makes it an unsigned operand
+        v = (int32_t)modq((uint32_t)v + 2u * (uint32_t)q);
         acc = (acc << q_bits) | (uint64_t)(uint32_t)v;
         kb = (kb << 1) | (uint32_t)(e[idx] & 1);
     }
@@ -88,7 +153,7 @@ __global__ void ens_unpack_kernel(uint32_t batch, const uint8_t *ct, size_t ct_s
 {
     const size_t th = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = n / 4;
-    const uint32_t i = (uint32_t)(th / per); const int gq = (int)(th % per);
+    const uint32_t i = (uint32_t)(th >> sc::pow2_shift(per)); const int gq = (int)(th & (size_t)(per - 1));
     if (i >= batch) return;
     const int nbytes = 4 * q_bits / 8;
     const uint8_t *s = ct + (size_t)i * ct_stride + (size_t)gq * nbytes;
@@ -117,10 +182,10 @@ __global__ void ens_dec_finish_kernel(const int32_t *gt, const uint32_t *inv_g, 
     }
     if (tid < W) bs[tid] = inv_g[tid];
     __syncthreads();
-    const int s = tid + 1, ws = (s >> 5) % W, bsft = s & 31;           // rotate right by s = tid + 1 positions
-    uint32_t acc = 0;
+    const int s = tid + 1, ws = (s >> 5) & (W - 1), bsft = s & 31;     // rotate right by s = tid + 1 positions (W = n / 32 is a power of two: the
+    uint32_t acc = 0;                                                  // three runtime modulo operations per word were 90 % of this kernel's instructions)
     for (int j = 0; j < W; j++) {
-        const int j0 = (j - ws + W) % W, j1 = (j0 - 1 + W) % W;
+        const int j0 = (j - ws) & (W - 1), j1 = (j0 - 1) & (W - 1);
         const uint32_t word = bsft ? ((bs[j1] << (32 - bsft)) | (bs[j0] >> bsft)) : bs[j0];
         acc ^= xs[j] & word;
     }
@@ -224,7 +289,7 @@ extern "C" int sc_hip_ens_encaps(sc_hip_ens_t *h, size_t batch, const uint32_t *
     uint32_t *used = h->ws.take<uint32_t>(batch);
     EnsC C;
     for (int j = 0; j < 12; j++) C.c[j] = h->P.coeff_rnd[j];
-    hipLaunchKernelGGL(ens_sample_kernel, dim3((B + HT - 1) / HT), dim3(HT), (size_t)n * HT, s, B, d_tapes, tape_stride, d_tape_lens, C, r, e,
+    hipLaunchKernelGGL(ens_sample_kernel, dim3((B + HT - 1) / HT), dim3(HT), (size_t)HT * n, s, B, d_tapes, tape_stride, d_tape_lens, C, r, e,
                        d_used ? d_used : used, d_status, n);
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(h->plan, batch, r, h->d_h, t, s)) return SC_HIP_FAILURE;
