@@ -462,7 +462,7 @@ size_t sc_hip_kyber_noise_bytes(const sc_hip_kyber_t *h);                   /* (
 
 /* replaces: kyber_cpa_enc (module_lwe.c:1268-1401) for `batch` 32-byte messages d_m [batch][32]; d_noise [batch][noise_stride]
  * holds, per message, the bytes binomial_rand_sample_csprng draws from the CSPRNG seeded with r (r, e1, e2 in that order);
- * outputs the compressed ciphertext polynomials u int32 [batch][k][n] (d_u bits) and v int32 [batch][n] (d_v bits) */
+ * outputs the compressed ciphertext polynomials u int32 [batch][k][n] (d_u bits) and v int32 [batch][n] (d_v bits), both 16-byte aligned */
 int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8_t *d_m, const uint8_t *d_noise, size_t noise_stride,
                          int32_t *d_u, int32_t *d_v, void *stream);
 /* replaces: kyber_cpa_dec (module_lwe.c:1415-1481); u, v are not modified; d_m [batch][32] */

@@ -34,38 +34,49 @@ __device__ __forceinline__ int32_t ky_compress(int32_t x, int d, uint32_t q, uin
     return (int32_t)((uint32_t)t & ((1u << d) - 1u));
 }
 
+#define KY_ITEMS(item, count) for (uint32_t item = blockIdx.y; item < (count); item += gridDim.y)
+static inline dim3 ky_grid(size_t per, size_t batch) { return dim3((unsigned)((per + 255) / 256), (unsigned)(batch < 65535 ? batch : 65535)); }
+
 // binomial_rand_sample_csprng: coefficient group g (4 values) of a sampler reads its eta bytes [g*eta, (g+1)*eta)
 __global__ void ky_binomial_kernel(const uint8_t *noise, size_t noise_stride, uint32_t count, int32_t *r, int32_t *e1, int32_t *e2, KyP P)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid: x over the groups of an item, y over the items (KY_ITEMS): no division of a flat thread index by the runtime group count - as a 64-bit
+    // division per thread that was most of what these one-load-one-store kernels executed
     const int kn4 = P.k * P.n / 4, n4 = P.n / 4, per = 2 * kn4 + n4;
-    const uint32_t item = (uint32_t)(t / per); const int g = (int)(t % per);
-    if (item >= count) return;
-    const uint8_t *b = noise + (size_t)item * noise_stride + (size_t)g * P.eta;
-    uint32_t a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    for (int e = 0; e < P.eta; e++) { const uint32_t v = b[e]; for (int i = 0; i < 8; i++) a[i] += v & (1u << i); }
-    int32_t *dst = (g < kn4) ? r + ((size_t)item * kn4 + g) * 4 : (g < 2 * kn4) ? e1 + ((size_t)item * kn4 + (g - kn4)) * 4 : e2 + ((size_t)item * n4 + (g - 2 * kn4)) * 4;
-    dst[0] = (int32_t)a[0] - (int32_t)(a[1] >> 1);
-    dst[1] = (int32_t)(a[2] >> 2) - (int32_t)(a[3] >> 3);
-    dst[2] = (int32_t)(a[4] >> 4) - (int32_t)(a[5] >> 5);
-    dst[3] = (int32_t)(a[6] >> 6) - (int32_t)(a[7] >> 7);
+    const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (g >= per) return;
+    KY_ITEMS(item, count) {
+        const uint8_t *b = noise + (size_t)item * noise_stride + (size_t)g * P.eta;
+        uint32_t a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int e = 0; e < P.eta; e++) { const uint32_t v = b[e]; for (int i = 0; i < 8; i++) a[i] += v & (1u << i); }
+        int32_t *dst = (g < kn4) ? r + ((size_t)item * kn4 + g) * 4 : (g < 2 * kn4) ? e1 + ((size_t)item * kn4 + (g - kn4)) * 4 : e2 + ((size_t)item * n4 + (g - 2 * kn4)) * 4;
+        *reinterpret_cast<int4 *>(dst) = make_int4((int32_t)a[0] - (int32_t)(a[1] >> 1), (int32_t)(a[2] >> 2) - (int32_t)(a[3] >> 3),
+                                                   (int32_t)(a[4] >> 4) - (int32_t)(a[5] >> 5), (int32_t)(a[6] >> 6) - (int32_t)(a[7] >> 7));
+    }
 }
 
 // u = compress(u0 + e1, d_u) ; v = compress(v0 + [m bit] floor(q/2) + e2, d_v)   (module_lwe.c:1355-1395)
 __global__ void ky_enc_finish_kernel(const int32_t *u0, const int32_t *v0, const int32_t *e1, const int32_t *e2, const uint8_t *m, uint32_t count,
                                      int32_t *u, int32_t *v, KyP P)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = (P.k + 1) * P.n;
-    const uint32_t item = (uint32_t)(t / per); const int e = (int)(t % per);
-    if (item >= count) return;
-    if (e < P.k * P.n) {
-        const size_t i = (size_t)item * P.k * P.n + e;
-        u[i] = ky_compress(u0[i] + e1[i], P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm);
-    } else {
-        const int j = e - P.k * P.n; const size_t i = (size_t)item * P.n + j;
-        const int32_t bit = (m[(size_t)item * 32 + (j >> 3)] & (0x80u >> (j & 7))) ? (P.q >> 1) : 0;
-        v[i] = ky_compress(v0[i] + bit + e2[i], P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm);
+    // four coefficients per thread (16-byte loads and stores), grid as ky_binomial_kernel
+    const int e = 4 * (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= (P.k + 1) * P.n) return;
+    KY_ITEMS(item, count) {
+        if (e < P.k * P.n) {
+            const size_t i = (size_t)item * P.k * P.n + e;
+            const int4 a = *reinterpret_cast<const int4 *>(u0 + i), b = *reinterpret_cast<const int4 *>(e1 + i);
+            *reinterpret_cast<int4 *>(u + i) = make_int4(ky_compress(a.x + b.x, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.y + b.y, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm),
+                                                         ky_compress(a.z + b.z, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.w + b.w, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm));
+        } else {
+            const int j = e - P.k * P.n; const size_t i = (size_t)item * P.n + j;
+            const uint32_t mb = m[(size_t)item * 32 + (j >> 3)];               // j is a multiple of 4: its four bits sit in one byte, most significant first
+            const int32_t h = P.q >> 1;
+            const int4 a = *reinterpret_cast<const int4 *>(v0 + i), b = *reinterpret_cast<const int4 *>(e2 + i);
+            const int32_t b0 = (mb & (0x80u >> (j & 7))) ? h : 0, b1 = (mb & (0x40u >> (j & 7))) ? h : 0, b2 = (mb & (0x20u >> (j & 7))) ? h : 0, b3 = (mb & (0x10u >> (j & 7))) ? h : 0;
+            *reinterpret_cast<int4 *>(v + i) = make_int4(ky_compress(a.x + b0 + b.x, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.y + b1 + b.y, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm),
+                                                         ky_compress(a.z + b2 + b.z, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.w + b3 + b.w, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm));
+        }
     }
 }
 
@@ -314,15 +325,15 @@ __global__ __launch_bounds__(KHT) void ky_h2_kernel(uint32_t batch, const uint8_
 // last 32 lanes of the message's range).
 __global__ void ky_pack_kernel(uint32_t batch, const int32_t *__restrict__ u, const int32_t *__restrict__ v, const uint8_t *__restrict__ krd, uint8_t *__restrict__ ct, size_t ct_stride, KyP P)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ug = (uint32_t)(P.k * P.n / 8), vg = (uint32_t)(P.n / 8), per = ug + vg + 32;
-    const uint32_t i = (uint32_t)(t / per), j = (uint32_t)(t % per);
-    if (i >= batch) return;
-    uint8_t *out = ct + (size_t)i * ct_stride;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
     const uint32_t ubytes = ug * (uint32_t)P.d_u, vbytes = vg * (uint32_t)P.d_v;
-    if (j >= ug + vg) { const uint32_t b = j - ug - vg; out[ubytes + vbytes + b] = krd[(size_t)i * 96 + 64 + b]; return; }
     const bool isu = j < ug;
     const int d = isu ? P.d_u : P.d_v;
+    KY_ITEMS(i, batch) {
+    uint8_t *out = ct + (size_t)i * ct_stride;
+    if (j >= ug + vg) { const uint32_t b = j - ug - vg; out[ubytes + vbytes + b] = krd[(size_t)i * 96 + 64 + b]; continue; }
     const int32_t *src = isu ? u + (size_t)i * P.k * P.n + (size_t)j * 8 : v + (size_t)i * P.n + (size_t)(j - ug) * 8;
     uint8_t *o = out + (isu ? (size_t)j * d : (size_t)ubytes + (size_t)(j - ug) * d);
     const int4 lo = *reinterpret_cast<const int4 *>(src), hi = *reinterpret_cast<const int4 *>(src + 4);
@@ -333,17 +344,18 @@ __global__ void ky_pack_kernel(uint32_t batch, const int32_t *__restrict__ u, co
         acc = (acc << d) | (c[e] & ((1u << d) - 1u)); nb += d;
         while (nb >= 8) { o[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
     }
+    }
 }
 
 // kyber_kem.c:976-983: one lane unpacks the d bytes of a group of eight coefficients
 __global__ void ky_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ ct, size_t ct_stride, int32_t *__restrict__ u, int32_t *__restrict__ v, KyP P)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t ug = (uint32_t)(P.k * P.n / 8), vg = (uint32_t)(P.n / 8), per = ug + vg;
-    const uint32_t i = (uint32_t)(t / per), j = (uint32_t)(t % per);
-    if (i >= batch) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= per) return;
     const bool isu = j < ug;
     const int d = isu ? P.d_u : P.d_v;
+    KY_ITEMS(i, batch) {
     const uint8_t *src = ct + (size_t)i * ct_stride + (isu ? (size_t)j * d : (size_t)ug * P.d_u + (size_t)(j - ug) * d);
     int32_t *dst = isu ? u + (size_t)i * P.k * P.n + (size_t)j * 8 : v + (size_t)i * P.n + (size_t)(j - ug) * 8;
     uint32_t acc = 0, c[8]; int nb = 0, r = 0;
@@ -354,6 +366,7 @@ __global__ void ky_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ ct,
     }
     *reinterpret_cast<int4 *>(dst) = make_int4((int32_t)c[0], (int32_t)c[1], (int32_t)c[2], (int32_t)c[3]);
     *reinterpret_cast<int4 *>(dst + 4) = make_int4((int32_t)c[4], (int32_t)c[5], (int32_t)c[6], (int32_t)c[7]);
+    }
 }
 
 }  // namespace
@@ -474,6 +487,7 @@ extern "C" int sc_hip_kyber_cpa_enc(sc_hip_kyber_t *h, size_t batch, const uint8
 {
     if (!h) return fail("kyber_cpa_enc: null handle");
     if (!h->have_pub) return fail("kyber_cpa_enc: no public key loaded");
+    if ((reinterpret_cast<uintptr_t>(d_u) | reinterpret_cast<uintptr_t>(d_v)) & 15) return fail("kyber_cpa_enc: u and v must be 16-byte aligned");
     const KyKeys K = { h->d_A, h->d_t, h->d_s, 0, 0, nullptr, false };
     return ky_cpa_enc_core(h, K, batch, d_m, d_noise, noise_stride, d_u, d_v, stream);
 }
@@ -490,8 +504,7 @@ static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     const KyP &P = h->P;
     const uint32_t B = (uint32_t)batch;
     const int k = P.k;
-    const size_t ng = batch * (size_t)((2 * k + 1) * N / 4);
-    hipLaunchKernelGGL(ky_binomial_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, d_noise, noise_stride, B, h->r, h->e1, h->e2, P);
+    hipLaunchKernelGGL(ky_binomial_kernel, ky_grid((size_t)((2 * k + 1) * N / 4), batch), dim3(256), 0, s, d_noise, noise_stride, B, h->r, h->e1, h->e2, P);
     HIPCHK(hipGetLastError());
     DilNtt a = mlwe_base_args(h->plan, k, k, 1 << 20);
     a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
@@ -501,8 +514,7 @@ static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
     a.key = K.t; a.key_item_stride = K.st; a.w = h->v0; a.kk = 1; a.key_nat = K.nat ? 1 : 0;
     if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
-    const size_t ne = batch * (size_t)(k + 1) * N;
-    hipLaunchKernelGGL(ky_enc_finish_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, h->u0, h->v0, h->e1, h->e2, d_m, B, d_u, d_v, P);
+    hipLaunchKernelGGL(ky_enc_finish_kernel, ky_grid((size_t)(k + 1) * N / 4, batch), dim3(256), 0, s, h->u0, h->v0, h->e1, h->e2, d_m, B, d_u, d_v, P);
     HIPCHK(hipGetLastError());
     // the ephemeral secret r and the noise do not outlive the call (kyber_kem.c:1014, module_lwe.c:1397-1400)
     const size_t kb = batch * (size_t)k * N * 4;
@@ -653,8 +665,7 @@ static int ky_encaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_m, uin
     if (ky_kem_core(h, batch, d_m, s, K, rho, tk)) return SC_HIP_FAILURE;
     if (ky_two_lanes(h, batch)) hipLaunchKernelGGL(ky_h2_kernel, dim3((2 * B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
     else hipLaunchKernelGGL(ky_h_kernel, dim3((B + KHT - 1) / KHT), dim3(KHT), 0, s, B, h->krd, h->ku, h->kv, h->krd + 64, (size_t)96, d_keys, h->P);
-    const size_t nb = batch * (size_t)((h->P.k + 1) * N / 8 + 32);
-    hipLaunchKernelGGL(ky_pack_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
+    hipLaunchKernelGGL(ky_pack_kernel, ky_grid((size_t)((h->P.k + 1) * N / 8 + 32), batch), dim3(256), 0, s, B, h->ku, h->kv, h->krd, d_ct, ct_stride, h->P);
     HIPCHK(hipGetLastError());
     ky_kem_wipe(h, batch, s);
     return SC_HIP_SUCCESS;
@@ -677,8 +688,7 @@ static int ky_decaps_core(sc_hip_kyber *h, size_t batch, const uint8_t *d_ct, si
     if (ky_kem_ensure(h, batch)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t B = (uint32_t)batch;
-    const size_t ne = batch * (size_t)((h->P.k + 1) * N / 8);
-    hipLaunchKernelGGL(ky_unpack_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, B, d_ct, ct_stride, h->ku, h->kv, h->P);
+    hipLaunchKernelGGL(ky_unpack_kernel, ky_grid((size_t)((h->P.k + 1) * N / 8), batch), dim3(256), 0, s, B, d_ct, ct_stride, h->ku, h->kv, h->P);
     HIPCHK(hipGetLastError());
     if (K ? ky_cpa_dec_core(h, *K, batch, h->ku, h->kv, h->mbuf, s) : sc_hip_kyber_cpa_dec(h, batch, h->ku, h->kv, h->mbuf, s)) return SC_HIP_FAILURE;
     if (ky_kem_core(h, batch, h->mbuf, s, K, rho, tk)) return SC_HIP_FAILURE;
