@@ -476,26 +476,32 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
 
 // ---- verify -----------------------------------------------------------------------------------------------------------
 
-// unpack t (z1_bits, signed), z (z2_bits, signed), c_idx (n_bits): bliss_b.c:1641-1657
+// unpack t (z1_bits, signed), z (z2_bits, signed), c_idx (n_bits): bliss_b.c:1641-1657.  Grid: x over the 2n + kappa fields of a signature, y over the
+// signatures - a field's width and bit offset are the same for every signature, and no thread divides a flat index by the runtime field count (as a
+// 64-bit division, with a byte load per BIT of the field, this kernel was 29 % of a verification call); a field is cut out of the two to four bytes
+// it touches.
 __global__ void bl_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, int32_t *t, int16_t *z, int32_t *cidx,
                                  uint32_t *verdict, BlissP P)
 {
-    const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int per = 2 * P.n + P.kappa;
-    const uint32_t item = (uint32_t)(tt / per); const int e = (int)(tt % per);
-    if (item >= count) return;
+    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= per) return;
     const uint32_t need_bits = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits);
-    if (siglens[item] * 8 < need_bits) { if (e == 0) verdict[item] = 1; if (e < P.n) t[(size_t)item * P.n + e] = 0; return; }
     int bits; uint32_t off;
     if (e < P.n) { bits = P.z1_bits; off = (uint32_t)e * P.z1_bits; }
     else if (e < 2 * P.n) { bits = P.z2_bits; off = (uint32_t)(P.n * P.z1_bits + (e - P.n) * P.z2_bits); }
     else { bits = P.n_bits; off = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + (e - 2 * P.n) * P.n_bits); }
-    const uint8_t *s = sigs + (size_t)item * sig_stride;
-    uint32_t val = 0;
-    for (int b = 0; b < bits; b++) { const uint32_t bp = off + b; val = (val << 1) | ((s[bp >> 3] >> (7 - (bp & 7))) & 1u); }
-    if (e < P.n) t[(size_t)item * P.n + e] = (int32_t)(val << (32 - bits)) >> (32 - bits);
-    else if (e < 2 * P.n) z[(size_t)item * P.n + (e - P.n)] = (int16_t)((int32_t)(val << (32 - bits)) >> (32 - bits));
-    else cidx[(size_t)item * P.kappa + (e - 2 * P.n)] = (int32_t)val;
+    const uint32_t first = off >> 3, last = (off + (uint32_t)bits - 1) >> 3;           // bits <= 25: at most four bytes
+    for (uint32_t item = blockIdx.y; item < count; item += gridDim.y) {
+        if (siglens[item] * 8 < need_bits) { if (e == 0) verdict[item] = 1; if (e < P.n) t[(size_t)item * P.n + e] = 0; continue; }
+        const uint8_t *s = sigs + (size_t)item * sig_stride;
+        uint32_t win = 0;
+        for (uint32_t b = first; b <= last; b++) win = (win << 8) | s[b];
+        const uint32_t val = (win >> (8 * (last + 1) - off - (uint32_t)bits)) & ((1u << bits) - 1u);
+        if (e < P.n) t[(size_t)item * P.n + e] = (int32_t)(val << (32 - bits)) >> (32 - bits);
+        else if (e < 2 * P.n) z[(size_t)item * P.n + (e - P.n)] = (int16_t)((int32_t)(val << (32 - bits)) >> (32 - bits));
+        else cidx[(size_t)item * P.kappa + (e - 2 * P.n)] = (int32_t)val;
+    }
 }
 
 // check_norms on the received (t, z): one wavefront per signature
@@ -1446,7 +1452,7 @@ static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, 
     const uint32_t B = (uint32_t)batch;
     const int n = P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    const size_t nu = batch * (size_t)(2 * n + P.kappa), ne = batch * (size_t)n;
+    const size_t ne = batch * (size_t)n;
     if (b->entropy == 2) {
         uint32_t lpw = 64;
         while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 4) lpw >>= 1;
@@ -1457,7 +1463,7 @@ static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, 
         while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 8) lpw >>= 1;
         hipLaunchKernelGGL(bl_huff_unpack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, B, lpw, b->tin, b->z, b->cidx, d_verdicts, P, b->ht[0], b->ht[1]);
     }
-    else hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
+    else hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((2 * P.n + P.kappa + 255) / 256), B < 65535u ? B : 65535u), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
     hipLaunchKernelGGL(bl_vnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, b->tin, b->z, B, d_verdicts, P);
     HIPCHK(hipGetLastError());
     if (ka16) {

@@ -1238,8 +1238,9 @@ __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uin
 
 __device__ __forceinline__ int32_t centre_mod(int32_t x, int32_t q)      // ntt center_32: the representative in [-(q-1)/2, (q-1)/2]
 {
-    int32_t r = x % q;
     const int32_t q2 = (q - 1) >> 1;
+    if (x >= -q2 && x <= q2) return x;                                   // already the representative (every unpacked 12-bit field is): no division
+    int32_t r = x % q;
     if (r < -q2) r += q;
     if (r > q2) r -= q;
     return r;
@@ -1355,7 +1356,7 @@ __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ si
     // one lane per PAIR of coefficients; with the 12-bit coding of both parameter sets a pair is exactly three bytes
     const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int hn = P.n / 2;
-    const uint32_t b = (uint32_t)(tt / hn); const int e = (int)(tt % hn) * 2;
+    const uint32_t b = (uint32_t)(tt >> sc::pow2_shift(hn)); const int e = (int)(tt & (size_t)(hn - 1)) * 2;     // n is a power of two
     if (b >= batch) return;
     int32_t *o = s2 + (size_t)b * P.n + e;
     if ((size_t)siglens[b] * 8 < (size_t)P.n * bits || siglens[b] > sig_stride) { if (e == 0) verdict[b] = 1; o[0] = o[1] = 0; return; }   // short, or longer than its row
