@@ -1430,8 +1430,8 @@ void make_gm(std::vector<double> &gm)
 __global__ void dlp_pack_kernel(uint32_t batch, const int32_t *__restrict__ v, uint32_t *__restrict__ status, uint8_t *__restrict__ sk, size_t sk_stride, int n, int ubits)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int per = n / 8;
-    const uint32_t i = (uint32_t)(t / per); const int g = (int)(t % per);
+    const int per = n / 8;                                       // a power of two
+    const uint32_t i = (uint32_t)(t >> sc::pow2_shift(per)); const int g = (int)(t & (size_t)(per - 1));
     if (i >= batch || status[i] == 2) return;
     const int32_t *src = v + (size_t)i * n + 8 * g;
     uint8_t *o = sk + (size_t)i * sk_stride + (size_t)g * ubits;
@@ -1719,10 +1719,10 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
 __global__ void klein_pack_kernel(uint32_t batch, uint32_t B, const int32_t *__restrict__ ci, const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, size_t sig_stride,
                                   int n, int q, int q_bits)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int g = (int)(t / batch);                              // consecutive threads = consecutive signatures: coalesced reads of the state
-    const uint32_t i = (uint32_t)(t % batch);
-    if (g >= n / 8) return;
+    // grid: x over the signatures (consecutive threads = consecutive signatures: coalesced reads of the state), y over the n / 8 groups
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int g = (int)blockIdx.y;
+    if (i >= batch) return;
     const bool ok = status[i] == 1;
     uint8_t *o = sigs + (size_t)i * sig_stride + (size_t)g * q_bits;
     uint64_t acc = 0; int nb = 0, w = 0;
@@ -2272,7 +2272,7 @@ __global__ void fal_gather_keys_kernel(uint32_t batch, const uint32_t *__restric
                                        uint32_t *__restrict__ verdicts)
 {
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t i = t / (size_t)(n / 4); const int j = (int)(t % (size_t)(n / 4));
+    const size_t i = t >> sc::pow2_shift(n / 4); const int j = (int)(t & (size_t)(n / 4 - 1));
     if (i >= batch) return;
     const uint32_t kx = key_of[i];
     int4 v = make_int4(0, 0, 0, 0);
@@ -2585,8 +2585,7 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     }
     else hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
     HIPCHK(hipGetLastError());
-    const size_t nt = batch * (n / 8);
-    hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
+    hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((batch + 255) / 256), (unsigned)(n / 8)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
     h->ws.wipe(s);                                                  // the sampler state (the lattice point before packing)
     return SC_HIP_SUCCESS;
