@@ -75,6 +75,8 @@ def test_seeded_batch_matches_oracle(eng, G, tag, batch):
     lens = np.full(batch, W, dtype=np.int32)
     lens[3] = 100                                                  # r cannot be completed
     lens[4] = 450 if E.n == 512 else 900                          # r fits, e does not
+    lens[5] = 0                                                    # nothing to draw from
+    lens[6] = 7                                                    # shorter than the kernel's read-ahead window
     ct, keys, used, st = k.encaps(dev(tapes), dev(lens))
     torch.cuda.synchronize()
     ctn, kn, un, sn = (x.cpu().numpy() for x in (ct, keys, used, st))
@@ -83,7 +85,7 @@ def test_seeded_batch_matches_oracle(eng, G, tag, batch):
         assert (rc, int(sn[i])) in ((0, 1), (2, 2)), i
         if rc == 0:
             assert bytes(ctn[i]) == oc and bytes(kn[i]) == ok and un[i] == ou, i
-    assert sn[3] == 2 and sn[4] == 2
+    assert sn[3] == 2 and sn[4] == 2 and sn[5] == 2 and sn[6] == 2 and un[5] == 0 and un[6] == 7
     junk = rng.integers(0, 256, size=(batch, k.ct_bytes), dtype=np.uint8)
     kj = k.decaps(dev(junk)).cpu().numpy()
     for i in range(0, batch, 7):
