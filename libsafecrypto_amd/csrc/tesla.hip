@@ -398,18 +398,24 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const ui
     if (bad && lane == 0) verdict[item] = 1;
 }
 
-// w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products
+// w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products.  The two public polynomials sit in LDS
+// (8n bytes, filled once per workgroup, which then walks its share of the batch): every coefficient reads 2 omega of their entries at positions that
+// differ per signature, and fetched from global memory those reads - 300 load instructions per wavefront through the L1 - were the kernel (173 us of a
+// 330 us verification call at batch 16384).
 __global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *t1, const int32_t *t2, const int32_t *cidx, TsP P, sc::ModK mk)
 {
+    extern __shared__ int32_t tl[];                                   // t1 | t2
     const int lane = threadIdx.x & 63, n = P.n;
-    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= batch) return;
-    Pos pos; load_pos(pos, cidx + (size_t)item * P.omega, P.omega);
-    for (int j = lane; j < n; j += 64) {
-        const size_t k = (size_t)item * n + j;
-        // any int32 -> [0, q) by a Barrett step (modarith.h) instead of the division normalize_32 compiles to
-        w1[k] = (int32_t)sc::csub(sc::reduce_i32(w1[k] - sparse_reg(t1, pos, P.omega, n, j), mk), mk.q);
-        w2[k] = (int32_t)sc::csub(sc::reduce_i32(w2[k] - sparse_reg(t2, pos, P.omega, n, j), mk), mk.q);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { tl[i] = t1[i]; tl[n + i] = t2[i]; }
+    __syncthreads();
+    for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < batch; item += gridDim.x * 4) {
+        Pos pos; load_pos(pos, cidx + (size_t)item * P.omega, P.omega);
+        for (int j = lane; j < n; j += 64) {
+            const size_t k = (size_t)item * n + j;
+            // any int32 -> [0, q) by a Barrett step (modarith.h) instead of the division normalize_32 compiles to
+            w1[k] = (int32_t)sc::csub(sc::reduce_i32(w1[k] - sparse_reg(tl, pos, P.omega, n, j), mk), mk.q);
+            w2[k] = (int32_t)sc::csub(sc::reduce_i32(w2[k] - sparse_reg(tl + n, pos, P.omega, n, j), mk), mk.q);
+        }
     }
 }
 
@@ -623,7 +629,10 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
-    hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P, t->plan->k[1]);
+    {
+        const uint32_t need = (B + 3) / 4, cap = (uint32_t)t->ctx->cus * 8;
+        hipLaunchKernelGGL(ts_vw_kernel, dim3(need < cap ? need : cap), dim3(256), sizeof(int32_t) * 2 * (size_t)P.n, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P, t->plan->k[1]);
+    }
     hipLaunchKernelGGL(ts_round_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->r1, t->r2, t->nz, 0, P);
     hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, 1u, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                        t->d_zstate, t->zblocks, (uint8_t *)nullptr, 1, d_verdicts, d_sigs, sig_stride, md_off, P);
