@@ -110,15 +110,31 @@ __global__ __launch_bounds__(256) void ts_round_kernel(uint32_t nact, const int3
     const int lane = threadIdx.x & 63;
     const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (aidx >= nact) return;
+    // r1, r2 are written only where something is non-zero (ts_oracle_kernel reads them only then, and with the reference's rounding - the remainder is
+    // taken modulo q, not 2^d - that is the rare case): the kernel is bandwidth-bound and the 8n bytes of zeros per slot were half of what it moved
     uint32_t any = 0;
-    for (int i = lane; i < P.n; i += 64) {
-        const size_t k = (size_t)aidx * P.n + i;
-        const int32_t a = cen ? centre_q(v1[k], P.q) : v1[k], b = cen ? centre_q(v2[k], P.q) : v2[k];
-        const int32_t ra = (a - a % P.q) >> P.d, rb = (b - b % P.q) >> P.d;
-        r1[k] = ra; r2[k] = rb;
-        any |= (uint32_t)(ra | rb);
+    int32_t ra[8], rb[8];                                            // n = 512 (sc_hip_tesla_create)
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const int i = lane + 64 * t;
+        ra[t] = rb[t] = 0;
+        if (i < P.n) {
+            const size_t k = (size_t)aidx * P.n + i;
+            const int32_t a = cen ? centre_q(v1[k], P.q) : v1[k], b = cen ? centre_q(v2[k], P.q) : v2[k];
+            // x % q is x itself for |x| < q - what both callers hand in (centred or canonical values): the division only for anything else
+            const int32_t ma = (a > -P.q && a < P.q) ? a : a % P.q, mb = (b > -P.q && b < P.q) ? b : b % P.q;
+            ra[t] = (a - ma) >> P.d; rb[t] = (b - mb) >> P.d;
+            any |= (uint32_t)(ra[t] | rb[t]);
+        }
     }
     for (int o = 32; o > 0; o >>= 1) any |= (uint32_t)__shfl_xor((int)any, o);
+    if (any) {
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const int i = lane + 64 * t;
+            if (i < P.n) { r1[(size_t)aidx * P.n + i] = ra[t]; r2[(size_t)aidx * P.n + i] = rb[t]; }
+        }
+    }
     if (lane == 0) nz[aidx] = any != 0;
 }
 
