@@ -49,9 +49,16 @@ __global__ void ky_binomial_kernel(const uint8_t *noise, size_t noise_stride, ui
         const uint8_t *b = noise + (size_t)item * noise_stride + (size_t)g * P.eta;
         uint32_t a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int e = 0; e < P.eta; e++) { const uint32_t v = b[e]; for (int i = 0; i < 8; i++) a[i] += v & (1u << i); }
-        int32_t *dst = (g < kn4) ? r + ((size_t)item * kn4 + g) * 4 : (g < 2 * kn4) ? e1 + ((size_t)item * kn4 + (g - kn4)) * 4 : e2 + ((size_t)item * n4 + (g - 2 * kn4)) * 4;
-        *reinterpret_cast<int4 *>(dst) = make_int4((int32_t)a[0] - (int32_t)(a[1] >> 1), (int32_t)(a[2] >> 2) - (int32_t)(a[3] >> 3),
-                                                   (int32_t)(a[4] >> 4) - (int32_t)(a[5] >> 5), (int32_t)(a[6] >> 6) - (int32_t)(a[7] >> 7));
+        const int32_t c0 = (int32_t)a[0] - (int32_t)(a[1] >> 1), c1 = (int32_t)(a[2] >> 2) - (int32_t)(a[3] >> 3), c2 = (int32_t)(a[4] >> 4) - (int32_t)(a[5] >> 5),
+                      c3 = (int32_t)(a[6] >> 6) - (int32_t)(a[7] >> 7);
+        if (g < kn4) *reinterpret_cast<int4 *>(r + ((size_t)item * kn4 + g) * 4) = make_int4(c0, c1, c2, c3);        // r feeds the transform: 32-bit words
+        else {
+            // e1, e2 (|value| <= eta) only meet ky_enc_finish_kernel: a signed byte each - these kernels are bandwidth-bound, and as 32-bit words the two
+            // noise vectors were 8 KB written and read back per operation
+            const uint32_t packed = ((uint32_t)c0 & 0xFFu) | (((uint32_t)c1 & 0xFFu) << 8) | (((uint32_t)c2 & 0xFFu) << 16) | ((uint32_t)c3 << 24);
+            if (g < 2 * kn4) reinterpret_cast<uint32_t *>(e1)[(size_t)item * kn4 + (g - kn4)] = packed;
+            else reinterpret_cast<uint32_t *>(e2)[(size_t)item * n4 + (g - 2 * kn4)] = packed;
+        }
     }
 }
 
@@ -65,14 +72,18 @@ __global__ void ky_enc_finish_kernel(const int32_t *u0, const int32_t *v0, const
     KY_ITEMS(item, count) {
         if (e < P.k * P.n) {
             const size_t i = (size_t)item * P.k * P.n + e;
-            const int4 a = *reinterpret_cast<const int4 *>(u0 + i), b = *reinterpret_cast<const int4 *>(e1 + i);
+            const int4 a = *reinterpret_cast<const int4 *>(u0 + i);
+            const uint32_t pb = reinterpret_cast<const uint32_t *>(e1)[i >> 2];        // four signed bytes (ky_binomial_kernel)
+            const int4 b = make_int4((int32_t)(int8_t)pb, (int32_t)(int8_t)(pb >> 8), (int32_t)(int8_t)(pb >> 16), (int32_t)(int8_t)(pb >> 24));
             *reinterpret_cast<int4 *>(u + i) = make_int4(ky_compress(a.x + b.x, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.y + b.y, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm),
                                                          ky_compress(a.z + b.z, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.w + b.w, P.d_u, (uint32_t)P.q, P.q_inv, P.q_norm));
         } else {
             const int j = e - P.k * P.n; const size_t i = (size_t)item * P.n + j;
             const uint32_t mb = m[(size_t)item * 32 + (j >> 3)];               // j is a multiple of 4: its four bits sit in one byte, most significant first
             const int32_t h = P.q >> 1;
-            const int4 a = *reinterpret_cast<const int4 *>(v0 + i), b = *reinterpret_cast<const int4 *>(e2 + i);
+            const int4 a = *reinterpret_cast<const int4 *>(v0 + i);
+            const uint32_t pb = reinterpret_cast<const uint32_t *>(e2)[i >> 2];
+            const int4 b = make_int4((int32_t)(int8_t)pb, (int32_t)(int8_t)(pb >> 8), (int32_t)(int8_t)(pb >> 16), (int32_t)(int8_t)(pb >> 24));
             const int32_t b0 = (mb & (0x80u >> (j & 7))) ? h : 0, b1 = (mb & (0x40u >> (j & 7))) ? h : 0, b2 = (mb & (0x20u >> (j & 7))) ? h : 0, b3 = (mb & (0x10u >> (j & 7))) ? h : 0;
             *reinterpret_cast<int4 *>(v + i) = make_int4(ky_compress(a.x + b0 + b.x, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.y + b1 + b.y, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm),
                                                          ky_compress(a.z + b2 + b.z, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm), ky_compress(a.w + b3 + b.w, P.d_v, (uint32_t)P.q, P.q_inv, P.q_norm));
@@ -518,7 +529,7 @@ static int ky_cpa_enc_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     HIPCHK(hipGetLastError());
     // the ephemeral secret r and the noise do not outlive the call (kyber_kem.c:1014, module_lwe.c:1397-1400)
     const size_t kb = batch * (size_t)k * N * 4;
-    HIPCHK(hipMemsetAsync(h->r, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e1, 0, kb, s)); HIPCHK(hipMemsetAsync(h->yh, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e2, 0, batch * N * 4, s));
+    HIPCHK(hipMemsetAsync(h->r, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e1, 0, kb / 4, s)); HIPCHK(hipMemsetAsync(h->yh, 0, kb, s)); HIPCHK(hipMemsetAsync(h->e2, 0, batch * N, s));      // (e1, e2: bytes)
     return SC_HIP_SUCCESS;
 }
 
@@ -817,6 +828,8 @@ extern "C" int sc_hip_kyber_keygen(sc_hip_kyber_t *h, size_t batch, const uint8_
     // the stored NTT forms are in the reference's natural order, centred (kyber_kem.c:648-651, module_lwe.c:1256)
     if (sc_hip_ntt_fwd(h->plan, batch * (size_t)k, h->r, d_s_ntt, s) || sc_hip_center(h->plan, batch * kn, d_s_ntt, d_s_ntt, s)) return SC_HIP_FAILURE;
     if (sc_hip_ntt_fwd(h->plan, batch * (size_t)k, d_t, d_t_ntt, s) || sc_hip_center(h->plan, batch * kn, d_t_ntt, d_t_ntt, s)) return SC_HIP_FAILURE;
+    // s, e and NTT(s) in the handle's scratch do not outlive the call (the encryption path, whose e1 / e2 are bytes, wipes only what it wrote)
+    HIPCHK(hipMemsetAsync(h->r, 0, batch * kn * 4, s)); HIPCHK(hipMemsetAsync(h->e1, 0, batch * kn * 4, s)); HIPCHK(hipMemsetAsync(h->yh, 0, batch * kn * 4, s));
     HIPCHK(hipStreamSynchronize(s));                                   // the scoped temporaries are released on return
     return SC_HIP_SUCCESS;
 }
