@@ -392,6 +392,7 @@ struct sc_hip_kyber {
     bool have_pub, have_priv;
     uint32_t *d_A, *d_t, *d_s;            // internal order, Montgomery form: A^T-ready [k][k], t [1][k], s [1][k]
     uint32_t *d_As;                       // the same A^T rows with t as row k, plain values | Shoup companions (dil_yaw_kernel: u0 | v0 in one launch)
+    uint32_t *d_Ss;                       // s as a 1 x k matrix in that form (decryption's s . u the same way)
     size_t cap;
     int32_t *r, *e1, *e2, *u0, *v0;
     uint32_t *yh;
@@ -448,7 +449,7 @@ extern "C" int sc_hip_kyber_create(sc_hip_ctx_t *ctx, const sc_hip_kyber_params_
 extern "C" void sc_hip_kyber_destroy(sc_hip_kyber_t *h)
 {
     if (!h) return;
-    void *ptrs[] = { h->d_As, h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv, h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
+    void *ptrs[] = { h->d_As, h->d_Ss, h->d_A, h->d_t, h->d_s, h->r, h->e1, h->e2, h->u0, h->v0, h->yh, h->d_gstate, h->d_gtail, h->krd, h->noise, h->mbuf, h->ku, h->kv, h->pk_gen, h->pk_A, h->pk_t, h->pk_s };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -501,6 +502,17 @@ extern "C" int sc_hip_kyber_set_privkey(sc_hip_kyber_t *h, const int32_t *s_ntt)
 {
     if (!h || !s_ntt) return fail("kyber_set_privkey: null argument");
     if (ky_load(h, s_ntt, (size_t)h->P.k, &h->d_s, 0, 0)) return SC_HIP_FAILURE;
+    {
+        const size_t words = (size_t)h->P.k * N;
+        DevBuf tb;
+        if (tb.get(words * 4)) return SC_HIP_FAILURE;
+        if (!h->d_Ss) HIPCHK(hipMalloc((void **)&h->d_Ss, 2 * words * 4));
+        HIPCHK(sc::copy_in(tb.as<int32_t>(), s_ntt, words * 4));
+        hipLaunchKernelGGL(dil_to_internal_shoup, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, nullptr, tb.as<int32_t>(), h->d_Ss, h->d_Ss + words, (size_t)h->P.k, h->plan->k[1]);
+        const bool ok = hipDeviceSynchronize() == hipSuccess;
+        (void)hipMemset(tb.as<int32_t>(), 0, words * 4);                   // the staging copy of the secret key
+        if (!ok) return fail("kyber_set_privkey: kernel failed");
+    }
     h->have_priv = true;
     return SC_HIP_SUCCESS;
 }
@@ -586,11 +598,19 @@ static int ky_cpa_dec_core(sc_hip_kyber *h, const KyKeys &K, size_t batch, const
     const size_t nu = batch * (size_t)k * N;
     hipLaunchKernelGGL(ky_decompress_kernel, dim3((unsigned)((nu + 255) / 256)), dim3(256), 0, s, d_u, h->r, nu, P.d_u, P.q);
     HIPCHK(hipGetLastError());
-    DilNtt a = mlwe_base_args(h->plan, 1, k, 1 << 20);
-    a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
-    if (K.nat ? mlwe_launch<DOP_KEYPREP>(h->ctx, a, B, k, s) : mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
-    a.key = K.s; a.key_item_stride = K.st; a.w = h->v0; a.w1 = nullptr; a.key_nat = K.nat ? 1 : 0;
-    if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
+    bool fused = false;
+    if (K.s == h->d_s && K.st == 0 && !K.nat && h->d_Ss && k >= 2 && k <= 5) {     // the handle's own key: NTT(u) -> s . NTT(u) -> INTT in one launch (as ky_cpa_enc_core)
+        DilNtt a = mlwe_base_args(h->plan, 1, k, 1 << 20);
+        a.in = h->r; a.key = h->d_Ss; a.keyp = h->d_Ss + (size_t)k * N; a.w = h->v0; a.w1 = nullptr; a.w_chunked = 0;
+        fused = mlwe_launch_yaw(h->ctx, a, B, s) == SC_HIP_SUCCESS;
+    }
+    if (!fused) {
+        DilNtt a = mlwe_base_args(h->plan, 1, k, 1 << 20);
+        a.in = h->r; a.out_int = h->yh; a.yh = h->yh;
+        if (K.nat ? mlwe_launch<DOP_KEYPREP>(h->ctx, a, B, k, s) : mlwe_launch<DOP_FWD_INT>(h->ctx, a, B, k, s)) return SC_HIP_FAILURE;
+        a.key = K.s; a.key_item_stride = K.st; a.w = h->v0; a.w1 = nullptr; a.key_nat = K.nat ? 1 : 0;
+        if (mlwe_launch<DOP_MATVEC>(h->ctx, a, B, 1, s)) return SC_HIP_FAILURE;
+    }
     hipLaunchKernelGGL(ky_dec_finish_kernel, dim3((unsigned)((batch * 32 + 255) / 256)), dim3(256), 0, s, d_v, h->v0, d_m, B, P);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(h->v0, 0, batch * N * 4, s));                   // s . u: with v it is the plaintext
