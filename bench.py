@@ -661,6 +661,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='only the contract line (profiling runs)')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--no-spin', action='store_true', help='leave the runtime\'s host-thread scheduling at its default (the bench asks it to spin in synchronisations)')
     ap.add_argument('--no-live-pmc', action='store_true', help='scheme rooflines from the committed counter pass instead of rocprofv3 child processes of this run')
     args = ap.parse_args()
 
@@ -677,6 +678,21 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the engine has no CPU fallback')
     torch.cuda.set_device(local_rank)
+    if not args.no_spin:
+        # the timed region is K ~35 us kernels (0.7 ms at the driver's K = 20) bracketed by synchronisations: a host thread that sleeps in them adds its wake-up
+        # latency to every figure (a box with a slow host gave 2.9 G NTT/s from the same 34 us kernel); ask the runtime to spin instead
+        try:
+            import ctypes
+            hip = None
+            for name in ('libamdhip64.so.7', 'libamdhip64.so.6', 'libamdhip64.so'):
+                try:
+                    hip = ctypes.CDLL(name); break
+                except OSError:
+                    continue
+            if hip is not None:
+                hip.hipSetDeviceFlags(ctypes.c_uint(1))        # hipDeviceScheduleSpin
+        except Exception:
+            pass
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
