@@ -25,7 +25,7 @@
  *     device workspace its batched calls use, so calls on ONE handle must not overlap in time - give each host thread /
  *     stream its own handle (they are cheap next to a batch); sc_hip_last_error is per thread
  *   - a batched call may run parts of its work on streams of the handle's own beside the caller's (the calls with a key per item do: independent
- *     per-key chains, forked and joined by events inside the call; Falcon verification runs its hash to the ring beside its unpacking and product); everything it does is ordered after what the caller queued on `stream`
+ *     per-key chains, forked and joined by events inside the call); everything it does is ordered after what the caller queued on `stream`
  *     before the call and before what the caller queues after it, as if it ran on `stream` alone.  Rejection loops (sign calls) read one
  *     4-byte counter per round back to the host, so those calls return with most of their work done
  *   - device memory that held key material, masks, noise or CSPRNG output is zeroed before it is freed, and the per-call secrets of

@@ -1752,7 +1752,6 @@ struct sc_hip_falcon {
     int32_t *c, *s1, *s2;
     uint32_t *status, *siglens;
     sc::Workspace srt;           // sc_hip_falcon_sign_keys with the keys of the batch interleaved: the batch regrouped by key (fal_sign_grouped)
-    hipStream_t side; hipEvent_t ev_fork, ev_join;   // verification: the hash to the ring (a quarter of the chip's SIMDs for most of the call) runs beside the unpacking and the product
 };
 
 static void fal_free_ws(sc_hip_falcon *f)
@@ -1833,9 +1832,6 @@ extern "C" int sc_hip_falcon_set_variant(sc_hip_falcon_t *f, int spw, int lm)
 extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
 {
     if (!f) return;
-    if (f->side) { (void)hipStreamSynchronize(f->side); (void)hipStreamDestroy(f->side); }
-    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
-    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     fal_free_ws(f);
     f->srt.release();
     void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
@@ -2299,17 +2295,9 @@ static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_k
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    // the hash writes c only; it starts at once on the handle's side stream and is joined in front of fal_vfinish_kernel
-    if (!f->side) { HIPCHK(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming)); }
-    HIPCHK(hipEventRecord(f->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(f->side, f->ev_fork, 0));
-    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, f->side, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, f->side, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
-    const hipError_t herr = hipGetLastError();
-    HIPCHK(hipEventRecord(f->ev_join, f->side));
-    struct Join { hipStream_t s; hipEvent_t e; bool done; ~Join() { if (!done) (void)hipStreamWaitEvent(s, e, 0); } } join{ s, f->ev_join, false };   // every exit path leaves the caller's stream joined
-    HIPCHK(herr);
     hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (d_key_of) {                                                    // the public keys of the batch, gathered into the (otherwise idle) sampler workspace
         int32_t *rows = reinterpret_cast<int32_t *>(f->ws);
@@ -2317,7 +2305,6 @@ static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_k
         HIPCHK(hipGetLastError());
         if (sc_hip_polymul_ntt(f->plan, batch, f->s2, rows, f->s1, s)) return SC_HIP_FAILURE;
     } else if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
-    HIPCHK(hipStreamWaitEvent(s, f->ev_join, 0)); join.done = true;
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
