@@ -1200,15 +1200,17 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
 #undef SC_CFIN
             HIPCHK(hipGetLastError());
         }
+        // the last queued round's slots (every earlier round's were zeroed by its successor's surplus workgroups) - in front of the look at the count, not behind
+        // it: the call usually ends here, and the zeroing then runs while the host waits for the count instead of after it has woken up (a round that follows
+        // finds its predecessor's slots zeroed twice)
+        hipLaunchKernelGGL(dil_wipe_kernel, dim3(cap < 4096u ? cap : 4096u), dim3(256), 0, s, d->rs, d->y, (uint32_t)(l * P.n), d->w, (uint32_t)(k * P.n), yh_wipe);
+        HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, d->cnt, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         left = cnt;
         todo = 1;
     }
-    // the last round's slots (every earlier round's were zeroed by its successor's surplus workgroups)
-    hipLaunchKernelGGL(dil_wipe_kernel, dim3(cap < 4096u ? cap : 4096u), dim3(256), 0, s, d->rs, d->y, (uint32_t)(l * P.n), d->w, (uint32_t)(k * P.n), yh_wipe);
-    HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
 
