@@ -169,7 +169,7 @@ __global__ void ens_unpack_kernel(uint32_t batch, const uint8_t *ct, size_t ct_s
 // One workgroup (n threads) per operation.
 __global__ void ens_dec_finish_kernel(const int32_t *gt, const uint32_t *inv_g, uint8_t *keys, size_t key_stride, int n, int32_t q)
 {
-    __shared__ uint32_t xs[32], bs[32], outw[32];
+    __shared__ uint32_t xs[32], bs[32], outw[32], sb[32 * 33];
     const uint32_t i = blockIdx.x;
     const int tid = threadIdx.x, W = n / 32;
     int32_t v = gt[(size_t)i * n + tid] % q;
@@ -182,13 +182,18 @@ __global__ void ens_dec_finish_kernel(const int32_t *gt, const uint32_t *inv_g, 
     }
     if (tid < W) bs[tid] = inv_g[tid];
     __syncthreads();
+    // the 32 bit-shifts of b, once per workgroup (32 W words: n threads build one word each, W = n / 32): the n rotations a workgroup needs are these rows
+    // read at a word offset, so the inner loop is two reads, an AND and an XOR per word instead of a funnel shift over two reads of b
+    {
+        const int sh = tid & 31, j = tid >> 5;                             // sb[sh][j] = word j of (b rotated right by sh bits)
+        const uint32_t w0 = bs[j], w1 = bs[(j - 1) & (W - 1)];
+        sb[sh * (W + 1) + j] = sh ? ((w1 << (32 - sh)) | (w0 >> sh)) : w0;                  // (rows W + 1 apart: the 32 rows a wavefront reads sit on distinct banks)
+    }
+    __syncthreads();
     const int s = tid + 1, ws = (s >> 5) & (W - 1), bsft = s & 31;     // rotate right by s = tid + 1 positions (W = n / 32 is a power of two: the
     uint32_t acc = 0;                                                  // three runtime modulo operations per word were 90 % of this kernel's instructions)
-    for (int j = 0; j < W; j++) {
-        const int j0 = (j - ws) & (W - 1), j1 = (j0 - 1) & (W - 1);
-        const uint32_t word = bsft ? ((bs[j1] << (32 - bsft)) | (bs[j0] >> bsft)) : bs[j0];
-        acc ^= xs[j] & word;
-    }
+    const uint32_t *row = sb + bsft * (W + 1);
+    for (int j = 0; j < W; j++) acc ^= xs[j] & row[(j - ws) & (W - 1)];
     const uint32_t bit = (uint32_t)__builtin_popcount(acc) & 1u;
     const unsigned long long om = __ballot(bit);
     if ((tid & 63) == 0) {
