@@ -113,7 +113,9 @@ __global__ __launch_bounds__(HT) void ens_sample_kernel(uint32_t batch, const ui
             const bool good = (okm >> it) & 1;
             for (int k4 = threadIdx.x; k4 < n / 4; k4 += HT) {
                 const uint32_t v = good ? rows[it * RS + k4] : 0u;
-                reinterpret_cast<int4 *>(dst + (size_t)(base + it) * n)[k4] = make_int4((int32_t)(int8_t)v, (int32_t)(int8_t)(v >> 8), (int32_t)(int8_t)(v >> 16), (int32_t)(int8_t)(v >> 24));
+                // r feeds the transform as 32-bit words; e only meets ens_enc_finish_kernel and stays four signed bytes per word (a quarter of the traffic)
+                if (which) reinterpret_cast<uint32_t *>(e)[(size_t)(base + it) * (n / 4) + k4] = v;
+                else reinterpret_cast<int4 *>(dst + (size_t)(base + it) * n)[k4] = make_int4((int32_t)(int8_t)v, (int32_t)(int8_t)(v >> 8), (int32_t)(int8_t)(v >> 16), (int32_t)(int8_t)(v >> 24));
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -132,14 +134,18 @@ __global__ void ens_enc_finish_kernel(uint32_t batch, const int32_t *hr, const i
     if (i >= batch || status[i] != 1) return;
     const sc::FastMod modq((uint32_t)q);
     uint64_t acc = 0; uint32_t kb = 0;
+    const uint32_t e4 = reinterpret_cast<const uint32_t *>(e)[(size_t)i * per + gq];       // the four noise values of this group as signed bytes (ens_sample_kernel)
+    const int4 h4 = *reinterpret_cast<const int4 *>(hr + (size_t)i * n + 4 * gq);
+    const int32_t hv[4] = { h4.x, h4.y, h4.z, h4.w };
+#pragma unroll
     for (int k = 0; k < 4; k++) {
-        const size_t idx = (size_t)i * n + 4 * gq + k;
-        int32_t v = hr[idx];
+        const int32_t ek = (int32_t)(int8_t)(e4 >> (8 * k));
+        int32_t v = hv[k];
         if (v > q / 2) v -= q;
-        v = 2 * v + e[idx];                                        // |v| <= q + 12: + 2q makes it an unsigned operand
+        v = 2 * v + ek;                                            // |v| <= q + 12: + 2q makes it an unsigned operand
         v = (int32_t)modq((uint32_t)v + 2u * (uint32_t)q);
         acc = (acc << q_bits) | (uint64_t)(uint32_t)v;
-        kb = (kb << 1) | (uint32_t)(e[idx] & 1);
+        kb = (kb << 1) | (uint32_t)(ek & 1);
     }
     const int nbytes = 4 * q_bits / 8;                             // 7 for 14-bit coefficients
     uint8_t *o = ct + (size_t)i * ct_stride + (size_t)gq * nbytes;
