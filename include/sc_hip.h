@@ -280,6 +280,13 @@ size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *h);
 int sc_hip_bliss_sign(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* sc_hip_bliss_sign with the reference's default CSPRNG inside the call (csrc/drbg.hip): message i draws from the AES-256 CTR-DRBG the reference makes of
+ * d_seeds row i (prng_create / create_csprng with user entropy: src/utils/crypto/prng.c:963-1107, ctr_drbg.c:37-197), read as bliss_b_sign reads
+ * sc->prng_ctx[0] (bliss_b.c:1372-1373).  Words are expanded on the device only as far as a message's attempts get and zeroed behind the call; the
+ * signatures equal sc_hip_bliss_sign's over sc_hip_drbg_words(seeds) rows.  d_status 2: more than 26 attempts (p ~ 1e-12). */
+int sc_hip_bliss_sign_seeded(sc_hip_bliss_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                             const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                             uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
 /* how many CSPRNG words the reference has drawn from sc->prng_ctx[0] when the `attempts`-th attempt of a signature ends (prng.c:963-1048: 4n words per fresh
  * attempt - every other one - and 1 + 27 + 26 reservoir bits per attempt, a word whenever the reservoir runs short): the tape length a signature of that many
  * attempts needs.  Host arithmetic; no device is touched. */
@@ -352,6 +359,11 @@ size_t sc_hip_tesla_sig_bytes(const sc_hip_tesla_t *h);        /* n*q_bits/8 + 6
 int sc_hip_tesla_sign(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                       uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+/* the same with the CSPRNG inside the call: the masks of message i come straight out of the AES-256 CTR-DRBG seeded with d_seeds row i
+ * (ring_tesla.c:818-822 reads sc->prng_ctx[0] through prng_32); no tape exists and none can run out */
+int sc_hip_tesla_sign_seeded(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                             const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                             uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
 /* replaces: safecrypto_verify -> ring_tesla_verify (ring_tesla.c:922-1040); d_verdicts[i] = 0 valid / 1 invalid */
 int sc_hip_tesla_verify(sc_hip_tesla_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                         const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
@@ -513,6 +525,11 @@ int sc_hip_falcon_sample(sc_hip_falcon_t *h, size_t batch, const int32_t *d_c, c
 int sc_hip_falcon_sign(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                        const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
+/* the same with the CSPRNG inside the call: the 4n pool words of signature i are expanded on the device from d_seeds row i (AES-256 CTR-DRBG as the
+ * reference seeds it, see sc_hip_bliss_sign_seeded; falcon.c:808-935 draws through gpv.c:2671-2686) and zeroed behind the call */
+int sc_hip_falcon_sign_seeded(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                              const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                              uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);
 int sc_hip_falcon_sign_keys(sc_hip_falcon_t *h, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                             const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                             uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream);

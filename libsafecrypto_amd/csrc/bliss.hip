@@ -939,6 +939,8 @@ struct sc_hip_bliss {
     uint32_t *d_huff;            // the two code tables and their decoding orders, one allocation
     HuffT ht[2];
     double tie_rel;              // accept / reject draws closer to the threshold than this (relative) are reported, not decided: status 5
+    // sc_hip_bliss_sign_seeded: the batch's CSPRNG word tapes, expanded from the caller's seeds as far as the attempts get (rows of seed_words words)
+    uint32_t *seed_tape, *seed_list; size_t seed_rows, seed_words;
 };
 
 static void bl_free_ws(sc_hip_bliss *b)
@@ -1076,6 +1078,8 @@ extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
     if (!b) return;
     bl_free_ws(b);
     bl_free_ws2(b);
+    if (b->seed_tape) (void)sc::wipe_free(b->seed_tape);
+    if (b->seed_list) (void)hipFree(b->seed_list);
     if (b->d_f) (void)sc::wipe_free(b->d_f);
     if (b->d_g) (void)sc::wipe_free(b->d_g);
     if (b->d_a) (void)sc::wipe_free(b->d_a);
@@ -1116,7 +1120,8 @@ extern "C" size_t sc_hip_bliss_sig_bytes(const sc_hip_bliss_t *b)
 // one key for the batch (kf / kg / ka16 null: the handle's), or a key per message: kf, kg, ka16 = SINT16 [batch][n] rows as sc_hip_bliss_keygen writes them
 static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
                         const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream);
+                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream,
+                        const uint8_t *d_seeds = nullptr, size_t seed_stride = 0, size_t seed_len = 0);
 
 extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                  const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
@@ -1125,6 +1130,22 @@ extern "C" int sc_hip_bliss_sign(sc_hip_bliss_t *b, size_t batch, const uint8_t 
     if (!b) return fail("bliss_sign: null handle");
     if (!b->have_key || !b->d_f) return fail("bliss_sign: no private key loaded");
     return bl_sign_core(b, nullptr, nullptr, nullptr, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream);
+}
+
+// sc_hip_bliss_sign with the CSPRNG inside the call: message i signs with the generator the reference makes of seed i (AES-256 CTR-DRBG as create_csprng /
+// prng_create instantiate it: src/utils/crypto/prng.c:963-1107, ctr_drbg.c:37-197), read through prng_32 / prng_64 / prng_var exactly as bliss_b_sign reads
+// sc->prng_ctx[0] (bliss_b.c:1372-1373, sampling.c:211-228).  The words are expanded on the device as far as a message's attempts get: 4n + a few for the
+// first pair of attempts of every message, the later pairs' only for the messages that fail both.  Byte-identical to sc_hip_bliss_sign over
+// sc_hip_drbg_words(seeds, ...) rows; a message that would need more than 26 attempts (p ~ 1e-12) ends with status 2.
+extern "C" int sc_hip_bliss_sign_seeded(sc_hip_bliss_t *b, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                        const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!b) return fail("bliss_sign_seeded: null handle");
+    if (!b->have_key || !b->d_f) return fail("bliss_sign_seeded: no private key loaded");
+    if (!d_seeds) return fail("bliss_sign_seeded: null seed buffer");
+    return bl_sign_core(b, nullptr, nullptr, nullptr, batch, d_msgs, msg_stride, d_mlens, fixed_len, nullptr, 0, nullptr, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream,
+                        d_seeds, seed_stride, seed_len);
 }
 
 // replaces: safecrypto_sign -> bliss_b_sign for a batch of messages EACH under its own key pair (distinct keys)
@@ -1147,6 +1168,8 @@ struct BlRun {
 struct BlIn {
     const int16_t *kf, *kg, *ka16; const uint8_t *msgs; size_t msg_stride; const uint32_t *mlens; uint32_t fixed_len;
     const uint32_t *tapes; size_t tape_stride; const uint32_t *tape_lens;
+    // seeded call (sc_hip_bliss_sign_seeded): `tapes` is the handle's own buffer, filled from these seeds as the passes need it
+    const uint8_t *seeds = nullptr; size_t seed_stride = 0, seed_len = 0;
 };
 
 // several arrays zeroed by one launch (a hipMemsetAsync each costs a launch gap of its own: seven in front of a signing call, four behind each pass)
@@ -1355,12 +1378,33 @@ static int bl_wipe_vectors(sc_hip_bliss_t *b, size_t batch, hipStream_t s)
     return bl_zero(b, { { b->tu, batch * 2 * n * 4 }, { b->tin, batch * n * 4 }, { b->v, batch * n * 4 }, { b->z, batch * n * 2 } }, s);
 }
 
+// the later pairs of a seeded call reach at most this many attempts on the handle's own tape rows (a message needs more with probability ~0.12^13; it ends with status 2)
+constexpr unsigned BL_SEED_ATTEMPTS = 2 + 2 * 4 * 3;
+
 static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg, const int16_t *ka16, size_t batch, const uint8_t *d_msgs, size_t msg_stride,
                         const uint32_t *d_mlens, uint32_t fixed_len, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream,
+                        const uint8_t *d_seeds, size_t seed_stride, size_t seed_len)
 {
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 2048) return fail("bliss_sign: batch too large");
+    const bool seeded = d_seeds != nullptr;
+    if (seeded) {
+        // Seeded call: the tape rows are the handle's own, filled from the seeds as far as the passes below consume them - the first pair of attempts of every
+        // message, then the later pairs of the messages that get that far (a tape position does not depend on any value, see ResSim) - and zeroed behind the call.
+        if (seed_len == 0 || seed_len > seed_stride || seed_len > 0xffffffffu) return fail("bliss_sign_seeded: bad seed length / stride");
+        HIPCHK(hipSetDevice(b->ctx->device));
+        const size_t words = (sc_hip_bliss_tape_words(b->P.n, BL_SEED_ATTEMPTS) + 3) & ~(size_t)3;
+        if (batch > b->seed_rows || words != b->seed_words) {
+            if (b->seed_tape) (void)sc::wipe_free(b->seed_tape);
+            if (b->seed_list) (void)hipFree(b->seed_list);
+            b->seed_tape = b->seed_list = nullptr; b->seed_rows = 0;
+            HIPCHK(hipMalloc((void **)&b->seed_tape, batch * words * 4));
+            HIPCHK(hipMalloc((void **)&b->seed_list, batch * 4));
+            b->seed_rows = batch; b->seed_words = words;
+        }
+        d_tapes = b->seed_tape; tape_stride = words; d_tape_lens = nullptr;
+    }
     if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("bliss_sign: null buffer");
     if (!d_mlens && fixed_len == 0) return fail("bliss_sign: empty messages are rejected by the reference's oracle (bliss_b.c:571-574)");
     if (sig_stride < sc_hip_bliss_sig_bytes(b)) return fail("bliss_sign: sig_stride smaller than sc_hip_bliss_sig_bytes()");
@@ -1376,8 +1420,19 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     if (bl_zero(b, { { st.pos, batch * 4 }, { st.var_buf, batch * 4 }, { st.var_bits, batch * 4 }, { st.iter, batch * 4 }, { st.cur, batch * 4 }, { st.status, batch * 4 } }, s))
         return SC_HIP_FAILURE;
     HIPCHK(hipMemsetAsync(trials, 0, batch * 4, s));               // (the caller's array: any alignment)
-    const BlIn in{ kf, kg, ka16, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens };
+    BlIn in{ kf, kg, ka16, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens };
+    in.seeds = d_seeds; in.seed_stride = seed_stride; in.seed_len = seed_len;
     const bool spec = b->speculate != 0;
+    // seeded: blocks (16 bytes = 4 words) of every row filled so far, of the rows of the later passes (seed_list[0..seed_nu)), and whether some rows were filled whole
+    size_t blk_all = 0, blk_later = 0; uint32_t seed_nu = 0; bool seed_whole = false;
+    auto seed_fill = [&](const uint32_t *list, uint32_t count, size_t from, size_t to) -> int {
+        return sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, list, count, nullptr, b->seed_tape, tape_stride * 4, from, to, 1, false, s);
+    };
+    if (seeded) {
+        blk_all = spec ? (sc_hip_bliss_tape_words(P.n, 2) + 3) / 4 : tape_stride / 4;      // the plain loop's consumption is not known in advance: whole rows
+        if (seed_fill(nullptr, B, 0, blk_all)) return SC_HIP_FAILURE;
+        blk_later = blk_all;
+    }
     bool dirty = true;                                                // the handle's vector arrays hold this call's secrets
     bool status_out = false;                                          // the caller's status array holds the final statuses
     // every message: its first pair of attempts (all of them when the handle runs the plain loop)
@@ -1413,6 +1468,13 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
                 sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);
             }
             const uint32_t nv = nu * pp;
+            if (seeded) {
+                // the words these pairs draw, for the messages that go on (every later pass works on a subset of the first one's list)
+                if (p0 == 1) { HIPCHK(hipMemcpyAsync(b->seed_list, ulist, (size_t)nu * 4, hipMemcpyDeviceToDevice, s)); seed_nu = nu; }
+                size_t to = ((size_t)sim.pos + 3) / 4;
+                if (to > tape_stride / 4) to = tape_stride / 4;
+                if (to > blk_later) { if (seed_fill(ulist, nu, blk_later, to)) return SC_HIP_FAILURE; blk_later = to; }
+            }
             if (bl_ensure_ws2(b, nv, sig_stride)) return SC_HIP_FAILURE;
             St v = b->st2;
             hipLaunchKernelGGL(bl_pair_init_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, ulist, nu, pp, pi, v, b->msg_of2, d_tapes, tape_stride, d_tape_lens, b->siglens2, b->trials2);
@@ -1433,6 +1495,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             uint32_t *redo = b->act[1];                                // (the round loop's first round reads this list and writes act[0]; later rounds alternate)
             hipLaunchKernelGGL(bl_reset_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, redo, n8, st);
             HIPCHK(hipGetLastError());
+            if (seeded) { if (seed_fill(redo, n8, 0, tape_stride / 4)) return SC_HIP_FAILURE; seed_whole = true; }
             if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, n8, redo, 0u }, in, s)) return SC_HIP_FAILURE;
             dirty = true; status_out = false;
         }
@@ -1461,6 +1524,15 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     // the Gaussian vectors t, u (with the signature they give s), their products and the unpacked candidates do not outlive the call
     // (zeroed as far as this batch used them: the arrays are sized for the largest batch the handle has seen)
     if (dirty && bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
+    if (seeded) {
+        // the expanded CSPRNG words are per-call secrets like the vectors: zeroed as far as they were written
+        if (seed_whole) HIPCHK(hipMemsetAsync(b->seed_tape, 0, batch * tape_stride * 4, s));
+        else {
+            if (sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, nullptr, B, nullptr, b->seed_tape, tape_stride * 4, 0, blk_all, 1, true, s)) return SC_HIP_FAILURE;
+            if (seed_nu && blk_later > blk_all &&
+                sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, b->seed_list, seed_nu, nullptr, b->seed_tape, tape_stride * 4, blk_all, blk_later, 1, true, s)) return SC_HIP_FAILURE;
+        }
+    }
     return SC_HIP_SUCCESS;
 }
 

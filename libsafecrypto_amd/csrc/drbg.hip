@@ -74,21 +74,32 @@ const DrbgConst &drbg_const()
 
 namespace {
 
-// out row i = the first nblk 16-byte blocks of generator i's stream; words != 0: in prng_32 order (w1, w0, w3, w2 per block)
-__global__ __launch_bounds__(256) void drbg_expand_kernel(uint32_t batch, const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len,
-                                                          uint8_t *__restrict__ out, size_t out_stride, uint32_t nblk, int words, DrbgConst C)
+// Blocks [b0, b1) of the streams of `count` generators (rows `list[0..count)`, or rows 0..count-1; count_dev: the count lives on the device and `count`
+// bounds it), 2^lg lanes per generator.  CTR mode: block b of a stream is AES_key(counter0 + b) whatever came before it, so the lanes of a generator take
+// blocks b0 + j, b0 + j + G, ... after each has run the (same) key schedule - a lane-per-generator walk of a 16 KB Falcon tape is 1024 sequential AES blocks
+// on 128 wavefronts; with G = 32 it is 32 blocks per lane on 4096 wavefronts, and the G lanes of a generator write 16 G contiguous bytes per step.
+// words != 0: prng_32 order (w1, w0, w3, w2 per block), else prng_mem's byte order.  zero != 0: the same walk storing zeros (the wipe behind a seeded call).
+__global__ __launch_bounds__(256) void drbg_fill_kernel(uint32_t count, const uint32_t *__restrict__ count_dev, const uint32_t *__restrict__ list,
+                                                        const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len,
+                                                        uint8_t *__restrict__ out, size_t out_stride, uint32_t b0, uint32_t b1, uint32_t lg, int words, int zero, DrbgConst C)
 {
     __shared__ AesLdsWide L;
-    L.fill(C);
-    __syncthreads();
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= batch) return;
+    if (!zero) { L.fill(C); __syncthreads(); }
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, G = 1u << lg;
+    const uint32_t gen = t >> lg, j = t & (G - 1);
+    uint32_t cnt = count;
+    if (count_dev) { const uint32_t c = *count_dev; cnt = c < count ? c : count; }
+    if (gen >= cnt) return;
+    const uint32_t row = list ? list[gen] : gen;
+    uint4 *o = reinterpret_cast<uint4 *>(out + (size_t)row * out_stride);
+    if (zero) { for (uint32_t b = b0 + j; b < b1; b += G) o[b] = make_uint4(0, 0, 0, 0); return; }
     Drbg d;
-    d.init(seeds + (size_t)i * seed_stride, seed_len, C, L);
-    uint4 *o = reinterpret_cast<uint4 *>(out + (size_t)i * out_stride);
-    for (uint32_t b = 0; b < nblk; b++) {
+    d.init(seeds + (size_t)row * seed_stride, seed_len, C, L);
+    d.counter += b0 + j;
+    for (uint32_t b = b0 + j; b < b1; b += G) {
         uint32_t w[4];
         d.block(w, L);
+        d.counter += G - 1;
         o[b] = words ? make_uint4(w[1], w[0], w[3], w[2]) : make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
@@ -128,11 +139,7 @@ int run_expand(sc_hip_ctx *ctx, size_t batch, const uint8_t *d_seeds, size_t see
     if ((nbytes & 15) != 0 || out_stride < nbytes || (out_stride & 15) != 0 || ((uintptr_t)d_out & 15) != 0)
         return fail(std::string(who) + ": output rows must be 16-byte aligned multiples of 16 bytes");
     if (batch > 0x7fffffffu || nbytes / 16 > 0xffffffffu) return fail(std::string(who) + ": too large");
-    HIPCHK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(drbg_expand_kernel, dim3((unsigned)((batch + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint32_t)batch, d_seeds, seed_stride, (uint32_t)seed_len,
-                       (uint8_t *)d_out, out_stride, (uint32_t)(nbytes / 16), words, sc::drbg_const());
-    HIPCHK(hipGetLastError());
-    return SC_HIP_SUCCESS;
+    return sc::drbg_fill(ctx, d_seeds, seed_stride, seed_len, nullptr, (uint32_t)batch, nullptr, d_out, out_stride, 0, nbytes / 16, words, false, (hipStream_t)stream);
 }
 
 }  // namespace
@@ -162,3 +169,22 @@ extern "C" int sc_hip_mlwe_expand_matrix(sc_hip_ctx_t *ctx, size_t nkeys, const 
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
+
+namespace sc {
+// see engine_internal.h
+int drbg_fill(sc_hip_ctx *ctx, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, const uint32_t *d_list, uint32_t count, const uint32_t *d_count,
+              void *d_out, size_t out_stride_bytes, size_t blk0, size_t blk1, int words, bool zero, hipStream_t s)
+{
+    if (count == 0 || blk1 <= blk0) return SC_HIP_SUCCESS;
+    if (blk1 > 0xffffffffu) return fail("drbg_fill: stream position too large");
+    // lanes per generator: enough to give every SIMD four wavefronts (the cipher is a chain of dependent table look-ups), not more than the blocks to make
+    const size_t nblk = blk1 - blk0, want = (size_t)ctx->cus * 4 * 4 * 64;
+    uint32_t lg = 0;
+    while (lg < 6 && ((size_t)count << lg) < want && ((size_t)2 << lg) <= nblk) lg++;
+    const size_t threads = (size_t)count << lg;
+    hipLaunchKernelGGL(drbg_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, count, d_count, d_list, d_seeds, seed_stride, (uint32_t)seed_len,
+                       (uint8_t *)d_out, out_stride_bytes, (uint32_t)blk0, (uint32_t)blk1, lg, words, zero ? 1 : 0, drbg_const());
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+}  // namespace sc

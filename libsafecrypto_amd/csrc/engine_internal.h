@@ -332,6 +332,15 @@ struct sc_hip_plan {
 };
 
 namespace sc {
+// The reference's CSPRNG for a SEEDED call (sc_hip_*_sign_seeded: message i signs with the generator create_csprng() would make of seed i - AES-256 CTR-DRBG,
+// csrc/drbg_dev.h - instead of a tape the caller filled): 16-byte blocks [blk0, blk1) of the streams of rows d_list[0..count) (null: rows 0..count-1; d_count:
+// the count on the device, `count` its bound) into d_out + row * out_stride_bytes + 16 * block; words != 0: prng_32 word order (the tape format).
+// zero: the same rows and blocks zeroed (the per-call secrets do not outlive the call).
+int drbg_fill(sc_hip_ctx *ctx, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, const uint32_t *d_list, uint32_t count, const uint32_t *d_count,
+              void *d_out, size_t out_stride_bytes, size_t blk0, size_t blk1, int words, bool zero, hipStream_t s);
+}
+
+namespace sc {
 int polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream);
 }
 

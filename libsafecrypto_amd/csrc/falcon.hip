@@ -1752,6 +1752,7 @@ struct sc_hip_falcon {
     int32_t *c, *s1, *s2;
     uint32_t *status, *siglens;
     sc::Workspace srt;           // sc_hip_falcon_sign_keys with the keys of the batch interleaved: the batch regrouped by key (fal_sign_grouped)
+    sc::Workspace stape;         // sc_hip_falcon_sign_seeded: the batch's CSPRNG word tapes, expanded from the caller's seeds for the length of the call
 };
 
 static void fal_free_ws(sc_hip_falcon *f)
@@ -1834,6 +1835,7 @@ extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
     if (!f) return;
     fal_free_ws(f);
     f->srt.release();
+    f->stape.release();
     void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(f->plan);
@@ -2065,6 +2067,30 @@ extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_
                                   const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
                                   uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
 { return fal_sign_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_status, stream); }
+
+// sc_hip_falcon_sign with the CSPRNG inside the call: message i signs with the generator the reference makes of seed i (prng_create(SC_ENTROPY_USER_PROVIDED ...,
+// SC_PRNG_AES_CTR_DRBG) seeded through the entropy callback, as create_csprng does: src/utils/crypto/prng.c:963-1107, ctr_drbg.c:37-197) read through prng_64 /
+// prng_32 (gpv.c:2671-2686 -> sampling.c).  The 4n pool words a signature draws are expanded from the seed on the device (csrc/drbg.hip) into the handle's
+// workspace, consumed by the same kernels as a caller's tape, and zeroed behind the call.  Signatures are byte-identical to sc_hip_falcon_sign over
+// sc_hip_drbg_words(seeds, 4n).
+extern "C" int sc_hip_falcon_sign_seeded(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                         const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream)
+{
+    if (fal_check_common(f, batch, "falcon_sign_seeded")) return SC_HIP_FAILURE;
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_seeds || seed_len == 0 || seed_len > seed_stride || seed_len > 0xffffffffu) return fail("falcon_sign_seeded: bad seed buffer / length / stride");
+    if (batch > 0x7fffffffu) return fail("falcon_sign_seeded: batch too large");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    const size_t words = 4 * (size_t)f->P.n;
+    if (f->stape.reserve(batch * words * 4)) return SC_HIP_FAILURE;
+    uint32_t *tapes = f->stape.take<uint32_t>(batch * words);
+    hipStream_t s = (hipStream_t)stream;
+    if (sc::drbg_fill(f->ctx, d_seeds, seed_stride, seed_len, nullptr, (uint32_t)batch, nullptr, tapes, words * 4, 0, words / 4, 1, false, s)) return SC_HIP_FAILURE;
+    const int rc = fal_sign_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, tapes, words, nullptr, d_sigs, sig_stride, d_siglens, d_status, stream);
+    f->stape.wipe(s);
+    return rc;
+}
 
 // replaces: safecrypto_sign -> falcon_sig_sign for a batch of messages EACH under one of the keys loaded with sc_hip_falcon_set_privkeys: d_key_of[i] = the key's index
 // (distinct keys).  d_status[i] = 6 for an index outside the key set.

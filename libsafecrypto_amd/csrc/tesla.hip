@@ -17,6 +17,8 @@
 // Salsa20 stream, one wavefront per message for the sparse products, the three tests and the packing.
 #include "engine_internal.h"
 #include "keccak_dev.h"
+#include "drbg_dev.h"
+namespace sc { const DrbgConst &drbg_const(); }
 
 #include <string.h>
 
@@ -84,6 +86,34 @@ __global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint3
         if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
         else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
         *dst = make_int4((int32_t)(w[0] & msk) - P.b, (int32_t)(w[1] & msk) - P.b, (int32_t)(w[2] & msk) - P.b, (int32_t)(w[3] & msk) - P.b);
+    }
+}
+
+// The same masks for a SEEDED call (sc_hip_tesla_sign_seeded): the n words of an attempt are blocks pos/4 .. pos/4 + n/4 - 1 of the message's own AES-256
+// CTR-DRBG stream (csrc/drbg_dev.h; prng_32 order: the words of a block come out as w1, w0, w3, w2), produced where they are consumed - no tape exists.
+// 32 lanes per slot: every lane runs the key schedule of its message's seed (a quarter of the cost of its n/128 blocks), then block j, j + 32, ...
+__global__ __launch_bounds__(256) void ts_y_seeded_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase,
+                                                          const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len, int32_t *y, TsP P, const uint32_t *rs, sc::DrbgConst C)
+{
+    __shared__ sc::AesLdsWide L;
+    L.fill(C);
+    __syncthreads();
+    if (rs) { nslots = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, slot = t >> 5, j = t & 31;
+    if (slot >= nslots) return;
+    int4 *dst = reinterpret_cast<int4 *>(y + (size_t)slot * P.n);
+    const uint32_t nblk = (uint32_t)P.n / 4;
+    if (need[slot] != 1) { for (uint32_t i = j; i < nblk; i += 32) dst[i] = make_int4(0, 0, 0, 0); return; }
+    const uint32_t aidx = slot / S, item = active ? active[aidx] : aidx;
+    const uint32_t msk = (1u << (P.b_bits + 1)) - 1u;
+    sc::Drbg d;
+    d.init(seeds + (size_t)item * seed_stride, seed_len, C, L);
+    d.counter += sbase[slot] / 4 + j;
+    for (uint32_t i = j; i < nblk; i += 32) {
+        uint32_t w[4];
+        d.block(w, L);
+        d.counter += 31;
+        dst[i] = make_int4((int32_t)(w[1] & msk) - P.b, (int32_t)(w[0] & msk) - P.b, (int32_t)(w[3] & msk) - P.b, (int32_t)(w[2] & msk) - P.b);
     }
 }
 
@@ -544,15 +574,21 @@ extern "C" int sc_hip_tesla_set_key(sc_hip_tesla_t *t, const int32_t *a1, const 
 extern "C" size_t sc_hip_tesla_sig_bytes(const sc_hip_tesla_t *t)
 { return t ? ((size_t)t->P.n * t->P.q_bits + 7) / 8 + 64 : 0; }
 
-extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
-                                 const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                                 uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                        const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream,
+                        const uint8_t *d_seeds, size_t seed_stride, size_t seed_len)
 {
     if (!t) return fail("tesla_sign: null handle");
     if (!t->have_priv) return fail("tesla_sign: no private key loaded");
     if (batch == 0) return SC_HIP_SUCCESS;
     if (batch > 0x7fffffffu / 2048) return fail("tesla_sign: batch too large");
-    if (!d_msgs || !d_tapes || !d_sigs || !d_siglens) return fail("tesla_sign: null buffer");
+    const bool seeded = d_seeds != nullptr;
+    if (seeded) {
+        if (seed_len == 0 || seed_len > seed_stride || seed_len > 0xffffffffu) return fail("tesla_sign_seeded: bad seed length / stride");
+        d_tape_lens = nullptr; tape_stride = 0xfffffff0u;                 // a generator does not run out (the 32-bit word position does, after 2^23 attempts)
+    }
+    if (!d_msgs || (!d_tapes && !seeded) || !d_sigs || !d_siglens) return fail("tesla_sign: null buffer");
     if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_sign: sig_stride smaller than sc_hip_tesla_sig_bytes()");
     if (tape_stride > 0xffffffffu) return fail("tesla_sign: tape too long");
     HIPCHK(hipSetDevice(t->ctx->device));
@@ -590,7 +626,9 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
             size_t yb = (ne / 4 + 255) / 256;                             // a lane per four coefficients; persistent beyond 16 workgroups per CU
             if (yb > (size_t)t->ctx->cus * 16) yb = (size_t)t->ctx->cus * 16;
             hipLaunchKernelGGL(ts_begin_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nslots, S, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, n, rs);
-            hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs);
+            if (seeded) hipLaunchKernelGGL(ts_y_seeded_kernel, dim3((unsigned)(((size_t)nslots * 32 + 255) / 256)), dim3(256), 0, s, active, nslots, S, t->need, t->sbase,
+                                           d_seeds, seed_stride, (uint32_t)seed_len, t->y, P, rs, sc::drbg_const());
+            else hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs);
             HIPCHK(hipGetLastError());
             // (a planned round's products run over the whole slot budget: rows past the round's slots hold what an earlier round left there and are read by nobody)
             if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
@@ -622,6 +660,26 @@ extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t 
         HIPCHK(hipGetLastError());
     }
     return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_tesla_sign(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                 const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                                 uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!d_tapes && batch) return fail("tesla_sign: null buffer");
+    return ts_sign_core(t, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream, nullptr, 0, 0);
+}
+
+// sc_hip_tesla_sign with the CSPRNG inside the call: message i draws its masks from the generator the reference makes of seed i (AES-256 CTR-DRBG,
+// src/utils/crypto/prng.c:963-1107, ctr_drbg.c:37-197; ring_tesla.c:818-822 reads it through prng_32).  The words of an attempt are produced by the kernel
+// that turns them into the mask (ts_y_seeded_kernel): nothing is expanded ahead and no tape exists.  Byte-identical to sc_hip_tesla_sign over
+// sc_hip_drbg_words(seeds, ...) rows that are long enough.
+extern "C" int sc_hip_tesla_sign_seeded(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                        const uint8_t *d_seeds, size_t seed_stride, size_t seed_len,
+                                        uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_trials, uint32_t *d_status, void *stream)
+{
+    if (!d_seeds && batch) return fail("tesla_sign_seeded: null seed buffer");
+    return ts_sign_core(t, batch, d_msgs, msg_stride, d_mlens, fixed_len, nullptr, 0, nullptr, d_sigs, sig_stride, d_siglens, d_trials, d_status, stream, d_seeds, seed_stride, seed_len);
 }
 
 extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,

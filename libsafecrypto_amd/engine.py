@@ -23,14 +23,14 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_set_entropy_bac', 'sc_hip_bliss_tape_words',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_sign_seeded', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_set_entropy_bac', 'sc_hip_bliss_tape_words',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_set_privkeys', 'sc_hip_falcon_set_pubkeys', 'sc_hip_falcon_sign_keys', 'sc_hip_falcon_verify_keys', 'sc_hip_falcon_sig_bytes',
-    'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
+    'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_sign_seeded', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
     'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
-    'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_verify',
+    'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_sign_seeded', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
     'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey', 'sc_hip_ens_dlp_signer_set_mapping',
     'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
@@ -161,6 +161,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_bliss_sig_bytes.argtypes = [vp]
     L.sc_hip_bliss_sig_bytes.restype = sz
     L.sc_hip_bliss_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_bliss_sign_seeded.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, sz, vp, sz, vp, vp, vp, vp]
     L.sc_hip_bliss_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_bliss_set_tie_margin.argtypes = [vp, C.c_double]
     L.sc_hip_bliss_set_speculation.argtypes = [vp, C.c_int]
@@ -200,6 +201,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_tesla_sig_bytes.argtypes = [vp]
     L.sc_hip_tesla_sig_bytes.restype = sz
     L.sc_hip_tesla_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
+    L.sc_hip_tesla_sign_seeded.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, sz, vp, sz, vp, vp, vp, vp]
     L.sc_hip_tesla_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_polymul_ntt_steps.argtypes = [vp, sz, vp, vp, vp, C.c_int, vp]
     L.sc_hip_poly_uniform.argtypes = [vp, sz, C.c_int, vp, C.c_int, vp, sz, vp, vp, vp, vp, vp]
@@ -290,6 +292,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_falcon_set_variant.argtypes = [vp, C.c_int, C.c_int]
     L.sc_hip_falcon_sample.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp, vp, vp]
     L.sc_hip_falcon_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp]
+    L.sc_hip_falcon_sign_seeded.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, sz, vp, sz, vp, vp, vp]
     L.sc_hip_falcon_verify.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, vp]
     L.sc_hip_time_op.argtypes = [vp, C.c_int, sz, vp, vp, vp, vp, C.c_int, C.POINTER(C.c_float)]
     _LIB = L
@@ -1129,6 +1132,21 @@ class Bliss:
                                               _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'bliss_sign')
         return sigs, siglens, trials, status
 
+    def sign_seeded(self, msgs, seeds, mlens=None, fixed_len=0):
+        """sign with the reference's CSPRNG inside the call: seeds uint8 [batch][seed_len], message i draws from the AES-256 CTR-DRBG seeded with row i"""
+        import torch
+        batch = msgs.shape[0]
+        dev = msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        trials = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_bliss_sign_seeded(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                     _ptr(seeds), _rows(seeds), seeds.shape[1],
+                                                     _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'bliss_sign_seeded')
+        return sigs, siglens, trials, status
+
     def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
         import torch
         batch = msgs.shape[0]
@@ -1214,6 +1232,20 @@ class Tesla:
         _chk(self.L, self.L.sc_hip_tesla_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
                                               _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
                                               _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'tesla_sign')
+        return sigs, siglens, trials, status
+
+    def sign_seeded(self, msgs, seeds, mlens=None, fixed_len=0):
+        """sign with the reference's CSPRNG inside the call (seeds uint8 [batch][seed_len]): no tape exists, the masks come straight out of the cipher"""
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        trials = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_tesla_sign_seeded(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                     _ptr(seeds), _rows(seeds), seeds.shape[1],
+                                                     _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(trials), _ptr(status), _stream()), 'tesla_sign_seeded')
         return sigs, siglens, trials, status
 
     def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):
@@ -1589,6 +1621,19 @@ class Falcon:
         _chk(self.L, self.L.sc_hip_falcon_sign(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
                                                _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
                                                _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(status), _stream()), 'falcon_sign')
+        return sigs, siglens, status
+
+    def sign_seeded(self, msgs, seeds, mlens=None, fixed_len=0):
+        """sign with the reference's CSPRNG inside the call (seeds uint8 [batch][seed_len]): the 4n words of a signature are expanded on the device"""
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        sigs = torch.zeros((batch, self.sig_stride), dtype=torch.uint8, device=dev)
+        siglens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_falcon_sign_seeded(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                      _ptr(seeds), _rows(seeds), seeds.shape[1],
+                                                      _ptr(sigs), self.sig_stride, _ptr(siglens), _ptr(status), _stream()), 'falcon_sign_seeded')
         return sigs, siglens, status
 
     def verify(self, msgs, sigs, siglens, mlens=None, fixed_len=0):

@@ -448,6 +448,14 @@ class Drbg:
             self.h = None
 
 
+def drbg_words(seed, nwords):
+    """the first nwords prng_32 draws of the generator create_csprng makes of `seed`: the tape a seeded signing call stands for"""
+    d = Drbg(seed)
+    out = np.array([d.u32() for _ in range(nwords)], dtype=np.int64)
+    d.close()
+    return (out & 0xFFFFFFFF).astype(np.uint32)
+
+
 def kyber_kem_enc(par, t, t_ntt, rho, Agen, m):
     f = lambda a, dt: np.ascontiguousarray(np.asarray(a), dtype=dt)
     par = f(par, np.int32)
