@@ -840,8 +840,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # the K timed steps are K kernel launches captured in one HIP graph (sc_hip_polymul_ntt_steps; it runs the plain loop if the capture is refused):
-    # the loop is launch-bound - 37 us of kernel against ~2 us of host work per plain call.  Captured (and checked) before the timed regions.
+    # the K timed steps are K kernel launches issued by ONE C call (sc_hip_polymul_ntt_steps): plain launches back to back for K < 64, a captured HIP graph
+    # replayed for longer loops (a replay has a fixed start-up that only pays off over many steps: 762 us against 664 us at K = 20, equal at K = 200).
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         for _ in range(args.warmup):
@@ -982,7 +982,7 @@ def main():
             'config': {'workload': 'BASELINE configs[1]: Kyber set 1 (n=256, q=7681 - the reference has no q=3329) batched NTT + pointwise-mul + INTT, batch=65536'
                                    + (' cut across the ranks' if args.shard else ' per GPU'), 'n': N, 'q': Q,
                        'batch_per_gpu': batch, 'parallelism': f'shard{world} (independent polynomials, no collective)',
-                       'timing': f'value = MEDIAN of {len(regs)} timed regions of {args.steps} graph-replayed steps each (barrier + synchronize both sides); '
+                       'timing': f'value = MEDIAN of {len(regs)} timed regions of {args.steps} steps each ({"one HIP-graph replay" if args.steps >= 64 else "plain launches from one C call"}; barrier + synchronize both sides); '
                                  + ('host thread spins in synchronisations (hipDeviceScheduleSpin)' if spin else 'default host scheduling'),
                        'ms_per_step_min_max': [all_el[0] / args.steps * 1e3, all_el[-1] / args.steps * 1e3],
                        'ms_per_step_200_step_region': (long_reg / long_steps * 1e3) if long_reg else elapsed / args.steps * 1e3},

@@ -64,6 +64,11 @@ void sc_hip_bench_set_host_pin(int on);
  * would take: state reset, the loop in order) - a self-test.  Signatures, attempt counts and statuses do not depend on it. */
 int sc_hip_bliss_set_speculation(sc_hip_bliss_t *h, int on);
 
+/* process-wide: how the batched NTT kernels touch memory.  1 (default): operations whose operands exceed the 256 MiB Infinity Cache move their
+ * coefficient rows 16 bytes per lane with the non-temporal policy (transposed through LDS), smaller ones 4 bytes per lane with the default policy -
+ * the faster form on either side of that size (profiles/r04_ntt_stream_variants.txt); 0: never; 2: always.  Results are identical. */
+void sc_hip_bench_set_ntt_stream(int mode);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,6 +315,7 @@ struct sc_hip_plan {
     bool mad_ok;                  // the small-modulus multiply-add forms are safe for this (q, n)
     std::vector<int32_t> w, r;    // reference-format tables (host)
     uint32_t *d_tab[2];           // per mode: [zf | zfp | zi | zip], n entries each
+    int32_t *d_sink;              // 4 KB nobody reads: store target of the lanes past the end of a ragged last group (ntt_kernel)
     uint32_t *d_tab_s;            // MODE_SMAD (q = 7681 at n = 256; q < 14654 at n = 512, 1024): centred twiddles, signed companions; same layout
     sc::ModK k[2];
     uint32_t c_inv[2][4];         // scale = n^-1          : c0,c0p,c1,c1p

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "cdt_guide.h"
 
@@ -24,6 +25,7 @@ struct NttArgs {
     const int32_t *in0;
     const int32_t *in1;
     int32_t *out;
+    int32_t *sink;                // 4 KB nobody reads: where the lanes of a ragged last group that lie past the batch store (plain form)
     const uint32_t *zf, *zfp;     // forward twiddles zeta[k] = g^bitrev(k) and Shoup companions
     const uint32_t *zi, *zip;     // inverse twiddles zeta[k]^-1 and companions
     unsigned long long batch;
@@ -31,6 +33,8 @@ struct NttArgs {
     ModK k;
     uint32_t c0, c0p, c1, c1p;    // inverse output scale (n^-1 [* 2^32]) and zeta[1]^-1 * scale
 };
+
+typedef int v4i __attribute__((ext_vector_type(4)));      // a native 16-byte vector: what the non-temporal builtins take
 
 __host__ __device__ constexpr int brv4(int r) { return ((r & 1) << 3) | ((r & 2) << 1) | ((r & 4) >> 1) | ((r & 8) >> 3); }
 
@@ -53,16 +57,27 @@ struct Io {
     static __device__ __forceinline__ int off_ntt(int r, int blp) { return brv4(r) * Y::LP + blp; }
 };
 
-template <int L, int MODE, bool LAZY, int OP>
+// STREAM (round 4): how the kernel touches memory when the operands cannot be resident in the 256 MiB Infinity Cache anyway (the host picks it by working
+// set).  Measured on n = 256 over 3 x 1 GiB (tools/exp_ntt_stream.hip, profiles/r04_ntt_stream_variants.txt): what pays is 16 bytes per lane AND the
+// non-temporal policy together - the wavefront's 4 KB group moves as four 1 KB instructions (one whole polynomial each at n = 256) and is transposed into /
+// out of the register layout through the wave's LDS image (padded by 16 words per polynomial at n = 256 so that the four polynomials of a wavefront fall
+// on different banks) - fwd 0.67 -> 0.70, fused 0.67 -> 0.72 of 8 TB/s; either half alone loses (4-byte nt accesses 0.62, 16-byte default-policy 0.65), and on a
+// working set that replays out of the Infinity Cache the non-temporal form gives the cache hits away (0.78 -> 0.70): hence a variant, not a rewrite.
+// The second operand stays on 4-byte loads (non-temporal when streaming).  STREAM kernels take whole groups only; the host runs a ragged tail on the plain one.
+template <int L, int MODE, bool LAZY, int OP, bool STREAM>
 __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 {
     using Y = Lay<L>;
     constexpr int N = Y::N, LP = Y::LP, PW = Y::PW;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * 1024];
+    constexpr int NP = (STREAM && L == 8) ? N + 16 : N;            // words per polynomial in the transposition image
+    constexpr int WW = STREAM ? PW * NP : 1024;                   // LDS words per wavefront
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4 * WW];
 
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // wave-uniform: the group walk below is scalar arithmetic
     const int pw = lane / LP, lp = lane % LP;
-    uint32_t *lds_poly = lds + wid * 1024 + pw * N;
+    uint32_t *lds_wave = lds + wid * WW;
+    uint32_t *lds_poly = lds_wave + pw * N;
     const int blp = (int)(__builtin_bitreverse32((uint32_t)lp) >> (32 - (L - 4)));   // bitrev_{L-4}(lp)
     const ModK k = a.k;
 
@@ -75,23 +90,65 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
     unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
     if (g >= groups) return;
 
-    // in0 is read in the layout the first transform wants
+    // in0 is read in the layout the first transform wants; image index of register r of this lane in either domain
     const int off0 = (OP == OP_INV) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp);
+    auto img_coef = [&](int r) { return pw * NP + r * LP + lp; };
+    auto img_ntt = [&](int r) { return pw * NP + brv4(r) * LP + blp; };
     int32_t nx[16];                                      // raw words of the group about to be processed
-    // loads are unconditional: a group past the end of the batch reads polynomial 0 and is never stored (a guarded load is an exec-mask save, a branch
+    v4i wx[4];                                           // STREAM: the same as 4 x 16 bytes per lane, memory order
+    // loads are unconditional: a group past the end of the batch reads group 0 and is never stored (a guarded load is an exec-mask save, a branch
     // and a restore per instruction: 80 scalar instructions per trip of the fused kernel)
-    {
-        const unsigned long long poly = g * PW + pw;
-        const int32_t *src = a.in0 + (size_t)(poly < a.batch ? poly : 0) * N + off0;
+    auto request_in0 = [&](unsigned long long gg) {
+        if constexpr (STREAM) {
+            const v4i *src = reinterpret_cast<const v4i *>(a.in0 + (size_t)(gg < groups ? gg : 0) * (PW * N)) + lane;
 #pragma unroll
-        for (int r = 0; r < 16; r++) nx[r] = src[(OP == OP_INV ? brv4(r) : r) * LP];
-    }
+            for (int c = 0; c < 4; c++) wx[c] = __builtin_nontemporal_load(src + c * 64);
+        } else {
+            const unsigned long long poly = gg * PW + pw;
+            const int32_t *src = a.in0 + (size_t)((gg < groups && poly < a.batch) ? poly : 0) * N + off0;
+#pragma unroll
+            for (int r = 0; r < 16; r++) nx[r] = src[(OP == OP_INV ? brv4(r) : r) * LP];
+        }
+    };
+    // out: registers -> memory.  NTT = the NTT-domain order (forward output), else coefficient order.  Stores are unguarded: one guarded store is an exec-mask
+    // save, a branch and a restore, and sixteen of them split the store burst into sixteen islands (the forward kernel ran 456 us against 382 us over 2 GiB
+    // with them) - the lanes of a ragged last group that lie past the batch store into a 4 KB sink instead
+    auto store_out = [&](uint32_t (&x)[16], size_t base, bool valid, auto ntt_order) {
+        constexpr bool NTT = decltype(ntt_order)::value;
+        if constexpr (STREAM) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) lds_wave[NTT ? img_ntt(r) : img_coef(r)] = x[r];
+            wave_lds_fence();
+            v4i *dst = reinterpret_cast<v4i *>(a.out + (base - (size_t)pw * N)) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int cw = (c * 256) / N * NP + (c * 256) % N;                // word c * 256 of the group, in the padded image
+                const v4i v = *reinterpret_cast<const v4i *>(lds_wave + cw + 4 * lane);
+                __builtin_nontemporal_store(v, dst + c * 64);
+            }
+            wave_lds_fence();
+        } else {
+            int32_t *dst = (valid ? a.out + base : a.sink + pw * N) + (NTT ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
+#pragma unroll
+            for (int r = 0; r < 16; r++) dst[(NTT ? brv4(r) : r) * LP] = (int32_t)x[r];
+        }
+    };
+    request_in0(g);
 
     for (; g < groups; g += gstride) {
         const unsigned long long poly = g * PW + pw;
         const bool valid = poly < a.batch;
         const size_t base = (size_t)poly * N;
         uint32_t x[16];
+        if constexpr (STREAM) {
+            // the group's 4 KB as it lies in memory -> image -> this lane's 16 positions
+#pragma unroll
+            for (int c = 0; c < 4; c++) *reinterpret_cast<v4i *>(lds_wave + (c * 256) / N * NP + (c * 256) % N + 4 * lane) = wx[c];
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 16; r++) nx[r] = (int32_t)lds_wave[OP == OP_INV ? img_ntt(r) : img_coef(r)];
+            wave_lds_fence();
+        }
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r] = (MODE == MODE_SMAD) ? reduce_signed(nx[r], k) : (MODE == MODE_S32) ? reduce_s32(nx[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nx[r], k) : reduce_i32(nx[r], k);
 
@@ -100,22 +157,17 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         if (OP == OP_MULNTT || OP == OP_MUL) {
             const int32_t *srcb = a.in1 + ((a.in1_bcast || !valid) ? 0 : base) + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
-            for (int r = 0; r < 16; r++) nb[r] = srcb[(OP == OP_MULNTT ? brv4(r) : r) * LP];
+            for (int r = 0; r < 16; r++) {
+                const int32_t *q = srcb + (OP == OP_MULNTT ? brv4(r) : r) * LP;
+                nb[r] = STREAM ? __builtin_nontemporal_load(q) : *q;
+            }
         }
         // first operand of the next group (run-ahead)
-        auto prefetch = [&]() {
-            const unsigned long long npoly = (g + gstride) * PW + pw;
-            const bool nvalid = (g + gstride < groups) && (npoly < a.batch);
-            const int32_t *src = a.in0 + (size_t)(nvalid ? npoly : 0) * N + off0;
-#pragma unroll
-            for (int r = 0; r < 16; r++) nx[r] = src[(OP == OP_INV ? brv4(r) : r) * LP];
-        };
-        if (OP == OP_FWD || OP == OP_INV) prefetch();
+        if (OP == OP_FWD || OP == OP_INV) request_in0(g + gstride);
 
         if (OP != OP_INV) fwd_core<L, MODE, LAZY>(x, twf, lds_poly, lp, k);
 
         if (OP == OP_FWD) {
-            int32_t *dst = a.out + base + Io<L, OP>::off_ntt(0, blp);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 uint32_t v = x[r];
@@ -128,8 +180,9 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
                     if (LAZY) v = Mod<MODE>::mulc(v, 1u, k.one_p, k);
                     v = csub(v, k.q);
                 }
-                if (valid) dst[brv4(r) * LP] = (int32_t)v;
+                x[r] = v;
             }
+            store_out(x, base, valid, std::true_type{});
             continue;
         }
 
@@ -141,13 +194,13 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
                 else if (MODE == MODE_MAD) x[r] = mulmod_small(x[r], csub(reduce_i32_small(nb[r], k), k.q), k);    // < 2q(L+1) * q < 2^32
                 else x[r] = montmul(x[r], reduce_i32(nb[r], k), k);
             }
-            prefetch();
+            request_in0(g + gstride);
         }
         if (OP == OP_MUL) {
             uint32_t y[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) y[r] = (MODE == MODE_SMAD) ? reduce_signed(nb[r], k) : (MODE == MODE_S32) ? reduce_s32(nb[r], k) : (MODE == MODE_MAD) ? reduce_i32_small(nb[r], k) : reduce_i32(nb[r], k);
-            prefetch();
+            request_in0(g + gstride);
             fwd_core<L, MODE, (MODE == MODE_SMAD || MODE == MODE_S32)>(y, twf, lds_poly, lp, k);      // [0,2q) (signed modes: lazy, reduced below)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -159,10 +212,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         }
 
         inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-        int32_t *dst = a.out + base + Io<L, OP>::off_coef(0, lp);
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            if (valid) dst[r * LP] = (int32_t)x[r];
+        store_out(x, base, valid, std::false_type{});
     }
 }
 
@@ -310,6 +360,15 @@ thread_local bool sc::t_skip_host_pin = false;
 thread_local const sc::HostPins *sc::t_driver_pins = nullptr;
 extern "C" void sc_hip_bench_set_host_pin(int on) { sc::HostPins::mode() = on; }
 static int g_cus = 256;
+// streaming I/O of the NTT kernels (ntt_kernel<..., STREAM>): taken when an operation's operands exceed the threshold (default: the Infinity Cache's 256 MiB)
+static bool g_stream_io = true;
+static size_t g_stream_threshold = (size_t)256 << 20;
+extern "C" void sc_hip_bench_set_ntt_stream(int mode)
+{
+    // measurement / test hook: 0 never, 1 by working set (default), 2 always (whatever the size: the parity tests run every transform through both forms)
+    g_stream_io = mode != 0;
+    g_stream_threshold = mode == 2 ? 0 : (size_t)256 << 20;
+}
 int sc::fail(const std::string &m) { g_err = m; return SC_HIP_FAILURE; }
 using sc::fail;
 
@@ -378,6 +437,8 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
     sc_hip_plan *p = new sc_hip_plan;
     p->ctx = ctx; p->q = q; p->n = n; p->g = (int32_t)g;
     p->mv_ws = nullptr; p->mv_cap = 0; p->mv_event = nullptr; p->d_tab_s = nullptr; p->smad_ok = p->s32_ok = false;
+    p->d_sink = nullptr; p->d_tab[0] = p->d_tab[1] = nullptr;
+    if (hipMalloc((void **)&p->d_sink, 4096) != hipSuccess) { delete p; return fail("plan_create: device allocation failed"); }
     p->g_exec = nullptr; p->g_a = p->g_b = nullptr; p->g_out = nullptr; p->g_batch = 0; p->g_steps = 0;
     p->L = (n == 256) ? 8 : (n == 512) ? 9 : 10;
     p->w.resize(n); p->r.resize(n);
@@ -409,7 +470,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
         p->d_tab[mi] = nullptr;
         if (hipMalloc(&p->d_tab[mi], h.size() * 4) != hipSuccess ||
             sc::copy_in(p->d_tab[mi], h.data(), h.size() * 4) != hipSuccess) {
-            delete p;
+            sc_hip_plan_destroy(p);
             return fail("plan_create: cannot upload twiddle tables");
         }
         const uint64_t s0 = ninv, s1 = mulmod(ninv, zi[1], Q);
@@ -471,6 +532,7 @@ extern "C" void sc_hip_plan_destroy(sc_hip_plan_t *p)
     if (!p) return;
     for (int i = 0; i < 2; i++) if (p->d_tab[i]) (void)sc::wipe_free(p->d_tab[i]);
     if (p->d_tab_s) (void)sc::wipe_free(p->d_tab_s);
+    if (p->d_sink) (void)hipFree(p->d_sink);
     if (p->g_exec) (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec);
     if (p->mv_event) { (void)hipEventSynchronize((hipEvent_t)p->mv_event); (void)hipEventDestroy((hipEvent_t)p->mv_event); }
     if (p->mv_ws) (void)sc::wipe_free(p->mv_ws);
@@ -502,26 +564,27 @@ extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 
 // grid = what is resident at once (occupancy x CUs), so that every wave loops over many groups
 // and the run-ahead pipeline stays primed; never more blocks than there are groups of 4 waves
-template <int L, int MODE, bool LAZY, int OP>
+template <int L, int MODE, bool LAZY, int OP, bool STREAM = false>
 static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
 {
     static int per_cu = 0;
     if (per_cu == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_kernel<L, MODE, LAZY, OP>, 256, 0) != hipSuccess || nb < 1) nb = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_kernel<L, MODE, LAZY, OP, STREAM>, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb;
     }
     const long long cap = (long long)per_cu * g_cus;
     if (blocks > cap) blocks = (int)cap;
     if (blocks <= 0) return hipSuccess;                       // warm-up call: the occupancy query above is all that was wanted
-    hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP>), dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP, STREAM>), dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 template <int L, int OP>
-static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
+static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s, bool stream_io)
 {
-    if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
-    if (mode == MODE_S32) return launch_ntt_t<L, MODE_S32, true, OP>(a, blocks, s);
+    // the streaming I/O form exists for the two signed modes (every modulus of the reference's parameter sets runs on one of them)
+    if (mode == MODE_SMAD) return stream_io ? launch_ntt_t<L, MODE_SMAD, true, OP, true>(a, blocks, s) : launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
+    if (mode == MODE_S32) return stream_io ? launch_ntt_t<L, MODE_S32, true, OP, true>(a, blocks, s) : launch_ntt_t<L, MODE_S32, true, OP>(a, blocks, s);
     if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
         if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
@@ -532,12 +595,12 @@ static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks
     }
 }
 template <int OP>
-static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s)
+static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s, bool stream_io)
 {
     switch (L) {
-    case 8: return launch_ntt_l<8, OP>(a, mode, lazy, blocks, s);
-    case 9: return launch_ntt_l<9, OP>(a, mode, lazy, blocks, s);
-    default: return launch_ntt_l<10, OP>(a, mode, lazy, blocks, s);
+    case 8: return launch_ntt_l<8, OP>(a, mode, lazy, blocks, s, stream_io);
+    case 9: return launch_ntt_l<9, OP>(a, mode, lazy, blocks, s, stream_io);
+    default: return launch_ntt_l<10, OP>(a, mode, lazy, blocks, s, stream_io);
     }
 }
 
@@ -550,7 +613,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int mi = p->mode == MODE_U24 ? 0 : 1;
     const int n = p->n;
     NttArgs a;
-    a.in0 = d0; a.in1 = d1; a.out = dout; a.in1_bcast = bcast ? 1u : 0u;
+    a.in0 = d0; a.in1 = d1; a.out = dout; a.sink = p->d_sink; a.in1_bcast = bcast ? 1u : 0u;
     const bool sgn = p->mode == MODE_SMAD || p->mode == MODE_S32;
     a.zf = sgn ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
@@ -559,17 +622,34 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
     const bool lazy = mi == 0 ? p->lazy24 : p->lazy32;
     const int pw = 1024 / n;                                  // polynomials per wave
-    const size_t groups = (batch + pw - 1) / pw;
-    size_t blocks = (groups + 3) / 4;
-    if (blocks > (size_t)1 << 30) blocks = (size_t)1 << 30;
-    if (warm_only) blocks = 0;                                // only the per-instantiation occupancy query runs (launch_ntt_t)
+    // operands that cannot stay in the Infinity Cache between two uses are streamed: 16 bytes per lane, non-temporal (see ntt_kernel); whole groups only
+    const size_t ws_bytes = batch * (size_t)n * 4 * ((op == OP_MULNTT || op == OP_MUL) && !bcast ? 3 : 2);
+    const bool stream_io = !warm_only && sgn && !bcast && g_stream_io && ws_bytes > g_stream_threshold && batch >= (size_t)pw &&
+                           (((uintptr_t)d0 | (uintptr_t)dout) & 15) == 0;
+    auto launch = [&](const NttArgs &aa, size_t nb, bool st) -> hipError_t {
+        const size_t groups = (nb + pw - 1) / pw;
+        size_t blocks = (groups + 3) / 4;
+        if (blocks > (size_t)1 << 30) blocks = (size_t)1 << 30;
+        if (warm_only) blocks = 0;                                // only the per-instantiation occupancy query runs (launch_ntt_t)
+        switch (op) {
+        case OP_FWD: return launch_ntt_op<OP_FWD>(p->L, aa, p->mode, lazy, (int)blocks, (hipStream_t)stream, st);
+        case OP_INV: return launch_ntt_op<OP_INV>(p->L, aa, p->mode, lazy, (int)blocks, (hipStream_t)stream, st);
+        case OP_MULNTT: return launch_ntt_op<OP_MULNTT>(p->L, aa, p->mode, lazy, (int)blocks, (hipStream_t)stream, st);
+        default: return launch_ntt_op<OP_MUL>(p->L, aa, p->mode, lazy, (int)blocks, (hipStream_t)stream, st);
+        }
+    };
     hipError_t e;
-    switch (op) {
-    case OP_FWD: e = launch_ntt_op<OP_FWD>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
-    case OP_INV: e = launch_ntt_op<OP_INV>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
-    case OP_MULNTT: e = launch_ntt_op<OP_MULNTT>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
-    default: e = launch_ntt_op<OP_MUL>(p->L, a, p->mode, lazy, (int)blocks, (hipStream_t)stream); break;
-    }
+    if (stream_io) {
+        const size_t whole = batch / pw * pw, tail = batch - whole;
+        a.batch = whole;
+        e = launch(a, whole, true);
+        if (e == hipSuccess && tail) {                            // the ragged last group: the plain form, on its own
+            NttArgs t = a;
+            t.in0 = d0 + whole * n; t.out = dout + whole * n; t.batch = tail;
+            if (d1) t.in1 = d1 + whole * n;
+            e = launch(t, tail, false);
+        }
+    } else e = launch(a, batch, false);
     if (e != hipSuccess) return fail(std::string("ntt kernel launch: ") + hipGetErrorString(e));
     return SC_HIP_SUCCESS;
 }
@@ -967,8 +1047,8 @@ extern "C" int sc_hip_center_host(sc_hip_plan_t *p, size_t len, const int32_t *h
 
 // ---- a launch-bound loop as one HIP graph ------------------------------------------------------
 
-// `steps` back-to-back fused products (the same call as sc_hip_polymul_ntt, on the same buffers) captured once into a HIP graph and replayed:
-// at 37 us per kernel the per-launch host cost of a loop of plain calls is ~5 % of the wall time.  The executable graph is cached in the plan for
+// `steps` back-to-back fused products (the same call as sc_hip_polymul_ntt, on the same buffers); 64 steps or more are captured once into a HIP graph and
+// replayed.  The executable graph is cached in the plan for
 // the (buffers, batch, steps) it was captured with.  `stream` must be a real stream (stream capture does not work on the null stream); if anything
 // in the capture fails the plain loop runs instead - same result either way.
 extern "C" int sc_hip_polymul_ntt_steps(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, int steps, void *stream)
@@ -978,8 +1058,12 @@ extern "C" int sc_hip_polymul_ntt_steps(sc_hip_plan_t *p, size_t batch, const in
     HIPCHK(hipSetDevice(p->ctx->device));
     hipStream_t s = (hipStream_t)stream;
     if (d_out == d_a || d_out == d_bhat) return fail("polymul_ntt_steps: the output must not alias an input (the steps would feed each other)");
+    // A replay pays a fixed start-up (the runtime turns the graph's nodes into packets at launch time): measured at batch 65536, 20 steps take 762 us
+    // replayed against 664 us as plain launches, 200 steps 6196 us either way (tools/exp_ntt_stream.hip, profiles/r04_ntt_stream_variants.txt) - so short
+    // loops run as plain launches (the kernel is 31 us, a launch costs the host 2 us: the queue stays ahead) and only long ones are replayed
+    const bool use_graph = s && steps >= 64;
     const bool same = p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps;
-    if (s && !same) {
+    if (use_graph && !same) {
         if (p->g_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)p->g_exec); p->g_exec = nullptr; }
         if (run_ntt(p, OP_MULNTT, 0, d_a, d_bhat, d_out, stream, false, true) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;   // first-use initialisation (occupancy query) outside the capture, no launch
         hipGraph_t graph = nullptr;
@@ -995,7 +1079,7 @@ extern "C" int sc_hip_polymul_ntt_steps(sc_hip_plan_t *p, size_t batch, const in
         }
         (void)hipGetLastError();
     }
-    if (s && p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps) {
+    if (use_graph && p->g_exec && p->g_a == d_a && p->g_b == d_bhat && p->g_out == d_out && p->g_batch == batch && p->g_steps == steps) {
         if (hipGraphLaunch((hipGraphExec_t)p->g_exec, s) == hipSuccess) return SC_HIP_SUCCESS;
         (void)hipGetLastError();
     }

@@ -49,7 +49,7 @@ SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('creat
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
+BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_bench_set_ntt_stream', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
@@ -87,6 +87,8 @@ def load_library(path=LIB_PATH):
     vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
     L.sc_hip_bench_set_host_pin.argtypes = [C.c_int]
     L.sc_hip_bench_set_host_pin.restype = None
+    L.sc_hip_bench_set_ntt_stream.argtypes = [C.c_int]
+    L.sc_hip_bench_set_ntt_stream.restype = None
     if os.environ.get('SC_TEST_HOST_PIN') in ('0', '2'):     # test harness only (tools/dbg/bisect_pin.sh): the library itself reads no environment
         L.sc_hip_bench_set_host_pin(int(os.environ['SC_TEST_HOST_PIN']))
     L.sc_hip_last_error.restype = C.c_char_p
