@@ -848,18 +848,26 @@ def main():
             plan.polymul_ntt(a, bhat, out)
         plan.polymul_ntt_steps(a, bhat, out, args.steps)            # capture + one untimed replay
 
+    # everything the timed region needs is made before it: the two events exist (torch creates the HIP event lazily, at its first record: ~30 us) and the
+    # step loop is ONE ctypes call with ready-made arguments (tools/exp_region.py: 709 us per 20-step region the naive way, 644 us like this)
+    import ctypes
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(side); ev1.record(side)
+    c_steps = plan.L.sc_hip_polymul_ntt_steps
+    c_args = (plan.h, batch, ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(bhat.data_ptr()), ctypes.c_void_p(out.data_ptr()))
+    c_stream = ctypes.c_void_p(side.cuda_stream)
+
     def region(steps):
         """one timed region of exactly `steps` steps: barrier + synchronize on both sides, MAX over ranks; HIP events on the stream the kernels run on"""
         barrier()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        with torch.cuda.stream(side):
-            ev0.record(side)
-            plan.polymul_ntt_steps(a, bhat, out, steps)
-            ev1.record(side)
+        ev0.record(side)
+        rc_ = c_steps(*c_args, steps, c_stream)
+        ev1.record(side)
         torch.cuda.synchronize()
         barrier()
         el = time.perf_counter() - t0
+        assert rc_ == 0, 'sc_hip_polymul_ntt_steps failed'
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device='cuda')
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

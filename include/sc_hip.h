@@ -130,6 +130,9 @@ int  sc_hip_cdt_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t 
  * not across hosts; samples are a pure function of (table, uniform word). */
 int  sc_hip_cdt_table_size(float tail, float sigma);
 int  sc_hip_cdt_build_table(float tail, float sigma, uint64_t *h_cdf, int size);
+/* the table gaussian_cdf_create_64 builds for a sampler created with BLINDING_SAMPLES (gaussian_cdf.c:586-589): the plain sampler's size, tabulated at
+ * sigma / sqrt(2) - the blinding vector filler (sampling.c:168-191) subtracts a second sample from every coefficient */
+int  sc_hip_cdt_build_table_blinding(float tail, float sigma, uint64_t *h_cdf, int size);
 /* sampler over a caller-supplied monotone table (size a power of two, 2..4096), e.g. the
  * per-leaf tables Falcon's tree sampler creates on the fly (src/utils/arith/gpv.c:2671-2686)
  * precomputed at key load */

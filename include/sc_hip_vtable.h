@@ -145,12 +145,22 @@ typedef struct __attribute__((__packed__)) sc_hip_utils_sampling {
     float   tail, sigma, sigma2;
     void   *gauss;                                                       /* the sc_hip_sampler_t */
     void   *prng_ctx;                                                    /* the reference's prng_ctx_t, as given to create */
-    uint32_t discard;                                                    /* must stay 0 (the default, src/safecrypto.c:486) */
+    uint32_t discard;                                                    /* 0 (the default, src/safecrypto.c:486) or SCA_PATTERN_SAMPLE_DISCARD_LO / MD / HI = 2 / 4 / 6 with a prng_32 source set */
     void   *bootstrap;
 } sc_hip_utils_sampling_t;
 /* fills dst around s (dst->gauss = s; dst->prng_ctx = the rng_ctx given at creation); get_vector_32 / get_vector_16 /
  * get_sample of the reference (sampling.c:521-580) then run on the engine */
 int sc_hip_utils_sampling_fill(sc_hip_utils_sampling_t *dst, sc_hip_sampler_t *s);
+/* The side-channel variants of the vector fillers (sampling.c:107-228; create_sampler's `blinding`, selected by flags[2] & SC_FLAG_2_SAMPLE_SCA_SHUFFLE /
+ * _BLINDING, src/safecrypto.c:492-497; sample discarding SC_FLAG_2_SAMPLE_SCA_DISCARD_*, set_discard -> dst->discard = 2 / 4 / 6).  They interleave
+ * prng_32 draws (rand_range, discard_sample) with the samples' prng_64 draws on the SAME generator, so the sampler needs the reference's prng_32 as well:
+ * sc_hip_sampler_set_rng32 (same rng_ctx).  blinding: 0 NORMAL_SAMPLES, 1 BLINDING_SAMPLES (the sampler's table must be the blinding one:
+ * sc_hip_cdt_build_table_blinding, or the reference's own), 2 SHUFFLE_SAMPLES (safecrypto_private.h:154-158).  What runs where: the order of draws and
+ * the shuffle's moves are control flow that depends on the drawn words - replayed on the host exactly as sampling.c does; every table search (the samples
+ * themselves) runs on the device, all of a vector's draws in one launch. */
+typedef uint32_t (*sc_hip_rng32_fn)(void *rng_ctx);
+void sc_hip_sampler_set_rng32(sc_hip_sampler_t *s, sc_hip_rng32_fn rng32);
+int sc_hip_utils_sampling_fill_sca(sc_hip_utils_sampling_t *dst, sc_hip_sampler_t *s, int blinding);
 
 /* ---- device binding and error reporting ---------------------------------------------------------------------------- */
 /* binds the calling host thread's table calls to `device` (default: device 0).  One host thread per GPU, each with its own

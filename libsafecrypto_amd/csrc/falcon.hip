@@ -1753,6 +1753,8 @@ struct sc_hip_falcon {
     uint32_t *status, *siglens;
     sc::Workspace srt;           // sc_hip_falcon_sign_keys with the keys of the batch interleaved: the batch regrouped by key (fal_sign_grouped)
     sc::Workspace stape;         // sc_hip_falcon_sign_seeded: the batch's CSPRNG word tapes, expanded from the caller's seeds for the length of the call
+    hipStream_t side = nullptr;  // ... on a stream of the handle's own, beside the hash to the ring (forked / joined with events inside the call)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static void fal_free_ws(sc_hip_falcon *f)
@@ -1836,6 +1838,9 @@ extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
     fal_free_ws(f);
     f->srt.release();
     f->stape.release();
+    if (f->side) (void)hipStreamDestroy(f->side);
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
     void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(f->plan);
@@ -2061,7 +2066,7 @@ extern "C" int sc_hip_falcon_sample_profile(sc_hip_falcon_t *f, size_t batch, co
 
 static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped = false);
+                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped = false, hipEvent_t tapes_ready = nullptr);
 
 extern "C" int sc_hip_falcon_sign(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                                   const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
@@ -2086,8 +2091,19 @@ extern "C" int sc_hip_falcon_sign_seeded(sc_hip_falcon_t *f, size_t batch, const
     if (f->stape.reserve(batch * words * 4)) return SC_HIP_FAILURE;
     uint32_t *tapes = f->stape.take<uint32_t>(batch * words);
     hipStream_t s = (hipStream_t)stream;
-    if (sc::drbg_fill(f->ctx, d_seeds, seed_stride, seed_len, nullptr, (uint32_t)batch, nullptr, tapes, words * 4, 0, words / 4, 1, false, s)) return SC_HIP_FAILURE;
-    const int rc = fal_sign_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, tapes, words, nullptr, d_sigs, sig_stride, d_siglens, d_status, stream);
+    // the expansion (the cipher: vector-ALU-bound, 0.25 ms per 8192 tapes) runs on a stream of the handle's own beside the hash to the ring (a chain of 25
+    // dependent permutations per message: latency-bound, most issue slots idle); the sampler waits for both
+    if (!f->side) {
+        HIPCHK(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(f->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(f->side, f->ev_fork, 0));
+    if (sc::drbg_fill(f->ctx, d_seeds, seed_stride, seed_len, nullptr, (uint32_t)batch, nullptr, tapes, words * 4, 0, words / 4, 1, false, f->side)) return SC_HIP_FAILURE;
+    HIPCHK(hipEventRecord(f->ev_join, f->side));
+    const int rc = fal_sign_core(f, batch, nullptr, d_msgs, msg_stride, d_mlens, fixed_len, tapes, words, nullptr, d_sigs, sig_stride, d_siglens, d_status, stream, false, f->ev_join);
+    if (rc != SC_HIP_SUCCESS) (void)hipStreamWaitEvent(s, f->ev_join, 0);      // (an argument error before the wait was queued: the wipe below still follows the expansion)
     f->stape.wipe(s);
     return rc;
 }
@@ -2194,7 +2210,7 @@ __global__ void fal_scatter_sigs_kernel(uint32_t rows, const uint32_t *__restric
 
 static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped);
+                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped, hipEvent_t tapes_ready);
 
 static int fal_sign_grouped(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                             const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
@@ -2244,7 +2260,7 @@ static int fal_sign_grouped(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_
 
 static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                          const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped)
+                         uint8_t *d_sigs, size_t sig_stride, uint32_t *d_siglens, uint32_t *d_status, void *stream, bool grouped, hipEvent_t tapes_ready)
 {
     if (fal_check_common(f, batch, "falcon_sign")) return SC_HIP_FAILURE;
     if (!f->have_sk) return fail("falcon_sign: no private key loaded");
@@ -2271,6 +2287,7 @@ static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
+    if (tapes_ready) HIPCHK(hipStreamWaitEvent(s, tapes_ready, 0));     // seeded call: the tapes are being expanded on the handle's side stream
     if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s, nullptr, d_key_of)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P,
                        f->ws, (uint32_t)((batch + SPW_MAX - 1) / SPW_MAX * SPW_MAX));

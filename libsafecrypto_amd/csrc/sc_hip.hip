@@ -708,10 +708,9 @@ extern "C" int sc_hip_cdt_table_size(float tail, float sigma)
     return 1 << bits;
 }
 
-extern "C" int sc_hip_cdt_build_table(float tail, float sigma, uint64_t *cdf, int size)
+// long-double recurrence of gaussian_cdf.c:588-607 (sigma*sigma is a FLOAT product there) for the standard deviation the table is tabulated at
+static void cdt_tabulate(float sigma, uint64_t *cdf, int size)
 {
-    if (!cdf || size != sc_hip_cdt_table_size(tail, sigma) || size < 2) return fail("cdt_build_table: bad size");
-    // long-double recurrence of gaussian_cdf.c:588-607 (sigma*sigma is a FLOAT product there)
     const long double two_sqrtpi = 1.128379167095512573896158903121545172L;
     const long double sqrt1_2 = 0.707106781186547524400844362104849039L;
     const long double d = two_sqrtpi * sqrt1_2 * 18446744073709551616.0L / (long double)sigma;
@@ -726,6 +725,20 @@ extern "C" int sc_hip_cdt_build_table(float tail, float sigma, uint64_t *cdf, in
         s += d * expl(e * ((long double)(i * i)));
     }
     for (; i < size; i++) cdf[i] = 0xFFFFFFFFFFFFFFFFull;
+}
+extern "C" int sc_hip_cdt_build_table(float tail, float sigma, uint64_t *cdf, int size)
+{
+    if (!cdf || size != sc_hip_cdt_table_size(tail, sigma) || size < 2) return fail("cdt_build_table: bad size");
+    cdt_tabulate(sigma, cdf, size);
+    return SC_HIP_SUCCESS;
+}
+// the table of a sampler created with BLINDING_SAMPLES (gaussian_cdf.c:586-589): as many entries as the plain sampler's, tabulated at sigma / sqrt(2) (the
+// blinding filler subtracts a second sample from every coefficient, sampling.c:168-191) - the scaling is a FLOAT *= long double
+extern "C" int sc_hip_cdt_build_table_blinding(float tail, float sigma, uint64_t *cdf, int size)
+{
+    if (!cdf || size != sc_hip_cdt_table_size(tail, sigma) || size < 2) return fail("cdt_build_table_blinding: bad size");
+    const float scaled = (float)((long double)sigma * 0.707106781186547524400844362104849039L);
+    cdt_tabulate(scaled, cdf, size);
     return SC_HIP_SUCCESS;
 }
 

@@ -14,6 +14,7 @@
 #include <mutex>
 #include <string.h>
 #include <utility>
+#include <algorithm>
 #include <vector>
 
 #include "engine_internal.h"
@@ -294,6 +295,7 @@ struct sc_hip_sampler {
     int dev;
     sc_hip_cdt_t *cdt;
     sc_hip_rng64_fn rng; void *rng_ctx;
+    sc_hip_rng32_fn rng32 = nullptr;
     float tail, sigma;
     std::vector<uint64_t> words;
 };
@@ -312,6 +314,7 @@ extern "C" int sc_hip_sampler_create(float tail, float sigma, const uint64_t *h_
     return SC_HIP_SUCCESS;
 }
 extern "C" void sc_hip_sampler_set_rng(sc_hip_sampler_t *s, sc_hip_rng64_fn rng, void *rng_ctx) { if (s && rng) { s->rng = rng; s->rng_ctx = rng_ctx; } }
+extern "C" void sc_hip_sampler_set_rng32(sc_hip_sampler_t *s, sc_hip_rng32_fn rng32) { if (s) s->rng32 = rng32; }
 extern "C" void sc_hip_sampler_destroy(sc_hip_sampler_t *s)
 {
     if (!s) return;
@@ -337,21 +340,74 @@ int32_t sm_sample(void *gauss)
     note(sampler_vector((sc_hip_sampler *)gauss, &v, 1, 0));
     return v;
 }
-int32_t sm_vector_32(const sc_hip_utils_sampling_t *t, int32_t *v, size_t n, int32_t centre)
+// The side-channel fillers (sampling.c:107-228).  Which word goes where is decided by the words themselves - rand_range's rejection, discard_sample's
+// repeats - so the host replays the reference's loop over the two callbacks (prng_32 / prng_64 of ONE generator) and only RECORDS: the 64-bit words of the
+// samples in draw order and the moves of the shuffle.  The samples - every table search - are then made on the device in one launch, and the moves
+// (v[i] = v[j]; v[j] = sample_k + centre) are applied to the vector in order.
+int sampler_vector_sca(sc_hip_sampler *s, int32_t *v, size_t n, int32_t centre, uint32_t discard, int blinding)
+{
+    if (!s || !v) return sc::fail("sampler: null argument");
+    if (n == 0) return SC_HIP_SUCCESS;
+    if (discard != 0 && discard != 2 && discard != 4 && discard != 6) return sc::fail("sampler: discard must be 0 or SCA_PATTERN_SAMPLE_DISCARD_LO / MD / HI (2 / 4 / 6)");
+    if ((discard != 0 || blinding != 0) && !s->rng32)
+        return sc::fail("sampler: shuffle / blinding / sample discarding draw prng_32 words between the samples: give the sampler the generator's prng_32 (sc_hip_sampler_set_rng32)");
+    const uint32_t thresh = discard == 2 ? 1u << 28 : discard == 4 ? 1u << 30 : discard == 6 ? 1u << 31 : 0;      // set_threshold, sampling.c:85-92
+    auto discarded = [&]() -> size_t { return thresh ? (s->rng32(s->rng_ctx) < thresh ? 1 : 0) : 0; };             // discard_sample, :95-105
+    struct Move { uint32_t i, j; };                                    // j == ~0u: v[i] = sample (+ centre unless i is the shuffle's first element)
+    std::vector<Move> moves;
+    std::vector<uint64_t> &w = s->words;
+    w.clear();
+    if (blinding == 0) {                                               // sample_vector_32, :211-228
+        for (size_t i = 0; i < n; i++) {
+            w.push_back(s->rng(s->rng_ctx)); moves.push_back({ (uint32_t)i, ~0u });
+            i -= discarded();
+        }
+    } else {                                                           // shuffle_sample_vector_32, :127-145
+        w.push_back(s->rng(s->rng_ctx));
+        for (size_t i = 1; i < n; i++) {
+            const size_t rem = 0xFFFFFFFFu % i;                        // rand_range(ctx, i), :68-83: y % i over the accepted range
+            size_t y;
+            do y = s->rng32(s->rng_ctx); while (y >= 0xFFFFFFFFu - rem);
+            w.push_back(s->rng(s->rng_ctx)); moves.push_back({ (uint32_t)i, (uint32_t)(y % i) });
+            i -= discarded();
+        }
+        if (blinding == 1) for (size_t i = 0; i < n; i++) w.push_back(s->rng(s->rng_ctx));       // blinding_sample_vector_32, :168-191
+    }
+    std::vector<int32_t> smp(w.size());
+    {
+        std::lock_guard<std::mutex> lk(g_dev[s->dev].mu);
+        if (sc_hip_cdt_sample_host(s->cdt, w.size(), w.data(), 0, smp.data()) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    }
+    size_t k = 0;
+    if (blinding == 0) for (const Move &m : moves) v[m.i] = smp[k++] + centre;
+    else {
+        v[0] = smp[k++];                                               // (no centre on the first element: sampling.c:134)
+        for (const Move &m : moves) { if (m.i != m.j) v[m.i] = v[m.j]; v[m.j] = smp[k++] + centre; }
+        if (blinding == 1) for (size_t i = 0; i < n; i++) v[i] -= smp[k++];                      // (the closing swap loop exchanges v[i] with itself)
+    }
+    std::fill(smp.begin(), smp.end(), 0); std::fill(w.begin(), w.end(), 0);
+    return SC_HIP_SUCCESS;
+}
+template <int BLINDING>
+int32_t sm_vector_32_t(const sc_hip_utils_sampling_t *t, int32_t *v, size_t n, int32_t centre)
 {
     if (!t) { note(sc::fail("sampler: null table")); return 1; }
-    if (t->discard != 0) { note(sc::fail("sampler: sample discarding (SCA_PATTERN_SAMPLE_DISCARD_*) is not served")); return 1; }
-    const int rc = sampler_vector((sc_hip_sampler *)t->gauss, v, n, centre);
+    const int rc = (BLINDING == 0 && t->discard == 0) ? sampler_vector((sc_hip_sampler *)t->gauss, v, n, centre)
+                                                      : sampler_vector_sca((sc_hip_sampler *)t->gauss, v, n, centre, t->discard, BLINDING);
     note(rc);
     return rc;
 }
-int32_t sm_vector_16(const sc_hip_utils_sampling_t *t, int16_t *v, size_t n, int32_t centre)
+template <int BLINDING>
+int32_t sm_vector_16_t(const sc_hip_utils_sampling_t *t, int16_t *v, size_t n, int32_t centre)
 {
+    // (the 16-bit fillers run the same loops on SINT16 storage, sampling.c:107-125,147-166,193-206: the moves copy values, the subtraction wraps the same way)
     std::vector<int32_t> w(n);
-    const int32_t rc = sm_vector_32(t, w.data(), n, centre);
+    const int32_t rc = sm_vector_32_t<BLINDING>(t, w.data(), n, centre);
     if (rc == 0) for (size_t i = 0; i < n; i++) v[i] = (int16_t)w[i];
     return rc;
 }
+int32_t sm_vector_32(const sc_hip_utils_sampling_t *t, int32_t *v, size_t n, int32_t centre) { return sm_vector_32_t<0>(t, v, n, centre); }
+int32_t sm_vector_16(const sc_hip_utils_sampling_t *t, int16_t *v, size_t n, int32_t centre) { return sm_vector_16_t<0>(t, v, n, centre); }
 }  // namespace
 
 extern "C" int sc_hip_utils_sampling_fill(sc_hip_utils_sampling_t *dst, sc_hip_sampler_t *s)
@@ -362,6 +418,15 @@ extern "C" int sc_hip_utils_sampling_fill(sc_hip_utils_sampling_t *dst, sc_hip_s
     dst->precision = 64; dst->dimension = 0; dst->bootstrapped = 0;
     dst->tail = s->tail; dst->sigma = s->sigma; dst->sigma2 = 0.f;
     dst->gauss = s; dst->prng_ctx = s->rng_ctx; dst->discard = 0; dst->bootstrap = nullptr;
+    return SC_HIP_SUCCESS;
+}
+
+extern "C" int sc_hip_utils_sampling_fill_sca(sc_hip_utils_sampling_t *dst, sc_hip_sampler_t *s, int blinding)
+{
+    if (blinding < 0 || blinding > 2) return sc::fail("utils_sampling_fill_sca: blinding must be 0 (NORMAL_SAMPLES), 1 (BLINDING_SAMPLES) or 2 (SHUFFLE_SAMPLES)");
+    if (sc_hip_utils_sampling_fill(dst, s) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    if (blinding == 1) { dst->vector_32 = sm_vector_32_t<1>; dst->vector_16 = sm_vector_16_t<1>; }
+    else if (blinding == 2) { dst->vector_32 = sm_vector_32_t<2>; dst->vector_16 = sm_vector_16_t<2>; }
     return SC_HIP_SUCCESS;
 }
 

@@ -13,7 +13,7 @@ SYMBOLS = [
     'sc_hip_plan_tables', 'sc_hip_plan_set_arith',
     'sc_hip_ntt_fwd', 'sc_hip_ntt_inv', 'sc_hip_pointwise', 'sc_hip_polymul_ntt', 'sc_hip_polymul',
     'sc_hip_normalize', 'sc_hip_center', 'sc_hip_poly_add', 'sc_hip_poly_sub', 'sc_hip_matvec',
-    'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_create_from_table',
+    'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_build_table_blinding', 'sc_hip_cdt_create_from_table',
     'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
     'sc_hip_cdt32_build_table', 'sc_hip_cdt32_create', 'sc_hip_cdt32_create_from_table', 'sc_hip_cdt32_table', 'sc_hip_cdt32_sample',
     'sc_hip_ntt_fwd_host', 'sc_hip_ntt_inv_host', 'sc_hip_polymul_ntt_host', 'sc_hip_cdt_sample_host',
@@ -51,7 +51,7 @@ SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
 BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_bench_set_ntt_stream', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
 # include/sc_hip_vtable.h
-VTABLE_SYMBOLS = ['sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
+VTABLE_SYMBOLS = ['sc_hip_sampler_set_rng32', 'sc_hip_utils_sampling_fill_sca', 'sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
 
 
@@ -118,6 +118,7 @@ def load_library(path=LIB_PATH):
     L.sc_hip_cdt_create.argtypes = [vp, C.c_float, C.c_float, C.POINTER(vp)]
     L.sc_hip_cdt_table_size.argtypes = [C.c_float, C.c_float]
     L.sc_hip_cdt_build_table.argtypes = [C.c_float, C.c_float, vp, C.c_int]
+    L.sc_hip_cdt_build_table_blinding.argtypes = [C.c_float, C.c_float, vp, C.c_int]
     L.sc_hip_cdt_create_from_table.argtypes = [vp, vp, C.c_int, C.POINTER(vp)]
     L.sc_hip_cdt_destroy.argtypes = [vp]
     L.sc_hip_cdt_destroy.restype = None

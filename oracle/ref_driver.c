@@ -304,6 +304,51 @@ static int gen_cdt(const char *dir)
     return rc;
 }
 
+/* The vector fillers behind get_vector_32 in their side-channel variants (src/utils/sampling/sampling.c:107-228): NORMAL / SHUFFLE / BLINDING samples
+ * (create_sampler's `blinding`, safecrypto.c:492-497) x sample discarding off / LO / MD / HI (set_discard, bliss_b.c:350).  One seeded CSPRNG per case;
+ * its twin (same seed) yields the pool words the filler is about to consume - prng_32 and prng_64 read the same word pool (prng.c:95-143,963-993). */
+static int sampling_case(FILE *f, int blinding, unsigned discard, int n, int centre, const char *tag)
+{
+    static const uint8_t seed[32] = { 1, 6, 1, 8, 0, 3, 3, 9, 8, 8, 7, 4, 9, 8, 9, 4, 8, 4, 8, 2, 0, 4, 5, 8, 6, 8, 3, 4, 3, 6, 5, 6 };
+    char name[96];
+    uint8_t sd[32];
+    memcpy(sd, seed, 32); sd[0] = (uint8_t)(blinding * 16 + discard); sd[1] = (uint8_t)n;
+    prng_ctx_t *p1 = seeded_prng(sd, 32), *p2 = seeded_prng(sd, 32);
+    utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, (sample_blinding_e)blinding, 512,
+                                         SAMPLING_DISABLE_BOOTSTRAP, p1, 13.42f, 215.0f);
+    if (!s) return 1;
+    set_discard(s, discard);
+    const size_t words = 16 * (size_t)n + 64;
+    int32_t *tape = malloc(sizeof(int32_t) * words), *v = malloc(sizeof(int32_t) * n);
+    for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(p2);
+    get_vector_32(s, v, n, centre);
+    snprintf(name, sizeof name, "%s_par", tag);
+    { int32_t par[4] = { blinding, (int32_t)discard, n, centre }; rec_i32(f, name, par, 4); }
+    snprintf(name, sizeof name, "%s_tape", tag); rec_i32(f, name, tape, words);
+    snprintf(name, sizeof name, "%s_v", tag); rec_i32(f, name, v, n);
+    free(tape); free(v);
+    destroy_sampler(&s);
+    prng_destroy(p1); prng_destroy(p2);
+    return 0;
+}
+static int gen_sampling(const char *dir)
+{
+    char path[512], tag[64];
+    snprintf(path, sizeof path, "%s/sampling_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = 0, k = 0;
+    static const int bl[3] = { NORMAL_SAMPLES, SHUFFLE_SAMPLES, BLINDING_SAMPLES };
+    static const unsigned dc[4] = { 0, SCA_PATTERN_SAMPLE_DISCARD_LO, SCA_PATTERN_SAMPLE_DISCARD_MD, SCA_PATTERN_SAMPLE_DISCARD_HI };
+    for (int b = 0; b < 3; b++) for (int d = 0; d < 4; d++) {
+        snprintf(tag, sizeof tag, "sca%d", k++);
+        rc |= sampling_case(f, bl[b], dc[d], b == 1 && d == 3 ? 96 : 128, d == 2 ? 37 : 0, tag);
+    }
+    { int32_t cnt = k; rec_i32(f, "sca_cases", &cnt, 1); }
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------------------ Dilithium ---- */
 
 #include "schemes/sig/dilithium/dilithium.h"
@@ -1676,6 +1721,7 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
     if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
     if (all || !strcmp(argv[1], "cdt32")) rc |= gen_cdt32(argv[2]);
+    if (all || !strcmp(argv[1], "sampling")) rc |= gen_sampling(argv[2]);
     if (all || !strcmp(argv[1], "bliss_huff")) rc |= gen_bliss_huff(argv[2]);
     if (all || !strcmp(argv[1], "bliss_bac")) rc |= gen_bliss_bac(argv[2]);
     if (all || !strcmp(argv[1], "huff_rows")) rc |= gen_huff_rows(argv[2]);

@@ -287,6 +287,15 @@ int orc_cdt_create(float tail, float sigma_f, uint64_t *cdf, int size)
     return 0;
 }
 
+/* the table of a sampler created with BLINDING_SAMPLES (gaussian_cdf.c:586-589): sigma *= SC_M_SQRT1_2l (a FLOAT) before the recurrence, the size
+ * (taken from the unscaled tail * sigma, :562) unchanged */
+int orc_cdt_create_blinding(float tail, float sigma_f, uint64_t *cdf, int size)
+{
+    float scaled = sigma_f;
+    scaled *= 0.707106781186547524400844362104849039L;
+    return orc_cdt_create(tail, scaled, cdf, size);
+}
+
 /* gaussian_cdf.c:536-553 + :639-659 (k == 0): a = largest index reached by the halving
  * search with "cdf[b] < x"; the sign is the LSB of the same uniform word. */
 int32_t orc_cdt_sample(uint64_t x, const uint64_t *cdf, int size)
@@ -337,6 +346,54 @@ void orc_cdt32_sample_vector(int32_t *v, size_t n, const uint32_t *x, const uint
 void orc_cdt_sample_vector(int32_t *v, size_t n, const uint64_t *x, const uint64_t *cdf, int size, int32_t centre)
 {
     for (size_t i = 0; i < n; i++) v[i] = orc_cdt_sample(x[i], cdf, size) + centre;
+}
+
+/* The side-channel variants of the vector fillers (sampling.c:68-228), restated over the word tape the CSPRNG would deliver (prng_32 takes one pool
+ * word, prng_64 two, high word first: prng.c:963-993).  blinding: 0 NORMAL_SAMPLES (sample_vector_32), 1 BLINDING_SAMPLES, 2 SHUFFLE_SAMPLES
+ * (safecrypto_private.h:154-158); discard: 0 or SCA_PATTERN_SAMPLE_DISCARD_LO / MD / HI = 2 / 4 / 6 (:164-167), thresholds 2^28 / 2^30 / 2^31
+ * (set_threshold, sampling.c:85-92).  Returns the words consumed, or -1 when the tape runs out.  Test infrastructure only. */
+typedef struct { const uint32_t *w; size_t n, pos; int dry; } orc_tape_t;
+static uint32_t tape32(orc_tape_t *t) { if (t->pos >= t->n) { t->dry = 1; return 0; } return t->w[t->pos++]; }
+static uint64_t tape64(orc_tape_t *t) { const uint64_t hi = tape32(t); return (hi << 32) | tape32(t); }
+static size_t orc_rand_range(orc_tape_t *t, size_t x)                       /* sampling.c:68-83 */
+{
+    const size_t rem = 0xFFFFFFFFu % x;
+    for (;;) {
+        const size_t y = tape32(t);
+        if (t->dry) return 0;
+        if (y >= (0xFFFFFFFFu - rem)) continue;
+        return y % x;
+    }
+}
+static int orc_discard(orc_tape_t *t, uint32_t thresh) { return thresh ? (tape32(t) < thresh) : 0; }   /* :95-105 */
+static void orc_shuffle_fill(orc_tape_t *t, int32_t *v, size_t n, int32_t centre, uint32_t thresh, const uint64_t *cdf, int size)   /* :127-145 */
+{
+    v[0] = orc_cdt_sample(tape64(t), cdf, size);
+    for (size_t i = 1; i < n && !t->dry; i++) {
+        const size_t j = orc_rand_range(t, i);
+        const int32_t cond = (int32_t)((-(int32_t)(i ^ j) >> 31) & 1);
+        v[i] = cond * v[j] + (1 ^ cond) * v[i];
+        v[j] = orc_cdt_sample(tape64(t), cdf, size) + centre;
+        i -= (size_t)orc_discard(t, thresh);
+    }
+}
+long orc_sample_vector_sca(int32_t *v, size_t n, int32_t centre, int blinding, uint32_t discard, const uint32_t *tape, size_t tape_words,
+                           const uint64_t *cdf, int size)
+{
+    orc_tape_t t = { tape, tape_words, 0, 0 };
+    const uint32_t thresh = discard == 2 ? 1u << 28 : discard == 4 ? 1u << 30 : discard == 6 ? 1u << 31 : 0;
+    if (n == 0) return 0;
+    if (blinding == 0) {                                                       /* :211-228 */
+        for (size_t i = 0; i < n && !t.dry; i++) {
+            v[i] = orc_cdt_sample(tape64(&t), cdf, size) + centre;
+            i -= (size_t)orc_discard(&t, thresh);
+        }
+    } else {
+        orc_shuffle_fill(&t, v, n, centre, thresh, cdf, size);
+        if (blinding == 1)                                                     /* :168-191; the closing swap loop exchanges v[i] with itself */
+            for (size_t i = 0; i < n && !t.dry; i++) v[i] -= orc_cdt_sample(tape64(&t), cdf, size);
+    }
+    return t.dry ? -1 : (long)t.pos;
 }
 
 /* ---------------------------------------------------------------- batches ---- */

@@ -53,11 +53,14 @@ def lib():
         L.orc_cdt_bits.restype = C.c_int
         L.orc_cdt_bits.argtypes = [C.c_float, C.c_float]
         L.orc_cdt_create.argtypes = [C.c_float, C.c_float, u64p, C.c_int]
+        L.orc_cdt_create_blinding.argtypes = [C.c_float, C.c_float, u64p, C.c_int]
         L.orc_cdt32_create.argtypes = [C.c_float, C.c_float, u32p_g, C.c_int]
         L.orc_cdt32_sample_vector.argtypes = [i32p, C.c_size_t, u32p_g, u32p_g, C.c_int, C.c_int32]
         L.orc_cdt_sample.restype = C.c_int32
         L.orc_cdt_sample.argtypes = [C.c_uint64, u64p, C.c_int]
         L.orc_cdt_sample_vector.argtypes = [i32p, C.c_size_t, u64p, u64p, C.c_int, C.c_int32]
+        L.orc_sample_vector_sca.restype = C.c_long
+        L.orc_sample_vector_sca.argtypes = [i32p, C.c_size_t, C.c_int32, C.c_int, C.c_uint32, np.ctypeslib.ndpointer(dtype=np.uint32, flags='C_CONTIGUOUS'), C.c_size_t, u64p, C.c_int]
         L.orc_batch_fwd_ntt.argtypes = [i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p]
         L.orc_batch_inv_ntt.argtypes = [i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p, i32p]
         L.orc_batch_polymul_ntt.argtypes = [i32p, i32p, i32p, C.c_size_t, C.c_int, C.c_int32, i32p, i32p]
@@ -402,6 +405,14 @@ def cdt_table(tail, sigma):
     return cdf
 
 
+def cdt_table_blinding(tail, sigma):
+    """the table of a sampler created with BLINDING_SAMPLES: the plain one's size, sigma / sqrt(2)"""
+    bits = lib().orc_cdt_bits(tail, sigma)
+    cdf = np.zeros(1 << bits, dtype=np.uint64)
+    lib().orc_cdt_create_blinding(tail, sigma, cdf, 1 << bits)
+    return cdf
+
+
 def cdt32_table(tail, sigma):
     """gaussian_cdf_create_32 restated (float accumulators)"""
     bits = lib().orc_cdt_bits(tail, sigma)
@@ -415,6 +426,15 @@ def cdt32_sample(x, cdf, centre=0):
     v = np.empty(x.size, dtype=np.int32)
     lib().orc_cdt32_sample_vector(v, x.size, x, cdf, cdf.size, centre)
     return v
+
+
+def sample_vector_sca(n, centre, blinding, discard, tape, cdf):
+    """sampling.c:107-228: (vector, words consumed); blinding 0 NORMAL / 1 BLINDING / 2 SHUFFLE, discard 0 / 2 / 4 / 6"""
+    tp = _tape(tape)
+    cdf = np.ascontiguousarray(cdf, dtype=np.uint64)
+    v = np.zeros(n, dtype=np.int32)
+    used = lib().orc_sample_vector_sca(v, n, centre, blinding, discard, tp, tp.size, cdf, cdf.size)
+    return v, used
 
 
 def cdt_sample(x, cdf, centre=0):

@@ -293,9 +293,68 @@ def test_sampler_table_pulls_words_in_order():
     assert np.array_equal(v16.astype(np.int32), O.cdt_sample(words[512:612], table) + 3)
     one = tab.sample(tab.gauss)
     assert one == int(O.cdt_sample(words[612:613], table)[0]) and state['i'] == 613
-    tab.discard = 2                                                      # sample discarding is not served: refused, counted
+    tab.discard = 2                                                      # sample discarding draws prng_32 words: refused (and counted) until the sampler has the generator's prng_32
     L.sc_hip_vtable_errors.restype = C.c_ulong
     e0 = L.sc_hip_vtable_errors()
     assert tab.vector_32(C.byref(tab), P(v), 4, 0) == 1 and L.sc_hip_vtable_errors() == e0 + 1
     g = VOIDP(tab.gauss)
     assert tab.destroy(C.byref(g)) == 0 and not g.value
+
+
+def test_sampler_side_channel_variants_match_the_reference():
+    """shuffle / blinding fillers and sample discarding (sampling.c:107-228) behind the utils_sampling_t mirror: the vectors the reference itself filled from a
+    seeded CSPRNG (tests/golden/sampling_ref.txt), reproduced from the same pool words delivered through the prng_32 / prng_64 callbacks; and the oracle"""
+    from libsafecrypto_amd import load_library
+    from tests.golden_io import load_golden
+    L = load_library()
+    G = load_golden('sampling_ref.txt')
+
+    class SAMP(C.Structure):
+        _pack_ = 1
+    SAMP._fields_ = [('create', VOIDP), ('destroy', F(C.c_int32, C.POINTER(VOIDP))), ('get_prng', VOIDP), ('sample', F(C.c_int32, VOIDP)),
+                     ('vector_16', F(C.c_int32, C.POINTER(SAMP), i16p, C.c_size_t, C.c_int32)), ('vector_32', F(C.c_int32, C.POINTER(SAMP), i32p, C.c_size_t, C.c_int32)),
+                     ('precision', C.c_int32), ('dimension', C.c_int32), ('bootstrapped', C.c_int32), ('tail', C.c_float), ('sigma', C.c_float), ('sigma2', C.c_float),
+                     ('gauss', VOIDP), ('prng_ctx', VOIDP), ('discard', C.c_uint32), ('bootstrap', VOIDP)]
+    RNG64, RNG32 = F(C.c_uint64, VOIDP), F(C.c_uint32, VOIDP)
+    L.sc_hip_sampler_create.argtypes = [C.c_float, C.c_float, C.c_void_p, C.c_int, RNG64, C.c_void_p, C.POINTER(VOIDP)]
+    L.sc_hip_sampler_set_rng32.argtypes = [C.c_void_p, RNG32]
+    L.sc_hip_sampler_set_rng32.restype = None
+    L.sc_hip_utils_sampling_fill_sca.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    plain = O.cdt_table(13.42, 215.0)
+    blind = np.zeros(plain.size, dtype=np.uint64)
+    assert L.sc_hip_cdt_build_table_blinding(13.42, 215.0, blind.ctypes.data, blind.size) == 0
+    seen = set()
+    for k in range(int(G['sca_cases'][0])):
+        blinding, discard, n, centre = (int(x) for x in G[f'sca{k}_par'])
+        tape = (np.asarray(G[f'sca{k}_tape']).astype(np.int64) & 0xFFFFFFFF).astype(np.uint32)
+        st = {'i': 0}
+
+        def d32(_c):
+            w = int(tape[st['i']]); st['i'] += 1
+            return w
+
+        def d64(_c):                                              # prng_64: two pool words, high word first (prng.c:963-979)
+            hi = int(tape[st['i']]); lo = int(tape[st['i'] + 1]); st['i'] += 2
+            return (hi << 32) | lo
+        c64, c32 = RNG64(d64), RNG32(d32)
+        table = blind if blinding == 1 else plain
+        h = VOIDP()
+        assert L.sc_hip_sampler_create(13.42, 215.0, table.ctypes.data, table.size, c64, None, C.byref(h)) == 0, L.sc_hip_last_error()
+        L.sc_hip_sampler_set_rng32(h, c32)
+        tab = SAMP()
+        assert L.sc_hip_utils_sampling_fill_sca(C.byref(tab), h, blinding) == 0
+        tab.discard = discard
+        v = np.full(n, 12345, dtype=np.int32)
+        assert tab.vector_32(C.byref(tab), P(v), n, centre) == 0, L.sc_hip_last_error()
+        assert np.array_equal(v, G[f'sca{k}_v']), (k, blinding, discard)
+        want, used = O.sample_vector_sca(n, centre, blinding, discard, tape, table)
+        assert np.array_equal(v, want) and used == st['i']        # the same words consumed, in the same order
+        if k in (5, 10):                                          # the 16-bit fillers, on a fresh stretch of the same tape
+            st['i'] = 0
+            v16 = np.zeros(n, dtype=np.int16)
+            assert tab.vector_16(C.byref(tab), v16.ctypes.data_as(i16p), n, centre) == 0
+            assert np.array_equal(v16.astype(np.int32), G[f'sca{k}_v'])
+        seen.add((blinding, discard))
+        g = VOIDP(tab.gauss)
+        assert tab.destroy(C.byref(g)) == 0
+    assert len(seen) == 12
