@@ -326,15 +326,21 @@ static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
             /* the context's OWN sampler table (long double expl is host-dependent in its last bit): the samples are the reference's on any host */
             if (NULL != sc->sc_gauss && CDF_GAUSSIAN_SAMPLING == sc->sampling && SAMPLING_64BIT == sc->sc_gauss->precision) {
                 const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)sc->sc_gauss->gauss;
-                if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table(g_reg[i].bliss, v->cdf, v->cdf_size)) return NULL;
+                if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table(g_reg[i].bliss, v->cdf, v->cdf_size)) goto drop;
             }
-            if (SC_HIP_SUCCESS != bliss_coding(sc, g_reg[i].bliss)) return NULL;
+            if (SC_HIP_SUCCESS != bliss_coding(sc, g_reg[i].bliss)) goto drop;
         }
         const SINT16 *priv = (sc->privkey && sc->privkey->key) ? (const SINT16 *)sc->privkey->key : NULL;
-        if (SC_HIP_SUCCESS != sc_hip_bliss_set_key(g_reg[i].bliss, priv, priv ? priv + P->n : NULL, (const SINT16 *)sc->pubkey->key)) return NULL;
+        if (SC_HIP_SUCCESS != sc_hip_bliss_set_key(g_reg[i].bliss, priv, priv ? priv + P->n : NULL, (const SINT16 *)sc->pubkey->key)) goto drop;
         g_reg[i].have_priv = priv != NULL; g_reg[i].have_pub = 1;
     }
     return g_reg[i].bliss;
+drop:
+    /* a handle that is only partly set up (host-tabulated table, raw coding) must not be found by the next call, which would skip the set-up and sign in
+     * the wrong format: destroyed and forgotten, as the other schemes' handles are on a partial failure */
+    sc_hip_bliss_destroy(g_reg[i].bliss);
+    g_reg[i].bliss = NULL; g_reg[i].have_priv = g_reg[i].have_pub = 0;
+    return NULL;
 }
 
 static sc_hip_tesla_t *tesla_handle(safecrypto_t *sc)

@@ -118,14 +118,21 @@ struct HostPins {
     {
         flags = register_flags;
         if (!enabled() || t_skip_host_pin) return;
-        // merge what overlaps or shares a page, then keep the whole pages inside
+        // merge what overlaps or abuts; two DISJOINT ranges that merely share a page stay separate - the gap between them is somebody else's memory
+        // (allocator metadata, a foreign heap block) and must not become an interior page of a union - and the later one gives the shared
+        // page up: its start moves past it, so that page is staged, not registered
         for (size_t i = 0; i < want.size(); i++)
             for (size_t j = i + 1; j < want.size();) {
-                const uintptr_t li = want[i].lo & ~(PAGE - 1), hi_i = (want[i].hi + PAGE - 1) & ~(PAGE - 1);
-                if (want[j].lo < hi_i && want[j].hi > li) {
+                if (want[j].lo <= want[i].hi && want[j].hi >= want[i].lo) {
                     want[i].lo = want[i].lo < want[j].lo ? want[i].lo : want[j].lo; want[i].hi = want[i].hi > want[j].hi ? want[i].hi : want[j].hi;
                     want.erase(want.begin() + (long)j); j = i + 1;
                 } else j++;
+            }
+        for (size_t i = 0; i < want.size(); i++)
+            for (size_t j = 0; j < want.size(); j++) {
+                if (i == j || want[j].lo < want[i].hi) continue;                    // j lies behind i
+                const uintptr_t page_end = (want[i].hi + PAGE - 1) & ~(PAGE - 1);   // end of the page i's last byte is on
+                if (want[j].lo < page_end) want[j].lo = page_end < want[j].hi ? page_end : want[j].hi;
             }
         for (const Range &r : want) {
             const bool raw = mode() == 2;                                  // bisecting only: the caller's range as it is, edge pages included

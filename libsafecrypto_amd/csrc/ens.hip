@@ -39,7 +39,7 @@ constexpr int ENS_LOOK = 16;
 __global__ __launch_bounds__(HT) void ens_sample_kernel(uint32_t batch, const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens, EnsC C,
                                                         int32_t *r, int32_t *e, uint32_t *used, uint32_t *status, int n)
 {
-    extern __shared__ uint32_t rows[];                             // HT rows of n / 4 words (n = 1024: the 64 KB a workgroup may have)
+    extern __shared__ uint32_t rows[];                             // HT rows of n / 4 words: 64 KB at n = 1024, + the 520 bytes below - above a 64 KB workgroup limit; gfx950 gives a workgroup up to 160 KB, checked when the handle is created
     __shared__ int8_t s_lvl[1024 / 2 + 8];                         // s_lvl[a]: the magnitude the (a + 1)-th accepted draw of a polynomial writes (12 - j while the counts of 0..j cover a)
     const int RS = n / 4;
     const uint32_t base = blockIdx.x * HT, i = base + threadIdx.x;
@@ -242,6 +242,13 @@ extern "C" int sc_hip_ens_create(sc_hip_ctx_t *ctx, const sc_hip_ens_params_t *p
     int total = 0;
     for (int j = 0; j < 12; j++) { if (P.coeff_rnd[j] < 0) return fail("ens_create: negative coefficient count"); total += P.coeff_rnd[j]; }
     if (total > P.n / 2) return fail("ens_create: more than n/2 non-zero coefficients");
+    {
+        // ens_sample_kernel: a row of n signed bytes per lane + its level table; ens_dec_finish_kernel stays below this
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device) != hipSuccess) { (void)hipGetLastError(); lds = 65536; }
+        if ((size_t)HT * (size_t)P.n + 1024 / 2 + 8 + 64 > (size_t)lds)
+            return fail("ens_create: the sampling kernel needs " + std::to_string((size_t)HT * (size_t)P.n + 584) + " bytes of LDS per workgroup, this device allows " + std::to_string(lds));
+    }
     sc_hip_ens *h = new sc_hip_ens();
     h->ctx = ctx; h->P = P;
     if (sc_hip_plan_create(ctx, P.q, P.n, &h->plan) != SC_HIP_SUCCESS) { sc_hip_ens_destroy(h); return SC_HIP_FAILURE; }

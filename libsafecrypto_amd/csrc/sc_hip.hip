@@ -975,9 +975,10 @@ static int host_roundtrip(sc_hip_plan_t *p, int op, size_t batch, const int32_t 
     // driver pinned for its workers or one the caller allocated pinned moves direct as it is; everything else in pieces the runtime stages
     sc::HostPins own;
     const sc::HostPins *use = sc::t_driver_pins;                   // a worker of the multi-device driver: the driver's registrations, none of its own
-    bool cp[3] = { false, false, false };
+    // (a read-only attribute query, in the driver's workers too: the driver's registration of a buffer the caller allocated pinned fails silently, and such a
+    // buffer would otherwise move in staged 1 MiB pieces - ADVICE r03)
+    const bool cp[3] = { sc::caller_allocated_pinned(h0), h1 && sc::caller_allocated_pinned(h1), sc::caller_allocated_pinned(hout) };
     if (!use) {
-        cp[0] = sc::caller_allocated_pinned(h0); cp[1] = h1 && sc::caller_allocated_pinned(h1); cp[2] = sc::caller_allocated_pinned(hout);
         if (!cp[0]) own.add(h0, bytes);
         if (h1 && !cp[1]) own.add(h1, bytes);
         if (!cp[2]) own.add(hout, bytes);
