@@ -293,6 +293,20 @@ __device__ __forceinline__ int32_t wave_fold(int32_t v, F op)
 __device__ __forceinline__ int32_t wave_sum(int32_t v) { return wave_fold(v, [](int32_t a, int32_t b) { return a + b; }); }
 __device__ __forceinline__ int32_t wave_max(int32_t v) { return wave_fold(v, [](int32_t a, int32_t b) { return max(a, b); }); }
 
+// A[d] = <f, x^d f> + <g, x^d g> in Z[x] / (x^n + 1): (x^d f)[m] = f[m - d] for m >= d, -f[m - d + n] below.  Once per key load; a thread per d.
+__global__ void bl_acorr_kernel(const int16_t *__restrict__ f, const int16_t *__restrict__ g, int32_t *__restrict__ out, int n)
+{
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n) return;
+    int32_t acc = 0;
+    for (int m = 0; m < n; m++) {
+        const int k = m - d;
+        const int32_t fv = k >= 0 ? (int32_t)f[k] : -(int32_t)f[k + n], gv = k >= 0 ? (int32_t)g[k] : -(int32_t)g[k + n];
+        acc += (int32_t)f[m] * fv + (int32_t)g[m] * gv;
+    }
+    out[d] = acc;
+}
+
 struct BitW {
     uint8_t *p; uint32_t nbytes; uint64_t acc; int nb;
     __device__ __forceinline__ void put(uint32_t v, int bits)
@@ -305,14 +319,15 @@ struct BitW {
 
 // one wavefront per message: greedy_sc, the +-(x,y) choice, the rejection test, signature_gen, check_norms, packing
 // (bliss_b.c:1399-1463).  Coefficient j = lane + 64 c.
+template <int KMAX>                                                       // kappa <= KMAX (32: BLISS-B-0 .. III, 64: anything bliss_create admits)
 __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *ok, St s,
                                                         const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens,
                                                         const int16_t *f, const int16_t *g, int32_t *tu, const int32_t *v, const int16_t *z,
                                                         const int32_t *cidx, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
                                                         uint32_t *next_active, uint32_t *next_count, BlissP P, double tie_rel, size_t key_stride, uint32_t max_iter,
-                                                        const uint32_t *nd)
+                                                        const uint32_t *nd, const int32_t *acorr)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]
+    extern __shared__ __attribute__((aligned(16))) int32_t xy[];         // per wave: x[n], y[n]; behind the four waves' pairs: per wave the key's 2n-word shift table (one-key path)
     if (nd) nact = min(nact, *nd);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, n = P.n, C = n / 64;
     const uint32_t aidx = blockIdx.x * 4 + wid;
@@ -336,16 +351,11 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
     }
     f += (size_t)src * key_stride; g += (size_t)src * key_stride;        // key_stride = n: a private key per message
 
-    // greedy_sc
-    for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    // the lane's coefficients of f and g do not change over the kappa steps: read once (n <= 512: eight per lane), as is the next step's index
     constexpr int MAXC = 8;
-    int32_t fr[MAXC], gr[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) { const int j = lane + 64 * c; fr[c] = c < C ? (int32_t)f[j] : 0; gr[c] = c < C ? (int32_t)g[j] : 0; }
-    // ... and everything else the decision reads from global memory - the reservoir's state and tape words, the attempt's vectors t and u, the
-    // (v and its rounding z further down) - is requested here, in front of the kappa dependent steps of greedy_sc, not after them
+    int32_t xr[MAXC], yr[MAXC];                                           // the lane's coefficients of greedy_sc's x and y (j = lane + 64 c)
+    int32_t num = 0;
+    // everything the decision reads from global memory besides the key - the reservoir's state and tape words, the attempt's vectors t and u (v and its
+    // rounding z further down) - is requested here, in front of greedy_sc, not after it
     Tape T{ tapes + (size_t)src * tape_stride, tape_lens ? tape_lens[src] : (uint32_t)tape_stride, s.pos[item], s.var_buf[item], s.var_bits[item], false };
     T.prefetch();
     const uint32_t cur = s.cur[item];
@@ -356,6 +366,71 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         const int j = lane + 64 * c;
         tr[c] = c < C ? t[j] : 0; ur[c] = c < C ? u[j] : 0;
     }
+    if (acorr) {
+        // greedy_sc (bliss_b.c:622-679) under ONE key, without its kappa dependent sweeps over x and y.  x = sum_k s_k x^{i_k} f and y likewise with g (x^i: the
+        // negacyclic shift the two inner loops of a step apply); multiplication by x^i preserves inner products, so the quantity step k tests is
+        //     sgn_k = <x^{i_k} f, x> + <x^{i_k} g, y> = sum_{k' < k} s_k' A[|i_k - i_k'|],   A[d] = <f, x^d f> + <g, x^d g>
+        // - the key's autocorrelation, n integers tabulated when the key is loaded (bl_acorr_kernel).  The kappa signs are therefore kappa steps of ONE
+        // multiply-add per lane (lane k carries sgn_k) instead of kappa sweeps of 2n products with a wavefront reduction each, and x, y are then built in one
+        // pass with no dependence between its terms.  All integers, the same sums: the signatures are the reference's byte for byte (tests/test_gpu_bliss.py).
+        // the key in LDS as this wavefront's shift table: word n + m = (f[m], g[m]) as two int16, word m = their negatives, m = 0 .. n-1 - then
+        // (x^i f, x^i g)[j] = word n + j - i for every j, the sign of the wrapped part included, and a lane's eight coefficients of a term are eight reads
+        // at fixed offsets from one address
+        uint32_t *fg2 = reinterpret_cast<uint32_t *>(xy + (size_t)4 * 2 * n) + (size_t)wid * 2 * n;
+        for (int c = 0; c < C; c++) {
+            const int j = lane + 64 * c;
+            const int32_t fv = f[j], gv = g[j];
+            fg2[n + j] = ((uint32_t)fv & 0xFFFFu) | ((uint32_t)gv << 16);
+            fg2[j] = ((uint32_t)(-fv) & 0xFFFFu) | ((uint32_t)(-gv) << 16);
+        }
+        const int kap = P.kappa;
+        const int my_i = lane < kap ? cidx[(size_t)aidx * kap + lane] : 0;
+        int32_t m[KMAX];                                                  // m[k'] = A[|i_lane - i_k'|]: independent look-ups, all requested before the chain below
+#pragma unroll
+        for (int kp = 0; kp < KMAX; kp++) {
+            if (kp < kap) { const int d = my_i - __builtin_amdgcn_readlane(my_i, kp); m[kp] = acorr[d < 0 ? -d : d]; }
+            else m[kp] = 0;
+        }
+        int32_t acc = 0, my_s = 0;
+#pragma unroll
+        for (int kp = 0; kp < KMAX; kp++) {
+            if (kp < kap) {
+                const int32_t sg = __builtin_amdgcn_readlane(acc, kp) > 0 ? -1 : 1;      // step kp's sign: its sum is complete (contributions of the steps before it)
+                if (lane == kp) my_s = sg;
+                if (lane > kp) acc += sg * m[kp];
+            }
+        }
+        // |x|^2 + |y|^2 = sum_k A[0] + 2 sum_k s_k sgn_k
+        num = wave_sum(lane < kap ? acorr[0] + 2 * my_s * acc : 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();      // fg2 is written
+        // x, y as packed int16 pairs (|x|, |y| <= kappa max|f|, max|g|: far below 2^15): one packed multiply-add per term and coefficient
+        typedef short s2 __attribute__((ext_vector_type(2)));
+        s2 xy16[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) xy16[c] = s2{ 0, 0 };
+        for (int kp = 0; kp < kap; kp++) {
+            const int i = __builtin_amdgcn_readlane(my_i, kp), sg = __builtin_amdgcn_readlane(my_s, kp);
+            const s2 sgp = s2{ (short)sg, (short)sg };
+            const uint32_t *row = fg2 + (n + lane - i);
+#pragma unroll
+            for (int c = 0; c < MAXC; c++) {
+                if (c < C) {
+                    const uint32_t w = row[64 * c];
+                    s2 fg; __builtin_memcpy(&fg, &w, 4);
+                    xy16[c] = fg * sgp + xy16[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) { xr[c] = (int32_t)xy16[c].x; yr[c] = (int32_t)xy16[c].y; }
+    } else {
+    // greedy_sc as the reference runs it (a private key per message: its autocorrelation would cost more than the sweeps)
+    for (int c = 0; c < C; c++) { x[lane + 64 * c] = 0; y[lane + 64 * c] = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // the lane's coefficients of f and g do not change over the kappa steps: read once (n <= 512: eight per lane), as is the next step's index
+    int32_t fr[MAXC], gr[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) { const int j = lane + 64 * c; fr[c] = c < C ? (int32_t)f[j] : 0; gr[c] = c < C ? (int32_t)g[j] : 0; }
     int inext = cidx[(size_t)aidx * P.kappa];
     for (int k = 0; k < P.kappa; k++) {
         const int i = inext;
@@ -382,24 +457,31 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
     }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        const int j = lane + 64 * c;
+        xr[c] = c < C ? x[j] : 0; yr[c] = c < C ? y[j] : 0;
+        num += xr[c] * xr[c] + yr[c] * yr[c];
+    }
+    num = wave_sum(num);
+    }
 
     // the CSPRNG reservoir of this message (every lane computes the same scalar sequence; lane 0 writes it back)
     // (T, t, u and the registers tr, ur, vr, zr: loaded above)
     const bool sub = T.var(1) != 0;
-    int32_t num = 0, den = 0;
+    int32_t den = 0;
 #pragma unroll
     for (int c = 0; c < MAXC; c++) {
         if (c < C) {
             const int j = lane + 64 * c;
-            const int32_t xx = x[j], yy = y[j];
+            const int32_t xx = xr[c], yy = yr[c];
             const int32_t tt = sub ? tr[c] - xx : tr[c] + xx, uu = sub ? ur[c] - yy : ur[c] + yy;
             t[j] = tt; u[j] = uu;
             tr[c] = tt; ur[c] = uu;
-            num += xx * xx + yy * yy;
             den += tt * xx + uu * yy;
         }
     }
-    num = wave_sum(num); den = wave_sum(den);
+    den = wave_sum(den);
     // v and its rounding z are needed behind the rejection test: requested here, in front of the exp / cosh arithmetic
     int32_t vr[MAXC], zr[MAXC];
 #pragma unroll
@@ -927,6 +1009,7 @@ struct sc_hip_bliss {
     bool have_key;
     int16_t *d_f, *d_g;
     int32_t *d_a;
+    int32_t *d_acorr;            // A[d] = <f, x^d f> + <g, x^d g>, d = 0 .. n-1: what greedy_sc's sign decisions need of the key (bl_decide_kernel)
     size_t cap;
     St st;
     uint32_t *act[2], *cnt, *need, *sbase, *ok, *trials;
@@ -1082,6 +1165,7 @@ extern "C" void sc_hip_bliss_destroy(sc_hip_bliss_t *b)
     if (b->seed_list) (void)hipFree(b->seed_list);
     if (b->d_f) (void)sc::wipe_free(b->d_f);
     if (b->d_g) (void)sc::wipe_free(b->d_g);
+    if (b->d_acorr) (void)sc::wipe_free(b->d_acorr);
     if (b->d_a) (void)sc::wipe_free(b->d_a);
     if (b->d_huff) (void)hipFree(b->d_huff);
     if (b->d_bac) (void)hipFree(b->d_bac);
@@ -1106,6 +1190,10 @@ extern "C" int sc_hip_bliss_set_key(sc_hip_bliss_t *b, const int16_t *f, const i
         if (!b->d_g) HIPCHK(hipMalloc((void **)&b->d_g, n * 2));
         HIPCHK(sc::copy_in(b->d_f, f, n * 2));
         HIPCHK(sc::copy_in(b->d_g, g, n * 2));
+        if (!b->d_acorr) HIPCHK(hipMalloc((void **)&b->d_acorr, n * 4));
+        hipLaunchKernelGGL(bl_acorr_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, b->d_f, b->d_g, b->d_acorr, (int)n);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(nullptr));
     }
     b->have_key = true;
     return SC_HIP_SUCCESS;
@@ -1234,9 +1322,12 @@ static int bl_round_launch(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hi
     else
         hipLaunchKernelGGL(bl_oracle1_kernel, dim3((nact + HT - 1) / HT), dim3(HT), 0, s, active, nact, b->need, in.msgs, in.msg_stride, in.mlens, in.fixed_len, b->z, b->cidx, b->ok,
                            0, (uint32_t *)nullptr, P, st.msg_of, nd);
-    hipLaunchKernelGGL(bl_decide_kernel, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n, s, active, nact, b->need, b->ok, st, in.tapes, in.tape_stride, in.tape_lens,
-                       in.kf ? in.kf : b->d_f, in.kg ? in.kg : b->d_g, r.tu, b->v, b->z, b->cidx, r.sigs, r.sig_stride, r.siglens, r.trials, next, next_cnt, P, b->tie_rel,
-                       in.kf ? (size_t)n : (size_t)0, r.max_iter, nd);
+#define BL_DECIDE(KM) hipLaunchKernelGGL(bl_decide_kernel<KM>, dim3((nact + 3) / 4), dim3(256), sizeof(int32_t) * 8 * (size_t)n + (in.kf ? 0 : sizeof(uint32_t) * 8 * (size_t)n), s, active, nact, b->need, b->ok, st, \
+                       in.tapes, in.tape_stride, in.tape_lens, \
+                       in.kf ? in.kf : b->d_f, in.kg ? in.kg : b->d_g, r.tu, b->v, b->z, b->cidx, r.sigs, r.sig_stride, r.siglens, r.trials, next, next_cnt, P, b->tie_rel, \
+                       in.kf ? (size_t)n : (size_t)0, r.max_iter, nd, in.kf ? (const int32_t *)nullptr : b->d_acorr)
+    if (P.kappa <= 32) BL_DECIDE(32); else BL_DECIDE(64);
+#undef BL_DECIDE
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
