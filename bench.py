@@ -702,6 +702,15 @@ def cdt_extra(eng, torch):
             'algorithmic_bytes_per_sample': 12, **out}
 
 
+def batch_share(total, world, rank, shard):
+    """units of a BASELINE batch this rank works on: all of them (weak scaling, the default: every rank runs the stated batch) or, with --shard,
+    its contiguous slice of them (strong scaling: sc_hip_shard_range, the cut the C driver csrc/multi.cpp makes; sizes differ by at most one)"""
+    if not shard:
+        return total
+    from libsafecrypto_amd import shard_range
+    return shard_range(total, world, rank)[1]
+
+
 def north_star_summary(extra, cfg):
     """BASELINE configs[2..4] in a few hundred bytes each (the full blocks go to bench_extra.json / the EXTRA line)"""
     def rl(b):
@@ -823,9 +832,7 @@ def main():
 
     # weak scaling (default): every rank runs the stated batch; --shard: the stated batch is cut into contiguous slices, one per rank
     def my_share(total):
-        if not args.shard:
-            return total
-        return shard_range(total, world, rank)[1]                   # sc_hip_shard_range: (begin, count) of this rank's contiguous slice
+        return batch_share(total, world, rank, args.shard)
     batch = my_share(BATCH)
     total_batch = BATCH if args.shard else BATCH * world
 

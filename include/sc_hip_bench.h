@@ -61,7 +61,9 @@ void sc_hip_bench_set_host_pin(int on);
 /* BLISS-B signer: 1 (default) = after a message's first pair of attempts its later pairs are evaluated side by side (the tape position of an attempt does
  * not depend on any value, so pair p starts from a state the host computes; the lowest successful attempt is the signature); 0 = the reference's loop
  * round by round; 2 = as 1, but every third message that goes on to its later pairs is sent through the redo path (the one a failed oracle call
- * would take: state reset, the loop in order) - a self-test.  Signatures, attempt counts and statuses do not depend on it. */
+ * would take: state reset, the loop in order) - a self-test; 3 = as 1, but the first later pass (queued without a look at how many messages go on, for
+ * batches of 1024 and more) is sized for ONE message, so that it is refused and redone with the count in hand - a self-test of that path.
+ * Signatures, attempt counts and statuses do not depend on it. */
 int sc_hip_bliss_set_speculation(sc_hip_bliss_t *h, int on);
 
 /* process-wide: how the batched NTT kernels touch memory.  1 (default): operations whose operands exceed the 256 MiB Infinity Cache move their

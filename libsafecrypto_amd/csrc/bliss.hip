@@ -1151,7 +1151,7 @@ static void bl_free_ws2(sc_hip_bliss *b);
 extern "C" int sc_hip_bliss_set_speculation(sc_hip_bliss_t *b, int on)
 {
     if (!b) return fail("bliss_set_speculation: null handle");
-    if (on < 0 || on > 2) return fail("bliss_set_speculation: 0, 1 or 2");
+    if (on < 0 || on > 3) return fail("bliss_set_speculation: 0, 1, 2 or 3");
     b->speculate = on;
     return SC_HIP_SUCCESS;
 }
@@ -1252,6 +1252,7 @@ extern "C" int sc_hip_bliss_sign_keys(sc_hip_bliss_t *b, size_t batch, const int
 struct BlRun {
     St st; int32_t *tu; uint8_t *sigs; size_t sig_stride; uint32_t *siglens, *trials;
     uint32_t items; const uint32_t *active0; uint32_t max_iter;
+    const uint32_t *items_dev = nullptr;      // the item count where only the device knows it (`items` is then the host's upper bound): a pass queued without a look
 };
 struct BlIn {
     const int16_t *kf, *kg, *ka16; const uint8_t *msgs; size_t msg_stride; const uint32_t *mlens; uint32_t fixed_len;
@@ -1313,7 +1314,7 @@ static int bl_round_launch(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hi
     hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, r.tu, b->tin, n, in.ka16, b->ain, st.msg_of, nd);
     HIPCHK(hipGetLastError());
     // (with a device-side count the product runs over the bound: rows past the count hold what an earlier round left there and are read by nobody)
-    if (in.ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s)) return SC_HIP_FAILURE;
+    if (in.ka16 ? sc_hip_polymul_ntt(b->plan, nact, b->tin, b->ain, b->v, s) : sc::polymul_ntt_bcast(b->plan, nact, b->tin, b->d_a, b->v, s, nd)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(bl_round_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, st.cur, r.tu, b->v, b->z, P, nd);
     // two lanes per message while the one-lane kernel would not give every SIMD a wavefront (measured: +10 % sign at 16384, +12 % at 65536)
     if ((size_t)nact <= (size_t)b->ctx->cus * 4 * 64)
@@ -1340,7 +1341,7 @@ static int bl_rounds(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStrea
         // its count stay on the device (its kernels read them; grids sized for the first round's count), so nothing is read back here: a read-back
         // idles the device for 40-50 us, a fifth of such a round.
         HIPCHK(hipMemsetAsync(b->cnt, 0, 8, s));
-        if (bl_round_launch(b, r, in, s, r.active0, r.items, nullptr, b->act[0], b->cnt)) return SC_HIP_FAILURE;
+        if (bl_round_launch(b, r, in, s, r.active0, r.items, r.items_dev, b->act[0], b->cnt)) return SC_HIP_FAILURE;
         return bl_round_launch(b, r, in, s, b->act[0], r.items, b->cnt, b->act[1], b->cnt + 1);
     }
     uint32_t nact = r.items;
@@ -1396,10 +1397,21 @@ __global__ void bl_collect_kernel(const uint32_t *status, uint32_t count, uint32
     if (st == 7) list7[atomicAdd(&cnt[0], 1u)] = i;
     else if (st == 8) list8[atomicAdd(&cnt[1], 1u)] = i;
 }
+// a later pass queued WITHOUT a look at how many messages go on: the device checks the count against what the pass was sized for and derives the item count
+// (out[0] = messages, out[1] = items, out[2] = messages again, kept for the closing wipe of a seeded call, out[3] = the pass was refused)
+// More messages than the pass was sized for (a quarter of the batch where an eighth is expected: tens of standard deviations away, but possible): the pass
+// serves NOBODY - serving some would leave the others to skip pairs - and out[3] tells the look behind it to start over with the count in hand.
+__global__ void bl_blind_kernel(const uint32_t *cnt7, uint32_t bound, uint32_t pp, uint32_t *out)
+{
+    const bool over = cnt7[0] > bound;
+    const uint32_t nu = over ? 0u : cnt7[0];
+    out[0] = nu; out[1] = nu * pp; out[2] = nu; out[3] = over ? 1u : 0u;
+}
 // item j * pp + k = pair p0 + k of message list[j]
 __global__ void bl_pair_init_kernel(const uint32_t *list, uint32_t nu, uint32_t pp, PairInit pi, St v, uint32_t *msg_of, const uint32_t *tapes, size_t tape_stride,
-                                    const uint32_t *tape_lens, uint32_t *siglens, uint32_t *trials)
+                                    const uint32_t *tape_lens, uint32_t *siglens, uint32_t *trials, const uint32_t *nud)
 {
+    if (nud) nu = min(nu, *nud);
     const uint32_t vid = blockIdx.x * blockDim.x + threadIdx.x;
     if (vid >= nu * pp) return;
     const uint32_t m = list[vid / pp], k = vid % pp;
@@ -1412,8 +1424,10 @@ __global__ void bl_pair_init_kernel(const uint32_t *list, uint32_t nu, uint32_t 
 }
 // one wavefront per message of the list: the first of its pairs that did not fail twice decides it
 __global__ __launch_bounds__(64) void bl_resolve_kernel(const uint32_t *msg_of, uint32_t pp, uint32_t p0, const uint32_t *vstatus, const uint8_t *vsigs, const uint32_t *vsiglens,
-                                                        const uint32_t *vtrials, size_t sig_stride, uint32_t *status, uint8_t *sigs, uint32_t *siglens, uint32_t *trials)
+                                                        const uint32_t *vtrials, size_t sig_stride, uint32_t *status, uint8_t *sigs, uint32_t *siglens, uint32_t *trials,
+                                                        const uint32_t *nud)
 {
+    if (nud && blockIdx.x >= *nud) return;
     const uint32_t j = blockIdx.x, m = msg_of[j * pp];
     uint32_t k = 0;
     while (k < pp && vstatus[j * pp + k] == 7) k++;
@@ -1516,12 +1530,13 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     const bool spec = b->speculate != 0;
     // seeded: blocks (16 bytes = 4 words) of every row filled so far, of the rows of the later passes (seed_list[0..seed_nu)), and whether some rows were filled whole
     size_t blk_all = 0, blk_later = 0; uint32_t seed_nu = 0; bool seed_whole = false;
-    auto seed_fill = [&](const uint32_t *list, uint32_t count, size_t from, size_t to) -> int {
-        return sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, list, count, nullptr, b->seed_tape, tape_stride * 4, from, to, 1, false, s);
+    const uint32_t *seed_nud = nullptr;
+    auto seed_fill = [&](const uint32_t *list, uint32_t count, const uint32_t *count_dev, size_t from, size_t to) -> int {
+        return sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, list, count, count_dev, b->seed_tape, tape_stride * 4, from, to, 1, false, s);
     };
     if (seeded) {
         blk_all = spec ? (sc_hip_bliss_tape_words(P.n, 2) + 3) / 4 : tape_stride / 4;      // the plain loop's consumption is not known in advance: whole rows
-        if (seed_fill(nullptr, B, 0, blk_all)) return SC_HIP_FAILURE;
+        if (seed_fill(nullptr, B, nullptr, 0, blk_all)) return SC_HIP_FAILURE;
         blk_later = blk_all;
     }
     bool dirty = true;                                                // the handle's vector arrays hold this call's secrets
@@ -1534,25 +1549,45 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);                 // pair 0 is behind us
         uint32_t *ulist = b->act[0];                                  // (the round loop is idle here: its two lists are free)
         uint32_t n8 = 0;
+        ResSim sim_saved; size_t blk_saved = 0; bool was_blind = false, refused = false;
         for (uint32_t p0 = 1;; ) {
             if (p0 > 50000) return fail("bliss_sign: rejection loop did not terminate");
             uint32_t both[2] = { 0, 0 };
-            HIPCHK(hipMemsetAsync(b->cnt, 0, 8, s));
-            hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, ulist, b->act[1], b->cnt);
-            HIPCHK(hipMemcpyAsync(both, b->cnt, 8, hipMemcpyDeviceToHost, s));
-            if (p0 > 1 && dirty) {
-                // behind a pass of later pairs this look almost always finds nobody left: the call's closing wipes are queued in front of the wait, so
-                // the device zeroes while the host waits for the two counts (should a message be left, the arrays are simply used and zeroed again)
-                if (bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
-                dirty = false;
-                if (d_status && !b->entropy) { HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s)); status_out = true; }
+            uint32_t *cnt7 = b->cnt + 8;                              // (b->cnt[0..1] belong to the round loop)
+            HIPCHK(hipMemsetAsync(cnt7, 0, 8, s));
+            hipLaunchKernelGGL(bl_collect_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B, ulist, b->act[1], cnt7);
+            // The first later pass is queued WITHOUT a look (a look idles the device for ~45 us and leaves the pass's first launches exposed one by one): one
+            // message in eight goes on, so the pass is sized for a sixth of the batch (+ 64), the device checks the count against that (bl_blind_kernel) and every kernel of the
+            // pass takes its count from the device; whoever is not served - beyond the bound, or failing all four pairs - is found by the look behind it.
+            const bool blind = p0 == 1 && B >= 1024 && !refused;
+            uint32_t nu, pp = BL_PAIRS;
+            const uint32_t *nud = nullptr, *nvd = nullptr;
+            if (blind) {
+                nu = b->speculate == 3 ? 1u : B / 6 + 64;            // an eighth is expected (+- 0.3 % of the batch at 16384): ten standard deviations of room at 1024, more above; (3: self-test of the refusal path - a pass sized for one message)
+                hipLaunchKernelGGL(bl_blind_kernel, dim3(1), dim3(1), 0, s, cnt7, nu, pp, b->cnt + 10);
+                nud = b->cnt + 10; nvd = b->cnt + 11;
+                sim_saved = sim; blk_saved = blk_later; was_blind = true;
+            } else {
+                uint32_t flag = 0;
+                HIPCHK(hipMemcpyAsync(both, cnt7, 8, hipMemcpyDeviceToHost, s));
+                if (was_blind) HIPCHK(hipMemcpyAsync(&flag, b->cnt + 13, 4, hipMemcpyDeviceToHost, s));
+                if (p0 > 1 && dirty) {
+                    // behind a pass of later pairs this look almost always finds nobody left: the call's closing wipes are queued in front of the wait, so
+                    // the device zeroes while the host waits for the two counts (should a message be left, the arrays are simply used and zeroed again)
+                    if (bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
+                    dirty = false;
+                    if (d_status && !b->entropy) { HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s)); status_out = true; }
+                }
+                HIPCHK(hipStreamSynchronize(s));
+                if (was_blind && flag) {                              // the unlooked pass was refused (see bl_blind_kernel): nothing was served, start the later pairs over
+                    sim = sim_saved; blk_later = blk_saved; p0 = 1; refused = true; seed_nu = 0; seed_nud = nullptr;
+                }
+                was_blind = false;
+                nu = both[0];
+                n8 = both[1];                                         // (status 8 stays: the last pass, the one that finds no 7, leaves the whole list in act[1])
+                if (nu == 0) break;
+                while (pp > 1 && (size_t)nu * pp > batch) pp >>= 1;   // the per-round arrays are sized for the batch
             }
-            HIPCHK(hipStreamSynchronize(s));
-            const uint32_t nu = both[0];
-            n8 = both[1];                                             // (status 8 stays: the last pass, the one that finds no 7, leaves the whole list in act[1])
-            if (nu == 0) break;
-            uint32_t pp = BL_PAIRS;
-            while (pp > 1 && (size_t)nu * pp > batch) pp >>= 1;       // the per-round arrays are sized for the batch
             PairInit pi{};
             for (uint32_t k = 0; k < pp; k++) {
                 pi.pos[k] = sim.pos; pi.lrp[k] = sim.lrp; pi.vb[k] = sim.vb;
@@ -1561,22 +1596,24 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             const uint32_t nv = nu * pp;
             if (seeded) {
                 // the words these pairs draw, for the messages that go on (every later pass works on a subset of the first one's list)
-                if (p0 == 1) { HIPCHK(hipMemcpyAsync(b->seed_list, ulist, (size_t)nu * 4, hipMemcpyDeviceToDevice, s)); seed_nu = nu; }
+                if (p0 == 1) { HIPCHK(hipMemcpyAsync(b->seed_list, ulist, (size_t)nu * 4, hipMemcpyDeviceToDevice, s)); seed_nu = nu; seed_nud = blind ? b->cnt + 12 : nullptr; }
                 size_t to = ((size_t)sim.pos + 3) / 4;
                 if (to > tape_stride / 4) to = tape_stride / 4;
-                if (to > blk_later) { if (seed_fill(ulist, nu, blk_later, to)) return SC_HIP_FAILURE; blk_later = to; }
+                if (to > blk_later) { if (seed_fill(ulist, nu, nud, blk_later, to)) return SC_HIP_FAILURE; blk_later = to; }
             }
             if (bl_ensure_ws2(b, nv, sig_stride)) return SC_HIP_FAILURE;
             St v = b->st2;
-            hipLaunchKernelGGL(bl_pair_init_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, ulist, nu, pp, pi, v, b->msg_of2, d_tapes, tape_stride, d_tape_lens, b->siglens2, b->trials2);
+            hipLaunchKernelGGL(bl_pair_init_kernel, dim3((nv + 255) / 256), dim3(256), 0, s, ulist, nu, pp, pi, v, b->msg_of2, d_tapes, tape_stride, d_tape_lens, b->siglens2, b->trials2, nud);
             HIPCHK(hipGetLastError());
             v.msg_of = b->msg_of2;
-            if (bl_rounds(b, BlRun{ v, b->tu2, b->sigs2, sig_stride, b->siglens2, b->trials2, nv, nullptr, 2u }, in, s)) return SC_HIP_FAILURE;
+            BlRun pass{ v, b->tu2, b->sigs2, sig_stride, b->siglens2, b->trials2, nv, nullptr, 2u };
+            pass.items_dev = nvd;
+            if (bl_rounds(b, pass, in, s)) return SC_HIP_FAILURE;
             dirty = true; status_out = false;
-            hipLaunchKernelGGL(bl_resolve_kernel, dim3(nu), dim3(64), 0, s, b->msg_of2, pp, p0, v.status, b->sigs2, b->siglens2, b->trials2, sig_stride, st.status, d_sigs, d_siglens, trials);
+            hipLaunchKernelGGL(bl_resolve_kernel, dim3(nu), dim3(64), 0, s, b->msg_of2, pp, p0, v.status, b->sigs2, b->siglens2, b->trials2, sig_stride, st.status, d_sigs, d_siglens, trials, nud);
             HIPCHK(hipGetLastError());
             // the later pairs' candidate signatures - valid signatures under fresh randomness, all but one per message discarded - their vectors and their
-            // bookkeeping do not outlive the call either: zeroed as far as this pass used them
+            // bookkeeping do not outlive the call either: zeroed as far as this pass used them (a pass queued without a look: as far as it was sized for)
             if (bl_zero(b, { { b->sigs2, (size_t)nv * sig_stride }, { b->siglens2, (size_t)nv * 4 }, { b->trials2, (size_t)nv * 4 }, { b->tu2, (size_t)nv * 2 * P.n * 4 } }, s))
                 return SC_HIP_FAILURE;
             p0 += pp;
@@ -1586,7 +1623,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             uint32_t *redo = b->act[1];                                // (the round loop's first round reads this list and writes act[0]; later rounds alternate)
             hipLaunchKernelGGL(bl_reset_kernel, dim3((n8 + 255) / 256), dim3(256), 0, s, redo, n8, st);
             HIPCHK(hipGetLastError());
-            if (seeded) { if (seed_fill(redo, n8, 0, tape_stride / 4)) return SC_HIP_FAILURE; seed_whole = true; }
+            if (seeded) { if (seed_fill(redo, n8, nullptr, 0, tape_stride / 4)) return SC_HIP_FAILURE; seed_whole = true; }
             if (bl_rounds(b, BlRun{ st, b->tu, d_sigs, sig_stride, d_siglens, trials, n8, redo, 0u }, in, s)) return SC_HIP_FAILURE;
             dirty = true; status_out = false;
         }
@@ -1621,7 +1658,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         else {
             if (sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, nullptr, B, nullptr, b->seed_tape, tape_stride * 4, 0, blk_all, 1, true, s)) return SC_HIP_FAILURE;
             if (seed_nu && blk_later > blk_all &&
-                sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, b->seed_list, seed_nu, nullptr, b->seed_tape, tape_stride * 4, blk_all, blk_later, 1, true, s)) return SC_HIP_FAILURE;
+                sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, b->seed_list, seed_nu, seed_nud, b->seed_tape, tape_stride * 4, blk_all, blk_later, 1, true, s)) return SC_HIP_FAILURE;
         }
     }
     return SC_HIP_SUCCESS;

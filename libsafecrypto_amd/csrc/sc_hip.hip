@@ -29,6 +29,7 @@ struct NttArgs {
     const uint32_t *zf, *zfp;     // forward twiddles zeta[k] = g^bitrev(k) and Shoup companions
     const uint32_t *zi, *zip;     // inverse twiddles zeta[k]^-1 and companions
     unsigned long long batch;
+    const uint32_t *batch_dev;    // non-null: the batch where only the device knows it (a count a previous kernel left); `batch` is then the host's upper bound
     unsigned in1_bcast;           // != 0: every polynomial is multiplied by the SAME second operand (a public key)
     ModK k;
     uint32_t c0, c0p, c1, c1p;    // inverse output scale (n^-1 [* 2^32]) and zeta[1]^-1 * scale
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
     if (OP != OP_INV) twf.load(a.zf, a.zfp, lp);
     if (OP != OP_FWD) twi.load(a.zi, a.zip, lp);
 
+    if (a.batch_dev) { const unsigned long long bd = *a.batch_dev; if (bd < a.batch) a.batch = bd; }
     const unsigned long long groups = (a.batch + PW - 1) / PW;
     const unsigned long long gstride = (unsigned long long)gridDim.x * 4;
     unsigned long long g = (unsigned long long)blockIdx.x * 4 + wid;
@@ -604,7 +606,8 @@ static hipError_t launch_ntt_op(int L, const NttArgs &a, int mode, bool lazy, in
     }
 }
 
-static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream, bool bcast = false, bool warm_only = false)
+static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, const int32_t *d1, int32_t *dout, void *stream, bool bcast = false, bool warm_only = false,
+                   const uint32_t *batch_dev = nullptr)
 {
     if (!p) return fail("ntt: null plan");
     if (batch == 0 && !warm_only) return SC_HIP_SUCCESS;
@@ -613,7 +616,7 @@ static int run_ntt(sc_hip_plan_t *p, int op, size_t batch, const int32_t *d0, co
     const int mi = p->mode == MODE_U24 ? 0 : 1;
     const int n = p->n;
     NttArgs a;
-    a.in0 = d0; a.in1 = d1; a.out = dout; a.sink = p->d_sink; a.in1_bcast = bcast ? 1u : 0u;
+    a.in0 = d0; a.in1 = d1; a.out = dout; a.sink = p->d_sink; a.in1_bcast = bcast ? 1u : 0u; a.batch_dev = batch_dev;
     const bool sgn = p->mode == MODE_SMAD || p->mode == MODE_S32;
     a.zf = sgn ? p->d_tab_s : p->d_tab[mi]; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
     a.batch = batch; a.k = p->k[mi];
@@ -661,8 +664,8 @@ extern "C" int sc_hip_ntt_inv(sc_hip_plan_t *p, size_t batch, const int32_t *d_i
 extern "C" int sc_hip_polymul_ntt(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
 { return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream); }
 // internal: out[b] = INTT(NTT(a[b]) o bhat) with ONE NTT-domain operand for the whole batch (bliss_b.c:1378-1384: bhat = public key a)
-int sc::polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
-{ return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream, true); }
+int sc::polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream, const uint32_t *batch_dev)
+{ return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream, true, false, batch_dev); }
 extern "C" int sc_hip_polymul(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_b, int32_t *d_out, void *stream)
 { return run_ntt(p, OP_MUL, batch, d_a, d_b, d_out, stream); }
 

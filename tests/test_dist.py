@@ -74,3 +74,32 @@ def test_library_shard_range_is_the_same_rule():
                 lo, hi = shard_range(total, r, world)
                 assert engine.shard_range(total, world, r) == (lo, hi - lo)
     assert engine.shard_range(10, 0, 0) == (0, 0) and engine.shard_range(10, 2, 5) == (0, 0)     # nonsense arguments: an empty slice
+
+
+def _share_worker(rank, world, port, outdir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    rows = []
+    for total in (65536, 16384, 8192, 203):
+        for shard in (False, True):
+            mine = bench.batch_share(total, world, rank, shard)
+            t = torch.tensor([mine], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)               # what bench.py's `value` counts: the units all ranks processed
+            rows.append((total, int(shard), mine, int(t.item())))
+    np.save(os.path.join(outdir, f'share{rank}.npy'), np.array(rows))
+    dist.destroy_process_group()
+
+
+def test_bench_batch_shares_weak_and_strong(tmp_path):
+    """bench.py --gpus N [--shard]: weak scaling repeats the BASELINE batch on every rank, --shard cuts it - the per-rank batches the timed legs run on add
+    up to N x batch and to batch, and the slices differ by at most one unit"""
+    world = 2
+    mp.spawn(_share_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    per = [np.load(tmp_path / f'share{r_}.npy') for r_ in range(world)]
+    for row0, row1 in zip(*per):
+        total, shard, m0, s0 = (int(x) for x in row0)
+        m1, s1 = int(row1[2]), int(row1[3])
+        assert s0 == s1 == (total if shard else total * world)
+        assert m0 + m1 == s0 and abs(m0 - m1) <= 1

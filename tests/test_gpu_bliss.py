@@ -496,6 +496,10 @@ def test_pairs_side_by_side_equal_the_loop_in_order(eng, G):
     # mode 2 sends a third of the late messages through the redo path (state reset, the loop in order): the same again
     assert np.array_equal(st2, st0) and np.array_equal(l2, l0) and np.array_equal(t2, t0)
     assert all(bytes(s2[i, :l2[i]]) == bytes(s0[i, :l0[i]]) for i in range(B))
+    # mode 3 sizes the first later pass (queued without a look) for one message: refused on the device, redone with the count in hand
+    s3, l3, t3, st3 = run(3)
+    assert np.array_equal(st3, st0) and np.array_equal(l3, l0) and np.array_equal(t3, t0)
+    assert all(bytes(s3[i, :l3[i]]) == bytes(s0[i, :l0[i]]) for i in range(B))
     assert sum(1 for i in range(0, B, 3) if t0[i] >= 3) >= 20
     assert set(np.unique(st1)) <= {1, 2} and (st1[late] == 2).sum() >= 10 and (st1[late] == 1).sum() >= 3
     for i in late + [i for i in range(B) if t1[i] >= 3 and i not in late][:15] + list(range(0, B, 101)):

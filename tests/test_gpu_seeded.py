@@ -40,7 +40,7 @@ def test_tapes_of_the_seeds_match_the_oracle(eng):
 
 
 @pytest.mark.parametrize('B', [1, 37, 3000])
-@pytest.mark.parametrize('spec', [1, 0, 2])
+@pytest.mark.parametrize('spec', [1, 0, 2, 3])
 def test_bliss_seeded_equals_tape_fed(eng, B, spec):
     import torch
     G = load_golden('bliss_ref.txt')
