@@ -79,12 +79,13 @@ namespace {
 // blocks b0 + j, b0 + j + G, ... after each has run the (same) key schedule - a lane-per-generator walk of a 16 KB Falcon tape is 1024 sequential AES blocks
 // on 128 wavefronts; with G = 32 it is 32 blocks per lane on 4096 wavefronts, and the G lanes of a generator write 16 G contiguous bytes per step.
 // words != 0: prng_32 order (w1, w0, w3, w2 per block), else prng_mem's byte order.  zero != 0: the same walk storing zeros (the wipe behind a seeded call).
-__global__ __launch_bounds__(256) void drbg_fill_kernel(uint32_t count, const uint32_t *__restrict__ count_dev, const uint32_t *__restrict__ list,
+__global__ __launch_bounds__(512) void drbg_fill_kernel(uint32_t count, const uint32_t *__restrict__ count_dev, const uint32_t *__restrict__ list,
                                                         const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len,
                                                         uint8_t *__restrict__ out, size_t out_stride, uint32_t b0, uint32_t b1, uint32_t lg, int words, int zero, DrbgConst C)
 {
-    __shared__ AesLdsWide L;
-    if (!zero) { L.fill(C); __syncthreads(); }
+    __shared__ AesLds64 T;                                             // a table copy per lane: one v_perm_b32 forms a look-up's address (drbg_dev.h)
+    if (!zero) { T.fill(C); __syncthreads(); }
+    const AesLane64 L(T);
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, G = 1u << lg;
     const uint32_t gen = t >> lg, j = t & (G - 1);
     uint32_t cnt = count;
@@ -96,10 +97,19 @@ __global__ __launch_bounds__(256) void drbg_fill_kernel(uint32_t count, const ui
     Drbg d;
     d.init(seeds + (size_t)row * seed_stride, seed_len, C, L);
     d.counter += b0 + j;
-    for (uint32_t b = b0 + j; b < b1; b += G) {
+    uint32_t b = b0 + j;
+    for (; b + G < b1; b += 2 * G) {                                  // two blocks of the lane side by side (aes256_encrypt2)
+        const uint32_t c0 = d.counter, c1 = d.counter + G;
+        const uint32_t in0[4] = { c0, c0, c0, c0 }, in1[4] = { c1, c1, c1, c1 };
+        uint32_t w[4], v[4];
+        aes256_encrypt2(d.aes, in0, in1, w, v, L);
+        d.counter += 2 * G;
+        o[b] = words ? make_uint4(w[1], w[0], w[3], w[2]) : make_uint4(w[0], w[1], w[2], w[3]);
+        o[b + G] = words ? make_uint4(v[1], v[0], v[3], v[2]) : make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (b < b1) {
         uint32_t w[4];
         d.block(w, L);
-        d.counter += G - 1;
         o[b] = words ? make_uint4(w[1], w[0], w[3], w[2]) : make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
@@ -182,7 +192,7 @@ int drbg_fill(sc_hip_ctx *ctx, const uint8_t *d_seeds, size_t seed_stride, size_
     uint32_t lg = 0;
     while (lg < 6 && ((size_t)count << lg) < want && ((size_t)2 << lg) <= nblk) lg++;
     const size_t threads = (size_t)count << lg;
-    hipLaunchKernelGGL(drbg_fill_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, count, d_count, d_list, d_seeds, seed_stride, (uint32_t)seed_len,
+    hipLaunchKernelGGL(drbg_fill_kernel, dim3((unsigned)((threads + 511) / 512)), dim3(512), 0, s, count, d_count, d_list, d_seeds, seed_stride, (uint32_t)seed_len,
                        (uint8_t *)d_out, out_stride_bytes, (uint32_t)blk0, (uint32_t)blk1, lg, words, zero ? 1 : 0, drbg_const());
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
