@@ -171,13 +171,13 @@ def _pmc(leg):
             sys.stderr.write(f'live PMC pass of {leg} failed: {e}\n')
     if _PMC_COMMITTED is None:
         try:
-            _PMC_COMMITTED = json.load(open(os.path.join(ROOT, 'profiles', 'r03_scheme_pmc.json')))
+            _PMC_COMMITTED = json.load(open(os.path.join(ROOT, 'profiles', 'r04_scheme_pmc.json' if os.path.exists(os.path.join(ROOT, 'profiles', 'r04_scheme_pmc.json')) else 'r03_scheme_pmc.json')))
         except Exception:
             _PMC_COMMITTED = {}
     r = _PMC_COMMITTED.get(leg)
     if r:
         r = dict(r)
-        r['source'] = 'committed: profiles/r03_scheme_pmc.json (tools/pmc_leg.py run by tools/prof_schemes_r3.sh on an earlier box) - NOT this run'
+        r['source'] = 'committed: profiles/r04_scheme_pmc.json (tools/pmc_leg.py run by tools/profile_r04.sh on an earlier box) - NOT this run'
     return r
 
 
@@ -941,7 +941,7 @@ def main():
         if pm and str(pm.get('source', '')).startswith('live'):
             traffic = pm['hbm_bytes_per_op_2xfetch_plus_write'] * pm['batch']
             traffic_source = 'live'
-        for name in ('r03_pmc_traffic.json', 'pmc_traffic.json'):
+        for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'pmc_traffic.json'):
             tp = os.path.join(ROOT, 'profiles', name)
             if not os.path.exists(tp):
                 continue

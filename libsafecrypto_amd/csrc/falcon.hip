@@ -1206,6 +1206,9 @@ __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uin
                                                       int32_t *__restrict__ c, FalP P, int dlp)
 {
     __shared__ uint32_t st[25 * HT];
+    // a chain of 25 dependent permutations on a wavefront that issues one instruction in five cycles: in a seeded call the tape expansion (the cipher, which
+    // fills every issue slot it is given) runs beside this kernel on the handle's side stream - the chain's instructions go first
+    __builtin_amdgcn_s_setprio(3);
     const uint32_t b = (blockIdx.x * HT + threadIdx.x) >> 1;
     const int h = threadIdx.x & 1;
     Sponge2<HT> sp; sp.init(st, threadIdx.x, 168);

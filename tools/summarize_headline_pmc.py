@@ -7,7 +7,7 @@ def values(d, counter):
     out = []
     for f in glob.glob(d + '/*/*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
-            if 'ntt_kernel<8, 4, true, 2>' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+            if 'ntt_kernel<8, 4, true, 2' in r['Kernel_Name'] and r['Counter_Name'] == counter:      # <.., false> plain form, <.., true> streaming form (round 4)
                 out.append(float(r['Counter_Value']))
     return out
 
@@ -23,7 +23,7 @@ for name, lo_hi in (('polymul_ntt_n256_b65536', (0.0, 2.0)), ('polymul_ntt_n256_
         res[name + '_launches'] = [len(ff), len(ww)]
 res['algorithmic_bytes'] = {'b65536': 65536 * 3072, 'b1048576': 1048576 * 3072}
 res['note'] = ('2*FETCH_SIZE + WRITE_SIZE (KB -> bytes), separate rocprofv3 --pmc passes over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras`, '
-               'kernel ntt_kernel<8,4,true,2> (signed small-modulus mode), launches averaged per batch size')
+               'kernel ntt_kernel<8,4,true,2,*> (signed small-modulus mode; the 2^20 batch runs the streaming I/O form), launches averaged per batch size')
 print(json.dumps(res, indent=1))
 
 # the same split for the kernel trace of the full bench command: average duration per batch size (the stats CSV averages both together)
@@ -31,10 +31,10 @@ tr = glob.glob(root + '/trace/*/*_kernel_trace.csv')
 if tr and len(sys.argv) > 2 and sys.argv[2] == 'durations':
     d = []
     for r in csv.DictReader(open(tr[0])):
-        if 'ntt_kernel<8, 4, true, 2>' in r['Kernel_Name']:
+        if 'ntt_kernel<8, 4, true, 2' in r['Kernel_Name']:
             d.append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
     small, big = [x for x in d if x < 4 * min(d)], [x for x in d if x >= 4 * min(d)]
-    print('ntt_kernel<8, 4, true, 2> in the kernel trace of `python3 bench.py --no-cpu-baseline`:', file=sys.stderr)
+    print('ntt_kernel<8, 4, true, 2, *> in the kernel trace of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc`:', file=sys.stderr)
     print(f'  batch 65536 (BASELINE): {len(small)} launches, average {sum(small) / len(small) / 1e3:.2f} us, min {min(small) / 1e3:.2f} us', file=sys.stderr)
     if big:
         print(f'  batch 1048576 (past the Infinity Cache): {len(big)} launches, average {sum(big) / len(big) / 1e3:.2f} us', file=sys.stderr)
