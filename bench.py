@@ -790,6 +790,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
     ap.add_argument('--no-spin', action='store_true', help='leave the runtime\'s host-thread scheduling at its default (the bench asks it to spin in synchronisations)')
     ap.add_argument('--no-live-pmc', action='store_true', help='scheme rooflines from the committed counter pass instead of rocprofv3 child processes of this run')
+    ap.add_argument('--test-one-device', action='store_true', help='testing only: every rank on device 0 over gloo (exercises the N > 1 path on a one-GPU box; figures mean nothing)')
     ap.add_argument('--extra-file', default=os.path.join(ROOT, 'bench_extra.json'), help='where the full tree of legs goes (also printed as an earlier "EXTRA " line)')
     args = ap.parse_args()
 
@@ -805,6 +806,8 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device: the engine has no CPU fallback')
+    if args.test_one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     spin = not args.no_spin
     if spin:
@@ -824,7 +827,10 @@ def main():
             spin = False
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if args.test_one_device:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from libsafecrypto_amd import Engine, shard_range
     eng = Engine(local_rank)

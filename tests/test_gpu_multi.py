@@ -122,3 +122,28 @@ def test_multi_bliss_falcon_tesla_kyber_match_one_device(workers):
     assert np.array_equal(mk.decaps_host(ct), key)
     k1.close()
     m.close(); eng.close()
+
+
+@pytest.mark.parametrize('shard', [False, True])
+def test_bench_two_ranks_contract_line(tmp_path, shard):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with both ranks on device 0 over gloo
+    (--test-one-device): the N > 1 code path - barrier, MAX over ranks, the gathered scheme legs, the weak and the --shard batch arithmetic - must
+    produce a contract line the driver can parse"""
+    import json, os, subprocess, sys, socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2', '--regions', '3', '--test-one-device', '--no-cpu-baseline', '--no-live-pmc',
+           '--extra-file', str(tmp_path / 'extra.json')] + (['--shard'] if shard else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith('{')]
+    line = lines[-1]
+    assert len(line) < 8000
+    d = json.loads(line)
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['scaling'] == ('strong' if shard else 'weak')
+    assert d['config']['batch_per_gpu'] == (32768 if shard else 65536)
+    assert d['value'] > 0 and 0 < d['roofline']['frac'] <= 1.0
+    agg = d['multi_gpu']['aggregate']
+    assert all(v > 0 for v in agg.values()), agg
+    assert d['multi_gpu']['batch_per_gpu'] == ({'dil_batch': 8192, 'bliss_batch': 8192, 'falcon_batch': 4096} if shard else {'dil_batch': 16384, 'bliss_batch': 16384, 'falcon_batch': 8192})
