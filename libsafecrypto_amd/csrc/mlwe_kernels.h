@@ -71,6 +71,7 @@ struct DilNtt {
                                           // the key pair hold it; the other operand (yh) must then carry the Montgomery factor (DOP_KEYPREP's output form).
                                           // 1: polynomial (row, col) at [row][col]; 2: at [col][row] (the transposed product of encryption)
     const uint32_t *ch;                   // [item][n] internal (NTT of c)
+    const uint32_t *t1s;                  // dil_yaw_kernel<..., CT1 = true> (verification): NTT(t1 2^d), [kk][n] internal order, Montgomery form
     const int32_t *y;                     // [item][l][n] natural (mask)
     int32_t *w;                           // [item][k][n] natural canonical
     uint8_t *w1;                          // [item][k*n]
@@ -231,7 +232,9 @@ __global__ __launch_bounds__(256) void dil_ntt_kernel(DilNtt a)
 // ALDS: the matrix (plain values | Shoup companions, 2 kk LL KB) is copied into LDS once per (persistent) workgroup and every product reads it from there:
 // with two wavefronts per SIMD the L2 round trip of the 8 matrix loads per (row, column) was what the wavefronts waited for (49 % of their cycles in
 // s_waitcnt, tools/prof_kernel_pmc.sh).  The host picks it when the matrix and the transforms' exchange image fit twice into a CU's 160 KB.
-template <int LL, int MODE, bool ALDS>
+// CT1 (round 4, verification): the row's c t1 2^d is subtracted IN the NTT domain (NTT(c) from the launch before, NTT(t1 2^d) a key constant) and the row's epilogue
+// is UseHint -> w1: w' = A z - c t1 2^d never exists in HBM, the k inverse transforms of c t1 2^d and the DOP_CT1 launch are gone (dilithium.c:1286-1312).
+template <int LL, int MODE, bool ALDS, bool CT1 = false>
 __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
 {
     constexpr bool SG = MODE == MODE_S32;
@@ -295,9 +298,42 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
 #pragma unroll
                 for (int r = 0; r < 16; r++) x[r] = Mod<MODE_U32>::mulc(x[r], 1u, k.one_p, k);
             }
+            uint32_t hbits = 0;                                         // CT1: the row's sixteen hints of this lane, one bit each (sixteen live bytes spilled)
+            if constexpr (CT1) {
+                const size_t hoff = ((size_t)s * a.kk + i) * N + lp;     // requested first, packed behind the products: in flight under them, one register across the transform
+                uint8_t preh[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) preh[r] = a.h[hoff + r * LP];
+                const uint4 *pc = reinterpret_cast<const uint4 *>(a.ch + (size_t)s * N + lp * 16), *pk = reinterpret_cast<const uint4 *>(a.t1s + (size_t)i * N + lp * 16);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint4 vc = pc[c], vk = pk[c];
+                    if constexpr (SG) {                                 // one more term of magnitude below q beside the LL terms in [0, 2q): the host checks 16 (2 LL + 1) q < 2^31
+                        x[4 * c + 0] -= montmul_s32(vc.x, vk.x, k); x[4 * c + 1] -= montmul_s32(vc.y, vk.y, k);
+                        x[4 * c + 2] -= montmul_s32(vc.z, vk.z, k); x[4 * c + 3] -= montmul_s32(vc.w, vk.w, k);
+                    } else {
+                        x[4 * c + 0] = csub(x[4 * c + 0] + k.q2 - montmul(vc.x, vk.x, k), k.q2); x[4 * c + 1] = csub(x[4 * c + 1] + k.q2 - montmul(vc.y, vk.y, k), k.q2);
+                        x[4 * c + 2] = csub(x[4 * c + 2] + k.q2 - montmul(vc.z, vk.z, k), k.q2); x[4 * c + 3] = csub(x[4 * c + 3] + k.q2 - montmul(vc.w, vk.w, k), k.q2);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) hbits |= (uint32_t)(preh[r] == 1) << r;
+            }
             inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);    // canonical, natural order j = r*16+lp
             if (!valid) continue;
             const size_t off = ((size_t)slot * a.kk + i) * N + lp;
+            if constexpr (CT1) {                                        // w1 = UseHint(h, w')
+                const int32_t m = ((int32_t)k.q - 1) / a.alpha, m_mask = m - 1;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    int32_t a0;
+                    int32_t a1 = (int32_t)round_alpha(x[r], a0, a.alpha, a.am, (int32_t)k.q);
+                    if ((hbits >> r) & 1u) { if (a0 > 0) a1++; else a1--; }
+                    if (a1 < 0) a1 += m;
+                    a.w1[off + r * LP] = (uint8_t)(a1 & m_mask);
+                }
+                continue;
+            }
             if (a.w_chunked) {
                 int4 *d4 = reinterpret_cast<int4 *>(a.w + ((size_t)slot * a.kk + i) * N) + lp;
 #pragma unroll
@@ -374,7 +410,7 @@ static int mlwe_launch(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, int per, hipS
 }
 
 // fused NTT(y) -> A NTT(y) -> INTT for `nitems` attempts (l = 2..5); returns SC_HIP_FAILURE for other l (the caller falls back to the pair)
-static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream_t s)
+static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream_t s, bool ct1 = false)
 {
     a.njobs = nitems; a.per = 1;
     if (nitems == 0) return SC_HIP_SUCCESS;
@@ -387,7 +423,13 @@ static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream
         static bool attr_done = false; \
         if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dil_yaw_kernel<LLv, M, AL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ex + (AL ? 80 * 1024 - ex : 0)))); attr_done = true; } \
         hipLaunchKernelGGL((dil_yaw_kernel<LLv, M, AL>), dim3((unsigned)blocks), dim3(256), AL ? ex + mat : ex, s, a); } while (0)
-#define SC_YAW(LLv) do { if (a.sg) { if (alds) SC_YAW_(LLv, MODE_S32, true); else SC_YAW_(LLv, MODE_S32, false); } \
+#define SC_YAWC_(LLv, M, AL) do { \
+        static bool attr_done = false; \
+        if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&dil_yaw_kernel<LLv, M, AL, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ex + (AL ? 80 * 1024 - ex : 0)))); attr_done = true; } \
+        hipLaunchKernelGGL((dil_yaw_kernel<LLv, M, AL, true>), dim3((unsigned)blocks), dim3(256), AL ? ex + mat : ex, s, a); } while (0)
+#define SC_YAW(LLv) do { if (ct1) { if (a.sg) { if (alds) SC_YAWC_(LLv, MODE_S32, true); else SC_YAWC_(LLv, MODE_S32, false); } \
+                                   else { if (alds) SC_YAWC_(LLv, MODE_U32, true); else SC_YAWC_(LLv, MODE_U32, false); } } \
+                        else if (a.sg) { if (alds) SC_YAW_(LLv, MODE_S32, true); else SC_YAW_(LLv, MODE_S32, false); } \
                         else { if (alds) SC_YAW_(LLv, MODE_U32, true); else SC_YAW_(LLv, MODE_U32, false); } } while (0)
     switch (a.l) {
     case 2: SC_YAW(2); break;
@@ -398,6 +440,7 @@ static int mlwe_launch_yaw(sc_hip_ctx *ctx, DilNtt a, uint32_t nitems, hipStream
     }
 #undef SC_YAW
 #undef SC_YAW_
+#undef SC_YAWC_
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
