@@ -480,6 +480,7 @@ struct sc_hip_tesla {
     uint32_t *act[2], *cnt, *rs, *need, *sbase, *nz, *trials, *acc;
     int32_t *y, *v1, *v2, *r1, *r2, *cidx, *zs;
     uint8_t *md;
+    uint32_t *h_pin = nullptr;           // pinned host word the call's look at the device's count lands in (a copy to pageable memory blocks the host before the closing work is queued)
 };
 
 static void ts_free_ws(sc_hip_tesla *t)
@@ -534,6 +535,7 @@ extern "C" void sc_hip_tesla_destroy(sc_hip_tesla_t *t)
 {
     if (!t) return;
     ts_free_ws(t);
+    if (t->h_pin) (void)hipHostFree(t->h_pin);
     void *ptrs[] = { t->d_a1, t->d_a2, t->d_t1, t->d_t2, t->d_key, t->d_zstate };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(t->plan);
@@ -641,23 +643,34 @@ static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, 
             hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P, rs);
             HIPCHK(hipGetLastError());
         }
-        if (!left) break;
-        uint32_t cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, t->cnt, 4, hipMemcpyDeviceToHost, s));
+        if (!left) {                                                          // the reference's round cap: no look follows, the closing work does
+            if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+            const size_t used = t->slot_cap * (size_t)n * 4;
+            ZeroSix z6{ { t->y, t->v1, t->v2, t->r1, t->r2, t->zs }, used / 16 };
+            size_t zb = (used / 16 + 255) / 256;
+            if (zb > (size_t)t->ctx->cus * 8) zb = (size_t)t->ctx->cus * 8;
+            hipLaunchKernelGGL(ts_zero6_kernel, dim3((unsigned)(zb ? zb : 1)), dim3(256), 0, s, z6);
+            HIPCHK(hipGetLastError());
+            break;
+        }
+        // The look at the count - and in front of it, not behind it, the call's closing work: the call usually ends here, so the zeroing of the masks y, their
+        // products and the rejected candidates (one launch over the six arrays; every round's slots are cut from the handle's slot budget, so that is how far they
+        // were written) and the copy of the statuses run while the host waits for the count instead of after it has woken up.  A round that follows rewrites
+        // what it reads and is zeroed again.
+        if (!t->h_pin) HIPCHK(hipHostMalloc((void **)&t->h_pin, 64, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(t->h_pin, t->cnt, 4, hipMemcpyDeviceToHost, s));
+        if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
+        {
+            const size_t used = t->slot_cap * (size_t)n * 4;
+            ZeroSix z6{ { t->y, t->v1, t->v2, t->r1, t->r2, t->zs }, used / 16 };
+            size_t zb = (used / 16 + 255) / 256;
+            if (zb > (size_t)t->ctx->cus * 8) zb = (size_t)t->ctx->cus * 8;
+            hipLaunchKernelGGL(ts_zero6_kernel, dim3((unsigned)(zb ? zb : 1)), dim3(256), 0, s, z6);
+            HIPCHK(hipGetLastError());
+        }
         HIPCHK(hipStreamSynchronize(s));
-        left = cnt;
+        left = *(volatile uint32_t *)t->h_pin;
         todo = 1; planned = false;
-    }
-    if (d_status) HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s));
-    // the masks y, their products and the rejected candidates do not outlive the call: one launch over the six arrays (as six memsets they cost a
-    // launch gap each); every round's slot count is cut from the handle's slot budget, so that is how far they were written
-    {
-        const size_t used = t->slot_cap * (size_t)n * 4;
-        ZeroSix z6{ { t->y, t->v1, t->v2, t->r1, t->r2, t->zs }, used / 16 };
-        size_t zb = (used / 16 + 255) / 256;
-        if (zb > (size_t)t->ctx->cus * 8) zb = (size_t)t->ctx->cus * 8;
-        hipLaunchKernelGGL(ts_zero6_kernel, dim3((unsigned)(zb ? zb : 1)), dim3(256), 0, s, z6);
-        HIPCHK(hipGetLastError());
     }
     return SC_HIP_SUCCESS;
 }
