@@ -429,6 +429,9 @@ def bliss_extra(eng, torch, cpu_seconds, batch=16384, sweep=True, variants=True)
            'drbg_alone': {'ms': td * 1e3, 'tape_GB_per_s': B * w1 * 4 / td / 1e9, 'bytes_per_message_first_pair': w1 * 4},
            'mean_attempts_per_signature': attempts, 'undecided_near_ties': int((status == 5).sum()), 'dtype': 'u32',
            'timing': f'median of {REPS} calls; sign_ops_per_s = end to end with the CSPRNG inside the call (seeds in HBM), tape_resident_sign_ops_per_s = word tapes in HBM'}
+    out['drbg_alone']['roofline'] = valu_roofline('drbg', B / td, 32 + w1 * 4,
+                                                  'drbg_fill_kernel: a 32-byte seed in, the 8208 bytes of a first pair of attempts out per message (513 AES-256 blocks); vector-ALU-bound on the byte '
+                                                  'permutes and rotates of the T-table rounds (4-cycle class: the ceiling that applies is frac_4cycle_ceiling)', top=1)
     out['roofline'] = valu_roofline('bliss_sign', out['tape_resident_sign_ops_per_s'], 64 + 986 + 8 * 1024 * (attempts + 1) / 2,
                                     'tape-resident leg (the counter pass profiles that call); per signature: 64 B message + 986 B signature + 8 KB of uniform words per fresh pair of '
                                     'Gaussian vectors (12 B per sample in the sampler kernel)')

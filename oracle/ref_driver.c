@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -1284,6 +1284,92 @@ static int gen_ensdlp(const char *dir)
     return rc;
 }
 
+/* ens_dlp_sig_sign_recovery / ens_dlp_sig_verify_recovery (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1319-1501, 1663-1826: SC_SCHEME_SIG_ENS_WITH_RECOVERY /
+ * SC_SCHEME_SIG_DLP_WITH_RECOVERY): per message the fixture carries what went in (m), what came out of the signer (the PRNG word tape it consumed, the
+ * signature s1 | s2, the remainder m2 the signer leaves in the message buffer), and what the reference's verifier makes of signature + m2: its verdict
+ * and the message it rebuilds in a zeroed buffer - plus its verdicts on a tampered signature and on a tampered m2.  Message lengths sit on both sides
+ * of the (n - k)(q_bits - 1) bits that travel inside the signature. */
+static int ensdlp_rec_case(FILE *f, sc_scheme_e scheme, const char *tag, int set, const ens_dlp_sig_set_t *P)
+{
+    UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
+    char name[96];
+    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    if (!sc) return 1;
+    FILE *devnull = fopen("/dev/null", "w"), *saved = stdout, *saved_err = stderr;
+    stdout = devnull; stderr = devnull;
+    const int krc = safecrypto_keygen(sc);
+    stdout = saved; stderr = saved_err;
+    if (SC_FUNC_SUCCESS != krc) return 1;
+    const int n = P->n, k = (int)P->k_recovery;
+    int32_t par[8] = { (int32_t)P->n, (int32_t)P->q, (int32_t)P->q_bits, (int32_t)P->n_bits, set, 0, k, 0 };
+    float bd = P->bd;
+    memcpy(&par[5], &bd, 4);
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 8);
+    snprintf(name, sizeof name, "%s_h", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    snprintf(name, sizeof name, "%s_fgFG", tag); rec_i32(f, name, (const int32_t *)sc->privkey->key, (size_t)4 * n);
+    const size_t m1_bits = (size_t)(n - k) * (P->q_bits - 1), m1_bytes = (m1_bits + 7) >> 3;
+    const size_t lens[8] = { 1, 8, 128, m1_bytes - 1, m1_bytes, m1_bytes + 1, m1_bytes + 2, m1_bytes + 77 };
+    int32_t verdicts[8 * 3];
+    sm_state = 0x5ec0e47ULL + set + (scheme == SC_SCHEME_SIG_DLP_WITH_RECOVERY ? 64 : 0);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    for (int m = 0; m < 8; m++) {
+        const size_t cap = 2048;
+        uint8_t *msg = calloc(cap, 1), *back = calloc(cap, 1), seed[32];
+        size_t mlen = lens[m];
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+        uint8_t *sig = NULL; size_t siglen = 0;
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine;
+        uint8_t *mp = msg;
+        if (SC_FUNC_SUCCESS != safecrypto_sign_with_recovery(sc, &mp, &mlen, &sig, &siglen)) return 1;
+        if (mp != msg) return 1;
+        const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+        int32_t *tape = malloc(sizeof(int32_t) * words);
+        for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+        snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+        free(tape);
+        sc->prng_ctx[0] = orig;
+        prng_destroy(mine); prng_destroy(twin);
+        snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+        snprintf(name, sizeof name, "%s_m2_%d", tag, m); rec_u8(f, name, msg, mlen);          /* mlen is now the length of m2 (0: an empty record) */
+        /* the verifier: signature + m2 in a zeroed buffer */
+        size_t blen = mlen;
+        memcpy(back, msg, mlen);
+        uint8_t *bp = back;
+        verdicts[3 * m] = safecrypto_verify_with_recovery(sc, &bp, &blen, sig, siglen);
+        if (bp != back) return 1;
+        snprintf(name, sizeof name, "%s_back%d", tag, m); rec_u8(f, name, back, blen);
+        /* a tampered signature: one low bit of a coefficient in s2's half */
+        sig[siglen - 9] ^= 0x04;
+        memset(back, 0, cap); memcpy(back, msg, mlen); blen = mlen; bp = back;
+        verdicts[3 * m + 1] = safecrypto_verify_with_recovery(sc, &bp, &blen, sig, siglen);
+        sig[siglen - 9] ^= 0x04;
+        /* a tampered remainder (where there is one) / a tampered high bit of s1 (where there is none) */
+        memset(back, 0, cap); memcpy(back, msg, mlen); blen = mlen; bp = back;
+        if (mlen) back[0] ^= 0x80; else sig[2] ^= 0x40;
+        verdicts[3 * m + 2] = safecrypto_verify_with_recovery(sc, &bp, &blen, sig, siglen);
+        free(sig); free(msg); free(back);
+    }
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, 24);
+    safecrypto_destroy(sc);
+    fclose(devnull);
+    return 0;
+}
+
+static int gen_ensdlp_rec(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/ensdlp_rec_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = ensdlp_rec_case(f, SC_SCHEME_SIG_DLP_WITH_RECOVERY, "dlprec0", 0, &param_dlp_sig_0);
+    rc |= ensdlp_rec_case(f, SC_SCHEME_SIG_ENS_WITH_RECOVERY, "ensrec0", 0, &param_ens_sig_0);
+    fclose(f);
+    return rc;
+}
+
 /* ------------------------------------------------- small arithmetic entries ---- */
 /* pwr_32 / invert_32 / div_32 / mul_32_sparse of the NTT table (ntt_template.c.in:1689-1775, ntt.c:381-422) and the
  * utils_arith_poly / utils_arith_vectors entries the schemes use (poly_32.c:26-191, vectors.c:25-60), run on seeded
@@ -1713,7 +1799,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
     if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
@@ -1734,5 +1820,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "ens")) rc |= gen_ens(argv[2]);
     if (all || !strcmp(argv[1], "dlp")) rc |= gen_dlp(argv[2]);
     if (all || !strcmp(argv[1], "ensdlp")) rc |= gen_ensdlp(argv[2]);
+    if (all || !strcmp(argv[1], "ensdlp_rec")) rc |= gen_ensdlp_rec(argv[2]);
     return rc;
 }

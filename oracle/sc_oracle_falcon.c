@@ -612,3 +612,202 @@ int orc_ensdlp_sign(const int32_t *par, const int32_t *b, const float *b_gs, con
     free(c); free(ci);
     return tp.underrun ? 2 : 0;
 }
+
+/* ---- ENS / DLP signatures WITH MESSAGE RECOVERY (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1319-1501 sign, 1663-1826 verify; the XOF forms of the
+ * random oracles, which is what the default build compiles: ens_dlp_sig.h:31) ------------------------------------------------------------------
+ * par = {n, q, q_bits, n_bits, set, bd as float bits, k_recovery, 0}.  The message m = m1 || m2: the first (n - k)(q_bits - 1) bits (m1) ride in
+ * the target t1 = F(t2) + m1 of the lattice point, t2 = H'(m) = k coefficients; the signature is s1 | s2 (n q_bits-bit signed fields each) and the
+ * signer leaves m2 in the message buffer. */
+
+/* H'(m): SHAKE128 over m, zero-extended to min_len bytes when shorter (oracle_recovery_xof, :686-697; SC_MALLOC zeroes) / as it is (oracle_xof,
+ * :660-665), then k 32-bit words masked to q_bits with q subtracted when >= q (h_function_xof, :728-742) */
+static void rec_hash(int32_t *out, int k, int q, int q_bits, const uint8_t *m, size_t mlen, size_t min_len)
+{
+    shake_t sh;
+    shake_init(&sh, 128);
+    shake_absorb(&sh, m, mlen);
+    for (size_t i = mlen; i < min_len; i++) { const uint8_t z = 0; shake_absorb(&sh, &z, 1); }
+    shake_final(&sh);
+    const uint32_t mask = (1u << q_bits) - 1;
+    for (int i = 0; i < k; i++) {
+        uint8_t b[4];
+        shake_squeeze(&sh, b, 4);
+        int32_t y = (int32_t)(((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24)) & mask);
+        out[i] = y - (y >= q) * q;
+    }
+}
+
+/* F (f_function, :746-792, XOF form): SHAKE128 over the k words of t2 as they lie in memory, squeezed a block (168 bytes) at a time, two bytes per
+ * output, first byte high, masked to q_bits - 1 bits */
+static void rec_f(int32_t *out, int count, int q_bits, const int32_t *in, int k)
+{
+    shake_t sh;
+    shake_init(&sh, 128);
+    for (int i = 0; i < k; i++) {
+        const uint32_t v = (uint32_t)in[i];
+        const uint8_t b[4] = { (uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24) };
+        shake_absorb(&sh, b, 4);
+    }
+    shake_final(&sh);
+    const int32_t mask = (1 << (q_bits - 1)) - 1;
+    for (int i = 0; i < count; i++) {
+        uint8_t b[2];
+        shake_squeeze(&sh, b, 2);
+        out[i] = (((int32_t)b[0] << 8) | (int32_t)b[1]) & mask;
+    }
+}
+
+/* bit `pos` (MSB first) of a byte string zero-extended past its end: what the reference's packer hands out (packer.c:265-297; its buffer is zeroed
+ * and a read past it leaves the bits it had) */
+static inline uint32_t bit_at(const uint8_t *m, size_t len, size_t pos) { return (pos >> 3) < len ? (m[pos >> 3] >> (7 - (pos & 7))) & 1u : 0u; }
+
+size_t orc_ensdlp_rec_m1_bits(const int32_t *par) { return (size_t)(par[0] - par[6]) * (size_t)(par[2] - 1); }
+
+/* ens_dlp_sig_sign_recovery.  m (mlen bytes) in; sig (2 n q_bits / 8 bytes) and m2 (at most mlen bytes; *m2len) out.  0 = signed, 2 = tape too short */
+int orc_ensdlp_sign_recovery(const int32_t *par, const int32_t *b, const float *b_gs, const float *inv_norm, const uint8_t *msg, size_t mlen,
+                             const uint32_t *tape, size_t tape_len, uint8_t *sig, uint8_t *m2, size_t *m2len)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], k = par[6];
+    const size_t N = (size_t)n, N2 = 2 * N;
+    const size_t m1_bits = orc_ensdlp_rec_m1_bits(par), m1_bytes = (m1_bits + 7) >> 3;
+    int32_t *c = malloc(sizeof(int32_t) * N);
+    int64_t *ci = malloc(sizeof(int64_t) * N2);
+    rec_hash(c + n - k, k, q, q_bits, msg, mlen, m1_bytes);
+    rec_f(c, n - k, q_bits, c + n - k, k);
+    {   /* add_recovery_msg (:797-832): the first min(m1_bytes, mlen) bytes, q_bits - 1 bits per coefficient, no reduction */
+        const size_t avail = m1_bytes < mlen ? m1_bytes : mlen;
+        size_t bp = 0;
+        for (int i = 0; i < n - k; i++) {
+            uint32_t v = 0;
+            for (int bb = 0; bb < q_bits - 1; bb++, bp++) v = (v << 1) | bit_at(msg, avail, bp);
+            c[i] += (int32_t)v;
+        }
+    }
+    for (size_t j = 0; j < N; j++) { ci[j] = c[j]; ci[N + j] = 0; }
+    const float sig0 = (float)(2.0L / inv_norm[0]);                                  /* :1404 */
+    const double s_f = sig0;
+    ftape_t tp = { tape, tape_len, 0, 0 };
+    uint64_t cdf[4096];
+    for (size_t j = N2; j--;) {                                                      /* gaussian_lattice_sample_flt, gpv.c:2409-2492, as in orc_ensdlp_sign */
+        const float *row = b_gs + j * N2;
+        float dot = 0;
+        for (size_t kk = 0; kk < N2; kk++) dot += (float)ci[kk] * row[kk];
+        const float d = dot * inv_norm[j] * inv_norm[j];
+        const float sg = (float)(s_f * inv_norm[j]);
+        const int size = 1 << orc_cdt_bits(10.0f, sg);
+        if (size > 4096) { free(c); free(ci); return 1; }
+        orc_cdt_create(10.0f, sg, cdf, size);
+        const int64_t z = (int64_t)orc_cdt_sample(f64w(&tp), cdf, size) + (int32_t)d;
+        const int32_t *brow = b + j * N2;
+        for (size_t i = N2; i--;) ci[i] -= z * brow[i];
+    }
+    /* s1 = centre(ci[n, 2n)), s2 = centre(ci[0, n)) (gpv.c:2480-2489, :1418, :1441), one packer stream */
+    const size_t bytes = (2 * N * (size_t)q_bits + 7) / 8;
+    memset(sig, 0, bytes);
+    size_t bp = 0;
+    for (int half = 0; half < 2; half++) {
+        for (size_t j = 0; j < N; j++) c[j] = (int32_t)ci[(half ? 0 : N) + j];
+        orc_center(c, N, q);
+        for (size_t i = 0; i < N; i++) for (int bb = q_bits - 1; bb >= 0; bb--, bp++) sig[bp >> 3] |= (uint8_t)((((uint32_t)c[i] >> bb) & 1u) << (7 - (bp & 7)));
+    }
+    /* m2 (:1455-1479): what lies behind the m1 bits, shifted up to a byte boundary - byte for byte as the reference's loop leaves it (its last byte
+     * carries no bits of its own when the shift is not zero; nothing at all is kept of a message that ends inside the last m1 byte) */
+    if (mlen <= m1_bytes) *m2len = 0;
+    else {
+        const unsigned shiftu = (unsigned)(m1_bits & 7), shiftl = 8 - shiftu;
+        const uint32_t low = (1u << shiftu) - 1;                                     /* sc_bit_reverse_8 of it: the top shiftu bits */
+        uint32_t maskl = 0;
+        for (int i = 0; i < 8; i++) if (low & (1u << i)) maskl |= 0x80u >> i;
+        const uint32_t masku = maskl ^ 0xFF;
+        const uint8_t *ptr = msg + (m1_bits >> 3);
+        uint8_t *w = m2;
+        uint8_t byte = *ptr++;
+        uint32_t msb = (byte & masku) << shiftu, lsb;
+        while (ptr < msg + mlen) {
+            byte = *ptr++;
+            lsb = (byte & maskl) >> shiftl;
+            *w++ = (uint8_t)(msb | lsb);
+            msb = (byte & masku) << shiftu;
+        }
+        lsb = (byte & maskl) << shiftl;
+        *w++ = (uint8_t)(msb | lsb);
+        *m2len = (size_t)(w - m2);
+    }
+    free(c); free(ci);
+    return tp.underrun ? 2 : 0;
+}
+
+/* ens_dlp_sig_verify_recovery.  buf holds m2 (*len bytes) followed by whatever the caller has there, cap bytes in all (the reference rebuilds the
+ * message in place in the caller's buffer); on return buf / *len = the rebuilt message.  0 = valid. */
+int orc_ensdlp_verify_recovery(const int32_t *par, const int16_t *h, uint8_t *buf, size_t *len, size_t cap, const uint8_t *sig, size_t siglen)
+{
+    const int n = par[0], q = par[1], q_bits = par[2], k = par[6];
+    float bd; memcpy(&bd, &par[5], 4);
+    const size_t m1_bits = orc_ensdlp_rec_m1_bits(par), m1_bytes = (m1_bits + 7) >> 3;
+    if (siglen * 8 < 2 * (size_t)n * (size_t)q_bits) return 1;
+    const size_t m2_len = *len, m2_bits = m2_len << 3;
+    if (cap < m1_bytes + m2_len + 1) return 1;
+    int32_t *s1 = malloc(sizeof(int32_t) * 4 * (size_t)n), *s2 = s1 + n, *t = s2 + n, *fo = t + n;
+    int rc = 1;
+    size_t bp = 0;
+    for (int half = 0; half < 2; half++)
+        for (int i = 0; i < n; i++) {
+            uint32_t v = 0;
+            for (int bb = 0; bb < q_bits; bb++, bp++) v = (v << 1) | ((sig[bp >> 3] >> (7 - (bp & 7))) & 1u);
+            (half ? s2 : s1)[i] = (int32_t)(v << (32 - q_bits)) >> (32 - q_bits);
+        }
+    if (norm_fails(bd, s1, s2, n)) goto done;                                        /* :1726-1729, on the fields as decoded */
+    /* m2 back to where it sat in m (:1733-1759) */
+    *len = m1_bytes;
+    if (m2_bits) {
+        const unsigned shiftu = (unsigned)(m1_bits & 7), shiftl = 8 - shiftu;
+        const uint32_t masku = (1u << shiftl) - 1, maskl = masku ^ 0xFF;
+        const uint8_t *ptr = buf + m2_len - (shiftu != 0);
+        uint8_t *w = buf + ((m1_bits + m2_bits) >> 3) - (shiftu != 0);
+        uint8_t byte = *ptr--;
+        uint32_t lsb = (byte >> shiftu) & masku, msb;
+        while (ptr >= buf) {
+            byte = *ptr--;
+            msb = ((uint32_t)byte << shiftl) & maskl;
+            *w-- = (uint8_t)(msb | lsb);
+            lsb = (byte >> shiftu) & masku;
+        }
+        *w = (uint8_t)lsb;
+        *len = (m1_bits + m2_bits) >> 3;
+    }
+    /* t = s1 h + s2 (small_mul_mod_ring, :892-912: a schoolbook product in 32-bit words that wrap), normalised */
+    for (int j = 0; j < n; j++) {
+        uint32_t acc = 0;
+        for (int kk = 0; kk < n; kk++) {
+            const uint32_t p = (uint32_t)s1[kk] * (uint32_t)(int32_t)h[(j - kk) & (n - 1)];
+            acc += (kk <= j) ? p : 0u - p;
+        }
+        t[j] = (int32_t)(acc + (uint32_t)s2[j]);
+    }
+    orc_normalize(t, (size_t)n, q);
+    rec_f(fo, n - k, q_bits, t + n - k, k);
+    for (int i = 0; i < n - k; i++) t[i] -= fo[i];
+    orc_normalize(t, (size_t)n, q);
+    {   /* recover_msg (:835-890): every m1 coefficient must fit q_bits - 1 bits; the bits go to the front of the buffer, the last byte shared with m2 */
+        const uint32_t bound = (1u << (q_bits - 1)) - 1;
+        for (int i = 0; i < n - k; i++) if ((uint32_t)t[i] > bound) goto done;
+        uint8_t *tmp = calloc(m1_bytes + 4, 1);
+        size_t wp = 0;
+        for (int i = 0; i < n - k; i++) for (int bb = q_bits - 2; bb >= 0; bb--, wp++) tmp[wp >> 3] |= (uint8_t)((((uint32_t)t[i] >> bb) & 1u) << (7 - (wp & 7)));
+        const unsigned offset = (unsigned)(m1_bits & 7);
+        const size_t last = m1_bytes - 1;
+        memcpy(buf, tmp, last);
+        if (offset == 0) buf[last] = tmp[last];
+        else {
+            const uint8_t mask = (uint8_t)((((1u << (8 - offset)) - 1) ^ 0xFF));
+            buf[last] = (uint8_t)((buf[last] & (mask ^ 0xFF)) | (tmp[last] & mask));
+        }
+        free(tmp);
+    }
+    rec_hash(fo, k, q, q_bits, buf, *len, 0);
+    rc = 0;
+    for (int i = 0; i < k; i++) if (fo[i] != t[n - k + i]) rc = 1;
+done:
+    free(s1);
+    return rc;
+}

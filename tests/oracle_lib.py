@@ -122,6 +122,10 @@ def lib():
         L.orc_ensdlp_gso.restype = None
         L.orc_ensdlp_sign.argtypes = [i32p, i32p, f32p, f32p, u8p, C.c_size_t, u32p, C.c_size_t, u8p]
         L.orc_ensdlp_verify.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS'), u8p, C.c_size_t, u8p, C.c_size_t]
+        L.orc_ensdlp_rec_m1_bits.restype = C.c_size_t
+        L.orc_ensdlp_rec_m1_bits.argtypes = [i32p]
+        L.orc_ensdlp_sign_recovery.argtypes = [i32p, i32p, f32p, f32p, u8p, C.c_size_t, u32p, C.c_size_t, u8p, u8p, C.POINTER(C.c_size_t)]
+        L.orc_ensdlp_verify_recovery.argtypes = [i32p, np.ctypeslib.ndpointer(dtype=np.int16, flags='C_CONTIGUOUS'), u8p, C.POINTER(C.c_size_t), C.c_size_t, u8p, C.c_size_t]
         L.orc_dlp_ct_bytes.restype = C.c_size_t
         L.orc_dlp_ct_bytes.argtypes = [i32p]
         L.orc_dlp_encrypt.argtypes = [i32p, i32p, u8p, C.c_size_t, u8p, u32p, C.c_size_t, u8p]
@@ -590,6 +594,35 @@ def ensdlp_sign(par, b, bgs, inv, msg, tape):
     sig = np.zeros((int(par[0]) * int(par[2]) + 7) // 8, dtype=np.uint8)
     rc = lib().orc_ensdlp_sign(par, b.reshape(-1), bgs.reshape(-1), inv, m, ml, tp, tp.size, sig)
     return rc, bytes(sig)
+
+
+def ensdlp_rec_m1_bytes(par):
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    return (int(lib().orc_ensdlp_rec_m1_bits(par)) + 7) // 8
+
+
+def ensdlp_sign_recovery(par, b, bgs, inv, msg, tape):
+    """(rc, signature s1 | s2, m2) - ens_dlp_sig_sign_recovery"""
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    m, ml = _msgbuf(msg)
+    tp = _tape(tape)
+    sig = np.zeros((2 * int(par[0]) * int(par[2]) + 7) // 8, dtype=np.uint8)
+    m2 = np.zeros(ml + 2, dtype=np.uint8)
+    m2len = C.c_size_t(0)
+    rc = lib().orc_ensdlp_sign_recovery(par, b.reshape(-1), bgs.reshape(-1), inv, m, ml, tp, tp.size, sig, m2, C.byref(m2len))
+    return rc, bytes(sig), bytes(m2[:m2len.value])
+
+
+def ensdlp_verify_recovery(par, h, m2, sig, fill=0):
+    """(verdict, rebuilt message) - ens_dlp_sig_verify_recovery over a buffer that holds m2 and `fill` bytes behind it"""
+    par = np.ascontiguousarray(np.asarray(par), dtype=np.int32)
+    cap = ensdlp_rec_m1_bytes(par) + len(m2) + 8
+    buf = np.full(cap, fill, dtype=np.uint8)
+    buf[:len(m2)] = np.frombuffer(bytes(m2), dtype=np.uint8)
+    ln = C.c_size_t(len(m2))
+    s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
+    rc = lib().orc_ensdlp_verify_recovery(par, np.ascontiguousarray(np.asarray(h), dtype=np.int16), buf, C.byref(ln), cap, s, s.size)
+    return rc, bytes(buf[:ln.value])
 
 
 def dlp_encrypt(par, h_ntt, ident, msg, tape):

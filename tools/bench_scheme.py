@@ -1,7 +1,7 @@
 """One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls] [signature file]` runs one warm-up call and `calls`
 timed calls of
    dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | ens_sign |
-   rlwe_encrypt | polymul | cdt
+   rlwe_encrypt | polymul | cdt | drbg
 on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call.
 A verify leg never signs in the profiled process: given a signature file that does not exist yet it signs, writes the file and stops (the unprofiled
 preparation run); given one that exists it loads the signatures and only verifies - so a counter pass over the leg contains the leg's kernels alone
@@ -140,6 +140,11 @@ def main():
         u = torch.randint(-2**63, 2**63 - 1, (B,), dtype=torch.int64, device='cuda', generator=g)
         o = s.sample(u); torch.cuda.synchronize(); made = 1
         fn = lambda: s.sample(u)
+    elif leg == 'drbg':                                          # the device CTR-DRBG alone: the words of BLISS-B-I's first pair of attempts, a seed per message
+        B, W = 16384, 2052
+        seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+        eng.drbg_words(seeds, W); torch.cuda.synchronize(); made = 1
+        fn = lambda: eng.drbg_words(seeds, W)
     else:
         raise SystemExit('unknown leg')
     ts_ = []

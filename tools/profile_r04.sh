@@ -19,7 +19,7 @@ import json, sys
 sys.path.insert(0, 'tools')
 import pmc_leg
 out = {}
-for leg in ('dil_sign', 'dil_verify', 'bliss_sign', 'bliss_verify', 'falcon_sign', 'ens_sign', 'rlwe_encrypt', 'polymul'):
+for leg in ('dil_sign', 'dil_verify', 'bliss_sign', 'bliss_verify', 'falcon_sign', 'ens_sign', 'rlwe_encrypt', 'polymul', 'drbg'):
     r = pmc_leg.profile_leg(leg, calls=2)
     if r.get('ok'):
         r.pop('ok')
