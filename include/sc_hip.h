@@ -584,6 +584,25 @@ size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h);   /* 4n:
 int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                             const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_status, void *stream);
 
+/* ---- ENS / DLP signatures WITH MESSAGE RECOVERY (SC_SCHEME_SIG_ENS_WITH_RECOVERY / SC_SCHEME_SIG_DLP_WITH_RECOVERY) -------------------------------
+ * replaces: safecrypto_sign_with_recovery -> ens_dlp_sig_sign_recovery (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1319-1501) and
+ * safecrypto_verify_with_recovery -> ens_dlp_sig_verify_recovery (:1663-1826), with the XOF random oracles the default build compiles (ens_dlp_sig.h:31).
+ * Handles as for the plain signatures, created with k_recovery (ens_dlp_sig_params.c:23-62: 19 / 20) in params.pad[0].  The first
+ * (n - k)(q_bits - 1) bits of a message (m1) travel inside the signature s1 | s2 (2 n q_bits / 8 bytes); the signer hands back the rest (m2).
+ * Out of place where the reference rewrites the caller's message buffer: row i of d_m2 / d_m2lens[i] = what the reference leaves in *m / *m_len
+ * (m2_stride >= the longest message less the whole m1 bytes).  d_status as sc_hip_ens_dlp_sig_sign. */
+size_t sc_hip_ens_dlp_sig_rec_bytes(const sc_hip_ens_dlp_signer_t *h);      /* 2 n q_bits / 8 */
+size_t sc_hip_ens_dlp_sig_rec_m1_bytes(const sc_hip_ens_dlp_signer_t *h);   /* ceil((n - k)(q_bits - 1) / 8); 0 when the handle carries no k_recovery */
+int sc_hip_ens_dlp_sig_sign_recovery(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                     const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride,
+                                     uint8_t *d_m2, size_t m2_stride, uint32_t *d_m2lens, uint32_t *d_status, void *stream);
+/* the verifier (a Falcon-shaped handle with h loaded, as sc_hip_ens_dlp_sig_verify): d_verdicts[i] = 0 valid / 1 invalid; a valid signature's message
+ * is rebuilt in row i of d_msgs_out (d_mlens_out[i] bytes: the m1 bytes, then what m2 carried; out_stride >= that) - what the reference leaves in *m
+ * when it is handed m2 in a zeroed buffer.  d_m2lens null: no remainders.  A refused signature reports length 0. */
+int sc_hip_ens_dlp_sig_verify_recovery(sc_hip_falcon_t *h, size_t batch, const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens,
+                                       const uint8_t *d_m2, size_t m2_stride, const uint32_t *d_m2lens,
+                                       uint8_t *d_msgs_out, size_t out_stride, uint32_t *d_mlens_out, uint32_t *d_verdicts, void *stream);
+
 /* KEM level, with the reference's build options (SHA3-512 with its own permutation, AES CTR-DRBG for oracle bytes and noise):
  * extra public-key material that only enters the G hash - t: the coefficient-domain vector as stored (first k*n words of
  * sc->pubkey->key, kyber_kem.c:636-650), rho: the 32-byte matrix seed */

@@ -1470,6 +1470,7 @@ struct KleinArgs {
     const uint32_t *__restrict__ tapes; uint32_t tape_stride; const uint32_t *__restrict__ tape_lens;
     int32_t *__restrict__ ci;              // [2n][B]
     uint32_t *__restrict__ status;
+    int want_s2;                           // the register form writes ci[0, n) as well (signatures with message recovery send s2 = centre(ci[0, n)) too)
 };
 
 constexpr int KU = 16;                     // sweep unroll: loads in flight per lane
@@ -1710,15 +1711,16 @@ __global__ __launch_bounds__(64 * KW) void kleinr_kernel(KleinArgs A)
         __syncthreads();
     }
     if (valid) {
-        int32_t *__restrict__ out = A.ci + col;                  // [2n][B]; only s1 = the second half is needed
+        int32_t *__restrict__ out = A.ci + col;                  // [2n][B]; only s1 = the second half is needed (with message recovery: both)
 #pragma unroll
-        for (int c = NCH / 2; c < NCH; c++) out[(size_t)(G * c + r) * A.B] = st[c];
+        for (int c = 0; c < NCH; c++) if (c >= NCH / 2 || A.want_s2) out[(size_t)(G * c + r) * A.B] = st[c];
         if (r == 0) A.status[col] = short_tape ? 2u : dead ? 3u : 1u;
     }
 }
 
 // s1 = centre(ci[n, 2n)) (ens_dlp_sig.c:1273), n q_bits-bit two's complement fields, MSB first (entropy_poly_encode_32, SC_ENTROPY_NONE).
 // One thread per eight coefficients = q_bits bytes.  Signatures whose status is not 1 are zero-filled.
+// With message recovery (grid.y = 2n / 8) the second n fields are s2 = centre(ci[0, n)) (ens_dlp_sig.c:1434-1445: one packer stream).
 __global__ void klein_pack_kernel(uint32_t batch, uint32_t B, const int32_t *__restrict__ ci, const uint32_t *__restrict__ status, uint8_t *__restrict__ sigs, size_t sig_stride,
                                   int n, int q, int q_bits)
 {
@@ -1730,8 +1732,9 @@ __global__ void klein_pack_kernel(uint32_t batch, uint32_t B, const int32_t *__r
     uint8_t *o = sigs + (size_t)i * sig_stride + (size_t)g * q_bits;
     uint64_t acc = 0; int nb = 0, w = 0;
     const uint32_t mask = (1u << q_bits) - 1u;
+    const int first = 8 * g < n ? n + 8 * g : 8 * g - n;          // s1 = the state's second half, then s2 = its first
     for (int e = 0; e < 8; e++) {
-        const int32_t v = ok ? centre_mod(ci[(size_t)(n + 8 * g + e) * B + i], q) : 0;
+        const int32_t v = ok ? centre_mod(ci[(size_t)(first + e) * B + i], q) : 0;
         acc = (acc << q_bits) | (uint64_t)((uint32_t)v & mask); nb += q_bits;
         while (nb >= 8) { o[w++] = (uint8_t)(acc >> (nb - 8)); nb -= 8; }
     }
@@ -1750,6 +1753,7 @@ struct sc_hip_falcon {
     int var_spw, var_lm, var_nw; // sc_hip_falcon_set_variant (measurement hook): 0 = chosen per batch
     int force_g;                 // sc_hip_falcon_set_mapping: 0 / 64 = 8 signatures per wavefront, lower tree in LDS; 1 / 8 = lanes per signature, state in HBM
     int32_t *d_hhat;
+    int32_t *d_hraw;             // key 0 as it was handed over (SINT16 widened, not reduced): sc_hip_ens_dlp_sig_verify_recovery multiplies by it in wrapping 32-bit words
     size_t cap;
     double *ws;
     int32_t *c, *s1, *s2;
@@ -1844,7 +1848,7 @@ extern "C" void sc_hip_falcon_destroy(sc_hip_falcon_t *f)
     if (f->side) (void)hipStreamDestroy(f->side);
     if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
-    void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat };
+    void *ptrs[] = { f->d_sk, f->d_gm, f->d_tabs, f->d_hhat, f->d_hraw };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(f->plan);
     delete f;
@@ -1917,9 +1921,13 @@ extern "C" int sc_hip_falcon_set_pubkeys(sc_hip_falcon_t *f, size_t nkeys, const
     std::vector<int32_t> h32(nkeys * n);
     for (size_t i = 0; i < nkeys * n; i++) { int32_t v = h[i] % f->P.q; if (v < 0) v += f->P.q; h32[i] = v; }
     if (f->d_hhat) { (void)sc::wipe_free(f->d_hhat); f->d_hhat = nullptr; }
+    if (f->d_hraw) { (void)sc::wipe_free(f->d_hraw); f->d_hraw = nullptr; }
     f->have_pk = false; f->npk = 0;
     HIPCHK(hipMalloc((void **)&f->d_hhat, nkeys * n * 4));
     HIPCHK(sc::copy_in(f->d_hhat, h32.data(), nkeys * n * 4));
+    for (size_t i = 0; i < n; i++) h32[i] = h[i];
+    HIPCHK(hipMalloc((void **)&f->d_hraw, n * 4));
+    HIPCHK(sc::copy_in(f->d_hraw, h32.data(), n * 4));
     if (sc_hip_ntt_fwd(f->plan, nkeys, f->d_hhat, f->d_hhat, nullptr) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
     HIPCHK(hipStreamSynchronize(nullptr));
     f->npk = nkeys;
@@ -2574,35 +2582,15 @@ extern "C" int sc_hip_ens_dlp_signer_set_privkey(sc_hip_ens_dlp_signer_t *h, con
 extern "C" size_t sc_hip_ens_dlp_sig_bytes(const sc_hip_ens_dlp_signer_t *h) { return h ? ((size_t)h->P.n * (size_t)h->P.q_bits + 7) / 8 : 0; }
 extern "C" size_t sc_hip_ens_dlp_sig_tape_words(const sc_hip_ens_dlp_signer_t *h) { return h ? 4 * (size_t)h->P.n : 0; }
 
-// replaces: safecrypto_sign -> ens_dlp_sig_sign (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315, ENS and DLP signatures without message recovery)
-// for `batch` messages under one private key: t = H(m) (SHAKE128, :728-742), Klein's sampler (gaussian_lattice_sample_flt, gpv.c:2409-2492),
-// s1 = centre(ci[n, 2n)), n q_bits-bit signed fields.  d_tapes row i = the prng_32 word stream of sc->prng_ctx[0] during signature i: one prng_64
-// (two words, high word first) per basis row = 4n words; rows 8-byte aligned.  d_status: 1 signed, 2 tape too short, 3 the sampler state left 32 bits.
-extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
-                                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_status, void *stream)
+// Klein's sampler for `batch` targets c (n words each) -> the state ci [2n][B]; want_s2: the register form keeps the first half of the state too
+static int klein_launch(sc_hip_ens_dlp_signer_t *h, size_t batch, size_t B, const int32_t *c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
+                        int32_t *ci, uint32_t *d_status, int want_s2, hipStream_t s)
 {
-    if (!h) return fail("ens_dlp_sig_sign: null handle");
-    if (!h->have_key) return fail("ens_dlp_sig_sign: no key loaded");
-    if (batch == 0) return SC_HIP_SUCCESS;
-    if (batch > 0x7fffffc0u) return fail("ens_dlp_sig_sign: batch too large");
-    if (!d_msgs || !d_tapes || !d_sigs || !d_status) return fail("ens_dlp_sig_sign: null buffer");
     const size_t n = (size_t)h->P.n, n2 = 2 * n;
-    if (tape_stride < 2 * n2 || tape_stride > 0xffffffffu || (tape_stride & 1) != 0 || ((uintptr_t)d_tapes & 7) != 0)
-        return fail("ens_dlp_sig_sign: tapes must be 8-byte aligned rows of at least 4n words (even tape_stride)");
-    if (sig_stride < sc_hip_ens_dlp_sig_bytes(h)) return fail("ens_dlp_sig_sign: sig_stride too small");
-    HIPCHK(hipSetDevice(h->ctx->device));
-    const size_t B = (batch + 63) & ~(size_t)63;
-    if (h->ws.reserve(B * n2 * 4 + batch * n * 4 + 1024)) return SC_HIP_FAILURE;
-    int32_t *ci = h->ws.take<int32_t>(B * n2);
-    int32_t *c = h->ws.take<int32_t>(batch * n);
-    hipStream_t s = (hipStream_t)stream;
     const uint32_t nb = (uint32_t)batch;
-    if (batch <= (size_t)h->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
-    HIPCHK(hipGetLastError());
     KleinArgs A;
     A.batch = nb; A.B = (uint32_t)B; A.n = (int)n; A.n2 = (int)n2; A.c = c; A.b = h->d_b; A.bgs = h->d_bgs; A.inv = h->d_inv; A.tabs = h->d_tabs; A.sizes = h->d_sizes;
-    A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status;
+    A.ts_log = h->ts_log; A.maxb = h->maxb; A.tapes = d_tapes; A.tape_stride = (uint32_t)tape_stride; A.tape_lens = d_tape_lens; A.ci = ci; A.status = d_status; A.want_s2 = want_s2;
     // lanes per signature.  Register form: the fewest (down to 128 state words per lane) that still give every SIMD a wavefront (two, below).
     // sc_hip_ens_dlp_signer_set_mapping: 1 = the lane-per-signature kernel (state in memory), 4 / 8 / 16 = the register form with that many lanes.
     int G = 16, in_regs = 1;
@@ -2631,9 +2619,280 @@ extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch,
     }
     else hipLaunchKernelGGL(klein_kernel, dim3((unsigned)(B / 64)), dim3(64), 0, s, A);
     HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_sign -> ens_dlp_sig_sign (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1171-1315, ENS and DLP signatures without message recovery)
+// for `batch` messages under one private key: t = H(m) (SHAKE128, :728-742), Klein's sampler (gaussian_lattice_sample_flt, gpv.c:2409-2492),
+// s1 = centre(ci[n, 2n)), n q_bits-bit signed fields.  d_tapes row i = the prng_32 word stream of sc->prng_ctx[0] during signature i: one prng_64
+// (two words, high word first) per basis row = 4n words; rows 8-byte aligned.  d_status: 1 signed, 2 tape too short, 3 the sampler state left 32 bits.
+extern "C" int sc_hip_ens_dlp_sig_sign(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                       const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride, uint32_t *d_status, void *stream)
+{
+    if (!h) return fail("ens_dlp_sig_sign: null handle");
+    if (!h->have_key) return fail("ens_dlp_sig_sign: no key loaded");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffc0u) return fail("ens_dlp_sig_sign: batch too large");
+    if (!d_msgs || !d_tapes || !d_sigs || !d_status) return fail("ens_dlp_sig_sign: null buffer");
+    const size_t n = (size_t)h->P.n, n2 = 2 * n;
+    if (tape_stride < 2 * n2 || tape_stride > 0xffffffffu || (tape_stride & 1) != 0 || ((uintptr_t)d_tapes & 7) != 0)
+        return fail("ens_dlp_sig_sign: tapes must be 8-byte aligned rows of at least 4n words (even tape_stride)");
+    if (sig_stride < sc_hip_ens_dlp_sig_bytes(h)) return fail("ens_dlp_sig_sign: sig_stride too small");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t B = (batch + 63) & ~(size_t)63;
+    if (h->ws.reserve(B * n2 * 4 + batch * n * 4 + 1024)) return SC_HIP_FAILURE;
+    int32_t *ci = h->ws.take<int32_t>(B * n2);
+    int32_t *c = h->ws.take<int32_t>(batch * n);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = (uint32_t)batch;
+    if (batch <= (size_t)h->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
+    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, h->P, 1);
+    HIPCHK(hipGetLastError());
+    if (klein_launch(h, batch, B, c, d_tapes, tape_stride, d_tape_lens, ci, d_status, 0, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((batch + 255) / 256), (unsigned)(n / 8)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
     HIPCHK(hipGetLastError());
     h->ws.wipe(s);                                                  // the sampler state (the lattice point before packing)
+    return SC_HIP_SUCCESS;
+}
+
+// ---- ENS / DLP signatures WITH MESSAGE RECOVERY (SC_SCHEME_SIG_ENS_WITH_RECOVERY / _DLP_WITH_RECOVERY) ----------------------------------------
+// ens_dlp_sig_sign_recovery / ens_dlp_sig_verify_recovery (src/schemes/sig/ens_dlp/ens_dlp_sig.c:1319-1501, 1663-1826), the XOF forms of the random
+// oracles (what the default build compiles, ens_dlp_sig.h:31).  m = m1 || m2: the first (n - k)(q_bits - 1) bits ride in the target of the lattice
+// point - t2 = H'(m) (k coefficients: SHAKE128 over m, zero-extended to the m1 bytes when shorter), t1 = F(t2) + m1 (F: SHAKE128 over the k words of
+// t2, two bytes per coefficient, first byte high, q_bits - 1 bits kept; m1 added WITHOUT reduction) - the signature is s1 | s2 and the signer hands
+// back m2.  k = k_recovery travels in the parameter block's first spare word (sc_hip_falcon_params_t::pad[0]; ens_dlp_sig_params.c:23-62).
+namespace {
+
+struct RecP { int n, k, q, q_bits; uint32_t m1_bits, m1_bytes; };
+
+static inline RecP rec_params(const FalP &P)
+{
+    RecP r;
+    r.n = P.n; r.k = P.pad[0]; r.q = P.q; r.q_bits = P.q_bits;
+    r.m1_bits = (uint32_t)(P.n - P.pad[0]) * (uint32_t)(P.q_bits - 1); r.m1_bytes = (r.m1_bits + 7) >> 3;
+    return r;
+}
+
+static inline bool rec_params_ok(const FalP &P) { return P.pad[0] >= 1 && P.pad[0] < P.n / 2 && P.q_bits > 8 && P.q_bits <= 16; }    // f_function's own range check (:754-756)
+
+// H'(m) -> k words masked to q_bits, q subtracted when >= q (oracle_recovery_xof :686-697 / oracle_xof :660-665, h_function_xof :728-742)
+template <class SP>
+__device__ __forceinline__ void rec_hash(SP &sp, const uint8_t *m, uint32_t mlen, uint32_t min_len, int32_t *out, const RecP &P)
+{
+    sp.absorb(m, mlen);
+    for (uint32_t i = mlen; i < min_len; i++) sp.absorb_byte(0);
+    sp.finalize(0x1F);
+    const uint32_t mask = (1u << P.q_bits) - 1u;
+    for (int i = 0; i < P.k; i++) {
+        uint32_t y = 0;
+        for (int j = 0; j < 4; j++) y |= (uint32_t)sp.squeeze_byte() << (8 * j);
+        y &= mask;
+        out[i] = (int32_t)(y - (y >= (uint32_t)P.q ? (uint32_t)P.q : 0u));
+    }
+}
+
+// the sponge of F absorbed and finalised (f_function :746-792): the k words of t2 as they lie in memory
+template <class SP>
+__device__ __forceinline__ void rec_f_begin(SP &sp, const int32_t *t2, const RecP &P)
+{
+    for (int i = 0; i < P.k; i++) {
+        const uint32_t v = (uint32_t)t2[i];
+        for (int j = 0; j < 4; j++) sp.absorb_byte((uint8_t)(v >> (8 * j)));
+    }
+    sp.finalize(0x1F);
+}
+
+// One lane per message: the target c (n words) and the remainder m2.
+__global__ __launch_bounds__(HT) void rec_target_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
+                                                       int32_t *__restrict__ c, uint8_t *__restrict__ m2, size_t m2_stride, uint32_t *__restrict__ m2lens, RecP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t b = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    if (b >= batch) return;
+    const uint32_t mlen = mlens ? mlens[b] : fixed_len;
+    const uint8_t *m = msgs + (size_t)b * msg_stride;
+    int32_t *cb = c + (size_t)b * P.n;
+    rec_hash(sp, m, mlen, P.m1_bytes, cb + P.n - P.k, P);
+    sp.init(st, threadIdx.x, 168);
+    rec_f_begin(sp, cb + P.n - P.k, P);
+    // add_recovery_msg (:797-832): q_bits - 1 bits per coefficient from the first min(m1 bytes, mlen) bytes, MSB first, zero behind them
+    const uint32_t avail = mlen < P.m1_bytes ? mlen : P.m1_bytes, fb = (uint32_t)P.q_bits - 1u, fmask = (1u << fb) - 1u;
+    uint64_t acc = 0; uint32_t nb = 0, rp = 0;
+    for (int i = 0; i < P.n - P.k; i++) {
+        const uint32_t hi = sp.squeeze_byte(), lo = sp.squeeze_byte();
+        while (nb < fb) { acc = (acc << 8) | (uint64_t)(rp < avail ? m[rp] : 0); rp++; nb += 8; }
+        const uint32_t v = (uint32_t)(acc >> (nb - fb)) & fmask;
+        nb -= fb;
+        cb[i] = (int32_t)((((hi << 8) | lo) & fmask) + v);
+    }
+    // m2 (:1455-1479): what lies behind the m1 bits, moved up to a byte boundary; the reference's loop gives the last byte no bits of a successor, and keeps
+    // nothing at all of a message that ends inside the last m1 byte
+    uint32_t l2 = 0;
+    if (mlen > P.m1_bytes) {
+        const uint32_t sh = P.m1_bits & 7u, base = P.m1_bits >> 3, masku = 0xFFu >> sh, maskl = masku ^ 0xFFu;
+        uint8_t *o = m2 + (size_t)b * m2_stride;
+        l2 = mlen - base;
+        if (l2 > m2_stride) l2 = (uint32_t)m2_stride;                  // (the host checked the strides; a length beyond its row is the caller's error)
+        for (uint32_t i = 0; i < l2; i++) {
+            const uint32_t cur = m[base + i], nxt = (base + i + 1 < mlen) ? m[base + i + 1] : 0u;
+            o[i] = (uint8_t)(((cur & masku) << sh) | ((nxt & maskl) >> (8 - sh)));
+        }
+    }
+    m2lens[b] = l2;
+}
+
+// One wavefront per signature: unpack s1 | s2, norm, t = s1 h + s2 (schoolbook, 32-bit words that wrap: small_mul_mod_ring :892-912), m1 = t1 - F(t2),
+// the message rebuilt in the output row, H'(m) against t2.
+__global__ __launch_bounds__(64) void rec_verify_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens,
+                                                       const uint8_t *__restrict__ m2, size_t m2_stride, const uint32_t *__restrict__ m2lens, const int32_t *__restrict__ hraw,
+                                                       uint8_t *__restrict__ out, size_t out_stride, uint32_t *__restrict__ outlens, uint32_t *__restrict__ verdicts, RecP P, float bd)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t rv_lds[];          // s1 | s2 | t | h (n words each), then the sponge state
+    const int lane = threadIdx.x, n = P.n;
+    const uint32_t b = blockIdx.x;
+    int32_t *s1 = rv_lds, *s2 = s1 + n, *t = s2 + n, *hh = t + n;
+    uint64_t *st = reinterpret_cast<uint64_t *>(hh + n);
+    const uint32_t l2 = m2lens ? m2lens[b] : 0u, siglen = siglens[b];
+    uint8_t *ob = out + (size_t)b * out_stride;
+    const uint32_t sh = P.m1_bits & 7u, base = P.m1_bits >> 3;
+    const uint32_t olen = l2 ? base + l2 : P.m1_bytes;                         // (m1_bits + 8 l2) >> 3 (:1757)
+    auto refuse = [&]() { if (lane == 0) { verdicts[b] = 1; outlens[b] = 0; } };
+    if ((size_t)siglen * 8 < (size_t)2 * n * P.q_bits || siglen > sig_stride || (size_t)l2 > m2_stride || (size_t)olen > out_stride) { refuse(); return; }
+    const uint8_t *sg = sigs + (size_t)b * sig_stride;
+    for (int i = lane; i < 2 * n; i += 64) {
+        uint32_t val = 0;
+        for (int k = 0; k < P.q_bits; k++) { const uint32_t bp = (uint32_t)i * P.q_bits + k; val = (val << 1) | ((sg[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+        s1[i] = (int32_t)(val << (32 - P.q_bits)) >> (32 - P.q_bits);       // (s2 follows s1 in LDS)
+    }
+    for (int i = lane; i < n; i += 64) hh[i] = hraw[i];
+    __syncthreads();
+    for (int i = lane; i < n; i += 64) t[i] = s1[i] * s1[i] + s2[i] * s2[i];
+    __syncthreads();
+    int bad = 0;
+    if (lane == 0) bad = norm_fails_lds(t, n, bd) ? 1 : 0;                     // check_norm_bd on the fields as decoded (:1726-1729)
+    bad = __shfl(bad, 0);
+    if (bad) { refuse(); return; }
+    __syncthreads();
+    for (int j = lane; j < n; j += 64) {
+        uint32_t acc = 0;
+        for (int k = 0; k <= j; k++) acc += (uint32_t)s1[k] * (uint32_t)hh[j - k];
+        for (int k = j + 1; k < n; k++) acc -= (uint32_t)s1[k] * (uint32_t)hh[n + j - k];
+        int32_t v = (int32_t)(acc + (uint32_t)s2[j]) % P.q;                    // normalize_32: any correct reduction of a 32-bit word gives this canonical value
+        if (v < 0) v += P.q;
+        t[j] = v;
+    }
+    __syncthreads();
+    if (lane == 0) {                                                           // F(t2) into s2's place, two bytes per coefficient
+        Sponge<1> sp; sp.init(st, 0, 168);
+        rec_f_begin(sp, t + n - P.k, P);
+        const uint32_t fmask = (1u << (P.q_bits - 1)) - 1u;
+        for (int i = 0; i < n - P.k; i++) { const uint32_t hi = sp.squeeze_byte(), lo = sp.squeeze_byte(); s2[i] = (int32_t)(((hi << 8) | lo) & fmask); }
+    }
+    __syncthreads();
+    const uint32_t bound = (1u << (P.q_bits - 1)) - 1u;
+    int over = 0;
+    for (int i = lane; i < n - P.k; i += 64) {
+        int32_t v = t[i] - s2[i];                                              // in (-2^(q_bits-1), q): one conditional addition normalises it (:1782-1788)
+        if (v < 0) v += P.q;
+        s1[i] = v;
+        over |= ((uint32_t)v > bound) ? 1 : 0;                                 // recover_msg (:852-856)
+    }
+    if (__any(over)) { refuse(); return; }
+    __syncthreads();
+    // the row: m1's bits from the front; m2 behind them, moved back down by the bits it was moved up; the byte they share takes m1's bits on top
+    const uint32_t fb = (uint32_t)P.q_bits - 1u, masku = 0xFFu >> sh, maskl = masku ^ 0xFFu;
+    for (uint32_t j = lane; j < olen; j += 64) {
+        uint32_t byte = 0;
+        if (j < P.m1_bytes) {
+            for (int k = 0; k < 8; k++) {
+                const uint32_t bp = 8 * j + k;
+                if (bp < P.m1_bits) { const uint32_t ci = bp / fb, bi = bp - ci * fb; byte |= (((uint32_t)s1[ci] >> (fb - 1 - bi)) & 1u) << (7 - k); }
+            }
+        }
+        if (l2 && j >= base) {
+            const uint32_t i = j - base;
+            const uint8_t *mb = m2 + (size_t)b * m2_stride;
+            const uint32_t lo = ((uint32_t)mb[i] >> sh) & masku, hi = i ? (((uint32_t)mb[i - 1] << (8 - sh)) & maskl) : 0u;
+            byte = (j == base && sh) ? ((byte & maskl) | lo) : (hi | lo);
+        }
+        ob[j] = (uint8_t)byte;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        Sponge<1> sp; sp.init(st, 0, 168);
+        rec_hash(sp, ob, olen, 0, s2, P);
+    }
+    __syncthreads();
+    int neq = 0;
+    for (int i = lane; i < P.k; i += 64) neq |= (s2[i] != t[n - P.k + i]) ? 1 : 0;
+    neq = __any(neq) ? 1 : 0;
+    if (lane == 0) { verdicts[b] = (uint32_t)neq; outlens[b] = neq ? 0u : olen; }
+}
+
+}  // namespace
+
+extern "C" size_t sc_hip_ens_dlp_sig_rec_bytes(const sc_hip_ens_dlp_signer_t *h) { return h ? (2 * (size_t)h->P.n * (size_t)h->P.q_bits + 7) / 8 : 0; }
+extern "C" size_t sc_hip_ens_dlp_sig_rec_m1_bytes(const sc_hip_ens_dlp_signer_t *h) { return (h && rec_params_ok(h->P)) ? rec_params(h->P).m1_bytes : 0; }
+
+// replaces: safecrypto_sign_with_recovery -> ens_dlp_sig_sign_recovery (ens_dlp_sig.c:1319-1501) for `batch` messages under one private key.
+// Out of place where the reference works in the caller's buffer: d_m2 row i / d_m2lens[i] = what the reference leaves in *m / *m_len.
+// d_status as sc_hip_ens_dlp_sig_sign.  Signatures are 2 n q_bits / 8 bytes (s1 | s2).
+extern "C" int sc_hip_ens_dlp_sig_sign_recovery(sc_hip_ens_dlp_signer_t *h, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
+                                                const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens, uint8_t *d_sigs, size_t sig_stride,
+                                                uint8_t *d_m2, size_t m2_stride, uint32_t *d_m2lens, uint32_t *d_status, void *stream)
+{
+    if (!h) return fail("ens_dlp_sig_sign_recovery: null handle");
+    if (!h->have_key) return fail("ens_dlp_sig_sign_recovery: no key loaded");
+    if (!rec_params_ok(h->P)) return fail("ens_dlp_sig_sign_recovery: the handle's parameters carry no k_recovery (params.pad[0]) or q_bits is outside 9..16");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (batch > 0x7fffffc0u) return fail("ens_dlp_sig_sign_recovery: batch too large");
+    if (!d_msgs || !d_tapes || !d_sigs || !d_status || !d_m2 || !d_m2lens) return fail("ens_dlp_sig_sign_recovery: null buffer");
+    const size_t n = (size_t)h->P.n, n2 = 2 * n;
+    const RecP R = rec_params(h->P);
+    if (tape_stride < 2 * n2 || tape_stride > 0xffffffffu || (tape_stride & 1) != 0 || ((uintptr_t)d_tapes & 7) != 0)
+        return fail("ens_dlp_sig_sign_recovery: tapes must be 8-byte aligned rows of at least 4n words (even tape_stride)");
+    if (sig_stride < sc_hip_ens_dlp_sig_rec_bytes(h)) return fail("ens_dlp_sig_sign_recovery: sig_stride too small (2 n q_bits / 8 bytes)");
+    const size_t longest = d_mlens ? msg_stride : (size_t)fixed_len;
+    if (longest > (R.m1_bits >> 3) && m2_stride < longest - (R.m1_bits >> 3)) return fail("ens_dlp_sig_sign_recovery: m2_stride too small for the longest message's remainder");
+    HIPCHK(hipSetDevice(h->ctx->device));
+    const size_t B = (batch + 63) & ~(size_t)63;
+    if (h->ws.reserve(B * n2 * 4 + batch * n * 4 + 1024)) return SC_HIP_FAILURE;
+    int32_t *ci = h->ws.take<int32_t>(B * n2);
+    int32_t *c = h->ws.take<int32_t>(batch * n);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = (uint32_t)batch;
+    hipLaunchKernelGGL(rec_target_kernel, dim3((nb + HT - 1) / HT), dim3(HT), 0, s, nb, d_msgs, msg_stride, d_mlens, fixed_len, c, d_m2, m2_stride, d_m2lens, R);
+    HIPCHK(hipGetLastError());
+    if (klein_launch(h, batch, B, c, d_tapes, tape_stride, d_tape_lens, ci, d_status, 1, s)) return SC_HIP_FAILURE;
+    hipLaunchKernelGGL(klein_pack_kernel, dim3((unsigned)((batch + 255) / 256), (unsigned)(n2 / 8)), dim3(256), 0, s, nb, (uint32_t)B, ci, d_status, d_sigs, sig_stride, (int)n, h->P.q, h->P.q_bits);
+    HIPCHK(hipGetLastError());
+    h->ws.wipe(s);
+    return SC_HIP_SUCCESS;
+}
+
+// replaces: safecrypto_verify_with_recovery -> ens_dlp_sig_verify_recovery (ens_dlp_sig.c:1663-1826) for `batch` signatures under one public key (the
+// Falcon-shaped handle of sc_hip_ens_dlp_sig_verify, created with k_recovery in params.pad[0]).  In: the signatures and the remainders m2 (d_m2lens null:
+// none).  Out: d_verdicts[i] = 0 valid / 1 invalid, and for a valid signature the rebuilt message in row i of d_msgs_out (d_mlens_out[i] bytes: the m1
+// bytes, then what m2 carried) - what the reference leaves in *m when it is handed m2 in a ZEROED buffer (it takes the low bits of the byte m1 and m2
+// share from the caller's buffer when m2 is empty).  A refused signature leaves length 0.
+extern "C" int sc_hip_ens_dlp_sig_verify_recovery(sc_hip_falcon_t *f, size_t batch, const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens,
+                                                  const uint8_t *d_m2, size_t m2_stride, const uint32_t *d_m2lens,
+                                                  uint8_t *d_msgs_out, size_t out_stride, uint32_t *d_mlens_out, uint32_t *d_verdicts, void *stream)
+{
+    if (fal_check_common(f, batch, "ens_dlp_sig_verify_recovery")) return SC_HIP_FAILURE;
+    if (!f->have_pk) return fail("ens_dlp_sig_verify_recovery: no public key loaded");
+    if (!rec_params_ok(f->P)) return fail("ens_dlp_sig_verify_recovery: the handle's parameters carry no k_recovery (params.pad[0]) or q_bits is outside 9..16");
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_sigs || !d_siglens || !d_msgs_out || !d_mlens_out || !d_verdicts || (d_m2lens && !d_m2)) return fail("ens_dlp_sig_verify_recovery: null buffer");
+    const RecP R = rec_params(f->P);
+    if (out_stride < R.m1_bytes) return fail("ens_dlp_sig_verify_recovery: out_stride smaller than the bytes a signature carries");
+    HIPCHK(hipSetDevice(f->ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)4 * f->P.n * sizeof(int32_t) + 25 * sizeof(uint64_t);
+    hipLaunchKernelGGL(rec_verify_kernel, dim3((unsigned)batch), dim3(64), lds, s, (uint32_t)batch, d_sigs, sig_stride, d_siglens, d_m2, m2_stride, d_m2lens, f->d_hraw,
+                       d_msgs_out, out_stride, d_mlens_out, d_verdicts, R, f->P.bd);
+    HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
 

@@ -33,7 +33,7 @@ SYMBOLS = [
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_sign_seeded', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
     'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey', 'sc_hip_ens_dlp_signer_set_mapping',
-    'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
+    'sc_hip_ens_dlp_sig_bytes', 'sc_hip_ens_dlp_sig_tape_words', 'sc_hip_ens_dlp_sig_sign', 'sc_hip_ens_dlp_sig_rec_bytes', 'sc_hip_ens_dlp_sig_rec_m1_bytes', 'sc_hip_ens_dlp_sig_sign_recovery', 'sc_hip_ens_dlp_sig_verify_recovery', 'sc_hip_dlp_create', 'sc_hip_dlp_destroy', 'sc_hip_dlp_set_pubkey', 'sc_hip_dlp_set_user_key', 'sc_hip_dlp_msg_bytes',
     'sc_hip_dlp_ct_bytes', 'sc_hip_dlp_enc_words', 'sc_hip_dlp_encrypt', 'sc_hip_dlp_decrypt',
     'sc_hip_ens_create', 'sc_hip_ens_destroy', 'sc_hip_ens_set_pubkey', 'sc_hip_ens_set_privkey', 'sc_hip_ens_ct_bytes', 'sc_hip_ens_key_bytes',
     'sc_hip_ens_encaps', 'sc_hip_ens_decaps',
@@ -221,6 +221,11 @@ def load_library(path=LIB_PATH):
     L.sc_hip_ens_dlp_sig_tape_words.argtypes = [vp]
     L.sc_hip_ens_dlp_sig_tape_words.restype = sz
     L.sc_hip_ens_dlp_sig_sign.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
+    for fn in ('sc_hip_ens_dlp_sig_rec_bytes', 'sc_hip_ens_dlp_sig_rec_m1_bytes'):
+        getattr(L, fn).argtypes = [vp]
+        getattr(L, fn).restype = sz
+    L.sc_hip_ens_dlp_sig_sign_recovery.argtypes = [vp, sz, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, sz, vp, vp, vp]
+    L.sc_hip_ens_dlp_sig_verify_recovery.argtypes = [vp, sz, vp, sz, vp, vp, sz, vp, vp, sz, vp, vp, vp]
     L.sc_hip_dlp_ibe_extract.argtypes = [vp, sz, C.c_int, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp]
     L.sc_hip_dlp_create.argtypes = [vp, vp, C.POINTER(vp)]
     L.sc_hip_dlp_destroy.argtypes = [vp]
@@ -1483,6 +1488,22 @@ class EnsDlpSigner:
                                                     _ptr(sigs), self.sig_bytes, _ptr(status), _stream()), 'ens_dlp_sig_sign')
         return sigs, status
 
+    def sign_recovery(self, msgs, tapes, mlens=None, fixed_len=0, tape_lens=None):
+        """with message recovery (the handle's params carry k_recovery in word 6): -> signatures uint8 [batch][2 n q_bits / 8] (s1 | s2), the remainders
+        m2 uint8 [batch][stride] and their lengths, status"""
+        import torch
+        batch, dev = msgs.shape[0], msgs.device
+        nb = self.L.sc_hip_ens_dlp_sig_rec_bytes(self.h)
+        sigs = torch.zeros((batch, nb), dtype=torch.uint8, device=dev)
+        m2 = torch.zeros((batch, max(8, msgs.shape[1])), dtype=torch.uint8, device=dev)
+        m2lens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        status = torch.zeros(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ens_dlp_sig_sign_recovery(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else nul, fixed_len,
+                                                             _ptr(tapes), _rows(tapes), _ptr(tape_lens) if tape_lens is not None else nul,
+                                                             _ptr(sigs), nb, _ptr(m2), _rows(m2), _ptr(m2lens), _ptr(status), _stream()), 'ens_dlp_sig_sign_recovery')
+        return sigs, m2, m2lens, status
+
 
 class Falcon:
     """Batched Falcon (sets 0 and 2) tree sampler / sign / verify under one key (gaussian_sample_with_tree, falcon_sig_sign,
@@ -1587,6 +1608,23 @@ class Falcon:
         _chk(self.L, self.L.sc_hip_ens_dlp_sig_verify(self.h, batch, _ptr(msgs), _rows(msgs), _ptr(mlens) if mlens is not None else C.c_void_p(), fixed_len,
                                                       _ptr(sigs), _rows(sigs), _ptr(siglens), _ptr(verdicts), _stream()), 'ens_dlp_sig_verify')
         return verdicts
+
+    def ens_dlp_verify_recovery(self, sigs, siglens, m2=None, m2lens=None, out_bytes=0):
+        """ENS / DLP signatures with message recovery (params word 6 = k_recovery, h loaded): -> verdicts (0 valid), the rebuilt messages uint8
+        [batch][out_bytes or what the longest can need] and their lengths (0 for a refused signature)"""
+        import torch
+        batch, dev = sigs.shape[0], sigs.device
+        k, qb = int(self.par[6]), int(self.par[2])
+        m1 = ((self.n - k) * (qb - 1) + 7) // 8
+        stride = int(out_bytes) if out_bytes else m1 + (m2.shape[1] if m2 is not None else 0)
+        out = torch.zeros((batch, stride), dtype=torch.uint8, device=dev)
+        outlens = torch.zeros(batch, dtype=torch.int32, device=dev)
+        verdicts = torch.ones(batch, dtype=torch.int32, device=dev)
+        nul = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_ens_dlp_sig_verify_recovery(self.h, batch, _ptr(sigs), _rows(sigs), _ptr(siglens),
+                                                               _ptr(m2) if m2 is not None else nul, _rows(m2) if m2 is not None else 0, _ptr(m2lens) if m2lens is not None else nul,
+                                                               _ptr(out), stride, _ptr(outlens), _ptr(verdicts), _stream()), 'ens_dlp_sig_verify_recovery')
+        return verdicts, out, outlens
 
     def dlp_extract(self, ubits, ids, tapes, idlens=None, fixed_len=0, tape_lens=None):
         """DLP-IBE extract (the handle holds the DLP-IBE parameters and the master tree): ids uint8 [batch][stride], tapes [batch][>= 4n]

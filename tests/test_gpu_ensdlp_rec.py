@@ -1,0 +1,159 @@
+"""GPU parity for batched ENS / DLP signatures WITH MESSAGE RECOVERY (sc_hip_ens_dlp_sig_sign_recovery / sc_hip_ens_dlp_sig_verify_recovery against
+ens_dlp_sig_sign_recovery / ens_dlp_sig_verify_recovery, src/schemes/sig/ens_dlp/ens_dlp_sig.c:1319-1501, 1663-1826).  Signing: the reference's
+signatures s1 | s2 and remainders m2 byte for byte given its PRNG word tape (tests/golden/ensdlp_rec_ref.txt), every form of Klein's sampler, and the
+oracle's on seeded messages of every length around the bits a signature carries.  Verification: the reference's verdicts and rebuilt messages on its
+own signatures and on tampered copies, the oracle's on further tampering, and what the device signs comes back as the message that went in."""
+import numpy as np
+import pytest
+
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+CASES = ['dlprec0', 'ensrec0']
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from libsafecrypto_amd import Engine
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def G():
+    return load_golden('ensdlp_rec_ref.txt')
+
+
+def _b(x):
+    return bytes(np.asarray(x, dtype=np.uint8))
+
+
+def _rows(items, stride=None, fill=0):
+    stride = stride or max(8, max(len(x) for x in items))
+    buf = np.full((len(items), stride), fill, dtype=np.uint8); lens = np.zeros(len(items), dtype=np.int32)
+    for i, x in enumerate(items):
+        buf[i, :len(x)] = np.frombuffer(bytes(x), dtype=np.uint8); lens[i] = len(x)
+    return buf, lens
+
+
+def _signer(eng, G, tag):
+    par = np.asarray(G[f'{tag}_params'])
+    hp = par.copy(); hp[4] = 0
+    s = eng.ens_dlp_signer(hp)
+    s.set_privkey(G[f'{tag}_fgFG'])
+    return s, par
+
+
+@pytest.mark.parametrize('tag', CASES)
+@pytest.mark.parametrize('lanes', [0, 1, 16])
+def test_signatures_and_remainders_are_the_references(eng, G, tag, lanes):
+    import torch
+    s, par = _signer(eng, G, tag)
+    if lanes:
+        s.set_mapping(lanes)
+    msgs = [_b(G[f'{tag}_msg{m}']) for m in range(8)]
+    mb, ml = _rows(msgs)
+    tapes = np.stack([np.asarray(G[f'{tag}_tape{m}'], dtype=np.int64).astype(np.uint32) for m in range(8)])
+    sigs, m2, m2l, st = s.sign_recovery(torch.from_numpy(mb).cuda(), torch.from_numpy(tapes.view(np.int32)).cuda(), mlens=torch.from_numpy(ml).cuda())
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [1] * 8
+    for m in range(8):
+        assert bytes(sigs[m].cpu().numpy()) == _b(G[f'{tag}_sig{m}']), m
+        assert bytes(m2[m, :int(m2l[m])].cpu().numpy()) == _b(G[f'{tag}_m2_{m}']), m
+    s.close()
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_verdicts_and_rebuilt_messages_are_the_references(eng, G, tag):
+    import torch
+    par, h = np.asarray(G[f'{tag}_params']), G[f'{tag}_h']
+    hp = par.copy(); hp[4] = 0
+    f = eng.falcon(hp)
+    f.set_pubkey(h)
+    rng = np.random.default_rng(5)
+    sigs, m2s, want, back = [], [], [], []
+    for m in range(8):
+        sig, m2 = _b(G[f'{tag}_sig{m}']), _b(G[f'{tag}_m2_{m}'])
+        v = [int(x) for x in G[f'{tag}_verify'][3 * m:3 * m + 3]]
+        sigs.append(sig); m2s.append(m2); want.append(v[0]); back.append(_b(G[f'{tag}_back{m}']) if v[0] == 0 else b'')
+        t1 = bytearray(sig); t1[len(sig) - 9] ^= 0x04
+        sigs.append(bytes(t1)); m2s.append(m2); want.append(v[1]); back.append(None)
+        t2, t3 = bytearray(sig), bytearray(m2)
+        if m2:
+            t3[0] ^= 0x80
+        else:
+            t2[2] ^= 0x40
+        sigs.append(bytes(t2)); m2s.append(bytes(t3)); want.append(v[2]); back.append(None)
+        for _ in range(4):                                        # further single-bit flips: the oracle decides
+            t4 = bytearray(sig); t4[int(rng.integers(0, len(sig)))] ^= 1 << int(rng.integers(0, 8))
+            rc, bk = O.ensdlp_verify_recovery(par, h, m2, bytes(t4))
+            sigs.append(bytes(t4)); m2s.append(m2); want.append(rc); back.append(bk if rc == 0 else b'')
+    sigs.append(sigs[0]); m2s.append(m2s[0]); want.append(1); back.append(b'')       # a truncated signature
+    sb, sl = _rows(sigs); sl[-1] -= 1
+    m2b, m2l = _rows(m2s)
+    v, out, ol = f.ens_dlp_verify_recovery(torch.from_numpy(sb).cuda(), torch.from_numpy(sl).cuda(), torch.from_numpy(m2b).cuda(), torch.from_numpy(m2l).cuda())
+    torch.cuda.synchronize()
+    assert v.cpu().tolist() == want
+    assert want.count(0) >= 7
+    for i, bk in enumerate(back):
+        if bk is not None:
+            assert bytes(out[i, :int(ol[i])].cpu().numpy()) == bk, i
+    # no remainders at all (d_m2lens null): the signatures whose messages fit inside
+    v2, out2, ol2 = f.ens_dlp_verify_recovery(torch.from_numpy(sb[:1].copy()).cuda(), torch.from_numpy(sl[:1].copy()).cuda())
+    assert v2.cpu().tolist() == [want[0]] and bytes(out2[0, :int(ol2[0])].cpu().numpy()) == back[0]
+    f.close()
+
+
+@pytest.mark.parametrize('tag', CASES)
+def test_seeded_batch_against_the_oracle_and_round_trip(eng, G, tag):
+    """a ragged batch (lengths 0 .. beyond the carried bits, every residue mod 8 of the boundary) signed on the device: the oracle's bytes for a
+    sample of rows, and every row verifies and comes back as the message that went in (zero-extended to the carried bytes) - except the rows whose
+    last bits the reference's format cannot carry, which the device refuses as the reference does"""
+    import torch
+    s, par = _signer(eng, G, tag)
+    n, q = int(par[0]), int(par[1])
+    m1 = O.ensdlp_rec_m1_bytes(par)
+    m1_bits = (n - int(par[6])) * (int(par[2]) - 1)
+    rng = np.random.default_rng(99)
+    lens = [0, 1, 7, m1 - 2, m1 - 1, m1, m1 + 1, m1 + 2, m1 + 3, m1 + 9, m1 + 200] + [int(x) for x in rng.integers(0, m1 + 300, size=53)]
+    B = len(lens)
+    msgs = [bytes(rng.integers(0, 256, size=L, dtype=np.uint8)) for L in lens]
+    mb, ml = _rows(msgs, stride=m1 + 304)
+    tapes = rng.integers(0, 2**32, size=(B, 4 * n), dtype=np.uint32)
+    sigs, m2, m2l, st = s.sign_recovery(torch.from_numpy(mb).cuda(), torch.from_numpy(tapes.view(np.int32)).cuda(), mlens=torch.from_numpy(ml).cuda())
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [1] * B
+    b, bgs, inv = O.ensdlp_basis(n, q, G[f'{tag}_fgFG'])
+    for i in list(range(11)) + [20, 40]:
+        rc, want, want2 = O.ensdlp_sign_recovery(par, b, bgs, inv, msgs[i], tapes[i])
+        assert rc == 0 and bytes(sigs[i].cpu().numpy()) == want, i
+        assert bytes(m2[i, :int(m2l[i])].cpu().numpy()) == want2, i
+    hp = par.copy(); hp[4] = 0
+    f = eng.falcon(hp)
+    f.set_pubkey(G[f'{tag}_h'])
+    sl = torch.full((B,), sigs.shape[1], dtype=torch.int32, device='cuda')
+    v, out, ol = f.ens_dlp_verify_recovery(sigs, sl, m2, m2l)
+    torch.cuda.synchronize()
+    lost = 0
+    for i, L in enumerate(lens):
+        carried = L <= (m1_bits >> 3) or L > m1 or (m1_bits & 7) == 0 or not (msgs[i][m1 - 1] & (0xFF >> (m1_bits & 7)))
+        if carried:
+            assert int(v[i]) == 0, (i, L)
+            assert bytes(out[i, :int(ol[i])].cpu().numpy()) == (msgs[i] + bytes(m1))[:max(m1, L)], (i, L)
+        else:                                                     # ends inside the byte m1 and m2 share: its last bits are dropped by the signer
+            assert int(v[i]) == 1 and int(ol[i]) == 0, (i, L)
+            lost += 1
+    assert lost <= 3
+    # a tape one word short, and a handle without k_recovery
+    tl = torch.full((B,), 4 * n, dtype=torch.int32, device='cuda'); tl[3] = 4 * n - 1
+    st2 = s.sign_recovery(torch.from_numpy(mb).cuda(), torch.from_numpy(tapes.view(np.int32)).cuda(), mlens=torch.from_numpy(ml).cuda(), tape_lens=tl)[3]
+    assert int(st2[3]) == 2 and int(st2[4]) == 1
+    s.close(); f.close()
+    plain = par.copy(); plain[4] = 0; plain[6] = 0
+    s0 = eng.ens_dlp_signer(plain)
+    s0.set_privkey(G[f'{tag}_fgFG'])
+    with pytest.raises(Exception):
+        s0.sign_recovery(torch.from_numpy(mb).cuda(), torch.from_numpy(tapes.view(np.int32)).cuda(), mlens=torch.from_numpy(ml).cuda())
+    s0.close()
