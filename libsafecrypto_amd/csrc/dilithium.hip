@@ -527,7 +527,14 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
                 const uint4 *pk = reinterpret_cast<const uint4 *>(key + (size_t)tt * N);
 #pragma unroll
                 for (int c = 0; c < 4; c++) d.key[c] = pk[c];
-                if (arr == a.w) {                                       // w is stored in 16-byte pieces (DilNtt::w_chunked)
+                if (arr == a.w && a.w_chunked == 2) {                   // ... 24 bits per coefficient: three pieces, unpacked into the same sixteen registers
+                    const int4 *pa = reinterpret_cast<const int4 *>(arr + ((size_t)slot * per + tt) * sc_mlwe::W24) + lp;
+                    uint32_t pk[12];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { const int4 v = pa[16 * c]; pk[4 * c] = (uint32_t)v.x; pk[4 * c + 1] = (uint32_t)v.y; pk[4 * c + 2] = (uint32_t)v.z; pk[4 * c + 3] = (uint32_t)v.w; }
+#pragma unroll
+                    for (int e = 0; e < 16; e++) d.pre[e] = (int32_t)sc_mlwe::unpack24(pk, e);
+                } else if (arr == a.w) {                                // w is stored in 16-byte pieces (DilNtt::w_chunked)
                     const int4 *pa = reinterpret_cast<const int4 *>(arr + ((size_t)slot * per + tt) * N) + lp;
 #pragma unroll
                     for (int c = 0; c < 4; c++) { const int4 v = pa[16 * c]; d.pre[4 * c] = v.x; d.pre[4 * c + 1] = v.y; d.pre[4 * c + 2] = v.z; d.pre[4 * c + 3] = v.w; }
@@ -838,7 +845,7 @@ struct sc_hip_dilithium {
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
     hipStream_t side, side2;                          // verify_keys / sign_keys: per-key chains that depend on nothing of each other run beside each other
     hipEvent_t ev_fork, ev_join, ev_join2;
-    int tune_slots, tune_unfused, tune_sync, tune_exp1 = 0;        // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
+    int tune_slots, tune_unfused, tune_sync, tune_exp1 = 0, tune_w24 = 0;        // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
 };
 
 static void free_ws(sc_hip_dilithium *d)
@@ -1064,7 +1071,7 @@ extern "C" int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *d, unsigne
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
-    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_unfused = unfused ? 1 : 0;
+    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_w24 = (slots_per_message >> 10) & 1; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -1158,6 +1165,14 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     const bool exp2 = d->tune_exp1 ? false : (size_t)cap <= (size_t)d->ctx->cus * 4 * 64;
     const unsigned eb = (unsigned)(((size_t)cap * (exp2 ? 2 : 1) + EXP_T - 1) / EXP_T) + 1, hb = (cap + CH_T - 1) / CH_T;
     uint32_t *yh_wipe = (ks.As && !ks.per_item) ? nullptr : d->yh;     // NTT(y) where the unfused transform / product pair leaves it in HBM
+    // sc_hip_dilithium_set_tuning bit 10 (one key for the batch: the fused kernel): w = A y travels between the round's kernels in 24 bits per coefficient
+    // (mlwe_kernels.h: W24) - a quarter less of what the signer moves most of.  Measured on one box, three alternating pairs of runs:
+    // 205 -> 187 KB per signature by the counters, 2.656 -> 2.687 ms per 16384-signature call - the finishing kernel (255 registers, waiting on its loads)
+    // pays more for the unpacking than it gains from the shorter rows.  Throughput is the metric, so 32-bit words stay the default and this form stays
+    // behind the hook.  Tried on top of it and dropped: the masks y in 24 bits as well (ExpandMask writing q + y at byte 3 j, unaligned word loads in the
+    // fused and the finishing kernel): 166 KB per signature, 2.75 ms per call.
+    const bool packed = d->tune_w24 && ks.As && !ks.per_item && P.q < (1 << 24) && P.n == N;
+    const uint32_t w_words = packed ? (uint32_t)(k * W24) : (uint32_t)(k * P.n);
     uint32_t round = 0, todo = d->tune_sync ? 1 : plan_rounds(batch, cap, s_max), left = B;
     while (left > 0) {
         for (uint32_t i = 0; i < todo; i++, round++) {
@@ -1166,13 +1181,13 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
             f.active = active; f.next_active = d->act[round & 1];
             hipLaunchKernelGGL(dil_round_kernel, dim3(1), dim3(1), 0, s, d->rs, d->cnt, round ? 0u : B, cap, s_max);
             if (exp2) hipLaunchKernelGGL(dil_expand_kernel<true>, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
-                                         d->w, (uint32_t)(k * P.n), yh_wipe);
+                                         d->w, w_words, yh_wipe);
             else hipLaunchKernelGGL(dil_expand_kernel<false>, dim3(eb), dim3(EXP_T), 0, s, d->rs, active, d->kappa, ks.K, d->mu, d->y, l * P.n, P.gamma1, P.q, ks.per_item ? 32u : 0u, d->slot_item,
-                                    d->w, (uint32_t)(k * P.n), yh_wipe);
+                                    d->w, w_words, yh_wipe);
             HIPCHK(hipGetLastError());
             DilNtt a = base_args(d);
             a.in = d->y; a.out_int = d->yh;
-            a.njobs_dev = d->rs + RS_NSLOTS; a.w_chunked = 1;
+            a.njobs_dev = d->rs + RS_NSLOTS; a.w_chunked = packed ? 2 : 1;
             a.key_of = d->slot_item;                                    // per-message keys: the key of a slot is its message's
             if (ks.As && !ks.per_item) {                                // w = A y with NTT(y) kept in registers
                 a.key = ks.As; a.keyp = ks.As + (size_t)k * l * N;
@@ -1203,7 +1218,7 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         // the last queued round's slots (every earlier round's were zeroed by its successor's surplus workgroups) - in front of the look at the count, not behind
         // it: the call usually ends here, and the zeroing then runs while the host waits for the count instead of after it has woken up (a round that follows
         // finds its predecessor's slots zeroed twice)
-        hipLaunchKernelGGL(dil_wipe_kernel, dim3(cap < 4096u ? cap : 4096u), dim3(256), 0, s, d->rs, d->y, (uint32_t)(l * P.n), d->w, (uint32_t)(k * P.n), yh_wipe);
+        hipLaunchKernelGGL(dil_wipe_kernel, dim3(cap < 4096u ? cap : 4096u), dim3(256), 0, s, d->rs, d->y, (uint32_t)(l * P.n), d->w, w_words, yh_wipe);
         HIPCHK(hipGetLastError());
         uint32_t cnt = 0;
         HIPCHK(hipMemcpyAsync(&cnt, d->cnt, 4, hipMemcpyDeviceToHost, s));

@@ -49,6 +49,25 @@ __device__ __forceinline__ bool norm_bad(uint32_t v, uint32_t q, uint32_t b)
 
 enum { DOP_FWD_INT = 0, DOP_MATVEC = 1, DOP_CT1 = 5, DOP_KEYPREP = 6 };
 
+// The signer's per-attempt w = A y in 24 bits per coefficient (DilNtt::w_chunked == 2; q < 2^24): the 16 values v[0..15] of a lane as 12 words, value e in
+// bits [24 e, 24 e + 24) of the little-endian string.  192 words per polynomial instead of 256.
+constexpr int W24 = 192;
+__device__ __forceinline__ uint32_t pack24_word(const uint32_t (&v)[16], int w)          // w: 0..11, compile-time after unrolling
+{
+    const int e = (4 * w) / 3, sh = 32 * w - 24 * e;                  // the first value with bits in word w, and how many of its bits lie in earlier words
+    uint32_t r = v[e] >> sh;
+    if (e + 1 < 16) r |= v[e + 1] << (24 - sh);
+    if (24 - sh + 24 < 32 && e + 2 < 16) r |= v[e + 2] << (48 - sh);
+    return r;
+}
+__device__ __forceinline__ uint32_t unpack24(const uint32_t (&p)[12], int e)              // e: 0..15, compile-time after unrolling
+{
+    const int w = (3 * e) / 4, sh = 24 * e - 32 * w;
+    uint32_t r = p[w] >> sh;
+    if (sh > 8) r |= p[w + 1] << (32 - sh);
+    return r & 0xFFFFFFu;
+}
+
 struct DilNtt {
     const uint32_t *zf, *zfp, *zi, *zip;
     ModK k;
@@ -77,7 +96,8 @@ struct DilNtt {
     uint8_t *w1;                          // [item][k*n]
     int32_t *z;                           // [item][l][n]
     uint8_t *h;                           // [item][k*n]
-    int w_chunked;                        // 1 (the signer's per-attempt w, which only its own kernels read): coefficient j = 16 r + lp of a polynomial is stored at
+    int w_chunked;                        // 2: as 1, in 24 bits per coefficient (W24 below; the fused kernel and the signer's finishing kernel only).
+                                          // 1 (the signer's per-attempt w, which only its own kernels read): coefficient j = 16 r + lp of a polynomial is stored at
                                           // 64 (r / 4) + 4 lp + r % 4 - a lane moves its 16 coefficients as four 16-byte pieces and each of the four wave
                                           // instructions covers 256 contiguous bytes per polynomial (sixteen 4-byte stores of 64 bytes each otherwise).
                                           // (Measured and dropped: 16 contiguous words per lane - every instruction then touches 16 lines per polynomial - and
@@ -334,7 +354,16 @@ __global__ __launch_bounds__(256, 2) void dil_yaw_kernel(DilNtt a)
                 }
                 continue;
             }
-            if (a.w_chunked) {
+            if (a.w_chunked == 2) {                                     // 24 bits per coefficient (q < 2^24): the lane's 16 values as three 16-byte pieces, 768 bytes per polynomial
+                int4 *d4 = reinterpret_cast<int4 *>(a.w + ((size_t)slot * a.kk + i) * W24) + lp;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pk[e] = pack24_word(x, 4 * c + e);
+                    d4[16 * c] = make_int4((int32_t)pk[0], (int32_t)pk[1], (int32_t)pk[2], (int32_t)pk[3]);
+                }
+            } else if (a.w_chunked) {
                 int4 *d4 = reinterpret_cast<int4 *>(a.w + ((size_t)slot * a.kk + i) * N) + lp;
 #pragma unroll
                 for (int c = 0; c < 4; c++) d4[16 * c] = make_int4((int32_t)x[4 * c], (int32_t)x[4 * c + 1], (int32_t)x[4 * c + 2], (int32_t)x[4 * c + 3]);

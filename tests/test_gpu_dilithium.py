@@ -96,8 +96,9 @@ def test_batch_vs_oracle_seeded(eng, G):
     for i in range(0, 257, 32):
         assert O.dilithium_verify(key, msgs[i], sigs[i]) == 0
     # the forms a batch of this size does not pick by itself give the same bytes: ExpandMask and the challenge hash with one lane per state (what a
-    # batch beyond 64 K attempt slots runs; sc_hip_dilithium_set_tuning bit 9), the host looking at the count after every round (bit 8)
-    for tuning in (1 << 9, 1 << 8, (1 << 9) | (1 << 8)):
+    # batch beyond 64 K attempt slots runs; sc_hip_dilithium_set_tuning bit 9), the host looking at the count after every round (bit 8), w = A y
+    # between the round's kernels in 24 bits per coefficient (bit 10)
+    for tuning in (1 << 9, 1 << 8, (1 << 9) | (1 << 8), 1 << 10, (1 << 10) | (1 << 9)):
         d.set_tuning(tuning)
         s2, t2 = d.sign_host(msgs)
         assert s2 == sigs and t2 == trials, tuning
