@@ -604,10 +604,12 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
             inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
             epi_r(o[0], 0);
             if constexpr (K2P) {
-                product(o[1]);
-                issue(o[0], s1k, a.y, l, 0);
-                inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-                epi_r(o[1], 1);
+                if (__ballot(bad) == 0) {                                   // an attempt the first four rows already reject skips the rest of the stage
+                    product(o[1]);
+                    issue(o[0], s1k, a.y, l, 0);
+                    inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                    epi_r(o[1], 1);
+                }
             }
             bool ok = __ballot(bad) == 0;
             if (ok) {
@@ -625,10 +627,12 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
                 inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
                 epi_z(o[Z0], 0);
                 if constexpr (L2P) {
-                    product(o[Z1]);
-                    issue(o[Z0], t0k, nullptr, kk, 0);
-                    inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-                    epi_z(o[Z1], 1);
+                    if (__ballot(bad) == 0) {                               // likewise: four of the five rows decide most rejections
+                        product(o[Z1]);
+                        issue(o[Z0], t0k, nullptr, kk, 0);
+                        inv_core<L8, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+                        epi_z(o[Z1], 1);
+                    }
                 }
                 ok = __ballot(bad) == 0;
             }
