@@ -320,45 +320,90 @@ __device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
     return left > d_sub - P.bound;
 }
 
+// The sparse products of the deciding kernel through a SHIFT TABLE (round 4): for a polynomial t, T[m] = t[m] (m < n), T[m] = -t[m - n] (n <= m < 2n), so that
+// the term of mul_32_sparse (ntt.c:381-422) for position p at coefficient j - +t[j + n - p] when j < p, -t[j - p] otherwise - is T[n + j - p]: one LDS read
+// at an address that is the same for the lane's n / 64 coefficients up to a constant, and one addition - no comparison, no select, no wrap-around mask
+// (the plain form, sparse_reg, spends seven vector instructions per term).  acc[c] = the sum over the omega positions for j = lane + 64 c.
+// my_pos: lane k holds position k (one vector load per slot, omega <= 64); the loop reads them with v_readlane - no memory access inside the chain of
+// additions.  (Measured, per 32768 slots: this form 92 us, positions fetched by scalar loads inside the loop 93 us, positions in a register array behind an
+// unrolled guarded loop over the 32 a parameter set may have - the plain form's way - 120 us.)
+constexpr int TS_MAXC = 8;                                             // n <= 512
+template <typename T>
+__device__ __forceinline__ void sparse_shift(int32_t (&acc)[TS_MAXC], const T *tab, int my_pos, int omega, int n, int lane)
+{
+    const int C = n / 64;
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) acc[c] = 0;
+    for (int k = 0; k < omega; k++) {                                  // wave-uniform
+        const T *row = tab + (n + lane - __builtin_amdgcn_readlane(my_pos, k));
+#pragma unroll
+        for (int c = 0; c < TS_MAXC; c++) if (c < C) acc[c] += (int32_t)row[64 * c];
+    }
+}
+
 // one wavefront per slot (ring_tesla.c:852-880): w1 = v1 - e1*c, w2 = v2 - e2*c normalised and tested, z = y + s*c centred and
-// tested.  v1, v2 are canonical products; the key polynomials sit in LDS.  acc[slot] = 1 and z[slot] are left for the selection.
+// tested.  v1, v2 are canonical products; the key polynomials sit in LDS as shift tables (built when the key is loaded: `key` = three tables of 2n
+// entries).  acc[slot] = 1 and z[slot] are left for the selection.
+// Round 4: 125 -> 69 us per 32768 slots (ring-TESLA-I signing 13.7 -> 16 M/s at batch 16384) - the shift tables (-> 92 us), then the tables copied from
+// memory in 16-byte pieces instead of rebuilt per workgroup and the slot's rows of v1, v2 and y requested together before the first test (three
+// dependent round trips to memory became one).  Measured and dropped: fewer, persistent workgroups walking the slots (147 us: a slot is a chain of
+// dependent steps, it is the slots beside it that hide them).
 __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const uint32_t *need, const int16_t *key, const int32_t *v1, const int32_t *v2,
                                                         const int32_t *y, const int32_t *cidx, int32_t *zout, uint32_t *acc, TsP P, const uint32_t *rs)
 {
-    extern __shared__ int16_t ks[];                                    // s | e1 | e2
+    extern __shared__ __attribute__((aligned(16))) int16_t ks[];       // shift tables of s | e1 | e2: 2n entries each
     if (rs) nslots = rs[TRS_NSLOTS];
     if (blockIdx.x * 4 >= nslots) return;                              // (whole workgroup)
-    const int n = P.n;
-    for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) ks[i] = key[i];
+    const int n = P.n, C = n / 64;
+    for (int i = threadIdx.x; i < 6 * n / 8; i += blockDim.x) reinterpret_cast<uint4 *>(ks)[i] = reinterpret_cast<const uint4 *>(key)[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t slot = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (slot >= nslots) return;
     if (need[slot] == 2) { if (lane == 0) acc[slot] = 0; return; }
-    Pos pos; load_pos(pos, cidx + (size_t)slot * P.omega, P.omega);
+    const int pos = lane < P.omega ? cidx[(size_t)slot * P.omega + lane] : 0;
+    int32_t r1[TS_MAXC], r2[TS_MAXC], ry[TS_MAXC];
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) {
+        const size_t k = (size_t)slot * n + lane + 64 * (c < C ? c : 0);
+        r1[c] = v1[k]; r2[c] = v2[k]; ry[c] = y[k];
+    }
     // Every value normalised below is a centred residue (at most (q-1)/2 in magnitude) or a mask coefficient (at most b) plus omega key coefficients of
     // 16 bits: inside (-q, q) because omega * 2^15 < q / 2 and b < q / 2 (checked by sc_hip_tesla_create) - normalize_32 without the division.
     // the reference tests w1, then w2, then z and leaves at the first failure (ring_tesla.c:852-880): so does the wavefront
+    int32_t sp[TS_MAXC];
     int32_t bad = 0;
-    for (int j = lane; j < n; j += 64) {
-        const int32_t a = norm_near(centre_q(v1[(size_t)slot * n + j], P.q) - sparse_reg(ks + n, pos, P.omega, n, j), P.q);
-        bad |= w_bad(a, P) ? 1 : 0;
+    sparse_shift(sp, ks + 2 * n, pos, P.omega, n, lane);
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) {
+        if (c < C) {
+            const int32_t a = norm_near(centre_q(r1[c], P.q) - sp[c], P.q);
+            bad |= w_bad(a, P) ? 1 : 0;
+        }
     }
     bad = wave_or(bad);
     if (!bad) {
-        for (int j = lane; j < n; j += 64) {
-            const int32_t b = norm_near(centre_q(v2[(size_t)slot * n + j], P.q) - sparse_reg(ks + 2 * n, pos, P.omega, n, j), P.q);
-            bad |= w_bad(b, P) ? 1 : 0;
+        sparse_shift(sp, ks + 4 * n, pos, P.omega, n, lane);
+#pragma unroll
+        for (int c = 0; c < TS_MAXC; c++) {
+            if (c < C) {
+                const int32_t b = norm_near(centre_q(r2[c], P.q) - sp[c], P.q);
+                bad |= w_bad(b, P) ? 1 : 0;
+            }
         }
         bad = wave_or(bad);
     }
     const int32_t th = P.b - P.u;
     if (!bad) {
-        for (int j = lane; j < n; j += 64) {
-            const size_t k = (size_t)slot * n + j;
-            const int32_t z = centre_q(norm_near(sparse_reg(ks, pos, P.omega, n, j) + y[k], P.q), P.q);
-            zout[k] = z;
-            bad |= (z < -th || z > th) ? 1 : 0;
+        sparse_shift(sp, ks, pos, P.omega, n, lane);
+#pragma unroll
+        for (int c = 0; c < TS_MAXC; c++) {
+            if (c < C) {
+                const size_t k = (size_t)slot * n + lane + 64 * c;
+                const int32_t z = centre_q(norm_near(sp[c] + ry[c], P.q), P.q);
+                zout[k] = z;
+                bad |= (z < -th || z > th) ? 1 : 0;
+            }
         }
         bad = wave_or(bad);
     }
@@ -368,14 +413,22 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
 // one wavefront per active message: the lowest accepted slot becomes the signature (z: q_bits-bit two's complement MSB first -
 // three bytes per coefficient for q_bits = 24 - then the digest, ring_tesla.c:882-900); a slot beyond the end of the tape before
 // any acceptance ends the message with status 2; otherwise the message goes to the next round S attempts further on.
+constexpr int SEL_PER = 8;                  // messages per wavefront of ts_select_kernel
 __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint32_t *acc, St s, const int32_t *zs,
                                                         const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
                                                         uint32_t *next_active, uint32_t *next_count, TsP P, const uint32_t *rs)
 {
+    // A wavefront takes SEL_PER messages in turn and the workgroup files the ones that go on to the next round with ONE addition to the global count:
+    // with a wavefront per message and an atomic each, the 6 K messages a first round leaves behind queued up on one address - 90 us of a 400 us round
+    // (round 2: 24 us for 2.5 K, round 3: 9 us for 1 K) against ~10 us for the packing itself.
+    __shared__ uint32_t go_cnt, go_base, go_items[4 * SEL_PER];
     if (rs) { nact = rs[TRS_NACT]; S = rs[TRS_S]; }
     const int lane = threadIdx.x & 63, n = P.n;
-    const uint32_t aidx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (aidx >= nact) return;
+    if (threadIdx.x == 0) go_cnt = 0;
+    __syncthreads();
+    for (int turn = 0; turn < SEL_PER; turn++) {
+    const uint32_t aidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SEL_PER + turn;
+    if (aidx >= nact) break;
     const uint32_t item = active ? active[aidx] : aidx;
     uint32_t win = S, dead = S;                                      // first accepted slot / first slot past the tape
     for (uint32_t k = 0; k < S; k++) {
@@ -386,9 +439,9 @@ __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, 
     if (win == S) {
         if (lane == 0) {
             if (dead < S) { trials[item] += dead; s.pos[item] += dead * (uint32_t)n; s.status[item] = 2; siglens[item] = 0; }
-            else { trials[item] += S; s.pos[item] += S * (uint32_t)n; next_active[atomicAdd(next_count, 1u)] = item; }
+            else { trials[item] += S; s.pos[item] += S * (uint32_t)n; go_items[atomicAdd(&go_cnt, 1u)] = item; }
         }
-        return;
+        continue;
     }
     const uint32_t slot = aidx * S + win;
     const int32_t *z = zs + (size_t)slot * n;
@@ -417,6 +470,11 @@ __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, 
     const uint32_t zb = ((uint32_t)n * P.q_bits + 7) / 8;
     out[zb + lane] = md[(size_t)slot * 64 + lane];
     if (lane == 0) { siglens[item] = zb + 64; s.status[item] = 1; trials[item] += win + 1; s.pos[item] += (win + 1) * (uint32_t)n; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && go_cnt) go_base = atomicAdd(next_count, go_cnt);
+    __syncthreads();
+    if (threadIdx.x < go_cnt) next_active[go_base + threadIdx.x] = go_items[threadIdx.x];
 }
 
 // ---- verify ---------------------------------------------------------------------------------------------------------------
@@ -473,7 +531,7 @@ struct sc_hip_tesla {
     TsP P;
     bool have_priv, have_pub;
     int32_t *d_a1, *d_a2, *d_t1, *d_t2;
-    int16_t *d_key;                      // s | e1 | e2
+    int16_t *d_key;                      // s | e1 | e2, each as a shift table of 2n entries (t | -t)
     uint64_t *d_zstate; uint32_t zblocks;
     size_t cap, slot_cap;                // messages / slots (attempts evaluated side by side) the workspace holds
     St st;
@@ -560,10 +618,14 @@ extern "C" int sc_hip_tesla_set_key(sc_hip_tesla_t *t, const int32_t *a1, const 
     const size_t n = t->P.n;
     if (ts_upload32(&t->d_a1, a1, n) || ts_upload32(&t->d_a2, a2, n)) return SC_HIP_FAILURE;
     if (s) {
-        if (!t->d_key) HIPCHK(hipMalloc((void **)&t->d_key, 3 * n * 2));
-        HIPCHK(sc::copy_in(t->d_key, s, n * 2));
-        HIPCHK(sc::copy_in(t->d_key + n, e1, n * 2));
-        HIPCHK(sc::copy_in(t->d_key + 2 * n, e2, n * 2));
+        // the three small polynomials as the deciding kernel's shift tables (sparse_shift): T[m] = t[m], T[n + m] = -t[m]
+        if (!t->d_key) HIPCHK(hipMalloc((void **)&t->d_key, 6 * n * 2));
+        std::vector<int16_t> tab(6 * n);
+        const int16_t *src[3] = { s, e1, e2 };
+        for (int p = 0; p < 3; p++)
+            for (size_t m = 0; m < n; m++) { tab[2 * n * p + m] = src[p][m]; tab[2 * n * p + n + m] = (int16_t)-src[p][m]; }
+        HIPCHK(sc::copy_in(t->d_key, tab.data(), 6 * n * 2));
+        for (auto &v : tab) v = 0;
         t->have_priv = true;
     }
     if (t1) {
@@ -639,8 +701,8 @@ static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, 
             hipLaunchKernelGGL(ts_oracle_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, active, nslots, S, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                                t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P, rs);
             hipLaunchKernelGGL(ts_f_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, nslots, t->need, t->md, (size_t)64, 0u, 0, t->cidx, P, rs);
-            hipLaunchKernelGGL(ts_decide_kernel, dim3((nslots + 3) / 4), dim3(256), sizeof(int16_t) * 3 * (size_t)n, s, nslots, t->need, t->d_key, t->v1, t->v2, t->y, t->cidx, t->zs, t->acc, P, rs);
-            hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 3) / 4), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P, rs);
+            hipLaunchKernelGGL(ts_decide_kernel, dim3((nslots + 3) / 4), dim3(256), sizeof(int16_t) * 6 * (size_t)n, s, nslots, t->need, t->d_key, t->v1, t->v2, t->y, t->cidx, t->zs, t->acc, P, rs);
+            hipLaunchKernelGGL(ts_select_kernel, dim3((nact + 4 * SEL_PER - 1) / (4 * SEL_PER)), dim3(256), 0, s, active, nact, S, t->need, t->acc, st, t->zs, t->md, d_sigs, sig_stride, d_siglens, trials, next, t->cnt, P, rs);
             HIPCHK(hipGetLastError());
         }
         if (!left) {                                                          // the reference's round cap: no look follows, the closing work does
