@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void ts_decide_kernel(uint32_t nslots, const u
 // one wavefront per active message: the lowest accepted slot becomes the signature (z: q_bits-bit two's complement MSB first -
 // three bytes per coefficient for q_bits = 24 - then the digest, ring_tesla.c:882-900); a slot beyond the end of the tape before
 // any acceptance ends the message with status 2; otherwise the message goes to the next round S attempts further on.
-constexpr int SEL_PER = 8;                  // messages per wavefront of ts_select_kernel
+constexpr int SEL_PER = 4;                  // messages per wavefront of ts_select_kernel
 __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, uint32_t nact, uint32_t S, const uint32_t *need, const uint32_t *acc, St s, const int32_t *zs,
                                                         const uint8_t *md, uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials,
                                                         uint32_t *next_active, uint32_t *next_count, TsP P, const uint32_t *rs)
@@ -426,8 +426,9 @@ __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, 
     const int lane = threadIdx.x & 63, n = P.n;
     if (threadIdx.x == 0) go_cnt = 0;
     __syncthreads();
-    for (int turn = 0; turn < SEL_PER; turn++) {
-    const uint32_t aidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * SEL_PER + turn;
+    const int per = nact <= gridDim.x * 4u ? 1 : SEL_PER;               // a later round's few messages: one each (the grid was sized for the first round's)
+    for (int turn = 0; turn < per; turn++) {
+    const uint32_t aidx = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (uint32_t)per + turn;
     if (aidx >= nact) break;
     const uint32_t item = active ? active[aidx] : aidx;
     uint32_t win = S, dead = S;                                      // first accepted slot / first slot past the tape
