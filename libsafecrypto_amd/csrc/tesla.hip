@@ -503,25 +503,33 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const ui
     if (bad && lane == 0) verdict[item] = 1;
 }
 
-// w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products.  The two public polynomials sit in LDS
-// (8n bytes, filled once per workgroup, which then walks its share of the batch): every coefficient reads 2 omega of their entries at positions that
-// differ per signature, and fetched from global memory those reads - 300 load instructions per wavefront through the L1 - were the kernel (173 us of a
-// 330 us verification call at batch 16384).
-__global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *t1, const int32_t *t2, const int32_t *cidx, TsP P, sc::ModK mk)
+// w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products.  The two public polynomials sit in LDS as
+// SHIFT TABLES (sparse_shift above; built when the key is loaded, copied in 16-byte pieces): a term of a sparse product is one LDS read at an address the
+// lane's eight coefficients share up to a constant, and one addition.  Round 3 had the plain polynomials in LDS (they were fetched from global memory
+// before that: 173 us of a 330 us call) under persistent workgroups, seven vector instructions per term: 105 us per 16384 signatures, 42 % of a
+// verification call; round 4: a wavefront per signature, its two rows requested up front: 105 -> 33 us (ring-TESLA-I verification 66 -> 88-91 M/s at batch 16384).
+__global__ __launch_bounds__(256) void ts_vw_kernel(uint32_t batch, int32_t *w1, int32_t *w2, const int32_t *ttab, const int32_t *cidx, TsP P, sc::ModK mk)
 {
-    extern __shared__ int32_t tl[];                                   // t1 | t2
-    const int lane = threadIdx.x & 63, n = P.n;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { tl[i] = t1[i]; tl[n + i] = t2[i]; }
+    extern __shared__ __attribute__((aligned(16))) int32_t tl[];      // tables of t1 | t2: 2n entries each
+    const int lane = threadIdx.x & 63, n = P.n, C = n / 64;
+    for (int i = threadIdx.x; i < 4 * n / 4; i += blockDim.x) reinterpret_cast<uint4 *>(tl)[i] = reinterpret_cast<const uint4 *>(ttab)[i];
     __syncthreads();
-    for (uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6); item < batch; item += gridDim.x * 4) {
-        Pos pos; load_pos(pos, cidx + (size_t)item * P.omega, P.omega);
-        for (int j = lane; j < n; j += 64) {
-            const size_t k = (size_t)item * n + j;
-            // any int32 -> [0, q) by a Barrett step (modarith.h) instead of the division normalize_32 compiles to
-            w1[k] = (int32_t)sc::csub(sc::reduce_i32(w1[k] - sparse_reg(tl, pos, P.omega, n, j), mk), mk.q);
-            w2[k] = (int32_t)sc::csub(sc::reduce_i32(w2[k] - sparse_reg(tl + n, pos, P.omega, n, j), mk), mk.q);
-        }
+    const uint32_t item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (item >= batch) return;
+    const int pos = lane < P.omega ? cidx[(size_t)item * P.omega + lane] : 0;
+    int32_t r1[TS_MAXC], r2[TS_MAXC], sp[TS_MAXC];
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) {
+        const size_t k = (size_t)item * n + lane + 64 * (c < C ? c : 0);
+        r1[c] = w1[k]; r2[c] = w2[k];
     }
+    // any int32 -> [0, q) by a Barrett step (modarith.h) instead of the division normalize_32 compiles to
+    sparse_shift(sp, tl, pos, P.omega, n, lane);
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) if (c < C) w1[(size_t)item * n + lane + 64 * c] = (int32_t)sc::csub(sc::reduce_i32(r1[c] - sp[c], mk), mk.q);
+    sparse_shift(sp, tl + 2 * n, pos, P.omega, n, lane);
+#pragma unroll
+    for (int c = 0; c < TS_MAXC; c++) if (c < C) w2[(size_t)item * n + lane + 64 * c] = (int32_t)sc::csub(sc::reduce_i32(r2[c] - sp[c], mk), mk.q);
 }
 
 }  // namespace
@@ -532,6 +540,7 @@ struct sc_hip_tesla {
     TsP P;
     bool have_priv, have_pub;
     int32_t *d_a1, *d_a2, *d_t1, *d_t2;
+    int32_t *d_ttab = nullptr;           // t1 | t2 as the verifier's shift tables (t | -t, 2n entries each)
     int16_t *d_key;                      // s | e1 | e2, each as a shift table of 2n entries (t | -t)
     uint64_t *d_zstate; uint32_t zblocks;
     size_t cap, slot_cap;                // messages / slots (attempts evaluated side by side) the workspace holds
@@ -595,7 +604,7 @@ extern "C" void sc_hip_tesla_destroy(sc_hip_tesla_t *t)
     if (!t) return;
     ts_free_ws(t);
     if (t->h_pin) (void)hipHostFree(t->h_pin);
-    void *ptrs[] = { t->d_a1, t->d_a2, t->d_t1, t->d_t2, t->d_key, t->d_zstate };
+    void *ptrs[] = { t->d_a1, t->d_a2, t->d_t1, t->d_t2, t->d_key, t->d_zstate, t->d_ttab };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(t->plan);
     delete t;
@@ -631,6 +640,9 @@ extern "C" int sc_hip_tesla_set_key(sc_hip_tesla_t *t, const int32_t *a1, const 
     }
     if (t1) {
         if (ts_upload32(&t->d_t1, t1, n) || ts_upload32(&t->d_t2, t2, n)) return SC_HIP_FAILURE;
+        std::vector<int32_t> tt(4 * n);
+        for (size_t m = 0; m < n; m++) { tt[m] = t1[m]; tt[n + m] = -t1[m]; tt[2 * n + m] = t2[m]; tt[3 * n + m] = -t2[m]; }
+        if (ts_upload32(&t->d_ttab, tt.data(), 4 * n)) return SC_HIP_FAILURE;
         t->have_pub = true;
     }
     return SC_HIP_SUCCESS;
@@ -780,8 +792,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
     if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
     {
-        const uint32_t need = (B + 3) / 4, cap = (uint32_t)t->ctx->cus * 8;
-        hipLaunchKernelGGL(ts_vw_kernel, dim3(need < cap ? need : cap), dim3(256), sizeof(int32_t) * 2 * (size_t)P.n, s, B, t->v1, t->v2, t->d_t1, t->d_t2, t->cidx, P, t->plan->k[1]);
+        hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), sizeof(int32_t) * 4 * (size_t)P.n, s, B, t->v1, t->v2, t->d_ttab, t->cidx, P, t->plan->k[1]);
     }
     hipLaunchKernelGGL(ts_round_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, t->v1, t->v2, t->r1, t->r2, t->nz, 0, P);
     hipLaunchKernelGGL(ts_oracle_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, 1u, (const uint32_t *)nullptr, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,

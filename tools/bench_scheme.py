@@ -1,6 +1,6 @@
 """One scheme-level leg of bench.py, alone, for profiling: `python3 tools/bench_scheme.py <leg> [calls] [signature file]` runs one warm-up call and `calls`
 timed calls of
-   dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | ens_sign |
+   dil_sign | dil_verify | dil_sign_keys | dil_verify_keys | bliss_sign | bliss_verify | falcon_sign | falcon_verify | kyber_encaps | tesla_sign | tesla_verify | ens_sign |
    rlwe_encrypt | polymul | cdt | drbg
 on the configuration bench.py uses (BASELINE configs[1..4]) and prints one JSON line: calls made (warm-up included), batch, ms per call.
 A verify leg never signs in the profiled process: given a signature file that does not exist yet it signs, writes the file and stops (the unprofiled
@@ -105,13 +105,19 @@ def main():
         s_ntt, tk, t_ntt, rho, _ = ky.keygen(seeds)
         ky.encaps_keys(tk, t_ntt, rho, m); torch.cuda.synchronize(); made = 1
         fn = lambda: ky.encaps_keys(tk, t_ntt, rho, m)
-    elif leg == 'tesla_sign':
+    elif leg in ('tesla_sign', 'tesla_verify'):
         G = load_golden('tesla_ref.txt'); B = 16384
         ts = eng.tesla(G['tesla0_params']); ts.set_key(*(G[f'tesla0_{x}'] for x in ('a1', 'a2', 's', 'e1', 'e2', 't1', 't2')))
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         tapes = torch.randint(-2**31, 2**31 - 1, (B, 24 * 512), dtype=torch.int32, device='cuda', generator=g)
-        ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize(); made = 1
-        fn = lambda: ts.sign(msgs, tapes, fixed_len=64)
+        made = 1
+        if leg == 'tesla_sign':
+            ts.sign(msgs, tapes, fixed_len=64); torch.cuda.synchronize()
+            fn = lambda: ts.sign(msgs, tapes, fixed_len=64)
+        else:
+            sigs, siglens = sigs_from(lambda: ts.sign(msgs, tapes, fixed_len=64))
+            fn = lambda: ts.verify(msgs, sigs, siglens, fixed_len=64)
+            fn()
     elif leg == 'ens_sign':                               # ENS signature set 0: Klein's sampler (kleinr_kernel), as bench.py's ens_sig_0
         G = load_golden('ensdlp_ref.txt'); B = 16384
         par = np.asarray(G['enssig0_params']); n = int(par[0])
