@@ -275,37 +275,7 @@ __global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32
 
 __device__ __forceinline__ int32_t wave_or(int32_t v) { for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o); return v; }
 
-// mul_32_sparse[_16] on coefficient j (ntt.c:381-422): sum_k (j < pos_k ? t[j + n - pos_k] : -t[j - pos_k])
-template <typename T>
-__device__ __forceinline__ int32_t sparse_at(const T *t, const int32_t *c, int omega, int n, int j)
-{
-    int32_t acc = 0;
-    for (int k = 0; k < omega; k++) { const int p = c[k]; acc += (j < p) ? (int32_t)t[j + n - p] : -(int32_t)t[j - p]; }
-    return acc;
-}
-
-// the same with the positions already in registers (a wavefront reuses them for every coefficient of three polynomials): pos[k] for k < omega <= MAXW
-constexpr int MAXW = 32;
-struct Pos { int p[MAXW]; };
-__device__ __forceinline__ void load_pos(Pos &P_, const int32_t *c, int omega)
-{
-#pragma unroll
-    for (int k = 0; k < MAXW; k++) P_.p[k] = k < omega ? c[k] : 0;
-}
-template <typename T>
-__device__ __forceinline__ int32_t sparse_reg(const T *t, const Pos &P_, int omega, int n, int j)
-{
-    int32_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < MAXW; k++) {
-        if (k < omega) {                                               // wave-uniform
-            const int d = j - P_.p[k];
-            const int32_t v = (int32_t)t[d & (n - 1)];                  // d < 0: index d + n (n a power of two), sign +
-            acc += d < 0 ? v : -v;
-        }
-    }
-    return acc;
-}
+constexpr int MAXW = 32;                   // omega of a parameter set (sc_hip_tesla_create checks it)
 
 __device__ __forceinline__ int32_t norm_q(int32_t x, int32_t q) { int32_t r = x % q; return r < 0 ? r + q : r; }     // normalize_32
 // normalize_32 of a value known to lie in (-q, 2q): no division (x % q by a run-time q is some forty instructions)
@@ -323,7 +293,7 @@ __device__ __forceinline__ bool w_bad(int32_t val, const TsP &P)
 // The sparse products of the deciding kernel through a SHIFT TABLE (round 4): for a polynomial t, T[m] = t[m] (m < n), T[m] = -t[m - n] (n <= m < 2n), so that
 // the term of mul_32_sparse (ntt.c:381-422) for position p at coefficient j - +t[j + n - p] when j < p, -t[j - p] otherwise - is T[n + j - p]: one LDS read
 // at an address that is the same for the lane's n / 64 coefficients up to a constant, and one addition - no comparison, no select, no wrap-around mask
-// (the plain form, sparse_reg, spends seven vector instructions per term).  acc[c] = the sum over the omega positions for j = lane + 64 c.
+// (the plain form - a comparison, a select and a wrap-around mask per term, as round 3's kernels had it - spends seven vector instructions per term).  acc[c] = the sum over the omega positions for j = lane + 64 c.
 // my_pos: lane k holds position k (one vector load per slot, omega <= 64); the loop reads them with v_readlane - no memory access inside the chain of
 // additions.  (Measured, per 32768 slots: this form 92 us, positions fetched by scalar loads inside the loop 93 us, positions in a register array behind an
 // unrolled guarded loop over the 32 a parameter set may have - the plain form's way - 120 us.)
