@@ -558,46 +558,52 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
 
 // ---- verify -----------------------------------------------------------------------------------------------------------
 
-// unpack t (z1_bits, signed), z (z2_bits, signed), c_idx (n_bits): bliss_b.c:1641-1657.  Grid: x over the 2n + kappa fields of a signature, y over the
-// signatures - a field's width and bit offset are the same for every signature, and no thread divides a flat index by the runtime field count (as a
-// 64-bit division, with a byte load per BIT of the field, this kernel was 29 % of a verification call); four fields are cut out of the bytes they touch.
-__global__ void bl_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, int32_t *t, int16_t *z, int32_t *cidx,
-                                 uint32_t *verdict, BlissP P)
+// unpack t (z1_bits, signed), z (z2_bits, signed), c_idx (n_bits): bliss_b.c:1641-1657.  A workgroup per signature (walking the batch): the row is copied
+// into LDS in whole words - the bytes a field touches were fetched from global memory one load each, up to thirteen per thread, and the kappa index fields had a
+// workgroup of their own with 23 of 256 lanes at work: 47 us of a 254 us verification call at batch 16384 - and a thread cuts FOUR consecutive fields of t
+// or of z (one 16-byte / 8-byte store) or one index out of it.  A field's width and bit offset are the same for every signature.
+__global__ __launch_bounds__(256) void bl_unpack_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, int32_t *t, int16_t *z, int32_t *cidx,
+                                                        uint32_t *verdict, BlissP P)
 {
-    // a thread takes FOUR consecutive fields of t or of z (one 16-byte / 8-byte store; the signature's length is looked at once per four fields) or one index
+    extern __shared__ __attribute__((aligned(16))) uint8_t row[];      // the signature's bytes (+ 16 of slack behind them)
     const int n4 = P.n / 4, per = 2 * n4 + P.kappa;
-    const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (e >= per) return;
-    const uint32_t need_bits = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits);
-    const int sect = e < n4 ? 0 : e < 2 * n4 ? 1 : 2;
-    const int bits = sect == 0 ? P.z1_bits : sect == 1 ? P.z2_bits : P.n_bits, nf = sect == 2 ? 1 : 4;
-    const int f0 = sect == 0 ? 4 * e : sect == 1 ? 4 * (e - n4) : e - 2 * n4;                 // first field of this thread within its section
-    const uint32_t off = sect == 0 ? (uint32_t)f0 * bits : sect == 1 ? (uint32_t)(P.n * P.z1_bits + f0 * bits) : (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + f0 * bits);
-    const uint32_t first = off >> 3, last = (off + (uint32_t)(nf * bits) - 1) >> 3;              // 4 * bits + 7 <= 103 bits: up to 13 bytes
-    for (uint32_t item = blockIdx.y; item < count; item += gridDim.y) {
-        if (siglens[item] * 8 < need_bits) {
-            if (e == 0) verdict[item] = 1;
-            if (sect == 0) *reinterpret_cast<int4 *>(t + (size_t)item * P.n + f0) = make_int4(0, 0, 0, 0);
+    const uint32_t need_bits = (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits), need_bytes = (need_bits + 7) / 8;
+    for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+        if (siglens[item] * 8 < need_bits || need_bytes > sig_stride) {
+            if (threadIdx.x == 0) verdict[item] = 1;
+            for (int e = threadIdx.x; e < n4; e += blockDim.x) *reinterpret_cast<int4 *>(t + (size_t)item * P.n + 4 * e) = make_int4(0, 0, 0, 0);
             continue;
         }
         const uint8_t *s = sigs + (size_t)item * sig_stride;
-        // the window as two 64-bit halves, most significant byte first, left-aligned at the first field's first bit
-        uint64_t hi = 0, lo = 0;
-        for (uint32_t b = first; b <= last; b++) { const uint32_t k = b - first; if (k < 8) hi |= (uint64_t)s[b] << (56 - 8 * k); else lo |= (uint64_t)s[b] << (56 - 8 * (k - 8)); }
-        const uint32_t skew = off & 7;
-        if (skew) { hi = (hi << skew) | (lo >> (64 - skew)); lo <<= skew; }
-        int32_t val[4];
+        __syncthreads();                                               // (the previous signature's readers are done with the row)
+        if ((reinterpret_cast<uintptr_t>(s) & 3) == 0) for (uint32_t i = threadIdx.x; i < (need_bytes + 3) / 4 && 4 * i + 4 <= sig_stride; i += blockDim.x) reinterpret_cast<uint32_t *>(row)[i] = reinterpret_cast<const uint32_t *>(s)[i];
+        else for (uint32_t i = threadIdx.x; i < need_bytes; i += blockDim.x) row[i] = s[i];
+        if ((reinterpret_cast<uintptr_t>(s) & 3) == 0) for (uint32_t i = (uint32_t)(sig_stride / 4) * 4 + threadIdx.x; i < need_bytes; i += blockDim.x) row[i] = s[i];   // a row whose pitch is not a multiple of four: its last bytes
+        __syncthreads();
+        for (int e = threadIdx.x; e < per; e += blockDim.x) {
+            const int sect = e < n4 ? 0 : e < 2 * n4 ? 1 : 2;
+            const int bits = sect == 0 ? P.z1_bits : sect == 1 ? P.z2_bits : P.n_bits, nf = sect == 2 ? 1 : 4;
+            const int f0 = sect == 0 ? 4 * e : sect == 1 ? 4 * (e - n4) : e - 2 * n4;                 // first field of this thread within its section
+            const uint32_t off = sect == 0 ? (uint32_t)f0 * bits : sect == 1 ? (uint32_t)(P.n * P.z1_bits + f0 * bits) : (uint32_t)(P.n * (P.z1_bits + P.z2_bits) + f0 * bits);
+            const uint32_t first = off >> 3, last = (off + (uint32_t)(nf * bits) - 1) >> 3;              // 4 * bits + 7 <= 103 bits: up to 13 bytes
+            // the window as two 64-bit halves, most significant byte first, left-aligned at the first field's first bit
+            uint64_t hi = 0, lo = 0;
+            for (uint32_t b = first; b <= last; b++) { const uint32_t k = b - first; if (k < 8) hi |= (uint64_t)row[b] << (56 - 8 * k); else lo |= (uint64_t)row[b] << (56 - 8 * (k - 8)); }
+            const uint32_t skew = off & 7;
+            if (skew) { hi = (hi << skew) | (lo >> (64 - skew)); lo <<= skew; }
+            int32_t val[4];
 #pragma unroll
-        for (int f = 0; f < 4; f++) {
-            const uint32_t raw = (uint32_t)(hi >> (64 - bits));
-            val[f] = sect == 2 ? (int32_t)raw : ((int32_t)(raw << (32 - bits)) >> (32 - bits));
-            hi = (hi << bits) | (lo >> (64 - bits)); lo <<= bits;
+            for (int f = 0; f < 4; f++) {
+                const uint32_t raw = (uint32_t)(hi >> (64 - bits));
+                val[f] = sect == 2 ? (int32_t)raw : ((int32_t)(raw << (32 - bits)) >> (32 - bits));
+                hi = (hi << bits) | (lo >> (64 - bits)); lo <<= bits;
+            }
+            if (sect == 0) *reinterpret_cast<int4 *>(t + (size_t)item * P.n + f0) = make_int4(val[0], val[1], val[2], val[3]);
+            else if (sect == 1) {
+                const uint32_t w0 = ((uint32_t)val[0] & 0xFFFFu) | ((uint32_t)val[1] << 16), w1 = ((uint32_t)val[2] & 0xFFFFu) | ((uint32_t)val[3] << 16);
+                *reinterpret_cast<uint2 *>(z + (size_t)item * P.n + f0) = make_uint2(w0, w1);
+            } else cidx[(size_t)item * P.kappa + f0] = val[0];
         }
-        if (sect == 0) *reinterpret_cast<int4 *>(t + (size_t)item * P.n + f0) = make_int4(val[0], val[1], val[2], val[3]);
-        else if (sect == 1) {
-            const uint32_t w0 = ((uint32_t)val[0] & 0xFFFFu) | ((uint32_t)val[1] << 16), w1 = ((uint32_t)val[2] & 0xFFFFu) | ((uint32_t)val[3] << 16);
-            *reinterpret_cast<uint2 *>(z + (size_t)item * P.n + f0) = make_uint2(w0, w1);
-        } else cidx[(size_t)item * P.kappa + f0] = val[0];
     }
 }
 
@@ -660,8 +666,10 @@ __global__ __launch_bounds__(256) void bl_vfix_kernel(const int32_t *v, const in
     for (int t = 0; t < NT; t++) { const int32_t a = vi[lane + 64 * t]; x[t] = a + (a & 1) * P.q; }
     const int32_t two_q = 2 * P.q;
     const int64_t mu = (1 << 30) / two_q;
+    // the kappa <= 64 positions in one vector register, read with v_readlane: a load per step inside the loop was a chain of kappa dependent round trips
+    const int my_pos = lane < P.kappa ? cidx[(size_t)item * P.kappa + lane] : 0;
     for (int k = 0; k < P.kappa; k++) {
-        const int pos = cidx[(size_t)item * P.kappa + k] & (P.n - 1);  // (a signature too short to hold its indices leaves them unset)
+        const int pos = __builtin_amdgcn_readlane(my_pos, k) & (P.n - 1);  // (a signature too short to hold its indices leaves them unset)
         if (lane == (pos & 63)) {
             const int t0 = pos >> 6;
             int32_t sel = x[0];
@@ -1720,7 +1728,7 @@ static int bl_verify_core(sc_hip_bliss_t *b, const int16_t *ka16, size_t batch, 
         while (lpw > 1 && (size_t)(B + lpw - 1) / lpw < (size_t)b->ctx->cus * 8) lpw >>= 1;
         hipLaunchKernelGGL(bl_huff_unpack_kernel, dim3((B + lpw - 1) / lpw), dim3(64), 0, s, d_sigs, sig_stride, d_siglens, B, lpw, b->tin, b->z, b->cidx, d_verdicts, P, b->ht[0], b->ht[1]);
     }
-    else hipLaunchKernelGGL(bl_unpack_kernel, dim3((unsigned)((P.n / 2 + P.kappa + 255) / 256), B < 65535u ? B : 65535u), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
+    else hipLaunchKernelGGL(bl_unpack_kernel, dim3(B), dim3(256), (size_t)((P.n * (P.z1_bits + P.z2_bits) + P.kappa * P.n_bits + 7) / 8 + 16 + 3) & ~(size_t)3, s, d_sigs, sig_stride, d_siglens, B, b->tin, b->z, b->cidx, d_verdicts, P);
     hipLaunchKernelGGL(bl_vnorm_kernel, dim3((B + 3) / 4), dim3(256), 0, s, b->tin, b->z, B, d_verdicts, P);
     HIPCHK(hipGetLastError());
     if (ka16) {
