@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         const int j = lane + 64 * c;
         tr[c] = c < C ? t[j] : 0; ur[c] = c < C ? u[j] : 0;
     }
+    const int pos_v = lane < P.kappa ? cidx[(size_t)aidx * P.kappa + lane] : 0;      // the challenge's positions, lane k holds position k (kappa <= 64): read with v_readlane wherever a step needs one
     if (acorr) {
         // greedy_sc (bliss_b.c:622-679) under ONE key, without its kappa dependent sweeps over x and y.  x = sum_k s_k x^{i_k} f and y likewise with g (x^i: the
         // negacyclic shift the two inner loops of a step apply); multiplication by x^i preserves inner products, so the quantity step k tests is
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
             fg2[j] = ((uint32_t)(-fv) & 0xFFFFu) | ((uint32_t)(-gv) << 16);
         }
         const int kap = P.kappa;
-        const int my_i = lane < kap ? cidx[(size_t)aidx * kap + lane] : 0;
+        const int my_i = pos_v;
         int32_t m[KMAX];                                                  // m[k'] = A[|i_lane - i_k'|]: independent look-ups, all requested before the chain below
 #pragma unroll
         for (int kp = 0; kp < KMAX; kp++) {
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         }
         if (lane == 0) {
             BitW bw{ out, (uint32_t)(n * 15 / 8), 0, 0 };
-            for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);
+            for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)__builtin_amdgcn_readlane(pos_v, k), P.n_bits);      // (no load per index: the lane that packs them had kappa round trips in a row here)
             bw.flush();
             siglens[item] = bw.nbytes;
         }
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(256) void bl_decide_kernel(const uint32_t *active, 
         BitW bw{ out, 0, 0, 0 };
         for (int j = 0; j < n; j++) bw.put((uint32_t)x[j], P.z1_bits);
         for (int j = 0; j < n; j++) bw.put((uint32_t)y[j], P.z2_bits);
-        for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);
+        for (int k = 0; k < P.kappa; k++) bw.put((uint32_t)__builtin_amdgcn_readlane(pos_v, k), P.n_bits);
         bw.flush();
         siglens[item] = bw.nbytes;
     }
