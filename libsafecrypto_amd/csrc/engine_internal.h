@@ -351,6 +351,8 @@ int drbg_fill(sc_hip_ctx *ctx, const uint8_t *d_seeds, size_t seed_stride, size_
 namespace sc {
 // batch_dev != null: the number of rows where only the device knows it (batch is then the host's bound; rows past the count are not touched)
 int polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream, const uint32_t *batch_dev = nullptr);
+int polymul_ntt_bcast2(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_b1hat, const int32_t *d_b2hat, int32_t *d_out1, int32_t *d_out2, void *stream,
+                       const uint32_t *batch_dev = nullptr);      // two broadcast operands, two outputs, one forward transform
 }
 
 struct sc_hip_cdt {

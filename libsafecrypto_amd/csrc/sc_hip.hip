@@ -19,11 +19,13 @@ using namespace sc;
 // kernels
 // ------------------------------------------------------------------------------------------
 
-enum { OP_FWD = 0, OP_INV = 1, OP_MULNTT = 2, OP_MUL = 3 };
+enum { OP_FWD = 0, OP_INV = 1, OP_MULNTT = 2, OP_MUL = 3, OP_MULNTT2 = 4 };      // OP_MULNTT2: two NTT-domain operands for the whole batch, two outputs, ONE forward transform (ring-TESLA's v1 = a1 y, v2 = a2 y)
 
 struct NttArgs {
     const int32_t *in0;
     const int32_t *in1;
+    const int32_t *in2;           // OP_MULNTT2: the second NTT-domain operand (both are broadcast) ...
+    int32_t *out2;                // ... and where its product goes
     int32_t *out;
     int32_t *sink;                // 4 KB nobody reads: where the lanes of a ragged last group that lie past the batch store (plain form)
     const uint32_t *zf, *zfp;     // forward twiddles zeta[k] = g^bitrev(k) and Shoup companions
@@ -115,13 +117,13 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
     // out: registers -> memory.  NTT = the NTT-domain order (forward output), else coefficient order.  Stores are unguarded: one guarded store is an exec-mask
     // save, a branch and a restore, and sixteen of them split the store burst into sixteen islands (the forward kernel ran 456 us against 382 us over 2 GiB
     // with them) - the lanes of a ragged last group that lie past the batch store into a 4 KB sink instead
-    auto store_out = [&](uint32_t (&x)[16], size_t base, bool valid, auto ntt_order) {
+    auto store_out = [&](uint32_t (&x)[16], size_t base, bool valid, auto ntt_order, int32_t *outp) {
         constexpr bool NTT = decltype(ntt_order)::value;
         if constexpr (STREAM) {
 #pragma unroll
             for (int r = 0; r < 16; r++) lds_wave[NTT ? img_ntt(r) : img_coef(r)] = x[r];
             wave_lds_fence();
-            v4i *dst = reinterpret_cast<v4i *>(a.out + (base - (size_t)pw * N)) + lane;
+            v4i *dst = reinterpret_cast<v4i *>(outp + (base - (size_t)pw * N)) + lane;
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const int cw = (c * 256) / N * NP + (c * 256) % N;                // word c * 256 of the group, in the padded image
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
             }
             wave_lds_fence();
         } else {
-            int32_t *dst = (valid ? a.out + base : a.sink + pw * N) + (NTT ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
+            int32_t *dst = (valid ? outp + base : a.sink + pw * N) + (NTT ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
             for (int r = 0; r < 16; r++) dst[(NTT ? brv4(r) : r) * LP] = (int32_t)x[r];
         }
@@ -156,11 +158,12 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
 
         // second operand of this group: requested now, consumed after the forward transform
         int32_t nb[16];
-        if (OP == OP_MULNTT || OP == OP_MUL) {
-            const int32_t *srcb = a.in1 + ((a.in1_bcast || !valid) ? 0 : base) + ((OP == OP_MULNTT) ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
+        constexpr bool PW_NTT = OP == OP_MULNTT || OP == OP_MULNTT2;      // the second operand is already in the NTT domain
+        if (PW_NTT || OP == OP_MUL) {
+            const int32_t *srcb = a.in1 + ((a.in1_bcast || !valid) ? 0 : base) + (PW_NTT ? Io<L, OP>::off_ntt(0, blp) : Io<L, OP>::off_coef(0, lp));
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int32_t *q = srcb + (OP == OP_MULNTT ? brv4(r) : r) * LP;
+                const int32_t *q = srcb + (PW_NTT ? brv4(r) : r) * LP;
                 nb[r] = STREAM ? __builtin_nontemporal_load(q) : *q;
             }
         }
@@ -184,10 +187,41 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
                 }
                 x[r] = v;
             }
-            store_out(x, base, valid, std::true_type{});
+            store_out(x, base, valid, std::true_type{}, a.out);
             continue;
         }
 
+        if (OP == OP_MULNTT2) {
+            // NTT(y) is kept: first product -> inverse -> out, second product (its operand requested before the first inverse) -> inverse -> out2
+            uint32_t f[16];
+            int32_t nb2[16];
+            const int32_t *src2 = a.in2 + Io<L, OP>::off_ntt(0, blp);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                f[r] = (MODE == MODE_SMAD && L > 8) ? reduce_signed((int32_t)x[r], k) : x[r];
+                nb2[r] = src2[brv4(r) * LP];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(f[r], reduce_signed(nb[r], k), k);
+                else if (MODE == MODE_S32) x[r] = montmul_s32(f[r], reduce_s32(nb[r], k), k);
+                else if (MODE == MODE_MAD) x[r] = mulmod_small(f[r], csub(reduce_i32_small(nb[r], k), k.q), k);
+                else x[r] = montmul(f[r], reduce_i32(nb[r], k), k);
+            }
+            inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+            store_out(x, base, valid, std::false_type{}, a.out);
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                if (MODE == MODE_SMAD) x[r] = mulmod_ssmall(f[r], reduce_signed(nb2[r], k), k);
+                else if (MODE == MODE_S32) x[r] = montmul_s32(f[r], reduce_s32(nb2[r], k), k);
+                else if (MODE == MODE_MAD) x[r] = mulmod_small(f[r], csub(reduce_i32_small(nb2[r], k), k.q), k);
+                else x[r] = montmul(f[r], reduce_i32(nb2[r], k), k);
+            }
+            request_in0(g + gstride);
+            inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
+            store_out(x, base, valid, std::false_type{}, a.out2);
+            continue;
+        }
         if (OP == OP_MULNTT) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -214,7 +248,7 @@ __global__ __launch_bounds__(256) void ntt_kernel(NttArgs a)
         }
 
         inv_core<L, MODE>(x, twi, lds_poly, lp, k, a.c0, a.c0p, a.c1, a.c1p);
-        store_out(x, base, valid, std::false_type{});
+        store_out(x, base, valid, std::false_type{}, a.out);
     }
 }
 
@@ -585,9 +619,15 @@ template <int L, int OP>
 static hipError_t launch_ntt_l(const NttArgs &a, int mode, bool lazy, int blocks, hipStream_t s, bool stream_io)
 {
     // the streaming I/O form exists for the two signed modes (every modulus of the reference's parameter sets runs on one of them)
+    if constexpr (OP == OP_MULNTT2) {                                  // no streaming form: its two operands are broadcast and its callers' batches are cache-sized
+        if (mode == MODE_SMAD) return launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
+        if (mode == MODE_S32) return launch_ntt_t<L, MODE_S32, true, OP>(a, blocks, s);
+    } else {
     if (mode == MODE_SMAD) return stream_io ? launch_ntt_t<L, MODE_SMAD, true, OP, true>(a, blocks, s) : launch_ntt_t<L, MODE_SMAD, true, OP>(a, blocks, s);
     if (mode == MODE_S32) return stream_io ? launch_ntt_t<L, MODE_S32, true, OP, true>(a, blocks, s) : launch_ntt_t<L, MODE_S32, true, OP>(a, blocks, s);
-    if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
+    }
+    if constexpr (OP == OP_MULNTT2) return hipErrorInvalidValue;      // (signed modes only: sc::polymul_ntt_bcast2 falls back before it gets here)
+    else if constexpr (OP == OP_INV) {       // the inverse has no lazy variant: one instantiation per mode
         if (mode == MODE_MAD) return launch_ntt_t<L, MODE_MAD, false, OP>(a, blocks, s);
         return mode == MODE_U24 ? launch_ntt_t<L, MODE_U24, false, OP>(a, blocks, s) : launch_ntt_t<L, MODE_U32, false, OP>(a, blocks, s);
     } else {
@@ -663,6 +703,34 @@ extern "C" int sc_hip_ntt_inv(sc_hip_plan_t *p, size_t batch, const int32_t *d_i
 { return run_ntt(p, OP_INV, batch, d_in, nullptr, d_out, stream); }
 extern "C" int sc_hip_polymul_ntt(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream)
 { return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream); }
+// internal: out1[b] = INTT(NTT(a[b]) o b1hat), out2[b] = INTT(NTT(a[b]) o b2hat) with ONE forward transform (ring-TESLA: v1 = a1 y, v2 = a2 y, ring_tesla.c:842-850,
+// 1005-1012): a sixth of the two products' transforms and one of their two reads of a.  The signed modes only (every reference modulus runs on one of them);
+// any other plan takes the two single products.
+int sc::polymul_ntt_bcast2(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_b1hat, const int32_t *d_b2hat, int32_t *d_out1, int32_t *d_out2, void *stream,
+                           const uint32_t *batch_dev)
+{
+    if (!p) return fail("ntt: null plan");
+    if (p->mode != MODE_SMAD && p->mode != MODE_S32) {
+        if (sc::polymul_ntt_bcast(p, batch, d_a, d_b1hat, d_out1, stream, batch_dev)) return SC_HIP_FAILURE;
+        return sc::polymul_ntt_bcast(p, batch, d_a, d_b2hat, d_out2, stream, batch_dev);
+    }
+    if (batch == 0) return SC_HIP_SUCCESS;
+    if (!d_a || !d_b1hat || !d_b2hat || !d_out1 || !d_out2) return fail("ntt: null device pointer");
+    HIPCHK(hipSetDevice(p->ctx->device));
+    const int n = p->n;
+    NttArgs a;
+    a.in0 = d_a; a.in1 = d_b1hat; a.in2 = d_b2hat; a.out = d_out1; a.out2 = d_out2; a.sink = p->d_sink; a.in1_bcast = 1u; a.batch_dev = batch_dev;
+    a.zf = p->d_tab_s; a.zfp = a.zf + n; a.zi = a.zf + 2 * n; a.zip = a.zf + 3 * n;
+    a.batch = batch; a.k = p->k[1];
+    const uint32_t *c = p->mode == MODE_SMAD ? (p->q < 8192 ? p->c_inv[1] : p->c_inv_s) : p->c_mont_s;      // as run_ntt for OP_MULNTT
+    a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
+    const int pw = 1024 / n;
+    size_t blocks = ((batch + pw - 1) / pw + 3) / 4;
+    if (blocks > (size_t)1 << 30) blocks = (size_t)1 << 30;
+    const hipError_t e = launch_ntt_op<OP_MULNTT2>(p->L, a, p->mode, true, (int)blocks, (hipStream_t)stream, false);
+    if (e != hipSuccess) return fail(std::string("ntt kernel launch: ") + hipGetErrorString(e));
+    return SC_HIP_SUCCESS;
+}
 // internal: out[b] = INTT(NTT(a[b]) o bhat) with ONE NTT-domain operand for the whole batch (bliss_b.c:1378-1384: bhat = public key a)
 int sc::polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream, const uint32_t *batch_dev)
 { return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream, true, false, batch_dev); }

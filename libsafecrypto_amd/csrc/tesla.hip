@@ -678,8 +678,7 @@ static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, 
             else hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs);
             HIPCHK(hipGetLastError());
             // (a planned round's products run over the whole slot budget: rows past the round's slots hold what an earlier round left there and are read by nobody)
-            if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
-            if (sc::polymul_ntt_bcast(t->plan, nslots, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+            if (sc::polymul_ntt_bcast2(t->plan, nslots, t->y, t->d_a1, t->d_a2, t->v1, t->v2, s)) return SC_HIP_FAILURE;      // v1 = a1 y, v2 = a2 y: one forward transform of y for both
             hipLaunchKernelGGL(ts_round_kernel, dim3((nslots + 3) / 4), dim3(256), 0, s, nslots, t->v1, t->v2, t->r1, t->r2, t->nz, 1, P, rs);
             hipLaunchKernelGGL(ts_oracle_kernel, dim3((nslots + HT - 1) / HT), dim3(HT), 0, s, active, nslots, S, t->need, d_msgs, msg_stride, d_mlens, fixed_len, t->r1, t->r2, t->nz,
                                t->d_zstate, t->zblocks, t->md, 0, (uint32_t *)nullptr, (const uint8_t *)nullptr, (size_t)0, 0u, P, rs);
@@ -759,8 +758,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     hipLaunchKernelGGL(ts_unpack_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, t->y, d_verdicts, P);
     hipLaunchKernelGGL(ts_f_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_sigs, sig_stride, md_off, 1, t->cidx, P);
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a1, t->v1, s)) return SC_HIP_FAILURE;
-    if (sc::polymul_ntt_bcast(t->plan, batch, t->y, t->d_a2, t->v2, s)) return SC_HIP_FAILURE;
+    if (sc::polymul_ntt_bcast2(t->plan, batch, t->y, t->d_a1, t->d_a2, t->v1, t->v2, s)) return SC_HIP_FAILURE;
     {
         hipLaunchKernelGGL(ts_vw_kernel, dim3((B + 3) / 4), dim3(256), sizeof(int32_t) * 4 * (size_t)P.n, s, B, t->v1, t->v2, t->d_ttab, t->cidx, P, t->plan->k[1]);
     }
