@@ -2306,28 +2306,6 @@ static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key
     return SC_HIP_SUCCESS;
 }
 
-// The verifiers' two independent halves - the hash of the message to the ring (a chain of 25 dependent permutations on a fraction of the SIMDs) and the
-// signature's unpacking + product with the public key (the transform kernels) - run beside each other: the second on the handle's side stream, forked
-// from and joined back into the caller's stream with events inside the call (round 4: Falcon-1024 verification 0.28 -> 0.26 ms per 8192 signatures, 29 -> 31 M/s;
-// the fork and the join themselves cost ~20 us of the ~45 us they hide - the same step lost for Dilithium's verifier, dilithium.hip).
-static int fal_fork_side(sc_hip_falcon *f, hipStream_t s)
-{
-    if (!f->side) {
-        HIPCHK(hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming));
-    }
-    HIPCHK(hipEventRecord(f->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(f->side, f->ev_fork, 0));
-    return SC_HIP_SUCCESS;
-}
-static int fal_join_side(sc_hip_falcon *f, hipStream_t s)
-{
-    HIPCHK(hipEventRecord(f->ev_join, f->side));
-    HIPCHK(hipStreamWaitEvent(s, f->ev_join, 0));
-    return SC_HIP_SUCCESS;
-}
-
 static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key_of, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens, uint32_t fixed_len,
                            const uint8_t *d_sigs, size_t sig_stride, const uint32_t *d_siglens, uint32_t *d_verdicts, void *stream);
 
@@ -2371,19 +2349,16 @@ static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_k
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    if (fal_fork_side(f, s)) return SC_HIP_FAILURE;
-    hipStream_t sp = f->side;                                          // unpacking and product; the hash stays on the caller's stream
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, sp, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (d_key_of) {                                                    // the public keys of the batch, gathered into the (otherwise idle) sampler workspace
         int32_t *rows = reinterpret_cast<int32_t *>(f->ws);
-        hipLaunchKernelGGL(fal_gather_keys_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, sp, B, d_key_of, (uint32_t)f->npk, f->d_hhat, rows, f->P.n, d_verdicts);
+        hipLaunchKernelGGL(fal_gather_keys_kernel, dim3((unsigned)((ne / 4 + 255) / 256)), dim3(256), 0, s, B, d_key_of, (uint32_t)f->npk, f->d_hhat, rows, f->P.n, d_verdicts);
         HIPCHK(hipGetLastError());
-        if (sc_hip_polymul_ntt(f->plan, batch, f->s2, rows, f->s1, sp)) { (void)fal_join_side(f, s); return SC_HIP_FAILURE; }
-    } else if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, sp)) { (void)fal_join_side(f, s); return SC_HIP_FAILURE; }
-    if (fal_join_side(f, s)) return SC_HIP_FAILURE;
+        if (sc_hip_polymul_ntt(f->plan, batch, f->s2, rows, f->s1, s)) return SC_HIP_FAILURE;
+    } else if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
@@ -2439,14 +2414,11 @@ extern "C" int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *f, size_t batch, const
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    if (fal_fork_side(f, s)) return SC_HIP_FAILURE;
-    hipStream_t sp = f->side;                                          // as fal_verify_core: the hash beside the unpacking and the product
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, sp, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits, 0);
+    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits, 0);
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
     HIPCHK(hipGetLastError());
-    if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, sp)) { (void)fal_join_side(f, s); return SC_HIP_FAILURE; }          // the signature's s1 sits in the s2 buffer: the roles are swapped
-    if (fal_join_side(f, s)) return SC_HIP_FAILURE;
+    if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;          // the signature's s1 sits in the s2 buffer: the roles are swapped
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
