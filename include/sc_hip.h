@@ -97,6 +97,10 @@ int sc_hip_pointwise(sc_hip_plan_t *plan, size_t len, const int32_t *d_a, const 
  * module_lwe.c:1357-1370): out = INTT(NTT(a) o bhat), bhat given in the NTT domain in the
  * reference's natural order (e.g. a stored public key).  BASELINE.json config 2. */
 int sc_hip_polymul_ntt(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream);
+/* the same for TWO stored NTT-domain polynomials and one batch of inputs (ring-TESLA's v1 = a1 y, v2 = a2 y: ring_tesla.c:842-850 / 1005-1012 call
+ * fwd_ntt once and mul_32_pointwise + inv_ntt twice): out1[i] = INTT(NTT(a[i]) o b1hat), out2[i] = INTT(NTT(a[i]) o b2hat), ONE forward transform per
+ * input.  b1hat, b2hat: n words each, used for every input (broadcast). */
+int sc_hip_polymul_ntt_pair(sc_hip_plan_t *plan, size_t batch, const int32_t *d_a, const int32_t *d_b1hat, const int32_t *d_b2hat, int32_t *d_out1, int32_t *d_out2, void *stream);
 
 /* fused product of two coefficient-domain polynomials: out = a*b mod (x^n+1, q), canonical
  * (fwd, fwd, mul_32_pointwise, inv: ring_tesla.c:752-910 pattern). */

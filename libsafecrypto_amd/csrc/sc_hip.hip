@@ -731,6 +731,8 @@ int sc::polymul_ntt_bcast2(sc_hip_plan *p, size_t batch, const int32_t *d_a, con
     if (e != hipSuccess) return fail(std::string("ntt kernel launch: ") + hipGetErrorString(e));
     return SC_HIP_SUCCESS;
 }
+extern "C" int sc_hip_polymul_ntt_pair(sc_hip_plan_t *p, size_t batch, const int32_t *d_a, const int32_t *d_b1hat, const int32_t *d_b2hat, int32_t *d_out1, int32_t *d_out2, void *stream)
+{ return sc::polymul_ntt_bcast2(p, batch, d_a, d_b1hat, d_b2hat, d_out1, d_out2, stream); }
 // internal: out[b] = INTT(NTT(a[b]) o bhat) with ONE NTT-domain operand for the whole batch (bliss_b.c:1378-1384: bhat = public key a)
 int sc::polymul_ntt_bcast(sc_hip_plan *p, size_t batch, const int32_t *d_a, const int32_t *d_bhat, int32_t *d_out, void *stream, const uint32_t *batch_dev)
 { return run_ntt(p, OP_MULNTT, batch, d_a, d_bhat, d_out, stream, true, false, batch_dev); }

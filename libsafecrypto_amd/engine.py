@@ -11,7 +11,7 @@ SYMBOLS = [
     'sc_hip_ctx_create', 'sc_hip_ctx_destroy', 'sc_hip_last_error', 'sc_hip_device_count', 'sc_hip_synchronize',
     'sc_hip_plan_create', 'sc_hip_plan_destroy', 'sc_hip_plan_q', 'sc_hip_plan_n', 'sc_hip_plan_root',
     'sc_hip_plan_tables', 'sc_hip_plan_set_arith',
-    'sc_hip_ntt_fwd', 'sc_hip_ntt_inv', 'sc_hip_pointwise', 'sc_hip_polymul_ntt', 'sc_hip_polymul',
+    'sc_hip_ntt_fwd', 'sc_hip_ntt_inv', 'sc_hip_pointwise', 'sc_hip_polymul_ntt', 'sc_hip_polymul_ntt_pair', 'sc_hip_polymul',
     'sc_hip_normalize', 'sc_hip_center', 'sc_hip_poly_add', 'sc_hip_poly_sub', 'sc_hip_matvec',
     'sc_hip_cdt_create', 'sc_hip_cdt_table_size', 'sc_hip_cdt_build_table', 'sc_hip_cdt_build_table_blinding', 'sc_hip_cdt_create_from_table',
     'sc_hip_cdt_destroy', 'sc_hip_cdt_size', 'sc_hip_cdt_table', 'sc_hip_cdt_sample',
@@ -110,6 +110,7 @@ def load_library(path=LIB_PATH):
         getattr(L, name).argtypes = [vp, sz, vp, vp, vp]
     for name in ('sc_hip_polymul_ntt', 'sc_hip_polymul', 'sc_hip_pointwise'):
         getattr(L, name).argtypes = [vp, sz, vp, vp, vp, vp]
+    L.sc_hip_polymul_ntt_pair.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp]
     for name in ('sc_hip_normalize', 'sc_hip_center'):
         getattr(L, name).argtypes = [vp, sz, vp, vp, vp]
     for name in ('sc_hip_poly_add', 'sc_hip_poly_sub'):
@@ -761,6 +762,13 @@ class NttPlan:
         out = self._out(a, out)
         _chk(self.L, self.L.sc_hip_polymul_ntt(self.h, self._batch(a), _ptr(a), _ptr(bhat), _ptr(out), _stream()), 'polymul_ntt')
         return out
+
+    def polymul_ntt_pair(self, a, b1hat, b2hat):
+        """(INTT(NTT(a) o b1hat), INTT(NTT(a) o b2hat)) for two stored NTT-domain polynomials (n words each), one forward transform per input"""
+        import torch
+        o1, o2 = torch.empty_like(a), torch.empty_like(a)
+        _chk(self.L, self.L.sc_hip_polymul_ntt_pair(self.h, self._batch(a), _ptr(a), _ptr(b1hat), _ptr(b2hat), _ptr(o1), _ptr(o2), _stream()), 'polymul_ntt_pair')
+        return o1, o2
 
     def polymul_ntt_steps(self, a, bhat, out, steps):
         """`steps` fused products on the same buffers as one HIP graph launch on torch's current (non-default) stream"""
