@@ -639,7 +639,11 @@ static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, 
     if (sig_stride < sc_hip_tesla_sig_bytes(t)) return fail("tesla_sign: sig_stride smaller than sc_hip_tesla_sig_bytes()");
     if (tape_stride > 0xffffffffu) return fail("tesla_sign: tape too long");
     HIPCHK(hipSetDevice(t->ctx->device));
-    size_t slot_target = batch * 2;                                    // two attempts per message while the whole batch is active
+    // Attempts evaluated side by side per round: two per message while that is at most 16 K slots, one per message beyond.  Measured (tools/bench_seeded.py,
+    // ms per call tape-resident / seeded, one against two attempts per message): batch 4096 0.59 / 0.67 against 0.41 / 0.50; 8192 0.62 / 0.76 against 0.59 / 0.72;
+    // 16384 0.89 / 1.20 against 0.89 / 1.27; 65536 2.47 / 3.13 against 3.00 / 4.24 - a round's kernels are throughput-bound from ~16 K slots up, and every
+    // speculative attempt costs its 2 KB of mask (in a seeded call: of cipher output) whether it is needed or not.
+    size_t slot_target = batch * 2 < 16384 ? batch * 2 : (batch > 16384 ? batch : 16384);
     if (slot_target < 4096) slot_target = 4096;
     if (ts_ensure_ws(t, batch, slot_target)) return SC_HIP_FAILURE;
     hipStream_t s = (hipStream_t)stream;
