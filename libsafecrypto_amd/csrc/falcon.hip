@@ -2742,27 +2742,31 @@ __global__ __launch_bounds__(HT) void rec_target_kernel(uint32_t batch, const ui
     m2lens[b] = l2;
 }
 
-// One wavefront per signature: unpack s1 | s2, norm, t = s1 h + s2 (schoolbook, 32-bit words that wrap: small_mul_mod_ring :892-912), m1 = t1 - F(t2),
-// the message rebuilt in the output row, H'(m) against t2.
-__global__ __launch_bounds__(64) void rec_verify_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens,
-                                                       const uint8_t *__restrict__ m2, size_t m2_stride, const uint32_t *__restrict__ m2lens, const int32_t *__restrict__ hraw,
-                                                       uint8_t *__restrict__ out, size_t out_stride, uint32_t *__restrict__ outlens, uint32_t *__restrict__ verdicts, RecP P, float bd)
+// The verifier in four kernels: the two sponges (F over t2, H' over the rebuilt message: seven and six permutations at n = 512) are lane-per-signature
+// kernels; run by one lane of a wavefront that also does the wide work they were 98 % of its instructions on 1 / 64 of its lanes (2.8 ms per 16384 ENS
+// signatures; the wide work - unpacking, norm, the wrapping schoolbook product - is a tenth of that).  verdicts[] is zeroed by the caller; a stage that refuses a
+// signature sets 1 and the later stages pass it by.
+//
+// (1) a wavefront per signature: unpack s1 | s2, the norm, t = s1 h + s2 (schoolbook, 32-bit words that wrap: small_mul_mod_ring :892-912), normalised -> tbuf
+__global__ __launch_bounds__(64) void rec_v1_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens,
+                                                   size_t m2_stride, const uint32_t *__restrict__ m2lens, const int32_t *__restrict__ hraw, size_t out_stride,
+                                                   int32_t *__restrict__ tbuf, uint32_t *__restrict__ verdicts, RecP P, float bd)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t rv_lds[];          // s1 | s2 | t | h (n words each), then the sponge state
+    extern __shared__ __attribute__((aligned(16))) int32_t rv_lds[];          // s1 | s2 | t | h (n words each)
     const int lane = threadIdx.x, n = P.n;
     const uint32_t b = blockIdx.x;
     int32_t *s1 = rv_lds, *s2 = s1 + n, *t = s2 + n, *hh = t + n;
-    uint64_t *st = reinterpret_cast<uint64_t *>(hh + n);
     const uint32_t l2 = m2lens ? m2lens[b] : 0u, siglen = siglens[b];
-    uint8_t *ob = out + (size_t)b * out_stride;
-    const uint32_t sh = P.m1_bits & 7u, base = P.m1_bits >> 3;
+    const uint32_t base = P.m1_bits >> 3;
     const uint32_t olen = l2 ? base + l2 : P.m1_bytes;                         // (m1_bits + 8 l2) >> 3 (:1757)
-    auto refuse = [&]() { if (lane == 0) { verdicts[b] = 1; outlens[b] = 0; } };
-    if ((size_t)siglen * 8 < (size_t)2 * n * P.q_bits || siglen > sig_stride || (size_t)l2 > m2_stride || (size_t)olen > out_stride) { refuse(); return; }
+    if ((size_t)siglen * 8 < (size_t)2 * n * P.q_bits || siglen > sig_stride || (size_t)l2 > m2_stride || (size_t)olen > out_stride) { if (lane == 0) verdicts[b] = 1; return; }
     const uint8_t *sg = sigs + (size_t)b * sig_stride;
-    for (int i = lane; i < 2 * n; i += 64) {
-        uint32_t val = 0;
-        for (int k = 0; k < P.q_bits; k++) { const uint32_t bp = (uint32_t)i * P.q_bits + k; val = (val << 1) | ((sg[bp >> 3] >> (7 - (bp & 7))) & 1u); }
+    for (int i = lane; i < 2 * n; i += 64) {                                   // a field (q_bits <= 16) and its skew fit the four bytes from its first one
+        const uint32_t bp = (uint32_t)i * P.q_bits, b0 = bp >> 3;
+        uint32_t w = 0;
+        if ((size_t)b0 + 4 <= sig_stride) { __builtin_memcpy(&w, sg + b0, 4); w = __builtin_bswap32(w); }
+        else for (uint32_t k = 0; k < 4; k++) w |= (b0 + k < siglen ? (uint32_t)sg[b0 + k] : 0u) << (24 - 8 * k);      // the row's last bytes
+        const uint32_t val = (w >> (32 - (bp & 7) - P.q_bits)) & ((1u << P.q_bits) - 1u);
         s1[i] = (int32_t)(val << (32 - P.q_bits)) >> (32 - P.q_bits);       // (s2 follows s1 in LDS)
     }
     for (int i = lane; i < n; i += 64) hh[i] = hraw[i];
@@ -2772,35 +2776,78 @@ __global__ __launch_bounds__(64) void rec_verify_kernel(uint32_t batch, const ui
     int bad = 0;
     if (lane == 0) bad = norm_fails_lds(t, n, bd) ? 1 : 0;                     // check_norm_bd on the fields as decoded (:1726-1729)
     bad = __shfl(bad, 0);
-    if (bad) { refuse(); return; }
+    if (bad) { if (lane == 0) verdicts[b] = 1; return; }
     __syncthreads();
-    for (int j = lane; j < n; j += 64) {
-        uint32_t acc = 0;
-        for (int k = 0; k <= j; k++) acc += (uint32_t)s1[k] * (uint32_t)hh[j - k];
-        for (int k = j + 1; k < n; k++) acc -= (uint32_t)s1[k] * (uint32_t)hh[n + j - k];
-        int32_t v = (int32_t)(acc + (uint32_t)s2[j]) % P.q;                    // normalize_32: any correct reduction of a 32-bit word gives this canonical value
-        if (v < 0) v += P.q;
-        t[j] = v;
+    // t[j] = sum_k s1[k] H[n + j - k] with the shift table H[m] = -h[m] (m < n), h[m - n] (m >= n) in t | hh (the sign of the wrapped part is in the table);
+    // a lane owns the coefficients j = lane + 64 c: a step is one broadcast read of s1[k], n / 64 reads at constant offsets from one address and as many
+    // 32-bit multiply-adds that wrap - the reference's words
+    for (int i = lane; i < n; i += 64) t[i] = -hh[i];
+    __syncthreads();
+    constexpr int MAXC = 16;                                                   // n <= 1024
+    const int C = n / 64;
+    uint32_t acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) acc[c] = 0;
+    const int32_t *row0 = t + n + lane;                                        // H = t | hh: contiguous in LDS
+    // (both factors fit 24 signed bits - a q_bits <= 16 field, a SINT16 key coefficient - so a term is one v_mad_i32_i24: exact product, sum that wraps)
+#pragma unroll 4
+    for (int k = 0; k < n; k++) {
+        const int32_t sk = s1[k];
+        const int32_t *row = row0 - k;
+#pragma unroll
+        for (int c = 0; c < MAXC; c++) if (c < C) acc[c] += (uint32_t)__mul24(sk, row[64 * c]);
     }
-    __syncthreads();
-    if (lane == 0) {                                                           // F(t2) into s2's place, two bytes per coefficient
-        Sponge<1> sp; sp.init(st, 0, 168);
-        rec_f_begin(sp, t + n - P.k, P);
-        const uint32_t fmask = (1u << (P.q_bits - 1)) - 1u;
-        for (int i = 0; i < n - P.k; i++) { const uint32_t hi = sp.squeeze_byte(), lo = sp.squeeze_byte(); s2[i] = (int32_t)(((hi << 8) | lo) & fmask); }
+    int32_t *to = tbuf + (size_t)b * n;
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c < C) {
+            const int j = lane + 64 * c;
+            int32_t v = (int32_t)(acc[c] + (uint32_t)s2[j]) % P.q;             // normalize_32: any correct reduction of a 32-bit word gives this canonical value
+            if (v < 0) v += P.q;
+            to[j] = v;
+        }
     }
-    __syncthreads();
+}
+
+// (2) a lane per signature: F(t2) -> fbuf (n - k words), two bytes per coefficient (f_function :746-792)
+__global__ __launch_bounds__(HT) void rec_v2_kernel(uint32_t batch, const int32_t *__restrict__ tbuf, int32_t *__restrict__ fbuf, const uint32_t *__restrict__ verdicts, RecP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t b = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    if (b >= batch || verdicts[b]) return;
+    rec_f_begin(sp, tbuf + (size_t)b * P.n + P.n - P.k, P);
+    const uint32_t fmask = (1u << (P.q_bits - 1)) - 1u;
+    int32_t *fo = fbuf + (size_t)b * P.n;
+    for (int i = 0; i < P.n - P.k; i++) { const uint32_t hi = sp.squeeze_byte(), lo = sp.squeeze_byte(); fo[i] = (int32_t)(((hi << 8) | lo) & fmask); }
+}
+
+// (3) a wavefront per signature: m1 = t1 - F(t2) with its range check (recover_msg :852-856), the message rebuilt in the output row
+__global__ __launch_bounds__(64) void rec_v3_kernel(uint32_t batch, const int32_t *__restrict__ tbuf, const int32_t *__restrict__ fbuf, const uint8_t *__restrict__ m2, size_t m2_stride,
+                                                   const uint32_t *__restrict__ m2lens, uint8_t *__restrict__ out, size_t out_stride, uint32_t *__restrict__ outlens,
+                                                   uint32_t *__restrict__ verdicts, RecP P)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t rv_lds[];          // m1's coefficients
+    const int lane = threadIdx.x, n = P.n;
+    const uint32_t b = blockIdx.x;
+    if (verdicts[b]) { if (lane == 0) outlens[b] = 0; return; }
+    int32_t *s1 = rv_lds;
+    const int32_t *t = tbuf + (size_t)b * n, *fo = fbuf + (size_t)b * n;
+    const uint32_t l2 = m2lens ? m2lens[b] : 0u;
+    const uint32_t sh = P.m1_bits & 7u, base = P.m1_bits >> 3;
+    const uint32_t olen = l2 ? base + l2 : P.m1_bytes;
     const uint32_t bound = (1u << (P.q_bits - 1)) - 1u;
     int over = 0;
     for (int i = lane; i < n - P.k; i += 64) {
-        int32_t v = t[i] - s2[i];                                              // in (-2^(q_bits-1), q): one conditional addition normalises it (:1782-1788)
+        int32_t v = t[i] - fo[i];                                              // in (-2^(q_bits-1), q): one conditional addition normalises it (:1782-1788)
         if (v < 0) v += P.q;
         s1[i] = v;
-        over |= ((uint32_t)v > bound) ? 1 : 0;                                 // recover_msg (:852-856)
+        over |= ((uint32_t)v > bound) ? 1 : 0;
     }
-    if (__any(over)) { refuse(); return; }
+    if (__any(over)) { if (lane == 0) { verdicts[b] = 1; outlens[b] = 0; } return; }
     __syncthreads();
     // the row: m1's bits from the front; m2 behind them, moved back down by the bits it was moved up; the byte they share takes m1's bits on top
+    uint8_t *ob = out + (size_t)b * out_stride;
     const uint32_t fb = (uint32_t)P.q_bits - 1u, masku = 0xFFu >> sh, maskl = masku ^ 0xFFu;
     for (uint32_t j = lane; j < olen; j += 64) {
         uint32_t byte = 0;
@@ -2818,16 +2865,23 @@ __global__ __launch_bounds__(64) void rec_verify_kernel(uint32_t batch, const ui
         }
         ob[j] = (uint8_t)byte;
     }
-    __syncthreads();
-    if (lane == 0) {
-        Sponge<1> sp; sp.init(st, 0, 168);
-        rec_hash(sp, ob, olen, 0, s2, P);
-    }
-    __syncthreads();
+    if (lane == 0) outlens[b] = olen;
+}
+
+// (4) a lane per signature: H'(m) over the rebuilt message against t2 (:1797-1812)
+__global__ __launch_bounds__(HT) void rec_v4_kernel(uint32_t batch, const int32_t *__restrict__ tbuf, const uint8_t *__restrict__ out, size_t out_stride, uint32_t *__restrict__ outlens,
+                                                   uint32_t *__restrict__ verdicts, int32_t *__restrict__ hbuf, RecP P)
+{
+    __shared__ uint64_t st[25 * HT];
+    const uint32_t b = blockIdx.x * HT + threadIdx.x;
+    Sponge<HT> sp; sp.init(st, threadIdx.x, 168);
+    if (b >= batch || verdicts[b]) return;
+    int32_t *hv = hbuf + (size_t)b * P.n;                                       // (the F row is done with: its first k words take the hash)
+    rec_hash(sp, out + (size_t)b * out_stride, outlens[b], 0, hv, P);
+    const int32_t *t2 = tbuf + (size_t)b * P.n + P.n - P.k;
     int neq = 0;
-    for (int i = lane; i < P.k; i += 64) neq |= (s2[i] != t[n - P.k + i]) ? 1 : 0;
-    neq = __any(neq) ? 1 : 0;
-    if (lane == 0) { verdicts[b] = (uint32_t)neq; outlens[b] = neq ? 0u : olen; }
+    for (int i = 0; i < P.k; i++) neq |= (hv[i] != t2[i]) ? 1 : 0;
+    if (neq) { verdicts[b] = 1; outlens[b] = 0; }
 }
 
 }  // namespace
@@ -2889,9 +2943,15 @@ extern "C" int sc_hip_ens_dlp_sig_verify_recovery(sc_hip_falcon_t *f, size_t bat
     if (out_stride < R.m1_bytes) return fail("ens_dlp_sig_verify_recovery: out_stride smaller than the bytes a signature carries");
     HIPCHK(hipSetDevice(f->ctx->device));
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)4 * f->P.n * sizeof(int32_t) + 25 * sizeof(uint64_t);
-    hipLaunchKernelGGL(rec_verify_kernel, dim3((unsigned)batch), dim3(64), lds, s, (uint32_t)batch, d_sigs, sig_stride, d_siglens, d_m2, m2_stride, d_m2lens, f->d_hraw,
-                       d_msgs_out, out_stride, d_mlens_out, d_verdicts, R, f->P.bd);
+    if (fal_ensure_ws(f, batch)) return SC_HIP_FAILURE;
+    const uint32_t B = (uint32_t)batch;
+    const size_t n = (size_t)f->P.n;
+    HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
+    HIPCHK(hipMemsetAsync(d_mlens_out, 0, batch * 4, s));
+    hipLaunchKernelGGL(rec_v1_kernel, dim3(B), dim3(64), 4 * n * sizeof(int32_t), s, B, d_sigs, sig_stride, d_siglens, m2_stride, d_m2lens, f->d_hraw, out_stride, f->s1, d_verdicts, R, f->P.bd);
+    hipLaunchKernelGGL(rec_v2_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, f->s1, f->s2, d_verdicts, R);
+    hipLaunchKernelGGL(rec_v3_kernel, dim3(B), dim3(64), n * sizeof(int32_t), s, B, f->s1, f->s2, d_m2, m2_stride, d_m2lens, d_msgs_out, out_stride, d_mlens_out, d_verdicts, R);
+    hipLaunchKernelGGL(rec_v4_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, f->s1, d_msgs_out, out_stride, d_mlens_out, d_verdicts, f->s2, R);
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
 }
