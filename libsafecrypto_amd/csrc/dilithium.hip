@@ -44,11 +44,11 @@ struct DilP {                             // dilithium_set_t (dilithium_params.h
 // ------------------------------------------------------------------------------------------------
 
 // mu = SHAKE256(tr || M)  (collision_resistant_hash_message, module_lwe.c:182-198)
-__global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uint8_t *msgs, size_t stride, const uint32_t *lens,
-                                                    uint32_t fixed_len, uint8_t *mu, uint32_t count, uint32_t tr_stride = 0)
+__device__ __forceinline__ void dil_mu_body(uint32_t block, const uint8_t *tr, const uint8_t *msgs, size_t stride, const uint32_t *lens,
+                                            uint32_t fixed_len, uint8_t *mu, uint32_t count, uint32_t tr_stride)
 {
     __shared__ uint64_t st[25 * HT];
-    const uint32_t item = blockIdx.x * HT + threadIdx.x;
+    const uint32_t item = block * HT + threadIdx.x;
     const bool valid = item < count;
     Sponge<HT> sp; sp.init(st, threadIdx.x, 136);
     if (!valid) return;
@@ -58,6 +58,9 @@ __global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uin
     sp.finalize();
     for (int i = 0; i < 48; i++) mu[(size_t)item * 48 + i] = sp.squeeze_byte();
 }
+__global__ __launch_bounds__(HT) void dil_mu_kernel(const uint8_t *tr, const uint8_t *msgs, size_t stride, const uint32_t *lens,
+                                                    uint32_t fixed_len, uint8_t *mu, uint32_t count, uint32_t tr_stride = 0)
+{ dil_mu_body(blockIdx.x, tr, msgs, stride, lens, fixed_len, mu, count, tr_stride); }
 
 // tr = SHAKE256( pack(rho: 32 x 8 bits, t1: k*n x bits) )  (collision_resistant_hash_t1, module_lwe.c:140-180)
 // tr = CRH(rho, t1) (collision_resistant_hash_t1, dilithium.c:1038-1075): SHAKE256 over rho and the bit-packed t1 -> 48 bytes;
@@ -772,12 +775,12 @@ __global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint3
 // the tail of a signature (dilithium.c:2085-2123): omega_bits count, `count` hint positions of h_bits each, then c as n 2-bit
 // codes (3 = -1).  One wavefront per signature: every field has a fixed width, so lane i reads hint i and four codes of c; the
 // number of DISTINCT hint positions (what the reference's "cnt += h[p] == 0; h[p] = 1" loop counts) comes from an LDS bitmap.
-__global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
-                                                              uint8_t *h, int32_t *c, uint32_t *verdict, DilP P)
+__device__ __forceinline__ void dil_unpack_tail_body(uint32_t block, const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
+                                                     uint8_t *h, int32_t *c, uint32_t *verdict, const DilP &P)
 {
     __shared__ uint32_t seen[4][64];                                   // k*n <= 2048 hint positions per signature
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t item = blockIdx.x * 4 + wv;
+    const uint32_t item = block * 4 + wv;
     if (item >= count) return;
     const int kn = P.k * P.n, h_bits = 8 + ((P.k + 1) >> 1);
     const uint8_t *s = sigs + (size_t)item * sig_stride;
@@ -820,6 +823,20 @@ __global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sig
         *reinterpret_cast<int4 *>(ci + i) = make_int4(o4[0], o4[1], o4[2], o4[3]);
     }
     if (lane == 0 && (err || oob || fresh > (uint32_t)P.omega)) verdict[item] = 1;     // check_hint_ones (dilithium.c:2119-2123)
+}
+__global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count,
+                                                              uint8_t *h, int32_t *c, uint32_t *verdict, DilP P)
+{ dil_unpack_tail_body(blockIdx.x, sigs, sig_stride, siglens, count, h, c, verdict, P); }
+
+// The verifier's tail unpacking and mu = CRH(tr, message) as ONE launch: the first workgroups hash (a workgroup's first HT lanes: a lane per message), the rest unpack.  The two have nothing to do with each other, and mu is a chain of one permutation that took a launch of its own to wait
+// for (16 us of a 300 us verification call at batch 16384); forking a stream for it costs as much as it hides (measured in round 3), a second role in a
+// launch that is running anyway costs nothing.
+__global__ __launch_bounds__(256) void dil_tail_mu_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, uint8_t *h, int32_t *c, uint32_t *verdict, DilP P,
+                                                          const uint8_t *tr, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens, uint32_t fixed_len, uint8_t *mu)
+{
+    const uint32_t nb_mu = (count + HT - 1) / HT;                       // the hashing workgroups first: their chain starts with the launch and runs under the unpacking
+    if (blockIdx.x >= nb_mu) dil_unpack_tail_body(blockIdx.x - nb_mu, sigs, sig_stride, siglens, count, h, c, verdict, P);
+    else if (threadIdx.x < HT) dil_mu_body(blockIdx.x, tr, msgs, msg_stride, mlens, fixed_len, mu, count, 0u);
 }
 
 }  // namespace
@@ -1271,8 +1288,8 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     else hipLaunchKernelGGL(dil_unpackz_kernel<0>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
     // (measured and dropped: the tail unpacking and mu = CRH(tr, message) on a stream of the handle's own beside the unpacking of z and the matrix product -
     // 39 us of kernels off the critical path, but forking and joining cost as much: 354 -> 359 us per 16384 signatures)
-    hipLaunchKernelGGL(dil_unpack_tail_kernel, dim3((B + 3) / 4), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P);
-    hipLaunchKernelGGL(dil_mu_kernel, dim3(hb), dim3(HT), 0, s, d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, B);
+    hipLaunchKernelGGL(dil_tail_mu_kernel, dim3((B + 3) / 4 + hb), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P,
+                       d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
     // one key for the batch: NTT(c) first, then ONE fused launch - NTT(z), the k rows of A NTT(z) - NTT(c) NTT(t1 2^d), their inverse transforms and UseHint -> w1
