@@ -1581,18 +1581,20 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
                 nud = b->cnt + 10; nvd = b->cnt + 11;
                 sim_saved = sim; blk_saved = blk_later; was_blind = true;
             } else {
-                b->h_pin[2] = 0;
-                HIPCHK(hipMemcpyAsync(b->h_pin, cnt7, 8, hipMemcpyDeviceToHost, s));
-                if (was_blind) HIPCHK(hipMemcpyAsync(b->h_pin + 2, b->cnt + 13, 4, hipMemcpyDeviceToHost, s));
                 if (p0 > 1 && dirty) {
                     // behind a pass of later pairs this look almost always finds nobody left: the call's closing wipes are queued in front of the wait, so
-                    // the device zeroes while the host waits for the two counts (should a message be left, the arrays are simply used and zeroed again)
+                    // the device zeroes while the host waits for the two counts (should a message be left, the arrays are simply used and zeroed again).
+                    // They are queued in front of the read-back, too: by now the device has caught up with the host, every call here is exposed, and the
+                    // device-to-host copy is the slowest of them to issue (~20 us each: the kernel trace showed two such gaps in a row - the counts and the
+                    // refusal flag are one copy now)
                     if (bl_wipe_vectors(b, batch, s)) return SC_HIP_FAILURE;
                     dirty = false;
                     if (d_status && !b->entropy) { HIPCHK(hipMemcpyAsync(d_status, st.status, batch * 4, hipMemcpyDeviceToDevice, s)); status_out = true; }
                 }
+                b->h_pin[5] = 0;
+                HIPCHK(hipMemcpyAsync(b->h_pin, cnt7, was_blind ? 24 : 8, hipMemcpyDeviceToHost, s));      // cnt[8..9]: the two counts; cnt[13]: the unlooked pass was refused
                 HIPCHK(hipStreamSynchronize(s));
-                if (was_blind && both[2]) {                              // the unlooked pass was refused (see bl_blind_kernel): nothing was served, start the later pairs over
+                if (was_blind && both[5]) {                              // the unlooked pass was refused (see bl_blind_kernel): nothing was served, start the later pairs over
                     sim = sim_saved; blk_later = blk_saved; p0 = 1; refused = true; seed_nu = 0; seed_nud = nullptr;
                 }
                 was_blind = false;
