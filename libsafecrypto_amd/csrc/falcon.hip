@@ -1202,14 +1202,14 @@ __global__ __launch_bounds__(HT) void fal_hash1_kernel(uint32_t batch, const uin
 
 // The same with two lanes per message (Sponge2, keccak_dev.h): lane h of a pair owns the 32-bit half h of every state word, i.e.
 // every second draw.  Used while the one-lane form would leave SIMDs without a wavefront (see fal_launch_hash).
-__global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
-                                                      int32_t *__restrict__ c, FalP P, int dlp)
+__device__ __forceinline__ void fal_hash2_body(uint32_t block, uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
+                                               int32_t *__restrict__ c, const FalP &P, int dlp)
 {
     __shared__ uint32_t st[25 * HT];
     // a chain of 25 dependent permutations on a wavefront that issues one instruction in five cycles: in a seeded call the tape expansion (the cipher, which
     // fills every issue slot it is given) runs beside this kernel on the handle's side stream - the chain's instructions go first
     __builtin_amdgcn_s_setprio(3);
-    const uint32_t b = (blockIdx.x * HT + threadIdx.x) >> 1;
+    const uint32_t b = (block * HT + threadIdx.x) >> 1;
     const int h = threadIdx.x & 1;
     Sponge2<HT> sp; sp.init(st, threadIdx.x, 168);
     if (b >= batch) return;
@@ -1238,6 +1238,9 @@ __global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uin
     for (int w = 0; w < 21; w++)
         if (i + 2 * w < P.n) cb[i + 2 * w + h] = map(x[w]);
 }
+__global__ __launch_bounds__(HT) void fal_hash2_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
+                                                      int32_t *__restrict__ c, FalP P, int dlp)
+{ fal_hash2_body(blockIdx.x, batch, msgs, msg_stride, mlens, fixed_len, c, P, dlp); }
 
 __device__ __forceinline__ int32_t centre_mod(int32_t x, int32_t q)      // ntt center_32: the representative in [-(q-1)/2, (q-1)/2]
 {
@@ -1353,11 +1356,11 @@ __global__ __launch_bounds__(64 * FW) void fal_finish_kernel(uint32_t batch, int
 
 // ---- verify (falcon.c:988-1024) -----------------------------------------------------------------------------------------
 // bits: field width (Falcon q_bits - 2; ENS / DLP signatures q_bits); centre == 0: the signed field is taken as it is (ens_dlp_sig.c:1617-1618)
-__global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
-                                  uint32_t *__restrict__ verdict, FalP P, int bits, int centre)
+__device__ __forceinline__ void fal_unpack_body(size_t block, uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
+                                                uint32_t *__restrict__ verdict, const FalP &P, int bits, int centre)
 {
     // one lane per PAIR of coefficients; with the 12-bit coding of both parameter sets a pair is exactly three bytes
-    const size_t tt = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tt = block * blockDim.x + threadIdx.x;
     const int hn = P.n / 2;
     const uint32_t b = (uint32_t)(tt >> sc::pow2_shift(hn)); const int e = (int)(tt & (size_t)(hn - 1)) * 2;     // n is a power of two
     if (b >= batch) return;
@@ -1377,6 +1380,22 @@ __global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ si
         const int32_t sv = (int32_t)(val << (32 - bits)) >> (32 - bits);
         o[h] = centre ? centre_mod(sv, P.q) : sv;
     }
+}
+__global__ void fal_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ sigs, size_t sig_stride, const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2,
+                                  uint32_t *__restrict__ verdict, FalP P, int bits, int centre)
+{ fal_unpack_body(blockIdx.x, batch, sigs, sig_stride, siglens, s2, verdict, P, bits, centre); }
+
+// The verifiers' hash to the ring (two lanes per message) and the signature's unpacking as ONE launch of 256-thread workgroups: the first workgroups hash
+// (their first HT lanes: the chain of 25 permutations starts with the launch), the rest unpack under it.  The two are independent; the unpacking used to be
+// a launch of its own in front of the chain (17 us of a 272 us call at batch 8192).  (A second stream for the product as well was measured and dropped:
+// DESIGN 4.8 - the product's wavefronts slow the chain; the unpacking is light.)
+__global__ __launch_bounds__(256) void fal_hash2_unpack_kernel(uint32_t batch, const uint8_t *__restrict__ msgs, size_t msg_stride, const uint32_t *__restrict__ mlens, uint32_t fixed_len,
+                                                              int32_t *__restrict__ c, FalP P, int dlp, const uint8_t *__restrict__ sigs, size_t sig_stride,
+                                                              const uint32_t *__restrict__ siglens, int32_t *__restrict__ s2, uint32_t *__restrict__ verdict, int bits, int centre)
+{
+    const uint32_t nbh = (2 * batch + HT - 1) / HT;
+    if (blockIdx.x >= nbh) fal_unpack_body(blockIdx.x - nbh, batch, sigs, sig_stride, siglens, s2, verdict, P, bits, centre);
+    else if (threadIdx.x < HT) fal_hash2_body(blockIdx.x, batch, msgs, msg_stride, mlens, fixed_len, c, P, dlp);
 }
 
 // s1 = centre(c - s2*h) ; norm test.  One wavefront per signature.
@@ -2349,9 +2368,13 @@ static int fal_verify_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_k
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
-    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64)
+        hipLaunchKernelGGL(fal_hash2_unpack_kernel, dim3((2 * B + HT - 1) / HT + (unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0,
+                           d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P.q_bits - 2, 1);
+    else {
+        hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits - 2, 1);
+        hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
+    }   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (d_key_of) {                                                    // the public keys of the batch, gathered into the (otherwise idle) sampler workspace
         int32_t *rows = reinterpret_cast<int32_t *>(f->ws);
@@ -2414,9 +2437,13 @@ extern "C" int sc_hip_ens_dlp_sig_verify(sc_hip_falcon_t *f, size_t batch, const
     const uint32_t B = (uint32_t)batch;
     const size_t ne = batch * (size_t)f->P.n;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits, 0);
-    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
-    else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
+    if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64)                     // as fal_verify_core: the unpacking under the hash chain, one launch
+        hipLaunchKernelGGL(fal_hash2_unpack_kernel, dim3((2 * B + HT - 1) / HT + (unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1,
+                           d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P.q_bits, 0);
+    else {
+        hipLaunchKernelGGL(fal_unpack_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, f->s2, d_verdicts, f->P, f->P.q_bits, 0);
+        hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 1);
+    }
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast(f->plan, batch, f->s2, f->d_hhat, f->s1, s)) return SC_HIP_FAILURE;          // the signature's s1 sits in the s2 buffer: the roles are swapped
     hipLaunchKernelGGL(fal_vfinish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->c, f->s1, f->s2, d_verdicts, f->P);

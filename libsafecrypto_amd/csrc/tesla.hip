@@ -227,12 +227,12 @@ __global__ __launch_bounds__(HT) void ts_oracle_kernel(const uint32_t *active, u
 }
 
 // f_function alone: c from a 64-byte digest (md rows for signing, the signature's digest for verification)
-__global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *md_rows, size_t md_stride, uint32_t md_off, int by_item,
-                                                  int32_t *cidx, TsP P, const uint32_t *rs = nullptr)
+__device__ __forceinline__ void ts_f_body(uint32_t block, const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *md_rows, size_t md_stride, uint32_t md_off, int by_item,
+                                          int32_t *cidx, const TsP &P, const uint32_t *rs)
 {
     __shared__ uint32_t used[16 * HT];                                 // n <= 512 flags per lane, bit-packed
     if (rs) nact = rs[TRS_NSLOTS];
-    const uint32_t aidx = blockIdx.x * HT + threadIdx.x;
+    const uint32_t aidx = block * HT + threadIdx.x;
     if (aidx >= nact) return;
     if (need && need[aidx] == 2) return;
     const uint32_t item = active ? active[aidx] : aidx;
@@ -272,6 +272,9 @@ __global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32
         }
     }
 }
+__global__ __launch_bounds__(HT) void ts_f_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint8_t *md_rows, size_t md_stride, uint32_t md_off, int by_item,
+                                                  int32_t *cidx, TsP P, const uint32_t *rs = nullptr)
+{ ts_f_body(blockIdx.x, active, nact, need, md_rows, md_stride, md_off, by_item, cidx, P, rs); }
 
 __device__ __forceinline__ int32_t wave_or(int32_t v) { for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o); return v; }
 
@@ -451,10 +454,10 @@ __global__ __launch_bounds__(256) void ts_select_kernel(const uint32_t *active, 
 // ---- verify ---------------------------------------------------------------------------------------------------------------
 
 // z from the signature (ring_tesla.c:984-996) + test_rejection; one wavefront per signature
-__global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int32_t *z, uint32_t *verdict, TsP P)
+__device__ __forceinline__ void ts_unpack_body(uint32_t block, uint32_t batch, const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int32_t *z, uint32_t *verdict, const TsP &P)
 {
     const int lane = threadIdx.x & 63, n = P.n;
-    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t item = block * 4 + (threadIdx.x >> 6);
     if (item >= batch) return;
     const uint32_t zb = ((uint32_t)n * P.q_bits + 7) / 8;
     if (siglens[item] < zb + 64) { for (int j = lane; j < n; j += 64) z[(size_t)item * n + j] = 0; if (lane == 0) verdict[item] = 1; return; }
@@ -471,6 +474,15 @@ __global__ __launch_bounds__(256) void ts_unpack_kernel(uint32_t batch, const ui
     }
     bad = wave_or(bad);
     if (bad && lane == 0) verdict[item] = 1;
+}
+// The verifier's two readers of the signature as ONE launch: the first workgroups (their first HT lanes, a lane per signature) turn the digest into the
+// challenge's positions (F: twelve Salsa20 blocks in a row), the rest unpack z under them.
+__global__ __launch_bounds__(256) void ts_unpack_f_kernel(uint32_t batch, const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int32_t *z, uint32_t *verdict, TsP P,
+                                                         uint32_t md_off, int32_t *cidx)
+{
+    const uint32_t nbf = (batch + HT - 1) / HT;
+    if (blockIdx.x >= nbf) ts_unpack_body(blockIdx.x - nbf, batch, sigs, sig_stride, siglens, z, verdict, P);
+    else if (threadIdx.x < HT) ts_f_body(blockIdx.x, nullptr, batch, nullptr, sigs, sig_stride, md_off, 1, cidx, P, nullptr);
 }
 
 // w = normalize(prod - t*c)  (ring_tesla.c:1014-1026); one wavefront per signature, in place on the products.  The two public polynomials sit in LDS as
@@ -759,8 +771,7 @@ extern "C" int sc_hip_tesla_verify(sc_hip_tesla_t *t, size_t batch, const uint8_
     const uint32_t B = (uint32_t)batch;
     const uint32_t md_off = ((uint32_t)P.n * P.q_bits + 7) / 8;
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
-    hipLaunchKernelGGL(ts_unpack_kernel, dim3((B + 3) / 4), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, t->y, d_verdicts, P);
-    hipLaunchKernelGGL(ts_f_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, (const uint32_t *)nullptr, B, (const uint32_t *)nullptr, d_sigs, sig_stride, md_off, 1, t->cidx, P);
+    hipLaunchKernelGGL(ts_unpack_f_kernel, dim3((B + HT - 1) / HT + (B + 3) / 4), dim3(256), 0, s, B, d_sigs, sig_stride, d_siglens, t->y, d_verdicts, P, md_off, t->cidx);
     HIPCHK(hipGetLastError());
     if (sc::polymul_ntt_bcast2(t->plan, batch, t->y, t->d_a1, t->d_a2, t->v1, t->v2, s)) return SC_HIP_FAILURE;
     {
