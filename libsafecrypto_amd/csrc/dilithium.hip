@@ -732,11 +732,11 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
 // 64-bit division for its indices - took 51 of the verifier's 378 us at batch 16384.)
 // ZB: z_bits at compile time (the word a field starts in is then a constant: the group's words stay in registers); 0 = any width, at run time
 template <int ZB>
-__global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits_rt, int32_t q,
-                                   uint32_t gamma1_beta, uint32_t *verdict)
+__device__ __forceinline__ void dil_unpackz_body(uint32_t block, const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits_rt, int32_t q,
+                                                 uint32_t gamma1_beta, uint32_t *verdict)
 {
     const int z_bits = ZB ? ZB : z_bits_rt;
-    const uint32_t item = blockIdx.x;
+    const uint32_t item = block;
     const int grp = threadIdx.x;
     if (item >= count || grp >= ln / 8) return;
     const uint8_t *src = sigs + (size_t)item * sig_stride + (size_t)grp * z_bits;
@@ -771,6 +771,10 @@ __global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint3
     dst[0] = make_int4(out[0], out[1], out[2], out[3]); dst[1] = make_int4(out[4], out[5], out[6], out[7]);
     if (bad) verdict[item] = 1;
 }
+template <int ZB>
+__global__ void dil_unpackz_kernel(const uint8_t *sigs, size_t sig_stride, uint32_t count, int32_t *z, int ln, int z_bits_rt, int32_t q,
+                                   uint32_t gamma1_beta, uint32_t *verdict)
+{ dil_unpackz_body<ZB>(blockIdx.x, sigs, sig_stride, count, z, ln, z_bits_rt, q, gamma1_beta, verdict); }
 
 // the tail of a signature (dilithium.c:2085-2123): omega_bits count, `count` hint positions of h_bits each, then c as n 2-bit
 // codes (3 = -1).  One wavefront per signature: every field has a fixed width, so lane i reads hint i and four codes of c; the
@@ -831,11 +835,14 @@ __global__ __launch_bounds__(256) void dil_unpack_tail_kernel(const uint8_t *sig
 // The verifier's tail unpacking and mu = CRH(tr, message) as ONE launch: the first workgroups hash (a workgroup's first HT lanes: a lane per message), the rest unpack.  The two have nothing to do with each other, and mu is a chain of one permutation that took a launch of its own to wait
 // for (16 us of a 300 us verification call at batch 16384); forking a stream for it costs as much as it hides (measured in round 3), a second role in a
 // launch that is running anyway costs nothing.
+// (and z's unpacking, a workgroup per signature, behind them: the three readers of a verification call's inputs are one launch)
+template <int ZB>
 __global__ __launch_bounds__(256) void dil_tail_mu_kernel(const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t count, uint8_t *h, int32_t *c, uint32_t *verdict, DilP P,
-                                                          const uint8_t *tr, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens, uint32_t fixed_len, uint8_t *mu)
+                                                          const uint8_t *tr, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens, uint32_t fixed_len, uint8_t *mu, int32_t *z)
 {
-    const uint32_t nb_mu = (count + HT - 1) / HT;                       // the hashing workgroups first: their chain starts with the launch and runs under the unpacking
-    if (blockIdx.x >= nb_mu) dil_unpack_tail_body(blockIdx.x - nb_mu, sigs, sig_stride, siglens, count, h, c, verdict, P);
+    const uint32_t nb_mu = (count + HT - 1) / HT, nb_tail = (count + 3) / 4;      // the hashing workgroups first: their chain starts with the launch and runs under the unpacking
+    if (blockIdx.x >= nb_mu + nb_tail) dil_unpackz_body<ZB>(blockIdx.x - nb_mu - nb_tail, sigs, sig_stride, count, z, P.l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), verdict);
+    else if (blockIdx.x >= nb_mu) dil_unpack_tail_body(blockIdx.x - nb_mu, sigs, sig_stride, siglens, count, h, c, verdict, P);
     else if (threadIdx.x < HT) dil_mu_body(blockIdx.x, tr, msgs, msg_stride, mlens, fixed_len, mu, count, 0u);
 }
 
@@ -1283,13 +1290,13 @@ extern "C" int sc_hip_dilithium_verify(sc_hip_dilithium_t *d, size_t batch, cons
     if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return fail("dilithium_verify: sig_stride too small");
     HIPCHK(hipMemsetAsync(d_verdicts, 0, batch * 4, s));
     const unsigned hb = (B + HT - 1) / HT;
-    const unsigned zblock = (unsigned)((l * P.n / 8 + 63) / 64 * 64);                // a lane per eight coefficients, a workgroup per signature
-    if (P.z_bits == 20) hipLaunchKernelGGL(dil_unpackz_kernel<20>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
-    else hipLaunchKernelGGL(dil_unpackz_kernel<0>, dim3(B), dim3(zblock), 0, s, d_sigs, sig_stride, B, d->z, l * P.n, P.z_bits, P.q, (uint32_t)(P.gamma1 - P.beta), d_verdicts);
+    if (l * P.n / 8 > 256) return fail("dilithium_verify: l n above 2048");      // (z's unpacking: a lane per eight coefficients, a workgroup per signature)
     // (measured and dropped: the tail unpacking and mu = CRH(tr, message) on a stream of the handle's own beside the unpacking of z and the matrix product -
     // 39 us of kernels off the critical path, but forking and joining cost as much: 354 -> 359 us per 16384 signatures)
-    hipLaunchKernelGGL(dil_tail_mu_kernel, dim3((B + 3) / 4 + hb), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P,
-                       d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu);
+    if (P.z_bits == 20) hipLaunchKernelGGL(dil_tail_mu_kernel<20>, dim3((B + 3) / 4 + hb + B), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P,
+                                           d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, d->z);
+    else hipLaunchKernelGGL(dil_tail_mu_kernel<0>, dim3((B + 3) / 4 + hb + B), dim3(256), 0, s, d_sigs, sig_stride, d_siglens, B, d->h, d->c, d_verdicts, P,
+                            d->d_tr_pub, d_msgs, msg_stride, d_mlens, fixed_len, d->mu, d->z);
     HIPCHK(hipGetLastError());
     DilNtt a = base_args(d);
     // one key for the batch: NTT(c) first, then ONE fused launch - NTT(z), the k rows of A NTT(z) - NTT(c) NTT(t1 2^d), their inverse transforms and UseHint -> w1
