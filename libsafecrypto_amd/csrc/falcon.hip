@@ -1961,14 +1961,15 @@ extern "C" size_t sc_hip_falcon_sig_bytes(const sc_hip_falcon_t *f)
 }
 
 static int fal_launch_sample(sc_hip_falcon *f, size_t batch, const int32_t *d_c, const uint32_t *d_tapes, size_t tape_stride, const uint32_t *d_tape_lens,
-                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s, unsigned long long *d_prof = nullptr, const uint32_t *d_key_of = nullptr)
+                             int32_t *d_s1, int32_t *d_s2, uint32_t *d_status, hipStream_t s, unsigned long long *d_prof = nullptr, const uint32_t *d_key_of = nullptr,
+                             bool status_zeroed = false)                // the caller has zeroed d_status already (the signer: in front of the hash, off the path between it and the walk)
 {
     const double ni = 1.0 / (double)(long)f->P.q;                    /* fpr_inverse_of, falcon_fft.h:57-60 */
     if (tape_stride < 4 * (size_t)f->P.n) {                          // no tape can hold the 4n words a signature draws
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_status, 2, batch, s));
         return SC_HIP_SUCCESS;
     }
-    HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
+    if (!status_zeroed) HIPCHK(hipMemsetAsync(d_status, 0, batch * 4, s));
     // 8 signatures per wavefront with the lower tree in LDS (fal_sample_w8_kernel) unless another mapping is forced
     const size_t sk_stride = (size_t)(f->P.n_bits + 5) * (size_t)f->P.n, tab_stride = (size_t)f->P.n << f->ts_log;
     const bool w8 = f->force_g == 0 || f->force_g == 64;
@@ -2314,11 +2315,13 @@ static int fal_sign_core(sc_hip_falcon_t *f, size_t batch, const uint32_t *d_key
             return fal_sign_grouped(f, batch, d_key_of, d_msgs, msg_stride, d_mlens, fixed_len, d_tapes, tape_stride, d_tape_lens, d_sigs, sig_stride, d_siglens, d_status, s);
     }
     uint32_t *status = d_status ? d_status : f->status;
+    const bool pre_zero = tape_stride >= 4 * (size_t)f->P.n;            // (a tape stride too short for any signature: fal_launch_sample fills the status itself)
+    if (pre_zero) HIPCHK(hipMemsetAsync(status, 0, batch * 4, s));
     if ((size_t)B <= (size_t)f->ctx->cus * 4 * 64) hipLaunchKernelGGL(fal_hash2_kernel, dim3((2 * B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);
     else hipLaunchKernelGGL(fal_hash1_kernel, dim3((B + HT - 1) / HT), dim3(HT), 0, s, B, d_msgs, msg_stride, d_mlens, fixed_len, f->c, f->P, 0);   // two lanes per message only while SIMDs would idle (measured: +11 % verify at 8192, -8 % at 131072)
     HIPCHK(hipGetLastError());
     if (tapes_ready) HIPCHK(hipStreamWaitEvent(s, tapes_ready, 0));     // seeded call: the tapes are being expanded on the handle's side stream
-    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s, nullptr, d_key_of)) return SC_HIP_FAILURE;
+    if (fal_launch_sample(f, batch, f->c, d_tapes, tape_stride, d_tape_lens, f->s1, f->s2, status, s, nullptr, d_key_of, pre_zero)) return SC_HIP_FAILURE;
     hipLaunchKernelGGL(fal_finish_kernel, dim3((B + FW - 1) / FW), dim3(64 * FW), sizeof(int32_t) * FW * (size_t)f->P.n, s, B, f->s1, f->s2, d_sigs, sig_stride, d_siglens, status, f->P,
                        f->ws, (uint32_t)((batch + SPW_MAX - 1) / SPW_MAX * SPW_MAX));
     HIPCHK(hipGetLastError());
