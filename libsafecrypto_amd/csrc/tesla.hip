@@ -50,24 +50,23 @@ __global__ void ts_rs_kernel(uint32_t *rs, uint32_t *cnt, uint32_t first_nact, u
     *cnt = 0;
 }
 
-__global__ void ts_begin_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, St s, const uint32_t *tape_lens, uint32_t tape_stride, uint32_t *need, uint32_t *sbase, int n,
-                                const uint32_t *rs)
+// A slot's state: does it draw (1) or does its message's tape end before it (2), and where on the tape.  The mask
+// kernels work it out themselves (wave-uniform: three scalar loads per kilobyte of mask) and leave need[] / sbase[] behind for the round's later kernels - a
+// launch of its own for it was 5 us of a 290 us round
+__device__ __forceinline__ uint32_t ts_slot_state(const uint32_t *active, uint32_t slot, uint32_t S, const St &s, const uint32_t *tape_lens, uint32_t tape_stride, int n, uint32_t &item, uint32_t &pos)
 {
-    if (rs) { nslots = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= nslots) return;
     const uint32_t aidx = slot / S, k = slot % S;
-    const uint32_t item = active ? active[aidx] : aidx;
-    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride, pos = s.pos[item] + k * (uint32_t)n;
-    if (pos + (uint32_t)n > len) { need[slot] = 2; return; }             // the tape ends before this attempt
-    need[slot] = 1; sbase[slot] = pos;
+    item = active ? active[aidx] : aidx;
+    const uint32_t len = tape_lens ? tape_lens[item] : tape_stride;
+    pos = s.pos[item] + k * (uint32_t)n;
+    return pos + (uint32_t)n > len ? 2u : 1u;
 }
 
 // y = (word & (2^(b_bits+1) - 1)) - b   (ring_tesla.c:818-822)
 // A wavefront takes 256 consecutive coefficients of one slot per step (a lane four of them: 16 bytes of tape in, 16 bytes out), so the slot's state -
 // does it draw, which message, where on its tape - is wave-uniform and read once per kilobyte rather than per coefficient.
-__global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P,
-                                                   const uint32_t *rs)
+__global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, uint32_t *need, uint32_t *sbase, const uint32_t *tapes, size_t tape_stride, int32_t *y, TsP P,
+                                                   const uint32_t *rs, St st, const uint32_t *tape_lens)
 {
     if (rs) { nslots = rs[TRS_NSLOTS]; S = rs[TRS_S]; }
     const int lps = 31 - __clz(P.n / 256);                                // log2 of the steps per slot (n a power of two, >= 256: tesla_create)
@@ -78,10 +77,11 @@ __global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint3
         const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ws >> lps));
         const int i = (((int)ws & ((1 << lps) - 1)) << 8) + 4 * lane;
         int4 *dst = reinterpret_cast<int4 *>(y + (size_t)slot * P.n + i);
-        if (need[slot] != 1) { *dst = make_int4(0, 0, 0, 0); continue; }
-        const uint32_t aidx = slot / S;
-        const uint32_t item = active ? active[aidx] : aidx;
-        const uint32_t *tp = tapes + (size_t)item * tape_stride + sbase[slot] + i;
+        uint32_t item, pos;
+        const uint32_t nd = ts_slot_state(active, slot, S, st, tape_lens, (uint32_t)tape_stride, P.n, item, pos);
+        if (i == 0 && lane == 0) { need[slot] = nd; sbase[slot] = pos; }     // (the slot's first step files its state)
+        if (nd != 1) { *dst = make_int4(0, 0, 0, 0); continue; }
+        const uint32_t *tp = tapes + (size_t)item * tape_stride + pos + i;
         uint32_t w[4];
         if ((reinterpret_cast<uintptr_t>(tp) & 15) == 0) { const uint4 q = *reinterpret_cast<const uint4 *>(tp); w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w; }
         else { w[0] = tp[0]; w[1] = tp[1]; w[2] = tp[2]; w[3] = tp[3]; }
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void ts_y_kernel(const uint32_t *active, uint3
 // The same masks for a SEEDED call (sc_hip_tesla_sign_seeded): the n words of an attempt are blocks pos/4 .. pos/4 + n/4 - 1 of the message's own AES-256
 // CTR-DRBG stream (csrc/drbg_dev.h; prng_32 order: the words of a block come out as w1, w0, w3, w2), produced where they are consumed - no tape exists.
 // 32 lanes per slot: every lane runs the key schedule of its message's seed (a quarter of the cost of its n/128 blocks), then block j, j + 32, ...
-__global__ __launch_bounds__(256) void ts_y_seeded_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, const uint32_t *need, const uint32_t *sbase,
-                                                          const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len, int32_t *y, TsP P, const uint32_t *rs, sc::DrbgConst C)
+__global__ __launch_bounds__(256) void ts_y_seeded_kernel(const uint32_t *active, uint32_t nslots, uint32_t S, uint32_t *need, uint32_t *sbase,
+                                                          const uint8_t *__restrict__ seeds, size_t seed_stride, uint32_t seed_len, int32_t *y, TsP P, const uint32_t *rs, sc::DrbgConst C, St st)
 {
     __shared__ sc::AesLdsWide L;
     L.fill(C);
@@ -103,12 +103,14 @@ __global__ __launch_bounds__(256) void ts_y_seeded_kernel(const uint32_t *active
     if (slot >= nslots) return;
     int4 *dst = reinterpret_cast<int4 *>(y + (size_t)slot * P.n);
     const uint32_t nblk = (uint32_t)P.n / 4;
-    if (need[slot] != 1) { for (uint32_t i = j; i < nblk; i += 32) dst[i] = make_int4(0, 0, 0, 0); return; }
-    const uint32_t aidx = slot / S, item = active ? active[aidx] : aidx;
+    uint32_t item, pos;
+    const uint32_t nd = ts_slot_state(active, slot, S, st, nullptr, 0xfffffff0u, P.n, item, pos);      // (a generator does not run out: ts_sign_core's tape_stride for a seeded call)
+    if (j == 0) { need[slot] = nd; sbase[slot] = pos; }
+    if (nd != 1) { for (uint32_t i = j; i < nblk; i += 32) dst[i] = make_int4(0, 0, 0, 0); return; }
     const uint32_t msk = (1u << (P.b_bits + 1)) - 1u;
     sc::Drbg d;
     d.init(seeds + (size_t)item * seed_stride, seed_len, C, L);
-    d.counter += sbase[slot] / 4 + j;
+    d.counter += pos / 4 + j;
     for (uint32_t i = j; i < nblk; i += 32) {
         uint32_t w[4];
         d.block(w, L);
@@ -688,10 +690,9 @@ static int ts_sign_core(sc_hip_tesla_t *t, size_t batch, const uint8_t *d_msgs, 
             const size_t ne = (size_t)nslots * n;
             size_t yb = (ne / 4 + 255) / 256;                             // a lane per four coefficients; persistent beyond 16 workgroups per CU
             if (yb > (size_t)t->ctx->cus * 16) yb = (size_t)t->ctx->cus * 16;
-            hipLaunchKernelGGL(ts_begin_kernel, dim3((nslots + 255) / 256), dim3(256), 0, s, active, nslots, S, st, d_tape_lens, (uint32_t)tape_stride, t->need, t->sbase, n, rs);
             if (seeded) hipLaunchKernelGGL(ts_y_seeded_kernel, dim3((unsigned)(((size_t)nslots * 32 + 255) / 256)), dim3(256), 0, s, active, nslots, S, t->need, t->sbase,
-                                           d_seeds, seed_stride, (uint32_t)seed_len, t->y, P, rs, sc::drbg_const());
-            else hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs);
+                                           d_seeds, seed_stride, (uint32_t)seed_len, t->y, P, rs, sc::drbg_const(), st);
+            else hipLaunchKernelGGL(ts_y_kernel, dim3((unsigned)yb), dim3(256), 0, s, active, nslots, S, t->need, t->sbase, d_tapes, tape_stride, t->y, P, rs, st, d_tape_lens);
             HIPCHK(hipGetLastError());
             // (a planned round's products run over the whole slot budget: rows past the round's slots hold what an earlier round left there and are read by nobody)
             if (sc::polymul_ntt_bcast2(t->plan, nslots, t->y, t->d_a1, t->d_a2, t->v1, t->v2, s)) return SC_HIP_FAILURE;      // v1 = a1 y, v2 = a2 y: one forward transform of y for both
