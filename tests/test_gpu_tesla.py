@@ -99,3 +99,30 @@ def test_batch_vs_oracle_seeded_tapes(eng, G, tag):
     v = t.verify(mb, sigs, siglens, mlens=ml).cpu().numpy()
     assert np.array_equal(v[ok], np.zeros(ok.sum(), dtype=v.dtype)) and v[3] == 1
     t.close()
+
+
+def test_beyond_16k_slots_one_attempt_per_message_rounds(eng, G):
+    """a batch above 16 K messages starts with ONE attempt per message per round (the slot rule of sc_hip_tesla_sign) and deepens as the batch thins out:
+    a strided sample against the oracle - attempts included, and the messages whose tape ends first - and every signature verifies"""
+    import torch
+    key, t = open_key(eng, G, 'tesla0')
+    B, W = 16500, 10 * 512
+    g = torch.Generator(device='cuda'); g.manual_seed(77)
+    mb = torch.randint(0, 256, (B, 48), dtype=torch.uint8, device='cuda', generator=g)
+    tb = torch.randint(-2**31, 2**31 - 1, (B, W), dtype=torch.int32, device='cuda', generator=g)
+    sigs, siglens, trials, status = t.sign(mb, tb, fixed_len=48)
+    torch.cuda.synchronize()
+    st = status.cpu().numpy()
+    assert (st == 1).sum() > 0.95 * B and set(np.unique(st)) <= {1, 2}
+    mh, th = mb.cpu().numpy(), tb.cpu().numpy().view(np.uint32)
+    sh, lh, tr = sigs.cpu().numpy(), siglens.cpu().numpy(), trials.cpu().numpy()
+    picks = list(range(0, B, 1500)) + [int(i) for i in np.nonzero(st == 2)[0][:3]]
+    for i in picks:
+        rc, sig, otr, used = O.tesla_sign(key, bytes(mh[i]), th[i])
+        assert (rc, int(st[i])) in ((0, 1), (2, 2)), i
+        assert tr[i] == otr, i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == sig, i
+    v = t.verify(mb, sigs, siglens, fixed_len=48).cpu().numpy()
+    assert int(v[st == 1].sum()) == 0 and int((v[st == 2] == 1).all())
+    t.close()
