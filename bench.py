@@ -552,6 +552,9 @@ def kyber_tesla_more_extra(eng, torch, cpu_on):
                    '3 s of safecrypto_sign + 0.75 s of safecrypto_verify, set 0, 64-byte messages, one key, 1 thread')
     if ref:
         rt['cpu_reference'] = ref
+    rt['roofline'] = valu_roofline('tesla_sign', rt['tape_resident_sign_ops_per_s'], 64 + 1600 + 2048 * rt['mean_attempts_per_signature'],
+                                   'tape-resident signing; algorithmic bytes: the message, the signature, 2 KB of tape per attempt the reference\'s loop makes', top=3)
+    rt['roofline_verify'] = valu_roofline('tesla_verify', rt['verify_ops_per_s'], 64 + 1600 + 4, 'message + signature in, verdict out', top=3)
     out['ring_tesla_0'] = rt
     ts.close()
     del msgs, tapes, sigs
@@ -751,7 +754,8 @@ def north_star_summary(extra, cfg):
     t = extra.get('ring_tesla_0')
     if t and 'sign_ops_per_s' in t:
         out['ring_tesla_0_b16384'] = _round({'sign_ops_per_s': t['sign_ops_per_s'], 'csprng': 'inside the call', 'tape_resident_sign_ops_per_s': t['tape_resident_sign_ops_per_s'],
-                                             'verify_ops_per_s': t['verify_ops_per_s'], 'cpu_thread_sign_ops_per_s': cpu(t)})
+                                             'verify_ops_per_s': t['verify_ops_per_s'], 'cpu_thread_sign_ops_per_s': cpu(t), 'roofline_sign_tape_resident': rl(t.get('roofline')),
+                                             'roofline_verify': rl(t.get('roofline_verify'))})
     return out
 
 

@@ -16,5 +16,7 @@ T() { python3 tools/timeline.py $P/tl_$1/trace/*/*kernel_trace.csv "$2" ${3:-}; 
  echo "Round 3 (profiles/r03_dil_sign_timeline.txt): 2707 us; round 4: the hash kernels (theta folded into three-way XORs: 125 -> 119 instructions per round) and the finishing kernel (a stage left at its first failing pass: 408 / 263 / 136 -> what is below)."; echo; T dil_sign dil_mu_kernel) > profiles/r04_dil_sign_timeline.txt
 (echo "BLISS-B-I sign, batch 16384, one key, tapes resident: kernel timeline of one signing call at the end of round 4 (rocprofv3 --kernel-trace over python3 tools/bench_scheme.py bliss_sign 3, read with tools/timeline.py; one MI355X)"
  echo "Round 3 (profiles/r03_bliss_sign_timeline.txt): 1252 us - bl_decide_kernel 187 / 55 / 50 / 46 us, a 45 us look between the first pair of attempts and the later pairs."; echo; T bliss_sign bl_zero_kernel 4096) > profiles/r04_bliss_sign_timeline.txt
+(echo "ring-TESLA-I sign, batch 16384, one key, tapes resident: kernel timeline of one signing call at the end of round 4 (rocprofv3 --kernel-trace over python3 tools/bench_scheme.py tesla_sign 3, read with tools/timeline.py; one MI355X)"
+ echo "At the start of the round's last day: 1205 us - ts_decide_kernel 125-136 us and ts_select_kernel 90 / 24 / 9 us per round, two products of 50 us each, 32768 slots per round."; echo; T tesla_sign closes:ts_zero6_kernel) > profiles/r04_tesla_sign_timeline.txt
 (echo "Falcon-1024 sign, batch 8192, one key, tapes resident: kernel timeline of one signing call at the end of round 4 (rocprofv3 --kernel-trace over python3 tools/bench_scheme.py falcon_sign 3, read with tools/timeline.py; one MI355X)"; echo; T falcon_sign fal_hash2) > profiles/r04_falcon_sign_timeline.txt
 git diff --stat profiles | tail -3

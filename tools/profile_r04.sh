@@ -19,7 +19,7 @@ import json, sys
 sys.path.insert(0, 'tools')
 import pmc_leg
 out = {}
-for leg in ('dil_sign', 'dil_verify', 'bliss_sign', 'bliss_verify', 'falcon_sign', 'ens_sign', 'rlwe_encrypt', 'polymul', 'drbg'):
+for leg in ('dil_sign', 'dil_verify', 'bliss_sign', 'bliss_verify', 'falcon_sign', 'ens_sign', 'rlwe_encrypt', 'polymul', 'drbg', 'tesla_sign', 'tesla_verify'):
     r = pmc_leg.profile_leg(leg, calls=2)
     if r.get('ok'):
         r.pop('ok')
@@ -28,7 +28,7 @@ json.dump(out, open(sys.argv[1] + '/scheme_pmc.json', 'w'), indent=1)
 print({k: (round(v['valu_wave_instructions_per_op']), round(v['hbm_bytes_per_op_2xfetch_plus_write'])) for k, v in out.items()})
 PY
 # kernel timelines of one call of the north-star legs, and the GPU suite once WITHOUT the harness's two runtime variables
-for leg in dil_sign bliss_sign falcon_sign; do
+for leg in dil_sign bliss_sign falcon_sign tesla_sign; do
   mkdir -p $OUT/tl_$leg
   timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$leg/trace -- python3 tools/bench_scheme.py $leg 3 > $OUT/tl_$leg/out.txt 2> $OUT/tl_$leg/err.txt
 done
