@@ -726,6 +726,243 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
     if (again) { f.kappa[item] += S; f.next_active[fin_lds[1] + rpos] = item; }
 }
 
+// ---- the finishing kernel WITHOUT transforms (one key for the batch; round 4) -------------------------------------------------------------------
+// c has `weight` coefficients +-1, the key vectors are small (|s1|, |s2| <= eta, |t0| <= 2^(d-1)): c s is `weight` shifted copies of s added up.  With s as a
+// SHIFT TABLE in LDS - U[m] = -s[m] (m < n), U[m] = s[m - n] (n <= m < 2n), so that (x^p s)[j] = U[n + j - p], the sign of the wrapped part in the table -
+// a term is one LDS read per word and one packed 16-bit addition per TWO rows (the rows are stored in pairs, two 16-bit values a word: the sums stay below
+// 2^15 because weight * max|s| does - checked when the key is loaded).  No NTT(c), no products, no inverse transforms, no exchange images: a stage is
+// `weight` x (rows / 2) x 4 reads and additions per lane, nothing in it waits for anything but LDS, the kernel needs a third of the registers and three
+// wavefronts share a SIMD.  Same integers as dil_cfin_kernel computes modulo q, same tests in the same order: the same signatures (tests/test_gpu_dilithium.py
+// runs both).  A lane owns the coefficients j_c = 64 c + 16 (lane & 3) + (lane >> 2), c = 0..3 - word 64 c + lane of a row of w in its 16-byte-piece
+// layout (DilNtt::w_chunked), so a row of w is four fully coalesced loads.
+struct DilFinS { const uint32_t *tabs; };     // us2 [(k+1)/2][2n] | us1 [(l+1)/2][2n] | ut0 [(k+1)/2][2n], 16-bit pairs
+constexpr int CSP = 3;                        // row pairs: k, l <= 6
+
+__global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilFinS g)
+{
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) uint32_t fin_lds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const DilP &P = f.P;
+    const int l = P.l, kk = P.k, kp = (kk + 1) / 2, lp2 = (l + 1) / 2;
+    const int32_t q = P.q;
+    uint32_t *T2 = fin_lds + 4, *T1 = T2 + kp * 2 * N, *T0 = T1 + lp2 * 2 * N;
+    uint32_t *wbase = T0 + kp * 2 * N + (size_t)wid * (256u * l + 128u + 64u + 64u * kk + 64u);
+    uint32_t *zl = wbase;                                               // z of the current attempt, natural order [l][n]
+    uint32_t *tw = zl + 256 * l;                                        // signature tail, big-endian words
+    uint32_t *cb = tw + 128;                                            // c as n signed bytes
+    uint8_t *hl = reinterpret_cast<uint8_t *>(cb + 64);                 // hints [k][n]
+    uint32_t *cpos = cb + 64 + 64 * kk;                                 // c's positions: the +1 ones, then the -1 ones
+    {
+        const uint32_t words = (uint32_t)(2 * kp + lp2) * 2 * N;
+        for (uint32_t i = threadIdx.x; i < words / 4; i += 256) reinterpret_cast<uint4 *>(T2)[i] = reinterpret_cast<const uint4 *>(g.tabs)[i];
+    }
+    if (threadIdx.x == 0) fin_lds[0] = 0;
+    __syncthreads();
+    const uint32_t nact = f.rs[RS_NACT], S = f.rs[RS_S];
+    const uint32_t aidx = blockIdx.x * 4 + wid;
+    const bool live = aidx < nact;                                      // wave-uniform
+    int found = -1;
+    uint32_t item = 0;
+    if (live) {
+        item = f.active ? f.active[aidx] : aidx;
+        const int jb = 16 * (lane & 3) + (lane >> 2);                   // the lane's coefficient inside every block of 64
+        const uint32_t *c32 = reinterpret_cast<const uint32_t *>(f.c8) + (size_t)aidx * S * 64 + lane;
+        uint32_t creg = c32[0];
+        for (uint32_t at = 0; at < S && found < 0; at++) {
+            const uint32_t slot = aidx * S + at;
+            // the attempt's w (k rows, four words a lane) and the first rows of y are requested before anything is computed
+            int32_t wv[2 * CSP][4];
+#pragma unroll
+            for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) wv[i][c] = i < kk ? a.w[((size_t)slot * kk + i) * N + 64 * c + lane] : 0;
+            const uint32_t cw = creg;
+            cb[lane] = cw;
+            if (at + 1 < S) creg = c32[(size_t)(at + 1) * 64];              // the next attempt's c, should this one fail
+            // c's positions: lane's word holds c[4 lane .. 4 lane + 3] as signed bytes
+            uint32_t np = 0, nm = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const int32_t b = (int32_t)(int8_t)(cw >> (8 * e)); np += b > 0; nm += b < 0; }
+            uint32_t ip = np, im = nm;                                      // inclusive scans over the lanes
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t tp_ = (uint32_t)__shfl_up((int)ip, o), tm_ = (uint32_t)__shfl_up((int)im, o); if (lane >= o) { ip += tp_; im += tm_; } }
+            const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)ip, 63), tm = (uint32_t)__builtin_amdgcn_readlane((int)im, 63);      // (scalars: the loops below are uniform)
+            {
+                uint32_t op = ip - np, om = tp + im - nm;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const int32_t b = (int32_t)(int8_t)(cw >> (8 * e));
+                    if (b > 0) cpos[op++] = (uint32_t)(4 * lane + e);
+                    if (b < 0) cpos[om++] = (uint32_t)(4 * lane + e);
+                }
+            }
+            wave_lds_fence();
+            const int my_pos = (uint32_t)lane < tp + tm ? (int)cpos[lane] : 0;    // weight <= 64: position t in lane t
+            // sum of the shifted rows of a table of row pairs: acc[pp][c] (two 16-bit sums a word)
+            auto sparse = [&](const uint32_t *T, int npairs, s2 (&acc)[CSP][4]) {
+#pragma unroll
+                for (int pp = 0; pp < CSP; pp++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[pp][c] = s2{ 0, 0 };
+                for (uint32_t t = 0; t < tp; t++) {
+                    const uint32_t *row = T + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
+#pragma unroll
+                    for (int pp = 0; pp < CSP; pp++)
+                        if (pp < npairs) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) { const uint32_t w = row[pp * 2 * N + 64 * c]; s2 v; __builtin_memcpy(&v, &w, 4); acc[pp][c] += v; }
+                        }
+                }
+                for (uint32_t t = tp; t < tp + tm; t++) {
+                    const uint32_t *row = T + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
+#pragma unroll
+                    for (int pp = 0; pp < CSP; pp++)
+                        if (pp < npairs) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) { const uint32_t w = row[pp * 2 * N + 64 * c]; s2 v; __builtin_memcpy(&v, &w, 4); acc[pp][c] -= v; }
+                        }
+                }
+            };
+            s2 acc[CSP][4];
+            bool bad = false;
+            // ---- r = w - c s2; ||LowBits(r)||inf < gamma_2 - beta (dilithium.c:1671-1700)
+            sparse(T2, kp, acc);
+            int32_t rr[2 * CSP][4];
+#pragma unroll
+            for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int32_t cs = (i & 1) ? (int32_t)acc[i >> 1][c].y : (int32_t)acc[i >> 1][c].x;
+                    int32_t v = wv[i][c] - cs;                              // w canonical, |c s2| small: one correction either way
+                    v += (v >> 31) & q; v -= (v >= q) ? q : 0;
+                    rr[i][c] = v;
+                    int32_t a0;
+                    round_alpha((uint32_t)v, a0, a.alpha, a.am, q);
+                    const uint32_t lo = a0 < 0 ? (uint32_t)(a0 + q) : (uint32_t)a0;       // low_order_bits
+                    bad |= (i < kk) && norm_bad(lo, (uint32_t)q, (uint32_t)a.gamma2_beta);
+                }
+            bool ok = __ballot(bad) == 0;
+            if (ok) {
+                // ---- z = y + c s1, normalised; ||z||inf < gamma_1 - beta (dilithium.c:1655-1669)
+                int32_t yv[2 * CSP][4];
+#pragma unroll
+                for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) yv[i][c] = i < l ? a.y[((size_t)slot * l + i) * N + 64 * c + jb] : 0;
+                sparse(T1, lp2, acc);
+#pragma unroll
+                for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (i < l) {
+                            const int32_t cs = (i & 1) ? (int32_t)acc[i >> 1][c].y : (int32_t)acc[i >> 1][c].x;
+                            int32_t v = yv[i][c] - q + cs;                  // y is stored as q + (a value in (-gamma_1, gamma_1)) (dil_expand_kernel)
+                            v += (v >> 31) & q;
+                            zl[i * N + 64 * c + jb] = (uint32_t)v;
+                            bad |= norm_bad((uint32_t)v, (uint32_t)q, (uint32_t)a.gamma1_beta);
+                        }
+                    }
+                ok = __ballot(bad) == 0;
+            }
+            uint32_t ones = 0;
+            if (ok) {
+                // ---- c t0; ||c t0||inf < gamma_2 - beta; hints (make_hint, dilithium.c:1258-1284, 1702-1725).  |c t0| can pass 2^15: the 16-bit table entries are
+                // added up in 32 bits
+                int32_t a0s[2 * CSP][4];
+#pragma unroll
+                for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) a0s[i][c] = 0;
+                for (uint32_t t = 0; t < tp + tm; t++) {
+                    const uint32_t *row = T0 + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
+                    const bool neg = t >= tp;
+#pragma unroll
+                    for (int pp = 0; pp < CSP; pp++)
+                        if (pp < kp) {
+#pragma unroll
+                            for (int c = 0; c < 4; c++) {
+                                const uint32_t w = row[pp * 2 * N + 64 * c];
+                                const int32_t lo = (int32_t)(int16_t)w, hi = (int32_t)w >> 16;
+                                a0s[2 * pp][c] += neg ? -lo : lo; a0s[2 * pp + 1][c] += neg ? -hi : hi;
+                            }
+                        }
+                }
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int i = 0; i < 2 * CSP; i++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        if (i < kk) {
+                            int32_t x = a0s[i][c];
+                            x += (x >> 31) & q;                                   // canonical c t0
+                            const uint32_t sum = csub((uint32_t)rr[i][c] + (uint32_t)x, (uint32_t)q);        // (w - c s2) + c t0
+                            int32_t a0;
+                            const uint32_t hb = round_alpha(sum, a0, a.alpha, a.am, q) != round_alpha((uint32_t)rr[i][c], a0, a.alpha, a.am, q);
+                            bad |= norm_bad((uint32_t)x, (uint32_t)q, (uint32_t)a.gamma2_beta);
+                            hl[i * N + 64 * c + jb] = (uint8_t)hb; cnt += hb;
+                        }
+                    }
+                for (int o_ = 32; o_ > 0; o_ >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o_);
+                ones = cnt;
+                ok = __ballot(bad) == 0 && ones <= (uint32_t)P.omega;
+            }
+            if (!ok) { wave_lds_fence(); continue; }                            // (cpos is rewritten by the next attempt)
+            // ---- accepted: the signature (as dil_cfin_kernel)
+            found = (int)at;
+            wave_lds_fence();
+            uint8_t *out = f.sigs + (size_t)item * f.sig_stride;
+            {
+                const int32_t half = (q - 1) >> 1;
+                const int pairs = l * N / 2, nbytes = 2 * P.z_bits / 8;
+                const uint64_t m = (1ull << P.z_bits) - 1;
+                for (int pr = lane; pr < pairs; pr += 64) {
+                    int32_t v0 = (int32_t)zl[2 * pr], v1 = (int32_t)zl[2 * pr + 1];
+                    if (v0 > half) v0 -= q;
+                    if (v1 > half) v1 -= q;
+                    const uint64_t bits = (((uint64_t)(uint32_t)v0 & m) << P.z_bits) | ((uint64_t)(uint32_t)v1 & m);     // 2 z_bits bits, MSB first
+                    uint8_t *dst = out + (size_t)pr * nbytes;
+                    for (int b = 0; b < nbytes; b++) dst[b] = (uint8_t)(bits >> (8 * (nbytes - 1 - b)));
+                }
+            }
+            const int kn = kk * P.n, h_bits = 8 + ((kk + 1) >> 1);
+            tw[lane] = 0; tw[lane + 64] = 0;
+            wave_lds_fence();
+            auto put = [&](uint32_t off, uint32_t v, int bits) {                // bits <= 16: at most two words
+                const uint32_t w = off >> 5; const int sh = 32 - (int)(off & 31) - bits;
+                if (sh >= 0) atomicOr(&tw[w], v << sh);
+                else { atomicOr(&tw[w], v >> (-sh)); atomicOr(&tw[w + 1], v << (32 + sh)); }
+            };
+            if (lane == 0) put(0, ones, P.omega_bits);
+            const int chunk = kn / 64;                                          // kn = k * 256
+            const uint8_t *hh = hl + lane * chunk;
+            uint32_t mine = 0;
+            for (int i = 0; i < chunk; i++) mine += hh[i];
+            uint32_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += t; }
+            uint32_t rank = incl - mine;
+            for (int i = 0; i < chunk; i++)
+                if (hh[i]) { put((uint32_t)P.omega_bits + rank * (uint32_t)h_bits, (uint32_t)(lane * chunk + i), h_bits); rank++; }
+            const uint32_t cbase = (uint32_t)P.omega_bits + ones * (uint32_t)h_bits;
+            {
+                const uint32_t v = cb[lane];                                    // c[4 lane .. 4 lane + 3]: two bits each, -1 -> 3 (dilithium.c:1939-1945)
+                const uint32_t b = ((v & 3u) << 6) | (((v >> 8) & 3u) << 4) | (((v >> 16) & 3u) << 2) | ((v >> 24) & 3u);
+                put(cbase + 8u * (uint32_t)lane, b, 8);
+            }
+            wave_lds_fence();
+            const uint32_t tbits = cbase + 2u * (uint32_t)P.n, tbytes = (tbits + 7) / 8, zbytes = (uint32_t)(l * P.n * P.z_bits / 8);
+            for (uint32_t i = lane; i < tbytes; i += 64) out[zbytes + i] = (uint8_t)(tw[i >> 2] >> (24 - 8 * (i & 3)));
+            if (lane == 0) { f.trials[item] = f.kappa[item] + at + 1; f.siglens[item] = zbytes + tbytes; }
+        }
+    }
+    const bool again = live && found < 0 && lane == 0;
+    uint32_t rpos = 0;
+    if (again) rpos = atomicAdd(&fin_lds[0], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0 && fin_lds[0]) fin_lds[1] = atomicAdd(f.next_count, fin_lds[0]);
+    __syncthreads();
+    if (again) { f.kappa[item] += S; f.next_active[fin_lds[1] + rpos] = item; }
+}
+
 // verify: unpack z (-> canonical), hints, c; structural checks (dilithium.c:2065-2123)
 // One workgroup per signature, a lane per EIGHT coefficients: 8 z_bits bits are z_bits whole bytes (20 for every reference parameter set: five words
 // where the row starts on a word boundary), out as two 16-byte stores.  (One lane per pair of coefficients - five byte loads, two 4-byte stores, a
@@ -859,6 +1096,7 @@ struct sc_hip_dilithium {
     bool have_priv, have_pub;
     uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
     uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
+    uint32_t *d_tabs;                                 // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel); null: the key does not fit them
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
     size_t cap;                                       // per message / per signature (verify): mu, kappa, trials, act, z, h, c, ch
@@ -873,7 +1111,7 @@ struct sc_hip_dilithium {
     sc::Workspace kws;                                // sc_hip_dilithium_verify_keys: per-item key material
     hipStream_t side, side2;                          // verify_keys / sign_keys: per-key chains that depend on nothing of each other run beside each other
     hipEvent_t ev_fork, ev_join, ev_join2;
-    int tune_slots, tune_unfused, tune_sync, tune_exp1 = 0, tune_w24 = 0;        // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
+    int tune_slots, tune_unfused, tune_sync, tune_exp1 = 0, tune_w24 = 0, tune_sparse_fin = 0;        // measurement hooks (sc_hip_dilithium_set_tuning): slots per message (0 = default), unfused NTT(y) / matrix product, a read-back after every round
 };
 
 static void free_ws(sc_hip_dilithium *d)
@@ -944,7 +1182,7 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
     if (d->ev_fork) (void)hipEventDestroy(d->ev_fork);
     if (d->ev_join) (void)hipEventDestroy(d->ev_join);
     if (d->ev_join2) (void)hipEventDestroy(d->ev_join2);
-    void *ptrs[] = { d->d_A, d->d_As, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
+    void *ptrs[] = { d->d_A, d->d_As, d->d_tabs, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
     sc_hip_plan_destroy(d->plan);
     delete d;
@@ -994,6 +1232,33 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = (x >= 0) ? x : x + q; }
     if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
+    {
+        // dil_cfins_kernel's shift tables: rows in pairs, two 16-bit values a word; U[m] = -s[m] (m < n), s[m - n] (m >= n), s centred.  Only for keys whose
+        // products with c stay inside 16 bits (s1, s2) and whose t0 fits 16 bits - every key the reference generates; any other keeps the transform kernel
+        const int kp = (k + 1) / 2, lp2 = (l + 1) / 2;
+        std::vector<uint32_t> tabs((size_t)(2 * kp + lp2) * 2 * N, 0u);
+        bool fits = k <= 2 * CSP && l <= 2 * CSP && d->P.weight <= 64;
+        auto centred = [&](int32_t x) { int32_t r = x % q; if (r < 0) r += q; return r > (q - 1) / 2 ? r - q : r; };
+        auto fill = [&](uint32_t *T, const int32_t *src, int rows, int32_t bound) {
+            for (int i = 0; i < rows; i++)
+                for (int j = 0; j < N; j++) {
+                    const int32_t v = centred(src[(size_t)i * N + j]);
+                    if (v > bound || v < -bound) fits = false;
+                    const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v), pos = (uint32_t)(uint16_t)(int16_t)v;
+                    uint32_t *row = T + (size_t)(i >> 1) * 2 * N;
+                    const int sh = 16 * (i & 1);
+                    row[j] |= neg << sh; row[N + j] |= pos << sh;
+                }
+        };
+        fill(tabs.data(), s2, k, 32767 / d->P.weight);
+        fill(tabs.data() + (size_t)kp * 2 * N, s1, l, 32767 / d->P.weight);
+        fill(tabs.data() + (size_t)(kp + lp2) * 2 * N, t0.data(), k, 32767);
+        if (fits) {
+            if (!d->d_tabs) HIPCHK(hipMalloc((void **)&d->d_tabs, tabs.size() * 4));
+            HIPCHK(sc::copy_in(d->d_tabs, tabs.data(), tabs.size() * 4));
+        } else if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
+        for (auto &w : tabs) *(volatile uint32_t *)&w = 0;
+    }
     if (!d->d_K) HIPCHK(hipMalloc((void **)&d->d_K, 32));
     if (!d->d_tr_priv) HIPCHK(hipMalloc((void **)&d->d_tr_priv, 48));
     HIPCHK(sc::copy_in(d->d_K, K, 32));
@@ -1099,7 +1364,7 @@ extern "C" int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *d, unsigne
 extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_message, int unfused)
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
-    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_w24 = (slots_per_message >> 10) & 1; d->tune_unfused = unfused ? 1 : 0;
+    d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_w24 = (slots_per_message >> 10) & 1; d->tune_sparse_fin = (slots_per_message >> 11) & 1; d->tune_unfused = unfused ? 1 : 0;
     return SC_HIP_SUCCESS;
 }
 
@@ -1184,6 +1449,10 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     // from the count its predecessor's last kernel left behind; grids are sized for the slot budget and the surplus workgroups leave at once.  The
     // host queues as many rounds as the schedule is expected to need, looks at the count once, and adds single rounds while messages are left.
     const size_t fin_lds = (4 + 4 * cfin_wave_words(P)) * sizeof(uint32_t);
+    // one key for the batch whose coefficient-domain tables exist: the finishing kernel without transforms - ONLY behind tuning bit 11: the kernel was written
+    // while the GPU pool was closed to this build and has not run on hardware yet; the transform kernel stays the product path until it has
+    const bool sparse_fin = d->tune_sparse_fin && !ks.per_item && ks.s1 == d->d_s1 && d->d_tabs && !d->tune_w24;
+    const size_t fins_lds = (4 + (size_t)(2 * ((P.k + 1) / 2) + (P.l + 1) / 2) * 2 * N + 4 * (256u * P.l + 128u + 64u + 64u * P.k + 64u)) * sizeof(uint32_t);
     DilFin f;
     f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
     f.s1_stride = ks.per_item ? (size_t)l * N : 0; f.k_stride = ks.per_item ? (size_t)k * N : 0;
@@ -1239,7 +1508,8 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
                         else if (l > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, true, false>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else if (k > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, false, true>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else hipLaunchKernelGGL((dil_cfin_kernel<M, false, false>), dim3(fb), dim3(256), fin_lds, s, a, f); } while (0)
-            if (a.sg) SC_CFIN(MODE_S32); else SC_CFIN(MODE_U32);
+            if (sparse_fin) hipLaunchKernelGGL(dil_cfins_kernel, dim3(fb), dim3(256), fins_lds, s, a, f, DilFinS{ d->d_tabs });
+            else if (a.sg) SC_CFIN(MODE_S32); else SC_CFIN(MODE_U32);
 #undef SC_CFIN
             HIPCHK(hipGetLastError());
         }
