@@ -1220,6 +1220,53 @@ static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
     return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
 }
 
+// dil_cfins_kernel's shift tables: us2 | us1 | ut0, rows in pairs, two 16-bit values a word; U[m] = -s[m] (m < n), s[m - n] (m >= n), s centred.  Returns
+// false for a key whose products with c could leave 16 bits (s1, s2) or whose t0 does not fit 16 bits - none the reference generates; such a key keeps
+// the transform kernel.  t0 canonical in [0, q) or centred.
+static bool fin_tables(const DilP &P, const int32_t *s1, const int32_t *s2, const int32_t *t0, std::vector<uint32_t> &tabs)
+{
+    const int k = P.k, l = P.l, q = P.q;
+    const int kp = (k + 1) / 2, lp2 = (l + 1) / 2;
+    tabs.assign((size_t)(2 * kp + lp2) * 2 * N, 0u);
+    bool fits = k <= 2 * CSP && l <= 2 * CSP && P.weight >= 1 && P.weight <= 64;
+    auto centred = [&](int32_t x) { int32_t r = x % q; if (r < 0) r += q; return r > (q - 1) / 2 ? r - q : r; };
+    auto fill = [&](uint32_t *T, const int32_t *src, int rows, int32_t bound) {
+        for (int i = 0; i < rows; i++)
+            for (int j = 0; j < N; j++) {
+                const int32_t v = centred(src[(size_t)i * N + j]);
+                if (v > bound || v < -bound) fits = false;
+                const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v), pos = (uint32_t)(uint16_t)(int16_t)v;
+                uint32_t *row = T + (size_t)(i >> 1) * 2 * N;
+                const int sh = 16 * (i & 1);
+                row[j] |= neg << sh; row[N + j] |= pos << sh;
+            }
+    };
+    fill(tabs.data(), s2, k, 32767 / (P.weight > 0 ? P.weight : 1));
+    fill(tabs.data() + (size_t)kp * 2 * N, s1, l, 32767 / (P.weight > 0 ? P.weight : 1));
+    fill(tabs.data() + (size_t)(kp + lp2) * 2 * N, t0, k, 32767);
+    return fits;
+}
+
+// test hook (include/sc_hip_bench.h): the tables of a key, built on the host exactly as sc_hip_dilithium_set_privkey builds them - no device involved
+extern "C" int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t *params, const int32_t *s1, const int32_t *s2, const int32_t *t,
+                                                uint32_t *out, size_t out_words, int *fits)
+{
+    if (!params || !s1 || !s2 || !t || !fits) return fail("dilithium_fin_tables_host: null argument");
+    DilP P;
+    memcpy(&P, params, sizeof P);
+    if (P.n != N || P.k < 1 || P.k > 8 || P.l < 1 || P.l > 8 || P.q < 2 || P.d < 1 || P.d > 30) return fail("dilithium_fin_tables_host: unsupported parameters");
+    std::vector<int32_t> t0((size_t)P.k * N);
+    const int32_t mask = (1 << P.d) - 1, sign = 1 << P.d, thresh = 1 << (P.d - 1);
+    for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = x; }
+    std::vector<uint32_t> tabs;
+    *fits = fin_tables(P, s1, s2, t0.data(), tabs) ? 1 : 0;
+    if (out) {
+        if (out_words < tabs.size()) return fail("dilithium_fin_tables_host: output too small");
+        memcpy(out, tabs.data(), tabs.size() * 4);
+    }
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t *s1, const int32_t *s2, const int32_t *t,
                                             const uint8_t *K, const uint8_t *tr, const int32_t *Ahat)
 {
@@ -1233,26 +1280,8 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
     {
-        // dil_cfins_kernel's shift tables: rows in pairs, two 16-bit values a word; U[m] = -s[m] (m < n), s[m - n] (m >= n), s centred.  Only for keys whose
-        // products with c stay inside 16 bits (s1, s2) and whose t0 fits 16 bits - every key the reference generates; any other keeps the transform kernel
-        const int kp = (k + 1) / 2, lp2 = (l + 1) / 2;
-        std::vector<uint32_t> tabs((size_t)(2 * kp + lp2) * 2 * N, 0u);
-        bool fits = k <= 2 * CSP && l <= 2 * CSP && d->P.weight <= 64;
-        auto centred = [&](int32_t x) { int32_t r = x % q; if (r < 0) r += q; return r > (q - 1) / 2 ? r - q : r; };
-        auto fill = [&](uint32_t *T, const int32_t *src, int rows, int32_t bound) {
-            for (int i = 0; i < rows; i++)
-                for (int j = 0; j < N; j++) {
-                    const int32_t v = centred(src[(size_t)i * N + j]);
-                    if (v > bound || v < -bound) fits = false;
-                    const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v), pos = (uint32_t)(uint16_t)(int16_t)v;
-                    uint32_t *row = T + (size_t)(i >> 1) * 2 * N;
-                    const int sh = 16 * (i & 1);
-                    row[j] |= neg << sh; row[N + j] |= pos << sh;
-                }
-        };
-        fill(tabs.data(), s2, k, 32767 / d->P.weight);
-        fill(tabs.data() + (size_t)kp * 2 * N, s1, l, 32767 / d->P.weight);
-        fill(tabs.data() + (size_t)(kp + lp2) * 2 * N, t0.data(), k, 32767);
+        std::vector<uint32_t> tabs;
+        const bool fits = fin_tables(d->P, s1, s2, t0.data(), tabs);
         if (fits) {
             if (!d->d_tabs) HIPCHK(hipMalloc((void **)&d->d_tabs, tabs.size() * 4));
             HIPCHK(sc::copy_in(d->d_tabs, tabs.data(), tabs.size() * 4));
