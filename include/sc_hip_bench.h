@@ -45,11 +45,12 @@ int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
 int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, int unfused);
 
 /* test hook, host only (no device call): the coefficient-domain shift tables sc_hip_dilithium_set_privkey builds for the finishing kernel without
- * transforms - us2 [(k+1)/2][2n] | us1 [(l+1)/2][2n] | ut0 [(k+1)/2][2n] words, rows in pairs (row 2i in the low, 2i+1 in the high 16 bits),
- * U[m] = -s[m] (m < n), s[m - n] (m >= n), s centred; *fits = 0 when the key cannot use them (sums of `weight` terms outside 16 bits, k or l > 6).
+ * transforms - us2 [ceil(k/3)][3n] | us1 [ceil(l/3)][3n] words of three 10-bit fields (row 3r + f in bits 10f.. of word row r, each entry U + *bias) |
+ * ut0 [ceil(k/2)][3n] words of two signed 16-bit values; U[m] = -s[m] (m < n), s[m - n] (n <= m < 2n), -s[m - 2n] (2n <= m), s centred, *bias = max |s|
+ * over s1 and s2; *fits = 0 when the key cannot use them (biased sums of `weight` entries outside 10 bits, t0 outside 16 bits, k or l > 6).
  * s1, s2, t as the private key holds them (dilithium.c:810-823); out may be null to ask for *fits only. */
 int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t *params, const int32_t *s1, const int32_t *s2, const int32_t *t,
-                                     uint32_t *out, size_t out_words, int *fits);
+                                     uint32_t *out, size_t out_words, int *fits, uint32_t *bias);
 
 /* test hook: how many 32-bit words of the signer's per-call secrets (masks y, w = A y, NTT(y) where it is kept in HBM) are non-zero in the handle's
  * workspace - 0 behind every signing call (the reference zeroes sc->temp, dilithium.c:1964-1975) */

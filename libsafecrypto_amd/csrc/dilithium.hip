@@ -728,33 +728,40 @@ __global__ __launch_bounds__(256, 2) void dil_cfin_kernel(DilNtt a, DilFin f)
 
 // ---- the finishing kernel WITHOUT transforms (one key for the batch; round 4) -------------------------------------------------------------------
 // c has `weight` coefficients +-1, the key vectors are small (|s1|, |s2| <= eta, |t0| <= 2^(d-1)): c s is `weight` shifted copies of s added up.  With s as a
-// SHIFT TABLE in LDS - U[m] = -s[m] (m < n), U[m] = s[m - n] (n <= m < 2n), so that (x^p s)[j] = U[n + j - p], the sign of the wrapped part in the table -
-// a term is one LDS read per word and one packed 16-bit addition per TWO rows (the rows are stored in pairs, two 16-bit values a word: the sums stay below
-// 2^15 because weight * max|s| does - checked when the key is loaded).  No NTT(c), no products, no inverse transforms, no exchange images: a stage is
-// `weight` x (rows / 2) x 4 reads and additions per lane, nothing in it waits for anything but LDS, the kernel needs a third of the registers and three
-// wavefronts share a SIMD.  Same integers as dil_cfin_kernel computes modulo q, same tests in the same order: the same signatures (tests/test_gpu_dilithium.py
-// runs both).  A lane owns the coefficients j_c = 64 c + 16 (lane & 3) + (lane >> 2), c = 0..3 - word 64 c + lane of a row of w in its 16-byte-piece
-// layout (DilNtt::w_chunked), so a row of w is four fully coalesced loads.
-struct DilFinS { const uint32_t *tabs; };     // us2 [(k+1)/2][2n] | us1 [(l+1)/2][2n] | ut0 [(k+1)/2][2n], 16-bit pairs
-constexpr int CSP = 3;                        // row pairs: k, l <= 6
+// SHIFT TABLE in LDS - U[m] = -s[m] (m < n), s[m - n] (n <= m < 2n), -s[m - 2n] (2n <= m < 3n): (x^p s)[j] = U[n + j - p] and -(x^p s)[j] = U[2n + j - p],
+// the wrap's sign and the term's sign both inside the table - a term of c is one LDS read and one 32-bit addition per THREE rows: a word holds three rows'
+// entries as 10-bit fields, each biased by B = max |s| so that no field ever borrows from its neighbour (the sum of `weight` entries stays below 2^10:
+// checked when the key is loaded; the bias comes off once at the end).  t0 (14 bits) is two rows a word, added up in 32 bits.  No NTT(c), no products, no
+// inverse transforms, no exchange images: the r stage is weight x ceil(k / 3) x 4 reads and additions per lane, nothing in it waits for anything but LDS,
+// the kernel needs half the registers and three wavefronts share a SIMD.  Same integers as dil_cfin_kernel computes modulo q, same tests in the same order,
+// the same packing code: the same signatures.  A lane owns the coefficients j_c = 64 c + 16 (lane & 3) + (lane >> 2), c = 0..3 - word 64 c + lane of a
+// row of w in its 16-byte-piece layout (DilNtt::w_chunked), so a row of w is four fully coalesced loads (tests/test_dilithium_fin_tables.py walks the
+// tables with this mapping on the CPU).
+struct DilFinS { const uint32_t *tabs; uint32_t bias; };     // us2 [ceil(k/3)][3n] | us1 [ceil(l/3)][3n] (10-bit fields) | ut0 [ceil(k/2)][3n] (16-bit pairs)
+constexpr int CSW = 2;                        // words of 10-bit fields per coefficient: k, l <= 6
+constexpr int CSP = 3;                        // row pairs of t0
 
+static inline size_t cfins_table_words(const DilP &P) { return (size_t)((P.k + 2) / 3 + (P.l + 2) / 3 + (P.k + 1) / 2) * 3 * N; }
+static inline size_t cfins_wave_words(const DilP &P) { return 256u * (size_t)P.l + 128u + 64u + 64u * (size_t)P.k + 64u; }
+
+template <int K, int L>
 __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilFinS g)
 {
-    typedef short s2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) uint32_t fin_lds[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const DilP &P = f.P;
-    const int l = P.l, kk = P.k, kp = (kk + 1) / 2, lp2 = (l + 1) / 2;
+    constexpr int l = L, kk = K, kw = (K + 2) / 3, lw = (L + 2) / 3, kp = (K + 1) / 2;
+    static_assert(kw <= CSW && lw <= CSW && kp <= CSP, "row counts");
     const int32_t q = P.q;
-    uint32_t *T2 = fin_lds + 4, *T1 = T2 + kp * 2 * N, *T0 = T1 + lp2 * 2 * N;
-    uint32_t *wbase = T0 + kp * 2 * N + (size_t)wid * (256u * l + 128u + 64u + 64u * kk + 64u);
+    uint32_t *T2 = fin_lds + 4, *T1 = T2 + kw * 3 * N, *T0 = T1 + lw * 3 * N;
+    uint32_t *wbase = T0 + kp * 3 * N + (size_t)wid * (256u * l + 128u + 64u + 64u * kk + 64u);
     uint32_t *zl = wbase;                                               // z of the current attempt, natural order [l][n]
     uint32_t *tw = zl + 256 * l;                                        // signature tail, big-endian words
     uint32_t *cb = tw + 128;                                            // c as n signed bytes
     uint8_t *hl = reinterpret_cast<uint8_t *>(cb + 64);                 // hints [k][n]
-    uint32_t *cpos = cb + 64 + 64 * kk;                                 // c's positions: the +1 ones, then the -1 ones
+    uint32_t *cpos = cb + 64 + 64 * kk;                                 // c's terms: n - p for a +1 at p, 2n - p for a -1
     {
-        const uint32_t words = (uint32_t)(2 * kp + lp2) * 2 * N;
+        const uint32_t words = (uint32_t)(kw + lw + kp) * 3 * N;
         for (uint32_t i = threadIdx.x; i < words / 4; i += 256) reinterpret_cast<uint4 *>(T2)[i] = reinterpret_cast<const uint4 *>(g.tabs)[i];
     }
     if (threadIdx.x == 0) fin_lds[0] = 0;
@@ -771,69 +778,83 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
         uint32_t creg = c32[0];
         for (uint32_t at = 0; at < S && found < 0; at++) {
             const uint32_t slot = aidx * S + at;
-            // the attempt's w (k rows, four words a lane) and the first rows of y are requested before anything is computed
-            int32_t wv[2 * CSP][4];
+            // the attempt's w (k rows, four words a lane) is requested before anything is computed
+            int32_t wv[3 * CSW][4];
 #pragma unroll
-            for (int i = 0; i < 2 * CSP; i++)
+            for (int i = 0; i < 3 * CSW; i++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) wv[i][c] = i < kk ? a.w[((size_t)slot * kk + i) * N + 64 * c + lane] : 0;
             const uint32_t cw = creg;
             cb[lane] = cw;
             if (at + 1 < S) creg = c32[(size_t)(at + 1) * 64];              // the next attempt's c, should this one fail
-            // c's positions: lane's word holds c[4 lane .. 4 lane + 3] as signed bytes
-            uint32_t np = 0, nm = 0;
+            // c's terms: the lane's word holds c[4 lane .. 4 lane + 3] as signed bytes
+            uint32_t mine_t = 0;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { const int32_t b = (int32_t)(int8_t)(cw >> (8 * e)); np += b > 0; nm += b < 0; }
-            uint32_t ip = np, im = nm;                                      // inclusive scans over the lanes
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t tp_ = (uint32_t)__shfl_up((int)ip, o), tm_ = (uint32_t)__shfl_up((int)im, o); if (lane >= o) { ip += tp_; im += tm_; } }
-            const uint32_t tp = (uint32_t)__builtin_amdgcn_readlane((int)ip, 63), tm = (uint32_t)__builtin_amdgcn_readlane((int)im, 63);      // (scalars: the loops below are uniform)
+            for (int e = 0; e < 4; e++) mine_t += (uint8_t)(cw >> (8 * e)) != 0;
+            uint32_t incl_t = mine_t;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t_ = (uint32_t)__shfl_up((int)incl_t, o); if (lane >= o) incl_t += t_; }
+            uint32_t nt = (uint32_t)__builtin_amdgcn_readlane((int)incl_t, 63);      // = weight (a scalar: the loops below are uniform)
+            nt = nt < 64u ? nt : 64u;
             {
-                uint32_t op = ip - np, om = tp + im - nm;
+                uint32_t o_ = incl_t - mine_t;
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     const int32_t b = (int32_t)(int8_t)(cw >> (8 * e));
-                    if (b > 0) cpos[op++] = (uint32_t)(4 * lane + e);
-                    if (b < 0) cpos[om++] = (uint32_t)(4 * lane + e);
+                    if (b != 0 && o_ < 64u) cpos[o_++] = (uint32_t)((b > 0 ? N : 2 * N) - (4 * lane + e));
                 }
             }
             wave_lds_fence();
-            const int my_pos = (uint32_t)lane < tp + tm ? (int)cpos[lane] : 0;    // weight <= 64: position t in lane t
-            // sum of the shifted rows of a table of row pairs: acc[pp][c] (two 16-bit sums a word)
-            auto sparse = [&](const uint32_t *T, int npairs, s2 (&acc)[CSP][4]) {
+            const int my_base = (uint32_t)lane < nt ? (int)cpos[lane] : N;       // weight <= 64: term t in lane t
+            const uint32_t off = nt * g.bias;
+            // sums of the shifted rows of a table of 10-bit fields: acc[r][c], three rows a word
+            // (four terms' reads are issued before the first addition: the loop is a chain of LDS round trips otherwise; weight = 60 leaves no remainder)
+            auto sparse = [&](const uint32_t *T, auto nw_, uint32_t (&acc)[CSW][4]) {
+                constexpr int nw = decltype(nw_)::value;
 #pragma unroll
-                for (int pp = 0; pp < CSP; pp++)
+                for (int r = 0; r < CSW; r++)
 #pragma unroll
-                    for (int c = 0; c < 4; c++) acc[pp][c] = s2{ 0, 0 };
-                for (uint32_t t = 0; t < tp; t++) {
-                    const uint32_t *row = T + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
+                    for (int c = 0; c < 4; c++) acc[r][c] = 0;
+                uint32_t t = 0;
+                for (; t + 4 <= nt; t += 4) {
+                    uint32_t v[4][nw][4];
 #pragma unroll
-                    for (int pp = 0; pp < CSP; pp++)
-                        if (pp < npairs) {
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t *row = T + (jb + __builtin_amdgcn_readlane(my_base, (int)(t + u)));
 #pragma unroll
-                            for (int c = 0; c < 4; c++) { const uint32_t w = row[pp * 2 * N + 64 * c]; s2 v; __builtin_memcpy(&v, &w, 4); acc[pp][c] += v; }
-                        }
+                        for (int r = 0; r < nw; r++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) v[u][r][c] = row[r * 3 * N + 64 * c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int r = 0; r < nw; r++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) acc[r][c] += v[u][r][c];
                 }
-                for (uint32_t t = tp; t < tp + tm; t++) {
-                    const uint32_t *row = T + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
+                for (; t < nt; t++) {
+                    const uint32_t *row = T + (jb + __builtin_amdgcn_readlane(my_base, (int)t));
 #pragma unroll
-                    for (int pp = 0; pp < CSP; pp++)
-                        if (pp < npairs) {
+                    for (int r = 0; r < nw; r++)
 #pragma unroll
-                            for (int c = 0; c < 4; c++) { const uint32_t w = row[pp * 2 * N + 64 * c]; s2 v; __builtin_memcpy(&v, &w, 4); acc[pp][c] -= v; }
-                        }
+                        for (int c = 0; c < 4; c++) acc[r][c] += row[r * 3 * N + 64 * c];
                 }
             };
-            s2 acc[CSP][4];
+            auto field = [&](const uint32_t (&acc)[CSW][4], int i, int c) -> int32_t {          // row i's sum with the bias taken off
+                const uint32_t w = acc[i / 3][c];
+                const uint32_t raw = (i % 3) == 0 ? (w & 1023u) : (i % 3) == 1 ? ((w >> 10) & 1023u) : (w >> 20);
+                return (int32_t)raw - (int32_t)off;
+            };
+            uint32_t acc[CSW][4];
             bool bad = false;
             // ---- r = w - c s2; ||LowBits(r)||inf < gamma_2 - beta (dilithium.c:1671-1700)
-            sparse(T2, kp, acc);
-            int32_t rr[2 * CSP][4];
+            sparse(T2, std::integral_constant<int, kw>{}, acc);
+            int32_t rr[3 * CSW][4];
 #pragma unroll
-            for (int i = 0; i < 2 * CSP; i++)
+            for (int i = 0; i < 3 * CSW; i++)
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
-                    const int32_t cs = (i & 1) ? (int32_t)acc[i >> 1][c].y : (int32_t)acc[i >> 1][c].x;
-                    int32_t v = wv[i][c] - cs;                              // w canonical, |c s2| small: one correction either way
+                    int32_t v = wv[i][c] - field(acc, i, c);                  // w canonical, |c s2| small: one correction either way
                     v += (v >> 31) & q; v -= (v >= q) ? q : 0;
                     rr[i][c] = v;
                     int32_t a0;
@@ -844,19 +865,18 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
             bool ok = __ballot(bad) == 0;
             if (ok) {
                 // ---- z = y + c s1, normalised; ||z||inf < gamma_1 - beta (dilithium.c:1655-1669)
-                int32_t yv[2 * CSP][4];
+                int32_t yv[3 * CSW][4];
 #pragma unroll
-                for (int i = 0; i < 2 * CSP; i++)
+                for (int i = 0; i < 3 * CSW; i++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) yv[i][c] = i < l ? a.y[((size_t)slot * l + i) * N + 64 * c + jb] : 0;
-                sparse(T1, lp2, acc);
+                sparse(T1, std::integral_constant<int, lw>{}, acc);
 #pragma unroll
-                for (int i = 0; i < 2 * CSP; i++)
+                for (int i = 0; i < 3 * CSW; i++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
                         if (i < l) {
-                            const int32_t cs = (i & 1) ? (int32_t)acc[i >> 1][c].y : (int32_t)acc[i >> 1][c].x;
-                            int32_t v = yv[i][c] - q + cs;                  // y is stored as q + (a value in (-gamma_1, gamma_1)) (dil_expand_kernel)
+                            int32_t v = yv[i][c] - q + field(acc, i, c);    // y is stored as q + (a value in (-gamma_1, gamma_1)) (dil_expand_kernel)
                             v += (v >> 31) & q;
                             zl[i * N + 64 * c + jb] = (uint32_t)v;
                             bad |= norm_bad((uint32_t)v, (uint32_t)q, (uint32_t)a.gamma1_beta);
@@ -873,18 +893,32 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
                 for (int i = 0; i < 2 * CSP; i++)
 #pragma unroll
                     for (int c = 0; c < 4; c++) a0s[i][c] = 0;
-                for (uint32_t t = 0; t < tp + tm; t++) {
-                    const uint32_t *row = T0 + (N + jb - __builtin_amdgcn_readlane(my_pos, (int)t));
-                    const bool neg = t >= tp;
+                uint32_t t = 0;
+                for (; t + 2 <= nt; t += 2) {
+                    uint32_t v[2][kp][4];
 #pragma unroll
-                    for (int pp = 0; pp < CSP; pp++)
-                        if (pp < kp) {
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t *row = T0 + (jb + __builtin_amdgcn_readlane(my_base, (int)(t + u)));
 #pragma unroll
-                            for (int c = 0; c < 4; c++) {
-                                const uint32_t w = row[pp * 2 * N + 64 * c];
-                                const int32_t lo = (int32_t)(int16_t)w, hi = (int32_t)w >> 16;
-                                a0s[2 * pp][c] += neg ? -lo : lo; a0s[2 * pp + 1][c] += neg ? -hi : hi;
-                            }
+                        for (int pp = 0; pp < kp; pp++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) v[u][pp][c] = row[pp * 3 * N + 64 * c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++)
+#pragma unroll
+                        for (int pp = 0; pp < kp; pp++)
+#pragma unroll
+                            for (int c = 0; c < 4; c++) { a0s[2 * pp][c] += (int32_t)(int16_t)v[u][pp][c]; a0s[2 * pp + 1][c] += (int32_t)v[u][pp][c] >> 16; }
+                }
+                for (; t < nt; t++) {
+                    const uint32_t *row = T0 + (jb + __builtin_amdgcn_readlane(my_base, (int)t));
+#pragma unroll
+                    for (int pp = 0; pp < kp; pp++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const uint32_t w = row[pp * 3 * N + 64 * c];
+                            a0s[2 * pp][c] += (int32_t)(int16_t)w; a0s[2 * pp + 1][c] += (int32_t)w >> 16;
                         }
                 }
                 uint32_t cnt = 0;
@@ -927,8 +961,8 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
             const int kn = kk * P.n, h_bits = 8 + ((kk + 1) >> 1);
             tw[lane] = 0; tw[lane + 64] = 0;
             wave_lds_fence();
-            auto put = [&](uint32_t off, uint32_t v, int bits) {                // bits <= 16: at most two words
-                const uint32_t w = off >> 5; const int sh = 32 - (int)(off & 31) - bits;
+            auto put = [&](uint32_t off_, uint32_t v, int bits) {               // bits <= 16: at most two words
+                const uint32_t w = off_ >> 5; const int sh = 32 - (int)(off_ & 31) - bits;
                 if (sh >= 0) atomicOr(&tw[w], v << sh);
                 else { atomicOr(&tw[w], v >> (-sh)); atomicOr(&tw[w + 1], v << (32 + sh)); }
             };
@@ -1096,7 +1130,7 @@ struct sc_hip_dilithium {
     bool have_priv, have_pub;
     uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
     uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
-    uint32_t *d_tabs;                                 // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel); null: the key does not fit them
+    uint32_t *d_tabs; uint32_t fin_bias;              // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel) and their fields' bias; null: the key does not fit them
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
     size_t cap;                                       // per message / per signature (verify): mu, kappa, trials, act, z, h, c, ch
@@ -1220,38 +1254,52 @@ static int load_matrix(sc_hip_dilithium *d, const int32_t *h_Ahat)
     return (hipDeviceSynchronize() == hipSuccess) ? SC_HIP_SUCCESS : fail("dilithium matrix load: kernel failed");
 }
 
-// dil_cfins_kernel's shift tables: us2 | us1 | ut0, rows in pairs, two 16-bit values a word; U[m] = -s[m] (m < n), s[m - n] (m >= n), s centred.  Returns
-// false for a key whose products with c could leave 16 bits (s1, s2) or whose t0 does not fit 16 bits - none the reference generates; such a key keeps
-// the transform kernel.  t0 canonical in [0, q) or centred.
-static bool fin_tables(const DilP &P, const int32_t *s1, const int32_t *s2, const int32_t *t0, std::vector<uint32_t> &tabs)
+// dil_cfins_kernel's shift tables: us2 [ceil(k/3)][3n] | us1 [ceil(l/3)][3n], three rows a word as 10-bit fields holding U + bias, and ut0 [ceil(k/2)][3n], two
+// rows a word as signed 16-bit values; U[m] = -s[m] (m < n), s[m - n] (n <= m < 2n), -s[m - 2n] (2n <= m), s centred; bias = max |s| over s1 and s2.
+// Returns false for a key whose biased sums of `weight` entries could leave 10 bits or whose t0 does not fit 16 bits - none the reference generates;
+// such a key keeps the transform kernel.  t0 canonical in [0, q) or centred.
+static bool fin_tables(const DilP &P, const int32_t *s1, const int32_t *s2, const int32_t *t0, std::vector<uint32_t> &tabs, uint32_t &bias)
 {
     const int k = P.k, l = P.l, q = P.q;
-    const int kp = (k + 1) / 2, lp2 = (l + 1) / 2;
-    tabs.assign((size_t)(2 * kp + lp2) * 2 * N, 0u);
-    bool fits = k <= 2 * CSP && l <= 2 * CSP && P.weight >= 1 && P.weight <= 64;
+    const int kw = (k + 2) / 3, lw = (l + 2) / 3, kp = (k + 1) / 2;
+    tabs.assign(cfins_table_words(P), 0u);
+    bool fits = k <= 3 * CSW && l <= 3 * CSW && k <= 2 * CSP && P.weight >= 1 && P.weight <= 64;
     auto centred = [&](int32_t x) { int32_t r = x % q; if (r < 0) r += q; return r > (q - 1) / 2 ? r - q : r; };
-    auto fill = [&](uint32_t *T, const int32_t *src, int rows, int32_t bound) {
+    int32_t b = 0;
+    for (size_t i = 0; i < (size_t)l * N; i++) { const int32_t v = centred(s1[i]); b = std::max(b, v < 0 ? -v : v); }
+    for (size_t i = 0; i < (size_t)k * N; i++) { const int32_t v = centred(s2[i]); b = std::max(b, v < 0 ? -v : v); }
+    if ((int64_t)2 * b * (P.weight > 0 ? P.weight : 1) > 1023) { fits = false; b = 0; }
+    bias = (uint32_t)b;
+    auto fill10 = [&](uint32_t *T, const int32_t *src, int rows) {
         for (int i = 0; i < rows; i++)
             for (int j = 0; j < N; j++) {
-                const int32_t v = centred(src[(size_t)i * N + j]);
-                if (v > bound || v < -bound) fits = false;
-                const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v), pos = (uint32_t)(uint16_t)(int16_t)v;
-                uint32_t *row = T + (size_t)(i >> 1) * 2 * N;
-                const int sh = 16 * (i & 1);
-                row[j] |= neg << sh; row[N + j] |= pos << sh;
+                const int32_t v = fits ? centred(src[(size_t)i * N + j]) : 0;
+                uint32_t *row = T + (size_t)(i / 3) * 3 * N;
+                const int sh = 10 * (i % 3);
+                row[j] |= (uint32_t)(b - v) << sh; row[N + j] |= (uint32_t)(b + v) << sh; row[2 * N + j] |= (uint32_t)(b - v) << sh;
             }
     };
-    fill(tabs.data(), s2, k, 32767 / (P.weight > 0 ? P.weight : 1));
-    fill(tabs.data() + (size_t)kp * 2 * N, s1, l, 32767 / (P.weight > 0 ? P.weight : 1));
-    fill(tabs.data() + (size_t)(kp + lp2) * 2 * N, t0, k, 32767);
+    fill10(tabs.data(), s2, k);
+    fill10(tabs.data() + (size_t)kw * 3 * N, s1, l);
+    uint32_t *T0 = tabs.data() + (size_t)(kw + lw) * 3 * N;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < N; j++) {
+            const int32_t v = centred(t0[(size_t)i * N + j]);
+            if (v > 32767 || v < -32767) fits = false;
+            const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v), pos = (uint32_t)(uint16_t)(int16_t)v;
+            uint32_t *row = T0 + (size_t)(i >> 1) * 3 * N;
+            const int sh = 16 * (i & 1);
+            row[j] |= neg << sh; row[N + j] |= pos << sh; row[2 * N + j] |= neg << sh;
+        }
+    (void)kp;
     return fits;
 }
 
 // test hook (include/sc_hip_bench.h): the tables of a key, built on the host exactly as sc_hip_dilithium_set_privkey builds them - no device involved
 extern "C" int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t *params, const int32_t *s1, const int32_t *s2, const int32_t *t,
-                                                uint32_t *out, size_t out_words, int *fits)
+                                                uint32_t *out, size_t out_words, int *fits, uint32_t *bias)
 {
-    if (!params || !s1 || !s2 || !t || !fits) return fail("dilithium_fin_tables_host: null argument");
+    if (!params || !s1 || !s2 || !t || !fits || !bias) return fail("dilithium_fin_tables_host: null argument");
     DilP P;
     memcpy(&P, params, sizeof P);
     if (P.n != N || P.k < 1 || P.k > 8 || P.l < 1 || P.l > 8 || P.q < 2 || P.d < 1 || P.d > 30) return fail("dilithium_fin_tables_host: unsupported parameters");
@@ -1259,7 +1307,7 @@ extern "C" int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t 
     const int32_t mask = (1 << P.d) - 1, sign = 1 << P.d, thresh = 1 << (P.d - 1);
     for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = x; }
     std::vector<uint32_t> tabs;
-    *fits = fin_tables(P, s1, s2, t0.data(), tabs) ? 1 : 0;
+    *fits = fin_tables(P, s1, s2, t0.data(), tabs, *bias) ? 1 : 0;
     if (out) {
         if (out_words < tabs.size()) return fail("dilithium_fin_tables_host: output too small");
         memcpy(out, tabs.data(), tabs.size() * 4);
@@ -1281,7 +1329,7 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
     {
         std::vector<uint32_t> tabs;
-        const bool fits = fin_tables(d->P, s1, s2, t0.data(), tabs);
+        const bool fits = fin_tables(d->P, s1, s2, t0.data(), tabs, d->fin_bias);
         if (fits) {
             if (!d->d_tabs) HIPCHK(hipMalloc((void **)&d->d_tabs, tabs.size() * 4));
             HIPCHK(sc::copy_in(d->d_tabs, tabs.data(), tabs.size() * 4));
@@ -1480,8 +1528,8 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     const size_t fin_lds = (4 + 4 * cfin_wave_words(P)) * sizeof(uint32_t);
     // one key for the batch whose coefficient-domain tables exist: the finishing kernel without transforms - ONLY behind tuning bit 11: the kernel was written
     // while the GPU pool was closed to this build and has not run on hardware yet; the transform kernel stays the product path until it has
-    const bool sparse_fin = d->tune_sparse_fin && !ks.per_item && ks.s1 == d->d_s1 && d->d_tabs && !d->tune_w24;
-    const size_t fins_lds = (4 + (size_t)(2 * ((P.k + 1) / 2) + (P.l + 1) / 2) * 2 * N + 4 * (256u * P.l + 128u + 64u + 64u * P.k + 64u)) * sizeof(uint32_t);
+    const bool sparse_fin = d->tune_sparse_fin && !ks.per_item && ks.s1 == d->d_s1 && d->d_tabs && !d->tune_w24 && l == k - 1 && k >= 3 && k <= 6;     // (the four parameter sets, dilithium_params.c)
+    const size_t fins_lds = (4 + cfins_table_words(P) + 4 * cfins_wave_words(P)) * sizeof(uint32_t);
     DilFin f;
     f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
     f.s1_stride = ks.per_item ? (size_t)l * N : 0; f.k_stride = ks.per_item ? (size_t)k * N : 0;
@@ -1537,7 +1585,13 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
                         else if (l > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, true, false>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else if (k > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, false, true>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else hipLaunchKernelGGL((dil_cfin_kernel<M, false, false>), dim3(fb), dim3(256), fin_lds, s, a, f); } while (0)
-            if (sparse_fin) hipLaunchKernelGGL(dil_cfins_kernel, dim3(fb), dim3(256), fins_lds, s, a, f, DilFinS{ d->d_tabs });
+            if (sparse_fin) {
+                const DilFinS g{ d->d_tabs, d->fin_bias };
+                if (k == 6 && l == 5) hipLaunchKernelGGL((dil_cfins_kernel<6, 5>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
+                else if (k == 5 && l == 4) hipLaunchKernelGGL((dil_cfins_kernel<5, 4>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
+                else if (k == 4 && l == 3) hipLaunchKernelGGL((dil_cfins_kernel<4, 3>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
+                else hipLaunchKernelGGL((dil_cfins_kernel<3, 2>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
+            }
             else if (a.sg) SC_CFIN(MODE_S32); else SC_CFIN(MODE_U32);
 #undef SC_CFIN
             HIPCHK(hipGetLastError());
