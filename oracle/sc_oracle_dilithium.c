@@ -227,6 +227,31 @@ int orc_dilithium_sign(const int32_t *par, const int32_t *s1, const int32_t *s2,
     return 0;
 }
 
+/* Test support for the CPU wave emulation (tests/emu/): what the signer's kernels in front of the finishing kernel leave per attempt - the mask y
+ * (as expand_mask writes it: q + a value in (-gamma_1, gamma_1)), w = A y canonical and the challenge c - for attempts kappa0 .. kappa0 + count - 1 of one
+ * message, by the same routines orc_dilithium_sign runs (dilithium.c:1555-1650). */
+int orc_dilithium_attempts(const int32_t *par, const uint8_t *K, const uint8_t *tr, const int32_t *Ahat, const uint8_t *msg, size_t mlen,
+                           uint32_t kappa0, uint32_t count, int32_t *y_out, int32_t *w_out, int8_t *c_out)
+{
+    dilp_t P; memcpy(&P, par, sizeof P);
+    const int n = P.n, k = P.k, l = P.l, q = P.q, alpha = 2 * P.gamma2;
+    int32_t *w_t = malloc(sizeof(int32_t) * (size_t)n * 3), *r_t = w_t + n, *c = r_t + n;
+    if (orc_make_tables(q, n, w_t, r_t)) { free(w_t); return 1; }
+    uint8_t *w1b = malloc((size_t)k * n);
+    uint8_t mu[48];
+    { shake_t x; shake_init(&x, 256); shake_absorb(&x, tr, 48); shake_absorb(&x, msg, mlen); shake_final(&x); shake_squeeze(&x, mu, 48); }
+    for (uint32_t a = 0; a < count; a++) {
+        int32_t *y = y_out + (size_t)a * l * n, *w = w_out + (size_t)a * k * n;
+        expand_mask(K, mu, (uint16_t)(kappa0 + a), P.gamma1, q, (size_t)l * n, y);
+        matvec(w, Ahat, y, n, k, l, q, w_t, r_t);
+        for (int i = 0; i < k * n; i++) { int32_t r1; w1b[i] = (uint8_t)round_alpha((uint32_t)w[i], &r1, alpha, q); }
+        h_function(c, mu, w1b, (size_t)k * n, n, P.weight);
+        for (int i = 0; i < n; i++) c_out[(size_t)a * n + i] = (int8_t)c[i];
+    }
+    free(w1b); free(w_t);
+    return 0;
+}
+
 /* module_lwe.c:140-180 collision_resistant_hash_t1: SHAKE256( pack(rho as 32x8 bits, t1 as k*n x bits) ) -> 48 B */
 void orc_dilithium_crh_t1(const uint8_t *rho, const int32_t *t1, size_t len, int bits, uint8_t *out48)
 {

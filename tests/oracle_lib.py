@@ -347,6 +347,20 @@ def dilithium_sign(key, msg):
     return bytes(sig[:sl.value]), tr.value
 
 
+def dilithium_attempts(key, msg, kappa0, count):
+    """(y [count][l][n] as ExpandMask writes it, w = A y [count][k][n] canonical, c [count][n] int8) of attempts kappa0 .. kappa0 + count - 1"""
+    y = np.zeros((count, key.l, key.n), dtype=np.int32)
+    w = np.zeros((count, key.k, key.n), dtype=np.int32)
+    c = np.zeros((count, key.n), dtype=np.int8)
+    m, ml = _msgbuf(msg)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    f = lib().orc_dilithium_attempts
+    f.argtypes = [C.c_void_p] * 5 + [C.c_size_t, C.c_uint32, C.c_uint32] + [C.c_void_p] * 3
+    rc = f(p(key.par), p(key.K), p(key.tr), p(key.Ahat), p(m), ml, kappa0, count, p(y), p(w), p(c))
+    assert rc == 0
+    return y, w, c
+
+
 def dilithium_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))

@@ -1,6 +1,6 @@
 """The Dilithium finishing kernel WITHOUT transforms (dil_cfins_kernel, sc_hip_dilithium_set_tuning bit 11): c s2, c s1, c t0 as sums of shifted table
 rows in the coefficient domain instead of NTT(c) and five-to-six inverse transforms per stage.  It was written while the GPU pool was closed to this
-build and HAS NOT RUN ON HARDWARE: it is not the product path (the tuning bit selects it) and this file is skipped unless SC_TEST_UNVALIDATED=1 -
+build and HAS NOT RUN ON HARDWARE (its text has run on the CPU lane by lane against the oracle: tests/test_emu_dil_cfins.py): it is not the product path (the tuning bit selects it) and this file is skipped unless SC_TEST_UNVALIDATED=1 -
 `SC_TEST_UNVALIDATED=1 python -m pytest tests/test_gpu_zz_dilithium_sparse_fin.py -q`, then `python tools/bench_scheme.py dil_sign 9` against
 `SC_BENCH_DIL_TUNING=2048 python tools/bench_scheme.py dil_sign 9`, is the first thing to do with a GPU.  Same bar as every other form of the
 signer: the reference's signatures byte for byte, attempt counts included."""
