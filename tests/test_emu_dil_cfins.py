@@ -100,7 +100,7 @@ def _runtime(name):
     return out if os.path.isabs(out) and os.path.exists(out) else None
 
 
-@pytest.mark.parametrize('tag,B,S', [('dil3', 10, 3), ('dil2', 5, 2), ('dil1', 5, 3), ('dil0', 6, 1)])
+@pytest.mark.parametrize('tag,B,S', [('dil3', 10, 3), ('dil2', 5, 2), ('dil1', 5, 3), ('dil0', 6, 1), ('dil3', 3, 40)])
 def test_rounds_of_the_signer_give_the_oracles_signatures(tag, B, S):
     """ragged last workgroup (B not a multiple of 4), several rounds (the slot count shrinks as sign_core's does), every parameter set"""
     out = _run(_build(None), tag, B, S, 7 * B + S)
