@@ -12,14 +12,22 @@
 // the same packing code: the same signatures.  A lane owns the coefficients j_c = 64 c + 16 (lane & 3) + (lane >> 2), c = 0..3 - word 64 c + lane of a
 // row of w in its 16-byte-piece layout (DilNtt::w_chunked), so a row of w is four fully coalesced loads (tests/test_dilithium_fin_tables.py walks the
 // tables with this mapping on the CPU).
-struct DilFinS { const uint32_t *tabs; uint32_t bias; };     // us2 [ceil(k/3)][3n] | us1 [ceil(l/3)][3n] (10-bit fields) | ut0 [ceil(k/2)][3n] (16-bit pairs)
+struct DilFinS {
+    const uint32_t *tabs; uint32_t bias;      // us2 [ceil(k/3)][3n] | us1 [ceil(l/3)][3n] (10-bit fields) | ut0 [ceil(k/2)][3n] (16-bit pairs)
+    // PERKEY (a key per message): the keys in the coefficient domain as the caller holds them, s1 [item][l][n], s2 [item][k][n] (canonical or centred), t0
+    // [item][k][n] (canonical: dil_t0_kernel); every wavefront builds its message's tables in LDS itself.  *refused is OR-ed with 1 when a key's
+    // coefficients exceed `bias` (the fields could run into each other): the message is then neither signed nor queued, and the host runs the call again
+    // with the transform kernel
+    const int32_t *s1, *s2, *t0; uint32_t *refused;
+};
 constexpr int CSW = 2;                        // words of 10-bit fields per coefficient: k, l <= 6
 constexpr int CSP = 3;                        // row pairs of t0
 
 static inline size_t cfins_table_words(const DilP &P) { return (size_t)((P.k + 2) / 3 + (P.l + 2) / 3 + (P.k + 1) / 2) * 3 * N; }
 static inline size_t cfins_wave_words(const DilP &P) { return 256u * (size_t)P.l + 128u + 64u + 64u * (size_t)P.k + 64u; }
 
-template <int K, int L>
+// PERKEY: two wavefronts a workgroup (each holds its own 21 KB of tables: two workgroups a CU), launched as (messages + 1) / 2 workgroups of 128 threads
+template <int K, int L, bool PERKEY = false>
 __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilFinS g)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t fin_lds[];
@@ -28,21 +36,22 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
     constexpr int l = L, kk = K, kw = (K + 2) / 3, lw = (L + 2) / 3, kp = (K + 1) / 2;
     static_assert(kw <= CSW && lw <= CSW && kp <= CSP, "row counts");
     const int32_t q = P.q;
-    uint32_t *T2 = fin_lds + 4, *T1 = T2 + kw * 3 * N, *T0 = T1 + lw * 3 * N;
-    uint32_t *wbase = T0 + kp * 3 * N + (size_t)wid * (256u * l + 128u + 64u + 64u * kk + 64u);
+    constexpr int WPB = PERKEY ? 2 : 4;                                 // wavefronts per workgroup
+    constexpr uint32_t TW = (uint32_t)(kw + lw + kp) * 3 * N, WW = 256u * l + 128u + 64u + 64u * kk + 64u;
+    uint32_t *T2 = fin_lds + 4 + (PERKEY ? (size_t)wid * (TW + WW) : 0), *T1 = T2 + kw * 3 * N, *T0 = T1 + lw * 3 * N;
+    uint32_t *wbase = PERKEY ? T2 + TW : T2 + TW + (size_t)wid * WW;
     uint32_t *zl = wbase;                                               // z of the current attempt, natural order [l][n]
     uint32_t *tw = zl + 256 * l;                                        // signature tail, big-endian words
     uint32_t *cb = tw + 128;                                            // c as n signed bytes
     uint8_t *hl = reinterpret_cast<uint8_t *>(cb + 64);                 // hints [k][n]
     uint32_t *cpos = cb + 64 + 64 * kk;                                 // c's terms: n - p for a +1 at p, 2n - p for a -1
-    {
-        const uint32_t words = (uint32_t)(kw + lw + kp) * 3 * N;
-        for (uint32_t i = threadIdx.x; i < words / 4; i += 256) reinterpret_cast<uint4 *>(T2)[i] = reinterpret_cast<const uint4 *>(g.tabs)[i];
+    if constexpr (!PERKEY) {
+        for (uint32_t i = threadIdx.x; i < TW / 4; i += 256) reinterpret_cast<uint4 *>(T2)[i] = reinterpret_cast<const uint4 *>(g.tabs)[i];
     }
     if (threadIdx.x == 0) fin_lds[0] = 0;
     __syncthreads();
     const uint32_t nact = f.rs[RS_NACT], S = f.rs[RS_S];
-    const uint32_t aidx = blockIdx.x * 4 + wid;
+    const uint32_t aidx = blockIdx.x * WPB + wid;
     const bool live = aidx < nact;                                      // wave-uniform
     int found = -1;
     uint32_t item = 0;
@@ -51,7 +60,47 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
         const int jb = 16 * (lane & 3) + (lane >> 2);                   // the lane's coefficient inside every block of 64
         const uint32_t *c32 = reinterpret_cast<const uint32_t *>(f.c8) + (size_t)aidx * S * 64 + lane;
         uint32_t creg = c32[0];
-        for (uint32_t at = 0; at < S && found < 0; at++) {
+        if constexpr (PERKEY) {
+            // the message's key -> the wavefront's tables (what fin_tables in dilithium.hip builds on the host for the handle's key)
+            const int32_t B = (int32_t)g.bias, hq = (q - 1) >> 1;
+            bool wide = false;
+            auto cen = [&](int32_t x) { x -= (x > hq) ? q : 0; x += (x < -hq) ? q : 0; return x; };
+            auto build10 = [&](uint32_t *T, const int32_t *src, auto rows_) {
+                constexpr int rows = decltype(rows_)::value;
+#pragma unroll
+                for (int r = 0; r < (rows + 2) / 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const int j = lane + 64 * c;
+                        uint32_t neg = 0, pos = 0;
+#pragma unroll
+                        for (int fi = 0; fi < 3; fi++)
+                            if (3 * r + fi < rows) {
+                                const int32_t v = cen(src[(3 * r + fi) * N + j]);
+                                wide |= v > B || v < -B;
+                                neg |= (uint32_t)(B - v) << (10 * fi); pos |= (uint32_t)(B + v) << (10 * fi);
+                            }
+                        T[r * 3 * N + j] = neg; T[r * 3 * N + N + j] = pos; T[r * 3 * N + 2 * N + j] = neg;
+                    }
+            };
+            build10(T2, g.s2 + (size_t)item * K * N, std::integral_constant<int, K>{});
+            build10(T1, g.s1 + (size_t)item * L * N, std::integral_constant<int, L>{});
+            const int32_t *t0 = g.t0 + (size_t)item * K * N;
+#pragma unroll
+            for (int pp = 0; pp < kp; pp++)
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int j = lane + 64 * c;
+                    const int32_t v0 = cen(t0[2 * pp * N + j]), v1 = 2 * pp + 1 < K ? cen(t0[(2 * pp + 1) * N + j]) : 0;
+                    wide |= v0 > 32767 || v0 < -32767 || v1 > 32767 || v1 < -32767;
+                    const uint32_t neg = (uint32_t)(uint16_t)(int16_t)(-v0) | ((uint32_t)(uint16_t)(int16_t)(-v1) << 16);
+                    const uint32_t pos = (uint32_t)(uint16_t)(int16_t)v0 | ((uint32_t)(uint16_t)(int16_t)v1 << 16);
+                    T0[pp * 3 * N + j] = neg; T0[pp * 3 * N + N + j] = pos; T0[pp * 3 * N + 2 * N + j] = neg;
+                }
+            wave_lds_fence();
+            if (__ballot(wide) != 0) { found = -2; if (lane == 0) atomicOr(g.refused, 1u); }
+        }
+        for (uint32_t at = 0; at < S && found == -1; at++) {
             const uint32_t slot = aidx * S + at;
             // the attempt's w (k rows, four words a lane) is requested before anything is computed
             int32_t wv[3 * CSW][4];
@@ -263,7 +312,7 @@ __global__ __launch_bounds__(256) void dil_cfins_kernel(DilNtt a, DilFin f, DilF
             if (lane == 0) { f.trials[item] = f.kappa[item] + at + 1; f.siglens[item] = zbytes + tbytes; }
         }
     }
-    const bool again = live && found < 0 && lane == 0;
+    const bool again = live && found == -1 && lane == 0;
     uint32_t rpos = 0;
     if (again) rpos = atomicAdd(&fin_lds[0], 1u);
     __syncthreads();

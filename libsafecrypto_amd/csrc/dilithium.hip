@@ -1194,6 +1194,10 @@ struct DilSignKeys {
     bool per_item;
     bool A_nat;                           // A is in natural order and plain form (as the expansion writes it): NTT(y) then carries the Montgomery factor (DilNtt::key_nat)
     hipEvent_t matrix_ready;              // non-null: A is being written on another stream; the first kernel that reads it waits for this
+    // per_item, optional (dil_cfins_kernel<K, L, true>, tuning bit 11): the keys in the coefficient domain - s1 [item][l][n], s2 [item][k][n] as the caller
+    // holds them, t0 [item][k][n] canonical; *sparse_refused = true when a key was outside the range that kernel serves (the caller signs again without it)
+    const int32_t *s1n = nullptr, *s2n = nullptr, *t0n = nullptr;
+    bool *sparse_refused = nullptr;
 };
 
 static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch, const uint8_t *d_msgs, size_t msg_stride, const uint32_t *d_mlens,
@@ -1260,6 +1264,13 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
     // one key for the batch whose coefficient-domain tables exist: the finishing kernel without transforms - ONLY behind tuning bit 11: the kernel was written
     // while the GPU pool was closed to this build and has not run on hardware yet; the transform kernel stays the product path until it has
     const bool sparse_fin = d->tune_sparse_fin && !ks.per_item && ks.s1 == d->d_s1 && d->d_tabs && !d->tune_w24 && l == k - 1 && k >= 3 && k <= 6;     // (the four parameter sets, dilithium_params.c)
+    // a key per message: the same kernel building every message's tables in LDS from the raw key rows, the fields sized for |s| <= eta (what key generation
+    // gives; anything else is refused on the device and signed again by the caller through the transform kernel)
+    const bool sparse_keys = d->tune_sparse_fin && ks.per_item && ks.s1n && ks.s2n && ks.t0n && ks.sparse_refused && l == k - 1 && k >= 3 && k <= 6
+                             && P.eta >= 1 && 2 * P.eta * P.weight <= 1023 && P.d <= 16;
+    const size_t fink_lds = (4 + 2 * (cfins_table_words(P) + cfins_wave_words(P))) * sizeof(uint32_t);
+    uint32_t *refused_dev = d->cnt + 8;                                 // (d->cnt is 16 words; the rounds use the first)
+    if (sparse_keys) HIPCHK(hipMemsetAsync(refused_dev, 0, 4, s));
     const size_t fins_lds = (4 + cfins_table_words(P) + 4 * cfins_wave_words(P)) * sizeof(uint32_t);
     DilFin f;
     f.c8 = d->c8; f.s1 = ks.s1; f.s2 = ks.s2; f.t0 = ks.t0;
@@ -1316,7 +1327,14 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
                         else if (l > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, true, false>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else if (k > 4) hipLaunchKernelGGL((dil_cfin_kernel<M, false, true>), dim3(fb), dim3(256), fin_lds, s, a, f); \
                         else hipLaunchKernelGGL((dil_cfin_kernel<M, false, false>), dim3(fb), dim3(256), fin_lds, s, a, f); } while (0)
-            if (sparse_fin) {
+            if (sparse_keys) {
+                const DilFinS g{ nullptr, (uint32_t)P.eta, ks.s1n, ks.s2n, ks.t0n, refused_dev };
+                const unsigned fk = (left + 1) / 2;
+                if (k == 6) hipLaunchKernelGGL((dil_cfins_kernel<6, 5, true>), dim3(fk), dim3(128), fink_lds, s, a, f, g);
+                else if (k == 5) hipLaunchKernelGGL((dil_cfins_kernel<5, 4, true>), dim3(fk), dim3(128), fink_lds, s, a, f, g);
+                else if (k == 4) hipLaunchKernelGGL((dil_cfins_kernel<4, 3, true>), dim3(fk), dim3(128), fink_lds, s, a, f, g);
+                else hipLaunchKernelGGL((dil_cfins_kernel<3, 2, true>), dim3(fk), dim3(128), fink_lds, s, a, f, g);
+            } else if (sparse_fin) {
                 const DilFinS g{ d->d_tabs, d->fin_bias };
                 if (k == 6 && l == 5) hipLaunchKernelGGL((dil_cfins_kernel<6, 5>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
                 else if (k == 5 && l == 4) hipLaunchKernelGGL((dil_cfins_kernel<5, 4>), dim3(fb), dim3(256), fins_lds, s, a, f, g);
@@ -1337,6 +1355,12 @@ static int sign_core(sc_hip_dilithium_t *d, const DilSignKeys &ks, size_t batch,
         HIPCHK(hipStreamSynchronize(s));
         left = cnt;
         todo = 1;
+    }
+    if (sparse_keys) {
+        uint32_t refused = 0;
+        HIPCHK(hipMemcpyAsync(&refused, refused_dev, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        *ks.sparse_refused = refused != 0;
     }
     return SC_HIP_SUCCESS;
 }
@@ -1546,8 +1570,14 @@ extern "C" int sc_hip_dilithium_sign_keys(sc_hip_dilithium_t *d, size_t batch, c
     a.in = d_s1; a.out_int = s1h; if (launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)l, 1, s)) rc = SC_HIP_FAILURE;
     a.in = d_s2; a.out_int = s2h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
     a.in = t0n; a.out_int = t0h; if (rc == SC_HIP_SUCCESS && launch_dil<DOP_KEYPREP>(d, a, B * (uint32_t)k, 1, s)) rc = SC_HIP_FAILURE;
-    const DilSignKeys ks = { reinterpret_cast<const uint32_t *>(ab), nullptr, s1h, s2h, t0h, d_K, d_tr, true, true, d->ev_join };
+    DilSignKeys ks = { reinterpret_cast<const uint32_t *>(ab), nullptr, s1h, s2h, t0h, d_K, d_tr, true, true, d->ev_join };
+    bool refused = false;
+    if (d->tune_sparse_fin) { ks.s1n = d_s1; ks.s2n = d_s2; ks.t0n = t0n; ks.sparse_refused = &refused; }
     if (rc == SC_HIP_SUCCESS) rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    if (rc == SC_HIP_SUCCESS && refused) {                          // a key outside the table kernel's range: the whole call again through the transform kernel
+        ks.s1n = nullptr; ks.matrix_ready = nullptr;
+        rc = sign_core(d, ks, batch, d_msgs, msg_stride, d_mlens, fixed_len, d_sigs, sig_stride, d_siglens, d_trials, stream);
+    }
     (void)hipStreamWaitEvent(s, d->ev_join, 0);                    // (again, in case the signing did not get as far as its first matrix product)
     d->kws.wipe_upto(secret_end, s);                                // the per-item t0, NTT(s1), NTT(s2), NTT(t0)
     return rc;

@@ -59,3 +59,26 @@ def test_same_bytes_as_the_transform_kernel(eng, G, B):
     assert d.verify_host(msgs, got) == [0] * B
     d.set_tuning(0)
     d.close()
+
+
+@pytest.mark.parametrize('tag,B', [('dil3', 1), ('dil3', 1500), ('dil1', 333)])
+def test_a_key_per_message_same_bytes(eng, G, tag, B):
+    """sc_hip_dilithium_sign_keys with the bit set: every wavefront builds its message's tables from the raw key rows (dil_cfins_kernel<K, L, true>)"""
+    import torch
+    par, eb = G[f'{tag}_params'], int(G[f'{tag}_eta_bits'][0])
+    d = eng.dilithium(par)
+    g = torch.Generator(device='cuda'); g.manual_seed(B)
+    seeds = torch.randint(0, 256, (B, 32), dtype=torch.uint8, device='cuda', generator=g)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, eb)
+    want = d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64)
+    d.set_tuning(SPARSE)
+    got = d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64)
+    assert all(torch.equal(a, b) for a, b in zip(want, got))
+    # a key outside the range the fields are sized for: refused on the device, the call signed again through the transform kernel - same bytes as without the bit
+    s2w = s2.clone(); s2w.view(-1)[5] = int(par[10]) + 1
+    got_w = d.sign_keys(s1, s2w, t, rho, K, tr, msgs, fixed_len=64)
+    d.set_tuning(0)
+    want_w = d.sign_keys(s1, s2w, t, rho, K, tr, msgs, fixed_len=64)
+    assert all(torch.equal(a, b) for a, b in zip(want_w, got_w))
+    d.close()

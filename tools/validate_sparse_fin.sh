@@ -2,7 +2,7 @@
 # First GPU job of the next round (run on the GPU box through gpurun): the Dilithium finishing kernel without transforms (csrc/dil_cfins.h, tuning bit 11)
 # has only run on the CPU wave emulation so far.
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/validate_sparse_fin.sh'   ->  gpurun_out/sparse_fin/
-#  1. its opt-in GPU tests (reference signatures under all four parameter sets; byte equality with the transform kernel at batch 1 / 257 / 5000)
+#  1. its opt-in GPU tests (reference signatures under all four parameter sets; byte equality with the transform kernel at batch 1 / 257 / 5000; a key per message)
 #  2. A/B of the north-star leg: three alternating pairs of runs on the same box (medians inside bench_scheme.py)
 #  3. kernel timeline of one signing call with the bit set
 # If 1 is green and 2 says faster: make `sparse_fin` the one-key default in sign_core (csrc/dilithium.hip), drop the skip in
