@@ -15,9 +15,9 @@ rank runs its own batch); the only collectives are the timing barrier, the MAX o
 time and the gather of the per-rank scheme rates.  The scheme-level legs (BASELINE configs[2..4]: Dilithium-III
 sign / verify, BLISS-B-I sign, Falcon-1024 sign) run on every rank as well and are reported per GPU and summed.
 
-Output: the LAST stdout line is the contract line - compact (< 8 KB, asserted), medians with their spread, `roofline`, `cpu_baseline`, `north_star`; the
-full tree of every leg goes to bench_extra.json beside this script and to an earlier stdout line prefixed "EXTRA " (round 3's single 27.7 KB line was
-not parsed by the driver).  --shard cuts the BASELINE batches across the ranks (strong scaling) instead of repeating them (weak, the default).
+Output: the LAST stdout line is the contract line - compact (< 6 KB, asserted; the driver keeps the last 8 KB of stdout), medians with their spread,
+`roofline`, `cpu_baseline`, `north_star`; the full tree of every leg goes to bench_extra.json beside this script and only its path is printed (round 3's
+single 27.7 KB line was not parsed by the driver).  --shard cuts the BASELINE batches across the ranks (strong scaling) instead of repeating them (weak, the default).
 Sign figures of the schemes that draw randomness (BLISS-B, Falcon, ring-TESLA) are END TO END: a 32-byte seed per message, the reference's AES-256
 CTR-DRBG on the device inside the timed call (sc_hip_*_sign_seeded); the tape-resident figure of rounds 1-3 is reported beside it, labelled.
 
@@ -718,7 +718,7 @@ def batch_share(total, world, rank, shard):
 
 
 def north_star_summary(extra, cfg):
-    """BASELINE configs[2..4] in a few hundred bytes each (the full blocks go to bench_extra.json / the EXTRA line)"""
+    """BASELINE configs[2..4] in a few hundred bytes each (the full blocks go to bench_extra.json)"""
     def rl(b):
         if not b:
             return None
@@ -782,7 +782,7 @@ def frac_violations(node, path='line'):
     return bad
 
 
-LINE_LIMIT = 8000                # bytes: the driver parsed a 15.5 KB line in round 2 and failed on 27.7 KB in round 3; the contract line stays far below either
+LINE_LIMIT = 6000                # bytes: the driver parsed a 15.5 KB line in round 2 and failed on 27.7 KB in round 3; the contract line stays far below either
 
 
 def main():
@@ -798,7 +798,7 @@ def main():
     ap.add_argument('--no-spin', action='store_true', help='leave the runtime\'s host-thread scheduling at its default (the bench asks it to spin in synchronisations)')
     ap.add_argument('--no-live-pmc', action='store_true', help='scheme rooflines from the committed counter pass instead of rocprofv3 child processes of this run')
     ap.add_argument('--test-one-device', action='store_true', help='testing only: every rank on device 0 over gloo (exercises the N > 1 path on a one-GPU box; figures mean nothing)')
-    ap.add_argument('--extra-file', default=os.path.join(ROOT, 'bench_extra.json'), help='where the full tree of legs goes (also printed as an earlier "EXTRA " line)')
+    ap.add_argument('--extra-file', default=os.path.join(ROOT, 'bench_extra.json'), help='where the full tree of legs goes ')
     args = ap.parse_args()
 
     import torch
@@ -1042,7 +1042,7 @@ def main():
             res['extra_file'] = os.path.relpath(args.extra_file, ROOT)
         except OSError as e:
             res['extra_file'] = f'not written: {e}'
-        print('EXTRA ' + full, flush=True)
+        print(f'# full tree of every leg: {res["extra_file"]} ({len(full)} bytes)', flush=True)
         line = json.dumps(res)
         if len(line) >= LINE_LIMIT:                                  # never let the line outgrow the driver again: drop the optional blocks, largest first
             for k in ('multi_gpu', 'frac_violations'):
