@@ -861,7 +861,8 @@ struct sc_hip_dilithium {
     bool have_priv, have_pub;
     uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
     uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
-    uint32_t *d_tabs; uint32_t fin_bias;              // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel) and their fields' bias; null: the key does not fit them
+    uint32_t *d_tabs; uint32_t fin_bias;              // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel) and their fields' bias; null: the key does not fit them, or tuning bit 11 never asked for them
+    std::vector<uint32_t> h_tabs;                     // the same tables on the host from key load on (empty: the key does not fit); they reach the device only when bit 11 is set
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
     size_t cap;                                       // per message / per signature (verify): mu, kappa, trials, act, z, h, c, ch
@@ -949,6 +950,7 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
     if (d->ev_join2) (void)hipEventDestroy(d->ev_join2);
     void *ptrs[] = { d->d_A, d->d_As, d->d_tabs, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
+    for (auto &w : d->h_tabs) *(volatile uint32_t *)&w = 0;
     sc_hip_plan_destroy(d->plan);
     delete d;
 }
@@ -1046,6 +1048,15 @@ extern "C" int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t 
     return SC_HIP_SUCCESS;
 }
 
+static int upload_fin_tables(sc_hip_dilithium *d)
+{
+    if (d->d_tabs || d->h_tabs.empty()) return SC_HIP_SUCCESS;
+    HIPCHK(hipSetDevice(d->ctx->device));
+    HIPCHK(hipMalloc((void **)&d->d_tabs, d->h_tabs.size() * 4));
+    HIPCHK(sc::copy_in(d->d_tabs, d->h_tabs.data(), d->h_tabs.size() * 4));
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t *s1, const int32_t *s2, const int32_t *t,
                                             const uint8_t *K, const uint8_t *tr, const int32_t *Ahat)
 {
@@ -1058,14 +1069,11 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = (x >= 0) ? x : x + q; }
     if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
-    {
-        std::vector<uint32_t> tabs;
-        const bool fits = fin_tables(d->P, s1, s2, t0.data(), tabs, d->fin_bias);
-        if (fits) {
-            if (!d->d_tabs) HIPCHK(hipMalloc((void **)&d->d_tabs, tabs.size() * 4));
-            HIPCHK(sc::copy_in(d->d_tabs, tabs.data(), tabs.size() * 4));
-        } else if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
-        for (auto &w : tabs) *(volatile uint32_t *)&w = 0;
+    {   // the opt-in finishing kernel's tables (tuning bit 11): built on the host here, no device work on the default path - upload_fin_tables below
+        for (auto &w : d->h_tabs) *(volatile uint32_t *)&w = 0;
+        if (!fin_tables(d->P, s1, s2, t0.data(), d->h_tabs, d->fin_bias)) { for (auto &w : d->h_tabs) *(volatile uint32_t *)&w = 0; d->h_tabs.clear(); }
+        if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
+        if (d->tune_sparse_fin && upload_fin_tables(d)) return SC_HIP_FAILURE;
     }
     if (!d->d_K) HIPCHK(hipMalloc((void **)&d->d_K, 32));
     if (!d->d_tr_priv) HIPCHK(hipMalloc((void **)&d->d_tr_priv, 48));
@@ -1173,6 +1181,7 @@ extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
     d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_w24 = (slots_per_message >> 10) & 1; d->tune_sparse_fin = (slots_per_message >> 11) & 1; d->tune_unfused = unfused ? 1 : 0;
+    if (d->tune_sparse_fin && d->have_priv && upload_fin_tables(d)) return SC_HIP_FAILURE;
     return SC_HIP_SUCCESS;
 }
 
