@@ -215,6 +215,35 @@ static int gen_ntt_large(const char *dir)
     fclose(f);
     return 0;
 }
+/* ------------------------------------------------- reproducible contexts ----
+ * Every scheme context of a fixture generator draws its entropy from a callback (safecrypto_entropy_callback + SC_FLAG_1_CSPRNG_USE_CALLBACK_RANDOM,
+ * include/safecrypto.h:108,281; the flag is read at safecrypto.c:440-442 and the CSPRNG instances then seed and reseed through
+ * get_entropy_callback, prng_get_func.c:51-55) that returns a fixed stream per (generator, context number): `ref_driver all <dir>` writes the same
+ * bytes every time, keys included.  The stream is splitmix64 on a state of its own (the messages' generator sm_state is not touched). */
+static uint64_t ent_state, ent_domain;
+static unsigned ent_serial;
+static void fixed_entropy(size_t n, UINT8 *data)
+{
+    for (size_t i = 0; i < n; i++) {
+        uint64_t z = (ent_state += 0x9E3779B97F4A7C15ULL);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        data[i] = (UINT8)((z ^ (z >> 31)) >> 24);
+    }
+}
+static void fixed_domain(const char *name)
+{
+    uint64_t h = 0xcbf29ce484222325ULL;                     /* FNV-1a of the generator's name */
+    for (const char *c = name; *c; c++) h = (h ^ (uint8_t)*c) * 0x100000001b3ULL;
+    ent_domain = h; ent_serial = 0;
+    safecrypto_entropy_callback(fixed_entropy);
+}
+static safecrypto_t *create_fixed(sc_scheme_e scheme, SINT32 set, const UINT32 *flags)
+{
+    UINT32 fl[2] = { flags[0] | SC_FLAG_MORE, ((flags[0] & SC_FLAG_MORE) ? flags[1] : 0) | SC_FLAG_1_CSPRNG_USE_CALLBACK_RANDOM };
+    ent_state = ent_domain ^ ((uint64_t)(++ent_serial) * 0xD6E8FEB86659FD93ULL);
+    return safecrypto_create(scheme, set, fl);
+}
 
 /* ------------------------------------------------------------------ CDT ---- */
 
@@ -372,7 +401,7 @@ static int dilithium_case(FILE *f, int set, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "dil%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_DILITHIUM, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const dilithium_set_t *P = sc->dilithium->params;
@@ -427,7 +456,7 @@ static int dilithium_case(FILE *f, int set, int nmsg)
     for (int kg = 0; kg < 2; kg++) {
         uint8_t seed[32];
         for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
-        safecrypto_t *s2 = safecrypto_create(SC_SCHEME_SIG_DILITHIUM, set, flags);
+        safecrypto_t *s2 = create_fixed(SC_SCHEME_SIG_DILITHIUM, set, flags);
         if (!s2) return 1;
         prng_ctx_t *o2 = s2->prng_ctx[0], *mine = seeded_prng(seed, 32);
         s2->prng_ctx[0] = mine;
@@ -483,7 +512,7 @@ static int bliss_case(FILE *f, int set, int nmsg, int huffman)
     UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE | (huffman == 1 ? SC_FLAG_0_ENTROPY_HUFFMAN : huffman == 2 ? SC_FLAG_0_ENTROPY_BAC : 0), SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, huffman == 1 ? "blissh%d" : huffman == 2 ? "blissb%d" : "bliss%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_BLISS, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const bliss_set_t *P = sc->bliss->params;
@@ -554,7 +583,7 @@ static int bliss_keygen_case(FILE *f, int set, int nkeep)
     UINT32 flags[2] = { SC_FLAG_0_SAMPLE_64BIT | SC_FLAG_MORE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "bliss%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_BLISS, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_BLISS, set, flags);
     if (!sc) return 1;
     const bliss_set_t *P = sc->bliss->params;
     const int n = P->n;
@@ -647,7 +676,7 @@ static int huff_rows_case(FILE *f, sc_scheme_e scheme, int set, const char *tag,
 {
     UINT32 flags[2] = { SC_FLAG_0_ENTROPY_HUFFMAN, SC_FLAG_NONE };
     char name[96];
-    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    safecrypto_t *sc = create_fixed(scheme, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     int32_t par[4] = { n, bits, tail, set };
@@ -724,7 +753,7 @@ static int kyber_case(FILE *f, int set, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE | SC_FLAG_MORE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "kyber%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_KEM_KYBER, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const kyber_set_t *P = sc->kyber->params;
@@ -797,7 +826,7 @@ static int kyber_case(FILE *f, int set, int nmsg)
     for (int kg = 0; kg < 2; kg++) {
         uint8_t seed[32];
         for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
-        safecrypto_t *s2 = safecrypto_create(SC_SCHEME_KEM_KYBER, set, flags);
+        safecrypto_t *s2 = create_fixed(SC_SCHEME_KEM_KYBER, set, flags);
         if (!s2) return 1;
         prng_ctx_t *o2 = s2->prng_ctx[0], *mine = seeded_prng(seed, 32);
         s2->prng_ctx[0] = mine;
@@ -882,7 +911,7 @@ static int tesla_case(FILE *f, int set, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "tesla%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_RING_TESLA, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_RING_TESLA, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const ring_tesla_set_t *P = sc->ring_tesla->params;
@@ -963,7 +992,7 @@ static int rlwe_case(FILE *f, int set, int nkeys, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "rlwe%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_ENC_RLWE, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_ENC_RLWE, set, flags);
     if (!sc) return 1;
     const rlwe_set_t *P = set ? &param_rlwe_enc_1 : &param_rlwe_enc_0;       /* the config struct is private to rlwe_enc.c */
     const int n = P->n;
@@ -1047,7 +1076,7 @@ static int ens_case(FILE *f, int set, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "ens%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_KEM_ENS, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_KEM_ENS, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const ens_kem_set_t *P = set == 0 ? &param_ens_kem_0 : set == 1 ? &param_ens_kem_1 : set == 2 ? &param_ens_kem_2 : &param_ens_kem_3;
@@ -1116,7 +1145,7 @@ static int dlp_case(FILE *f, int set, int nids)
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "dlp%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_IBE_DLP, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_IBE_DLP, set, flags);
     if (!sc) return 1;
     FILE *devnull = fopen("/dev/null", "w");
     FILE *saved = stdout, *saved_err = stderr;
@@ -1206,7 +1235,7 @@ static int ensdlp_case(FILE *f, sc_scheme_e scheme, const char *tag, int set, co
 {
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96];
-    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    safecrypto_t *sc = create_fixed(scheme, set, flags);
     if (!sc) return 1;
     FILE *devnull = fopen("/dev/null", "w"), *saved = stdout, *saved_err = stderr;
     stdout = devnull; stderr = devnull;
@@ -1293,7 +1322,7 @@ static int ensdlp_rec_case(FILE *f, sc_scheme_e scheme, const char *tag, int set
 {
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96];
-    safecrypto_t *sc = safecrypto_create(scheme, set, flags);
+    safecrypto_t *sc = create_fixed(scheme, set, flags);
     if (!sc) return 1;
     FILE *devnull = fopen("/dev/null", "w"), *saved = stdout, *saved_err = stderr;
     stdout = devnull; stderr = devnull;
@@ -1476,7 +1505,7 @@ static int falcon_case(FILE *f, int set, int nsamp, int nmsg)
     UINT32 flags[2] = { SC_FLAG_NONE, SC_FLAG_NONE };
     char name[96], tag[32];
     snprintf(tag, sizeof tag, "falcon%d", set);
-    safecrypto_t *sc = safecrypto_create(SC_SCHEME_SIG_FALCON, set, flags);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_FALCON, set, flags);
     if (!sc) return 1;
     if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
     const falcon_set_t *P = sc->falcon->params;
@@ -1801,25 +1830,25 @@ int main(int argc, char **argv)
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
-    if (all || !strcmp(argv[1], "ntt")) rc |= gen_ntt(argv[2]);
-    if (all || !strcmp(argv[1], "ntt_large")) rc |= gen_ntt_large(argv[2]);
-    if (all || !strcmp(argv[1], "cdt")) rc |= gen_cdt(argv[2]);
-    if (all || !strcmp(argv[1], "dilithium")) rc |= gen_dilithium(argv[2]);
-    if (all || !strcmp(argv[1], "bliss")) rc |= gen_bliss(argv[2]);
-    if (all || !strcmp(argv[1], "cdt32")) rc |= gen_cdt32(argv[2]);
-    if (all || !strcmp(argv[1], "sampling")) rc |= gen_sampling(argv[2]);
-    if (all || !strcmp(argv[1], "bliss_huff")) rc |= gen_bliss_huff(argv[2]);
-    if (all || !strcmp(argv[1], "bliss_bac")) rc |= gen_bliss_bac(argv[2]);
-    if (all || !strcmp(argv[1], "huff_rows")) rc |= gen_huff_rows(argv[2]);
-    if (all || !strcmp(argv[1], "kyber")) rc |= gen_kyber(argv[2]);
-    if (all || !strcmp(argv[1], "falcon")) rc |= gen_falcon(argv[2]);
-    if (all || !strcmp(argv[1], "ops")) rc |= gen_ops(argv[2]);
-    if (all || !strcmp(argv[1], "drbg")) rc |= gen_drbg(argv[2]);
-    if (all || !strcmp(argv[1], "tesla")) rc |= gen_tesla(argv[2]);
-    if (all || !strcmp(argv[1], "rlwe")) rc |= gen_rlwe(argv[2]);
-    if (all || !strcmp(argv[1], "ens")) rc |= gen_ens(argv[2]);
-    if (all || !strcmp(argv[1], "dlp")) rc |= gen_dlp(argv[2]);
-    if (all || !strcmp(argv[1], "ensdlp")) rc |= gen_ensdlp(argv[2]);
-    if (all || !strcmp(argv[1], "ensdlp_rec")) rc |= gen_ensdlp_rec(argv[2]);
+    if (all || !strcmp(argv[1], "ntt")) { fixed_domain("ntt"); rc |= gen_ntt(argv[2]); }
+    if (all || !strcmp(argv[1], "ntt_large")) { fixed_domain("ntt_large"); rc |= gen_ntt_large(argv[2]); }
+    if (all || !strcmp(argv[1], "cdt")) { fixed_domain("cdt"); rc |= gen_cdt(argv[2]); }
+    if (all || !strcmp(argv[1], "dilithium")) { fixed_domain("dilithium"); rc |= gen_dilithium(argv[2]); }
+    if (all || !strcmp(argv[1], "bliss")) { fixed_domain("bliss"); rc |= gen_bliss(argv[2]); }
+    if (all || !strcmp(argv[1], "cdt32")) { fixed_domain("cdt32"); rc |= gen_cdt32(argv[2]); }
+    if (all || !strcmp(argv[1], "sampling")) { fixed_domain("sampling"); rc |= gen_sampling(argv[2]); }
+    if (all || !strcmp(argv[1], "bliss_huff")) { fixed_domain("bliss_huff"); rc |= gen_bliss_huff(argv[2]); }
+    if (all || !strcmp(argv[1], "bliss_bac")) { fixed_domain("bliss_bac"); rc |= gen_bliss_bac(argv[2]); }
+    if (all || !strcmp(argv[1], "huff_rows")) { fixed_domain("huff_rows"); rc |= gen_huff_rows(argv[2]); }
+    if (all || !strcmp(argv[1], "kyber")) { fixed_domain("kyber"); rc |= gen_kyber(argv[2]); }
+    if (all || !strcmp(argv[1], "falcon")) { fixed_domain("falcon"); rc |= gen_falcon(argv[2]); }
+    if (all || !strcmp(argv[1], "ops")) { fixed_domain("ops"); rc |= gen_ops(argv[2]); }
+    if (all || !strcmp(argv[1], "drbg")) { fixed_domain("drbg"); rc |= gen_drbg(argv[2]); }
+    if (all || !strcmp(argv[1], "tesla")) { fixed_domain("tesla"); rc |= gen_tesla(argv[2]); }
+    if (all || !strcmp(argv[1], "rlwe")) { fixed_domain("rlwe"); rc |= gen_rlwe(argv[2]); }
+    if (all || !strcmp(argv[1], "ens")) { fixed_domain("ens"); rc |= gen_ens(argv[2]); }
+    if (all || !strcmp(argv[1], "dlp")) { fixed_domain("dlp"); rc |= gen_dlp(argv[2]); }
+    if (all || !strcmp(argv[1], "ensdlp")) { fixed_domain("ensdlp"); rc |= gen_ensdlp(argv[2]); }
+    if (all || !strcmp(argv[1], "ensdlp_rec")) { fixed_domain("ensdlp_rec"); rc |= gen_ensdlp_rec(argv[2]); }
     return rc;
 }

@@ -96,7 +96,6 @@ def test_verdicts_and_rebuilt_messages_are_the_references(eng, G, tag):
     v, out, ol = f.ens_dlp_verify_recovery(torch.from_numpy(sb).cuda(), torch.from_numpy(sl).cuda(), torch.from_numpy(m2b).cuda(), torch.from_numpy(m2l).cuda())
     torch.cuda.synchronize()
     assert v.cpu().tolist() == want
-    assert want.count(0) >= 7
     for i, bk in enumerate(back):
         if bk is not None:
             assert bytes(out[i, :int(ol[i])].cpu().numpy()) == bk, i

@@ -56,7 +56,9 @@ def test_verdicts_and_rebuilt_messages_match_reference(G, tag):
         else:
             sig[2] ^= 0x40
         assert O.ensdlp_verify_recovery(par, h, m2, sig)[0] == v[2], m
-    assert accepted >= 7
+    # how many the reference accepted is a property of the key it drew (a key can make it reject every one of its own signatures with recovery): the count is the
+    # fixture's, not a constant
+    assert accepted == sum(1 for m in range(8) if int(G[f'{tag}_verify'][3 * m]) == 0)
 
 
 def test_short_signature_is_refused(G):
