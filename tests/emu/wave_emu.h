@@ -10,6 +10,9 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <functional>
 #include <thread>
 #include <type_traits>
@@ -20,7 +23,13 @@
 #define __host__
 #define __forceinline__ inline
 #define __launch_bounds__(...)
-#define __shared__
+// EMU_SHARED: what `__shared__` becomes.  Empty (the default) suits a kernel whose LDS is one `extern __shared__` array the harness defines; `static` suits
+// kernels that declare their LDS arrays inside the function (one instance per instantiation, shared by the workgroup's threads; workgroups run one after the other)
+#ifndef EMU_SHARED
+#define EMU_SHARED
+#endif
+#define __shared__ EMU_SHARED
+#define __restrict__
 
 struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
 static thread_local EmuDim3 threadIdx;
@@ -30,13 +39,27 @@ struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }
 
 namespace emu {
-struct Wave { pthread_barrier_t bar; uint64_t buf[64]; };
-struct Block { pthread_barrier_t bar; std::vector<Wave> waves; };
+// A barrier out of a mutex and a condition variable rather than pthread_barrier_t: ThreadSanitizer models the former exactly, while behind a
+// pthread_barrier_wait it no longer reported a race that followed (found by removing a wavefront fence from csrc/ntt_core.h on purpose and watching the
+// result go wrong without a report; tests/test_emu_ntt.py keeps that experiment as a test of the harness).
+struct Barrier {
+    std::mutex m; std::condition_variable cv; unsigned n = 0, count = 0, gen = 0;
+    void init(unsigned threads) { n = threads; count = 0; gen = 0; }
+    void wait()
+    {
+        std::unique_lock<std::mutex> l(m);
+        const unsigned g = gen;
+        if (++count == n) { count = 0; gen++; cv.notify_all(); }
+        else cv.wait(l, [&] { return gen != g; });
+    }
+};
+struct Wave { Barrier bar; uint64_t buf[64]; };
+struct Block { Barrier bar; std::deque<Wave> waves; };
 static Block *cur_block;
 static thread_local Wave *my_wave;
 static thread_local int my_lane;
 
-static inline void wave_sync() { pthread_barrier_wait(&my_wave->bar); }
+static inline void wave_sync() { my_wave->bar.wait(); }
 static inline uint64_t exchange(uint64_t v, int src)
 {
     my_wave->buf[my_lane] = v;
@@ -46,22 +69,25 @@ static inline uint64_t exchange(uint64_t v, int src)
     return r;
 }
 
-// run `body` as grid x block threads (block a multiple of 64)
+// run `body` as grid x block threads (block a multiple of 64).  wave_serial: the wavefronts of a workgroup one after the other - ONLY for kernels without a
+// workgroup barrier, whose wavefronts share nothing (the NTT kernel).  ThreadSanitizer needs it: it has 256 thread slots, and with a whole 256-lane
+// workgroup alive beside the host's own threads the slots are recycled and races go unreported (found by removing a fence on purpose: tests/test_emu_ntt.py).
+static bool wave_serial = false;
 static inline void launch(unsigned grid, unsigned block, const std::function<void()> &body)
 {
     gridDim.x = grid; blockDim.x = block;
     for (unsigned b = 0; b < grid; b++) {
         Block blk;
         blk.waves.resize(block / 64);
-        pthread_barrier_init(&blk.bar, nullptr, block);
-        for (auto &w : blk.waves) pthread_barrier_init(&w.bar, nullptr, 64);
+        blk.bar.init(block);
+        for (auto &w : blk.waves) w.bar.init(64);
         cur_block = &blk; blockIdx.x = b;
-        std::vector<std::thread> th;
-        for (unsigned t = 0; t < block; t++)
-            th.emplace_back([&, t]() { threadIdx.x = t; my_lane = (int)(t & 63); my_wave = &blk.waves[t >> 6]; body(); });
-        for (auto &x : th) x.join();
-        for (auto &w : blk.waves) pthread_barrier_destroy(&w.bar);
-        pthread_barrier_destroy(&blk.bar);
+        for (unsigned t0 = 0; t0 < block; t0 += wave_serial ? 64 : block) {
+            std::vector<std::thread> th;
+            for (unsigned t = t0; t < (wave_serial ? t0 + 64 : block); t++)
+                th.emplace_back([&, t]() { threadIdx.x = t; my_lane = (int)(t & 63); my_wave = &blk.waves[t >> 6]; body(); });
+            for (auto &x : th) x.join();
+        }
     }
 }
 }  // namespace emu
@@ -80,8 +106,27 @@ static inline uint64_t __ballot(bool p)
     emu::wave_sync();
     return r;
 }
+#ifndef EMU_HAVE_NTT_CORE              // a harness that includes csrc/ntt_core.h gets sc::wave_lds_fence from there, over the two builtins below
 static inline void wave_lds_fence() { emu::wave_sync(); }               // csrc/ntt_core.h: a wavefront-scope fence + wave barrier
-static inline void __syncthreads() { pthread_barrier_wait(&emu::cur_block->bar); }
+#endif
+#define __builtin_amdgcn_fence(...) ((void)0)
+#define __builtin_amdgcn_wave_barrier() emu::wave_sync()
+#define __builtin_amdgcn_readfirstlane(v) emu_readlane((v), 0)
+static inline void __syncthreads() { emu::cur_block->bar.wait(); }
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline int32_t __mulhi(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * b) >> 32); }
+static inline uint32_t emu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+#define __builtin_amdgcn_alignbit(hi, lo, sh) emu_alignbit((hi), (lo), (sh))
+using std::min;
+using std::max;
+// csrc/modarith.h declares the 24-bit multiplies as functions bound to LLVM intrinsic names; the harness's hip/hip_runtime.h stand-in removes the binding
+// (tests/emu/shim) and these are the functions (v_mul_u32_u24, v_mul_hi_u32_u24, v_mul_i32_i24: operands taken modulo 2^24, the signed one sign-extended from bit 23)
+extern "C" inline uint32_t sc_llvm_mul_u24(uint32_t a, uint32_t b) { return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)); }
+extern "C" inline uint32_t sc_llvm_mulhi_u24(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (b & 0xFFFFFFu)) >> 32); }
+extern "C" inline int32_t sc_llvm_mul_i24(int32_t a, int32_t b)
+{
+    const int64_t x = (int64_t)((int32_t)((uint32_t)a << 8) >> 8), y = (int64_t)((int32_t)((uint32_t)b << 8) >> 8);
+    return (int32_t)(uint32_t)(uint64_t)(x * y);
+}
