@@ -8,6 +8,7 @@
 #pragma once
 #include <pthread.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <condition_variable>
@@ -37,6 +38,9 @@ static EmuDim3 blockIdx, blockDim, gridDim;            // workgroups run one aft
 
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }
+struct alignas(16) int4 { int32_t x, y, z, w; };
+static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{ x, y, z, w }; }
+struct alignas(8) uint2 { uint32_t x, y; };
 
 namespace emu {
 // A barrier out of a mutex and a condition variable rather than pthread_barrier_t: ThreadSanitizer models the former exactly, while behind a
@@ -52,8 +56,14 @@ struct Barrier {
         if (++count == n) { count = 0; gen++; cv.notify_all(); }
         else cv.wait(l, [&] { return gen != g; });
     }
+    void leave()            // a lane whose kernel body has returned no longer takes part (the device masks it out)
+    {
+        std::unique_lock<std::mutex> l(m);
+        if (n) n--;
+        if (n && count == n) { count = 0; gen++; cv.notify_all(); }
+    }
 };
-struct Wave { Barrier bar; uint64_t buf[64]; };
+struct Wave { Barrier bar; Barrier pair[32]; uint64_t buf[64]; uint32_t pbuf[64]; };
 struct Block { Barrier bar; std::deque<Wave> waves; };
 static Block *cur_block;
 static thread_local Wave *my_wave;
@@ -80,12 +90,12 @@ static inline void launch(unsigned grid, unsigned block, const std::function<voi
         Block blk;
         blk.waves.resize(block / 64);
         blk.bar.init(block);
-        for (auto &w : blk.waves) w.bar.init(64);
+        for (auto &w : blk.waves) { w.bar.init(64); for (auto &pb : w.pair) pb.init(2); }
         cur_block = &blk; blockIdx.x = b;
         for (unsigned t0 = 0; t0 < block; t0 += wave_serial ? 64 : block) {
             std::vector<std::thread> th;
             for (unsigned t = t0; t < (wave_serial ? t0 + 64 : block); t++)
-                th.emplace_back([&, t]() { threadIdx.x = t; my_lane = (int)(t & 63); my_wave = &blk.waves[t >> 6]; body(); });
+                th.emplace_back([&, t]() { threadIdx.x = t; my_lane = (int)(t & 63); my_wave = &blk.waves[t >> 6]; body(); my_wave->pair[my_lane >> 1].leave(); my_wave->bar.leave(); blk.bar.leave(); });
             for (auto &x : th) x.join();
         }
     }
@@ -97,6 +107,34 @@ static inline int __shfl_xor(int v, int m) { return (int)(uint32_t)emu::exchange
 static inline int __shfl(int v, int src) { return (int)(uint32_t)emu::exchange((uint32_t)v, src); }
 static inline int emu_readlane(int v, int l) { return (int)(uint32_t)emu::exchange((uint32_t)v, l); }
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
+// DPP quad_perm moves whose every lane reads from its own PAIR of lanes (the two-lane Keccak's exchanges: [1,0,3,2], [0,0,2,2], [1,1,3,3]): a barrier
+// over the pair, not the wavefront - pairs run different numbers of permutations (a rejected sample in ExpandMask), as they do under the device's exec mask
+static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+{
+    (void)old; (void)bound_ctrl;
+    const int q = emu::my_lane & 3, sel = (ctrl >> (2 * q)) & 3;
+    if (ctrl > 0xFF || row_mask != 0xF || bank_mask != 0xF || (sel >> 1) != (q >> 1)) abort();      // anything else: not emulated
+    emu::Barrier &b = emu::my_wave->pair[emu::my_lane >> 1];
+    emu::my_wave->pbuf[emu::my_lane] = (uint32_t)src;
+    b.wait();
+    const int r = (int)emu::my_wave->pbuf[(emu::my_lane & ~3) | sel];
+    b.wait();
+    return r;
+}
+#define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
+// V_BITOP3_B32: bit (a << 2 | b << 1 | c) of the truth table, per bit position
+static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, unsigned tt)
+{
+    uint32_t r = 0;
+    for (unsigned i = 0; i < 8; i++)
+        if (tt & (1u << i)) r |= ((i & 4) ? a : ~a) & ((i & 2) ? b : ~b) & ((i & 1) ? c : ~c);
+    return r;
+}
+#define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+namespace emu { alignas(16) static unsigned char dyn_lds[160 * 1024]; }     // the workgroup's dynamic LDS (`extern __shared__`, rewritten by the harness's build step)
+
 static inline uint64_t __ballot(bool p)
 {
     emu::my_wave->buf[emu::my_lane] = p ? 1 : 0;

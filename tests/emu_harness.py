@@ -1,0 +1,70 @@
+"""Builds and runs the lane-by-lane CPU emulation of the engine's kernels (tests/emu/; test infrastructure only).
+
+A harness tests/emu/<name>.cpp includes kernel headers of libsafecrypto_amd/csrc/ as HOST code over tests/emu/wave_emu.h.  The headers are compiled from
+a copy (tests/emu/_build/src*/) in which ONE construct is rewritten mechanically - the declaration of a workgroup's dynamic LDS,
+`extern __shared__ [aligned] T name[];`, becomes a pointer to the emulation's LDS array - everything else is the product's text; csrc/scalar_hint.h and
+<hip/hip_runtime.h> come from tests/emu/shim.  `mutate` removes the k-th `wave_lds_fence();` of one header: the harness's own test - a build with a fence
+missing must come back from ThreadSanitizer as a data race."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, 'tests', 'emu')
+CSRC = os.path.join(ROOT, 'libsafecrypto_amd', 'csrc')
+CLANG = '/opt/rocm/lib/llvm/bin/clang++'          # host mode: the kernel text uses clang vector types and builtins (ext_vector_type, __builtin_nontemporal_*)
+DYN_LDS = re.compile(r'extern __shared__ (?:__attribute__\(\(aligned\(16\)\)\) )?(\w+) (\w+)\[\];')
+
+
+def _sources(dst, mutate=None):
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    for h in glob.glob(os.path.join(CSRC, '*.h')):
+        base = os.path.basename(h)
+        if os.path.exists(os.path.join(EMU, 'shim', base)):
+            continue
+        text = DYN_LDS.sub(lambda m: f'{m.group(1)} *const {m.group(2)} = reinterpret_cast<{m.group(1)} *>(emu::dyn_lds);', open(h).read())
+        if mutate and mutate[0] == base:
+            at = [m.start() for m in re.finditer(r'wave_lds_fence\(\);', text)][mutate[1]]
+            text = text[:at] + text[at + len('wave_lds_fence();'):]
+        with open(os.path.join(dst, base), 'w') as f:
+            f.write(text)
+
+
+def build(name, sanitize, mutate=None, out=None):
+    """tests/emu/<name>.cpp -> lib<name>_<sanitize>.so under tests/emu/_build (or `out`), rebuilt when a source is newer.  -O0: the run time is the threads'
+    barriers either way, and the sanitizer builds of the larger harnesses take a minute at -O1"""
+    out = out or os.path.join(EMU, '_build')
+    os.makedirs(out, exist_ok=True)
+    tag = (sanitize or 'plain').replace(',', '_') + (f'_mut{mutate[1]}' if mutate else '')
+    so = os.path.join(out, f'lib{name}_{tag}.so')
+    deps = [os.path.join(EMU, f'{name}.cpp'), os.path.join(EMU, 'wave_emu.h'), __file__] + glob.glob(os.path.join(EMU, 'shim', '*.h')) + \
+           glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h'))
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        src = os.path.join(out, f'src_{name}_{tag}')
+        _sources(src, mutate)
+        flags = ['-O0', '-g', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function',
+                 '-Wno-unused-variable', '-Wno-shift-count-negative', '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
+        if sanitize:
+            flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
+        subprocess.check_call([CLANG] + flags + ['-o', so, deps[0]])
+    return so
+
+
+def sanitizer_env(sanitize):
+    """a sanitized .so loaded into an unsanitized python needs its runtime preloaded"""
+    env = dict(os.environ)
+    if sanitize:
+        rt = 'tsan' if 'thread' in sanitize else 'asan'
+        env['LD_PRELOAD'] = subprocess.check_output([CLANG, f'-print-file-name=libclang_rt.{rt}-x86_64.so']).decode().strip()
+        env['ASAN_OPTIONS'] = 'detect_leaks=0:abort_on_error=1'
+        env['UBSAN_OPTIONS'] = 'halt_on_error=1:print_stacktrace=1'
+        env['TSAN_OPTIONS'] = 'halt_on_error=1:report_signal_unsafe=0'
+    return env
+
+
+def drive(driver, args, sanitize, timeout=1500):
+    """runs `driver` (python source) in a child with the sanitizer's runtime preloaded; returns the CompletedProcess"""
+    return subprocess.run(['python3', '-c', driver, ROOT] + [str(a) for a in args], env=sanitizer_env(sanitize), capture_output=True, text=True, timeout=timeout)

@@ -1,0 +1,85 @@
+"""CPU: a whole Dilithium signing call of the engine, one key for the batch, run lane by lane - every kernel sc_hip_dilithium_set_privkey and sign_core
+queue (csrc/dilithium.hip), in their order and with their grids: key preparation through the transform kernel, the matrix into plain + Shoup form, mu, and
+per round the round state, ExpandMask (the two-lane Keccak with its DPP exchanges), the fused NTT(y) -> A NTT(y) -> INTT kernel with the matrix in LDS, both
+forms of the challenge hash, the finishing kernel - the transform one, which is the product's default, or the table one behind tuning bit 11 - and the wipe.
+
+The kernels' own text (csrc/dil_sign_dev.h, mlwe_dev.h, keccak_dev.h, ntt_core.h, dil_cfins.h) is compiled as host code over tests/emu/wave_emu.h
+(tests/emu_harness.py) with AddressSanitizer + UBSan, and with ThreadSanitizer (a missing wavefront fence is a data race: checked by taking one out).
+The GPU pool offers neither.  Signatures, lengths and attempt counts must be the oracle's, byte for byte, under all four parameter sets, over several
+rounds of the speculative rejection loop (few slots per message, so that messages go round again), ragged and empty messages; the per-call secrets must
+be zero behind the call.  The round loop in tests/emu/emu_dil_sign.cpp restates sign_core's (HIP API calls around these launches); this checks the
+kernels' logic and their interplay, not code generation or speed - tests/test_gpu_dilithium.py does that on the GPU."""
+import pytest
+
+from tests.emu_harness import build, drive
+
+DRIVER = r'''
+import ctypes as C, sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+from tests.test_emu_ntt import PlanConsts, OP_INV, S32, U32
+from tests.test_dilithium_fin_tables import _lib, _tables
+so, tag, B, cap, s_max, flags, seed = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
+E = C.CDLL(so)
+vp = C.c_void_p
+E.emu_dil_sign.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, C.c_size_t, vp, vp, vp, vp]
+G = load_golden('dilithium_ref.txt')
+key = O.DilKey.from_golden(G, tag)
+q, n = key.q, key.n
+P = PlanConsts(q, n)
+lm = max(key.k, key.l)
+sg = 1 if (P.s32_ok and 32 * lm * q < (1 << 31)) else 0
+tab, modk, cinv, _ = P.args(S32 if sg else U32, OP_INV)
+_, modk32, _, _ = P.args(U32, OP_INV)
+r2 = P.R; r2p = (P.R << 32) // q
+T, fits, bias = _tables(_lib(), key.par, key.s1, key.s2, key.t)
+rng = np.random.default_rng(seed)
+msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 100)), dtype=np.uint8)) for _ in range(B)]
+stride = 104
+mb = np.zeros((B, stride), dtype=np.uint8); ml = np.zeros(B, dtype=np.uint32)
+for i, m in enumerate(msgs):
+    mb[i, :len(m)] = np.frombuffer(m, dtype=np.uint8); ml[i] = len(m)
+sst = 4096
+sigs = np.zeros((B, sst), dtype=np.uint8); siglens = np.zeros(B, dtype=np.uint32); trials = np.zeros(B, dtype=np.uint32)
+rounds = C.c_uint32(0); residue = C.c_uint32(1)
+p = lambda a: a.ctypes.data_as(vp)
+t0 = time.time()
+rc = E.emu_dil_sign(p(key.par), p(tab), p(modk32), p(cinv), r2, r2p, sg, p(key.s1), p(key.s2), p(key.t), p(key.K), p(key.tr), p(key.Ahat), p(T), bias,
+                    B, p(mb), stride, p(ml), 0, cap, s_max, flags, p(sigs), sst, p(siglens), p(trials), C.byref(rounds), C.byref(residue))
+dt = time.time() - t0
+assert rc == 0, rc
+for i, m in enumerate(msgs):
+    es, et = O.dilithium_sign(key, m)
+    assert int(trials[i]) == et, (i, int(trials[i]), et)
+    assert int(siglens[i]) == len(es) and bytes(sigs[i, :len(es)]) == es, i
+    assert not sigs[i, len(es):].any()
+assert residue.value == 0
+print('EMU_OK', tag, B, 'rounds', rounds.value, 'max trials', int(trials.max()), f'{dt:.1f}s')
+'''
+
+
+def _sign(sanitize, tag, B, cap, s_max, flags, seed, so=None):
+    so = so or build('emu_dil_sign', sanitize)
+    return drive(DRIVER, [so, tag, B, cap, s_max, flags, seed], sanitize)
+
+
+# (parameter set, messages, attempt slots per round, most slots per message, flags: 1 = the table finishing kernel, 2 = one lane per hash, 4 = persistent fused kernel)
+@pytest.mark.parametrize('tag,B,cap,s_max,flags', [('dil3', 9, 18, 3, 0), ('dil3', 6, 12, 3, 1), ('dil3', 7, 20, 32, 2), ('dil3', 13, 32, 4, 4),
+                                                   ('dil0', 6, 12, 32, 0), ('dil1', 6, 12, 32, 1), ('dil2', 4, 8, 2, 3)])
+def test_signing_call_equals_the_oracle_asan_ubsan(tag, B, cap, s_max, flags):
+    r = _sign('address,undefined', tag, B, cap, s_max, flags, 11 * B + flags)
+    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize('flags', [0, 1])
+def test_signing_call_is_race_free_tsan(flags):
+    r = _sign('thread', 'dil3', 5, 10, 3, flags, 2)
+    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_the_harness_reports_a_removed_fence(tmp_path):
+    """the finishing kernel without the fence between a wavefront's write of c into LDS and the lanes' reads of it: a data race in dil_cfin_kernel"""
+    so = build('emu_dil_sign', 'thread', mutate=('dil_sign_dev.h', 2), out=str(tmp_path))
+    r = _sign('thread', 'dil3', 5, 10, 3, 0, 2, so=so)
+    assert r.returncode != 0 and 'ThreadSanitizer: data race' in r.stderr and 'dil_cfin_kernel' in r.stderr, (r.stdout[-500:], r.stderr[-2000:])

@@ -16,41 +16,10 @@ import pytest
 
 from tests import oracle_lib as O
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EMU = os.path.join(ROOT, 'tests', 'emu')
-CSRC = os.path.join(ROOT, 'libsafecrypto_amd', 'csrc')
-CLANG = '/opt/rocm/lib/llvm/bin/clang++'          # host mode: the kernel text uses clang vector types and builtins (ext_vector_type, __builtin_nontemporal_*)
+from tests.emu_harness import ROOT, build, drive
 
 OP_FWD, OP_INV, OP_MULNTT, OP_MUL, OP_MULNTT2 = range(5)
 U24, U32, MAD, SMAD, S32 = 1, 2, 3, 4, 5
-
-
-def build(name, sanitize, deps, csrc=CSRC, out=None):
-    """tests/emu/<name>.cpp -> tests/emu/_build/lib<name>_<sanitize>.so (rebuilt when a dependency is newer); csrc: where the kernel headers are taken from"""
-    out = out or os.path.join(EMU, '_build')
-    os.makedirs(out, exist_ok=True)
-    so = os.path.join(out, f'lib{name}_{(sanitize or "plain").replace(",", "_")}.so')
-    deps = [os.path.join(EMU, f'{name}.cpp'), os.path.join(EMU, 'wave_emu.h'), os.path.join(EMU, 'shim', 'hip', 'hip_runtime.h')] + [os.path.join(csrc, d) for d in deps]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        flags = ['-O1', '-g', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function',
-                 '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + csrc]
-        if sanitize:
-            flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
-        subprocess.check_call([CLANG] + flags + ['-o', so, deps[0]])
-    return so
-
-
-def sanitizer_env(sanitize):
-    """a sanitized .so loaded into an unsanitized python needs its runtime preloaded"""
-    env = dict(os.environ)
-    if sanitize:
-        rt = 'tsan' if 'thread' in sanitize else 'asan'
-        lib = subprocess.check_output([CLANG, f'-print-file-name=libclang_rt.{rt}-x86_64.so']).decode().strip()
-        env['LD_PRELOAD'] = lib
-        env['ASAN_OPTIONS'] = 'detect_leaks=0:abort_on_error=1'
-        env['UBSAN_OPTIONS'] = 'halt_on_error=1:print_stacktrace=1'
-        env['TSAN_OPTIONS'] = 'halt_on_error=1:report_signal_unsafe=0'
-    return env
 
 
 def brv(x, bits):
@@ -195,9 +164,8 @@ CFGS = [(7681, 256), (8380417, 256), (12289, 512), (12289, 1024), (8399873, 512)
 
 
 def _drive(sanitize, q, n, extreme, only=None):
-    so = build('emu_ntt', sanitize, ['ntt_kernel.h', 'ntt_core.h', 'modarith.h'])
-    cmd = ['python3', '-c', DRIVER, ROOT, so, str(q), str(n), str(extreme)] + ([only] if only else [])
-    r = subprocess.run(cmd, env=sanitizer_env(sanitize), capture_output=True, text=True, timeout=1500)
+    so = build('emu_ntt', sanitize)
+    r = drive(DRIVER, [so, q, n, extreme] + ([only] if only else []), sanitize)
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -214,19 +182,8 @@ def test_lds_exchanges_are_race_free_tsan(q, n, only):
 
 @pytest.mark.parametrize('which', [0, 1])
 def test_the_harness_reports_a_removed_fence(tmp_path, which):
-    """the harness tested: a copy of the kernel headers with ONE of the two fences of ntt_core.h's LDS exchange taken out (the first: lanes read what other lanes
+    """the harness tested: a copy of the kernel headers with ONE of the two fences of ntt_core.h's LDS exchange (its only two `wave_lds_fence();` calls) taken out (the first: lanes read what other lanes
     have not written yet; the second: the next round's writes overtake this round's reads) must come back from ThreadSanitizer as a data race in `exchange`"""
-    import shutil
-    HDRS = ['ntt_kernel.h', 'ntt_core.h', 'modarith.h']
-    for h in HDRS:
-        shutil.copy(os.path.join(CSRC, h), tmp_path)
-    text = open(tmp_path / 'ntt_core.h').read()
-    fence = '    wave_lds_fence();\n'
-    start = text.index('__device__ __forceinline__ void exchange(')
-    first = text.index(fence, start)
-    at = first if which == 0 else text.index(fence, first + 1)
-    assert at < text.index('// Twiddles of round RI')                # both inside exchange
-    open(tmp_path / 'ntt_core.h', 'w').write(text[:at] + text[at + len(fence):])
-    so = build('emu_ntt', 'thread', HDRS, csrc=str(tmp_path), out=str(tmp_path))
-    r = subprocess.run(['python3', '-c', DRIVER, ROOT, so, '8380417', '256', '0', '5'], env=sanitizer_env('thread'), capture_output=True, text=True, timeout=900)
+    so = build('emu_ntt', 'thread', mutate=('ntt_core.h', which), out=str(tmp_path))
+    r = drive(DRIVER, [so, 8380417, 256, 0, 5], 'thread', timeout=900)
     assert r.returncode != 0 and 'ThreadSanitizer: data race' in r.stderr and 'exchange' in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
