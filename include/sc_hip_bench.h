@@ -52,6 +52,11 @@ int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, in
 int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t *params, const int32_t *s1, const int32_t *s2, const int32_t *t,
                                      uint32_t *out, size_t out_words, int *fits, uint32_t *bias);
 
+/* test hook, host only (no device call): what sc_hip_cdt_create_from_table puts on the device for a table - guide_params: the ten words of the guide
+ * (csrc/cdt_guide.h CdtGuide: lb_shift, tail_thr, K, MB, lin, total, S, sat_hi, sat_lo, jump; S = 0: the kernels fall back to the halving search), bins:
+ * the guide's bin table (*bins_len entries), probe: the table the kernels search (size + 8 entries) */
+int sc_hip_cdt_guide_host(const uint64_t *h_cdf, int size, uint32_t *guide_params, uint16_t *bins, size_t bins_cap, uint64_t *probe, size_t probe_cap, size_t *bins_len);
+
 /* test hook: how many 32-bit words of the signer's per-call secrets (masks y, w = A y, NTT(y) where it is kept in HBM) are non-zero in the handle's
  * workspace - 0 behind every signing call (the reference zeroes sc->temp, dilithium.c:1964-1975) */
 int sc_hip_dilithium_workspace_residue(sc_hip_dilithium_t *h, unsigned long long *nonzero_words);

@@ -647,6 +647,24 @@ void sc::cdt_build_guide(const std::vector<uint64_t> &cdf, CdtGuide *out, std::v
     probe->resize(size + CDT_PAD, ~0ULL);
 }
 
+// test hook (include/sc_hip_bench.h), host only: the guide, the bin table and the probe table sc_hip_cdt_create_from_table would put on the device for this table
+extern "C" int sc_hip_cdt_guide_host(const uint64_t *h_cdf, int size, uint32_t *guide_params, uint16_t *bins, size_t bins_cap, uint64_t *probe, size_t probe_cap, size_t *bins_len)
+{
+    if (!h_cdf || !guide_params || !bins || !probe || !bins_len) return fail("cdt_guide_host: null argument");
+    if (size < 2 || size > 4096 || (size & (size - 1))) return fail("cdt_guide_host: table must have 2..4096 entries, a power of two");
+    std::vector<uint64_t> cdf(h_cdf, h_cdf + size), padded;
+    std::vector<uint16_t> guide;
+    CdtGuide g;
+    sc::cdt_build_guide(cdf, &g, &guide, &padded);
+    if (guide.size() > bins_cap || padded.size() > probe_cap) return fail("cdt_guide_host: output too small");
+    static_assert(sizeof(CdtGuide) == 10 * sizeof(uint32_t), "CdtGuide is ten words");
+    memcpy(guide_params, &g, sizeof g);
+    memcpy(bins, guide.data(), guide.size() * 2);
+    memcpy(probe, padded.data(), padded.size() * 8);
+    *bins_len = guide.size();
+    return SC_HIP_SUCCESS;
+}
+
 extern "C" int sc_hip_cdt_create_from_table(sc_hip_ctx_t *ctx, const uint64_t *h_cdf, int size, sc_hip_cdt_t **out)
 {
     if (!ctx || !out || !h_cdf) return fail("cdt_create_from_table: null argument");

@@ -49,7 +49,7 @@ SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('creat
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
-BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_bench_set_ntt_stream', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_dilithium_fin_tables_host', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
+BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_bench_set_ntt_stream', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_dilithium_fin_tables_host', 'sc_hip_cdt_guide_host', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
 # include/sc_hip_vtable.h
 VTABLE_SYMBOLS = ['sc_hip_sampler_set_rng32', 'sc_hip_utils_sampling_fill_sca', 'sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']

@@ -1,0 +1,104 @@
+// emu_bliss_sign.cpp - a BLISS-B signing call of the engine, one key for the batch, run on the CPU lane by lane: the kernels' own text
+// (libsafecrypto_amd/csrc/bliss_sign_dev.h, keccak_dev.h, cdt_guide.h, and the NTT kernel of ntt_kernel.h for the product a t) compiled as host code over
+// wave_emu.h, queued per round as bl_round_launch (csrc/bliss.hip) queues them: begin, the CDT sampler (guide + probes), stage, the fused NTT product with
+// the public key broadcast and the round's count on the "device", round_and_drop, the oracle (one lane or two per message), and the deciding kernel
+// (greedy_sc from the key's autocorrelation, the +-(x, y) choice, the exp / cosh rejection, signature_gen, check_norms, packing).
+// The loop around the rounds is the reference's open-ended one (bl_rounds with max_iter = 0: what sc_hip_bliss_set_speculation(h, 0) selects); the
+// speculative later pairs of the default path add bookkeeping kernels (collect / pair_init / resolve) around the SAME round, and are not replayed here.
+// Test infrastructure (tests/test_emu_bliss_sign.py); nothing here is part of the product.
+#define EMU_SHARED static
+#define EMU_HAVE_NTT_CORE
+#include "wave_emu.h"
+#include "keccak_dev.h"
+#include "cdt_guide.h"
+#include "ntt_kernel.h"
+
+namespace {
+#include "bliss_sign_dev.h"
+}
+
+namespace {
+template <typename F> void launch(unsigned grid, unsigned block, F &&f) { if (grid) emu::launch(grid, block, std::function<void()>(f)); }
+
+template <int L> void mulntt_bcast(const NttArgs &a, int mode, unsigned blocks)           // launch_ntt_l<L, OP_MULNTT>, the forms a broadcast operand can take
+{
+    if (mode == MODE_SMAD) launch(blocks, 256, [&]() { ntt_kernel<L, MODE_SMAD, true, OP_MULNTT, false>(a); });
+    else if (mode == MODE_S32) launch(blocks, 256, [&]() { ntt_kernel<L, MODE_S32, true, OP_MULNTT, false>(a); });
+    else if (mode == MODE_MAD) launch(blocks, 256, [&]() { ntt_kernel<L, MODE_MAD, true, OP_MULNTT, false>(a); });
+    else launch(blocks, 256, [&]() { ntt_kernel<L, MODE_U32, true, OP_MULNTT, false>(a); });
+}
+}  // namespace
+
+// par: the 16 words of BlissP; tab / modk / c: the plan's table, ModK and scale constants for `mode` and OP_MULNTT (tests/test_emu_ntt.py PlanConsts);
+// probe / bins / gp: what sc_hip_cdt_guide_host returns for the sampler's table; two_lane: bl_oracle2_kernel instead of bl_oracle1_kernel.
+extern "C" int emu_bliss_sign(const int32_t *par, int mode, const uint32_t *tab, const uint32_t *modk, const uint32_t *c,
+                              const uint64_t *probe, int cdf_size, const uint16_t *bins, const uint32_t *gp,
+                              const int16_t *kf, const int16_t *kg, const int16_t *ka,
+                              uint32_t batch, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+                              const uint32_t *tapes, size_t tape_stride, const uint32_t *tape_lens, int two_lane,
+                              uint8_t *sigs, size_t sig_stride, uint32_t *siglens, uint32_t *trials, uint32_t *status, uint32_t *rounds)
+{
+    BlissP P;
+    memcpy(&P, par, sizeof P);
+    const int n = P.n, L = n == 256 ? 8 : n == 512 ? 9 : 0;
+    if (!L) return 1;
+    CdtGuide g;
+    memcpy(&g, gp, sizeof g);
+    const uint32_t B = batch;
+    // ---- sc_hip_bliss_set_key
+    std::vector<int32_t> d_a(n), d_acorr(n);
+    for (int i = 0; i < n; i++) d_a[i] = ka[i];
+    launch((unsigned)((n + 63) / 64), 64, [&]() { bl_acorr_kernel(kf, kg, d_acorr.data(), n); });
+    // ---- bl_ensure_ws / bl_sign_core's zeroing
+    std::vector<uint32_t> pos(B, 0u), var_buf(B, 0u), iter(B, 0u), cur(B, 0u), stat(B, 0u), act0(B), act1(B), cnt(16, 0u), need(B), sbase(B), ok(B);
+    std::vector<int32_t> var_bits(B, 0), tu((size_t)B * 2 * n), tin((size_t)B * n), v((size_t)B * n), cidx((size_t)B * P.kappa);
+    std::vector<int16_t> z((size_t)B * n);
+    St st{ pos.data(), var_buf.data(), iter.data(), cur.data(), stat.data(), var_bits.data(), nullptr };
+    for (uint32_t i = 0; i < B; i++) trials[i] = 0;
+    static int32_t sink[1024];
+    // the dynamic LDS of the sampler: the table, its padding, the bins (sc::cdt_lds_bytes)
+    const size_t slds = ((size_t)(cdf_size + CDT_PAD) * 8 + ((size_t)g.total + 2) * 2 + 15) & ~(size_t)15;
+    if (slds > sizeof emu::dyn_lds || (size_t)8 * n * 4 * 2 > sizeof emu::dyn_lds) return 2;
+
+    uint32_t nact = B, round = 0;
+    const uint32_t *active = nullptr;
+    for (; nact > 0; round++) {
+        if (round > 200) return 3;
+        uint32_t *next = (round & 1) ? act1.data() : act0.data();
+        cnt[0] = 0;
+        const uint32_t *nd = nullptr;
+        launch((nact + 255) / 256, 256, [&]() { bl_begin_kernel(active, nact, st, tape_lens, (uint32_t)tape_stride, n, need.data(), sbase.data(), siglens, mlens, nd); });
+        const size_t nsamp = (size_t)nact * 2 * n;
+        const unsigned sblocks = (unsigned)((nsamp + 256 * 32 - 1) / (256 * 32));
+#define BL_SAMPLE(SS) launch(sblocks, 256, [&]() { bl_sample_kernel<SS>(active, nact, need.data(), sbase.data(), cur.data(), tapes, tape_stride, probe, bins, g, cdf_size, tu.data(), n, st.msg_of, nd); })
+        switch (g.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#undef BL_SAMPLE
+        const size_t ne = (size_t)nact * n;
+        launch((unsigned)((ne + 255) / 256), 256, [&]() { bl_stage_kernel(active, nact, need.data(), cur.data(), tu.data(), tin.data(), n, nullptr, nullptr, st.msg_of, nd); });
+        {   // sc::polymul_ntt_bcast -> run_ntt(OP_MULNTT, bcast): the count is handed over as the device would hold it
+            NttArgs a{};
+            a.in0 = tin.data(); a.in1 = d_a.data(); a.out = v.data(); a.sink = sink; a.in1_bcast = 1u;
+            const uint32_t nd_here = nact;
+            a.batch_dev = &nd_here; a.batch = nact;
+            a.zf = tab; a.zfp = tab + n; a.zi = tab + 2 * n; a.zip = tab + 3 * n;
+            a.k = ModK{ modk[0], modk[1], modk[2], modk[3], modk[4], modk[5] };
+            a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
+            const int pw = 1024 / n;
+            const unsigned blocks = (unsigned)(((nact + pw - 1) / pw + 3) / 4);
+            if (L == 8) mulntt_bcast<8>(a, mode, blocks); else mulntt_bcast<9>(a, mode, blocks);
+        }
+        launch((unsigned)((ne + 255) / 256), 256, [&]() { bl_round_kernel(active, nact, cur.data(), tu.data(), v.data(), z.data(), P, nd); });
+        if (two_lane) launch((2 * nact + HT - 1) / HT, HT, [&]() { bl_oracle2_kernel(active, nact, need.data(), msgs, msg_stride, mlens, 0u, z.data(), cidx.data(), ok.data(), 0, nullptr, P, st.msg_of, nd); });
+        else launch((nact + HT - 1) / HT, HT, [&]() { bl_oracle1_kernel(active, nact, need.data(), msgs, msg_stride, mlens, 0u, z.data(), cidx.data(), ok.data(), 0, nullptr, P, st.msg_of, nd); });
+        // the deciding kernel on the one-key path: x | y per wavefront, then the key's shift table per wavefront (bl_round_launch's LDS size)
+        if (P.kappa <= 32) launch((nact + 3) / 4, 256, [&]() { bl_decide_kernel<32>(active, nact, need.data(), ok.data(), st, tapes, tape_stride, tape_lens, kf, kg, tu.data(), v.data(), z.data(), cidx.data(),
+                                                                                  sigs, sig_stride, siglens, trials, next, cnt.data(), P, 0x1p-40, (size_t)0, 0u, nd, d_acorr.data()); });
+        else launch((nact + 3) / 4, 256, [&]() { bl_decide_kernel<64>(active, nact, need.data(), ok.data(), st, tapes, tape_stride, tape_lens, kf, kg, tu.data(), v.data(), z.data(), cidx.data(),
+                                                                     sigs, sig_stride, siglens, trials, next, cnt.data(), P, 0x1p-40, (size_t)0, 0u, nd, d_acorr.data()); });
+        nact = cnt[0];
+        active = next;
+    }
+    for (uint32_t i = 0; i < B; i++) status[i] = stat[i];
+    *rounds = round;
+    return 0;
+}

@@ -9,6 +9,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 #include <algorithm>
 #include <condition_variable>
@@ -107,20 +108,37 @@ static inline int __shfl_xor(int v, int m) { return (int)(uint32_t)emu::exchange
 static inline int __shfl(int v, int src) { return (int)(uint32_t)emu::exchange((uint32_t)v, src); }
 static inline int emu_readlane(int v, int l) { return (int)(uint32_t)emu::exchange((uint32_t)v, l); }
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
-// DPP quad_perm moves whose every lane reads from its own PAIR of lanes (the two-lane Keccak's exchanges: [1,0,3,2], [0,0,2,2], [1,1,3,3]): a barrier
-// over the pair, not the wavefront - pairs run different numbers of permutations (a rejected sample in ExpandMask), as they do under the device's exec mask
+// DPP moves.  quad_perm controls whose every lane reads from its own PAIR of lanes (the two-lane Keccak's exchanges: [1,0,3,2], [0,0,2,2], [1,1,3,3]) are a
+// barrier over the pair, not the wavefront - pairs run different numbers of permutations (a rejected sample in ExpandMask), as they do under the
+// device's exec mask.  Any other quad_perm, row_half_mirror (0x141) and row_mirror (0x140) - the wave reductions' steps - are reached by the whole wavefront.
 static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
     (void)old; (void)bound_ctrl;
-    const int q = emu::my_lane & 3, sel = (ctrl >> (2 * q)) & 3;
-    if (ctrl > 0xFF || row_mask != 0xF || bank_mask != 0xF || (sel >> 1) != (q >> 1)) abort();      // anything else: not emulated
-    emu::Barrier &b = emu::my_wave->pair[emu::my_lane >> 1];
-    emu::my_wave->pbuf[emu::my_lane] = (uint32_t)src;
-    b.wait();
-    const int r = (int)emu::my_wave->pbuf[(emu::my_lane & ~3) | sel];
-    b.wait();
-    return r;
+    if (row_mask != 0xF || bank_mask != 0xF) abort();                                                 // not emulated
+    const int lane = emu::my_lane, q = lane & 3;
+    if (ctrl <= 0xFF) {
+        const int sel = (ctrl >> (2 * q)) & 3;
+        if ((sel >> 1) == (q >> 1)) {
+            bool pair_local = true;
+            for (int i = 0; i < 4; i++) pair_local &= (((ctrl >> (2 * i)) & 3) >> 1) == (i >> 1);
+            if (pair_local) {
+                emu::Barrier &b = emu::my_wave->pair[lane >> 1];
+                emu::my_wave->pbuf[lane] = (uint32_t)src;
+                b.wait();
+                const int r = (int)emu::my_wave->pbuf[(lane & ~3) | sel];
+                b.wait();
+                return r;
+            }
+        }
+        return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~3) | sel);
+    }
+    if (ctrl == 0x141) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~7) | (7 - (lane & 7)));
+    if (ctrl == 0x140) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~15) | (15 - (lane & 15)));
+    abort();
 }
+// The two lanes of a pair run in lockstep on the device; where a kernel relies on that for data the pair shares in LDS (one lane reads the half of a sponge
+// state the other has just written back), the harness inserts this into the copy it compiles (tests/emu_harness.py `rewrites`)
+static inline void emu_pair_sync() { emu::my_wave->pair[emu::my_lane >> 1].wait(); }
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) emu_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 // V_BITOP3_B32: bit (a << 2 | b << 1 | c) of the truth table, per bit position
 static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, unsigned tt)
@@ -131,6 +149,7 @@ static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, unsigned t
     return r;
 }
 #define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
+static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 namespace emu { alignas(16) static unsigned char dyn_lds[160 * 1024]; }     // the workgroup's dynamic LDS (`extern __shared__`, rewritten by the harness's build step)

@@ -3,7 +3,8 @@
 A harness tests/emu/<name>.cpp includes kernel headers of libsafecrypto_amd/csrc/ as HOST code over tests/emu/wave_emu.h.  The headers are compiled from
 a copy (tests/emu/_build/src*/) in which ONE construct is rewritten mechanically - the declaration of a workgroup's dynamic LDS,
 `extern __shared__ [aligned] T name[];`, becomes a pointer to the emulation's LDS array - everything else is the product's text; csrc/scalar_hint.h and
-<hip/hip_runtime.h> come from tests/emu/shim.  `mutate` removes the k-th `wave_lds_fence();` of one header: the harness's own test - a build with a fence
+<hip/hip_runtime.h> come from tests/emu/shim.  `rewrites` = further (header, old text, new text, occurrences) substitutions a harness needs and documents (a register read across lanes inside a
+branch only one lane takes, which the device answers from the idle lanes' registers and a thread per lane cannot).  `mutate` removes the k-th `wave_lds_fence();` of one header: the harness's own test - a build with a fence
 missing must come back from ThreadSanitizer as a data race."""
 import glob
 import os
@@ -18,7 +19,7 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'          # host mode: the kernel text u
 DYN_LDS = re.compile(r'extern __shared__ (?:__attribute__\(\(aligned\(16\)\)\) )?(\w+) (\w+)\[\];')
 
 
-def _sources(dst, mutate=None):
+def _sources(dst, mutate=None, rewrites=()):
     shutil.rmtree(dst, ignore_errors=True)
     os.makedirs(dst)
     for h in glob.glob(os.path.join(CSRC, '*.h')):
@@ -29,11 +30,15 @@ def _sources(dst, mutate=None):
         if mutate and mutate[0] == base:
             at = [m.start() for m in re.finditer(r'wave_lds_fence\(\);', text)][mutate[1]]
             text = text[:at] + text[at + len('wave_lds_fence();'):]
+        for fname, old, new, count in rewrites:
+            if fname == base:
+                assert text.count(old) == count, (fname, old, text.count(old))
+                text = text.replace(old, new)
         with open(os.path.join(dst, base), 'w') as f:
             f.write(text)
 
 
-def build(name, sanitize, mutate=None, out=None):
+def build(name, sanitize, mutate=None, out=None, rewrites=()):
     """tests/emu/<name>.cpp -> lib<name>_<sanitize>.so under tests/emu/_build (or `out`), rebuilt when a source is newer.  -O0: the run time is the threads'
     barriers either way, and the sanitizer builds of the larger harnesses take a minute at -O1"""
     out = out or os.path.join(EMU, '_build')
@@ -44,7 +49,7 @@ def build(name, sanitize, mutate=None, out=None):
            glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h'))
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         src = os.path.join(out, f'src_{name}_{tag}')
-        _sources(src, mutate)
+        _sources(src, mutate, rewrites)
         flags = ['-O0', '-g', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function',
                  '-Wno-unused-variable', '-Wno-shift-count-negative', '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
         if sanitize:
