@@ -150,6 +150,21 @@ static inline uint32_t emu_bitop3(uint32_t a, uint32_t b, uint32_t c, unsigned t
 }
 #define __builtin_amdgcn_bitop3_b32(a, b, c, tt) emu_bitop3((a), (b), (c), (tt))
 static inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
+// V_PERM_B32: byte i of the result is picked by byte i of the selector from the eight bytes { s0 (4-7), s1 (0-3) }; 8-11: sign bits (not used by the engine: abort),
+// 12: 0x00, 13-15: 0xFF
+static inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel)
+{
+    const uint64_t src = ((uint64_t)s0 << 32) | s1;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) {
+        const uint32_t k = (sel >> (8 * i)) & 0xFFu;
+        uint32_t b;
+        if (k < 8) b = (uint32_t)(src >> (8 * k)) & 0xFFu; else if (k == 12) b = 0; else if (k >= 13) b = 0xFFu; else abort();
+        r |= b << (8 * i);
+    }
+    return r;
+}
+#define __builtin_amdgcn_perm(a, b, sel) emu_perm((a), (b), (sel))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 namespace emu { alignas(16) static unsigned char dyn_lds[160 * 1024]; }     // the workgroup's dynamic LDS (`extern __shared__`, rewritten by the harness's build step)
