@@ -16,6 +16,7 @@ using namespace sc_mlwe;
 
 namespace {
 #include "dil_sign_dev.h"
+#include "dil_verify_dev.h"
 }
 
 namespace {
@@ -48,12 +49,17 @@ template <int OP> void launch_dil(DilNtt a, uint32_t nitems, int per)          /
     else launch(blocks, 256, [&]() { dil_ntt_kernel<OP, MODE_U32>(a); });
 }
 
+template <int LL> void launch_yawc_l(const DilNtt &a, unsigned blocks, bool alds)          // the verifier's form: c t1 2^d and UseHint fused in (CT1)
+{
+    if (a.sg) { if (alds) launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_S32, true, true>(a); }); else launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_S32, false, true>(a); }); }
+    else { if (alds) launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_U32, true, true>(a); }); else launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_U32, false, true>(a); }); }
+}
 template <int LL> void launch_yaw_l(const DilNtt &a, unsigned blocks, bool alds)
 {
     if (a.sg) { if (alds) launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_S32, true>(a); }); else launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_S32, false>(a); }); }
     else { if (alds) launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_U32, true>(a); }); else launch(blocks, 256, [&]() { dil_yaw_kernel<LL, MODE_U32, false>(a); }); }
 }
-int launch_yaw(DilNtt a, uint32_t nitems, unsigned max_blocks)                    // mlwe_launch_yaw
+int launch_yaw(DilNtt a, uint32_t nitems, unsigned max_blocks, bool ct1 = false)  // mlwe_launch_yaw
 {
     a.njobs = nitems; a.per = 1;
     if (!nitems) return 0;
@@ -62,10 +68,10 @@ int launch_yaw(DilNtt a, uint32_t nitems, unsigned max_blocks)                  
     const size_t ex = 4 * 1024 * sizeof(uint32_t), mat = (size_t)2 * a.kk * a.l * N * sizeof(uint32_t);
     const bool alds = 2 * (ex + mat) <= 160 * 1024;
     switch (a.l) {
-    case 2: launch_yaw_l<2>(a, blocks, alds); break;
-    case 3: launch_yaw_l<3>(a, blocks, alds); break;
-    case 4: launch_yaw_l<4>(a, blocks, alds); break;
-    case 5: launch_yaw_l<5>(a, blocks, alds); break;
+    case 2: if (ct1) launch_yawc_l<2>(a, blocks, alds); else launch_yaw_l<2>(a, blocks, alds); break;
+    case 3: if (ct1) launch_yawc_l<3>(a, blocks, alds); else launch_yaw_l<3>(a, blocks, alds); break;
+    case 4: if (ct1) launch_yawc_l<4>(a, blocks, alds); else launch_yaw_l<4>(a, blocks, alds); break;
+    case 5: if (ct1) launch_yawc_l<5>(a, blocks, alds); else launch_yaw_l<5>(a, blocks, alds); break;
     default: return 1;
     }
     return 0;
@@ -170,5 +176,53 @@ extern "C" int emu_dil_sign(const int32_t *par, const uint32_t *tab, const uint3
     for (int32_t v : y) res |= (uint32_t)v;
     for (int32_t v : w) res |= (uint32_t)v;
     *residue = res;
+    return 0;
+}
+
+// A verification call, one key for the batch: sc_hip_dilithium_set_pubkey (t1 2^d through the transform kernel, the matrix, tr = CRH(rho, t1)) and
+// sc_hip_dilithium_verify's default path - the three readers of the inputs as one launch, NTT(c), the fused NTT(z) -> A NTT(z) - NTT(c) NTT(t1 2^d) -> INTT ->
+// UseHint kernel, the challenge hash compared with the signature's c.  flags bit 1: one lane per challenge hash.  verdicts[i] = 0: signature i verifies.
+extern "C" int emu_dil_verify(const int32_t *par, const uint32_t *tab, const uint32_t *modk, const uint32_t *cinv, uint32_t r2, uint32_t r2p, int sg,
+                              const int32_t *t1, const uint8_t *rho, const int32_t *Ahat,
+                              uint32_t batch, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens, uint32_t fixed_len,
+                              const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int flags, uint32_t *verdicts)
+{
+    DilP P;
+    memcpy(&P, par, sizeof P);
+    const int k = P.k, l = P.l;
+    if (P.n != N || l < 2 || l > 5 || l * P.n / 8 > 256) return 1;
+    if ((size_t)(l * P.n * P.z_bits) / 8 > sig_stride) return 2;
+    Plan pl{ tab, ModK{ modk[0], modk[1], modk[2], modk[3], modk[4], modk[5] }, { cinv[0], cinv[1], cinv[2], cinv[3] }, r2, r2p, sg };
+    const uint32_t B = batch;
+    // ---- sc_hip_dilithium_set_pubkey
+    std::vector<int32_t> t1s((size_t)k * N);
+    for (size_t i = 0; i < t1s.size(); i++) t1s[i] = t1[i] << P.d;
+    std::vector<uint32_t> d_t1s((size_t)k * N), d_As((size_t)2 * k * l * N);
+    std::vector<uint8_t> tr_pub(48);
+    {
+        DilNtt a = base_args(pl, P);
+        a.in = t1s.data(); a.out_int = d_t1s.data(); launch_dil<DOP_KEYPREP>(a, (uint32_t)k, 1);
+        const size_t np = (size_t)k * l;
+        launch((unsigned)((np * N + 255) / 256), 256, [&]() { dil_to_internal_shoup(Ahat, d_As.data(), d_As.data() + np * N, np, pl.k); });
+        launch(1, HT, [&]() { dil_crh_t1_kernel(rho, t1, (uint32_t)t1s.size(), P.q_bits - P.d, tr_pub.data(), 1u); });
+    }
+    // ---- sc_hip_dilithium_verify
+    std::vector<uint8_t> mu((size_t)B * 48), h((size_t)B * k * N), w1((size_t)B * k * N);
+    std::vector<int32_t> c((size_t)B * N), z((size_t)B * l * N);
+    std::vector<uint32_t> ch((size_t)B * N), yh((size_t)B * l * N);
+    for (uint32_t i = 0; i < B; i++) verdicts[i] = 0;
+    const unsigned hb = (B + HT - 1) / HT;
+    if (P.z_bits == 20) launch((B + 3) / 4 + hb + B, 256, [&]() { dil_tail_mu_kernel<20>(sigs, sig_stride, siglens, B, h.data(), c.data(), verdicts, P, tr_pub.data(), msgs, msg_stride, mlens, fixed_len, mu.data(), z.data()); });
+    else launch((B + 3) / 4 + hb + B, 256, [&]() { dil_tail_mu_kernel<0>(sigs, sig_stride, siglens, B, h.data(), c.data(), verdicts, P, tr_pub.data(), msgs, msg_stride, mlens, fixed_len, mu.data(), z.data()); });
+    DilNtt a = base_args(pl, P);
+    a.yh = yh.data(); a.ch = ch.data(); a.w1 = w1.data(); a.z = z.data(); a.h = h.data();
+    if (a.sg && !(16ull * (2ull * (uint64_t)l + 1) * (uint64_t)P.q < (1ull << 31))) return 3;      // (the fused form's bound; every reference parameter set meets it)
+    a.in = c.data(); a.out_int = ch.data();
+    launch_dil<DOP_FWD_INT>(a, B, 1);
+    a.in = z.data(); a.out_int = yh.data();
+    a.key = d_As.data(); a.keyp = d_As.data() + (size_t)k * l * N; a.t1s = d_t1s.data();
+    if (launch_yaw(a, B, 512u, true)) return 4;
+    if (!(flags & 2)) launch((2 * B + CH_T - 1) / CH_T, CH_T, [&]() { dil_challenge_kernel<false, true>(nullptr, nullptr, B, mu.data(), w1.data(), k * P.n, P.weight, nullptr, c.data(), verdicts, 0u); });
+    else launch((B + CH_T - 1) / CH_T, CH_T, [&]() { dil_challenge_kernel<false, false>(nullptr, nullptr, B, mu.data(), w1.data(), k * P.n, P.weight, nullptr, c.data(), verdicts, 0u); });
     return 0;
 }

@@ -7,6 +7,7 @@ a copy (tests/emu/_build/src*/) in which ONE construct is rewritten mechanically
 branch only one lane takes, which the device answers from the idle lanes' registers and a thread per lane cannot).  `mutate` removes the k-th `wave_lds_fence();` of one header: the harness's own test - a build with a fence
 missing must come back from ThreadSanitizer as a data race."""
 import glob
+import hashlib
 import os
 import re
 import shutil
@@ -43,7 +44,7 @@ def build(name, sanitize, mutate=None, out=None, rewrites=()):
     barriers either way, and the sanitizer builds of the larger harnesses take a minute at -O1"""
     out = out or os.path.join(EMU, '_build')
     os.makedirs(out, exist_ok=True)
-    tag = (sanitize or 'plain').replace(',', '_') + (f'_mut{mutate[1]}' if mutate else '')
+    tag = (sanitize or 'plain').replace(',', '_') + (f'_mut{mutate[1]}' if mutate else '') + (('_' + hashlib.sha1(repr(rewrites).encode()).hexdigest()[:8]) if rewrites else '')
     so = os.path.join(out, f'lib{name}_{tag}.so')
     deps = [os.path.join(EMU, f'{name}.cpp'), os.path.join(EMU, 'wave_emu.h'), __file__] + glob.glob(os.path.join(EMU, 'shim', '*.h')) + \
            glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h'))

@@ -59,8 +59,19 @@ print('EMU_OK', tag, B, 'rounds', rounds.value, 'max trials', int(trials.max()),
 '''
 
 
+# the verifier's "this signature is invalid" flag is stored by every lane that finds a reason - the same value to the same word, one store instruction on the
+# device - which two threads cannot do without a report: an atomic store in the copy that is compiled
+REWRITES = (('dil_sign_dev.h', 'if (neq) verdict[item] = 1;', 'if (neq) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
+            ('dil_verify_dev.h', 'if (bad) verdict[item] = 1;', 'if (bad) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
+            ('dil_verify_dev.h', 'fresh > (uint32_t)P.omega)) verdict[item] = 1;', 'fresh > (uint32_t)P.omega)) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1))
+
+
+def _build(sanitize, **kw):
+    return build('emu_dil_sign', sanitize, rewrites=REWRITES, **kw)
+
+
 def _sign(sanitize, tag, B, cap, s_max, flags, seed, so=None):
-    so = so or build('emu_dil_sign', sanitize)
+    so = so or _build(sanitize)
     return drive(DRIVER, [so, tag, B, cap, s_max, flags, seed], sanitize)
 
 
@@ -80,6 +91,70 @@ def test_signing_call_is_race_free_tsan(flags):
 
 def test_the_harness_reports_a_removed_fence(tmp_path):
     """the finishing kernel without the fence between a wavefront's write of c into LDS and the lanes' reads of it: a data race in dil_cfin_kernel"""
-    so = build('emu_dil_sign', 'thread', mutate=('dil_sign_dev.h', 2), out=str(tmp_path))
+    so = _build('thread', mutate=('dil_sign_dev.h', 2), out=str(tmp_path))
     r = _sign('thread', 'dil3', 5, 10, 3, 0, 2, so=so)
     assert r.returncode != 0 and 'ThreadSanitizer: data race' in r.stderr and 'dil_cfin_kernel' in r.stderr, (r.stdout[-500:], r.stderr[-2000:])
+
+
+VERIFY_DRIVER = r'''
+import ctypes as C, sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+from tests.test_emu_ntt import PlanConsts, OP_INV, S32, U32
+so, tag, B, flags, seed = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+E = C.CDLL(so)
+vp = C.c_void_p
+E.emu_dil_verify.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp, vp, vp, C.c_uint32, vp, C.c_size_t, vp, C.c_uint32, vp, C.c_size_t, vp, C.c_int, vp]
+G = load_golden('dilithium_ref.txt')
+key = O.DilKey.from_golden(G, tag)
+q, n = key.q, key.n
+P = PlanConsts(q, n)
+sg = 1 if (P.s32_ok and 32 * max(key.k, key.l) * q < (1 << 31)) else 0
+tab, modk, cinv, _ = P.args(S32 if sg else U32, OP_INV)
+r2 = P.R; r2p = (P.R << 32) // q
+rng = np.random.default_rng(seed)
+msgs, sigs = [], []
+for i in range(B):
+    m = bytes(rng.integers(0, 256, size=int(rng.integers(0, 100)), dtype=np.uint8))
+    sg_, _ = O.dilithium_sign(key, m)
+    kind = i % 6
+    s = bytearray(sg_)
+    if kind == 1: s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))            # a flipped bit anywhere
+    elif kind == 2: s[len(s) - 70 - int(rng.integers(0, 40))] ^= 0x10                           # in the tail: hint count / positions / c
+    elif kind == 3: m = m + b'x'                                                               # another message
+    elif kind == 4: s = s[:len(s) - 1 - int(rng.integers(0, 60))]                               # truncated
+    elif kind == 5: s[key.l * n * int(key.par[11]) // 8] = 0xFF                                 # a hint count above omega
+    msgs.append(m); sigs.append(bytes(s))
+stride, sst = 104, 4096
+mb = np.zeros((B, stride), dtype=np.uint8); ml = np.zeros(B, dtype=np.uint32)
+sb = np.zeros((B, sst), dtype=np.uint8); sl = np.zeros(B, dtype=np.uint32)
+for i in range(B):
+    mb[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8); ml[i] = len(msgs[i])
+    sb[i, :len(sigs[i])] = np.frombuffer(sigs[i], dtype=np.uint8); sl[i] = len(sigs[i])
+sl[B - 1] = sst + 5                                                                            # a stated length beyond the row: invalid before anything is read
+verdicts = np.full(B, 7, dtype=np.uint32)
+p = lambda a: a.ctypes.data_as(vp)
+t0 = time.time()
+rc = E.emu_dil_verify(p(key.par), p(tab), p(modk), p(cinv), r2, r2p, sg, p(key.t1), p(key.rho), p(key.Ahat), B, p(mb), stride, p(ml), 0, p(sb), sst, p(sl), flags, p(verdicts))
+assert rc == 0, rc
+want = [0 if O.dilithium_verify(key, msgs[i], sigs[i]) == 0 else 1 for i in range(B)]
+want[B - 1] = 1
+assert verdicts.tolist() == want, (verdicts.tolist(), want)
+assert want.count(0) >= B // 6 and want.count(1) >= B // 2
+print('EMU_OK', tag, B, 'accepted', want.count(0), f'{time.time() - t0:.1f}s')
+'''
+
+
+# (parameter set, signatures - a sixth of them genuine, the rest tampered five ways -, flags: 2 = one lane per challenge hash)
+@pytest.mark.parametrize('tag,B,flags', [('dil3', 13, 0), ('dil3', 7, 2), ('dil0', 7, 0), ('dil1', 7, 0), ('dil2', 7, 0)])
+def test_verification_call_equals_the_oracle_asan_ubsan(tag, B, flags):
+    """sc_hip_dilithium_set_pubkey + sc_hip_dilithium_verify's default path (the three readers of the inputs as one launch, NTT(c), the fused matrix product with
+    c t1 2^d and UseHint, the challenge hash): the oracle's verdict on every signature"""
+    r = drive(VERIFY_DRIVER, [_build('address,undefined'), tag, B, flags, 3 * B + flags], 'address,undefined')
+    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_verification_call_is_race_free_tsan():
+    r = drive(VERIFY_DRIVER, [_build('thread'), 'dil3', 7, 0, 5], 'thread')
+    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
