@@ -42,6 +42,11 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 struct alignas(16) int4 { int32_t x, y, z, w; };
 static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{ x, y, z, w }; }
 struct alignas(8) uint2 { uint32_t x, y; };
+struct alignas(8) int2 { int32_t x, y; };
+static inline int2 make_int2(int32_t x, int32_t y) { return int2{ x, y }; }
+struct alignas(16) double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { return double2{ x, y }; }
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
 
 namespace emu {
 // A barrier out of a mutex and a condition variable rather than pthread_barrier_t: ThreadSanitizer models the former exactly, while behind a
@@ -65,7 +70,7 @@ struct Barrier {
     }
 };
 struct Wave { Barrier bar; Barrier pair[32]; uint64_t buf[64]; uint32_t pbuf[64]; };
-struct Block { Barrier bar; std::deque<Wave> waves; };
+struct Block { Barrier bar; std::deque<Wave> waves; int or_acc = 0; };
 static Block *cur_block;
 static thread_local Wave *my_wave;
 static thread_local int my_lane;
@@ -185,6 +190,18 @@ static inline void wave_lds_fence() { emu::wave_sync(); }               // csrc/
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync()
 #define __builtin_amdgcn_readfirstlane(v) emu_readlane((v), 0)
 static inline void __syncthreads() { emu::cur_block->bar.wait(); }
+static inline int __syncthreads_or(int p)           // a barrier that also returns whether any thread of the workgroup brought a non-zero value
+{
+    if (p) __atomic_store_n(&emu::cur_block->or_acc, 1, __ATOMIC_RELAXED);
+    emu::cur_block->bar.wait();
+    const int r = __atomic_load_n(&emu::cur_block->or_acc, __ATOMIC_RELAXED);
+    emu::cur_block->bar.wait();
+    if (threadIdx.x == 0) __atomic_store_n(&emu::cur_block->or_acc, 0, __ATOMIC_RELAXED);
+    emu::cur_block->bar.wait();
+    return r;
+}
+static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+#define __builtin_amdgcn_s_memtime() 0ull
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
