@@ -74,3 +74,13 @@ def sanitizer_env(sanitize):
 def drive(driver, args, sanitize, timeout=1500):
     """runs `driver` (python source) in a child with the sanitizer's runtime preloaded; returns the CompletedProcess"""
     return subprocess.run(['python3', '-c', driver, ROOT] + [str(a) for a in args], env=sanitizer_env(sanitize), capture_output=True, text=True, timeout=timeout)
+
+
+def drive_all(cases, workers=4):
+    """cases: {key: (driver, args, sanitize[, timeout])} -> {key: CompletedProcess}, `workers` children at a time (a child is a few hundred threads that
+    mostly wait on each other: several of them side by side is what keeps the CPU suite in minutes)"""
+    from concurrent.futures import ThreadPoolExecutor
+    keys = list(cases)
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        futs = [ex.submit(drive, *cases[k][:3], **({'timeout': cases[k][3]} if len(cases[k]) > 3 else {})) for k in keys]
+        return {k: f.result() for k, f in zip(keys, futs)}

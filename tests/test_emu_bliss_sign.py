@@ -11,7 +11,7 @@ made in the copy that is compiled, and only there: the two packing loops that ON
 pair barriers stand where the two lanes of a hash rely on running in lockstep (REWRITES below)."""
 import pytest
 
-from tests.emu_harness import build, drive
+from tests.emu_harness import build, drive_all
 
 REWRITES = (('bliss_sign_dev.h', 'bw.put((uint32_t)__builtin_amdgcn_readlane(pos_v, k), P.n_bits);', 'bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);', 2),
             # the two lanes of a hash run in lockstep on the device: a lane reads the half of the sponge state its partner wrote back, and both lanes test the
@@ -83,19 +83,27 @@ print('EMU_OK', tag, B, 'rounds', rounds.value, 'signed', int((status == 1).sum(
 '''
 
 
-def _sign(sanitize, tag, B, two_lane, seed):
-    so = build('emu_bliss_sign', sanitize, rewrites=REWRITES)
-    return drive(DRIVER, [so, tag, B, two_lane, seed], sanitize)
+CASES = [('bliss1', 12, 1), ('bliss1', 6, 0), ('bliss4', 8, 1), ('bliss3', 6, 1)]          # (parameter set, messages, two lanes per oracle hash)
 
 
-@pytest.mark.parametrize('tag,B,two_lane', [('bliss1', 12, 1), ('bliss1', 6, 0), ('bliss4', 8, 1), ('bliss3', 6, 1)])
-def test_signing_call_equals_the_oracle_asan_ubsan(tag, B, two_lane):
-    r = _sign('address,undefined', tag, B, two_lane, 7 * B + two_lane)
+@pytest.fixture(scope='module')
+def runs():
+    asan, tsan = build('emu_bliss_sign', 'address,undefined', rewrites=REWRITES), build('emu_bliss_sign', 'thread', rewrites=REWRITES)
+    cases = {c: (DRIVER, [asan, c[0], c[1], c[2], 7 * c[1] + c[2]], 'address,undefined') for c in CASES}
+    cases['tsan'] = (DRIVER, [tsan, 'bliss1', 6, 0, 3], 'thread')
+    return drive_all(cases)
+
+
+def _ok(r):
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_signing_call_is_race_free_tsan():
+@pytest.mark.parametrize('tag,B,two_lane', CASES)
+def test_signing_call_equals_the_oracle_asan_ubsan(runs, tag, B, two_lane):
+    _ok(runs[(tag, B, two_lane)])
+
+
+def test_signing_call_is_race_free_tsan(runs):
     """with one lane per oracle hash: the two lanes of bl_oracle2_kernel keep ONE bitmap of drawn indices and both store the same value to the same word
     - by design (one store instruction on the device), a write-write report for two threads"""
-    r = _sign('thread', 'bliss1', 6, 0, 3)
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    _ok(runs['tsan'])

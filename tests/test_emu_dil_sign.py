@@ -11,7 +11,7 @@ be zero behind the call.  The round loop in tests/emu/emu_dil_sign.cpp restates 
 kernels' logic and their interplay, not code generation or speed - tests/test_gpu_dilithium.py does that on the GPU."""
 import pytest
 
-from tests.emu_harness import build, drive
+from tests.emu_harness import build, drive, drive_all
 
 DRIVER = r'''
 import ctypes as C, sys, time, numpy as np
@@ -76,17 +76,34 @@ def _sign(sanitize, tag, B, cap, s_max, flags, seed, so=None):
 
 
 # (parameter set, messages, attempt slots per round, most slots per message, flags: 1 = the table finishing kernel, 2 = one lane per hash, 4 = persistent fused kernel)
-@pytest.mark.parametrize('tag,B,cap,s_max,flags', [('dil3', 9, 18, 3, 0), ('dil3', 6, 12, 3, 1), ('dil3', 7, 20, 32, 2), ('dil3', 13, 32, 4, 4),
-                                                   ('dil0', 6, 12, 32, 0), ('dil1', 6, 12, 32, 1), ('dil2', 4, 8, 2, 3)])
-def test_signing_call_equals_the_oracle_asan_ubsan(tag, B, cap, s_max, flags):
-    r = _sign('address,undefined', tag, B, cap, s_max, flags, 11 * B + flags)
+SIGN_CASES = [('dil3', 9, 18, 3, 0), ('dil3', 6, 12, 3, 1), ('dil3', 7, 20, 32, 2), ('dil3', 13, 32, 4, 4), ('dil0', 6, 12, 32, 0), ('dil1', 6, 12, 32, 1), ('dil2', 4, 8, 2, 3)]
+# (parameter set, signatures - a sixth of them genuine, the rest tampered five ways -, flags: 2 = one lane per challenge hash)
+VERIFY_CASES = [('dil3', 13, 0), ('dil3', 7, 2), ('dil0', 7, 0), ('dil1', 7, 0), ('dil2', 7, 0)]
+
+
+@pytest.fixture(scope='module')
+def runs():
+    """every case of this module, a few children at a time"""
+    asan, tsan = _build('address,undefined'), _build('thread')
+    cases = {('sign', 'asan') + c: (DRIVER, [asan, c[0], c[1], c[2], c[3], c[4], 11 * c[1] + c[4]], 'address,undefined') for c in SIGN_CASES}
+    cases.update({('sign', 'tsan', f): (DRIVER, [tsan, 'dil3', 5, 10, 3, f, 2], 'thread') for f in (0, 1)})
+    cases.update({('verify', 'asan') + c: (VERIFY_DRIVER, [asan, c[0], c[1], c[2], 3 * c[1] + c[2]], 'address,undefined') for c in VERIFY_CASES})
+    cases[('verify', 'tsan')] = (VERIFY_DRIVER, [tsan, 'dil3', 7, 0, 5], 'thread')
+    return drive_all(cases)
+
+
+def _ok(r):
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize('tag,B,cap,s_max,flags', SIGN_CASES)
+def test_signing_call_equals_the_oracle_asan_ubsan(runs, tag, B, cap, s_max, flags):
+    _ok(runs[('sign', 'asan', tag, B, cap, s_max, flags)])
 
 
 @pytest.mark.parametrize('flags', [0, 1])
-def test_signing_call_is_race_free_tsan(flags):
-    r = _sign('thread', 'dil3', 5, 10, 3, flags, 2)
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+def test_signing_call_is_race_free_tsan(runs, flags):
+    _ok(runs[('sign', 'tsan', flags)])
 
 
 def test_the_harness_reports_a_removed_fence(tmp_path):
@@ -146,15 +163,12 @@ print('EMU_OK', tag, B, 'accepted', want.count(0), f'{time.time() - t0:.1f}s')
 '''
 
 
-# (parameter set, signatures - a sixth of them genuine, the rest tampered five ways -, flags: 2 = one lane per challenge hash)
-@pytest.mark.parametrize('tag,B,flags', [('dil3', 13, 0), ('dil3', 7, 2), ('dil0', 7, 0), ('dil1', 7, 0), ('dil2', 7, 0)])
-def test_verification_call_equals_the_oracle_asan_ubsan(tag, B, flags):
+@pytest.mark.parametrize('tag,B,flags', VERIFY_CASES)
+def test_verification_call_equals_the_oracle_asan_ubsan(runs, tag, B, flags):
     """sc_hip_dilithium_set_pubkey + sc_hip_dilithium_verify's default path (the three readers of the inputs as one launch, NTT(c), the fused matrix product with
     c t1 2^d and UseHint, the challenge hash): the oracle's verdict on every signature"""
-    r = drive(VERIFY_DRIVER, [_build('address,undefined'), tag, B, flags, 3 * B + flags], 'address,undefined')
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    _ok(runs[('verify', 'asan', tag, B, flags)])
 
 
-def test_verification_call_is_race_free_tsan():
-    r = drive(VERIFY_DRIVER, [_build('thread'), 'dil3', 7, 0, 5], 'thread')
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+def test_verification_call_is_race_free_tsan(runs):
+    _ok(runs[('verify', 'tsan')])

@@ -10,7 +10,7 @@ ragged last workgroup, a tape that is too short, and the per-call secrets zero b
 functions (sc_hip_cdt_table_size / sc_hip_cdt_build_table, as sc_hip_falcon_set_privkeys does), the root table is the oracle's regenerated fpr_gm_tab."""
 import pytest
 
-from tests.emu_harness import build, drive
+from tests.emu_harness import build, drive_all
 
 DRIVER = r'''
 import ctypes as C, sys, time, numpy as np
@@ -86,20 +86,29 @@ print('EMU_OK', tag, B, 'variant', variant, 'signed', signed, f'{time.time() - t
 REWRITES = (('falcon_sign_dev.h', 'const double *LL = stree + (toff - toffLM);', 'const double *LL = l <= LM ? stree + (toff - toffLM) : stree;', 1),)
 
 
-def _sign(sanitize, tag, B, variant, two_lane, seed):
-    return drive(DRIVER, [build('emu_falcon_sign', sanitize, rewrites=REWRITES), tag, B, variant, two_lane, seed], sanitize, timeout=2400)
-
-
 # (parameter set, messages, sampler mapping: 0 = the default (8 per wavefront, two wavefronts), 1 = one wavefront, 2 = 64-coefficient sub-trees in LDS,
 #  3 = a lane per signature, 4 = eight lanes per signature; hash with two lanes per message or one)
-@pytest.mark.parametrize('tag,B,variant,two_lane', [('falcon2', 9, 0, 1), ('falcon0', 11, 0, 0), ('falcon0', 9, 1, 1), ('falcon0', 9, 2, 1), ('falcon0', 5, 3, 1), ('falcon0', 5, 4, 1)])
-def test_signing_call_equals_the_oracle_asan_ubsan(tag, B, variant, two_lane):
-    r = _sign('address,undefined', tag, B, variant, two_lane, 13 * B + variant)
+CASES = [('falcon2', 9, 0, 1), ('falcon0', 11, 0, 0), ('falcon0', 9, 1, 1), ('falcon0', 9, 2, 1), ('falcon0', 5, 3, 1), ('falcon0', 5, 4, 1)]
+
+
+@pytest.fixture(scope='module')
+def runs():
+    asan, tsan = build('emu_falcon_sign', 'address,undefined', rewrites=REWRITES), build('emu_falcon_sign', 'thread', rewrites=REWRITES)
+    cases = {c: (DRIVER, [asan, c[0], c[1], c[2], c[3], 13 * c[1] + c[2]], 'address,undefined', 2400) for c in CASES}
+    cases['tsan'] = (DRIVER, [tsan, 'falcon2', 5, 0, 1, 6], 'thread', 2400)
+    return drive_all(cases)
+
+
+def _ok(r):
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_default_mapping_is_race_free_tsan():
+@pytest.mark.parametrize('tag,B,variant,two_lane', CASES)
+def test_signing_call_equals_the_oracle_asan_ubsan(runs, tag, B, variant, two_lane):
+    _ok(runs[(tag, B, variant, two_lane)])
+
+
+def test_default_mapping_is_race_free_tsan(runs):
     """Falcon-1024.  (At n = 512 the two wavefronts of a workgroup have more lanes than a transform pass has butterfly groups; the spare lanes "redo group 0
     and store nothing" - they READ the points lane 0 is writing back and discard what they computed: a report for two threads, nothing on the device.)"""
-    r = _sign('thread', 'falcon2', 5, 0, 1, 6)
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    _ok(runs['tsan'])

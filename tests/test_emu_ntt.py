@@ -16,7 +16,7 @@ import pytest
 
 from tests import oracle_lib as O
 
-from tests.emu_harness import ROOT, build, drive
+from tests.emu_harness import ROOT, build, drive, drive_all
 
 OP_FWD, OP_INV, OP_MULNTT, OP_MUL, OP_MULNTT2 = range(5)
 U24, U32, MAD, SMAD, S32 = 1, 2, 3, 4, 5
@@ -163,21 +163,30 @@ print('EMU_OK', ran)
 CFGS = [(7681, 256), (8380417, 256), (12289, 512), (12289, 1024), (8399873, 512), (15361, 512)]
 
 
-def _drive(sanitize, q, n, extreme, only=None):
-    so = build('emu_ntt', sanitize)
-    r = drive(DRIVER, [so, q, n, extreme] + ([only] if only else []), sanitize)
+TSAN_CASES = [(7681, 256, '4'), (8380417, 256, '5'), (12289, 512, '4,3'), (12289, 1024, '5,2')]
+
+
+@pytest.fixture(scope='module')
+def runs():
+    asan, tsan = build('emu_ntt', 'address,undefined'), build('emu_ntt', 'thread')
+    cases = {('asan', q, n): (DRIVER, [asan, q, n, 1], 'address,undefined') for q, n in CFGS}
+    cases.update({('tsan', q, n): (DRIVER, [tsan, q, n, 0, only], 'thread') for q, n, only in TSAN_CASES})
+    return drive_all(cases)
+
+
+def _ok(r):
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 @pytest.mark.parametrize('q,n', CFGS)
-def test_every_instantiation_gives_the_oracles_words_asan_ubsan(q, n):
-    _drive('address,undefined', q, n, 1)
+def test_every_instantiation_gives_the_oracles_words_asan_ubsan(runs, q, n):
+    _ok(runs[('asan', q, n)])
 
 
-@pytest.mark.parametrize('q,n,only', [(7681, 256, '4'), (8380417, 256, '5'), (12289, 512, '4,3'), (12289, 1024, '5,2')])
-def test_lds_exchanges_are_race_free_tsan(q, n, only):
+@pytest.mark.parametrize('q,n,only', TSAN_CASES)
+def test_lds_exchanges_are_race_free_tsan(runs, q, n, only):
     """the modes the schemes run (signed) plus one unsigned form per size; seeded inputs"""
-    _drive('thread', q, n, 0, only)
+    _ok(runs[('tsan', q, n)])
 
 
 @pytest.mark.parametrize('which', [0, 1])

@@ -9,7 +9,7 @@ reference's (tests/test_oracle_tesla.py) - over several rounds with a shrinking 
 ends inside the rejection loop, and the per-call secrets zero behind the call."""
 import pytest
 
-from tests.emu_harness import build, drive
+from tests.emu_harness import build, drive_all
 
 DRIVER = r'''
 import ctypes as C, sys, time, numpy as np
@@ -63,17 +63,25 @@ print('EMU_OK', tag, B, 'rounds', rounds.value, 'signed', int((status == 1).sum(
 '''
 
 
-def _sign(sanitize, tag, B, cap, seed):
-    return drive(DRIVER, [build('emu_tesla_sign', sanitize), tag, B, cap, seed], sanitize)
+CASES = [('tesla0', 10, 12), ('tesla0', 5, 20), ('tesla1', 6, 8)]          # (parameter set, messages, attempt slots per round)
 
 
-# (parameter set, messages, attempt slots per round)
-@pytest.mark.parametrize('tag,B,cap', [('tesla0', 10, 12), ('tesla0', 5, 20), ('tesla1', 6, 8)])
-def test_signing_call_equals_the_oracle_asan_ubsan(tag, B, cap):
-    r = _sign('address,undefined', tag, B, cap, 5 * B + cap)
+@pytest.fixture(scope='module')
+def runs():
+    asan, tsan = build('emu_tesla_sign', 'address,undefined'), build('emu_tesla_sign', 'thread')
+    cases = {c: (DRIVER, [asan, c[0], c[1], c[2], 5 * c[1] + c[2]], 'address,undefined') for c in CASES}
+    cases['tsan'] = (DRIVER, [tsan, 'tesla0', 6, 8, 4], 'thread')
+    return drive_all(cases)
+
+
+def _ok(r):
     assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_signing_call_is_race_free_tsan():
-    r = _sign('thread', 'tesla0', 6, 8, 4)
-    assert r.returncode == 0 and 'EMU_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+@pytest.mark.parametrize('tag,B,cap', CASES)
+def test_signing_call_equals_the_oracle_asan_ubsan(runs, tag, B, cap):
+    _ok(runs[(tag, B, cap)])
+
+
+def test_signing_call_is_race_free_tsan(runs):
+    _ok(runs['tsan'])
