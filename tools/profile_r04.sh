@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$1
 mkdir -p $OUT
 timeout 900 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+cp bench_extra.json $OUT/bench_extra.json 2>/dev/null
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc > $OUT/trace_bench.json 2> $OUT/trace.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/pmc_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $OUT/pmc_write.err
