@@ -15,6 +15,7 @@
 
 namespace {
 #include "bliss_sign_dev.h"
+#include "bliss_verify_dev.h"
 }
 
 namespace {
@@ -100,5 +101,43 @@ extern "C" int emu_bliss_sign(const int32_t *par, int mode, const uint32_t *tab,
     }
     for (uint32_t i = 0; i < B; i++) status[i] = stat[i];
     *rounds = round;
+    return 0;
+}
+
+// A verification call, one key for the batch, raw signature coding: sc_hip_bliss_verify's path (bl_verify_core) - the signature's unpacking, the norm tests, the
+// product a t on the NTT kernel with the public key broadcast, z recovered from it and the challenge positions, the oracle compared with the signature's.
+// verdicts[i] = 0: signature i verifies.
+extern "C" int emu_bliss_verify(const int32_t *par, int mode, const uint32_t *tab, const uint32_t *modk, const uint32_t *c, const int16_t *ka,
+                                uint32_t batch, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+                                const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, int two_lane, uint32_t *verdicts)
+{
+    BlissP P;
+    memcpy(&P, par, sizeof P);
+    const int n = P.n, L = n == 256 ? 8 : n == 512 ? 9 : 0;
+    if (!L) return 1;
+    const uint32_t B = batch;
+    const size_t sigb = ((size_t)P.n * (P.z1_bits + P.z2_bits) + (size_t)P.kappa * P.n_bits + 7) / 8;
+    if (sig_stride < sigb || ((sigb + 16 + 3) & ~(size_t)3) > sizeof emu::dyn_lds) return 2;
+    std::vector<int32_t> d_a(n), tin((size_t)B * n), v((size_t)B * n), cidx((size_t)B * P.kappa);
+    std::vector<int16_t> z((size_t)B * n);
+    for (int i = 0; i < n; i++) d_a[i] = ka[i];
+    for (uint32_t i = 0; i < B; i++) verdicts[i] = 0;
+    static int32_t sink[1024];
+    launch(B, 256, [&]() { bl_unpack_kernel(sigs, sig_stride, siglens, B, tin.data(), z.data(), cidx.data(), verdicts, P); });
+    launch((B + 3) / 4, 256, [&]() { bl_vnorm_kernel(tin.data(), z.data(), B, verdicts, P); });
+    {
+        NttArgs a{};
+        a.in0 = tin.data(); a.in1 = d_a.data(); a.out = v.data(); a.sink = sink; a.in1_bcast = 1u; a.batch = B;
+        a.zf = tab; a.zfp = tab + n; a.zi = tab + 2 * n; a.zip = tab + 3 * n;
+        a.k = ModK{ modk[0], modk[1], modk[2], modk[3], modk[4], modk[5] };
+        a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
+        const int pw = 1024 / n;
+        const unsigned blocks = (unsigned)(((B + pw - 1) / pw + 3) / 4);
+        if (L == 8) mulntt_bcast<8>(a, mode, blocks); else mulntt_bcast<9>(a, mode, blocks);
+    }
+    if (n == 512) launch((B + 3) / 4, 256, [&]() { bl_vfix_kernel<8>(v.data(), cidx.data(), z.data(), B, P); });
+    else launch((B + 3) / 4, 256, [&]() { bl_vfix_kernel<4>(v.data(), cidx.data(), z.data(), B, P); });
+    if (two_lane) launch((2 * B + HT - 1) / HT, HT, [&]() { bl_oracle2_kernel(nullptr, B, nullptr, msgs, msg_stride, mlens, 0u, z.data(), cidx.data(), nullptr, 1, verdicts, P); });
+    else launch((B + HT - 1) / HT, HT, [&]() { bl_oracle1_kernel(nullptr, B, nullptr, msgs, msg_stride, mlens, 0u, z.data(), cidx.data(), nullptr, 1, verdicts, P); });
     return 0;
 }

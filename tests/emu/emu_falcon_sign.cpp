@@ -7,13 +7,16 @@
 // Test infrastructure (tests/test_emu_falcon_sign.py); nothing here is part of the product.
 #pragma clang fp contract(off)
 #define EMU_SHARED static
+#define EMU_HAVE_NTT_CORE
 #include "wave_emu.h"
 #include "keccak_dev.h"
+#include "ntt_kernel.h"
 
-using namespace sc;
+namespace sc { static inline int pow2_shift(int per) { return 31 - __builtin_clz((unsigned)per); } }      // csrc/engine_internal.h:47 (a header of the host runtime)
 
 namespace {
 #include "falcon_sign_dev.h"
+#include "falcon_verify_dev.h"
 }
 
 namespace {
@@ -84,5 +87,47 @@ extern "C" int emu_falcon_sign(const int32_t *par, const double *sk, const doubl
     for (int32_t v : s1) res |= (uint32_t)v;
     for (int32_t v : s2) res |= (uint32_t)v;
     *residue = res ? 1u : 0u;
+    return 0;
+}
+
+// A verification call, one key for the batch: sc_hip_falcon_set_pubkey (h reduced and transformed on the NTT kernel) and fal_verify_core - the hash to the ring
+// and the signature's unpacking as one launch, s2 h on the NTT kernel with the key broadcast, the finishing kernel (s1 = c - s2 h centred, the float norm
+// test).  tab / modk / cf / cm: the plan's table, ModK and the scale constants for OP_FWD and for OP_MULNTT in `mode`.  verdicts[i] = 0: valid.
+extern "C" int emu_falcon_verify(const int32_t *par, int mode, const uint32_t *tab, const uint32_t *modk, const uint32_t *cf, const uint32_t *cm, const int16_t *h,
+                                 uint32_t batch, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+                                 const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t *verdicts)
+{
+    FalP P;
+    memcpy(&P, par, sizeof P);
+    const int n = P.n;
+    if ((n != 512 && n != 1024) || (mode != MODE_SMAD && mode != MODE_S32)) return 1;
+    const uint32_t B = batch;
+    static int32_t sink[1024];
+    const ModK mk{ modk[0], modk[1], modk[2], modk[3], modk[4], modk[5] };
+    auto args = [&](const uint32_t *c) { NttArgs a{}; a.sink = sink; a.zf = tab; a.zfp = tab + n; a.zi = tab + 2 * n; a.zip = tab + 3 * n; a.k = mk; a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3]; return a; };
+    // ---- sc_hip_falcon_set_pubkeys
+    std::vector<int32_t> hhat(n);
+    for (int i = 0; i < n; i++) { int32_t v = h[i] % P.q; if (v < 0) v += P.q; hhat[i] = v; }
+    {
+        NttArgs a = args(cf);
+        a.in0 = hhat.data(); a.out = hhat.data(); a.batch = 1;
+        if (n == 512) { if (mode == MODE_SMAD) launch(1, 256, [&]() { ntt_kernel<9, MODE_SMAD, true, OP_FWD, false>(a); }); else launch(1, 256, [&]() { ntt_kernel<9, MODE_S32, true, OP_FWD, false>(a); }); }
+        else { if (mode == MODE_SMAD) launch(1, 256, [&]() { ntt_kernel<10, MODE_SMAD, true, OP_FWD, false>(a); }); else launch(1, 256, [&]() { ntt_kernel<10, MODE_S32, true, OP_FWD, false>(a); }); }
+    }
+    // ---- fal_verify_core
+    std::vector<int32_t> c((size_t)B * n), s1((size_t)B * n), s2((size_t)B * n);
+    for (uint32_t i = 0; i < B; i++) verdicts[i] = 0;
+    const size_t ne = (size_t)B * n;
+    launch((2 * B + HT - 1) / HT + (unsigned)((ne / 2 + 255) / 256), 256, [&]() { fal_hash2_unpack_kernel(B, msgs, msg_stride, mlens, 0u, c.data(), P, 0, sigs, sig_stride, siglens, s2.data(), verdicts, P.q_bits - 2, 1); });
+    {
+        NttArgs a = args(cm);
+        a.in0 = s2.data(); a.in1 = hhat.data(); a.out = s1.data(); a.in1_bcast = 1u; a.batch = B;
+        const int pw = 1024 / n;
+        const unsigned blocks = (unsigned)(((B + pw - 1) / pw + 3) / 4);
+        if (n == 512) { if (mode == MODE_SMAD) launch(blocks, 256, [&]() { ntt_kernel<9, MODE_SMAD, true, OP_MULNTT, false>(a); }); else launch(blocks, 256, [&]() { ntt_kernel<9, MODE_S32, true, OP_MULNTT, false>(a); }); }
+        else { if (mode == MODE_SMAD) launch(blocks, 256, [&]() { ntt_kernel<10, MODE_SMAD, true, OP_MULNTT, false>(a); }); else launch(blocks, 256, [&]() { ntt_kernel<10, MODE_S32, true, OP_MULNTT, false>(a); }); }
+    }
+    if (sizeof(int32_t) * FW * (size_t)n > sizeof emu::dyn_lds) return 2;
+    launch((B + FW - 1) / FW, 64 * FW, [&]() { fal_vfinish_kernel(B, c.data(), s1.data(), s2.data(), verdicts, P); });
     return 0;
 }

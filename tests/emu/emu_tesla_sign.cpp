@@ -14,6 +14,7 @@
 
 namespace {
 #include "tesla_sign_dev.h"
+#include "tesla_verify_dev.h"
 }
 
 namespace {
@@ -95,5 +96,56 @@ extern "C" int emu_tesla_sign(const int32_t *par, int mode, int lazy, const uint
     *residue = res;
     for (uint32_t i = 0; i < B; i++) status[i] = stat[i];
     *rounds = round;
+    return 0;
+}
+
+// A verification call: sc_hip_tesla_verify's path - z's unpacking with test_rejection and F from the signature's digest as one launch, a1 z and a2 z from one
+// forward transform, w = a z - t c through the public key's shift tables, rounding, the oracle compared with the signature's digest.  verdicts[i] = 0: valid.
+extern "C" int emu_tesla_verify(const int32_t *par, int mode, int lazy, const uint32_t *tab, const uint32_t *modk, const uint32_t *c,
+                                const int32_t *a1, const int32_t *a2, const int32_t *t1, const int32_t *t2,
+                                uint32_t batch, const uint8_t *msgs, size_t msg_stride, const uint32_t *mlens,
+                                const uint8_t *sigs, size_t sig_stride, const uint32_t *siglens, uint32_t *verdicts)
+{
+    TsP P;
+    memcpy(&P, par, sizeof P);
+    const int n = P.n;
+    if (n != 512 || (mode != MODE_SMAD && mode != MODE_S32 && mode != MODE_U32)) return 1;
+    const uint32_t B = batch;
+    const uint32_t zblocks = (uint32_t)(8 * n / 72);
+    std::vector<uint64_t> zstate(25);
+    launch(1, HT, [&]() { ts_zero_prefix_kernel(zblocks, zstate.data()); });
+    std::vector<int32_t> ttab(4 * (size_t)n);                               // sc_hip_tesla_set_key: t1 | -t1 | t2 | -t2
+    for (int m = 0; m < n; m++) { ttab[m] = t1[m]; ttab[n + m] = -t1[m]; ttab[2 * n + m] = t2[m]; ttab[3 * n + m] = -t2[m]; }
+    std::vector<int32_t> y((size_t)B * n), v1((size_t)B * n), v2((size_t)B * n), r1((size_t)B * n), r2((size_t)B * n), cidx((size_t)B * P.omega);
+    std::vector<uint32_t> nz(B);
+    for (uint32_t i = 0; i < B; i++) verdicts[i] = 0;
+    static int32_t sink[1024];
+    const uint32_t md_off = ((uint32_t)P.n * P.q_bits + 7) / 8;
+    if (sig_stride < md_off + 64) return 2;
+    launch((B + HT - 1) / HT + (B + 3) / 4, 256, [&]() { ts_unpack_f_kernel(B, sigs, sig_stride, siglens, y.data(), verdicts, P, md_off, cidx.data()); });
+    const ModK mk{ modk[0], modk[1], modk[2], modk[3], modk[4], modk[5] };
+    {
+        NttArgs a{};
+        a.in0 = y.data(); a.in1 = a1; a.in2 = a2; a.out = v1.data(); a.out2 = v2.data(); a.sink = sink; a.in1_bcast = 1u; a.batch = B;
+        a.zf = tab; a.zfp = tab + n; a.zi = tab + 2 * n; a.zip = tab + 3 * n; a.k = mk;
+        a.c0 = c[0]; a.c0p = c[1]; a.c1 = c[2]; a.c1p = c[3];
+        const int pw = 1024 / n;
+        const unsigned blocks = (unsigned)(((B + pw - 1) / pw + 3) / 4);
+        if (mode == MODE_SMAD) launch(blocks, 256, [&]() { ntt_kernel<9, MODE_SMAD, true, OP_MULNTT2, false>(a); });
+        else if (mode == MODE_S32) launch(blocks, 256, [&]() { ntt_kernel<9, MODE_S32, true, OP_MULNTT2, false>(a); });
+        else {
+            for (int which = 0; which < 2; which++) {
+                NttArgs b = a;
+                if (which) { b.in1 = a2; b.out = v2.data(); }
+                if (lazy) launch(blocks, 256, [&]() { ntt_kernel<9, MODE_U32, true, OP_MULNTT, false>(b); });
+                else launch(blocks, 256, [&]() { ntt_kernel<9, MODE_U32, false, OP_MULNTT, false>(b); });
+            }
+        }
+    }
+    if (sizeof(int32_t) * 4 * (size_t)n > sizeof emu::dyn_lds) return 3;
+    launch((B + 3) / 4, 256, [&]() { ts_vw_kernel(B, v1.data(), v2.data(), ttab.data(), cidx.data(), P, mk); });
+    launch((B + 3) / 4, 256, [&]() { ts_round_kernel(B, v1.data(), v2.data(), r1.data(), r2.data(), nz.data(), 0, P, nullptr); });
+    launch((B + HT - 1) / HT, HT, [&]() { ts_oracle_kernel(nullptr, B, 1u, nullptr, msgs, msg_stride, mlens, 0u, r1.data(), r2.data(), nz.data(), zstate.data(), zblocks, nullptr, 1, verdicts,
+                                                           sigs, sig_stride, md_off, P, nullptr); });
     return 0;
 }

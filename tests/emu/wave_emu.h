@@ -42,6 +42,7 @@ static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
 struct alignas(16) int4 { int32_t x, y, z, w; };
 static inline int4 make_int4(int32_t x, int32_t y, int32_t z, int32_t w) { return int4{ x, y, z, w }; }
 struct alignas(8) uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{ x, y }; }
 struct alignas(8) int2 { int32_t x, y; };
 static inline int2 make_int2(int32_t x, int32_t y) { return int2{ x, y }; }
 struct alignas(16) double2 { double x, y; };

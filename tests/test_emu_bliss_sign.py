@@ -83,6 +83,56 @@ print('EMU_OK', tag, B, 'rounds', rounds.value, 'signed', int((status == 1).sum(
 '''
 
 
+VERIFY_DRIVER = r'''
+import ctypes as C, sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+from tests.test_emu_ntt import PlanConsts, OP_MULNTT, SMAD, S32, MAD, U32
+so, tag, B, two_lane, seed = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+E = C.CDLL(so)
+vp = C.c_void_p
+E.emu_bliss_verify.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp, C.c_size_t, vp, C.c_int, vp]
+G = load_golden('bliss_ref.txt')
+key = O.BlissKey.from_golden(G, tag)
+n, q = key.n, key.q
+P = PlanConsts(q, n)
+mode = SMAD if P.smad_ok else S32 if P.s32_ok else MAD if P.mad_ok else U32
+tab, modk, c, _ = P.args(mode, OP_MULNTT)
+rng = np.random.default_rng(seed)
+msgs, sigs = [], []
+while len(msgs) < B:
+    m = bytes(rng.integers(0, 256, size=int(rng.integers(1, 90)), dtype=np.uint8))
+    tape = rng.integers(0, 2**32, size=6 * 4 * n + 64, dtype=np.uint64).astype(np.uint32)
+    rc, sg, _, _ = O.bliss_sign(key, m, tape)
+    if rc != 0:
+        continue
+    i = len(msgs); kind = i % 5
+    s = bytearray(sg)
+    if kind == 1: s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))       # a flipped bit anywhere
+    elif kind == 2: s[len(s) - 1 - int(rng.integers(0, 20))] ^= 0x08                       # in the challenge positions
+    elif kind == 3: m = m + b'x'                                                          # another message
+    elif kind == 4: s[0] ^= 0x80                                                          # the top bit of the first coefficient of t: a norm violation
+    msgs.append(m); sigs.append(bytes(s))
+stride, sst = 96, 1536
+mb = np.zeros((B, stride), dtype=np.uint8); ml = np.zeros(B, dtype=np.uint32)
+sb = np.zeros((B, sst), dtype=np.uint8); sl = np.zeros(B, dtype=np.uint32)
+for i in range(B):
+    mb[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8); ml[i] = len(msgs[i])
+    sb[i, :len(sigs[i])] = np.frombuffer(sigs[i], dtype=np.uint8); sl[i] = len(sigs[i])
+verdicts = np.full(B, 7, dtype=np.uint32)
+p = lambda a: a.ctypes.data_as(vp)
+t0 = time.time()
+rc = E.emu_bliss_verify(p(key.par), mode, p(tab), p(modk), p(c), p(key.a), B, p(mb), stride, p(ml), p(sb), sst, p(sl), two_lane, p(verdicts))
+assert rc == 0, rc
+want = [0 if O.bliss_verify(key, msgs[i], sigs[i]) == 0 else 1 for i in range(B)]
+assert verdicts.tolist() == want, (verdicts.tolist(), want)
+assert want.count(0) >= B // 5 and want.count(1) >= B // 2
+print('EMU_OK', tag, B, 'accepted', want.count(0), f'{time.time() - t0:.1f}s')
+'''
+
+VERIFY_CASES = [('bliss1', 11, 1), ('bliss4', 6, 0), ('bliss3', 6, 1)]          # (parameter set, signatures - a fifth genuine, the rest tampered four ways -, two lanes per oracle hash)
+
 CASES = [('bliss1', 12, 1), ('bliss1', 6, 0), ('bliss4', 8, 1), ('bliss3', 6, 1)]          # (parameter set, messages, two lanes per oracle hash)
 
 
@@ -91,6 +141,8 @@ def runs():
     asan, tsan = build('emu_bliss_sign', 'address,undefined', rewrites=REWRITES), build('emu_bliss_sign', 'thread', rewrites=REWRITES)
     cases = {c: (DRIVER, [asan, c[0], c[1], c[2], 7 * c[1] + c[2]], 'address,undefined') for c in CASES}
     cases['tsan'] = (DRIVER, [tsan, 'bliss1', 6, 0, 3], 'thread')
+    cases.update({('verify',) + c: (VERIFY_DRIVER, [asan, c[0], c[1], c[2], 9 * c[1] + c[2]], 'address,undefined') for c in VERIFY_CASES})
+    cases['verify tsan'] = (VERIFY_DRIVER, [tsan, 'bliss1', 6, 0, 4], 'thread')
     return drive_all(cases)
 
 
@@ -107,3 +159,14 @@ def test_signing_call_is_race_free_tsan(runs):
     """with one lane per oracle hash: the two lanes of bl_oracle2_kernel keep ONE bitmap of drawn indices and both store the same value to the same word
     - by design (one store instruction on the device), a write-write report for two threads"""
     _ok(runs['tsan'])
+
+
+@pytest.mark.parametrize('tag,B,two_lane', VERIFY_CASES)
+def test_verification_call_equals_the_oracle_asan_ubsan(runs, tag, B, two_lane):
+    """sc_hip_bliss_verify's path for raw signatures (unpacking, norm tests, a t on the NTT kernel, z from it and the challenge positions, the oracle compared):
+    the oracle's verdict on genuine and tampered signatures"""
+    _ok(runs[('verify', tag, B, two_lane)])
+
+
+def test_verification_call_is_race_free_tsan(runs):
+    _ok(runs['verify tsan'])

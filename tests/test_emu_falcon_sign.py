@@ -86,6 +86,56 @@ print('EMU_OK', tag, B, 'variant', variant, 'signed', signed, f'{time.time() - t
 REWRITES = (('falcon_sign_dev.h', 'const double *LL = stree + (toff - toffLM);', 'const double *LL = l <= LM ? stree + (toff - toffLM) : stree;', 1),)
 
 
+VERIFY_DRIVER = r'''
+import ctypes as C, sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+from tests.test_emu_ntt import PlanConsts, OP_FWD, OP_MULNTT, SMAD, S32
+so, tag, B, seed = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+E = C.CDLL(so)
+vp = C.c_void_p
+E.emu_falcon_verify.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp]
+G = load_golden('falcon_ref.txt')
+key = O.FalconKey.from_golden(G, tag)
+n, q = key.n, key.q
+P = PlanConsts(q, n)
+mode = SMAD if P.smad_ok else S32
+assert P.smad_ok or P.s32_ok
+tab, modk, cf, _ = P.args(mode, OP_FWD)
+_, _, cm, _ = P.args(mode, OP_MULNTT)
+rng = np.random.default_rng(seed)
+msgs, sigs = [], []
+while len(msgs) < B:
+    m = bytes(rng.integers(0, 256, size=int(rng.integers(0, 80)), dtype=np.uint8))
+    rc, sg = O.falcon_sign(key, m, rng.integers(0, 2**32, size=4 * n, dtype=np.uint64).astype(np.uint32))
+    if rc != 0:
+        continue
+    i = len(msgs); kind = i % 4
+    s = bytearray(sg)
+    if kind == 1: s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))       # a flipped bit anywhere
+    elif kind == 2: m = m + b'x'                                                          # another message
+    elif kind == 3: s = s[:len(s) - 2]                                                    # truncated
+    msgs.append(m); sigs.append(bytes(s))
+stride, sst = 88, key.sig_bytes + 8
+mb = np.zeros((B, stride), dtype=np.uint8); ml = np.zeros(B, dtype=np.uint32)
+sb = np.zeros((B, sst), dtype=np.uint8); sl = np.zeros(B, dtype=np.uint32)
+for i in range(B):
+    mb[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8); ml[i] = len(msgs[i])
+    sb[i, :len(sigs[i])] = np.frombuffer(sigs[i], dtype=np.uint8); sl[i] = len(sigs[i])
+verdicts = np.full(B, 7, dtype=np.uint32)
+p = lambda a: a.ctypes.data_as(vp)
+t0 = time.time()
+rc = E.emu_falcon_verify(p(key.par), mode, p(tab), p(modk), p(cf), p(cm), p(key.h), B, p(mb), stride, p(ml), p(sb), sst, p(sl), p(verdicts))
+assert rc == 0, rc
+want = [0 if O.falcon_verify(key, msgs[i], sigs[i]) == 0 else 1 for i in range(B)]
+assert verdicts.tolist() == want, (verdicts.tolist(), want)
+assert want.count(0) >= B // 4 and want.count(1) >= B // 2
+print('EMU_OK', tag, B, 'accepted', want.count(0), f'{time.time() - t0:.1f}s')
+'''
+
+VERIFY_CASES = [('falcon0', 9), ('falcon2', 6)]          # (parameter set, signatures - a quarter genuine, the rest tampered three ways)
+
 # (parameter set, messages, sampler mapping: 0 = the default (8 per wavefront, two wavefronts), 1 = one wavefront, 2 = 64-coefficient sub-trees in LDS,
 #  3 = a lane per signature, 4 = eight lanes per signature; hash with two lanes per message or one)
 CASES = [('falcon2', 9, 0, 1), ('falcon0', 11, 0, 0), ('falcon0', 9, 1, 1), ('falcon0', 9, 2, 1), ('falcon0', 5, 3, 1), ('falcon0', 5, 4, 1)]
@@ -96,6 +146,8 @@ def runs():
     asan, tsan = build('emu_falcon_sign', 'address,undefined', rewrites=REWRITES), build('emu_falcon_sign', 'thread', rewrites=REWRITES)
     cases = {c: (DRIVER, [asan, c[0], c[1], c[2], c[3], 13 * c[1] + c[2]], 'address,undefined', 2400) for c in CASES}
     cases['tsan'] = (DRIVER, [tsan, 'falcon2', 5, 0, 1, 6], 'thread', 2400)
+    cases.update({('verify',) + c: (VERIFY_DRIVER, [asan, c[0], c[1], 5 * c[1]], 'address,undefined') for c in VERIFY_CASES})
+    cases['verify tsan'] = (VERIFY_DRIVER, [tsan, 'falcon0', 5, 3], 'thread')
     return drive_all(cases)
 
 
@@ -112,3 +164,14 @@ def test_default_mapping_is_race_free_tsan(runs):
     """Falcon-1024.  (At n = 512 the two wavefronts of a workgroup have more lanes than a transform pass has butterfly groups; the spare lanes "redo group 0
     and store nothing" - they READ the points lane 0 is writing back and discard what they computed: a report for two threads, nothing on the device.)"""
     _ok(runs['tsan'])
+
+
+@pytest.mark.parametrize('tag,B', VERIFY_CASES)
+def test_verification_call_equals_the_oracle_asan_ubsan(runs, tag, B):
+    """sc_hip_falcon_set_pubkey + fal_verify_core (hash and unpacking as one launch, s2 h on the NTT kernel, s1 = c - s2 h centred and the float norm test):
+    the oracle's verdict on genuine and tampered signatures"""
+    _ok(runs[('verify', tag, B)])
+
+
+def test_verification_call_is_race_free_tsan(runs):
+    _ok(runs['verify tsan'])

@@ -63,6 +63,55 @@ print('EMU_OK', tag, B, 'rounds', rounds.value, 'signed', int((status == 1).sum(
 '''
 
 
+VERIFY_DRIVER = r'''
+import ctypes as C, sys, time, numpy as np
+sys.path.insert(0, sys.argv[1])
+from tests.golden_io import load_golden
+from tests import oracle_lib as O
+from tests.test_emu_ntt import PlanConsts, OP_MULNTT, SMAD, S32, U32
+so, tag, B, seed = sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+E = C.CDLL(so)
+vp = C.c_void_p
+E.emu_tesla_verify.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp, C.c_size_t, vp, vp]
+G = load_golden('tesla_ref.txt')
+key = O.TeslaKey.from_golden(G, tag)
+n, q = key.n, key.q
+P = PlanConsts(q, n)
+mode = SMAD if P.smad_ok else S32 if P.s32_ok else U32
+tab, modk, c, lazy = P.args(mode, OP_MULNTT)
+rng = np.random.default_rng(seed)
+msgs, sigs = [], []
+while len(msgs) < B:
+    m = bytes(rng.integers(0, 256, size=int(rng.integers(0, 120)), dtype=np.uint8))
+    rc, sg, _, _ = O.tesla_sign(key, m, rng.integers(0, 2**32, size=12 * n, dtype=np.uint64).astype(np.uint32))
+    if rc != 0:
+        continue
+    i = len(msgs); kind = i % 5
+    s = bytearray(sg)
+    if kind == 1: s[int(rng.integers(0, len(s)))] ^= 1 << int(rng.integers(0, 8))       # a flipped bit anywhere
+    elif kind == 2: s[len(s) - 1 - int(rng.integers(0, 64))] ^= 0x20                       # in the digest
+    elif kind == 3: m = m + b'x'                                                          # another message
+    elif kind == 4: s = s[:len(s) - 3]                                                    # truncated
+    msgs.append(m); sigs.append(bytes(s))
+stride, sst = 128, key.sig_bytes + 16
+mb = np.zeros((B, stride), dtype=np.uint8); ml = np.zeros(B, dtype=np.uint32)
+sb = np.zeros((B, sst), dtype=np.uint8); sl = np.zeros(B, dtype=np.uint32)
+for i in range(B):
+    mb[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8); ml[i] = len(msgs[i])
+    sb[i, :len(sigs[i])] = np.frombuffer(sigs[i], dtype=np.uint8); sl[i] = len(sigs[i])
+verdicts = np.full(B, 7, dtype=np.uint32)
+p = lambda a: a.ctypes.data_as(vp)
+t0 = time.time()
+rc = E.emu_tesla_verify(p(key.par), mode, int(lazy), p(tab), p(modk), p(c), p(key.a1), p(key.a2), p(key.t1), p(key.t2), B, p(mb), stride, p(ml), p(sb), sst, p(sl), p(verdicts))
+assert rc == 0, rc
+want = [0 if O.tesla_verify(key, msgs[i], sigs[i]) == 0 else 1 for i in range(B)]
+assert verdicts.tolist() == want, (verdicts.tolist(), want)
+assert want.count(0) >= B // 5 and want.count(1) >= B // 2
+print('EMU_OK', tag, B, 'accepted', want.count(0), f'{time.time() - t0:.1f}s')
+'''
+
+VERIFY_CASES = [('tesla0', 11), ('tesla1', 6)]          # (parameter set, signatures - a fifth genuine, the rest tampered four ways)
+
 CASES = [('tesla0', 10, 12), ('tesla0', 5, 20), ('tesla1', 6, 8)]          # (parameter set, messages, attempt slots per round)
 
 
@@ -71,6 +120,8 @@ def runs():
     asan, tsan = build('emu_tesla_sign', 'address,undefined'), build('emu_tesla_sign', 'thread')
     cases = {c: (DRIVER, [asan, c[0], c[1], c[2], 5 * c[1] + c[2]], 'address,undefined') for c in CASES}
     cases['tsan'] = (DRIVER, [tsan, 'tesla0', 6, 8, 4], 'thread')
+    cases.update({('verify',) + c: (VERIFY_DRIVER, [asan, c[0], c[1], 3 * c[1]], 'address,undefined') for c in VERIFY_CASES})
+    cases['verify tsan'] = (VERIFY_DRIVER, [tsan, 'tesla0', 6, 2], 'thread')
     return drive_all(cases)
 
 
@@ -85,3 +136,14 @@ def test_signing_call_equals_the_oracle_asan_ubsan(runs, tag, B, cap):
 
 def test_signing_call_is_race_free_tsan(runs):
     _ok(runs['tsan'])
+
+
+@pytest.mark.parametrize('tag,B', VERIFY_CASES)
+def test_verification_call_equals_the_oracle_asan_ubsan(runs, tag, B):
+    """sc_hip_tesla_verify's path (z's unpacking and F as one launch, a1 z and a2 z from one forward transform, w = a z - t c through the key's shift tables,
+    rounding, the oracle compared with the signature's digest): the oracle's verdict on genuine and tampered signatures"""
+    _ok(runs[('verify', tag, B)])
+
+
+def test_verification_call_is_race_free_tsan(runs):
+    _ok(runs['verify tsan'])
