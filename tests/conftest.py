@@ -20,3 +20,62 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+# ---- emulation mode (tests/test_emu_library.py only): the `-m gpu` tests against the product library built for the CPU -------------------------------------
+# SC_EMU_LIB = path of tests/emu/_build/libsc_hip_emu_*.so (tests/emu_harness.py build_library: the product's own host code and kernels over a host-side HIP
+# shim, a host thread per lane).  The binding is pointed at that library and torch's "cuda" at the CPU - the tests themselves run unchanged.  Never set by the
+# driver's runs or on the GPU box; the product has no such switch (libsafecrypto_amd/engine.py loads its one library and fails without a device).
+def _emulation_mode(path):
+    import ctypes as C
+    import torch
+    from libsafecrypto_amd import engine
+    engine.load_library(path)
+    engine._stream = lambda: C.c_void_p(0)
+
+    def cpu(dev):
+        if dev is None:
+            return None
+        return 'cpu' if str(dev).startswith('cuda') else dev
+
+    class _Stream:
+        cuda_stream = 0
+
+        def synchronize(self):
+            pass
+
+        def wait_stream(self, other):
+            pass
+
+    torch.cuda.is_available = lambda: True
+    torch.cuda.device_count = lambda: 1
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.Tensor.cuda = lambda self, *a, **k: self.clone()             # (a copy, as on the device: torch.from_numpy shares the array's memory)
+    _to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple(cpu(x) if isinstance(x, (str, torch.device)) else x for x in a)
+        if 'device' in k:
+            k['device'] = cpu(k['device'])
+        return _to(self, *a, **k)
+    torch.Tensor.to = to
+    for name in ('zeros', 'empty', 'ones', 'full', 'randint', 'rand', 'randn', 'arange', 'tensor', 'as_tensor', 'zeros_like', 'empty_like', 'ones_like', 'randperm', 'frombuffer'):
+        f = getattr(torch, name)
+
+        def wrap(f):
+            def g(*a, **k):
+                if 'device' in k:
+                    k['device'] = cpu(k['device'])
+                if 'generator' in k and k['generator'] is not None and not isinstance(k['generator'], torch.Generator):
+                    k['generator'] = None
+                return f(*a, **k)
+            return g
+        setattr(torch, name, wrap(f))
+    _Gen = torch.Generator
+    torch.Generator = lambda device=None: _Gen(device=cpu(device) or 'cpu')
+
+
+if os.environ.get('SC_EMU_LIB'):
+    _emulation_mode(os.environ['SC_EMU_LIB'])

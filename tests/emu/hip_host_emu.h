@@ -1,0 +1,108 @@
+// hip_host_emu.h - the HOST side of <hip/hip_runtime.h> for the lane-by-lane emulation: enough of the HIP API for the product's own host code
+// (libsafecrypto_amd/csrc/*.hip, *.cpp) to be compiled for the CPU and run - every allocation host memory (filled with 0xCD: device memory is not
+// zeroed either), every copy a memcpy, every stream the one in-order stream, every launch run to completion before hipLaunchKernelGGL returns
+// (emu::launch: a host thread per lane).  One "device" of EMU_CUS compute units.  Stream capture is refused (hipErrorNotSupported).
+// TEST INFRASTRUCTURE ONLY (tests/test_emu_library.py builds tests/emu/_build/libsc_hip_emu_*.so from it); the product never sees this file.
+#pragma once
+#include <stdio.h>
+#include <string.h>
+#include <mutex>
+
+#ifndef EMU_CUS
+#define EMU_CUS 2
+#endif
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorInvalidDevice = 101 };
+typedef struct EmuStream *hipStream_t;
+typedef struct EmuEvent *hipEvent_t;
+typedef struct EmuGraph *hipGraph_t;
+typedef struct EmuGraphExec *hipGraphExec_t;
+typedef void *hipDeviceptr_t;
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostRegisterDefault = 0, hipHostRegisterPortable = 1, hipStreamCaptureModeThreadLocal = 1 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 74, hipDeviceAttributeMultiprocessorCount = 63 };
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeUnregistered = 0 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void *devicePointer, *hostPointer; int isManaged; unsigned allocationFlags; };
+struct hipDeviceProp_t { char name[256]; int multiProcessorCount; size_t totalGlobalMem; size_t sharedMemPerBlock; int warpSize; char gcnArchName[256]; };
+
+struct dim3 { unsigned x, y, z; dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {} };
+
+static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorNotSupported ? "operation not supported (emulation)" : "error (emulation)"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "MI355X (CPU emulation)"); strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = EMU_CUS; p->totalGlobalMem = (size_t)1 << 34; p->sharedMemPerBlock = 160 * 1024; p->warpSize = 64; return hipSuccess; }
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeMaxSharedMemoryPerBlock ? 160 * 1024 : a == hipDeviceAttributeMultiprocessorCount ? EMU_CUS : 0; return hipSuccess; }
+template <typename T> static inline hipError_t hipMalloc(T **p, size_t n)
+{
+    void *q = nullptr;
+    if (posix_memalign(&q, 256, n ? n : 1)) { *p = nullptr; return hipErrorOutOfMemory; }
+    memset(q, 0xCD, n);
+    *p = (T *)q;
+    return hipSuccess;
+}
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { memset(a, 0, sizeof *a); return hipErrorInvalidValue; }      // "not a registered pointer"
+static inline hipError_t hipMemPtrGetInfo(void *, size_t *) { return hipErrorInvalidValue; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t = nullptr) { for (size_t i = 0; i < count; i++) ((int *)d)[i] = v; return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
+template <typename F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
+template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, F, int, size_t) { *nb = 2; return hipSuccess; }
+static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+static inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorNotSupported; }
+static inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t, void *, void *, size_t) { *e = nullptr; return hipErrorNotSupported; }
+static inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+static inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/asan_interface.h>
+#define EMU_POISON(p, n) __asan_poison_memory_region((p), (n))
+#define EMU_UNPOISON(p, n) __asan_unpoison_memory_region((p), (n))
+#endif
+#endif
+#ifndef EMU_POISON
+#define EMU_POISON(p, n) ((void)0)
+#define EMU_UNPOISON(p, n) ((void)0)
+#endif
+
+namespace emu {
+// a launch as the host code makes it: one at a time (the product's multi-device driver launches from several host threads), the dynamic LDS beyond what the
+// launch asked for poisoned under AddressSanitizer, the launch complete on return
+inline std::mutex launch_mu;
+template <typename F> static inline void launch_host(dim3 grid, dim3 block, size_t lds_bytes, F &&body)
+{
+    if (block.y != 1 || block.z != 1 || !block.x || lds_bytes > sizeof dyn_lds) { fprintf(stderr, "emu: launch shape (%u,%u,%u) x (%u,%u,%u), %zu bytes of LDS not emulated\n", grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes); abort(); }
+    std::lock_guard<std::mutex> g(launch_mu);
+    if (!grid.x || !grid.y || !grid.z) return;
+    const size_t keep = (lds_bytes + 7) & ~(size_t)7;
+    if (keep < sizeof dyn_lds) EMU_POISON(dyn_lds + keep, sizeof dyn_lds - keep);
+    const std::function<void()> fn(body);
+    for (unsigned z = 0; z < grid.z; z++)
+        for (unsigned y = 0; y < grid.y; y++) { gridDim.y = grid.y; gridDim.z = grid.z; blockIdx.y = y; blockIdx.z = z; launch(grid.x, block.x, fn); }
+    gridDim.y = gridDim.z = 1; blockIdx.y = blockIdx.z = 0;
+    EMU_UNPOISON(dyn_lds, sizeof dyn_lds);
+}
+}  // namespace emu
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch_host(dim3(grid), dim3(block), (size_t)(lds), [&]() { kernel(__VA_ARGS__); })

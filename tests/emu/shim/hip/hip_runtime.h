@@ -4,3 +4,6 @@
 #pragma once
 #include "../../wave_emu.h"
 #define __asm(x)
+#ifdef EMU_HOST_API
+#include "../../hip_host_emu.h"
+#endif

@@ -9,6 +9,7 @@
 #include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <math.h>
 #include <string.h>
 #include <algorithm>
@@ -34,8 +35,9 @@
 #define __restrict__
 
 struct EmuDim3 { unsigned x = 0, y = 0, z = 0; };
-static thread_local EmuDim3 threadIdx;
-static EmuDim3 blockIdx, blockDim, gridDim;            // workgroups run one after the other
+// (inline variables: ONE copy however many translation units of a library include this header - kernels' inline helpers are merged across them by the linker)
+inline thread_local EmuDim3 threadIdx;
+inline EmuDim3 blockIdx, blockDim, gridDim;            // workgroups run one after the other
 
 struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{ x, y, z, w }; }
@@ -48,6 +50,8 @@ static inline int2 make_int2(int32_t x, int32_t y) { return int2{ x, y }; }
 struct alignas(16) double2 { double x, y; };
 static inline double2 make_double2(double x, double y) { return double2{ x, y }; }
 struct alignas(16) ulonglong2 { unsigned long long x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{ x, y, z, w }; }
 
 namespace emu {
 // A barrier out of a mutex and a condition variable rather than pthread_barrier_t: ThreadSanitizer models the former exactly, while behind a
@@ -72,9 +76,9 @@ struct Barrier {
 };
 struct Wave { Barrier bar; Barrier pair[32]; uint64_t buf[64]; uint32_t pbuf[64]; };
 struct Block { Barrier bar; std::deque<Wave> waves; int or_acc = 0; };
-static Block *cur_block;
-static thread_local Wave *my_wave;
-static thread_local int my_lane;
+inline Block *cur_block;
+inline thread_local Wave *my_wave;
+inline thread_local int my_lane;
 
 static inline void wave_sync() { my_wave->bar.wait(); }
 static inline uint64_t exchange(uint64_t v, int src)
@@ -89,19 +93,25 @@ static inline uint64_t exchange(uint64_t v, int src)
 // run `body` as grid x block threads (block a multiple of 64).  wave_serial: the wavefronts of a workgroup one after the other - ONLY for kernels without a
 // workgroup barrier, whose wavefronts share nothing (the NTT kernel).  ThreadSanitizer needs it: it has 256 thread slots, and with a whole 256-lane
 // workgroup alive beside the host's own threads the slots are recycled and races go unreported (found by removing a fence on purpose: tests/test_emu_ntt.py).
-static bool wave_serial = false;
+inline bool wave_serial = false;
 static inline void launch(unsigned grid, unsigned block, const std::function<void()> &body)
 {
-    gridDim.x = grid; blockDim.x = block;
+    gridDim.x = grid; blockDim.x = block; blockDim.y = blockDim.z = 1;
+    if (!gridDim.y) gridDim.y = 1;
+    if (!gridDim.z) gridDim.z = 1;
     for (unsigned b = 0; b < grid; b++) {
         Block blk;
-        blk.waves.resize(block / 64);
+        blk.waves.resize((block + 63) / 64);
         blk.bar.init(block);
-        for (auto &w : blk.waves) { w.bar.init(64); for (auto &pb : w.pair) pb.init(2); }
+        for (unsigned w = 0; w < blk.waves.size(); w++) {                 // (a last wavefront with fewer than 64 lanes: its barriers count the lanes it has)
+            const unsigned lanes = std::min(64u, block - 64 * w);
+            blk.waves[w].bar.init(lanes);
+            for (unsigned pr = 0; pr < 32; pr++) blk.waves[w].pair[pr].init(2 * pr + 1 < lanes ? 2 : 1);
+        }
         cur_block = &blk; blockIdx.x = b;
         for (unsigned t0 = 0; t0 < block; t0 += wave_serial ? 64 : block) {
             std::vector<std::thread> th;
-            for (unsigned t = t0; t < (wave_serial ? t0 + 64 : block); t++)
+            for (unsigned t = t0; t < (wave_serial ? std::min(t0 + 64, block) : block); t++)
                 th.emplace_back([&, t]() { threadIdx.x = t; my_lane = (int)(t & 63); my_wave = &blk.waves[t >> 6]; body(); my_wave->pair[my_lane >> 1].leave(); my_wave->bar.leave(); blk.bar.leave(); });
             for (auto &x : th) x.join();
         }
@@ -120,7 +130,7 @@ static inline int emu_readlane(int v, int l) { return (int)(uint32_t)emu::exchan
 static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
     (void)old; (void)bound_ctrl;
-    if (row_mask != 0xF || bank_mask != 0xF) abort();                                                 // not emulated
+    if (row_mask != 0xF || bank_mask != 0xF) { fprintf(stderr, "emu: DPP row / bank mask %x %x not emulated\n", row_mask, bank_mask); abort(); }
     const int lane = emu::my_lane, q = lane & 3;
     if (ctrl <= 0xFF) {
         const int sel = (ctrl >> (2 * q)) & 3;
@@ -140,7 +150,7 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
     }
     if (ctrl == 0x141) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~7) | (7 - (lane & 7)));
     if (ctrl == 0x140) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~15) | (15 - (lane & 15)));
-    abort();
+    fprintf(stderr, "emu: DPP control 0x%x not emulated\n", ctrl); abort();
 }
 // The two lanes of a pair run in lockstep on the device; where a kernel relies on that for data the pair shares in LDS (one lane reads the half of a sponge
 // state the other has just written back), the harness inserts this into the copy it compiles (tests/emu_harness.py `rewrites`)
@@ -165,7 +175,7 @@ static inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel)
     for (int i = 0; i < 4; i++) {
         const uint32_t k = (sel >> (8 * i)) & 0xFFu;
         uint32_t b;
-        if (k < 8) b = (uint32_t)(src >> (8 * k)) & 0xFFu; else if (k == 12) b = 0; else if (k >= 13) b = 0xFFu; else abort();
+        if (k < 8) b = (uint32_t)(src >> (8 * k)) & 0xFFu; else if (k == 12) b = 0; else if (k >= 13) b = 0xFFu; else { fprintf(stderr, "emu: v_perm selector %u not emulated\n", k); abort(); }
         r |= b << (8 * i);
     }
     return r;
@@ -173,7 +183,7 @@ static inline uint32_t emu_perm(uint32_t s0, uint32_t s1, uint32_t sel)
 #define __builtin_amdgcn_perm(a, b, sel) emu_perm((a), (b), (sel))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
-namespace emu { alignas(16) static unsigned char dyn_lds[160 * 1024]; }     // the workgroup's dynamic LDS (`extern __shared__`, rewritten by the harness's build step)
+namespace emu { alignas(16) inline unsigned char dyn_lds[160 * 1024]; }     // the workgroup's dynamic LDS (`extern __shared__`, rewritten by the harness's build step)
 
 static inline uint64_t __ballot(bool p)
 {
@@ -184,6 +194,10 @@ static inline uint64_t __ballot(bool p)
     emu::wave_sync();
     return r;
 }
+static inline int __any(int p) { return __ballot(p != 0) != 0; }
+static inline int __all(int p) { return __ballot(p != 0) == ~0ull; }
+// row_ror:n of a DPP operand (lane i of a row of 16 reads lane (i - n) mod 16): the harness's stand-in for csrc/falcon.hip's v_add_f32_dpp chain (inline assembly)
+static inline float emu_row_ror(float v, int n) { uint32_t b; memcpy(&b, &v, 4); b = (uint32_t)emu::exchange(b, (emu::my_lane & ~15) | ((emu::my_lane - n) & 15)); float r; memcpy(&r, &b, 4); return r; }
 #ifndef EMU_HAVE_NTT_CORE              // a harness that includes csrc/ntt_core.h gets sc::wave_lds_fence from there, over the two builtins below
 static inline void wave_lds_fence() { emu::wave_sync(); }               // csrc/ntt_core.h: a wavefront-scope fence + wave barrier
 #endif
@@ -206,6 +220,12 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 static inline uint32_t atomicAdd(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t atomicOr(uint32_t *p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+static inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+static inline int __mul24(int a, int b) { return (int)(uint32_t)((int64_t)((int32_t)((uint32_t)a << 8) >> 8) * (int64_t)((int32_t)((uint32_t)b << 8) >> 8)); }
+static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int32_t __mulhi(int32_t a, int32_t b) { return (int32_t)(((int64_t)a * b) >> 32); }
 static inline uint32_t emu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
 #define __builtin_amdgcn_alignbit(hi, lo, sh) emu_alignbit((hi), (lo), (sh))

@@ -20,6 +20,20 @@ CLANG = '/opt/rocm/lib/llvm/bin/clang++'          # host mode: the kernel text u
 DYN_LDS = re.compile(r'extern __shared__ (?:__attribute__\(\(aligned\(16\)\)\) )?(\w+) (\w+)\[\];')
 
 
+def _rewrite(name, text, rewrites):
+    """(file, old text or compiled pattern, new text, occurrences) substitutions of one file"""
+    for fname, old, new, count in rewrites:
+        if fname != name:
+            continue
+        if isinstance(old, re.Pattern):
+            text, k = old.subn(new, text)
+            assert k == count, (fname, old.pattern, k)
+        else:
+            assert text.count(old) == count, (fname, old, text.count(old))
+            text = text.replace(old, new)
+    return text
+
+
 def _sources(dst, mutate=None, rewrites=()):
     shutil.rmtree(dst, ignore_errors=True)
     os.makedirs(dst)
@@ -31,10 +45,7 @@ def _sources(dst, mutate=None, rewrites=()):
         if mutate and mutate[0] == base:
             at = [m.start() for m in re.finditer(r'wave_lds_fence\(\);', text)][mutate[1]]
             text = text[:at] + text[at + len('wave_lds_fence();'):]
-        for fname, old, new, count in rewrites:
-            if fname == base:
-                assert text.count(old) == count, (fname, old, text.count(old))
-                text = text.replace(old, new)
+        text = _rewrite(base, text, rewrites)
         with open(os.path.join(dst, base), 'w') as f:
             f.write(text)
 
@@ -84,3 +95,65 @@ def drive_all(cases, workers=4):
     with ThreadPoolExecutor(max_workers=workers) as ex:
         futs = [ex.submit(drive, *cases[k][:3], **({'timeout': cases[k][3]} if len(cases[k]) > 3 else {})) for k in keys]
         return {k: f.result() for k, f in zip(keys, futs)}
+
+
+# What the CPU build of the whole library rewrites besides the dynamic LDS declarations: the constructs that only mean something on the device - inline
+# assembly (the ENS / DLP signer's v_add_f32_dpp chain -> the same additions in the same order through emu_row_ror; RLWE-Enc's borrow-chain compare-count ->
+# the two 64-bit comparisons it computes; s_nop wait states and register-class hints -> nothing) - plus the lockstep statements of the single-scheme
+# harnesses (tests/test_emu_*.py REWRITES), which apply to the same headers here.
+LIB_REWRITES = (
+    ('falcon.hip', re.compile(r'    if constexpr \(G == 4\)\n        asm\(.*?\n    return acc; ', re.S),
+     '    for (int i = G - 1; i >= 1; i--) acc = emu_row_ror(p, (16 / G) * i) + acc;\n    acc = acc + p;\n    return acc; ', 1),
+    ('falcon.hip', re.compile(r'asm volatile\("s_nop \d+"\);'), '', 2),
+    ('rlwe.hip', re.compile(r'asm\("v_sub_co_u32 %1, vcc, %3, %7.*?: "vcc"\);', re.S),
+     'scratch = 0; (void)scratch; { const uint64_t u_ = ((uint64_t)w[c + e].x << 32) | w[c + e].y; a = lo + ((((uint64_t)t1.y << 32) | t1.x) < u_ ? 1u : 0u) + ((((uint64_t)t2.y << 32) | t2.x) < u_ ? 1u : 0u); }', 1),
+    ('rlwe.hip', 'asm volatile("" : "+v"(off));', '', 2),
+)
+
+
+# ---- the whole product library for the CPU: libsafecrypto_amd/csrc/*.hip and *.cpp - host code and kernels - over tests/emu/hip_host_emu.h --------------------
+LIB_SOURCES = ['sc_hip.hip', 'dilithium.hip', 'kyber.hip', 'bliss.hip', 'falcon.hip', 'ops.hip', 'drbg.hip', 'tesla.hip', 'rlwe.hip', 'ens.hip', 'dlp.hip', 'entropy.hip',
+               'sc_vtable.cpp', 'multi.cpp']
+
+
+def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
+    """tests/emu/_build/libsc_hip_emu_<sanitize>.so: every source of csrc/Makefile compiled as host C++ (same rewrites as `build`), linked into one library with
+    the product's C ABI.  Rebuilt when a source is newer."""
+    from concurrent.futures import ThreadPoolExecutor
+    out = os.path.join(EMU, '_build')
+    os.makedirs(out, exist_ok=True)
+    tag = (sanitize or 'plain').replace(',', '_') + (('_' + hashlib.sha1(repr(rewrites).encode()).hexdigest()[:8]) if rewrites else '')
+    so = os.path.join(out, f'libsc_hip_emu_{tag}.so')
+    deps = [os.path.join(EMU, 'wave_emu.h'), os.path.join(EMU, 'hip_host_emu.h'), __file__] + glob.glob(os.path.join(EMU, 'shim', '*.h')) + \
+           glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(CSRC, f) for f in sources] + \
+           glob.glob(os.path.join(ROOT, 'include', '*.h'))
+    if os.path.exists(so) and not any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        return so
+    src = os.path.join(out, f'src_lib_{tag}')
+    _sources(src, None, rewrites)
+    os.makedirs(os.path.join(src, 'inc'), exist_ok=True)
+    for h in glob.glob(os.path.join(ROOT, 'include', '*.h')):          # the sources include "../../include/sc_hip.h" relative to csrc/
+        shutil.copy(h, os.path.join(src, 'inc'))
+    flags = ['-O0', '-g', '-std=c++17', '-fPIC', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function', '-Wno-unused-variable',
+             '-Wno-shift-count-negative', '-Wno-unused-but-set-variable', '-DEMU_SHARED=static', '-DEMU_HOST_API', '-DEMU_HAVE_NTT_CORE', '-D__HIPCC__',
+             '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
+    if sanitize:
+        flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
+    objs = []
+
+    def one(f):
+        text = DYN_LDS.sub(lambda m: f'{m.group(1)} *const {m.group(2)} = reinterpret_cast<{m.group(1)} *>(emu::dyn_lds);', open(os.path.join(CSRC, f)).read())
+        text = text.replace('#include "../../include/', '#include "inc/')
+        text = _rewrite(f, text, rewrites)
+        cpp = os.path.join(src, os.path.splitext(f)[0] + '_emu.cpp')
+        with open(cpp, 'w') as fh:
+            fh.write(text)
+        obj = cpp[:-4] + '.o'
+        extra = ['-ffp-contract=off'] if f == 'falcon.hip' else []
+        subprocess.check_call([CLANG] + flags + extra + ['-c', '-o', obj, cpp])
+        return obj
+
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(one, sources))
+    subprocess.check_call([CLANG, '-shared', '-pthread'] + (['-fsanitize=' + sanitize, '-shared-libsan'] if sanitize else []) + ['-o', so] + objs)
+    return so
