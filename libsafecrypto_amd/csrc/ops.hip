@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void flat_kernel(const int32_t *__restrict__ i
     const size_t nv = len / 4, stride = (size_t)gridDim.x * blockDim.x;
     auto f = [&](int32_t x) -> int32_t {
         if (OP == FL_MUL_SCALAR) return (int32_t)((uint32_t)x * (uint32_t)s);
-        if (OP == FL_MOD_NEGATE) return s - x;                                                // s = q (poly_32.c:149-155)
+        if (OP == FL_MOD_NEGATE) return (int32_t)((uint32_t)s - (uint32_t)x);                 // s = q (poly_32.c:149-155); any int32 x: the difference wraps
         return (int32_t)pow_mod(csub(reduce_i32(x, k), k.q), (uint32_t)s, k, r2, r2p);
     };
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {

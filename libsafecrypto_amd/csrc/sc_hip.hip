@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const int32_t *__restrict__ a, 
         int xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w}, o[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
-            if (OPE == EW_ADD) o[e] = xa[e] + xb[e];
-            else if (OPE == EW_SUB) o[e] = xa[e] - xb[e];
+            if (OPE == EW_ADD) o[e] = (int)((uint32_t)xa[e] + (uint32_t)xb[e]);          // (any int32 operands: the sum wraps, as the reference's add_32 does on this target)
+            else if (OPE == EW_SUB) o[e] = (int)((uint32_t)xa[e] - (uint32_t)xb[e]);
             else {
                 uint32_t v = reduce_i32(xa[e], k);
                 if (OPE == EW_POINTWISE) {
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256) void ew_kernel(const int32_t *__restrict__ a, 
     if (blockIdx.x == 0 && threadIdx.x < (len & 3)) {
         const size_t i = nv * 4 + threadIdx.x;
         int32_t o;
-        if (OPE == EW_ADD) o = a[i] + b[i];
-        else if (OPE == EW_SUB) o = a[i] - b[i];
+        if (OPE == EW_ADD) o = (int32_t)((uint32_t)a[i] + (uint32_t)b[i]);
+        else if (OPE == EW_SUB) o = (int32_t)((uint32_t)a[i] - (uint32_t)b[i]);
         else {
             uint32_t v = reduce_i32(a[i], k);
             if (OPE == EW_POINTWISE) {
@@ -302,7 +302,7 @@ extern "C" int sc_hip_plan_create(sc_hip_ctx_t *ctx, int32_t q, int n, sc_hip_pl
         std::vector<uint32_t> h(4 * (size_t)n, 0u);
         auto centre = [&](uint64_t w) -> int64_t { return w > Q / 2 ? (int64_t)w - (int64_t)Q : (int64_t)w; };
         auto sshoup = [&](int64_t w) -> uint32_t {                 // floor(w 2^32 / q) as a two's-complement 32-bit value
-            __int128 num = (__int128)w << 32;
+            __int128 num = (__int128)w * ((__int128)1 << 32);                  // (not w << 32: w may be negative)
             __int128 fl = num / (__int128)Q;
             if (num % (__int128)Q != 0 && num < 0) fl -= 1;
             return (uint32_t)(int32_t)fl;

@@ -61,6 +61,7 @@ def _emulation_mode(path):
             k['device'] = cpu(k['device'])
         return _to(self, *a, **k)
     torch.Tensor.to = to
+    _Gen = torch.Generator
     for name in ('zeros', 'empty', 'ones', 'full', 'randint', 'rand', 'randn', 'arange', 'tensor', 'as_tensor', 'zeros_like', 'empty_like', 'ones_like', 'randperm', 'frombuffer'):
         f = getattr(torch, name)
 
@@ -68,12 +69,11 @@ def _emulation_mode(path):
             def g(*a, **k):
                 if 'device' in k:
                     k['device'] = cpu(k['device'])
-                if 'generator' in k and k['generator'] is not None and not isinstance(k['generator'], torch.Generator):
+                if 'generator' in k and k['generator'] is not None and not isinstance(k['generator'], _Gen):
                     k['generator'] = None
                 return f(*a, **k)
             return g
         setattr(torch, name, wrap(f))
-    _Gen = torch.Generator
     torch.Generator = lambda device=None: _Gen(device=cpu(device) or 'cpu')
 
 

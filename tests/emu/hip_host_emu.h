@@ -1,10 +1,12 @@
 // hip_host_emu.h - the HOST side of <hip/hip_runtime.h> for the lane-by-lane emulation: enough of the HIP API for the product's own host code
-// (libsafecrypto_amd/csrc/*.hip, *.cpp) to be compiled for the CPU and run - every allocation host memory (filled with 0xCD: device memory is not
-// zeroed either), every copy a memcpy, every stream the one in-order stream, every launch run to completion before hipLaunchKernelGGL returns
+// (libsafecrypto_amd/csrc/*.hip, *.cpp) to be compiled for the CPU and run - every allocation host memory (zeroed, as the memory the library sees on the
+// device is - fresh from the driver, or its own after wipe_free; EMU_MALLOC_FILL=<byte> in the environment fills it with that byte instead, to show
+// that nothing but the residue hooks relies on the zeroes), every copy a memcpy, every stream the one in-order stream, every launch run to completion before hipLaunchKernelGGL returns
 // (emu::launch: a host thread per lane).  One "device" of EMU_CUS compute units.  Stream capture is refused (hipErrorNotSupported).
 // TEST INFRASTRUCTURE ONLY (tests/test_emu_library.py builds tests/emu/_build/libsc_hip_emu_*.so from it); the product never sees this file.
 #pragma once
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 
@@ -40,7 +42,8 @@ template <typename T> static inline hipError_t hipMalloc(T **p, size_t n)
 {
     void *q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1)) { *p = nullptr; return hipErrorOutOfMemory; }
-    memset(q, 0xCD, n);
+    static const int fill = getenv("EMU_MALLOC_FILL") ? (int)strtol(getenv("EMU_MALLOC_FILL"), nullptr, 0) : 0;
+    memset(q, fill, n);
     *p = (T *)q;
     return hipSuccess;
 }

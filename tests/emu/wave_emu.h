@@ -129,7 +129,6 @@ static inline int emu_readlane(int v, int l) { return (int)(uint32_t)emu::exchan
 // device's exec mask.  Any other quad_perm, row_half_mirror (0x141) and row_mirror (0x140) - the wave reductions' steps - are reached by the whole wavefront.
 static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
-    (void)old; (void)bound_ctrl;
     if (row_mask != 0xF || bank_mask != 0xF) { fprintf(stderr, "emu: DPP row / bank mask %x %x not emulated\n", row_mask, bank_mask); abort(); }
     const int lane = emu::my_lane, q = lane & 3;
     if (ctrl <= 0xFF) {
@@ -150,6 +149,13 @@ static inline int emu_update_dpp(int old, int src, int ctrl, int row_mask, int b
     }
     if (ctrl == 0x141) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~7) | (7 - (lane & 7)));
     if (ctrl == 0x140) return (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~15) | (15 - (lane & 15)));
+    if (ctrl >= 0x101 && ctrl <= 0x12F && (ctrl & 15)) {                          // row_shl / row_shr / row_ror by n: lane i of a row reads lane i + n / i - n / (i - n) mod 16
+        const int n = ctrl & 15, kind = (ctrl >> 4) & 3, i = lane & 15;
+        const int from = kind == 0 ? i + n : i - n;
+        const bool inside = kind == 2 || (from >= 0 && from < 16);
+        const int r = (int)(uint32_t)emu::exchange((uint32_t)src, (lane & ~15) | (from & 15));
+        return inside ? r : (bound_ctrl ? 0 : old);
+    }
     fprintf(stderr, "emu: DPP control 0x%x not emulated\n", ctrl); abort();
 }
 // The two lanes of a pair run in lockstep on the device; where a kernel relies on that for data the pair shares in LDS (one lane reads the half of a sponge

@@ -108,6 +108,14 @@ LIB_REWRITES = (
     ('rlwe.hip', re.compile(r'asm\("v_sub_co_u32 %1, vcc, %3, %7.*?: "vcc"\);', re.S),
      'scratch = 0; (void)scratch; { const uint64_t u_ = ((uint64_t)w[c + e].x << 32) | w[c + e].y; a = lo + ((((uint64_t)t1.y << 32) | t1.x) < u_ ? 1u : 0u) + ((((uint64_t)t2.y << 32) | t2.x) < u_ ? 1u : 0u); }', 1),
     ('rlwe.hip', 'asm volatile("" : "+v"(off));', '', 2),
+    # the lockstep statements (each explained where its single-scheme harness lists it: tests/test_emu_bliss_sign.py, test_emu_dil_sign.py, test_emu_falcon_sign.py)
+    ('bliss_sign_dev.h', 'bw.put((uint32_t)__builtin_amdgcn_readlane(pos_v, k), P.n_bits);', 'bw.put((uint32_t)cidx[(size_t)aidx * P.kappa + k], P.n_bits);', 2),
+    ('keccak_dev.h', 'for (int w = 0; w < 25; w++) st[w * NT + h] = x[w];', 'for (int w = 0; w < 25; w++) st[w * NT + h] = x[w];\n        emu_pair_sync();', 2),
+    ('bliss_sign_dev.h', 'wv = myfl[(idx >> 5) * (HT / 2)];', 'wv = myfl[(idx >> 5) * (HT / 2)]; emu_pair_sync();', 1),
+    ('dil_sign_dev.h', 'if (neq) verdict[item] = 1;', 'if (neq) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
+    ('dil_verify_dev.h', 'if (bad) verdict[item] = 1;', 'if (bad) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
+    ('dil_verify_dev.h', 'fresh > (uint32_t)P.omega)) verdict[item] = 1;', 'fresh > (uint32_t)P.omega)) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
+    ('falcon_sign_dev.h', 'const double *LL = stree + (toff - toffLM);', 'const double *LL = l <= LM ? stree + (toff - toffLM) : stree;', 1),
 )
 
 
@@ -138,7 +146,13 @@ def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
              '-Wno-shift-count-negative', '-Wno-unused-but-set-variable', '-DEMU_SHARED=static', '-DEMU_HOST_API', '-DEMU_HAVE_NTT_CORE', '-D__HIPCC__',
              '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
     if sanitize:
-        flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
+        # (float-cast-overflow off: the CDT table builder converts a long double that has reached 2^64 to a 64-bit integer and tests for 0, as the reference's does
+        # (gaussian_cdf.c:598-602) - undefined as C, 0 from both compilers on x86-64, and the table has to be the reference's)
+        flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan'] + (['-fno-sanitize=float-cast-overflow'] if 'undefined' in sanitize else [])
+        if os.environ.get('EMU_UBSAN_RECOVER'):          # triage: report every finding of a run instead of stopping at the first
+            flags += ['-fsanitize-recover=undefined']
+            tag += '_recover'
+            so = os.path.join(out, f'libsc_hip_emu_{tag}.so')
     objs = []
 
     def one(f):
