@@ -116,6 +116,8 @@ LIB_REWRITES = (
     ('dil_verify_dev.h', 'if (bad) verdict[item] = 1;', 'if (bad) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
     ('dil_verify_dev.h', 'fresh > (uint32_t)P.omega)) verdict[item] = 1;', 'fresh > (uint32_t)P.omega)) __atomic_store_n(&verdict[item], 1u, __ATOMIC_RELAXED);', 1),
     ('falcon_sign_dev.h', 'const double *LL = stree + (toff - toffLM);', 'const double *LL = l <= LM ? stree + (toff - toffLM) : stree;', 1),
+    # the lanes of a signature all test its status word before lane 0 clears it - one load instruction, then one store, on the device
+    ('falcon_sign_dev.h', 'if (status[b] != 7) return;', '{ const bool deferred_ = status[b] == 7; emu::wave_sync(); if (!deferred_) return; }', 1),
 )
 
 
