@@ -40,7 +40,9 @@ int sc_hip_falcon_set_variant(sc_hip_falcon_t *h, int spw, int lm);
  * built-in rule, about 48 K slots per round); bit 8 set: the host looks at the count of unsigned messages after EVERY round (round 2's loop) instead
  * of queueing the planned rounds back to back; bit 9 set: ExpandMask with one lane per attempt at every batch size (default: two lanes while SIMDs
  * would idle); bit 10 set (one-key calls): w = A y between the round's kernels in 24 bits per coefficient instead of 32-bit words (-9 % HBM traffic, +1 % time); bit 11 set
- * (one-key calls): the finishing kernel WITHOUT transforms (c s as sums of shifted table rows; NOT YET RUN ON HARDWARE - see DESIGN.md 4.4); unfused != 0 runs
+ * (one-key calls): the finishing kernel WITHOUT transforms (c s as sums of shifted table rows; NOT YET RUN ON HARDWARE - see DESIGN.md 4.4) - honoured at key load
+ * only: its tables are made from the raw key inside sc_hip_dilithium_set_privkey and no host copy of them is kept, so setting the bit on a handle whose key was loaded
+ * without it FAILS (load the key again afterwards); unfused != 0 runs
  * NTT(y) and the matrix product as two kernels instead of the fused one */
 int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *h, int slots_per_message, int unfused);
 

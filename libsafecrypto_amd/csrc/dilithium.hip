@@ -90,7 +90,7 @@ struct sc_hip_dilithium {
     uint32_t *d_A, *d_s1, *d_s2, *d_t0, *d_t1s;      // internal order, Montgomery form
     uint32_t *d_As;                                   // the matrix again in plain form | its Shoup companions (dil_yaw_kernel), l <= 5 only
     uint32_t *d_tabs; uint32_t fin_bias;              // shift tables of s2, s1, t0 in the coefficient domain (dil_cfins_kernel) and their fields' bias; null: the key does not fit them, or tuning bit 11 never asked for them
-    std::vector<uint32_t> *h_tabs;                    // (a pointer: the handle is zero-filled at creation) the same tables on the host from key load on (empty: the key does not fit); they reach the device only when bit 11 is set
+    bool tabs_tried;                                  // the loaded key went through the table builder (bit 11 was set at key load): d_tabs is either there or the key does not fit.  No host copy of the tables outlives set_privkey
     uint8_t *d_K, *d_tr_priv, *d_tr_pub, *d_rho;
     // workspace
     size_t cap;                                       // per message / per signature (verify): mu, kappa, trials, act, z, h, c, ch
@@ -178,7 +178,6 @@ extern "C" void sc_hip_dilithium_destroy(sc_hip_dilithium_t *d)
     if (d->ev_join2) (void)hipEventDestroy(d->ev_join2);
     void *ptrs[] = { d->d_A, d->d_As, d->d_tabs, d->d_s1, d->d_s2, d->d_t0, d->d_t1s, d->d_K, d->d_tr_priv, d->d_tr_pub, d->d_rho, d->msg_dev, d->sig_dev };
     for (void *p : ptrs) if (p) (void)sc::wipe_free(p);
-    if (d->h_tabs) { for (auto &w : *d->h_tabs) *(volatile uint32_t *)&w = 0; delete d->h_tabs; }
     sc_hip_plan_destroy(d->plan);
     delete d;
 }
@@ -276,13 +275,23 @@ extern "C" int sc_hip_dilithium_fin_tables_host(const sc_hip_dilithium_params_t 
     return SC_HIP_SUCCESS;
 }
 
-static int upload_fin_tables(sc_hip_dilithium *d)
+// The opt-in finishing kernel's tables (tuning bit 11) for the key being loaded: built on the host, uploaded, and the host copy zeroed before returning - the handle
+// keeps no host-side secret.  A failed upload leaves no half-filled device table behind (d_tabs stays null: sign_core then takes the transform kernel).
+static int build_fin_tables(sc_hip_dilithium *d, const int32_t *s1, const int32_t *s2, const int32_t *t0)
 {
-    if (d->d_tabs || !d->h_tabs || d->h_tabs->empty()) return SC_HIP_SUCCESS;
-    HIPCHK(hipSetDevice(d->ctx->device));
-    HIPCHK(hipMalloc((void **)&d->d_tabs, d->h_tabs->size() * 4));
-    HIPCHK(sc::copy_in(d->d_tabs, d->h_tabs->data(), d->h_tabs->size() * 4));
-    return SC_HIP_SUCCESS;
+    if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
+    d->tabs_tried = false;
+    std::vector<uint32_t> tabs;
+    auto wipe = [&] { for (auto &w : tabs) *(volatile uint32_t *)&w = 0; };
+    const bool fits = fin_tables(d->P, s1, s2, t0, tabs, d->fin_bias);
+    int rc = SC_HIP_SUCCESS;
+    if (fits) {
+        if (hipMalloc((void **)&d->d_tabs, tabs.size() * 4) != hipSuccess) { d->d_tabs = nullptr; rc = fail("dilithium_set_privkey: hipMalloc of the finishing tables failed"); }
+        else if (sc::copy_in(d->d_tabs, tabs.data(), tabs.size() * 4)) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; rc = SC_HIP_FAILURE; }
+    }
+    wipe();
+    d->tabs_tried = (rc == SC_HIP_SUCCESS);
+    return rc;
 }
 
 extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t *s1, const int32_t *s2, const int32_t *t,
@@ -297,13 +306,10 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = (x >= 0) ? x : x + q; }
     if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
     if (load_matrix(d, Ahat)) return SC_HIP_FAILURE;
-    {   // the opt-in finishing kernel's tables (tuning bit 11): built on the host here, no device work on the default path - upload_fin_tables below
-        if (!d->h_tabs) d->h_tabs = new std::vector<uint32_t>;
-        for (auto &w : *d->h_tabs) *(volatile uint32_t *)&w = 0;
-        if (!fin_tables(d->P, s1, s2, t0.data(), *d->h_tabs, d->fin_bias)) { for (auto &w : *d->h_tabs) *(volatile uint32_t *)&w = 0; d->h_tabs->clear(); }
-        if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
-        if (d->tune_sparse_fin && upload_fin_tables(d)) return SC_HIP_FAILURE;
-    }
+    // the opt-in finishing kernel's tables: only when tuning bit 11 is ALREADY set (the default path does no work for them, on the host or the device)
+    if (d->d_tabs) { (void)sc::wipe_free(d->d_tabs); d->d_tabs = nullptr; }
+    d->tabs_tried = false;
+    if (d->tune_sparse_fin && build_fin_tables(d, s1, s2, t0.data())) return SC_HIP_FAILURE;
     if (!d->d_K) HIPCHK(hipMalloc((void **)&d->d_K, 32));
     if (!d->d_tr_priv) HIPCHK(hipMalloc((void **)&d->d_tr_priv, 48));
     HIPCHK(sc::copy_in(d->d_K, K, 32));
@@ -410,7 +416,11 @@ extern "C" int sc_hip_dilithium_set_tuning(sc_hip_dilithium_t *d, int slots_per_
 {
     if (!d) return fail("dilithium_set_tuning: null handle");
     d->tune_slots = slots_per_message & 0xFF; d->tune_sync = (slots_per_message >> 8) & 1; d->tune_exp1 = (slots_per_message >> 9) & 1; d->tune_w24 = (slots_per_message >> 10) & 1; d->tune_sparse_fin = (slots_per_message >> 11) & 1; d->tune_unfused = unfused ? 1 : 0;
-    if (d->tune_sparse_fin && d->have_priv && upload_fin_tables(d)) return SC_HIP_FAILURE;
+    // bit 11's tables are made from the raw key at key load and nothing of the key stays on the host: a key loaded without the bit has to be loaded again
+    if (d->tune_sparse_fin && d->have_priv && !d->tabs_tried) {
+        d->tune_sparse_fin = 0;
+        return fail("dilithium_set_tuning: bit 11 (finishing kernel without transforms) must be set before sc_hip_dilithium_set_privkey - load the key again after setting it");
+    }
     return SC_HIP_SUCCESS;
 }
 

@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -881,6 +881,88 @@ static int gen_drbg(const char *dir)
             }
             prng_destroy(p);
         }
+    }
+    fclose(f);
+    return 0;
+}
+
+/* ------------------------------------------- module-LWE, XOF-driven variants ---- */
+#include "utils/crypto/xof.h"
+#include "utils/arith/module_lwe.h"
+
+/* The XOF-driven forms of the module-LWE helpers (src/utils/arith/module_lwe.c:330-367 uniform_rand_sample_xof / _small_xof, :449-512
+ * binomial_rand_sample_xof, :550-560 uniform_random_ring_q_xof, :751-912 create_rand_product_32_xof / _16_xof).  No scheme of the library as it is
+ * compiled reaches them (dilithium_params.h / kyber_kem_params.h define the *_USE_CSPRNG_SAM switches unconditionally), but the functions themselves are
+ * compiled and exported, so they are pinned here at the function level: called directly, on a XOF prepared the way the scheme code would
+ * (xof_init, xof_absorb(rho), xof_final - dilithium.c:866-870). */
+static int gen_mlwe_xof(const char *dir)
+{
+    char path[512], name[96];
+    snprintf(path, sizeof path, "%s/mlwe_xof_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    const utils_arith_ntt_t *sc_ntt = utils_arith_ntt(SC_NTT_FLOATING_POINT);
+    const utils_arith_poly_t *sc_poly = utils_arith_poly();
+    /* q, q_bits, k, l, 16-bit tables?, SHAKE width, seed bytes */
+    const struct { int32_t q, q_bits; int k, l, is16, shake, seedlen; } cs[5] = {
+        { 8380417, 23, 6, 5, 0, 128, 32 },          /* Dilithium-III shape */
+        { 8380417, 23, 3, 2, 0, 128, 32 },          /* Dilithium set 0 */
+        { 7681,    13, 3, 3, 1, 128, 32 },          /* Kyber-768 shape, 16-bit tables */
+        { 8380417, 23, 4, 3, 0, 256, 48 },          /* the other SHAKE width, a longer seed */
+        { 7681,    13, 2, 2, 1, 256, 7 } };         /* a short seed */
+    const int n = 256;
+    sm_state = 0x0f0f5eedULL;
+    for (int c = 0; c < 5; c++) {
+        const int k = cs[c].k, l = cs[c].l, q = cs[c].q, q_bits = cs[c].q_bits;
+        int32_t par[8] = { q, q_bits, k, l, cs[c].is16, cs[c].shake, cs[c].seedlen, n };
+        snprintf(name, sizeof name, "xof%d_params", c); rec_i32(f, name, par, 8);
+        uint8_t seed[64];
+        for (int i = 0; i < cs[c].seedlen; i++) seed[i] = (uint8_t)splitmix64();
+        snprintf(name, sizeof name, "xof%d_seed", c); rec_u8(f, name, seed, cs[c].seedlen);
+        utils_crypto_xof_t *xof = utils_crypto_xof_create(cs[c].shake == 128 ? SC_XOF_SHAKE128 : SC_XOF_SHAKE256);
+        if (!xof) { fclose(f); return 1; }
+        ntt_params_t ntt; init_reduce(&ntt, n, q);
+        int32_t *ring = malloc(sizeof(int32_t) * n * k * l), *y = malloc(sizeof(int32_t) * n * (k > l ? k : l)), *t = malloc(sizeof(int32_t) * n * (k > l ? k : l));
+        int32_t *cbuf = malloc(sizeof(int32_t) * n * 2), *temp = malloc(sizeof(int32_t) * n * (k > l ? k : l));
+        /* the matrix entries in generation order: k*l consecutive uniform_random_ring_q_xof calls on the one stream */
+        xof_init(xof); xof_absorb(xof, seed, cs[c].seedlen); xof_final(xof);
+        for (int p = 0; p < k * l; p++) uniform_random_ring_q_xof(xof, ring + p * n, n, q, q_bits);
+        snprintf(name, sizeof name, "xof%d_ring", c); rec_i32(f, name, ring, (size_t)n * k * l);
+        /* t = A y (transpose 0: y has l rows, t has k) and t = A^T y (transpose 1: the loops of :776-800 draw the matrix column by column; y has l rows, t k) */
+        for (int tr = 0; tr < 2; tr++) {
+            for (int i = 0; i < n * l; i++) y[i] = (c & 1) ? (int32_t)(splitmix64() % 11) - 5 : (int32_t)(splitmix64() % (uint64_t)q);
+            snprintf(name, sizeof name, "xof%d_y%d", c, tr); rec_i32(f, name, y, (size_t)n * l);
+            memset(t, 0, sizeof(int32_t) * n * (k > l ? k : l));
+            xof_init(xof); xof_absorb(xof, seed, cs[c].seedlen); xof_final(xof);
+            if (cs[c].is16)
+                create_rand_product_16_xof(xof, q, q_bits, t, y, n, k, l, cbuf, temp, 0, tr, w7681_n256, r7681_n256, sc_poly, sc_ntt, &ntt);
+            else
+                create_rand_product_32_xof(xof, q, q_bits, t, y, n, k, l, cbuf, temp, 0, tr, w8380417_n256, r8380417_n256, sc_poly, sc_ntt, &ntt);
+            snprintf(name, sizeof name, "xof%d_t%d", c, tr); rec_i32(f, name, t, (size_t)n * k);
+        }
+        /* the small-coefficient samplers on the same seeded stream, one after the other (the stream position carries over): the output buffer is pre-filled
+         * with a marker so that what a call does NOT write shows (uniform_rand_sample_small_xof writes floor(m n / 1024) * 1024 values, :355;
+         * binomial_rand_sample_xof restarts at s for every 1024-value block, :452-456) */
+        const int m = k > l ? k : l, eta = (q == 7681) ? 4 : 5, bits = 3;
+        int32_t *sm = malloc(sizeof(int32_t) * n * 8);
+        xof_init(xof); xof_absorb(xof, seed, cs[c].seedlen); xof_final(xof);
+        for (int i = 0; i < n * 8; i++) sm[i] = 99;
+        uniform_rand_sample_xof(xof, q, eta, bits, sm, n, m);
+        snprintf(name, sizeof name, "xof%d_unif", c); rec_i32(f, name, sm, (size_t)n * m);
+        for (int i = 0; i < n * 8; i++) sm[i] = 99;
+        uniform_rand_sample_small_xof(xof, q, eta, bits, sm, n, 5);                       /* 1280 values asked for */
+        snprintf(name, sizeof name, "xof%d_small5", c); rec_i32(f, name, sm, (size_t)n * 5);
+        for (int i = 0; i < n * 8; i++) sm[i] = 99;
+        uniform_rand_sample_small_xof(xof, q, eta, bits, sm, n, 8);                       /* 2048 */
+        snprintf(name, sizeof name, "xof%d_small8", c); rec_i32(f, name, sm, (size_t)n * 8);
+        for (int i = 0; i < n * 8; i++) sm[i] = 99;
+        binomial_rand_sample_xof(xof, q, eta > 4 ? 4 : eta, sm, n, 4);                     /* one block */
+        snprintf(name, sizeof name, "xof%d_binomial4", c); rec_i32(f, name, sm, (size_t)n * 4);
+        for (int i = 0; i < n * 8; i++) sm[i] = 99;
+        binomial_rand_sample_xof(xof, q, 3, sm, n, 8);                                     /* two blocks */
+        snprintf(name, sizeof name, "xof%d_binomial8", c); rec_i32(f, name, sm, (size_t)n * 8);
+        free(sm); free(ring); free(y); free(t); free(cbuf); free(temp);
+        utils_crypto_xof_destroy(xof);
     }
     fclose(f);
     return 0;
@@ -1828,7 +1910,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) { fixed_domain("ntt"); rc |= gen_ntt(argv[2]); }
     if (all || !strcmp(argv[1], "ntt_large")) { fixed_domain("ntt_large"); rc |= gen_ntt_large(argv[2]); }
@@ -1850,5 +1932,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "dlp")) { fixed_domain("dlp"); rc |= gen_dlp(argv[2]); }
     if (all || !strcmp(argv[1], "ensdlp")) { fixed_domain("ensdlp"); rc |= gen_ensdlp(argv[2]); }
     if (all || !strcmp(argv[1], "ensdlp_rec")) { fixed_domain("ensdlp_rec"); rc |= gen_ensdlp_rec(argv[2]); }
+    if (all || !strcmp(argv[1], "mlwe_xof")) { fixed_domain("mlwe_xof"); rc |= gen_mlwe_xof(argv[2]); }
     return rc;
 }

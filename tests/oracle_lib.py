@@ -16,7 +16,7 @@ def lib():
     global _LIB
     if _LIB is None:
         path = os.path.join(ROOT, 'oracle', 'libsc_oracle.so')
-        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle_rlwe.c', 'sc_oracle_ens.c', 'sc_oracle.h')]
+        srcs = [os.path.join(ROOT, 'oracle', f) for f in ('sc_oracle.c', 'sc_oracle_keccak.c', 'sc_oracle_dilithium.c', 'sc_oracle_bliss.c', 'sc_oracle_kyber.c', 'sc_oracle_falcon.c', 'sc_oracle_drbg.c', 'sc_oracle_tesla.c', 'sc_oracle_rlwe.c', 'sc_oracle_ens.c', 'sc_oracle_mlwe_xof.c', 'sc_oracle.h')]
         if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in srcs):
             subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), 'libsc_oracle.so'])
         L = C.CDLL(path)
@@ -729,3 +729,47 @@ def dilithium_keygen(par, eta_bits, seed):
     sd = f(seed, np.uint8)
     assert lib().orc_dilithium_keygen(par, int(eta_bits), sd, sd.size, s1, s2, t, rho, K, tr, t1) == 0
     return s1, s2, t, rho, K, tr, t1
+
+
+# ---- module-LWE, XOF-driven variants (oracle/sc_oracle_mlwe_xof.c); every call takes the stream position to start from and returns (values, position after) ----
+def _xof_args(shake_bits, seed, skip):
+    sd = np.ascontiguousarray(np.asarray(seed), dtype=np.uint8)
+    return int(shake_bits), sd.ctypes.data_as(C.c_void_p), C.c_size_t(sd.size), C.c_size_t(int(skip)), sd
+
+
+def ring_q_xof(shake_bits, seed, skip, npoly, q, q_bits, n=256):
+    L = lib(); L.orc_ring_q_xof.restype = C.c_size_t
+    out = np.zeros(npoly * n, dtype=np.int32)
+    a = _xof_args(shake_bits, seed, skip)
+    pos = L.orc_ring_q_xof(a[0], a[1], a[2], a[3], int(npoly), int(n), C.c_int32(int(q)), int(q_bits), out.ctypes.data_as(C.c_void_p))
+    return out, int(pos)
+
+
+def sample_xof(kind, shake_bits, seed, skip, eta, bits, count, fill=99):
+    """kind: 'uniform' | 'small' | 'binomial' (uniform_rand_sample_xof / uniform_rand_sample_small_xof / binomial_rand_sample_xof); the output starts
+    as `fill` everywhere so that what the reference's function does not write shows"""
+    L = lib()
+    out = np.full(count, fill, dtype=np.int32)
+    a = _xof_args(shake_bits, seed, skip)
+    op = out.ctypes.data_as(C.c_void_p)
+    if kind == 'uniform':
+        L.orc_uniform_sample_xof.restype = C.c_size_t
+        pos = L.orc_uniform_sample_xof(a[0], a[1], a[2], a[3], C.c_int32(int(eta)), int(bits), op, C.c_size_t(count))
+    elif kind == 'small':
+        L.orc_uniform_sample_small_xof.restype = C.c_size_t
+        pos = L.orc_uniform_sample_small_xof(a[0], a[1], a[2], a[3], C.c_int32(int(eta)), int(bits), op, C.c_size_t(count))
+    else:
+        L.orc_binomial_sample_xof.restype = C.c_size_t
+        pos = L.orc_binomial_sample_xof(a[0], a[1], a[2], a[3], C.c_int32(int(eta)), op, C.c_size_t(count))
+    return out, int(pos)
+
+
+def rand_product_xof(shake_bits, seed, skip, q, q_bits, k, l, transposed, y, n=256, width=16):
+    L = lib(); L.orc_rand_product_xof.restype = C.c_size_t
+    w, r = tables(q, n)
+    yy = np.ascontiguousarray(np.asarray(y), dtype=np.int32)
+    t = np.zeros(k * n, dtype=np.int32)
+    a = _xof_args(shake_bits, seed, skip)
+    pos = L.orc_rand_product_xof(a[0], a[1], a[2], a[3], C.c_int32(int(q)), int(q_bits), int(k), int(l), 1 if transposed else 0,
+                                 yy.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), int(n), w.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), int(width))
+    return t, int(pos)

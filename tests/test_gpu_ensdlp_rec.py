@@ -96,6 +96,7 @@ def test_verdicts_and_rebuilt_messages_are_the_references(eng, G, tag):
     v, out, ol = f.ens_dlp_verify_recovery(torch.from_numpy(sb).cuda(), torch.from_numpy(sl).cuda(), torch.from_numpy(m2b).cuda(), torch.from_numpy(m2l).cuda())
     torch.cuda.synchronize()
     assert v.cpu().tolist() == want
+    assert sum(1 for m in range(8) if int(G[f'{tag}_verify'][3 * m]) == 0) >= 7        # the committed (seeded) fixture's key accepts: the recovery branch below is exercised
     for i, bk in enumerate(back):
         if bk is not None:
             assert bytes(out[i, :int(ol[i])].cpu().numpy()) == bk, i

@@ -13,6 +13,15 @@ from tests.golden_io import load_golden
 from tests import oracle_lib as O
 from tests.test_gpu_dilithium import make, golden_msgs
 
+
+def make_sparse(eng, key, tuning):
+    """bit 11 is honoured at key load only (the tables are made from the raw key there and no host copy of the key is kept): set it, then load the key"""
+    d = eng.dilithium(key.par)
+    d.set_tuning(tuning)
+    d.set_privkey(key.s1, key.s2, key.t, key.K, key.tr, key.Ahat)
+    d.set_pubkey(key.t1, key.rho, key.Ahat)
+    return d
+
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(os.environ.get('SC_TEST_UNVALIDATED') != '1', reason='kernel not yet run on hardware: opt in with SC_TEST_UNVALIDATED=1')]
 
@@ -35,8 +44,7 @@ def G():
 @pytest.mark.parametrize('tag', ['dil3', 'dil1', 'dil0', 'dil2'])
 def test_reference_signatures(eng, G, tag):
     key = O.DilKey.from_golden(G, tag)
-    d = make(eng, key)
-    d.set_tuning(SPARSE)
+    d = make_sparse(eng, key, SPARSE)
     gm = golden_msgs(G, tag)
     sigs, trials = d.sign_host([m for m, _, _ in gm])
     for i, (m, sig, tr) in enumerate(gm):
@@ -52,6 +60,10 @@ def test_same_bytes_as_the_transform_kernel(eng, G, B):
     rng = np.random.default_rng(B)
     msgs = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 201)), dtype=np.uint8)) for _ in range(B)]
     want, wt = d.sign_host(msgs)
+    with pytest.raises(Exception):                  # a key loaded without the bit: the request is refused, not silently ignored
+        d.set_tuning(SPARSE)
+    d.close()
+    d = make_sparse(eng, key, SPARSE)
     for tuning in (SPARSE, SPARSE | (1 << 9), SPARSE | (1 << 8)):
         d.set_tuning(tuning)
         got, gt = d.sign_host(msgs)

@@ -36,11 +36,11 @@ def main():
     if leg.startswith('dil'):
         G = load_golden('dilithium_ref.txt'); tag, B = 'dil3', 16384
         d = eng.dilithium(G[f'{tag}_params'])
+        if os.environ.get('SC_BENCH_DIL_TUNING'):                 # measurement only: the first argument of sc_hip_dilithium_set_tuning (include/sc_hip_bench.h); before the key load (bit 11's tables are made there)
+            d.set_tuning(int(os.environ['SC_BENCH_DIL_TUNING'], 0))
         d.set_privkey(*(G[f'{tag}_{x}'] for x in ('s1', 's2', 't', 'K', 'tr', 'Ahat'))); d.set_pubkey(G[f'{tag}_t1'], G[f'{tag}_rho'], G[f'{tag}_Ahat'])
         msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         made = 1
-        if os.environ.get('SC_BENCH_DIL_TUNING'):                 # measurement only: the first argument of sc_hip_dilithium_set_tuning (include/sc_hip_bench.h)
-            d.set_tuning(int(os.environ['SC_BENCH_DIL_TUNING'], 0))
         if os.environ.get('SC_BENCH_BATCH'):
             B = int(os.environ['SC_BENCH_BATCH']); msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
         if leg == 'dil_sign':
