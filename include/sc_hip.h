@@ -258,6 +258,32 @@ int sc_hip_drbg_words(sc_hip_ctx_t *ctx, size_t batch, const uint8_t *d_seeds, s
 int sc_hip_mlwe_expand_matrix(sc_hip_ctx_t *ctx, size_t nkeys, const uint8_t *d_rho, size_t rho_stride, size_t rho_len, int npoly, int32_t q, int q_bits,
                               int32_t *d_out, void *stream);
 
+/* ---- the XOF-driven forms of the module-LWE helpers (src/utils/arith/module_lwe.c:330-367,449-512,550-560,751-912) ----
+ * The reference compiles two forms of every module-LWE helper: *_csprng (above; what its Kyber and Dilithium are built with, kyber_kem_params.h:31 /
+ * dilithium_params.h) and *_xof, driven by a SHAKE context prepared with xof_init / xof_absorb(seed) / xof_final (dilithium.c:866-870 in a build without
+ * DILITHIUM_USE_CSPRNG_SAM).  The stream is SHAKE128 (shake_bits = 128; sc->xof of Kyber and Dilithium) or SHAKE256 with the reference's permutation.
+ * Every entry takes the byte position of the stream to start at (`skip_bytes`: where the previous call on the same xof context stopped, 0 after xof_final).
+ *
+ * replaces: the npoly calls of uniform_random_ring_q_xof (module_lwe.c:550-560) with which create_rand_product_32_xof / _16_xof (:751-912) draw the matrix:
+ * d_out int32 [nkeys][npoly][n] in generation order - row-major [k][l] for the plain product, [l][k] for the transposed one (the order the loops of
+ * :776-800 / :806-830 visit it), i.e. the d_Ahat argument of sc_hip_matvec either way.  An entry is a 32-bit little-endian word of the stream masked to
+ * q_bits, minus q when >= q (NOT the 16-bit draws of the CSPRNG form).  create_rand_product_*_xof = this call, then sc_hip_matvec.
+ * NOTE on the transposed product: sc_hip_matvec computes A^T y, as create_rand_product_16_xof / _16_csprng do (module_lwe.c:875).  The _32 forms'
+ * transposed branch, which no caller of the reference reaches, has add_32(t_i, n, out, c) in place of the accumulation (:629, :796) and returns
+ * INTT(A[l-1][i] o (NTT(y[l-1]) + 1)) for l > 1; that is not served (the test suite's CPU checker restates it to explain the fixture). */
+int sc_hip_mlwe_expand_matrix_xof(sc_hip_ctx_t *ctx, size_t nkeys, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, int shake_bits, size_t skip_bytes,
+                                  int npoly, int n, int32_t q, int q_bits, int32_t *d_out, void *stream);
+/* replaces: uniform_rand_sample_xof (kind SC_HIP_XOF_UNIFORM, module_lwe.c:330-344), uniform_rand_sample_small_xof (SC_HIP_XOF_UNIFORM_SMALL, :347-367) and
+ * binomial_rand_sample_xof (SC_HIP_XOF_BINOMIAL, :449-485; `bits` unused) for nseeds independent streams: count = m * n values asked for per seed, row i of
+ * d_out (int32, pitch out_stride values) receives EXACTLY the entries the reference's function writes and no others - the small form fills whole blocks of
+ * 1024 values only (count = 1280 leaves the last 256 entries of the row as they were), the binomial form writes every block of 1024 values at the START of
+ * the row (the last block's values stay, the stream still moves by a block each time).  *pos_after (optional, host) = the stream position after the call. */
+#define SC_HIP_XOF_UNIFORM        0
+#define SC_HIP_XOF_UNIFORM_SMALL  1
+#define SC_HIP_XOF_BINOMIAL       2
+int sc_hip_mlwe_sample_xof(sc_hip_ctx_t *ctx, int kind, size_t nseeds, const uint8_t *d_seeds, size_t seed_stride, size_t seed_len, int shake_bits, size_t skip_bytes,
+                           int32_t eta, int bits, size_t count, int32_t *d_out, size_t out_stride, size_t *pos_after, void *stream);
+
 /* ---- BLISS-B: batched sign / verify under one key ------------------------------------------ */
 
 /* the fields of bliss_set_t the engine needs (src/schemes/sig/bliss_b/bliss_params.h:43-75, values

@@ -29,7 +29,7 @@ SYMBOLS = [
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
-    'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix',
+    'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix', 'sc_hip_mlwe_expand_matrix_xof', 'sc_hip_mlwe_sample_xof',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_sign_seeded', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
     'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey', 'sc_hip_ens_dlp_signer_set_mapping',
@@ -260,6 +260,8 @@ def load_library(path=LIB_PATH):
     L.sc_hip_rlwe_decrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp]
     L.sc_hip_rlwe_keygen.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
     L.sc_hip_mlwe_expand_matrix.argtypes = [vp, sz, vp, sz, sz, C.c_int, i32, C.c_int, vp, vp]
+    L.sc_hip_mlwe_expand_matrix_xof.argtypes = [vp, sz, vp, sz, sz, C.c_int, sz, C.c_int, C.c_int, i32, C.c_int, vp, vp]
+    L.sc_hip_mlwe_sample_xof.argtypes = [vp, C.c_int, sz, vp, sz, sz, C.c_int, sz, i32, C.c_int, sz, vp, sz, C.POINTER(C.c_size_t), vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_drbg_words.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
     L.sc_hip_falcon_create.argtypes = [vp, vp, C.POINTER(vp)]
@@ -662,6 +664,28 @@ class Engine:
         _chk(self.L, self.L.sc_hip_mlwe_expand_matrix(self.h, rho.shape[0], _ptr(rho), _rows(rho), rho.shape[1], npoly, int(q), int(q_bits), _ptr(out), _stream()), 'mlwe_expand_matrix')
         return out
 
+    # the XOF-driven forms (module_lwe.c:330-367,449-512,550-560): SHAKE128 / SHAKE256 of each seed row, read from byte `skip` of the squeezed stream
+    def expand_matrix_xof(self, seeds, npoly, q, q_bits, shake_bits=128, skip=0, n=256):
+        """seeds uint8 [nkeys][len] (device) -> int32 [nkeys][npoly][n]: uniform_random_ring_q_xof npoly times on xof_absorb(seed)"""
+        import torch
+        out = torch.empty((seeds.shape[0], npoly, n), dtype=torch.int32, device=seeds.device)
+        _chk(self.L, self.L.sc_hip_mlwe_expand_matrix_xof(self.h, seeds.shape[0], _ptr(seeds), _rows(seeds), seeds.shape[1], int(shake_bits), int(skip), int(npoly), int(n), int(q), int(q_bits),
+                                                          _ptr(out), _stream()), 'mlwe_expand_matrix_xof')
+        return out
+
+    XOF_KINDS = {'uniform': 0, 'small': 1, 'binomial': 2}
+
+    def sample_xof(self, kind, seeds, eta, bits, count, shake_bits=128, skip=0, out=None, fill=0):
+        """uniform_rand_sample_xof / uniform_rand_sample_small_xof / binomial_rand_sample_xof for a stream per seed row -> (int32 [nseeds][count], stream position after);
+        entries the reference's function does not write keep what `out` held (a fresh `out` is filled with `fill`)"""
+        import torch
+        if out is None:
+            out = torch.full((seeds.shape[0], count), int(fill), dtype=torch.int32, device=seeds.device)
+        pos = C.c_size_t(0)
+        _chk(self.L, self.L.sc_hip_mlwe_sample_xof(self.h, self.XOF_KINDS[kind], seeds.shape[0], _ptr(seeds), _rows(seeds), seeds.shape[1], int(shake_bits), int(skip), int(eta), int(bits),
+                                                   int(count), _ptr(out), out.stride(0), C.byref(pos), _stream()), 'mlwe_sample_xof')
+        return out, int(pos.value)
+
     def drbg_words(self, seeds, nwords):
         import torch
         out = torch.empty((seeds.shape[0], nwords), dtype=torch.int32, device=seeds.device)
@@ -787,6 +811,12 @@ class NttPlan:
         t = torch.empty((batch, k, self.n), dtype=torch.int32, device=y.device)
         _chk(self.L, self.L.sc_hip_matvec(self.h, batch, k, l, 1 if transposed else 0, _ptr(Ahat), _ptr(y), _ptr(t), _stream()), 'matvec')
         return t
+
+    def rand_product_xof(self, seed, y, k, l, q_bits, transposed=False, shake_bits=128, skip=0):
+        """create_rand_product_32_xof / _16_xof (module_lwe.c:751-912) under one seed: the matrix drawn from SHAKE(seed) in the loops' order, then the product.
+        seed uint8 [len] or [1][len] (device); y int32 [batch][l][n]; -> (t int32 [batch][k][n] canonical, stream position after)"""
+        A = self.eng.expand_matrix_xof(seed.reshape(1, -1), k * l, self.q, q_bits, shake_bits, skip, self.n)
+        return self.matvec(A, y, k, l, transposed), int(skip) + k * l * self.n * 4
 
     def pointwise(self, a, b, out=None):
         out = self._out(a, out)

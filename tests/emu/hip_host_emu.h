@@ -9,6 +9,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
+#include <tuple>
+#include <utility>
+#include <type_traits>
 
 #ifndef EMU_CUS
 #define EMU_CUS 2
@@ -107,5 +110,10 @@ template <typename F> static inline void launch_host(dim3 grid, dim3 block, size
     gridDim.y = gridDim.z = 1; blockIdx.y = blockIdx.z = 0;
     EMU_UNPOISON(dyn_lds, sizeof dyn_lds);
 }
+// the argument expressions of a launch are evaluated ONCE, on the launching thread, and kept by value - as a real launch marshals them; every lane then calls the
+// kernel with the same values (a lambda around `kernel(expressions...)` would re-evaluate the expressions in every lane thread, concurrently).  The kernel is still
+// called BY NAME inside the macro so that its default arguments and template-ids work as they do in a <<<>>> launch.
+template <typename... A> static inline std::tuple<std::decay_t<A>...> launch_args(A &&...a) { return std::tuple<std::decay_t<A>...>(std::forward<A>(a)...); }
 }  // namespace emu
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) emu::launch_host(dim3(grid), dim3(block), (size_t)(lds), [&]() { kernel(__VA_ARGS__); })
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) do { const auto emu_launch_args = emu::launch_args(__VA_ARGS__); \
+    emu::launch_host(dim3(grid), dim3(block), (size_t)(lds), [&]() { std::apply([&](const auto &...emu_a) { kernel(emu_a...); }, emu_launch_args); }); } while (0)

@@ -123,7 +123,7 @@ LIB_REWRITES = (
 
 # ---- the whole product library for the CPU: libsafecrypto_amd/csrc/*.hip and *.cpp - host code and kernels - over tests/emu/hip_host_emu.h --------------------
 LIB_SOURCES = ['sc_hip.hip', 'dilithium.hip', 'kyber.hip', 'bliss.hip', 'falcon.hip', 'ops.hip', 'drbg.hip', 'tesla.hip', 'rlwe.hip', 'ens.hip', 'dlp.hip', 'entropy.hip',
-               'sc_vtable.cpp', 'multi.cpp']
+               'mlwe_xof.hip', 'sc_vtable.cpp', 'multi.cpp']
 
 
 def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
