@@ -48,25 +48,27 @@ void h_aes256_zero_key_encrypt(const uint8_t sbox[256], const uint8_t in[16], ui
 }
 }  // namespace
 
+static DrbgConst make_drbg_const()
+{
+    DrbgConst c;
+    for (int x = 0; x < 256; x++) {
+        uint8_t inv = 0;
+        if (x) for (int y = 1; y < 256; y++) if (h_gmul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
+        uint8_t s = inv, r = inv;
+        for (int i = 0; i < 4; i++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
+        c.sbox[x] = s ^ 0x63;
+    }
+    for (uint32_t ctr = 1; ctr <= 3; ctr++) {                      // ctr_drbg.c:104-128: block index 2, 1, 0
+        uint8_t blk[16];
+        for (int w = 0; w < 4; w++) { blk[4 * w] = (uint8_t)ctr; blk[4 * w + 1] = blk[4 * w + 2] = blk[4 * w + 3] = 0; }
+        h_aes256_zero_key_encrypt(c.sbox, blk, c.init_bytes + 16 * (3 - ctr));
+    }
+    return c;
+}
+
 const DrbgConst &drbg_const()
 {
-    static DrbgConst c;
-    static bool ready = false;
-    if (!ready) {
-        for (int x = 0; x < 256; x++) {
-            uint8_t inv = 0;
-            if (x) for (int y = 1; y < 256; y++) if (h_gmul((uint8_t)x, (uint8_t)y) == 1) { inv = (uint8_t)y; break; }
-            uint8_t s = inv, r = inv;
-            for (int i = 0; i < 4; i++) { r = (uint8_t)((r << 1) | (r >> 7)); s ^= r; }
-            c.sbox[x] = s ^ 0x63;
-        }
-        for (uint32_t ctr = 1; ctr <= 3; ctr++) {                      // ctr_drbg.c:104-128: block index 2, 1, 0
-            uint8_t blk[16];
-            for (int w = 0; w < 4; w++) { blk[4 * w] = (uint8_t)ctr; blk[4 * w + 1] = blk[4 * w + 2] = blk[4 * w + 3] = 0; }
-            h_aes256_zero_key_encrypt(c.sbox, blk, c.init_bytes + 16 * (3 - ctr));
-        }
-        ready = true;
-    }
+    static const DrbgConst c = make_drbg_const();                  // (a function-local static's initialisation is thread-safe: calls come from any host thread)
     return c;
 }
 

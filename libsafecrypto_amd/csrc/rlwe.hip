@@ -17,6 +17,7 @@
 // q < 2^14 for both parameter sets, so everything runs in the small-modulus arithmetic (modarith.h MODE_MAD).  The sampler is
 // a guide-table search (64-entry table + 4096-entry guide in LDS, see Sampler below).
 #include "engine_internal.h"
+#include <atomic>
 #include "ntt_core.h"
 #include "../../include/sc_hip_bench.h"
 
@@ -599,11 +600,13 @@ static void rl_args(const sc_hip_rlwe *h, size_t batch, RlArgs &a)
 template <typename K>
 static hipError_t rl_launch(K kernel, const sc_hip_rlwe *h, size_t batch, const RlArgs &a, void *stream)
 {
-    static int per_cu = 0;                                      // one static per kernel instantiation
+    static std::atomic<int> per_cu_cache{0};                    // one static per kernel instantiation; atomic: handles of several host threads launch through here
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb;
+        per_cu_cache.store(nb, std::memory_order_relaxed);
     }
     const size_t pw = 1024 / (size_t)h->P.n, groups = (batch + pw - 1) / pw;
     size_t blocks = (groups + 3) / 4;

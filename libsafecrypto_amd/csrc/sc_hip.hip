@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -155,12 +156,13 @@ __global__ __launch_bounds__(256) void cdt_halving_kernel(const uint64_t *__rest
 // ------------------------------------------------------------------------------------------
 
 #include "engine_internal.h"
+#include <atomic>
 
 static thread_local std::string g_err;
 thread_local bool sc::t_skip_host_pin = false;
 thread_local const sc::HostPins *sc::t_driver_pins = nullptr;
 extern "C" void sc_hip_bench_set_host_pin(int on) { sc::HostPins::mode() = on; }
-static int g_cus = 256;
+static std::atomic<int> g_cus{256};                  // (read by launches on any host thread, written by sc_hip_ctx_create)
 // streaming I/O of the NTT kernels (ntt_kernel<..., STREAM>): taken when an operation's operands exceed the threshold (default: the Infinity Cache's 256 MiB)
 static bool g_stream_io = true;
 static size_t g_stream_threshold = (size_t)256 << 20;
@@ -204,7 +206,7 @@ extern "C" int sc_hip_ctx_create(int device, sc_hip_ctx_t **out)
     sc_hip_ctx *c = new sc_hip_ctx;
     c->device = device;
     c->cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    g_cus = c->cus;
+    g_cus.store(c->cus, std::memory_order_relaxed);
     *out = c;
     return SC_HIP_SUCCESS;
 }
@@ -368,13 +370,16 @@ extern "C" int sc_hip_plan_set_arith(sc_hip_plan_t *p, int mode)
 template <int L, int MODE, bool LAZY, int OP, bool STREAM = false>
 static hipError_t launch_ntt_t(const NttArgs &a, int blocks, hipStream_t s)
 {
-    static int per_cu = 0;
+    // (atomic: plans are shared between host threads - the multi-device driver launches from one thread per worker - and two first launches may both fill it in, with the same value)
+    static std::atomic<int> per_cu_cache{0};
+    int per_cu = per_cu_cache.load(std::memory_order_relaxed);
     if (per_cu == 0) {
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_kernel<L, MODE, LAZY, OP, STREAM>, 256, 0) != hipSuccess || nb < 1) nb = 2;
         per_cu = nb;
+        per_cu_cache.store(nb, std::memory_order_relaxed);
     }
-    const long long cap = (long long)per_cu * g_cus;
+    const long long cap = (long long)per_cu * g_cus.load(std::memory_order_relaxed);
     if (blocks > cap) blocks = (int)cap;
     if (blocks <= 0) return hipSuccess;                       // warm-up call: the occupancy query above is all that was wanted
     hipLaunchKernelGGL((ntt_kernel<L, MODE, LAZY, OP, STREAM>), dim3(blocks), dim3(256), 0, s, a);
