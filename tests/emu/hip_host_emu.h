@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <mutex>
 #include <tuple>
 #include <utility>
@@ -41,34 +42,53 @@ static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; 
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "MI355X (CPU emulation)"); strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = EMU_CUS; p->totalGlobalMem = (size_t)1 << 34; p->sharedMemPerBlock = 160 * 1024; p->warpSize = 64; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeMaxSharedMemoryPerBlock ? 160 * 1024 : a == hipDeviceAttributeMultiprocessorCount ? EMU_CUS : 0; return hipSuccess; }
+// ---- fault injection (tests/test_emu_faults.py): the (N+1)-th call from now of a class fails, once; live allocations are counted so that a failed call can be held to
+// "nothing of it stays allocated".  Classes: 0 allocations (hipMalloc / hipHostMalloc), 1 copies and memsets, 2 stream / event creation, 3 hipHostRegister.
+namespace emu {
+inline std::atomic<long> fault_in[4] = { {-1}, {-1}, {-1}, {-1} };      // calls of the class still to succeed before one fails; < 0: none will
+inline std::atomic<long> calls[4] = { {0}, {0}, {0}, {0} };             // calls of the class seen so far
+inline std::atomic<long> live_allocs{0};
+static inline bool trip(int cls)
+{
+    calls[cls].fetch_add(1, std::memory_order_relaxed);
+    long v = fault_in[cls].load(std::memory_order_relaxed);
+    while (v >= 0) if (fault_in[cls].compare_exchange_weak(v, v - 1, std::memory_order_relaxed)) return v == 0;
+    return false;
+}
+}  // namespace emu
+extern "C" __attribute__((weak, used, visibility("default"))) void sc_emu_fault(int cls, long countdown) { if (cls >= 0 && cls < 4) emu::fault_in[cls].store(countdown); }
+extern "C" __attribute__((weak, used, visibility("default"))) long sc_emu_calls(int cls) { return cls >= 0 && cls < 4 ? emu::calls[cls].load() : -1; }
+extern "C" __attribute__((weak, used, visibility("default"))) long sc_emu_live_allocs(void) { return emu::live_allocs.load(); }
+
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t n)
 {
     void *q = nullptr;
-    if (posix_memalign(&q, 256, n ? n : 1)) { *p = nullptr; return hipErrorOutOfMemory; }
+    if (emu::trip(0) || posix_memalign(&q, 256, n ? n : 1)) { *p = nullptr; return hipErrorOutOfMemory; }
     static const int fill = getenv("EMU_MALLOC_FILL") ? (int)strtol(getenv("EMU_MALLOC_FILL"), nullptr, 0) : 0;
     memset(q, fill, n);
     *p = (T *)q;
+    emu::live_allocs.fetch_add(1, std::memory_order_relaxed);
     return hipSuccess;
 }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p) { if (p) emu::live_allocs.fetch_sub(1, std::memory_order_relaxed); free(p); return hipSuccess; }
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
-static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return emu::trip(3) ? hipErrorInvalidValue : hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { memset(a, 0, sizeof *a); return hipErrorInvalidValue; }      // "not a registered pointer"
 static inline hipError_t hipMemPtrGetInfo(void *, size_t *) { return hipErrorInvalidValue; }
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (n) memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t = nullptr) { for (size_t i = 0; i < count; i++) ((int *)d)[i] = v; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)malloc(8); return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { if (emu::trip(2)) { *s = nullptr; return hipErrorOutOfMemory; } *s = (hipStream_t)malloc(8); emu::live_allocs.fetch_add(1); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { if (s) emu::live_allocs.fetch_sub(1); free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
-static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = (hipEvent_t)malloc(8); return hipSuccess; }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { if (emu::trip(2)) { *e = nullptr; return hipErrorOutOfMemory; } *e = (hipEvent_t)malloc(8); emu::live_allocs.fetch_add(1); return hipSuccess; }
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) emu::live_allocs.fetch_sub(1); free(e); return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
