@@ -64,6 +64,9 @@ struct sc_hip_glue {
 /* the private struct behind a 64-bit CDF sampler's `gauss` pointer (src/utils/sampling/gaussian_cdf.c:74-81) */
 typedef struct __attribute__((packed)) { UINT64 *cdf; SINT32 cdf_size; SINT32 k; SINT32 use_kl; prng_ctx_t *prng_ctx; } gauss_cdf_64_view_t;
 
+/* ... and behind a 128- / 192-bit one (gauss_cdf_high_t, :59-68): limbs of SC_LIMB_BITS = 64, least significant first */
+typedef struct __attribute__((packed)) { UINT64 *cdf_256, *cdf_192, *cdf_128; SINT32 cdf_size; SINT32 k; SINT32 use_kl; prng_ctx_t *prng_ctx; } gauss_cdf_high_view_t;
+
 static uint64_t glue_rng64(void *ctx) { return prng_64((prng_ctx_t *)ctx); }
 
 sc_hip_glue_t *sc_hip_glue_attach(safecrypto_t *sc, int device)
@@ -86,6 +89,20 @@ sc_hip_glue_t *sc_hip_glue_attach(safecrypto_t *sc, int device)
         SAMPLING_DISABLE_BOOTSTRAP == g->gauss0->bootstrapped && 0 == g->gauss0->discard) {
         const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)g->gauss0->gauss;
         if (SC_HIP_SUCCESS == sc_hip_sampler_create(g->gauss0->tail, g->gauss0->sigma, v->cdf, v->cdf_size, glue_rng64, g->gauss0->prng_ctx, &g->sampler) &&
+            SC_HIP_SUCCESS == sc_hip_utils_sampling_fill(&g->sampling, g->sampler)) {
+            g->sampling.dimension = g->gauss0->dimension;
+            sc->sc_gauss = (utils_sampling_t *)&g->sampling;
+        }
+    }
+    /* a 128- / 192-bit CDF sampler (SC_FLAG_0_SAMPLE_128BIT / _192BIT: what the reference's BLISS-B harness asks for, test/functional/func_alg_bliss_b.c:118): the
+     * context's table - MPFR arithmetic, made by the library as it always was (gauss_cdf_create_high_precision, gaussian_cdf.c:186-330) - is handed to the engine, which
+     * runs the search (gaussian_cdf_sample_128 / _192) for the words the context's generator yields, two / three prng_64 a sample */
+    else if (NULL != g->gauss0 && CDF_GAUSSIAN_SAMPLING == sc->sampling && (SAMPLING_128BIT == g->gauss0->precision || SAMPLING_192BIT == g->gauss0->precision) &&
+             SAMPLING_DISABLE_BOOTSTRAP == g->gauss0->bootstrapped && 0 == g->gauss0->discard) {
+        const gauss_cdf_high_view_t *v = (const gauss_cdf_high_view_t *)g->gauss0->gauss;
+        const int prec = (int)g->gauss0->precision;
+        if (SC_HIP_SUCCESS == sc_hip_sampler_create_hp(prec, g->gauss0->tail, g->gauss0->sigma, 128 == prec ? v->cdf_128 : v->cdf_192, v->cdf_size, glue_rng64,
+                                                       g->gauss0->prng_ctx, &g->sampler) &&
             SC_HIP_SUCCESS == sc_hip_utils_sampling_fill(&g->sampling, g->sampler)) {
             g->sampling.dimension = g->gauss0->dimension;
             sc->sc_gauss = (utils_sampling_t *)&g->sampling;

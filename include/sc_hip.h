@@ -154,13 +154,31 @@ int sc_hip_cdt_sample(sc_hip_cdt_t *cdt, size_t count, const uint64_t *d_uniform
  * replaces: create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, ...) -> gaussian_cdf_create_32, and get_vector_32 -> gaussian_cdf_sample_32 +
  * binary_search_32 (src/utils/sampling/gaussian_cdf.c:661-774): a table of 32-bit entries built with FLOAT (float) accumulators, one prng_32 word per
  * sample, "entry < word", the sign from the word's bit 0.  A handle made here is served by sc_hip_cdt32_sample only (and the other way round); size /
- * destroy are sc_hip_cdt_size / sc_hip_cdt_destroy.  (The reference's 128- / 192-bit samplers do not terminate a BLISS-B signature in the build of
- * SURVEY 8(c) - safecrypto_sign loops - and its 256-bit one draws an uninitialised limb, gaussian_cdf.c:519-527: neither can be pinned, neither is served.) */
+ * destroy are sc_hip_cdt_size / sc_hip_cdt_destroy. */
 int sc_hip_cdt32_build_table(float tail, float sigma, uint32_t *h_cdf, int size);
 int sc_hip_cdt32_create(sc_hip_ctx_t *ctx, float tail, float sigma, sc_hip_cdt_t **cdt);
 int sc_hip_cdt32_create_from_table(sc_hip_ctx_t *ctx, const uint32_t *h_cdf, int size, sc_hip_cdt_t **cdt);
 int sc_hip_cdt32_table(const sc_hip_cdt_t *cdt, uint32_t *h_cdf);
 int sc_hip_cdt32_sample(sc_hip_cdt_t *cdt, size_t count, const uint32_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
+
+/* The sampler at 128- and 192-bit precision, over a caller-supplied table.
+ * replaces: get_vector_32 -> gaussian_cdf_sample_128 / _192 + binary_search_128 / _192 + compare_ge_prec (src/utils/sampling/gaussian_cdf.c:110-184,468-509) of a sampler
+ * made by create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_128BIT / SAMPLING_192BIT, ...) - what the reference's BLISS-B harness asks for (test/functional/func_alg_bliss_b.c:118).
+ * h_cdf: the table as the reference holds it, [size][W] 64-bit limbs, least significant limb first (u128_t / u192_t with SC_LIMB_BITS = 64), W = precision_bits / 64;
+ * d_uniform: [count][W] 64-bit words, the sample's prng_64 draws in the order the reference makes them (limb 0 first, :482-483,498-500).
+ * What the reference's search does, and this reproduces: the sign is bit 0 of limb 0; the step to entry b is taken when compare_ge_prec says "x >= entry" - and
+ * that function's loop over the limbs ends with the verdict of the MOST SIGNIFICANT limb alone (retval = !(a < b) | (equal & retval): when a limb is equal the first term is
+ * already 1), so the limbs below the top one never decide anything; ties in the top limb go to the entry (">=", where the 64-bit sampler has "<").  The fixture
+ * tests/golden/cdt_hp_ref.txt holds the reference's own get_vector_32 run over tables whose lower limbs are noise and whose top limbs tie with drawn words.
+ * The TABLE is not built here: gauss_cdf_create_high_precision (:186-330) is MPFR arithmetic (sc_mpf_exp, sc_mpf_get_pi) - a libsafecrypto built with MPFR hands its
+ * table over; the monotone check is on the top limbs, which is all the search reads.  256-bit precision is refused: the reference's
+ * gaussian_cdf_sample_256 never writes the top limb of its word and stores one draw past the end of it (:519-522) - there is no defined result to reproduce.
+ * A handle made here is served by sc_hip_cdt_hp_sample only; size / destroy are sc_hip_cdt_size / sc_hip_cdt_destroy. */
+int sc_hip_cdt_hp_create_from_table(sc_hip_ctx_t *ctx, int precision_bits, const uint64_t *h_cdf, int size, sc_hip_cdt_t **cdt);
+int sc_hip_cdt_hp_precision(const sc_hip_cdt_t *cdt);                  /* 32 / 64 / 128 / 192: what a handle was created at */
+int sc_hip_cdt_hp_table(const sc_hip_cdt_t *cdt, uint64_t *h_cdf);      /* [size][W], as handed in */
+int sc_hip_cdt_hp_sample(sc_hip_cdt_t *cdt, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream);
+int sc_hip_cdt_hp_sample_host(sc_hip_cdt_t *cdt, size_t count, const uint64_t *h_uniform, int32_t centre, int32_t *h_out);   /* host buffers in and out */
 
 /* ---- Dilithium: batched sign / verify under one key --------------------------------------- */
 

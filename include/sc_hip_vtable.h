@@ -129,6 +129,10 @@ int sc_hip_utils_arith_vec_fill(sc_hip_utils_arith_vec_t *dst);
 typedef uint64_t (*sc_hip_rng64_fn)(void *rng_ctx);
 typedef struct sc_hip_sampler sc_hip_sampler_t;
 int  sc_hip_sampler_create(float tail, float sigma, const uint64_t *h_cdf, int size, sc_hip_rng64_fn rng, void *rng_ctx, sc_hip_sampler_t **out);
+/* the same at 128- / 192-bit precision (create_sampler(..., SAMPLING_128BIT / SAMPLING_192BIT, ...): gaussian_cdf_sample_128 / _192, gaussian_cdf.c:468-509): h_cdf is the
+ * reference's own table (gauss_cdf_high_t::cdf_128 / cdf_192, [size][precision_bits / 64] limbs - MPFR arithmetic the engine does not redo), precision_bits / 64 draws of
+ * `rng` per sample; sc_hip_utils_sampling_fill then reports precision 128 / 192; the shuffle / blinding fillers stay 64-bit only */
+int  sc_hip_sampler_create_hp(int precision_bits, float tail, float sigma, const uint64_t *h_cdf, int size, sc_hip_rng64_fn rng, void *rng_ctx, sc_hip_sampler_t **out);
 void sc_hip_sampler_set_rng(sc_hip_sampler_t *s, sc_hip_rng64_fn rng, void *rng_ctx);
 void sc_hip_sampler_destroy(sc_hip_sampler_t *s);
 
@@ -139,7 +143,7 @@ typedef struct __attribute__((__packed__)) sc_hip_utils_sampling {
     int32_t (*sample)(void *gauss);                                      /* utils_sampling_sample: one draw */
     int32_t (*vector_16)(const struct sc_hip_utils_sampling *, int16_t *v, size_t n, int32_t centre);
     int32_t (*vector_32)(const struct sc_hip_utils_sampling *, int32_t *v, size_t n, int32_t centre);
-    int32_t precision;                                                   /* sample_precision_e: 64 */
+    int32_t precision;                                                   /* sample_precision_e: 64 (128 / 192 behind sc_hip_sampler_create_hp) */
     int32_t dimension;
     int32_t bootstrapped;                                                /* SAMPLING_DISABLE_BOOTSTRAP */
     float   tail, sigma, sigma2;

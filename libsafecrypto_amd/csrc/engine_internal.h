@@ -364,4 +364,6 @@ struct sc_hip_cdt {
     uint16_t *d_guide;            // g.total bins (cdt_guide.h); g.S = 0: no usable guide, the kernels fall back to the halving search
     CdtGuide g;
     bool w32 = false;             // a 32-bit precision table widened to the 64-bit form (sc_hip_cdt32_*): searched with widened 32-bit words
+    int hp_words = 0;             // 2 / 3: a 128- / 192-bit precision sampler (sc_hip_cdt_hp_*): cdf holds the table's most significant limbs, hp_low the limbs below them (kept for sc_hip_cdt_hp_table only)
+    std::vector<uint64_t> hp_low;
 };

@@ -136,6 +136,32 @@ __global__ __launch_bounds__(256) void cdt_kernel(const uint64_t *__restrict__ c
     }
 }
 
+// 128- / 192-bit precision (gaussian_cdf_sample_128 / _192 over binary_search_128 / _192, gaussian_cdf.c:134-166,468-509): W = 2 / 3 prng_64 words a sample, limb 0
+// first; the sign is limb 0's bit 0; the search goes to b when "x >= entry b" by compare_ge_prec (:110-132) - whose loop over the limbs ends with the verdict of
+// the MOST SIGNIFICANT limb alone (retval = !(a < b) | (equal & retval): equality already makes the first term 1, so the limbs below never carry over).  So the
+// search is the 64-bit one on the top limbs with ">=" for "<" - and x >= e is e < x + 1: it rides on the guide of the 64-bit form with x + 1, the one word
+// without a successor (2^64 - 1, at or above every entry) answered directly: every step of the halving search is taken, the result is size - 1.
+template <int S, bool HALF>
+__global__ __launch_bounds__(256) void cdt_hp_kernel(const uint64_t *__restrict__ cdf, const uint16_t *__restrict__ gd, int size, CdtGuide g, const uint64_t *__restrict__ x, int W,
+                                                     int32_t *__restrict__ out, size_t count, int32_t centre)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
+    for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
+    if (!HALF) for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
+    __syncthreads();
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint64_t low = x[i * (size_t)W], top = x[i * (size_t)W + (size_t)(W - 1)];
+        const uint64_t u = top + 1;
+        uint32_t r;
+        if constexpr (!HALF) r = cdt_lookup<S>(u, tab, guide, g);
+        else { r = 0; for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = r + st; if (tab[b] < u) r = b; } }
+        if (top == ~0ull) r = (uint32_t)size - 1u;
+        out[i] = ((low & 1) ? (int32_t)r : -(int32_t)r) + centre;
+    }
+}
+
 // no usable guide (a table some bin of which holds more than 7 entries): the halving search itself
 __global__ __launch_bounds__(256) void cdt_halving_kernel(const uint64_t *__restrict__ cdf, int size, const uint64_t *__restrict__ x, int32_t *__restrict__ out, size_t count, int32_t centre)
 {
@@ -718,6 +744,7 @@ extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *
 {
     if (!c) return fail("cdt_sample: null sampler");
     if (c->w32) return fail("cdt_sample: the sampler was created at 32-bit precision (sc_hip_cdt32_sample takes its 32-bit words)");
+    if (c->hp_words) return fail("cdt_sample: the sampler was created at 128- / 192-bit precision (sc_hip_cdt_hp_sample takes its 2 / 3 words a sample)");
     if (count == 0) return SC_HIP_SUCCESS;
     if (!d_uniform || !d_out) return fail("cdt_sample: null device pointer");
     HIPCHK(hipSetDevice(c->ctx->device));
@@ -735,6 +762,62 @@ extern "C" int sc_hip_cdt_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *
     case 2: hipLaunchKernelGGL(cdt_kernel<2>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
     case 3: hipLaunchKernelGGL(cdt_kernel<3>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
     default: hipLaunchKernelGGL(cdt_kernel<0>, gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, d_out, count, centre); break;
+    }
+    HIPCHK(hipGetLastError());
+    return SC_HIP_SUCCESS;
+}
+
+// ---- the sampler at 128- / 192-bit precision over a caller-supplied table (create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_128BIT / _192BIT, ...): gaussian_cdf_sample_128 /
+// _192, src/utils/sampling/gaussian_cdf.c:110-184,468-509).  The table itself is MPFR arithmetic (gauss_cdf_create_high_precision, :186-330) and stays the caller's. ----
+extern "C" int sc_hip_cdt_hp_create_from_table(sc_hip_ctx_t *ctx, int precision_bits, const uint64_t *h_cdf, int size, sc_hip_cdt_t **out)
+{
+    if (!ctx || !h_cdf || !out) return fail("cdt_hp_create_from_table: null argument");
+    if (precision_bits == 256) return fail("cdt_hp_create_from_table: the reference's 256-bit sampler reads an uninitialised limb (gaussian_cdf.c:519-522): it has no defined result to reproduce");
+    if (precision_bits != 128 && precision_bits != 192) return fail("cdt_hp_create_from_table: precision must be 128 or 192 bits (64: sc_hip_cdt_create_from_table, 32: sc_hip_cdt32_*)");
+    if (size < 2 || size > 4096 || (size & (size - 1))) return fail("cdt_hp_create_from_table: size must be a power of two in 2..4096");
+    const int W = precision_bits / 64;
+    std::vector<uint64_t> top((size_t)size);
+    for (int i = 0; i < size; i++) top[(size_t)i] = h_cdf[(size_t)i * W + (W - 1)];
+    for (int i = 1; i < size; i++) if (top[(size_t)i] < top[(size_t)i - 1]) return fail("cdt_hp_create_from_table: the table's most significant limbs are not monotone");
+    if (sc_hip_cdt_create_from_table(ctx, top.data(), size, out) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    (*out)->hp_words = W;
+    (*out)->hp_low.resize((size_t)size * (W - 1));
+    for (int i = 0; i < size; i++) for (int j = 0; j < W - 1; j++) (*out)->hp_low[(size_t)i * (W - 1) + j] = h_cdf[(size_t)i * W + j];
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt_hp_precision(const sc_hip_cdt_t *c) { return c ? (c->hp_words ? 64 * c->hp_words : c->w32 ? 32 : 64) : 0; }
+extern "C" int sc_hip_cdt_hp_table(const sc_hip_cdt_t *c, uint64_t *h)
+{
+    if (!c || !h) return fail("cdt_hp_table: null argument");
+    if (!c->hp_words) return fail("cdt_hp_table: not a 128- / 192-bit sampler");
+    const int W = c->hp_words;
+    for (int i = 0; i < c->size; i++) {
+        for (int j = 0; j < W - 1; j++) h[(size_t)i * W + j] = c->hp_low[(size_t)i * (W - 1) + j];
+        h[(size_t)i * W + (W - 1)] = c->cdf[(size_t)i];
+    }
+    return SC_HIP_SUCCESS;
+}
+extern "C" int sc_hip_cdt_hp_sample(sc_hip_cdt_t *c, size_t count, const uint64_t *d_uniform, int32_t centre, int32_t *d_out, void *stream)
+{
+    if (!c) return fail("cdt_hp_sample: null sampler");
+    if (!c->hp_words) return fail("cdt_hp_sample: the sampler was not created by sc_hip_cdt_hp_create_from_table");
+    if (count == 0) return SC_HIP_SUCCESS;
+    if (!d_uniform || !d_out) return fail("cdt_hp_sample: null device pointer");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    size_t blocks = (count + 256 * 32 - 1) / (256 * 32);
+    if (blocks == 0) blocks = 1;
+    const size_t lds = sc::cdt_lds_bytes(c);
+    const size_t per_cu = lds ? (size_t)(160 * 1024) / lds : 8;
+    const size_t cap = (size_t)c->ctx->cus * (per_cu > 8 ? 8 : (per_cu ? per_cu : 1));
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gr((unsigned)blocks), bl(256);
+    switch (c->g.S) {
+    case 0: hipLaunchKernelGGL((cdt_hp_kernel<0, true>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, c->hp_words, d_out, count, centre); break;
+    case 1: hipLaunchKernelGGL((cdt_hp_kernel<1, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, c->hp_words, d_out, count, centre); break;
+    case 2: hipLaunchKernelGGL((cdt_hp_kernel<2, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, c->hp_words, d_out, count, centre); break;
+    case 3: hipLaunchKernelGGL((cdt_hp_kernel<3, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, c->hp_words, d_out, count, centre); break;
+    default: hipLaunchKernelGGL((cdt_hp_kernel<0, false>), gr, bl, lds, s, c->d_cdf, c->d_guide, c->size, c->g, d_uniform, c->hp_words, d_out, count, centre); break;
     }
     HIPCHK(hipGetLastError());
     return SC_HIP_SUCCESS;
@@ -884,6 +967,25 @@ extern "C" int sc_hip_cdt_sample_host(sc_hip_cdt_t *c, size_t count, const uint6
     if (hipMalloc(&dv, count * 4) != hipSuccess || sc::copy_in(dx, h_uniform, count * 8) != hipSuccess) rc = fail("cdt_sample_host: H2D failed");
     if (rc == SC_HIP_SUCCESS) rc = sc_hip_cdt_sample(c, count, dx, centre, dv, nullptr);
     if (rc == SC_HIP_SUCCESS && sc::copy_out(h_out, dv, count * 4) != hipSuccess) rc = fail("cdt_sample_host: D2H failed");
+    (void)sc::wipe_free(dx);
+    if (dv) (void)sc::wipe_free(dv);
+    return rc;
+}
+
+extern "C" int sc_hip_cdt_hp_sample_host(sc_hip_cdt_t *c, size_t count, const uint64_t *h_uniform, int32_t centre, int32_t *h_out)
+{
+    if (!c) return fail("cdt_hp_sample_host: null sampler");
+    if (!c->hp_words) return fail("cdt_hp_sample_host: the sampler was not created by sc_hip_cdt_hp_create_from_table");
+    if (count == 0) return SC_HIP_SUCCESS;
+    if (!h_uniform || !h_out) return fail("cdt_hp_sample_host: null host pointer");
+    HIPCHK(hipSetDevice(c->ctx->device));
+    const size_t xb = count * 8 * (size_t)c->hp_words;
+    uint64_t *dx = nullptr; int32_t *dv = nullptr;
+    HIPCHK(hipMalloc(&dx, xb));
+    int rc = SC_HIP_SUCCESS;
+    if (hipMalloc(&dv, count * 4) != hipSuccess || sc::copy_in(dx, h_uniform, xb) != hipSuccess) rc = fail("cdt_hp_sample_host: H2D failed");
+    if (rc == SC_HIP_SUCCESS) rc = sc_hip_cdt_hp_sample(c, count, dx, centre, dv, nullptr);
+    if (rc == SC_HIP_SUCCESS && sc::copy_out(h_out, dv, count * 4) != hipSuccess) rc = fail("cdt_hp_sample_host: D2H failed");
     (void)sc::wipe_free(dx);
     if (dv) (void)sc::wipe_free(dv);
     return rc;

@@ -298,6 +298,7 @@ struct sc_hip_sampler {
     sc_hip_rng32_fn rng32 = nullptr;
     float tail, sigma;
     std::vector<uint64_t> words;
+    int hp_words = 0;             // 2 / 3: a 128- / 192-bit sampler (sc_hip_sampler_create_hp)
 };
 
 extern "C" int sc_hip_sampler_create(float tail, float sigma, const uint64_t *h_cdf, int size, sc_hip_rng64_fn rng, void *rng_ctx, sc_hip_sampler_t **out)
@@ -310,6 +311,20 @@ extern "C" int sc_hip_sampler_create(float tail, float sigma, const uint64_t *h_
     if (rc != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
     sc_hip_sampler *s = new sc_hip_sampler;
     s->dev = b.dev; s->cdt = cdt; s->rng = rng; s->rng_ctx = rng_ctx; s->tail = tail; s->sigma = sigma;
+    *out = s;
+    return SC_HIP_SUCCESS;
+}
+// the same object at 128- / 192-bit precision (create_sampler(..., SAMPLING_128BIT / SAMPLING_192BIT, ...)): the caller's table ([size][precision / 64] limbs), precision / 64
+// draws of the generator per sample (gaussian_cdf.c:482-483,498-500)
+extern "C" int sc_hip_sampler_create_hp(int precision_bits, float tail, float sigma, const uint64_t *h_cdf, int size, sc_hip_rng64_fn rng, void *rng_ctx, sc_hip_sampler_t **out)
+{
+    if (!rng || !out || !h_cdf) return sc::fail("sampler_create_hp: null argument (the table of a 128- / 192-bit sampler is the caller's: it is MPFR arithmetic)");
+    Bound b;
+    if (!ensure_ctx(b.s, b.dev)) return SC_HIP_FAILURE;
+    sc_hip_cdt_t *cdt = nullptr;
+    if (sc_hip_cdt_hp_create_from_table(b.s.ctx, precision_bits, h_cdf, size, &cdt) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    sc_hip_sampler *s = new sc_hip_sampler;
+    s->dev = b.dev; s->cdt = cdt; s->rng = rng; s->rng_ctx = rng_ctx; s->tail = tail; s->sigma = sigma; s->hp_words = precision_bits / 64;
     *out = s;
     return SC_HIP_SUCCESS;
 }
@@ -328,10 +343,11 @@ int sampler_vector(sc_hip_sampler *s, int32_t *v, size_t n, int32_t centre)
 {
     if (!s || !v) return sc::fail("sampler: null argument");
     if (n == 0) return SC_HIP_SUCCESS;
-    s->words.resize(n);
-    for (size_t i = 0; i < n; i++) s->words[i] = s->rng(s->rng_ctx);
+    const size_t per = s->hp_words ? (size_t)s->hp_words : 1;
+    s->words.resize(n * per);
+    for (size_t i = 0; i < n * per; i++) s->words[i] = s->rng(s->rng_ctx);
     std::lock_guard<std::mutex> lk(g_dev[s->dev].mu);
-    return sc_hip_cdt_sample_host(s->cdt, n, s->words.data(), centre, v);
+    return s->hp_words ? sc_hip_cdt_hp_sample_host(s->cdt, n, s->words.data(), centre, v) : sc_hip_cdt_sample_host(s->cdt, n, s->words.data(), centre, v);
 }
 int32_t sm_destroy(void **gauss) { if (gauss && *gauss) { sc_hip_sampler_destroy((sc_hip_sampler *)*gauss); *gauss = nullptr; } return 0; }
 int32_t sm_sample(void *gauss)
@@ -348,6 +364,7 @@ int sampler_vector_sca(sc_hip_sampler *s, int32_t *v, size_t n, int32_t centre, 
 {
     if (!s || !v) return sc::fail("sampler: null argument");
     if (n == 0) return SC_HIP_SUCCESS;
+    if (s->hp_words) return sc::fail("sampler: shuffle / blinding / sample discarding are served at 64-bit precision only");
     if (discard != 0 && discard != 2 && discard != 4 && discard != 6) return sc::fail("sampler: discard must be 0 or SCA_PATTERN_SAMPLE_DISCARD_LO / MD / HI (2 / 4 / 6)");
     if ((discard != 0 || blinding != 0) && !s->rng32)
         return sc::fail("sampler: shuffle / blinding / sample discarding draw prng_32 words between the samples: give the sampler the generator's prng_32 (sc_hip_sampler_set_rng32)");
@@ -415,7 +432,7 @@ extern "C" int sc_hip_utils_sampling_fill(sc_hip_utils_sampling_t *dst, sc_hip_s
     if (!dst || !s) return sc::fail("utils_sampling_fill: null argument");
     memset(dst, 0, sizeof *dst);
     dst->destroy = sm_destroy; dst->sample = sm_sample; dst->vector_16 = sm_vector_16; dst->vector_32 = sm_vector_32;
-    dst->precision = 64; dst->dimension = 0; dst->bootstrapped = 0;
+    dst->precision = s->hp_words ? 64 * s->hp_words : 64; dst->dimension = 0; dst->bootstrapped = 0;
     dst->tail = s->tail; dst->sigma = s->sigma; dst->sigma2 = 0.f;
     dst->gauss = s; dst->prng_ctx = s->rng_ctx; dst->discard = 0; dst->bootstrap = nullptr;
     return SC_HIP_SUCCESS;
@@ -424,6 +441,7 @@ extern "C" int sc_hip_utils_sampling_fill(sc_hip_utils_sampling_t *dst, sc_hip_s
 extern "C" int sc_hip_utils_sampling_fill_sca(sc_hip_utils_sampling_t *dst, sc_hip_sampler_t *s, int blinding)
 {
     if (blinding < 0 || blinding > 2) return sc::fail("utils_sampling_fill_sca: blinding must be 0 (NORMAL_SAMPLES), 1 (BLINDING_SAMPLES) or 2 (SHUFFLE_SAMPLES)");
+    if (s && s->hp_words && blinding) return sc::fail("utils_sampling_fill_sca: the shuffle / blinding fillers are served at 64-bit precision only");
     if (sc_hip_utils_sampling_fill(dst, s) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
     if (blinding == 1) { dst->vector_32 = sm_vector_32_t<1>; dst->vector_16 = sm_vector_16_t<1>; }
     else if (blinding == 2) { dst->vector_32 = sm_vector_32_t<2>; dst->vector_16 = sm_vector_16_t<2>; }

@@ -29,7 +29,7 @@ SYMBOLS = [
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
     'sc_hip_poly_mul_scalar', 'sc_hip_poly_mod_negate', 'sc_hip_poly_add_scalar', 'sc_hip_poly_cmp_not_equal',
     'sc_hip_vec_absmax', 'sc_hip_vec_scalar', 'sc_hip_ntt_invert_host', 'sc_hip_ntt_div_host', 'sc_hip_mult_sparse_host',
-    'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix', 'sc_hip_mlwe_expand_matrix_xof', 'sc_hip_mlwe_sample_xof',
+    'sc_hip_drbg_mem', 'sc_hip_drbg_words', 'sc_hip_mlwe_expand_matrix', 'sc_hip_mlwe_expand_matrix_xof', 'sc_hip_mlwe_sample_xof', 'sc_hip_cdt_hp_create_from_table', 'sc_hip_cdt_hp_precision', 'sc_hip_cdt_hp_table', 'sc_hip_cdt_hp_sample', 'sc_hip_cdt_hp_sample_host',
     'sc_hip_tesla_create', 'sc_hip_tesla_destroy', 'sc_hip_tesla_set_key', 'sc_hip_tesla_sig_bytes', 'sc_hip_tesla_sign', 'sc_hip_tesla_sign_seeded', 'sc_hip_tesla_verify',
     'sc_hip_rlwe_create', 'sc_hip_rlwe_destroy', 'sc_hip_rlwe_set_pubkey', 'sc_hip_rlwe_set_privkey', 'sc_hip_rlwe_msg_bytes', 'sc_hip_rlwe_ct_bytes',
     'sc_hip_poly_uniform', 'sc_hip_dlp_ibe_extract', 'sc_hip_ens_dlp_sig_verify', 'sc_hip_ens_dlp_signer_create', 'sc_hip_ens_dlp_signer_destroy', 'sc_hip_ens_dlp_signer_set_key', 'sc_hip_ens_dlp_signer_set_privkey', 'sc_hip_ens_dlp_signer_set_mapping',
@@ -51,7 +51,7 @@ SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
 BENCH_SYMBOLS = ['sc_hip_bench_set_host_pin', 'sc_hip_bench_set_ntt_stream', 'sc_hip_dilithium_workspace_residue', 'sc_hip_falcon_workspace_residue', 'sc_hip_polymul_ntt_steps', 'sc_hip_time_op', 'sc_hip_shake_host', 'sc_hip_falcon_sample_profile', 'sc_hip_falcon_set_variant', 'sc_hip_dilithium_set_tuning', 'sc_hip_dilithium_fin_tables_host', 'sc_hip_cdt_guide_host', 'sc_hip_bliss_set_speculation', 'sc_hip_rlwe_set_arith']
 # include/sc_hip_vtable.h
-VTABLE_SYMBOLS = ['sc_hip_sampler_set_rng32', 'sc_hip_utils_sampling_fill_sca', 'sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
+VTABLE_SYMBOLS = ['sc_hip_sampler_create_hp', 'sc_hip_sampler_set_rng32', 'sc_hip_utils_sampling_fill_sca', 'sc_hip_utils_arith_ntt32', 'sc_hip_vtable_errors', 'sc_hip_utils_arith_ntt_fill', 'sc_hip_utils_arith_poly_fill', 'sc_hip_utils_arith_vec_fill',
                   'sc_hip_sampler_create', 'sc_hip_sampler_set_rng', 'sc_hip_sampler_destroy', 'sc_hip_utils_sampling_fill', 'sc_hip_vtable_bind_device']
 
 
@@ -260,6 +260,10 @@ def load_library(path=LIB_PATH):
     L.sc_hip_rlwe_decrypt.argtypes = [vp, sz, vp, sz, vp, sz, vp]
     L.sc_hip_rlwe_keygen.argtypes = [vp, sz, vp, sz, vp, vp, vp, vp]
     L.sc_hip_mlwe_expand_matrix.argtypes = [vp, sz, vp, sz, sz, C.c_int, i32, C.c_int, vp, vp]
+    L.sc_hip_cdt_hp_create_from_table.argtypes = [vp, C.c_int, vp, C.c_int, C.POINTER(vp)]
+    L.sc_hip_cdt_hp_precision.argtypes = [vp]
+    L.sc_hip_cdt_hp_table.argtypes = [vp, vp]
+    L.sc_hip_cdt_hp_sample.argtypes = [vp, sz, vp, i32, vp, vp]
     L.sc_hip_mlwe_expand_matrix_xof.argtypes = [vp, sz, vp, sz, sz, C.c_int, sz, C.c_int, C.c_int, i32, C.c_int, vp, vp]
     L.sc_hip_mlwe_sample_xof.argtypes = [vp, C.c_int, sz, vp, sz, sz, C.c_int, sz, i32, C.c_int, sz, vp, sz, C.POINTER(C.c_size_t), vp]
     L.sc_hip_drbg_mem.argtypes = [vp, sz, vp, sz, sz, vp, sz, sz, vp]
@@ -635,6 +639,9 @@ class Engine:
     def sampler32(self, tail=None, sigma=None, table=None):
         return CdtSampler32(self, tail, sigma, table)
 
+    def sampler_hp(self, precision_bits, table):
+        return CdtSamplerHp(self, precision_bits, table)
+
     def synchronize(self):
         _chk(self.L, self.L.sc_hip_synchronize(self.h, _stream()), 'sc_hip_synchronize')
 
@@ -962,6 +969,41 @@ class CdtSampler32:
         assert uniform.element_size() == 4 and uniform.is_contiguous()
         out = torch.empty(uniform.numel(), dtype=torch.int32, device=uniform.device) if out is None else out
         _chk(self.L, self.L.sc_hip_cdt32_sample(self.h, uniform.numel(), _ptr(uniform), centre, _ptr(out), _stream()), 'cdt32_sample')
+        return out
+
+
+class CdtSamplerHp:
+    """create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_128BIT / SAMPLING_192BIT, ...) counterpart over the caller's table: uint64 [size][precision / 64] limbs, least
+    significant first; precision / 64 64-bit words per sample (limb 0 first)."""
+
+    def __init__(self, eng, precision_bits, table):
+        import numpy as np
+        self.eng, self.L, self.words = eng, eng.L, int(precision_bits) // 64
+        t = np.ascontiguousarray(table, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(self.L, self.L.sc_hip_cdt_hp_create_from_table(eng.h, int(precision_bits), _ptr(t), t.size // max(self.words, 1), C.byref(h)), 'sc_hip_cdt_hp_create_from_table')
+        self.h = h
+        self.size = self.L.sc_hip_cdt_size(h)
+        self.precision = self.L.sc_hip_cdt_hp_precision(h)
+
+    def close(self):
+        if self.h:
+            self.L.sc_hip_cdt_destroy(self.h)
+            self.h = None
+
+    def table(self):
+        import numpy as np
+        t = np.empty((self.size, self.words), dtype=np.uint64)
+        _chk(self.L, self.L.sc_hip_cdt_hp_table(self.h, _ptr(t)), 'cdt_hp_table')
+        return t
+
+    def sample(self, uniform, centre=0, out=None):
+        """uniform: int64 device tensor [count][words] holding the u64 draws bit-for-bit"""
+        import torch
+        assert uniform.element_size() == 8 and uniform.is_contiguous() and uniform.numel() % self.words == 0
+        n = uniform.numel() // self.words
+        out = torch.empty(n, dtype=torch.int32, device=uniform.device) if out is None else out
+        _chk(self.L, self.L.sc_hip_cdt_hp_sample(self.h, n, _ptr(uniform), centre, _ptr(out), _stream()), 'cdt_hp_sample')
         return out
 
 

@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -315,6 +315,82 @@ static int gen_cdt32(const char *dir)
     rc |= cdt32_case(f, 13.42f, 215.0f, 2048, "bliss1_s215_t13.42");
     rc |= cdt32_case(f, 12.0f, 100.0f, 1024, "unit_s100_t12");
     rc |= cdt32_case(f, 10.0f, 1.7f, 512, "leaf_s1.7_t10");
+    fclose(f);
+    return rc;
+}
+
+/* The samplers at 128- and 192-bit precision (SAMPLING_128BIT / _192BIT: gaussian_cdf_sample_128 / _192 over binary_search_128 / _192 and compare_ge_prec,
+ * src/utils/sampling/gaussian_cdf.c:110-184,468-509).  Their TABLES are MPFR arithmetic the hand build does not have (sc_mpf_exp and sc_mpf_get_pi are empty
+ * under USE_SAFECRYPTO_FLOAT_MP, sc_mpf.c:99-106,822-828): create_sampler returns a context whose table is noise.  The SEARCH is plain C and is what a
+ * batched engine serves - so the table of the context the reference made is REPLACED here by a table of known content and the reference's own
+ * get_vector_32 (-> gaussian_cdf_sample_128 / _192) is run over it: the fixture pins the search, the limb order of the draws and the sign rule, on
+ *   most significant limb = the 64-bit table of the same (tail, sigma) (gaussian_cdf_create_64: monotone, ends in a run of equal entries),
+ *   lower limbs            = noise (so that it shows whether they take part in the comparison),
+ * with a handful of entries set equal, in the most significant limb, to words the sampler is about to draw (ties: "x >= entry", not "entry < x") and
+ * the limbs below them set just above / just below the drawn ones. */
+typedef struct __attribute__((packed)) { UINT64 *cdf_256, *cdf_192, *cdf_128; SINT32 cdf_size; } cdfhp_view_t;   /* gaussian_cdf.c:59-68 */
+static int cdt_hp_case(FILE *f, int prec, float tail, float sigma, int nsamp, const char *tag)
+{
+    static const uint8_t seed[32] = { 1, 4, 1, 4, 2, 1, 3, 5, 6, 2, 3, 7, 3, 0, 9, 5, 0, 4, 8, 8, 0, 1, 6, 8, 8, 7, 2, 4, 2, 0, 9, 6 };
+    char name[96];
+    uint8_t sd[32];
+    memcpy(sd, seed, 32); sd[0] = (uint8_t)prec; sd[1] = (uint8_t)nsamp;
+    const int W = prec / 64;
+    prng_ctx_t *p1 = seeded_prng(sd, 32), *p2 = seeded_prng(sd, 32), *p3 = seeded_prng(sd, 32);
+    utils_sampling_t *s64 = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, NORMAL_SAMPLES, 512, SAMPLING_DISABLE_BOOTSTRAP, p3, tail, sigma);
+    utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, prec == 128 ? SAMPLING_128BIT : SAMPLING_192BIT, NORMAL_SAMPLES, 512,
+                                         SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
+    if (!s || !s64) return 1;
+    const cdf64_view_t *g64 = (const cdf64_view_t *)s64->gauss;
+    const cdfhp_view_t *g = (const cdfhp_view_t *)s->gauss;
+    const int size = g->cdf_size;
+    if (size != g64->cdf_size || size < 2) { fprintf(stderr, "cdt_hp: table sizes differ (%d, %d)\n", size, g64->cdf_size); return 1; }
+    UINT64 *tab = prec == 128 ? g->cdf_128 : g->cdf_192;                       /* [size][W] limbs, least significant first */
+    /* the words the sampler is about to draw: W prng_64 a sample, limb 0 first (gaussian_cdf.c:482-483,498-500) */
+    uint64_t *x = malloc(sizeof(uint64_t) * (size_t)nsamp * W);
+    for (int i = 0; i < nsamp * W; i++) x[i] = prng_64(p2);
+    sm_state = 0x6870000000000000ULL + (uint64_t)prec * 65536 + (uint64_t)size;
+    for (int b = 0; b < size; b++) {
+        for (int j = 0; j < W - 1; j++) tab[(size_t)b * W + j] = splitmix64();
+        tab[(size_t)b * W + W - 1] = g64->cdf[b];
+    }
+    /* ties: for every 16th sample (while the table stays monotone) the entry just above the word takes the word's most significant limb */
+    int ties = 0;
+    for (int i = 0; i < nsamp; i += 16) {
+        const uint64_t top = x[(size_t)i * W + W - 1];
+        int a = 0;
+        for (int st = size >> 1; st > 0; st >>= 1) { const int b = a + st; if (b < size && tab[(size_t)b * W + W - 1] < top) a = b; }
+        const int b = a + 1;
+        if (b >= size || tab[(size_t)b * W + W - 1] == top) continue;
+        if (b + 1 < size && tab[(size_t)(b + 1) * W + W - 1] < top) continue;
+        tab[(size_t)b * W + W - 1] = top;
+        /* the limbs below: alternately just above and just below the word's (a full-width comparison would decide differently in the two cases) */
+        for (int j = 0; j < W - 1; j++) tab[(size_t)b * W + j] = x[(size_t)i * W + j] + ((ties & 1) ? (uint64_t)-1 : 1);
+        ties++;
+    }
+    int32_t par[4] = { prec, size, nsamp, ties };
+    snprintf(name, sizeof name, "%s_par", tag); rec_i32(f, name, par, 4);
+    snprintf(name, sizeof name, "%s_table", tag); rec_u64(f, name, tab, (size_t)size * W);
+    snprintf(name, sizeof name, "%s_words", tag); rec_u64(f, name, x, (size_t)nsamp * W);
+    int32_t *v = malloc(sizeof(int32_t) * nsamp);
+    get_vector_32(s, v, nsamp, 0);
+    snprintf(name, sizeof name, "%s_samples", tag); rec_i32(f, name, v, nsamp);
+    free(x); free(v);
+    destroy_sampler(&s); destroy_sampler(&s64);
+    prng_destroy(p1); prng_destroy(p2); prng_destroy(p3);
+    return 0;
+}
+static int gen_cdt_hp(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/cdt_hp_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = 0;
+    rc |= cdt_hp_case(f, 128, 13.42f, 215.0f, 2048, "hp128_bliss1_s215_t13.42");      /* what the reference's BLISS-B harness asks for: func_alg_bliss_b.c:118 */
+    rc |= cdt_hp_case(f, 192, 13.42f, 215.0f, 1024, "hp192_bliss1_s215_t13.42");
+    rc |= cdt_hp_case(f, 128, 12.0f, 3.33f, 512, "hp128_unit_s3.33_t12");              /* src/unit/unit_sampling.c:44 */
+    rc |= cdt_hp_case(f, 192, 10.0f, 1.7f, 512, "hp192_leaf_s1.7_t10");
     fclose(f);
     return rc;
 }
@@ -1910,7 +1986,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) { fixed_domain("ntt"); rc |= gen_ntt(argv[2]); }
     if (all || !strcmp(argv[1], "ntt_large")) { fixed_domain("ntt_large"); rc |= gen_ntt_large(argv[2]); }
@@ -1933,5 +2009,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "ensdlp")) { fixed_domain("ensdlp"); rc |= gen_ensdlp(argv[2]); }
     if (all || !strcmp(argv[1], "ensdlp_rec")) { fixed_domain("ensdlp_rec"); rc |= gen_ensdlp_rec(argv[2]); }
     if (all || !strcmp(argv[1], "mlwe_xof")) { fixed_domain("mlwe_xof"); rc |= gen_mlwe_xof(argv[2]); }
+    if (all || !strcmp(argv[1], "cdt_hp")) { fixed_domain("cdt_hp"); rc |= gen_cdt_hp(argv[2]); }
     return rc;
 }

@@ -440,3 +440,32 @@ int orc_poly_uniform(int32_t *v, int n, const uint16_t *c, int c_len, const uint
     *consumed = pos;
     return 0;
 }
+
+/* gaussian_cdf_sample_128 / _192 (src/utils/sampling/gaussian_cdf.c:468-509) over binary_search_128 / _192 (:134-166) and compare_ge_prec (:110-132), for 64-bit limbs:
+ * x = W words in the order the sampler draws them (limb 0 first), tab = [size][W] limbs, least significant first.  compare_ge_prec is restated as it is written -
+ * a loop from the least to the most significant limb with retval = !(a < b) | (equal & retval) - not as what it amounts to (the top limb's ">=" alone:
+ * tests/test_oracle_cdt_hp.py shows the two agree and that a full-width comparison does not). */
+static int orc_compare_ge_prec(const uint64_t *x, const uint64_t *y, int words)
+{
+    uint64_t retval = 1;
+    for (int i = 0; i < words; i++) {
+        const uint64_t a = x[i], b = y[i];
+        const uint64_t equal = !(a ^ b);
+        const uint64_t x_lt_y = a < b;
+        retval = !x_lt_y | (equal & retval);
+    }
+    return (int)retval;
+}
+int32_t orc_cdt_hp_sample(const uint64_t *x, const uint64_t *tab, int size, int words)
+{
+    uint32_t a = 0;
+    for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) {
+        const uint32_t b = a + st;
+        if (b < (uint32_t)size && orc_compare_ge_prec(x, tab + (size_t)b * words, words)) a = b;
+    }
+    return (x[0] & 1) ? (int32_t)a : -(int32_t)a;
+}
+void orc_cdt_hp_sample_vector(int32_t *v, size_t n, const uint64_t *x, const uint64_t *tab, int size, int words, int32_t centre)
+{
+    for (size_t i = 0; i < n; i++) v[i] = orc_cdt_hp_sample(x + i * (size_t)words, tab, size, words) + centre;
+}

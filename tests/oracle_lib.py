@@ -773,3 +773,11 @@ def rand_product_xof(shake_bits, seed, skip, q, q_bits, k, l, transposed, y, n=2
     pos = L.orc_rand_product_xof(a[0], a[1], a[2], a[3], C.c_int32(int(q)), int(q_bits), int(k), int(l), 1 if transposed else 0,
                                  yy.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), int(n), w.ctypes.data_as(C.c_void_p), r.ctypes.data_as(C.c_void_p), int(width))
     return t, int(pos)
+
+
+def cdt_hp_sample(x, tab, words, centre=0):
+    """x uint64 [n][words] (limb 0 first), tab uint64 [size][words] -> int32 [n]: gaussian_cdf_sample_128 / _192 as the reference computes them"""
+    xx = np.ascontiguousarray(np.asarray(x, dtype=np.uint64).reshape(-1, words)); tt = np.ascontiguousarray(np.asarray(tab, dtype=np.uint64).reshape(-1, words))
+    v = np.zeros(xx.shape[0], dtype=np.int32)
+    lib().orc_cdt_hp_sample_vector(v.ctypes.data_as(C.c_void_p), C.c_size_t(xx.shape[0]), xx.ctypes.data_as(C.c_void_p), tt.ctypes.data_as(C.c_void_p), int(tt.shape[0]), int(words), C.c_int32(int(centre)))
+    return v
