@@ -8,7 +8,7 @@
  * create_sampler()/get_vector_32() src/utils/sampling/sampling.c:425,556) and dumps
  * seeded inputs + the reference's outputs as small text fixtures for tests/golden/.
  *
- * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|all> <outdir>
+ * Usage: ref_driver <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|bliss_hp|all> <outdir>
  *        ref_driver bench <q> <n> <seconds>      (single-thread CPU baseline of the reference)
  *        ref_driver bench_kyber <set> <seconds>  (single-thread safecrypto_encapsulation / safecrypto_decapsulation)
  *        ref_driver bench_ens <set> <seconds>    (the same for ENS-KEM)
@@ -649,6 +649,102 @@ static int bliss_case(FILE *f, int set, int nmsg, int huffman)
     free(trials); free(verdicts);
     safecrypto_destroy(sc);
     return 0;
+}
+
+/* BLISS-B signing with the sampler at 128- / 192-bit precision - what the reference's own harness asks for (test/functional/func_alg_bliss_b.c:118:
+ * SC_FLAG_0_SAMPLE_CDF | SC_FLAG_0_SAMPLE_128BIT).  In this build the context's table is noise (no MPFR: cdt_hp_case above), so it is replaced right after creation by
+ * one of known content - most significant limbs = the 64-bit table of the set's (tail, sigma), the limbs below = noise - and recorded; everything else is bliss_case:
+ * a fresh seeded generator per message, its twin read as the tape (a sample now takes precision / 64 prng_64 draws, i.e. 4 or 6 tape words). */
+typedef struct __attribute__((packed)) { UINT64 *cdf_256, *cdf_192, *cdf_128; SINT32 cdf_size; SINT32 k; SINT32 use_kl; prng_ctx_t *prng_ctx; } cdfhp_full_view_t;
+static int bliss_hp_case(FILE *f, int set, int nmsg, int prec)
+{
+    UINT32 flags[2] = { SC_FLAG_0_SAMPLE_CDF | (prec == 128 ? SC_FLAG_0_SAMPLE_128BIT : SC_FLAG_0_SAMPLE_192BIT) | SC_FLAG_MORE, SC_FLAG_NONE };
+    char name[96], tag[32];
+    snprintf(tag, sizeof tag, "blisshp%d_%d", prec, set);
+    safecrypto_t *sc = create_fixed(SC_SCHEME_SIG_BLISS, set, flags);
+    if (!sc) return 1;
+    if (!sc->sc_gauss || (int)sc->sc_gauss->precision != prec) { fprintf(stderr, "bliss_hp: the context's sampler is not %d-bit\n", prec); return 1; }
+    const bliss_set_t *P = sc->bliss->params;
+    const int n = P->n, W = prec / 64;
+    cdfhp_full_view_t *g = (cdfhp_full_view_t *)sc->sc_gauss->gauss;
+    {
+        static const uint8_t sd[32] = { 9, 9, 1 };
+        prng_ctx_t *p3 = seeded_prng(sd, 32);
+        utils_sampling_t *s64 = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, NORMAL_SAMPLES, 512, SAMPLING_DISABLE_BOOTSTRAP, p3, 13.42f, P->sig);
+        if (!s64) return 1;
+        const cdf64_view_t *g64 = (const cdf64_view_t *)s64->gauss;
+        if (g64->cdf_size != g->cdf_size) { fprintf(stderr, "bliss_hp: table sizes differ\n"); return 1; }
+        UINT64 *tab = prec == 128 ? g->cdf_128 : g->cdf_192;
+        sm_state = 0xb1155480ULL + (uint64_t)prec + set;
+        for (int b = 0; b < g->cdf_size; b++) {
+            for (int j = 0; j < W - 1; j++) tab[(size_t)b * W + j] = splitmix64();
+            tab[(size_t)b * W + W - 1] = g64->cdf[b];
+        }
+        snprintf(name, sizeof name, "%s_table", tag); rec_u64(f, name, tab, (size_t)g->cdf_size * W);
+        destroy_sampler(&s64); prng_destroy(p3);
+    }
+    if (SC_FUNC_SUCCESS != safecrypto_keygen(sc)) return 1;
+    int32_t par[16] = { P->n, P->q, P->q_bits, P->n_bits, P->d, P->p, P->kappa, P->b_inf, (int32_t)P->b_l2, P->z1_bits, P->z2_bits, set, 0, 0, 0, 0 };
+    float fl[3] = { P->sig, P->m, 13.42f };
+    memcpy(&par[12], fl, 12);
+    snprintf(name, sizeof name, "%s_params", tag); rec_i32(f, name, par, 16);
+    { int32_t pr[2] = { prec, g->cdf_size }; snprintf(name, sizeof name, "%s_precision", tag); rec_i32(f, name, pr, 2); }
+    snprintf(name, sizeof name, "%s_f", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key, n);
+    snprintf(name, sizeof name, "%s_g", tag); rec_i16(f, name, (const int16_t *)sc->privkey->key + n, n);
+    snprintf(name, sizeof name, "%s_a", tag); rec_i16(f, name, (const int16_t *)sc->pubkey->key, n);
+    int32_t *trials = malloc(sizeof(int32_t) * nmsg), *verdicts = malloc(sizeof(int32_t) * nmsg * 2);
+    prng_ctx_t *orig = sc->prng_ctx[0];
+    sm_state = 0xb1155900ULL + (uint64_t)prec * 16 + set;
+    int kept = 0, long_ones = 0;
+    for (int cand = 0; cand < 4000 && kept < nmsg; cand++) {
+        uint8_t msg[96], seed[32];
+        size_t mlen = (cand == 0) ? 1 : (cand == 1) ? 96 : 64;
+        for (size_t i = 0; i < mlen; i++) msg[i] = (uint8_t)splitmix64();
+        for (int i = 0; i < 32; i++) seed[i] = (uint8_t)splitmix64();
+        prng_ctx_t *mine = seeded_prng(seed, 32), *twin = seeded_prng(seed, 32);
+        sc->prng_ctx[0] = mine; sc->sc_gauss->prng_ctx = mine; g->prng_ctx = mine;
+        uint8_t *sig = NULL; size_t siglen = 0;
+        size_t before = sc->stats.sig_num_trials;
+        if (SC_FUNC_SUCCESS != safecrypto_sign(sc, msg, mlen, &sig, &siglen)) return 1;
+        const int tr = (int)(sc->stats.sig_num_trials - before);
+        const int keep = (kept < nmsg - 2) || (tr >= 3 && long_ones < 2);
+        if (keep) {
+            const int m = kept++;
+            if (tr >= 3 && m >= nmsg - 2) long_ones++;
+            trials[m] = tr;
+            const size_t words = (size_t)(prng_get_out_bytes(mine) / 4);
+            int32_t *tape = malloc(sizeof(int32_t) * words);
+            for (size_t i = 0; i < words; i++) tape[i] = (int32_t)prng_32(twin);
+            snprintf(name, sizeof name, "%s_msg%d", tag, m); rec_u8(f, name, msg, mlen);
+            snprintf(name, sizeof name, "%s_tape%d", tag, m); rec_i32(f, name, tape, words);
+            snprintf(name, sizeof name, "%s_sig%d", tag, m); rec_u8(f, name, sig, siglen);
+            verdicts[2 * m] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+            sig[siglen / 3] ^= 0x04;
+            verdicts[2 * m + 1] = safecrypto_verify(sc, msg, mlen, sig, siglen);
+            free(tape);
+        }
+        free(sig);
+        sc->prng_ctx[0] = orig; sc->sc_gauss->prng_ctx = orig; g->prng_ctx = orig;
+        prng_destroy(mine); prng_destroy(twin);
+    }
+    if (kept != nmsg) return 1;
+    snprintf(name, sizeof name, "%s_trials", tag); rec_i32(f, name, trials, nmsg);
+    snprintf(name, sizeof name, "%s_verify", tag); rec_i32(f, name, verdicts, (size_t)nmsg * 2);
+    free(trials); free(verdicts);
+    safecrypto_destroy(sc);
+    return 0;
+}
+static int gen_bliss_hp(const char *dir)
+{
+    char path[512];
+    snprintf(path, sizeof path, "%s/bliss_hp_ref.txt", dir);
+    FILE *f = fopen(path, "w");
+    if (!f) return 1;
+    int rc = bliss_hp_case(f, 1, 7, 128);                              /* BLISS-B-I, the harness's configuration */
+    rc |= bliss_hp_case(f, 1, 3, 192);
+    rc |= bliss_hp_case(f, 4, 3, 128);
+    fclose(f);
+    return rc;
 }
 
 /* bliss_b_keygen (bliss_b.c:1124-1264) draws g, then f until NTT(f) is invertible, from sc->prng_ctx[0] through
@@ -1986,7 +2082,7 @@ int main(int argc, char **argv)
     if (argc == 4 && !strcmp(argv[1], "bench_tesla")) return bench_sig(SC_SCHEME_SIG_RING_TESLA, atoi(argv[2]), atof(argv[3]));
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
-    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|all> <outdir>\n", argv[0]); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|bliss_hp|all> <outdir>\n", argv[0]); return 2; }
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) { fixed_domain("ntt"); rc |= gen_ntt(argv[2]); }
     if (all || !strcmp(argv[1], "ntt_large")) { fixed_domain("ntt_large"); rc |= gen_ntt_large(argv[2]); }
@@ -2010,5 +2106,6 @@ int main(int argc, char **argv)
     if (all || !strcmp(argv[1], "ensdlp_rec")) { fixed_domain("ensdlp_rec"); rc |= gen_ensdlp_rec(argv[2]); }
     if (all || !strcmp(argv[1], "mlwe_xof")) { fixed_domain("mlwe_xof"); rc |= gen_mlwe_xof(argv[2]); }
     if (all || !strcmp(argv[1], "cdt_hp")) { fixed_domain("cdt_hp"); rc |= gen_cdt_hp(argv[2]); }
+    if (all || !strcmp(argv[1], "bliss_hp")) { fixed_domain("bliss_hp"); rc |= gen_bliss_hp(argv[2]); }
     return rc;
 }

@@ -115,8 +115,24 @@ static void bw_put(bw_t *w, uint32_t v, int bits)
  * fixture's *_params record; f, g, a = the key as the reference stores it (SINT16; a in the NTT domain);
  * tape = the CSPRNG's 32-bit word stream.  Returns 0, the packed signature, the attempts taken and the words consumed;
  * 2 = the tape ran out before a signature was accepted. */
+static int bliss_sign_core(const int32_t *par, const int16_t *f, const int16_t *g, const int16_t *a, const uint8_t *msg, size_t mlen,
+                           const uint32_t *tape, size_t tape_len, uint8_t *sig, size_t *siglen, int32_t *trials, size_t *consumed,
+                           int hp_words, const uint64_t *hp_table, int hp_size);
 int orc_bliss_sign(const int32_t *par, const int16_t *f, const int16_t *g, const int16_t *a, const uint8_t *msg, size_t mlen,
                    const uint32_t *tape, size_t tape_len, uint8_t *sig, size_t *siglen, int32_t *trials, size_t *consumed)
+{ return bliss_sign_core(par, f, g, a, msg, mlen, tape, tape_len, sig, siglen, trials, consumed, 0, NULL, 0); }
+/* the same with the sampler at 128- / 192-bit precision (SC_FLAG_0_SAMPLE_128BIT / _192BIT; gaussian_cdf_sample_128 / _192, gaussian_cdf.c:468-509): hp_words = 2 / 3
+ * prng_64 draws a sample over the caller's table [hp_size][hp_words] - pinned by tests/golden/bliss_hp_ref.txt */
+int orc_bliss_sign_hp(const int32_t *par, const int16_t *f, const int16_t *g, const int16_t *a, const uint8_t *msg, size_t mlen,
+                      const uint32_t *tape, size_t tape_len, int hp_words, const uint64_t *hp_table, int hp_size,
+                      uint8_t *sig, size_t *siglen, int32_t *trials, size_t *consumed)
+{
+    if (hp_words < 2 || hp_words > 3 || !hp_table || hp_size < 2) return 1;
+    return bliss_sign_core(par, f, g, a, msg, mlen, tape, tape_len, sig, siglen, trials, consumed, hp_words, hp_table, hp_size);
+}
+static int bliss_sign_core(const int32_t *par, const int16_t *f, const int16_t *g, const int16_t *a, const uint8_t *msg, size_t mlen,
+                           const uint32_t *tape, size_t tape_len, uint8_t *sig, size_t *siglen, int32_t *trials, size_t *consumed,
+                           int hp_words, const uint64_t *hp_table, int hp_size)
 {
     blissp_t P; memcpy(&P, par, sizeof P);
     const int n = P.n, q = P.q;
@@ -137,8 +153,16 @@ int orc_bliss_sign(const int32_t *par, const int16_t *f, const int16_t *g, const
     for (iter = 0; iter < 99999 && !T.underrun; iter++) {
         if (iter & 1) { int32_t *tmp = t; t = u; u = tmp; }
         else {
-            for (int i = 0; i < n; i++) t[i] = orc_cdt_sample(t64(&T), cdf, size);
-            for (int i = 0; i < n; i++) u[i] = orc_cdt_sample(t64(&T), cdf, size);
+            if (hp_words) {
+                for (int i = 0; i < 2 * n; i++) {
+                    uint64_t x[3];
+                    for (int j = 0; j < hp_words; j++) x[j] = t64(&T);
+                    (i < n ? t : u)[i < n ? i : i - n] = orc_cdt_hp_sample(x, hp_table, hp_size, hp_words);
+                }
+            } else {
+                for (int i = 0; i < n; i++) t[i] = orc_cdt_sample(t64(&T), cdf, size);
+                for (int i = 0; i < n; i++) u[i] = orc_cdt_sample(t64(&T), cdf, size);
+            }
         }
         if (T.underrun) break;
         orc_polymul_ntt(v, n, q, t, a32, wt, rt);                       /* fwd_ntt, mul_32_pointwise_16, inv_ntt: canonical */

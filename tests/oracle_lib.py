@@ -241,6 +241,20 @@ def bliss_sign(key, msg, tape):
     return rc, bytes(sig[:sl.value]), tr.value, used.value
 
 
+def bliss_sign_hp(key, msg, tape, table, words):
+    """bliss_b_sign with the sampler at 128- / 192-bit precision: table uint64 [size][words], words = 2 / 3 prng_64 draws a sample"""
+    sig = np.zeros(4096, dtype=np.uint8)
+    sl, tr, used = C.c_size_t(0), C.c_int32(0), C.c_size_t(0)
+    m, ml = _msgbuf(msg)
+    tp = np.ascontiguousarray(np.asarray(tape).astype(np.int64) & 0xFFFFFFFF, dtype=np.uint32)
+    tb = np.ascontiguousarray(np.asarray(table, dtype=np.uint64).reshape(-1, words))
+    L = lib()
+    rc = L.orc_bliss_sign_hp(key.par.ctypes.data_as(C.c_void_p), key.f.ctypes.data_as(C.c_void_p), key.g.ctypes.data_as(C.c_void_p), key.a.ctypes.data_as(C.c_void_p),
+                             m.ctypes.data_as(C.c_void_p) if hasattr(m, 'ctypes') else m, C.c_size_t(int(ml)), tp.ctypes.data_as(C.c_void_p), C.c_size_t(tp.size), int(words),
+                             tb.ctypes.data_as(C.c_void_p), int(tb.shape[0]), sig.ctypes.data_as(C.c_void_p), C.byref(sl), C.byref(tr), C.byref(used))
+    return rc, bytes(sig[:sl.value]), tr.value, used.value
+
+
 def bliss_verify(key, msg, sig):
     m, ml = _msgbuf(msg)
     s = np.ascontiguousarray(np.frombuffer(bytes(sig), dtype=np.uint8))
