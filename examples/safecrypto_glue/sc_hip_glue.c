@@ -328,7 +328,9 @@ static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
 {
     if (NULL == sc || SC_SCHEME_SIG_BLISS != sc->scheme || NULL == sc->bliss || NULL == sc->pubkey || NULL == sc->pubkey->key) return NULL;
     if (SC_ENTROPY_NONE != sc->coding_signature.type && SC_ENTROPY_BAC != sc->coding_signature.type && SC_ENTROPY_HUFFMAN_STATIC != sc->coding_signature.type) return NULL;
-    if (need_priv && (NULL == sc->sc_gauss || CDF_GAUSSIAN_SAMPLING != sc->sampling || SAMPLING_64BIT != sc->sc_gauss->precision)) return NULL;
+    /* 64-bit samplers, and the 128- / 192-bit ones the reference's own BLISS-B harness creates (func_alg_bliss_b.c:118); 32 and 256 bits stay on the reference path */
+    if (need_priv && (NULL == sc->sc_gauss || CDF_GAUSSIAN_SAMPLING != sc->sampling ||
+                      (SAMPLING_64BIT != sc->sc_gauss->precision && SAMPLING_128BIT != sc->sc_gauss->precision && SAMPLING_192BIT != sc->sc_gauss->precision))) return NULL;
     if (need_priv && (NULL == sc->privkey || NULL == sc->privkey->key)) return NULL;
     const int i = reg_ctx(sc);
     if (i < 0) return NULL;
@@ -344,6 +346,12 @@ static sc_hip_bliss_t *bliss_handle(safecrypto_t *sc, int need_priv)
             if (NULL != sc->sc_gauss && CDF_GAUSSIAN_SAMPLING == sc->sampling && SAMPLING_64BIT == sc->sc_gauss->precision) {
                 const gauss_cdf_64_view_t *v = (const gauss_cdf_64_view_t *)sc->sc_gauss->gauss;
                 if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table(g_reg[i].bliss, v->cdf, v->cdf_size)) goto drop;
+            }
+            else if (NULL != sc->sc_gauss && CDF_GAUSSIAN_SAMPLING == sc->sampling && (SAMPLING_128BIT == sc->sc_gauss->precision || SAMPLING_192BIT == sc->sc_gauss->precision)) {
+                /* the table stays the library's (MPFR arithmetic, gaussian_cdf.c:186-330); the engine runs the search, two / three prng_64 draws a sample */
+                const gauss_cdf_high_view_t *v = (const gauss_cdf_high_view_t *)sc->sc_gauss->gauss;
+                const int prec = (int)sc->sc_gauss->precision;
+                if (SC_HIP_SUCCESS != sc_hip_bliss_set_cdt_table_hp(g_reg[i].bliss, prec, 128 == prec ? v->cdf_128 : v->cdf_192, v->cdf_size)) goto drop;
             }
             if (SC_HIP_SUCCESS != bliss_coding(sc, g_reg[i].bliss)) goto drop;
         }
@@ -448,7 +456,8 @@ size_t sc_hip_glue_sig_bytes(safecrypto_t *sc)
 size_t sc_hip_glue_tape_words(safecrypto_t *sc, unsigned attempts)
 {
     if (NULL == sc) return 0;
-    if (SC_SCHEME_SIG_BLISS == sc->scheme && sc->bliss) return sc_hip_bliss_tape_words((int)sc->bliss->params->n, attempts);
+    if (SC_SCHEME_SIG_BLISS == sc->scheme && sc->bliss)        /* a 128- / 192-bit sampler takes two / three prng_64 draws a sample */
+        return sc_hip_bliss_tape_words_hp((int)sc->bliss->params->n, attempts, (sc->sc_gauss && sc->sc_gauss->precision > 64) ? (int)sc->sc_gauss->precision : 64);
     if (SC_SCHEME_SIG_RING_TESLA == sc->scheme && sc->ring_tesla) return (size_t)sc->ring_tesla->params->n * attempts;     /* n words per attempt (ring_tesla.c:790-800) */
     if (SC_SCHEME_SIG_FALCON == sc->scheme && sc->falcon) return 4 * (size_t)sc->falcon->params->n;                         /* two prng_64 per tree leaf, no retry */
     return 0;

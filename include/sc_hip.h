@@ -353,6 +353,12 @@ int sc_hip_bliss_verify_keys(sc_hip_bliss_t *h, size_t batch, const int16_t *d_a
 /* replaces the sampler table sc_hip_bliss_create built on this host (long double expl: host-dependent in its last bit) by the caller's - the reference
  * context's own (the private struct behind sc->sc_gauss->gauss, gaussian_cdf.c:74-81: cdf, cdf_size): the samples are then the reference's on any host */
 int sc_hip_bliss_set_cdt_table(sc_hip_bliss_t *h, const uint64_t *h_cdf, int size);
+/* the same for a context created with SC_FLAG_0_SAMPLE_128BIT / _192BIT (the reference's BLISS-B harness: test/functional/func_alg_bliss_b.c:118): the context's table
+ * (gauss_cdf_high_t::cdf_128 / cdf_192, [size][precision_bits / 64] limbs: see sc_hip_cdt_hp_create_from_table), after which a Gaussian sample of sc_hip_bliss_sign / _sign_seeded /
+ * _sign_keys takes precision_bits / 64 prng_64 draws of the tape - 4 n precision_bits / 64 words per fresh attempt; sc_hip_bliss_tape_words_hp is the matching tape length.
+ * Signatures byte-identical to the reference's from such a context (tests/golden/bliss_hp_ref.txt).  sc_hip_bliss_set_cdt_table returns the handle to 64 bits. */
+int sc_hip_bliss_set_cdt_table_hp(sc_hip_bliss_t *h, int precision_bits, const uint64_t *h_cdf, int size);
+size_t sc_hip_bliss_tape_words_hp(int n, unsigned attempts, int precision_bits);
 /* the relative margin of the status-5 report above (default 2^-40; 0 decides everything on the device; 1 reports every attempt - self-test) */
 int sc_hip_bliss_set_tie_margin(sc_hip_bliss_t *h, double relative);
 /* replaces: sc->coding_signature.type (bliss_b.c:197-200, set from SC_FLAG_0_ENTROPY_HUFFMAN by safecrypto_create).  type 0 = SC_ENTROPY_NONE: the

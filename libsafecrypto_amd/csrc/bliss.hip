@@ -366,6 +366,7 @@ struct sc_hip_bliss {
     int32_t *tu, *tin, *v, *cidx, *ain;
     int16_t *z;
     int speculate;               // 1: later pairs of attempts side by side (bl_sign_core); 0: the reference's loop round by round; 2: self-test of the redo path
+    uint32_t spw;                // tape words a Gaussian sample takes: 2 (one prng_64: the 64-bit sampler), 4 / 6 behind sc_hip_bliss_set_cdt_table_hp
     St st2; int32_t *tu2; uint8_t *sigs2; uint32_t *siglens2, *trials2, *msg_of2; size_t cap2, stride2;     // the pairs' state, vectors and output rows
     int entropy;                 // 0: raw signature fields, 1: SC_ENTROPY_HUFFMAN_STATIC (sc_hip_bliss_set_entropy), 2: SC_ENTROPY_BAC (sc_hip_bliss_set_entropy_bac)
     uint64_t *d_bac;             // SC_ENTROPY_BAC: the coder's two distributions, 2^z1_bits + 2^z2_bits entries (sc_hip_bliss_set_entropy_bac)
@@ -418,6 +419,7 @@ extern "C" int sc_hip_bliss_create(sc_hip_ctx_t *ctx, const sc_hip_bliss_params_
     b->ctx = ctx; b->plan = plan; b->cdt = cdt; b->P = P;
     b->tie_rel = 0x1p-40;
     b->speculate = 1;
+    b->spw = 2;
     *out = b;
     return SC_HIP_SUCCESS;
 }
@@ -434,6 +436,21 @@ extern "C" int sc_hip_bliss_set_cdt_table(sc_hip_bliss_t *b, const uint64_t *h_c
     HIPCHK(hipDeviceSynchronize());                                    // nothing in flight may still read the old table
     sc_hip_cdt_destroy(b->cdt);
     b->cdt = cdt;
+    b->spw = 2;
+    return SC_HIP_SUCCESS;
+}
+// the sampler of a context created with SC_FLAG_0_SAMPLE_128BIT / _192BIT (what the reference's BLISS-B harness asks for, test/functional/func_alg_bliss_b.c:118): the context's
+// own table (gauss_cdf_high_t::cdf_128 / cdf_192 - MPFR arithmetic, the library's), a sample = precision / 64 prng_64 draws of the tape
+extern "C" int sc_hip_bliss_set_cdt_table_hp(sc_hip_bliss_t *b, int precision_bits, const uint64_t *h_cdf, int size)
+{
+    if (!b || !h_cdf) return fail("bliss_set_cdt_table_hp: null argument");
+    sc_hip_cdt *cdt = nullptr;
+    if (sc_hip_cdt_hp_create_from_table(b->ctx, precision_bits, h_cdf, size, &cdt) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
+    HIPCHK(hipSetDevice(b->ctx->device));
+    HIPCHK(hipDeviceSynchronize());
+    sc_hip_cdt_destroy(b->cdt);
+    b->cdt = cdt;
+    b->spw = (uint32_t)(precision_bits / 32);
     return SC_HIP_SUCCESS;
 }
 
@@ -653,7 +670,10 @@ static int bl_round_launch(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hi
     const BlissP &P = b->P;
     const int n = P.n;
     const St &st = r.st;
-    hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, b->need, b->sbase, r.siglens, in.mlens, nd);
+    const int hpw = b->cdt->hp_words;                                  // 0: the 64-bit sampler; 2 / 3: 128- / 192-bit precision (sc_hip_bliss_set_cdt_table_hp)
+    if (hpw) hipLaunchKernelGGL(bl_begin_hp_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, (uint32_t)(4 * n * hpw),
+                                b->need, b->sbase, r.siglens, in.mlens, nd);
+    else hipLaunchKernelGGL(bl_begin_kernel, dim3((nact + 255) / 256), dim3(256), 0, s, active, nact, st, in.tape_lens, (uint32_t)in.tape_stride, n, b->need, b->sbase, r.siglens, in.mlens, nd);
     const size_t nsamp = (size_t)nact * 2 * n;
     size_t sblocks = (nsamp + 256 * 32 - 1) / (256 * 32);
     const size_t slds = sc::cdt_lds_bytes(b->cdt), sper = (size_t)(160 * 1024) / slds;
@@ -661,7 +681,11 @@ static int bl_round_launch(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hi
     const CdtGuide &cg = b->cdt->g;
 #define BL_SAMPLE(SS) hipLaunchKernelGGL(bl_sample_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
                        in.tapes, in.tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, r.tu, n, st.msg_of, nd)
-    switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#define BL_SAMPLE_HP(SS) hipLaunchKernelGGL(bl_sample_hp_kernel<SS>, dim3((unsigned)sblocks), dim3(256), slds, s, active, nact, b->need, b->sbase, st.cur, \
+                       in.tapes, in.tape_stride, b->cdt->d_cdf, b->cdt->d_guide, cg, b->cdt->size, r.tu, n, hpw, st.msg_of, nd)
+    if (hpw) { switch (cg.S) { case 0: BL_SAMPLE_HP(0); break; case 1: BL_SAMPLE_HP(1); break; case 2: BL_SAMPLE_HP(2); break; case 3: BL_SAMPLE_HP(3); break; default: BL_SAMPLE_HP(4); break; } }
+    else switch (cg.S) { case 0: BL_SAMPLE(0); break; case 1: BL_SAMPLE(1); break; case 2: BL_SAMPLE(2); break; case 3: BL_SAMPLE(3); break; default: BL_SAMPLE(4); break; }
+#undef BL_SAMPLE_HP
 #undef BL_SAMPLE
     const size_t ne = (size_t)nact * n;
     hipLaunchKernelGGL(bl_stage_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, active, nact, b->need, st.cur, r.tu, b->tin, n, in.ka16, b->ain, st.msg_of, nd);
@@ -721,21 +745,27 @@ static int bl_rounds(sc_hip_bliss_t *b, const BlRun &r, const BlIn &in, hipStrea
 // practice; such a message is redone in order, status 8 below.)
 struct ResSim {
     uint32_t pos = 0, lrp = 0; int vb = 0;
-    void attempt(bool fresh, uint32_t n)
+    void attempt(bool fresh, uint32_t n, uint32_t spw = 2)            // spw: tape words a sample (2: one prng_64; 4 / 6: a 128- / 192-bit sampler's two / three)
     {
-        if (fresh) pos += 4 * n;
+        if (fresh) pos += 2 * n * spw;
         const int req[3] = { 1, 27, 26 };
         for (int nreq : req) { if (vb < nreq) { const int bits = nreq - vb; lrp = pos; pos++; vb = 32 - bits; } else vb -= nreq; }
     }
 };
 // the CSPRNG words bliss_b_sign has drawn when its `attempts`-th attempt ends (what a tape must hold for a signature that takes that many): host arithmetic
 // only - the same bookkeeping that places the later pairs
-extern "C" size_t sc_hip_bliss_tape_words(int n, unsigned attempts)
+static size_t bl_tape_words(int n, unsigned attempts, uint32_t spw)
 {
     if (n <= 0) return 0;
     ResSim sim;
-    for (unsigned k = 0; k < attempts; k++) sim.attempt((k & 1u) == 0, (uint32_t)n);
+    for (unsigned k = 0; k < attempts; k++) sim.attempt((k & 1u) == 0, (uint32_t)n, spw);
     return sim.pos;
+}
+extern "C" size_t sc_hip_bliss_tape_words(int n, unsigned attempts) { return bl_tape_words(n, attempts, 2); }
+extern "C" size_t sc_hip_bliss_tape_words_hp(int n, unsigned attempts, int precision_bits)
+{
+    if (precision_bits != 64 && precision_bits != 128 && precision_bits != 192) return 0;
+    return bl_tape_words(n, attempts, (uint32_t)(precision_bits / 32));
 }
 
 constexpr int BL_PAIRS = 4;                    // later pairs of a message evaluated side by side
@@ -852,7 +882,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         // message, then the later pairs of the messages that get that far (a tape position does not depend on any value, see ResSim) - and zeroed behind the call.
         if (seed_len == 0 || seed_len > seed_stride || seed_len > 0xffffffffu) return fail("bliss_sign_seeded: bad seed length / stride");
         HIPCHK(hipSetDevice(b->ctx->device));
-        const size_t words = (sc_hip_bliss_tape_words(b->P.n, BL_SEED_ATTEMPTS) + 3) & ~(size_t)3;
+        const size_t words = (bl_tape_words(b->P.n, BL_SEED_ATTEMPTS, b->spw) + 3) & ~(size_t)3;
         if (batch > b->seed_rows || words != b->seed_words) {
             if (b->seed_tape) (void)sc::wipe_free(b->seed_tape);
             if (b->seed_list) (void)hipFree(b->seed_list);
@@ -888,7 +918,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
         return sc::drbg_fill(b->ctx, d_seeds, seed_stride, seed_len, list, count, count_dev, b->seed_tape, tape_stride * 4, from, to, 1, false, s);
     };
     if (seeded) {
-        blk_all = spec ? (sc_hip_bliss_tape_words(P.n, 2) + 3) / 4 : tape_stride / 4;      // the plain loop's consumption is not known in advance: whole rows
+        blk_all = spec ? (bl_tape_words(P.n, 2, b->spw) + 3) / 4 : tape_stride / 4;      // the plain loop's consumption is not known in advance: whole rows
         if (seed_fill(nullptr, B, nullptr, 0, blk_all)) return SC_HIP_FAILURE;
         blk_later = blk_all;
     }
@@ -899,7 +929,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
     if (spec) {
         if (b->speculate == 2) hipLaunchKernelGGL(bl_force_redo_kernel, dim3((B + 255) / 256), dim3(256), 0, s, st.status, B);
         ResSim sim;
-        sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);                 // pair 0 is behind us
+        sim.attempt(true, (uint32_t)P.n, b->spw); sim.attempt(false, (uint32_t)P.n, b->spw);   // pair 0 is behind us
         uint32_t *ulist = b->act[0];                                  // (the round loop is idle here: its two lists are free)
         uint32_t n8 = 0;
         ResSim sim_saved; size_t blk_saved = 0; bool was_blind = false, refused = false;
@@ -947,7 +977,7 @@ static int bl_sign_core(sc_hip_bliss_t *b, const int16_t *kf, const int16_t *kg,
             PairInit pi{};
             for (uint32_t k = 0; k < pp; k++) {
                 pi.pos[k] = sim.pos; pi.lrp[k] = sim.lrp; pi.vb[k] = sim.vb;
-                sim.attempt(true, (uint32_t)P.n); sim.attempt(false, (uint32_t)P.n);
+                sim.attempt(true, (uint32_t)P.n, b->spw); sim.attempt(false, (uint32_t)P.n, b->spw);
             }
             const uint32_t nv = nu * pp;
             if (seeded) {

@@ -124,6 +124,58 @@ __global__ __launch_bounds__(256) void bl_sample_kernel(const uint32_t *active, 
     }
 }
 
+// ---- the same two kernels for a sampler at 128- / 192-bit precision (SC_FLAG_0_SAMPLE_128BIT / _192BIT: gaussian_cdf_sample_128 / _192, gaussian_cdf.c:468-509) -----------
+// A sample is W = 2 / 3 prng_64 draws, i.e. 2 W tape words: words 0 / 1 the first draw's high / low half (limb 0: its bit 0 is the sign), words 2 W - 2 / 2 W - 1 the last
+// draw's (the most significant limb: the only one the reference's comparison reads, ">=" - sc_hip.hip cdt_hp_kernel has the derivation); the handle's table holds the top
+// limbs, searched with top + 1.  A fresh attempt is 2 n samples = 4 n W words.  Separate kernels, so that the text of the 64-bit ones above stays what the GPU suite ran.
+__global__ void bl_begin_hp_kernel(const uint32_t *active, uint32_t nact, St s, const uint32_t *tape_lens, uint32_t tape_stride, int n, uint32_t wpa,
+                                   uint32_t *need, uint32_t *sbase, uint32_t *siglens, const uint32_t *mlens, const uint32_t *nd)
+{
+    if (nd) nact = min(nact, *nd);
+    const uint32_t aidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (aidx >= nact) return;
+    const uint32_t item = active ? active[aidx] : aidx, src = s.msg_of ? s.msg_of[item] : item;
+    if (mlens && mlens[src] == 0) { s.status[item] = 3; siglens[item] = 0; need[aidx] = 2; return; }
+    if (s.iter[item] & 1) { s.cur[item] ^= 1; need[aidx] = 0; return; }
+    const uint32_t len = tape_lens ? tape_lens[src] : tape_stride, pos = s.pos[item];
+    if (pos + wpa > len) { s.status[item] = 2; siglens[item] = 0; need[aidx] = 2; return; }                 // tape exhausted
+    need[aidx] = 1; sbase[aidx] = pos; s.pos[item] = pos + wpa;
+}
+
+// a lane takes one sample per step (a wavefront 64 consecutive ones of one item): 16 or 24 bytes of tape in, one word out
+template <int S>
+__global__ __launch_bounds__(256) void bl_sample_hp_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *sbase, const uint32_t *cur,
+                                                           const uint32_t *tapes, size_t tape_stride, const uint64_t *cdf, const uint16_t *gd, CdtGuide g, int size, int32_t *tu, int n,
+                                                           int W, const uint32_t *msg_of, const uint32_t *nd)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tab[];
+    if (nd) nact = min(nact, *nd);
+    const int lps = 31 - __clz(2 * n / 64);                           // log2 of the steps per item
+    const size_t steps = (size_t)nact << lps, nwaves = (size_t)gridDim.x * 4;
+    if ((size_t)blockIdx.x * 4 >= steps) return;
+    uint16_t *guide = reinterpret_cast<uint16_t *>(tab + size + CDT_PAD);
+    for (int i = threadIdx.x; i < size + CDT_PAD; i += blockDim.x) tab[i] = cdf[i];
+    if (S) for (uint32_t i = threadIdx.x; i < (g.total + 1) / 2; i += blockDim.x) reinterpret_cast<uint32_t *>(guide)[i] = reinterpret_cast<const uint32_t *>(gd)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (size_t ws = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); ws < steps; ws += nwaves) {
+        const uint32_t aidx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ws >> lps));
+        if (need[aidx] != 1) continue;
+        const uint32_t item = active ? active[aidx] : aidx;
+        const int sidx = (((int)ws & ((1 << lps) - 1)) << 6) + lane;                   // the lane's sample, 0 .. 2n-1
+        const uint32_t *tp = tapes + (size_t)(msg_of ? msg_of[item] : item) * tape_stride + sbase[aidx] + (size_t)2 * W * sidx;
+        const uint32_t sign = tp[1] & 1u;
+        const uint64_t top = ((uint64_t)tp[2 * W - 2] << 32) | tp[2 * W - 1], u = top + 1;
+        uint32_t a = 0;
+        if (S) a = cdt_lookup<(S > 3 ? 0 : S)>(u, tab, guide, g);
+        else for (uint32_t st = (uint32_t)size >> 1; st > 0; st >>= 1) { const uint32_t b = a + st; if (tab[b] < u) a = b; }
+        if (top == ~0ull) a = (uint32_t)size - 1u;
+        const uint32_t c = cur[item];
+        const int which = sidx < n ? (int)c : (int)(c ^ 1);
+        tu[((size_t)item * 2 + which) * n + (sidx & (n - 1))] = sign ? (int32_t)a : -(int32_t)a;
+    }
+}
+
 // dense copy of the current t for the NTT product
 // (a key per message: the active messages' public keys a, SINT16 rows, are gathered beside it as the product's second operand)
 __global__ void bl_stage_kernel(const uint32_t *active, uint32_t nact, const uint32_t *need, const uint32_t *cur, const int32_t *tu, int32_t *tin, int n,

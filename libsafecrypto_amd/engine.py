@@ -23,7 +23,7 @@ SYMBOLS = [
     'sc_hip_dilithium_verify_host', 'sc_hip_dilithium_keygen',
     'sc_hip_kyber_create', 'sc_hip_kyber_destroy', 'sc_hip_kyber_set_pubkey', 'sc_hip_kyber_set_privkey', 'sc_hip_kyber_noise_bytes',
     'sc_hip_kyber_cpa_enc', 'sc_hip_kyber_cpa_dec', 'sc_hip_kyber_set_kem_pubkey', 'sc_hip_kyber_ct_bytes', 'sc_hip_kyber_kem_encaps', 'sc_hip_kyber_kem_decaps', 'sc_hip_kyber_kem_encaps_keys', 'sc_hip_kyber_kem_decaps_keys', 'sc_hip_kyber_keygen',
-    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_sign_seeded', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_set_entropy_bac', 'sc_hip_bliss_tape_words',
+    'sc_hip_bliss_create', 'sc_hip_bliss_destroy', 'sc_hip_bliss_set_key', 'sc_hip_bliss_sig_bytes', 'sc_hip_bliss_sign', 'sc_hip_bliss_sign_seeded', 'sc_hip_bliss_verify', 'sc_hip_bliss_sign_keys', 'sc_hip_bliss_verify_keys', 'sc_hip_bliss_keygen', 'sc_hip_bliss_set_tie_margin', 'sc_hip_bliss_set_cdt_table', 'sc_hip_bliss_set_cdt_table_hp', 'sc_hip_bliss_tape_words_hp', 'sc_hip_bliss_set_entropy', 'sc_hip_bliss_set_entropy_bac', 'sc_hip_bliss_tape_words',
     'sc_hip_falcon_create', 'sc_hip_falcon_destroy', 'sc_hip_falcon_set_privkey', 'sc_hip_falcon_set_pubkey', 'sc_hip_falcon_set_privkeys', 'sc_hip_falcon_set_pubkeys', 'sc_hip_falcon_sign_keys', 'sc_hip_falcon_verify_keys', 'sc_hip_falcon_sig_bytes',
     'sc_hip_falcon_sample', 'sc_hip_falcon_sign', 'sc_hip_falcon_sign_seeded', 'sc_hip_falcon_verify', 'sc_hip_falcon_set_mapping',
     'sc_hip_ntt_pwr', 'sc_hip_ntt_flip', 'sc_hip_ntt_invert', 'sc_hip_ntt_div', 'sc_hip_mult_sparse', 'sc_hip_mult_sparse_16',
@@ -172,6 +172,9 @@ def load_library(path=LIB_PATH):
     L.sc_hip_rlwe_set_arith.argtypes = [vp, C.c_int]
     L.sc_hip_bliss_tape_words.argtypes = [C.c_int, C.c_uint]
     L.sc_hip_bliss_tape_words.restype = sz
+    L.sc_hip_bliss_tape_words_hp.argtypes = [C.c_int, C.c_uint, C.c_int]
+    L.sc_hip_bliss_tape_words_hp.restype = sz
+    L.sc_hip_bliss_set_cdt_table_hp.argtypes = [vp, C.c_int, vp, C.c_int]
     L.sc_hip_bliss_set_entropy.argtypes = [vp, C.c_int, vp, vp, C.c_uint32, vp, vp, C.c_uint32]
     L.sc_hip_bliss_set_entropy_bac.argtypes = [vp, vp, vp]
     L.sc_hip_bliss_sign_keys.argtypes = [vp, sz, vp, vp, vp, vp, sz, vp, C.c_uint32, vp, sz, vp, vp, sz, vp, vp, vp, vp]
@@ -1163,6 +1166,12 @@ class Bliss:
         import numpy as np
         t = np.ascontiguousarray(np.asarray(cdf), dtype=np.uint64)
         _chk(self.L, self.L.sc_hip_bliss_set_cdt_table(self.h, _ptr(t), t.size), 'bliss_set_cdt_table')
+
+    def set_cdt_table_hp(self, precision_bits, table):
+        """the table of a context created with SC_FLAG_0_SAMPLE_128BIT / _192BIT (uint64 [size][precision / 64] limbs): a sample then takes precision / 64 prng_64 draws of the tape"""
+        import numpy as np
+        t = np.ascontiguousarray(np.asarray(table), dtype=np.uint64)
+        _chk(self.L, self.L.sc_hip_bliss_set_cdt_table_hp(self.h, int(precision_bits), _ptr(t), t.size // (int(precision_bits) // 64)), 'bliss_set_cdt_table_hp')
 
     def set_tie_margin(self, relative):
         """relative margin around the rejection threshold inside which a draw is reported (status 5) instead of decided; default 2^-40"""

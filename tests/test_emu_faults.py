@@ -275,7 +275,7 @@ print('FAULT SWEEP DONE')
 # the default suite: every call of every class for the scenarios whose faulted runs cost seconds; the signing calls of Dilithium and ring-TESLA cost 10 s and more
 # per run in the emulation - creation and key loading (where the tables of secrets are built) are swept here, the whole calls with SC_TEST_SLOW_EMU=1 (run in round 6
 # on the plain build: dilithium 66 + dilithium_tables 68 + tesla 46 faulted runs, every one a clean error, nothing left allocated)
-GROUPS = [['ntt', 'multi', 'kyber', 'dilithium_load'], ['bliss', 'falcon', 'tesla_load']]
+GROUPS = [['ntt', 'multi', 'dilithium_load'], ['bliss', 'falcon', 'tesla_load', 'kyber']]
 SLOW_GROUPS = [['dilithium'], ['dilithium_tables'], ['tesla']]
 SLOW = os.environ.get('SC_TEST_SLOW_EMU') == '1'
 

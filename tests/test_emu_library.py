@@ -21,6 +21,7 @@ QUICK = [
     'tests/test_gpu_vtable.py',
     'tests/test_gpu_mlwe_xof.py',
     'tests/test_gpu_cdt_hp.py',
+    'tests/test_gpu_bliss_hp.py::test_reference_signatures',
     'tests/test_gpu_ntt.py::test_golden_fwd_inv_mul',
     'tests/test_gpu_ntt.py::test_tables_match_reference',
     'tests/test_gpu_ntt.py::test_extreme_inputs_every_mode',
@@ -43,4 +44,4 @@ def test_gpu_suite_subset_on_the_cpu_build_asan_ubsan():
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=2400)
     tail = r.stdout[-3000:]
     m = re.search(r'(\d+) passed', tail)
-    assert r.returncode == 0 and m and int(m.group(1)) >= 97 and 'failed' not in tail.splitlines()[-1], (tail, r.stderr[-3000:])
+    assert r.returncode == 0 and m and int(m.group(1)) >= 103 and 'failed' not in tail.splitlines()[-1], (tail, r.stderr[-3000:])
