@@ -19,9 +19,9 @@ QUICK = [
     'tests/test_gpu_ops.py',
     'tests/test_gpu_drbg.py',
     'tests/test_gpu_vtable.py',
-    'tests/test_gpu_mlwe_xof.py',
-    'tests/test_gpu_cdt_hp.py',
-    'tests/test_gpu_bliss_hp.py::test_reference_signatures',
+    'tests/test_gpu_zx_mlwe_xof.py',
+    'tests/test_gpu_zx_cdt_hp.py',
+    'tests/test_gpu_zx_bliss_hp.py::test_reference_signatures',
     'tests/test_gpu_ntt.py::test_golden_fwd_inv_mul',
     'tests/test_gpu_ntt.py::test_tables_match_reference',
     'tests/test_gpu_ntt.py::test_extreme_inputs_every_mode',

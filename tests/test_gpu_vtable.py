@@ -301,50 +301,6 @@ def test_sampler_table_pulls_words_in_order():
     assert tab.destroy(C.byref(g)) == 0 and not g.value
 
 
-@pytest.mark.parametrize('tag', ['hp128_bliss1_s215_t13.42', 'hp192_leaf_s1.7_t10'])
-def test_sampler_table_at_128_and_192_bits(tag):
-    """create_sampler(..., SAMPLING_128BIT / SAMPLING_192BIT, ...) behind the utils_sampling_t mirror (sc_hip_sampler_create_hp): the reference's table handed over, 2 / 3
-    draws of the generator per sample in the reference's order - the vector the reference's own get_vector_32 filled over the same table (tests/golden/cdt_hp_ref.txt)"""
-    from libsafecrypto_amd import load_library
-    from tests.golden_io import load_golden
-    L = load_library()
-    G = load_golden('cdt_hp_ref.txt')
-    prec, size, ns, _ = (int(v) for v in G[f'{tag}_par'])
-    W = prec // 64
-    table = np.asarray(G[f'{tag}_table'], dtype=np.uint64)
-    words = np.asarray(G[f'{tag}_words'], dtype=np.uint64)
-    want = np.asarray(G[f'{tag}_samples'], dtype=np.int32)
-
-    class SAMP(C.Structure):
-        _pack_ = 1
-    SAMP._fields_ = [('create', VOIDP), ('destroy', F(C.c_int32, C.POINTER(VOIDP))), ('get_prng', VOIDP), ('sample', F(C.c_int32, VOIDP)),
-                     ('vector_16', F(C.c_int32, C.POINTER(SAMP), i16p, C.c_size_t, C.c_int32)), ('vector_32', F(C.c_int32, C.POINTER(SAMP), i32p, C.c_size_t, C.c_int32)),
-                     ('precision', C.c_int32), ('dimension', C.c_int32), ('bootstrapped', C.c_int32), ('tail', C.c_float), ('sigma', C.c_float), ('sigma2', C.c_float),
-                     ('gauss', VOIDP), ('prng_ctx', VOIDP), ('discard', C.c_uint32), ('bootstrap', VOIDP)]
-    state = {'i': 0}
-    RNG = F(C.c_uint64, VOIDP)
-
-    def draw(_ctx):
-        v = int(words[state['i']]); state['i'] += 1
-        return v
-    cb = RNG(draw)
-    h = VOIDP()
-    L.sc_hip_sampler_create_hp.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, RNG, C.c_void_p, C.POINTER(VOIDP)]
-    assert L.sc_hip_sampler_create_hp(prec, 13.42, 215.0, table.ctypes.data, size, cb, None, C.byref(h)) == 0, L.sc_hip_last_error()
-    tab = SAMP()
-    L.sc_hip_utils_sampling_fill.argtypes = [C.c_void_p, C.c_void_p]
-    assert L.sc_hip_utils_sampling_fill(C.byref(tab), h) == 0 and tab.precision == prec
-    n = min(ns - 1, 300)
-    v = np.zeros(n, dtype=np.int32)
-    assert tab.vector_32(C.byref(tab), P(v), n, 0) == 0 and state['i'] == n * W
-    assert np.array_equal(v, want[:n])
-    assert tab.sample(tab.gauss) == int(want[n]) and state['i'] == (n + 1) * W
-    L.sc_hip_utils_sampling_fill_sca.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    assert L.sc_hip_utils_sampling_fill_sca(C.byref(SAMP()), h, 2) != 0               # the shuffle / blinding fillers stay 64-bit
-    g = VOIDP(tab.gauss)
-    assert tab.destroy(C.byref(g)) == 0 and not g.value
-
-
 def test_sampler_side_channel_variants_match_the_reference():
     """shuffle / blinding fillers and sample discarding (sampling.c:107-228) behind the utils_sampling_t mirror: the vectors the reference itself filled from a
     seeded CSPRNG (tests/golden/sampling_ref.txt), reproduced from the same pool words delivered through the prng_32 / prng_64 callbacks; and the oracle"""

@@ -1,4 +1,7 @@
-"""GPU: BLISS-B signing with the sampler at 128- / 192-bit precision (sc_hip_bliss_set_cdt_table_hp) - what the reference's own harness asks for
+"""(Sorted behind the rest of the GPU suite on purpose: written in round 6, while the GPU pool was closed - these tests have run against the CPU build of the library only, and a
+run that stops at the first failure should have been through everything that HAS run on hardware before it gets here.)
+
+GPU: BLISS-B signing with the sampler at 128- / 192-bit precision (sc_hip_bliss_set_cdt_table_hp) - what the reference's own harness asks for
 (/root/reference/test/functional/func_alg_bliss_b.c:118: SC_FLAG_0_SAMPLE_CDF | SC_FLAG_0_SAMPLE_128BIT).  Against the reference's signatures from such contexts
 (tests/golden/bliss_hp_ref.txt: their tables recorded in the fixture) and, on seeded batches, the oracle; the later pairs of attempts side by side and the seeded form too
 (a sample takes two / three prng_64 draws, so every tape position moves)."""

@@ -1,4 +1,7 @@
-"""GPU: the CDT sampler at 128- / 192-bit precision through the C ABI (sc_hip_cdt_hp_*) against the reference's own get_vector_32 -> gaussian_cdf_sample_128 / _192
+"""(Sorted behind the rest of the GPU suite on purpose: written in round 6, while the GPU pool was closed - these tests have run against the CPU build of the library only, and a
+run that stops at the first failure should have been through everything that HAS run on hardware before it gets here.)
+
+GPU: the CDT sampler at 128- / 192-bit precision through the C ABI (sc_hip_cdt_hp_*) against the reference's own get_vector_32 -> gaussian_cdf_sample_128 / _192
 run over tables of known content (tests/golden/cdt_hp_ref.txt; /root/reference/src/utils/sampling/gaussian_cdf.c:110-184,468-509) and, on seeded tables and words, the oracle."""
 import ctypes as C
 
@@ -83,3 +86,47 @@ def test_what_is_refused(eng):
         if eng.L.sc_hip_cdt_sample(s.h, 1, C.c_void_p(torch.zeros(2, dtype=torch.int64, device='cuda').data_ptr()), 0, C.c_void_p(torch.zeros(1, dtype=torch.int32, device='cuda').data_ptr()), None) != 0:
             raise EngineError(eng.L.sc_hip_last_error().decode())
     s.close()
+
+
+@pytest.mark.parametrize('tag', ['hp128_bliss1_s215_t13.42', 'hp192_leaf_s1.7_t10'])
+def test_sampler_table_at_128_and_192_bits(tag):
+    """create_sampler(..., SAMPLING_128BIT / SAMPLING_192BIT, ...) behind the utils_sampling_t mirror (sc_hip_sampler_create_hp): the reference's table handed over, 2 / 3
+    draws of the generator per sample in the reference's order - the vector the reference's own get_vector_32 filled over the same table (tests/golden/cdt_hp_ref.txt)"""
+    from libsafecrypto_amd import load_library
+    from tests.golden_io import load_golden
+    L = load_library()
+    G = load_golden('cdt_hp_ref.txt')
+    prec, size, ns, _ = (int(v) for v in G[f'{tag}_par'])
+    W = prec // 64
+    table = np.asarray(G[f'{tag}_table'], dtype=np.uint64)
+    words = np.asarray(G[f'{tag}_words'], dtype=np.uint64)
+    want = np.asarray(G[f'{tag}_samples'], dtype=np.int32)
+
+    class SAMP(C.Structure):
+        _pack_ = 1
+    SAMP._fields_ = [('create', C.c_void_p), ('destroy', C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_void_p))), ('get_prng', C.c_void_p), ('sample', C.CFUNCTYPE(C.c_int32, C.c_void_p)),
+                     ('vector_16', C.CFUNCTYPE(C.c_int32, C.POINTER(SAMP), C.POINTER(C.c_int16), C.c_size_t, C.c_int32)), ('vector_32', C.CFUNCTYPE(C.c_int32, C.POINTER(SAMP), C.POINTER(C.c_int32), C.c_size_t, C.c_int32)),
+                     ('precision', C.c_int32), ('dimension', C.c_int32), ('bootstrapped', C.c_int32), ('tail', C.c_float), ('sigma', C.c_float), ('sigma2', C.c_float),
+                     ('gauss', C.c_void_p), ('prng_ctx', C.c_void_p), ('discard', C.c_uint32), ('bootstrap', C.c_void_p)]
+    state = {'i': 0}
+    RNG = C.CFUNCTYPE(C.c_uint64, C.c_void_p)
+
+    def draw(_ctx):
+        v = int(words[state['i']]); state['i'] += 1
+        return v
+    cb = RNG(draw)
+    h = C.c_void_p()
+    L.sc_hip_sampler_create_hp.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int, RNG, C.c_void_p, C.POINTER(C.c_void_p)]
+    assert L.sc_hip_sampler_create_hp(prec, 13.42, 215.0, table.ctypes.data, size, cb, None, C.byref(h)) == 0, L.sc_hip_last_error()
+    tab = SAMP()
+    L.sc_hip_utils_sampling_fill.argtypes = [C.c_void_p, C.c_void_p]
+    assert L.sc_hip_utils_sampling_fill(C.byref(tab), h) == 0 and tab.precision == prec
+    n = min(ns - 1, 300)
+    v = np.zeros(n, dtype=np.int32)
+    assert tab.vector_32(C.byref(tab), v.ctypes.data_as(C.POINTER(C.c_int32)), n, 0) == 0 and state['i'] == n * W
+    assert np.array_equal(v, want[:n])
+    assert tab.sample(tab.gauss) == int(want[n]) and state['i'] == (n + 1) * W
+    L.sc_hip_utils_sampling_fill_sca.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    assert L.sc_hip_utils_sampling_fill_sca(C.byref(SAMP()), h, 2) != 0               # the shuffle / blinding fillers stay 64-bit
+    g = C.c_void_p(tab.gauss)
+    assert tab.destroy(C.byref(g)) == 0 and not g.value

@@ -1,4 +1,7 @@
-"""GPU: the XOF-driven module-LWE helpers through the C ABI (sc_hip_mlwe_expand_matrix_xof, sc_hip_mlwe_sample_xof, and the product as expansion + sc_hip_matvec)
+"""(Sorted behind the rest of the GPU suite on purpose: written in round 6, while the GPU pool was closed - these tests have run against the CPU build of the library only, and a
+run that stops at the first failure should have been through everything that HAS run on hardware before it gets here.)
+
+GPU: the XOF-driven module-LWE helpers through the C ABI (sc_hip_mlwe_expand_matrix_xof, sc_hip_mlwe_sample_xof, and the product as expansion + sc_hip_matvec)
 against the reference's own functions (tests/golden/mlwe_xof_ref.txt: uniform_random_ring_q_xof, create_rand_product_32_xof / _16_xof, uniform_rand_sample_xof /
 _small_xof, binomial_rand_sample_xof - /root/reference/src/utils/arith/module_lwe.c:330-367,449-512,550-560,751-912) and, on seeded batches, the oracle."""
 import numpy as np
