@@ -9,10 +9,10 @@ cd "$(dirname "$0")/.."
 C=${1:?commit}
 OLD=$(mktemp -d); A=$(mktemp -d); B=$(mktemp -d)
 git archive "$C" libsafecrypto_amd/csrc include | tar -x -C "$OLD"
-FILES="sc_hip dilithium kyber bliss falcon ops drbg tesla rlwe ens dlp entropy"
+FILES=$(sed -n 's/^SRC *:= *//p' libsafecrypto_amd/csrc/Makefile | tr " " "\n" | sed -n 's/\.hip$//p' | tr "\n" " ")       # every .hip the product is built from now
 for f in $FILES; do
   fl=""; [ $f = falcon ] && fl="-ffp-contract=off"
-  (cd "$OLD/libsafecrypto_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $fl --cuda-device-only -S $f.hip -o "$A/$f.s" 2> "$A/$f.err" || echo "compile failed" >> "$A/$f.err.rc") &
+  [ -e "$OLD/libsafecrypto_amd/csrc/$f.hip" ] && (cd "$OLD/libsafecrypto_amd/csrc" && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $fl --cuda-device-only -S $f.hip -o "$A/$f.s" 2> "$A/$f.err" || echo "compile failed" >> "$A/$f.err.rc") &
   (cd libsafecrypto_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $fl --cuda-device-only -S $f.hip -o "$B/$f.s" 2> "$B/$f.err" || echo "compile failed" >> "$B/$f.err.rc") &
   while (( $(jobs -r | wc -l) >= ${JOBS:-6} )); do wait -n; done
 done
@@ -21,6 +21,11 @@ echo "device code: $C (first) against the working tree at $(git rev-parse --shor
 rc=0
 for f in $FILES; do
   echo -n "$f.hip: "
+  if [ ! -e "$OLD/libsafecrypto_amd/csrc/$f.hip" ]; then
+    if [ -e "$B/$f.err.rc" ] || [ ! -s "$B/$f.s" ]; then echo "COMPILE FAILED:"; grep -v "argument unused during compilation" "$B/$f.err" | head -20; rc=1
+    else echo "a file $C does not have: $(grep -c '^[[:space:]]*\.amdhsa_kernel ' "$B/$f.s") kernels, all additions"; fi
+    continue
+  fi
   for side in "$A" "$B"; do
     if [ -e "$side/$f.err.rc" ] || [ ! -s "$side/$f.s" ]; then echo "COMPILE FAILED ($side):"; grep -v "argument unused during compilation" "$side/$f.err" | head -20; rc=1; fi
   done
