@@ -766,6 +766,8 @@ typedef struct sc_hip_multi_kyber sc_hip_multi_kyber_t;
 int  sc_hip_multi_bliss_create(sc_hip_multi_t *m, const sc_hip_bliss_params_t *params, sc_hip_multi_bliss_t **h);
 void sc_hip_multi_bliss_destroy(sc_hip_multi_bliss_t *h);
 int  sc_hip_multi_bliss_set_key(sc_hip_multi_bliss_t *h, const int16_t *f, const int16_t *g, const int16_t *a);
+/* the sampler table on every worker (precision_bits 64: sc_hip_bliss_set_cdt_table; 128 / 192: sc_hip_bliss_set_cdt_table_hp) */
+int  sc_hip_multi_bliss_set_cdt_table(sc_hip_multi_bliss_t *h, int precision_bits, const uint64_t *h_cdf, int size);
 size_t sc_hip_multi_bliss_sig_bytes(const sc_hip_multi_bliss_t *h);
 int  sc_hip_multi_bliss_sign_host(sc_hip_multi_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
                                   const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,

@@ -247,6 +247,13 @@ SC_MULTI_CREATE(kyber, sc_hip_kyber_params_t)
 
 extern "C" int sc_hip_multi_bliss_set_key(sc_hip_multi_bliss_t *h, const int16_t *f, const int16_t *g, const int16_t *a)
 { return for_all(h, "multi_bliss_set_key", [&](sc_hip_bliss_t *x) { return sc_hip_bliss_set_key(x, f, g, a); }); }
+// the sampler table of every worker's handle: the reference context's own (64: sc_hip_bliss_set_cdt_table; 128 / 192: sc_hip_bliss_set_cdt_table_hp - the configuration of the
+// reference's BLISS-B harness)
+extern "C" int sc_hip_multi_bliss_set_cdt_table(sc_hip_multi_bliss_t *h, int precision_bits, const uint64_t *h_cdf, int size)
+{
+    if (!h_cdf) return sc::fail("multi_bliss_set_cdt_table: null table");
+    return for_all(h, "multi_bliss_set_cdt_table", [&](sc_hip_bliss_t *x) { return precision_bits == 64 ? sc_hip_bliss_set_cdt_table(x, h_cdf, size) : sc_hip_bliss_set_cdt_table_hp(x, precision_bits, h_cdf, size); });
+}
 extern "C" size_t sc_hip_multi_bliss_sig_bytes(const sc_hip_multi_bliss_t *h) { return (h && !h->h.empty()) ? sc_hip_bliss_sig_bytes(h->h[0]) : 0; }
 extern "C" int sc_hip_multi_bliss_sign_host(sc_hip_multi_bliss_t *h, size_t batch, const uint8_t *h_msgs, size_t msg_stride, const uint32_t *h_mlens, uint32_t fixed_len,
                                             const uint32_t *h_tapes, size_t tape_stride, const uint32_t *h_tape_lens,

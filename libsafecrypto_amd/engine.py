@@ -45,7 +45,7 @@ SYMBOLS += ['sc_hip_shard_range', 'sc_hip_multi_create', 'sc_hip_multi_destroy',
             'sc_hip_multi_dilithium_verify_host']
 SYMBOLS += ['sc_hip_huffman_create', 'sc_hip_huffman_destroy', 'sc_hip_huffman_encode_rows', 'sc_hip_huffman_decode_rows']
 SYMBOLS += [f'sc_hip_{k}_{f}_host' for k in ('bliss', 'tesla', 'falcon') for f in ('sign', 'verify')] + ['sc_hip_kyber_kem_encaps_host', 'sc_hip_kyber_kem_decaps_host']
-SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('create', 'destroy', 'set_key', 'sig_bytes', 'sign_host', 'verify_host')]
+SYMBOLS += [f'sc_hip_multi_{k}_{f}' for k in ('bliss', 'tesla') for f in ('create', 'destroy', 'set_key', 'sig_bytes', 'sign_host', 'verify_host')] + ['sc_hip_multi_bliss_set_cdt_table']
 SYMBOLS += [f'sc_hip_multi_falcon_{f}' for f in ('create', 'destroy', 'set_privkey', 'set_pubkey', 'sig_bytes', 'sign_host', 'verify_host')]
 SYMBOLS += [f'sc_hip_multi_kyber_{f}' for f in ('create', 'destroy', 'set_pubkey', 'set_privkey', 'ct_bytes', 'kem_encaps_host', 'kem_decaps_host')]
 # include/sc_hip_bench.h (measurement / self-test hooks, not part of the drop-in ABI)
@@ -501,6 +501,14 @@ class MultiScheme:
         if self.h:
             self.f('destroy')(self.h)
             self.h = None
+
+    def set_cdt_table(self, precision_bits, table):
+        """BLISS-B: the reference context's own sampler table on every worker (64-bit entries, or [size][2 | 3] limbs of a 128- / 192-bit sampler)"""
+        import numpy as np
+        assert self.kind == 'bliss'
+        t = np.ascontiguousarray(np.asarray(table), dtype=np.uint64)
+        self.L.sc_hip_multi_bliss_set_cdt_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        _chk(self.L, self.L.sc_hip_multi_bliss_set_cdt_table(self.h, int(precision_bits), _ptr(t), t.size // (int(precision_bits) // 64)), 'multi_bliss_set_cdt_table')
 
     def set_key(self, *a, **kw):
         import numpy as np

@@ -95,3 +95,26 @@ def test_batch_vs_oracle_and_seeded_form(eng, G, tag, B):
         assert torch.equal(s64, r64[0]) and torch.equal(tr64, r64[2])
         b2.close()
     b.close()
+
+
+def test_multi_device_driver_with_the_128_bit_table(eng, G):
+    """sc_hip_multi_bliss_set_cdt_table: the fixture's messages over two workers, the reference's signatures"""
+    from libsafecrypto_amd import Multi
+    tag, nmsg = CASES[0]
+    key = O.BlissKey.from_golden(G, tag)
+    prec, size = (int(v) for v in G[f'{tag}_precision'])
+    table = np.asarray(G[f'{tag}_table'], dtype=np.uint64).reshape(size, prec // 64)
+    msgs = [bytes(G[f'{tag}_msg{m}'].astype(np.uint8)) for m in range(2, nmsg)]           # the 64-byte ones
+    tapes = [u32(G[f'{tag}_tape{m}']) for m in range(2, nmsg)]
+    W = max(len(t) for t in tapes) + 8
+    tb = np.zeros((len(msgs), W), dtype=np.uint32)
+    for i, t in enumerate(tapes):
+        tb[i, :len(t)] = t
+    mb = np.stack([np.frombuffer(m, dtype=np.uint8) for m in msgs])
+    m = Multi([0, 0])
+    h = m.scheme('bliss', key.par); h.set_key(key.f, key.g, key.a); h.set_cdt_table(prec, table)
+    s, l, t, st = h.sign_host(mb, 64, tb)
+    assert st.tolist() == [1] * len(msgs)
+    for i in range(len(msgs)):
+        assert bytes(s[i, :l[i]]) == bytes(G[f'{tag}_sig{i + 2}'].astype(np.uint8)) and int(t[i]) == int(G[f'{tag}_trials'][i + 2]), i
+    h.close(); m.close()
