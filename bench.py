@@ -782,6 +782,39 @@ def frac_violations(node, path='line'):
     return bad
 
 
+REQUIRED_KEYS = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline')
+
+
+def contract_line(res, limit=None):
+    """The contract line as a string below `limit` bytes WHATEVER the legs produced: optional blocks are dropped largest first, then the north-star blocks are cut
+    to their figures, then everything that is not a required key goes - a run never ends without its line because an optional block grew (the full tree is in
+    bench_extra.json either way).  `res` is not modified."""
+    import copy
+    limit = LINE_LIMIT if limit is None else limit
+    r = copy.deepcopy(res)
+    steps = [
+        lambda: [r.pop(k, None) for k in ('multi_gpu', 'frac_violations')],
+        lambda: [v.pop(k, None) for v in r.get('north_star', {}).values() if isinstance(v, dict) for k in ('roofline_verify', 'sign_ms', 'verify_ms', 'roofline_sign_tape_resident')],
+        lambda: [r.get('roofline', {}).pop('note', None), r.get('config', {}).pop('timing', None)],
+        lambda: [v.pop(k, None) for v in r.get('north_star', {}).values() if isinstance(v, dict) for k in list(v) if isinstance(v.get(k), (dict, list))],
+        lambda: [r.pop(k, None) for k in list(r) if k not in REQUIRED_KEYS and k != 'north_star'],
+        lambda: r.pop('north_star', None),
+        lambda: [r.__setitem__(k, {kk: vv for kk, vv in r[k].items() if not isinstance(vv, (dict, list, str)) or kk in ('workload', 'bound', 'unit', 'kind')}) for k in ('config', 'roofline', 'cpu_baseline') if isinstance(r.get(k), dict)],
+    ]
+    line = json.dumps(r)
+    dropped = 0
+    for step in steps:
+        if len(line) < limit:
+            break
+        step()
+        dropped += 1
+        if dropped and 'line_trimmed' not in r:
+            r['line_trimmed'] = True                                  # (says so: the reader goes to bench_extra.json for the rest)
+        line = json.dumps(r)
+    assert json.loads(line)['value'] == res['value'] and all(k in json.loads(line) for k in REQUIRED_KEYS if k in res)
+    return line
+
+
 LINE_LIMIT = 6000                # bytes: the driver parsed a 15.5 KB line in round 2 and failed on 27.7 KB in round 3; the contract line stays far below either
 
 
@@ -1043,16 +1076,7 @@ def main():
         except OSError as e:
             res['extra_file'] = f'not written: {e}'
         print(f'# full tree of every leg: {res["extra_file"]} ({len(full)} bytes)', flush=True)
-        line = json.dumps(res)
-        if len(line) >= LINE_LIMIT:                                  # never let the line outgrow the driver again: drop the optional blocks, largest first
-            for k in ('multi_gpu', 'frac_violations'):
-                res.pop(k, None)
-            for v in res.get('north_star', {}).values():
-                for k in ('roofline_verify', 'sign_ms', 'verify_ms', 'roofline_sign_tape_resident'):
-                    v.pop(k, None)
-            res['roofline'].pop('note', None); res['config'].pop('timing', None)
-            line = json.dumps(res)
-        assert len(line) < LINE_LIMIT and json.loads(line)['value'] == res['value'], f'contract line is {len(line)} bytes'
+        line = contract_line(res)
         print(line, flush=True)
     if world > 1:
         dist.barrier()
