@@ -44,10 +44,14 @@
 #include "utils/sampling/sampling.h"
 #include "utils/crypto/prng.h"
 
+/* SC_REF_SALT=<n> in the environment (0 / unset: the committed fixtures): every seeded stream of the driver - the messages' and inputs' generator, the entropy the
+ * contexts draw their keys from, the per-case CSPRNG seeds - is perturbed by it, so that `ref_driver all <dir>` writes an independently seeded set of fixtures of the
+ * same shape: other keys, other messages, other tapes (tests/test_oracle_fresh_fixtures.py holds the oracle to such a set as well) */
+static uint64_t g_salt;
 static uint64_t sm_state;
 static uint64_t splitmix64(void)
 {
-    uint64_t z = (sm_state += 0x9E3779B97F4A7C15ULL);
+    uint64_t z = (sm_state += 0x9E3779B97F4A7C15ULL) + g_salt * 0xD1342543DE82EF95ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     return z ^ (z >> 31);
@@ -241,7 +245,7 @@ static void fixed_domain(const char *name)
 static safecrypto_t *create_fixed(sc_scheme_e scheme, SINT32 set, const UINT32 *flags)
 {
     UINT32 fl[2] = { flags[0] | SC_FLAG_MORE, ((flags[0] & SC_FLAG_MORE) ? flags[1] : 0) | SC_FLAG_1_CSPRNG_USE_CALLBACK_RANDOM };
-    ent_state = ent_domain ^ ((uint64_t)(++ent_serial) * 0xD6E8FEB86659FD93ULL);
+    ent_state = ent_domain ^ ((uint64_t)(++ent_serial) * 0xD6E8FEB86659FD93ULL) ^ (g_salt * 0xA0761D6478BD642FULL);
     return safecrypto_create(scheme, set, fl);
 }
 
@@ -257,12 +261,21 @@ static prng_ctx_t *seeded_prng(const uint8_t *seed, size_t len)
     prng_init(ctx, NULL, 0);
     return ctx;
 }
+/* for the cases whose seed is a constant of this file (not recorded in the fixture): the salt goes into a copy */
+static prng_ctx_t *const_seeded_prng(const uint8_t *seed, size_t len)
+{
+    uint8_t salted[64];
+    if (!g_salt || len > sizeof salted) return seeded_prng(seed, len);
+    memcpy(salted, seed, len);
+    for (size_t i = 0; i < len && i < 8; i++) salted[i] ^= (uint8_t)((g_salt * 0x9E3779B97F4A7C15ULL) >> (8 * i));
+    return seeded_prng(salted, len);
+}
 
 static int cdt_case(FILE *f, float tail, float sigma, int nsamp, const char *tag)
 {
     static const uint8_t seed[32] = { 3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3, 2, 3, 8, 4, 6, 2, 6, 4, 3, 3, 8, 3, 2, 7, 9, 5 };
     char name[96];
-    prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32);
+    prng_ctx_t *p1 = const_seeded_prng(seed, 32), *p2 = const_seeded_prng(seed, 32);
     utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, NORMAL_SAMPLES, 512,
                                          SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
     if (!s) return 1;
@@ -290,7 +303,7 @@ static int cdt32_case(FILE *f, float tail, float sigma, int nsamp, const char *t
 {
     static const uint8_t seed[32] = { 2, 7, 1, 8, 2, 8, 1, 8, 2, 8, 4, 5, 9, 0, 4, 5, 2, 3, 5, 3, 6, 0, 2, 8, 7, 4, 7, 1, 3, 5, 2, 6 };
     char name[96];
-    prng_ctx_t *p1 = seeded_prng(seed, 32), *p2 = seeded_prng(seed, 32);
+    prng_ctx_t *p1 = const_seeded_prng(seed, 32), *p2 = const_seeded_prng(seed, 32);
     utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_32BIT, NORMAL_SAMPLES, 512, SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
     if (!s) return 1;
     const cdf32_view_t *g = (const cdf32_view_t *)s->gauss;
@@ -336,7 +349,7 @@ static int cdt_hp_case(FILE *f, int prec, float tail, float sigma, int nsamp, co
     uint8_t sd[32];
     memcpy(sd, seed, 32); sd[0] = (uint8_t)prec; sd[1] = (uint8_t)nsamp;
     const int W = prec / 64;
-    prng_ctx_t *p1 = seeded_prng(sd, 32), *p2 = seeded_prng(sd, 32), *p3 = seeded_prng(sd, 32);
+    prng_ctx_t *p1 = const_seeded_prng(sd, 32), *p2 = const_seeded_prng(sd, 32), *p3 = const_seeded_prng(sd, 32);
     utils_sampling_t *s64 = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, NORMAL_SAMPLES, 512, SAMPLING_DISABLE_BOOTSTRAP, p3, tail, sigma);
     utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, prec == 128 ? SAMPLING_128BIT : SAMPLING_192BIT, NORMAL_SAMPLES, 512,
                                          SAMPLING_DISABLE_BOOTSTRAP, p1, tail, sigma);
@@ -418,7 +431,7 @@ static int sampling_case(FILE *f, int blinding, unsigned discard, int n, int cen
     char name[96];
     uint8_t sd[32];
     memcpy(sd, seed, 32); sd[0] = (uint8_t)(blinding * 16 + discard); sd[1] = (uint8_t)n;
-    prng_ctx_t *p1 = seeded_prng(sd, 32), *p2 = seeded_prng(sd, 32);
+    prng_ctx_t *p1 = const_seeded_prng(sd, 32), *p2 = const_seeded_prng(sd, 32);
     utils_sampling_t *s = create_sampler(CDF_GAUSSIAN_SAMPLING, SAMPLING_64BIT, (sample_blinding_e)blinding, 512,
                                          SAMPLING_DISABLE_BOOTSTRAP, p1, 13.42f, 215.0f);
     if (!s) return 1;
@@ -2083,6 +2096,7 @@ int main(int argc, char **argv)
     if (argc == 5 && !strcmp(argv[1], "falcon_keys")) return falcon_keys(atoi(argv[2]), atoi(argv[3]), argv[4]);
     if (argc == 5 && !strcmp(argv[1], "bench")) return bench_ntt(atoi(argv[2]), atoi(argv[3]), atof(argv[4]));
     if (argc < 3) { fprintf(stderr, "usage: %s <ntt|cdt|cdt32|dilithium|bliss|bliss_huff|bliss_bac|kyber|falcon|ops|drbg|tesla|rlwe|ens|dlp|ensdlp|ensdlp_rec|mlwe_xof|cdt_hp|bliss_hp|all> <outdir>\n", argv[0]); return 2; }
+    if (getenv("SC_REF_SALT")) g_salt = strtoull(getenv("SC_REF_SALT"), NULL, 0);
     int all = !strcmp(argv[1], "all"), rc = 0;
     if (all || !strcmp(argv[1], "ntt")) { fixed_domain("ntt"); rc |= gen_ntt(argv[2]); }
     if (all || !strcmp(argv[1], "ntt_large")) { fixed_domain("ntt_large"); rc |= gen_ntt_large(argv[2]); }

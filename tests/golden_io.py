@@ -2,7 +2,8 @@
 import os
 import numpy as np
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+# SC_GOLDEN_DIR: another directory of fixtures of the same shape (tests/test_oracle_fresh_fixtures.py: a set the reference has just written from other seeds)
+GOLDEN_DIR = os.environ.get('SC_GOLDEN_DIR') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def load_golden(name):

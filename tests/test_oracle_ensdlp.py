@@ -2,6 +2,8 @@
 on tampered copies, and the oracle's signer (basis expansion, single-precision Gram-Schmidt, Klein sampler: orc_ensdlp_expand_basis / _gso /
 _sign) against the reference's matrices and its signatures byte for byte, given the same PRNG word tape
 (tests/golden/ensdlp_ref.txt, generator oracle/ref_driver.c)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -23,7 +25,9 @@ def test_verdicts_match_reference(G, tag, nmsg):
         msg = bytes(np.asarray(G[f'{tag}_msg{m}'], dtype=np.uint8))
         sig = bytearray(np.asarray(G[f'{tag}_sig{m}'], dtype=np.uint8))
         v = [int(x) for x in G[f'{tag}_verify'][3 * m:3 * m + 3]]
-        assert O.ensdlp_verify(par, h, msg, bytes(sig)) == v[0] == 0, m
+        assert O.ensdlp_verify(par, h, msg, bytes(sig)) == v[0], m        # the reference's verdict on its own signature ...
+        if not os.environ.get('SC_GOLDEN_DIR'):
+            assert v[0] == 0, m                                            # ... which is "valid" under the committed fixtures' keys (a key can make the reference reject them: tests/test_oracle_fresh_fixtures.py)
         sig[len(sig) // 2] ^= 0x01
         assert O.ensdlp_verify(par, h, msg, bytes(sig)) == v[1], m
         sig[len(sig) // 2] ^= 0x01; sig[3] ^= 0x80
