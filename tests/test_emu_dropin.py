@@ -32,3 +32,18 @@ def test_bliss_with_the_harness_128_bit_sampler_through_the_glue(tmp_path):
     names = ' | '.join(x['check'] for x in lines if 'check' in x)
     for must in ("signatures over the engine's tables == over the CPU tables", 'sc_hip_glue sign == safecrypto_sign from the same CSPRNG state', 'a batch of 16 through sc_hip_glue_sign_batch'):
         assert must in names, must
+
+
+def test_plain_c_host_on_the_cpu_build(tmp_path):
+    """examples/c_host.c (C99, no HIP headers, no Python in the process): the reference-shaped vtable and the batched host entries, the probe vectors SURVEY.md lists for the
+    reference - linked against the CPU build of the library under the product's name (tests/test_gpu_c_host.py is the same program on the device)"""
+    import shutil
+    gcc = shutil.which('gcc')
+    assert gcc, 'gcc not found'
+    so = build_library(None)
+    os.symlink(so, tmp_path / 'libsc_hip.so')
+    exe = str(tmp_path / 'c_host')
+    subprocess.check_call([gcc, '-std=c99', '-O2', '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'c_host.c'),
+                           '-L' + str(tmp_path), '-lsc_hip', '-Wl,-rpath,' + str(tmp_path), '-o', exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'all reference probe vectors reproduced' in r.stdout, r.stdout + r.stderr
