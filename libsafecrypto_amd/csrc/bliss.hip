@@ -432,8 +432,10 @@ extern "C" int sc_hip_bliss_set_cdt_table(sc_hip_bliss_t *b, const uint64_t *h_c
     if (!b || !h_cdf) return fail("bliss_set_cdt_table: null argument");
     sc_hip_cdt *cdt = nullptr;
     if (sc_hip_cdt_create_from_table(b->ctx, h_cdf, size, &cdt) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
-    HIPCHK(hipSetDevice(b->ctx->device));
-    HIPCHK(hipDeviceSynchronize());                                    // nothing in flight may still read the old table
+    if (hipSetDevice(b->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {      // nothing in flight may still read the old table
+        sc_hip_cdt_destroy(cdt);                                       // (the handle keeps the table it had)
+        return fail("bliss_set_cdt_table: device synchronisation failed");
+    }
     sc_hip_cdt_destroy(b->cdt);
     b->cdt = cdt;
     b->spw = 2;
@@ -446,8 +448,10 @@ extern "C" int sc_hip_bliss_set_cdt_table_hp(sc_hip_bliss_t *b, int precision_bi
     if (!b || !h_cdf) return fail("bliss_set_cdt_table_hp: null argument");
     sc_hip_cdt *cdt = nullptr;
     if (sc_hip_cdt_hp_create_from_table(b->ctx, precision_bits, h_cdf, size, &cdt) != SC_HIP_SUCCESS) return SC_HIP_FAILURE;
-    HIPCHK(hipSetDevice(b->ctx->device));
-    HIPCHK(hipDeviceSynchronize());
+    if (hipSetDevice(b->ctx->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        sc_hip_cdt_destroy(cdt);
+        return fail("bliss_set_cdt_table_hp: device synchronisation failed");
+    }
     sc_hip_cdt_destroy(b->cdt);
     b->cdt = cdt;
     b->spw = (uint32_t)(precision_bits / 32);

@@ -124,6 +124,32 @@ def sc_dilithium_load(sign=False):
     finally:
         eng.close()
 
+def sc_bliss_tables():
+    """the sampler-table setters of a BLISS-B handle: the reference's 64-bit table, then a 128-bit one and a 192-bit one, then back (a setter that fails keeps the table it had)"""
+    G = load_golden('bliss_hp_ref.txt'); C64 = load_golden('cdt_ref.txt')
+    key = O.BlissKey.from_golden(G, 'blisshp128_1')
+    t128 = np.asarray(G['blisshp128_1_table'], dtype=np.uint64); t192 = np.asarray(G['blisshp192_1_table'], dtype=np.uint64)
+    t64 = np.asarray(C64['bliss1_s215_t13.42_cdf'], dtype=np.uint64)
+    eng = Engine(0)
+    try:
+        b = eng.bliss(key.par)
+        try:
+            b.set_key(key.f, key.g, key.a)
+            b.set_cdt_table(t64)
+            b.set_cdt_table_hp(128, t128)
+            b.set_cdt_table_hp(192, t192)
+            b.set_cdt_table(t64)
+        finally:
+            b.close()
+        s = eng.sampler_hp(128, t128.reshape(-1, 2))
+        try:
+            x = np.asarray(load_golden('cdt_hp_ref.txt')['hp128_bliss1_s215_t13.42_words'], dtype=np.uint64)[:64].reshape(32, 2)
+            assert np.array_equal(s.sample(dev(x.view(np.int64), np.int64)).cpu().numpy(), O.cdt_hp_sample(x, t128.reshape(-1, 2), 2)), 'WRONG SAMPLES'
+        finally:
+            s.close()
+    finally:
+        eng.close()
+
 def sc_tesla_load():
     G = load_golden('tesla_ref.txt')
     key = O.TeslaKey.from_golden(G, 'tesla0')
@@ -225,7 +251,7 @@ def sc_multi():
     finally:
         m.close()
 
-SCEN = {'ntt': sc_ntt, 'dilithium_load': sc_dilithium_load, 'tesla_load': sc_tesla_load, 'dilithium': sc_dilithium, 'dilithium_tables': sc_dilithium_tables, 'kyber': sc_kyber, 'bliss': sc_bliss, 'tesla': sc_tesla, 'falcon': sc_falcon, 'multi': sc_multi}
+SCEN = {'ntt': sc_ntt, 'bliss_tables': sc_bliss_tables, 'dilithium_load': sc_dilithium_load, 'tesla_load': sc_tesla_load, 'dilithium': sc_dilithium, 'dilithium_tables': sc_dilithium_tables, 'kyber': sc_kyber, 'bliss': sc_bliss, 'tesla': sc_tesla, 'falcon': sc_falcon, 'multi': sc_multi}
 CLASSES = {0: 'alloc', 1: 'copy', 2: 'create', 3: 'pin'}
 report = {}
 for name in which:
@@ -277,7 +303,7 @@ print('FAULT SWEEP DONE')
 # the default suite: every call of every class for the scenarios whose faulted runs cost seconds; the signing calls of Dilithium and ring-TESLA cost 10 s and more
 # per run in the emulation - creation and key loading (where the tables of secrets are built) are swept here, the whole calls with SC_TEST_SLOW_EMU=1 (run in round 6
 # on the plain build: dilithium 66 + dilithium_tables 68 + tesla 46 faulted runs, every one a clean error, nothing left allocated)
-GROUPS = [['ntt', 'multi', 'dilithium_load'], ['bliss', 'falcon', 'tesla_load', 'kyber']]
+GROUPS = [['ntt', 'multi', 'dilithium_load', 'bliss_tables'], ['bliss', 'falcon', 'tesla_load', 'kyber']]
 SLOW_GROUPS = [['dilithium'], ['dilithium_tables'], ['tesla']]
 SLOW = os.environ.get('SC_TEST_SLOW_EMU') == '1'
 
