@@ -118,3 +118,29 @@ def test_multi_device_driver_with_the_128_bit_table(eng, G):
     for i in range(len(msgs)):
         assert bytes(s[i, :l[i]]) == bytes(G[f'{tag}_sig{i + 2}'].astype(np.uint8)) and int(t[i]) == int(G[f'{tag}_trials'][i + 2]), i
     h.close(); m.close()
+
+
+def test_full_config4_with_the_harness_sampler(eng, G):
+    """BASELINE config 3 shape as the reference's own harness creates it: BLISS-B-I, batch 16384, 64-byte messages, the sampler at 128 bits - everything signs (2 fresh
+    attempts of tape: 2 x 4 n W words), verifies; 350 strided signatures byte for byte against the oracle.  (Sized for the device: hours on the CPU build.)"""
+    import torch
+    tag = 'blisshp128_1'
+    key, b, W, table = open_key(eng, G, tag)
+    B, words = 16384, 2 * 4 * key.n * W + 64
+    g = torch.Generator(device='cuda'); g.manual_seed(13)
+    msgs = torch.randint(0, 256, (B, 64), dtype=torch.uint8, device='cuda', generator=g)
+    tapes = torch.randint(-2**31, 2**31 - 1, (B, words), dtype=torch.int32, device='cuda', generator=g)
+    sigs, siglens, trials, status = b.sign(msgs, tapes, fixed_len=64)
+    torch.cuda.synchronize()
+    ok = status == 1
+    assert int(ok.sum()) > B - 20
+    assert 1.1 < float(trials[ok].float().mean()) < 1.6
+    assert int(b.verify(msgs, sigs, siglens, fixed_len=64)[ok].sum()) == 0
+    mh, th, sh, lh = msgs.cpu().numpy(), tapes.cpu().numpy().view(np.uint32), sigs.cpu().numpy(), siglens.cpu().numpy()
+    st, tr = status.cpu().numpy(), trials.cpu().numpy()
+    for i in list(range(0, B, 47)) + [B - 1]:
+        rc, es, et, _ = O.bliss_sign_hp(key, bytes(mh[i]), th[i], table, W)
+        assert (rc == 0) == (st[i] == 1), i
+        if rc == 0:
+            assert bytes(sh[i, :lh[i]]) == es and int(tr[i]) == et, i
+    b.close()
