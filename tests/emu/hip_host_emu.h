@@ -9,7 +9,11 @@
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
+#include <deque>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <vector>
 #include <tuple>
 #include <utility>
 #include <type_traits>
@@ -39,7 +43,7 @@ static inline const char *hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize();
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof *p); strcpy(p->name, "MI355X (CPU emulation)"); strcpy(p->gcnArchName, "gfx950"); p->multiProcessorCount = EMU_CUS; p->totalGlobalMem = (size_t)1 << 34; p->sharedMemPerBlock = 160 * 1024; p->warpSize = 64; return hipSuccess; }
 static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int) { *v = a == hipDeviceAttributeMaxSharedMemoryPerBlock ? 160 * 1024 : a == hipDeviceAttributeMultiprocessorCount ? EMU_CUS : 0; return hipSuccess; }
 // ---- fault injection (tests/test_emu_faults.py): the (N+1)-th call from now of a class fails, once; live allocations are counted so that a failed call can be held to
@@ -70,28 +74,95 @@ template <typename T> static inline hipError_t hipMalloc(T **p, size_t n)
     emu::live_allocs.fetch_add(1, std::memory_order_relaxed);
     return hipSuccess;
 }
-static inline hipError_t hipFree(void *p) { if (p) emu::live_allocs.fetch_sub(1, std::memory_order_relaxed); free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p);
 template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
+static inline hipError_t hipHostFree(void *p);
 static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return emu::trip(3) ? hipErrorInvalidValue : hipSuccess; }
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { memset(a, 0, sizeof *a); return hipErrorInvalidValue; }      // "not a registered pointer"
 static inline hipError_t hipMemPtrGetInfo(void *, size_t *) { return hipErrorInvalidValue; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memmove(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memmove(d, s, n); return hipSuccess; }
+// ---- streams and events ---------------------------------------------------------------------------------------------------------------------------------
+// Default: every stream is the one in-order stream - work runs where it is issued.
+// EMU_SIDE_STREAMS=late (tests/test_emu_stream_order.py): an adversary for the library's fork / join logic.  Work issued to the NULL stream (the caller's: the tests read
+// results right behind a call, as a caller that synchronises its stream would) still runs at once; work issued to any OTHER stream - the streams the library creates for itself
+// - is QUEUED and runs only when something the HIP model says must wait for it asks: hipStreamWaitEvent on an event recorded behind it (at the moment the waiting stream's own
+// work reaches that point), hipEventSynchronize, hipStreamSynchronize, hipDeviceSynchronize, hipFree (a device-wide synchronisation), hipStreamDestroy.  A consumer on the
+// caller's stream that was not made to wait for its producer on a side stream therefore reads what was there BEFORE - and the test comparing the call's result with the
+// oracle fails; so does a synchronous hipMemcpy behind side-stream work that nobody joined (a non-blocking stream does not synchronise with the null stream).  What this
+// adversary cannot show is the opposite slip - side work started before its inputs are ready - since the caller's stream runs ahead here, not behind.
+struct EmuStream { std::deque<std::function<void()>> q; unsigned long long enq = 0, done = 0; bool blocking = true; };
+struct EmuEvent { EmuStream *s = nullptr; unsigned long long seq = 0; };
+namespace emu {
+inline const bool side_late = getenv("EMU_SIDE_STREAMS") && !strcmp(getenv("EMU_SIDE_STREAMS"), "late");
+inline std::recursive_mutex order_mu;                                   // (the multi-device driver issues from several host threads)
+inline std::vector<EmuStream *> all_streams;
+inline std::atomic<long> deferred_total{0};                              // items that ran later than they were issued (a run that reports 0 has exercised nothing)
+static inline void run_upto(EmuStream *s, unsigned long long seq)
+{
+    std::lock_guard<std::recursive_mutex> g(order_mu);
+    while (s && s->done < seq && !s->q.empty()) { std::function<void()> f = std::move(s->q.front()); s->q.pop_front(); s->done++; f(); }
+}
+static inline void flush_all() { std::lock_guard<std::recursive_mutex> g(order_mu); for (size_t i = 0; i < all_streams.size(); i++) run_upto(all_streams[i], all_streams[i]->enq); }
+// issue `f` to stream `st`: at once (null stream, or the default mode), or behind what the stream already holds
+template <typename F> static inline void issue(hipStream_t st, F &&f)
+{
+    if (!side_late || !st) { f(); return; }
+    std::lock_guard<std::recursive_mutex> g(order_mu);
+    st->q.emplace_back(std::forward<F>(f)); st->enq++;
+    deferred_total.fetch_add(1, std::memory_order_relaxed);
+}
+}  // namespace emu
+extern "C" __attribute__((weak, used, visibility("default"))) long sc_emu_deferred(void) { return emu::deferred_total.load(); }
+
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind kind, hipStream_t st = nullptr)
+{
+    if (emu::trip(1)) return hipErrorInvalidValue;
+    if (!n) return hipSuccess;
+    if (emu::side_late && st && kind == hipMemcpyHostToDevice) {         // a pageable source is staged before the call returns: what the copy delivers is what the host held NOW
+        auto buf = std::make_shared<std::vector<unsigned char>>((const unsigned char *)s, (const unsigned char *)s + n);
+        emu::issue(st, [d, buf]() { memcpy(d, buf->data(), buf->size()); });
+    } else emu::issue(st, [d, s, n]() { memmove(d, s, n); });
+    return hipSuccess;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t = nullptr) { for (size_t i = 0; i < count; i++) ((int *)d)[i] = v; return hipSuccess; }
-static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { if (emu::trip(2)) { *s = nullptr; return hipErrorOutOfMemory; } *s = (hipStream_t)malloc(8); emu::live_allocs.fetch_add(1); return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { if (s) emu::live_allocs.fetch_sub(1); free(s); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t *e) { if (emu::trip(2)) { *e = nullptr; return hipErrorOutOfMemory; } *e = (hipEvent_t)malloc(8); emu::live_allocs.fetch_add(1); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) emu::issue(st, [d, v, n]() { memset(d, v, n); }); return hipSuccess; }
+static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t st = nullptr) { emu::issue(st, [d, v, count]() { for (size_t i = 0; i < count; i++) ((int *)d)[i] = v; }); return hipSuccess; }
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags)
+{
+    if (emu::trip(2)) { *s = nullptr; return hipErrorOutOfMemory; }
+    EmuStream *st = new EmuStream; st->blocking = !(flags & hipStreamNonBlocking);
+    { std::lock_guard<std::recursive_mutex> g(emu::order_mu); emu::all_streams.push_back(st); }
+    *s = st; emu::live_allocs.fetch_add(1);
+    return hipSuccess;
+}
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { if (s) emu::run_upto(s, s->enq); return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s)
+{
+    if (!s) return hipSuccess;
+    emu::run_upto(s, s->enq);                                            // (the runtime lets a destroyed stream drain)
+    { std::lock_guard<std::recursive_mutex> g(emu::order_mu); for (size_t i = 0; i < emu::all_streams.size(); i++) if (emu::all_streams[i] == s) { emu::all_streams.erase(emu::all_streams.begin() + (long)i); break; } }
+    emu::live_allocs.fetch_sub(1); delete s;
+    return hipSuccess;
+}
+static inline hipError_t hipEventCreate(hipEvent_t *e) { if (emu::trip(2)) { *e = nullptr; return hipErrorOutOfMemory; } *e = new EmuEvent; emu::live_allocs.fetch_add(1); return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
-static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) emu::live_allocs.fetch_sub(1); free(e); return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 1.0f; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) { emu::live_allocs.fetch_sub(1); delete e; } return hipSuccess; }
+// an event stands for "everything issued to that stream so far"; a wait captures that point when it is issued (a later re-record does not move it)
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) { if (e) { std::lock_guard<std::recursive_mutex> g(emu::order_mu); e->s = s; e->seq = s ? s->enq : 0; } return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    if (!e || !emu::side_late) return hipSuccess;
+    EmuStream *es; unsigned long long seq;
+    { std::lock_guard<std::recursive_mutex> g(emu::order_mu); es = e->s; seq = e->seq; }
+    if (es) emu::issue(s, [es, seq]() { emu::run_upto(es, seq); });
+    return hipSuccess;
+}
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { if (e && e->s) emu::run_upto(e->s, e->seq); return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { hipEventSynchronize(a); hipEventSynchronize(b); *ms = 1.0f; return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { if (emu::side_late) emu::flush_all(); return hipSuccess; }
+static inline hipError_t hipFree(void *p) { if (emu::side_late) emu::flush_all(); if (p) emu::live_allocs.fetch_sub(1, std::memory_order_relaxed); free(p); return hipSuccess; }   // (hipFree synchronises the device)
+static inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 template <typename F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 template <typename F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, F, int, size_t) { *nb = 2; return hipSuccess; }
 static inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
@@ -135,5 +206,6 @@ template <typename F> static inline void launch_host(dim3 grid, dim3 block, size
 // called BY NAME inside the macro so that its default arguments and template-ids work as they do in a <<<>>> launch.
 template <typename... A> static inline std::tuple<std::decay_t<A>...> launch_args(A &&...a) { return std::tuple<std::decay_t<A>...>(std::forward<A>(a)...); }
 }  // namespace emu
-#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) do { const auto emu_launch_args = emu::launch_args(__VA_ARGS__); \
-    emu::launch_host(dim3(grid), dim3(block), (size_t)(lds), [&]() { std::apply([&](const auto &...emu_a) { kernel(emu_a...); }, emu_launch_args); }); } while (0)
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) do { const auto emu_launch_args = std::make_shared<decltype(emu::launch_args(__VA_ARGS__))>(emu::launch_args(__VA_ARGS__)); \
+    const dim3 emu_g = dim3(grid), emu_b = dim3(block); const size_t emu_l = (size_t)(lds); \
+    emu::issue((hipStream_t)(stream), [=]() { emu::launch_host(emu_g, emu_b, emu_l, [&]() { std::apply([&](const auto &...emu_a) { kernel(emu_a...); }, *emu_launch_args); }); }); } while (0)
