@@ -18,8 +18,32 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# ---- the CPU suite (`-m "not gpu"`) runs its files on several workers ---------------------------------------------------------------------------------------
+# Most of its time is emulation harnesses - children made of hundreds of threads that mostly wait on each other - and run one file after the other the suite takes ten
+# minutes; with pytest-xdist (installed in this image) and a file per worker at a time it takes about four.  Only for exactly that marker expression: a `-m gpu` run is
+# ONE process on ONE device and is never touched.  SC_TEST_SERIAL=1, an explicit -n or a missing xdist leave the run as it was typed.  (The emulation builds are
+# serialised per target: tests/emu_harness.py _BuildLock.)
+def _cpu_suite_workers(config):
+    if os.environ.get('SC_TEST_SERIAL') == '1' or hasattr(config, 'workerinput') or os.environ.get('PYTEST_XDIST_WORKER'):
+        return 0
+    opt = config.option
+    if getattr(opt, 'numprocesses', None) or getattr(opt, 'collectonly', False) or getattr(opt, 'usepdb', False) or getattr(opt, 'dist', 'no') != 'no':
+        return 0
+    if (getattr(opt, 'markexpr', '') or '').strip() != 'not gpu':
+        return 0
+    if not config.pluginmanager.hasplugin('xdist'):
+        return 0
+    return int(os.environ.get('SC_TEST_WORKERS', '4'))
+
+
+@pytest.hookimpl(tryfirst=True)
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    n = _cpu_suite_workers(config)
+    if n > 1:                                               # (ahead of xdist's own pytest_configure, which starts its session from these options)
+        config.option.numprocesses = n
+        config.option.dist = 'loadfile'
+        config.option.tx = ['popen'] * n
 
 
 # ---- emulation mode (tests/test_emu_library.py only): the `-m gpu` tests against the product library built for the CPU -------------------------------------

@@ -50,6 +50,24 @@ def _sources(dst, mutate=None, rewrites=()):
             f.write(text)
 
 
+class _BuildLock:
+    """one builder per target at a time (the CPU suite runs its files on several workers: two of them asking for the same library must not compile into the same directory)"""
+
+    def __init__(self, target):
+        self.path = target + '.lock'
+
+    def __enter__(self):
+        import fcntl
+        self.fh = open(self.path, 'w')
+        fcntl.flock(self.fh, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.fh, fcntl.LOCK_UN)
+        self.fh.close()
+
+
 def build(name, sanitize, mutate=None, out=None, rewrites=()):
     """tests/emu/<name>.cpp -> lib<name>_<sanitize>.so under tests/emu/_build (or `out`), rebuilt when a source is newer.  -O0: the run time is the threads'
     barriers either way, and the sanitizer builds of the larger harnesses take a minute at -O1"""
@@ -59,14 +77,17 @@ def build(name, sanitize, mutate=None, out=None, rewrites=()):
     so = os.path.join(out, f'lib{name}_{tag}.so')
     deps = [os.path.join(EMU, f'{name}.cpp'), os.path.join(EMU, 'wave_emu.h'), __file__] + glob.glob(os.path.join(EMU, 'shim', '*.h')) + \
            glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h'))
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        src = os.path.join(out, f'src_{name}_{tag}')
-        _sources(src, mutate, rewrites)
-        flags = ['-O0', '-g', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function',
-                 '-Wno-unused-variable', '-Wno-shift-count-negative', '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
-        if sanitize:
-            flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
-        subprocess.check_call([CLANG] + flags + ['-o', so, deps[0]])
+    with _BuildLock(so):
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            src = os.path.join(out, f'src_{name}_{tag}')
+            _sources(src, mutate, rewrites)
+            flags = ['-O0', '-g', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unknown-pragmas', '-Wno-keyword-macro', '-Wno-unused-function',
+                     '-Wno-unused-variable', '-Wno-shift-count-negative', '-I' + os.path.join(EMU, 'shim'), '-I' + EMU, '-I' + src]
+            if sanitize:
+                flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan']
+            tmp = so + f'.tmp{os.getpid()}'
+            subprocess.check_call([CLANG] + flags + ['-o', tmp, deps[0]])
+            os.replace(tmp, so)                                  # (a library in use elsewhere is replaced, never rewritten in place)
     return so
 
 
@@ -128,17 +149,25 @@ LIB_SOURCES = ['sc_hip.hip', 'dilithium.hip', 'kyber.hip', 'bliss.hip', 'falcon.
 
 def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
     """tests/emu/_build/libsc_hip_emu_<sanitize>.so: every source of csrc/Makefile compiled as host C++ (same rewrites as `build`), linked into one library with
-    the product's C ABI.  Rebuilt when a source is newer."""
-    from concurrent.futures import ThreadPoolExecutor
+    the product's C ABI.  Rebuilt when a source is newer; one builder at a time per library, and a library in use elsewhere is replaced, never rewritten in place."""
     out = os.path.join(EMU, '_build')
     os.makedirs(out, exist_ok=True)
     tag = (sanitize or 'plain').replace(',', '_') + (('_' + hashlib.sha1(repr(rewrites).encode()).hexdigest()[:8]) if rewrites else '')
+    if sanitize and os.environ.get('EMU_UBSAN_RECOVER'):          # triage: report every finding of a run instead of stopping at the first
+        tag += '_recover'
     so = os.path.join(out, f'libsc_hip_emu_{tag}.so')
     deps = [os.path.join(EMU, 'wave_emu.h'), os.path.join(EMU, 'hip_host_emu.h'), __file__] + glob.glob(os.path.join(EMU, 'shim', '*.h')) + \
            glob.glob(os.path.join(EMU, 'shim', 'hip', '*.h')) + glob.glob(os.path.join(CSRC, '*.h')) + [os.path.join(CSRC, f) for f in sources] + \
            glob.glob(os.path.join(ROOT, 'include', '*.h'))
-    if os.path.exists(so) and not any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        return so
+    with _BuildLock(so):
+        if os.path.exists(so) and not any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            return so
+        _build_library(so, tag, sanitize, rewrites, sources, jobs, out)
+    return so
+
+
+def _build_library(so, tag, sanitize, rewrites, sources, jobs, out):
+    from concurrent.futures import ThreadPoolExecutor
     src = os.path.join(out, f'src_lib_{tag}')
     _sources(src, None, rewrites)
     os.makedirs(os.path.join(src, 'inc'), exist_ok=True)
@@ -151,11 +180,8 @@ def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
         # (float-cast-overflow off: the CDT table builder converts a long double that has reached 2^64 to a 64-bit integer and tests for 0, as the reference's does
         # (gaussian_cdf.c:598-602) - undefined as C, 0 from both compilers on x86-64, and the table has to be the reference's)
         flags += ['-fsanitize=' + sanitize, '-fno-omit-frame-pointer', '-fno-sanitize-recover=all', '-shared-libsan'] + (['-fno-sanitize=float-cast-overflow'] if 'undefined' in sanitize else [])
-        if os.environ.get('EMU_UBSAN_RECOVER'):          # triage: report every finding of a run instead of stopping at the first
+        if os.environ.get('EMU_UBSAN_RECOVER'):
             flags += ['-fsanitize-recover=undefined']
-            tag += '_recover'
-            so = os.path.join(out, f'libsc_hip_emu_{tag}.so')
-    objs = []
 
     def one(f):
         text = DYN_LDS.sub(lambda m: f'{m.group(1)} *const {m.group(2)} = reinterpret_cast<{m.group(1)} *>(emu::dyn_lds);', open(os.path.join(CSRC, f)).read())
@@ -171,5 +197,6 @@ def build_library(sanitize, rewrites=LIB_REWRITES, sources=LIB_SOURCES, jobs=4):
 
     with ThreadPoolExecutor(max_workers=jobs) as ex:
         objs = list(ex.map(one, sources))
-    subprocess.check_call([CLANG, '-shared', '-pthread'] + (['-fsanitize=' + sanitize, '-shared-libsan'] if sanitize else []) + ['-o', so] + objs)
-    return so
+    tmp = so + f'.tmp{os.getpid()}'
+    subprocess.check_call([CLANG, '-shared', '-pthread'] + (['-fsanitize=' + sanitize, '-shared-libsan'] if sanitize else []) + ['-o', tmp] + objs)
+    os.replace(tmp, so)

@@ -1,7 +1,8 @@
 #!/bin/bash
 # The whole `-m gpu` suite against the product library built for the CPU (tests/emu_harness.py build_library: host code + kernels over tests/emu/hip_host_emu.h,
 # a host thread per lane; tests/conftest.py SC_EMU_LIB points the binding at it and torch's "cuda" at the CPU).  Test infrastructure - about an hour on 8 cores.
-#   tools/emu_gpu_suite.sh [plain|asan]      ->  gpurun_out/emu_suite/<kind>.txt ; copy the summary under profiles/ to keep it
+#   tools/emu_gpu_suite.sh [plain|asan|late]      ->  gpurun_out/emu_suite/<kind>.txt ; copy the summary under profiles/ to keep it
+# late: the plain build with EMU_SIDE_STREAMS=late - work on the library's own streams held back as long as the HIP model allows (tests/test_emu_stream_order.py)
 # Deselected: what only means something on the device (the bench line, a C host linked against the device library, the glue over the reference's own build,
 # graph capture, two ranks sharing a device) - and listed at the end of the output: the tests that did not finish inside the per-test limit (the full
 # BASELINE batches: a 16384-message signing call is days of emulation).
@@ -15,6 +16,7 @@ from tests import emu_harness as H
 print(H.build_library('$SAN' or None))" | tail -1)
 mkdir -p gpurun_out/emu_suite
 ENVV="SC_EMU_LIB=$LIB"
+[ "$KIND" = late ] && ENVV="$ENVV EMU_SIDE_STREAMS=late"
 if [ -n "$SAN" ]; then
   CL=/opt/rocm/lib/llvm/bin/clang++
   ENVV="$ENVV LD_PRELOAD=$($CL -print-file-name=libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1"
