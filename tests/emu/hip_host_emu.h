@@ -81,21 +81,26 @@ static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return emu:
 static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
 static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *) { memset(a, 0, sizeof *a); return hipErrorInvalidValue; }      // "not a registered pointer"
 static inline hipError_t hipMemPtrGetInfo(void *, size_t *) { return hipErrorInvalidValue; }
-static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind);
 // ---- streams and events ---------------------------------------------------------------------------------------------------------------------------------
 // Default: every stream is the one in-order stream - work runs where it is issued.
-// EMU_SIDE_STREAMS=late (tests/test_emu_stream_order.py): an adversary for the library's fork / join logic.  Work issued to the NULL stream (the caller's: the tests read
-// results right behind a call, as a caller that synchronises its stream would) still runs at once; work issued to any OTHER stream - the streams the library creates for itself
-// - is QUEUED and runs only when something the HIP model says must wait for it asks: hipStreamWaitEvent on an event recorded behind it (at the moment the waiting stream's own
-// work reaches that point), hipEventSynchronize, hipStreamSynchronize, hipDeviceSynchronize, hipFree (a device-wide synchronisation), hipStreamDestroy.  A consumer on the
-// caller's stream that was not made to wait for its producer on a side stream therefore reads what was there BEFORE - and the test comparing the call's result with the
-// oracle fails; so does a synchronous hipMemcpy behind side-stream work that nobody joined (a non-blocking stream does not synchronise with the null stream).  What this
-// adversary cannot show is the opposite slip - side work started before its inputs are ready - since the caller's stream runs ahead here, not behind.
+// EMU_SIDE_STREAMS (tests/test_emu_stream_order.py): two adversaries for the library's fork / join logic.
+//   late      - work issued to the NULL stream (the caller's: the tests read results right behind a call, as a caller that synchronises its stream would) runs at once;
+//               work issued to any OTHER stream - the streams the library creates for itself - is QUEUED and runs only when something the HIP model says must wait for it
+//               asks: hipStreamWaitEvent on an event recorded behind it (when the waiting stream's own work reaches that point), hipEventSynchronize,
+//               hipStreamSynchronize, hipDeviceSynchronize, hipFree (a device-wide synchronisation), hipStreamDestroy.  A consumer on the caller's stream that was not made
+//               to wait for its producer on a side stream reads what was there BEFORE (a missing JOIN) - and so does a synchronous hipMemcpy behind unjoined side work
+//               (a non-blocking stream does not synchronise with the null stream).
+//   null-late - the other way round: the caller's stream is the one held back (until a synchronisation of it or of the device, a synchronous copy, hipFree, or an event
+//               wait issued to a side stream that names a point on it) and the library's own streams run at once - side work that was not made to wait for the caller's
+//               earlier work reads its inputs before they are written (a missing FORK).  The caller has to synchronise before it reads (sc_emu_sync).
 struct EmuStream { std::deque<std::function<void()>> q; unsigned long long enq = 0, done = 0; bool blocking = true; };
 struct EmuEvent { EmuStream *s = nullptr; unsigned long long seq = 0; };
 namespace emu {
-inline const bool side_late = getenv("EMU_SIDE_STREAMS") && !strcmp(getenv("EMU_SIDE_STREAMS"), "late");
+inline const int stream_mode = !getenv("EMU_SIDE_STREAMS") ? 0 : !strcmp(getenv("EMU_SIDE_STREAMS"), "late") ? 1 : !strcmp(getenv("EMU_SIDE_STREAMS"), "null-late") ? 2 : 0;
+inline const bool side_late = stream_mode != 0;                          // (either adversary: streams are real queues)
 inline std::recursive_mutex order_mu;                                   // (the multi-device driver issues from several host threads)
+inline EmuStream null_stream;
 inline std::vector<EmuStream *> all_streams;
 inline std::atomic<long> deferred_total{0};                              // items that ran later than they were issued (a run that reports 0 has exercised nothing)
 static inline void run_upto(EmuStream *s, unsigned long long seq)
@@ -103,29 +108,39 @@ static inline void run_upto(EmuStream *s, unsigned long long seq)
     std::lock_guard<std::recursive_mutex> g(order_mu);
     while (s && s->done < seq && !s->q.empty()) { std::function<void()> f = std::move(s->q.front()); s->q.pop_front(); s->done++; f(); }
 }
-static inline void flush_all() { std::lock_guard<std::recursive_mutex> g(order_mu); for (size_t i = 0; i < all_streams.size(); i++) run_upto(all_streams[i], all_streams[i]->enq); }
-// issue `f` to stream `st`: at once (null stream, or the default mode), or behind what the stream already holds
+static inline void flush_all()
+{
+    std::lock_guard<std::recursive_mutex> g(order_mu);
+    run_upto(&null_stream, null_stream.enq);
+    for (size_t i = 0; i < all_streams.size(); i++) run_upto(all_streams[i], all_streams[i]->enq);
+    run_upto(&null_stream, null_stream.enq);
+}
+static inline bool held(hipStream_t st) { return stream_mode == 1 ? st != nullptr : stream_mode == 2 ? st == nullptr : false; }
+// issue `f` to stream `st`: at once, or behind what the stream already holds
 template <typename F> static inline void issue(hipStream_t st, F &&f)
 {
-    if (!side_late || !st) { f(); return; }
+    if (!held(st)) { f(); return; }
     std::lock_guard<std::recursive_mutex> g(order_mu);
-    st->q.emplace_back(std::forward<F>(f)); st->enq++;
+    EmuStream *s = st ? st : &null_stream;
+    s->q.emplace_back(std::forward<F>(f)); s->enq++;
     deferred_total.fetch_add(1, std::memory_order_relaxed);
 }
 }  // namespace emu
 extern "C" __attribute__((weak, used, visibility("default"))) long sc_emu_deferred(void) { return emu::deferred_total.load(); }
+extern "C" __attribute__((weak, used, visibility("default"))) void sc_emu_sync(void) { if (emu::side_late) emu::flush_all(); }     // what a caller's hipDeviceSynchronize would do
 
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind kind, hipStream_t st = nullptr)
 {
     if (emu::trip(1)) return hipErrorInvalidValue;
     if (!n) return hipSuccess;
-    if (emu::side_late && st && kind == hipMemcpyHostToDevice) {         // a pageable source is staged before the call returns: what the copy delivers is what the host held NOW
+    if (emu::held(st) && kind == hipMemcpyHostToDevice) {         // a pageable source is staged before the call returns: what the copy delivers is what the host held NOW
         auto buf = std::make_shared<std::vector<unsigned char>>((const unsigned char *)s, (const unsigned char *)s + n);
         emu::issue(st, [d, buf]() { memcpy(d, buf->data(), buf->size()); });
     } else emu::issue(st, [d, s, n]() { memmove(d, s, n); });
     return hipSuccess;
 }
-static inline hipError_t hipMemset(void *d, int v, size_t n) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (emu::trip(1)) return hipErrorInvalidValue; if (emu::stream_mode == 2) emu::run_upto(&emu::null_stream, emu::null_stream.enq); if (n) memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void *d, int v, size_t n) { if (emu::trip(1)) return hipErrorInvalidValue; if (emu::stream_mode == 2) emu::run_upto(&emu::null_stream, emu::null_stream.enq); if (n) memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = nullptr) { if (emu::trip(1)) return hipErrorInvalidValue; if (n) emu::issue(st, [d, v, n]() { memset(d, v, n); }); return hipSuccess; }
 static inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t st = nullptr) { emu::issue(st, [d, v, count]() { for (size_t i = 0; i < count; i++) ((int *)d)[i] = v; }); return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags)
@@ -136,7 +151,7 @@ static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags
     *s = st; emu::live_allocs.fetch_add(1);
     return hipSuccess;
 }
-static inline hipError_t hipStreamSynchronize(hipStream_t s) { if (s) emu::run_upto(s, s->enq); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { EmuStream *q = s ? s : &emu::null_stream; emu::run_upto(q, q->enq); return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s)
 {
     if (!s) return hipSuccess;
@@ -149,7 +164,7 @@ static inline hipError_t hipEventCreate(hipEvent_t *e) { if (emu::trip(2)) { *e 
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { if (e) { emu::live_allocs.fetch_sub(1); delete e; } return hipSuccess; }
 // an event stands for "everything issued to that stream so far"; a wait captures that point when it is issued (a later re-record does not move it)
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) { if (e) { std::lock_guard<std::recursive_mutex> g(emu::order_mu); e->s = s; e->seq = s ? s->enq : 0; } return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr) { if (e) { std::lock_guard<std::recursive_mutex> g(emu::order_mu); e->s = s ? s : &emu::null_stream; e->seq = e->s->enq; } return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
 {
     if (!e || !emu::side_late) return hipSuccess;

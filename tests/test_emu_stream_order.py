@@ -29,6 +29,7 @@ from tests.golden_io import load_golden
 
 L = E.load_library()
 L.sc_emu_deferred.restype = C.c_long
+sync = L.sc_emu_sync                                             # what a caller's hipDeviceSynchronize does: before every read of a result (the null-late adversary holds the caller's stream back)
 dev = lambda a, dt=np.int32: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).cuda()
 
 
@@ -54,11 +55,18 @@ def sc_kyber_keys(eng):
     rng = np.random.default_rng(41)
     B = 3
     seeds = dev(rng.integers(0, 256, size=(B, 32), dtype=np.uint8), np.uint8)
-    s_ntt, t, t_ntt, rho, z = ky.keygen(seeds)
     m = rng.integers(0, 256, size=(B, 32), dtype=np.uint8)
+    md = dev(m, np.uint8)                                        # (inputs stay referenced until the synchronisation: torch's allocator does that for a caller on the device)
     for _ in range(2):                                           # twice: the second call finds the handle's stream and events already there
-        ct, keys = ky.encaps_keys(t, t_ntt, rho, dev(m, np.uint8))
+        s_ntt, t, t_ntt, rho0, z = ky.keygen(seeds)
+        sync()
+        # rho reaches the calls through one more kernel on the caller's stream, with no synchronisation behind it: it is still being written when the matrices' stream
+        # is forked (the key generation itself ends in a hipFree, which synchronises the device)
+        rho_in, zero = rho0.view(torch.int32), torch.zeros(B * 8, dtype=torch.int32, device=rho0.device).view(B, 8)     # (referenced until the synchronisation below)
+        rho = eng.poly_add(rho_in, zero).view(torch.uint8)
+        ct, keys = ky.encaps_keys(t, t_ntt, rho, md)
         dk = ky.decaps_keys(s_ntt, t, t_ntt, rho, ct)
+        sync()
         assert torch.equal(dk, keys)
         sh, th, tnh, rh, cth, kh = (x.cpu().numpy() for x in (s_ntt, t, t_ntt, rho, ct, keys))
         for i in range(B):
@@ -79,6 +87,7 @@ def sc_dilithium_keys(eng):
     msgs = dev(rng.integers(0, 256, size=(B, 64), dtype=np.uint8), np.uint8)
     s1, s2, t, rho, K, tr, t1 = d.keygen(seeds, eb)
     sigs, siglens = d.sign_keys(s1, s2, t, rho, K, tr, msgs, fixed_len=64)[:2]
+    sync()
     h = lambda x: x.cpu().numpy()
     for i in range(B):
         Ahat = O.expand_matrix(h(rho)[i], int(par[3]) * int(par[4]), int(par[1]), int(par[2]))
@@ -87,9 +96,11 @@ def sc_dilithium_keys(eng):
         assert bytes(h(sigs)[i, :int(siglens[i])]) == want, i
     t1f = t1.reshape(B, -1).contiguous()
     for _ in range(2):
-        assert d.verify_keys(t1f, rho, msgs, sigs, siglens, fixed_len=64).cpu().tolist() == [0] * B
+        v = d.verify_keys(t1f, rho, msgs, sigs, siglens, fixed_len=64); sync()
+        assert v.cpu().tolist() == [0] * B
     bad = sigs.clone(); bad[0, 40] ^= 1
-    assert d.verify_keys(t1f, rho, msgs, bad, siglens, fixed_len=64).cpu().tolist() == [1, 0]
+    v = d.verify_keys(t1f, rho, msgs, bad, siglens, fixed_len=64); sync()
+    assert v.cpu().tolist() == [1, 0]
     d.close()
 
 
@@ -107,10 +118,14 @@ def sc_dilithium_verify_keys(eng):
         mb[i, :len(msgs[i])] = np.frombuffer(msgs[i], dtype=np.uint8); sb[i, :sg[i].size] = sg[i]
     ml = dev(np.array([len(m) for m in msgs], dtype=np.int32)); sl = dev(np.array([x.size for x in sg], dtype=np.int32))
     t1 = dev(np.tile(G[f'{tag}_t1'].astype(np.int32), (B, 1))); rho = dev(np.tile(G[f'{tag}_rho'].astype(np.uint8), (B, 1)), np.uint8)
+    mbd, sbd = dev(mb, np.uint8), dev(sb, np.uint8)
     for _ in range(2):
-        assert d.verify_keys(t1, rho, dev(mb, np.uint8), dev(sb, np.uint8), sl, mlens=ml).cpu().tolist() == [0] * B
+        v = d.verify_keys(t1, rho, mbd, sbd, sl, mlens=ml); sync()
+        assert v.cpu().tolist() == [0] * B
     bad = sb.copy(); bad[1, 40] ^= 1
-    assert d.verify_keys(t1, rho, dev(mb, np.uint8), dev(bad, np.uint8), sl, mlens=ml).cpu().tolist() == [0, 1, 0]
+    badd = dev(bad, np.uint8)
+    v = d.verify_keys(t1, rho, mbd, badd, sl, mlens=ml); sync()
+    assert v.cpu().tolist() == [0, 1, 0]
     d.close()
 
 
@@ -122,14 +137,17 @@ def sc_falcon_seeded(eng):
     f.set_privkey(key.sk); f.set_pubkey(key.h)
     rng = np.random.default_rng(9)
     B = 2
-    seeds = dev(rng.integers(0, 256, size=(B, 48), dtype=np.uint8), np.uint8)
+    seed0 = dev(rng.integers(0, 256, size=(B, 32), dtype=np.uint8), np.uint8)
     msgs = dev(rng.integers(0, 256, size=(B, 64), dtype=np.uint8), np.uint8)
+    seeds = eng.drbg_mem(seed0, 48); sync()
     tapes = eng.drbg_words(seeds, 4 * f.n)
-    s0, l0, st0 = f.sign(msgs, tapes, fixed_len=64)
+    s0, l0, st0 = f.sign(msgs, tapes, fixed_len=64); sync()
     for _ in range(2):
-        s1, l1, st1 = f.sign_seeded(msgs, seeds, fixed_len=64)
+        seeds2 = eng.drbg_mem(seed0, 48)                         # (the seeds are still being written on the caller's stream when the tape expansion's stream is forked)
+        s1, l1, st1 = f.sign_seeded(msgs, seeds2, fixed_len=64); sync()
         assert torch.equal(st0, st1) and torch.equal(l0, l1) and torch.equal(s0, s1)
-    assert f.verify(msgs, s1, l1, fixed_len=64)[st1 == 1].sum() == 0
+    v = f.verify(msgs, s1, l1, fixed_len=64); sync()
+    assert v[st1 == 1].sum() == 0
     f.close()
 
 
@@ -141,7 +159,7 @@ for name in which:
     eng.close()
     held = L.sc_emu_deferred() - before
     print('STREAM ORDER', name, held, flush=True)
-    assert held > 0 or os.environ.get('EMU_SIDE_STREAMS') != 'late', (name, 'nothing was held back: the scenario does not reach a stream of the library')
+    assert held > 0 or os.environ.get('EMU_SIDE_STREAMS') not in ('late', 'null-late'), (name, 'nothing was held back: the scenario does not reach a stream of the library')
 print('STREAM ORDER DONE')
 '''
 
@@ -150,12 +168,13 @@ SLOW_GROUPS = [['dilithium_keys']]                        # key generation, sign
 
 
 def run(groups, late, sanitize='address,undefined', timeout=2400):
+    """late: True / 'late' - the library's own streams held back; 'null-late' - the caller's stream held back; False - streams in issue order"""
     from concurrent.futures import ThreadPoolExecutor
     import subprocess
     so = build_library(sanitize)
     env = sanitizer_env(sanitize)
     if late:
-        env['EMU_SIDE_STREAMS'] = 'late'
+        env['EMU_SIDE_STREAMS'] = late if isinstance(late, str) else 'late'
     from tests.emu_harness import ROOT
 
     def one(g):
@@ -174,30 +193,44 @@ def test_results_do_not_depend_on_how_late_the_library_s_own_streams_run():
     assert set(held) == {n for g in GROUPS for n in g} and all(v > 0 for v in held.values()), held
 
 
+def test_results_do_not_depend_on_how_late_the_caller_s_stream_runs():
+    """the other adversary: the caller's stream held back, the library's own streams at once - side work that is not made to wait for the caller's earlier work (a missing
+    fork) reads its inputs before they are written"""
+    groups = [[n for n in g if n != 'host_entries'] for g in GROUPS]          # (the *_host entries issue nothing to the caller's stream: there is nothing of theirs to hold back)
+    held = run(groups, late='null-late')
+    assert set(held) == {n for g in groups for n in g} and all(v > 0 for v in held.values()), held
+
+
 @pytest.mark.skipif(os.environ.get('SC_TEST_SLOW_EMU') != '1', reason='Dilithium key generation + signing + verification with a key per message under the adversary: ten minutes (SC_TEST_SLOW_EMU=1)')
 def test_the_same_through_dilithium_signing_with_a_key_per_message():
     held = run(SLOW_GROUPS, late=True, timeout=5400)
     assert all(v > 0 for v in held.values()), held
 
 
-MUTANTS = {'kyber': (('kyber.hip', 'if (K.ready) HIPCHK(hipStreamWaitEvent(s, K.ready, 0));', '', 1), 'kyber_keys'),
-           'falcon': (('falcon.hip', 'if (tapes_ready) HIPCHK(hipStreamWaitEvent(s, tapes_ready, 0));', '', 1), 'falcon_seeded')}
+MUTANTS = {'kyber': (('kyber.hip', 'if (K.ready) HIPCHK(hipStreamWaitEvent(s, K.ready, 0));', '', 1), 'kyber_keys', 'late'),
+           'falcon': (('falcon.hip', 'if (tapes_ready) HIPCHK(hipStreamWaitEvent(s, tapes_ready, 0));', '', 1), 'falcon_seeded', 'late'),
+           'kyber_fork': (('kyber.hip', 'HIPCHK(hipStreamWaitEvent(h->side, h->ev_fork, 0));', '', 1), 'kyber_keys', 'null-late'),
+           'falcon_fork': (('falcon.hip', 'HIPCHK(hipStreamWaitEvent(f->side, f->ev_fork, 0));', '', 1), 'falcon_seeded', 'null-late')}
 
 
-@pytest.mark.parametrize('what', [pytest.param('kyber'), pytest.param('falcon', marks=pytest.mark.skipif(os.environ.get('SC_TEST_SLOW_EMU') != '1', reason='the second mutant: SC_TEST_SLOW_EMU=1 (run in round 6: noticed)'))])
+_slow = pytest.mark.skipif(os.environ.get('SC_TEST_SLOW_EMU') != '1', reason='further mutants: SC_TEST_SLOW_EMU=1 (run in round 6: each noticed)')
+
+
+@pytest.mark.parametrize('what', [pytest.param('kyber'), pytest.param('kyber_fork'), pytest.param('falcon', marks=_slow), pytest.param('falcon_fork', marks=_slow)])
 def test_the_adversary_notices_a_removed_join(what):
-    """the harness itself: a copy of the library with ONE join taken out - the caller's stream no longer waits for the matrices (Kyber, a key per item) / the tapes
-    (Falcon, seeded) being written on the handle's own stream - gives wrong results when that stream runs late, and passes when streams run in issue order (as it would,
-    most of the time, on the device)"""
+    """the harness itself: a copy of the library with ONE wait taken out - a JOIN (the caller's stream no longer waits for the matrices of Kyber's keys / the tapes of the
+    seeded Falcon signer being written on the handle's own stream: noticed when that stream runs late) or a FORK (the handle's stream no longer waits for what the caller
+    queued before - the keys' rho, the seeds - : noticed when the caller's stream runs late) - gives wrong results under the matching adversary, and passes when streams
+    run in issue order (as it would, most of the time, on the device)"""
     import subprocess
     from tests.emu_harness import LIB_REWRITES, ROOT
-    rw, scen = MUTANTS[what]
+    rw, scen, mode = MUTANTS[what]
     so = build_library(None, rewrites=LIB_REWRITES + (rw,))
     res = {}
-    for late in (True, False):
+    for late in (mode, None):
         env = sanitizer_env(None)
         if late:
-            env['EMU_SIDE_STREAMS'] = 'late'
+            env['EMU_SIDE_STREAMS'] = late
         res[late] = subprocess.run(['python3', '-c', DRIVER, ROOT, so, scen], env=env, capture_output=True, text=True, timeout=1200)
-    assert res[False].returncode == 0 and 'STREAM ORDER DONE' in res[False].stdout, res[False].stderr[-2000:]
-    assert res[True].returncode != 0 and 'AssertionError' in res[True].stderr, (res[True].stdout[-500:], res[True].stderr[-1500:])
+    assert res[None].returncode == 0 and 'STREAM ORDER DONE' in res[None].stdout, res[None].stderr[-2000:]
+    assert res[mode].returncode != 0 and 'AssertionError' in res[mode].stderr, (res[mode].stdout[-500:], res[mode].stderr[-1500:])
