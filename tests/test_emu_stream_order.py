@@ -6,7 +6,8 @@ library runs with every such stream held back as long as the HIP model allows: w
 stream, a stream / event / device synchronisation or hipFree (a device-wide synchronisation) forces it, while the caller's stream runs at once - so a consumer that was
 not made to wait for its producer reads what was there before, and the comparison with the oracle fails.  Every scenario also asserts that work WAS held back
 (sc_emu_deferred): a run in which nothing was deferred has shown nothing.  Under ASan + UBSan, so that held-back work touching a buffer freed in the meantime is a report.
-What this cannot show: side work started too EARLY (the caller's stream runs ahead here); DESIGN.md 2."""
+EMU_SIDE_STREAMS=null-late is the adversary for the other slip - the caller's stream held back, the library's own at once: side work not made to wait for what the
+caller queued before (a missing fork) reads its inputs before they are written.  Both adversaries are shown to work on copies of the library with one wait removed.  DESIGN.md 2."""
 import os
 import re
 
