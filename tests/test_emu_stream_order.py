@@ -47,6 +47,20 @@ def sc_host_entries(eng):
     p.close()
 
 
+def sc_multi(eng):
+    """the multi-device driver: two worker threads, each moving its slice through the *_host ring of streams of its own context"""
+    from libsafecrypto_amd import Multi
+    q, n = 7681, 256
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, q, size=(7, n)).astype(np.int32); b = rng.integers(0, q, size=(7, n)).astype(np.int32)
+    w, r = O.tables(q, n)
+    m = Multi([0, 0])
+    assert np.array_equal(m.polymul_ntt_host(q, a, b), O.polymul_ntt(a, b, q, w, r))
+    f = m.ntt_host(q, a)
+    assert np.array_equal(f, O.fwd_ntt(a, q, w)) and np.array_equal(m.ntt_host(q, f, inverse=True), a)
+    m.close()
+
+
 def sc_kyber_keys(eng):
     """sc_hip_kyber_kem_encaps_keys / _decaps_keys: every key's matrix expanded on a stream of the handle's own beside the hashing"""
     G = load_golden('kyber_ref.txt'); tag = 'kyber0'
@@ -152,7 +166,7 @@ def sc_falcon_seeded(eng):
     f.close()
 
 
-SCEN = {'host_entries': sc_host_entries, 'dilithium_verify_keys': sc_dilithium_verify_keys, 'kyber_keys': sc_kyber_keys, 'dilithium_keys': sc_dilithium_keys, 'falcon_seeded': sc_falcon_seeded}
+SCEN = {'host_entries': sc_host_entries, 'multi': sc_multi, 'dilithium_verify_keys': sc_dilithium_verify_keys, 'kyber_keys': sc_kyber_keys, 'dilithium_keys': sc_dilithium_keys, 'falcon_seeded': sc_falcon_seeded}
 for name in which:
     eng = Engine(0)
     before = L.sc_emu_deferred()
@@ -164,7 +178,7 @@ for name in which:
 print('STREAM ORDER DONE')
 '''
 
-GROUPS = [['host_entries', 'kyber_keys', 'falcon_seeded'], ['dilithium_verify_keys']]
+GROUPS = [['host_entries', 'multi', 'kyber_keys', 'falcon_seeded'], ['dilithium_verify_keys']]
 SLOW_GROUPS = [['dilithium_keys']]                        # key generation, signing and verification with a key per message: ten minutes under ASan (SC_TEST_SLOW_EMU=1; run in round 6: passes)
 
 
@@ -197,7 +211,7 @@ def test_results_do_not_depend_on_how_late_the_library_s_own_streams_run():
 def test_results_do_not_depend_on_how_late_the_caller_s_stream_runs():
     """the other adversary: the caller's stream held back, the library's own streams at once - side work that is not made to wait for the caller's earlier work (a missing
     fork) reads its inputs before they are written"""
-    groups = [[n for n in g if n != 'host_entries'] for g in GROUPS]          # (the *_host entries issue nothing to the caller's stream: there is nothing of theirs to hold back)
+    groups = [[n for n in g if n not in ('host_entries', 'multi')] for g in GROUPS]          # (the *_host entries issue nothing to the caller's stream: there is nothing of theirs to hold back)
     held = run(groups, late='null-late')
     assert set(held) == {n for g in groups for n in g} and all(v > 0 for v in held.values()), held
 
