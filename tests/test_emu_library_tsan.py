@@ -52,6 +52,20 @@ if what == 'ntt':
     [t.start() for t in ts]; [t.join() for t in ts]
     assert all(np.array_equal(o, w_) for o, w_ in zip(out, want))
     p.close(); eng.close()
+elif what == 'vtable':
+    # the reference-shaped function-pointer tables from two host threads at once (a libsafecrypto context per thread, as the reference asks): the slots of one device are
+    # serialised by the binding's own lock; the error counter and the per-device state are shared
+    import tests.test_gpu_vtable as V
+    errs = []
+    def work(args):
+        try:
+            for _ in range(2):
+                V.test_vtable_calls(*args)
+        except BaseException as e:
+            errs.append(repr(e))
+    ts = [threading.Thread(target=work, args=(a,)) for a in ((12289, 512, True), (8380417, 256, False))]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
 else:
     # the multi-device Dilithium driver (set 0): 4 messages over 2 workers, signatures = the oracle's, then verified by the same driver
     G = load_golden('dilithium_ref.txt')
@@ -77,6 +91,10 @@ def _run(what, timeout):
 
 def test_multi_driver_and_shared_plan_are_race_free():
     _run('ntt', 900)
+
+
+def test_vtable_slots_from_two_threads_are_race_free():
+    _run('vtable', 900)
 
 
 @pytest.mark.skipif(os.environ.get('SC_TEST_SLOW_EMU') != '1', reason='about ten minutes of emulation under TSan: SC_TEST_SLOW_EMU=1 (run in round 6: clean)')
