@@ -41,8 +41,10 @@ size_t sc_hip_glue_dilithium_sig_max(safecrypto_t *sc);
  * "tape"), Kyber's m with the reference's own prng_mem call.  A signature equals safecrypto_sign's for the same CSPRNG state whenever that state has an
  * empty bit reservoir (a freshly seeded generator - prng_var's left-over bits of an earlier call are invisible from outside prng.c); the generator is
  * advanced by the whole tape drawn, which for the rejection-sampling signers is more than the reference would have consumed.
- * Output buffers follow packer.c:142-176 like the Dilithium entries.  Raw coding only (SC_ENTROPY_NONE); BLISS-B needs the 64-bit CDF sampler
- * (SC_FLAG_0_SAMPLE_64BIT, what the engine implements); anything else returns SC_FUNC_FAILURE and the caller stays on the reference path. */
+ * Output buffers follow packer.c:142-176 like the Dilithium entries.  BLISS-B: the CDF sampler at 64 bits (SC_FLAG_0_SAMPLE_64BIT) or at 128 / 192 bits
+ * (SC_FLAG_0_SAMPLE_128BIT / _192BIT - what the reference's own harness creates, test/functional/func_alg_bliss_b.c:118: the context's table is handed to the
+ * engine, sc_hip_bliss_set_cdt_table_hp), signatures raw, static-Huffman or arithmetic coded; anything else returns SC_FUNC_FAILURE and the caller stays on
+ * the reference path. */
 SINT32 sc_hip_glue_bliss_b_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
 SINT32 sc_hip_glue_bliss_b_verify(safecrypto_t *sc, const UINT8 *m, size_t m_len, const UINT8 *sigbuf, size_t siglen);
 SINT32 sc_hip_glue_ring_tesla_sign(safecrypto_t *sc, const UINT8 *m, size_t m_len, UINT8 **sigret, size_t *siglen);
