@@ -302,6 +302,7 @@ extern "C" int sc_hip_dilithium_set_privkey(sc_hip_dilithium_t *d, const int32_t
     const int k = d->P.k, l = d->P.l, q = d->P.q, dd = d->P.d;
     // decompose(t) -> t0 in [0,q) (module_lwe.c:89-104); only t0 is needed by the signer
     std::vector<int32_t> t0((size_t)k * N);
+    struct Wipe { std::vector<int32_t> &v; ~Wipe() { for (auto &w : v) *(volatile int32_t *)&w = 0; } } wipe_t0{ t0 };      // t0 is key material: the host copy does not outlive the call, on any path out
     const int32_t mask = (1 << dd) - 1, sign = 1 << dd, thresh = 1 << (dd - 1);
     for (size_t i = 0; i < t0.size(); i++) { int32_t x = t[i] & mask; x -= (x > thresh) * sign; t0[i] = (x >= 0) ? x : x + q; }
     if (key_ntt(d, s1, (size_t)l, &d->d_s1) || key_ntt(d, s2, (size_t)k, &d->d_s2) || key_ntt(d, t0.data(), (size_t)k, &d->d_t0)) return SC_HIP_FAILURE;
