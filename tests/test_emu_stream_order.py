@@ -217,8 +217,9 @@ def test_results_do_not_depend_on_how_late_the_caller_s_stream_runs():
 
 
 @pytest.mark.skipif(os.environ.get('SC_TEST_SLOW_EMU') != '1', reason='Dilithium key generation + signing + verification with a key per message under the adversary: ten minutes (SC_TEST_SLOW_EMU=1)')
-def test_the_same_through_dilithium_signing_with_a_key_per_message():
-    held = run(SLOW_GROUPS, late=True, timeout=5400)
+@pytest.mark.parametrize('mode', ['late', 'null-late'])
+def test_the_same_through_dilithium_signing_with_a_key_per_message(mode):
+    held = run(SLOW_GROUPS, late=mode, timeout=5400)
     assert all(v > 0 for v in held.values()), held
 
 
